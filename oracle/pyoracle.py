@@ -1,0 +1,280 @@
+"""ctypes front end of oracle/cnn_oracle.c (TEST INFRASTRUCTURE -- see that file's header).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "build", "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "cnn_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    for suf, real in (("", C.c_float), ("_f64", C.c_double)):
+        P = C.POINTER(real)
+        I = C.c_int
+        IP = C.POINTER(C.c_int)
+
+        def sig(name, res, *args):
+            f = getattr(L, name + suf)
+            f.restype = res
+            f.argtypes = list(args)
+
+        sig("oracle_conv2d_forward", None, P, P, P, P, I, I, I, I, I, I, I)
+        sig("oracle_conv2d_backward", None, P, P, P, P, P, P, I, I, I, I, I, I, I)
+        sig("oracle_sgd_update", None, P, P, C.c_size_t, real)
+        sig("oracle_maxpool_forward", None, P, P, IP, I, I, I, I, I, I)
+        sig("oracle_maxpool_backward", None, P, IP, P, I, I, I, I, I, I)
+        sig("oracle_relu_forward", None, P, P, C.c_size_t)
+        sig("oracle_relu_backward", None, P, P, C.c_size_t)
+        sig("oracle_linear_forward", None, P, P, P, P, I, I, I)
+        sig("oracle_linear_backward", None, P, P, P, P, P, P, I, I, I)
+        sig("oracle_softmax", None, P, P, I, I)
+        sig("oracle_cross_entropy_backward", real, P, IP, P, I, I)
+        sig("oracle_net_create", C.c_void_p, I, I, I, I)
+        sig("oracle_net_destroy", None, C.c_void_p)
+        sig("oracle_net_num_params", C.c_size_t, C.c_void_p)
+        sig("oracle_net_params", P, C.c_void_p)
+        sig("oracle_net_grads", P, C.c_void_p)
+        sig("oracle_net_linear_in", I, C.c_void_p)
+        sig("oracle_net_forward", P, C.c_void_p, P)
+        sig("oracle_net_backward", None, C.c_void_p, P)
+        sig("oracle_net_update", None, C.c_void_p, real)
+        sig("oracle_net_train_step", real, C.c_void_p, P, IP, real, P)
+        sig("oracle_net_conv_out", P, C.c_void_p, I)
+        sig("oracle_net_relu_out", P, C.c_void_p, I)
+        sig("oracle_net_pool_out", P, C.c_void_p)
+        sig("oracle_net_pool_mask", IP, C.c_void_p)
+        sig("oracle_net_d_conv", P, C.c_void_p, I)
+
+
+def _dt(f64):
+    return (np.float64, C.c_double, "_f64") if f64 else (np.float32, C.c_float, "")
+
+
+def _p(a, ct):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ct))
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def conv_out_dim(h, k, s):
+    return (h - k) // s + 1
+
+
+def conv2d_forward(x, w, bias, stride, f64=False):
+    dt, ct, suf = _dt(f64)
+    x, w, bias = _c(x, dt), _c(w, dt), _c(bias, dt)
+    B, Ci, H, W = x.shape
+    Co, _, k, _ = w.shape
+    y = np.empty((B, Co, conv_out_dim(H, k, stride), conv_out_dim(W, k, stride)), dt)
+    getattr(lib(), "oracle_conv2d_forward" + suf)(_p(x, ct), _p(w, ct), _p(bias, ct), _p(y, ct), B, Ci, H, W, Co, k, stride)
+    return y
+
+
+def conv2d_backward(x, dy, w, stride, f64=False, need=(True, True, True)):
+    dt, ct, suf = _dt(f64)
+    x, dy, w = _c(x, dt), _c(dy, dt), _c(w, dt)
+    B, Ci, H, W = x.shape
+    Co, _, k, _ = w.shape
+    gw = np.empty_like(w) if need[0] else None
+    gb = np.empty(Co, dt) if need[1] else None
+    dx = np.empty_like(x) if need[2] else None
+    getattr(lib(), "oracle_conv2d_backward" + suf)(
+        _p(x, ct), _p(dy, ct), _p(w, ct), _p(gw, ct), _p(gb, ct), _p(dx, ct), B, Ci, H, W, Co, k, stride
+    )
+    return gw, gb, dx
+
+
+def maxpool_forward(x, k, step, record_mask=True, f64=False):
+    dt, ct, suf = _dt(f64)
+    x = _c(x, dt)
+    B, Cc, H, W = x.shape
+    Ho, Wo = (H - k) // step + 1, (W - k) // step + 1
+    y = np.empty((B, Cc, Ho, Wo), dt)
+    mask = np.zeros((B, Cc, Ho, Wo), np.int32) if record_mask else None
+    getattr(lib(), "oracle_maxpool_forward" + suf)(_p(x, ct), _p(y, ct), _p(mask, C.c_int), B, Cc, H, W, k, step)
+    return y, mask
+
+
+def maxpool_backward(dy, mask, in_shape, k, step, f64=False):
+    dt, ct, suf = _dt(f64)
+    dy = _c(dy, dt)
+    mask = _c(mask, np.int32)
+    B, Cc, H, W = in_shape
+    dx = np.empty(in_shape, dt)
+    getattr(lib(), "oracle_maxpool_backward" + suf)(_p(dy, ct), _p(mask, C.c_int), _p(dx, ct), B, Cc, H, W, k, step)
+    return dx
+
+
+def relu_forward(x, f64=False):
+    dt, ct, suf = _dt(f64)
+    x = _c(x, dt)
+    y = np.empty_like(x)
+    getattr(lib(), "oracle_relu_forward" + suf)(_p(x, ct), _p(y, ct), x.size)
+    return y
+
+
+def relu_backward(y, dy, f64=False):
+    """Returns the masked delta (the reference masks in place, relu.cpp:37-39)."""
+    dt, ct, suf = _dt(f64)
+    y = _c(y, dt)
+    dy = np.array(dy, dtype=dt, order="C", copy=True)
+    getattr(lib(), "oracle_relu_backward" + suf)(_p(y, ct), _p(dy, ct), y.size)
+    return dy
+
+
+def linear_forward(x, w, bias, f64=False):
+    dt, ct, suf = _dt(f64)
+    x, w, bias = _c(x, dt), _c(w, dt), _c(bias, dt)
+    B = x.shape[0]
+    n_in, n_out = w.shape
+    x2 = x.reshape(B, n_in)
+    y = np.empty((B, n_out), dt)
+    getattr(lib(), "oracle_linear_forward" + suf)(_p(x2, ct), _p(w, ct), _p(bias, ct), _p(y, ct), B, n_in, n_out)
+    return y
+
+
+def linear_backward(x, dy, w, f64=False):
+    dt, ct, suf = _dt(f64)
+    x, dy, w = _c(x, dt), _c(dy, dt), _c(w, dt)
+    B = x.shape[0]
+    n_in, n_out = w.shape
+    gw = np.empty_like(w)
+    gb = np.empty(n_out, dt)
+    dx = np.empty((B, n_in), dt)
+    getattr(lib(), "oracle_linear_backward" + suf)(
+        _p(x.reshape(B, n_in), ct), _p(dy, ct), _p(w, ct), _p(gw, ct), _p(gb, ct), _p(dx, ct), B, n_in, n_out
+    )
+    return gw, gb, dx.reshape(x.shape)
+
+
+def sgd_update(p, g, lr, f64=False):
+    dt, ct, suf = _dt(f64)
+    p = np.array(p, dtype=dt, order="C", copy=True)
+    g = _c(g, dt)
+    getattr(lib(), "oracle_sgd_update" + suf)(_p(p, ct), _p(g, ct), p.size, ct(lr))
+    return p
+
+
+def softmax(logits, f64=False):
+    dt, ct, suf = _dt(f64)
+    logits = _c(logits, dt)
+    B, n = logits.shape
+    out = np.empty_like(logits)
+    getattr(lib(), "oracle_softmax" + suf)(_p(logits, ct), _p(out, ct), B, n)
+    return out
+
+
+def cross_entropy_backward(probs, labels, f64=False):
+    dt, ct, suf = _dt(f64)
+    probs = _c(probs, dt)
+    labels = _c(labels, np.int32)
+    B, n = probs.shape
+    delta = np.empty_like(probs)
+    loss = getattr(lib(), "oracle_cross_entropy_backward" + suf)(_p(probs, ct), _p(labels, C.c_int), _p(delta, ct), B, n)
+    return float(loss), delta
+
+
+class Net:
+    """The reference network (alexnet.cpp:10-33, batch_norm=false) on the oracle."""
+
+    def __init__(self, batch, classes=3, H=224, W=224, f64=False):
+        self.dt, self.ct, self.suf = _dt(f64)
+        self.B, self.classes, self.H, self.W = batch, classes, H, W
+        self._L = lib()
+        self._h = C.c_void_p(self._f("oracle_net_create")(batch, classes, H, W))
+        self.n_params = self._f("oracle_net_num_params")(self._h)
+        self.lin_in = self._f("oracle_net_linear_in")(self._h)
+        self.chans = [3, 16, 32, 64, 128]
+        self.conv_in_hw, self.conv_out_hw = [], []
+        h, w = H, W
+        for l in range(4):
+            self.conv_in_hw.append((h, w))
+            h, w = conv_out_dim(h, 3, 2), conv_out_dim(w, 3, 2)
+            self.conv_out_hw.append((h, w))
+            if l == 0:
+                h, w = (h - 2) // 2 + 1, (w - 2) // 2 + 1
+        self.pool_out_hw = self.conv_in_hw[1]
+
+    def _f(self, name):
+        return getattr(self._L, name + self.suf)
+
+    def __del__(self):
+        try:
+            self._f("oracle_net_destroy")(self._h)
+        except Exception:
+            pass
+
+    def _view(self, ptr, shape):
+        n = int(np.prod(shape))
+        return np.ctypeslib.as_array(ptr, shape=(n,)).reshape(shape)
+
+    @property
+    def params(self):
+        return self._view(self._f("oracle_net_params")(self._h), (self.n_params,))
+
+    @property
+    def grads(self):
+        return self._view(self._f("oracle_net_grads")(self._h), (self.n_params,))
+
+    def load_checkpoint(self, path):
+        raw = np.fromfile(path, dtype=np.float32)
+        assert raw.size == self.n_params, (raw.size, self.n_params)
+        self.params[:] = raw.astype(self.dt)
+
+    def forward(self, x):
+        self._x = _c(x, self.dt)
+        p = self._f("oracle_net_forward")(self._h, _p(self._x, self.ct))
+        return self._view(p, (self.B, self.classes)).copy()
+
+    def backward(self, delta):
+        d = _c(delta, self.dt)
+        self._f("oracle_net_backward")(self._h, _p(d, self.ct))
+
+    def update(self, lr):
+        self._f("oracle_net_update")(self._h, self.ct(lr))
+
+    def train_step(self, x, labels, lr):
+        self._x = _c(x, self.dt)
+        lab = _c(labels, np.int32)
+        probs = np.empty((self.B, self.classes), self.dt)
+        loss = self._f("oracle_net_train_step")(self._h, _p(self._x, self.ct), _p(lab, C.c_int), self.ct(lr), _p(probs, self.ct))
+        return float(loss), probs
+
+    def conv_out(self, l):
+        return self._view(self._f("oracle_net_conv_out")(self._h, l), (self.B, self.chans[l + 1]) + self.conv_out_hw[l]).copy()
+
+    def relu_out(self, l):
+        return self._view(self._f("oracle_net_relu_out")(self._h, l), (self.B, self.chans[l + 1]) + self.conv_out_hw[l]).copy()
+
+    def pool_out(self):
+        return self._view(self._f("oracle_net_pool_out")(self._h), (self.B, 16) + self.pool_out_hw).copy()
+
+    def pool_mask(self):
+        return self._view(self._f("oracle_net_pool_mask")(self._h), (self.B, 16) + self.pool_out_hw).copy()
+
+    def d_conv(self, l):
+        return self._view(self._f("oracle_net_d_conv")(self._h, l), (self.B, self.chans[l]) + self.conv_in_hw[l]).copy()

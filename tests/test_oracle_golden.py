@@ -1,0 +1,129 @@
+"""Pins oracle/ against the only known answer the reference publishes (README.md:92, the
+inference.exe screenshot) and checks its edge-case semantics against hand-computed vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+
+
+def _kat(golden_dir):
+    imgs = np.load(os.path.join(golden_dir, "readme_kat_images_u8.npy"))
+    exp = json.load(open(os.path.join(golden_dir, "readme_kat_expected.json")))
+    ckpt = os.path.join(golden_dir, "readme_kat_checkpoint.model")
+    # Tensor3D::read_from_opencv_mat (data_format.cpp:13-23): plane c <- img[3i+c] * 1.f / 255
+    x = (imgs.astype(np.float32) * np.float32(1.0) / np.float32(255)).transpose(0, 3, 1, 2)
+    return np.ascontiguousarray(x), exp, ckpt
+
+
+@pytest.mark.parametrize("f64", [False, True])
+def test_readme_known_answer(golden_dir, f64):
+    x, exp, ckpt = _kat(golden_dir)
+    assert os.path.getsize(ckpt) == 445068  # 111 267 floats, SURVEY 3.5
+    for i in range(3):
+        net = O.Net(1, 3, f64=f64)  # inference.cpp:46-47 runs batch 1
+        net.load_checkpoint(ckpt)
+        probs = O.softmax(net.forward(x[i : i + 1]), f64=f64)
+        assert int(probs.argmax()) == exp["argmax"][i]
+        # the screenshot prints 6 significant digits (operator<< default precision)
+        assert abs(float(probs.max()) - exp["prob"][i]) < 1.5e-6, (i, probs, exp["prob"][i])
+
+
+def test_readme_known_answer_batched(golden_dir):
+    """same three images as ONE batch of 3: per-sample independence of the forward (conv2d.cpp:69)."""
+    x, exp, ckpt = _kat(golden_dir)
+    net = O.Net(3, 3)
+    net.load_checkpoint(ckpt)
+    probs = O.softmax(net.forward(x))
+    assert probs.argmax(axis=1).tolist() == exp["argmax"]
+    assert np.allclose(probs.max(axis=1), exp["prob"], atol=1.5e-6)
+
+
+def test_conv_shapes_and_hand_vector():
+    # 1 channel, 5x5 ramp, 3x3 all-ones kernel, stride 2 -> 2x2 of window sums + bias
+    x = np.arange(25, dtype=np.float32).reshape(1, 1, 5, 5)
+    w = np.ones((1, 1, 3, 3), np.float32)
+    y = O.conv2d_forward(x, w, np.array([0.5], np.float32), 2)
+    win = lambda r, c: x[0, 0, r : r + 3, c : c + 3].sum() + 0.5
+    assert y.shape == (1, 1, 2, 2)
+    assert np.array_equal(y[0, 0], np.array([[win(0, 0), win(0, 2)], [win(2, 0), win(2, 2)]], np.float32))
+    # out = (H-k)/s + 1 with integer division (conv2d.cpp:41): 224->111, 55->27, 27->13, 13->6
+    for h, e in ((224, 111), (55, 27), (27, 13), (13, 6), (6, 2)):
+        assert O.conv_out_dim(h, 3, 2) == e
+
+
+def test_conv_dgrad_uncovered_rows_stay_zero():
+    # H=6,k=3,s=2: windows cover rows 0..4 only; row/col 5 never receives gradient (conv2d.cpp:168,183)
+    x = np.ones((1, 2, 6, 6), np.float32)
+    w = np.ones((3, 2, 3, 3), np.float32)
+    dy = np.ones((1, 3, 2, 2), np.float32)
+    _, _, dx = O.conv2d_backward(x, dy, w, 2)
+    assert np.all(dx[:, :, 5, :] == 0) and np.all(dx[:, :, :, 5] == 0)
+    assert dx[0, 0, 2, 2] == 3 * 4  # centre tap is shared by all four windows, 3 output channels
+
+
+def test_maxpool_tie_nan_negzero_semantics():
+    nan = np.float32(np.nan)
+    x = np.array(
+        [
+            [1, 1, 5, 5],  # ties: first maximum wins (strict <, pool2d.cpp:71)
+            [1, 1, 5, 5],
+            [nan, 2, 3, nan],  # NaN first: never replaced (max < comp false); NaN later: never wins
+            [1, 0, 1, 2],
+        ],
+        np.float32,
+    ).reshape(1, 1, 4, 4)
+    y, m = O.maxpool_forward(x, 2, 2)
+    assert m[0, 0].tolist() == [[0, 2], [8, 10]]
+    assert y[0, 0, 0, 0] == 1 and y[0, 0, 0, 1] == 5 and np.isnan(y[0, 0, 1, 0]) and y[0, 0, 1, 1] == 3
+    z = np.array([[-0.0, 0.0], [0.0, -0.0]], np.float32).reshape(1, 1, 2, 2)
+    y, m = O.maxpool_forward(z, 2, 2)
+    assert m.item() == 0 and np.signbit(y.item())  # -0.0 < +0.0 is false: window[0] stays
+    # floor: 111 -> 55 drops the last row/col (pool2d.cpp:14-15); mask is a flat index into C*H*W (:81)
+    x = np.zeros((1, 2, 5, 5), np.float32)
+    x[0, 1, 3, 3] = 7
+    y, m = O.maxpool_forward(x, 2, 2)
+    assert y.shape == (1, 2, 2, 2) and m[0, 1, 1, 1] == 25 + 3 * 5 + 3
+    dx = O.maxpool_backward(np.full((1, 2, 2, 2), 2.0, np.float32), m, x.shape, 2, 2)
+    assert dx[0, 1, 3, 3] == 2 and dx.sum() == 2 * 8 and np.all(dx[:, :, 4, :] == 0)
+
+
+def test_maxpool_backward_overlap_is_assignment():
+    # k=3, step=1: windows overlap; dx[mask[i]] = dy[i] -> the highest output index wins (pool2d.cpp:105-106)
+    x = np.zeros((1, 1, 4, 4), np.float32)
+    x[0, 0, 1, 1] = 9
+    y, m = O.maxpool_forward(x, 3, 1)
+    assert np.all(m == 5)
+    dx = O.maxpool_backward(np.array([1, 2, 3, 4], np.float32).reshape(1, 1, 2, 2), m, x.shape, 3, 1)
+    assert dx[0, 0, 1, 1] == 4 and dx.sum() == 4
+
+
+def test_relu_semantics():
+    x = np.array([-1.0, -0.0, 0.0, 2.0, np.nan, -np.inf, np.inf], np.float32)
+    y = O.relu_forward(x)
+    assert y[0] == 0 and np.signbit(y[1]) and y[1] == 0 and y[3] == 2 and y[4] == 0 and y[5] == 0 and np.isinf(y[6])
+    d = O.relu_backward(y, np.ones_like(x))
+    assert d.tolist() == [0, 0, 0, 1, 0, 0, 1]  # y <= 0 -> 0 (relu.cpp:38)
+
+
+def test_linear_and_loss_hand_vectors():
+    x = np.array([[1, 2], [3, 4]], np.float32)
+    w = np.array([[1, 0, -1], [2, 1, 0]], np.float32)  # [in][out] (linear.cpp:40)
+    b = np.array([0.5, 0, 0], np.float32)
+    y = O.linear_forward(x, w, b)
+    assert np.array_equal(y, x @ w + b)
+    dy = np.array([[1, 0, 0], [0, 1, 0]], np.float32)
+    gw, gb, dx = O.linear_backward(x, dy, w)
+    assert np.array_equal(gw, (x.T @ dy) / 2) and np.array_equal(gb, dy.sum(0) / 2) and np.array_equal(dx, dy @ w.T)
+    p = O.softmax(np.array([[0, 0, 0], [100, 0, -100]], np.float32))
+    assert np.allclose(p[0], 1 / 3) and p[1, 0] == 1 and p[1, 2] == 0  # clamped exp: x <= -50 -> 0 (func.cpp:9)
+    loss, delta = O.cross_entropy_backward(p[:1], np.array([1]))
+    assert np.isclose(loss, np.log(3)) and np.allclose(delta, [[1 / 3, 1 / 3 - 1, 1 / 3]])  # no 1/B in delta
+
+
+def test_net_param_layout_matches_checkpoint_order():
+    net = O.Net(2, 3)
+    sizes = [16 * 27 + 16, 32 * 144 + 32, 64 * 288 + 64, 128 * 576 + 128, 4608 * 3 + 3]
+    assert net.n_params == sum(sizes) == 111267 and net.lin_in == 4608
