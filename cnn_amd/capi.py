@@ -1,0 +1,285 @@
+"""ctypes binding of libcnn_amd.so (include/cnn_amd.h).
+
+This is plumbing for tests and bench.py: it passes raw device pointers (torch tensors' data_ptr()) and the
+current HIP stream through the C ABI.  There is NO fallback: if the shared library is missing or a call returns
+non-zero, a CnnAmdError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcnn_amd.so")
+
+
+class CnnAmdError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """mirror of cnn_conv2d_desc"""
+
+    _fields_ = [(n, C.c_int) for n in ("B", "Ci", "H", "W", "Co", "k", "s", "pad")]
+
+
+_lib = None
+
+# name -> (restype, argtypes); the single source for the "exports every declared symbol" test
+_P = C.c_void_p
+_D = C.POINTER(ConvDesc)
+SIGNATURES = {
+    "cnn_amd_abi_version": (C.c_int, []),
+    "cnn_amd_last_error": (C.c_char_p, []),
+    "cnn_amd_device_arch": (C.c_char_p, []),
+    "cnn_conv2d_out_dim": (C.c_int, [C.c_int] * 4),
+    "cnn_maxpool2d_out_dim": (C.c_int, [C.c_int] * 3),
+    "cnn_conv2d_workspace_bytes": (C.c_size_t, [_D]),
+    "cnn_conv2d_forward": (C.c_int, [_D, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cnn_conv2d_backward_weight": (C.c_int, [_D, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P]),
+    "cnn_conv2d_backward_data": (C.c_int, [_D, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cnn_conv2d_im2col_workspace_bytes": (C.c_size_t, [_D]),
+    "cnn_conv2d_forward_im2col": (C.c_int, [_D, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cnn_conv2d_backward_weight_im2col": (C.c_int, [_D, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P]),
+    "cnn_conv2d_backward_data_im2col": (C.c_int, [_D, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cnn_maxpool2d_forward": (C.c_int, [_P, _P, _P] + [C.c_int] * 6 + [_P]),
+    "cnn_maxpool2d_backward": (C.c_int, [_P, _P, _P] + [C.c_int] * 6 + [_P]),
+    "cnn_relu_forward": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "cnn_relu_backward": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "cnn_linear_forward": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "cnn_linear_backward": (C.c_int, [_P] * 6 + [C.c_int] * 3 + [C.c_float, _P]),
+    "cnn_sgd_update": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P]),
+    "cnn_softmax_xent": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "cnn_device_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "cnn_device_free": (C.c_int, [_P]),
+    "cnn_memcpy_h2d": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "cnn_memcpy_d2h": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "cnn_memcpy_d2d": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "cnn_memset_zero": (C.c_int, [_P, C.c_size_t, _P]),
+    "cnn_stream_synchronize": (C.c_int, [_P]),
+}
+
+
+def load():
+    """dlopen the in-tree library (built by __graft_entry__.build() / make -C cnn_amd/csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CnnAmdError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here == the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise CnnAmdError(f"{what} failed with code {rc}: {load().cnn_amd_last_error().decode()}")
+
+
+def conv_out_dim(n, k, s, pad=0):
+    return (n + 2 * pad - k) // s + 1
+
+
+def pool_out_dim(n, k, step):
+    return (n - k) // step + 1
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and (not t.is_cuda or not t.is_contiguous()):
+            raise CnnAmdError("tensors passed to the HIP path must be contiguous device tensors")
+
+
+class Conv2d:
+    """One Conv2D geometry: owns the scratch buffer, forwards to the C ABI.  Weight layout [Co][Ci][k][k]."""
+
+    def __init__(self, B, Ci, H, W, Co, k=3, s=2, pad=0, device="cuda"):
+        import torch
+
+        self.desc = ConvDesc(B, Ci, H, W, Co, k, s, pad)
+        self.Ho, self.Wo = conv_out_dim(H, k, s, pad), conv_out_dim(W, k, s, pad)
+        self.lib = load()
+        self.ws_bytes = int(self.lib.cnn_conv2d_workspace_bytes(C.byref(self.desc)))
+        if self.ws_bytes == 0:
+            raise CnnAmdError("cnn_conv2d_workspace_bytes: " + self.lib.cnn_amd_last_error().decode())
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self._im2col_ws = None
+
+    def out_shape(self):
+        d = self.desc
+        return (d.B, d.Co, self.Ho, self.Wo)
+
+    def forward(self, x, w, bias, y=None):
+        import torch
+
+        _need_gpu(x, w, bias, y)
+        if y is None:
+            y = torch.empty(self.out_shape(), dtype=torch.float32, device=x.device)
+        check(self.lib.cnn_conv2d_forward(C.byref(self.desc), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(self.ws),
+                                          self.ws_bytes, _stream()), "cnn_conv2d_forward")
+        return y
+
+    def backward_weight(self, x, dy, divisor, gw=None, gb=None, want_bias=True):
+        import torch
+
+        _need_gpu(x, dy, gw, gb)
+        d = self.desc
+        if gw is None:
+            gw = torch.empty((d.Co, d.Ci, d.k, d.k), dtype=torch.float32, device=x.device)
+        if gb is None and want_bias:
+            gb = torch.empty((d.Co,), dtype=torch.float32, device=x.device)
+        check(self.lib.cnn_conv2d_backward_weight(C.byref(d), _ptr(x), _ptr(dy), _ptr(gw), _ptr(gb), float(divisor),
+                                                  _ptr(self.ws), self.ws_bytes, _stream()), "cnn_conv2d_backward_weight")
+        return gw, gb
+
+    def backward_data(self, dy, w, dx=None):
+        import torch
+
+        _need_gpu(dy, w, dx)
+        d = self.desc
+        if dx is None:
+            dx = torch.empty((d.B, d.Ci, d.H, d.W), dtype=torch.float32, device=dy.device)
+        check(self.lib.cnn_conv2d_backward_data(C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(self.ws), self.ws_bytes,
+                                                _stream()), "cnn_conv2d_backward_data")
+        return dx
+
+    # ---- im2col functional fallback (parity cross-check only) ----
+    def _iws(self, device):
+        import torch
+
+        if self._im2col_ws is None:
+            n = int(self.lib.cnn_conv2d_im2col_workspace_bytes(C.byref(self.desc)))
+            self._im2col_ws = torch.empty(n, dtype=torch.uint8, device=device)
+        return self._im2col_ws
+
+    def forward_im2col(self, x, w, bias):
+        import torch
+
+        _need_gpu(x, w, bias)
+        y = torch.empty(self.out_shape(), dtype=torch.float32, device=x.device)
+        ws = self._iws(x.device)
+        check(self.lib.cnn_conv2d_forward_im2col(C.byref(self.desc), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(ws),
+                                                 ws.numel(), _stream()), "cnn_conv2d_forward_im2col")
+        return y
+
+    def backward_weight_im2col(self, x, dy, divisor):
+        import torch
+
+        _need_gpu(x, dy)
+        d = self.desc
+        gw = torch.empty((d.Co, d.Ci, d.k, d.k), dtype=torch.float32, device=x.device)
+        gb = torch.empty((d.Co,), dtype=torch.float32, device=x.device)
+        ws = self._iws(x.device)
+        check(self.lib.cnn_conv2d_backward_weight_im2col(C.byref(d), _ptr(x), _ptr(dy), _ptr(gw), _ptr(gb), float(divisor),
+                                                         _ptr(ws), ws.numel(), _stream()), "cnn_conv2d_backward_weight_im2col")
+        return gw, gb
+
+    def backward_data_im2col(self, dy, w):
+        import torch
+
+        _need_gpu(dy, w)
+        d = self.desc
+        dx = torch.empty((d.B, d.Ci, d.H, d.W), dtype=torch.float32, device=dy.device)
+        ws = self._iws(dy.device)
+        check(self.lib.cnn_conv2d_backward_data_im2col(C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), ws.numel(),
+                                                       _stream()), "cnn_conv2d_backward_data_im2col")
+        return dx
+
+
+def maxpool_forward(x, k, step, record_mask=True):
+    import torch
+
+    _need_gpu(x)
+    B, Cc, H, W = x.shape
+    Ho, Wo = pool_out_dim(H, k, step), pool_out_dim(W, k, step)
+    y = torch.empty((B, Cc, Ho, Wo), dtype=torch.float32, device=x.device)
+    mask = torch.empty((B, Cc, Ho, Wo), dtype=torch.int32, device=x.device) if record_mask else None
+    check(load().cnn_maxpool2d_forward(_ptr(x), _ptr(y), _ptr(mask), B, Cc, H, W, k, step, _stream()), "cnn_maxpool2d_forward")
+    return y, mask
+
+
+def maxpool_backward(dy, mask, in_shape, k, step, dx=None):
+    import torch
+
+    _need_gpu(dy, mask, dx)
+    B, Cc, H, W = in_shape
+    if dx is None:
+        dx = torch.empty(in_shape, dtype=torch.float32, device=dy.device)
+    check(load().cnn_maxpool2d_backward(_ptr(dy), _ptr(mask), _ptr(dx), B, Cc, H, W, k, step, _stream()), "cnn_maxpool2d_backward")
+    return dx
+
+
+def relu_forward(x, y=None):
+    import torch
+
+    _need_gpu(x, y)
+    if y is None:
+        y = torch.empty_like(x)
+    check(load().cnn_relu_forward(_ptr(x), _ptr(y), x.numel(), _stream()), "cnn_relu_forward")
+    return y
+
+
+def relu_backward(y, dy):
+    """in place on dy (relu.cpp:37-39); returns dy"""
+    _need_gpu(y, dy)
+    check(load().cnn_relu_backward(_ptr(y), _ptr(dy), y.numel(), _stream()), "cnn_relu_backward")
+    return dy
+
+
+def linear_forward(x, w, bias, y=None):
+    import torch
+
+    _need_gpu(x, w, bias, y)
+    B = x.shape[0]
+    n_in, n_out = w.shape
+    if y is None:
+        y = torch.empty((B, n_out), dtype=torch.float32, device=x.device)
+    check(load().cnn_linear_forward(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, n_in, n_out, _stream()), "cnn_linear_forward")
+    return y
+
+
+def linear_backward(x, dy, w, divisor, gw=None, gb=None, dx=None):
+    import torch
+
+    _need_gpu(x, dy, w, gw, gb, dx)
+    B = x.shape[0]
+    n_in, n_out = w.shape
+    if gw is None:
+        gw = torch.empty_like(w)
+    if gb is None:
+        gb = torch.empty((n_out,), dtype=torch.float32, device=x.device)
+    if dx is None:
+        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(load().cnn_linear_backward(_ptr(x), _ptr(dy), _ptr(w), _ptr(gw), _ptr(gb), _ptr(dx), B, n_in, n_out,
+                                     float(divisor), _stream()), "cnn_linear_backward")
+    return gw, gb, dx
+
+
+def sgd_update(params, grads, lr, grad_scale=1.0):
+    _need_gpu(params, grads)
+    check(load().cnn_sgd_update(_ptr(params), _ptr(grads), params.numel(), float(lr), float(grad_scale), _stream()), "cnn_sgd_update")
+    return params
+
+
+def softmax_xent(logits, labels, want_probs=True):
+    import torch
+
+    _need_gpu(logits, labels)
+    B, n = logits.shape
+    probs = torch.empty_like(logits) if want_probs else None
+    delta = torch.empty_like(logits)
+    loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    check(load().cnn_softmax_xent(_ptr(logits), _ptr(labels), _ptr(probs), _ptr(delta), _ptr(loss), B, n, _stream()), "cnn_softmax_xent")
+    return probs, delta, loss

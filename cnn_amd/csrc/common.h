@@ -1,0 +1,46 @@
+// common.h -- shared host-side helpers for the libcnn_amd.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "cnn_amd.h"
+
+namespace cnn_amd {
+
+// last-error text (per thread), surfaced through cnn_amd_last_error()
+char* error_buffer();
+int fail(int code, const char* fmt, ...);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define CNN_HIP_CHECK(expr)                                                                         \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess)                                                                      \
+            return ::cnn_amd::fail(CNN_AMD_E_HIP + (int)e__, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+// every kernel launch is followed by this: catches bad launch configs without synchronising
+#define CNN_LAUNCH_CHECK() CNN_HIP_CHECK(hipGetLastError())
+
+#define CNN_REQUIRE(cond, ...)                                             \
+    do {                                                                   \
+        if (!(cond)) return ::cnn_amd::fail(CNN_AMD_E_BADARG, __VA_ARGS__); \
+    } while (0)
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kNumCU = 256;        // MI355X
+constexpr int kNumXCD = 8;
+
+inline unsigned ceil_div(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// grid for HBM-bound streaming kernels: enough workgroups to fill 256 CUs x 8, grid-stride the rest
+inline unsigned stream_grid(size_t work_items, int block) {
+    size_t need = (work_items + block - 1) / block;
+    size_t cap = (size_t)kNumCU * 8;
+    return (unsigned)(need < 1 ? 1 : (need > cap ? cap : need));
+}
+
+}  // namespace cnn_amd

@@ -1,0 +1,364 @@
+// conv_wgrad.hip -- Conv2D weight / bias gradient (cpu/src/conv2d.cpp:117-159) as a split-K GEMM on the fp32
+// matrix cores:      gw[co][(ci,kx,ky)] = (1/divisor) * sum_{b,p,q} dy[b,co,p,q] * x[b,ci,p*s+kx-pad,q*s+ky-pad]
+//   M = Co, N = Ci*k*k (already the reference's [Co][Ci][k][k] layout), K = B*Ho*Wo output pixels.
+// MFMA operands: A[i=co][k=pixel] from a dy tile, B[k=pixel][j=(ci,tap)] gathered from the staged input rows --
+// the "batched outer-product reduction" of north_star; im2col never exists in memory.
+// The pixel axis is split over workgroups (and, for small M*N, over the waves of a workgroup); every split writes
+// its partial [Co][N] slab and a second kernel adds the slabs in a FIXED order and divides once: deterministic, no
+// atomics.  (The reference divides each sample's sum by B and accumulates, :148; algebraically (1/B)*sum.)
+// Bias gradient (conv2d.cpp:153-157) is a per-channel two-stage reduction of dy.
+#include "common.h"
+
+using namespace cnn_amd;
+
+namespace cnn_amd {
+size_t igemm_workspace_floats(const cnn_conv2d_desc* d);  // conv_igemm.hip
+}
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WgradParams {
+    const float* x;
+    const float* dy;
+    float* part;  // [nslots][Co][Ntot]
+    int B, Ci, H, W, Co, k, s, pad, Ho, Wo;
+    int R, QC, QCP;    // chunk = R output rows x QC output columns (QCP = QC rounded up to the MFMA k-step)
+    int nrc, ncc;      // chunks per image along rows / columns
+    int DROW;          // LDS floats per dy channel (R*QCP, padded for banking)
+    int XR, LWc, CHS;  // staged input rows per channel, their pitch, channel stride
+    int CIB;           // channel slots staged per workgroup
+    int Ntot;          // Ci*k*k
+    long long chunks_total;
+    int chunks_per_split;
+};
+
+template <int MF>
+struct Mfma;
+template <>
+struct Mfma<32> {
+    typedef f32x16 type;
+    static constexpr int kRegs = 16, kStep = 2;
+    __device__ static __forceinline__ type run(float a, float b, type c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ int row(int reg, int lh) { return (reg & 3) + 8 * (reg >> 2) + 4 * lh; }
+};
+template <>
+struct Mfma<16> {
+    typedef f32x4 type;
+    static constexpr int kRegs = 4, kStep = 4;
+    __device__ static __forceinline__ type run(float a, float b, type c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ int row(int reg, int lh) { return 4 * lh + reg; }
+};
+
+// MA x NB MFMA tiles per wave, WM x WN waves tile the (co, n) block, WK waves split the chunk's rows.
+template <int MF, int MA, int NB, int WM, int WN, int WK>
+__global__ __launch_bounds__(64 * WM * WN * WK, 2) void wgrad_kernel(const WgradParams p) {
+    using M_ = Mfma<MF>;
+    constexpr int NWAVES = WM * WN * WK;
+    constexpr int MTB = MF * MA * WM;
+    constexpr int NTB = MF * NB * WN;
+    constexpr int KSTEP = M_::kStep;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ds = smem;                              // [MTB][DROW]
+    float* Xs = smem + (size_t)MTB * p.DROW;       // [CIB][CHS]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
+    const int li = lane & (MF - 1), lh = lane / MF;
+    const int split = blockIdx.x, nblk = blockIdx.y, mblk = blockIdx.z;
+    const int kk2 = p.k * p.k;
+    const int ci_first = (nblk * NTB) / kk2;
+
+    int a_off[MA], b_off[NB];
+#pragma unroll
+    for (int ma = 0; ma < MA; ++ma) a_off[ma] = ((wm * MA + ma) * MF + li) * p.DROW + lh;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        int n = nblk * NTB + (wn * NB + nb) * MF + li;
+        if (n >= p.Ntot) n = nblk * NTB;  // padded column: reads something valid, never stored
+        const int ci = n / kk2, tap = n - ci * kk2, kx = tap / p.k, ky = tap - kx * p.k;
+        b_off[nb] = (ci - ci_first) * p.CHS + kx * p.LWc + ky + lh * p.s;
+    }
+
+    typename M_::type acc[MA][NB];
+#pragma unroll
+    for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < M_::kRegs; ++r) acc[ma][nb][r] = 0.f;
+
+    const long long ch_begin = (long long)split * p.chunks_per_split;
+    long long ch_end = ch_begin + p.chunks_per_split;
+    if (ch_end > p.chunks_total) ch_end = p.chunks_total;
+    const int per_img = p.nrc * p.ncc;
+
+    for (long long ch = ch_begin; ch < ch_end; ++ch) {
+        const int b = (int)(ch / per_img);
+        const int rem = (int)(ch - (long long)b * per_img);
+        const int rc = rem / p.ncc, cq = rem - rc * p.ncc;
+        const int p0 = rc * p.R, q0 = cq * p.QC;
+        const int Rv = (p.Ho - p0 < p.R) ? p.Ho - p0 : p.R;
+        const int QCv = (p.Wo - q0 < p.QC) ? p.Wo - q0 : p.QC;
+        __syncthreads();
+        // ---- stage dy tile: one wave per (channel,row), zero beyond the valid columns / rows / channels ----
+        for (int row = wave; row < MTB * p.R; row += NWAVES) {
+            const int col_ = row / p.R, r = row - col_ * p.R;
+            const int co = mblk * MTB + col_;
+            float* d = Ds + col_ * p.DROW + r * p.QCP;
+            const bool live = (co < p.Co) && (r < Rv);
+            const float* g = p.dy + (((size_t)b * p.Co + (live ? co : 0)) * p.Ho + p0 + (live ? r : 0)) * p.Wo + q0;
+            for (int c = lane; c < p.QCP; c += 64) d[c] = (live && c < QCv) ? g[c] : 0.f;
+        }
+        // ---- stage input rows (zero outside the image: padding and the k-step overreach) ----
+        for (int row = wave; row < p.CIB * p.XR; row += NWAVES) {
+            const int slot = row / p.XR, xr = row - slot * p.XR;
+            const int ci = ci_first + slot;
+            const int h = p0 * p.s + xr - p.pad;
+            const bool live = (ci < p.Ci) && (h >= 0) && (h < p.H);
+            const float* g = p.x + (((size_t)b * p.Ci + (live ? ci : 0)) * p.H + (live ? h : 0)) * p.W;
+            float* d = Xs + slot * p.CHS + xr * p.LWc;
+            const int w0 = q0 * p.s - p.pad;
+            for (int c = lane; c < p.LWc; c += 64) {
+                const int w = w0 + c;
+                d[c] = (live && w >= 0 && w < p.W) ? g[w] : 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA: k-steps walk the chunk's pixels ----
+        for (int r = wk; r < Rv; r += WK) {
+            const int arow = r * p.QCP, brow = r * p.s * p.LWc;
+#pragma unroll 2
+            for (int q = 0; q < p.QCP; q += KSTEP) {
+                float a[MA], bv[NB];
+#pragma unroll
+                for (int ma = 0; ma < MA; ++ma) a[ma] = Ds[a_off[ma] + arow + q];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bv[nb] = Xs[b_off[nb] + brow + q * p.s];
+#pragma unroll
+                for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[ma][nb] = M_::run(a[ma], bv[nb], acc[ma][nb]);
+            }
+        }
+    }
+
+    // ---- write this (split, wk) slab ----
+    float* out = p.part + ((size_t)split * WK + wk) * p.Co * p.Ntot;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = nblk * NTB + (wn * NB + nb) * MF + li;
+        if (n >= p.Ntot) continue;
+#pragma unroll
+        for (int ma = 0; ma < MA; ++ma) {
+            const int cbase = mblk * MTB + (wm * MA + ma) * MF;
+#pragma unroll
+            for (int r = 0; r < M_::kRegs; ++r) {
+                const int co = cbase + M_::row(r, lh);
+                if (co < p.Co) out[(size_t)co * p.Ntot + n] = acc[ma][nb][r];
+            }
+        }
+    }
+}
+
+// gw[i] = (sum_slots part[slot][i]) / divisor, slots added in ascending order
+__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ part, float* __restrict__ gw, int nslots,
+                                                    size_t n, float divisor) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int t = 0; t < nslots; ++t) s += part[(size_t)t * n + i];
+        gw[i] = s / divisor;
+    }
+}
+
+// bias gradient stage 1: partial[g][co] = sum over this group's samples of sum_pq dy[b][co][pq]
+constexpr int kBiasBlock = 256;
+__global__ __launch_bounds__(kBiasBlock) void bias_grad_partial(const float* __restrict__ dy,
+                                                                float* __restrict__ partial, int B, int Co, int P,
+                                                                int groups) {
+    __shared__ float red[kBiasBlock / 64];
+    const int co = blockIdx.x, g = blockIdx.y;
+    const int per = (B + groups - 1) / groups;
+    const int bb = g * per, be = (bb + per < B) ? bb + per : B;
+    float s = 0.f;
+    for (int b = bb; b < be; ++b) {
+        const float* d = dy + ((size_t)b * Co + co) * P;
+        for (int i = threadIdx.x; i < P; i += kBiasBlock) s += d[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < kBiasBlock / 64; ++w) t += red[w];
+        partial[(size_t)g * Co + co] = t;
+    }
+}
+__global__ void bias_grad_final(const float* __restrict__ partial, float* __restrict__ gb, int Co, int groups,
+                                float divisor) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= Co) return;
+    float s = 0.f;
+    for (int g = 0; g < groups; ++g) s += partial[(size_t)g * Co + co];
+    gb[co] = s / divisor;
+}
+
+// ---- host planning -----------------------------------------------------------------------------------------
+enum { W_128x288 = 0, W_64x320, W_32x160, W_16x32 };
+
+struct WPlan {
+    int cfg, MF, MTB, NTB, WK, threads;
+    WgradParams p;
+    size_t lds_bytes;
+    int nsplit, nslots;
+    unsigned gy, gz;
+    int bias_groups;
+    size_t part_floats, bias_floats;
+};
+
+constexpr size_t kLdsBudget = 78 * 1024;  // two workgroups per CU: the second one computes while this one stages
+
+int make_wplan(const char* who, const cnn_conv2d_desc* d, WPlan* pl) {
+    WgradParams& p = pl->p;
+    p = WgradParams();
+    p.B = d->B; p.Ci = d->Ci; p.H = d->H; p.W = d->W; p.Co = d->Co; p.k = d->k; p.s = d->s; p.pad = d->pad;
+    p.Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad);
+    p.Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
+    CNN_REQUIRE(p.Ho > 0 && p.Wo > 0, "%s: empty output", who);
+    p.Ntot = d->Ci * d->k * d->k;
+    if (p.Co > 64) { pl->cfg = W_128x288; pl->MF = 32; pl->MTB = 128; pl->NTB = 288; pl->WK = 1; pl->threads = 256; }
+    else if (p.Co > 32) { pl->cfg = W_64x320; pl->MF = 32; pl->MTB = 64; pl->NTB = 320; pl->WK = 1; pl->threads = 256; }
+    else if (p.Co > 16) { pl->cfg = W_32x160; pl->MF = 32; pl->MTB = 32; pl->NTB = 160; pl->WK = 4; pl->threads = 256; }
+    else { pl->cfg = W_16x32; pl->MF = 16; pl->MTB = 16; pl->NTB = 32; pl->WK = 4; pl->threads = 256; }
+    const int kstep = pl->MF == 32 ? 2 : 4;
+    const int kk2 = d->k * d->k;
+    p.CIB = (pl->NTB + kk2 - 2) / kk2 + 1;
+    if (p.CIB > p.Ci) p.CIB = p.Ci;
+    // pick the chunk: as many whole output rows as fit the LDS budget (a multiple of WK), else a slice of one row
+    auto drow_for = [&](int R, int QCP) {
+        int drow = R * QCP;
+        if (pl->MF == 32) drow |= 1;                     // odd stride: 32 channels hit 32 banks
+        else drow += ((2 - drow % 32) + 32) % 32;        // == 2 (mod 32): 16 channels x 2 k-lanes per half-wave
+        return drow;
+    };
+    auto lds_for = [&](int R, int QC) {
+        const int QCP = (QC + kstep - 1) / kstep * kstep;
+        const int XR = (R - 1) * d->s + d->k, LWc = (QCP - 1) * d->s + d->k;
+        return ((size_t)pl->MTB * drow_for(R, QCP) + (size_t)p.CIB * (XR * LWc + 1)) * sizeof(float);
+    };
+    int R = 1, QC = p.Wo;
+    if (lds_for(1, p.Wo) <= kLdsBudget) {
+        const int target_pixels = 512;  // enough k-steps per barrier; more only costs LDS
+        while (R < p.Ho && (R + pl->WK) * p.Wo <= target_pixels + p.Wo && lds_for(R + 1, p.Wo) <= kLdsBudget) ++R;
+        if (pl->WK > 1 && R >= pl->WK) R = R / pl->WK * pl->WK;
+    } else {
+        while (QC > kstep && lds_for(1, QC) > kLdsBudget) QC = (QC + 1) / 2;
+        CNN_REQUIRE(lds_for(1, QC) <= kLdsBudget, "%s: Ci*k*k tile does not fit LDS (k=%d)", who, d->k);
+    }
+    p.R = R; p.QC = QC; p.QCP = (QC + kstep - 1) / kstep * kstep;
+    p.nrc = (p.Ho + R - 1) / R; p.ncc = (p.Wo + QC - 1) / QC;
+    p.DROW = drow_for(R, p.QCP);
+    p.XR = (R - 1) * d->s + d->k; p.LWc = (p.QCP - 1) * d->s + d->k; p.CHS = p.XR * p.LWc + 1;
+    pl->lds_bytes = ((size_t)pl->MTB * p.DROW + (size_t)p.CIB * p.CHS) * sizeof(float);
+    CNN_REQUIRE(pl->lds_bytes <= 160 * 1024, "%s: LDS plan %zu B too large", who, pl->lds_bytes);
+    p.chunks_total = (long long)p.B * p.nrc * p.ncc;
+    pl->gy = (unsigned)((p.Ntot + pl->NTB - 1) / pl->NTB);
+    pl->gz = (unsigned)((p.Co + pl->MTB - 1) / pl->MTB);
+    int bpc = (int)((160 * 1024) / pl->lds_bytes);
+    if (bpc < 1) bpc = 1;
+    if (bpc > 4) bpc = 4;
+    long long want = (long long)kNumCU * bpc / ((long long)pl->gy * pl->gz);
+    if (want < 1) want = 1;
+    if (want > p.chunks_total) want = p.chunks_total;
+    p.chunks_per_split = (int)((p.chunks_total + want - 1) / want);
+    pl->nsplit = (int)((p.chunks_total + p.chunks_per_split - 1) / p.chunks_per_split);
+    pl->nslots = pl->nsplit * pl->WK;
+    pl->part_floats = (size_t)pl->nslots * p.Co * p.Ntot;
+    pl->bias_groups = p.B < 64 ? p.B : 64;
+    pl->bias_floats = (size_t)pl->bias_groups * p.Co;
+    return CNN_AMD_OK;
+}
+
+template <int MF, int MA, int NB, int WM, int WN, int WK>
+int launch_w(const WPlan& pl, hipStream_t s) {
+    auto kern = wgrad_kernel<MF, MA, NB, WM, WN, WK>;
+    static thread_local bool attr_set = false;
+    if (pl.lds_bytes > 48 * 1024 && !attr_set) {
+        CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    kern<<<dim3(pl.nsplit, pl.gy, pl.gz), 64 * WM * WN * WK, pl.lds_bytes, s>>>(pl.p);
+    CNN_LAUNCH_CHECK();
+    return CNN_AMD_OK;
+}
+
+int check_desc(const char* who, const cnn_conv2d_desc* d) {
+    CNN_REQUIRE(d != nullptr, "%s: desc is null", who);
+    CNN_REQUIRE(d->B > 0 && d->Ci > 0 && d->H > 0 && d->W > 0 && d->Co > 0 && d->k > 0 && d->s > 0 && d->pad >= 0,
+                "%s: bad desc B=%d Ci=%d H=%d W=%d Co=%d k=%d s=%d pad=%d", who, d->B, d->Ci, d->H, d->W, d->Co, d->k,
+                d->s, d->pad);
+    CNN_REQUIRE(d->H + 2 * d->pad >= d->k && d->W + 2 * d->pad >= d->k, "%s: kernel %d larger than padded input", who,
+                d->k);
+    return CNN_AMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d) {
+    if (check_desc("cnn_conv2d_workspace_bytes", d)) return 0;
+    WPlan pl;
+    size_t wg = 0;
+    if (make_wplan("cnn_conv2d_workspace_bytes", d, &pl) == CNN_AMD_OK) wg = pl.part_floats + pl.bias_floats;
+    const size_t ig = igemm_workspace_floats(d);
+    return ((wg > ig ? wg : ig) + 64) * sizeof(float);
+}
+
+int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const float* dy, float* gw, float* gb,
+                               float divisor, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = check_desc("cnn_conv2d_backward_weight", d)) return rc;
+    CNN_REQUIRE(x && dy && gw, "cnn_conv2d_backward_weight: null pointer");
+    CNN_REQUIRE(divisor != 0.f, "cnn_conv2d_backward_weight: divisor is 0");
+    WPlan pl;
+    if (int rc = make_wplan("cnn_conv2d_backward_weight", d, &pl)) return rc;
+    CNN_REQUIRE(ws != nullptr, "cnn_conv2d_backward_weight: workspace is null");
+    const size_t need = (pl.part_floats + pl.bias_floats) * sizeof(float);
+    if (ws_bytes < need)
+        return fail(CNN_AMD_E_WORKSPACE, "cnn_conv2d_backward_weight: workspace %zu B < %zu B", ws_bytes, need);
+    hipStream_t s = as_stream(stream);
+    pl.p.x = x; pl.p.dy = dy; pl.p.part = (float*)ws;
+    int rc;
+    switch (pl.cfg) {
+        case W_128x288: rc = launch_w<32, 1, 9, 4, 1, 1>(pl, s); break;
+        case W_64x320: rc = launch_w<32, 1, 5, 2, 2, 1>(pl, s); break;
+        case W_32x160: rc = launch_w<32, 1, 5, 1, 1, 4>(pl, s); break;
+        default: rc = launch_w<16, 1, 2, 1, 1, 4>(pl, s); break;
+    }
+    if (rc) return rc;
+    const size_t n = (size_t)pl.p.Co * pl.p.Ntot;
+    unsigned rg = (unsigned)((n + 255) / 256);
+    if (rg > 2048) rg = 2048;
+    wgrad_reduce<<<rg, 256, 0, s>>>((const float*)ws, gw, pl.nslots, n, divisor);
+    CNN_LAUNCH_CHECK();
+    if (gb) {
+        float* bpart = (float*)ws + pl.part_floats;
+        bias_grad_partial<<<dim3(pl.p.Co, pl.bias_groups), kBiasBlock, 0, s>>>(dy, bpart, pl.p.B, pl.p.Co,
+                                                                              pl.p.Ho * pl.p.Wo, pl.bias_groups);
+        CNN_LAUNCH_CHECK();
+        bias_grad_final<<<(pl.p.Co + 63) / 64, 64, 0, s>>>(bpart, gb, pl.p.Co, pl.bias_groups, divisor);
+        CNN_LAUNCH_CHECK();
+    }
+    return CNN_AMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+// elementwise.hip -- HBM-bound streaming kernels: ReLU fwd/bwd (relu.cpp:21-26,35-40), the SGD step
+// (conv2d.cpp:205-217, linear.cpp:95-102) and the softmax / cross-entropy glue (func.cpp:16-73).
+// All are 16 B/lane vectorised grid-stride loops; roofline = HBM (8 / 12 / 12 B per element).
+#include <cfloat>
+#include <cstdint>
+
+#include "common.h"
+
+using namespace cnn_amd;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float relu_f(float v) { return v >= 0.f ? v : 0.f; }        // relu.cpp:25
+__device__ __forceinline__ float relu_b(float y, float d) { return y <= 0.f ? 0.f : d; }  // relu.cpp:38
+
+__global__ __launch_bounds__(kBlock) void relu_fwd_vec(const float4* __restrict__ x, float4* __restrict__ y,
+                                                       size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (size_t)gridDim.x * kBlock) {
+        float4 v = x[i];
+        v.x = relu_f(v.x); v.y = relu_f(v.y); v.z = relu_f(v.z); v.w = relu_f(v.w);
+        y[i] = v;
+    }
+}
+__global__ __launch_bounds__(kBlock) void relu_fwd_scalar(const float* __restrict__ x, float* __restrict__ y,
+                                                          size_t begin, size_t n) {
+    for (size_t i = begin + (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+        y[i] = relu_f(x[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void relu_bwd_vec(const float4* __restrict__ y, float4* __restrict__ d,
+                                                       size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (size_t)gridDim.x * kBlock) {
+        const float4 yv = y[i];
+        float4 dv = d[i];
+        dv.x = relu_b(yv.x, dv.x); dv.y = relu_b(yv.y, dv.y); dv.z = relu_b(yv.z, dv.z); dv.w = relu_b(yv.w, dv.w);
+        d[i] = dv;
+    }
+}
+__global__ __launch_bounds__(kBlock) void relu_bwd_scalar(const float* __restrict__ y, float* __restrict__ d,
+                                                          size_t begin, size_t n) {
+    for (size_t i = begin + (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+        d[i] = relu_b(y[i], d[i]);
+}
+
+// p - lr*(g*scale) with every product/sum rounded separately: the reference is built without FMA
+// (x86-64 -O2, CMakeLists.txt:5), so w -= lr*g is mul-then-sub; __fmul_rn/__fsub_rn stop hipcc contracting it.
+__device__ __forceinline__ float sgd_one(float p, float g, float lr, float scale, bool scaled) {
+    const float gs = scaled ? __fmul_rn(g, scale) : g;
+    return __fsub_rn(p, __fmul_rn(lr, gs));
+}
+__global__ __launch_bounds__(kBlock) void sgd_vec(float4* __restrict__ p, const float4* __restrict__ g, size_t n4,
+                                                  float lr, float scale, bool scaled) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (size_t)gridDim.x * kBlock) {
+        float4 pv = p[i];
+        const float4 gv = g[i];
+        pv.x = sgd_one(pv.x, gv.x, lr, scale, scaled); pv.y = sgd_one(pv.y, gv.y, lr, scale, scaled);
+        pv.z = sgd_one(pv.z, gv.z, lr, scale, scaled); pv.w = sgd_one(pv.w, gv.w, lr, scale, scaled);
+        p[i] = pv;
+    }
+}
+__global__ __launch_bounds__(kBlock) void sgd_scalar(float* __restrict__ p, const float* __restrict__ g,
+                                                     size_t begin, size_t n, float lr, float scale, bool scaled) {
+    for (size_t i = begin + (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+        p[i] = sgd_one(p[i], g[i], lr, scale, scaled);
+}
+
+// func.cpp:6-12
+__device__ __forceinline__ float clamped_exp(float v) {
+    if (v >= 88.f) return FLT_MAX;
+    if (v <= -50.f) return 0.f;
+    return expf(v);
+}
+
+// One workgroup; thread t owns samples t, t+256, ...  Per-sample arithmetic is the reference's sequential
+// loop (func.cpp:22-33, 63-68); the loss terms are then added in ascending sample order by one lane so the
+// fp32 loss sum has the reference's order (func.cpp:60-71).
+__global__ __launch_bounds__(kBlock) void softmax_xent_kernel(const float* __restrict__ logits,
+                                                              const int32_t* __restrict__ labels,
+                                                              float* __restrict__ probs, float* __restrict__ delta,
+                                                              float* __restrict__ loss_sum, int B, int classes) {
+    __shared__ float terms[kBlock];
+    float running = 0.f;
+    for (int base = 0; base < B; base += kBlock) {
+        const int b = base + threadIdx.x;
+        float term = 0.f;
+        if (b < B) {
+            const float* in = logits + (size_t)b * classes;
+            float mx = in[0];  // Tensor3D::max = first maximum, strict '>' (data_format.cpp:37-48)
+            for (int i = 1; i < classes; ++i)
+                if (in[i] > mx) mx = in[i];
+            float sum = 0.f;
+            for (int i = 0; i < classes; ++i) sum += clamped_exp(in[i] - mx);
+            const int label = labels[b];
+            for (int i = 0; i < classes; ++i) {
+                float p = clamped_exp(in[i] - mx) / sum;
+                if (isnan(p)) p = 0.f;
+                const float yv = (i == label) ? 1.f : 0.f;
+                if (probs) probs[(size_t)b * classes + i] = p;
+                delta[(size_t)b * classes + i] = p - yv;  // no 1/B here (func.cpp:64)
+                term += __fmul_rn(logf(p), yv);           // func.cpp:65, incl. its log(0)*0 = NaN behaviour
+            }
+        }
+        terms[threadIdx.x] = term;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int cnt = min(kBlock, B - base);
+            for (int i = 0; i < cnt; ++i) running += terms[i];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && loss_sum) loss_sum[0] = -running;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int cnn_relu_forward(const float* x, float* y, size_t n, void* stream) {
+    if (n == 0) return CNN_AMD_OK;
+    CNN_REQUIRE(x && y, "cnn_relu_forward: null pointer");
+    hipStream_t s = as_stream(stream);
+    size_t done = 0;
+    if (aligned16(x) && aligned16(y) && n >= 4) {
+        const size_t n4 = n / 4;
+        relu_fwd_vec<<<stream_grid(n4, kBlock), kBlock, 0, s>>>((const float4*)x, (float4*)y, n4);
+        CNN_LAUNCH_CHECK();
+        done = n4 * 4;
+    }
+    if (done < n) {
+        relu_fwd_scalar<<<stream_grid(n - done, kBlock), kBlock, 0, s>>>(x, y, done, n);
+        CNN_LAUNCH_CHECK();
+    }
+    return CNN_AMD_OK;
+}
+
+int cnn_relu_backward(const float* y, float* dy, size_t n, void* stream) {
+    if (n == 0) return CNN_AMD_OK;
+    CNN_REQUIRE(y && dy, "cnn_relu_backward: null pointer");
+    hipStream_t s = as_stream(stream);
+    size_t done = 0;
+    if (aligned16(y) && aligned16(dy) && n >= 4) {
+        const size_t n4 = n / 4;
+        relu_bwd_vec<<<stream_grid(n4, kBlock), kBlock, 0, s>>>((const float4*)y, (float4*)dy, n4);
+        CNN_LAUNCH_CHECK();
+        done = n4 * 4;
+    }
+    if (done < n) {
+        relu_bwd_scalar<<<stream_grid(n - done, kBlock), kBlock, 0, s>>>(y, dy, done, n);
+        CNN_LAUNCH_CHECK();
+    }
+    return CNN_AMD_OK;
+}
+
+int cnn_sgd_update(float* params, const float* grads, size_t n, float lr, float grad_scale, void* stream) {
+    if (n == 0) return CNN_AMD_OK;
+    CNN_REQUIRE(params && grads, "cnn_sgd_update: null pointer");
+    hipStream_t s = as_stream(stream);
+    const bool scaled = grad_scale != 1.0f;
+    size_t done = 0;
+    if (aligned16(params) && aligned16(grads) && n >= 4) {
+        const size_t n4 = n / 4;
+        sgd_vec<<<stream_grid(n4, kBlock), kBlock, 0, s>>>((float4*)params, (const float4*)grads, n4, lr, grad_scale,
+                                                          scaled);
+        CNN_LAUNCH_CHECK();
+        done = n4 * 4;
+    }
+    if (done < n) {
+        sgd_scalar<<<stream_grid(n - done, kBlock), kBlock, 0, s>>>(params, grads, done, n, lr, grad_scale, scaled);
+        CNN_LAUNCH_CHECK();
+    }
+    return CNN_AMD_OK;
+}
+
+int cnn_softmax_xent(const float* logits, const int32_t* labels, float* probs, float* delta, float* loss_sum, int B,
+                     int classes, void* stream) {
+    CNN_REQUIRE(logits && labels && delta, "cnn_softmax_xent: null pointer");
+    CNN_REQUIRE(B > 0 && classes > 0, "cnn_softmax_xent: B=%d classes=%d", B, classes);
+    softmax_xent_kernel<<<1, kBlock, 0, as_stream(stream)>>>(logits, labels, probs, delta, loss_sum, B, classes);
+    CNN_LAUNCH_CHECK();
+    return CNN_AMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+// pool.hip -- MaxPool2D forward / backward (cpu/src/pool2d.cpp:53-87, 96-107).
+// HBM-bound, one wavefront per image row so that a wave's loads/stores are one contiguous run of the NCHW row;
+// no per-element integer division (row -> (plane,h) is wave-uniform scalar arithmetic).
+//   fwd algorithmic bytes: 4*C*(H*W + 2*Ho*Wo) per sample (input + output + int32 mask)
+//   bwd algorithmic bytes: 4*C*(2*Ho*Wo + H*W) per sample (delta + mask + dx written once, no separate memset)
+#include <cstdint>
+
+#include "common.h"
+
+using namespace cnn_amd;
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+
+// One wave per OUTPUT row (plane, ho).  Window scan order and the strict '<' are the reference's
+// (pool2d.cpp:67-75): max starts at window[0]; a later element replaces it only if max < comp, so the first
+// maximum wins ties, a NaN in window[0] is never replaced and a later NaN never wins, -0.0/+0.0 tie.
+template <int K, int STEP>  // 0 = runtime value
+__global__ __launch_bounds__(kBlock) void maxpool_fwd_rows(const float* __restrict__ x, float* __restrict__ y,
+                                                           int32_t* __restrict__ mask, long long n_rows, int C,
+                                                           int H, int W, int Ho, int Wo, int k_rt, int step_rt) {
+    const int k = K ? K : k_rt;
+    const int step = STEP ? STEP : step_rt;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    for (long long r = (long long)blockIdx.x * kWavesPerBlock + wave; r < n_rows;
+         r += (long long)gridDim.x * kWavesPerBlock) {
+        const long long plane = r / Ho;  // = b*C + c
+        const int ho = (int)(r - plane * Ho);
+        const int c = (int)(plane % C);
+        const float* xrow = x + plane * H * W + (size_t)(ho * step) * W;
+        float* yrow = y + r * Wo;
+        int32_t* mrow = mask ? mask + r * Wo : nullptr;
+        const int mbase = c * H * W + ho * step * W;
+        for (int wo = lane; wo < Wo; wo += kWave) {
+            const float* win = xrow + wo * step;
+            float best = win[0];
+            int best_off = 0;
+#pragma unroll
+            for (int di = 0; di < k; ++di) {
+#pragma unroll
+                for (int dj = 0; dj < k; ++dj) {
+                    if (di == 0 && dj == 0) continue;
+                    const float comp = win[di * W + dj];
+                    if (best < comp) {
+                        best = comp;
+                        best_off = di * W + dj;
+                    }
+                }
+            }
+            yrow[wo] = best;
+            if (mrow) mrow[wo] = mbase + wo * step + best_off;
+        }
+    }
+}
+
+// One wave per INPUT row (plane, h): dx[h][w] = dy of the highest-index window whose recorded argmax is this
+// element, else 0 -- the gather form of "dx = 0; for i ascending: dx[mask[i]] = dy[i]" (pool2d.cpp:96-107).
+// With k <= step (the only configuration the reference net uses) at most one window covers an element.
+template <int K, int STEP>
+__global__ __launch_bounds__(kBlock) void maxpool_bwd_rows(const float* __restrict__ dy,
+                                                           const int32_t* __restrict__ mask, float* __restrict__ dx,
+                                                           long long n_rows, int C, int H, int W, int Ho, int Wo,
+                                                           int k_rt, int step_rt) {
+    const int k = K ? K : k_rt;
+    const int step = STEP ? STEP : step_rt;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    for (long long r = (long long)blockIdx.x * kWavesPerBlock + wave; r < n_rows;
+         r += (long long)gridDim.x * kWavesPerBlock) {
+        const long long plane = r / H;
+        const int h = (int)(r - plane * H);
+        const int c = (int)(plane % C);
+        // windows (rows) that contain h: ho*step <= h <= ho*step + k - 1
+        int ho_hi = h / step;
+        if (ho_hi > Ho - 1) ho_hi = Ho - 1;
+        int ho_lo = (h - k + 1 + step - 1);
+        ho_lo = ho_lo <= 0 ? 0 : ho_lo / step;
+        const int32_t self_row = c * H * W + h * W;
+        const float* dplane = dy + plane * Ho * Wo;
+        const int32_t* mplane = mask + plane * Ho * Wo;
+        float* out = dx + r * W;
+        for (int w = lane; w < W; w += kWave) {
+            int wo_hi = w / step;
+            if (wo_hi > Wo - 1) wo_hi = Wo - 1;
+            int wo_lo = (w - k + 1 + step - 1);
+            wo_lo = wo_lo <= 0 ? 0 : wo_lo / step;
+            float v = 0.f;
+            bool found = false;
+            for (int ho = ho_hi; ho >= ho_lo && !found; --ho)
+                for (int wo = wo_hi; wo >= wo_lo; --wo) {
+                    if (mplane[ho * Wo + wo] == self_row + w) {
+                        v = dplane[ho * Wo + wo];
+                        found = true;
+                        break;
+                    }
+                }
+            out[w] = v;
+        }
+    }
+}
+
+inline unsigned row_grid(long long rows) {
+    long long need = (rows + kWavesPerBlock - 1) / kWavesPerBlock;
+    long long cap = (long long)kNumCU * 16;
+    return (unsigned)(need < 1 ? 1 : (need > cap ? cap : need));
+}
+
+int check_geom(const char* who, int B, int C, int H, int W, int k, int step) {
+    CNN_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && k > 0 && step > 0, "%s: bad dims B=%d C=%d H=%d W=%d k=%d step=%d",
+                who, B, C, H, W, k, step);
+    CNN_REQUIRE(H >= k && W >= k, "%s: window %d larger than %dx%d input", who, k, H, W);
+    CNN_REQUIRE((long long)C * H * W < (1ll << 31), "%s: C*H*W overflows the int32 mask", who);
+    return CNN_AMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cnn_maxpool2d_forward(const float* x, float* y, int32_t* mask, int B, int C, int H, int W, int k, int step,
+                          void* stream) {
+    CNN_REQUIRE(x && y, "cnn_maxpool2d_forward: null pointer");
+    if (int rc = check_geom("cnn_maxpool2d_forward", B, C, H, W, k, step)) return rc;
+    const int Ho = cnn_maxpool2d_out_dim(H, k, step), Wo = cnn_maxpool2d_out_dim(W, k, step);
+    const long long rows = (long long)B * C * Ho;
+    hipStream_t s = as_stream(stream);
+    if (k == 2 && step == 2)
+        maxpool_fwd_rows<2, 2><<<row_grid(rows), kBlock, 0, s>>>(x, y, mask, rows, C, H, W, Ho, Wo, k, step);
+    else if (k == 3 && step == 2)
+        maxpool_fwd_rows<3, 2><<<row_grid(rows), kBlock, 0, s>>>(x, y, mask, rows, C, H, W, Ho, Wo, k, step);
+    else
+        maxpool_fwd_rows<0, 0><<<row_grid(rows), kBlock, 0, s>>>(x, y, mask, rows, C, H, W, Ho, Wo, k, step);
+    CNN_LAUNCH_CHECK();
+    return CNN_AMD_OK;
+}
+
+int cnn_maxpool2d_backward(const float* dy, const int32_t* mask, float* dx, int B, int C, int H, int W, int k,
+                           int step, void* stream) {
+    CNN_REQUIRE(dy && mask && dx, "cnn_maxpool2d_backward: null pointer");
+    if (int rc = check_geom("cnn_maxpool2d_backward", B, C, H, W, k, step)) return rc;
+    const int Ho = cnn_maxpool2d_out_dim(H, k, step), Wo = cnn_maxpool2d_out_dim(W, k, step);
+    const long long rows = (long long)B * C * H;
+    hipStream_t s = as_stream(stream);
+    if (k == 2 && step == 2)
+        maxpool_bwd_rows<2, 2><<<row_grid(rows), kBlock, 0, s>>>(dy, mask, dx, rows, C, H, W, Ho, Wo, k, step);
+    else
+        maxpool_bwd_rows<0, 0><<<row_grid(rows), kBlock, 0, s>>>(dy, mask, dx, rows, C, H, W, Ho, Wo, k, step);
+    CNN_LAUNCH_CHECK();
+    return CNN_AMD_OK;
+}
+
+}  // extern "C"

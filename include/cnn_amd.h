@@ -1,0 +1,131 @@
+/*
+ * cnn_amd.h -- C ABI of libcnn_amd.so: the MI355X (gfx950) replacement for the arithmetic inside
+ * hermosayhl/CNN's Layer::forward / Layer::backward / update_gradients (cpu/include/architectures.h:34-138).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 (int32 for the pool mask) unless it says "host";
+ *     a batch is contiguous NCHW: sample b of the reference's std::vector<tensor> (data_format.h:53) lives
+ *     at base + b*C*H*W, each sample in the reference's own CHW order (data_format.h:11-18);
+ *   - weight layouts are the reference's: conv [Co][Ci][k][k] then bias [Co] (conv2d.cpp:18-21,220-226),
+ *     linear [in][out] then bias [out] (linear.cpp:40,105-108) -- a .model checkpoint streams straight in;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call only ENQUEUES work;
+ *   - no allocation inside: scratch comes from the caller (`ws`, sized by the *_workspace_bytes query);
+ *   - return value: 0 = ok, non-zero = CNN_AMD_E_* (or 1000 + hipError_t); cnn_amd_last_error() gives text.
+ *     The reference has no error channel (assert only), so the host layer classes abort on non-zero.
+ */
+#ifndef CNN_AMD_H
+#define CNN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNN_AMD_ABI_VERSION 1
+
+enum {
+    CNN_AMD_OK = 0,
+    CNN_AMD_E_BADARG = 1,    /* null pointer / non-positive dimension / unsupported geometry */
+    CNN_AMD_E_WORKSPACE = 2, /* ws too small for this call */
+    CNN_AMD_E_HIP = 1000     /* 1000 + hipError_t */
+};
+
+int cnn_amd_abi_version(void);
+const char* cnn_amd_last_error(void);
+/* "gfx950" when a device is present and matches, otherwise an explanatory string; never throws */
+const char* cnn_amd_device_arch(void);
+
+/* ---- geometry helpers (host side, pure) -------------------------------------------------------------- */
+/* conv2d.cpp:41-42:  out = (H + 2*pad - k)/s + 1, integer division (the reference has pad == 0) */
+int cnn_conv2d_out_dim(int in, int k, int s, int pad);
+/* pool2d.cpp:14-15:  out = (H - k)/step + 1 */
+int cnn_maxpool2d_out_dim(int in, int k, int step);
+
+/* ---- Conv2D : conv2d.cpp --------------------------------------------------------------------------- */
+typedef struct {
+    int B, Ci, H, W; /* input  batch / channels / height / width */
+    int Co, k, s;    /* filters, kernel edge (any k >= 1; the reference asserts odd >= 3), stride */
+    int pad;         /* zero padding on each side (extension; the reference is fixed at 0, architectures.h:59) */
+} cnn_conv2d_desc;
+
+/* scratch needed by ANY of the three MFMA entry points below for this geometry */
+size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d);
+
+/* replaces Conv2D::forward's loop nest (conv2d.cpp:69-92): y = bias + valid cross-correlation.
+ * Implicit GEMM on v_mfma_f32_32x32x2_f32 / 16x16x4_f32, input rows + filter slabs staged in LDS. */
+int cnn_conv2d_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* replaces conv2d.cpp:117-159: gw = (sum_b sum_pq dy*x)/divisor, gb = (sum_b sum_pq dy)/divisor.
+ * The reference divides by the batch size per sample and accumulates (:148,:157); pass divisor = B of the
+ * WHOLE batch (per-rank shard size under data parallelism, see cnn_sgd_update).  gb may be NULL.
+ * Split-K over pixels with a deterministic second-stage reduction (no atomics). */
+int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const float* dy, float* gw, float* gb,
+                               float divisor, void* ws, size_t ws_bytes, void* stream);
+
+/* replaces conv2d.cpp:168-199 (zero fill + scatter-add) by the equivalent gather: transposed implicit GEMM,
+ * stride handled by output-parity classes; input rows/cols no window covers come out 0 like the reference. */
+int cnn_conv2d_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws,
+                             size_t ws_bytes, void* stream);
+
+/* im2col + plain tiled GEMM: functional fallback kept ONLY for parity checks of the three calls above */
+size_t cnn_conv2d_im2col_workspace_bytes(const cnn_conv2d_desc* d);
+int cnn_conv2d_forward_im2col(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias,
+                              float* y, void* ws, size_t ws_bytes, void* stream);
+int cnn_conv2d_backward_weight_im2col(const cnn_conv2d_desc* d, const float* x, const float* dy, float* gw,
+                                      float* gb, float divisor, void* ws, size_t ws_bytes, void* stream);
+int cnn_conv2d_backward_data_im2col(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx,
+                                    void* ws, size_t ws_bytes, void* stream);
+
+/* ---- MaxPool2D : pool2d.cpp ------------------------------------------------------------------------ */
+/* replaces pool2d.cpp:53-87. mask (may be NULL = the no_grad path, :41,:61,:79) receives the int32 flat index
+ * into the sample's C*H*W of each window's FIRST maximum (strict '<', :71).  Bit-exact vs the reference. */
+int cnn_maxpool2d_forward(const float* x, float* y, int32_t* mask, int B, int C, int H, int W, int k, int step,
+                          void* stream);
+/* replaces pool2d.cpp:96-107: dx = 0; dx[mask[i]] = dy[i] (assignment; with overlapping windows the highest
+ * output index wins, reproduced deterministically). */
+int cnn_maxpool2d_backward(const float* dy, const int32_t* mask, float* dx, int B, int C, int H, int W, int k,
+                           int step, void* stream);
+
+/* ---- ReLU : relu.cpp ------------------------------------------------------------------------------- */
+/* relu.cpp:21-26: y = x >= 0 ? x : 0   (keeps -0.0, NaN -> 0) */
+int cnn_relu_forward(const float* x, float* y, size_t n, void* stream);
+/* relu.cpp:35-40: dy = (y <= 0) ? 0 : dy, IN PLACE on the caller's delta */
+int cnn_relu_backward(const float* y, float* dy_inout, size_t n, void* stream);
+
+/* ---- LinearLayer : linear.cpp ---------------------------------------------------------------------- */
+/* linear.cpp:33-43: y[b][j] = (sum_i x[b][i]*W[i*out+j]) + bias[j] */
+int cnn_linear_forward(const float* x, const float* w, const float* bias, float* y, int B, int in, int out,
+                       void* stream);
+/* linear.cpp:56-90: gW = (x^T dy)/divisor (assigned), gb = (sum_b dy)/divisor, dx = dy W^T; any output may be NULL */
+int cnn_linear_backward(const float* x, const float* dy, const float* w, float* gw, float* gb, float* dx, int B,
+                        int in, int out, float divisor, void* stream);
+
+/* ---- SGD step : conv2d.cpp:205-217, linear.cpp:95-102 ---------------------------------------------- */
+/* p -= lr * (g * grad_scale) over one flat parameter arena.  grad_scale = 1 reproduces the reference exactly
+ * (two roundings, no FMA); grad_scale = 1/G folds the data-parallel mean after an all-reduce(sum) over G ranks
+ * whose kernels each divided by their local batch. */
+int cnn_sgd_update(float* params, const float* grads, size_t n, float lr, float grad_scale, void* stream);
+
+/* ---- loss glue : func.cpp:16-73 (caller side of the path; keeps the step on the device) -------------- */
+/* probs = softmax(logits) with the reference's clamped exp and NaN->0; delta = probs - onehot(labels);
+ * loss_sum[0] = -sum_b log(probs[b][label_b])  (the caller divides by the global batch, func.cpp:67,71).
+ * probs / loss_sum may be NULL. */
+int cnn_softmax_xent(const float* logits, const int32_t* labels, float* probs, float* delta, float* loss_sum,
+                     int B, int classes, void* stream);
+
+/* ---- device memory / transfer helpers (the host layer classes use only these) ------------------------ */
+int cnn_device_alloc(void** ptr, size_t bytes);
+int cnn_device_free(void* ptr);
+int cnn_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream); /* async on stream */
+int cnn_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream); /* async on stream */
+int cnn_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
+int cnn_memset_zero(void* dst_dev, size_t bytes, void* stream);
+int cnn_stream_synchronize(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNN_AMD_H */

@@ -1,0 +1,55 @@
+"""CPU-side checks of the drop-in boundary: libcnn_amd.so loads and exports every symbol include/cnn_amd.h
+declares, and the pure host helpers agree with the reference's shape rules.  No device calls."""
+import os
+import re
+
+import pytest
+
+from cnn_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "cnn_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(cnn_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/cnn_amd.h but not exported"
+    # and the binding table covers exactly the header
+    assert sorted(capi.SIGNATURES) == declared
+
+
+def test_host_helpers_follow_reference_shape_rules():
+    lib = capi.load()
+    assert lib.cnn_amd_abi_version() == 1
+    # conv2d.cpp:41-42 (pad = 0): 224 -> 111 -> (pool) 55 -> 27 -> 13 -> 6
+    assert [lib.cnn_conv2d_out_dim(h, 3, 2, 0) for h in (224, 55, 27, 13)] == [111, 27, 13, 6]
+    assert lib.cnn_conv2d_out_dim(112, 3, 1, 0) == 110 and lib.cnn_conv2d_out_dim(112, 3, 1, 1) == 112
+    assert lib.cnn_maxpool2d_out_dim(111, 2, 2) == 55  # pool2d.cpp:14-15 drops the last row/col
+
+
+def test_workspace_query_and_bad_args_do_not_need_a_gpu():
+    lib = capi.load()
+    import ctypes as C
+
+    d = capi.ConvDesc(256, 64, 112, 112, 128, 3, 1, 0)
+    assert lib.cnn_conv2d_workspace_bytes(C.byref(d)) > 128 * 64 * 9 * 4
+    bad = capi.ConvDesc(1, 3, 2, 2, 4, 3, 1, 0)  # kernel larger than the image
+    assert lib.cnn_conv2d_workspace_bytes(C.byref(bad)) == 0
+    assert lib.cnn_relu_forward(None, None, 16, None) == 1  # CNN_AMD_E_BADARG, message set
+    assert b"null" in lib.cnn_amd_last_error()
+    assert isinstance(lib.cnn_amd_device_arch(), bytes)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libcnn_amd.so")
+    with pytest.raises(capi.CnnAmdError):
+        capi.load()

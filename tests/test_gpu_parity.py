@@ -1,0 +1,303 @@
+"""GPU parity: every HIP entry point (called through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (north_star): bit-exact for MaxPool values/argmax/backward, ReLU and SGD; tensor-normalised 1e-4 for conv /
+linear activations and gradients (tests/util.py: max|a-b| <= 1e-4 * max|ref|).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+from tests.util import REL_TOL, assert_close, normal_scaled, rel_err, uniform01, uniform_pm1
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    from cnn_amd import capi
+
+    arch = capi.load().cnn_amd_device_arch().decode()
+    assert arch == "gfx950", f"built for gfx950, running on {arch}"
+    return torch
+
+
+def dev(T, a):
+    return T.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# (B, Ci, H, W, Co, k, s, pad): SURVEY 8(c) cases + every reference-net layer + the north-star shape
+CONV_CASES = [
+    (2, 3, 9, 9, 4, 3, 2, 0),
+    (2, 16, 55, 55, 32, 3, 2, 0),
+    (3, 8, 12, 12, 8, 3, 1, 0),
+    (2, 8, 9, 9, 4, 1, 2, 0),
+    (2, 5, 13, 11, 7, 5, 2, 0),
+    (2, 3, 224, 224, 16, 3, 2, 0),   # conv_layer_1 (alexnet.cpp:12)
+    (3, 32, 27, 27, 64, 3, 2, 0),    # conv_layer_3
+    (5, 64, 13, 13, 128, 3, 2, 0),   # conv_layer_4 (tiles span several images)
+    (2, 64, 112, 112, 128, 3, 1, 0), # north-star shape at B=2
+    (2, 6, 10, 10, 40, 3, 1, 1),     # padding extension
+    (1, 20, 17, 19, 130, 3, 3, 0),   # stride 3, Co not a tile multiple
+    (2, 7, 8, 8, 5, 3, 2, 1),        # stride 2 with padding
+]
+
+
+def _conv_inputs(case, seed):
+    B, Ci, H, W, Co, k, s, pad = case
+    x = uniform01(seed, (B, Ci, H, W))
+    w = normal_scaled(seed + 1, (Co, Ci, k, k))
+    b = normal_scaled(seed + 2, (Co,))
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    dy = uniform_pm1(seed + 3, (B, Co, Ho, Wo))
+    return x, w, b, dy
+
+
+def _oracle_conv(case, x, w, b, dy):
+    """oracle results; padding = reference conv on the zero-padded input (Tensor3D::pad, data_format.cpp:139-150)"""
+    B, Ci, H, W, Co, k, s, pad = case
+    xp = np.pad(x, ((0, 0), (0, 0), (pad, pad), (pad, pad))) if pad else x
+    y = O.conv2d_forward(xp, w, b, s)
+    gw, gb, dxp = O.conv2d_backward(xp, dy, w, s)
+    dx = dxp[:, :, pad : pad + H, pad : pad + W] if pad else dxp
+    return y, gw, gb, dx
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_conv2d_mfma_vs_oracle(T, case):
+    from cnn_amd import capi
+
+    x, w, b, dy = _conv_inputs(case, 100)
+    y_ref, gw_ref, gb_ref, dx_ref = _oracle_conv(case, x, w, b, dy)
+    conv = capi.Conv2d(*case)
+    xd, wd, bd, dyd = dev(T, x), dev(T, w), dev(T, b), dev(T, dy)
+    assert_close(host(conv.forward(xd, wd, bd)), y_ref, REL_TOL, "forward")
+    gw, gb = conv.backward_weight(xd, dyd, float(case[0]))
+    assert_close(host(gw), gw_ref, REL_TOL, "weight grad")
+    assert_close(host(gb), gb_ref, REL_TOL, "bias grad")
+    assert_close(host(conv.backward_data(dyd, wd)), dx_ref, REL_TOL, "data grad")
+
+
+@pytest.mark.parametrize("case", CONV_CASES[:5] + CONV_CASES[9:], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_conv2d_im2col_fallback_vs_oracle(T, case):
+    from cnn_amd import capi
+
+    x, w, b, dy = _conv_inputs(case, 200)
+    y_ref, gw_ref, gb_ref, dx_ref = _oracle_conv(case, x, w, b, dy)
+    conv = capi.Conv2d(*case)
+    xd, wd, bd, dyd = dev(T, x), dev(T, w), dev(T, b), dev(T, dy)
+    assert_close(host(conv.forward_im2col(xd, wd, bd)), y_ref, REL_TOL, "im2col forward")
+    gw, gb = conv.backward_weight_im2col(xd, dyd, float(case[0]))
+    assert_close(host(gw), gw_ref, REL_TOL, "im2col weight grad")
+    assert_close(host(gb), gb_ref, REL_TOL, "im2col bias grad")
+    assert_close(host(conv.backward_data_im2col(dyd, wd)), dx_ref, REL_TOL, "im2col data grad")
+
+
+def test_conv2d_dgrad_uncovered_rows_are_zero(T):
+    from cnn_amd import capi
+
+    case = (2, 3, 224, 224, 16, 3, 2, 0)  # row/col 223 is never covered (conv2d.cpp:168,183)
+    x, w, b, dy = _conv_inputs(case, 7)
+    dx = host(capi.Conv2d(*case).backward_data(dev(T, dy), dev(T, w)))
+    assert np.all(dx[:, :, 223, :] == 0) and np.all(dx[:, :, :, 223] == 0) and np.any(dx[:, :, 222, :] != 0)
+
+
+@pytest.mark.parametrize("shape,k,step", [((2, 16, 111, 111), 2, 2), ((3, 5, 7, 7), 2, 2), ((2, 4, 9, 10), 3, 2),
+                                          ((2, 3, 8, 8), 3, 1), ((1, 2, 6, 6), 2, 3)])
+def test_maxpool_bit_exact(T, shape, k, step):
+    from cnn_amd import capi
+
+    x = uniform_pm1(5, shape)
+    # deliberate ties, signed zeros and NaNs (SURVEY H4 / pool2d.cpp:67-75)
+    flat = x.reshape(-1)
+    rs = np.random.RandomState(1)
+    flat[rs.choice(flat.size, flat.size // 6, replace=False)] = 0.5
+    flat[rs.choice(flat.size, flat.size // 20, replace=False)] = -0.0
+    flat[rs.choice(flat.size, flat.size // 20, replace=False)] = 0.0
+    flat[rs.choice(flat.size, flat.size // 50, replace=False)] = np.nan
+    y_ref, m_ref = O.maxpool_forward(x, k, step)
+    y, m = capi.maxpool_forward(dev(T, x), k, step)
+    assert np.array_equal(host(m), m_ref), "argmax mask must be bit-exact"
+    assert np.array_equal(host(y).view(np.uint32), y_ref.view(np.uint32)), "pooled values must be bit-exact"
+    y2, none = capi.maxpool_forward(dev(T, x), k, step, record_mask=False)  # the no_grad path
+    assert none is None and np.array_equal(host(y2).view(np.uint32), y_ref.view(np.uint32))
+    dy = uniform_pm1(6, y_ref.shape)
+    dx_ref = O.maxpool_backward(dy, m_ref, shape, k, step)
+    dx = capi.maxpool_backward(dev(T, dy), m, shape, k, step)
+    assert np.array_equal(host(dx).view(np.uint32), dx_ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1000, 16 * 111 * 111 * 2 + 1])
+def test_relu_bit_exact(T, n):
+    from cnn_amd import capi
+
+    x = uniform_pm1(8, (n,))
+    x[:: 7] = -0.0
+    x[1 :: 11] = 0.0
+    x[2 :: 13] = np.nan
+    x[3 :: 17] = -np.inf
+    y_ref = O.relu_forward(x)
+    y = capi.relu_forward(dev(T, x))
+    assert np.array_equal(host(y).view(np.uint32), y_ref.view(np.uint32))
+    d = uniform_pm1(9, (n,))
+    d_ref = O.relu_backward(y_ref, d)
+    dd = capi.relu_backward(y, dev(T, d))
+    assert np.array_equal(host(dd).view(np.uint32), d_ref.view(np.uint32))
+    # unaligned views take the scalar path
+    if n > 8:
+        xo = dev(T, np.concatenate([[0.0], x]).astype(np.float32))[1:]
+        assert np.array_equal(host(capi.relu_forward(xo.contiguous())).view(np.uint32), y_ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("B,n_in,n_out", [(4, 4608, 3), (3, 100, 10), (5, 33, 17)])
+def test_linear_vs_oracle(T, B, n_in, n_out):
+    from cnn_amd import capi
+
+    x, w, b = uniform01(10, (B, n_in)), normal_scaled(11, (n_in, n_out)), normal_scaled(12, (n_out,))
+    dy = uniform_pm1(13, (B, n_out))
+    y_ref = O.linear_forward(x, w, b)
+    gw_ref, gb_ref, dx_ref = O.linear_backward(x, dy, w)
+    xd, wd = dev(T, x), dev(T, w)
+    assert_close(host(capi.linear_forward(xd, wd, dev(T, b))), y_ref, REL_TOL, "linear forward")
+    gw, gb, dx = capi.linear_backward(xd, dev(T, dy), wd, float(B))
+    assert_close(host(gw), gw_ref, REL_TOL, "linear gW")
+    assert_close(host(gb), gb_ref, REL_TOL, "linear gb")
+    assert_close(host(dx), dx_ref, REL_TOL, "linear dx")
+
+
+def test_sgd_bit_exact_and_scaled(T):
+    from cnn_amd import capi
+
+    n = 111267
+    p, g = normal_scaled(14, (n,)), uniform_pm1(15, (n,))
+    out = capi.sgd_update(dev(T, p), dev(T, g), 1e-3)
+    assert np.array_equal(host(out).view(np.uint32), O.sgd_update(p, g, 1e-3).view(np.uint32))
+    out = capi.sgd_update(dev(T, p), dev(T, g), 1e-3, 0.125)  # power-of-two scale is exact
+    assert np.array_equal(host(out).view(np.uint32), O.sgd_update(p, g * np.float32(0.125), 1e-3).view(np.uint32))
+
+
+def test_softmax_xent_vs_oracle(T):
+    from cnn_amd import capi
+
+    B, n = 300, 3
+    logits = (uniform_pm1(16, (B, n)) * 12).astype(np.float32)
+    logits[0] = [100, 0, -100]  # clamped exp (func.cpp:7-11)
+    logits[1] = [0, 0, 0]
+    labels = (np.arange(B) % n).astype(np.int32)
+    labels[0] = 0
+    p_ref = O.softmax(logits)
+    loss_ref, d_ref = O.cross_entropy_backward(p_ref, labels)
+    probs, delta, loss = capi.softmax_xent(dev(T, logits), dev(T, labels))
+    assert np.allclose(host(probs), p_ref, rtol=1e-5, atol=1e-7)
+    assert np.allclose(host(delta), d_ref, rtol=1e-5, atol=1e-6)
+    assert np.isclose(float(host(loss)[0]) / B, loss_ref, rtol=1e-5)
+
+
+def test_readme_known_answer_on_gpu(T, golden_dir):
+    """the reference's published inference result (README.md:92) through the HIP path"""
+    from cnn_amd.pynet import AlexNetHip
+
+    imgs = np.load(os.path.join(golden_dir, "readme_kat_images_u8.npy"))
+    exp = json.load(open(os.path.join(golden_dir, "readme_kat_expected.json")))
+    x = np.ascontiguousarray((imgs.astype(np.float32) * np.float32(1.0) / np.float32(255)).transpose(0, 3, 1, 2))
+    net = AlexNetHip(3, 3)
+    net.load_checkpoint(os.path.join(golden_dir, "readme_kat_checkpoint.model"))
+    logits = host(net.forward(dev(T, x), record=False))
+    probs = O.softmax(logits)
+    assert probs.argmax(axis=1).tolist() == exp["argmax"]
+    assert np.allclose(probs.max(axis=1), exp["prob"], atol=3e-6), probs
+    onet = O.Net(3, 3)
+    onet.load_checkpoint(os.path.join(golden_dir, "readme_kat_checkpoint.model"))
+    assert_close(logits, onet.forward(x), REL_TOL, "logits vs oracle")
+
+
+def test_whole_net_train_steps_vs_oracle(T):
+    """config 1 plumbing: two full train steps (cnn.cpp:79-90) at B=4, 224x224: every activation, the pool mask,
+    every gradient and the post-SGD weights against the oracle."""
+    from cnn_amd.pynet import AlexNetHip
+
+    B = 4
+    x = uniform01(20, (B, 3, 224, 224))
+    labels = (np.arange(B) % 3).astype(np.int32)
+    onet = O.Net(B, 3)
+    p0 = normal_scaled(21, (onet.n_params,))
+    onet.params[:] = p0
+    net = AlexNetHip(B, 3)
+    assert net.n_params == onet.n_params == 111267
+    net.load_params(p0)
+    xd, ld = dev(T, x), dev(T, labels)
+    for step in range(2):
+        net.forward(xd)
+        net.loss_backward_seed(ld)
+        ologits = onet.forward(x)
+        oprobs = O.softmax(ologits)
+        oloss, odelta = O.cross_entropy_backward(oprobs, labels)
+        for l in range(4):
+            assert_close(host(net.conv_out[l]), onet.conv_out(l), REL_TOL, f"step{step} conv{l} out")
+        # pool argmax: bit-exact is only meaningful on identical inputs -> checked op-level above; here the
+        # conv outputs differ in the last bits, so compare values and allow rare near-tie flips in the mask
+        assert_close(host(net.pool_out), onet.pool_out(), REL_TOL, f"step{step} pool out")
+        assert np.mean(host(net.pool_mask) != onet.pool_mask()) < 1e-3
+        assert_close(host(net.logits), ologits, REL_TOL, f"step{step} logits")
+        assert np.isclose(float(host(net.loss_sum)[0]) / B, oloss, rtol=1e-4)
+        net.backward(net.delta)
+        onet.backward(odelta)
+        for l in range(4):
+            assert_close(host(net.d_conv[l]), onet.d_conv(l), 2e-4 if l == 0 else REL_TOL, f"step{step} d_conv{l}")
+        g, og = host(net.grads), onet.grads
+        for name, lo, hi in _param_slices(net):
+            assert_close(g[lo:hi], og[lo:hi], 2e-4, f"step{step} grad {name}")
+        net.update(1e-3)
+        onet.update(1e-3)
+        assert_close(host(net.params), onet.params, REL_TOL, f"step{step} params")
+
+
+def _param_slices(net):
+    out = []
+    for l in range(4):
+        out.append((f"conv{l}.w", net.w_off[l], net.b_off[l]))
+        out.append((f"conv{l}.b", net.b_off[l], net.b_off[l] + net.CHANS[l + 1]))
+    out.append(("linear.w", net.lw_off, net.lb_off))
+    out.append(("linear.b", net.lb_off, net.n_params))
+    return out
+
+
+def test_full_size_northstar_properties(T):
+    """BASELINE config 2 at its full size (B=256, 64->128, 112x112): the oracle would need minutes, so check
+    size-independent properties: implicit-GEMM == im2col fallback, and per-sample agreement with the oracle on a
+    3-sample slice (conv is per-sample independent, conv2d.cpp:69)."""
+    from cnn_amd import capi
+
+    case = (256, 64, 112, 112, 128, 3, 1, 0)
+    conv = capi.Conv2d(*case)
+    g = T.Generator(device="cuda").manual_seed(3)
+    x = T.rand((256, 64, 112, 112), generator=g, device="cuda")
+    w = T.randn((128, 64, 3, 3), generator=g, device="cuda") * 0.1
+    b = T.randn((128,), generator=g, device="cuda") * 0.1
+    y = conv.forward(x, w, b)
+    y2 = conv.forward_im2col(x, w, b)
+    scale = float(y2.abs().max())
+    assert float((y - y2).abs().max()) <= REL_TOL * scale
+    idx = [0, 131, 255]
+    y_ref = O.conv2d_forward(host(x[idx]), host(w), host(b), 1)
+    assert_close(host(y[idx]), y_ref, REL_TOL, "north-star forward slice")
+    dy = T.rand(y.shape, generator=g, device="cuda") * 2 - 1
+    del y2
+    gw, gb = conv.backward_weight(x, dy, 256.0)
+    gw2, gb2 = conv.backward_weight_im2col(x, dy, 256.0)
+    assert float((gw - gw2).abs().max()) <= REL_TOL * float(gw2.abs().max())
+    assert float((gb - gb2).abs().max()) <= REL_TOL * float(gb2.abs().max())
+    dx = conv.backward_data(dy, w)
+    _, _, dx_ref = O.conv2d_backward(host(x[idx]), host(dy[idx]), host(w), 1, need=(False, False, True))
+    assert_close(host(dx[idx]), dx_ref, REL_TOL, "north-star dgrad slice")
+    # linearity in dy: dgrad(2*dy) == 2*dgrad(dy) exactly (power-of-two scaling commutes with fp32 rounding)
+    assert T.equal(conv.backward_data(dy * 2, w), dx * 2)
