@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of one full train step of the reference network on the HIP path (MI355X).
+
+A "step" = one iteration of cpu/src/cnn.cpp:79-90 on one batch of synthetic 224x224x3 fp32 images already resident
+in HBM: forward, softmax + cross-entropy, backward, [RCCL all-reduce of the flat gradient arena], SGD.
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+Prints ONE JSON line on rank 0 (contract in the task brief) with two extra objects:
+  roofline     -- the dominant kernel of the step: algorithmic bytes (or FLOPs) per launch / its average duration,
+                  measured with HIP events on the launch stream DURING the timed region (only that kernel is
+                  bracketed, so the perturbation is two event records per step);
+  cpu_baseline -- the CPU oracle (oracle/cnn_oracle.c, a line-by-line port of the reference loop nests) timed on the
+                  host, 1 thread, bounded sample.
+plus conv_ns: the north-star Conv2d forward shape (3x3, 64->128, 112x112, batch 256) against the fp32-MFMA peak.
+"""
+import argparse
+import json
+import os
+import re
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+PEAK_MFMA_F32_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (256 CU x 2.4 GHz x 256 FLOP/clk)
+
+
+def algorithmic_work(key):
+    """(bytes, flops) of ONE launch of the kernel identified by "<kernel>|<geometry>" (SURVEY.md 8(d) figures)."""
+    kernel, geo = key.split("|", 1)
+    m = re.match(r"B(\d+) Ci(\d+) (\d+)x(\d+) Co(\d+) k(\d+) s(\d+) p(\d+)", geo)
+    if m:
+        B, Ci, H, W, Co, k, s, p = map(int, m.groups())
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        flops = 2.0 * B * Co * Ho * Wo * Ci * k * k
+        x_b, y_b, w_b = 4.0 * B * Ci * H * W, 4.0 * B * Co * Ho * Wo, 4.0 * Co * Ci * k * k
+        if kernel.startswith("igemm_kernel") or kernel.startswith("wgrad_kernel"):
+            return x_b + y_b + w_b, flops  # fwd: x,w -> y ; dgrad: dy,w -> dx ; wgrad: x,dy -> gw
+        if kernel.startswith("bias_grad_partial"):
+            return y_b, B * Co * Ho * Wo
+        return w_b * 2, 0.0  # prep / reduce kernels: weight-sized
+    m = re.match(r"n=(\d+)", geo)
+    if m:
+        n = int(m.group(1))
+        per = {"relu_fwd_vec": 8, "relu_bwd_vec": 12, "sgd_vec": 12}.get(kernel, 8)
+        return float(per * n), float(n)
+    m = re.match(r"B(\d+) C(\d+) (\d+)x(\d+) k(\d+) step(\d+)", geo)
+    if m:
+        B, C, H, W, k, st = map(int, m.groups())
+        Ho, Wo = (H - k) // st + 1, (W - k) // st + 1
+        if "fwd" in kernel:
+            return 4.0 * B * C * (H * W + 2 * Ho * Wo), float(B * C * Ho * Wo * k * k)
+        return 4.0 * B * C * (2 * Ho * Wo + H * W), 0.0
+    m = re.match(r"B(\d+) in(\d+) out(\d+)", geo)
+    if m:
+        B, n_in, n_out = map(int, m.groups())
+        return 4.0 * (B * n_in + n_in * n_out + B * n_out), 2.0 * B * n_in * n_out
+    return 0.0, 0.0
+
+
+def roofline_entry(key, launches, total_ms):
+    nbytes, flops = algorithmic_work(key)
+    avg_s = total_ms / 1e3 / max(launches, 1)
+    ridge = PEAK_MFMA_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    if nbytes > 0 and flops / nbytes >= ridge:
+        ach = flops / avg_s / 1e12
+        return {"bound": "mfma", "kernel": key, "achieved": round(ach, 3), "peak": PEAK_MFMA_F32_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                "avg_us": round(avg_s * 1e6, 2), "launches": launches}
+    ach = nbytes / avg_s / 1e9
+    return {"bound": "hbm", "kernel": key, "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "avg_us": round(avg_s * 1e6, 2),
+            "launches": launches, "algorithmic_bytes": nbytes}
+
+
+def cpu_baseline(batch=16, budget_s=12.0):
+    """the reference's own loop nests (oracle port) on 1 host thread: full train steps at batch 16 (BASELINE config 1)"""
+    import numpy as np
+
+    from oracle import pyoracle as O
+
+    rs = np.random.RandomState(0)
+    x = rs.rand(batch, 3, 224, 224).astype(np.float32)
+    labels = (np.arange(batch) % 3).astype(np.int32)
+    net = O.Net(batch, 3)
+    net.params[:] = (rs.standard_normal(net.n_params) * 0.1).astype(np.float32)
+    net.train_step(x, labels, 1e-3)  # warm-up
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        net.train_step(x, labels, 1e-3)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or steps >= 64:
+            break
+    return {"value": round(steps * batch / el, 2), "unit": "images/sec", "cores": 1, "kind": "port",
+            "host_cores": os.cpu_count(),
+            "sample": f"{steps} full train steps of the reference net at batch {batch}, 224x224x3 (after 1 warm-up); "
+                      f"oracle/cnn_oracle.c built -O2 without FMA like cpu/CMakeLists.txt:5"}
+
+
+def conv_ns_bench(torch, capi, reps=5):
+    """Conv2d forward, 3x3, 64->128, 112x112 (pad 0 -> 110x110), batch 256: FLOPs / kernel time vs fp32-MFMA peak"""
+    case = (256, 64, 112, 112, 128, 3, 1, 0)
+    conv = capi.Conv2d(*case)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.rand((256, 64, 112, 112), generator=g, device="cuda")
+    w = torch.randn((128, 64, 3, 3), generator=g, device="cuda") * 0.1
+    b = torch.randn((128,), generator=g, device="cuda") * 0.1
+    y = torch.empty(conv.out_shape(), device="cuda")
+    dy = torch.rand(conv.out_shape(), generator=g, device="cuda") * 2 - 1
+    dx = torch.empty_like(x)
+    for _ in range(2):
+        conv.forward(x, w, b, y)
+        conv.backward_data(dy, w, dx)
+        conv.backward_weight(x, dy, 256.0)
+    torch.cuda.synchronize()
+    capi.kernel_timing(1)
+    for _ in range(reps):
+        conv.forward(x, w, b, y)
+        conv.backward_data(dy, w, dx)
+        conv.backward_weight(x, dy, 256.0)
+    rep = capi.kernel_timing_report()
+    capi.kernel_timing(0)
+    flops = 2.0 * 256 * 128 * 110 * 110 * 64 * 9
+    out = {"shape": "B256 64->128 k3 s1 112x112->110x110", "gflop": round(flops / 1e9, 2), "peak_tflops": PEAK_MFMA_F32_TFLOPS}
+    for key, (cnt, ms) in rep.items():
+        name = key.split("|")[0]
+        if name.startswith("igemm_kernel") or name.startswith("wgrad_kernel"):
+            tf = flops / (ms / 1e3 / cnt) / 1e12
+            tag = "fwd" if name.endswith("/fwd") else ("dgrad" if name.endswith("/dgrad") else "wgrad")
+            out[tag] = {"kernel": name, "avg_ms": round(ms / cnt, 4), "tflops": round(tf, 2),
+                        "frac_of_mfma_peak": round(tf / PEAK_MFMA_F32_TFLOPS, 4)}
+    del x, y, dy, dx
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE configs 2/3: 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-conv-ns", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from cnn_amd import capi
+    from cnn_amd.pynet import AlexNetHip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    arch = capi.load().cnn_amd_device_arch().decode()
+    assert arch == "gfx950", f"libcnn_amd.so targets gfx950, device reports {arch}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    B = args.batch
+    net = AlexNetHip(B, 3)
+    rs = np.random.RandomState(1234)  # identical init on every rank: replicas stay in lock-step without a broadcast
+    net.load_params((rs.standard_normal(net.n_params) * 0.1).astype(np.float32))
+    g = torch.Generator(device="cuda").manual_seed(100 + rank)  # each rank has its own shard of the global batch
+    x = torch.rand((B, 3, 224, 224), generator=g, device="cuda")
+    labels = (torch.arange(B, device="cuda") % 3).to(torch.int32)
+    lr = 1e-3
+
+    def step():
+        net.train_step(x, labels, lr, dist, world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # --- untimed: one instrumented step to find the dominant kernel, then the warm-up ---
+    step()
+    torch.cuda.synchronize()
+    capi.kernel_timing(1)
+    step()
+    table = capi.kernel_timing_report()
+    capi.kernel_timing(0)
+    dominant = max(table.items(), key=lambda kv: kv[1][1])[0]
+    for _ in range(args.warmup):
+        step()
+
+    # --- timed region: exactly K steps; only the dominant kernel is event-bracketed ---
+    capi.kernel_timing(2, dominant)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dom = capi.kernel_timing_report()
+    capi.kernel_timing(0)
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(net.loss_sum.item()) / B
+    assert np.isfinite(loss), "training diverged: loss is not finite"
+
+    out = None
+    if rank == 0:
+        cnt, ms = dom[dominant]
+        out = {
+            "metric": "images/sec (train step, 224x224x3)",
+            "value": round(world * B * args.steps / elapsed, 1),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "reference AlexNet-style net (cpu/src/alexnet.cpp:10-33: 4x Conv3x3/s2 + ReLU, one MaxPool2x2, "
+                            "Linear 4608->3), full train step (fwd + softmax/CE + bwd + SGD), 224x224x3 fp32, BASELINE configs[1]",
+                "per_gpu_batch": B,
+                "global_batch": world * B,
+                "parallelism": f"dp{world}" + (" (RCCL all-reduce of the 111267-float gradient arena per step)" if world > 1 else ""),
+            },
+            "roofline": roofline_entry(dominant, cnt, ms),
+            "final_loss": round(loss, 5),
+        }
+        if args.breakdown:
+            tot = sum(v[1] for v in table.values())
+            for k, (c, m) in sorted(table.items(), key=lambda kv: -kv[1][1]):
+                r = roofline_entry(k, c, m)
+                print(f"{m:9.4f} ms {100 * m / tot:5.1f}%  {r['achieved']:>9} {r['unit']:8} {k}", file=sys.stderr)
+            print(f"{tot:9.4f} ms kernel total for one step", file=sys.stderr)
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1:
+        if not args.no_conv_ns:
+            out["conv_ns"] = conv_ns_bench(torch, capi)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,8 @@ SIGNATURES = {
     "cnn_amd_abi_version": (C.c_int, []),
     "cnn_amd_last_error": (C.c_char_p, []),
     "cnn_amd_device_arch": (C.c_char_p, []),
+    "cnn_amd_kernel_timing_enable": (C.c_int, [C.c_int, C.c_char_p]),
+    "cnn_amd_kernel_timing_report": (C.c_longlong, [C.c_char_p, C.c_size_t]),
     "cnn_conv2d_out_dim": (C.c_int, [C.c_int] * 4),
     "cnn_maxpool2d_out_dim": (C.c_int, [C.c_int] * 3),
     "cnn_conv2d_workspace_bytes": (C.c_size_t, [_D]),
@@ -283,3 +285,27 @@ def softmax_xent(logits, labels, want_probs=True):
     loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
     check(load().cnn_softmax_xent(_ptr(logits), _ptr(labels), _ptr(probs), _ptr(delta), _ptr(loss), B, n, _stream()), "cnn_softmax_xent")
     return probs, delta, loss
+
+
+def kernel_timing(mode, filter_key=""):
+    """0 = off, 1 = every kernel, 2 = only keys containing filter_key"""
+    check(load().cnn_amd_kernel_timing_enable(int(mode), filter_key.encode()), "cnn_amd_kernel_timing_enable")
+
+
+def kernel_timing_report():
+    """-> {key: (launches, total_ms)} in first-launch order; clears the records"""
+    lib = load()
+    cap = 1 << 16
+    while True:
+        buf = C.create_string_buffer(cap)
+        need = lib.cnn_amd_kernel_timing_report(buf, cap)
+        if need < 0:
+            raise CnnAmdError("cnn_amd_kernel_timing_report failed")
+        if need <= cap:
+            break
+        cap = int(need) + 64
+    out = {}
+    for line in buf.value.decode().splitlines():
+        key, cnt, ms = line.rsplit("\t", 2)
+        out[key] = (int(cnt), float(ms))
+    return out

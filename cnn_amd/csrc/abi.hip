@@ -1,5 +1,9 @@
 // abi.hip -- version / error / memory-helper entry points of include/cnn_amd.h
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -15,6 +19,55 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+
+// ---- per-kernel event timing -----------------------------------------------------------------------------
+namespace {
+struct KRecord {
+    std::string key;
+    hipEvent_t e0, e1;
+};
+struct KTimer {
+    int mode = 0;
+    std::string filter;
+    std::vector<KRecord> recs;
+    bool open = false;
+    std::mutex mu;
+};
+KTimer& kt() {
+    static KTimer t;
+    return t;
+}
+}  // namespace
+
+bool ktimer_active() { return kt().mode != 0; }
+
+void ktimer_begin(hipStream_t s, const char* kernel, const char* fmt, ...) {
+    KTimer& t = kt();
+    char tag[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tag, sizeof(tag), fmt, ap);
+    va_end(ap);
+    std::string key = std::string(kernel) + "|" + tag;
+    std::lock_guard<std::mutex> lk(t.mu);
+    t.open = false;
+    if (t.mode == 2 && key.find(t.filter) == std::string::npos) return;
+    KRecord r;
+    r.key = key;
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    (void)hipEventRecord(r.e0, s);
+    t.recs.push_back(r);
+    t.open = true;
+}
+
+void ktimer_end(hipStream_t s) {
+    KTimer& t = kt();
+    std::lock_guard<std::mutex> lk(t.mu);
+    if (!t.open) return;
+    (void)hipEventRecord(t.recs.back().e1, s);
+    t.open = false;
+}
+
 }  // namespace cnn_amd
 
 using namespace cnn_amd;
@@ -43,6 +96,51 @@ const char* cnn_amd_device_arch(void) {
     char* colon = strchr(arch, ':');
     if (colon) *colon = 0;
     return arch;
+}
+
+int cnn_amd_kernel_timing_enable(int mode, const char* filter) {
+    KTimer& t = kt();
+    std::lock_guard<std::mutex> lk(t.mu);
+    CNN_REQUIRE(mode >= 0 && mode <= 2, "cnn_amd_kernel_timing_enable: mode %d", mode);
+    t.mode = mode;
+    t.filter = filter ? filter : "";
+    return CNN_AMD_OK;
+}
+
+// Synchronises the device, then writes one line per distinct key: "<key>\t<launches>\t<total_ms>\n" and clears
+// the records.  Returns the number of bytes needed (call again with a larger buffer if > cap; records are kept).
+long long cnn_amd_kernel_timing_report(char* buf, size_t cap) {
+    KTimer& t = kt();
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lk(t.mu);
+    std::map<std::string, std::pair<long long, double>> agg;
+    std::vector<std::string> order;
+    for (auto& r : t.recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        auto it = agg.find(r.key);
+        if (it == agg.end()) {
+            order.push_back(r.key);
+            agg[r.key] = {1, ms};
+        } else {
+            it->second.first += 1;
+            it->second.second += ms;
+        }
+    }
+    std::string out;
+    char line[512];
+    for (auto& k : order) {
+        snprintf(line, sizeof(line), "%s\t%lld\t%.6f\n", k.c_str(), agg[k].first, agg[k].second);
+        out += line;
+    }
+    if (out.size() + 1 > cap || !buf) return (long long)out.size() + 1;
+    memcpy(buf, out.c_str(), out.size() + 1);
+    for (auto& r : t.recs) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    t.recs.clear();
+    return (long long)out.size() + 1;
 }
 
 int cnn_conv2d_out_dim(int in, int k, int s, int pad) { return (in + 2 * pad - k) / s + 1; }

@@ -25,6 +25,22 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 // every kernel launch is followed by this: catches bad launch configs without synchronising
 #define CNN_LAUNCH_CHECK() CNN_HIP_CHECK(hipGetLastError())
 
+// Optional per-kernel timing with HIP events recorded on the launch stream (cnn_amd_kernel_timing_* in the ABI).
+// mode 0 = off (one predictable branch per launch), 1 = every kernel, 2 = only records whose key contains `filter`.
+bool ktimer_active();
+void ktimer_begin(hipStream_t s, const char* kernel, const char* fmt, ...);
+void ktimer_end(hipStream_t s);
+
+// launch `expr` (a kernel<<<...>>>(...) expression), timed when profiling is on; `...` = printf-style geometry tag
+#define CNN_KLAUNCH(stream, kernel_name, expr, ...)                                         \
+    do {                                                                                    \
+        const bool t__ = ::cnn_amd::ktimer_active();                                        \
+        if (t__) ::cnn_amd::ktimer_begin(stream, kernel_name, __VA_ARGS__);                 \
+        expr;                                                                               \
+        if (t__) ::cnn_amd::ktimer_end(stream);                                             \
+        CNN_LAUNCH_CHECK();                                                                 \
+    } while (0)
+
 #define CNN_REQUIRE(cond, ...)                                             \
     do {                                                                   \
         if (!(cond)) return ::cnn_amd::fail(CNN_AMD_E_BADARG, __VA_ARGS__); \

@@ -380,21 +380,25 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl) {
     return CNN_AMD_OK;
 }
 
+#define CONV_TAG(d) "B%d Ci%d %dx%d Co%d k%d s%d p%d", (d)->B, (d)->Ci, (d)->H, (d)->W, (d)->Co, (d)->k, (d)->s, (d)->pad
+
 template <int MF, int MA, int NB, int WM, int WN, int CK>
-int launch_cfg(const Plan& pl, hipStream_t s) {
+int launch_cfg(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
     auto kern = igemm_kernel<MF, MA, NB, WM, WN, CK>;
     static thread_local size_t max_set = 0;
     if (pl.lds_bytes > 48 * 1024 && pl.lds_bytes > max_set) {
         CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         max_set = 160 * 1024;
     }
-    kern<<<dim3(pl.grid_x, pl.grid_y), 64 * WM * WN, pl.lds_bytes, s>>>(pl.p);
-    CNN_LAUNCH_CHECK();
+    char name[96];
+    snprintf(name, sizeof(name), "igemm_kernel<%d,%d,%d,%d,%d,%d>%s", MF, MA, NB, WM, WN, CK,
+             pl.p.mode == MODE_FWD ? "/fwd" : "/dgrad");
+    CNN_KLAUNCH(s, name, (kern<<<dim3(pl.grid_x, pl.grid_y), 64 * WM * WN, pl.lds_bytes, s>>>(pl.p)), CONV_TAG(d));
     return CNN_AMD_OK;
 }
 
-int run_plan(Plan& pl, const float* X, const float* w, const float* bias, float* Y, void* ws, size_t ws_bytes,
-             hipStream_t s, const char* who) {
+int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w, const float* bias, float* Y, void* ws,
+             size_t ws_bytes, hipStream_t s, const char* who) {
     CNN_REQUIRE(ws != nullptr, "%s: workspace is null", who);
     if (ws_bytes < pl.a_floats * sizeof(float))
         return fail(CNN_AMD_E_WORKSPACE, "%s: workspace %zu B < %zu B", who, ws_bytes, pl.a_floats * sizeof(float));
@@ -403,15 +407,15 @@ int run_plan(Plan& pl, const float* X, const float* w, const float* bias, float*
     const long long total = (long long)pl.a_floats;
     unsigned pg = (unsigned)((total + 255) / 256);
     if (pg > 4096) pg = 4096;
-    igemm_prep_weights<<<pg, 256, 0, s>>>(pl.q);
-    CNN_LAUNCH_CHECK();
+    CNN_KLAUNCH(s, pl.p.mode == MODE_FWD ? "igemm_prep_weights/fwd" : "igemm_prep_weights/dgrad",
+                (igemm_prep_weights<<<pg, 256, 0, s>>>(pl.q)), CONV_TAG(d));
     pl.p.X = X; pl.p.A = (const float*)ws; pl.p.bias = bias; pl.p.Y = Y;
     switch (pl.cfg) {
-        case CFG_M128: return launch_cfg<32, 4, 1, 1, 4, 8>(pl, s);
-        case CFG_M64: return launch_cfg<32, 2, 2, 1, 4, 8>(pl, s);
-        case CFG_M32: return launch_cfg<32, 1, 4, 1, 4, 8>(pl, s);
-        case CFG_M16_CK4: return launch_cfg<16, 1, 4, 1, 4, 4>(pl, s);
-        default: return launch_cfg<16, 1, 4, 1, 4, 16>(pl, s);
+        case CFG_M128: return launch_cfg<32, 4, 1, 1, 4, 8>(pl, s, d);
+        case CFG_M64: return launch_cfg<32, 2, 2, 1, 4, 8>(pl, s, d);
+        case CFG_M32: return launch_cfg<32, 1, 4, 1, 4, 8>(pl, s, d);
+        case CFG_M16_CK4: return launch_cfg<16, 1, 4, 1, 4, 4>(pl, s, d);
+        default: return launch_cfg<16, 1, 4, 1, 4, 16>(pl, s, d);
     }
 }
 
@@ -446,7 +450,7 @@ int cnn_conv2d_forward(const cnn_conv2d_desc* d, const float* x, const float* w,
     CNN_REQUIRE(x && w && bias && y, "cnn_conv2d_forward: null pointer");
     Plan pl;
     if (int rc = make_plan("cnn_conv2d_forward", d, MODE_FWD, &pl)) return rc;
-    return run_plan(pl, x, w, bias, y, ws, ws_bytes, as_stream(stream), "cnn_conv2d_forward");
+    return run_plan(pl, d, x, w, bias, y, ws, ws_bytes, as_stream(stream), "cnn_conv2d_forward");
 }
 
 int cnn_conv2d_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws,
@@ -455,7 +459,7 @@ int cnn_conv2d_backward_data(const cnn_conv2d_desc* d, const float* dy, const fl
     CNN_REQUIRE(dy && w && dx, "cnn_conv2d_backward_data: null pointer");
     Plan pl;
     if (int rc = make_plan("cnn_conv2d_backward_data", d, MODE_DGRAD, &pl)) return rc;
-    return run_plan(pl, dy, w, nullptr, dx, ws, ws_bytes, as_stream(stream), "cnn_conv2d_backward_data");
+    return run_plan(pl, d, dy, w, nullptr, dx, ws, ws_bytes, as_stream(stream), "cnn_conv2d_backward_data");
 }
 
 }  // extern "C"

@@ -288,16 +288,19 @@ int make_wplan(const char* who, const cnn_conv2d_desc* d, WPlan* pl) {
     return CNN_AMD_OK;
 }
 
+#define CONV_TAG(d) "B%d Ci%d %dx%d Co%d k%d s%d p%d", (d)->B, (d)->Ci, (d)->H, (d)->W, (d)->Co, (d)->k, (d)->s, (d)->pad
+
 template <int MF, int MA, int NB, int WM, int WN, int WK>
-int launch_w(const WPlan& pl, hipStream_t s) {
+int launch_w(const WPlan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
     auto kern = wgrad_kernel<MF, MA, NB, WM, WN, WK>;
     static thread_local bool attr_set = false;
     if (pl.lds_bytes > 48 * 1024 && !attr_set) {
         CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    kern<<<dim3(pl.nsplit, pl.gy, pl.gz), 64 * WM * WN * WK, pl.lds_bytes, s>>>(pl.p);
-    CNN_LAUNCH_CHECK();
+    char name[96];
+    snprintf(name, sizeof(name), "wgrad_kernel<%d,%d,%d,%d,%d,%d>", MF, MA, NB, WM, WN, WK);
+    CNN_KLAUNCH(s, name, (kern<<<dim3(pl.nsplit, pl.gy, pl.gz), 64 * WM * WN * WK, pl.lds_bytes, s>>>(pl.p)), CONV_TAG(d));
     return CNN_AMD_OK;
 }
 
@@ -339,24 +342,24 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
     pl.p.x = x; pl.p.dy = dy; pl.p.part = (float*)ws;
     int rc;
     switch (pl.cfg) {
-        case W_128x288: rc = launch_w<32, 1, 9, 4, 1, 1>(pl, s); break;
-        case W_64x320: rc = launch_w<32, 1, 5, 2, 2, 1>(pl, s); break;
-        case W_32x160: rc = launch_w<32, 1, 5, 1, 1, 4>(pl, s); break;
-        default: rc = launch_w<16, 1, 2, 1, 1, 4>(pl, s); break;
+        case W_128x288: rc = launch_w<32, 1, 9, 4, 1, 1>(pl, s, d); break;
+        case W_64x320: rc = launch_w<32, 1, 5, 2, 2, 1>(pl, s, d); break;
+        case W_32x160: rc = launch_w<32, 1, 5, 1, 1, 4>(pl, s, d); break;
+        default: rc = launch_w<16, 1, 2, 1, 1, 4>(pl, s, d); break;
     }
     if (rc) return rc;
     const size_t n = (size_t)pl.p.Co * pl.p.Ntot;
     unsigned rg = (unsigned)((n + 255) / 256);
     if (rg > 2048) rg = 2048;
-    wgrad_reduce<<<rg, 256, 0, s>>>((const float*)ws, gw, pl.nslots, n, divisor);
-    CNN_LAUNCH_CHECK();
+    CNN_KLAUNCH(s, "wgrad_reduce", (wgrad_reduce<<<rg, 256, 0, s>>>((const float*)ws, gw, pl.nslots, n, divisor)), CONV_TAG(d));
     if (gb) {
         float* bpart = (float*)ws + pl.part_floats;
-        bias_grad_partial<<<dim3(pl.p.Co, pl.bias_groups), kBiasBlock, 0, s>>>(dy, bpart, pl.p.B, pl.p.Co,
-                                                                              pl.p.Ho * pl.p.Wo, pl.bias_groups);
-        CNN_LAUNCH_CHECK();
-        bias_grad_final<<<(pl.p.Co + 63) / 64, 64, 0, s>>>(bpart, gb, pl.p.Co, pl.bias_groups, divisor);
-        CNN_LAUNCH_CHECK();
+        CNN_KLAUNCH(s, "bias_grad_partial",
+                    (bias_grad_partial<<<dim3(pl.p.Co, pl.bias_groups), kBiasBlock, 0, s>>>(dy, bpart, pl.p.B, pl.p.Co,
+                                                                                           pl.p.Ho * pl.p.Wo, pl.bias_groups)),
+                    CONV_TAG(d));
+        CNN_KLAUNCH(s, "bias_grad_final",
+                    (bias_grad_final<<<(pl.p.Co + 63) / 64, 64, 0, s>>>(bpart, gb, pl.p.Co, pl.bias_groups, divisor)), CONV_TAG(d));
     }
     return CNN_AMD_OK;
 }

@@ -45,10 +45,13 @@ __global__ __launch_bounds__(kBlock) void relu_bwd_scalar(const float* __restric
 }
 
 // p - lr*(g*scale) with every product/sum rounded separately: the reference is built without FMA
-// (x86-64 -O2, CMakeLists.txt:5), so w -= lr*g is mul-then-sub; __fmul_rn/__fsub_rn stop hipcc contracting it.
+// (x86-64 -O2, CMakeLists.txt:5), so w -= lr*g is mul-then-sub; the fp-contract pragma stops hipcc fusing it
+// (HIP's __fmul_rn/__fsub_rn are plain operators and do get contracted).
 __device__ __forceinline__ float sgd_one(float p, float g, float lr, float scale, bool scaled) {
-    const float gs = scaled ? __fmul_rn(g, scale) : g;
-    return __fsub_rn(p, __fmul_rn(lr, gs));
+#pragma clang fp contract(off)
+    const float gs = scaled ? g * scale : g;
+    const float step = lr * gs;
+    return p - step;
 }
 __global__ __launch_bounds__(kBlock) void sgd_vec(float4* __restrict__ p, const float4* __restrict__ g, size_t n4,
                                                   float lr, float scale, bool scaled) {
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void softmax_xent_kernel(const float* __res
                 const float yv = (i == label) ? 1.f : 0.f;
                 if (probs) probs[(size_t)b * classes + i] = p;
                 delta[(size_t)b * classes + i] = p - yv;  // no 1/B here (func.cpp:64)
-                term += __fmul_rn(logf(p), yv);           // func.cpp:65, incl. its log(0)*0 = NaN behaviour
+                term += logf(p) * yv;                     // func.cpp:65, incl. its log(0)*0 = NaN behaviour
             }
         }
         terms[threadIdx.x] = term;
@@ -126,13 +129,13 @@ int cnn_relu_forward(const float* x, float* y, size_t n, void* stream) {
     size_t done = 0;
     if (aligned16(x) && aligned16(y) && n >= 4) {
         const size_t n4 = n / 4;
-        relu_fwd_vec<<<stream_grid(n4, kBlock), kBlock, 0, s>>>((const float4*)x, (float4*)y, n4);
-        CNN_LAUNCH_CHECK();
+        CNN_KLAUNCH(s, "relu_fwd_vec", (relu_fwd_vec<<<stream_grid(n4, kBlock), kBlock, 0, s>>>((const float4*)x, (float4*)y, n4)),
+                    "n=%zu", n);
         done = n4 * 4;
     }
     if (done < n) {
-        relu_fwd_scalar<<<stream_grid(n - done, kBlock), kBlock, 0, s>>>(x, y, done, n);
-        CNN_LAUNCH_CHECK();
+        CNN_KLAUNCH(s, "relu_fwd_scalar", (relu_fwd_scalar<<<stream_grid(n - done, kBlock), kBlock, 0, s>>>(x, y, done, n)),
+                    "tail n=%zu", n - done);
     }
     return CNN_AMD_OK;
 }
@@ -144,13 +147,13 @@ int cnn_relu_backward(const float* y, float* dy, size_t n, void* stream) {
     size_t done = 0;
     if (aligned16(y) && aligned16(dy) && n >= 4) {
         const size_t n4 = n / 4;
-        relu_bwd_vec<<<stream_grid(n4, kBlock), kBlock, 0, s>>>((const float4*)y, (float4*)dy, n4);
-        CNN_LAUNCH_CHECK();
+        CNN_KLAUNCH(s, "relu_bwd_vec", (relu_bwd_vec<<<stream_grid(n4, kBlock), kBlock, 0, s>>>((const float4*)y, (float4*)dy, n4)),
+                    "n=%zu", n);
         done = n4 * 4;
     }
     if (done < n) {
-        relu_bwd_scalar<<<stream_grid(n - done, kBlock), kBlock, 0, s>>>(y, dy, done, n);
-        CNN_LAUNCH_CHECK();
+        CNN_KLAUNCH(s, "relu_bwd_scalar", (relu_bwd_scalar<<<stream_grid(n - done, kBlock), kBlock, 0, s>>>(y, dy, done, n)),
+                    "tail n=%zu", n - done);
     }
     return CNN_AMD_OK;
 }
@@ -163,14 +166,16 @@ int cnn_sgd_update(float* params, const float* grads, size_t n, float lr, float 
     size_t done = 0;
     if (aligned16(params) && aligned16(grads) && n >= 4) {
         const size_t n4 = n / 4;
-        sgd_vec<<<stream_grid(n4, kBlock), kBlock, 0, s>>>((float4*)params, (const float4*)grads, n4, lr, grad_scale,
-                                                          scaled);
-        CNN_LAUNCH_CHECK();
+        CNN_KLAUNCH(s, "sgd_vec",
+                    (sgd_vec<<<stream_grid(n4, kBlock), kBlock, 0, s>>>((float4*)params, (const float4*)grads, n4, lr,
+                                                                       grad_scale, scaled)),
+                    "n=%zu", n);
         done = n4 * 4;
     }
     if (done < n) {
-        sgd_scalar<<<stream_grid(n - done, kBlock), kBlock, 0, s>>>(params, grads, done, n, lr, grad_scale, scaled);
-        CNN_LAUNCH_CHECK();
+        CNN_KLAUNCH(s, "sgd_scalar",
+                    (sgd_scalar<<<stream_grid(n - done, kBlock), kBlock, 0, s>>>(params, grads, done, n, lr, grad_scale, scaled)),
+                    "tail n=%zu", n - done);
     }
     return CNN_AMD_OK;
 }
@@ -179,8 +184,10 @@ int cnn_softmax_xent(const float* logits, const int32_t* labels, float* probs, f
                      int classes, void* stream) {
     CNN_REQUIRE(logits && labels && delta, "cnn_softmax_xent: null pointer");
     CNN_REQUIRE(B > 0 && classes > 0, "cnn_softmax_xent: B=%d classes=%d", B, classes);
-    softmax_xent_kernel<<<1, kBlock, 0, as_stream(stream)>>>(logits, labels, probs, delta, loss_sum, B, classes);
-    CNN_LAUNCH_CHECK();
+    hipStream_t s = as_stream(stream);
+    CNN_KLAUNCH(s, "softmax_xent_kernel",
+                (softmax_xent_kernel<<<1, kBlock, 0, s>>>(logits, labels, probs, delta, loss_sum, B, classes)), "B=%d classes=%d",
+                B, classes);
     return CNN_AMD_OK;
 }
 

@@ -116,8 +116,8 @@ int cnn_linear_forward(const float* x, const float* w, const float* bias, float*
                        void* stream) {
     CNN_REQUIRE(x && w && bias && y, "cnn_linear_forward: null pointer");
     CNN_REQUIRE(B > 0 && in > 0 && out > 0, "cnn_linear_forward: B=%d in=%d out=%d", B, in, out);
-    linear_fwd<<<B, kBlock, 0, as_stream(stream)>>>(x, w, bias, y, in, out);
-    CNN_LAUNCH_CHECK();
+    hipStream_t s = as_stream(stream);
+    CNN_KLAUNCH(s, "linear_fwd", (linear_fwd<<<B, kBlock, 0, s>>>(x, w, bias, y, in, out)), "B%d in%d out%d", B, in, out);
     return CNN_AMD_OK;
 }
 
@@ -129,18 +129,17 @@ int cnn_linear_backward(const float* x, const float* dy, const float* w, float* 
     hipStream_t s = as_stream(stream);
     if (gw) {
         CNN_REQUIRE(x != nullptr, "cnn_linear_backward: x is null");
-        linear_bwd_w<<<ceil_div(in, kBlock), kBlock, 0, s>>>(x, dy, gw, B, in, out, divisor);
-        CNN_LAUNCH_CHECK();
+        CNN_KLAUNCH(s, "linear_bwd_w", (linear_bwd_w<<<ceil_div(in, kBlock), kBlock, 0, s>>>(x, dy, gw, B, in, out, divisor)),
+                    "B%d in%d out%d", B, in, out);
     }
     if (gb) {
-        linear_bwd_b<<<ceil_div(out, 64), 64, 0, s>>>(dy, gb, B, out, divisor);
-        CNN_LAUNCH_CHECK();
+        CNN_KLAUNCH(s, "linear_bwd_b", (linear_bwd_b<<<ceil_div(out, 64), 64, 0, s>>>(dy, gb, B, out, divisor)), "B%d out%d", B,
+                    out);
     }
     if (dx) {
         CNN_REQUIRE(w != nullptr, "cnn_linear_backward: w is null");
         dim3 grid(ceil_div(in, kBlock) > 64 ? 64 : ceil_div(in, kBlock), B);
-        linear_bwd_x<<<grid, kBlock, 0, s>>>(dy, w, dx, in, out);
-        CNN_LAUNCH_CHECK();
+        CNN_KLAUNCH(s, "linear_bwd_x", (linear_bwd_x<<<grid, kBlock, 0, s>>>(dy, w, dx, in, out)), "B%d in%d out%d", B, in, out);
     }
     return CNN_AMD_OK;
 }

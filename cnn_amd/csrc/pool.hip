@@ -127,13 +127,16 @@ int cnn_maxpool2d_forward(const float* x, float* y, int32_t* mask, int B, int C,
     const int Ho = cnn_maxpool2d_out_dim(H, k, step), Wo = cnn_maxpool2d_out_dim(W, k, step);
     const long long rows = (long long)B * C * Ho;
     hipStream_t s = as_stream(stream);
+#define POOL_TAG "B%d C%d %dx%d k%d step%d mask%d", B, C, H, W, k, step, mask ? 1 : 0
     if (k == 2 && step == 2)
-        maxpool_fwd_rows<2, 2><<<row_grid(rows), kBlock, 0, s>>>(x, y, mask, rows, C, H, W, Ho, Wo, k, step);
+        CNN_KLAUNCH(s, "maxpool_fwd_rows<2,2>",
+                    (maxpool_fwd_rows<2, 2><<<row_grid(rows), kBlock, 0, s>>>(x, y, mask, rows, C, H, W, Ho, Wo, k, step)), POOL_TAG);
     else if (k == 3 && step == 2)
-        maxpool_fwd_rows<3, 2><<<row_grid(rows), kBlock, 0, s>>>(x, y, mask, rows, C, H, W, Ho, Wo, k, step);
+        CNN_KLAUNCH(s, "maxpool_fwd_rows<3,2>",
+                    (maxpool_fwd_rows<3, 2><<<row_grid(rows), kBlock, 0, s>>>(x, y, mask, rows, C, H, W, Ho, Wo, k, step)), POOL_TAG);
     else
-        maxpool_fwd_rows<0, 0><<<row_grid(rows), kBlock, 0, s>>>(x, y, mask, rows, C, H, W, Ho, Wo, k, step);
-    CNN_LAUNCH_CHECK();
+        CNN_KLAUNCH(s, "maxpool_fwd_rows<0,0>",
+                    (maxpool_fwd_rows<0, 0><<<row_grid(rows), kBlock, 0, s>>>(x, y, mask, rows, C, H, W, Ho, Wo, k, step)), POOL_TAG);
     return CNN_AMD_OK;
 }
 
@@ -145,10 +148,11 @@ int cnn_maxpool2d_backward(const float* dy, const int32_t* mask, float* dx, int 
     const long long rows = (long long)B * C * H;
     hipStream_t s = as_stream(stream);
     if (k == 2 && step == 2)
-        maxpool_bwd_rows<2, 2><<<row_grid(rows), kBlock, 0, s>>>(dy, mask, dx, rows, C, H, W, Ho, Wo, k, step);
+        CNN_KLAUNCH(s, "maxpool_bwd_rows<2,2>",
+                    (maxpool_bwd_rows<2, 2><<<row_grid(rows), kBlock, 0, s>>>(dy, mask, dx, rows, C, H, W, Ho, Wo, k, step)), POOL_TAG);
     else
-        maxpool_bwd_rows<0, 0><<<row_grid(rows), kBlock, 0, s>>>(dy, mask, dx, rows, C, H, W, Ho, Wo, k, step);
-    CNN_LAUNCH_CHECK();
+        CNN_KLAUNCH(s, "maxpool_bwd_rows<0,0>",
+                    (maxpool_bwd_rows<0, 0><<<row_grid(rows), kBlock, 0, s>>>(dy, mask, dx, rows, C, H, W, Ho, Wo, k, step)), POOL_TAG);
     return CNN_AMD_OK;
 }
 

@@ -37,6 +37,13 @@ const char* cnn_amd_last_error(void);
 /* "gfx950" when a device is present and matches, otherwise an explanatory string; never throws */
 const char* cnn_amd_device_arch(void);
 
+/* ---- measurement: per-kernel durations from HIP events recorded on the launch stream --------------------- */
+/* mode 0 = off, 1 = time every kernel launch, 2 = only launches whose "<kernel>|<geometry>" key contains filter */
+int cnn_amd_kernel_timing_enable(int mode, const char* filter);
+/* device-synchronises; writes "<kernel>|<geometry>\t<launches>\t<total_ms>\n" lines (host buffer) and clears
+ * the records; returns bytes needed (records are kept when cap is too small), -1 on error */
+long long cnn_amd_kernel_timing_report(char* buf, size_t cap);
+
 /* ---- geometry helpers (host side, pure) -------------------------------------------------------------- */
 /* conv2d.cpp:41-42:  out = (H + 2*pad - k)/s + 1, integer division (the reference has pad == 0) */
 int cnn_conv2d_out_dim(int in, int k, int s, int pad);
