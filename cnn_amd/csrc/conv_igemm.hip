@@ -48,6 +48,8 @@ struct IgemmParams {
     int mode;           // 0 = forward NCHW store (+bias), 1 = dgrad parity scatter
     int s_out, c_out, OH, OW;  // mode 1: stride, real channel count Ci, dx height/width
     int ntiles;         // number of pixel tiles (grid.x)
+    int rw_shift;       // log2(lanes per staged row): narrow rows share one wave-wide load
+    int need_zero;      // the row image has pad columns / out-of-image rows -> zero it once
 };
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
@@ -124,7 +126,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
     const int nrows = (nseg == 1) ? nrows0 : nrows0 + (nseg - 2) * full + u1 * p.su + p.TR;
 
     // ---- one-time LDS setup: zero the row image (pad columns / out-of-image rows stay 0 for every chunk) ----
-    for (int i = tid; i < CK * p.chs; i += NT) Xs[i] = 0.f;
+    if (p.need_zero)
+        for (int i = tid; i < CK * p.chs; i += NT) Xs[i] = 0.f;
     for (int r = tid; r < nrows; r += NT) {
         int b, xrow;
         if (r < nrows0) {
@@ -165,29 +168,66 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
 
     for (int cc = 0; cc < p.nchunk; ++cc) {
         __syncthreads();  // previous chunk's reads are done (and, first time, the zero fill / row table landed)
-        // ---- stage the filter slab: one contiguous block ----
+        // ---- stage the filter slab: one contiguous block, 4 independent 16-byte loads in flight per thread ----
         {
             const float4* src = Ag + (size_t)cc * a_vec;
             float4* dst = (float4*)As;
-            for (int i = tid; i < a_vec; i += NT) dst[i] = src[i];
+            for (int i0 = tid; i0 < a_vec; i0 += NT * 4) {
+                float4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u * NT < a_vec) t[u] = src[i0 + u * NT];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u * NT < a_vec) dst[i0 + u * NT] = t[u];
+            }
         }
-        // ---- stage input rows: wave per (channel,row), lanes along the row ----
-        for (int ck = 0; ck < CK; ++ck) {
-            const int c = cc * CK + ck;
-            float* xdst = Xs + ck * p.chs + p.padL;
-            if (c < p.C) {
-                for (int r = wave; r < nrows; r += NWAVES) {
-                    const int src = rowsrc[r];
-                    if (src >= 0) {
-                        const float* g = p.X + ((size_t)src + (size_t)c * p.XH) * p.XW;
-                        float* d = xdst + r * p.LW;
-                        for (int col = lane; col < p.XW; col += 64) d[col] = g[col];
+        // ---- stage input rows: a wave covers 64 >> rw_shift rows per load instruction (lanes along the row),
+        //      kUn such instructions are issued back to back before the first LDS store ----
+        {
+            constexpr int kUn = 4, kMaxC = 4;
+            const int RW = 1 << p.rw_shift, RPI = 64 >> p.rw_shift;
+            const int sub = lane >> p.rw_shift, col0 = lane & (RW - 1);
+            for (int ck = 0; ck < CK; ++ck) {
+                const int c = cc * CK + ck;
+                float* xdst = Xs + ck * p.chs + p.padL;
+                if (c < p.C) {
+                    const float* gch = p.X + (size_t)c * p.XH * p.XW;
+                    for (int cb = 0; cb < p.XW; cb += 64 * kMaxC) {
+                        for (int rb = wave * RPI; rb < nrows; rb += NWAVES * RPI * kUn) {
+                            float v[kUn][kMaxC];
+                            int src[kUn];
+#pragma unroll
+                            for (int u = 0; u < kUn; ++u) {
+                                const int r = rb + u * NWAVES * RPI + sub;
+                                src[u] = (r < nrows) ? rowsrc[r] : -1;
+                            }
+#pragma unroll
+                            for (int u = 0; u < kUn; ++u) {
+                                const float* g = gch + (size_t)(src[u] < 0 ? 0 : src[u]) * p.XW;
+#pragma unroll
+                                for (int ci = 0; ci < kMaxC; ++ci) {
+                                    const int col = cb + col0 + ci * 64;
+                                    if ((ci == 0 || RW == 64) && src[u] >= 0 && col < p.XW) v[u][ci] = g[col];
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < kUn; ++u) {
+                                const int r = rb + u * NWAVES * RPI + sub;
+                                float* d = xdst + r * p.LW;
+#pragma unroll
+                                for (int ci = 0; ci < kMaxC; ++ci) {
+                                    const int col = cb + col0 + ci * 64;
+                                    if ((ci == 0 || RW == 64) && src[u] >= 0 && col < p.XW) d[col] = v[u][ci];
+                                }
+                            }
+                        }
                     }
-                }
-            } else if (cc == p.nchunk - 1) {  // channel padding of the last chunk: must be finite
-                for (int r = wave; r < nrows; r += NWAVES) {
-                    float* d = xdst + r * p.LW;
-                    for (int col = lane; col < p.XW; col += 64) d[col] = 0.f;
+                } else if (cc == p.nchunk - 1) {  // channel padding of the last chunk: must be finite
+                    for (int r = wave; r < nrows; r += NWAVES) {
+                        float* d = xdst + r * p.LW;
+                        for (int col = lane; col < p.XW; col += 64) d[col] = 0.f;
+                    }
                 }
             }
         }
@@ -303,7 +343,7 @@ struct Plan {
     unsigned grid_x, grid_y;
 };
 
-enum { CFG_M128 = 0, CFG_M64, CFG_M32, CFG_M16_CK4, CFG_M16_CK16 };
+enum { CFG_M128 = 0, CFG_M128_S, CFG_M64, CFG_M64_S, CFG_M32, CFG_M32_S, CFG_M16_CK4, CFG_M16_CK16 };
 
 // taps of dy one parity class reads: offsets d in [e - J + 1, e], e = (ph+pad)/s, J = #taps kx = kx0 + s*j < k
 void dgrad_window(int k, int s, int pad, int* r0, int* TR) {
@@ -343,10 +383,22 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl) {
     CNN_REQUIRE((long long)p.B * p.C * p.XH < (1ll << 31), "%s: B*C*H exceeds int32 row index", who);
     CNN_REQUIRE(p.N / 16 < (1ll << 30), "%s: too many output pixels", who);
 
-    if (p.M > 64) { pl->cfg = CFG_M128; pl->MF = 32; pl->MT = 128; pl->NPIX = 128; pl->CK = 8; }
-    else if (p.M > 32) { pl->cfg = CFG_M64; pl->MF = 32; pl->MT = 64; pl->NPIX = 256; pl->CK = 8; }
-    else if (p.M > 16) { pl->cfg = CFG_M32; pl->MF = 32; pl->MT = 32; pl->NPIX = 512; pl->CK = 8; }
-    else if (p.C <= 4) { pl->cfg = CFG_M16_CK4; pl->MF = 16; pl->MT = 16; pl->NPIX = 256; pl->CK = 4; }
+    // tile choice: the widest pixel tile that still gives every CU a couple of workgroups
+    auto blocks_for = [&](int MT, int NPIX) { return ((p.N + NPIX - 1) / NPIX) * ((p.M + MT - 1) / MT); };
+    const long long kWantBlocks = 2 * kNumCU;
+    if (p.M > 64) {
+        pl->MF = 32; pl->MT = 128; pl->CK = 8;
+        if (blocks_for(128, 128) >= kWantBlocks) { pl->cfg = CFG_M128; pl->NPIX = 128; }
+        else { pl->cfg = CFG_M128_S; pl->NPIX = 64; }
+    } else if (p.M > 32) {
+        pl->MF = 32; pl->MT = 64; pl->CK = 8;
+        if (blocks_for(64, 256) >= kWantBlocks) { pl->cfg = CFG_M64; pl->NPIX = 256; }
+        else { pl->cfg = CFG_M64_S; pl->NPIX = 64; }
+    } else if (p.M > 16) {
+        pl->MF = 32; pl->MT = 32; pl->CK = 8;
+        if (blocks_for(32, 512) >= kWantBlocks) { pl->cfg = CFG_M32; pl->NPIX = 512; }
+        else { pl->cfg = CFG_M32_S; pl->NPIX = 128; }
+    } else if (p.C <= 4) { pl->cfg = CFG_M16_CK4; pl->MF = 16; pl->MT = 16; pl->NPIX = 256; pl->CK = 4; }
     else { pl->cfg = CFG_M16_CK16; pl->MF = 16; pl->MT = 16; pl->NPIX = 256; pl->CK = 16; }
 
     p.nchunk = (p.C + pl->CK - 1) / pl->CK;
@@ -370,6 +422,9 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl) {
     pl->lds_bytes = ((size_t)T * pl->CK * pl->MT + (size_t)pl->CK * p.chs) * sizeof(float) + (size_t)p.nrows_max * 4;
     CNN_REQUIRE(pl->lds_bytes <= 160 * 1024, "%s: tile needs %zu B of LDS (> 160 KiB): k=%d W=%d not supported", who,
                 pl->lds_bytes, d->k, d->W);
+    p.rw_shift = 0;
+    while ((1 << p.rw_shift) < p.XW && p.rw_shift < 6) ++p.rw_shift;
+    p.need_zero = (p.padL > 0 || padR > 0 || p.r0 < 0 || (p.U - 1) * p.su + p.r0 + p.TR - 1 > p.XH - 1) ? 1 : 0;
     p.ntiles = (int)((p.N + pl->NPIX - 1) / pl->NPIX);
     pl->grid_x = (unsigned)p.ntiles;
     pl->grid_y = (unsigned)((p.M + pl->MT - 1) / pl->MT);
@@ -412,8 +467,11 @@ int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w,
     pl.p.X = X; pl.p.A = (const float*)ws; pl.p.bias = bias; pl.p.Y = Y;
     switch (pl.cfg) {
         case CFG_M128: return launch_cfg<32, 4, 1, 1, 4, 8>(pl, s, d);
+        case CFG_M128_S: return launch_cfg<32, 2, 1, 2, 2, 8>(pl, s, d);
         case CFG_M64: return launch_cfg<32, 2, 2, 1, 4, 8>(pl, s, d);
+        case CFG_M64_S: return launch_cfg<32, 1, 1, 2, 2, 8>(pl, s, d);
         case CFG_M32: return launch_cfg<32, 1, 4, 1, 4, 8>(pl, s, d);
+        case CFG_M32_S: return launch_cfg<32, 1, 1, 1, 4, 8>(pl, s, d);
         case CFG_M16_CK4: return launch_cfg<16, 1, 4, 1, 4, 4>(pl, s, d);
         default: return launch_cfg<16, 1, 4, 1, 4, 16>(pl, s, d);
     }

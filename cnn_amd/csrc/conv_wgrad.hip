@@ -33,6 +33,7 @@ struct WgradParams {
     int Ntot;          // Ci*k*k
     long long chunks_total;
     int chunks_per_split;
+    int rwd_shift, rwx_shift;  // log2(lanes per staged dy / x row)
 };
 
 template <int MF>
@@ -109,27 +110,80 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void wgrad_kernel(const Wgrad
         const int Rv = (p.Ho - p0 < p.R) ? p.Ho - p0 : p.R;
         const int QCv = (p.Wo - q0 < p.QC) ? p.Wo - q0 : p.QC;
         __syncthreads();
-        // ---- stage dy tile: one wave per (channel,row), zero beyond the valid columns / rows / channels ----
-        for (int row = wave; row < MTB * p.R; row += NWAVES) {
-            const int col_ = row / p.R, r = row - col_ * p.R;
-            const int co = mblk * MTB + col_;
-            float* d = Ds + col_ * p.DROW + r * p.QCP;
-            const bool live = (co < p.Co) && (r < Rv);
-            const float* g = p.dy + (((size_t)b * p.Co + (live ? co : 0)) * p.Ho + p0 + (live ? r : 0)) * p.Wo + q0;
-            for (int c = lane; c < p.QCP; c += 64) d[c] = (live && c < QCv) ? g[c] : 0.f;
+        constexpr int kUn = 4, kMaxC = 4;
+        // ---- stage dy tile rows (zero beyond the valid columns / rows / channels); narrow rows share a wave-wide
+        //      load, kUn loads are in flight per lane before the first LDS store ----
+        {
+            const int RW = 1 << p.rwd_shift, RPI = 64 >> p.rwd_shift;
+            const int sub = lane >> p.rwd_shift, col0 = lane & (RW - 1);
+            const int total = MTB * p.R;
+            for (int cb = 0; cb < p.QCP; cb += 64 * kMaxC) {
+                for (int rb = wave * RPI; rb < total; rb += NWAVES * RPI * kUn) {
+                    float v[kUn][kMaxC];
+#pragma unroll
+                    for (int u = 0; u < kUn; ++u) {
+                        const int ridx = rb + u * NWAVES * RPI + sub;
+                        const int col_ = ridx / p.R, r = ridx - col_ * p.R;
+                        const int co = mblk * MTB + col_;
+                        const bool live = (ridx < total) && (co < p.Co) && (r < Rv);
+                        const float* g =
+                            p.dy + (((size_t)b * p.Co + (live ? co : 0)) * p.Ho + p0 + (live ? r : 0)) * p.Wo + q0;
+#pragma unroll
+                        for (int ci = 0; ci < kMaxC; ++ci) {
+                            const int c = cb + col0 + ci * 64;
+                            if (ci == 0 || RW == 64) v[u][ci] = (live && c < QCv) ? g[c] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kUn; ++u) {
+                        const int ridx = rb + u * NWAVES * RPI + sub;
+                        const int col_ = ridx / p.R, r = ridx - col_ * p.R;
+                        float* d = Ds + col_ * p.DROW + r * p.QCP;
+#pragma unroll
+                        for (int ci = 0; ci < kMaxC; ++ci) {
+                            const int c = cb + col0 + ci * 64;
+                            if ((ci == 0 || RW == 64) && ridx < total && c < p.QCP) d[c] = v[u][ci];
+                        }
+                    }
+                }
+            }
         }
         // ---- stage input rows (zero outside the image: padding and the k-step overreach) ----
-        for (int row = wave; row < p.CIB * p.XR; row += NWAVES) {
-            const int slot = row / p.XR, xr = row - slot * p.XR;
-            const int ci = ci_first + slot;
-            const int h = p0 * p.s + xr - p.pad;
-            const bool live = (ci < p.Ci) && (h >= 0) && (h < p.H);
-            const float* g = p.x + (((size_t)b * p.Ci + (live ? ci : 0)) * p.H + (live ? h : 0)) * p.W;
-            float* d = Xs + slot * p.CHS + xr * p.LWc;
+        {
+            const int RW = 1 << p.rwx_shift, RPI = 64 >> p.rwx_shift;
+            const int sub = lane >> p.rwx_shift, col0 = lane & (RW - 1);
+            const int total = p.CIB * p.XR;
             const int w0 = q0 * p.s - p.pad;
-            for (int c = lane; c < p.LWc; c += 64) {
-                const int w = w0 + c;
-                d[c] = (live && w >= 0 && w < p.W) ? g[w] : 0.f;
+            for (int cb = 0; cb < p.LWc; cb += 64 * kMaxC) {
+                for (int rb = wave * RPI; rb < total; rb += NWAVES * RPI * kUn) {
+                    float v[kUn][kMaxC];
+#pragma unroll
+                    for (int u = 0; u < kUn; ++u) {
+                        const int ridx = rb + u * NWAVES * RPI + sub;
+                        const int slot = ridx / p.XR, xr = ridx - slot * p.XR;
+                        const int ci_ = ci_first + slot;
+                        const int h = p0 * p.s + xr - p.pad;
+                        const bool live = (ridx < total) && (ci_ < p.Ci) && (h >= 0) && (h < p.H);
+                        const float* g = p.x + (((size_t)b * p.Ci + (live ? ci_ : 0)) * p.H + (live ? h : 0)) * p.W;
+#pragma unroll
+                        for (int ci = 0; ci < kMaxC; ++ci) {
+                            const int c = cb + col0 + ci * 64;
+                            const int w = w0 + c;
+                            if (ci == 0 || RW == 64) v[u][ci] = (live && w >= 0 && w < p.W) ? g[w] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kUn; ++u) {
+                        const int ridx = rb + u * NWAVES * RPI + sub;
+                        const int slot = ridx / p.XR, xr = ridx - slot * p.XR;
+                        float* d = Xs + slot * p.CHS + xr * p.LWc;
+#pragma unroll
+                        for (int ci = 0; ci < kMaxC; ++ci) {
+                            const int c = cb + col0 + ci * 64;
+                            if ((ci == 0 || RW == 64) && ridx < total && c < p.LWc) d[c] = v[u][ci];
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
@@ -169,14 +223,53 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void wgrad_kernel(const Wgrad
     }
 }
 
-// gw[i] = (sum_slots part[slot][i]) / divisor, slots added in ascending order
-__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ part, float* __restrict__ gw, int nslots,
-                                                    size_t n, float divisor) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float s = 0.f;
-        for (int t = 0; t < nslots; ++t) s += part[(size_t)t * n + i];
-        gw[i] = s / divisor;
+// Deterministic slab reduction: out[g][i] = sum over slots of group g of in[slot][i] (optionally / divisor).
+// A workgroup owns 32 consecutive elements; its 8 slot-lanes walk the group's slots with independent loads and
+// are then combined through LDS in a fixed order, so the result does not depend on scheduling.
+constexpr int kRedElems = 32, kRedLanes = 8;
+__global__ __launch_bounds__(kRedElems * kRedLanes) void slab_reduce(const float* __restrict__ in,
+                                                                     float* __restrict__ out, int nslots, size_t n,
+                                                                     int per_group, float divisor, int final_stage) {
+    __shared__ float red[kRedLanes][kRedElems];
+    const int e = threadIdx.x & (kRedElems - 1), sl = threadIdx.x / kRedElems;
+    const size_t i = (size_t)blockIdx.x * kRedElems + e;
+    const int g = blockIdx.y;
+    const int s_begin = g * per_group;
+    const int s_end = (s_begin + per_group < nslots) ? s_begin + per_group : nslots;
+    float acc = 0.f;
+    if (i < n) {
+        int s = s_begin + sl;
+        for (; s + 3 * kRedLanes < s_end; s += 4 * kRedLanes) {
+            const float v0 = in[(size_t)s * n + i], v1 = in[(size_t)(s + kRedLanes) * n + i];
+            const float v2 = in[(size_t)(s + 2 * kRedLanes) * n + i], v3 = in[(size_t)(s + 3 * kRedLanes) * n + i];
+            acc += v0; acc += v1; acc += v2; acc += v3;
+        }
+        for (; s < s_end; s += kRedLanes) acc += in[(size_t)s * n + i];
     }
+    red[sl][e] = acc;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < kRedLanes; ++k) t += red[k][e];
+        out[(size_t)g * n + i] = final_stage ? t / divisor : t;
+    }
+}
+
+// sums `nslots` slabs of n floats held in `slabs` into dst (divided by divisor); `tmp` holds >= ceil(nslots/64)*n
+int reduce_slabs(hipStream_t s, const float* slabs, int nslots, size_t n, float* tmp, float* dst, float divisor,
+                 const char* tag) {
+    const unsigned gx = (unsigned)((n + kRedElems - 1) / kRedElems);
+    if (nslots > 64) {
+        const int per = 64, groups = (nslots + per - 1) / per;
+        CNN_KLAUNCH(s, "slab_reduce/stage1",
+                    (slab_reduce<<<dim3(gx, groups), kRedElems * kRedLanes, 0, s>>>(slabs, tmp, nslots, n, per, 1.f, 0)), "%s", tag);
+        slabs = tmp;
+        nslots = groups;
+    }
+    CNN_KLAUNCH(s, "slab_reduce/final",
+                (slab_reduce<<<dim3(gx, 1), kRedElems * kRedLanes, 0, s>>>(slabs, dst, nslots, n, nslots, divisor, 1)), "%s", tag);
+    return CNN_AMD_OK;
 }
 
 // bias gradient stage 1: partial[g][co] = sum over this group's samples of sum_pq dy[b][co][pq]
@@ -203,15 +296,6 @@ __global__ __launch_bounds__(kBiasBlock) void bias_grad_partial(const float* __r
         partial[(size_t)g * Co + co] = t;
     }
 }
-__global__ void bias_grad_final(const float* __restrict__ partial, float* __restrict__ gb, int Co, int groups,
-                                float divisor) {
-    const int co = blockIdx.x * blockDim.x + threadIdx.x;
-    if (co >= Co) return;
-    float s = 0.f;
-    for (int g = 0; g < groups; ++g) s += partial[(size_t)g * Co + co];
-    gb[co] = s / divisor;
-}
-
 // ---- host planning -----------------------------------------------------------------------------------------
 enum { W_128x288 = 0, W_64x320, W_32x160, W_16x32 };
 
@@ -222,7 +306,7 @@ struct WPlan {
     int nsplit, nslots;
     unsigned gy, gz;
     int bias_groups;
-    size_t part_floats, bias_floats;
+    size_t part_floats, bias_floats, tmp_floats;
 };
 
 constexpr size_t kLdsBudget = 78 * 1024;  // two workgroups per CU: the second one computes while this one stages
@@ -270,6 +354,10 @@ int make_wplan(const char* who, const cnn_conv2d_desc* d, WPlan* pl) {
     p.XR = (R - 1) * d->s + d->k; p.LWc = (p.QCP - 1) * d->s + d->k; p.CHS = p.XR * p.LWc + 1;
     pl->lds_bytes = ((size_t)pl->MTB * p.DROW + (size_t)p.CIB * p.CHS) * sizeof(float);
     CNN_REQUIRE(pl->lds_bytes <= 160 * 1024, "%s: LDS plan %zu B too large", who, pl->lds_bytes);
+    p.rwd_shift = 0;
+    while ((1 << p.rwd_shift) < p.QCP && p.rwd_shift < 6) ++p.rwd_shift;
+    p.rwx_shift = 0;
+    while ((1 << p.rwx_shift) < p.LWc && p.rwx_shift < 6) ++p.rwx_shift;
     p.chunks_total = (long long)p.B * p.nrc * p.ncc;
     pl->gy = (unsigned)((p.Ntot + pl->NTB - 1) / pl->NTB);
     pl->gz = (unsigned)((p.Co + pl->MTB - 1) / pl->MTB);
@@ -285,6 +373,7 @@ int make_wplan(const char* who, const cnn_conv2d_desc* d, WPlan* pl) {
     pl->part_floats = (size_t)pl->nslots * p.Co * p.Ntot;
     pl->bias_groups = p.B < 64 ? p.B : 64;
     pl->bias_floats = (size_t)pl->bias_groups * p.Co;
+    pl->tmp_floats = (size_t)((pl->nslots + 63) / 64) * p.Co * p.Ntot;
     return CNN_AMD_OK;
 }
 
@@ -322,7 +411,7 @@ size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d) {
     if (check_desc("cnn_conv2d_workspace_bytes", d)) return 0;
     WPlan pl;
     size_t wg = 0;
-    if (make_wplan("cnn_conv2d_workspace_bytes", d, &pl) == CNN_AMD_OK) wg = pl.part_floats + pl.bias_floats;
+    if (make_wplan("cnn_conv2d_workspace_bytes", d, &pl) == CNN_AMD_OK) wg = pl.part_floats + pl.bias_floats + pl.tmp_floats;
     const size_t ig = igemm_workspace_floats(d);
     return ((wg > ig ? wg : ig) + 64) * sizeof(float);
 }
@@ -335,7 +424,7 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
     WPlan pl;
     if (int rc = make_wplan("cnn_conv2d_backward_weight", d, &pl)) return rc;
     CNN_REQUIRE(ws != nullptr, "cnn_conv2d_backward_weight: workspace is null");
-    const size_t need = (pl.part_floats + pl.bias_floats) * sizeof(float);
+    const size_t need = (pl.part_floats + pl.bias_floats + pl.tmp_floats) * sizeof(float);
     if (ws_bytes < need)
         return fail(CNN_AMD_E_WORKSPACE, "cnn_conv2d_backward_weight: workspace %zu B < %zu B", ws_bytes, need);
     hipStream_t s = as_stream(stream);
@@ -349,17 +438,17 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
     }
     if (rc) return rc;
     const size_t n = (size_t)pl.p.Co * pl.p.Ntot;
-    unsigned rg = (unsigned)((n + 255) / 256);
-    if (rg > 2048) rg = 2048;
-    CNN_KLAUNCH(s, "wgrad_reduce", (wgrad_reduce<<<rg, 256, 0, s>>>((const float*)ws, gw, pl.nslots, n, divisor)), CONV_TAG(d));
+    char tag[160];
+    snprintf(tag, sizeof(tag), CONV_TAG(d));
+    float* bpart = (float*)ws + pl.part_floats;
+    float* tmp = bpart + pl.bias_floats;
+    if (int rc2 = reduce_slabs(s, (const float*)ws, pl.nslots, n, tmp, gw, divisor, tag)) return rc2;
     if (gb) {
-        float* bpart = (float*)ws + pl.part_floats;
         CNN_KLAUNCH(s, "bias_grad_partial",
                     (bias_grad_partial<<<dim3(pl.p.Co, pl.bias_groups), kBiasBlock, 0, s>>>(dy, bpart, pl.p.B, pl.p.Co,
                                                                                            pl.p.Ho * pl.p.Wo, pl.bias_groups)),
                     CONV_TAG(d));
-        CNN_KLAUNCH(s, "bias_grad_final",
-                    (bias_grad_final<<<(pl.p.Co + 63) / 64, 64, 0, s>>>(bpart, gb, pl.p.Co, pl.bias_groups, divisor)), CONV_TAG(d));
+        if (int rc2 = reduce_slabs(s, bpart, pl.bias_groups, (size_t)pl.p.Co, tmp, gb, divisor, tag)) return rc2;
     }
     return CNN_AMD_OK;
 }

@@ -52,47 +52,54 @@ __global__ __launch_bounds__(kBlock) void linear_fwd(const float* __restrict__ x
     }
 }
 
-// gW[i][j] = (sum_b x[b][i]*dy[b][j]) / divisor.  One thread per input neuron i (coalesced over i for every b),
-// dy rows broadcast from LDS in tiles of samples.
-constexpr int kBTile = 64;
+// gW[i][j] = (sum_b x[b][i]*dy[b][j]) / divisor.  A workgroup owns 64 input neurons; its 4 waves each take a
+// quarter of the samples (coalesced x rows, dy broadcast through the scalar cache) and are combined in fixed order.
+constexpr int kNeur = 64, kBGroups = kBlock / kNeur;
 __global__ __launch_bounds__(kBlock) void linear_bwd_w(const float* __restrict__ x, const float* __restrict__ dy,
                                                        float* __restrict__ gw, int B, int in, int out,
                                                        float divisor) {
-    __shared__ float dtile[kBTile * kOutTile];
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ float red[kBGroups][kOutTile][kNeur];
+    const int il = threadIdx.x & (kNeur - 1), grp = threadIdx.x / kNeur;
+    const int i = blockIdx.x * kNeur + il;
+    const int per = (B + kBGroups - 1) / kBGroups;
+    const int bb = grp * per, be = min(B, bb + per);
     for (int j0 = 0; j0 < out; j0 += kOutTile) {
         const int nj = min(kOutTile, out - j0);
         float acc[kOutTile];
 #pragma unroll
         for (int j = 0; j < kOutTile; ++j) acc[j] = 0.f;
-        for (int b0 = 0; b0 < B; b0 += kBTile) {
-            const int nb = min(kBTile, B - b0);
-            __syncthreads();
-            for (int t = threadIdx.x; t < nb * kOutTile; t += kBlock) {
-                const int bb = t / kOutTile, j = t % kOutTile;
-                dtile[t] = (j < nj) ? dy[(size_t)(b0 + bb) * out + j0 + j] : 0.f;
-            }
-            __syncthreads();
-            if (i < in) {
-                for (int bb = 0; bb < nb; ++bb) {
-                    const float xv = x[(size_t)(b0 + bb) * in + i];
+        if (i < in) {
+#pragma unroll 4
+            for (int b = bb; b < be; ++b) {
+                const float xv = x[(size_t)b * in + i];
+                const float* d = dy + (size_t)b * out + j0;
 #pragma unroll
-                    for (int j = 0; j < kOutTile; ++j) acc[j] += xv * dtile[bb * kOutTile + j];
-                }
+                for (int j = 0; j < kOutTile; ++j)
+                    if (j < nj) acc[j] += xv * d[j];
             }
         }
-        if (i < in)
-            for (int j = 0; j < nj; ++j) gw[(size_t)i * out + j0 + j] = acc[j] / divisor;
+#pragma unroll
+        for (int j = 0; j < kOutTile; ++j) red[grp][j][il] = acc[j];
+        __syncthreads();
+        if (grp == 0 && i < in)
+            for (int j = 0; j < nj; ++j) {
+                float t = 0.f;
+#pragma unroll
+                for (int g2 = 0; g2 < kBGroups; ++g2) t += red[g2][j][il];
+                gw[(size_t)i * out + j0 + j] = t / divisor;
+            }
+        __syncthreads();
     }
 }
 
-// gb[j] = (sum_b dy[b][j]) / divisor: sequential over b like linear.cpp:66-71 (B*out is tiny)
-__global__ void linear_bwd_b(const float* __restrict__ dy, float* __restrict__ gb, int B, int out, float divisor) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= out) return;
+// gb[j] = (sum_b dy[b][j]) / divisor: one wave per output, lanes over samples, fixed shuffle tree
+__global__ __launch_bounds__(64) void linear_bwd_b(const float* __restrict__ dy, float* __restrict__ gb, int B, int out,
+                                                   float divisor) {
+    const int j = blockIdx.x;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dy[(size_t)b * out + j];
-    gb[j] = s / divisor;
+    for (int b = threadIdx.x; b < B; b += 64) s += dy[(size_t)b * out + j];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) gb[j] = s / divisor;
 }
 
 // dx[b][i] = sum_j dy[b][j]*W[i][j]
@@ -129,11 +136,11 @@ int cnn_linear_backward(const float* x, const float* dy, const float* w, float* 
     hipStream_t s = as_stream(stream);
     if (gw) {
         CNN_REQUIRE(x != nullptr, "cnn_linear_backward: x is null");
-        CNN_KLAUNCH(s, "linear_bwd_w", (linear_bwd_w<<<ceil_div(in, kBlock), kBlock, 0, s>>>(x, dy, gw, B, in, out, divisor)),
+        CNN_KLAUNCH(s, "linear_bwd_w", (linear_bwd_w<<<ceil_div(in, kNeur), kBlock, 0, s>>>(x, dy, gw, B, in, out, divisor)),
                     "B%d in%d out%d", B, in, out);
     }
     if (gb) {
-        CNN_KLAUNCH(s, "linear_bwd_b", (linear_bwd_b<<<ceil_div(out, 64), 64, 0, s>>>(dy, gb, B, out, divisor)), "B%d out%d", B,
+        CNN_KLAUNCH(s, "linear_bwd_b", (linear_bwd_b<<<out, 64, 0, s>>>(dy, gb, B, out, divisor)), "B%d out%d", B,
                     out);
     }
     if (dx) {

@@ -199,6 +199,13 @@ def test_softmax_xent_vs_oracle(T):
     probs, delta, loss = capi.softmax_xent(dev(T, logits), dev(T, labels))
     assert np.allclose(host(probs), p_ref, rtol=1e-5, atol=1e-7)
     assert np.allclose(host(delta), d_ref, rtol=1e-5, atol=1e-6)
+    # sample 0 has p == 0 for a non-label class: the reference's log(p)*y gives -inf*0 = NaN (func.cpp:65) -- kept
+    assert np.isnan(loss_ref) and np.isnan(float(host(loss)[0]))
+    logits[0] = [1, 2, 3]
+    p_ref = O.softmax(logits)
+    loss_ref, d_ref = O.cross_entropy_backward(p_ref, labels)
+    probs, delta, loss = capi.softmax_xent(dev(T, logits), dev(T, labels))
+    assert np.allclose(host(delta), d_ref, rtol=1e-5, atol=1e-6)
     assert np.isclose(float(host(loss)[0]) / B, loss_ref, rtol=1e-5)
 
 
