@@ -37,7 +37,7 @@ def algorithmic_work(key):
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         flops = 2.0 * B * Co * Ho * Wo * Ci * k * k
         x_b, y_b, w_b = 4.0 * B * Ci * H * W, 4.0 * B * Co * Ho * Wo, 4.0 * Co * Ci * k * k
-        if kernel.startswith("igemm_kernel") or kernel.startswith("wgrad_kernel"):
+        if kernel.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel")):
             return x_b + y_b + w_b, flops  # fwd: x,w -> y ; dgrad: dy,w -> dx ; wgrad: x,dy -> gw
         if kernel.startswith("bias_grad_partial"):
             return y_b, B * Co * Ho * Wo
@@ -128,7 +128,7 @@ def conv_ns_bench(torch, capi, reps=5):
     out = {"shape": "B256 64->128 k3 s1 112x112->110x110", "gflop": round(flops / 1e9, 2), "peak_tflops": PEAK_MFMA_F32_TFLOPS}
     for key, (cnt, ms) in rep.items():
         name = key.split("|")[0]
-        if name.startswith("igemm_kernel") or name.startswith("wgrad_kernel"):
+        if name.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel")):
             tf = flops / (ms / 1e3 / cnt) / 1e12
             tag = "fwd" if name.endswith("/fwd") else ("dgrad" if name.endswith("/dgrad") else "wgrad")
             out[tag] = {"kernel": name, "avg_ms": round(ms / cnt, 4), "tflops": round(tf, 2),

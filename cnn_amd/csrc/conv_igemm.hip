@@ -21,6 +21,8 @@
 //   * MFMA B operands are ds_read_b32 gathers from the row image (im2col never exists in memory), A operands are
 //     conflict-free ds_read_b32 of the slab.
 // Roofline: MFMA-bound for the 64->128 112x112 shape (190 FLOP/B); HBM-bound for Ci = 3.
+#include <cstdlib>
+
 #include "common.h"
 
 using namespace cnn_amd;
@@ -50,6 +52,8 @@ struct IgemmParams {
     int ntiles;         // number of pixel tiles (grid.x)
     int rw_shift;       // log2(lanes per staged row): narrow rows share one wave-wide load
     int need_zero;      // the row image has pad columns / out-of-image rows -> zero it once
+    int run_mode;       // DMA kernel: rows of a channel are one contiguous 16-byte-aligned run
+    int dbg;            // ablation bits (CNN_AMD_DBG, tuning only): 1 no X DMA, 2 no A DMA, 4 no MFMA, 8 no stores
 };
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
@@ -78,6 +82,126 @@ struct Acc<16> {
     // C/D layout: col = lane & 15, row = 4*(lane >> 4) + reg
     __device__ static __forceinline__ int row(int reg, int lh) { return 4 * lh + reg; }
 };
+
+
+// ---- pieces shared by the single-buffered and the DMA double-buffered kernels ---------------------------------
+
+// Accumulators start at the bias (forward) or 0: the epilogue is then a pure store (no loads on the store path).
+template <int MF, int MA, int NB>
+__device__ __forceinline__ void init_acc(typename Acc<MF>::type (&acc)[MA][NB], const IgemmParams& p, int mbase_wave,
+                                         int lh) {
+    using A_ = Acc<MF>;
+#pragma unroll
+    for (int ma = 0; ma < MA; ++ma) {
+        float bv[A_::kRegs];
+#pragma unroll
+        for (int r = 0; r < A_::kRegs; ++r) {
+            const int m = mbase_wave + ma * MF + A_::row(r, lh);
+            bv[r] = (p.bias != nullptr && m < p.M) ? p.bias[m] : 0.f;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < A_::kRegs; ++r) acc[ma][nb][r] = bv[r];
+    }
+}
+
+// One chunk of CK channels: for every tap, CK/KSTEP MFMA k-steps.  Software pipelined by one k-step: the LDS reads of
+// step s+1 are issued before the MFMAs of step s, so the matrix pipe never waits on ds_read latency.
+// A operands walk the slab linearly ([tap][ck][MT] is contiguous: +KSTEP*MT floats per step); B operands are gathers
+// from the row image at pix_off + tap offset + channel offset.
+template <int MF, int MA, int NB, int CK, int MT>
+__device__ __forceinline__ void compute_chunk(const float* __restrict__ As, const float* __restrict__ Xs,
+                                              const int (&pix_off)[NB], int a_lane,
+                                              typename Acc<MF>::type (&acc)[MA][NB], const IgemmParams& p) {
+    using A_ = Acc<MF>;
+    constexpr int KSTEP = A_::kStep, S = CK / KSTEP;
+    const float* a_ptr = As + a_lane;
+    float a_cur[MA], b_cur[NB];
+#pragma unroll
+    for (int ma = 0; ma < MA; ++ma) a_cur[ma] = a_ptr[ma * MF];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) b_cur[nb] = Xs[pix_off[nb]];
+    const int T = p.TR * p.TC;
+    int tr = 0, tc = 0;
+    for (int t = 0; t < T; ++t) {
+        const int tap_off = tr * p.LW + tc;
+        int ntc = tc + 1, ntr = tr;
+        if (ntc == p.TC) { ntc = 0; ++ntr; }
+        const int tap_next = (t + 1 < T) ? ntr * p.LW + ntc : 0;  // after the last tap: a harmless re-read
+#pragma unroll
+        for (int c2 = 0; c2 < S; ++c2) {
+            float a_nxt[MA], b_nxt[NB];
+            a_ptr += KSTEP * MT;  // (one step past the slab on the very last step: still inside this LDS buffer)
+            const int boff = (c2 + 1 < S) ? tap_off + (c2 + 1) * KSTEP * p.chs : tap_next;
+#pragma unroll
+            for (int ma = 0; ma < MA; ++ma) a_nxt[ma] = a_ptr[ma * MF];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) b_nxt[nb] = Xs[pix_off[nb] + boff];
+            // keep the reads of step s+1 ABOVE the MFMAs of step s (hipcc otherwise sinks them next to their use and
+            // every MFMA pair waits a full LDS round trip)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[ma][nb] = A_::mfma(a_cur[ma], b_cur[nb], acc[ma][nb]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ma = 0; ma < MA; ++ma) a_cur[ma] = a_nxt[ma];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) b_cur[nb] = b_nxt[nb];
+        }
+        tr = ntr;
+        tc = ntc;
+    }
+}
+
+// Epilogue.  forward: y[b][m][pixel] (each (reg, half-wave) writes 32 / 16 consecutive pixels of one channel);
+// dgrad: virtual channel m = (ph*s+pw)*Ci + ci of grid pixel (u,v) -> dx[b][ci][u*s+ph][v*s+pw].
+template <int MF, int MA, int NB>
+__device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[MA][NB], const IgemmParams& p,
+                                           long long n_first, long long n1, int mbase_wave, int li, int lh) {
+    using A_ = Acc<MF>;
+    const long long UV = (long long)p.U * p.V;
+    const bool full_m = (mbase_wave + MA * MF <= p.M);  // wave-uniform: no per-row bounds checks in the common case
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const long long n = n_first + nb * MF + li;
+        if (n > n1) continue;
+        const int b = (int)(n / UV);
+        const int rem = (int)(n - b * UV);
+        if (p.mode == MODE_FWD) {
+            float* out = p.Y + ((size_t)b * p.M + mbase_wave) * UV + rem;
+#pragma unroll
+            for (int ma = 0; ma < MA; ++ma) {
+#pragma unroll
+                for (int g = 0; g < A_::kRegs / 4; ++g) {
+                    const int row0 = ma * MF + A_::row(4 * g, lh);  // rows row0 .. row0+3 are regs 4g .. 4g+3
+                    float* o = out + (size_t)row0 * UV;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (full_m || mbase_wave + row0 + j < p.M) o[(size_t)j * UV] = acc[ma][nb][4 * g + j];
+                }
+            }
+        } else {
+            const int u = rem / p.V, v = rem - u * p.V;
+#pragma unroll
+            for (int ma = 0; ma < MA; ++ma) {
+#pragma unroll
+                for (int r = 0; r < A_::kRegs; ++r) {
+                    const int m = mbase_wave + ma * MF + A_::row(r, lh);
+                    if (full_m || m < p.M) {
+                        const int cls = m / p.c_out, ci = m - cls * p.c_out;
+                        const int ph = cls / p.s_out;
+                        const int h = u * p.s_out + ph, w = v * p.s_out + (cls - ph * p.s_out);
+                        if (h < p.OH && w < p.OW)
+                            p.Y[(((size_t)b * p.c_out + ci) * p.OH + h) * p.OW + w] = acc[ma][nb][r];
+                    }
+                }
+            }
+        }
+    }
+}
 
 // MF: MFMA tile edge; MA x NB tiles per wave; WM x WN waves per workgroup; CK channels per LDS chunk.
 template <int MF, int MA, int NB, int WM, int WN, int CK>
@@ -125,9 +249,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
     const int full = (p.U - 1) * p.su + p.TR;
     const int nrows = (nseg == 1) ? nrows0 : nrows0 + (nseg - 2) * full + u1 * p.su + p.TR;
 
-    // ---- one-time LDS setup: zero the row image (pad columns / out-of-image rows stay 0 for every chunk) ----
-    if (p.need_zero)
-        for (int i = tid; i < CK * p.chs; i += NT) Xs[i] = 0.f;
+    // ---- one-time LDS setup: the row table, then zero ONLY what staging never writes (pad columns and rows
+    //      outside the image); those stay 0 for every chunk because the row -> image mapping is chunk-invariant ----
     for (int r = tid; r < nrows; r += NT) {
         int b, xrow;
         if (r < nrows0) {
@@ -139,6 +262,21 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
             xrow = p.r0 + rr % full;
         }
         rowsrc[r] = (xrow >= 0 && xrow < p.XH) ? (b * p.C * p.XH + xrow) : -1;
+    }
+    if (p.need_zero) {
+        __syncthreads();
+        const int npad = p.LW - p.XW;
+        for (int ck = 0; ck < CK; ++ck) {
+            float* xch = Xs + ck * p.chs;
+            for (int r = wave; r < nrows; r += NWAVES) {
+                float* d = xch + r * p.LW;
+                if (rowsrc[r] < 0) {
+                    for (int col = lane; col < p.LW; col += 64) d[col] = 0.f;
+                } else {
+                    for (int j = lane; j < npad; j += 64) d[j < p.padL ? j : j + p.XW] = 0.f;
+                }
+            }
+        }
     }
 
     // ---- per-lane pixel -> LDS offset of its window origin (B operand column = this lane's pixel) ----
@@ -156,12 +294,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
     const int a_lane = lh * MT + wm * MA * MF + li;
 
     typename A_::type acc[MA][NB];
-#pragma unroll
-    for (int ma = 0; ma < MA; ++ma)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int r = 0; r < A_::kRegs; ++r) acc[ma][nb][r] = 0.f;
+    const int mbase_wave = mb * MT + wm * MA * MF;
+    init_acc<MF, MA, NB>(acc, p, mbase_wave, lh);
 
     const float4* Ag = (const float4*)(p.A + (size_t)mb * p.nchunk * T * CK * MT);
     const int a_vec = T * CK * MT / 4;
@@ -232,63 +366,242 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
             }
         }
         __syncthreads();
-        // ---- MFMA over taps x channel steps ----
-        for (int tr = 0; tr < p.TR; ++tr) {
-            for (int tc = 0; tc < p.TC; ++tc) {
-                const int tap_off = tr * p.LW + tc;
-                const float* a_tap = As + (tr * p.TC + tc) * CK * MT + a_lane;
-#pragma unroll
-                for (int c2 = 0; c2 < CK / KSTEP; ++c2) {
-                    float a[MA], b[NB];
-#pragma unroll
-                    for (int ma = 0; ma < MA; ++ma) a[ma] = a_tap[c2 * KSTEP * MT + ma * MF];
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) b[nb] = Xs[pix_off[nb] + tap_off + c2 * KSTEP * p.chs];
-#pragma unroll
-                    for (int ma = 0; ma < MA; ++ma)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) acc[ma][nb] = A_::mfma(a[ma], b[nb], acc[ma][nb]);
-                }
-            }
-        }
+        compute_chunk<MF, MA, NB, CK, MT>(As, Xs, pix_off, a_lane, acc, p);
     }
 
-    // ---- epilogue ----
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const long long n = n0 + (wn * NB + nb) * MF + li;
-        if (n > n1) continue;
-        const int b = (int)(n / UV);
-        const int rem = (int)(n - b * UV);
-        if (p.mode == MODE_FWD) {
-            float* out = p.Y + (size_t)b * p.M * UV + rem;
-#pragma unroll
-            for (int ma = 0; ma < MA; ++ma) {
-                const int mbase = mb * MT + (wm * MA + ma) * MF;
-#pragma unroll
-                for (int r = 0; r < A_::kRegs; ++r) {
-                    const int m = mbase + A_::row(r, lh);
-                    if (m < p.M) out[(size_t)m * UV] = acc[ma][nb][r] + (p.bias ? p.bias[m] : 0.f);
-                }
-            }
+    store_tile<MF, MA, NB>(acc, p, n0 + (long long)wn * NB * MF, n1, mbase_wave, li, lh);
+}
+
+// ---- double-buffered variant: HBM -> LDS by DMA (global_load_lds), one barrier per chunk -------------------------
+// Same math and row image as igemm_kernel, specialised for the MFMA-bound shapes (32x32x2 tiles, 8 channels per
+// chunk):
+//   * chunk c+1's row image and filter slab are written straight into the second LDS buffer by
+//     global_load_lds_dword / _dwordx4 (no VGPR round trip; EXEC-masked lanes do not write -- probed on MI355X,
+//     tools/probes/glds_probe.cpp) while the MFMAs consume chunk c; __syncthreads() drains the DMA queue (vmcnt(0))
+//     exactly where the next chunk is needed;
+//   * when the image needs no padding and rows are 16-byte multiples, the rows of one channel form ONE contiguous run
+//     in HBM and in LDS and are moved 1 KiB per wave-instruction;
+//   * the filter slab is stored [tap][k-half][m][4 k-steps] ("A4"), so a lane fetches its A operands for a whole tap
+//     (4 MFMA k-steps) with one conflict-free ds_read_b128; operands of tap t+1 are read before the 4*MA*NB MFMAs of
+//     tap t are issued.
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+
+template <int MA, int NB, int WM, int WN, int S>  // S = k-steps per tap = channels per chunk / 2
+__global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmParams p) {
+    constexpr int MF = 32, CK = 2 * S;
+    typedef float avec_t __attribute__((ext_vector_type(S)));
+    using A_ = Acc<MF>;
+    constexpr int NWAVES = WM * WN;
+    constexpr int NT = 64 * NWAVES;
+    constexpr int MT = MF * MA * WM;
+    constexpr int NPIX = MF * NB * WN;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = p.TR * p.TC;
+    const int a_floats = T * CK * MT;
+    const int buf_floats = a_floats + CK * p.chs;  // one {slab, row image} pair; chs % 4 == 0
+    int* rowsrc = (int*)(smem + 2 * (size_t)buf_floats);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & (MF - 1), lh = lane / MF;
+
+    int tile;
+    {
+        const int nt = p.ntiles, id = blockIdx.x;
+        const int q = nt / kNumXCD, r = nt % kNumXCD, xcd = id % kNumXCD, k = id / kNumXCD;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int mb = blockIdx.y;
+    // all pixel indices fit int32 here (the host only picks this kernel when N < 2^31)
+    const int UV = p.U * p.V;
+    const int n0 = tile * NPIX;
+    const int n1 = (n0 + NPIX <= (int)p.N ? n0 + NPIX : (int)p.N) - 1;
+    const int b0 = n0 / UV;
+    const int u0 = (n0 - b0 * UV) / p.V;
+    const int b1 = n1 / UV;
+    const int u1 = (n1 - b1 * UV) / p.V;
+    const int nseg = b1 - b0 + 1;
+    const int nrows0 = ((nseg == 1 ? u1 : p.U - 1) - u0) * p.su + p.TR;
+    const int full = (p.U - 1) * p.su + p.TR;
+    const int nrows = (nseg == 1) ? nrows0 : nrows0 + (nseg - 2) * full + u1 * p.su + p.TR;
+
+    for (int r = tid; r < nrows; r += NT) {
+        int b, xrow;
+        if (r < nrows0) {
+            b = b0;
+            xrow = u0 * p.su + p.r0 + r;
         } else {
-            const int u = rem / p.V, v = rem - u * p.V;
-#pragma unroll
-            for (int ma = 0; ma < MA; ++ma) {
-                const int mbase = mb * MT + (wm * MA + ma) * MF;
-#pragma unroll
-                for (int r = 0; r < A_::kRegs; ++r) {
-                    const int m = mbase + A_::row(r, lh);
-                    if (m < p.M) {
-                        const int cls = m / p.c_out, ci = m - cls * p.c_out;
-                        const int h = u * p.s_out + cls / p.s_out, w = v * p.s_out + cls % p.s_out;
-                        if (h < p.OH && w < p.OW)
-                            p.Y[(((size_t)b * p.c_out + ci) * p.OH + h) * p.OW + w] = acc[ma][nb][r];
+            const int rr = r - nrows0;
+            b = b0 + 1 + rr / full;
+            xrow = p.r0 + rr % full;
+        }
+        rowsrc[r] = (xrow >= 0 && xrow < p.XH) ? (b * p.C * p.XH + xrow) : -1;
+    }
+    __syncthreads();
+    if (p.need_zero) {  // pad columns and out-of-image rows of BOTH buffers: never touched by the DMA
+        const int npad = p.LW - p.XW;
+        for (int bi = 0; bi < 2; ++bi)
+            for (int ck = 0; ck < CK; ++ck) {
+                float* xch = smem + bi * buf_floats + a_floats + ck * p.chs;
+                for (int r = wave; r < nrows; r += NWAVES) {
+                    float* d = xch + r * p.LW;
+                    if (rowsrc[r] < 0) {
+                        for (int col = lane; col < p.LW; col += 64) d[col] = 0.f;
+                    } else {
+                        for (int j = lane; j < npad; j += 64) d[j < p.padL ? j : j + p.XW] = 0.f;
                     }
                 }
             }
+    }
+
+    int pix_off[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        int n = n0 + (wn * NB + nb) * MF + li;
+        if (n > n1) n = n1;
+        const int b = n / UV;
+        const int rem = n - b * UV;
+        const int u = rem / p.V, v = rem - u * p.V;
+        const int lrow = (b == b0) ? (u - u0) * p.su : nrows0 + (b - b0 - 1) * full + u * p.su;
+        pix_off[nb] = lrow * p.LW + v * p.su + p.c0 + p.padL + lh * p.chs;
+    }
+    const int a_lane = (lh * MT + wm * MA * MF + li) * S;  // slab layout: [tap][lh][m][S k-steps]
+
+    typename A_::type acc[MA][NB];
+    const int mbase_wave = mb * MT + wm * MA * MF;
+    init_acc<MF, MA, NB>(acc, p, mbase_wave, lh);
+
+    const float* Ag = p.A + (size_t)mb * p.nchunk * a_floats;
+    const int a_vec = a_floats / 4;
+
+    // ---- DMA of one chunk into buffer bi, issued as one burst right after the barrier (measured: spreading the issue
+    //      over the taps costs more in decode math than it hides) ----
+    auto issue_dma = [&](int cc, int bi) {
+        float* Abuf = smem + bi * buf_floats;
+        float* Xbuf = Abuf + a_floats;
+        const float* asrc = Ag + (size_t)cc * a_floats;
+        if (!(p.dbg & 2)) {
+#pragma nounroll
+            for (int i = wave; i * 64 < a_vec; i += NWAVES) {
+                const int idx = i * 64 + lane;
+                if (idx < a_vec)
+                    __builtin_amdgcn_global_load_lds((gbl_void_ptr)(asrc + (size_t)idx * 4), (lds_void_ptr)(Abuf + i * 256), 16, 0, 0);
+            }
+        }
+        if (p.dbg & 1) return;
+        if (p.run_mode) {
+            // every channel's rows of one image segment are one contiguous run (HBM and LDS): 1 KiB per instruction
+            int lrow0 = 0;
+#pragma nounroll
+            for (int sg = 0; sg < nseg; ++sg) {
+                const int nr = (sg == 0) ? nrows0 : ((sg == nseg - 1) ? u1 * p.su + p.TR : full);
+                const int xrow0 = (sg == 0) ? u0 * p.su + p.r0 : p.r0;
+                const int run4 = nr * p.XW / 4;       // float4s per channel run
+                const int per_ch = (run4 + 63) / 64;  // wave-instructions per channel
+                const size_t gbase = ((size_t)(b0 + sg) * p.C * p.XH + xrow0) * p.XW;
+#pragma nounroll
+                for (int j = wave; j < CK * per_ch; j += NWAVES) {
+                    const int ck = j / per_ch, part = j - ck * per_ch;
+                    const int c = cc * CK + ck;
+                    const int idx = part * 64 + lane;
+                    float* d = Xbuf + ck * p.chs + lrow0 * p.LW + part * 256;
+                    if (c < p.C) {
+                        const float* g = p.X + gbase + (size_t)c * p.XH * p.XW;
+                        if (idx < run4)
+                            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(g + (size_t)idx * 4), (lds_void_ptr)d, 16, 0, 0);
+                    } else if (idx < run4) {
+                        *(float4*)(d + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+                lrow0 += nr;
+            }
+            return;
+        }
+#pragma nounroll
+        for (int ck = 0; ck < CK; ++ck) {
+            const int c = cc * CK + ck;
+            float* xch = Xbuf + ck * p.chs + p.padL;
+            if (c < p.C) {
+                const float* gch = p.X + (size_t)c * p.XH * p.XW;
+#pragma nounroll
+                for (int r = wave; r < nrows; r += NWAVES) {
+                    const int src = __builtin_amdgcn_readfirstlane(rowsrc[r]);
+                    if (src >= 0) {
+                        const float* g = gch + (size_t)src * p.XW;
+                        float* d = xch + r * p.LW;
+#pragma nounroll
+                        for (int cb = 0; cb < p.XW; cb += 64)
+                            if (cb + lane < p.XW)
+                                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(g + cb + lane), (lds_void_ptr)(d + cb), 4, 0, 0);
+                    }
+                }
+            } else {  // channel padding of the last chunk must be finite: plain LDS stores into the idle buffer
+                for (int r = wave; r < nrows; r += NWAVES) {
+                    float* d = xch + r * p.LW;
+                    for (int col = lane; col < p.XW; col += 64) d[col] = 0.f;
+                }
+            }
+        }
+    };
+
+    issue_dma(0, 0);
+    for (int cc = 0; cc < p.nchunk; ++cc) {
+        // Every wave first waits for ITS OWN outstanding LDS-DMA (chunk cc), then the barrier publishes all of them and
+        // guarantees every wave is done reading the other buffer.  The explicit wait is required: hipcc (ROCm 7.2) hoists
+        // its own vmcnt(0) out of this loop, leaving the in-loop s_barrier unprotected (caught by tools/det_check.py).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (cc + 1 < p.nchunk) issue_dma(cc + 1, (cc + 1) & 1);
+        if (p.dbg & 4) continue;
+        const float* As = smem + (cc & 1) * buf_floats;
+        const float* Xs = As + a_floats;
+        // ---- MFMA, software pipelined by one tap ----
+        avec_t a_cur[MA];
+        float b_cur[NB][S];
+#pragma unroll
+        for (int ma = 0; ma < MA; ++ma) a_cur[ma] = *(const avec_t*)(As + a_lane + ma * MF * S);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int c2 = 0; c2 < S; ++c2) b_cur[nb][c2] = Xs[pix_off[nb] + c2 * 2 * p.chs];
+        int tr = 0, tc = 0;
+        for (int t = 0; t < T; ++t) {
+            int ntc = tc + 1, ntr = tr;
+            if (ntc == p.TC) { ntc = 0; ++ntr; }
+            const bool last = (t + 1 == T);
+            const int tap_next = last ? 0 : ntr * p.LW + ntc;
+            const float* a_next = As + (last ? 0 : (t + 1) * 2 * MT * S) + a_lane;
+            avec_t a_nxt[MA];
+            float b_nxt[NB][S];
+#pragma unroll
+            for (int ma = 0; ma < MA; ++ma) a_nxt[ma] = *(const avec_t*)(a_next + ma * MF * S);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int c2 = 0; c2 < S; ++c2) b_nxt[nb][c2] = Xs[pix_off[nb] + tap_next + c2 * 2 * p.chs];
+            __builtin_amdgcn_sched_barrier(0);  // reads of tap t+1 stay above the MFMAs of tap t
+#pragma unroll
+            for (int c2 = 0; c2 < S; ++c2)
+#pragma unroll
+                for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[ma][nb] = A_::mfma(a_cur[ma][c2], b_cur[nb][c2], acc[ma][nb]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ma = 0; ma < MA; ++ma) a_cur[ma] = a_nxt[ma];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int c2 = 0; c2 < S; ++c2) b_cur[nb][c2] = b_nxt[nb][c2];
+            tr = ntr;
+            tc = ntc;
         }
     }
+    if (!(p.dbg & 8)) store_tile<MF, MA, NB>(acc, p, (long long)n0 + (long long)wn * NB * MF, n1, mbase_wave, li, lh);
 }
 
 // ---- weight preparation: [Co][Ci][k][k]  ->  A[mblock][chunk][tap][ck][MT] (zero padded) -------------------
@@ -299,6 +612,7 @@ struct PrepParams {
     int mode;
     int C, M, TR, TC, r0, c0;
     int CK, MT, nchunk, nmb;
+    int a4;  // S > 0: slab layout [tap][k-half][m][S k-steps] (DMA kernel) instead of [tap][ck][m]
 };
 
 __global__ void igemm_prep_weights(const PrepParams q) {
@@ -307,11 +621,19 @@ __global__ void igemm_prep_weights(const PrepParams q) {
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         long long r = idx;
-        const int mm = (int)(r % q.MT); r /= q.MT;
-        const int ck = (int)(r % q.CK); r /= q.CK;
-        const int t = (int)(r % T); r /= T;
-        const int cc = (int)(r % q.nchunk);
-        const int mb = (int)(r / q.nchunk);
+        int mm, ck, t, cc, mb;
+        if (q.a4) {  // [mb][cc][tap][lh][mm][c2]  with ck = 2*c2 + lh (32x32x2: k index = lane >> 5)
+            const int c2 = (int)(r % q.a4); r /= q.a4;
+            mm = (int)(r % q.MT); r /= q.MT;
+            const int lh = (int)(r % 2); r /= 2;
+            ck = 2 * c2 + lh;
+        } else {     // [mb][cc][tap][ck][mm]
+            mm = (int)(r % q.MT); r /= q.MT;
+            ck = (int)(r % q.CK); r /= q.CK;
+        }
+        t = (int)(r % T); r /= T;
+        cc = (int)(r % q.nchunk);
+        mb = (int)(r / q.nchunk);
         const int m = mb * q.MT + mm, c = cc * q.CK + ck;
         const int tr = t / q.TC, tc = t % q.TC;
         float v = 0.f;
@@ -341,9 +663,10 @@ struct Plan {
     size_t lds_bytes;
     size_t a_floats;
     unsigned grid_x, grid_y;
+    int dma;  // double-buffered DMA-staged kernel
 };
 
-enum { CFG_M128 = 0, CFG_M128_S, CFG_M64, CFG_M64_S, CFG_M32, CFG_M32_S, CFG_M16_CK4, CFG_M16_CK16 };
+enum { CFG_M128_L = 100, CFG_M128 = 0, CFG_M128_S, CFG_M64, CFG_M64_S, CFG_M32, CFG_M32_S, CFG_M16_CK4, CFG_M16_CK16, CFG_M16_CK4_L, CFG_M16_CK8, CFG_M16_CK8_L, CFG_D_M128 = 200, CFG_D_M64, CFG_D_M64W4, CFG_D_M128W4, CFG_D_M128W4N2, CFG_D_M128W4_C4, CFG_D_M128_C4, CFG_D_M64W4_C4, CFG_D_M64W4N1_C4 };
 
 // taps of dy one parity class reads: offsets d in [e - J + 1, e], e = (ph+pad)/s, J = #taps kx = kx0 + s*j < k
 void dgrad_window(int k, int s, int pad, int* r0, int* TR) {
@@ -359,7 +682,7 @@ void dgrad_window(int k, int s, int pad, int* r0, int* TR) {
     *TR = dmax - dmin + 1;
 }
 
-int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl) {
+int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, bool allow_dma = true) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
     CNN_REQUIRE(Ho > 0 && Wo > 0, "%s: empty output", who);
     IgemmParams& p = pl->p;
@@ -388,11 +711,14 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl) {
     const long long kWantBlocks = 2 * kNumCU;
     if (p.M > 64) {
         pl->MF = 32; pl->MT = 128; pl->CK = 8;
-        if (blocks_for(128, 128) >= kWantBlocks) { pl->cfg = CFG_M128; pl->NPIX = 128; }
+        if (allow_dma && blocks_for(128, 256) >= 2 * kNumCU && p.TR * p.TC <= 9 && p.N < (1ll << 31) - 1024) { pl->cfg = CFG_D_M128; pl->NPIX = 256; }
+        else if (blocks_for(128, 128) >= kWantBlocks) { pl->cfg = CFG_M128; pl->NPIX = 128; }
         else { pl->cfg = CFG_M128_S; pl->NPIX = 64; }
     } else if (p.M > 32) {
         pl->MF = 32; pl->MT = 64; pl->CK = 8;
-        if (blocks_for(64, 256) >= kWantBlocks) { pl->cfg = CFG_M64; pl->NPIX = 256; }
+        if (allow_dma && blocks_for(64, 128) >= 4 * kNumCU && p.TR * p.TC <= 9 && p.N < (1ll << 31) - 1024 && p.C >= 16) {
+            pl->cfg = CFG_D_M64W4N1_C4; pl->NPIX = 128; pl->CK = 4;
+        } else if (blocks_for(64, 256) >= kWantBlocks) { pl->cfg = CFG_M64; pl->NPIX = 256; }
         else { pl->cfg = CFG_M64_S; pl->NPIX = 64; }
     } else if (p.M > 16) {
         pl->MF = 32; pl->MT = 32; pl->CK = 8;
@@ -401,6 +727,22 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl) {
     } else if (p.C <= 4) { pl->cfg = CFG_M16_CK4; pl->MF = 16; pl->MT = 16; pl->NPIX = 256; pl->CK = 4; }
     else { pl->cfg = CFG_M16_CK16; pl->MF = 16; pl->MT = 16; pl->NPIX = 256; pl->CK = 16; }
 
+    // tuning override (debug only): CNN_AMD_IGEMM_CFG=<cfg id>
+    if (const char* ov = getenv("CNN_AMD_IGEMM_CFG")) {
+        const int c = atoi(ov);
+        struct { int cfg, MF, MT, NPIX, CK; } tab[] = {
+            {CFG_M128_L, 32, 128, 256, 8}, {CFG_M128, 32, 128, 128, 8}, {CFG_M128_S, 32, 128, 64, 8},
+            {CFG_M64, 32, 64, 256, 8}, {CFG_M64_S, 32, 64, 64, 8}, {CFG_M32, 32, 32, 512, 8}, {CFG_M32_S, 32, 32, 128, 8},
+            {CFG_M16_CK4, 16, 16, 256, 4}, {CFG_M16_CK16, 16, 16, 256, 16}, {CFG_M16_CK4_L, 16, 16, 512, 4},
+            {CFG_M16_CK8, 16, 16, 256, 8}, {CFG_M16_CK8_L, 16, 16, 512, 8},
+            {CFG_D_M128, 32, 128, 256, 8}, {CFG_D_M64, 32, 64, 256, 8}, {CFG_D_M64W4, 32, 64, 256, 8},
+            {CFG_D_M128W4, 32, 128, 128, 8}, {CFG_D_M128W4N2, 32, 128, 256, 8}, {CFG_D_M128W4_C4, 32, 128, 128, 4},
+            {CFG_D_M128_C4, 32, 128, 256, 4}, {CFG_D_M64W4_C4, 32, 64, 256, 4}, {CFG_D_M64W4N1_C4, 32, 64, 128, 4}};
+        for (auto& t : tab)
+            if (t.cfg == c && p.M <= ((p.M + t.MT - 1) / t.MT) * t.MT && (t.MT >= 32 || p.M <= 16)) {
+                pl->cfg = t.cfg; pl->MF = t.MF; pl->MT = t.MT; pl->NPIX = t.NPIX; pl->CK = t.CK;
+            }
+    }
     p.nchunk = (p.C + pl->CK - 1) / pl->CK;
     p.padL = p.c0 < 0 ? -p.c0 : 0;
     int padR = (p.V - 1) * p.su + p.TC - 1 + p.c0 - (p.XW - 1);
@@ -418,20 +760,27 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl) {
         p.chs += ((want - p.chs % 32) + 32) % 32;
     }
     const int T = p.TR * p.TC;
+    pl->dma = pl->cfg >= CFG_D_M128;
+    if (pl->dma) p.chs = (p.chs + 3) & ~3;  // 16-byte aligned buffers for the dwordx4 DMA
     pl->a_floats = (size_t)((p.M + pl->MT - 1) / pl->MT) * p.nchunk * T * pl->CK * pl->MT;
-    pl->lds_bytes = ((size_t)T * pl->CK * pl->MT + (size_t)pl->CK * p.chs) * sizeof(float) + (size_t)p.nrows_max * 4;
+    pl->lds_bytes = ((size_t)T * pl->CK * pl->MT + (size_t)pl->CK * p.chs) * sizeof(float) * (pl->dma ? 2 : 1) +
+                    (size_t)p.nrows_max * 4;
+    if (pl->lds_bytes > 160 * 1024 && pl->dma && allow_dma && !getenv("CNN_AMD_IGEMM_CFG"))
+        return make_plan(who, d, mode, pl, false);  // two buffers do not fit: single-buffered kernel
     CNN_REQUIRE(pl->lds_bytes <= 160 * 1024, "%s: tile needs %zu B of LDS (> 160 KiB): k=%d W=%d not supported", who,
                 pl->lds_bytes, d->k, d->W);
     p.rw_shift = 0;
     while ((1 << p.rw_shift) < p.XW && p.rw_shift < 6) ++p.rw_shift;
     p.need_zero = (p.padL > 0 || padR > 0 || p.r0 < 0 || (p.U - 1) * p.su + p.r0 + p.TR - 1 > p.XH - 1) ? 1 : 0;
+    p.dbg = getenv("CNN_AMD_DBG") ? atoi(getenv("CNN_AMD_DBG")) : 0;
     p.ntiles = (int)((p.N + pl->NPIX - 1) / pl->NPIX);
     pl->grid_x = (unsigned)p.ntiles;
     pl->grid_y = (unsigned)((p.M + pl->MT - 1) / pl->MT);
 
     q.Co = d->Co; q.Ci = d->Ci; q.k = d->k; q.s = d->s; q.pad = d->pad; q.mode = mode;
     q.C = p.C; q.M = p.M; q.TR = p.TR; q.TC = p.TC; q.r0 = p.r0; q.c0 = p.c0;
-    q.CK = pl->CK; q.MT = pl->MT; q.nchunk = p.nchunk; q.nmb = (int)pl->grid_y;
+    q.CK = pl->CK; q.MT = pl->MT; q.nchunk = p.nchunk; q.nmb = (int)pl->grid_y; q.a4 = pl->dma ? pl->CK / 2 : 0;
+    p.run_mode = (pl->dma && !p.need_zero && p.LW == p.XW && p.XW % 4 == 0) ? 1 : 0;
     return CNN_AMD_OK;
 }
 
@@ -452,6 +801,21 @@ int launch_cfg(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
     return CNN_AMD_OK;
 }
 
+template <int MA, int NB, int WM, int WN, int S>
+int launch_dma(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
+    auto kern = igemm_dma_kernel<MA, NB, WM, WN, S>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    char name[96];
+    snprintf(name, sizeof(name), "igemm_dma_kernel<%d,%d,%d,%d,%d>%s", MA, NB, WM, WN, S,
+             pl.p.mode == MODE_FWD ? "/fwd" : "/dgrad");
+    CNN_KLAUNCH(s, name, (kern<<<dim3(pl.grid_x, pl.grid_y), 64 * WM * WN, pl.lds_bytes, s>>>(pl.p)), CONV_TAG(d));
+    return CNN_AMD_OK;
+}
+
 int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w, const float* bias, float* Y, void* ws,
              size_t ws_bytes, hipStream_t s, const char* who) {
     CNN_REQUIRE(ws != nullptr, "%s: workspace is null", who);
@@ -466,6 +830,16 @@ int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w,
                 (igemm_prep_weights<<<pg, 256, 0, s>>>(pl.q)), CONV_TAG(d));
     pl.p.X = X; pl.p.A = (const float*)ws; pl.p.bias = bias; pl.p.Y = Y;
     switch (pl.cfg) {
+        case CFG_D_M128: return launch_dma<4, 1, 1, 8, 4>(pl, s, d);
+        case CFG_D_M64: return launch_dma<2, 1, 1, 8, 4>(pl, s, d);
+        case CFG_D_M64W4: return launch_dma<2, 2, 1, 4, 4>(pl, s, d);
+        case CFG_D_M128W4: return launch_dma<4, 1, 1, 4, 4>(pl, s, d);
+        case CFG_D_M128W4N2: return launch_dma<4, 2, 1, 4, 4>(pl, s, d);
+        case CFG_D_M128W4_C4: return launch_dma<4, 1, 1, 4, 2>(pl, s, d);
+        case CFG_D_M128_C4: return launch_dma<4, 1, 1, 8, 2>(pl, s, d);
+        case CFG_D_M64W4_C4: return launch_dma<2, 2, 1, 4, 2>(pl, s, d);
+        case CFG_D_M64W4N1_C4: return launch_dma<2, 1, 1, 4, 2>(pl, s, d);
+        case CFG_M128_L: return launch_cfg<32, 4, 2, 1, 4, 8>(pl, s, d);
         case CFG_M128: return launch_cfg<32, 4, 1, 1, 4, 8>(pl, s, d);
         case CFG_M128_S: return launch_cfg<32, 2, 1, 2, 2, 8>(pl, s, d);
         case CFG_M64: return launch_cfg<32, 2, 2, 1, 4, 8>(pl, s, d);
@@ -473,6 +847,9 @@ int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w,
         case CFG_M32: return launch_cfg<32, 1, 4, 1, 4, 8>(pl, s, d);
         case CFG_M32_S: return launch_cfg<32, 1, 1, 1, 4, 8>(pl, s, d);
         case CFG_M16_CK4: return launch_cfg<16, 1, 4, 1, 4, 4>(pl, s, d);
+        case CFG_M16_CK4_L: return launch_cfg<16, 1, 8, 1, 4, 4>(pl, s, d);
+        case CFG_M16_CK8: return launch_cfg<16, 1, 4, 1, 4, 8>(pl, s, d);
+        case CFG_M16_CK8_L: return launch_cfg<16, 1, 8, 1, 4, 8>(pl, s, d);
         default: return launch_cfg<16, 1, 4, 1, 4, 16>(pl, s, d);
     }
 }

@@ -308,3 +308,28 @@ def test_full_size_northstar_properties(T):
     assert_close(host(dx[idx]), dx_ref, REL_TOL, "north-star dgrad slice")
     # linearity in dy: dgrad(2*dy) == 2*dgrad(dy) exactly (power-of-two scaling commutes with fp32 rounding)
     assert T.equal(conv.backward_data(dy * 2, w), dx * 2)
+
+
+@pytest.mark.parametrize("case", [(64, 64, 112, 112, 128, 3, 1, 0), (64, 16, 55, 55, 32, 3, 2, 0), (96, 32, 27, 27, 64, 3, 2, 0)],
+                         ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_conv_determinism_and_exact_linearity(T, case):
+    """race screen for the double-buffered DMA kernels: run-to-run bit equality, and f(2x) == 2 f(x) bit-for-bit
+    (power-of-two scaling commutes with every fp32 rounding, so any mismatch is a stale LDS read)."""
+    from cnn_amd import capi
+
+    conv = capi.Conv2d(*case)
+    g = T.Generator(device="cuda").manual_seed(11)
+    B, Ci, H, W, Co, k, s, pad = case
+    x = T.rand((B, Ci, H, W), generator=g, device="cuda")
+    w = T.randn((Co, Ci, k, k), generator=g, device="cuda") * 0.1
+    b = T.randn((Co,), generator=g, device="cuda") * 0.1
+    dy = T.rand(conv.out_shape(), generator=g, device="cuda") * 2 - 1
+    for rep in range(3):
+        y1, y2, y3 = conv.forward(x, w, b).clone(), conv.forward(x, w, b).clone(), conv.forward(x * 2, w, b * 2).clone()
+        assert T.equal(y1, y2) and T.equal(y1 * 2, y3), f"forward rep {rep}"
+        d1, d2, d3 = conv.backward_data(dy, w).clone(), conv.backward_data(dy, w).clone(), conv.backward_data(dy * 2, w).clone()
+        assert T.equal(d1, d2) and T.equal(d1 * 2, d3), f"dgrad rep {rep}"
+        g1, b1 = conv.backward_weight(x, dy, float(B))
+        g1, b1 = g1.clone(), b1.clone()
+        g2, b2 = conv.backward_weight(x, dy, float(B))
+        assert T.equal(g1, g2) and T.equal(b1, b2), f"wgrad rep {rep}"
