@@ -66,6 +66,10 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise CnnAmdError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        try:  # torch bundles its own libamdhip64: import it FIRST so that this process has ONE HIP runtime (loading
+            import torch  # noqa: F401  ours first and torch later leaves torch with "No HIP GPUs are available")
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here == the .so does not export a declared symbol

@@ -1,0 +1,188 @@
+// architectures.h -- the reference's layer API (cpu/include/architectures.h:12-138, 196-215) on MI355X.
+// Constructors, virtuals and globals keep the reference's names, argument order and defaults; every forward /
+// backward / update body is a call into libcnn_amd.so (include/cnn_amd.h).  Errors from the C ABI abort, like the
+// reference's asserts (it has no error channel).
+#ifndef CNN_AMD_ARCHITECTURES_H
+#define CNN_AMD_ARCHITECTURES_H
+
+#include <filesystem>
+#include <fstream>
+#include <list>
+#include <random>
+
+#include "data_format.h"
+
+namespace architectures {
+
+extern data_type random_times;  // init scale divisor (architectures.cpp:6)
+extern bool no_grad;            // skip everything only backward needs (architectures.cpp:8)
+extern void* stream;            // hipStream_t all layers enqueue on (addition; default stream when null)
+
+class WithoutGrad final {
+public:
+    explicit WithoutGrad() { architectures::no_grad = true; }
+    ~WithoutGrad() noexcept { architectures::no_grad = false; }
+};
+
+// One contiguous NCHW device buffer + the B Tensor3D views over it that the std::vector<tensor> API needs.
+class BatchBuffer {
+public:
+    BatchBuffer() = default;
+    ~BatchBuffer();
+    BatchBuffer(const BatchBuffer&) = delete;
+    BatchBuffer& operator=(const BatchBuffer&) = delete;
+    void allocate(int B, int C, int H, int W, const std::string& name);
+    bool empty() const { return views.empty(); }
+    data_type* base = nullptr;
+    size_t sample_len = 0;
+    std::vector<tensor> views;
+};
+
+// returns the device base pointer of a batch: zero-copy when the tensors are consecutive views of one arena,
+// otherwise uploads / gathers them into `staging` (host tensors, or views from different arenas)
+const data_type* batch_device_pointer(const std::vector<tensor>& batch, BatchBuffer& staging, const std::string& who);
+data_type* batch_device_pointer_mut(std::vector<tensor>& batch, BatchBuffer& staging, const std::string& who);
+
+class Layer {
+public:
+    const std::string name;
+    std::vector<tensor> output;
+
+public:
+    Layer(std::string& _name) : name(std::move(_name)) {}
+    virtual ~Layer() = default;
+    virtual std::vector<tensor> forward(const std::vector<tensor>& input) = 0;
+    virtual std::vector<tensor> backward(std::vector<tensor>& delta) = 0;
+    virtual void update_gradients(const data_type learning_rate = 1e-4) {}
+    virtual void save_weights(std::ofstream& writer) const {}
+    virtual void load_weights(std::ifstream& reader) {}
+    // host-readable copy of the last forward's output (alexnet.cpp:97,105 contract): syncs device -> host
+    virtual std::vector<tensor> get_output() const;
+    // ---- additions: flat parameter arena support (one SGD kernel, one all-reduce per step) ----
+    virtual size_t param_count() const { return 0; }
+    virtual void bind_arena(data_type* params_dev, data_type* grads_dev) {}
+};
+
+class Conv2D : public Layer {
+private:
+    const int in_channels, out_channels, kernel_size, stride;
+    const int params_for_one_kernel;
+    const int padding = 0;
+    std::default_random_engine seed;
+    // device state: weights [Co][Ci][k][k] then bias [Co], same order as the checkpoint (conv2d.cpp:220-226)
+    data_type* params = nullptr;
+    data_type* grads = nullptr;
+    bool owns_params = true;
+    bool grads_ready = false;
+    BatchBuffer out_buf, delta_buf, in_stage, delta_stage;
+    const data_type* saved_input = nullptr;  // device pointer of the last forward's input (the reference keeps __input)
+    std::vector<tensor> saved_input_tensors;  // keeps host-uploaded inputs alive like conv2d.cpp:62
+    int in_H = 0, in_W = 0, batch = 0;
+    void* workspace = nullptr;
+    size_t workspace_bytes = 0;
+    void ensure_workspace(int B, int H, int W);
+    data_type* w_dev() const { return params; }
+    data_type* b_dev() const { return params + (size_t)out_channels * params_for_one_kernel; }
+
+public:
+    Conv2D(std::string _name, const int _in_channels = 3, const int _out_channels = 16, const int _kernel_size = 3,
+           const int _stride = 2);
+    ~Conv2D() override;
+    std::vector<tensor> forward(const std::vector<tensor>& input) override;
+    std::vector<tensor> backward(std::vector<tensor>& delta) override;
+    void update_gradients(const data_type learning_rate = 1e-4) override;
+    void save_weights(std::ofstream& writer) const override;
+    void load_weights(std::ifstream& reader) override;
+    int get_params_num() const;
+    size_t param_count() const override { return (size_t)get_params_num(); }
+    void bind_arena(data_type* params_dev, data_type* grads_dev) override;
+};
+
+class MaxPool2D : public Layer {
+private:
+    const int kernel_size, step, padding;
+    BatchBuffer out_buf, delta_buf, in_stage, delta_stage;
+    int* mask = nullptr;  // device int32 [B][C*Ho*Wo], flat indices into the sample's C*H*W (pool2d.cpp:81)
+    int in_C = 0, in_H = 0, in_W = 0, batch = 0;
+
+public:
+    MaxPool2D(std::string _name, const int _kernel_size = 2, const int _step = 2)
+        : Layer(_name), kernel_size(_kernel_size), step(_step), padding(0) {}
+    ~MaxPool2D() override;
+    std::vector<tensor> forward(const std::vector<tensor>& input) override;
+    std::vector<tensor> backward(std::vector<tensor>& delta) override;
+};
+
+class ReLU : public Layer {
+private:
+    BatchBuffer out_buf, in_stage, delta_stage;
+
+public:
+    ReLU(std::string _name) : Layer(_name) {}
+    std::vector<tensor> forward(const std::vector<tensor>& input) override;
+    std::vector<tensor> backward(std::vector<tensor>& delta) override;
+};
+
+class LinearLayer : public Layer {
+private:
+    const int in_channels, out_channels;
+    data_type* params = nullptr;  // W [in][out] then bias [out] (linear.cpp:105-108)
+    data_type* grads = nullptr;
+    bool owns_params = true;
+    bool grads_ready = false;
+    std::tuple<int, int, int> delta_shape;
+    BatchBuffer out_buf, delta_buf, in_stage, delta_stage;
+    const data_type* saved_input = nullptr;
+    std::vector<tensor> saved_input_tensors;
+    int batch = 0;
+
+public:
+    LinearLayer(std::string _name, const int _in_channels, const int _out_channels);
+    ~LinearLayer() override;
+    std::vector<tensor> forward(const std::vector<tensor>& input) override;
+    std::vector<tensor> backward(std::vector<tensor>& delta) override;
+    void update_gradients(const data_type learning_rate = 1e-4) override;
+    void save_weights(std::ofstream& writer) const override;
+    void load_weights(std::ifstream& reader) override;
+    size_t param_count() const override { return (size_t)in_channels * out_channels + out_channels; }
+    void bind_arena(data_type* params_dev, data_type* grads_dev) override;
+};
+
+// The reference's fixed network (alexnet.cpp:10-33) as a sequential container.  BatchNorm2D / Dropout / grad_cam are
+// outside this build's scope; batch_norm=true aborts.
+class AlexNet {
+public:
+    bool print_info = false;
+
+private:
+    std::list<std::shared_ptr<Layer> > layers_sequence;
+    data_type* param_arena = nullptr;  // every layer's parameters in checkpoint order
+    data_type* grad_arena = nullptr;
+    size_t n_params = 0;
+    bool owns_arena = true;
+
+public:
+    AlexNet(const int num_classes = 3, const bool batch_norm = false);
+    // addition: adopt caller-provided device arenas (e.g. torch tensors) so the gradient arena can be all-reduced
+    AlexNet(const int num_classes, data_type* params_dev, data_type* grads_dev);
+    ~AlexNet();
+    std::vector<tensor> forward(const std::vector<tensor>& input);
+    void backward(std::vector<tensor>& delta_start);
+    // one SGD kernel over the flat arena; grad_scale folds the 1/G of a data-parallel all-reduce(sum)
+    void update_gradients(const data_type learning_rate = 1e-4, const data_type grad_scale = 1.f);
+    void save_weights(const std::filesystem::path& save_path) const;
+    void load_weights(const std::filesystem::path& checkpoint_path);
+    // additions
+    size_t num_params() const { return n_params; }
+    data_type* params_device() const { return param_arena; }
+    data_type* grads_device() const { return grad_arena; }
+    const std::list<std::shared_ptr<Layer> >& layers() const { return layers_sequence; }
+
+private:
+    void build(int num_classes);
+    void bind(data_type* p, data_type* g);
+};
+
+}  // namespace architectures
+
+#endif  // CNN_AMD_ARCHITECTURES_H

@@ -1,0 +1,137 @@
+// host_capi.cpp -- a flat C handle API over the C++ host classes, used by tests/ and bench.py to drive the SAME
+// code a reference user would call (AlexNet::forward / backward / update_gradients, func.cpp's softmax and
+// cross_entroy_backward) from Python.  Not part of the drop-in boundary (that is include/cnn_amd.h).
+#include <cstring>
+#include <filesystem>
+#include <vector>
+
+#include "architectures.h"
+#include "func.h"
+#include "host_util.h"
+
+using namespace architectures;
+using cnn_amd_host::must;
+
+namespace {
+struct Handle {
+    AlexNet* net;
+    int classes;
+    std::vector<tensor> host_input;     // B host tensors the caller's images are copied into (cnn.cpp's DataLoader role)
+    std::vector<tensor> device_input;   // zero-copy views of a caller-owned contiguous device batch
+    std::vector<tensor> last_output;
+};
+std::vector<tensor>& host_batch(Handle* h, int B, int C, int H, int W) {
+    if ((int)h->host_input.size() != B) {
+        h->host_input.clear();
+        for (int b = 0; b < B; ++b) h->host_input.emplace_back(new Tensor3D(C, H, W, "input_" + std::to_string(b)));
+    }
+    return h->host_input;
+}
+}  // namespace
+
+extern "C" {
+
+void* cnnh_net_create(int classes, float* params_dev, float* grads_dev) {
+    Handle* h = new Handle();
+    h->classes = classes;
+    h->net = (params_dev && grads_dev) ? new AlexNet(classes, params_dev, grads_dev) : new AlexNet(classes, false);
+    return h;
+}
+void cnnh_net_destroy(void* hv) {
+    Handle* h = (Handle*)hv;
+    delete h->net;
+    delete h;
+}
+size_t cnnh_net_num_params(void* hv) { return ((Handle*)hv)->net->num_params(); }
+float* cnnh_net_params_device(void* hv) { return ((Handle*)hv)->net->params_device(); }
+float* cnnh_net_grads_device(void* hv) { return ((Handle*)hv)->net->grads_device(); }
+void cnnh_set_stream(void* hip_stream) { architectures::stream = hip_stream; }
+void cnnh_set_no_grad(int on) { architectures::no_grad = on != 0; }
+
+void cnnh_net_set_params(void* hv, const float* host) {
+    Handle* h = (Handle*)hv;
+    must(cnn_memcpy_h2d(h->net->params_device(), host, sizeof(float) * h->net->num_params(), stream), "cnn_memcpy_h2d");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+}
+void cnnh_net_get_params(void* hv, float* host) {
+    Handle* h = (Handle*)hv;
+    must(cnn_memcpy_d2h(host, h->net->params_device(), sizeof(float) * h->net->num_params(), stream), "cnn_memcpy_d2h");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+}
+void cnnh_net_get_grads(void* hv, float* host) {
+    Handle* h = (Handle*)hv;
+    must(cnn_memcpy_d2h(host, h->net->grads_device(), sizeof(float) * h->net->num_params(), stream), "cnn_memcpy_d2h");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+}
+int cnnh_net_load_checkpoint(void* hv, const char* path) {
+    if (!std::filesystem::exists(path)) return 1;
+    ((Handle*)hv)->net->load_weights(path);
+    return 0;
+}
+void cnnh_net_save_checkpoint(void* hv, const char* path) { ((Handle*)hv)->net->save_weights(path); }
+
+// forward on HOST images [B][3][H][W] (each sample becomes one host Tensor3D, like the reference's DataLoader buffers);
+// logits_out [B][classes]
+void cnnh_net_forward_host(void* hv, const float* x, int B, int H, int W, float* logits_out) {
+    Handle* h = (Handle*)hv;
+    auto& in = host_batch(h, B, 3, H, W);
+    const size_t len = (size_t)3 * H * W;
+    for (int b = 0; b < B; ++b) std::memcpy(in[b]->data, x + len * b, sizeof(float) * len);
+    h->last_output = h->net->forward(in);
+    for (int b = 0; b < B; ++b) std::memcpy(logits_out + (size_t)b * h->classes, h->last_output[b]->data, sizeof(float) * h->classes);
+}
+
+// one iteration of cnn.cpp:79-90 on HOST images: forward, softmax, one_hot, cross_entroy_backward, backward, SGD
+float cnnh_net_train_step_host(void* hv, const float* x, const int* labels, int B, int H, int W, float lr, float* probs_out) {
+    Handle* h = (Handle*)hv;
+    auto& in = host_batch(h, B, 3, H, W);
+    const size_t len = (size_t)3 * H * W;
+    for (int b = 0; b < B; ++b) std::memcpy(in[b]->data, x + len * b, sizeof(float) * len);
+    const auto output = h->net->forward(in);
+    const auto probs = softmax(output);
+    auto loss_delta = cross_entroy_backward(probs, one_hot(std::vector<int>(labels, labels + B), h->classes));
+    h->net->backward(loss_delta.second);
+    h->net->update_gradients(lr);
+    if (probs_out)
+        for (int b = 0; b < B; ++b) std::memcpy(probs_out + (size_t)b * h->classes, probs[b]->data, sizeof(float) * h->classes);
+    return loss_delta.first;
+}
+
+// the same step on a caller-owned contiguous DEVICE batch (zero-copy views); returns the loss.  do_update = 0 leaves
+// the gradients in the arena so the caller can all-reduce them before cnnh_net_update().
+float cnnh_net_train_step_device(void* hv, float* x_dev, const int* labels, int B, int H, int W, float lr, int do_update) {
+    Handle* h = (Handle*)hv;
+    if ((int)h->device_input.size() != B || h->device_input[0]->dev != x_dev) {
+        h->device_input.clear();
+        const size_t len = (size_t)3 * H * W;
+        for (int b = 0; b < B; ++b)
+            h->device_input.emplace_back(Tensor3D::device_view(3, H, W, x_dev + len * b, "input_" + std::to_string(b)));
+    }
+    const auto output = h->net->forward(h->device_input);
+    const auto probs = softmax(output);
+    auto loss_delta = cross_entroy_backward(probs, one_hot(std::vector<int>(labels, labels + B), h->classes));
+    h->net->backward(loss_delta.second);
+    if (do_update) h->net->update_gradients(lr);
+    return loss_delta.first;
+}
+void cnnh_net_update(void* hv, float lr, float grad_scale) { ((Handle*)hv)->net->update_gradients(lr, grad_scale); }
+
+// host copy of a layer's last output through Layer::get_output() (the Grad-CAM contract, alexnet.cpp:97,105)
+int cnnh_net_layer_output(void* hv, const char* layer_name, float* out, size_t cap_floats) {
+    Handle* h = (Handle*)hv;
+    for (const auto& layer : h->net->layers()) {
+        if (layer->name != layer_name) continue;
+        const auto ts = layer->get_output();
+        size_t off = 0;
+        for (const auto& t : ts) {
+            const size_t n = (size_t)t->get_length();
+            if (off + n > cap_floats) return 2;
+            std::memcpy(out + off, t->data, sizeof(float) * n);
+            off += n;
+        }
+        return 0;
+    }
+    return 1;
+}
+
+}  // extern "C"

@@ -1,0 +1,370 @@
+// layers.cpp -- Conv2D / MaxPool2D / ReLU / LinearLayer with the reference's interface
+// (cpu/include/architectures.h:49-138); every body is a call into the C ABI of libcnn_amd.so.
+#include <cassert>
+#include <cstring>
+#include <iostream>
+
+#include "architectures.h"
+#include "host_util.h"
+
+using namespace architectures;
+using cnn_amd_host::dev_alloc;
+using cnn_amd_host::must;
+
+data_type architectures::random_times = 10.f;  // architectures.cpp:6
+bool architectures::no_grad = false;           // architectures.cpp:8
+void* architectures::stream = nullptr;
+
+// ---------------------------------------------------------------------------------------------------------------
+BatchBuffer::~BatchBuffer() {
+    views.clear();
+    if (base) cnn_device_free(base);
+}
+
+void BatchBuffer::allocate(int B, int C, int H, int W, const std::string& name) {
+    sample_len = (size_t)C * H * W;
+    base = (data_type*)dev_alloc(sizeof(data_type) * sample_len * B);
+    views.reserve(B);
+    for (int b = 0; b < B; ++b)
+        views.emplace_back(Tensor3D::device_view(C, H, W, base + sample_len * b, name + "_" + std::to_string(b)));
+}
+
+namespace {
+bool is_contiguous_device_batch(const std::vector<tensor>& batch) {
+    const size_t len = (size_t)batch[0]->get_length();
+    for (size_t b = 0; b < batch.size(); ++b)
+        if (!batch[b]->on_device() || batch[b]->dev != batch[0]->dev + len * b) return false;
+    return true;
+}
+// host tensors / scattered views -> one contiguous device buffer (one H2D for an all-host batch)
+data_type* stage_batch(const std::vector<tensor>& batch, BatchBuffer& staging, const std::string& who) {
+    const int B = (int)batch.size();
+    const size_t len = (size_t)batch[0]->get_length();
+    if (staging.empty() || staging.views.size() < (size_t)B || staging.sample_len != len) {
+        staging.views.clear();
+        if (staging.base) cnn_device_free(staging.base);
+        staging.base = nullptr;
+        staging.allocate(B, batch[0]->C, batch[0]->H, batch[0]->W, who + "_staging");
+    }
+    bool all_host = true;
+    for (const auto& t : batch) all_host = all_host && !t->on_device();
+    if (all_host) {
+        std::vector<data_type> packed(len * B);
+        for (int b = 0; b < B; ++b) std::memcpy(packed.data() + len * b, batch[b]->data, sizeof(data_type) * len);
+        must(cnn_memcpy_h2d(staging.base, packed.data(), sizeof(data_type) * len * B, architectures::stream), "cnn_memcpy_h2d");
+        must(cnn_stream_synchronize(architectures::stream), "cnn_stream_synchronize");  // `packed` dies here
+    } else {
+        for (int b = 0; b < B; ++b) {
+            data_type* dst = staging.base + len * b;
+            if (batch[b]->on_device())
+                must(cnn_memcpy_d2d(dst, batch[b]->dev, sizeof(data_type) * len, architectures::stream), "cnn_memcpy_d2d");
+            else {
+                must(cnn_memcpy_h2d(dst, batch[b]->data, sizeof(data_type) * len, architectures::stream), "cnn_memcpy_h2d");
+                must(cnn_stream_synchronize(architectures::stream), "cnn_stream_synchronize");
+            }
+        }
+    }
+    return staging.base;
+}
+}  // namespace
+
+const data_type* architectures::batch_device_pointer(const std::vector<tensor>& batch, BatchBuffer& staging,
+                                                     const std::string& who) {
+    assert(!batch.empty());
+    if (is_contiguous_device_batch(batch)) return batch[0]->dev;
+    return stage_batch(batch, staging, who);
+}
+
+data_type* architectures::batch_device_pointer_mut(std::vector<tensor>& batch, BatchBuffer& staging,
+                                                   const std::string& who) {
+    assert(!batch.empty());
+    if (is_contiguous_device_batch(batch)) return batch[0]->dev;
+    return stage_batch(batch, staging, who);
+}
+
+std::vector<tensor> Layer::get_output() const {
+    for (const auto& t : output) t->sync_to_host();
+    return output;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Conv2D
+Conv2D::Conv2D(std::string _name, const int _in_channels, const int _out_channels, const int _kernel_size,
+               const int _stride)
+    : Layer(_name), in_channels(_in_channels), out_channels(_out_channels), kernel_size(_kernel_size), stride(_stride),
+      params_for_one_kernel(_in_channels * _kernel_size * _kernel_size) {
+    assert(_kernel_size >= 1 && _in_channels > 0 && _out_channels > 0 && _stride > 0);
+    const size_t n = param_count();
+    params = (data_type*)dev_alloc(sizeof(data_type) * n);
+    grads = (data_type*)dev_alloc(sizeof(data_type) * n);
+    // same generator, seed and draw order as conv2d.cpp:23-30 (bias first, then the filters), stored weights-then-bias
+    std::vector<data_type> host(n);
+    this->seed.seed(212);
+    std::normal_distribution<float> engine(0.0, 1.0);
+    data_type* bias = host.data() + (size_t)out_channels * params_for_one_kernel;
+    for (int o = 0; o < out_channels; ++o) bias[o] = engine(this->seed) / random_times;
+    for (size_t i = 0; i < (size_t)out_channels * params_for_one_kernel; ++i) host[i] = engine(this->seed) / random_times;
+    must(cnn_memcpy_h2d(params, host.data(), sizeof(data_type) * n, stream), "cnn_memcpy_h2d");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+}
+
+Conv2D::~Conv2D() {
+    if (owns_params) {
+        cnn_device_free(params);
+        cnn_device_free(grads);
+    }
+    if (workspace) cnn_device_free(workspace);
+}
+
+void Conv2D::bind_arena(data_type* params_dev, data_type* grads_dev) {
+    must(cnn_memcpy_d2d(params_dev, params, sizeof(data_type) * param_count(), stream), "cnn_memcpy_d2d");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+    if (owns_params) {
+        cnn_device_free(params);
+        cnn_device_free(grads);
+    }
+    params = params_dev;
+    grads = grads_dev;
+    owns_params = false;
+}
+
+void Conv2D::ensure_workspace(int B, int H, int W) {
+    cnn_conv2d_desc d{B, in_channels, H, W, out_channels, kernel_size, stride, padding};
+    const size_t need = cnn_conv2d_workspace_bytes(&d);
+    if (need == 0) must(1, "cnn_conv2d_workspace_bytes");
+    if (need > workspace_bytes) {
+        if (workspace) cnn_device_free(workspace);
+        workspace = dev_alloc(need);
+        workspace_bytes = need;
+    }
+}
+
+std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
+    const int B = (int)input.size();
+    const int H = input[0]->H, W = input[0]->W;
+    const int out_H = cnn_conv2d_out_dim(H, kernel_size, stride, padding);
+    const int out_W = cnn_conv2d_out_dim(W, kernel_size, stride, padding);
+    if (out_buf.empty()) {  // shape-static like conv2d.cpp:47-52: buffers are sized by the first batch
+        out_buf.allocate(B, out_channels, out_H, out_W, name + "_output");
+        output = out_buf.views;
+        batch = B;
+    }
+    assert(B <= batch && "batch larger than the first forward's (conv2d.cpp:47 has the same restriction)");
+    in_H = H;
+    in_W = W;
+    ensure_workspace(B, H, W);
+    const data_type* x = batch_device_pointer(input, in_stage, name);
+    if (!no_grad) {  // conv2d.cpp:62: keep the input for the weight gradient
+        saved_input = x;
+        saved_input_tensors = input;
+    }
+    cnn_conv2d_desc d{B, in_channels, H, W, out_channels, kernel_size, stride, padding};
+    must(cnn_conv2d_forward(&d, x, w_dev(), b_dev(), out_buf.base, workspace, workspace_bytes, stream), "cnn_conv2d_forward");
+    return output;
+}
+
+std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
+    const int B = (int)delta.size();
+    assert(saved_input != nullptr && "backward without a recorded forward (no_grad?)");
+    const data_type* dy = batch_device_pointer(delta, delta_stage, name + "_dy");
+    cnn_conv2d_desc d{B, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding};
+    // conv2d.cpp:117-159: gradients are recomputed (not accumulated) every call and averaged over the batch
+    must(cnn_conv2d_backward_weight(&d, saved_input, dy, grads, grads + (size_t)out_channels * params_for_one_kernel,
+                                    (float)B, workspace, workspace_bytes, stream),
+         "cnn_conv2d_backward_weight");
+    grads_ready = true;
+    if (delta_buf.empty()) delta_buf.allocate(batch, in_channels, in_H, in_W, name + "_delta");
+    must(cnn_conv2d_backward_data(&d, dy, w_dev(), delta_buf.base, workspace, workspace_bytes, stream),
+         "cnn_conv2d_backward_data");
+    return delta_buf.views;
+}
+
+void Conv2D::update_gradients(const data_type learning_rate) {
+    assert(grads_ready);  // conv2d.cpp:206
+    must(cnn_sgd_update(params, grads, param_count(), learning_rate, 1.f, stream), "cnn_sgd_update");
+}
+
+// checkpoint layout conv2d.cpp:220-226: Co filters then Co biases == the device layout, one contiguous block
+void Conv2D::save_weights(std::ofstream& writer) const {
+    std::vector<data_type> host(param_count());
+    must(cnn_memcpy_d2h(host.data(), params, sizeof(data_type) * host.size(), stream), "cnn_memcpy_d2h");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+    writer.write(reinterpret_cast<const char*>(host.data()), static_cast<std::streamsize>(sizeof(data_type) * host.size()));
+}
+
+void Conv2D::load_weights(std::ifstream& reader) {
+    std::vector<data_type> host(param_count());
+    reader.read(reinterpret_cast<char*>(host.data()), static_cast<std::streamsize>(sizeof(data_type) * host.size()));
+    must(cnn_memcpy_h2d(params, host.data(), sizeof(data_type) * host.size(), stream), "cnn_memcpy_h2d");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+}
+
+int Conv2D::get_params_num() const { return (params_for_one_kernel + 1) * out_channels; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// MaxPool2D
+MaxPool2D::~MaxPool2D() {
+    if (mask) cnn_device_free(mask);
+}
+
+std::vector<tensor> MaxPool2D::forward(const std::vector<tensor>& input) {
+    const int B = (int)input.size();
+    const int C = input[0]->C, H = input[0]->H, W = input[0]->W;
+    const int out_H = cnn_maxpool2d_out_dim(H, kernel_size, step), out_W = cnn_maxpool2d_out_dim(W, kernel_size, step);
+    if (out_buf.empty()) {
+        out_buf.allocate(B, C, out_H, out_W, name + "_output");
+        output = out_buf.views;
+        batch = B;
+    }
+    assert(B <= batch);
+    in_C = C; in_H = H; in_W = W;
+    if (!no_grad && mask == nullptr)  // pool2d.cpp:23-31 (allocated lazily so a no_grad first call is not fatal)
+        mask = (int*)dev_alloc(sizeof(int) * (size_t)batch * C * out_H * out_W);
+    const data_type* x = batch_device_pointer(input, in_stage, name);
+    must(cnn_maxpool2d_forward(x, out_buf.base, no_grad ? nullptr : mask, B, C, H, W, kernel_size, step, stream),
+         "cnn_maxpool2d_forward");
+    return output;
+}
+
+std::vector<tensor> MaxPool2D::backward(std::vector<tensor>& delta) {
+    const int B = (int)delta.size();
+    assert(mask != nullptr && "backward without a recorded forward (no_grad?)");
+    if (delta_buf.empty()) delta_buf.allocate(batch, in_C, in_H, in_W, name + "_delta");
+    const data_type* dy = batch_device_pointer(delta, delta_stage, name + "_dy");
+    must(cnn_maxpool2d_backward(dy, mask, delta_buf.base, B, in_C, in_H, in_W, kernel_size, step, stream),
+         "cnn_maxpool2d_backward");
+    return delta_buf.views;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ReLU
+std::vector<tensor> ReLU::forward(const std::vector<tensor>& input) {
+    const int B = (int)input.size();
+    if (out_buf.empty()) {
+        out_buf.allocate(B, input[0]->C, input[0]->H, input[0]->W, name + "_output");
+        output = out_buf.views;
+    }
+    assert((size_t)B <= out_buf.views.size());
+    const data_type* x = batch_device_pointer(input, in_stage, name);
+    must(cnn_relu_forward(x, out_buf.base, out_buf.sample_len * B, stream), "cnn_relu_forward");
+    return output;
+}
+
+// relu.cpp:30-44: masks the caller's delta IN PLACE and hands the same tensors back
+std::vector<tensor> ReLU::backward(std::vector<tensor>& delta) {
+    const int B = (int)delta.size();
+    const bool in_place = delta[0]->on_device();
+    data_type* d = batch_device_pointer_mut(delta, delta_stage, name + "_dy");
+    must(cnn_relu_backward(out_buf.base, d, out_buf.sample_len * B, stream), "cnn_relu_backward");
+    if (!in_place || d == delta_stage.base) {  // host (or scattered) deltas were staged: write the result back
+        for (int b = 0; b < B; ++b) {
+            if (delta[b]->on_device())
+                must(cnn_memcpy_d2d(delta[b]->dev, d + out_buf.sample_len * b, sizeof(data_type) * out_buf.sample_len, stream),
+                     "cnn_memcpy_d2d");
+            else
+                must(cnn_memcpy_d2h(delta[b]->data, d + out_buf.sample_len * b, sizeof(data_type) * out_buf.sample_len, stream),
+                     "cnn_memcpy_d2h");
+        }
+        must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+    }
+    for (int b = 0; b < B; ++b) delta[b]->name = name + "_delta_" + std::to_string(b);
+    return delta;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LinearLayer
+LinearLayer::LinearLayer(std::string _name, const int _in_channels, const int _out_channels)
+    : Layer(_name), in_channels(_in_channels), out_channels(_out_channels) {
+    const size_t n = param_count();
+    params = (data_type*)dev_alloc(sizeof(data_type) * n);
+    grads = (data_type*)dev_alloc(sizeof(data_type) * n);
+    std::vector<data_type> host(n);
+    std::default_random_engine e(1998);  // linear.cpp:14-18: bias first, then the matrix
+    std::normal_distribution<float> engine(0.0, 1.0);
+    data_type* bias = host.data() + (size_t)in_channels * out_channels;
+    for (int i = 0; i < out_channels; ++i) bias[i] = engine(e) / random_times;
+    for (size_t i = 0; i < (size_t)in_channels * out_channels; ++i) host[i] = engine(e) / random_times;
+    must(cnn_memcpy_h2d(params, host.data(), sizeof(data_type) * n, stream), "cnn_memcpy_h2d");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+}
+
+LinearLayer::~LinearLayer() {
+    if (owns_params) {
+        cnn_device_free(params);
+        cnn_device_free(grads);
+    }
+}
+
+void LinearLayer::bind_arena(data_type* params_dev, data_type* grads_dev) {
+    must(cnn_memcpy_d2d(params_dev, params, sizeof(data_type) * param_count(), stream), "cnn_memcpy_d2d");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+    if (owns_params) {
+        cnn_device_free(params);
+        cnn_device_free(grads);
+    }
+    params = params_dev;
+    grads = grads_dev;
+    owns_params = false;
+}
+
+std::vector<tensor> LinearLayer::forward(const std::vector<tensor>& input) {
+    const int B = (int)input.size();
+    delta_shape = input[0]->get_shape();  // linear.cpp:25
+    assert(input[0]->get_length() == in_channels);
+    if (out_buf.empty()) {
+        out_buf.allocate(B, out_channels, 1, 1, name + "_output");
+        output = out_buf.views;
+        batch = B;
+    }
+    assert(B <= batch);
+    const data_type* x = batch_device_pointer(input, in_stage, name);
+    if (!no_grad) {
+        saved_input = x;
+        saved_input_tensors = input;
+    }
+    must(cnn_linear_forward(x, params, params + (size_t)in_channels * out_channels, out_buf.base, B, in_channels,
+                            out_channels, stream),
+         "cnn_linear_forward");
+    // the callers read the logits on the host right away (softmax, func.cpp:24-28; argmax, cnn.cpp:92): one D2H
+    std::vector<data_type> host((size_t)B * out_channels);
+    must(cnn_memcpy_d2h(host.data(), out_buf.base, sizeof(data_type) * host.size(), stream), "cnn_memcpy_d2h");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+    for (int b = 0; b < B; ++b) {
+        if (!output[b]->data) output[b]->data = new data_type[out_channels];
+        std::memcpy(output[b]->data, host.data() + (size_t)b * out_channels, sizeof(data_type) * out_channels);
+    }
+    return output;
+}
+
+std::vector<tensor> LinearLayer::backward(std::vector<tensor>& delta) {
+    const int B = (int)delta.size();
+    assert(saved_input != nullptr && "backward without a recorded forward (no_grad?)");
+    const data_type* dy = batch_device_pointer(delta, delta_stage, name + "_dy");
+    if (delta_buf.empty())
+        delta_buf.allocate(batch, std::get<0>(delta_shape), std::get<1>(delta_shape), std::get<2>(delta_shape),
+                           "linear_delta");
+    must(cnn_linear_backward(saved_input, dy, params, grads, grads + (size_t)in_channels * out_channels, delta_buf.base, B,
+                             in_channels, out_channels, (float)B, stream),
+         "cnn_linear_backward");
+    grads_ready = true;
+    return delta_buf.views;
+}
+
+void LinearLayer::update_gradients(const data_type learning_rate) {
+    assert(grads_ready);  // linear.cpp:97
+    must(cnn_sgd_update(params, grads, param_count(), learning_rate, 1.f, stream), "cnn_sgd_update");
+}
+
+void LinearLayer::save_weights(std::ofstream& writer) const {
+    std::vector<data_type> host(param_count());
+    must(cnn_memcpy_d2h(host.data(), params, sizeof(data_type) * host.size(), stream), "cnn_memcpy_d2h");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+    writer.write(reinterpret_cast<const char*>(host.data()), static_cast<std::streamsize>(sizeof(data_type) * host.size()));
+}
+
+void LinearLayer::load_weights(std::ifstream& reader) {
+    std::vector<data_type> host(param_count());
+    reader.read(reinterpret_cast<char*>(host.data()), static_cast<std::streamsize>(sizeof(data_type) * host.size()));
+    must(cnn_memcpy_h2d(params, host.data(), sizeof(data_type) * host.size(), stream), "cnn_memcpy_h2d");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+}

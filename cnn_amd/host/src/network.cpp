@@ -1,0 +1,104 @@
+// network.cpp -- the reference's AlexNet container (cpu/src/alexnet.cpp:10-90) over the device layers, plus the
+// flat parameter / gradient arena that makes the SGD step one kernel and the data-parallel exchange one all-reduce.
+#include <cassert>
+#include <iostream>
+
+#include "architectures.h"
+#include "host_util.h"
+
+using namespace architectures;
+using cnn_amd_host::dev_alloc;
+using cnn_amd_host::must;
+
+void AlexNet::build(int num_classes) {
+    // alexnet.cpp:12-31: every convolution is 3x3 with the constructor's default stride 2; one MaxPool(2,2)
+    layers_sequence.emplace_back(new Conv2D("conv_layer_1", 3, 16, 3));
+    layers_sequence.emplace_back(new ReLU("relu_layer_1"));
+    layers_sequence.emplace_back(new MaxPool2D("max_pool_1", 2, 2));
+    layers_sequence.emplace_back(new Conv2D("conv_layer_2", 16, 32, 3));
+    layers_sequence.emplace_back(new ReLU("relu_layer_2"));
+    layers_sequence.emplace_back(new Conv2D("conv_layer_3", 32, 64, 3));
+    layers_sequence.emplace_back(new ReLU("relu_layer_3"));
+    layers_sequence.emplace_back(new Conv2D("conv_layer_4", 64, 128, 3));
+    layers_sequence.emplace_back(new ReLU("relu_layer_4"));
+    layers_sequence.emplace_back(new LinearLayer("linear_1", 6 * 6 * 128, num_classes));
+    n_params = 0;
+    for (const auto& layer : layers_sequence) n_params += layer->param_count();
+}
+
+void AlexNet::bind(data_type* p, data_type* g) {
+    param_arena = p;
+    grad_arena = g;
+    size_t off = 0;  // checkpoint order == layer order (alexnet.cpp:73-74)
+    for (auto& layer : layers_sequence) {
+        const size_t n = layer->param_count();
+        if (n) layer->bind_arena(p + off, g + off);
+        off += n;
+    }
+}
+
+AlexNet::AlexNet(const int num_classes, const bool batch_norm) {
+    if (batch_norm) {
+        std::cerr << "BatchNorm2D is outside this build's scope (SURVEY.md 8f)\n";
+        std::abort();
+    }
+    build(num_classes);
+    owns_arena = true;
+    bind((data_type*)dev_alloc(sizeof(data_type) * n_params), (data_type*)dev_alloc(sizeof(data_type) * n_params));
+    must(cnn_memset_zero(grad_arena, sizeof(data_type) * n_params, stream), "cnn_memset_zero");
+}
+
+AlexNet::AlexNet(const int num_classes, data_type* params_dev, data_type* grads_dev) {
+    build(num_classes);
+    owns_arena = false;
+    bind(params_dev, grads_dev);
+}
+
+AlexNet::~AlexNet() {
+    layers_sequence.clear();
+    if (owns_arena) {
+        cnn_device_free(param_arena);
+        cnn_device_free(grad_arena);
+    }
+}
+
+std::vector<tensor> AlexNet::forward(const std::vector<tensor>& input) {
+    assert(input.size() > 0);
+    if (print_info) input[0]->print_shape();
+    std::vector<tensor> output(input);
+    for (const auto& layer : layers_sequence) {
+        output = layer->forward(output);
+        if (print_info) output[0]->print_shape();
+    }
+    return output;
+}
+
+void AlexNet::backward(std::vector<tensor>& delta_start) {
+    if (print_info) delta_start[0]->print_shape();
+    for (auto layer = layers_sequence.rbegin(); layer != layers_sequence.rend(); ++layer) {
+        delta_start = (*layer)->backward(delta_start);
+        if (print_info) delta_start[0]->print_shape();
+    }
+}
+
+void AlexNet::update_gradients(const data_type learning_rate, const data_type grad_scale) {
+    must(cnn_sgd_update(param_arena, grad_arena, n_params, learning_rate, grad_scale, stream), "cnn_sgd_update");
+}
+
+void AlexNet::save_weights(const std::filesystem::path& save_path) const {
+    std::ofstream writer(save_path.c_str(), std::ios::binary);
+    for (const auto& layer : layers_sequence) layer->save_weights(writer);
+    std::cout << "weights have been saved to " << save_path.string() << std::endl;
+    writer.close();
+}
+
+void AlexNet::load_weights(const std::filesystem::path& checkpoint_path) {
+    if (!std::filesystem::exists(checkpoint_path)) {  // alexnet.cpp:81-84: report and carry on
+        std::cout << "checkpoint file  " << checkpoint_path << " does not exist !\n";
+        return;
+    }
+    std::ifstream reader(checkpoint_path.c_str(), std::ios::binary);
+    for (auto& layer : layers_sequence) layer->load_weights(reader);
+    std::cout << "load weights from" << checkpoint_path.string() << std::endl;
+    reader.close();
+}

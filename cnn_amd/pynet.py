@@ -135,6 +135,6 @@ class AlexNetHip:
         self.forward(x)
         self.loss_backward_seed(labels)
         self.backward(self.delta)
-        if world > 1:
-            dist.all_reduce(self.grads)
-        self.update(lr, 1.0 / world)
+        from .dp import allreduce_grads
+
+        self.update(lr, allreduce_grads(self.grads, dist, world))

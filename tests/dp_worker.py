@@ -1,0 +1,53 @@
+"""worker of tests/test_data_parallel_gloo.py: one rank of a world_size-N gloo job on CPU.
+Each rank computes the gradients of ITS shard with the oracle (divided by the local batch, like the kernels),
+all-reduces the flat arena through cnn_amd.dp (the function bench.py uses), applies SGD with the 1/G scale and
+rank 0 checks the result against the full-batch oracle step."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from cnn_amd import dp  # noqa: E402
+from oracle import pyoracle as O  # noqa: E402
+from tests.util import normal_scaled, uniform01  # noqa: E402
+
+
+def main():
+    world, rank, _ = dp.env_world()
+    dist = dp.init_process_group("gloo")
+    GB, Hh, lr = 4, 64, 1e-2
+    x = uniform01(50, (GB, 3, Hh, Hh))
+    labels = (np.arange(GB) % 3).astype(np.int32)
+    lo, hi = dp.shard_bounds(GB, rank, world)
+    net = O.Net(hi - lo, 3, Hh, Hh)
+    p0 = normal_scaled(51, (net.n_params,))
+    net.params[:] = p0
+    probs = O.softmax(net.forward(x[lo:hi]))
+    _, delta = O.cross_entropy_backward(probs, labels[lo:hi])
+    net.backward(delta)  # local gradients = (1/B_local) * sum over the shard
+    grads = torch.from_numpy(net.grads.copy())
+    scale = dp.allreduce_grads(grads, dist, world)
+    new_params = O.sgd_update(p0, grads.numpy() * np.float32(scale), lr)
+    # every rank must hold the same reduced arena (replicas stay in lock-step without a broadcast)
+    check = torch.from_numpy(new_params.copy())
+    ref = check.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(check, ref), "replicas diverged"
+    if rank == 0:
+        full = O.Net(GB, 3, Hh, Hh)
+        full.params[:] = p0
+        full.train_step(x, labels, lr)
+        err = np.abs(new_params - full.params).max() / np.abs(full.params).max()
+        assert err < 1e-5, err
+        print(f"DP_OK world={world} err={err:.2e}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
