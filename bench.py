@@ -61,7 +61,24 @@ def algorithmic_work(key):
     return 0.0, 0.0
 
 
-def roofline_entry(key, launches, total_ms):
+def pmc_traffic(key):
+    """HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (tools/profile_bench.sh ->
+    tools/pmc_traffic.py -> profiles/rNN/hbm_traffic.json), or None when that kernel was not profiled / is ambiguous."""
+    import glob
+
+    name = key.split("|")[0].split("/")[0].replace(" ", "")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic.json")), reverse=True):
+        try:
+            kernels = json.load(open(path))["kernels"]
+        except Exception:
+            continue
+        hits = [v for k, v in kernels.items() if k.split("|")[0].replace(" ", "") == name]
+        if len(hits) == 1:
+            return hits[0]["hbm_bytes"], os.path.relpath(path, ROOT)
+    return None, None
+
+
+def roofline_entry(key, launches, total_ms, with_traffic=False):
     nbytes, flops = algorithmic_work(key)
     avg_s = total_ms / 1e3 / max(launches, 1)
     ridge = PEAK_MFMA_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
@@ -71,9 +88,13 @@ def roofline_entry(key, launches, total_ms):
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
                 "avg_us": round(avg_s * 1e6, 2), "launches": launches}
     ach = nbytes / avg_s / 1e9
-    return {"bound": "hbm", "kernel": key, "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "avg_us": round(avg_s * 1e6, 2),
-            "launches": launches, "algorithmic_bytes": nbytes}
+    traffic, src = pmc_traffic(key) if with_traffic else (None, None)
+    out = {"bound": "hbm", "kernel": key, "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+           "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic, "avg_us": round(avg_s * 1e6, 2),
+           "launches": launches, "algorithmic_bytes": nbytes}
+    if src:
+        out["traffic_source"] = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2 on gfx950)"
+    return out
 
 
 def cpu_baseline(batch=16, budget_s=12.0):
@@ -238,7 +259,7 @@ def main():
                 "global_batch": world * B,
                 "parallelism": f"dp{world}" + (" (RCCL all-reduce of the 111267-float gradient arena per step)" if world > 1 else ""),
             },
-            "roofline": roofline_entry(dominant, cnt, ms),
+            "roofline": roofline_entry(dominant, cnt, ms, with_traffic=True),
             "final_loss": round(loss, 5),
         }
         if args.breakdown:
