@@ -387,11 +387,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
 
-template <int MA, int NB, int WM, int WN, int S>  // S = k-steps per tap = channels per chunk / 2
+template <int MF, int MA, int NB, int WM, int WN, int S>  // S = k-steps per tap = channels per chunk / KSTEP
 __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmParams p) {
-    constexpr int MF = 32, CK = 2 * S;
-    typedef float avec_t __attribute__((ext_vector_type(S)));
     using A_ = Acc<MF>;
+    constexpr int KSTEP = A_::kStep, CK = KSTEP * S;
+    typedef float avec_t __attribute__((ext_vector_type(S)));
     constexpr int NWAVES = WM * WN;
     constexpr int NT = 64 * NWAVES;
     constexpr int MT = MF * MA * WM;
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         const int lrow = (b == b0) ? (u - u0) * p.su : nrows0 + (b - b0 - 1) * full + u * p.su;
         pix_off[nb] = lrow * p.LW + v * p.su + p.c0 + p.padL + lh * p.chs;
     }
-    const int a_lane = (lh * MT + wm * MA * MF + li) * S;  // slab layout: [tap][lh][m][S k-steps]
+    const int a_lane = (lh * MT + wm * MA * MF + li) * S;  // slab layout: [tap][k-lane][m][S k-steps]
 
     typename A_::type acc[MA][NB];
     const int mbase_wave = mb * MT + wm * MA * MF;
@@ -566,14 +566,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int c2 = 0; c2 < S; ++c2) b_cur[nb][c2] = Xs[pix_off[nb] + c2 * 2 * p.chs];
+            for (int c2 = 0; c2 < S; ++c2) b_cur[nb][c2] = Xs[pix_off[nb] + c2 * KSTEP * p.chs];
         int tr = 0, tc = 0;
         for (int t = 0; t < T; ++t) {
             int ntc = tc + 1, ntr = tr;
             if (ntc == p.TC) { ntc = 0; ++ntr; }
             const bool last = (t + 1 == T);
             const int tap_next = last ? 0 : ntr * p.LW + ntc;
-            const float* a_next = As + (last ? 0 : (t + 1) * 2 * MT * S) + a_lane;
+            const float* a_next = As + (last ? 0 : (t + 1) * KSTEP * MT * S) + a_lane;
             avec_t a_nxt[MA];
             float b_nxt[NB][S];
 #pragma unroll
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int c2 = 0; c2 < S; ++c2) b_nxt[nb][c2] = Xs[pix_off[nb] + tap_next + c2 * 2 * p.chs];
+                for (int c2 = 0; c2 < S; ++c2) b_nxt[nb][c2] = Xs[pix_off[nb] + tap_next + c2 * KSTEP * p.chs];
             __builtin_amdgcn_sched_barrier(0);  // reads of tap t+1 stay above the MFMAs of tap t
 #pragma unroll
             for (int c2 = 0; c2 < S; ++c2)
@@ -612,7 +612,8 @@ struct PrepParams {
     int mode;
     int C, M, TR, TC, r0, c0;
     int CK, MT, nchunk, nmb;
-    int a4;  // S > 0: slab layout [tap][k-half][m][S k-steps] (DMA kernel) instead of [tap][ck][m]
+    int a4;  // S > 0: slab layout [tap][k-lane][m][S k-steps] (DMA kernel) instead of [tap][ck][m]
+    int kstep;  // MFMA k per instruction (2 for 32x32x2, 4 for 16x16x4)
 };
 
 __global__ void igemm_prep_weights(const PrepParams q) {
@@ -625,8 +626,8 @@ __global__ void igemm_prep_weights(const PrepParams q) {
         if (q.a4) {  // [mb][cc][tap][lh][mm][c2]  with ck = 2*c2 + lh (32x32x2: k index = lane >> 5)
             const int c2 = (int)(r % q.a4); r /= q.a4;
             mm = (int)(r % q.MT); r /= q.MT;
-            const int lh = (int)(r % 2); r /= 2;
-            ck = 2 * c2 + lh;
+            const int lh = (int)(r % q.kstep); r /= q.kstep;
+            ck = q.kstep * c2 + lh;
         } else {     // [mb][cc][tap][ck][mm]
             mm = (int)(r % q.MT); r /= q.MT;
             ck = (int)(r % q.CK); r /= q.CK;
@@ -666,7 +667,8 @@ struct Plan {
     int dma;  // double-buffered DMA-staged kernel
 };
 
-enum { CFG_M128_L = 100, CFG_M128 = 0, CFG_M128_S, CFG_M64, CFG_M64_S, CFG_M32, CFG_M32_S, CFG_M16_CK4, CFG_M16_CK16, CFG_M16_CK4_L, CFG_M16_CK8, CFG_M16_CK8_L, CFG_D_M128 = 200, CFG_D_M64, CFG_D_M64W4, CFG_D_M128W4, CFG_D_M128W4N2, CFG_D_M128W4_C4, CFG_D_M128_C4, CFG_D_M64W4_C4, CFG_D_M64W4N1_C4 };
+enum { CFG_M128_L = 100, CFG_M128 = 0, CFG_M128_S, CFG_M64, CFG_M64_S, CFG_M32, CFG_M32_S, CFG_M16_CK4, CFG_M16_CK16, CFG_M16_CK4_L, CFG_M16_CK8, CFG_M16_CK8_L, CFG_D_M128 = 200, CFG_D_M64, CFG_D_M64W4, CFG_D_M128W4, CFG_D_M128W4N2, CFG_D_M128W4_C4, CFG_D_M128_C4, CFG_D_M64W4_C4, CFG_D_M64W4N1_C4,
+       CFG_D16_C4 /*209*/, CFG_D16_C4_L, CFG_D16_C16, CFG_D16_C16_L, CFG_D16_C8, CFG_D16_C8_L };
 
 // taps of dy one parity class reads: offsets d in [e - J + 1, e], e = (ph+pad)/s, J = #taps kx = kx0 + s*j < k
 void dgrad_window(int k, int s, int pad, int* r0, int* TR) {
@@ -725,6 +727,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
         if (blocks_for(32, 512) >= kWantBlocks) { pl->cfg = CFG_M32; pl->NPIX = 512; }
         else { pl->cfg = CFG_M32_S; pl->NPIX = 128; }
     } else if (p.C <= 4) { pl->cfg = CFG_M16_CK4; pl->MF = 16; pl->MT = 16; pl->NPIX = 256; pl->CK = 4; }
+    else if (allow_dma && p.N < (1ll << 31) - 1024 && p.TR * p.TC <= 9) { pl->cfg = CFG_D16_C4; pl->MF = 16; pl->MT = 16; pl->NPIX = 256; pl->CK = 4; }
     else { pl->cfg = CFG_M16_CK16; pl->MF = 16; pl->MT = 16; pl->NPIX = 256; pl->CK = 16; }
 
     // tuning override (debug only): CNN_AMD_IGEMM_CFG=<cfg id>
@@ -737,7 +740,9 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
             {CFG_M16_CK8, 16, 16, 256, 8}, {CFG_M16_CK8_L, 16, 16, 512, 8},
             {CFG_D_M128, 32, 128, 256, 8}, {CFG_D_M64, 32, 64, 256, 8}, {CFG_D_M64W4, 32, 64, 256, 8},
             {CFG_D_M128W4, 32, 128, 128, 8}, {CFG_D_M128W4N2, 32, 128, 256, 8}, {CFG_D_M128W4_C4, 32, 128, 128, 4},
-            {CFG_D_M128_C4, 32, 128, 256, 4}, {CFG_D_M64W4_C4, 32, 64, 256, 4}, {CFG_D_M64W4N1_C4, 32, 64, 128, 4}};
+            {CFG_D_M128_C4, 32, 128, 256, 4}, {CFG_D_M64W4_C4, 32, 64, 256, 4}, {CFG_D_M64W4N1_C4, 32, 64, 128, 4},
+            {CFG_D16_C4, 16, 16, 256, 4}, {CFG_D16_C4_L, 16, 16, 512, 4}, {CFG_D16_C16, 16, 16, 256, 16},
+            {CFG_D16_C16_L, 16, 16, 512, 16}, {CFG_D16_C8, 16, 16, 256, 8}, {CFG_D16_C8_L, 16, 16, 512, 8}};
         for (auto& t : tab)
             if (t.cfg == c && p.M <= ((p.M + t.MT - 1) / t.MT) * t.MT && (t.MT >= 32 || p.M <= 16)) {
                 pl->cfg = t.cfg; pl->MF = t.MF; pl->MT = t.MT; pl->NPIX = t.NPIX; pl->CK = t.CK;
@@ -779,7 +784,8 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
 
     q.Co = d->Co; q.Ci = d->Ci; q.k = d->k; q.s = d->s; q.pad = d->pad; q.mode = mode;
     q.C = p.C; q.M = p.M; q.TR = p.TR; q.TC = p.TC; q.r0 = p.r0; q.c0 = p.c0;
-    q.CK = pl->CK; q.MT = pl->MT; q.nchunk = p.nchunk; q.nmb = (int)pl->grid_y; q.a4 = pl->dma ? pl->CK / 2 : 0;
+    q.CK = pl->CK; q.MT = pl->MT; q.nchunk = p.nchunk; q.nmb = (int)pl->grid_y; q.kstep = pl->MF == 32 ? 2 : 4;
+    q.a4 = pl->dma ? pl->CK / q.kstep : 0;
     p.run_mode = (pl->dma && !p.need_zero && p.LW == p.XW && p.XW % 4 == 0) ? 1 : 0;
     return CNN_AMD_OK;
 }
@@ -801,16 +807,16 @@ int launch_cfg(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
     return CNN_AMD_OK;
 }
 
-template <int MA, int NB, int WM, int WN, int S>
+template <int MF, int MA, int NB, int WM, int WN, int S>
 int launch_dma(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
-    auto kern = igemm_dma_kernel<MA, NB, WM, WN, S>;
+    auto kern = igemm_dma_kernel<MF, MA, NB, WM, WN, S>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     char name[96];
-    snprintf(name, sizeof(name), "igemm_dma_kernel<%d,%d,%d,%d,%d>%s", MA, NB, WM, WN, S,
+    snprintf(name, sizeof(name), "igemm_dma_kernel<%d,%d,%d,%d,%d,%d>%s", MF, MA, NB, WM, WN, S,
              pl.p.mode == MODE_FWD ? "/fwd" : "/dgrad");
     CNN_KLAUNCH(s, name, (kern<<<dim3(pl.grid_x, pl.grid_y), 64 * WM * WN, pl.lds_bytes, s>>>(pl.p)), CONV_TAG(d));
     return CNN_AMD_OK;
@@ -830,15 +836,21 @@ int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w,
                 (igemm_prep_weights<<<pg, 256, 0, s>>>(pl.q)), CONV_TAG(d));
     pl.p.X = X; pl.p.A = (const float*)ws; pl.p.bias = bias; pl.p.Y = Y;
     switch (pl.cfg) {
-        case CFG_D_M128: return launch_dma<4, 1, 1, 8, 4>(pl, s, d);
-        case CFG_D_M64: return launch_dma<2, 1, 1, 8, 4>(pl, s, d);
-        case CFG_D_M64W4: return launch_dma<2, 2, 1, 4, 4>(pl, s, d);
-        case CFG_D_M128W4: return launch_dma<4, 1, 1, 4, 4>(pl, s, d);
-        case CFG_D_M128W4N2: return launch_dma<4, 2, 1, 4, 4>(pl, s, d);
-        case CFG_D_M128W4_C4: return launch_dma<4, 1, 1, 4, 2>(pl, s, d);
-        case CFG_D_M128_C4: return launch_dma<4, 1, 1, 8, 2>(pl, s, d);
-        case CFG_D_M64W4_C4: return launch_dma<2, 2, 1, 4, 2>(pl, s, d);
-        case CFG_D_M64W4N1_C4: return launch_dma<2, 1, 1, 4, 2>(pl, s, d);
+        case CFG_D_M128: return launch_dma<32, 4, 1, 1, 8, 4>(pl, s, d);
+        case CFG_D_M64: return launch_dma<32, 2, 1, 1, 8, 4>(pl, s, d);
+        case CFG_D_M64W4: return launch_dma<32, 2, 2, 1, 4, 4>(pl, s, d);
+        case CFG_D_M128W4: return launch_dma<32, 4, 1, 1, 4, 4>(pl, s, d);
+        case CFG_D_M128W4N2: return launch_dma<32, 4, 2, 1, 4, 4>(pl, s, d);
+        case CFG_D_M128W4_C4: return launch_dma<32, 4, 1, 1, 4, 2>(pl, s, d);
+        case CFG_D_M128_C4: return launch_dma<32, 4, 1, 1, 8, 2>(pl, s, d);
+        case CFG_D_M64W4_C4: return launch_dma<32, 2, 2, 1, 4, 2>(pl, s, d);
+        case CFG_D_M64W4N1_C4: return launch_dma<32, 2, 1, 1, 4, 2>(pl, s, d);
+        case CFG_D16_C4: return launch_dma<16, 1, 4, 1, 4, 1>(pl, s, d);
+        case CFG_D16_C4_L: return launch_dma<16, 1, 8, 1, 4, 1>(pl, s, d);
+        case CFG_D16_C16: return launch_dma<16, 1, 4, 1, 4, 4>(pl, s, d);
+        case CFG_D16_C16_L: return launch_dma<16, 1, 8, 1, 4, 4>(pl, s, d);
+        case CFG_D16_C8: return launch_dma<16, 1, 4, 1, 4, 2>(pl, s, d);
+        case CFG_D16_C8_L: return launch_dma<16, 1, 8, 1, 4, 2>(pl, s, d);
         case CFG_M128_L: return launch_cfg<32, 4, 2, 1, 4, 8>(pl, s, d);
         case CFG_M128: return launch_cfg<32, 4, 1, 1, 4, 8>(pl, s, d);
         case CFG_M128_S: return launch_cfg<32, 2, 1, 2, 2, 8>(pl, s, d);
