@@ -34,6 +34,8 @@ struct WgradParams {
     long long chunks_total;
     int chunks_per_split;
     int rwd_shift, rwx_shift;  // log2(lanes per staged dy / x row)
+    int fuse_bias;             // column Ntot of the output tile accumulates sum(dy) (B operand = 1): the bias gradient
+    int pitch;                 // floats per output row of a partial slab (Ntot, or Ntot + 1 when fuse_bias)
 };
 
 template <int MF>
@@ -79,11 +81,13 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void wgrad_kernel(const Wgrad
     const int ci_first = (nblk * NTB) / kk2;
 
     int a_off[MA], b_off[NB];
+    bool ones[NB];  // this lane's column is the fused bias-gradient column
 #pragma unroll
     for (int ma = 0; ma < MA; ++ma) a_off[ma] = ((wm * MA + ma) * MF + li) * p.DROW + lh;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         int n = nblk * NTB + (wn * NB + nb) * MF + li;
+        ones[nb] = p.fuse_bias && n == p.Ntot;
         if (n >= p.Ntot) n = nblk * NTB;  // padded column: reads something valid, never stored
         const int ci = n / kk2, tap = n - ci * kk2, kx = tap / p.k, ky = tap - kx * p.k;
         b_off[nb] = (ci - ci_first) * p.CHS + kx * p.LWc + ky + lh * p.s;
@@ -196,7 +200,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void wgrad_kernel(const Wgrad
 #pragma unroll
                 for (int ma = 0; ma < MA; ++ma) a[ma] = Ds[a_off[ma] + arow + q];
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) bv[nb] = Xs[b_off[nb] + brow + q * p.s];
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float xv = Xs[b_off[nb] + brow + q * p.s];
+                    bv[nb] = ones[nb] ? 1.f : xv;  // dy is 0 on padded pixels, so the ones column sums exactly dy
+                }
 #pragma unroll
                 for (int ma = 0; ma < MA; ++ma)
 #pragma unroll
@@ -206,18 +213,18 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void wgrad_kernel(const Wgrad
     }
 
     // ---- write this (split, wk) slab ----
-    float* out = p.part + ((size_t)split * WK + wk) * p.Co * p.Ntot;
+    float* out = p.part + ((size_t)split * WK + wk) * p.Co * p.pitch;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int n = nblk * NTB + (wn * NB + nb) * MF + li;
-        if (n >= p.Ntot) continue;
+        if (n >= p.pitch) continue;
 #pragma unroll
         for (int ma = 0; ma < MA; ++ma) {
             const int cbase = mblk * MTB + (wm * MA + ma) * MF;
 #pragma unroll
             for (int r = 0; r < M_::kRegs; ++r) {
                 const int co = cbase + M_::row(r, lh);
-                if (co < p.Co) out[(size_t)co * p.Ntot + n] = acc[ma][nb][r];
+                if (co < p.Co) out[(size_t)co * p.pitch + n] = acc[ma][nb][r];
             }
         }
     }
@@ -229,7 +236,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void wgrad_kernel(const Wgrad
 constexpr int kRedElems = 32, kRedLanes = 8;
 __global__ __launch_bounds__(kRedElems * kRedLanes) void slab_reduce(const float* __restrict__ in,
                                                                      float* __restrict__ out, int nslots, size_t n,
-                                                                     int per_group, float divisor, int final_stage) {
+                                                                     int per_group, float divisor, int final_stage,
+                                                                     int split_n, float* __restrict__ out_b) {
     __shared__ float red[kRedLanes][kRedElems];
     const int e = threadIdx.x & (kRedElems - 1), sl = threadIdx.x / kRedElems;
     const size_t i = (size_t)blockIdx.x * kRedElems + e;
@@ -252,23 +260,29 @@ __global__ __launch_bounds__(kRedElems * kRedLanes) void slab_reduce(const float
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < kRedLanes; ++k) t += red[k][e];
-        out[(size_t)g * n + i] = final_stage ? t / divisor : t;
+        if (final_stage && split_n > 0) {  // slab rows are [split_n weight gradients | 1 bias gradient]
+            const size_t row = i / (split_n + 1), col = i - row * (split_n + 1);
+            if (col < (size_t)split_n) out[row * split_n + col] = t / divisor;
+            else if (out_b) out_b[row] = t / divisor;
+        } else {
+            out[(size_t)g * n + i] = final_stage ? t / divisor : t;
+        }
     }
 }
 
 // sums `nslots` slabs of n floats held in `slabs` into dst (divided by divisor); `tmp` holds >= ceil(nslots/64)*n
 int reduce_slabs(hipStream_t s, const float* slabs, int nslots, size_t n, float* tmp, float* dst, float divisor,
-                 const char* tag) {
+                 const char* tag, int split_n = 0, float* dst_b = nullptr) {
     const unsigned gx = (unsigned)((n + kRedElems - 1) / kRedElems);
     if (nslots > 64) {
         const int per = 64, groups = (nslots + per - 1) / per;
         CNN_KLAUNCH(s, "slab_reduce/stage1",
-                    (slab_reduce<<<dim3(gx, groups), kRedElems * kRedLanes, 0, s>>>(slabs, tmp, nslots, n, per, 1.f, 0)), "%s", tag);
+                    (slab_reduce<<<dim3(gx, groups), kRedElems * kRedLanes, 0, s>>>(slabs, tmp, nslots, n, per, 1.f, 0, 0, nullptr)), "%s", tag);
         slabs = tmp;
         nslots = groups;
     }
     CNN_KLAUNCH(s, "slab_reduce/final",
-                (slab_reduce<<<dim3(gx, 1), kRedElems * kRedLanes, 0, s>>>(slabs, dst, nslots, n, nslots, divisor, 1)), "%s", tag);
+                (slab_reduce<<<dim3(gx, 1), kRedElems * kRedLanes, 0, s>>>(slabs, dst, nslots, n, nslots, divisor, 1, split_n, dst_b)), "%s", tag);
     return CNN_AMD_OK;
 }
 
@@ -370,10 +384,13 @@ int make_wplan(const char* who, const cnn_conv2d_desc* d, WPlan* pl) {
     p.chunks_per_split = (int)((p.chunks_total + want - 1) / want);
     pl->nsplit = (int)((p.chunks_total + p.chunks_per_split - 1) / p.chunks_per_split);
     pl->nslots = pl->nsplit * pl->WK;
-    pl->part_floats = (size_t)pl->nslots * p.Co * p.Ntot;
+    p.fuse_bias = (p.Ntot % pl->NTB) != 0 ? 1 : 0;  // a spare padded column exists in the last N block
+    p.pitch = p.Ntot + p.fuse_bias;
+    pl->gy = (unsigned)((p.pitch + pl->NTB - 1) / pl->NTB);
+    pl->part_floats = (size_t)pl->nslots * p.Co * p.pitch;
     pl->bias_groups = p.B < 64 ? p.B : 64;
     pl->bias_floats = (size_t)pl->bias_groups * p.Co;
-    pl->tmp_floats = (size_t)((pl->nslots + 63) / 64) * p.Co * p.Ntot;
+    pl->tmp_floats = (size_t)((pl->nslots + 63) / 64) * p.Co * p.pitch;
     return CNN_AMD_OK;
 }
 
@@ -437,11 +454,15 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
         default: rc = launch_w<16, 1, 2, 1, 1, 4>(pl, s, d); break;
     }
     if (rc) return rc;
-    const size_t n = (size_t)pl.p.Co * pl.p.Ntot;
+    const size_t n = (size_t)pl.p.Co * pl.p.pitch;
     char tag[160];
     snprintf(tag, sizeof(tag), CONV_TAG(d));
     float* bpart = (float*)ws + pl.part_floats;
     float* tmp = bpart + pl.bias_floats;
+    if (pl.p.fuse_bias) {  // weight and bias gradients come out of the same slabs
+        if (int rc2 = reduce_slabs(s, (const float*)ws, pl.nslots, n, tmp, gw, divisor, tag, pl.p.Ntot, gb)) return rc2;
+        return CNN_AMD_OK;
+    }
     if (int rc2 = reduce_slabs(s, (const float*)ws, pl.nslots, n, tmp, gw, divisor, tag)) return rc2;
     if (gb) {
         CNN_KLAUNCH(s, "bias_grad_partial",

@@ -102,6 +102,46 @@ __global__ __launch_bounds__(kBlock) void maxpool_bwd_rows(const float* __restri
     }
 }
 
+// k = step = 2 (the reference net's only pool): one wave per OUTPUT row writes BOTH input rows it covers, so dy and
+// mask are read exactly once; rows/cols past the last window (H or W odd) are zero-filled by the same waves.
+__global__ __launch_bounds__(kBlock) void maxpool_bwd_k2s2(const float* __restrict__ dy, const int32_t* __restrict__ mask,
+                                                           float* __restrict__ dx, long long n_units, int C, int H, int W,
+                                                           int Ho, int Wo) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int extra = H - 2 * Ho;          // 0 or 1 uncovered row at the bottom
+    const int upp = Ho + extra;            // units per plane
+    for (long long u = (long long)blockIdx.x * kWavesPerBlock + wave; u < n_units;
+         u += (long long)gridDim.x * kWavesPerBlock) {
+        const long long plane = u / upp;
+        const int r = (int)(u - plane * upp);
+        const int c = (int)(plane % C);
+        float* xplane = dx + plane * H * W;
+        if (r >= Ho) {  // bottom row no window covers
+            float* row = xplane + (size_t)(2 * Ho + (r - Ho)) * W;
+            for (int w = lane; w < W; w += kWave) row[w] = 0.f;
+            continue;
+        }
+        const float* drow = dy + (plane * Ho + r) * Wo;
+        const int32_t* mrow = mask + (plane * Ho + r) * Wo;
+        float* row0 = xplane + (size_t)(2 * r) * W;
+        float* row1 = row0 + W;
+        const int32_t base = c * H * W + 2 * r * W;
+        for (int wo = lane; wo < Wo; wo += kWave) {
+            const float d = drow[wo];
+            const int off = mrow[wo] - base - 2 * wo;  // 0, 1, W or W+1
+            row0[2 * wo] = (off == 0) ? d : 0.f;
+            row0[2 * wo + 1] = (off == 1) ? d : 0.f;
+            row1[2 * wo] = (off == W) ? d : 0.f;
+            row1[2 * wo + 1] = (off == W + 1) ? d : 0.f;
+        }
+        for (int w = 2 * Wo + lane; w < W; w += kWave) {  // right-hand columns no window covers
+            row0[w] = 0.f;
+            row1[w] = 0.f;
+        }
+    }
+}
+
 inline unsigned row_grid(long long rows) {
     long long need = (rows + kWavesPerBlock - 1) / kWavesPerBlock;
     long long cap = (long long)kNumCU * 16;
@@ -147,9 +187,11 @@ int cnn_maxpool2d_backward(const float* dy, const int32_t* mask, float* dx, int 
     const int Ho = cnn_maxpool2d_out_dim(H, k, step), Wo = cnn_maxpool2d_out_dim(W, k, step);
     const long long rows = (long long)B * C * H;
     hipStream_t s = as_stream(stream);
-    if (k == 2 && step == 2)
-        CNN_KLAUNCH(s, "maxpool_bwd_rows<2,2>",
-                    (maxpool_bwd_rows<2, 2><<<row_grid(rows), kBlock, 0, s>>>(dy, mask, dx, rows, C, H, W, Ho, Wo, k, step)), POOL_TAG);
+    if (k == 2 && step == 2) {
+        const long long units = (long long)B * C * (Ho + (H - 2 * Ho));
+        CNN_KLAUNCH(s, "maxpool_bwd_k2s2", (maxpool_bwd_k2s2<<<row_grid(units), kBlock, 0, s>>>(dy, mask, dx, units, C, H, W, Ho, Wo)),
+                    POOL_TAG);
+    }
     else
         CNN_KLAUNCH(s, "maxpool_bwd_rows<0,0>",
                     (maxpool_bwd_rows<0, 0><<<row_grid(rows), kBlock, 0, s>>>(dy, mask, dx, rows, C, H, W, Ho, Wo, k, step)), POOL_TAG);
