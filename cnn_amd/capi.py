@@ -38,6 +38,9 @@ SIGNATURES = {
     "cnn_conv2d_forward": (C.c_int, [_D, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_backward_weight": (C.c_int, [_D, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P]),
     "cnn_conv2d_backward_data": (C.c_int, [_D, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cnn_conv2d_backward_workspace_bytes": (C.c_size_t, [_D]),
+    "cnn_conv2d_backward": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P, C.c_int]),
+    "cnn_amd_side_stream_join": (C.c_int, [_P]),
     "cnn_conv2d_im2col_workspace_bytes": (C.c_size_t, [_D]),
     "cnn_conv2d_forward_im2col": (C.c_int, [_D, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_backward_weight_im2col": (C.c_int, [_D, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P]),
@@ -122,6 +125,7 @@ class Conv2d:
             raise CnnAmdError("cnn_conv2d_workspace_bytes: " + self.lib.cnn_amd_last_error().decode())
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
         self._im2col_ws = None
+        self._bwd_ws = None
 
     def out_shape(self):
         d = self.desc
@@ -160,6 +164,25 @@ class Conv2d:
         check(self.lib.cnn_conv2d_backward_data(C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(self.ws), self.ws_bytes,
                                                 _stream()), "cnn_conv2d_backward_data")
         return dx
+
+    def backward(self, x, dy, w, divisor, gw=None, gb=None, dx=None, defer_join=False):
+        """both gradients in one call (weight-gradient kernels on the library's side stream, concurrently with dgrad)"""
+        import torch
+
+        _need_gpu(x, dy, w, gw, gb, dx)
+        d = self.desc
+        if self._bwd_ws is None:
+            n = int(self.lib.cnn_conv2d_backward_workspace_bytes(C.byref(d)))
+            self._bwd_ws = torch.empty(n, dtype=torch.uint8, device=x.device)
+        if gw is None:
+            gw = torch.empty((d.Co, d.Ci, d.k, d.k), dtype=torch.float32, device=x.device)
+        if gb is None:
+            gb = torch.empty((d.Co,), dtype=torch.float32, device=x.device)
+        if dx is None:
+            dx = torch.empty((d.B, d.Ci, d.H, d.W), dtype=torch.float32, device=x.device)
+        check(self.lib.cnn_conv2d_backward(C.byref(d), _ptr(x), _ptr(dy), _ptr(w), _ptr(gw), _ptr(gb), _ptr(dx), float(divisor),
+                                           _ptr(self._bwd_ws), self._bwd_ws.numel(), _stream(), 1 if defer_join else 0), "cnn_conv2d_backward")
+        return gw, gb, dx
 
     # ---- im2col functional fallback (parity cross-check only) ----
     def _iws(self, device):
@@ -313,3 +336,8 @@ def kernel_timing_report():
         key, cnt, ms = line.rsplit("\t", 2)
         out[key] = (int(cnt), float(ms))
     return out
+
+
+def side_stream_join():
+    """order the library's side stream (deferred weight gradients) before the current stream"""
+    check(load().cnn_amd_side_stream_join(_stream()), "cnn_amd_side_stream_join")

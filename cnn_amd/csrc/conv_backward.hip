@@ -1,0 +1,72 @@
+// conv_backward.hip -- Conv2D::backward (cpu/src/conv2d.cpp:97-202) as ONE call: the weight/bias-gradient kernels
+// (conv2d.cpp:117-159) and the data-gradient kernels (conv2d.cpp:168-199) only share their inputs, and for the
+// reference net's layers each of them alone is latency-bound, so they run CONCURRENTLY: fork an internal side stream
+// off the caller's stream with an event, join it back with a second event.  The pattern is capturable in a hipGraph.
+#include "common.h"
+
+using namespace cnn_amd;
+
+namespace cnn_amd {
+size_t igemm_workspace_floats(const cnn_conv2d_desc* d);  // conv_igemm.hip
+}
+
+namespace {
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int device = -1;
+};
+int get_side(SideStream** out) {
+    static thread_local SideStream side;
+    int dev = 0;
+    CNN_HIP_CHECK(hipGetDevice(&dev));
+    if (side.stream == nullptr || side.device != dev) {
+        CNN_HIP_CHECK(hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking));
+        CNN_HIP_CHECK(hipEventCreateWithFlags(&side.fork, hipEventDisableTiming));
+        CNN_HIP_CHECK(hipEventCreateWithFlags(&side.join, hipEventDisableTiming));
+        side.device = dev;
+    }
+    *out = &side;
+    return CNN_AMD_OK;
+}
+size_t dgrad_region_bytes(const cnn_conv2d_desc* d) { return ((igemm_workspace_floats(d) + 63) / 64) * 64 * sizeof(float); }
+}  // namespace
+
+extern "C" {
+
+size_t cnn_conv2d_backward_workspace_bytes(const cnn_conv2d_desc* d) {
+    const size_t w = cnn_conv2d_workspace_bytes(d);  // upper bound for the weight-gradient part
+    if (w == 0) return 0;
+    return dgrad_region_bytes(d) + w;
+}
+
+int cnn_amd_side_stream_join(void* stream) {
+    SideStream* side = nullptr;
+    if (int rc = get_side(&side)) return rc;
+    CNN_HIP_CHECK(hipEventRecord(side->join, side->stream));
+    CNN_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), side->join, 0));
+    return CNN_AMD_OK;
+}
+
+int cnn_conv2d_backward(const cnn_conv2d_desc* d, const float* x, const float* dy, const float* w, float* gw, float* gb,
+                        float* dx, float divisor, void* ws, size_t ws_bytes, void* stream, int defer_join) {
+    CNN_REQUIRE(d && x && dy && w && gw && dx && ws, "cnn_conv2d_backward: null pointer");
+    const size_t dbytes = dgrad_region_bytes(d);
+    if (ws_bytes < dbytes + 256)
+        return fail(CNN_AMD_E_WORKSPACE, "cnn_conv2d_backward: workspace %zu B too small", ws_bytes);
+    SideStream* side = nullptr;
+    if (int rc = get_side(&side)) return rc;
+    hipStream_t main = as_stream(stream);
+    char* base = (char*)ws;
+    CNN_HIP_CHECK(hipEventRecord(side->fork, main));
+    CNN_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+    if (int rc = cnn_conv2d_backward_weight(d, x, dy, gw, gb, divisor, base + dbytes, ws_bytes - dbytes, side->stream)) return rc;
+    if (int rc = cnn_conv2d_backward_data(d, dy, w, dx, base, dbytes, main)) return rc;
+    if (!defer_join) {
+        CNN_HIP_CHECK(hipEventRecord(side->join, side->stream));
+        CNN_HIP_CHECK(hipStreamWaitEvent(main, side->join, 0));
+    }
+    return CNN_AMD_OK;
+}
+
+}  // extern "C"

@@ -168,19 +168,25 @@ std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
     assert(saved_input != nullptr && "backward without a recorded forward (no_grad?)");
     const data_type* dy = batch_device_pointer(delta, delta_stage, name + "_dy");
     cnn_conv2d_desc d{B, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding};
-    // conv2d.cpp:117-159: gradients are recomputed (not accumulated) every call and averaged over the batch
-    must(cnn_conv2d_backward_weight(&d, saved_input, dy, grads, grads + (size_t)out_channels * params_for_one_kernel,
-                                    (float)B, workspace, workspace_bytes, stream),
-         "cnn_conv2d_backward_weight");
-    grads_ready = true;
+    // conv2d.cpp:117-199: weight/bias gradients (recomputed, not accumulated, averaged over the batch) and the data
+    // gradient in one call; the library overlaps the two on an internal side stream
     if (delta_buf.empty()) delta_buf.allocate(batch, in_channels, in_H, in_W, name + "_delta");
-    must(cnn_conv2d_backward_data(&d, dy, w_dev(), delta_buf.base, workspace, workspace_bytes, stream),
-         "cnn_conv2d_backward_data");
+    const size_t need = cnn_conv2d_backward_workspace_bytes(&d);
+    if (need > workspace_bytes) {
+        if (workspace) cnn_device_free(workspace);
+        workspace = dev_alloc(need);
+        workspace_bytes = need;
+    }
+    must(cnn_conv2d_backward(&d, saved_input, dy, w_dev(), grads, grads + (size_t)out_channels * params_for_one_kernel,
+                             delta_buf.base, (float)B, workspace, workspace_bytes, stream, /*defer_join=*/1),
+         "cnn_conv2d_backward");  // joined in update_gradients / AlexNet::backward
+    grads_ready = true;
     return delta_buf.views;
 }
 
 void Conv2D::update_gradients(const data_type learning_rate) {
     assert(grads_ready);  // conv2d.cpp:206
+    must(cnn_amd_side_stream_join(stream), "cnn_amd_side_stream_join");
     must(cnn_sgd_update(params, grads, param_count(), learning_rate, 1.f, stream), "cnn_sgd_update");
 }
 

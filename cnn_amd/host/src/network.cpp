@@ -79,6 +79,8 @@ void AlexNet::backward(std::vector<tensor>& delta_start) {
         delta_start = (*layer)->backward(delta_start);
         if (print_info) delta_start[0]->print_shape();
     }
+    // the layers' weight gradients were computed on the library's side stream: order them before whatever follows
+    must(cnn_amd_side_stream_join(stream), "cnn_amd_side_stream_join");
 }
 
 void AlexNet::update_gradients(const data_type learning_rate, const data_type grad_scale) {

@@ -121,9 +121,11 @@ class AlexNetHip:
                 cur = self.d_pool
             capi.relu_backward(self.relu_out[l], cur)  # in place on the upstream delta (relu.cpp:37-39)
             lin = self.x if l == 0 else (self.pool_out if l == 1 else self.relu_out[l - 1])
-            self.convs[l].backward_weight(lin, cur, div, self.conv_w(l, g), self.conv_b(l, g))
-            self.convs[l].backward_data(cur, self.conv_w(l), self.d_conv[l])
+            # Conv2D::backward in one call: weight/bias gradient on the library's side stream, concurrently with dgrad
+            self.convs[l].backward(lin, cur, self.conv_w(l), div, self.conv_w(l, g), self.conv_b(l, g), self.d_conv[l],
+                                   defer_join=True)
             cur = self.d_conv[l]
+        capi.side_stream_join()  # all weight gradients are in the arena before SGD / all-reduce read it
 
     # ---- alexnet.cpp:62-65 (+ the data-parallel mean) ----
     def update(self, lr, grad_scale=1.0):

@@ -77,6 +77,17 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
 int cnn_conv2d_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws,
                              size_t ws_bytes, void* stream);
 
+/* Conv2D::backward (conv2d.cpp:97-202) in one call: the weight/bias-gradient kernels run on an internal side stream
+ * CONCURRENTLY with the data-gradient kernels (fork/join by events on `stream`; hipGraph-capturable).  Same results as
+ * the two separate calls.  gb may be NULL. */
+size_t cnn_conv2d_backward_workspace_bytes(const cnn_conv2d_desc* d);
+/* defer_join = 0: gw/gb/dx are all ordered on `stream` when the call returns.  defer_join = 1: only dx is; gw/gb (and this
+ * call's half of ws) belong to the side stream until cnn_amd_side_stream_join(stream) -- lets the weight gradients of
+ * layer L overlap the whole backward of layers L-1.. (the caller joins once, before it reads the gradient arena). */
+int cnn_conv2d_backward(const cnn_conv2d_desc* d, const float* x, const float* dy, const float* w, float* gw, float* gb,
+                        float* dx, float divisor, void* ws, size_t ws_bytes, void* stream, int defer_join);
+int cnn_amd_side_stream_join(void* stream);
+
 /* im2col + plain tiled GEMM: functional fallback kept ONLY for parity checks of the three calls above */
 size_t cnn_conv2d_im2col_workspace_bytes(const cnn_conv2d_desc* d);
 int cnn_conv2d_forward_im2col(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias,

@@ -333,3 +333,19 @@ def test_conv_determinism_and_exact_linearity(T, case):
         g1, b1 = g1.clone(), b1.clone()
         g2, b2 = conv.backward_weight(x, dy, float(B))
         assert T.equal(g1, g2) and T.equal(b1, b2), f"wgrad rep {rep}"
+
+
+def test_conv2d_combined_backward_matches_separate_calls(T):
+    """cnn_conv2d_backward (weight gradient on the side stream || data gradient) == the two separate entry points"""
+    from cnn_amd import capi
+
+    for case in [(4, 16, 55, 55, 32, 3, 2, 0), (3, 64, 13, 13, 128, 3, 2, 0), (2, 3, 224, 224, 16, 3, 2, 0)]:
+        x, w, b, dy = _conv_inputs(case, 300)
+        conv = capi.Conv2d(*case)
+        xd, wd, dyd = dev(T, x), dev(T, w), dev(T, dy)
+        gw1, gb1 = conv.backward_weight(xd, dyd, float(case[0]))
+        dx1 = conv.backward_data(dyd, wd)
+        for _ in range(3):
+            gw2, gb2, dx2 = conv.backward(xd, dyd, wd, float(case[0]))  # defer_join=False: ordered on return
+            T.cuda.synchronize()
+            assert T.equal(gw1, gw2) and T.equal(gb1, gb2) and T.equal(dx1, dx2)
