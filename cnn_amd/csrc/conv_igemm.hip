@@ -140,12 +140,16 @@ __device__ __forceinline__ void compute_chunk(const float* __restrict__ As, cons
             for (int nb = 0; nb < NB; ++nb) b_nxt[nb] = Xs[pix_off[nb] + boff];
             // keep the reads of step s+1 ABOVE the MFMAs of step s (hipcc otherwise sinks them next to their use and
             // every MFMA pair waits a full LDS round trip)
+#ifndef CNN_NO_PIN
             __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int ma = 0; ma < MA; ++ma)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[ma][nb] = A_::mfma(a_cur[ma], b_cur[nb], acc[ma][nb]);
+#ifndef CNN_NO_PIN
             __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int ma = 0; ma < MA; ++ma) a_cur[ma] = a_nxt[ma];
 #pragma unroll
@@ -204,7 +208,8 @@ __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[M
 }
 
 // MF: MFMA tile edge; MA x NB tiles per wave; WM x WN waves per workgroup; CK channels per LDS chunk.
-template <int MF, int MA, int NB, int WM, int WN, int CK>
+// NARROW selects the row-staging scheme at compile time (keeping both in one kernel costs ~50 VGPRs of occupancy).
+template <int MF, int MA, int NB, int WM, int WN, int CK, bool NARROW>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p) {
     using A_ = Acc<MF>;
     constexpr int NWAVES = WM * WN;
@@ -237,13 +242,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
     }
     const int mb = blockIdx.y;
 
-    const long long UV = (long long)p.U * p.V;
-    const long long n0 = (long long)tile * NPIX;
-    const long long n1 = (n0 + NPIX <= p.N ? n0 + NPIX : p.N) - 1;
-    const int b0 = (int)(n0 / UV);
-    const int u0 = (int)((n0 - b0 * UV) / p.V);
-    const int b1 = (int)(n1 / UV);
-    const int u1 = (int)((n1 - b1 * UV) / p.V);
+    // pixel indices fit int32 (make_plan enforces N < 2^31), which keeps the divisions below cheap
+    const int UV = p.U * p.V;
+    const int n0 = tile * NPIX;
+    const int n1 = (n0 + NPIX <= (int)p.N ? n0 + NPIX : (int)p.N) - 1;
+    const int b0 = n0 / UV;
+    const int u0 = (n0 - b0 * UV) / p.V;
+    const int b1 = n1 / UV;
+    const int u1 = (n1 - b1 * UV) / p.V;
     const int nseg = b1 - b0 + 1;
     const int nrows0 = ((nseg == 1 ? u1 : p.U - 1) - u0) * p.su + p.TR;
     const int full = (p.U - 1) * p.su + p.TR;
@@ -283,10 +289,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
     int pix_off[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        long long n = n0 + (wn * NB + nb) * MF + li;
+        int n = n0 + (wn * NB + nb) * MF + li;
         if (n > n1) n = n1;  // clamp: results of padded lanes are never stored
-        const int b = (int)(n / UV);
-        const int rem = (int)(n - b * UV);
+        const int b = n / UV;
+        const int rem = n - b * UV;
         const int u = rem / p.V, v = rem - u * p.V;
         const int lrow = (b == b0) ? (u - u0) * p.su : nrows0 + (b - b0 - 1) * full + u * p.su;
         pix_off[nb] = lrow * p.LW + v * p.su + p.c0 + p.padL + lh * p.chs;
@@ -302,23 +308,26 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
 
     for (int cc = 0; cc < p.nchunk; ++cc) {
         __syncthreads();  // previous chunk's reads are done (and, first time, the zero fill / row table landed)
-        // ---- stage the filter slab: one contiguous block, 4 independent 16-byte loads in flight per thread ----
-        {
+        // ---- stage the filter slab: one contiguous block; every thread has 8 16-byte loads in flight
+        //      before the first LDS store ----
+        if (!(p.dbg & 2)) {
+            // (named registers instead of an array: hipcc leaves a 128-byte private array in scratch memory)
             const float4* src = Ag + (size_t)cc * a_vec;
             float4* dst = (float4*)As;
-            for (int i0 = tid; i0 < a_vec; i0 += NT * 4) {
-                float4 t[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (i0 + u * NT < a_vec) t[u] = src[i0 + u * NT];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (i0 + u * NT < a_vec) dst[i0 + u * NT] = t[u];
+            for (int i0 = tid; i0 < a_vec; i0 += NT * 8) {
+                float4 t0, t1, t2, t3, t4, t5, t6, t7;
+#define CNN_LD(u) if (i0 + u * NT < a_vec) t##u = src[i0 + u * NT];
+#define CNN_ST(u) if (i0 + u * NT < a_vec) dst[i0 + u * NT] = t##u;
+                CNN_LD(0) CNN_LD(1) CNN_LD(2) CNN_LD(3) CNN_LD(4) CNN_LD(5) CNN_LD(6) CNN_LD(7)
+                CNN_ST(0) CNN_ST(1) CNN_ST(2) CNN_ST(3) CNN_ST(4) CNN_ST(5) CNN_ST(6) CNN_ST(7)
+#undef CNN_LD
+#undef CNN_ST
             }
         }
         // ---- stage input rows: a wave covers 64 >> rw_shift rows per load instruction (lanes along the row),
-        //      kUn such instructions are issued back to back before the first LDS store ----
-        {
+        //      kUn such instructions are issued back to back before the first LDS store.  Used for rows wider than 64
+        //      floats, where one channel already provides a full batch of loads. ----
+        if constexpr (!NARROW) if (!(p.dbg & 1)) {
             constexpr int kUn = 4, kMaxC = 4;
             const int RW = 1 << p.rw_shift, RPI = 64 >> p.rw_shift;
             const int sub = lane >> p.rw_shift, col0 = lane & (RW - 1);
@@ -365,11 +374,54 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
                 }
             }
         }
+        // ---- stage input rows (narrow images).  Unit = one wave-wide load = (channel, group of 64>>rw_shift rows, 64-column block);
+        //      units of ALL channels of the chunk are dealt round-robin to the waves and kU of them are in flight per lane
+        //      before the first LDS store, so a chunk costs one or two memory round trips, not one per channel/row. ----
+        if constexpr (NARROW) if (!(p.dbg & 1)) {
+            constexpr int kU = 16;
+            const int RPI = 64 >> p.rw_shift;
+            const int sub = lane >> p.rw_shift, col0 = lane & ((1 << p.rw_shift) - 1);
+            const int ngroups = (nrows + RPI - 1) / RPI;
+            const int ncb = (p.rw_shift == 6) ? (p.XW + 63) / 64 : 1;
+            const int per_ch = ngroups * ncb;
+            const int cvalid = (p.C - cc * CK < CK) ? p.C - cc * CK : CK;  // real channels in this chunk
+            const int NU = cvalid * per_ch;
+            const float* gchunk = p.X + (size_t)cc * CK * p.XH * p.XW;
+            for (int u0 = wave; u0 < NU; u0 += NWAVES * kU) {
+                float v[kU];
+                int ldo[kU];  // LDS float offset of the element this lane stages in slot j, or -1
+#pragma unroll
+                for (int j = 0; j < kU; ++j) {
+                    const int uid = u0 + j * NWAVES;  // wave-uniform
+                    ldo[j] = -1;
+                    if (uid < NU) {
+                        const int ck = uid / per_ch, rem = uid - ck * per_ch;
+                        const int rg = rem / ncb, cbi = rem - rg * ncb;
+                        const int r = rg * RPI + sub, col = cbi * 64 + col0;
+                        const int src = (r < nrows) ? rowsrc[r] : -1;
+                        if (src >= 0 && col < p.XW) {
+                            v[j] = gchunk[((size_t)src + (size_t)ck * p.XH) * p.XW + col];
+                            ldo[j] = ck * p.chs + p.padL + r * p.LW + col;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < kU; ++j)
+                    if (ldo[j] >= 0) Xs[ldo[j]] = v[j];
+            }
+            if (cvalid < CK) {  // channel padding of the last chunk: must be finite
+                for (int ck = cvalid; ck < CK; ++ck)
+                    for (int r = wave; r < nrows; r += NWAVES) {
+                        float* d = Xs + ck * p.chs + p.padL + r * p.LW;
+                        for (int col = lane; col < p.XW; col += 64) d[col] = 0.f;
+                    }
+            }
+        }
         __syncthreads();
-        compute_chunk<MF, MA, NB, CK, MT>(As, Xs, pix_off, a_lane, acc, p);
+        if (!(p.dbg & 4)) compute_chunk<MF, MA, NB, CK, MT>(As, Xs, pix_off, a_lane, acc, p);
     }
 
-    store_tile<MF, MA, NB>(acc, p, n0 + (long long)wn * NB * MF, n1, mbase_wave, li, lh);
+    if (!(p.dbg & 8)) store_tile<MF, MA, NB>(acc, p, n0 + wn * NB * MF, n1, mbase_wave, li, lh);
 }
 
 // ---- double-buffered variant: HBM -> LDS by DMA (global_load_lds), one barrier per chunk -------------------------
@@ -706,7 +758,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     }
     p.N = (long long)p.B * p.U * p.V;
     CNN_REQUIRE((long long)p.B * p.C * p.XH < (1ll << 31), "%s: B*C*H exceeds int32 row index", who);
-    CNN_REQUIRE(p.N / 16 < (1ll << 30), "%s: too many output pixels", who);
+    CNN_REQUIRE(p.N < (1ll << 31) - 4096, "%s: too many output pixels (B*Ho*Wo must stay below 2^31)", who);
 
     // tile choice: the widest pixel tile that still gives every CU a couple of workgroups
     auto blocks_for = [&](int MT, int NPIX) { return ((p.N + NPIX - 1) / NPIX) * ((p.M + MT - 1) / MT); };
@@ -792,9 +844,9 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
 
 #define CONV_TAG(d) "B%d Ci%d %dx%d Co%d k%d s%d p%d", (d)->B, (d)->Ci, (d)->H, (d)->W, (d)->Co, (d)->k, (d)->s, (d)->pad
 
-template <int MF, int MA, int NB, int WM, int WN, int CK>
-int launch_cfg(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
-    auto kern = igemm_kernel<MF, MA, NB, WM, WN, CK>;
+template <int MF, int MA, int NB, int WM, int WN, int CK, bool NARROW>
+int launch_cfg2(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
+    auto kern = igemm_kernel<MF, MA, NB, WM, WN, CK, NARROW>;
     static thread_local size_t max_set = 0;
     if (pl.lds_bytes > 48 * 1024 && pl.lds_bytes > max_set) {
         CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -820,6 +872,12 @@ int launch_dma(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
              pl.p.mode == MODE_FWD ? "/fwd" : "/dgrad");
     CNN_KLAUNCH(s, name, (kern<<<dim3(pl.grid_x, pl.grid_y), 64 * WM * WN, pl.lds_bytes, s>>>(pl.p)), CONV_TAG(d));
     return CNN_AMD_OK;
+}
+
+template <int MF, int MA, int NB, int WM, int WN, int CK>
+int launch_cfg(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
+    return pl.p.XW <= 64 ? launch_cfg2<MF, MA, NB, WM, WN, CK, true>(pl, s, d)
+                         : launch_cfg2<MF, MA, NB, WM, WN, CK, false>(pl, s, d);
 }
 
 int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w, const float* bias, float* Y, void* ws,
