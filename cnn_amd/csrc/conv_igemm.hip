@@ -937,6 +937,9 @@ int check_desc(const char* who, const cnn_conv2d_desc* d) {
 }  // namespace
 
 namespace cnn_amd {
+bool direct_conv_supported(const cnn_conv2d_desc* d);  // conv_direct.hip: thin first layers bypass the implicit GEMM
+int direct_conv_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, hipStream_t s);
+int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, hipStream_t s);
 // scratch floats the forward / dgrad plans need (used by cnn_conv2d_workspace_bytes in conv_wgrad.hip)
 size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
     Plan a, b;
@@ -953,6 +956,7 @@ int cnn_conv2d_forward(const cnn_conv2d_desc* d, const float* x, const float* w,
                        void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_desc("cnn_conv2d_forward", d)) return rc;
     CNN_REQUIRE(x && w && bias && y, "cnn_conv2d_forward: null pointer");
+    if (direct_conv_supported(d)) return direct_conv_forward(d, x, w, bias, y, as_stream(stream));
     Plan pl;
     if (int rc = make_plan("cnn_conv2d_forward", d, MODE_FWD, &pl)) return rc;
     return run_plan(pl, d, x, w, bias, y, ws, ws_bytes, as_stream(stream), "cnn_conv2d_forward");
@@ -962,6 +966,7 @@ int cnn_conv2d_backward_data(const cnn_conv2d_desc* d, const float* dy, const fl
                              size_t ws_bytes, void* stream) {
     if (int rc = check_desc("cnn_conv2d_backward_data", d)) return rc;
     CNN_REQUIRE(dy && w && dx, "cnn_conv2d_backward_data: null pointer");
+    if (direct_conv_supported(d)) return direct_conv_dgrad(d, dy, w, dx, as_stream(stream));
     Plan pl;
     if (int rc = make_plan("cnn_conv2d_backward_data", d, MODE_DGRAD, &pl)) return rc;
     return run_plan(pl, d, dy, w, nullptr, dx, ws, ws_bytes, as_stream(stream), "cnn_conv2d_backward_data");
