@@ -37,7 +37,7 @@ def algorithmic_work(key):
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         flops = 2.0 * B * Co * Ho * Wo * Ci * k * k
         x_b, y_b, w_b = 4.0 * B * Ci * H * W, 4.0 * B * Co * Ho * Wo, 4.0 * Co * Ci * k * k
-        if kernel.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel")):
+        if kernel.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel", "conv_direct")):
             return x_b + y_b + w_b, flops  # fwd: x,w -> y ; dgrad: dy,w -> dx ; wgrad: x,dy -> gw
         if kernel.startswith("bias_grad_partial"):
             return y_b, B * Co * Ho * Wo
