@@ -545,27 +545,34 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         }
         if (p.dbg & 1) return;
         if (p.run_mode) {
-            // every channel's rows of one image segment are one contiguous run (HBM and LDS): 1 KiB per instruction
+            // every channel's rows of one image segment are one contiguous run (HBM and LDS): moved 1 KiB per instruction
+            // when rows are 16-byte multiples (run_mode 1), 256 B per instruction otherwise (run_mode 2)
+            const int unit = (p.run_mode == 1) ? 4 : 1;  // floats per lane
             int lrow0 = 0;
 #pragma nounroll
             for (int sg = 0; sg < nseg; ++sg) {
                 const int nr = (sg == 0) ? nrows0 : ((sg == nseg - 1) ? u1 * p.su + p.TR : full);
                 const int xrow0 = (sg == 0) ? u0 * p.su + p.r0 : p.r0;
-                const int run4 = nr * p.XW / 4;       // float4s per channel run
-                const int per_ch = (run4 + 63) / 64;  // wave-instructions per channel
+                const int runu = nr * p.XW / unit;     // lane-units per channel run
+                const int per_ch = (runu + 63) / 64;   // wave-instructions per channel
                 const size_t gbase = ((size_t)(b0 + sg) * p.C * p.XH + xrow0) * p.XW;
 #pragma nounroll
                 for (int j = wave; j < CK * per_ch; j += NWAVES) {
                     const int ck = j / per_ch, part = j - ck * per_ch;
                     const int c = cc * CK + ck;
                     const int idx = part * 64 + lane;
-                    float* d = Xbuf + ck * p.chs + lrow0 * p.LW + part * 256;
+                    float* d = Xbuf + ck * p.chs + lrow0 * p.LW + part * 64 * unit;
                     if (c < p.C) {
                         const float* g = p.X + gbase + (size_t)c * p.XH * p.XW;
-                        if (idx < run4)
-                            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(g + (size_t)idx * 4), (lds_void_ptr)d, 16, 0, 0);
-                    } else if (idx < run4) {
-                        *(float4*)(d + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (idx < runu) {
+                            if (p.run_mode == 1)
+                                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(g + (size_t)idx * 4), (lds_void_ptr)d, 16, 0, 0);
+                            else
+                                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(g + idx), (lds_void_ptr)d, 4, 0, 0);
+                        }
+                    } else if (idx < runu) {
+                        if (p.run_mode == 1) *(float4*)(d + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                        else d[lane] = 0.f;
                     }
                 }
                 lrow0 += nr;
@@ -720,7 +727,8 @@ struct Plan {
 };
 
 enum { CFG_M128_L = 100, CFG_M128 = 0, CFG_M128_S, CFG_M64, CFG_M64_S, CFG_M32, CFG_M32_S, CFG_M16_CK4, CFG_M16_CK16, CFG_M16_CK4_L, CFG_M16_CK8, CFG_M16_CK8_L, CFG_D_M128 = 200, CFG_D_M64, CFG_D_M64W4, CFG_D_M128W4, CFG_D_M128W4N2, CFG_D_M128W4_C4, CFG_D_M128_C4, CFG_D_M64W4_C4, CFG_D_M64W4N1_C4,
-       CFG_D16_C4 /*209*/, CFG_D16_C4_L, CFG_D16_C16, CFG_D16_C16_L, CFG_D16_C8, CFG_D16_C8_L };
+       CFG_D16_C4 /*209*/, CFG_D16_C4_L, CFG_D16_C16, CFG_D16_C16_L, CFG_D16_C8, CFG_D16_C8_L,
+       CFG_D_M32 /*215*/, CFG_D_M32_C4, CFG_D_M64N1 /*217*/, CFG_D_M128S /*218*/, CFG_D_M128S_C4, CFG_D_M64S /*220*/, CFG_D_M64S_C4 };
 
 // taps of dy one parity class reads: offsets d in [e - J + 1, e], e = (ph+pad)/s, J = #taps kx = kx0 + s*j < k
 void dgrad_window(int k, int s, int pad, int* r0, int* TR) {
@@ -763,10 +771,14 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     // tile choice: the widest pixel tile that still gives every CU a couple of workgroups
     auto blocks_for = [&](int MT, int NPIX) { return ((p.N + NPIX - 1) / NPIX) * ((p.M + MT - 1) / MT); };
     const long long kWantBlocks = 2 * kNumCU;
+    // forward without padding: the DMA kernel can move whole multi-row runs -> worth it even for small images
+    const bool unpadded = (mode == MODE_FWD && d->pad == 0);
+    const bool dma_ok = allow_dma && p.TR * p.TC <= 9 && p.N < (1ll << 31) - 4096;
     if (p.M > 64) {
         pl->MF = 32; pl->MT = 128; pl->CK = 8;
         if (allow_dma && blocks_for(128, 256) >= 2 * kNumCU && p.TR * p.TC <= 9 && p.N < (1ll << 31) - 1024) { pl->cfg = CFG_D_M128; pl->NPIX = 256; }
         else if (blocks_for(128, 128) >= kWantBlocks) { pl->cfg = CFG_M128; pl->NPIX = 128; }
+        else if (dma_ok && unpadded && blocks_for(128, 64) >= kNumCU / 2) { pl->cfg = CFG_D_M128S; pl->NPIX = 64; }
         else { pl->cfg = CFG_M128_S; pl->NPIX = 64; }
     } else if (p.M > 32) {
         pl->MF = 32; pl->MT = 64; pl->CK = 8;
@@ -776,7 +788,9 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
         else { pl->cfg = CFG_M64_S; pl->NPIX = 64; }
     } else if (p.M > 16) {
         pl->MF = 32; pl->MT = 32; pl->CK = 8;
-        if (blocks_for(32, 512) >= kWantBlocks) { pl->cfg = CFG_M32; pl->NPIX = 512; }
+        if (dma_ok && unpadded && blocks_for(32, 128) >= kWantBlocks && blocks_for(32, 512) < 4 * kWantBlocks) {
+            pl->cfg = CFG_D_M32_C4; pl->NPIX = 128; pl->CK = 4;
+        } else if (blocks_for(32, 512) >= kWantBlocks) { pl->cfg = CFG_M32; pl->NPIX = 512; }
         else { pl->cfg = CFG_M32_S; pl->NPIX = 128; }
     } else if (p.C <= 4) { pl->cfg = CFG_M16_CK4; pl->MF = 16; pl->MT = 16; pl->NPIX = 256; pl->CK = 4; }
     else if (allow_dma && p.N < (1ll << 31) - 1024 && p.TR * p.TC <= 9) { pl->cfg = CFG_D16_C4; pl->MF = 16; pl->MT = 16; pl->NPIX = 256; pl->CK = 4; }
@@ -794,7 +808,9 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
             {CFG_D_M128W4, 32, 128, 128, 8}, {CFG_D_M128W4N2, 32, 128, 256, 8}, {CFG_D_M128W4_C4, 32, 128, 128, 4},
             {CFG_D_M128_C4, 32, 128, 256, 4}, {CFG_D_M64W4_C4, 32, 64, 256, 4}, {CFG_D_M64W4N1_C4, 32, 64, 128, 4},
             {CFG_D16_C4, 16, 16, 256, 4}, {CFG_D16_C4_L, 16, 16, 512, 4}, {CFG_D16_C16, 16, 16, 256, 16},
-            {CFG_D16_C16_L, 16, 16, 512, 16}, {CFG_D16_C8, 16, 16, 256, 8}, {CFG_D16_C8_L, 16, 16, 512, 8}};
+            {CFG_D16_C16_L, 16, 16, 512, 16}, {CFG_D16_C8, 16, 16, 256, 8}, {CFG_D16_C8_L, 16, 16, 512, 8},
+            {CFG_D_M32, 32, 32, 128, 8}, {CFG_D_M32_C4, 32, 32, 128, 4}, {CFG_D_M64N1, 32, 64, 128, 8},
+            {CFG_D_M128S, 32, 128, 64, 8}, {CFG_D_M128S_C4, 32, 128, 64, 4}, {CFG_D_M64S, 32, 64, 64, 8}, {CFG_D_M64S_C4, 32, 64, 64, 4}};
         for (auto& t : tab)
             if (t.cfg == c && p.M <= ((p.M + t.MT - 1) / t.MT) * t.MT && (t.MT >= 32 || p.M <= 16)) {
                 pl->cfg = t.cfg; pl->MF = t.MF; pl->MT = t.MT; pl->NPIX = t.NPIX; pl->CK = t.CK;
@@ -838,7 +854,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     q.C = p.C; q.M = p.M; q.TR = p.TR; q.TC = p.TC; q.r0 = p.r0; q.c0 = p.c0;
     q.CK = pl->CK; q.MT = pl->MT; q.nchunk = p.nchunk; q.nmb = (int)pl->grid_y; q.kstep = pl->MF == 32 ? 2 : 4;
     q.a4 = pl->dma ? pl->CK / q.kstep : 0;
-    p.run_mode = (pl->dma && !p.need_zero && p.LW == p.XW && p.XW % 4 == 0) ? 1 : 0;
+    p.run_mode = (pl->dma && !p.need_zero && p.LW == p.XW) ? ((p.XW % 4 == 0) ? 1 : 2) : 0;
     return CNN_AMD_OK;
 }
 
@@ -903,6 +919,13 @@ int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w,
         case CFG_D_M128_C4: return launch_dma<32, 4, 1, 1, 8, 2>(pl, s, d);
         case CFG_D_M64W4_C4: return launch_dma<32, 2, 2, 1, 4, 2>(pl, s, d);
         case CFG_D_M64W4N1_C4: return launch_dma<32, 2, 1, 1, 4, 2>(pl, s, d);
+        case CFG_D_M32: return launch_dma<32, 1, 1, 1, 4, 4>(pl, s, d);
+        case CFG_D_M32_C4: return launch_dma<32, 1, 1, 1, 4, 2>(pl, s, d);
+        case CFG_D_M64N1: return launch_dma<32, 2, 1, 1, 4, 4>(pl, s, d);
+        case CFG_D_M128S: return launch_dma<32, 2, 1, 2, 2, 4>(pl, s, d);
+        case CFG_D_M128S_C4: return launch_dma<32, 2, 1, 2, 2, 2>(pl, s, d);
+        case CFG_D_M64S: return launch_dma<32, 1, 1, 2, 2, 4>(pl, s, d);
+        case CFG_D_M64S_C4: return launch_dma<32, 1, 1, 2, 2, 2>(pl, s, d);
         case CFG_D16_C4: return launch_dma<16, 1, 4, 1, 4, 1>(pl, s, d);
         case CFG_D16_C4_L: return launch_dma<16, 1, 8, 1, 4, 1>(pl, s, d);
         case CFG_D16_C16: return launch_dma<16, 1, 4, 1, 4, 4>(pl, s, d);
