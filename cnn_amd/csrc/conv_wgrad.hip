@@ -60,7 +60,8 @@ struct Mfma<16> {
 };
 
 // MA x NB MFMA tiles per wave, WM x WN waves tile the (co, n) block, WK waves split the chunk's rows.
-template <int MF, int MA, int NB, int WM, int WN, int WK>
+// NARROW (compile time): every staged row fits one 64-lane load -> 12 rows x 1 load in flight per lane; otherwise 4 x 4.
+template <int MF, int MA, int NB, int WM, int WN, int WK, bool NARROW>
 __global__ __launch_bounds__(64 * WM * WN * WK, 2) void wgrad_kernel(const WgradParams p) {
     using M_ = Mfma<MF>;
     constexpr int NWAVES = WM * WN * WK;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void wgrad_kernel(const Wgrad
         const int Rv = (p.Ho - p0 < p.R) ? p.Ho - p0 : p.R;
         const int QCv = (p.Wo - q0 < p.QC) ? p.Wo - q0 : p.QC;
         __syncthreads();
-        constexpr int kUn = 4, kMaxC = 4;
+        constexpr int kUn = NARROW ? 12 : 4, kMaxC = NARROW ? 1 : 4;
         // ---- stage dy tile rows (zero beyond the valid columns / rows / channels); narrow rows share a wave-wide
         //      load, kUn loads are in flight per lane before the first LDS store ----
         {
@@ -396,9 +397,9 @@ int make_wplan(const char* who, const cnn_conv2d_desc* d, WPlan* pl) {
 
 #define CONV_TAG(d) "B%d Ci%d %dx%d Co%d k%d s%d p%d", (d)->B, (d)->Ci, (d)->H, (d)->W, (d)->Co, (d)->k, (d)->s, (d)->pad
 
-template <int MF, int MA, int NB, int WM, int WN, int WK>
-int launch_w(const WPlan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
-    auto kern = wgrad_kernel<MF, MA, NB, WM, WN, WK>;
+template <int MF, int MA, int NB, int WM, int WN, int WK, bool NARROW>
+int launch_w2(const WPlan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
+    auto kern = wgrad_kernel<MF, MA, NB, WM, WN, WK, NARROW>;
     static thread_local bool attr_set = false;
     if (pl.lds_bytes > 48 * 1024 && !attr_set) {
         CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -408,6 +409,12 @@ int launch_w(const WPlan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
     snprintf(name, sizeof(name), "wgrad_kernel<%d,%d,%d,%d,%d,%d>", MF, MA, NB, WM, WN, WK);
     CNN_KLAUNCH(s, name, (kern<<<dim3(pl.nsplit, pl.gy, pl.gz), 64 * WM * WN * WK, pl.lds_bytes, s>>>(pl.p)), CONV_TAG(d));
     return CNN_AMD_OK;
+}
+
+template <int MF, int MA, int NB, int WM, int WN, int WK>
+int launch_w(const WPlan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
+    return (pl.p.QCP <= 64 && pl.p.LWc <= 64) ? launch_w2<MF, MA, NB, WM, WN, WK, true>(pl, s, d)
+                                              : launch_w2<MF, MA, NB, WM, WN, WK, false>(pl, s, d);
 }
 
 int check_desc(const char* who, const cnn_conv2d_desc* d) {
