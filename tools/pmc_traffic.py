@@ -19,6 +19,7 @@ def per_kernel(path):
     for r in csv.DictReader(open(path)):
         name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
         name = re.sub(r"^void ", "", name).split("(")[0]
+        name = re.sub(r",\s*(true|false)>$", ">", name)  # compile-time staging variant: same key as the ABI's timer name
         agg[(name, r["Grid_Size"])].append(float(r["Counter_Value"]))
     return agg
 
