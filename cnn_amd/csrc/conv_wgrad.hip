@@ -7,6 +7,8 @@
 // its partial [Co][N] slab and a second kernel adds the slabs in a FIXED order and divides once: deterministic, no
 // atomics.  (The reference divides each sample's sum by B and accumulates, :148; algebraically (1/B)*sum.)
 // Bias gradient (conv2d.cpp:153-157) is a per-channel two-stage reduction of dy.
+#include <cstdlib>
+
 #include "common.h"
 
 using namespace cnn_amd;
@@ -34,6 +36,7 @@ struct WgradParams {
     long long chunks_total;
     int chunks_per_split;
     int rwd_shift, rwx_shift;  // log2(lanes per staged dy / x row)
+    int dbg;                   // ablation bits (CNN_AMD_DBG, tuning only): 1 no dy staging, 2 no x staging, 4 no MFMA
     int fuse_bias;             // column Ntot of the output tile accumulates sum(dy) (B operand = 1): the bias gradient
     int pitch;                 // floats per output row of a partial slab (Ntot, or Ntot + 1 when fuse_bias)
 };
@@ -60,21 +63,27 @@ struct Mfma<16> {
 };
 
 // MA x NB MFMA tiles per wave, WM x WN waves tile the (co, n) block, WK waves split the chunk's rows.
-// NARROW (compile time): every staged row fits one 64-lane load -> 12 rows x 1 load in flight per lane; otherwise 4 x 4.
-template <int MF, int MA, int NB, int WM, int WN, int WK, bool NARROW>
-__global__ __launch_bounds__(64 * WM * WN * WK, 2) void wgrad_kernel(const WgradParams p) {
+// NARROW (compile time): every staged row fits one 64-lane load -> 8 rows x 1 load in flight per lane; otherwise 4 x 4.
+// PC (compile time): producer/consumer wave specialisation.  The workgroup has 2*NWAVES waves; waves [0,NWAVES) only
+// issue MFMAs on chunk c while waves [NWAVES,2*NWAVES) only stage chunk c+1 into the second LDS buffer; one barrier per
+// chunk.  (Two ordinary workgroups per CU were measured to run in lockstep: staging and compute times simply added up.)
+template <int MF, int MA, int NB, int WM, int WN, int WK, bool NARROW, bool PC>
+__global__ __launch_bounds__(64 * WM * WN * WK * (PC ? 2 : 1), PC ? 2 : 2) void wgrad_kernel(const WgradParams p) {
     using M_ = Mfma<MF>;
-    constexpr int NWAVES = WM * WN * WK;
+    constexpr int NWAVES = WM * WN * WK;  // waves per role
     constexpr int MTB = MF * MA * WM;
     constexpr int NTB = MF * NB * WN;
     constexpr int KSTEP = M_::kStep;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int buf_floats = MTB * p.DROW + p.CIB * p.CHS;  // one {dy tile, input rows} pair (PC uses two)
     float* Ds = smem;                              // [MTB][DROW]
     float* Xs = smem + (size_t)MTB * p.DROW;       // [CIB][CHS]
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = PC && wave_all >= NWAVES;                // wave-uniform role
+    const int wave = producer ? wave_all - NWAVES : wave_all;      // index within the role
     const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
     const int li = lane & (MF - 1), lh = lane / MF;
     const int split = blockIdx.x, nblk = blockIdx.y, mblk = blockIdx.z;
@@ -107,18 +116,25 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void wgrad_kernel(const Wgrad
     if (ch_end > p.chunks_total) ch_end = p.chunks_total;
     const int per_img = p.nrc * p.ncc;
 
-    for (long long ch = ch_begin; ch < ch_end; ++ch) {
-        const int b = (int)(ch / per_img);
-        const int rem = (int)(ch - (long long)b * per_img);
+    // stage(ch, dst buffer) and compute(ch, src buffer) as lambdas over the chunk geometry
+    struct ChunkGeo { int b, p0, q0, Rv, QCv; };
+    auto chunk_geo = [&](long long ch) {
+        ChunkGeo g;
+        g.b = (int)(ch / per_img);
+        const int rem = (int)(ch - (long long)g.b * per_img);
         const int rc = rem / p.ncc, cq = rem - rc * p.ncc;
-        const int p0 = rc * p.R, q0 = cq * p.QC;
-        const int Rv = (p.Ho - p0 < p.R) ? p.Ho - p0 : p.R;
-        const int QCv = (p.Wo - q0 < p.QC) ? p.Wo - q0 : p.QC;
-        __syncthreads();
-        constexpr int kUn = NARROW ? 12 : 4, kMaxC = NARROW ? 1 : 4;
+        g.p0 = rc * p.R; g.q0 = cq * p.QC;
+        g.Rv = (p.Ho - g.p0 < p.R) ? p.Ho - g.p0 : p.R;
+        g.QCv = (p.Wo - g.q0 < p.QC) ? p.Wo - g.q0 : p.QC;
+        return g;
+    };
+    auto stage_chunk = [&](const ChunkGeo& g, float* Ds, float* Xs) {
+        const int b = g.b, p0 = g.p0, q0 = g.q0, Rv = g.Rv, QCv = g.QCv;
+        (void)b; (void)p0; (void)q0; (void)Rv; (void)QCv;
+        constexpr int kUn = NARROW ? 8 : 4, kMaxC = NARROW ? 1 : 4;
         // ---- stage dy tile rows (zero beyond the valid columns / rows / channels); narrow rows share a wave-wide
         //      load, kUn loads are in flight per lane before the first LDS store ----
-        {
+        if (!(p.dbg & 1)) {
             const int RW = 1 << p.rwd_shift, RPI = 64 >> p.rwd_shift;
             const int sub = lane >> p.rwd_shift, col0 = lane & (RW - 1);
             const int total = MTB * p.R;
@@ -154,7 +170,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void wgrad_kernel(const Wgrad
             }
         }
         // ---- stage input rows (zero outside the image: padding and the k-step overreach) ----
-        {
+        if (!(p.dbg & 2)) {
             const int RW = 1 << p.rwx_shift, RPI = 64 >> p.rwx_shift;
             const int sub = lane >> p.rwx_shift, col0 = lane & (RW - 1);
             const int total = p.CIB * p.XR;
@@ -191,25 +207,72 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void wgrad_kernel(const Wgrad
                 }
             }
         }
-        __syncthreads();
+    };
+    auto compute_chunk = [&](const ChunkGeo& g, const float* Ds, const float* Xs) {
+        const int b = g.b, p0 = g.p0, q0 = g.q0, Rv = g.Rv, QCv = g.QCv;
+        (void)b; (void)p0; (void)q0; (void)Rv; (void)QCv;
         // ---- MFMA: k-steps walk the chunk's pixels ----
-        for (int r = wk; r < Rv; r += WK) {
+        for (int r = wk; r < Rv && !(p.dbg & 4); r += WK) {
             const int arow = r * p.QCP, brow = r * p.s * p.LWc;
-#pragma unroll 2
-            for (int q = 0; q < p.QCP; q += KSTEP) {
-                float a[MA], bv[NB];
+            // software pipelined by one k-step: the LDS reads of step q+KSTEP are issued above the MFMAs of step q
+            float a_cur[MA], b_cur[NB];
 #pragma unroll
-                for (int ma = 0; ma < MA; ++ma) a[ma] = Ds[a_off[ma] + arow + q];
+            for (int ma = 0; ma < MA; ++ma) a_cur[ma] = Ds[a_off[ma] + arow];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float xv = Xs[b_off[nb] + brow];
+                b_cur[nb] = ones[nb] ? 1.f : xv;  // dy is 0 on padded pixels, so the ones column sums exactly dy
+            }
+            for (int q = 0; q < p.QCP; q += KSTEP) {
+                const int qn = (q + KSTEP < p.QCP) ? q + KSTEP : 0;  // last step: harmless re-read of step 0
+                float a_nxt[MA], b_nxt[NB];
+#pragma unroll
+                for (int ma = 0; ma < MA; ++ma) a_nxt[ma] = Ds[a_off[ma] + arow + qn];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const float xv = Xs[b_off[nb] + brow + q * p.s];
-                    bv[nb] = ones[nb] ? 1.f : xv;  // dy is 0 on padded pixels, so the ones column sums exactly dy
+                    const float xv = Xs[b_off[nb] + brow + qn * p.s];
+                    b_nxt[nb] = ones[nb] ? 1.f : xv;
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ma = 0; ma < MA; ++ma)
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) acc[ma][nb] = M_::run(a[ma], bv[nb], acc[ma][nb]);
+                    for (int nb = 0; nb < NB; ++nb) acc[ma][nb] = M_::run(a_cur[ma], b_cur[nb], acc[ma][nb]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ma = 0; ma < MA; ++ma) a_cur[ma] = a_nxt[ma];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) b_cur[nb] = b_nxt[nb];
             }
+        }
+    };
+
+    if constexpr (!PC) {
+        for (long long ch = ch_begin; ch < ch_end; ++ch) {
+            const ChunkGeo g = chunk_geo(ch);
+            __syncthreads();
+            stage_chunk(g, Ds, Xs);
+            __syncthreads();
+            compute_chunk(g, Ds, Xs);
+        }
+    } else {
+        // Separate loops per role (their live ranges must not overlap: the MFMA role alone needs ~200 VGPRs).  Both roles
+        // execute exactly the same number of barriers: one after the first chunk is staged, then one per chunk.
+        if (producer) {
+            if (ch_begin < ch_end) stage_chunk(chunk_geo(ch_begin), Ds, Xs);
+            __syncthreads();
+            for (long long ch = ch_begin; ch < ch_end; ++ch) {
+                float* Dnxt = smem + (int)((ch - ch_begin + 1) & 1) * buf_floats;
+                if (ch + 1 < ch_end) stage_chunk(chunk_geo(ch + 1), Dnxt, Dnxt + MTB * p.DROW);
+                __syncthreads();  // chunk ch+1 is staged / every MFMA wave is done with chunk ch's buffer
+            }
+            return;
+        }
+        __syncthreads();
+        for (long long ch = ch_begin; ch < ch_end; ++ch) {
+            const float* Dcur = smem + (int)((ch - ch_begin) & 1) * buf_floats;
+            compute_chunk(chunk_geo(ch), Dcur, Dcur + MTB * p.DROW);
+            __syncthreads();
         }
     }
 
@@ -321,6 +384,7 @@ struct WPlan {
     int nsplit, nslots;
     unsigned gy, gz;
     int bias_groups;
+    int pc;  // producer/consumer kernel variant (two LDS buffers)
     size_t part_floats, bias_floats, tmp_floats;
 };
 
@@ -339,6 +403,13 @@ int make_wplan(const char* who, const cnn_conv2d_desc* d, WPlan* pl) {
     else if (p.Co > 16) { pl->cfg = W_32x160; pl->MF = 32; pl->MTB = 32; pl->NTB = 160; pl->WK = 4; pl->threads = 256; }
     else { pl->cfg = W_16x32; pl->MF = 16; pl->MTB = 16; pl->NTB = 32; pl->WK = 4; pl->threads = 256; }
     const int kstep = pl->MF == 32 ? 2 : 4;
+    // wave specialisation pays when the MFMA phase is long enough to hide a chunk's staging (the 128-channel tile)
+    // (measured on MI355X: no gain -- with half the waves loading, the latency-bound staging takes twice as long -- so the
+    //  variant stays opt-in for experiments: CNN_AMD_WGRAD_PC=1)
+    pl->pc = getenv("CNN_AMD_WGRAD_PC") ? atoi(getenv("CNN_AMD_WGRAD_PC")) : 0;
+    const int nbuf = pl->pc ? 2 : 1;
+    const size_t lds_budget = getenv("CNN_AMD_WGRAD_LDS") ? (size_t)atoi(getenv("CNN_AMD_WGRAD_LDS")) * 1024
+                                                          : (pl->pc ? 150 * 1024 : kLdsBudget);
     const int kk2 = d->k * d->k;
     p.CIB = (pl->NTB + kk2 - 2) / kk2 + 1;
     if (p.CIB > p.Ci) p.CIB = p.Ci;
@@ -352,33 +423,34 @@ int make_wplan(const char* who, const cnn_conv2d_desc* d, WPlan* pl) {
     auto lds_for = [&](int R, int QC) {
         const int QCP = (QC + kstep - 1) / kstep * kstep;
         const int XR = (R - 1) * d->s + d->k, LWc = (QCP - 1) * d->s + d->k;
-        return ((size_t)pl->MTB * drow_for(R, QCP) + (size_t)p.CIB * (XR * LWc + 1)) * sizeof(float);
+        return nbuf * ((size_t)pl->MTB * drow_for(R, QCP) + (size_t)p.CIB * (XR * LWc + 1)) * sizeof(float);
     };
     int R = 1, QC = p.Wo;
-    if (lds_for(1, p.Wo) <= kLdsBudget) {
+    if (lds_for(1, p.Wo) <= lds_budget) {
         const int target_pixels = 512;  // enough k-steps per barrier; more only costs LDS
-        while (R < p.Ho && (R + pl->WK) * p.Wo <= target_pixels + p.Wo && lds_for(R + 1, p.Wo) <= kLdsBudget) ++R;
+        while (R < p.Ho && (R + pl->WK) * p.Wo <= target_pixels + p.Wo && lds_for(R + 1, p.Wo) <= lds_budget) ++R;
         if (pl->WK > 1 && R >= pl->WK) R = R / pl->WK * pl->WK;
     } else {
-        while (QC > kstep && lds_for(1, QC) > kLdsBudget) QC = (QC + 1) / 2;
-        CNN_REQUIRE(lds_for(1, QC) <= kLdsBudget, "%s: Ci*k*k tile does not fit LDS (k=%d)", who, d->k);
+        while (QC > kstep && lds_for(1, QC) > lds_budget) QC = (QC + 1) / 2;
+        CNN_REQUIRE(lds_for(1, QC) <= lds_budget, "%s: Ci*k*k tile does not fit LDS (k=%d)", who, d->k);
     }
     p.R = R; p.QC = QC; p.QCP = (QC + kstep - 1) / kstep * kstep;
     p.nrc = (p.Ho + R - 1) / R; p.ncc = (p.Wo + QC - 1) / QC;
     p.DROW = drow_for(R, p.QCP);
     p.XR = (R - 1) * d->s + d->k; p.LWc = (p.QCP - 1) * d->s + d->k; p.CHS = p.XR * p.LWc + 1;
-    pl->lds_bytes = ((size_t)pl->MTB * p.DROW + (size_t)p.CIB * p.CHS) * sizeof(float);
+    pl->lds_bytes = nbuf * ((size_t)pl->MTB * p.DROW + (size_t)p.CIB * p.CHS) * sizeof(float);
     CNN_REQUIRE(pl->lds_bytes <= 160 * 1024, "%s: LDS plan %zu B too large", who, pl->lds_bytes);
     p.rwd_shift = 0;
     while ((1 << p.rwd_shift) < p.QCP && p.rwd_shift < 6) ++p.rwd_shift;
     p.rwx_shift = 0;
     while ((1 << p.rwx_shift) < p.LWc && p.rwx_shift < 6) ++p.rwx_shift;
+    p.dbg = getenv("CNN_AMD_DBG") ? atoi(getenv("CNN_AMD_DBG")) : 0;
     p.chunks_total = (long long)p.B * p.nrc * p.ncc;
     pl->gy = (unsigned)((p.Ntot + pl->NTB - 1) / pl->NTB);
     pl->gz = (unsigned)((p.Co + pl->MTB - 1) / pl->MTB);
     int bpc = (int)((160 * 1024) / pl->lds_bytes);
     if (bpc < 1) bpc = 1;
-    if (bpc > 4) bpc = 4;
+    if (bpc > 8) bpc = 8;
     long long want = (long long)kNumCU * bpc / ((long long)pl->gy * pl->gz);
     if (want < 1) want = 1;
     if (want > p.chunks_total) want = p.chunks_total;
@@ -397,24 +469,46 @@ int make_wplan(const char* who, const cnn_conv2d_desc* d, WPlan* pl) {
 
 #define CONV_TAG(d) "B%d Ci%d %dx%d Co%d k%d s%d p%d", (d)->B, (d)->Ci, (d)->H, (d)->W, (d)->Co, (d)->k, (d)->s, (d)->pad
 
-template <int MF, int MA, int NB, int WM, int WN, int WK, bool NARROW>
-int launch_w2(const WPlan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
-    auto kern = wgrad_kernel<MF, MA, NB, WM, WN, WK, NARROW>;
+template <int MF, int MA, int NB, int WM, int WN, int WK, bool NARROW, bool PC>
+int launch_w2(const WPlan& pl, hipStream_t s, const cnn_conv2d_desc* d, int* nsplit_used) {
+    auto kern = wgrad_kernel<MF, MA, NB, WM, WN, WK, NARROW, PC>;
+    constexpr int kThreads = 64 * WM * WN * WK * (PC ? 2 : 1);
     static thread_local bool attr_set = false;
     if (pl.lds_bytes > 48 * 1024 && !attr_set) {
         CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    // split count = exactly the number of workgroups the chip holds at once (registers + LDS): a larger grid would run a
+    // second, partly empty round.  The plan's nsplit is the upper bound the workspace was sized for.
+    static thread_local size_t occ_lds = (size_t)-1;
+    static thread_local int occ = 0;
+    if (occ_lds != pl.lds_bytes) {
+        int n = 0;
+        CNN_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kThreads, pl.lds_bytes));
+        occ = n < 1 ? 1 : n;
+        occ_lds = pl.lds_bytes;
+    }
+    WgradParams q = pl.p;
+    long long want = (long long)occ * kNumCU / ((long long)pl.gy * pl.gz);
+    if (want < 1) want = 1;
+    if (want > pl.nsplit) want = pl.nsplit;
+    if (want > q.chunks_total) want = q.chunks_total;
+    q.chunks_per_split = (int)((q.chunks_total + want - 1) / want);
+    const int nsplit = (int)((q.chunks_total + q.chunks_per_split - 1) / q.chunks_per_split);
+    *nsplit_used = nsplit;
     char name[96];
-    snprintf(name, sizeof(name), "wgrad_kernel<%d,%d,%d,%d,%d,%d>", MF, MA, NB, WM, WN, WK);
-    CNN_KLAUNCH(s, name, (kern<<<dim3(pl.nsplit, pl.gy, pl.gz), 64 * WM * WN * WK, pl.lds_bytes, s>>>(pl.p)), CONV_TAG(d));
+    snprintf(name, sizeof(name), "wgrad_kernel<%d,%d,%d,%d,%d,%d>%s", MF, MA, NB, WM, WN, WK, PC ? "/pc" : "");
+    CNN_KLAUNCH(s, name, (kern<<<dim3(nsplit, pl.gy, pl.gz), kThreads, pl.lds_bytes, s>>>(q)), CONV_TAG(d));
     return CNN_AMD_OK;
 }
 
 template <int MF, int MA, int NB, int WM, int WN, int WK>
-int launch_w(const WPlan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
-    return (pl.p.QCP <= 64 && pl.p.LWc <= 64) ? launch_w2<MF, MA, NB, WM, WN, WK, true>(pl, s, d)
-                                              : launch_w2<MF, MA, NB, WM, WN, WK, false>(pl, s, d);
+int launch_w(const WPlan& pl, hipStream_t s, const cnn_conv2d_desc* d, int* nsplit_used) {
+    const bool narrow = pl.p.QCP <= 64 && pl.p.LWc <= 64;
+    if (pl.pc) return narrow ? launch_w2<MF, MA, NB, WM, WN, WK, true, true>(pl, s, d, nsplit_used)
+                             : launch_w2<MF, MA, NB, WM, WN, WK, false, true>(pl, s, d, nsplit_used);
+    return narrow ? launch_w2<MF, MA, NB, WM, WN, WK, true, false>(pl, s, d, nsplit_used)
+                  : launch_w2<MF, MA, NB, WM, WN, WK, false, false>(pl, s, d, nsplit_used);
 }
 
 int check_desc(const char* who, const cnn_conv2d_desc* d) {
@@ -453,14 +547,15 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
         return fail(CNN_AMD_E_WORKSPACE, "cnn_conv2d_backward_weight: workspace %zu B < %zu B", ws_bytes, need);
     hipStream_t s = as_stream(stream);
     pl.p.x = x; pl.p.dy = dy; pl.p.part = (float*)ws;
-    int rc;
+    int rc, nsplit_used = pl.nsplit;
     switch (pl.cfg) {
-        case W_128x288: rc = launch_w<32, 1, 9, 4, 1, 1>(pl, s, d); break;
-        case W_64x320: rc = launch_w<32, 1, 5, 2, 2, 1>(pl, s, d); break;
-        case W_32x160: rc = launch_w<32, 1, 5, 1, 1, 4>(pl, s, d); break;
-        default: rc = launch_w<16, 1, 2, 1, 1, 4>(pl, s, d); break;
+        case W_128x288: rc = launch_w<32, 1, 9, 4, 1, 1>(pl, s, d, &nsplit_used); break;
+        case W_64x320: rc = launch_w<32, 1, 5, 2, 2, 1>(pl, s, d, &nsplit_used); break;
+        case W_32x160: rc = launch_w<32, 1, 5, 1, 1, 4>(pl, s, d, &nsplit_used); break;
+        default: rc = launch_w<16, 1, 2, 1, 1, 4>(pl, s, d, &nsplit_used); break;
     }
     if (rc) return rc;
+    pl.nslots = nsplit_used * pl.WK;
     const size_t n = (size_t)pl.p.Co * pl.p.pitch;
     char tag[160];
     snprintf(tag, sizeof(tag), CONV_TAG(d));
