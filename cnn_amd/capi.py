@@ -51,6 +51,9 @@ SIGNATURES = {
     "cnn_relu_backward": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "cnn_linear_forward": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "cnn_linear_backward": (C.c_int, [_P] * 6 + [C.c_int] * 3 + [C.c_float, _P]),
+    "cnn_batchnorm2d_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "cnn_batchnorm2d_forward": (C.c_int, [_P] * 8 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, _P, C.c_size_t, _P]),
+    "cnn_batchnorm2d_backward": (C.c_int, [_P] * 7 + [C.c_int] * 4 + [C.c_float, _P, C.c_size_t, _P]),
     "cnn_sgd_update": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P]),
     "cnn_softmax_xent": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "cnn_device_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
@@ -294,6 +297,37 @@ def linear_backward(x, dy, w, divisor, gw=None, gb=None, dx=None):
     check(load().cnn_linear_backward(_ptr(x), _ptr(dy), _ptr(w), _ptr(gw), _ptr(gb), _ptr(dx), B, n_in, n_out,
                                      float(divisor), _stream()), "cnn_linear_backward")
     return gw, gb, dx
+
+
+class BatchNorm2d:
+    """BatchNorm2D on the HIP path (batchnorm2d.cpp:6-182): owns the workspace and the saved batch statistics; gamma,
+    beta and the moving statistics are caller tensors of [C] (checkpoint order gamma, beta, moving_mean, moving_var,
+    batchnorm2d.cpp:168-173)."""
+
+    def __init__(self, batch, channels, H, W, eps=1e-5, momentum=0.1, device="cuda"):
+        import torch
+
+        self.B, self.C, self.H, self.W, self.eps, self.momentum = batch, channels, H, W, eps, momentum
+        self.ws_bytes = load().cnn_batchnorm2d_workspace_bytes(batch, channels, H, W)
+        self.ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=device)
+        self.saved_mean = torch.zeros(channels, dtype=torch.float32, device=device)
+        self.saved_var = torch.zeros(channels, dtype=torch.float32, device=device)
+
+    def forward(self, x, gamma, beta, moving_mean, moving_var, y, training=True):
+        _need_gpu(x, y, gamma, beta, moving_mean, moving_var)
+        check(load().cnn_batchnorm2d_forward(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(moving_mean), _ptr(moving_var),
+                                             _ptr(self.saved_mean), _ptr(self.saved_var), self.B, self.C, self.H, self.W,
+                                             self.eps, self.momentum, 1 if training else 0, _ptr(self.ws), self.ws_bytes,
+                                             _stream()), "cnn_batchnorm2d_forward")
+        return y
+
+    def backward(self, x, dy, gamma, ggamma, gbeta):
+        """dy -> dx in place (batchnorm2d.cpp:149-155)"""
+        _need_gpu(x, dy, gamma, ggamma, gbeta)
+        check(load().cnn_batchnorm2d_backward(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(self.saved_mean), _ptr(self.saved_var),
+                                              _ptr(ggamma), _ptr(gbeta), self.B, self.C, self.H, self.W, self.eps,
+                                              _ptr(self.ws), self.ws_bytes, _stream()), "cnn_batchnorm2d_backward")
+        return dy
 
 
 def sgd_update(params, grads, lr, grad_scale=1.0):

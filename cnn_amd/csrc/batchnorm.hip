@@ -1,0 +1,352 @@
+// batchnorm.hip -- BatchNorm2D forward / backward (cpu/src/batchnorm2d.cpp:24-95, 98-158); SURVEY.md 8(f) row n1.
+// HBM-bound per-channel reductions over the B strided H*W planes of an NCHW tensor plus an elementwise pass.
+//
+// Work decomposition: a UNIT is up to kSeg consecutive floats of one (b, c) plane; a wavefront owns whole units, so
+// the plane lookup is wave-uniform scalar arithmetic and a wave's loads are one contiguous run.  Planes start at
+// arbitrary 4-byte offsets (H*W is odd for every conv output of the reference net), so a unit is walked in 16-byte
+// SLOTS aligned to the tensor base: interior slots are one dwordx4 access, the two edge slots fall back to
+// per-component guarded accesses.  Grid = (G, C): block (g, c) reduces units g*4+w, +4G, ... of channel c into
+// partial sums part[c][g][k]; the consumer kernel re-reduces the G partials with a fixed lane/xor tree in every
+// block, so results are deterministic and no finalize launch is needed.
+//
+//   forward, training: 3 launches  (sum -> mean | sum (x-u)^2 -> var | apply)     12 + 4 = 16 B / element
+//                                                                                  (x read 3x, y written once)
+//   forward, eval:     1 launch   (apply with the moving statistics)               8 B / element
+//   backward:          2 launches (4 sums | in-place dx)                           8 + 12 = 20 B / element
+// The reference's normed_input buffer (batchnorm2d.cpp:38,71) is NOT materialised: (x-u)*var_inv is recomputed
+// from x and the saved batch statistics, which is the same arithmetic and saves a 4 B/element write + read.
+#include <cstdint>
+
+#include "common.h"
+
+using namespace cnn_amd;
+
+namespace {
+
+constexpr int kWaves = 4;
+constexpr int kBlock = kWave * kWaves;
+constexpr int kSeg = 2048;   // floats per unit (multiple of 4)
+constexpr int kMaxG = 256;   // partial-sum slots per channel (<= 4 per lane in the re-reduction)
+
+struct Geo {
+    int B, C, HW, nseg, G;
+    long long units;  // per channel = B * nseg
+};
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// deterministic sum of part[0..G) (stride `stride` floats), identical in every block that calls it
+__device__ inline float sum_partials(const float* __restrict__ part, int G, int stride, int lane) {
+    float v = 0.f;
+    for (int g = lane; g < G; g += kWave) v += part[(size_t)g * stride];
+    return wave_sum(v);
+}
+
+// walk the unit's 16-byte slots; f4(slot_float_index) handles a full slot, f1(float_index) a single element
+template <class F4, class F1>
+__device__ inline void walk_unit(long long g0, long long g1, int lane, F4&& f4, F1&& f1) {
+    const long long slot0 = g0 >> 2;
+    const int nslots = (int)(((g1 + 3) >> 2) - slot0);
+    for (int t = lane; t < nslots; t += kWave) {
+        const long long e = (slot0 + t) << 2;
+        if (e >= g0 && e + 4 <= g1) {
+            f4(e);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (e + k >= g0 && e + k < g1) f1(e + k);
+        }
+    }
+}
+
+// unit u of channel c -> [g0, g1) as float indices from the tensor base
+__device__ inline void unit_range(const Geo& q, int c, long long u, long long& g0, long long& g1) {
+    const int b = (int)(u / q.nseg);
+    const int sg = (int)(u - (long long)b * q.nseg);
+    const long long base = ((long long)b * q.C + c) * q.HW;
+    const int s0 = sg * kSeg;
+    const int s1 = s0 + kSeg < q.HW ? s0 + kSeg : q.HW;
+    g0 = base + s0;
+    g1 = base + s1;
+}
+
+// block-level: sum NS per-lane accumulators over the 4 waves -> part[(c*G+g)*NS + k]
+template <int NS>
+__device__ inline void block_store_partials(float (&acc)[NS], float* __restrict__ part, int G) {
+    __shared__ float red[kWaves][NS];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const float v = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NS) {
+        float v = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) v += red[w][threadIdx.x];
+        part[((size_t)blockIdx.y * G + blockIdx.x) * NS + threadIdx.x] = v;
+    }
+}
+
+// MODE 0: sum x            (batchnorm2d.cpp:48-55)
+// MODE 1: sum (x - u)^2    (batchnorm2d.cpp:57-63); u = (sum of part_in) / L, block g == 0 also publishes saved_mean
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void bn_stats(const float* __restrict__ x, const float* __restrict__ part_in,
+                                                   float* __restrict__ part_out, float* __restrict__ saved_mean,
+                                                   Geo q) {
+    const int c = blockIdx.y, g = blockIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    float u = 0.f;
+    if (MODE == 1) {
+        u = sum_partials(part_in + (size_t)c * q.G, q.G, 1, lane) / (float)((long long)q.B * q.HW);
+        if (g == 0 && threadIdx.x == 0) saved_mean[c] = u;
+    }
+    float acc[1] = {0.f};
+    for (long long un = (long long)g * kWaves + wave; un < q.units; un += (long long)q.G * kWaves) {
+        long long g0, g1;
+        unit_range(q, c, un, g0, g1);
+        walk_unit(
+            g0, g1, lane,
+            [&](long long e) {
+                const float4 v = *(const float4*)(x + e);
+                if (MODE == 0) {
+                    acc[0] += (v.x + v.y) + (v.z + v.w);
+                } else {
+                    const float a = v.x - u, b = v.y - u, cc = v.z - u, d = v.w - u;
+                    acc[0] += (a * a + b * b) + (cc * cc + d * d);
+                }
+            },
+            [&](long long e) {
+                const float v = x[e];
+                acc[0] += MODE == 0 ? v : (v - u) * (v - u);
+            });
+    }
+    block_store_partials<1>(acc, part_out, q.G);
+}
+
+struct BnApply {
+    const float* x;
+    float* y;
+    const float* gamma;
+    const float* beta;
+    float* moving_mean;
+    float* moving_var;
+    float* saved_mean;  // training: input (published by bn_stats<1>); unused in eval
+    float* saved_var;   // training: output
+    const float* part;  // training: partial sums of (x-u)^2
+    float eps, momentum;
+    int training;
+};
+
+// y = gamma * ((x - u) * var_inv) + beta  (batchnorm2d.cpp:69-77 / 84-92), moving statistics (:79-80)
+__global__ __launch_bounds__(kBlock) void bn_apply(BnApply a, Geo q) {
+#pragma clang fp contract(off)
+    const int c = blockIdx.y, g = blockIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    float u, var;
+    if (a.training) {
+        u = a.saved_mean[c];
+        var = sum_partials(a.part + (size_t)c * q.G, q.G, 1, lane) / (float)((long long)q.B * q.HW);
+        if (g == 0 && threadIdx.x == 0) {
+            a.saved_var[c] = var;
+            a.moving_mean[c] = (1.f - a.momentum) * a.moving_mean[c] + a.momentum * u;
+            a.moving_var[c] = (1.f - a.momentum) * a.moving_var[c] + a.momentum * var;
+        }
+    } else {
+        u = a.moving_mean[c];
+        var = a.moving_var[c];
+    }
+    const float var_inv = 1.f / sqrtf(var + a.eps);
+    const float gm = a.gamma[c], bt = a.beta[c];
+    for (long long un = (long long)g * kWaves + wave; un < q.units; un += (long long)q.G * kWaves) {
+        long long g0, g1;
+        unit_range(q, c, un, g0, g1);
+        walk_unit(
+            g0, g1, lane,
+            [&](long long e) {
+                const float4 v = *(const float4*)(a.x + e);
+                float4 o;
+                o.x = gm * ((v.x - u) * var_inv) + bt;
+                o.y = gm * ((v.y - u) * var_inv) + bt;
+                o.z = gm * ((v.z - u) * var_inv) + bt;
+                o.w = gm * ((v.w - u) * var_inv) + bt;
+                *(float4*)(a.y + e) = o;
+            },
+            [&](long long e) { a.y[e] = gm * ((a.x[e] - u) * var_inv) + bt; });
+    }
+}
+
+// partial sums of the backward pass, per channel (batchnorm2d.cpp:118-146):
+//   [0] sum dy*norm   [1] sum dy   [2] sum (dy*gamma)*(x-u)*(-0.5)*var_inv^3   [3] sum (x-u)
+__global__ __launch_bounds__(kBlock) void bn_bwd_stats(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ saved_mean,
+                                                       const float* __restrict__ saved_var, float* __restrict__ part,
+                                                       float eps, Geo q) {
+    const int c = blockIdx.y, g = blockIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const float u = saved_mean[c];
+    const float var_inv = 1.f / sqrtf(saved_var[c] + eps);
+    const float var_inv_3 = var_inv * var_inv * var_inv;
+    const float gm = gamma[c];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    auto one = [&](float xv, float d) {
+        const float xc = xv - u;
+        acc[0] += d * (xc * var_inv);
+        acc[1] += d;
+        acc[2] += (d * gm) * xc * -0.5f * var_inv_3;
+        acc[3] += xc;
+    };
+    for (long long un = (long long)g * kWaves + wave; un < q.units; un += (long long)q.G * kWaves) {
+        long long g0, g1;
+        unit_range(q, c, un, g0, g1);
+        walk_unit(
+            g0, g1, lane,
+            [&](long long e) {
+                const float4 v = *(const float4*)(x + e);
+                const float4 d = *(const float4*)(dy + e);
+                one(v.x, d.x);
+                one(v.y, d.y);
+                one(v.z, d.z);
+                one(v.w, d.w);
+            },
+            [&](long long e) { one(x[e], dy[e]); });
+    }
+    block_store_partials<4>(acc, part, q.G);
+}
+
+// dx = (dy*gamma)*var_inv + inv*2*(x-u) + u_g/L, in place on dy (batchnorm2d.cpp:148-155)
+__global__ __launch_bounds__(kBlock) void bn_bwd_apply(const float* __restrict__ x, float* __restrict__ dy,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ saved_mean,
+                                                       const float* __restrict__ saved_var,
+                                                       const float* __restrict__ part, float* __restrict__ ggamma,
+                                                       float* __restrict__ gbeta, float eps, Geo q) {
+#pragma clang fp contract(off)
+    const int c = blockIdx.y, g = blockIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const float L = (float)((long long)q.B * q.HW);
+    const float u = saved_mean[c];
+    const float var_inv = 1.f / sqrtf(saved_var[c] + eps);
+    const float gm = gamma[c];
+    const float* pc = part + (size_t)c * q.G * 4;
+    const float s_gg = sum_partials(pc + 0, q.G, 4, lane);
+    const float s_gb = sum_partials(pc + 1, q.G, 4, lane);
+    const float var_g = sum_partials(pc + 2, q.G, 4, lane);
+    const float s_xc = sum_partials(pc + 3, q.G, 4, lane);
+    const float inv = var_g / L;
+    // u_g = sum [ (dy*gamma)*(-var_inv) + inv*(-2)*(x-u) ]  (batchnorm2d.cpp:139-146), from the channel sums
+    const float u_g = (s_gb * gm) * (-var_inv) + inv * -2.f * s_xc;
+    const float u_term = u_g / L;
+    if (g == 0 && threadIdx.x == 0) {
+        ggamma[c] = s_gg;
+        gbeta[c] = s_gb;
+    }
+    const float inv2 = inv * 2.f;
+    for (long long un = (long long)g * kWaves + wave; un < q.units; un += (long long)q.G * kWaves) {
+        long long g0, g1;
+        unit_range(q, c, un, g0, g1);
+        walk_unit(
+            g0, g1, lane,
+            [&](long long e) {
+                const float4 v = *(const float4*)(x + e);
+                float4 d = *(float4*)(dy + e);
+                d.x = (d.x * gm) * var_inv + inv2 * (v.x - u) + u_term;
+                d.y = (d.y * gm) * var_inv + inv2 * (v.y - u) + u_term;
+                d.z = (d.z * gm) * var_inv + inv2 * (v.z - u) + u_term;
+                d.w = (d.w * gm) * var_inv + inv2 * (v.w - u) + u_term;
+                *(float4*)(dy + e) = d;
+            },
+            [&](long long e) { dy[e] = (dy[e] * gm) * var_inv + inv2 * (x[e] - u) + u_term; });
+    }
+}
+
+int make_geo(int B, int C, int H, int W, Geo* q) {
+    CNN_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "batchnorm2d: bad geometry B=%d C=%d H=%d W=%d", B, C, H, W);
+    CNN_REQUIRE((long long)H * W < (1ll << 30), "batchnorm2d: plane too large");
+    q->B = B;
+    q->C = C;
+    q->HW = H * W;
+    q->nseg = (q->HW + kSeg - 1) / kSeg;
+    q->units = (long long)B * q->nseg;
+    // ~2048 workgroups over the chip (8 per CU), at most one wave per unit, at most kMaxG partial slots
+    long long G = (2048 + C - 1) / C;
+    const long long gmax = (q->units + kWaves - 1) / kWaves;
+    if (G > gmax) G = gmax;
+    if (G > kMaxG) G = kMaxG;
+    if (G < 1) G = 1;
+    q->G = (int)G;
+    CNN_REQUIRE(C <= 65535, "batchnorm2d: more than 65535 channels");
+    return CNN_AMD_OK;
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+#define BN_TAG "B%d C%d %dx%d", B, C, H, W
+
+extern "C" {
+
+size_t cnn_batchnorm2d_workspace_bytes(int B, int C, int H, int W) {
+    Geo q;
+    if (make_geo(B, C, H, W, &q) != CNN_AMD_OK) return 0;
+    return (size_t)C * q.G * 4 * sizeof(float) * 2;  // two partial-sum arenas (ping / pong)
+}
+
+int cnn_batchnorm2d_forward(const float* x, float* y, const float* gamma, const float* beta, float* moving_mean,
+                            float* moving_var, float* saved_mean, float* saved_var, int B, int C, int H, int W, float eps,
+                            float momentum, int training, void* workspace, size_t workspace_bytes, void* stream) {
+    Geo q;
+    int rc = make_geo(B, C, H, W, &q);
+    if (rc != CNN_AMD_OK) return rc;
+    CNN_REQUIRE(x && y && gamma && beta && moving_mean && moving_var, "cnn_batchnorm2d_forward: null pointer");
+    CNN_REQUIRE(aligned16(x) && aligned16(y), "cnn_batchnorm2d_forward: x / y must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    const dim3 grid(q.G, C);
+    BnApply a{x, y, gamma, beta, moving_mean, moving_var, saved_mean, saved_var, nullptr, eps, momentum, training ? 1 : 0};
+    if (training) {
+        CNN_REQUIRE(saved_mean && saved_var, "cnn_batchnorm2d_forward: training needs saved_mean / saved_var");
+        CNN_REQUIRE(workspace && workspace_bytes >= cnn_batchnorm2d_workspace_bytes(B, C, H, W),
+                    "cnn_batchnorm2d_forward: workspace too small (%zu bytes)", workspace_bytes);
+        float* p0 = (float*)workspace;
+        float* p1 = p0 + (size_t)C * q.G * 4;
+        CNN_KLAUNCH(s, "bn_stats<0>", (bn_stats<0><<<grid, kBlock, 0, s>>>(x, nullptr, p0, nullptr, q)), BN_TAG);
+        CNN_KLAUNCH(s, "bn_stats<1>", (bn_stats<1><<<grid, kBlock, 0, s>>>(x, p0, p1, saved_mean, q)), BN_TAG);
+        a.part = p1;
+    }
+    CNN_KLAUNCH(s, "bn_apply", (bn_apply<<<grid, kBlock, 0, s>>>(a, q)), BN_TAG);
+    return CNN_AMD_OK;
+}
+
+int cnn_batchnorm2d_backward(const float* x, float* dy, const float* gamma, const float* saved_mean,
+                             const float* saved_var, float* ggamma, float* gbeta, int B, int C, int H, int W, float eps,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    Geo q;
+    int rc = make_geo(B, C, H, W, &q);
+    if (rc != CNN_AMD_OK) return rc;
+    CNN_REQUIRE(x && dy && gamma && saved_mean && saved_var && ggamma && gbeta, "cnn_batchnorm2d_backward: null pointer");
+    CNN_REQUIRE(aligned16(x) && aligned16(dy), "cnn_batchnorm2d_backward: x / dy must be 16-byte aligned");
+    CNN_REQUIRE(workspace && workspace_bytes >= cnn_batchnorm2d_workspace_bytes(B, C, H, W),
+                "cnn_batchnorm2d_backward: workspace too small (%zu bytes)", workspace_bytes);
+    hipStream_t s = as_stream(stream);
+    const dim3 grid(q.G, C);
+    float* part = (float*)workspace;
+    CNN_KLAUNCH(s, "bn_bwd_stats",
+                (bn_bwd_stats<<<grid, kBlock, 0, s>>>(x, dy, gamma, saved_mean, saved_var, part, eps, q)), BN_TAG);
+    CNN_KLAUNCH(s, "bn_bwd_apply",
+                (bn_bwd_apply<<<grid, kBlock, 0, s>>>(x, dy, gamma, saved_mean, saved_var, part, ggamma, gbeta, eps, q)),
+                BN_TAG);
+    return CNN_AMD_OK;
+}
+
+}  // extern "C"

@@ -121,6 +121,26 @@ int cnn_linear_forward(const float* x, const float* w, const float* bias, float*
 int cnn_linear_backward(const float* x, const float* dy, const float* w, float* gw, float* gb, float* dx, int B,
                         int in, int out, float divisor, void* stream);
 
+/* ---- BatchNorm2D : batchnorm2d.cpp:24-95 (forward), :98-158 (backward) ------------------------------- */
+/* Per-channel statistics over (B,H,W) of an NCHW tensor; gamma/beta/moving_mean/moving_var/saved_* are [C].
+ * training != 0 (the reference's !no_grad branch, :46-80): two-pass batch mean and BIASED variance are written to
+ *   saved_mean / saved_var (the reference's buffer_mean / buffer_var), y = gamma*((x-mean)/sqrt(var+eps)) + beta, and
+ *   moving = (1-momentum)*moving + momentum*stat (moving statistics start at 0/0 in the reference, :20).
+ * training == 0 (:82-93): the moving statistics are used; saved_* / workspace may be NULL.
+ * The reference's normed_input buffer is not produced: backward recomputes it from x and saved_*.
+ * x / y / dy must be 16-byte aligned.  workspace: cnn_batchnorm2d_workspace_bytes(B,C,H,W) bytes. */
+size_t cnn_batchnorm2d_workspace_bytes(int B, int C, int H, int W);
+int cnn_batchnorm2d_forward(const float* x, float* y, const float* gamma, const float* beta, float* moving_mean,
+                            float* moving_var, float* saved_mean, float* saved_var, int B, int C, int H, int W,
+                            float eps, float momentum, int training, void* workspace, size_t workspace_bytes,
+                            void* stream);
+/* dy is overwritten with dx IN PLACE, like the reference (:149-155).  ggamma[c] = sum dy*norm, gbeta[c] = sum dy:
+ * plain sums over (B,H,W), NOT divided by the batch (:123-124).  x is the forward input, saved_* the batch
+ * statistics of that forward call. */
+int cnn_batchnorm2d_backward(const float* x, float* dy, const float* gamma, const float* saved_mean,
+                             const float* saved_var, float* ggamma, float* gbeta, int B, int C, int H, int W, float eps,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- SGD step : conv2d.cpp:205-217, linear.cpp:95-102 ---------------------------------------------- */
 /* p -= lr * (g * grad_scale) over one flat parameter arena.  grad_scale = 1 reproduces the reference exactly
  * (two roundings, no FMA); grad_scale = 1/G folds the data-parallel mean after an all-reduce(sum) over G ranks

@@ -32,8 +32,10 @@
 #ifndef ORACLE_REAL
 #define ORACLE_REAL float
 #define SUF(name) name
+#define REAL_SQRT(v) sqrtf(v) /* std::sqrt(data_type) is the float overload */
 #else
 #define SUF(name) name##_f64
+#define REAL_SQRT(v) sqrt(v)
 #endif
 typedef ORACLE_REAL real;
 
@@ -267,6 +269,109 @@ void SUF(oracle_linear_backward)(const real* x, const real* dy, const real* w, r
                 for (int j = 0; j < out; ++j) sum += dy[(size_t)b * out + j] * w[(size_t)i * out + j];
                 dx[(size_t)b * in + i] = sum;
             }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm2D  (cpu/src/batchnorm2d.cpp) -- row n1 of SURVEY.md 8(f)
+ * ---------------------------------------------------------------------------------------- */
+
+/*
+ * batchnorm2d.cpp:24-95.  training != 0 (the !no_grad branch, :46-80): per channel, two-pass batch statistics over
+ * (B,H,W) -- mean (:48-55), then BIASED variance of (x-u)^2 (:57-63) --, saved into saved_mean/saved_var (:64-67),
+ * var_inv = 1/sqrt(var+eps) (:69), norm = (x-u)*var_inv, y = gamma*norm + beta (:70-77), and the moving statistics
+ * m = (1-momentum)*m + momentum*stat (:79-80; they start at 0/0, :20).  training == 0 (:82-93): the moving statistics
+ * are used instead.  norm_out may be NULL (the reference keeps it in normed_input for the backward pass).
+ */
+void SUF(oracle_batchnorm_forward)(const real* x, real* y, real* norm_out, const real* gamma, const real* beta,
+                                   real* moving_mean, real* moving_var, real* saved_mean, real* saved_var, int B, int C,
+                                   int H, int W, real eps, real momentum, int training) {
+    const int hw = H * W;
+    const int L = B * hw;
+    for (int o = 0; o < C; ++o) {
+        real u, var;
+        if (training) {
+            u = 0;
+            for (int b = 0; b < B; ++b) {
+                const real* src = x + ((size_t)b * C + o) * hw;
+                for (int i = 0; i < hw; ++i) u += src[i];
+            }
+            u = u / L;
+            var = 0;
+            for (int b = 0; b < B; ++b) {
+                const real* src = x + ((size_t)b * C + o) * hw;
+                for (int i = 0; i < hw; ++i) var += (src[i] - u) * (src[i] - u);
+            }
+            var = var / L;
+            if (saved_mean) saved_mean[o] = u;
+            if (saved_var) saved_var[o] = var;
+        } else {
+            u = moving_mean[o];
+            var = moving_var[o];
+        }
+        const real var_inv = (real)(1. / REAL_SQRT((real)(var + eps))) /* :69 */;
+        for (int b = 0; b < B; ++b) {
+            const real* src = x + ((size_t)b * C + o) * hw;
+            real* dst = y + ((size_t)b * C + o) * hw;
+            real* nrm = norm_out ? norm_out + ((size_t)b * C + o) * hw : NULL;
+            for (int i = 0; i < hw; ++i) {
+                const real n = (src[i] - u) * var_inv;
+                if (nrm) nrm[i] = n;
+                dst[i] = gamma[o] * n + beta[o];
+            }
+        }
+        if (training) {
+            moving_mean[o] = (1 - momentum) * moving_mean[o] + momentum * u;
+            moving_var[o] = (1 - momentum) * moving_var[o] + momentum * var;
+        }
+    }
+}
+
+/*
+ * batchnorm2d.cpp:98-158, in place on dy like the reference (:149-155).  Per channel:
+ *   ggamma = sum dy*norm, gbeta = sum dy (NOT divided by the batch, :123-124), norm_g = dy*gamma (:125),
+ *   var_g = sum norm_g*(x-u)*(-0.5)*var_inv^3 (:129-137), inv = var_g/L (:140),
+ *   u_g = sum [norm_g*(-var_inv) + inv*(-2)*(x-u)] (:139-146),
+ *   dx = norm_g*var_inv + inv*2*(x-u) + u_g/L (:148-155).
+ */
+void SUF(oracle_batchnorm_backward)(const real* x, real* dy, const real* gamma, const real* saved_mean,
+                                    const real* saved_var, real* ggamma, real* gbeta, int B, int C, int H, int W,
+                                    real eps) {
+    const int hw = H * W;
+    const int L = B * hw;
+    for (int o = 0; o < C; ++o) {
+        const real u = saved_mean[o];
+        const real var_inv = (real)(1. / REAL_SQRT((real)(saved_var[o] + eps))) /* :110 */;
+        const real var_inv_3 = var_inv * var_inv * var_inv;
+        real gg = 0, gb = 0, var_g = 0;
+        for (int b = 0; b < B; ++b) {
+            const real* d = dy + ((size_t)b * C + o) * hw;
+            const real* src = x + ((size_t)b * C + o) * hw;
+            for (int i = 0; i < hw; ++i) {
+                const real n = (src[i] - u) * var_inv;
+                gg += d[i] * n;
+                gb += d[i];
+            }
+        }
+        for (int b = 0; b < B; ++b) {
+            const real* d = dy + ((size_t)b * C + o) * hw;
+            const real* src = x + ((size_t)b * C + o) * hw;
+            for (int i = 0; i < hw; ++i) var_g += (d[i] * gamma[o]) * (src[i] - u) * (real)(-0.5) * var_inv_3;
+        }
+        const real inv = var_g / L;
+        real u_g = 0;
+        for (int b = 0; b < B; ++b) {
+            const real* d = dy + ((size_t)b * C + o) * hw;
+            const real* src = x + ((size_t)b * C + o) * hw;
+            for (int i = 0; i < hw; ++i) u_g += (d[i] * gamma[o]) * (-var_inv) + inv * (-2) * (src[i] - u);
+        }
+        for (int b = 0; b < B; ++b) {
+            real* d = dy + ((size_t)b * C + o) * hw;
+            const real* src = x + ((size_t)b * C + o) * hw;
+            for (int i = 0; i < hw; ++i) d[i] = (d[i] * gamma[o]) * var_inv + inv * 2 * (src[i] - u) + u_g / L;
+        }
+        ggamma[o] = gg;
+        gbeta[o] = gb;
+    }
 }
 
 /* ------------------------------------------------------------------------------------------

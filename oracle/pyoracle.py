@@ -49,6 +49,8 @@ def _declare(L):
         sig("oracle_relu_backward", None, P, P, C.c_size_t)
         sig("oracle_linear_forward", None, P, P, P, P, I, I, I)
         sig("oracle_linear_backward", None, P, P, P, P, P, P, I, I, I)
+        sig("oracle_batchnorm_forward", None, P, P, P, P, P, P, P, P, P, I, I, I, I, real, real, I)
+        sig("oracle_batchnorm_backward", None, P, P, P, P, P, P, P, I, I, I, I, real)
         sig("oracle_softmax", None, P, P, I, I)
         sig("oracle_cross_entropy_backward", real, P, IP, P, I, I)
         sig("oracle_net_create", C.c_void_p, I, I, I, I)
@@ -169,6 +171,34 @@ def linear_backward(x, dy, w, f64=False):
         _p(x.reshape(B, n_in), ct), _p(dy, ct), _p(w, ct), _p(gw, ct), _p(gb, ct), _p(dx, ct), B, n_in, n_out
     )
     return gw, gb, dx.reshape(x.shape)
+
+
+def batchnorm_forward(x, gamma, beta, moving_mean, moving_var, eps=1e-5, momentum=0.1, training=True, f64=False):
+    """-> (y, norm, saved_mean, saved_var, new_moving_mean, new_moving_var)   (batchnorm2d.cpp:24-95)"""
+    dt, ct, suf = _dt(f64)
+    x = _c(x, dt)
+    B, Cc, H, W = x.shape
+    gamma, beta = _c(gamma, dt), _c(beta, dt)
+    mm = np.array(moving_mean, dtype=dt, order="C", copy=True)
+    mv = np.array(moving_var, dtype=dt, order="C", copy=True)
+    y, norm = np.empty_like(x), np.empty_like(x)
+    sm, sv = np.zeros(Cc, dt), np.zeros(Cc, dt)
+    getattr(lib(), "oracle_batchnorm_forward" + suf)(_p(x, ct), _p(y, ct), _p(norm, ct), _p(gamma, ct), _p(beta, ct), _p(mm, ct),
+                                                     _p(mv, ct), _p(sm, ct), _p(sv, ct), B, Cc, H, W, ct(eps), ct(momentum),
+                                                     1 if training else 0)
+    return y, norm, sm, sv, mm, mv
+
+
+def batchnorm_backward(x, dy, gamma, saved_mean, saved_var, eps=1e-5, f64=False):
+    """-> (dx, ggamma, gbeta); the reference overwrites dy in place (batchnorm2d.cpp:149-155)"""
+    dt, ct, suf = _dt(f64)
+    x, gamma = _c(x, dt), _c(gamma, dt)
+    d = np.array(dy, dtype=dt, order="C", copy=True)
+    B, Cc, H, W = x.shape
+    gg, gb = np.zeros(Cc, dt), np.zeros(Cc, dt)
+    getattr(lib(), "oracle_batchnorm_backward" + suf)(_p(x, ct), _p(d, ct), _p(gamma, ct), _p(_c(saved_mean, dt), ct),
+                                                      _p(_c(saved_var, dt), ct), _p(gg, ct), _p(gb, ct), B, Cc, H, W, ct(eps))
+    return d, gg, gb
 
 
 def sgd_update(p, g, lr, f64=False):

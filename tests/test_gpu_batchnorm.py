@@ -1,0 +1,149 @@
+"""GPU parity of BatchNorm2D (cpu/src/batchnorm2d.cpp) against the CPU oracle, through the C ABI.
+
+Floating-point bar: tensor-normalised 1e-4 (tests/util.py) for activations, gradients and statistics.
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+from tests.util import REL_TOL, assert_close, rel_err, uniform_pm1
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    from cnn_amd import capi
+
+    assert capi.load().cnn_amd_device_arch().decode() == "gfx950"
+    return torch
+
+
+def dev(T, a):
+    return T.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# every BN site of AlexNet(batch_norm=true) (alexnet.cpp:13,17,20,23) at a small batch + ragged / tiny / long planes
+BN_SHAPES = [(2, 16, 111, 111), (3, 32, 27, 27), (4, 64, 13, 13), (5, 128, 6, 6), (1, 1, 1, 1), (2, 3, 1, 5),
+             (1, 2, 70, 71), (7, 5, 3, 3), (2, 4, 64, 64)]
+
+
+@pytest.mark.parametrize("shape", BN_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_batchnorm_train_forward_backward_vs_oracle(T, shape):
+    from cnn_amd import capi
+
+    B, C, H, W = shape
+    x = (uniform_pm1(70, shape) * 2 + 0.5).astype(np.float32)
+    gamma = (uniform_pm1(71, (C,)) + 1.5).astype(np.float32)
+    beta = uniform_pm1(72, (C,)).astype(np.float32)
+    mm0 = uniform_pm1(73, (C,)).astype(np.float32)
+    mv0 = (uniform_pm1(74, (C,)) + 1.5).astype(np.float32)
+    dy = uniform_pm1(75, shape).astype(np.float32)
+
+    y_o, norm_o, sm_o, sv_o, mm_o, mv_o = O.batchnorm_forward(x, gamma, beta, mm0, mv0)
+    dx_o, gg_o, gb_o = O.batchnorm_backward(x, dy, gamma, sm_o, sv_o)
+
+    bn = capi.BatchNorm2d(B, C, H, W)
+    xd, gd, bd, mmd, mvd = dev(T, x), dev(T, gamma), dev(T, beta), dev(T, mm0), dev(T, mv0)
+    yd = T.empty_like(xd)
+    bn.forward(xd, gd, bd, mmd, mvd, yd, training=True)
+    assert_close(host(yd), y_o, what="y")
+    assert_close(host(bn.saved_mean), sm_o, what="batch mean")
+    assert_close(host(bn.saved_var), sv_o, what="batch var")
+    assert_close(host(mmd), mm_o, what="moving mean")
+    assert_close(host(mvd), mv_o, what="moving var")
+
+    dyd = dev(T, dy)
+    ggd, gbd = T.full((C,), 7.0, device="cuda"), T.full((C,), 7.0, device="cuda")  # overwritten, not accumulated (:101-102)
+    bn.backward(xd, dyd, gd, ggd, gbd)
+    if B * H * W > 1:
+        assert_close(host(dyd), dx_o, what="dx (in place)")
+    else:  # one element per channel: dx is pure cancellation noise around 0 in both implementations
+        assert np.abs(host(dyd)).max() <= 1e-3 and np.abs(dx_o).max() <= 1e-3
+    assert_close(host(ggd), gg_o, what="gamma grad")
+    assert_close(host(gbd), gb_o, what="beta grad")
+
+    # determinism: the same call again gives the same bits
+    y2, dy2 = T.empty_like(xd), dev(T, dy)
+    mm2, mv2 = dev(T, mm0), dev(T, mv0)
+    bn.forward(xd, gd, bd, mm2, mv2, y2, training=True)
+    g2, b2 = T.empty_like(ggd), T.empty_like(gbd)
+    bn.backward(xd, dy2, gd, g2, b2)
+    assert T.equal(y2, yd) and T.equal(dy2, dyd) and T.equal(g2, ggd) and T.equal(b2, gbd) and T.equal(mm2, mmd)
+
+
+@pytest.mark.parametrize("shape", BN_SHAPES[:4] + BN_SHAPES[5:7], ids=lambda s: "x".join(map(str, s)))
+def test_batchnorm_eval_uses_moving_statistics(T, shape):
+    from cnn_amd import capi
+
+    B, C, H, W = shape
+    x = uniform_pm1(80, shape).astype(np.float32)
+    gamma = (uniform_pm1(81, (C,)) + 1.5).astype(np.float32)
+    beta = uniform_pm1(82, (C,)).astype(np.float32)
+    mm = uniform_pm1(83, (C,)).astype(np.float32)
+    mv = (uniform_pm1(84, (C,)) + 1.5).astype(np.float32)
+    y_o = O.batchnorm_forward(x, gamma, beta, mm, mv, training=False)[0]
+    bn = capi.BatchNorm2d(B, C, H, W)
+    mmd, mvd = dev(T, mm), dev(T, mv)
+    yd = T.empty(shape, device="cuda")
+    bn.forward(dev(T, x), dev(T, gamma), dev(T, beta), mmd, mvd, yd, training=False)
+    # same arithmetic, no reduction: bit-exact with the oracle, and the moving statistics are untouched (:82-93)
+    assert np.array_equal(host(yd), y_o)
+    assert np.array_equal(host(mmd), mm) and np.array_equal(host(mvd), mv)
+
+
+def test_batchnorm_full_size_properties(T):
+    """BN after conv_layer_1 at the benchmark batch (256 x 16 x 111 x 111): normalised output has per-channel mean
+    beta and variance gamma^2 * var/(var+eps); backward's dx sums to ~0 per channel and is orthogonal to norm."""
+    from cnn_amd import capi
+
+    B, C, H, W = 256, 16, 111, 111
+    g = T.Generator(device="cuda").manual_seed(5)
+    x = T.randn((B, C, H, W), device="cuda", generator=g) * 3 + 1
+    gamma = T.rand(C, device="cuda", generator=g) + 0.5
+    beta = T.rand(C, device="cuda", generator=g)
+    mm, mv = T.zeros(C, device="cuda"), T.zeros(C, device="cuda")
+    bn = capi.BatchNorm2d(B, C, H, W)
+    y = T.empty_like(x)
+    bn.forward(x, gamma, beta, mm, mv, y, training=True)
+    xd = x.double()
+    mean_ref, var_ref = xd.mean(dim=(0, 2, 3)), xd.var(dim=(0, 2, 3), unbiased=False)
+    assert rel_err(host(bn.saved_mean), host(mean_ref)) < REL_TOL and rel_err(host(bn.saved_var), host(var_ref)) < REL_TOL
+    assert rel_err(host(mm), 0.1 * host(mean_ref)) < REL_TOL and rel_err(host(mv), 0.1 * host(var_ref)) < REL_TOL
+    yd = y.double()
+    assert (yd.mean(dim=(0, 2, 3)) - beta.double()).abs().max().item() < 1e-4
+    assert rel_err(host(yd.var(dim=(0, 2, 3), unbiased=False)), host(gamma.double() ** 2 * var_ref / (var_ref + 1e-5))) < REL_TOL
+    dy = T.randn((B, C, H, W), device="cuda", generator=g)
+    dy0 = dy.clone()
+    gg, gb = T.empty(C, device="cuda"), T.empty(C, device="cuda")
+    bn.backward(x, dy, gamma, gg, gb)
+    norm = (xd - mean_ref[None, :, None, None]) / T.sqrt(var_ref + 1e-5)[None, :, None, None]
+    assert rel_err(host(gb), host(dy0.double().sum(dim=(0, 2, 3)))) < REL_TOL
+    assert rel_err(host(gg), host((dy0.double() * norm).sum(dim=(0, 2, 3)))) < REL_TOL
+    # closed form of batchnorm2d.cpp:118-155 in fp64
+    L = B * H * W
+    dn = dy0.double() * gamma.double()[None, :, None, None]
+    ref = (dn - dn.mean(dim=(0, 2, 3), keepdim=True) - norm * (dn * norm).sum(dim=(0, 2, 3), keepdim=True) / L) / T.sqrt(
+        var_ref + 1e-5)[None, :, None, None]
+    assert rel_err(host(dy), host(ref)) < REL_TOL
+
+
+def test_batchnorm_rejects_bad_arguments(T):
+    from cnn_amd import capi
+
+    L = capi.load()
+    x = T.zeros((2, 3, 4, 4), device="cuda")
+    v = T.zeros(3, device="cuda")
+    rc = L.cnn_batchnorm2d_forward(capi._ptr(x), capi._ptr(x), capi._ptr(v), capi._ptr(v), capi._ptr(v), capi._ptr(v),
+                                   None, None, 2, 3, 4, 4, 1e-5, 0.1, 1, None, 0, None)
+    assert rc != 0 and b"saved_mean" in L.cnn_amd_last_error()
+    rc = L.cnn_batchnorm2d_forward(capi._ptr(x), capi._ptr(x), capi._ptr(v), capi._ptr(v), capi._ptr(v), capi._ptr(v),
+                                   capi._ptr(v), capi._ptr(v), 2, 3, 4, 4, 1e-5, 0.1, 1, None, 0, None)
+    assert rc != 0 and b"workspace" in L.cnn_amd_last_error()

@@ -98,3 +98,29 @@ def test_whole_net_gradient_fp64_and_fp32_agree():
     _, delta = O.cross_entropy_backward(probs, labels, f64=True)
     net.backward(delta)
     assert rel_err(net32.grads, net.grads) < 1e-5
+
+
+def test_batchnorm_backward_is_gradient():
+    """BatchNorm2D: oracle backward == derivative of its own training-mode forward, in fp64"""
+    B, C, H, W = 3, 4, 5, 6
+    x = uniform_pm1(60, (B, C, H, W)).astype(np.float64)
+    gamma = (uniform_pm1(61, (C,)) + 1.5).astype(np.float64)
+    beta = uniform_pm1(62, (C,)).astype(np.float64)
+    r = uniform_pm1(63, (B, C, H, W)).astype(np.float64)
+    zeros = np.zeros(C)
+
+    def loss():
+        return float((O.batchnorm_forward(x, gamma, beta, zeros, zeros, f64=True)[0] * r).sum())
+
+    y, norm, sm, sv, mm, mv = O.batchnorm_forward(x, gamma, beta, zeros, zeros, f64=True)
+    dx, gg, gb = O.batchnorm_backward(x, r, gamma, sm, sv, f64=True)
+    assert rel_err(dx, _num_grad(loss, x)) < 1e-6
+    assert rel_err(gg, _num_grad(loss, gamma)) < 1e-7 and rel_err(gb, _num_grad(loss, beta)) < 1e-7
+    # forward semantics: biased variance, moving stats start at 0 and move by momentum 0.1 (batchnorm2d.cpp:20,78-80)
+    assert np.allclose(sm, x.mean(axis=(0, 2, 3))) and np.allclose(sv, x.var(axis=(0, 2, 3)))
+    assert np.allclose(mm, 0.1 * sm) and np.allclose(mv, 0.1 * sv)
+    assert np.allclose(y, gamma[None, :, None, None] * norm + beta[None, :, None, None])
+    # eval mode uses the moving statistics (batchnorm2d.cpp:82-93)
+    ye = O.batchnorm_forward(x, gamma, beta, mm, mv, training=False, f64=True)[0]
+    ref = gamma[None, :, None, None] * (x - mm[None, :, None, None]) / np.sqrt(mv[None, :, None, None] + 1e-5) + beta[None, :, None, None]
+    assert np.allclose(ye, ref, rtol=1e-6)
