@@ -148,8 +148,41 @@ public:
     void bind_arena(data_type* params_dev, data_type* grads_dev) override;
 };
 
-// The reference's fixed network (alexnet.cpp:10-33) as a sequential container.  BatchNorm2D / Dropout / grad_cam are
-// outside this build's scope; batch_norm=true aborts.
+// architectures.h:143-173 / batchnorm2d.cpp.  Device state: gamma [C], beta [C], moving_mean [C], moving_var [C] in ONE
+// block in checkpoint order (batchnorm2d.cpp:168-173); the gradient block has the same shape, its moving_* half stays 0
+// so that the flat-arena SGD kernel leaves the statistics untouched.  The reference's normed_input buffer is not kept
+// (backward recomputes it from the recorded input and the saved batch statistics).
+class BatchNorm2D : public Layer {
+private:
+    const int out_channels;
+    const data_type eps;
+    const data_type momentum;
+    data_type* params = nullptr;
+    data_type* grads = nullptr;
+    bool owns_params = true;
+    bool grads_ready = false;
+    data_type* saved_stats = nullptr;  // batch mean [C] then batch variance [C] (buffer_mean / buffer_var)
+    BatchBuffer out_buf, in_stage, delta_stage;
+    const data_type* saved_input = nullptr;
+    std::vector<tensor> saved_input_tensors;
+    int in_H = 0, in_W = 0, batch = 0;
+    void* workspace = nullptr;
+    size_t workspace_bytes = 0;
+
+public:
+    BatchNorm2D(std::string _name, const int _out_channels, const data_type _eps = 1e-5, const data_type _momentum = 0.1);
+    ~BatchNorm2D() override;
+    std::vector<tensor> forward(const std::vector<tensor>& input) override;
+    std::vector<tensor> backward(std::vector<tensor>& delta) override;
+    void update_gradients(const data_type learning_rate = 1e-4) override;
+    void save_weights(std::ofstream& writer) const override;
+    void load_weights(std::ifstream& reader) override;
+    size_t param_count() const override { return (size_t)4 * out_channels; }
+    void bind_arena(data_type* params_dev, data_type* grads_dev) override;
+};
+
+// The reference's fixed network (alexnet.cpp:10-33) as a sequential container.  Dropout / grad_cam are outside this
+// build's scope.
 class AlexNet {
 public:
     bool print_info = false;
@@ -164,7 +197,7 @@ private:
 public:
     AlexNet(const int num_classes = 3, const bool batch_norm = false);
     // addition: adopt caller-provided device arenas (e.g. torch tensors) so the gradient arena can be all-reduced
-    AlexNet(const int num_classes, data_type* params_dev, data_type* grads_dev);
+    AlexNet(const int num_classes, data_type* params_dev, data_type* grads_dev, const bool batch_norm = false);
     ~AlexNet();
     std::vector<tensor> forward(const std::vector<tensor>& input);
     void backward(std::vector<tensor>& delta_start);
@@ -179,7 +212,7 @@ public:
     const std::list<std::shared_ptr<Layer> >& layers() const { return layers_sequence; }
 
 private:
-    void build(int num_classes);
+    void build(int num_classes, bool batch_norm);
     void bind(data_type* p, data_type* g);
 };
 

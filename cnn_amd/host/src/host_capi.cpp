@@ -37,6 +37,14 @@ void* cnnh_net_create(int classes, float* params_dev, float* grads_dev) {
     h->net = (params_dev && grads_dev) ? new AlexNet(classes, params_dev, grads_dev) : new AlexNet(classes, false);
     return h;
 }
+// batch_norm != 0: AlexNet(classes, true) (alexnet.cpp:13,17,20,23)
+void* cnnh_net_create_ex(int classes, float* params_dev, float* grads_dev, int batch_norm) {
+    Handle* h = new Handle();
+    h->classes = classes;
+    h->net = (params_dev && grads_dev) ? new AlexNet(classes, params_dev, grads_dev, batch_norm != 0)
+                                       : new AlexNet(classes, batch_norm != 0);
+    return h;
+}
 void cnnh_net_destroy(void* hv) {
     Handle* h = (Handle*)hv;
     delete h->net;

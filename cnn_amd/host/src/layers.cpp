@@ -278,6 +278,121 @@ std::vector<tensor> ReLU::backward(std::vector<tensor>& delta) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// BatchNorm2D
+BatchNorm2D::BatchNorm2D(std::string _name, const int _out_channels, const data_type _eps, const data_type _momentum)
+    : Layer(_name), out_channels(_out_channels), eps(_eps), momentum(_momentum) {
+    assert(_out_channels > 0);
+    const size_t n = param_count();
+    params = (data_type*)dev_alloc(sizeof(data_type) * n);
+    grads = (data_type*)dev_alloc(sizeof(data_type) * n);
+    saved_stats = (data_type*)dev_alloc(sizeof(data_type) * 2 * out_channels);
+    std::vector<data_type> host(n, 0);  // batchnorm2d.cpp:18-20: gamma = 1, beta = 0, moving_mean = moving_var = 0
+    for (int o = 0; o < out_channels; ++o) host[o] = 1;
+    must(cnn_memcpy_h2d(params, host.data(), sizeof(data_type) * n, stream), "cnn_memcpy_h2d");
+    must(cnn_memset_zero(grads, sizeof(data_type) * n, stream), "cnn_memset_zero");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+}
+
+BatchNorm2D::~BatchNorm2D() {
+    if (owns_params) {
+        cnn_device_free(params);
+        cnn_device_free(grads);
+    }
+    cnn_device_free(saved_stats);
+    if (workspace) cnn_device_free(workspace);
+}
+
+void BatchNorm2D::bind_arena(data_type* params_dev, data_type* grads_dev) {
+    must(cnn_memcpy_d2d(params_dev, params, sizeof(data_type) * param_count(), stream), "cnn_memcpy_d2d");
+    // the moving_* half of the gradient block must be (and stay) zero: the arena-wide SGD step runs over it
+    must(cnn_memset_zero(grads_dev, sizeof(data_type) * param_count(), stream), "cnn_memset_zero");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+    if (owns_params) {
+        cnn_device_free(params);
+        cnn_device_free(grads);
+    }
+    params = params_dev;
+    grads = grads_dev;
+    owns_params = false;
+}
+
+std::vector<tensor> BatchNorm2D::forward(const std::vector<tensor>& input) {
+    const int B = (int)input.size();
+    const int H = input[0]->H, W = input[0]->W;
+    assert(input[0]->C == out_channels);
+    if (out_buf.empty()) {  // batchnorm2d.cpp:30-35
+        out_buf.allocate(B, out_channels, H, W, name + "_output");
+        output = out_buf.views;
+        batch = B;
+    }
+    assert(B <= batch);
+    in_H = H;
+    in_W = W;
+    const size_t need = cnn_batchnorm2d_workspace_bytes(B, out_channels, H, W);
+    if (need > workspace_bytes) {
+        if (workspace) cnn_device_free(workspace);
+        workspace = dev_alloc(need);
+        workspace_bytes = need;
+    }
+    const data_type* x = batch_device_pointer(input, in_stage, name);
+    if (!no_grad) {  // batchnorm2d.cpp:42
+        saved_input = x;
+        saved_input_tensors = input;
+    }
+    const int C = out_channels;
+    must(cnn_batchnorm2d_forward(x, out_buf.base, params, params + C, params + 2 * C, params + 3 * C, saved_stats,
+                                 saved_stats + C, B, C, H, W, eps, momentum, no_grad ? 0 : 1, workspace, workspace_bytes,
+                                 stream),
+         "cnn_batchnorm2d_forward");
+    return output;
+}
+
+// batchnorm2d.cpp:98-158: gamma / beta gradients (sums over the batch, not averaged) and the data gradient written
+// IN PLACE into the caller's delta, which is handed back
+std::vector<tensor> BatchNorm2D::backward(std::vector<tensor>& delta) {
+    const int B = (int)delta.size();
+    assert(saved_input != nullptr && "backward without a recorded forward (no_grad?)");
+    const int C = out_channels;
+    const bool in_place = delta[0]->on_device();
+    data_type* d = batch_device_pointer_mut(delta, delta_stage, name + "_dy");
+    must(cnn_batchnorm2d_backward(saved_input, d, params, saved_stats, saved_stats + C, grads, grads + C, B, C, in_H, in_W,
+                                  eps, workspace, workspace_bytes, stream),
+         "cnn_batchnorm2d_backward");
+    if (!in_place || d == delta_stage.base) {  // host (or scattered) deltas were staged: write the result back
+        const size_t len = out_buf.sample_len;
+        for (int b = 0; b < B; ++b) {
+            if (delta[b]->on_device())
+                must(cnn_memcpy_d2d(delta[b]->dev, d + len * b, sizeof(data_type) * len, stream), "cnn_memcpy_d2d");
+            else
+                must(cnn_memcpy_d2h(delta[b]->data, d + len * b, sizeof(data_type) * len, stream), "cnn_memcpy_d2h");
+        }
+        must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+    }
+    grads_ready = true;
+    return delta;
+}
+
+void BatchNorm2D::update_gradients(const data_type learning_rate) {  // batchnorm2d.cpp:160-166: gamma and beta only
+    assert(grads_ready);
+    must(cnn_sgd_update(params, grads, (size_t)2 * out_channels, learning_rate, 1.f, stream), "cnn_sgd_update");
+}
+
+// batchnorm2d.cpp:168-182: gamma, beta, moving_mean, moving_var == the device block
+void BatchNorm2D::save_weights(std::ofstream& writer) const {
+    std::vector<data_type> host(param_count());
+    must(cnn_memcpy_d2h(host.data(), params, sizeof(data_type) * host.size(), stream), "cnn_memcpy_d2h");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+    writer.write(reinterpret_cast<const char*>(host.data()), static_cast<std::streamsize>(sizeof(data_type) * host.size()));
+}
+
+void BatchNorm2D::load_weights(std::ifstream& reader) {
+    std::vector<data_type> host(param_count());
+    reader.read(reinterpret_cast<char*>(host.data()), static_cast<std::streamsize>(sizeof(data_type) * host.size()));
+    must(cnn_memcpy_h2d(params, host.data(), sizeof(data_type) * host.size(), stream), "cnn_memcpy_h2d");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // LinearLayer
 LinearLayer::LinearLayer(std::string _name, const int _in_channels, const int _out_channels)
     : Layer(_name), in_channels(_in_channels), out_channels(_out_channels) {

@@ -10,16 +10,21 @@ using namespace architectures;
 using cnn_amd_host::dev_alloc;
 using cnn_amd_host::must;
 
-void AlexNet::build(int num_classes) {
-    // alexnet.cpp:12-31: every convolution is 3x3 with the constructor's default stride 2; one MaxPool(2,2)
+void AlexNet::build(int num_classes, bool batch_norm) {
+    // alexnet.cpp:12-31: every convolution is 3x3 with the constructor's default stride 2; one MaxPool(2,2);
+    // batch_norm inserts a BatchNorm2D between each convolution and its ReLU (:13,17,20,23)
     layers_sequence.emplace_back(new Conv2D("conv_layer_1", 3, 16, 3));
+    if (batch_norm) layers_sequence.emplace_back(new BatchNorm2D("bn_layer_1", 16));
     layers_sequence.emplace_back(new ReLU("relu_layer_1"));
     layers_sequence.emplace_back(new MaxPool2D("max_pool_1", 2, 2));
     layers_sequence.emplace_back(new Conv2D("conv_layer_2", 16, 32, 3));
+    if (batch_norm) layers_sequence.emplace_back(new BatchNorm2D("bn_layer_2", 32));
     layers_sequence.emplace_back(new ReLU("relu_layer_2"));
     layers_sequence.emplace_back(new Conv2D("conv_layer_3", 32, 64, 3));
+    if (batch_norm) layers_sequence.emplace_back(new BatchNorm2D("bn_layer_3", 64));
     layers_sequence.emplace_back(new ReLU("relu_layer_3"));
     layers_sequence.emplace_back(new Conv2D("conv_layer_4", 64, 128, 3));
+    if (batch_norm) layers_sequence.emplace_back(new BatchNorm2D("bn_layer_4", 128));
     layers_sequence.emplace_back(new ReLU("relu_layer_4"));
     layers_sequence.emplace_back(new LinearLayer("linear_1", 6 * 6 * 128, num_classes));
     n_params = 0;
@@ -38,18 +43,16 @@ void AlexNet::bind(data_type* p, data_type* g) {
 }
 
 AlexNet::AlexNet(const int num_classes, const bool batch_norm) {
-    if (batch_norm) {
-        std::cerr << "BatchNorm2D is outside this build's scope (SURVEY.md 8f)\n";
-        std::abort();
-    }
-    build(num_classes);
+    build(num_classes, batch_norm);
     owns_arena = true;
-    bind((data_type*)dev_alloc(sizeof(data_type) * n_params), (data_type*)dev_alloc(sizeof(data_type) * n_params));
-    must(cnn_memset_zero(grad_arena, sizeof(data_type) * n_params, stream), "cnn_memset_zero");
+    data_type* p = (data_type*)dev_alloc(sizeof(data_type) * n_params);
+    data_type* g = (data_type*)dev_alloc(sizeof(data_type) * n_params);
+    must(cnn_memset_zero(g, sizeof(data_type) * n_params, stream), "cnn_memset_zero");
+    bind(p, g);
 }
 
-AlexNet::AlexNet(const int num_classes, data_type* params_dev, data_type* grads_dev) {
-    build(num_classes);
+AlexNet::AlexNet(const int num_classes, data_type* params_dev, data_type* grads_dev, const bool batch_norm) {
+    build(num_classes, batch_norm);
     owns_arena = false;
     bind(params_dev, grads_dev);
 }

@@ -15,6 +15,7 @@ _F = C.POINTER(C.c_float)
 _I = C.POINTER(C.c_int)
 SIGNATURES = {
     "cnnh_net_create": (C.c_void_p, [C.c_int, C.c_void_p, C.c_void_p]),
+    "cnnh_net_create_ex": (C.c_void_p, [C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "cnnh_net_destroy": (None, [C.c_void_p]),
     "cnnh_net_num_params": (C.c_size_t, [C.c_void_p]),
     "cnnh_net_params_device": (C.c_void_p, [C.c_void_p]),
@@ -56,13 +57,13 @@ def _fp(a):
 class HostAlexNet:
     """architectures::AlexNet (cnn_amd/host) behind a handle."""
 
-    def __init__(self, classes=3, params=None, grads=None):
+    def __init__(self, classes=3, params=None, grads=None, batch_norm=False):
         self.lib = load()
         self.classes = classes
         self._keep = (params, grads)  # torch tensors that own the arenas, if any
         p = C.c_void_p(params.data_ptr()) if params is not None else None
         g = C.c_void_p(grads.data_ptr()) if grads is not None else None
-        self.h = C.c_void_p(self.lib.cnnh_net_create(classes, p, g))
+        self.h = C.c_void_p(self.lib.cnnh_net_create_ex(classes, p, g, 1 if batch_norm else 0))
         self.n_params = int(self.lib.cnnh_net_num_params(self.h))
 
     def close(self):

@@ -308,3 +308,82 @@ class Net:
 
     def d_conv(self, l):
         return self._view(self._f("oracle_net_d_conv")(self._h, l), (self.B, self.chans[l]) + self.conv_in_hw[l]).copy()
+
+
+class BnNet:
+    """AlexNet(batch_norm=true) (alexnet.cpp:10-33 with the BatchNorm2D layers of :13,17,20,23) composed from the
+    oracle's layer functions; parameters are one flat vector in checkpoint order (conv w, conv b, then gamma, beta,
+    moving_mean, moving_var of the following BN, ..., linear W, linear b)."""
+
+    CH = [3, 16, 32, 64, 128]
+
+    def __init__(self, classes=3, H=224, W=224):
+        self.classes = classes
+        self.slices, off = {}, 0
+
+        def take(name, n):
+            nonlocal off
+            self.slices[name] = slice(off, off + n)
+            off += n
+
+        h, w = H, W
+        for l in range(4):
+            ci, co = self.CH[l], self.CH[l + 1]
+            take(f"w{l}", co * ci * 9), take(f"b{l}", co)
+            for nm in ("gamma", "beta", "mm", "mv"):
+                take(f"{nm}{l}", co)
+            h, w = conv_out_dim(h, 3, 2), conv_out_dim(w, 3, 2)
+            if l == 0:
+                h, w = (h - 2) // 2 + 1, (w - 2) // 2 + 1
+        self.lin_in = 128 * h * w
+        take("lw", self.lin_in * classes), take("lb", classes)
+        self.n_params = off
+        self.params = np.zeros(off, np.float32)
+        self.grads = np.zeros(off, np.float32)
+        for l in range(4):  # batchnorm2d.cpp:18-20
+            self.params[self.slices[f"gamma{l}"]] = 1
+
+    def p(self, name):
+        return self.params[self.slices[name]]
+
+    def forward(self, x, training=True):
+        B = x.shape[0]
+        cur = _c(x, np.float32)
+        self.t = {"in": [], "conv": [], "relu": [], "sm": [], "sv": []}
+        for l in range(4):
+            ci, co = self.CH[l], self.CH[l + 1]
+            self.t["in"].append(cur)
+            c = conv2d_forward(cur, self.p(f"w{l}").reshape(co, ci, 3, 3), self.p(f"b{l}"), 2)
+            y, _, sm, sv, mm, mv = batchnorm_forward(c, self.p(f"gamma{l}"), self.p(f"beta{l}"), self.p(f"mm{l}"), self.p(f"mv{l}"),
+                                                     training=training)
+            if training:
+                self.p(f"mm{l}")[:] = mm
+                self.p(f"mv{l}")[:] = mv
+            r = relu_forward(y)
+            self.t["conv"].append(c), self.t["relu"].append(r), self.t["sm"].append(sm), self.t["sv"].append(sv)
+            cur = r
+            if l == 0:
+                cur, self.t["mask"] = maxpool_forward(r, 2, 2)
+        self.t["flat"] = cur.reshape(B, -1)
+        return linear_forward(self.t["flat"], self.p("lw").reshape(self.lin_in, self.classes), self.p("lb"))
+
+    def train_step(self, x, labels, lr):
+        logits = self.forward(x, training=True)
+        probs = softmax(logits)
+        loss, delta = cross_entropy_backward(probs, labels)
+        g = self.grads
+        g[:] = 0
+        gw, gb, d = linear_backward(self.t["flat"], delta, self.p("lw").reshape(self.lin_in, self.classes))
+        g[self.slices["lw"]], g[self.slices["lb"]] = gw.ravel(), gb
+        d = d.reshape(self.t["relu"][3].shape)
+        for l in (3, 2, 1, 0):
+            ci, co = self.CH[l], self.CH[l + 1]
+            if l == 0:
+                d = maxpool_backward(d, self.t["mask"], self.t["relu"][0].shape, 2, 2)
+            d = relu_backward(self.t["relu"][l], d)
+            d, gg, gbeta = batchnorm_backward(self.t["conv"][l], d, self.p(f"gamma{l}"), self.t["sm"][l], self.t["sv"][l])
+            g[self.slices[f"gamma{l}"]], g[self.slices[f"beta{l}"]] = gg, gbeta
+            gw, gb, d = conv2d_backward(self.t["in"][l], d, self.p(f"w{l}").reshape(co, ci, 3, 3), 2)
+            g[self.slices[f"w{l}"]], g[self.slices[f"b{l}"]] = gw.ravel(), gb
+        self.params[:] = sgd_update(self.params, g, lr)  # the moving_* slots have zero gradient
+        return loss, probs

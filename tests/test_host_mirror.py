@@ -117,3 +117,64 @@ def test_host_net_device_batch_and_external_arena():
     net.update(1e-3, 1.0)
     torch.cuda.synchronize()
     assert_close(params.cpu().numpy(), onet.params, REL_TOL, "params in the caller's arena")
+
+
+@pytest.mark.gpu
+def test_host_batchnorm_net_train_steps_vs_oracle(tmp_path):
+    """AlexNet(num_classes, batch_norm=true) (alexnet.cpp:13,17,20,23) through the C++ classes against the oracle's
+    composition of the same layers: loss, probabilities, every gradient (BN gradients are batch SUMS), parameters and
+    moving statistics after two SGD steps, eval-mode forward, and the 4-vector checkpoint layout (batchnorm2d.cpp:168-182)."""
+    from cnn_amd import hostapi
+    from oracle import pyoracle as O
+
+    B = 4
+    x = uniform01(50, (B, 3, 224, 224))
+    labels = (np.arange(B) % 3).astype(np.int32)
+    onet = O.BnNet(3)
+    assert onet.n_params == 111267 + 4 * (16 + 32 + 64 + 128)
+    net = hostapi.HostAlexNet(3, batch_norm=True)
+    assert net.n_params == onet.n_params
+    fresh = net.get_params()
+    for l in range(4):  # gamma = 1, beta = 0, moving stats = 0/0 (batchnorm2d.cpp:18-20)
+        assert np.all(fresh[onet.slices[f"gamma{l}"]] == 1) and np.all(fresh[onet.slices[f"beta{l}"]] == 0)
+        assert np.all(fresh[onet.slices[f"mm{l}"]] == 0) and np.all(fresh[onet.slices[f"mv{l}"]] == 0)
+    p0 = normal_scaled(51, (onet.n_params,))
+    for l in range(4):
+        p0[onet.slices[f"gamma{l}"]] = 1 + 0.5 * p0[onet.slices[f"gamma{l}"]]
+        p0[onet.slices[f"mm{l}"]] = 0
+        p0[onet.slices[f"mv{l}"]] = 0
+    p0[onet.slices["lw"]] *= 0.02  # keep the logits tame: a saturated softmax makes the reference's loss log(0)*0 = NaN
+    onet.params[:] = p0
+    net.set_params(p0)
+    for step in range(2):
+        loss, probs = net.train_step_host(x, labels, 1e-3)
+        oloss, oprobs = onet.train_step(x, labels, 1e-3)
+        assert np.isclose(loss, oloss, rtol=2e-4), (step, loss, oloss)
+        assert_close(probs, oprobs, 2e-4, f"step{step} probs")
+        grads, params = net.get_grads(), net.get_params()
+        for name, sl in onet.slices.items():
+            if name.startswith(("mm", "mv")):
+                assert np.all(grads[sl] == 0), name  # statistics are not SGD parameters
+            elif name in ("b0", "b1", "b2", "b3"):
+                # a bias in front of a BatchNorm has an exactly-zero true gradient (BN removes the channel mean): both
+                # sides hold rounding noise, so compare against the scale of the layer's weight gradient instead
+                scale = np.abs(onet.grads[onet.slices["w" + name[1]]]).max()
+                assert np.abs(grads[sl]).max() <= 1e-3 * scale and np.abs(onet.grads[sl]).max() <= 1e-3 * scale, name
+            else:
+                assert_close(grads[sl], onet.grads[sl], 1e-3, f"step{step} grad {name}")
+            assert_close(params[sl], onet.params[sl], 2e-4, f"step{step} param {name}")
+    # eval mode: moving statistics, nothing recorded (batchnorm2d.cpp:82-93)
+    hostapi.load().cnnh_set_no_grad(1)
+    try:
+        logits = net.forward_host(x)
+    finally:
+        hostapi.load().cnnh_set_no_grad(0)
+    assert_close(logits, onet.forward(x, training=False), 5e-4, "eval logits")
+    assert_close(net.get_params(), onet.params, 2e-4, "eval forward leaves the moving statistics alone")
+    out = tmp_path / "bn.model"
+    net.save_checkpoint(out)
+    raw = np.fromfile(out, dtype=np.float32)
+    assert raw.size == onet.n_params and np.array_equal(raw, net.get_params())
+    again = hostapi.HostAlexNet(3, batch_norm=True)
+    again.load_checkpoint(out)
+    assert np.array_equal(again.get_params(), raw)
