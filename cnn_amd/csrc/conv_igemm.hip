@@ -54,6 +54,9 @@ struct IgemmParams {
     int need_zero;      // the row image has pad columns / out-of-image rows -> zero it once
     int run_mode;       // DMA kernel: rows of a channel are one contiguous 16-byte-aligned run
     int dbg;            // ablation bits (CNN_AMD_DBG, tuning only): 1 no X DMA, 2 no A DMA, 4 no MFMA, 8 no stores
+    int tc_inv;         // 65536 / TC + 1: t / TC == (t * tc_inv) >> 16 for the small tap indices used here
+    int ncls;           // dgrad: number of output-parity classes with a tap mask below (0: every tap is used by every row)
+    unsigned cls_mask[16];  // dgrad: bit t set <=> class cls = m / c_out has a filter tap at window position t
 };
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
@@ -439,7 +442,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
 
-template <int MF, int MA, int NB, int WM, int WN, int S>  // S = k-steps per tap = channels per chunk / KSTEP
+//   * XM > 0 ("whole-image" staging, small images): instead of the rows a tile needs, the COMPLETE CK-channel block of
+//     every image the tile touches is staged -- in NCHW that is ONE contiguous run of CK*XH*XW floats per image, so a
+//     chunk costs a handful of DMA instructions with trivial addressing (row staging of 6..27-float rows is bound by
+//     instruction issue, not by bytes).  LDS image = [image][ck][XH*XW]; there are no pad columns / zero rows: XM == 2
+//     masks the B operands of taps that leave the image instead (per-lane row / column bit masks).
+template <int MF, int MA, int NB, int WM, int WN, int S, int XM = 0>  // S = k-steps per tap = channels per chunk / KSTEP
 __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmParams p) {
     using A_ = Acc<MF>;
     constexpr int KSTEP = A_::kStep, CK = KSTEP * S;
@@ -452,7 +460,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = p.TR * p.TC;
     const int a_floats = T * CK * MT;
-    const int buf_floats = a_floats + CK * p.chs;  // one {slab, row image} pair; chs % 4 == 0
+    // one {slab, row image} pair; chs % 4 == 0.  XM != 0: nrows_max holds the number of images a tile can touch
+    const int buf_floats = a_floats + (XM != 0 ? p.nrows_max : 1) * CK * p.chs;
     int* rowsrc = (int*)(smem + 2 * (size_t)buf_floats);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -480,6 +489,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
     const int full = (p.U - 1) * p.su + p.TR;
     const int nrows = (nseg == 1) ? nrows0 : nrows0 + (nseg - 2) * full + u1 * p.su + p.TR;
 
+    if constexpr (XM == 0) {
     for (int r = tid; r < nrows; r += NT) {
         int b, xrow;
         if (r < nrows0) {
@@ -493,7 +503,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         rowsrc[r] = (xrow >= 0 && xrow < p.XH) ? (b * p.C * p.XH + xrow) : -1;
     }
     __syncthreads();
-    if (p.need_zero) {  // pad columns and out-of-image rows of BOTH buffers: never touched by the DMA
+    }
+    if (XM == 0 && p.need_zero) {  // pad columns and out-of-image rows of BOTH buffers: never touched by the DMA
         const int npad = p.LW - p.XW;
         for (int bi = 0; bi < 2; ++bi)
             for (int ck = 0; ck < CK; ++ck) {
@@ -510,6 +521,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
     }
 
     int pix_off[NB];
+    unsigned rmask[NB], cmask[NB];  // XM == 2: bit t set <=> window row / column t of this lane's pixel is inside the image
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         int n = n0 + (wn * NB + nb) * MF + li;
@@ -517,14 +529,43 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         const int b = n / UV;
         const int rem = n - b * UV;
         const int u = rem / p.V, v = rem - u * p.V;
-        const int lrow = (b == b0) ? (u - u0) * p.su : nrows0 + (b - b0 - 1) * full + u * p.su;
-        pix_off[nb] = lrow * p.LW + v * p.su + p.c0 + p.padL + lh * p.chs;
+        if constexpr (XM == 0) {
+            const int lrow = (b == b0) ? (u - u0) * p.su : nrows0 + (b - b0 - 1) * full + u * p.su;
+            pix_off[nb] = lrow * p.LW + v * p.su + p.c0 + p.padL + lh * p.chs;
+        } else {
+            const int xr = u * p.su + p.r0, xc = v * p.su + p.c0;
+            pix_off[nb] = (b - b0) * CK * p.chs + xr * p.XW + xc + lh * p.chs;
+            rmask[nb] = cmask[nb] = 0;
+            if constexpr (XM >= 2) {
+                for (int t = 0; t < p.TR; ++t) rmask[nb] |= (unsigned)(xr + t >= 0 && xr + t < p.XH) << t;
+                for (int t = 0; t < p.TC; ++t) cmask[nb] |= (unsigned)(xc + t >= 0 && xc + t < p.XW) << t;
+            }
+        }
     }
+    (void)rmask; (void)cmask;
     const int a_lane = (lh * MT + wm * MA * MF + li) * S;  // slab layout: [tap][k-lane][m][S k-steps]
 
     typename A_::type acc[MA][NB];
     const int mbase_wave = mb * MT + wm * MA * MF;
     init_acc<MF, MA, NB>(acc, p, mbase_wave, lh);
+
+    // taps each 32/16-row MFMA tile of this wave needs (wave-uniform); umask = their union
+    unsigned tmask[MA], umask = 0;
+#pragma unroll
+    for (int ma = 0; ma < MA; ++ma) {
+        unsigned m_ = (T >= 32) ? ~0u : ((1u << T) - 1u);
+        if (XM == 3 && p.ncls > 0) {
+            const int m_lo = mbase_wave + ma * MF;
+            int m_hi = m_lo + MF - 1;
+            if (m_hi > p.M - 1) m_hi = p.M - 1;
+            m_ = 0;
+            if (m_lo <= m_hi)
+                for (int cls = m_lo / p.c_out; cls <= m_hi / p.c_out; ++cls) m_ |= p.cls_mask[cls];
+        }
+        tmask[ma] = __builtin_amdgcn_readfirstlane(m_);
+        umask |= tmask[ma];
+    }
+    if (umask == 0) umask = 1;  // a wave entirely beyond M: keep the loop structure, its tiles are never stored
 
     const float* Ag = p.A + (size_t)mb * p.nchunk * a_floats;
     const int a_vec = a_floats / 4;
@@ -544,6 +585,33 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
             }
         }
         if (p.dbg & 1) return;
+        if constexpr (XM != 0) {
+            // whole images: the CK-channel block of image b0+img is one contiguous run in HBM and in LDS
+            const int HW = p.chs;  // == XH*XW
+            const int cvalid = (p.C - cc * CK < CK) ? p.C - cc * CK : CK;
+            const int unit = (p.run_mode == 1) ? 4 : 1;
+            const int runu = cvalid * HW / unit;
+            const int per_img = (runu + 63) / 64;
+            const float* g0 = p.X + ((size_t)b0 * p.C + (size_t)cc * CK) * HW;
+#pragma nounroll
+            for (int j = wave; j < nseg * per_img; j += NWAVES) {
+                const int img = j / per_img, part = j - img * per_img;
+                const int idx = part * 64 + lane;
+                const float* g = g0 + (size_t)img * p.C * HW;
+                float* d = Xbuf + img * CK * HW + part * 64 * unit;
+                if (idx < runu) {
+                    if (p.run_mode == 1)
+                        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(g + (size_t)idx * 4), (lds_void_ptr)d, 16, 0, 0);
+                    else
+                        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(g + idx), (lds_void_ptr)d, 4, 0, 0);
+                }
+            }
+            if (cvalid < CK) {  // channel padding of the last chunk must be finite
+                for (int img = 0; img < nseg; ++img)
+                    for (int i = cvalid * HW + tid; i < CK * HW; i += NT) Xbuf[img * CK * HW + i] = 0.f;
+            }
+            return;
+        }
         if (p.run_mode) {
             // every channel's rows of one image segment are one contiguous run (HBM and LDS): moved 1 KiB per instruction
             // when rows are 16-byte multiples (run_mode 1), 256 B per instruction otherwise (run_mode 2)
@@ -618,14 +686,20 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         const float* As = smem + (cc & 1) * buf_floats;
         const float* Xs = As + a_floats;
         // ---- MFMA, software pipelined by one tap ----
+        if constexpr (XM != 3) {
         avec_t a_cur[MA];
         float b_cur[NB][S];
 #pragma unroll
         for (int ma = 0; ma < MA; ++ma) a_cur[ma] = *(const avec_t*)(As + a_lane + ma * MF * S);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb) {
+            const bool ok = (XM < 2) || ((rmask[nb] & cmask[nb] & 1u) != 0);
 #pragma unroll
-            for (int c2 = 0; c2 < S; ++c2) b_cur[nb][c2] = Xs[pix_off[nb] + c2 * KSTEP * p.chs];
+            for (int c2 = 0; c2 < S; ++c2) {
+                const float xv = Xs[pix_off[nb] + c2 * KSTEP * p.chs];
+                b_cur[nb][c2] = ok ? xv : 0.f;
+            }
+        }
         int tr = 0, tc = 0;
         for (int t = 0; t < T; ++t) {
             int ntc = tc + 1, ntr = tr;
@@ -638,9 +712,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
 #pragma unroll
             for (int ma = 0; ma < MA; ++ma) a_nxt[ma] = *(const avec_t*)(a_next + ma * MF * S);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+            for (int nb = 0; nb < NB; ++nb) {
+                const bool ok = (XM < 2) || last || (((rmask[nb] >> ntr) & (cmask[nb] >> ntc) & 1u) != 0);
 #pragma unroll
-                for (int c2 = 0; c2 < S; ++c2) b_nxt[nb][c2] = Xs[pix_off[nb] + tap_next + c2 * KSTEP * p.chs];
+                for (int c2 = 0; c2 < S; ++c2) {
+                    const float xv = Xs[pix_off[nb] + tap_next + c2 * KSTEP * p.chs];
+                    b_nxt[nb][c2] = ok ? xv : 0.f;
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);  // reads of tap t+1 stay above the MFMAs of tap t
 #pragma unroll
             for (int c2 = 0; c2 < S; ++c2)
@@ -659,7 +738,72 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
             tr = ntr;
             tc = ntc;
         }
-    }
+        } else {
+        // ---- MFMA, software pipelined by one tap.  Only the taps some tile of this wave uses are visited, and a tile skips
+        //      the taps its parity class has no filter element for (dgrad, stride > 1: 7 of 16 (class, tap) pairs of a
+        //      3x3 / stride-2 filter are structurally zero) ----
+        avec_t a_cur[MA];
+        float b_cur[NB][S];
+        int t = __builtin_ctz(umask);
+        {
+            const int tr = (t * p.tc_inv) >> 16, tc = t - tr * p.TC;
+            const int tap_off = tr * p.LW + tc;
+            const float* a_p = As + t * KSTEP * MT * S + a_lane;
+#pragma unroll
+            for (int ma = 0; ma < MA; ++ma) a_cur[ma] = *(const avec_t*)(a_p + ma * MF * S);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const bool ok = (XM < 2) || (((rmask[nb] >> tr) & (cmask[nb] >> tc) & 1u) != 0);
+#pragma unroll
+                for (int c2 = 0; c2 < S; ++c2) {
+                    const float xv = Xs[pix_off[nb] + tap_off + c2 * KSTEP * p.chs];
+                    b_cur[nb][c2] = ok ? xv : 0.f;
+                }
+            }
+        }
+        while (true) {
+            const unsigned rest = umask & ((~1u) << t);
+            const bool last = (rest == 0);
+            const int tn = last ? t : __builtin_ctz(rest);  // after the last tap: a harmless re-read
+            const int ntr = (tn * p.tc_inv) >> 16, ntc = tn - ntr * p.TC;
+            const int tap_next = ntr * p.LW + ntc;
+            const float* a_next = As + tn * KSTEP * MT * S + a_lane;
+            avec_t a_nxt[MA];
+            float b_nxt[NB][S];
+#pragma unroll
+            for (int ma = 0; ma < MA; ++ma) a_nxt[ma] = *(const avec_t*)(a_next + ma * MF * S);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const bool ok = (XM < 2) || (((rmask[nb] >> ntr) & (cmask[nb] >> ntc) & 1u) != 0);
+#pragma unroll
+                for (int c2 = 0; c2 < S; ++c2) {
+                    const float xv = Xs[pix_off[nb] + tap_next + c2 * KSTEP * p.chs];
+                    b_nxt[nb][c2] = ok ? xv : 0.f;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // reads of the next tap stay above the MFMAs of this one
+#pragma unroll
+            for (int ma = 0; ma < MA; ++ma) {
+                if ((tmask[ma] >> t) & 1u) {
+#pragma unroll
+                    for (int c2 = 0; c2 < S; ++c2)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[ma][nb] = A_::mfma(a_cur[ma][c2], b_cur[nb][c2], acc[ma][nb]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ma = 0; ma < MA; ++ma) a_cur[ma] = a_nxt[ma];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int c2 = 0; c2 < S; ++c2) b_cur[nb][c2] = b_nxt[nb][c2];
+            if (last) break;
+            t = tn;
+        }
+        }
+        }
     if (!(p.dbg & 8)) store_tile<MF, MA, NB>(acc, p, (long long)n0 + (long long)wn * NB * MF, n1, mbase_wave, li, lh);
 }
 
@@ -724,11 +868,14 @@ struct Plan {
     size_t a_floats;
     unsigned grid_x, grid_y;
     int dma;  // double-buffered DMA-staged kernel
+    int xm;   // DMA kernel staging mode: 0 rows, 1 whole images, 2 whole images + masked taps
 };
 
 enum { CFG_M128_L = 100, CFG_M128 = 0, CFG_M128_S, CFG_M64, CFG_M64_S, CFG_M32, CFG_M32_S, CFG_M16_CK4, CFG_M16_CK16, CFG_M16_CK4_L, CFG_M16_CK8, CFG_M16_CK8_L, CFG_D_M128 = 200, CFG_D_M64, CFG_D_M64W4, CFG_D_M128W4, CFG_D_M128W4N2, CFG_D_M128W4_C4, CFG_D_M128_C4, CFG_D_M64W4_C4, CFG_D_M64W4N1_C4,
        CFG_D16_C4 /*209*/, CFG_D16_C4_L, CFG_D16_C16, CFG_D16_C16_L, CFG_D16_C8, CFG_D16_C8_L,
-       CFG_D_M32 /*215*/, CFG_D_M32_C4, CFG_D_M64N1 /*217*/, CFG_D_M128S /*218*/, CFG_D_M128S_C4, CFG_D_M64S /*220*/, CFG_D_M64S_C4 };
+       CFG_D_M32 /*215*/, CFG_D_M32_C4, CFG_D_M64N1 /*217*/, CFG_D_M128S /*218*/, CFG_D_M128S_C4, CFG_D_M64S /*220*/, CFG_D_M64S_C4,
+       CFG_D_M32_C16 /*222*/, CFG_D_M64S_C16, CFG_D_M128S_C16, CFG_D_M64W4N1_C16, CFG_D_M64W4N1_C8 /*226*/,
+       CFG_M64_S_C16 = 20, CFG_M64_S_C32, CFG_M128_S_C16, CFG_M128_S_C32, CFG_M32_S_C16 /*24*/ };
 
 // taps of dy one parity class reads: offsets d in [e - J + 1, e], e = (ph+pad)/s, J = #taps kx = kx0 + s*j < k
 void dgrad_window(int k, int s, int pad, int* r0, int* TR) {
@@ -774,7 +921,14 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     // forward without padding: the DMA kernel can move whole multi-row runs -> worth it even for small images
     const bool unpadded = (mode == MODE_FWD && d->pad == 0);
     const bool dma_ok = allow_dma && p.TR * p.TC <= 9 && p.N < (1ll << 31) - 4096;
-    if (p.M > 64) {
+    // small images (whole-image staging applies, see igemm_dma_kernel XM): tiles sized for enough workgroups at the
+    // batch sizes of the reference net; measured on conv_layer_3 / conv_layer_4 (alexnet.cpp:19,22) forward and dgrad
+    const bool small_img = dma_ok && p.XH * p.XW <= 1024 && p.M > 32 && !getenv("CNN_AMD_IGEMM_NOIMG");
+    if (small_img && p.M > 64 && mode == MODE_FWD) { pl->cfg = CFG_D_M64S; pl->MF = 32; pl->MT = 64; pl->NPIX = 64; pl->CK = 8; }
+    else if (small_img && p.M > 64 && p.C >= 128) { pl->cfg = CFG_D_M64S_C16; pl->MF = 32; pl->MT = 64; pl->NPIX = 64; pl->CK = 16; }
+    else if (small_img && p.M > 64) { pl->cfg = CFG_D_M32; pl->MF = 32; pl->MT = 32; pl->NPIX = 128; pl->CK = 8; }
+    else if (small_img && p.C >= 16) { pl->cfg = CFG_D_M64W4N1_C4; pl->MF = 32; pl->MT = 64; pl->NPIX = 128; pl->CK = 4; }
+    else if (p.M > 64) {
         pl->MF = 32; pl->MT = 128; pl->CK = 8;
         if (allow_dma && blocks_for(128, 256) >= 2 * kNumCU && p.TR * p.TC <= 9 && p.N < (1ll << 31) - 1024) { pl->cfg = CFG_D_M128; pl->NPIX = 256; }
         else if (blocks_for(128, 128) >= kWantBlocks) { pl->cfg = CFG_M128; pl->NPIX = 128; }
@@ -810,7 +964,11 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
             {CFG_D16_C4, 16, 16, 256, 4}, {CFG_D16_C4_L, 16, 16, 512, 4}, {CFG_D16_C16, 16, 16, 256, 16},
             {CFG_D16_C16_L, 16, 16, 512, 16}, {CFG_D16_C8, 16, 16, 256, 8}, {CFG_D16_C8_L, 16, 16, 512, 8},
             {CFG_D_M32, 32, 32, 128, 8}, {CFG_D_M32_C4, 32, 32, 128, 4}, {CFG_D_M64N1, 32, 64, 128, 8},
-            {CFG_D_M128S, 32, 128, 64, 8}, {CFG_D_M128S_C4, 32, 128, 64, 4}, {CFG_D_M64S, 32, 64, 64, 8}, {CFG_D_M64S_C4, 32, 64, 64, 4}};
+            {CFG_D_M128S, 32, 128, 64, 8}, {CFG_D_M128S_C4, 32, 128, 64, 4}, {CFG_D_M64S, 32, 64, 64, 8}, {CFG_D_M64S_C4, 32, 64, 64, 4},
+            {CFG_D_M32_C16, 32, 32, 128, 16}, {CFG_D_M64S_C16, 32, 64, 64, 16}, {CFG_D_M128S_C16, 32, 128, 64, 16},
+            {CFG_D_M64W4N1_C16, 32, 64, 128, 16}, {CFG_D_M64W4N1_C8, 32, 64, 128, 8},
+            {CFG_M64_S_C16, 32, 64, 64, 16}, {CFG_M64_S_C32, 32, 64, 64, 32}, {CFG_M128_S_C16, 32, 128, 64, 16},
+            {CFG_M128_S_C32, 32, 128, 64, 32}, {CFG_M32_S_C16, 32, 32, 128, 16}};
         for (auto& t : tab)
             if (t.cfg == c && p.M <= ((p.M + t.MT - 1) / t.MT) * t.MT && (t.MT >= 32 || p.M <= 16)) {
                 pl->cfg = t.cfg; pl->MF = t.MF; pl->MT = t.MT; pl->NPIX = t.NPIX; pl->CK = t.CK;
@@ -838,23 +996,67 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     pl->a_floats = (size_t)((p.M + pl->MT - 1) / pl->MT) * p.nchunk * T * pl->CK * pl->MT;
     pl->lds_bytes = ((size_t)T * pl->CK * pl->MT + (size_t)pl->CK * p.chs) * sizeof(float) * (pl->dma ? 2 : 1) +
                     (size_t)p.nrows_max * 4;
+    const int need_zero = (p.padL > 0 || padR > 0 || p.r0 < 0 || (p.U - 1) * p.su + p.r0 + p.TR - 1 > p.XH - 1) ? 1 : 0;
+    p.need_zero = need_zero;
+    pl->xm = 0;
+    // whole-image staging for small images (see igemm_dma_kernel): CNN_AMD_IGEMM_XM=0 disables (tuning only)
+    {
+        const int HW = p.XH * p.XW;
+        const int UVp = p.U * p.V;
+        long long nimg = (pl->NPIX + UVp - 2) / UVp + 1;
+        if (nimg > p.B) nimg = p.B;
+        const bool img_cfg = pl->cfg == CFG_D_M64W4N1_C4 || pl->cfg == CFG_D_M64W4N1_C8 || pl->cfg == CFG_D_M64W4N1_C16 ||
+                             pl->cfg == CFG_D_M32 || pl->cfg == CFG_D_M32_C4 || pl->cfg == CFG_D_M32_C16 ||
+                             pl->cfg == CFG_D_M128S || pl->cfg == CFG_D_M128S_C4 || pl->cfg == CFG_D_M128S_C16 ||
+                             pl->cfg == CFG_D_M64S || pl->cfg == CFG_D_M64S_C4 || pl->cfg == CFG_D_M64S_C16;
+        const char* xe = getenv("CNN_AMD_IGEMM_XM");
+        const size_t lds = 2 * ((size_t)T * pl->CK * pl->MT + (size_t)nimg * pl->CK * HW) * sizeof(float);
+        if (img_cfg && HW <= 1024 && lds <= 160 * 1024 && (long long)p.B * p.C * HW < (1ll << 31) && !(xe && atoi(xe) == 0)) {
+            pl->xm = p.need_zero ? 2 : 1;
+            p.padL = 0;
+            p.LW = p.XW;
+            p.chs = HW;
+            p.nrows_max = (int)nimg;  // images per tile (the row table is not used in this mode)
+            pl->lds_bytes = lds;
+            const bool vec = (p.C % pl->CK == 0) && ((pl->CK * HW) % 4 == 0) && (((long long)p.C * HW) % 4 == 0);
+            p.run_mode = vec ? 1 : 2;
+        }
+    }
     if (pl->lds_bytes > 160 * 1024 && pl->dma && allow_dma && !getenv("CNN_AMD_IGEMM_CFG"))
         return make_plan(who, d, mode, pl, false);  // two buffers do not fit: single-buffered kernel
     CNN_REQUIRE(pl->lds_bytes <= 160 * 1024, "%s: tile needs %zu B of LDS (> 160 KiB): k=%d W=%d not supported", who,
                 pl->lds_bytes, d->k, d->W);
     p.rw_shift = 0;
     while ((1 << p.rw_shift) < p.XW && p.rw_shift < 6) ++p.rw_shift;
-    p.need_zero = (p.padL > 0 || padR > 0 || p.r0 < 0 || (p.U - 1) * p.su + p.r0 + p.TR - 1 > p.XH - 1) ? 1 : 0;
     p.dbg = getenv("CNN_AMD_DBG") ? atoi(getenv("CNN_AMD_DBG")) : 0;
     p.ntiles = (int)((p.N + pl->NPIX - 1) / pl->NPIX);
     pl->grid_x = (unsigned)p.ntiles;
     pl->grid_y = (unsigned)((p.M + pl->MT - 1) / pl->MT);
 
+    p.tc_inv = 65536 / p.TC + 1;
+    p.ncls = 0;
+    if (mode == MODE_DGRAD && d->s > 1 && d->s * d->s <= 16 && T <= 32) {
+        // class (ph,pw) reads window position t = (tr,tc) iff tap kx = (ph+pad)%s + s*jr, jr = (ph+pad)/s - (r0+tr), exists
+        auto uses = [&](int phase, int tt, int org) {
+            const int j = (phase + d->pad) / d->s - (org + tt);
+            return j >= 0 && (phase + d->pad) % d->s + d->s * j < d->k;
+        };
+        p.ncls = d->s * d->s;
+        for (int cls = 0; cls < p.ncls; ++cls) {
+            unsigned mk = 0;
+            for (int tr = 0; tr < p.TR; ++tr)
+                for (int tc = 0; tc < p.TC; ++tc)
+                    if (uses(cls / d->s, tr, p.r0) && uses(cls % d->s, tc, p.c0)) mk |= 1u << (tr * p.TC + tc);
+            p.cls_mask[cls] = mk;
+        }
+    }
+    if (pl->xm == 2 && p.ncls > 0 && pl->CK >= 8 && !getenv("CNN_AMD_NO_TAPSKIP")) pl->xm = 3;  // (with 2 k-steps per tap the branches cost more than the skipped MFMAs)
+    if (pl->xm != 3) p.ncls = 0;
     q.Co = d->Co; q.Ci = d->Ci; q.k = d->k; q.s = d->s; q.pad = d->pad; q.mode = mode;
     q.C = p.C; q.M = p.M; q.TR = p.TR; q.TC = p.TC; q.r0 = p.r0; q.c0 = p.c0;
     q.CK = pl->CK; q.MT = pl->MT; q.nchunk = p.nchunk; q.nmb = (int)pl->grid_y; q.kstep = pl->MF == 32 ? 2 : 4;
     q.a4 = pl->dma ? pl->CK / q.kstep : 0;
-    p.run_mode = (pl->dma && !p.need_zero && p.LW == p.XW) ? ((p.XW % 4 == 0) ? 1 : 2) : 0;
+    if (pl->xm == 0) p.run_mode = (pl->dma && !p.need_zero && p.LW == p.XW) ? ((p.XW % 4 == 0) ? 1 : 2) : 0;
     return CNN_AMD_OK;
 }
 
@@ -875,19 +1077,31 @@ int launch_cfg2(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
     return CNN_AMD_OK;
 }
 
-template <int MF, int MA, int NB, int WM, int WN, int S>
-int launch_dma(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
-    auto kern = igemm_dma_kernel<MF, MA, NB, WM, WN, S>;
+template <int MF, int MA, int NB, int WM, int WN, int S, int XM>
+int launch_dma_xm(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
+    auto kern = igemm_dma_kernel<MF, MA, NB, WM, WN, S, XM>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     char name[96];
-    snprintf(name, sizeof(name), "igemm_dma_kernel<%d,%d,%d,%d,%d,%d>%s", MF, MA, NB, WM, WN, S,
-             pl.p.mode == MODE_FWD ? "/fwd" : "/dgrad");
+    snprintf(name, sizeof(name), "igemm_dma_kernel<%d,%d,%d,%d,%d,%d%s>%s", MF, MA, NB, WM, WN, S,
+             XM == 0 ? "" : (XM == 1 ? ",img" : (XM == 2 ? ",img+mask" : ",img+mask+skip")), pl.p.mode == MODE_FWD ? "/fwd" : "/dgrad");
     CNN_KLAUNCH(s, name, (kern<<<dim3(pl.grid_x, pl.grid_y), 64 * WM * WN, pl.lds_bytes, s>>>(pl.p)), CONV_TAG(d));
     return CNN_AMD_OK;
+}
+
+// IMG: this tile shape also has the whole-image staging instantiations (the small-image configs)
+template <int MF, int MA, int NB, int WM, int WN, int S, bool IMG = false>
+int launch_dma(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
+    if constexpr (IMG) {
+        if (pl.xm == 1) return launch_dma_xm<MF, MA, NB, WM, WN, S, 1>(pl, s, d);
+        if (pl.xm == 2) return launch_dma_xm<MF, MA, NB, WM, WN, S, 2>(pl, s, d);
+        if (pl.xm == 3) return launch_dma_xm<MF, MA, NB, WM, WN, S, 3>(pl, s, d);
+    }
+    if (pl.xm != 0) return fail(CNN_AMD_E_BADARG, "internal: whole-image staging not instantiated for cfg %d", pl.cfg);
+    return launch_dma_xm<MF, MA, NB, WM, WN, S, 0>(pl, s, d);
 }
 
 template <int MF, int MA, int NB, int WM, int WN, int CK>
@@ -918,14 +1132,24 @@ int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w,
         case CFG_D_M128W4_C4: return launch_dma<32, 4, 1, 1, 4, 2>(pl, s, d);
         case CFG_D_M128_C4: return launch_dma<32, 4, 1, 1, 8, 2>(pl, s, d);
         case CFG_D_M64W4_C4: return launch_dma<32, 2, 2, 1, 4, 2>(pl, s, d);
-        case CFG_D_M64W4N1_C4: return launch_dma<32, 2, 1, 1, 4, 2>(pl, s, d);
-        case CFG_D_M32: return launch_dma<32, 1, 1, 1, 4, 4>(pl, s, d);
-        case CFG_D_M32_C4: return launch_dma<32, 1, 1, 1, 4, 2>(pl, s, d);
+        case CFG_D_M64W4N1_C4: return launch_dma<32, 2, 1, 1, 4, 2, true>(pl, s, d);
+        case CFG_D_M32: return launch_dma<32, 1, 1, 1, 4, 4, true>(pl, s, d);
+        case CFG_D_M32_C4: return launch_dma<32, 1, 1, 1, 4, 2, true>(pl, s, d);
         case CFG_D_M64N1: return launch_dma<32, 2, 1, 1, 4, 4>(pl, s, d);
-        case CFG_D_M128S: return launch_dma<32, 2, 1, 2, 2, 4>(pl, s, d);
-        case CFG_D_M128S_C4: return launch_dma<32, 2, 1, 2, 2, 2>(pl, s, d);
-        case CFG_D_M64S: return launch_dma<32, 1, 1, 2, 2, 4>(pl, s, d);
-        case CFG_D_M64S_C4: return launch_dma<32, 1, 1, 2, 2, 2>(pl, s, d);
+        case CFG_D_M128S: return launch_dma<32, 2, 1, 2, 2, 4, true>(pl, s, d);
+        case CFG_D_M128S_C4: return launch_dma<32, 2, 1, 2, 2, 2, true>(pl, s, d);
+        case CFG_D_M64S: return launch_dma<32, 1, 1, 2, 2, 4, true>(pl, s, d);
+        case CFG_D_M64S_C4: return launch_dma<32, 1, 1, 2, 2, 2, true>(pl, s, d);
+        case CFG_D_M32_C16: return launch_dma<32, 1, 1, 1, 4, 8, true>(pl, s, d);
+        case CFG_D_M64S_C16: return launch_dma<32, 1, 1, 2, 2, 8, true>(pl, s, d);
+        case CFG_D_M128S_C16: return launch_dma<32, 2, 1, 2, 2, 8, true>(pl, s, d);
+        case CFG_D_M64W4N1_C16: return launch_dma<32, 2, 1, 1, 4, 8, true>(pl, s, d);
+        case CFG_D_M64W4N1_C8: return launch_dma<32, 2, 1, 1, 4, 4, true>(pl, s, d);
+        case CFG_M64_S_C16: return launch_cfg<32, 1, 1, 2, 2, 16>(pl, s, d);
+        case CFG_M64_S_C32: return launch_cfg<32, 1, 1, 2, 2, 32>(pl, s, d);
+        case CFG_M128_S_C16: return launch_cfg<32, 2, 1, 2, 2, 16>(pl, s, d);
+        case CFG_M128_S_C32: return launch_cfg<32, 2, 1, 2, 2, 32>(pl, s, d);
+        case CFG_M32_S_C16: return launch_cfg<32, 1, 1, 1, 4, 16>(pl, s, d);
         case CFG_D16_C4: return launch_dma<16, 1, 4, 1, 4, 1>(pl, s, d);
         case CFG_D16_C4_L: return launch_dma<16, 1, 8, 1, 4, 1>(pl, s, d);
         case CFG_D16_C16: return launch_dma<16, 1, 4, 1, 4, 4>(pl, s, d);
