@@ -36,6 +36,7 @@ SIGNATURES = {
     "cnn_maxpool2d_out_dim": (C.c_int, [C.c_int] * 3),
     "cnn_conv2d_workspace_bytes": (C.c_size_t, [_D]),
     "cnn_conv2d_forward": (C.c_int, [_D, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cnn_conv2d_forward_relu": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_backward_weight": (C.c_int, [_D, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P]),
     "cnn_conv2d_backward_data": (C.c_int, [_D, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_backward_workspace_bytes": (C.c_size_t, [_D]),
@@ -47,6 +48,7 @@ SIGNATURES = {
     "cnn_conv2d_backward_data_im2col": (C.c_int, [_D, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_maxpool2d_forward": (C.c_int, [_P, _P, _P] + [C.c_int] * 6 + [_P]),
     "cnn_maxpool2d_backward": (C.c_int, [_P, _P, _P] + [C.c_int] * 6 + [_P]),
+    "cnn_maxpool2d_backward_relu": (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 6 + [_P]),
     "cnn_relu_forward": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "cnn_relu_backward": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "cnn_linear_forward": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
@@ -143,6 +145,13 @@ class Conv2d:
         check(self.lib.cnn_conv2d_forward(C.byref(self.desc), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(self.ws),
                                           self.ws_bytes, _stream()), "cnn_conv2d_forward")
         return y
+
+    def forward_relu(self, x, w, bias, y, y_relu):
+        """Conv2D::forward + the ReLU::forward behind it in one kernel: writes y and y_relu = relu(y)"""
+        _need_gpu(x, w, bias, y, y_relu)
+        check(self.lib.cnn_conv2d_forward_relu(C.byref(self.desc), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(y_relu),
+                                               _ptr(self.ws), self.ws_bytes, _stream()), "cnn_conv2d_forward_relu")
+        return y_relu
 
     def backward_weight(self, x, dy, divisor, gw=None, gb=None, want_bias=True):
         import torch
@@ -250,6 +259,19 @@ def maxpool_backward(dy, mask, in_shape, k, step, dx=None):
     if dx is None:
         dx = torch.empty(in_shape, dtype=torch.float32, device=dy.device)
     check(load().cnn_maxpool2d_backward(_ptr(dy), _ptr(mask), _ptr(dx), B, Cc, H, W, k, step, _stream()), "cnn_maxpool2d_backward")
+    return dx
+
+
+def maxpool_backward_relu(dy, mask, pooled, in_shape, k, step, dx=None):
+    """MaxPool2D::backward + the ReLU::backward of the layer in front of the pool in one kernel (pooled = pool forward output)"""
+    import torch
+
+    _need_gpu(dy, mask, pooled, dx)
+    B, Cc, H, W = in_shape
+    if dx is None:
+        dx = torch.empty(in_shape, dtype=torch.float32, device=dy.device)
+    check(load().cnn_maxpool2d_backward_relu(_ptr(dy), _ptr(mask), _ptr(pooled), _ptr(dx), B, Cc, H, W, k, step, _stream()),
+          "cnn_maxpool2d_backward_relu")
     return dx
 
 

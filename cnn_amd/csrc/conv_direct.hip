@@ -23,8 +23,9 @@ constexpr int kBlock = 64 * kWaves;
 // one wave per output row (b, p); lanes stride over q
 template <int CI, int CO, int K, int S>
 __global__ __launch_bounds__(kBlock) void conv_direct_fwd(const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, float* __restrict__ y, int B,
-                                                          int H, int W, int Ho, int Wo) {
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          float* __restrict__ y_relu, int B, int H, int W, int Ho,
+                                                          int Wo) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long rows = (long long)B * Ho;
@@ -32,6 +33,7 @@ __global__ __launch_bounds__(kBlock) void conv_direct_fwd(const float* __restric
         const int b = (int)(r / Ho), p = (int)(r - (long long)b * Ho);
         const float* xb = x + (size_t)b * CI * H * W + (size_t)(p * S) * W;
         float* yb = y + (size_t)b * CO * Ho * Wo + (size_t)p * Wo;
+        float* rb = y_relu ? y_relu + (size_t)b * CO * Ho * Wo + (size_t)p * Wo : nullptr;  // fused ReLU::forward (relu.cpp:25)
         for (int q = lane; q < Wo; q += 64) {
             // the pixel's CI x K x K patch lives in registers; output channels are the outer loop so that each channel's
             // CI*K*K filter taps are one contiguous (scalar) load
@@ -50,7 +52,9 @@ __global__ __launch_bounds__(kBlock) void conv_direct_fwd(const float* __restric
                 float acc = 0.f;
 #pragma unroll
                 for (int t = 0; t < CI * K * K; ++t) acc = fmaf(patch[t], wc[t], acc);  // ci -> kx -> ky, like conv2d.cpp:80-84
-                yb[(size_t)co * Ho * Wo + q] = acc + bias[co];
+                const float v = acc + bias[co];
+                yb[(size_t)co * Ho * Wo + q] = v;
+                if (rb) rb[(size_t)co * Ho * Wo + q] = v >= 0.f ? v : 0.f;
             }
         }
     }
@@ -144,11 +148,11 @@ bool direct_conv_supported(const cnn_conv2d_desc* d) {
 }
 
 int direct_conv_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
-                        hipStream_t s) {
+                        float* y_relu, hipStream_t s) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
     const long long rows = (long long)d->B * Ho;
-    CNN_KLAUNCH(s, "conv_direct_fwd<3,16,3,2>",
-                (conv_direct_fwd<3, 16, 3, 2><<<wave_grid(rows), kBlock, 0, s>>>(x, w, bias, y, d->B, d->H, d->W, Ho, Wo)),
+    CNN_KLAUNCH(s, y_relu ? "conv_direct_fwd<3,16,3,2>+relu" : "conv_direct_fwd<3,16,3,2>",
+                (conv_direct_fwd<3, 16, 3, 2><<<wave_grid(rows), kBlock, 0, s>>>(x, w, bias, y, y_relu, d->B, d->H, d->W, Ho, Wo)),
                 CONV_TAG(d));
     return CNN_AMD_OK;
 }

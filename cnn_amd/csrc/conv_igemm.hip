@@ -37,6 +37,7 @@ struct IgemmParams {
     const float* A;     // prepared weights
     const float* bias;  // [M] or nullptr
     float* Y;
+    float* Y2;          // forward only, nullable: relu(Y) (the ReLU layer behind the convolution, relu.cpp:25)
     int B, C, XH, XW;   // input tensor
     int U, V;           // output grid per image
     int su;             // grid stride in input coordinates
@@ -178,7 +179,8 @@ __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[M
         const int b = (int)(n / UV);
         const int rem = (int)(n - b * UV);
         if (p.mode == MODE_FWD) {
-            float* out = p.Y + ((size_t)b * p.M + mbase_wave) * UV + rem;
+            const size_t obase = ((size_t)b * p.M + mbase_wave) * UV + rem;
+            float* out = p.Y + obase;
 #pragma unroll
             for (int ma = 0; ma < MA; ++ma) {
 #pragma unroll
@@ -188,6 +190,23 @@ __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[M
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (full_m || mbase_wave + row0 + j < p.M) o[(size_t)j * UV] = acc[ma][nb][4 * g + j];
+                }
+            }
+            if (p.Y2 != nullptr) {  // fused ReLU::forward: second output tensor, same layout
+                float* out2 = p.Y2 + obase;
+#pragma unroll
+                for (int ma = 0; ma < MA; ++ma) {
+#pragma unroll
+                    for (int g = 0; g < A_::kRegs / 4; ++g) {
+                        const int row0 = ma * MF + A_::row(4 * g, lh);
+                        float* o = out2 + (size_t)row0 * UV;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (full_m || mbase_wave + row0 + j < p.M) {
+                                const float v = acc[ma][nb][4 * g + j];
+                                o[(size_t)j * UV] = v >= 0.f ? v : 0.f;
+                            }
+                    }
                 }
             }
         } else {
@@ -1110,8 +1129,8 @@ int launch_cfg(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
                          : launch_cfg2<MF, MA, NB, WM, WN, CK, false>(pl, s, d);
 }
 
-int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w, const float* bias, float* Y, void* ws,
-             size_t ws_bytes, hipStream_t s, const char* who) {
+int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w, const float* bias, float* Y, float* Y2,
+             void* ws, size_t ws_bytes, hipStream_t s, const char* who) {
     CNN_REQUIRE(ws != nullptr, "%s: workspace is null", who);
     if (ws_bytes < pl.a_floats * sizeof(float))
         return fail(CNN_AMD_E_WORKSPACE, "%s: workspace %zu B < %zu B", who, ws_bytes, pl.a_floats * sizeof(float));
@@ -1122,7 +1141,7 @@ int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w,
     if (pg > 4096) pg = 4096;
     CNN_KLAUNCH(s, pl.p.mode == MODE_FWD ? "igemm_prep_weights/fwd" : "igemm_prep_weights/dgrad",
                 (igemm_prep_weights<<<pg, 256, 0, s>>>(pl.q)), CONV_TAG(d));
-    pl.p.X = X; pl.p.A = (const float*)ws; pl.p.bias = bias; pl.p.Y = Y;
+    pl.p.X = X; pl.p.A = (const float*)ws; pl.p.bias = bias; pl.p.Y = Y; pl.p.Y2 = Y2;
     switch (pl.cfg) {
         case CFG_D_M128: return launch_dma<32, 4, 1, 1, 8, 4>(pl, s, d);
         case CFG_D_M64: return launch_dma<32, 2, 1, 1, 8, 4>(pl, s, d);
@@ -1185,7 +1204,8 @@ int check_desc(const char* who, const cnn_conv2d_desc* d) {
 
 namespace cnn_amd {
 bool direct_conv_supported(const cnn_conv2d_desc* d);  // conv_direct.hip: thin first layers bypass the implicit GEMM
-int direct_conv_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, hipStream_t s);
+int direct_conv_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, float* y_relu,
+                        hipStream_t s);
 int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, hipStream_t s);
 // scratch floats the forward / dgrad plans need (used by cnn_conv2d_workspace_bytes in conv_wgrad.hip)
 size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
@@ -1199,14 +1219,25 @@ size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
 
 extern "C" {
 
+static int conv2d_forward_impl(const char* who, const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias,
+                               float* y, float* y_relu, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = check_desc(who, d)) return rc;
+    CNN_REQUIRE(x && w && bias && y, "%s: null pointer", who);
+    if (direct_conv_supported(d)) return direct_conv_forward(d, x, w, bias, y, y_relu, as_stream(stream));
+    Plan pl;
+    if (int rc = make_plan(who, d, MODE_FWD, &pl)) return rc;
+    return run_plan(pl, d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream), who);
+}
+
 int cnn_conv2d_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
                        void* ws, size_t ws_bytes, void* stream) {
-    if (int rc = check_desc("cnn_conv2d_forward", d)) return rc;
-    CNN_REQUIRE(x && w && bias && y, "cnn_conv2d_forward: null pointer");
-    if (direct_conv_supported(d)) return direct_conv_forward(d, x, w, bias, y, as_stream(stream));
-    Plan pl;
-    if (int rc = make_plan("cnn_conv2d_forward", d, MODE_FWD, &pl)) return rc;
-    return run_plan(pl, d, x, w, bias, y, ws, ws_bytes, as_stream(stream), "cnn_conv2d_forward");
+    return conv2d_forward_impl("cnn_conv2d_forward", d, x, w, bias, y, nullptr, ws, ws_bytes, stream);
+}
+
+int cnn_conv2d_forward_relu(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
+                            float* y_relu, void* ws, size_t ws_bytes, void* stream) {
+    CNN_REQUIRE(y_relu, "cnn_conv2d_forward_relu: null pointer");
+    return conv2d_forward_impl("cnn_conv2d_forward_relu", d, x, w, bias, y, y_relu, ws, ws_bytes, stream);
 }
 
 int cnn_conv2d_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws,
@@ -1216,7 +1247,7 @@ int cnn_conv2d_backward_data(const cnn_conv2d_desc* d, const float* dy, const fl
     if (direct_conv_supported(d)) return direct_conv_dgrad(d, dy, w, dx, as_stream(stream));
     Plan pl;
     if (int rc = make_plan("cnn_conv2d_backward_data", d, MODE_DGRAD, &pl)) return rc;
-    return run_plan(pl, d, dy, w, nullptr, dx, ws, ws_bytes, as_stream(stream), "cnn_conv2d_backward_data");
+    return run_plan(pl, d, dy, w, nullptr, dx, nullptr, ws, ws_bytes, as_stream(stream), "cnn_conv2d_backward_data");
 }
 
 }  // extern "C"

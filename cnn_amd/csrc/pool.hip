@@ -59,9 +59,13 @@ __global__ __launch_bounds__(kBlock) void maxpool_fwd_rows(const float* __restri
 // One wave per INPUT row (plane, h): dx[h][w] = dy of the highest-index window whose recorded argmax is this
 // element, else 0 -- the gather form of "dx = 0; for i ascending: dx[mask[i]] = dy[i]" (pool2d.cpp:96-107).
 // With k <= step (the only configuration the reference net uses) at most one window covers an element.
+// `pooled` (nullable) fuses the ReLU::backward of the layer in front of the pool (relu.cpp:35-40): the pool's input IS
+// that ReLU's output, and at an argmax position its value is the pooled output itself, so "output <= 0 ? 0 : delta" needs
+// only pooled[window]; everywhere else the delta is 0 either way.
 template <int K, int STEP>
 __global__ __launch_bounds__(kBlock) void maxpool_bwd_rows(const float* __restrict__ dy,
-                                                           const int32_t* __restrict__ mask, float* __restrict__ dx,
+                                                           const int32_t* __restrict__ mask,
+                                                           const float* __restrict__ pooled, float* __restrict__ dx,
                                                            long long n_rows, int C, int H, int W, int Ho, int Wo,
                                                            int k_rt, int step_rt) {
     const int k = K ? K : k_rt;
@@ -80,6 +84,7 @@ __global__ __launch_bounds__(kBlock) void maxpool_bwd_rows(const float* __restri
         ho_lo = ho_lo <= 0 ? 0 : ho_lo / step;
         const int32_t self_row = c * H * W + h * W;
         const float* dplane = dy + plane * Ho * Wo;
+        const float* pplane = pooled ? pooled + plane * Ho * Wo : nullptr;
         const int32_t* mplane = mask + plane * Ho * Wo;
         float* out = dx + r * W;
         for (int w = lane; w < W; w += kWave) {
@@ -93,6 +98,7 @@ __global__ __launch_bounds__(kBlock) void maxpool_bwd_rows(const float* __restri
                 for (int wo = wo_hi; wo >= wo_lo; --wo) {
                     if (mplane[ho * Wo + wo] == self_row + w) {
                         v = dplane[ho * Wo + wo];
+                        if (pplane && pplane[ho * Wo + wo] <= 0.f) v = 0.f;
                         found = true;
                         break;
                     }
@@ -105,8 +111,8 @@ __global__ __launch_bounds__(kBlock) void maxpool_bwd_rows(const float* __restri
 // k = step = 2 (the reference net's only pool): one wave per OUTPUT row writes BOTH input rows it covers, so dy and
 // mask are read exactly once; rows/cols past the last window (H or W odd) are zero-filled by the same waves.
 __global__ __launch_bounds__(kBlock) void maxpool_bwd_k2s2(const float* __restrict__ dy, const int32_t* __restrict__ mask,
-                                                           float* __restrict__ dx, long long n_units, int C, int H, int W,
-                                                           int Ho, int Wo) {
+                                                           const float* __restrict__ pooled, float* __restrict__ dx,
+                                                           long long n_units, int C, int H, int W, int Ho, int Wo) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     const int extra = H - 2 * Ho;          // 0 or 1 uncovered row at the bottom
@@ -124,11 +130,13 @@ __global__ __launch_bounds__(kBlock) void maxpool_bwd_k2s2(const float* __restri
         }
         const float* drow = dy + (plane * Ho + r) * Wo;
         const int32_t* mrow = mask + (plane * Ho + r) * Wo;
+        const float* prow = pooled ? pooled + (plane * Ho + r) * Wo : nullptr;
         float* row0 = xplane + (size_t)(2 * r) * W;
         float* row1 = row0 + W;
         const int32_t base = c * H * W + 2 * r * W;
         for (int wo = lane; wo < Wo; wo += kWave) {
-            const float d = drow[wo];
+            float d = drow[wo];
+            if (prow && prow[wo] <= 0.f) d = 0.f;  // fused ReLU::backward (relu.cpp:38) of the layer in front
             const int off = mrow[wo] - base - 2 * wo;  // 0, 1, W or W+1
             row0[2 * wo] = (off == 0) ? d : 0.f;
             row0[2 * wo + 1] = (off == 1) ? d : 0.f;
@@ -180,22 +188,33 @@ int cnn_maxpool2d_forward(const float* x, float* y, int32_t* mask, int B, int C,
     return CNN_AMD_OK;
 }
 
-int cnn_maxpool2d_backward(const float* dy, const int32_t* mask, float* dx, int B, int C, int H, int W, int k,
-                           int step, void* stream) {
-    CNN_REQUIRE(dy && mask && dx, "cnn_maxpool2d_backward: null pointer");
-    if (int rc = check_geom("cnn_maxpool2d_backward", B, C, H, W, k, step)) return rc;
+static int maxpool_backward_impl(const char* who, const float* dy, const int32_t* mask, const float* pooled, float* dx,
+                                 int B, int C, int H, int W, int k, int step, void* stream) {
+    CNN_REQUIRE(dy && mask && dx, "%s: null pointer", who);
+    if (int rc = check_geom(who, B, C, H, W, k, step)) return rc;
     const int Ho = cnn_maxpool2d_out_dim(H, k, step), Wo = cnn_maxpool2d_out_dim(W, k, step);
     const long long rows = (long long)B * C * H;
     hipStream_t s = as_stream(stream);
     if (k == 2 && step == 2) {
         const long long units = (long long)B * C * (Ho + (H - 2 * Ho));
-        CNN_KLAUNCH(s, "maxpool_bwd_k2s2", (maxpool_bwd_k2s2<<<row_grid(units), kBlock, 0, s>>>(dy, mask, dx, units, C, H, W, Ho, Wo)),
+        CNN_KLAUNCH(s, pooled ? "maxpool_bwd_k2s2+relu" : "maxpool_bwd_k2s2",
+                    (maxpool_bwd_k2s2<<<row_grid(units), kBlock, 0, s>>>(dy, mask, pooled, dx, units, C, H, W, Ho, Wo)), POOL_TAG);
+    } else
+        CNN_KLAUNCH(s, pooled ? "maxpool_bwd_rows<0,0>+relu" : "maxpool_bwd_rows<0,0>",
+                    (maxpool_bwd_rows<0, 0><<<row_grid(rows), kBlock, 0, s>>>(dy, mask, pooled, dx, rows, C, H, W, Ho, Wo, k, step)),
                     POOL_TAG);
-    }
-    else
-        CNN_KLAUNCH(s, "maxpool_bwd_rows<0,0>",
-                    (maxpool_bwd_rows<0, 0><<<row_grid(rows), kBlock, 0, s>>>(dy, mask, dx, rows, C, H, W, Ho, Wo, k, step)), POOL_TAG);
     return CNN_AMD_OK;
+}
+
+int cnn_maxpool2d_backward(const float* dy, const int32_t* mask, float* dx, int B, int C, int H, int W, int k,
+                           int step, void* stream) {
+    return maxpool_backward_impl("cnn_maxpool2d_backward", dy, mask, nullptr, dx, B, C, H, W, k, step, stream);
+}
+
+int cnn_maxpool2d_backward_relu(const float* dy, const int32_t* mask, const float* pooled, float* dx, int B, int C, int H,
+                                int W, int k, int step, void* stream) {
+    CNN_REQUIRE(pooled, "cnn_maxpool2d_backward_relu: null pointer");
+    return maxpool_backward_impl("cnn_maxpool2d_backward_relu", dy, mask, pooled, dx, B, C, H, W, k, step, stream);
 }
 
 }  // extern "C"

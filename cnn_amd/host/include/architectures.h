@@ -17,6 +17,9 @@ namespace architectures {
 extern data_type random_times;  // init scale divisor (architectures.cpp:6)
 extern bool no_grad;            // skip everything only backward needs (architectures.cpp:8)
 extern void* stream;            // hipStream_t all layers enqueue on (addition; default stream when null)
+// addition: let the AlexNet container run Conv2D+ReLU forward and MaxPool2D+ReLU backward as one kernel each
+// (bit-identical results, every layer's output / delta tensor is still produced); false = one kernel per layer call
+extern bool fuse_layers;
 
 class WithoutGrad final {
 public:
@@ -63,8 +66,11 @@ public:
     virtual void bind_arena(data_type* params_dev, data_type* grads_dev) {}
 };
 
+class ReLU;
+
 class Conv2D : public Layer {
 private:
+    ReLU* fused_relu = nullptr;  // the ReLU layer right behind this convolution (set by the container), or null
     const int in_channels, out_channels, kernel_size, stride;
     const int params_for_one_kernel;
     const int padding = 0;
@@ -94,6 +100,7 @@ public:
     void save_weights(std::ofstream& writer) const override;
     void load_weights(std::ifstream& reader) override;
     int get_params_num() const;
+    void set_fused_relu(ReLU* relu) { fused_relu = relu; }  // addition (see architectures::fuse_layers)
     size_t param_count() const override { return (size_t)get_params_num(); }
     void bind_arena(data_type* params_dev, data_type* grads_dev) override;
 };
@@ -104,11 +111,13 @@ private:
     BatchBuffer out_buf, delta_buf, in_stage, delta_stage;
     int* mask = nullptr;  // device int32 [B][C*Ho*Wo], flat indices into the sample's C*H*W (pool2d.cpp:81)
     int in_C = 0, in_H = 0, in_W = 0, batch = 0;
+    ReLU* fused_relu_below = nullptr;  // the ReLU layer whose output is this pool's input (set by the container), or null
 
 public:
     MaxPool2D(std::string _name, const int _kernel_size = 2, const int _step = 2)
         : Layer(_name), kernel_size(_kernel_size), step(_step), padding(0) {}
     ~MaxPool2D() override;
+    void set_fused_relu_below(ReLU* relu) { fused_relu_below = relu; }  // addition (see architectures::fuse_layers)
     std::vector<tensor> forward(const std::vector<tensor>& input) override;
     std::vector<tensor> backward(std::vector<tensor>& delta) override;
 };
@@ -116,9 +125,14 @@ public:
 class ReLU : public Layer {
 private:
     BatchBuffer out_buf, in_stage, delta_stage;
+    bool forward_done = false;   // this pass' output was already written by the producing Conv2D kernel
+    bool backward_done = false;  // this pass' delta was already masked by the consuming MaxPool2D kernel
 
 public:
     ReLU(std::string _name) : Layer(_name) {}
+    // additions used by Conv2D / MaxPool2D when the container fused this layer into their kernels
+    data_type* fused_forward_target(int B, int C, int H, int W);  // output arena (allocated on first use); arms forward_done
+    void fused_backward_done() { backward_done = true; }
     std::vector<tensor> forward(const std::vector<tensor>& input) override;
     std::vector<tensor> backward(std::vector<tensor>& delta) override;
 };

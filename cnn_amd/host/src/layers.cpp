@@ -14,6 +14,7 @@ using cnn_amd_host::must;
 data_type architectures::random_times = 10.f;  // architectures.cpp:6
 bool architectures::no_grad = false;           // architectures.cpp:8
 void* architectures::stream = nullptr;
+bool architectures::fuse_layers = true;
 
 // ---------------------------------------------------------------------------------------------------------------
 BatchBuffer::~BatchBuffer() {
@@ -159,7 +160,13 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
         saved_input_tensors = input;
     }
     cnn_conv2d_desc d{B, in_channels, H, W, out_channels, kernel_size, stride, padding};
-    must(cnn_conv2d_forward(&d, x, w_dev(), b_dev(), out_buf.base, workspace, workspace_bytes, stream), "cnn_conv2d_forward");
+    if (fused_relu != nullptr && fuse_layers) {  // the ReLU behind this layer gets its output from the same kernel
+        data_type* y_relu = fused_relu->fused_forward_target(B, out_channels, out_H, out_W);
+        must(cnn_conv2d_forward_relu(&d, x, w_dev(), b_dev(), out_buf.base, y_relu, workspace, workspace_bytes, stream),
+             "cnn_conv2d_forward_relu");
+    } else {
+        must(cnn_conv2d_forward(&d, x, w_dev(), b_dev(), out_buf.base, workspace, workspace_bytes, stream), "cnn_conv2d_forward");
+    }
     return output;
 }
 
@@ -237,15 +244,35 @@ std::vector<tensor> MaxPool2D::backward(std::vector<tensor>& delta) {
     assert(mask != nullptr && "backward without a recorded forward (no_grad?)");
     if (delta_buf.empty()) delta_buf.allocate(batch, in_C, in_H, in_W, name + "_delta");
     const data_type* dy = batch_device_pointer(delta, delta_stage, name + "_dy");
-    must(cnn_maxpool2d_backward(dy, mask, delta_buf.base, B, in_C, in_H, in_W, kernel_size, step, stream),
-         "cnn_maxpool2d_backward");
+    if (fused_relu_below != nullptr && fuse_layers) {  // also applies the ReLU::backward of the layer in front
+        must(cnn_maxpool2d_backward_relu(dy, mask, out_buf.base, delta_buf.base, B, in_C, in_H, in_W, kernel_size, step, stream),
+             "cnn_maxpool2d_backward_relu");
+        fused_relu_below->fused_backward_done();
+    } else {
+        must(cnn_maxpool2d_backward(dy, mask, delta_buf.base, B, in_C, in_H, in_W, kernel_size, step, stream),
+             "cnn_maxpool2d_backward");
+    }
     return delta_buf.views;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // ReLU
+data_type* ReLU::fused_forward_target(int B, int C, int H, int W) {
+    if (out_buf.empty()) {
+        out_buf.allocate(B, C, H, W, name + "_output");
+        output = out_buf.views;
+    }
+    assert((size_t)B <= out_buf.views.size() && out_buf.sample_len == (size_t)C * H * W);
+    forward_done = true;
+    return out_buf.base;
+}
+
 std::vector<tensor> ReLU::forward(const std::vector<tensor>& input) {
     const int B = (int)input.size();
+    if (forward_done) {  // written by the producing convolution's kernel in this pass
+        forward_done = false;
+        return output;
+    }
     if (out_buf.empty()) {
         out_buf.allocate(B, input[0]->C, input[0]->H, input[0]->W, name + "_output");
         output = out_buf.views;
@@ -259,6 +286,11 @@ std::vector<tensor> ReLU::forward(const std::vector<tensor>& input) {
 // relu.cpp:30-44: masks the caller's delta IN PLACE and hands the same tensors back
 std::vector<tensor> ReLU::backward(std::vector<tensor>& delta) {
     const int B = (int)delta.size();
+    if (backward_done) {  // masked by the pool's backward kernel in this pass
+        backward_done = false;
+        for (int b = 0; b < B; ++b) delta[b]->name = name + "_delta_" + std::to_string(b);
+        return delta;
+    }
     const bool in_place = delta[0]->on_device();
     data_type* d = batch_device_pointer_mut(delta, delta_stage, name + "_dy");
     must(cnn_relu_backward(out_buf.base, d, out_buf.sample_len * B, stream), "cnn_relu_backward");

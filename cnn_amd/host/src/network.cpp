@@ -2,6 +2,7 @@
 // flat parameter / gradient arena that makes the SGD step one kernel and the data-parallel exchange one all-reduce.
 #include <cassert>
 #include <iostream>
+#include <iterator>
 
 #include "architectures.h"
 #include "host_util.h"
@@ -27,6 +28,17 @@ void AlexNet::build(int num_classes, bool batch_norm) {
     if (batch_norm) layers_sequence.emplace_back(new BatchNorm2D("bn_layer_4", 128));
     layers_sequence.emplace_back(new ReLU("relu_layer_4"));
     layers_sequence.emplace_back(new LinearLayer("linear_1", 6 * 6 * 128, num_classes));
+    // fusion wiring (architectures::fuse_layers): Conv2D -> ReLU forward, ReLU -> MaxPool2D backward
+    for (auto it = layers_sequence.begin(); it != layers_sequence.end(); ++it) {
+        auto next = std::next(it);
+        if (next == layers_sequence.end()) break;
+        if (auto* relu = dynamic_cast<ReLU*>(next->get())) {
+            if (auto* conv = dynamic_cast<Conv2D*>(it->get())) conv->set_fused_relu(relu);
+        }
+        if (auto* pool = dynamic_cast<MaxPool2D*>(next->get())) {
+            if (auto* relu = dynamic_cast<ReLU*>(it->get())) pool->set_fused_relu_below(relu);
+        }
+    }
     n_params = 0;
     for (const auto& layer : layers_sequence) n_params += layer->param_count();
 }

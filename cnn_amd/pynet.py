@@ -15,10 +15,13 @@ from . import capi
 class AlexNetHip:
     CHANS = [3, 16, 32, 64, 128]
 
-    def __init__(self, batch, classes=3, H=224, W=224, device="cuda"):
+    def __init__(self, batch, classes=3, H=224, W=224, device="cuda", fuse=True):
         import torch
 
         self.torch = torch
+        # fuse: Conv2D+ReLU forward and MaxPool2D+ReLU backward run as one kernel each (bit-identical results, every
+        # layer's output tensor is still written); fuse=False issues the reference's one-call-per-layer sequence
+        self.fuse = fuse
         self.B, self.classes, self.H, self.W, self.dev = batch, classes, H, W, device
         f32 = dict(dtype=torch.float32, device=device)
         self.convs, self.conv_in_hw, self.conv_out_hw = [], [], []
@@ -87,9 +90,12 @@ class AlexNetHip:
         self.x = x
         cur = x
         for l in range(4):
-            self.convs[l].forward(cur, self.conv_w(l), self.conv_b(l), self.conv_out[l])
-            capi.check(capi.load().cnn_relu_forward(capi._ptr(self.conv_out[l]), capi._ptr(self.relu_out[l]),
-                                                    self.conv_out[l].numel(), capi._stream()), "cnn_relu_forward")
+            if self.fuse:
+                self.convs[l].forward_relu(cur, self.conv_w(l), self.conv_b(l), self.conv_out[l], self.relu_out[l])
+            else:
+                self.convs[l].forward(cur, self.conv_w(l), self.conv_b(l), self.conv_out[l])
+                capi.check(capi.load().cnn_relu_forward(capi._ptr(self.conv_out[l]), capi._ptr(self.relu_out[l]),
+                                                        self.conv_out[l].numel(), capi._stream()), "cnn_relu_forward")
             cur = self.relu_out[l]
             if l == 0:
                 hh, ww = self.conv_out_hw[0]
@@ -117,9 +123,13 @@ class AlexNetHip:
         for l in (3, 2, 1, 0):
             if l == 0:
                 hh, ww = self.conv_out_hw[0]
-                capi.maxpool_backward(cur, self.pool_mask, (self.B, 16, hh, ww), 2, 2, self.d_pool)
+                if self.fuse:  # pool backward + relu_layer_1 backward in one pass
+                    capi.maxpool_backward_relu(cur, self.pool_mask, self.pool_out, (self.B, 16, hh, ww), 2, 2, self.d_pool)
+                else:
+                    capi.maxpool_backward(cur, self.pool_mask, (self.B, 16, hh, ww), 2, 2, self.d_pool)
                 cur = self.d_pool
-            capi.relu_backward(self.relu_out[l], cur)  # in place on the upstream delta (relu.cpp:37-39)
+            if not (self.fuse and l == 0):
+                capi.relu_backward(self.relu_out[l], cur)  # in place on the upstream delta (relu.cpp:37-39)
             lin = self.x if l == 0 else (self.pool_out if l == 1 else self.relu_out[l - 1])
             # Conv2D::backward in one call: weight/bias gradient on the library's side stream, concurrently with dgrad
             self.convs[l].backward(lin, cur, self.conv_w(l), div, self.conv_w(l, g), self.conv_b(l, g), self.d_conv[l],

@@ -64,6 +64,11 @@ size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d);
  * Implicit GEMM on v_mfma_f32_32x32x2_f32 / 16x16x4_f32, input rows + filter slabs staged in LDS. */
 int cnn_conv2d_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
                        void* ws, size_t ws_bytes, void* stream);
+/* Conv2D::forward immediately followed by ReLU::forward (relu.cpp:21-26) in ONE kernel: y as above AND
+ * y_relu = (y >= 0 ? y : 0), both NCHW tensors are written (the convolution output stays observable, alexnet.cpp:97);
+ * saves the ReLU kernel's re-read of y.  Bit-identical to cnn_conv2d_forward + cnn_relu_forward. */
+int cnn_conv2d_forward_relu(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
+                            float* y_relu, void* workspace, size_t workspace_bytes, void* stream);
 
 /* replaces conv2d.cpp:117-159: gw = (sum_b sum_pq dy*x)/divisor, gb = (sum_b sum_pq dy)/divisor.
  * The reference divides by the batch size per sample and accumulates (:148,:157); pass divisor = B of the
@@ -106,6 +111,12 @@ int cnn_maxpool2d_forward(const float* x, float* y, int32_t* mask, int B, int C,
  * output index wins, reproduced deterministically). */
 int cnn_maxpool2d_backward(const float* dy, const int32_t* mask, float* dx, int B, int C, int H, int W, int k,
                            int step, void* stream);
+/* MaxPool2D::backward immediately followed by the ReLU::backward (relu.cpp:35-40) of the ReLU layer whose output was
+ * this pool's input, in ONE kernel.  pooled = the pool's forward output y: at an argmax position the ReLU output equals
+ * pooled[window], everywhere else the delta is 0 either way, so dx[argmax] = (pooled <= 0 ? 0 : dy) reproduces
+ * cnn_maxpool2d_backward + cnn_relu_backward bit for bit without reading the ReLU output tensor. */
+int cnn_maxpool2d_backward_relu(const float* dy, const int32_t* mask, const float* pooled, float* dx, int B, int C, int H,
+                                int W, int k, int step, void* stream);
 
 /* ---- ReLU : relu.cpp ------------------------------------------------------------------------------- */
 /* relu.cpp:21-26: y = x >= 0 ? x : 0   (keeps -0.0, NaN -> 0) */

@@ -349,3 +349,69 @@ def test_conv2d_combined_backward_matches_separate_calls(T):
             gw2, gb2, dx2 = conv.backward(xd, dyd, wd, float(case[0]))  # defer_join=False: ordered on return
             T.cuda.synchronize()
             assert T.equal(gw1, gw2) and T.equal(gb1, gb2) and T.equal(dx1, dx2)
+
+
+@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 5, 6, 7, 8, 9, 10)], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_conv2d_forward_relu_fusion_is_bit_identical(T, case):
+    """cnn_conv2d_forward_relu == cnn_conv2d_forward + cnn_relu_forward, both outputs, every kernel family"""
+    from cnn_amd import capi
+
+    x, w, b, _ = _conv_inputs(case, 300)
+    conv = capi.Conv2d(*case)
+    xd, wd, bd = dev(T, x), dev(T, w), dev(T, b)
+    y_sep = conv.forward(xd, wd, bd)
+    r_sep = capi.relu_forward(y_sep)
+    y_f, r_f = T.full_like(y_sep, 7.0), T.full_like(y_sep, 7.0)
+    conv.forward_relu(xd, wd, bd, y_f, r_f)
+    assert T.equal(y_f, y_sep) and T.equal(r_f, r_sep)
+    assert (r_f >= 0).all() and (r_f == 0).any() and (r_f > 0).any()
+
+
+@pytest.mark.parametrize("shape,k,step", [((2, 16, 111, 111), 2, 2), ((3, 5, 7, 7), 2, 2), ((2, 4, 9, 10), 3, 2), ((2, 3, 8, 8), 3, 1)])
+def test_maxpool_backward_relu_fusion_is_bit_identical(T, shape, k, step):
+    """cnn_maxpool2d_backward_relu(pooled) == cnn_maxpool2d_backward + cnn_relu_backward(relu_out) where the pool's
+    input is that ReLU's output (zeros, ties and NaN included)"""
+    from cnn_amd import capi
+
+    pre = uniform_pm1(310, shape)
+    pre[0, 0, :4, :4] = -1.0      # an all-zero window after ReLU: argmax value 0 -> delta masked
+    pre[-1, -1, 0, 0] = np.nan    # NaN survives ReLU (NaN >= 0 is false -> 0)? relu.cpp:25 gives 0; keep it as data
+    relu_out = capi.relu_forward(dev(T, pre))
+    relu_np = host(relu_out)
+    relu_np[0, 1, 2, 2] = np.nan  # a NaN activation inside the pool input
+    relu_out = dev(T, relu_np)
+    B, C, H, W = shape
+    Ho, Wo = (H - k) // step + 1, (W - k) // step + 1
+    pooled = T.empty((B, C, Ho, Wo), device="cuda")
+    mask = T.empty((B, C, Ho, Wo), dtype=T.int32, device="cuda")
+    L = capi.load()
+    capi.check(L.cnn_maxpool2d_forward(capi._ptr(relu_out), capi._ptr(pooled), capi._ptr(mask), B, C, H, W, k, step, None), "pool fwd")
+    dy = dev(T, uniform_pm1(311, (B, C, Ho, Wo)))
+    d_sep = capi.maxpool_backward(dy, mask, shape, k, step)
+    capi.relu_backward(relu_out, d_sep)
+    d_f = T.full(shape, 7.0, device="cuda")
+    capi.maxpool_backward_relu(dy, mask, pooled, shape, k, step, d_f)
+    a, b = host(d_f), host(d_sep)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert (a[0, 0, :4, :4] == 0).all()
+
+
+def test_whole_net_fused_equals_unfused(T):
+    """pynet with the fused Conv+ReLU / Pool+ReLU kernels gives bit-identical parameters, gradients and activations"""
+    from cnn_amd.pynet import AlexNetHip
+
+    B = 4
+    x = dev(T, uniform01(320, (B, 3, 224, 224)))
+    labels = dev(T, (np.arange(B) % 3).astype(np.int32))
+    nets = [AlexNetHip(B, 3, fuse=f) for f in (True, False)]
+    p0 = normal_scaled(321, (nets[0].n_params,))
+    for n in nets:
+        n.load_params(p0)
+        for _ in range(2):
+            n.train_step(x, labels, 1e-3)
+    a, b = nets
+    assert T.equal(a.params, b.params) and T.equal(a.grads, b.grads)
+    for l in range(4):
+        assert T.equal(a.conv_out[l], b.conv_out[l]) and T.equal(a.relu_out[l], b.relu_out[l])
+        assert T.equal(a.d_conv[l], b.d_conv[l])
+    assert T.equal(a.d_pool, b.d_pool)

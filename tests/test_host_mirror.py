@@ -178,3 +178,30 @@ def test_host_batchnorm_net_train_steps_vs_oracle(tmp_path):
     again = hostapi.HostAlexNet(3, batch_norm=True)
     again.load_checkpoint(out)
     assert np.array_equal(again.get_params(), raw)
+
+
+@pytest.mark.gpu
+def test_host_net_layer_fusion_is_bit_identical():
+    """architectures::fuse_layers only changes which kernels run: parameters after two steps and every layer's
+    observable output are bit-identical with and without it"""
+    from cnn_amd import hostapi
+
+    B = 3
+    x = uniform01(60, (B, 3, 224, 224))
+    labels = np.array([0, 2, 1], np.int32)
+    p0 = normal_scaled(61, (111267,))
+    res = []
+    for fuse in (1, 0):
+        hostapi.load().cnnh_set_fuse_layers(fuse)
+        try:
+            net = hostapi.HostAlexNet(3)
+            net.set_params(p0)
+            losses = [net.train_step_host(x, labels, 1e-3)[0] for _ in range(2)]
+            res.append((losses, net.get_params(), net.get_grads(), net.layer_output("conv_layer_1", (B, 16, 111, 111)),
+                        net.layer_output("relu_layer_1", (B, 16, 111, 111)), net.layer_output("relu_layer_4", (B, 128, 6, 6))))
+            net.close()
+        finally:
+            hostapi.load().cnnh_set_fuse_layers(1)
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert np.array_equal(a, b)
+    assert res[0][0] == res[1][0]
