@@ -37,8 +37,9 @@ def algorithmic_work(key):
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         flops = 2.0 * B * Co * Ho * Wo * Ci * k * k
         x_b, y_b, w_b = 4.0 * B * Ci * H * W, 4.0 * B * Co * Ho * Wo, 4.0 * Co * Ci * k * k
-        if kernel.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel", "conv_direct")):
-            return x_b + y_b + w_b, flops  # fwd: x,w -> y ; dgrad: dy,w -> dx ; wgrad: x,dy -> gw
+        if kernel.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel", "conv_direct", "conv_dgrad_pk", "conv_fwd_pk")):
+            fused = y_b if (kernel.endswith("+relu") or ",relu" in kernel) else 0.0  # fused ReLU: a second output tensor
+            return x_b + y_b + w_b + fused, flops  # fwd: x,w -> y ; dgrad: dy,w -> dx ; wgrad: x,dy -> gw
         if kernel.startswith("bias_grad_partial"):
             return y_b, B * Co * Ho * Wo
         return w_b * 2, 0.0  # prep / reduce kernels: weight-sized
@@ -53,7 +54,8 @@ def algorithmic_work(key):
         Ho, Wo = (H - k) // st + 1, (W - k) // st + 1
         if "fwd" in kernel:
             return 4.0 * B * C * (H * W + 2 * Ho * Wo), float(B * C * Ho * Wo * k * k)
-        return 4.0 * B * C * (2 * Ho * Wo + H * W), 0.0
+        fused = 1 if kernel.endswith("+relu") else 0  # fused ReLU backward also reads the pooled output
+        return 4.0 * B * C * ((2 + fused) * Ho * Wo + H * W), 0.0
     m = re.match(r"B(\d+) in(\d+) out(\d+)", geo)
     if m:
         B, n_in, n_out = map(int, m.groups())
@@ -151,7 +153,7 @@ def conv_ns_bench(torch, capi, reps=5):
         name = key.split("|")[0]
         if name.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel")):
             tf = flops / (ms / 1e3 / cnt) / 1e12
-            tag = "fwd" if name.endswith("/fwd") else ("dgrad" if name.endswith("/dgrad") else "wgrad")
+            tag = "fwd" if name.endswith(("/fwd", "/fwd+relu")) else ("dgrad" if name.endswith("/dgrad") else "wgrad")
             out[tag] = {"kernel": name, "avg_ms": round(ms / cnt, 4), "tflops": round(tf, 2),
                         "frac_of_mfma_peak": round(tf / PEAK_MFMA_F32_TFLOPS, 4)}
     del x, y, dy, dx

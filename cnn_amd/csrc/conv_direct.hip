@@ -61,9 +61,9 @@ __global__ __launch_bounds__(kBlock) void conv_direct_fwd(const float* __restric
 }
 
 // one wave per grid row (b, hh); lanes stride over ww.  pad == 0.
-template <int CI, int CO, int K, int S>
+template <int CI, int CO, int K, int S, int UN>
 __global__ __launch_bounds__(kBlock) void conv_direct_dgrad(const float* __restrict__ dy, const float* __restrict__ w,
-                                                            float* __restrict__ dx, int B, int H, int W, int Ho, int Wo) {
+                                                            float* __restrict__ dx, int B, int H, int W, int Ho, int Wo, int dbg) {
     constexpr int J = (K + S - 1) / S;  // dy rows / cols a grid pixel reads: hh - j, ww - j for j < J
     const int U = (H + S - 1) / S, V = (W + S - 1) / S;
     const int lane = threadIdx.x & 63;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void conv_direct_dgrad(const float* __restr
                 for (int pw = 0; pw < S; ++pw)
 #pragma unroll
                     for (int ci = 0; ci < CI; ++ci) acc[ph][pw][ci] = 0.f;
-#pragma unroll 4
+#pragma unroll(UN)
             for (int co = 0; co < CO; ++co) {
                 float d[J][J];
 #pragma unroll
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(kBlock) void conv_direct_dgrad(const float* __restr
 #pragma unroll
                     for (int jc = 0; jc < J; ++jc) {
                         const int pr = hh - jr, pc = ww - jc;
+                        if ((dbg & 1) && (jr | jc)) { d[jr][jc] = d[0][0]; continue; }
                         d[jr][jc] = (pr >= 0 && pr < Ho && pc >= 0 && pc < Wo) ? dyb[((size_t)co * Ho + pr) * Wo + pc] : 0.f;
                     }
                 const float* wc = w + (size_t)co * CI * K * K;  // wave-uniform
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(kBlock) void conv_direct_dgrad(const float* __restr
                                 }
                             }
             }
+            if (dbg & 8) { if (acc[0][0][0] == 123.456f) dxb[0] = 1.f; continue; }
 #pragma unroll
             for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
@@ -125,6 +127,217 @@ __global__ __launch_bounds__(kBlock) void conv_direct_dgrad(const float* __restr
                             if (ww * S + pw < W) row[pw] = acc[ph][pw][ci];
                     }
                 }
+        }
+    }
+}
+
+// ---- packed-math data gradient for the 3 -> 16, 3x3, stride-2 layer ------------------------------------------------
+// PMC counters of conv_direct_dgrad (profiles/r01) show the kernel is bound by instruction issue, not memory: 810 VALU
+// and 745 SALU instructions per 64 pixels against 272 useful packed FMAs -- hipcc shuffles the wave-uniform weights into
+// SGPR pairs with s_mov and spills SGPRs through v_writelane.  Here the weights are re-packed ONCE per call into the
+// exact operand order of the inner loop (pack_dgrad_weights: 16 float2 per output channel), so each v_pk_fma_f32 takes
+// an s_load'ed SGPR pair directly: 15 packed FMAs per channel, no scalar shuffling.
+// Accumulator pairs of one grid pixel (class = output parity (ph,pw), alexnet.cpp:12 geometry):
+//   P[cls] = (ci0, ci1) of class cls;  Q0 = ci2 of classes (0,0),(0,1);  Q1 = ci2 of classes (1,0),(1,1).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__global__ void pack_dgrad_weights_3_16_3_2(const float* __restrict__ w, float* __restrict__ wp) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= 16) return;
+    const float* wc = w + (size_t)co * 27;
+    auto W = [&](int ci, int kx, int ky) { return wc[(ci * 3 + kx) * 3 + ky]; };
+    float* o = wp + (size_t)co * 32;
+    int n = 0;
+    auto put = [&](float a, float b) { o[n++] = a; o[n++] = b; };
+    // d00 = dy[hh][ww]: tap (kx,ky) = (ph,pw)
+    for (int cls = 0; cls < 4; ++cls) put(W(0, cls >> 1, cls & 1), W(1, cls >> 1, cls & 1));
+    put(W(2, 0, 0), W(2, 0, 1));
+    put(W(2, 1, 0), W(2, 1, 1));
+    // d01 = dy[hh][ww-1]: classes with pw = 0, ky = 2
+    put(W(0, 0, 2), W(1, 0, 2));
+    put(W(0, 1, 2), W(1, 1, 2));
+    put(W(2, 0, 2), 0.f);
+    put(W(2, 1, 2), 0.f);
+    // d10 = dy[hh-1][ww]: classes with ph = 0, kx = 2
+    put(W(0, 2, 0), W(1, 2, 0));
+    put(W(0, 2, 1), W(1, 2, 1));
+    put(W(2, 2, 0), W(2, 2, 1));
+    // d11 = dy[hh-1][ww-1]: class (0,0), tap (2,2)
+    put(W(0, 2, 2), W(1, 2, 2));
+    put(W(2, 2, 2), 0.f);
+    put(0.f, 0.f);
+}
+
+// dy is read through a raw buffer descriptor: address = SGPR base + SGPR offset (image, channel, row) + per-lane byte
+// offset, i.e. NO vector address arithmetic per load, and a lane whose tap lies outside the image uses an offset beyond
+// num_records, for which the hardware returns 0 -- no masks, no branches (requires the dy tensor to be < 2 GiB).
+constexpr unsigned kBufOOB = 0x7ffffffcu;
+
+// One wave-item = 64 consecutive grid pixels of one image (rows are crossed, so every lane is busy); CB channels per
+// batch: all 4*CB loads of a batch are in flight before its first FMA.
+template <int CB, int DBG = 0>
+__global__ __launch_bounds__(kBlock) void conv_dgrad_pk_3_16_3_2(const float* __restrict__ dy, const v2f* __restrict__ wp,
+                                                                 float* __restrict__ dx, int B, int H, int W, int Ho,
+                                                                 int Wo, int items_per_img) {
+    constexpr int CO = 16, CI = 3;
+    const int U = (H + 1) / 2, V = (W + 1) / 2;
+    const int UV = U * V;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long items = (long long)B * items_per_img;
+    const int plane = Ho * Wo;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * CO * plane * 4u), 0x00020000);
+    for (long long it = (long long)blockIdx.x * kWaves + wave; it < items; it += (long long)gridDim.x * kWaves) {
+        const int b = (int)(it / items_per_img);
+        const int n = (int)(it - (long long)b * items_per_img) * 64 + lane;
+        const bool live = n < UV;
+        const int hh = (live ? n : 0) / V, ww = (live ? n : 0) - hh * V;
+        // taps: dy rows hh (jr = 0) / hh-1 (jr = 1), columns ww (jc = 0) / ww-1 (jc = 1); a missing tap gets an out-of-range
+        // offset and reads as 0
+        const bool r0ok = live && hh < Ho, r1ok = live && hh >= 1, c0ok = ww < Wo, c1ok = ww >= 1;
+        const unsigned o = (unsigned)(hh * Wo + ww) * 4u;
+        const unsigned v00 = (r0ok && c0ok) ? o : kBufOOB;
+        const unsigned v01 = (r0ok && c1ok) ? o - 4u : kBufOOB;
+        const unsigned v10 = (r1ok && c0ok) ? o - (unsigned)Wo * 4u : kBufOOB;
+        const unsigned v11 = (r1ok && c1ok) ? o - (unsigned)Wo * 4u - 4u : kBufOOB;
+        const int soff = b * CO * plane * 4;  // byte offset of dy[b][0][0][0]; wave-uniform
+        v2f P0 = {0.f, 0.f}, P1 = P0, P2 = P0, P3 = P0, Q0 = P0, Q1 = P0;
+#pragma unroll 1
+        for (int cg = 0; cg < CO; cg += CB) {
+            float dv[CB][4];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int so = soff + (cg + u) * plane * 4;
+                dv[u][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)v00, so, 0));
+                dv[u][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)v01, so, 0));
+                dv[u][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)v10, so, 0));
+                dv[u][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)v11, so, 0));
+            }
+            if constexpr (DBG & 4) {
+#pragma unroll
+                for (int u = 0; u < CB; ++u) P0.x += dv[u][0] + dv[u][1] + dv[u][2] + dv[u][3];
+                continue;
+            }
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                // (the fence keeps hipcc from hoisting the weight s_loads of all channels to the top, which would need
+                //  hundreds of SGPRs and spill them through v_writelane)
+                asm volatile("" ::: "memory");
+                const v2f* q = wp + (cg + u) * 16;  // wave-uniform -> scalar loads straight into SGPR pairs
+                const v2f a = {dv[u][0], dv[u][0]}, bq = {dv[u][1], dv[u][1]}, c = {dv[u][2], dv[u][2]},
+                          e = {dv[u][3], dv[u][3]};
+                P0 = __builtin_elementwise_fma(q[0], a, P0);
+                P1 = __builtin_elementwise_fma(q[1], a, P1);
+                P2 = __builtin_elementwise_fma(q[2], a, P2);
+                P3 = __builtin_elementwise_fma(q[3], a, P3);
+                Q0 = __builtin_elementwise_fma(q[4], a, Q0);
+                Q1 = __builtin_elementwise_fma(q[5], a, Q1);
+                P0 = __builtin_elementwise_fma(q[6], bq, P0);
+                P2 = __builtin_elementwise_fma(q[7], bq, P2);
+                Q0 = __builtin_elementwise_fma(q[8], bq, Q0);
+                Q1 = __builtin_elementwise_fma(q[9], bq, Q1);
+                P0 = __builtin_elementwise_fma(q[10], c, P0);
+                P1 = __builtin_elementwise_fma(q[11], c, P1);
+                Q0 = __builtin_elementwise_fma(q[12], c, Q0);
+                P0 = __builtin_elementwise_fma(q[13], e, P0);
+                Q0 = __builtin_elementwise_fma(q[14], e, Q0);
+            }
+        }
+        if (!live) continue;
+        if ((DBG & 8) && P0.x != 123.25f) continue;
+        // class (ph,pw) -> dx[ci][2hh+ph][2ww+pw]; the two pw of a row are adjacent in memory
+        float* dxb = dx + (size_t)b * CI * H * W;
+        const int h0 = 2 * hh;
+        const size_t col = (size_t)ww * 2;
+        const bool pair = ((W & 1) == 0);  // then both outputs of a row exist and the pair is 8-byte aligned
+        auto st = [&](int ci, int ph, float v0, float v1) {
+            const int h = h0 + ph;
+            if (h >= H) return;
+            float* row = dxb + ((size_t)ci * H + h) * W + col;
+            if (pair) {
+                *(float2*)row = make_float2(v0, v1);
+            } else {
+                row[0] = v0;
+                if (col + 1 < (size_t)W) row[1] = v1;
+            }
+        };
+        st(0, 0, P0.x, P1.x); st(0, 1, P2.x, P3.x);
+        st(1, 0, P0.y, P1.y); st(1, 1, P2.y, P3.y);
+        st(2, 0, Q0.x, Q0.y); st(2, 1, Q1.x, Q1.y);
+    }
+}
+
+// ---- packed-math forward for the same layer (+ optional fused ReLU output) ------------------------------------------
+// Same recipe as conv_dgrad_pk: weights re-packed once per call into operand order ([tap][co pair], then the bias pairs),
+// x read through a raw buffer descriptor (uniform base + SGPR (image, channel, row) offset + lane offset; tail lanes read
+// out of range = 0), 64 consecutive output pixels per wave-item so that every store is one contiguous 256-byte run.
+// Sum order per output: ci -> kx -> ky, then + bias (conv2d.cpp:78-87).
+__global__ void pack_fwd_weights_3_16_3_2(const float* __restrict__ w, const float* __restrict__ bias,
+                                          float* __restrict__ wp) {
+    for (int i = threadIdx.x; i < 27 * 16; i += blockDim.x) {
+        const int t = i >> 4, co = i & 15;
+        wp[i] = w[co * 27 + t];
+    }
+    if (threadIdx.x < 16) wp[27 * 16 + threadIdx.x] = bias[threadIdx.x];
+}
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+template <bool RELU>
+__global__ __launch_bounds__(kBlock) void conv_fwd_pk_3_16_3_2(const float* __restrict__ x, const v2f* __restrict__ wp,
+                                                               float* __restrict__ y, float* __restrict__ y_relu, int B,
+                                                               int H, int W, int Ho, int Wo, int items_per_img) {
+    constexpr int CI = 3, CO = 16, K = 3;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long items = (long long)B * items_per_img;
+    const int plane = Ho * Wo;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * CI * H * W * 4u), 0x00020000);
+    for (long long it = (long long)blockIdx.x * kWaves + wave; it < items; it += (long long)gridDim.x * kWaves) {
+        const int b = (int)(it / items_per_img);
+        const int n = (int)(it - (long long)b * items_per_img) * 64 + lane;
+        const bool live = n < plane;
+        const int p = (live ? n : 0) / Wo, q = (live ? n : 0) - p * Wo;
+        const unsigned vo = live ? (unsigned)(2 * p * W + 2 * q) * 4u : kBufOOB;  // x[.][2p][2q]
+        float patch[CI * K * K];
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int so = (((b * CI + ci) * H + kx) * W) * 4;  // wave-uniform
+                const int l0 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)vo, so, 0);
+                const int l1 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)vo, so + 4, 0);
+                const int hi = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)vo, so + 8, 0);
+                patch[(ci * K + kx) * K + 0] = __builtin_bit_cast(float, l0);
+                patch[(ci * K + kx) * K + 1] = __builtin_bit_cast(float, l1);
+                patch[(ci * K + kx) * K + 2] = __builtin_bit_cast(float, hi);
+            }
+        v2f acc[CO / 2];
+#pragma unroll
+        for (int j = 0; j < CO / 2; ++j) acc[j] = v2f{0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < CI * K * K; ++t) {
+            asm volatile("" ::: "memory");  // stream the weight s_loads tap by tap (see conv_dgrad_pk)
+            const v2f* qw = wp + t * (CO / 2);
+            const v2f pv = {patch[t], patch[t]};
+#pragma unroll
+            for (int j = 0; j < CO / 2; ++j) acc[j] = __builtin_elementwise_fma(qw[j], pv, acc[j]);
+        }
+        if (!live) continue;
+        const v2f* qb = wp + CI * K * K * (CO / 2);
+        float* yb = y + (size_t)b * CO * plane + n;
+        float* rb = RELU ? y_relu + (size_t)b * CO * plane + n : nullptr;
+#pragma unroll
+        for (int j = 0; j < CO / 2; ++j) {
+            const v2f v = acc[j] + qb[j];
+            yb[(size_t)(2 * j) * plane] = v.x;
+            yb[(size_t)(2 * j + 1) * plane] = v.y;
+            if (RELU) {
+                rb[(size_t)(2 * j) * plane] = v.x >= 0.f ? v.x : 0.f;
+                rb[(size_t)(2 * j + 1) * plane] = v.y >= 0.f ? v.y : 0.f;
+            }
         }
     }
 }
@@ -148,8 +361,24 @@ bool direct_conv_supported(const cnn_conv2d_desc* d) {
 }
 
 int direct_conv_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
-                        float* y_relu, hipStream_t s) {
+                        float* y_relu, void* ws, size_t ws_bytes, hipStream_t s) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
+    // measured: the packed kernel wins when the ReLU output is fused in (121 vs 142 us), the plain row kernel otherwise
+    if (y_relu != nullptr && ws != nullptr && ws_bytes >= 28 * 16 * sizeof(float) &&
+        (long long)d->B * 3 * d->H * d->W * 4 < (1ll << 31) - 16 && !getenv("CNN_AMD_FWD_NOPK")) {
+        CNN_KLAUNCH(s, "pack_fwd_weights", (pack_fwd_weights_3_16_3_2<<<1, 256, 0, s>>>(w, bias, (float*)ws)), CONV_TAG(d));
+        const int ipi = (Ho * Wo + 63) / 64;
+        const long long witems = (long long)d->B * ipi;
+        if (y_relu)
+            CNN_KLAUNCH(s, "conv_fwd_pk<3,16,3,2>+relu",
+                        (conv_fwd_pk_3_16_3_2<true><<<wave_grid(witems), kBlock, 0, s>>>(x, (const v2f*)ws, y, y_relu, d->B, d->H,
+                                                                                        d->W, Ho, Wo, ipi)), CONV_TAG(d));
+        else
+            CNN_KLAUNCH(s, "conv_fwd_pk<3,16,3,2>",
+                        (conv_fwd_pk_3_16_3_2<false><<<wave_grid(witems), kBlock, 0, s>>>(x, (const v2f*)ws, y, nullptr, d->B, d->H,
+                                                                                         d->W, Ho, Wo, ipi)), CONV_TAG(d));
+        return CNN_AMD_OK;
+    }
     const long long rows = (long long)d->B * Ho;
     CNN_KLAUNCH(s, y_relu ? "conv_direct_fwd<3,16,3,2>+relu" : "conv_direct_fwd<3,16,3,2>",
                 (conv_direct_fwd<3, 16, 3, 2><<<wave_grid(rows), kBlock, 0, s>>>(x, w, bias, y, y_relu, d->B, d->H, d->W, Ho, Wo)),
@@ -157,12 +386,46 @@ int direct_conv_forward(const cnn_conv2d_desc* d, const float* x, const float* w
     return CNN_AMD_OK;
 }
 
-int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, hipStream_t s) {
+int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes,
+                      hipStream_t s) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
     const long long rows = (long long)d->B * ((d->H + d->s - 1) / d->s);
-    CNN_KLAUNCH(s, "conv_direct_dgrad<3,16,3,2>",
-                (conv_direct_dgrad<3, 16, 3, 2><<<wave_grid(rows), kBlock, 0, s>>>(dy, w, dx, d->B, d->H, d->W, Ho, Wo)),
-                CONV_TAG(d));
+    const int dbg = getenv("CNN_AMD_DBG") ? atoi(getenv("CNN_AMD_DBG")) : 0;
+    if (ws != nullptr && ws_bytes >= 16 * 32 * sizeof(float) && (long long)d->B * 16 * Ho * Wo * 4 < (1ll << 31) - 16 &&
+        !getenv("CNN_AMD_DG_NOPK")) {
+        CNN_KLAUNCH(s, "pack_dgrad_weights", (pack_dgrad_weights_3_16_3_2<<<1, 64, 0, s>>>(w, (float*)ws)), CONV_TAG(d));
+        const int cb = getenv("CNN_AMD_DG_UNROLL") ? atoi(getenv("CNN_AMD_DG_UNROLL")) : 4;
+        const int UVg = ((d->H + 1) / 2) * ((d->W + 1) / 2);
+        const int ipi = (UVg + 63) / 64;
+        const long long witems = (long long)d->B * ipi;
+#define PK_LAUNCH(U)                                                                                                   \
+    CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>",                                                                         \
+                (conv_dgrad_pk_3_16_3_2<U><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, Wo, ipi)), \
+                CONV_TAG(d))
+        if (dbg == 4) {
+            CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>", (conv_dgrad_pk_3_16_3_2<4, 4><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, Wo, ipi)), CONV_TAG(d));
+        } else if (dbg == 8) {
+            CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>", (conv_dgrad_pk_3_16_3_2<4, 8><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, Wo, ipi)), CONV_TAG(d));
+        } else if (dbg == 12) {
+            CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>", (conv_dgrad_pk_3_16_3_2<4, 12><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, Wo, ipi)), CONV_TAG(d));
+        } else
+        if (cb == 2) PK_LAUNCH(2);
+        else if (cb == 4) PK_LAUNCH(4);
+        else if (cb == 16) PK_LAUNCH(16);
+        else PK_LAUNCH(8);
+#undef PK_LAUNCH
+        return CNN_AMD_OK;
+    }
+    const int un = getenv("CNN_AMD_DG_UNROLL") ? atoi(getenv("CNN_AMD_DG_UNROLL")) : 4;
+#define DG_LAUNCH(U)                                                                                                  \
+    CNN_KLAUNCH(s, "conv_direct_dgrad<3,16,3,2>",                                                                    \
+                (conv_direct_dgrad<3, 16, 3, 2, U><<<wave_grid(rows), kBlock, 0, s>>>(dy, w, dx, d->B, d->H, d->W, Ho, Wo, dbg)), \
+                CONV_TAG(d))
+    if (un == 1) DG_LAUNCH(1);
+    else if (un == 2) DG_LAUNCH(2);
+    else if (un == 8) DG_LAUNCH(8);
+    else DG_LAUNCH(4);
+#undef DG_LAUNCH
     return CNN_AMD_OK;
 }
 

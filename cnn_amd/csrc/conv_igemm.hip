@@ -166,7 +166,7 @@ __device__ __forceinline__ void compute_chunk(const float* __restrict__ As, cons
 
 // Epilogue.  forward: y[b][m][pixel] (each (reg, half-wave) writes 32 / 16 consecutive pixels of one channel);
 // dgrad: virtual channel m = (ph*s+pw)*Ci + ci of grid pixel (u,v) -> dx[b][ci][u*s+ph][v*s+pw].
-template <int MF, int MA, int NB>
+template <int MF, int MA, int NB, bool R2>
 __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[MA][NB], const IgemmParams& p,
                                            long long n_first, long long n1, int mbase_wave, int li, int lh) {
     using A_ = Acc<MF>;
@@ -179,8 +179,11 @@ __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[M
         const int b = (int)(n / UV);
         const int rem = (int)(n - b * UV);
         if (p.mode == MODE_FWD) {
-            const size_t obase = ((size_t)b * p.M + mbase_wave) * UV + rem;
-            float* out = p.Y + obase;
+            float* out = p.Y + ((size_t)b * p.M + mbase_wave) * UV + rem;
+            // fused ReLU::forward: the second output tensor has the same layout, so its address is the first one's plus a
+            // wave-uniform distance (keeps the epilogue's register footprint that of the plain store)
+            // (R2 is a compile-time variant: as a run-time branch the extra stores cost every kernel 32 VGPRs)
+            const ptrdiff_t d2 = R2 ? (p.Y2 - p.Y) : 0;
 #pragma unroll
             for (int ma = 0; ma < MA; ++ma) {
 #pragma unroll
@@ -189,24 +192,11 @@ __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[M
                     float* o = out + (size_t)row0 * UV;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (full_m || mbase_wave + row0 + j < p.M) o[(size_t)j * UV] = acc[ma][nb][4 * g + j];
-                }
-            }
-            if (p.Y2 != nullptr) {  // fused ReLU::forward: second output tensor, same layout
-                float* out2 = p.Y2 + obase;
-#pragma unroll
-                for (int ma = 0; ma < MA; ++ma) {
-#pragma unroll
-                    for (int g = 0; g < A_::kRegs / 4; ++g) {
-                        const int row0 = ma * MF + A_::row(4 * g, lh);
-                        float* o = out2 + (size_t)row0 * UV;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (full_m || mbase_wave + row0 + j < p.M) {
-                                const float v = acc[ma][nb][4 * g + j];
-                                o[(size_t)j * UV] = v >= 0.f ? v : 0.f;
-                            }
-                    }
+                        if (full_m || mbase_wave + row0 + j < p.M) {
+                            const float v = acc[ma][nb][4 * g + j];
+                            o[(size_t)j * UV] = v;
+                            if constexpr (R2) o[(size_t)j * UV + d2] = v >= 0.f ? v : 0.f;
+                        }
                 }
             }
         } else {
@@ -231,7 +221,7 @@ __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[M
 
 // MF: MFMA tile edge; MA x NB tiles per wave; WM x WN waves per workgroup; CK channels per LDS chunk.
 // NARROW selects the row-staging scheme at compile time (keeping both in one kernel costs ~50 VGPRs of occupancy).
-template <int MF, int MA, int NB, int WM, int WN, int CK, bool NARROW>
+template <int MF, int MA, int NB, int WM, int WN, int CK, bool NARROW, bool R2>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p) {
     using A_ = Acc<MF>;
     constexpr int NWAVES = WM * WN;
@@ -443,7 +433,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
         if (!(p.dbg & 4)) compute_chunk<MF, MA, NB, CK, MT>(As, Xs, pix_off, a_lane, acc, p);
     }
 
-    if (!(p.dbg & 8)) store_tile<MF, MA, NB>(acc, p, n0 + wn * NB * MF, n1, mbase_wave, li, lh);
+    if (!(p.dbg & 8)) store_tile<MF, MA, NB, R2>(acc, p, n0 + wn * NB * MF, n1, mbase_wave, li, lh);
 }
 
 // ---- double-buffered variant: HBM -> LDS by DMA (global_load_lds), one barrier per chunk -------------------------
@@ -466,7 +456,7 @@ typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
 //     chunk costs a handful of DMA instructions with trivial addressing (row staging of 6..27-float rows is bound by
 //     instruction issue, not by bytes).  LDS image = [image][ck][XH*XW]; there are no pad columns / zero rows: XM == 2
 //     masks the B operands of taps that leave the image instead (per-lane row / column bit masks).
-template <int MF, int MA, int NB, int WM, int WN, int S, int XM = 0>  // S = k-steps per tap = channels per chunk / KSTEP
+template <int MF, int MA, int NB, int WM, int WN, int S, int XM, bool R2>  // S = k-steps per tap = channels per chunk / KSTEP
 __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmParams p) {
     using A_ = Acc<MF>;
     constexpr int KSTEP = A_::kStep, CK = KSTEP * S;
@@ -823,7 +813,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         }
         }
         }
-    if (!(p.dbg & 8)) store_tile<MF, MA, NB>(acc, p, (long long)n0 + (long long)wn * NB * MF, n1, mbase_wave, li, lh);
+    if (!(p.dbg & 8)) store_tile<MF, MA, NB, R2>(acc, p, (long long)n0 + (long long)wn * NB * MF, n1, mbase_wave, li, lh);
 }
 
 // ---- weight preparation: [Co][Ci][k][k]  ->  A[mblock][chunk][tap][ck][MT] (zero padded) -------------------
@@ -1081,9 +1071,9 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
 
 #define CONV_TAG(d) "B%d Ci%d %dx%d Co%d k%d s%d p%d", (d)->B, (d)->Ci, (d)->H, (d)->W, (d)->Co, (d)->k, (d)->s, (d)->pad
 
-template <int MF, int MA, int NB, int WM, int WN, int CK, bool NARROW>
-int launch_cfg2(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
-    auto kern = igemm_kernel<MF, MA, NB, WM, WN, CK, NARROW>;
+template <int MF, int MA, int NB, int WM, int WN, int CK, bool NARROW, bool R2>
+int launch_cfg3(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
+    auto kern = igemm_kernel<MF, MA, NB, WM, WN, CK, NARROW, R2>;
     static thread_local size_t max_set = 0;
     if (pl.lds_bytes > 48 * 1024 && pl.lds_bytes > max_set) {
         CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1091,14 +1081,20 @@ int launch_cfg2(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
     }
     char name[96];
     snprintf(name, sizeof(name), "igemm_kernel<%d,%d,%d,%d,%d,%d>%s", MF, MA, NB, WM, WN, CK,
-             pl.p.mode == MODE_FWD ? "/fwd" : "/dgrad");
+             pl.p.mode == MODE_FWD ? (R2 ? "/fwd+relu" : "/fwd") : "/dgrad");
     CNN_KLAUNCH(s, name, (kern<<<dim3(pl.grid_x, pl.grid_y), 64 * WM * WN, pl.lds_bytes, s>>>(pl.p)), CONV_TAG(d));
     return CNN_AMD_OK;
 }
 
-template <int MF, int MA, int NB, int WM, int WN, int S, int XM>
-int launch_dma_xm(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
-    auto kern = igemm_dma_kernel<MF, MA, NB, WM, WN, S, XM>;
+template <int MF, int MA, int NB, int WM, int WN, int CK, bool NARROW>
+int launch_cfg2(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
+    return pl.p.Y2 != nullptr ? launch_cfg3<MF, MA, NB, WM, WN, CK, NARROW, true>(pl, s, d)
+                              : launch_cfg3<MF, MA, NB, WM, WN, CK, NARROW, false>(pl, s, d);
+}
+
+template <int MF, int MA, int NB, int WM, int WN, int S, int XM, bool R2>
+int launch_dma_xm2(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
+    auto kern = igemm_dma_kernel<MF, MA, NB, WM, WN, S, XM, R2>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1106,9 +1102,18 @@ int launch_dma_xm(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
     }
     char name[96];
     snprintf(name, sizeof(name), "igemm_dma_kernel<%d,%d,%d,%d,%d,%d%s>%s", MF, MA, NB, WM, WN, S,
-             XM == 0 ? "" : (XM == 1 ? ",img" : (XM == 2 ? ",img+mask" : ",img+mask+skip")), pl.p.mode == MODE_FWD ? "/fwd" : "/dgrad");
+             XM == 0 ? "" : (XM == 1 ? ",img" : (XM == 2 ? ",img+mask" : ",img+mask+skip")),
+             pl.p.mode == MODE_FWD ? (R2 ? "/fwd+relu" : "/fwd") : "/dgrad");
     CNN_KLAUNCH(s, name, (kern<<<dim3(pl.grid_x, pl.grid_y), 64 * WM * WN, pl.lds_bytes, s>>>(pl.p)), CONV_TAG(d));
     return CNN_AMD_OK;
+}
+
+template <int MF, int MA, int NB, int WM, int WN, int S, int XM>
+int launch_dma_xm(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
+    if constexpr (XM != 3) {  // (XM == 3 is a dgrad-only variant)
+        if (pl.p.Y2 != nullptr) return launch_dma_xm2<MF, MA, NB, WM, WN, S, XM, true>(pl, s, d);
+    }
+    return launch_dma_xm2<MF, MA, NB, WM, WN, S, XM, false>(pl, s, d);
 }
 
 // IMG: this tile shape also has the whole-image staging instantiations (the small-image configs)
@@ -1205,14 +1210,16 @@ int check_desc(const char* who, const cnn_conv2d_desc* d) {
 namespace cnn_amd {
 bool direct_conv_supported(const cnn_conv2d_desc* d);  // conv_direct.hip: thin first layers bypass the implicit GEMM
 int direct_conv_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, float* y_relu,
-                        hipStream_t s);
-int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, hipStream_t s);
+                        void* ws, size_t ws_bytes, hipStream_t s);
+int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes,
+                      hipStream_t s);
 // scratch floats the forward / dgrad plans need (used by cnn_conv2d_workspace_bytes in conv_wgrad.hip)
 size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
     Plan a, b;
     size_t n = 0;
     if (make_plan("ws", d, MODE_FWD, &a) == CNN_AMD_OK) n = a.a_floats;
     if (make_plan("ws", d, MODE_DGRAD, &b) == CNN_AMD_OK && b.a_floats > n) n = b.a_floats;
+    if (direct_conv_supported(d) && n < 1024) n = 1024;  // packed filter copies of the direct kernels (conv_direct.hip)
     return n;
 }
 }  // namespace cnn_amd
@@ -1223,7 +1230,7 @@ static int conv2d_forward_impl(const char* who, const cnn_conv2d_desc* d, const 
                                float* y, float* y_relu, void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_desc(who, d)) return rc;
     CNN_REQUIRE(x && w && bias && y, "%s: null pointer", who);
-    if (direct_conv_supported(d)) return direct_conv_forward(d, x, w, bias, y, y_relu, as_stream(stream));
+    if (direct_conv_supported(d)) return direct_conv_forward(d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream));
     Plan pl;
     if (int rc = make_plan(who, d, MODE_FWD, &pl)) return rc;
     return run_plan(pl, d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream), who);
@@ -1244,7 +1251,7 @@ int cnn_conv2d_backward_data(const cnn_conv2d_desc* d, const float* dy, const fl
                              size_t ws_bytes, void* stream) {
     if (int rc = check_desc("cnn_conv2d_backward_data", d)) return rc;
     CNN_REQUIRE(dy && w && dx, "cnn_conv2d_backward_data: null pointer");
-    if (direct_conv_supported(d)) return direct_conv_dgrad(d, dy, w, dx, as_stream(stream));
+    if (direct_conv_supported(d)) return direct_conv_dgrad(d, dy, w, dx, ws, ws_bytes, as_stream(stream));
     Plan pl;
     if (int rc = make_plan("cnn_conv2d_backward_data", d, MODE_DGRAD, &pl)) return rc;
     return run_plan(pl, d, dy, w, nullptr, dx, nullptr, ws, ws_bytes, as_stream(stream), "cnn_conv2d_backward_data");
