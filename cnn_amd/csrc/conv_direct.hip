@@ -173,12 +173,21 @@ __global__ void pack_dgrad_weights_3_16_3_2(const float* __restrict__ w, float* 
 // num_records, for which the hardware returns 0 -- no masks, no branches (requires the dy tensor to be < 2 GiB).
 constexpr unsigned kBufOOB = 0x7ffffffcu;
 
+// n / d for the small non-negative operands of the item -> (image, pixel) -> (row, column) decodes below, without the ~40
+// instruction integer-division sequence: magic = 2^32 / d + 1 (host side), one correction step covers the rounding
+__device__ __forceinline__ int fast_div(int n, unsigned magic, int d) {
+    int q = (int)__umulhi((unsigned)n, magic);
+    if (q * d > n) --q;
+    return q;
+}
+inline unsigned div_magic(int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
+
 // One wave-item = 64 consecutive grid pixels of one image (rows are crossed, so every lane is busy); CB channels per
 // batch: all 4*CB loads of a batch are in flight before its first FMA.
 template <int CB, int DBG = 0>
 __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_3_16_3_2(const float* __restrict__ dy, const v2f* __restrict__ wp,
                                                                  float* __restrict__ dx, int B, int H, int W, int Ho,
-                                                                 int Wo, int items_per_img) {
+                                                                 int Wo, int items_per_img, unsigned m_ipi, unsigned m_row) {
     constexpr int CO = 16, CI = 3;
     const int U = (H + 1) / 2, V = (W + 1) / 2;
     const int UV = U * V;
@@ -188,11 +197,11 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_3_16_3_2(const float* __
     const int plane = Ho * Wo;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * CO * plane * 4u), 0x00020000);
-    for (long long it = (long long)blockIdx.x * kWaves + wave; it < items; it += (long long)gridDim.x * kWaves) {
-        const int b = (int)(it / items_per_img);
-        const int n = (int)(it - (long long)b * items_per_img) * 64 + lane;
+    for (int it = blockIdx.x * kWaves + wave; it < (int)items; it += gridDim.x * kWaves) {
+        const int b = fast_div(it, m_ipi, items_per_img);
+        const int n = (it - b * items_per_img) * 64 + lane;
         const bool live = n < UV;
-        const int hh = (live ? n : 0) / V, ww = (live ? n : 0) - hh * V;
+        const int hh = fast_div(live ? n : 0, m_row, V), ww = (live ? n : 0) - hh * V;
         // taps: dy rows hh (jr = 0) / hh-1 (jr = 1), columns ww (jc = 0) / ww-1 (jc = 1); a missing tap gets an out-of-range
         // offset and reads as 0
         const bool r0ok = live && hh < Ho, r1ok = live && hh >= 1, c0ok = ww < Wo, c1ok = ww >= 1;
@@ -287,7 +296,8 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 template <bool RELU>
 __global__ __launch_bounds__(kBlock) void conv_fwd_pk_3_16_3_2(const float* __restrict__ x, const v2f* __restrict__ wp,
                                                                float* __restrict__ y, float* __restrict__ y_relu, int B,
-                                                               int H, int W, int Ho, int Wo, int items_per_img) {
+                                                               int H, int W, int Ho, int Wo, int items_per_img,
+                                                               unsigned m_ipi, unsigned m_row) {
     constexpr int CI = 3, CO = 16, K = 3;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -295,11 +305,11 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_pk_3_16_3_2(const float* __re
     const int plane = Ho * Wo;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * CI * H * W * 4u), 0x00020000);
-    for (long long it = (long long)blockIdx.x * kWaves + wave; it < items; it += (long long)gridDim.x * kWaves) {
-        const int b = (int)(it / items_per_img);
-        const int n = (int)(it - (long long)b * items_per_img) * 64 + lane;
+    for (int it = blockIdx.x * kWaves + wave; it < (int)items; it += gridDim.x * kWaves) {
+        const int b = fast_div(it, m_ipi, items_per_img);
+        const int n = (it - b * items_per_img) * 64 + lane;
         const bool live = n < plane;
-        const int p = (live ? n : 0) / Wo, q = (live ? n : 0) - p * Wo;
+        const int p = fast_div(live ? n : 0, m_row, Wo), q = (live ? n : 0) - p * Wo;
         const unsigned vo = live ? (unsigned)(2 * p * W + 2 * q) * 4u : kBufOOB;  // x[.][2p][2q]
         float patch[CI * K * K];
 #pragma unroll
@@ -342,6 +352,233 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_pk_3_16_3_2(const float* __re
     }
 }
 
+// ---- packed-math weight + bias gradient for the same layer ----------------------------------------------------------
+// gw[co][t] = sum_pixels dy[co][pixel] * patch[t][pixel], t = (ci,kx,ky); gb[co] = sum_pixels dy[co][pixel]
+// (conv2d.cpp:117-159 without the 1/B, which the slab reduction applies).  K = 27 is far too thin for MFMA tiles, so
+// this is a VALU kernel: a workgroup walks 64-pixel items; per item the 27 patch rows and 16 dy rows (64 floats each) are
+// fetched ONCE by the four waves together (raw buffer loads, tail pixels read 0) into a double-buffered LDS stage while
+// the previous item is being consumed; wave w owns output channels 4w..4w+3 and keeps its 4 x (27+1) running sums in
+// registers as 14 float pairs per channel (v_pk_fma_f32: patch pair x broadcast dy) + a bias sum.  At the end every wave
+// reduces its sums across lanes and writes one slab row set; reduce_slabs() adds the slabs in a fixed order.
+constexpr int kWgX = 7;       // patch rows each wave stages per item (4 x 7 = 28 >= 27 taps; the 28th is the zero pad)
+template <int kWgDepth>  // items in flight per workgroup
+__global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 float* __restrict__ slabs, int B, int H, int W, int Ho,
+                                                                 int Wo, int items_per_img, unsigned m_ipi, unsigned m_row) {
+    constexpr int CI = 3, CO = 16, NP = 14;  // NP float pairs cover the 27 taps (+1 zero pad)
+    __shared__ float stage[2][4 * kWgX][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long items = (long long)B * items_per_img;
+    const int plane = Ho * Wo;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * CI * H * W * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * CO * plane * 4u), 0x00020000);
+    // wave w stages taps 7w .. 7w+6 of x (tap 27 does not exist: it reads out of range = the zero pad) and loads the dy
+    // rows of ITS output channels 4w .. 4w+3, which never go through LDS.  Everything below is branch-free on purpose
+    // (an item past the end reads out of range = 0 and adds nothing): with straight-line code hipcc counts the outstanding
+    // loads (s_waitcnt vmcnt(N > 0)) instead of draining the queue at every control-flow merge.
+    int tap_off[kWgX];
+    bool tap_ok[kWgX];
+#pragma unroll
+    for (int i = 0; i < kWgX; ++i) {
+        const int r = wave * kWgX + i;
+        const int ci = r / 9, kx = (r - ci * 9) / 3, ky = r - ci * 9 - kx * 3;
+        tap_ok[i] = r < 27;
+        tap_off[i] = ((ci * H + kx) * W + ky) * 4;
+    }
+    float lx[kWgDepth][kWgX], ldy[kWgDepth][4];
+    auto issue = [&](long long it, float(&ax)[kWgX], float(&ad)[4]) {
+        const bool inr = it < items;
+        const int iti = inr ? (int)it : 0;
+        const int b = fast_div(iti, m_ipi, items_per_img);
+        const int n = (iti - b * items_per_img) * 64 + lane;
+        const bool live = inr && n < plane;
+        const int p = fast_div(live ? n : 0, m_row, Wo), q = (live ? n : 0) - p * Wo;
+        const unsigned vx = live ? (unsigned)(2 * p * W + 2 * q) * 4u : kBufOOB;
+        const unsigned vd = live ? (unsigned)n * 4u : kBufOOB;
+        const int sx = b * CI * H * W * 4, sd = (b * CO + 4 * wave) * plane * 4;
+#pragma unroll
+        for (int i = 0; i < kWgX; ++i)
+            ax[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(tap_ok[i] ? vx : kBufOOB), sx + tap_off[i], 0));
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            ad[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, (int)vd, sd + c * plane * 4, 0));
+    };
+
+    v2f A[4][NP];
+    float bs[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bs[c] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) A[c][j] = v2f{0.f, 0.f};
+    }
+    const long long stride = gridDim.x;
+    long long it = blockIdx.x;
+#pragma unroll
+    for (int dd = 0; dd < kWgDepth; ++dd) issue(it + dd * stride, lx[dd], ldy[dd]);
+    int k = 0;
+    auto consume = [&](float(&ax)[kWgX], float(&ad)[4]) {  // item `it`: registers -> LDS, refill the register set, accumulate
+        float(*st)[64] = stage[k & 1];
+#pragma unroll
+        for (int i = 0; i < kWgX; ++i) st[wave * kWgX + i][lane] = ax[i];
+        float d[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = ad[c];
+        // LDS-only barrier: __syncthreads() would also drain the global loads that are deliberately still in flight (its
+        // fence covers every address space -> s_waitcnt vmcnt(0)).  One barrier per item: the buffer written now was last
+        // read two items ago.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        issue(it + kWgDepth * stride, ax, ad);
+        v2f pv[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) pv[j] = v2f{st[2 * j][lane], st[2 * j + 1][lane]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const v2f dd = {d[c], d[c]};
+            bs[c] += d[c];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) A[c][j] = __builtin_elementwise_fma(pv[j], dd, A[c][j]);
+        }
+        ++k;
+        it += stride;
+    };
+    while (it < items) {  // (up to kWgDepth-1 trailing consume() calls see all-zero items)
+#pragma unroll
+        for (int dd = 0; dd < kWgDepth; ++dd) consume(lx[dd], ldy[dd]);
+    }
+    // ---- cross-lane reduction (fixed xor tree) and the slab row set of this workgroup ----
+    float* out = slabs + (size_t)blockIdx.x * CO * 28 + (size_t)(4 * wave) * 28;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            float a = A[c][j].x, b2 = A[c][j].y;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                a += __shfl_xor(a, o, 64);
+                b2 += __shfl_xor(b2, o, 64);
+            }
+            if (lane == 0) {
+                out[c * 28 + 2 * j] = a;
+                if (2 * j + 1 < 27) out[c * 28 + 2 * j + 1] = b2;
+            }
+        }
+        float t = bs[c];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (lane == 0) out[c * 28 + 27] = t;
+    }
+}
+
+// Variant without LDS and without barriers: wave w owns taps 7w .. 7w+6 for ALL 16 output channels (7 x 8 channel
+// pairs of running sums); it loads its 7 patch rows and the 16 dy rows itself (the dy rows are shared by the four waves
+// of a workgroup through L1).  The waves are independent, so each keeps kDepth items of loads in flight.
+template <int kDepth>
+__global__ __launch_bounds__(kBlock) void conv_wgrad_pk2_3_16_3_2(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  float* __restrict__ slabs, int B, int H, int W, int Ho,
+                                                                  int Wo, int items_per_img, unsigned m_ipi, unsigned m_row) {
+    constexpr int CI = 3, CO = 16, NT = 7;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long items = (long long)B * items_per_img;
+    const int plane = Ho * Wo;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * CI * H * W * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * CO * plane * 4u), 0x00020000);
+    int tap_off[NT];
+    bool tap_ok[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int r = wave * NT + i;
+        const int ci = r / 9, kx = (r - ci * 9) / 3, ky = r - ci * 9 - kx * 3;
+        tap_ok[i] = r < 27;
+        tap_off[i] = ((ci * H + kx) * W + ky) * 4;
+    }
+    float lx[kDepth][NT], ld[kDepth][CO];
+    auto issue = [&](long long it, float(&ax)[NT], float(&ad)[CO]) {  // branch-free, see conv_wgrad_pk
+        const bool inr = it < items;
+        const int iti = inr ? (int)it : 0;
+        const int b = fast_div(iti, m_ipi, items_per_img);
+        const int n = (iti - b * items_per_img) * 64 + lane;
+        const bool live = inr && n < plane;
+        const int p = fast_div(live ? n : 0, m_row, Wo), q = (live ? n : 0) - p * Wo;
+        const unsigned vx = live ? (unsigned)(2 * p * W + 2 * q) * 4u : kBufOOB;
+        const unsigned vd = live ? (unsigned)n * 4u : kBufOOB;
+        const int sx = b * CI * H * W * 4, sd = b * CO * plane * 4;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+            ax[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(tap_ok[i] ? vx : kBufOOB), sx + tap_off[i], 0));
+#pragma unroll
+        for (int c = 0; c < CO; ++c)
+            ad[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, (int)vd, sd + c * plane * 4, 0));
+    };
+    v2f A[NT][CO / 2], bs[CO / 2];
+#pragma unroll
+    for (int j = 0; j < CO / 2; ++j) {
+        bs[j] = v2f{0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NT; ++i) A[i][j] = v2f{0.f, 0.f};
+    }
+    const long long stride = gridDim.x;
+    long long it = blockIdx.x;
+#pragma unroll
+    for (int dd = 0; dd < kDepth; ++dd) issue(it + dd * stride, lx[dd], ld[dd]);
+    auto consume = [&](float(&ax)[NT], float(&ad)[CO]) {
+        float xv[NT];
+        v2f dv[CO / 2];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) xv[i] = ax[i];
+#pragma unroll
+        for (int j = 0; j < CO / 2; ++j) dv[j] = v2f{ad[2 * j], ad[2 * j + 1]};
+        issue(it + kDepth * stride, ax, ad);
+#pragma unroll
+        for (int j = 0; j < CO / 2; ++j) bs[j] += dv[j];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const v2f pv = {xv[i], xv[i]};
+#pragma unroll
+            for (int j = 0; j < CO / 2; ++j) A[i][j] = __builtin_elementwise_fma(dv[j], pv, A[i][j]);
+        }
+        it += stride;
+    };
+    while (it < items) {
+#pragma unroll
+        for (int dd = 0; dd < kDepth; ++dd) consume(lx[dd], ld[dd]);
+    }
+    float* out = slabs + (size_t)blockIdx.x * CO * 28;
+    auto wsum = [&](float v) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int t = wave * NT + i;
+#pragma unroll
+        for (int j = 0; j < CO / 2; ++j) {
+            const float a = wsum(A[i][j].x), b2 = wsum(A[i][j].y);
+            if (lane == 0 && t < 27) {
+                out[(2 * j) * 28 + t] = a;
+                out[(2 * j + 1) * 28 + t] = b2;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CO / 2; ++j) {
+        const float a = wsum(bs[j].x), b2 = wsum(bs[j].y);
+        if (lane == 0 && wave == 0) {
+            out[(2 * j) * 28 + 27] = a;
+            out[(2 * j + 1) * 28 + 27] = b2;
+        }
+    }
+}
+
 inline unsigned wave_grid(long long rows) {
     long long need = (rows + kWaves - 1) / kWaves;
     const long long cap = (long long)kNumCU * 32;
@@ -372,11 +609,11 @@ int direct_conv_forward(const cnn_conv2d_desc* d, const float* x, const float* w
         if (y_relu)
             CNN_KLAUNCH(s, "conv_fwd_pk<3,16,3,2>+relu",
                         (conv_fwd_pk_3_16_3_2<true><<<wave_grid(witems), kBlock, 0, s>>>(x, (const v2f*)ws, y, y_relu, d->B, d->H,
-                                                                                        d->W, Ho, Wo, ipi)), CONV_TAG(d));
+                                                                                        d->W, Ho, Wo, ipi, div_magic(ipi), div_magic(Wo))), CONV_TAG(d));
         else
             CNN_KLAUNCH(s, "conv_fwd_pk<3,16,3,2>",
                         (conv_fwd_pk_3_16_3_2<false><<<wave_grid(witems), kBlock, 0, s>>>(x, (const v2f*)ws, y, nullptr, d->B, d->H,
-                                                                                         d->W, Ho, Wo, ipi)), CONV_TAG(d));
+                                                                                         d->W, Ho, Wo, ipi, div_magic(ipi), div_magic(Wo))), CONV_TAG(d));
         return CNN_AMD_OK;
     }
     const long long rows = (long long)d->B * Ho;
@@ -400,14 +637,14 @@ int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w,
         const long long witems = (long long)d->B * ipi;
 #define PK_LAUNCH(U)                                                                                                   \
     CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>",                                                                         \
-                (conv_dgrad_pk_3_16_3_2<U><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, Wo, ipi)), \
+                (conv_dgrad_pk_3_16_3_2<U><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, Wo, ipi, div_magic(ipi), div_magic((d->W + 1) / 2))), \
                 CONV_TAG(d))
         if (dbg == 4) {
-            CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>", (conv_dgrad_pk_3_16_3_2<4, 4><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, Wo, ipi)), CONV_TAG(d));
+            CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>", (conv_dgrad_pk_3_16_3_2<4, 4><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, Wo, ipi, div_magic(ipi), div_magic((d->W + 1) / 2))), CONV_TAG(d));
         } else if (dbg == 8) {
-            CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>", (conv_dgrad_pk_3_16_3_2<4, 8><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, Wo, ipi)), CONV_TAG(d));
+            CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>", (conv_dgrad_pk_3_16_3_2<4, 8><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, Wo, ipi, div_magic(ipi), div_magic((d->W + 1) / 2))), CONV_TAG(d));
         } else if (dbg == 12) {
-            CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>", (conv_dgrad_pk_3_16_3_2<4, 12><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, Wo, ipi)), CONV_TAG(d));
+            CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>", (conv_dgrad_pk_3_16_3_2<4, 12><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, Wo, ipi, div_magic(ipi), div_magic((d->W + 1) / 2))), CONV_TAG(d));
         } else
         if (cb == 2) PK_LAUNCH(2);
         else if (cb == 4) PK_LAUNCH(4);
@@ -426,6 +663,48 @@ int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w,
     else if (un == 8) DG_LAUNCH(8);
     else DG_LAUNCH(4);
 #undef DG_LAUNCH
+    return CNN_AMD_OK;
+}
+
+
+// number of slabs (workgroups) the packed weight-gradient kernel writes; 0 when the geometry / sizes rule it out
+int direct_wgrad_slots(const cnn_conv2d_desc* d) {
+    if (!direct_conv_supported(d) || getenv("CNN_AMD_WG_NOPK")) return 0;
+    const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
+    if ((long long)d->B * 16 * Ho * Wo * 4 >= (1ll << 31) - 16 || (long long)d->B * 3 * d->H * d->W * 4 >= (1ll << 31) - 16) return 0;
+    const long long items = (long long)d->B * ((Ho * Wo + 63) / 64);
+    const long long cap = (long long)kNumCU * (getenv("CNN_AMD_WG_BPC") ? atoi(getenv("CNN_AMD_WG_BPC")) : 2);  // resident workgroups per CU (~200 VGPRs)
+    return (int)(items < cap ? items : cap);
+}
+
+// writes direct_wgrad_slots(d) slabs of 16 x 28 floats ([27 weight sums | 1 bias sum] per output channel)
+int direct_conv_wgrad(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s) {
+    const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
+    const int ipi = (Ho * Wo + 63) / 64;
+    const int depth = getenv("CNN_AMD_WG_DEPTH") ? atoi(getenv("CNN_AMD_WG_DEPTH")) : 3;
+#define WG_LAUNCH(D)                                                                                                      \
+    CNN_KLAUNCH(s, "conv_wgrad_pk<3,16,3,2>",                                                                            \
+                (conv_wgrad_pk_3_16_3_2<D><<<direct_wgrad_slots(d), kBlock, 0, s>>>(x, dy, slabs, d->B, d->H, d->W, Ho, Wo, ipi, div_magic(ipi), div_magic(Wo))), \
+                CONV_TAG(d))
+    if (getenv("CNN_AMD_WG_V2")) {
+        const int v = atoi(getenv("CNN_AMD_WG_V2"));
+#define WG2_LAUNCH(D)                                                                                                     \
+    CNN_KLAUNCH(s, "conv_wgrad_pk2<3,16,3,2>",                                                                           \
+                (conv_wgrad_pk2_3_16_3_2<D><<<direct_wgrad_slots(d), kBlock, 0, s>>>(x, dy, slabs, d->B, d->H, d->W, Ho, Wo, ipi, div_magic(ipi), div_magic(Wo))), \
+                CONV_TAG(d))
+        if (v == 1) WG2_LAUNCH(1);
+        else if (v == 3) WG2_LAUNCH(3);
+        else if (v == 4) WG2_LAUNCH(4);
+        else WG2_LAUNCH(2);
+#undef WG2_LAUNCH
+        return CNN_AMD_OK;
+    }
+    if (depth == 2) WG_LAUNCH(2);
+    else if (depth == 3) WG_LAUNCH(3);
+    else if (depth == 5) WG_LAUNCH(5);
+    else if (depth == 6) WG_LAUNCH(6);
+    else WG_LAUNCH(4);
+#undef WG_LAUNCH
     return CNN_AMD_OK;
 }
 

@@ -15,6 +15,8 @@ using namespace cnn_amd;
 
 namespace cnn_amd {
 size_t igemm_workspace_floats(const cnn_conv2d_desc* d);  // conv_igemm.hip
+int direct_wgrad_slots(const cnn_conv2d_desc* d);          // conv_direct.hip: thin first layer, packed VALU kernel
+int direct_conv_wgrad(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
 }
 
 namespace {
@@ -531,7 +533,11 @@ size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d) {
     size_t wg = 0;
     if (make_wplan("cnn_conv2d_workspace_bytes", d, &pl) == CNN_AMD_OK) wg = pl.part_floats + pl.bias_floats + pl.tmp_floats;
     const size_t ig = igemm_workspace_floats(d);
-    return ((wg > ig ? wg : ig) + 64) * sizeof(float);
+    const int ds = direct_wgrad_slots(d);
+    const size_t dw = ds ? (size_t)(ds + (ds + 63) / 64) * 16 * 28 : 0;  // slabs + stage-1 scratch of the direct kernel
+    size_t m = wg > ig ? wg : ig;
+    if (dw > m) m = dw;
+    return (m + 64) * sizeof(float);
 }
 
 int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const float* dy, float* gw, float* gb,
@@ -539,9 +545,21 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
     if (int rc = check_desc("cnn_conv2d_backward_weight", d)) return rc;
     CNN_REQUIRE(x && dy && gw, "cnn_conv2d_backward_weight: null pointer");
     CNN_REQUIRE(divisor != 0.f, "cnn_conv2d_backward_weight: divisor is 0");
+    CNN_REQUIRE(ws != nullptr, "cnn_conv2d_backward_weight: workspace is null");
+    if (const int ds = direct_wgrad_slots(d)) {
+        const size_t n = 16 * 28, need_d = (size_t)(ds + (ds + 63) / 64) * n * sizeof(float);
+        if (ws_bytes >= need_d) {
+            hipStream_t sd = as_stream(stream);
+            if (int rc = direct_conv_wgrad(d, x, dy, (float*)ws, sd)) return rc;
+            char tagd[160];
+            snprintf(tagd, sizeof(tagd), CONV_TAG(d));
+            float gb_dummy_unused = 0.f;
+            (void)gb_dummy_unused;
+            return reduce_slabs(sd, (const float*)ws, ds, n, (float*)ws + (size_t)ds * n, gw, divisor, tagd, 27, gb);
+        }
+    }
     WPlan pl;
     if (int rc = make_wplan("cnn_conv2d_backward_weight", d, &pl)) return rc;
-    CNN_REQUIRE(ws != nullptr, "cnn_conv2d_backward_weight: workspace is null");
     const size_t need = (pl.part_floats + pl.bias_floats + pl.tmp_floats) * sizeof(float);
     if (ws_bytes < need)
         return fail(CNN_AMD_E_WORKSPACE, "cnn_conv2d_backward_weight: workspace %zu B < %zu B", ws_bytes, need);
