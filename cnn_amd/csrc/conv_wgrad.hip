@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kBiasBlock) void bias_grad_partial(const float* __r
     }
 }
 // ---- host planning -----------------------------------------------------------------------------------------
-enum { W_128x288 = 0, W_64x320, W_32x160, W_16x32 };
+enum { W_128x288 = 0, W_64x320, W_32x160, W_16x32, W_64x64, W_64x128, W_64x192, W_128x96, W_32x64 };
 
 struct WPlan {
     int cfg, MF, MTB, NTB, WK, threads;
@@ -400,10 +400,25 @@ int make_wplan(const char* who, const cnn_conv2d_desc* d, WPlan* pl) {
     p.Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
     CNN_REQUIRE(p.Ho > 0 && p.Wo > 0, "%s: empty output", who);
     p.Ntot = d->Ci * d->k * d->k;
-    if (p.Co > 64) { pl->cfg = W_128x288; pl->MF = 32; pl->MTB = 128; pl->NTB = 288; pl->WK = 1; pl->threads = 256; }
+    const long long kpix = (long long)p.B * p.Ho * p.Wo;  // the GEMM's K
+    // short-K problems (the reference net's last layers): narrower tiles mean fewer / smaller split-K slabs, and an N tile
+    // that does not divide Ci*k*k leaves a spare column for the fused bias gradient (measured on conv_layer_3 / _4)
+    if (p.Co > 64 && kpix <= 16384) { pl->cfg = W_64x320; pl->MF = 32; pl->MTB = 64; pl->NTB = 320; pl->WK = 1; pl->threads = 256; }
+    else if (p.Co > 64) { pl->cfg = W_128x288; pl->MF = 32; pl->MTB = 128; pl->NTB = 288; pl->WK = 1; pl->threads = 256; }
+    else if (p.Co > 32 && kpix <= 65536 && p.Ntot <= 384) { pl->cfg = W_64x192; pl->MF = 32; pl->MTB = 64; pl->NTB = 192; pl->WK = 1; pl->threads = 256; }
     else if (p.Co > 32) { pl->cfg = W_64x320; pl->MF = 32; pl->MTB = 64; pl->NTB = 320; pl->WK = 1; pl->threads = 256; }
     else if (p.Co > 16) { pl->cfg = W_32x160; pl->MF = 32; pl->MTB = 32; pl->NTB = 160; pl->WK = 4; pl->threads = 256; }
     else { pl->cfg = W_16x32; pl->MF = 16; pl->MTB = 16; pl->NTB = 32; pl->WK = 4; pl->threads = 256; }
+    if (const char* ov = getenv("CNN_AMD_WGRAD_CFG")) {  // tuning override
+        const int c = atoi(ov);
+        if (c == W_64x64 && p.Co > 32) { pl->cfg = c; pl->MF = 32; pl->MTB = 64; pl->NTB = 64; pl->WK = 1; }
+        if (c == W_64x128 && p.Co > 32) { pl->cfg = c; pl->MF = 32; pl->MTB = 64; pl->NTB = 128; pl->WK = 1; }
+        if (c == W_64x192 && p.Co > 32) { pl->cfg = c; pl->MF = 32; pl->MTB = 64; pl->NTB = 192; pl->WK = 1; }
+        if (c == W_128x96 && p.Co > 64) { pl->cfg = c; pl->MF = 32; pl->MTB = 128; pl->NTB = 96; pl->WK = 1; }
+        if (c == W_32x64 && p.Co > 16) { pl->cfg = c; pl->MF = 32; pl->MTB = 32; pl->NTB = 64; pl->WK = 2; }
+        if (c == W_64x320 && p.Co > 32) { pl->cfg = c; pl->MF = 32; pl->MTB = 64; pl->NTB = 320; pl->WK = 1; }
+        if (c == W_32x160 && p.Co > 16) { pl->cfg = c; pl->MF = 32; pl->MTB = 32; pl->NTB = 160; pl->WK = 4; }
+    }
     const int kstep = pl->MF == 32 ? 2 : 4;
     // wave specialisation pays when the MFMA phase is long enough to hide a chunk's staging (the 128-channel tile)
     // (measured on MI355X: no gain -- with half the waves loading, the latency-bound staging takes twice as long -- so the
@@ -570,6 +585,11 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
         case W_128x288: rc = launch_w<32, 1, 9, 4, 1, 1>(pl, s, d, &nsplit_used); break;
         case W_64x320: rc = launch_w<32, 1, 5, 2, 2, 1>(pl, s, d, &nsplit_used); break;
         case W_32x160: rc = launch_w<32, 1, 5, 1, 1, 4>(pl, s, d, &nsplit_used); break;
+        case W_64x64: rc = launch_w<32, 1, 1, 2, 2, 1>(pl, s, d, &nsplit_used); break;
+        case W_64x128: rc = launch_w<32, 1, 2, 2, 2, 1>(pl, s, d, &nsplit_used); break;
+        case W_64x192: rc = launch_w<32, 1, 3, 2, 2, 1>(pl, s, d, &nsplit_used); break;
+        case W_128x96: rc = launch_w<32, 1, 3, 4, 1, 1>(pl, s, d, &nsplit_used); break;
+        case W_32x64: rc = launch_w<32, 1, 1, 1, 2, 2>(pl, s, d, &nsplit_used); break;
         default: rc = launch_w<16, 1, 2, 1, 1, 4>(pl, s, d, &nsplit_used); break;
     }
     if (rc) return rc;
