@@ -37,7 +37,7 @@ def algorithmic_work(key):
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         flops = 2.0 * B * Co * Ho * Wo * Ci * k * k
         x_b, y_b, w_b = 4.0 * B * Ci * H * W, 4.0 * B * Co * Ho * Wo, 4.0 * Co * Ci * k * k
-        if kernel.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel", "conv_direct", "conv_dgrad_pk", "conv_fwd_pk")):
+        if kernel.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel", "conv_direct", "conv_dgrad_pk", "conv_fwd_pk", "conv_wgrad_pk")):
             fused = y_b if (kernel.endswith("+relu") or ",relu" in kernel) else 0.0  # fused ReLU: a second output tensor
             return x_b + y_b + w_b + fused, flops  # fwd: x,w -> y ; dgrad: dy,w -> dx ; wgrad: x,dy -> gw
         if kernel.startswith("bias_grad_partial"):
@@ -68,7 +68,7 @@ def pmc_traffic(key):
     tools/pmc_traffic.py -> profiles/rNN/hbm_traffic.json), or None when that kernel was not profiled / is ambiguous."""
     import glob
 
-    name = key.split("|")[0].split("/")[0].replace(" ", "")
+    name = key.split("|")[0].split("/")[0].replace(" ", "").replace("+relu", "")
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic.json")), reverse=True):
         try:
             kernels = json.load(open(path))["kernels"]

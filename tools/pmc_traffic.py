@@ -14,12 +14,33 @@ import sys
 prof, out = sys.argv[1], sys.argv[2]
 
 
+XM_TAG = {"0": "", "1": ",img", "2": ",img+mask", "3": ",img+mask+skip"}
+
+
+def canonical(name):
+    """rocprofv3's demangled kernel name -> the key the ABI's kernel timer uses (cnn_amd_kernel_timing_report)"""
+    name = name.replace(" ", "")
+    m = re.match(r"igemm_dma_kernel<(\d+,\d+,\d+,\d+,\d+,\d+),(\d),(true|false)>$", name)
+    if m:
+        return f"igemm_dma_kernel<{m.group(1)}{XM_TAG[m.group(2)]}>"
+    m = re.match(r"(igemm_kernel|wgrad_kernel)<(\d+,\d+,\d+,\d+,\d+,\d+),(true|false),(true|false)>$", name)
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"
+    m = re.match(r"(conv_(?:dgrad|fwd|wgrad)_pk2?)_3_16_3_2(<.*>)?$", name)
+    if m:
+        return f"{m.group(1)}<3,16,3,2>"
+    m = re.match(r"(conv_direct_(?:fwd|dgrad))<(\d+,\d+,\d+,\d+)(,\d+)?>$", name)
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"
+    return name
+
+
 def per_kernel(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
         name = re.sub(r"^void ", "", name).split("(")[0]
-        name = re.sub(r",\s*(true|false)>$", ">", name)  # compile-time staging variant: same key as the ABI's timer name
+        name = canonical(name)
         agg[(name, r["Grid_Size"])].append(float(r["Counter_Value"]))
     return agg
 
