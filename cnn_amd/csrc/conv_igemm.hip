@@ -884,7 +884,8 @@ enum { CFG_M128_L = 100, CFG_M128 = 0, CFG_M128_S, CFG_M64, CFG_M64_S, CFG_M32, 
        CFG_D16_C4 /*209*/, CFG_D16_C4_L, CFG_D16_C16, CFG_D16_C16_L, CFG_D16_C8, CFG_D16_C8_L,
        CFG_D_M32 /*215*/, CFG_D_M32_C4, CFG_D_M64N1 /*217*/, CFG_D_M128S /*218*/, CFG_D_M128S_C4, CFG_D_M64S /*220*/, CFG_D_M64S_C4,
        CFG_D_M32_C16 /*222*/, CFG_D_M64S_C16, CFG_D_M128S_C16, CFG_D_M64W4N1_C16, CFG_D_M64W4N1_C8 /*226*/,
-       CFG_M64_S_C16 = 20, CFG_M64_S_C32, CFG_M128_S_C16, CFG_M128_S_C32, CFG_M32_S_C16 /*24*/ };
+       CFG_M64_S_C16 = 20, CFG_M64_S_C32, CFG_M128_S_C16, CFG_M128_S_C32, CFG_M32_S_C16 /*24*/, CFG_M64_S_C4 /*25*/, CFG_M128_S_C4 /*26*/,
+       CFG_M32_S_C4 /*27*/ };
 
 // taps of dy one parity class reads: offsets d in [e - J + 1, e], e = (ph+pad)/s, J = #taps kx = kx0 + s*j < k
 void dgrad_window(int k, int s, int pad, int* r0, int* TR) {
@@ -900,7 +901,7 @@ void dgrad_window(int k, int s, int pad, int* r0, int* TR) {
     *TR = dmax - dmin + 1;
 }
 
-int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, bool allow_dma = true) {
+int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, bool allow_dma = true, int shrink = 0) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
     CNN_REQUIRE(Ho > 0 && Wo > 0, "%s: empty output", who);
     IgemmParams& p = pl->p;
@@ -932,7 +933,9 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     const bool dma_ok = allow_dma && p.TR * p.TC <= 9 && p.N < (1ll << 31) - 4096;
     // small images (whole-image staging applies, see igemm_dma_kernel XM): tiles sized for enough workgroups at the
     // batch sizes of the reference net; measured on conv_layer_3 / conv_layer_4 (alexnet.cpp:19,22) forward and dgrad
-    const bool small_img = dma_ok && p.XH * p.XW <= 1024 && p.M > 32 && !getenv("CNN_AMD_IGEMM_NOIMG");
+    // (only when the large MFMA tiles below would leave CUs idle: a 28x28 layer at batch 128 is a big GEMM)
+    const bool small_img = dma_ok && p.XH * p.XW <= 1024 && p.M > 32 && !getenv("CNN_AMD_IGEMM_NOIMG") &&
+                           !(p.M > 64 && blocks_for(128, 256) >= 2 * kNumCU) && !(p.M <= 64 && blocks_for(64, 128) >= 8 * kNumCU);
     if (small_img && p.M > 64 && mode == MODE_FWD) { pl->cfg = CFG_D_M64S; pl->MF = 32; pl->MT = 64; pl->NPIX = 64; pl->CK = 8; }
     else if (small_img && p.M > 64 && p.C >= 128) { pl->cfg = CFG_D_M64S_C16; pl->MF = 32; pl->MT = 64; pl->NPIX = 64; pl->CK = 16; }
     else if (small_img && p.M > 64) { pl->cfg = CFG_D_M32; pl->MF = 32; pl->MT = 32; pl->NPIX = 128; pl->CK = 8; }
@@ -959,6 +962,14 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     else if (allow_dma && p.N < (1ll << 31) - 1024 && p.TR * p.TC <= 9) { pl->cfg = CFG_D16_C4; pl->MF = 16; pl->MT = 16; pl->NPIX = 256; pl->CK = 4; }
     else { pl->cfg = CFG_M16_CK16; pl->MF = 16; pl->MT = 16; pl->NPIX = 256; pl->CK = 16; }
 
+    // LDS fallback chain (large filters / wide rows): narrower pixel tile, then 4-channel chunks
+    if (shrink >= 1) {
+        const bool c4 = shrink >= 2;
+        if (p.M > 64) { pl->cfg = c4 ? CFG_M128_S_C4 : CFG_M128_S; pl->MF = 32; pl->MT = 128; pl->NPIX = 64; pl->CK = c4 ? 4 : 8; }
+        else if (p.M > 32) { pl->cfg = c4 ? CFG_M64_S_C4 : CFG_M64_S; pl->MF = 32; pl->MT = 64; pl->NPIX = 64; pl->CK = c4 ? 4 : 8; }
+        else if (p.M > 16) { pl->cfg = c4 ? CFG_M32_S_C4 : CFG_M32_S; pl->MF = 32; pl->MT = 32; pl->NPIX = 128; pl->CK = c4 ? 4 : 8; }
+        else { pl->cfg = CFG_M16_CK4; pl->MF = 16; pl->MT = 16; pl->NPIX = 256; pl->CK = 4; }
+    }
     // tuning override (debug only): CNN_AMD_IGEMM_CFG=<cfg id>
     if (const char* ov = getenv("CNN_AMD_IGEMM_CFG")) {
         const int c = atoi(ov);
@@ -977,7 +988,8 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
             {CFG_D_M32_C16, 32, 32, 128, 16}, {CFG_D_M64S_C16, 32, 64, 64, 16}, {CFG_D_M128S_C16, 32, 128, 64, 16},
             {CFG_D_M64W4N1_C16, 32, 64, 128, 16}, {CFG_D_M64W4N1_C8, 32, 64, 128, 8},
             {CFG_M64_S_C16, 32, 64, 64, 16}, {CFG_M64_S_C32, 32, 64, 64, 32}, {CFG_M128_S_C16, 32, 128, 64, 16},
-            {CFG_M128_S_C32, 32, 128, 64, 32}, {CFG_M32_S_C16, 32, 32, 128, 16}};
+            {CFG_M128_S_C32, 32, 128, 64, 32}, {CFG_M32_S_C16, 32, 32, 128, 16}, {CFG_M64_S_C4, 32, 64, 64, 4},
+            {CFG_M128_S_C4, 32, 128, 64, 4}, {CFG_M32_S_C4, 32, 32, 128, 4}};
         for (auto& t : tab)
             if (t.cfg == c && p.M <= ((p.M + t.MT - 1) / t.MT) * t.MT && (t.MT >= 32 || p.M <= 16)) {
                 pl->cfg = t.cfg; pl->MF = t.MF; pl->MT = t.MT; pl->NPIX = t.NPIX; pl->CK = t.CK;
@@ -1033,6 +1045,8 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     }
     if (pl->lds_bytes > 160 * 1024 && pl->dma && allow_dma && !getenv("CNN_AMD_IGEMM_CFG"))
         return make_plan(who, d, mode, pl, false);  // two buffers do not fit: single-buffered kernel
+    if (pl->lds_bytes > 160 * 1024 && shrink < 2 && !getenv("CNN_AMD_IGEMM_CFG"))
+        return make_plan(who, d, mode, pl, false, shrink + 1);
     CNN_REQUIRE(pl->lds_bytes <= 160 * 1024, "%s: tile needs %zu B of LDS (> 160 KiB): k=%d W=%d not supported", who,
                 pl->lds_bytes, d->k, d->W);
     p.rw_shift = 0;
@@ -1174,6 +1188,9 @@ int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w,
         case CFG_M128_S_C16: return launch_cfg<32, 2, 1, 2, 2, 16>(pl, s, d);
         case CFG_M128_S_C32: return launch_cfg<32, 2, 1, 2, 2, 32>(pl, s, d);
         case CFG_M32_S_C16: return launch_cfg<32, 1, 1, 1, 4, 16>(pl, s, d);
+        case CFG_M64_S_C4: return launch_cfg<32, 1, 1, 2, 2, 4>(pl, s, d);
+        case CFG_M128_S_C4: return launch_cfg<32, 2, 1, 2, 2, 4>(pl, s, d);
+        case CFG_M32_S_C4: return launch_cfg<32, 1, 1, 1, 4, 4>(pl, s, d);
         case CFG_D16_C4: return launch_dma<16, 1, 4, 1, 4, 1>(pl, s, d);
         case CFG_D16_C4_L: return launch_dma<16, 1, 8, 1, 4, 1>(pl, s, d);
         case CFG_D16_C16: return launch_dma<16, 1, 4, 1, 4, 4>(pl, s, d);

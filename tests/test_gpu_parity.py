@@ -49,6 +49,13 @@ CONV_CASES = [
     (2, 6, 10, 10, 40, 3, 1, 1),     # padding extension
     (1, 20, 17, 19, 130, 3, 3, 0),   # stride 3, Co not a tile multiple
     (2, 7, 8, 8, 5, 3, 2, 1),        # stride 2 with padding
+    # BASELINE configs 4 / 5 layer classes (VGG-11 / ResNet-18 shaped) at a small batch
+    (1, 3, 64, 64, 8, 7, 2, 3),      # ResNet stem: 7x7 stride 2 pad 3 (49 taps: LDS fallback chain)
+    (2, 8, 14, 14, 16, 1, 2, 0),     # ResNet downsample: 1x1 stride 2
+    (2, 16, 28, 28, 40, 3, 2, 1),    # ResNet stage entry: 3x3 stride 2 pad 1 (masked whole-image staging + tap skipping)
+    (2, 3, 32, 32, 16, 3, 1, 1),     # VGG first layer: 3 -> C, stride 1 pad 1
+    (2, 64, 14, 14, 128, 3, 1, 1),   # VGG deep layer: 3x3 stride 1 pad 1, small image
+    (1, 3, 224, 224, 64, 7, 2, 3),   # the ResNet stem at full resolution (row staging of 230-float rows)
 ]
 
 
