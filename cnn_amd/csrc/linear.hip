@@ -115,6 +115,63 @@ __global__ __launch_bounds__(kBlock) void linear_bwd_x(const float* __restrict__
     }
 }
 
+// All three gradients of a skinny layer (out <= kOutTile) in ONE launch: a workgroup owns 64 input neurons, its kFG
+// sample groups each walk B / kFG samples -- per (sample, neuron): one coalesced x load, the sample's dy row (broadcast),
+// gW partial sums in registers and the finished dx element written straight away -- and are combined through LDS in a
+// fixed order.  Workgroup 0 also reduces the bias gradient.  x is read once, dx written once (linear.cpp:56-90).
+constexpr int kFG = 16;
+__global__ __launch_bounds__(kNeur * kFG) void linear_bwd_fused(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               const float* __restrict__ w, float* __restrict__ gw,
+                                                               float* __restrict__ gb, float* __restrict__ dx, int B,
+                                                               int in, int out, float divisor) {
+    __shared__ float red[kFG][kOutTile + 1][kNeur];
+    const int il = threadIdx.x & (kNeur - 1), grp = threadIdx.x / kNeur;
+    const int i = blockIdx.x * kNeur + il;
+    const bool live = i < in;
+    const int per = (B + kFG - 1) / kFG;
+    const int bb = grp * per, be = min(B, bb + per);
+    float wr[kOutTile], acc[kOutTile], bsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < kOutTile; ++j) {
+        acc[j] = 0.f;
+        wr[j] = (live && j < out) ? w[(size_t)i * out + j] : 0.f;
+    }
+#pragma unroll 4
+    for (int b = bb; b < be; ++b) {
+        const float xv = live ? x[(size_t)b * in + i] : 0.f;
+        const float* d = dy + (size_t)b * out;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < kOutTile; ++j)
+            if (j < out) {
+                const float dj = d[j];
+                acc[j] += xv * dj;
+                s += dj * wr[j];
+            }
+        if (live) dx[(size_t)b * in + i] = s;
+        if (blockIdx.x == 0 && il < out) bsum += d[il];  // lane j of every group: bias partial of output j
+    }
+#pragma unroll
+    for (int j = 0; j < kOutTile; ++j) red[grp][j][il] = acc[j];
+    red[grp][kOutTile][il] = bsum;
+    __syncthreads();
+    if (grp == 0) {
+        if (live)
+            for (int j = 0; j < out; ++j) {
+                float t = 0.f;
+#pragma unroll
+                for (int g2 = 0; g2 < kFG; ++g2) t += red[g2][j][il];
+                gw[(size_t)i * out + j] = t / divisor;
+            }
+        if (blockIdx.x == 0 && il < out) {
+            float t = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < kFG; ++g2) t += red[g2][kOutTile][il];
+            gb[il] = t / divisor;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -134,6 +191,12 @@ int cnn_linear_backward(const float* x, const float* dy, const float* w, float* 
     CNN_REQUIRE(B > 0 && in > 0 && out > 0, "cnn_linear_backward: B=%d in=%d out=%d", B, in, out);
     CNN_REQUIRE(B <= 65535, "cnn_linear_backward: B=%d exceeds the grid.y limit", B);
     hipStream_t s = as_stream(stream);
+    if (gw && gb && dx && x && w && out <= kOutTile) {
+        CNN_KLAUNCH(s, "linear_bwd_fused",
+                    (linear_bwd_fused<<<ceil_div(in, kNeur), kNeur * kFG, 0, s>>>(x, dy, w, gw, gb, dx, B, in, out, divisor)),
+                    "B%d in%d out%d", B, in, out);
+        return CNN_AMD_OK;
+    }
     if (gw) {
         CNN_REQUIRE(x != nullptr, "cnn_linear_backward: x is null");
         CNN_KLAUNCH(s, "linear_bwd_w", (linear_bwd_w<<<ceil_div(in, kNeur), kBlock, 0, s>>>(x, dy, gw, B, in, out, divisor)),

@@ -165,7 +165,7 @@ def test_relu_bit_exact(T, n):
         assert np.array_equal(host(capi.relu_forward(xo.contiguous())).view(np.uint32), y_ref.view(np.uint32))
 
 
-@pytest.mark.parametrize("B,n_in,n_out", [(4, 4608, 3), (3, 100, 10), (5, 33, 17)])
+@pytest.mark.parametrize("B,n_in,n_out", [(4, 4608, 3), (3, 100, 10), (5, 33, 17), (37, 130, 8), (256, 4608, 3), (1, 7, 1)])
 def test_linear_vs_oracle(T, B, n_in, n_out):
     from cnn_amd import capi
 
