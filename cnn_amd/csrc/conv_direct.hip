@@ -140,6 +140,9 @@ __global__ __launch_bounds__(kBlock) void conv_direct_dgrad(const float* __restr
 // Accumulator pairs of one grid pixel (class = output parity (ph,pw), alexnet.cpp:12 geometry):
 //   P[cls] = (ci0, ci1) of class cls;  Q0 = ci2 of classes (0,0),(0,1);  Q1 = ci2 of classes (1,0),(1,1).
 typedef float v2f __attribute__((ext_vector_type(2)));
+// two adjacent floats stored with ONE dwordx2 even when only 4-byte aligned (odd row pitch): global memory accesses may
+// be unaligned on gfx950, and hipcc emits global_store_dwordx2 for this type
+struct __attribute__((packed, aligned(4))) f2u { float x, y; };
 
 __global__ void pack_dgrad_weights_3_16_3_2(const float* __restrict__ w, float* __restrict__ wp) {
     const int co = blockIdx.x * blockDim.x + threadIdx.x;
@@ -274,6 +277,143 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_3_16_3_2(const float* __
         st(0, 0, P0.x, P1.x); st(0, 1, P2.x, P3.x);
         st(1, 0, P0.y, P1.y); st(1, 1, P2.y, P3.y);
         st(2, 0, Q0.x, Q0.y); st(2, 1, Q1.x, Q1.y);
+    }
+}
+
+// ---- the same recipe for wider stride-2 3x3 layers (even CI): data gradient ---------------------------------------------
+// On gfx950 the packed fp32 VALU rate equals the fp32 MFMA rate (157 TFLOP/s), and for the reference net's small layers
+// the MFMA kernels spend most of their time staging operands through LDS.  Here the weights stream through SGPR pairs
+// and dy comes straight from L1/L2: per dy channel 9 (tap, class) groups x CI/2 packed FMAs on the 4 x CI running sums
+// of one grid pixel.  Group order (pack_dgrad_weights_s2): tap(0,0) classes 0..3 | tap(0,1) classes 0,2 | tap(1,0)
+// classes 0,1 | tap(1,1) class 0; class = ph*2 + pw reads filter tap (kx,ky) = (ph + 2*jr, pw + 2*jc).
+__global__ void pack_dgrad_weights_s2(const float* __restrict__ w, float* __restrict__ wp, int CI, int CO) {
+    const int gcls[9] = {0, 1, 2, 3, 0, 2, 0, 1, 0}, gjr[9] = {0, 0, 0, 0, 0, 0, 1, 1, 1}, gjc[9] = {0, 0, 0, 0, 1, 1, 0, 0, 1};
+    const int total = CO * 9 * CI;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ci = i % CI, g = (i / CI) % 9, co = i / (9 * CI);
+        const int cls = gcls[g], kx = (cls >> 1) + 2 * gjr[g], ky = (cls & 1) + 2 * gjc[g];
+        wp[i] = w[((size_t)(co * CI + ci) * 3 + kx) * 3 + ky];
+    }
+}
+
+template <int CI, int CB, int PX, int DBG = 0>  // PX grid pixels per lane: the broadcast weight reads are shared by both
+__global__ __launch_bounds__(kBlock) void conv_dgrad_pk_s2(const float* __restrict__ dy, const v2f* __restrict__ wp,
+                                                           float* __restrict__ dx, int B, int CO, int H, int W, int Ho,
+                                                           int Wo, int items_per_img, unsigned m_ipi, unsigned m_row) {
+    constexpr int HP = CI / 2;
+    const int U = (H + 1) / 2, V = (W + 1) / 2;
+    const int UV = U * V;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int items = B * items_per_img;
+    const int plane = Ho * Wo;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * CO * plane * 4u), 0x00020000);
+    // the packed filters of ALL dy channels live in LDS (CO * 9 * CI floats) and are read with wave-uniform addresses
+    // (broadcast ds_reads): 9*CI floats per channel are too many to stream through SGPRs without a scalar-load round
+    // trip per group
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    if (!(DBG & 16)) for (int i = threadIdx.x; i < CO * 9 * HP; i += kBlock) ((v2f*)wlds)[i] = wp[i];
+    __syncthreads();
+    if (DBG & 32) return;
+    for (int it = blockIdx.x * kWaves + wave; it < items; it += gridDim.x * kWaves) {
+        const int b = fast_div(it, m_ipi, items_per_img);
+        const int soff = b * CO * plane * 4;
+        int hh[PX], ww[PX];
+        bool live[PX];
+        unsigned v00[PX], v01[PX], v10[PX], v11[PX];
+#pragma unroll
+        for (int x = 0; x < PX; ++x) {
+            const int n = (it - b * items_per_img) * (64 * PX) + x * 64 + lane;
+            live[x] = n < UV;
+            hh[x] = fast_div(live[x] ? n : 0, m_row, V);
+            ww[x] = (live[x] ? n : 0) - hh[x] * V;
+            const bool r0ok = live[x] && hh[x] < Ho, r1ok = live[x] && hh[x] >= 1, c0ok = ww[x] < Wo, c1ok = ww[x] >= 1;
+            const unsigned o = (unsigned)(hh[x] * Wo + ww[x]) * 4u;
+            v00[x] = (r0ok && c0ok) ? o : kBufOOB;
+            v01[x] = (r0ok && c1ok) ? o - 4u : kBufOOB;
+            v10[x] = (r1ok && c0ok) ? o - (unsigned)Wo * 4u : kBufOOB;
+            v11[x] = (r1ok && c1ok) ? o - (unsigned)Wo * 4u - 4u : kBufOOB;
+        }
+        v2f A[PX][4][HP];
+#pragma unroll
+        for (int x = 0; x < PX; ++x)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < HP; ++j) A[x][c][j] = v2f{0.f, 0.f};
+#pragma unroll 1
+        for (int cg = 0; cg < CO; cg += CB) {
+            float dv[CB][PX][4];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int so = soff + (cg + u) * plane * 4;
+#pragma unroll
+                for (int x = 0; x < PX; ++x) {
+                    if constexpr (DBG & 1) { dv[u][x][0] = dv[u][x][1] = dv[u][x][2] = dv[u][x][3] = (float)so; continue; }
+                    dv[u][x][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)v00[x], so, 0));
+                    dv[u][x][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)v01[x], so, 0));
+                    dv[u][x][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)v10[x], so, 0));
+                    dv[u][x][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)v11[x], so, 0));
+                }
+            }
+            // the CB*9 (channel, group) steps of this batch as one software pipeline: the broadcast LDS reads of step s+1
+            // are issued before the FMAs of step s (hipcc alone keeps only two reads in flight and waits on each)
+            {
+                constexpr int gcls[9] = {0, 1, 2, 3, 0, 2, 0, 1, 0}, gtap[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
+                const v2f* q = (const v2f*)wlds + cg * 9 * HP;  // wave-uniform LDS address; [channel][group][HP] is contiguous
+                // pipeline granule = QP weight pairs (a quarter / half group): 2*QP staging registers keep the kernel at
+                // 128 VGPRs = 4 waves per SIMD, which lets all B*U*V/64 items of the reference layer run in one round
+                constexpr int QP = HP >= 8 ? 4 : HP, NQ = HP / QP;
+                v2f wcur[QP], wnxt[QP];
+#pragma unroll
+                for (int j = 0; j < QP; ++j) wcur[j] = q[j];
+#pragma unroll
+                for (int st = 0; st < CB * 9 * NQ; ++st) {
+                    const int u = st / (9 * NQ), g = (st / NQ) % 9, jb = (st % NQ) * QP;
+                    if (st + 1 < CB * 9 * NQ) {
+#pragma unroll
+                        for (int j = 0; j < QP; ++j) wnxt[j] = (DBG & 2) ? v2f{1.f + st, 2.f + j} : q[(st + 1) * QP + j];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < QP; ++j)
+#pragma unroll
+                        for (int x = 0; x < PX; ++x) {
+                            const float d = dv[u][x][gtap[g]];
+                            if constexpr (DBG & 4) { if (j == 0) A[x][gcls[g]][jb] += wcur[0] + v2f{d, d}; }
+                            else A[x][gcls[g]][jb + j] = __builtin_elementwise_fma(wcur[j], v2f{d, d}, A[x][gcls[g]][jb + j]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < QP; ++j) wcur[j] = wnxt[j];
+                }
+            }
+        }
+        const bool pair = ((W & 1) == 0);
+#pragma unroll
+        for (int x = 0; x < PX; ++x) {
+            if (!live[x]) continue;
+            if ((DBG & 8) && A[x][0][0].x != 123.25f) continue;
+            float* dxb = dx + (size_t)b * CI * H * W;
+#pragma unroll
+            for (int j = 0; j < HP; ++j)
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph) {
+                        const int ci = 2 * j + half, h = 2 * hh[x] + ph;
+                        if (h >= H) continue;
+                        const float v0 = half ? A[x][ph * 2 + 0][j].y : A[x][ph * 2 + 0][j].x;
+                        const float v1 = half ? A[x][ph * 2 + 1][j].y : A[x][ph * 2 + 1][j].x;
+                        float* row = dxb + ((size_t)ci * H + h) * W + (size_t)ww[x] * 2;
+                        if (pair || ww[x] * 2 + 1 < W) {
+                            *(f2u*)row = f2u{v0, v1};
+                        } else {
+                            row[0] = v0;
+                        }
+                    }
+        }
     }
 }
 
@@ -666,6 +806,44 @@ int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w,
     return CNN_AMD_OK;
 }
 
+
+// Packed VALU data gradient for k = 3, stride 2, pad 0 layers with 16 input channels (conv_layer_2 of the reference net).
+bool pk_dgrad_s2_supported(const cnn_conv2d_desc* d) {
+    const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
+    const char* e = getenv("CNN_AMD_PK_DGRAD");
+    if (e && atoi(e) == 0) return false;
+    return d->k == 3 && d->s == 2 && d->pad == 0 && (d->Ci == 16 || (e && d->Ci == 32)) && d->Co % 4 == 0 && d->Co * 9 * d->Ci * 4 <= 64 * 1024 &&
+           (long long)d->B * d->Co * Ho * Wo * 4 < (1ll << 31) - 16 && (long long)d->B * (((d->H + 1) / 2) * ((d->W + 1) / 2) + 63) / 64 < (1ll << 30);
+}
+size_t pk_dgrad_s2_workspace_floats(const cnn_conv2d_desc* d) { return (size_t)d->Co * 9 * d->Ci; }
+
+int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, hipStream_t s) {
+    const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
+    const int total = d->Co * 9 * d->Ci;
+    CNN_KLAUNCH(s, "pack_dgrad_weights", (pack_dgrad_weights_s2<<<(total + 255) / 256, 256, 0, s>>>(w, (float*)ws, d->Ci, d->Co)),
+                CONV_TAG(d));
+    const int V = (d->W + 1) / 2, UVg = ((d->H + 1) / 2) * V;
+    const int px = getenv("CNN_AMD_PK_PX") ? atoi(getenv("CNN_AMD_PK_PX")) : 1;
+    const int ipi = (UVg + 64 * px - 1) / (64 * px);
+    const long long witems = (long long)d->B * ipi;
+    const size_t wl = (size_t)total * sizeof(float);  // <= 64 KiB by pk_dgrad_s2_supported()
+#define PKS2(CI_, PX_, CB_)                                                                                                  \
+    CNN_KLAUNCH(s, "conv_dgrad_pk_s2<" #CI_ ">",                                                                        \
+                (conv_dgrad_pk_s2<CI_, CB_, PX_><<<wave_grid(witems), kBlock, wl, s>>>(dy, (const v2f*)ws, dx, d->B, d->Co, d->H, d->W, \
+                                                                                    Ho, Wo, ipi, div_magic(ipi), div_magic(V))), \
+                CONV_TAG(d))
+    const int cb = getenv("CNN_AMD_PK_CB") ? atoi(getenv("CNN_AMD_PK_CB")) : 4;
+    const int dbgk = getenv("CNN_AMD_DBG") ? atoi(getenv("CNN_AMD_DBG")) : 0;
+#define PKS2D(D_) CNN_KLAUNCH(s, "conv_dgrad_pk_s2<16>", (conv_dgrad_pk_s2<16, 4, 1, D_><<<wave_grid(witems), kBlock, wl, s>>>(dy, (const v2f*)ws, dx, d->B, d->Co, d->H, d->W, Ho, Wo, ipi, div_magic(ipi), div_magic(V))), CONV_TAG(d))
+    if (dbgk == 1) PKS2D(1); else if (dbgk == 2) PKS2D(2); else if (dbgk == 4) PKS2D(4); else if (dbgk == 8) PKS2D(8); else if (dbgk == 15) PKS2D(15); else if (dbgk == 11) PKS2D(11); else if (dbgk == 9) PKS2D(9); else if (dbgk == 31) PKS2D(31); else if (dbgk == 47) PKS2D(47); else if (dbgk == 63) PKS2D(63); else
+    if (d->Ci == 16 && px == 1 && cb == 2) PKS2(16, 1, 2);
+    else if (d->Ci == 16 && px == 1 && cb == 1) PKS2(16, 1, 1);
+    else if (d->Ci == 16 && px == 1) PKS2(16, 1, 4);
+    else if (d->Ci == 16) PKS2(16, 2, 4);
+    else PKS2(32, 1, 4);
+#undef PKS2
+    return CNN_AMD_OK;
+}
 
 // number of slabs (workgroups) the packed weight-gradient kernel writes; 0 when the geometry / sizes rule it out
 int direct_wgrad_slots(const cnn_conv2d_desc* d) {

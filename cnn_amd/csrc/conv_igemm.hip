@@ -1230,6 +1230,9 @@ int direct_conv_forward(const cnn_conv2d_desc* d, const float* x, const float* w
                         void* ws, size_t ws_bytes, hipStream_t s);
 int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes,
                       hipStream_t s);
+bool pk_dgrad_s2_supported(const cnn_conv2d_desc* d);  // conv_direct.hip: packed VALU dgrad for small stride-2 layers
+size_t pk_dgrad_s2_workspace_floats(const cnn_conv2d_desc* d);
+int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, hipStream_t s);
 // scratch floats the forward / dgrad plans need (used by cnn_conv2d_workspace_bytes in conv_wgrad.hip)
 size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
     Plan a, b;
@@ -1237,6 +1240,7 @@ size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
     if (make_plan("ws", d, MODE_FWD, &a) == CNN_AMD_OK) n = a.a_floats;
     if (make_plan("ws", d, MODE_DGRAD, &b) == CNN_AMD_OK && b.a_floats > n) n = b.a_floats;
     if (direct_conv_supported(d) && n < 1024) n = 1024;  // packed filter copies of the direct kernels (conv_direct.hip)
+    if (pk_dgrad_s2_supported(d) && n < pk_dgrad_s2_workspace_floats(d)) n = pk_dgrad_s2_workspace_floats(d);
     return n;
 }
 }  // namespace cnn_amd
@@ -1269,6 +1273,8 @@ int cnn_conv2d_backward_data(const cnn_conv2d_desc* d, const float* dy, const fl
     if (int rc = check_desc("cnn_conv2d_backward_data", d)) return rc;
     CNN_REQUIRE(dy && w && dx, "cnn_conv2d_backward_data: null pointer");
     if (direct_conv_supported(d)) return direct_conv_dgrad(d, dy, w, dx, ws, ws_bytes, as_stream(stream));
+    if (pk_dgrad_s2_supported(d) && ws != nullptr && ws_bytes >= pk_dgrad_s2_workspace_floats(d) * sizeof(float))
+        return pk_dgrad_s2(d, dy, w, dx, ws, as_stream(stream));
     Plan pl;
     if (int rc = make_plan("cnn_conv2d_backward_data", d, MODE_DGRAD, &pl)) return rc;
     return run_plan(pl, d, dy, w, nullptr, dx, nullptr, ws, ws_bytes, as_stream(stream), "cnn_conv2d_backward_data");

@@ -340,7 +340,9 @@ __global__ __launch_bounds__(kRedElems * kRedLanes) void slab_reduce(const float
 int reduce_slabs(hipStream_t s, const float* slabs, int nslots, size_t n, float* tmp, float* dst, float divisor,
                  const char* tag, int split_n = 0, float* dst_b = nullptr) {
     const unsigned gx = (unsigned)((n + kRedElems - 1) / kRedElems);
-    if (nslots > 64) {
+    // two stages only when one workgroup per 32 elements would walk too many slabs (small slabs are launch-bound: one
+    // launch of up to 512 slots x 8 slot-lanes beats two)
+    if (nslots > 512 || (nslots > 64 && n > 65536)) {
         const int per = 64, groups = (nslots + per - 1) / per;
         CNN_KLAUNCH(s, "slab_reduce/stage1",
                     (slab_reduce<<<dim3(gx, groups), kRedElems * kRedLanes, 0, s>>>(slabs, tmp, nslots, n, per, 1.f, 0, 0, nullptr)), "%s", tag);

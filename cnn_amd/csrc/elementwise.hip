@@ -53,8 +53,15 @@ __device__ __forceinline__ float sgd_one(float p, float g, float lr, float scale
     const float step = lr * gs;
     return p - step;
 }
+// (the <= 3 trailing elements of an arena whose length is not a multiple of 4 ride along in workgroup 0)
 __global__ __launch_bounds__(kBlock) void sgd_vec(float4* __restrict__ p, const float4* __restrict__ g, size_t n4,
-                                                  float lr, float scale, bool scaled) {
+                                                  size_t n, float lr, float scale, bool scaled) {
+    if (blockIdx.x == 0 && n4 * 4 + threadIdx.x < n) {
+        float* ps = (float*)p;
+        const float* gs = (const float*)g;
+        const size_t i = n4 * 4 + threadIdx.x;
+        ps[i] = sgd_one(ps[i], gs[i], lr, scale, scaled);
+    }
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (size_t)gridDim.x * kBlock) {
         float4 pv = p[i];
         const float4 gv = g[i];
@@ -167,10 +174,10 @@ int cnn_sgd_update(float* params, const float* grads, size_t n, float lr, float 
     if (aligned16(params) && aligned16(grads) && n >= 4) {
         const size_t n4 = n / 4;
         CNN_KLAUNCH(s, "sgd_vec",
-                    (sgd_vec<<<stream_grid(n4, kBlock), kBlock, 0, s>>>((float4*)params, (const float4*)grads, n4, lr,
+                    (sgd_vec<<<stream_grid(n4, kBlock), kBlock, 0, s>>>((float4*)params, (const float4*)grads, n4, n, lr,
                                                                        grad_scale, scaled)),
                     "n=%zu", n);
-        done = n4 * 4;
+        done = n;
     }
     if (done < n) {
         CNN_KLAUNCH(s, "sgd_scalar",
