@@ -812,7 +812,7 @@ bool pk_dgrad_s2_supported(const cnn_conv2d_desc* d) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
     const char* e = getenv("CNN_AMD_PK_DGRAD");
     if (e && atoi(e) == 0) return false;
-    return d->k == 3 && d->s == 2 && d->pad == 0 && (d->Ci == 16 || (e && d->Ci == 32)) && d->Co % 4 == 0 && d->Co * 9 * d->Ci * 4 <= 64 * 1024 &&
+    return d->k == 3 && d->s == 2 && d->pad == 0 && (d->Ci == 16 || (e && d->Ci == 32)) && d->Co % 4 == 0 && d->Co * 9 * d->Ci * 4 <= 144 * 1024 &&
            (long long)d->B * d->Co * Ho * Wo * 4 < (1ll << 31) - 16 && (long long)d->B * (((d->H + 1) / 2) * ((d->W + 1) / 2) + 63) / 64 < (1ll << 30);
 }
 size_t pk_dgrad_s2_workspace_floats(const cnn_conv2d_desc* d) { return (size_t)d->Co * 9 * d->Ci; }
@@ -840,7 +840,14 @@ int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float
     else if (d->Ci == 16 && px == 1 && cb == 1) PKS2(16, 1, 1);
     else if (d->Ci == 16 && px == 1) PKS2(16, 1, 4);
     else if (d->Ci == 16) PKS2(16, 2, 4);
-    else PKS2(32, 1, 4);
+    else {
+        static thread_local bool attr_set = false;
+        if (!attr_set) {
+            CNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_dgrad_pk_s2<32, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        PKS2(32, 1, 4);
+    }
 #undef PKS2
     return CNN_AMD_OK;
 }
