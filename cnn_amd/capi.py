@@ -37,6 +37,12 @@ SIGNATURES = {
     "cnn_conv2d_workspace_bytes": (C.c_size_t, [_D]),
     "cnn_conv2d_forward": (C.c_int, [_D, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_forward_relu": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cnn_conv2d_prepared_bytes": (C.c_size_t, [_D]),
+    "cnn_conv2d_prepare_filters": (C.c_int, [C.c_int, _D, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                             C.POINTER(C.c_void_p), _P]),
+    "cnn_conv2d_forward_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P, _P]),
+    "cnn_conv2d_backward_data_prepared": (C.c_int, [_D, _P, _P, _P, _P]),
+    "cnn_conv2d_backward_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P, C.c_int]),
     "cnn_conv2d_backward_weight": (C.c_int, [_D, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P]),
     "cnn_conv2d_backward_data": (C.c_int, [_D, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_backward_workspace_bytes": (C.c_size_t, [_D]),
@@ -196,6 +202,34 @@ class Conv2d:
                                            _ptr(self._bwd_ws), self._bwd_ws.numel(), _stream(), 1 if defer_join else 0), "cnn_conv2d_backward")
         return gw, gb, dx
 
+    # ---- prepared-filter path (cnn_conv2d_prepare_filters) ----
+    def prepared_buffers(self, device="cuda"):
+        """(fwd, dgrad) device buffers for prepare_filters()"""
+        import torch
+
+        n = int(self.lib.cnn_conv2d_prepared_bytes(C.byref(self.desc)))
+        return torch.empty(n, dtype=torch.uint8, device=device), torch.empty(n, dtype=torch.uint8, device=device)
+
+    def forward_prepared(self, x, prepared_fwd, bias, y, y_relu=None):
+        _need_gpu(x, prepared_fwd, bias, y)
+        check(self.lib.cnn_conv2d_forward_prepared(C.byref(self.desc), _ptr(x), _ptr(prepared_fwd), _ptr(bias), _ptr(y),
+                                                   _ptr(y_relu) if y_relu is not None else None, _stream()),
+              "cnn_conv2d_forward_prepared")
+        return y
+
+    def backward_data_prepared(self, dy, prepared_dgrad, dx):
+        _need_gpu(dy, prepared_dgrad, dx)
+        check(self.lib.cnn_conv2d_backward_data_prepared(C.byref(self.desc), _ptr(dy), _ptr(prepared_dgrad), _ptr(dx), _stream()),
+              "cnn_conv2d_backward_data_prepared")
+        return dx
+
+    def backward_prepared(self, x, dy, prepared_dgrad, divisor, gw, gb, dx, defer_join=False):
+        _need_gpu(x, dy, prepared_dgrad, gw, gb, dx)
+        check(self.lib.cnn_conv2d_backward_prepared(C.byref(self.desc), _ptr(x), _ptr(dy), _ptr(prepared_dgrad), _ptr(gw), _ptr(gb),
+                                                    _ptr(dx), float(divisor), _ptr(self.ws), self.ws_bytes, _stream(),
+                                                    1 if defer_join else 0), "cnn_conv2d_backward_prepared")
+        return gw, gb, dx
+
     # ---- im2col functional fallback (parity cross-check only) ----
     def _iws(self, device):
         import torch
@@ -350,6 +384,16 @@ class BatchNorm2d:
                                               _ptr(ggamma), _ptr(gbeta), self.B, self.C, self.H, self.W, self.eps,
                                               _ptr(self.ws), self.ws_bytes, _stream()), "cnn_batchnorm2d_backward")
         return dy
+
+
+def prepare_filters(convs, weights, biases, fwd_bufs, dgrad_bufs):
+    """re-arrange the filters of up to 6 layers for their forward / data-gradient kernels with one or two launches"""
+    n = len(convs)
+    _need_gpu(*weights, *biases)
+    descs = (ConvDesc * n)(*[c.desc for c in convs])
+    arr = lambda ts: (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in ts])
+    check(load().cnn_conv2d_prepare_filters(n, descs, arr(weights), arr(biases), arr(fwd_bufs) if fwd_bufs else None,
+                                            arr(dgrad_bufs) if dgrad_bufs else None, _stream()), "cnn_conv2d_prepare_filters")
 
 
 def sgd_update(params, grads, lr, grad_scale=1.0):

@@ -144,8 +144,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // be unaligned on gfx950, and hipcc emits global_store_dwordx2 for this type
 struct __attribute__((packed, aligned(4))) f2u { float x, y; };
 
-__global__ void pack_dgrad_weights_3_16_3_2(const float* __restrict__ w, float* __restrict__ wp) {
-    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ void pack_dgrad_3_16_3_2_body(const float* __restrict__ w, float* __restrict__ wp, int tid) {
+    const int co = tid;
     if (co >= 16) return;
     const float* wc = w + (size_t)co * 27;
     auto W = [&](int ci, int kx, int ky) { return wc[(ci * 3 + kx) * 3 + ky]; };
@@ -169,6 +169,10 @@ __global__ void pack_dgrad_weights_3_16_3_2(const float* __restrict__ w, float* 
     put(W(0, 2, 2), W(1, 2, 2));
     put(W(2, 2, 2), 0.f);
     put(0.f, 0.f);
+}
+
+__global__ void pack_dgrad_weights_3_16_3_2(const float* __restrict__ w, float* __restrict__ wp) {
+    pack_dgrad_3_16_3_2_body(w, wp, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // dy is read through a raw buffer descriptor: address = SGPR base + SGPR offset (image, channel, row) + per-lane byte
@@ -286,14 +290,18 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_3_16_3_2(const float* __
 // and dy comes straight from L1/L2: per dy channel 9 (tap, class) groups x CI/2 packed FMAs on the 4 x CI running sums
 // of one grid pixel.  Group order (pack_dgrad_weights_s2): tap(0,0) classes 0..3 | tap(0,1) classes 0,2 | tap(1,0)
 // classes 0,1 | tap(1,1) class 0; class = ph*2 + pw reads filter tap (kx,ky) = (ph + 2*jr, pw + 2*jc).
-__global__ void pack_dgrad_weights_s2(const float* __restrict__ w, float* __restrict__ wp, int CI, int CO) {
+__device__ void pack_dgrad_s2_body(const float* __restrict__ w, float* __restrict__ wp, int CI, int CO, int tid, int nt) {
     const int gcls[9] = {0, 1, 2, 3, 0, 2, 0, 1, 0}, gjr[9] = {0, 0, 0, 0, 0, 0, 1, 1, 1}, gjc[9] = {0, 0, 0, 0, 1, 1, 0, 0, 1};
     const int total = CO * 9 * CI;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    for (int i = tid; i < total; i += nt) {
         const int ci = i % CI, g = (i / CI) % 9, co = i / (9 * CI);
         const int cls = gcls[g], kx = (cls >> 1) + 2 * gjr[g], ky = (cls & 1) + 2 * gjc[g];
         wp[i] = w[((size_t)(co * CI + ci) * 3 + kx) * 3 + ky];
     }
+}
+
+__global__ void pack_dgrad_weights_s2(const float* __restrict__ w, float* __restrict__ wp, int CI, int CO) {
+    pack_dgrad_s2_body(w, wp, CI, CO, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 template <int CI, int CB, int PX, int DBG = 0>  // PX grid pixels per lane: the broadcast weight reads are shared by both
@@ -422,13 +430,38 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_s2(const float* __restri
 // x read through a raw buffer descriptor (uniform base + SGPR (image, channel, row) offset + lane offset; tail lanes read
 // out of range = 0), 64 consecutive output pixels per wave-item so that every store is one contiguous 256-byte run.
 // Sum order per output: ci -> kx -> ky, then + bias (conv2d.cpp:78-87).
-__global__ void pack_fwd_weights_3_16_3_2(const float* __restrict__ w, const float* __restrict__ bias,
-                                          float* __restrict__ wp) {
-    for (int i = threadIdx.x; i < 27 * 16; i += blockDim.x) {
+__device__ void pack_fwd_3_16_3_2_body(const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ wp,
+                                       int tid, int nt) {
+    for (int i = tid; i < 27 * 16; i += nt) {
         const int t = i >> 4, co = i & 15;
         wp[i] = w[co * 27 + t];
     }
-    if (threadIdx.x < 16) wp[27 * 16 + threadIdx.x] = bias[threadIdx.x];
+    if (tid < 16) wp[27 * 16 + tid] = bias[tid];
+}
+
+__global__ void pack_fwd_weights_3_16_3_2(const float* __restrict__ w, const float* __restrict__ bias,
+                                          float* __restrict__ wp) {
+    pack_fwd_3_16_3_2_body(w, bias, wp, threadIdx.x, blockDim.x);
+}
+
+// all packing jobs of a network in ONE launch (cnn_conv2d_prepare_filters): blockIdx.y = job
+struct PackJob {
+    int kind;  // 0 forward 3->16, 1 dgrad 3->16, 2 dgrad stride-2 generic
+    const float* w;
+    const float* bias;
+    float* out;
+    int CI, CO;
+};
+struct PackBatch {
+    int n;
+    PackJob j[8];
+};
+__global__ void pack_batch(const PackBatch pb) {
+    const PackJob& jb = pb.j[blockIdx.y];
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    if (jb.kind == 0) pack_fwd_3_16_3_2_body(jb.w, jb.bias, jb.out, tid, nt);
+    else if (jb.kind == 1) pack_dgrad_3_16_3_2_body(jb.w, jb.out, tid);
+    else pack_dgrad_s2_body(jb.w, jb.out, jb.CI, jb.CO, tid, nt);
 }
 
 typedef int v2i __attribute__((ext_vector_type(2)));
@@ -737,13 +770,17 @@ bool direct_conv_supported(const cnn_conv2d_desc* d) {
     return d->Ci == 3 && d->Co == 16 && d->k == 3 && d->s == 2 && d->pad == 0 && !getenv("CNN_AMD_NO_DIRECT");
 }
 
+// prepared: `ws` already holds the packed filters (cnn_conv2d_prepare_filters); w / bias are then unused
+bool direct_fwd_pk_ok(const cnn_conv2d_desc* d) {
+    return (long long)d->B * 3 * d->H * d->W * 4 < (1ll << 31) - 16 && !getenv("CNN_AMD_FWD_NOPK");
+}
 int direct_conv_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
-                        float* y_relu, void* ws, size_t ws_bytes, hipStream_t s) {
+                        float* y_relu, void* ws, size_t ws_bytes, hipStream_t s, bool prepared) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
     // measured: the packed kernel wins when the ReLU output is fused in (121 vs 142 us), the plain row kernel otherwise
-    if (y_relu != nullptr && ws != nullptr && ws_bytes >= 28 * 16 * sizeof(float) &&
-        (long long)d->B * 3 * d->H * d->W * 4 < (1ll << 31) - 16 && !getenv("CNN_AMD_FWD_NOPK")) {
-        CNN_KLAUNCH(s, "pack_fwd_weights", (pack_fwd_weights_3_16_3_2<<<1, 256, 0, s>>>(w, bias, (float*)ws)), CONV_TAG(d));
+    if ((y_relu != nullptr || prepared) && ws != nullptr && ws_bytes >= 28 * 16 * sizeof(float) && direct_fwd_pk_ok(d)) {
+        if (!prepared)
+            CNN_KLAUNCH(s, "pack_fwd_weights", (pack_fwd_weights_3_16_3_2<<<1, 256, 0, s>>>(w, bias, (float*)ws)), CONV_TAG(d));
         const int ipi = (Ho * Wo + 63) / 64;
         const long long witems = (long long)d->B * ipi;
         if (y_relu)
@@ -756,6 +793,7 @@ int direct_conv_forward(const cnn_conv2d_desc* d, const float* x, const float* w
                                                                                          d->W, Ho, Wo, ipi, div_magic(ipi), div_magic(Wo))), CONV_TAG(d));
         return CNN_AMD_OK;
     }
+    CNN_REQUIRE(!prepared, "internal: prepared forward without a packed kernel");
     const long long rows = (long long)d->B * Ho;
     CNN_KLAUNCH(s, y_relu ? "conv_direct_fwd<3,16,3,2>+relu" : "conv_direct_fwd<3,16,3,2>",
                 (conv_direct_fwd<3, 16, 3, 2><<<wave_grid(rows), kBlock, 0, s>>>(x, w, bias, y, y_relu, d->B, d->H, d->W, Ho, Wo)),
@@ -763,14 +801,18 @@ int direct_conv_forward(const cnn_conv2d_desc* d, const float* x, const float* w
     return CNN_AMD_OK;
 }
 
+bool direct_dgrad_pk_ok(const cnn_conv2d_desc* d) {
+    const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
+    return (long long)d->B * 16 * Ho * Wo * 4 < (1ll << 31) - 16 && !getenv("CNN_AMD_DG_NOPK");
+}
 int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes,
-                      hipStream_t s) {
+                      hipStream_t s, bool prepared) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
     const long long rows = (long long)d->B * ((d->H + d->s - 1) / d->s);
     const int dbg = getenv("CNN_AMD_DBG") ? atoi(getenv("CNN_AMD_DBG")) : 0;
-    if (ws != nullptr && ws_bytes >= 16 * 32 * sizeof(float) && (long long)d->B * 16 * Ho * Wo * 4 < (1ll << 31) - 16 &&
-        !getenv("CNN_AMD_DG_NOPK")) {
-        CNN_KLAUNCH(s, "pack_dgrad_weights", (pack_dgrad_weights_3_16_3_2<<<1, 64, 0, s>>>(w, (float*)ws)), CONV_TAG(d));
+    if (ws != nullptr && ws_bytes >= 16 * 32 * sizeof(float) && direct_dgrad_pk_ok(d)) {
+        if (!prepared)
+            CNN_KLAUNCH(s, "pack_dgrad_weights", (pack_dgrad_weights_3_16_3_2<<<1, 64, 0, s>>>(w, (float*)ws)), CONV_TAG(d));
         const int cb = getenv("CNN_AMD_DG_UNROLL") ? atoi(getenv("CNN_AMD_DG_UNROLL")) : 4;
         const int UVg = ((d->H + 1) / 2) * ((d->W + 1) / 2);
         const int ipi = (UVg + 63) / 64;
@@ -793,6 +835,7 @@ int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w,
 #undef PK_LAUNCH
         return CNN_AMD_OK;
     }
+    CNN_REQUIRE(!prepared, "internal: prepared dgrad without a packed kernel");
     const int un = getenv("CNN_AMD_DG_UNROLL") ? atoi(getenv("CNN_AMD_DG_UNROLL")) : 4;
 #define DG_LAUNCH(U)                                                                                                  \
     CNN_KLAUNCH(s, "conv_direct_dgrad<3,16,3,2>",                                                                    \
@@ -817,11 +860,12 @@ bool pk_dgrad_s2_supported(const cnn_conv2d_desc* d) {
 }
 size_t pk_dgrad_s2_workspace_floats(const cnn_conv2d_desc* d) { return (size_t)d->Co * 9 * d->Ci; }
 
-int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, hipStream_t s) {
+int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, hipStream_t s, bool prepared) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
     const int total = d->Co * 9 * d->Ci;
-    CNN_KLAUNCH(s, "pack_dgrad_weights", (pack_dgrad_weights_s2<<<(total + 255) / 256, 256, 0, s>>>(w, (float*)ws, d->Ci, d->Co)),
-                CONV_TAG(d));
+    if (!prepared)
+        CNN_KLAUNCH(s, "pack_dgrad_weights", (pack_dgrad_weights_s2<<<(total + 255) / 256, 256, 0, s>>>(w, (float*)ws, d->Ci, d->Co)),
+                    CONV_TAG(d));
     const int V = (d->W + 1) / 2, UVg = ((d->H + 1) / 2) * V;
     const int px = getenv("CNN_AMD_PK_PX") ? atoi(getenv("CNN_AMD_PK_PX")) : 1;
     const int ipi = (UVg + 64 * px - 1) / (64 * px);
@@ -850,6 +894,36 @@ int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float
     }
 #undef PKS2
     return CNN_AMD_OK;
+}
+
+// Packs, in ONE launch, the filters of every listed layer that runs on a kernel of this file; sets bit i of *fwd_done /
+// *dgrad_done for the layers it handled (the implicit-GEMM layers are prepared by conv_igemm.hip).
+int direct_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, const float* const* bias,
+                         void* const* fwd, void* const* dgrad, hipStream_t s, unsigned* fwd_done, unsigned* dgrad_done) {
+    PackBatch pb;
+    pb.n = 0;
+    *fwd_done = *dgrad_done = 0;
+    for (int i = 0; i < n; ++i) {
+        const cnn_conv2d_desc* d = &descs[i];
+        if (direct_conv_supported(d) && direct_fwd_pk_ok(d) && fwd && fwd[i] && pb.n < 8) {
+            pb.j[pb.n++] = PackJob{0, w[i], bias[i], (float*)fwd[i], 3, 16};
+            *fwd_done |= 1u << i;
+        }
+        if (direct_conv_supported(d) && direct_dgrad_pk_ok(d) && dgrad && dgrad[i] && pb.n < 8) {
+            pb.j[pb.n++] = PackJob{1, w[i], nullptr, (float*)dgrad[i], 3, 16};
+            *dgrad_done |= 1u << i;
+        } else if (!direct_conv_supported(d) && pk_dgrad_s2_supported(d) && dgrad && dgrad[i] && pb.n < 8) {
+            pb.j[pb.n++] = PackJob{2, w[i], nullptr, (float*)dgrad[i], d->Ci, d->Co};
+            *dgrad_done |= 1u << i;
+        }
+    }
+    if (pb.n > 0) CNN_KLAUNCH(s, "pack_batch", (pack_batch<<<dim3(8, pb.n), 256, 0, s>>>(pb)), "jobs=%d", pb.n);
+    return CNN_AMD_OK;
+}
+// can this layer's forward / data gradient run from prepared filters?
+bool direct_prepared_fwd_ok(const cnn_conv2d_desc* d) { return direct_conv_supported(d) && direct_fwd_pk_ok(d); }
+bool direct_prepared_dgrad_ok(const cnn_conv2d_desc* d) {
+    return (direct_conv_supported(d) && direct_dgrad_pk_ok(d)) || (!direct_conv_supported(d) && pk_dgrad_s2_supported(d));
 }
 
 // number of slabs (workgroups) the packed weight-gradient kernel writes; 0 when the geometry / sizes rule it out

@@ -828,11 +828,10 @@ struct PrepParams {
     int kstep;  // MFMA k per instruction (2 for 32x32x2, 4 for 16x16x4)
 };
 
-__global__ void igemm_prep_weights(const PrepParams q) {
+__device__ void igemm_prep_body(const PrepParams& q, long long tid, long long nt) {
     const int T = q.TR * q.TC;
     const long long total = (long long)q.nmb * q.nchunk * T * q.CK * q.MT;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+    for (long long idx = tid; idx < total; idx += nt) {
         long long r = idx;
         int mm, ck, t, cc, mb;
         if (q.a4) {  // [mb][cc][tap][lh][mm][c2]  with ck = 2*c2 + lh (32x32x2: k index = lane >> 5)
@@ -865,6 +864,19 @@ __global__ void igemm_prep_weights(const PrepParams q) {
         }
         q.A[idx] = v;
     }
+}
+
+__global__ void igemm_prep_weights(const PrepParams q) {
+    igemm_prep_body(q, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+}
+
+// the re-layouts of several layers / modes in ONE launch (cnn_conv2d_prepare_filters): blockIdx.y = job
+struct PrepBatch {
+    int n;
+    PrepParams q[12];
+};
+__global__ void igemm_prep_batch(const PrepBatch pb) {
+    igemm_prep_body(pb.q[blockIdx.y], (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
 }
 
 // ---- host-side planning ------------------------------------------------------------------------------------
@@ -1148,18 +1160,21 @@ int launch_cfg(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
                          : launch_cfg2<MF, MA, NB, WM, WN, CK, false>(pl, s, d);
 }
 
+// prepared: `ws` already holds the re-arranged filters (cnn_conv2d_prepare_filters); w is then unused
 int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w, const float* bias, float* Y, float* Y2,
-             void* ws, size_t ws_bytes, hipStream_t s, const char* who) {
+             void* ws, size_t ws_bytes, hipStream_t s, const char* who, bool prepared = false) {
     CNN_REQUIRE(ws != nullptr, "%s: workspace is null", who);
     if (ws_bytes < pl.a_floats * sizeof(float))
         return fail(CNN_AMD_E_WORKSPACE, "%s: workspace %zu B < %zu B", who, ws_bytes, pl.a_floats * sizeof(float));
-    pl.q.w = w;
-    pl.q.A = (float*)ws;
-    const long long total = (long long)pl.a_floats;
-    unsigned pg = (unsigned)((total + 255) / 256);
-    if (pg > 4096) pg = 4096;
-    CNN_KLAUNCH(s, pl.p.mode == MODE_FWD ? "igemm_prep_weights/fwd" : "igemm_prep_weights/dgrad",
-                (igemm_prep_weights<<<pg, 256, 0, s>>>(pl.q)), CONV_TAG(d));
+    if (!prepared) {
+        pl.q.w = w;
+        pl.q.A = (float*)ws;
+        const long long total = (long long)pl.a_floats;
+        unsigned pg = (unsigned)((total + 255) / 256);
+        if (pg > 4096) pg = 4096;
+        CNN_KLAUNCH(s, pl.p.mode == MODE_FWD ? "igemm_prep_weights/fwd" : "igemm_prep_weights/dgrad",
+                    (igemm_prep_weights<<<pg, 256, 0, s>>>(pl.q)), CONV_TAG(d));
+    }
     pl.p.X = X; pl.p.A = (const float*)ws; pl.p.bias = bias; pl.p.Y = Y; pl.p.Y2 = Y2;
     switch (pl.cfg) {
         case CFG_D_M128: return launch_dma<32, 4, 1, 1, 8, 4>(pl, s, d);
@@ -1227,12 +1242,16 @@ int check_desc(const char* who, const cnn_conv2d_desc* d) {
 namespace cnn_amd {
 bool direct_conv_supported(const cnn_conv2d_desc* d);  // conv_direct.hip: thin first layers bypass the implicit GEMM
 int direct_conv_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, float* y_relu,
-                        void* ws, size_t ws_bytes, hipStream_t s);
+                        void* ws, size_t ws_bytes, hipStream_t s, bool prepared);
 int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes,
-                      hipStream_t s);
+                      hipStream_t s, bool prepared);
+int direct_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, const float* const* bias,
+                         void* const* fwd, void* const* dgrad, hipStream_t s, unsigned* fwd_done, unsigned* dgrad_done);
+bool direct_prepared_fwd_ok(const cnn_conv2d_desc* d);
+bool direct_prepared_dgrad_ok(const cnn_conv2d_desc* d);
 bool pk_dgrad_s2_supported(const cnn_conv2d_desc* d);  // conv_direct.hip: packed VALU dgrad for small stride-2 layers
 size_t pk_dgrad_s2_workspace_floats(const cnn_conv2d_desc* d);
-int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, hipStream_t s);
+int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, hipStream_t s, bool prepared);
 // scratch floats the forward / dgrad plans need (used by cnn_conv2d_workspace_bytes in conv_wgrad.hip)
 size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
     Plan a, b;
@@ -1248,13 +1267,25 @@ size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
 extern "C" {
 
 static int conv2d_forward_impl(const char* who, const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias,
-                               float* y, float* y_relu, void* ws, size_t ws_bytes, void* stream) {
+                               float* y, float* y_relu, void* ws, size_t ws_bytes, void* stream, bool prepared = false) {
     if (int rc = check_desc(who, d)) return rc;
-    CNN_REQUIRE(x && w && bias && y, "%s: null pointer", who);
-    if (direct_conv_supported(d)) return direct_conv_forward(d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream));
+    CNN_REQUIRE(x && (w || prepared) && bias && y, "%s: null pointer", who);
+    if (direct_conv_supported(d)) return direct_conv_forward(d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream), prepared);
     Plan pl;
     if (int rc = make_plan(who, d, MODE_FWD, &pl)) return rc;
-    return run_plan(pl, d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream), who);
+    return run_plan(pl, d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream), who, prepared);
+}
+
+static int conv2d_backward_data_impl(const char* who, const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx,
+                                     void* ws, size_t ws_bytes, void* stream, bool prepared) {
+    if (int rc = check_desc(who, d)) return rc;
+    CNN_REQUIRE(dy && (w || prepared) && dx, "%s: null pointer", who);
+    if (direct_conv_supported(d)) return direct_conv_dgrad(d, dy, w, dx, ws, ws_bytes, as_stream(stream), prepared);
+    if (pk_dgrad_s2_supported(d) && ws != nullptr && ws_bytes >= pk_dgrad_s2_workspace_floats(d) * sizeof(float))
+        return pk_dgrad_s2(d, dy, w, dx, ws, as_stream(stream), prepared);
+    Plan pl;
+    if (int rc = make_plan(who, d, MODE_DGRAD, &pl)) return rc;
+    return run_plan(pl, d, dy, w, nullptr, dx, nullptr, ws, ws_bytes, as_stream(stream), who, prepared);
 }
 
 int cnn_conv2d_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
@@ -1270,14 +1301,65 @@ int cnn_conv2d_forward_relu(const cnn_conv2d_desc* d, const float* x, const floa
 
 int cnn_conv2d_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws,
                              size_t ws_bytes, void* stream) {
-    if (int rc = check_desc("cnn_conv2d_backward_data", d)) return rc;
-    CNN_REQUIRE(dy && w && dx, "cnn_conv2d_backward_data: null pointer");
-    if (direct_conv_supported(d)) return direct_conv_dgrad(d, dy, w, dx, ws, ws_bytes, as_stream(stream));
-    if (pk_dgrad_s2_supported(d) && ws != nullptr && ws_bytes >= pk_dgrad_s2_workspace_floats(d) * sizeof(float))
-        return pk_dgrad_s2(d, dy, w, dx, ws, as_stream(stream));
-    Plan pl;
-    if (int rc = make_plan("cnn_conv2d_backward_data", d, MODE_DGRAD, &pl)) return rc;
-    return run_plan(pl, d, dy, w, nullptr, dx, nullptr, ws, ws_bytes, as_stream(stream), "cnn_conv2d_backward_data");
+    return conv2d_backward_data_impl("cnn_conv2d_backward_data", d, dy, w, dx, ws, ws_bytes, stream, false);
+}
+
+/* ---- filter preparation hoisted out of the per-layer calls ---- */
+size_t cnn_conv2d_prepared_bytes(const cnn_conv2d_desc* d) {
+    if (check_desc("cnn_conv2d_prepared_bytes", d)) return 0;
+    return (igemm_workspace_floats(d) + 64) * sizeof(float);
+}
+
+int cnn_conv2d_prepare_filters(int n, const cnn_conv2d_desc* descs, const float* const* w, const float* const* bias,
+                               void* const* fwd, void* const* dgrad, void* stream) {
+    CNN_REQUIRE(n > 0 && n <= 6 && descs && w && bias, "cnn_conv2d_prepare_filters: n=%d (1..6 layers per call)", n);
+    hipStream_t s = as_stream(stream);
+    unsigned fdone = 0, ddone = 0;
+    if (int rc = direct_prepare_batch(n, descs, w, bias, fwd, dgrad, s, &fdone, &ddone)) return rc;
+    PrepBatch pb;
+    pb.n = 0;
+    long long most = 0;
+    for (int i = 0; i < n; ++i) {
+        if (int rc = check_desc("cnn_conv2d_prepare_filters", &descs[i])) return rc;
+        CNN_REQUIRE(w[i] != nullptr, "cnn_conv2d_prepare_filters: filters of layer %d are null", i);
+        for (int mode = 0; mode < 2; ++mode) {
+            void* out = mode == MODE_FWD ? (fwd ? fwd[i] : nullptr) : (dgrad ? dgrad[i] : nullptr);
+            if (!out || ((mode == MODE_FWD ? fdone : ddone) >> i & 1u)) continue;
+            CNN_REQUIRE(!direct_conv_supported(&descs[i]) && !(mode == MODE_DGRAD && pk_dgrad_s2_supported(&descs[i])),
+                        "cnn_conv2d_prepare_filters: layer %d has no prepared path for this mode", i);
+            Plan pl;
+            if (int rc = make_plan("cnn_conv2d_prepare_filters", &descs[i], mode, &pl)) return rc;
+            pl.q.w = w[i];
+            pl.q.A = (float*)out;
+            pb.q[pb.n++] = pl.q;
+            if ((long long)pl.a_floats > most) most = (long long)pl.a_floats;
+        }
+    }
+    if (pb.n > 0) {
+        unsigned pg = (unsigned)((most + 255) / 256);
+        if (pg > 1024) pg = 1024;
+        CNN_KLAUNCH(s, "igemm_prep_batch", (igemm_prep_batch<<<dim3(pg, pb.n), 256, 0, s>>>(pb)), "jobs=%d", pb.n);
+    }
+    return CNN_AMD_OK;
+}
+
+int cnn_conv2d_forward_prepared(const cnn_conv2d_desc* d, const float* x, const void* prepared_fwd, const float* bias, float* y,
+                                float* y_relu, void* stream) {
+    CNN_REQUIRE(prepared_fwd != nullptr, "cnn_conv2d_forward_prepared: null pointer");
+    if (int rc = check_desc("cnn_conv2d_forward_prepared", d)) return rc;
+    CNN_REQUIRE(!direct_conv_supported(d) || direct_prepared_fwd_ok(d), "cnn_conv2d_forward_prepared: no prepared path for this layer");
+    return conv2d_forward_impl("cnn_conv2d_forward_prepared", d, x, nullptr, bias, y, y_relu, (void*)prepared_fwd,
+                               cnn_conv2d_prepared_bytes(d), stream, true);
+}
+
+int cnn_conv2d_backward_data_prepared(const cnn_conv2d_desc* d, const float* dy, const void* prepared_dgrad, float* dx,
+                                      void* stream) {
+    CNN_REQUIRE(prepared_dgrad != nullptr, "cnn_conv2d_backward_data_prepared: null pointer");
+    if (int rc = check_desc("cnn_conv2d_backward_data_prepared", d)) return rc;
+    CNN_REQUIRE(!direct_conv_supported(d) || direct_prepared_dgrad_ok(d),
+                "cnn_conv2d_backward_data_prepared: no prepared path for this layer");
+    return conv2d_backward_data_impl("cnn_conv2d_backward_data_prepared", d, dy, nullptr, dx, (void*)prepared_dgrad,
+                                     cnn_conv2d_prepared_bytes(d), stream, true);
 }
 
 }  // extern "C"

@@ -12,6 +12,10 @@
 
 #include "data_format.h"
 
+extern "C" {
+#include "cnn_amd.h"
+}
+
 namespace architectures {
 
 extern data_type random_times;  // init scale divisor (architectures.cpp:6)
@@ -71,6 +75,9 @@ class ReLU;
 class Conv2D : public Layer {
 private:
     ReLU* fused_relu = nullptr;  // the ReLU layer right behind this convolution (set by the container), or null
+    void* prep_fwd = nullptr;    // prepared filters (forward / data gradient layouts)
+    void* prep_dgrad = nullptr;
+    bool prepared_active = false;
     const int in_channels, out_channels, kernel_size, stride;
     const int params_for_one_kernel;
     const int padding = 0;
@@ -101,6 +108,14 @@ public:
     void load_weights(std::ifstream& reader) override;
     int get_params_num() const;
     void set_fused_relu(ReLU* relu) { fused_relu = relu; }  // addition (see architectures::fuse_layers)
+    // additions: filter re-layout hoisted out of forward / backward (cnn_conv2d_prepare_filters); the container prepares
+    // all layers with one call after every parameter change and switches the layers to the *_prepared entry points
+    bool shape_known() const { return batch > 0; }
+    cnn_conv2d_desc current_desc() const { return cnn_conv2d_desc{batch, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding}; }
+    const data_type* filters_dev() const { return params; }
+    const data_type* bias_dev() const { return b_dev(); }
+    void prepared_buffers(void** fwd, void** dgrad);  // allocated on first use
+    void set_prepared(bool on) { prepared_active = on; }
     size_t param_count() const override { return (size_t)get_params_num(); }
     void bind_arena(data_type* params_dev, data_type* grads_dev) override;
 };
@@ -207,6 +222,8 @@ private:
     data_type* grad_arena = nullptr;
     size_t n_params = 0;
     bool owns_arena = true;
+    bool filters_prepared = false;  // the layers' prepared filters match the current parameters
+    void prepare_filters();
 
 public:
     AlexNet(const int num_classes = 3, const bool batch_norm = false);
@@ -222,6 +239,9 @@ public:
     // additions
     size_t num_params() const { return n_params; }
     data_type* params_device() const { return param_arena; }
+    // MUST be called after writing the parameter arena from outside (memcpy, collective, ...): the convolutions keep
+    // re-arranged copies of their filters between update_gradients() calls
+    void parameters_changed();
     data_type* grads_device() const { return grad_arena; }
     const std::list<std::shared_ptr<Layer> >& layers() const { return layers_sequence; }
 

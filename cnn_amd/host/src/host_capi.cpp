@@ -61,6 +61,7 @@ void cnnh_net_set_params(void* hv, const float* host) {
     Handle* h = (Handle*)hv;
     must(cnn_memcpy_h2d(h->net->params_device(), host, sizeof(float) * h->net->num_params(), stream), "cnn_memcpy_h2d");
     must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+    h->net->parameters_changed();
 }
 void cnnh_net_get_params(void* hv, float* host) {
     Handle* h = (Handle*)hv;

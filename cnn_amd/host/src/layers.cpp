@@ -115,6 +115,19 @@ Conv2D::~Conv2D() {
         cnn_device_free(grads);
     }
     if (workspace) cnn_device_free(workspace);
+    if (prep_fwd) cnn_device_free(prep_fwd);
+    if (prep_dgrad) cnn_device_free(prep_dgrad);
+}
+
+void Conv2D::prepared_buffers(void** fwd, void** dgrad) {
+    if (prep_fwd == nullptr) {
+        const cnn_conv2d_desc d = current_desc();
+        const size_t n = cnn_conv2d_prepared_bytes(&d);
+        prep_fwd = dev_alloc(n);
+        prep_dgrad = dev_alloc(n);
+    }
+    *fwd = prep_fwd;
+    *dgrad = prep_dgrad;
 }
 
 void Conv2D::bind_arena(data_type* params_dev, data_type* grads_dev) {
@@ -127,6 +140,7 @@ void Conv2D::bind_arena(data_type* params_dev, data_type* grads_dev) {
     params = params_dev;
     grads = grads_dev;
     owns_params = false;
+    prepared_active = false;
 }
 
 void Conv2D::ensure_workspace(int B, int H, int W) {
@@ -160,10 +174,16 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
         saved_input_tensors = input;
     }
     cnn_conv2d_desc d{B, in_channels, H, W, out_channels, kernel_size, stride, padding};
+    const bool prepared = prepared_active && fuse_layers && B == batch;
     if (fused_relu != nullptr && fuse_layers) {  // the ReLU behind this layer gets its output from the same kernel
         data_type* y_relu = fused_relu->fused_forward_target(B, out_channels, out_H, out_W);
-        must(cnn_conv2d_forward_relu(&d, x, w_dev(), b_dev(), out_buf.base, y_relu, workspace, workspace_bytes, stream),
-             "cnn_conv2d_forward_relu");
+        if (prepared)
+            must(cnn_conv2d_forward_prepared(&d, x, prep_fwd, b_dev(), out_buf.base, y_relu, stream), "cnn_conv2d_forward_prepared");
+        else
+            must(cnn_conv2d_forward_relu(&d, x, w_dev(), b_dev(), out_buf.base, y_relu, workspace, workspace_bytes, stream),
+                 "cnn_conv2d_forward_relu");
+    } else if (prepared) {
+        must(cnn_conv2d_forward_prepared(&d, x, prep_fwd, b_dev(), out_buf.base, nullptr, stream), "cnn_conv2d_forward_prepared");
     } else {
         must(cnn_conv2d_forward(&d, x, w_dev(), b_dev(), out_buf.base, workspace, workspace_bytes, stream), "cnn_conv2d_forward");
     }
@@ -184,9 +204,14 @@ std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
         workspace = dev_alloc(need);
         workspace_bytes = need;
     }
-    must(cnn_conv2d_backward(&d, saved_input, dy, w_dev(), grads, grads + (size_t)out_channels * params_for_one_kernel,
-                             delta_buf.base, (float)B, workspace, workspace_bytes, stream, /*defer_join=*/1),
-         "cnn_conv2d_backward");  // joined in update_gradients / AlexNet::backward
+    if (prepared_active && fuse_layers && B == batch)
+        must(cnn_conv2d_backward_prepared(&d, saved_input, dy, prep_dgrad, grads, grads + (size_t)out_channels * params_for_one_kernel,
+                                          delta_buf.base, (float)B, workspace, workspace_bytes, stream, /*defer_join=*/1),
+             "cnn_conv2d_backward_prepared");
+    else
+        must(cnn_conv2d_backward(&d, saved_input, dy, w_dev(), grads, grads + (size_t)out_channels * params_for_one_kernel,
+                                 delta_buf.base, (float)B, workspace, workspace_bytes, stream, /*defer_join=*/1),
+             "cnn_conv2d_backward");  // joined in update_gradients / AlexNet::backward
     grads_ready = true;
     return delta_buf.views;
 }
@@ -195,6 +220,7 @@ void Conv2D::update_gradients(const data_type learning_rate) {
     assert(grads_ready);  // conv2d.cpp:206
     must(cnn_amd_side_stream_join(stream), "cnn_amd_side_stream_join");
     must(cnn_sgd_update(params, grads, param_count(), learning_rate, 1.f, stream), "cnn_sgd_update");
+    prepared_active = false;
 }
 
 // checkpoint layout conv2d.cpp:220-226: Co filters then Co biases == the device layout, one contiguous block
@@ -206,6 +232,7 @@ void Conv2D::save_weights(std::ofstream& writer) const {
 }
 
 void Conv2D::load_weights(std::ifstream& reader) {
+    prepared_active = false;
     std::vector<data_type> host(param_count());
     reader.read(reinterpret_cast<char*>(host.data()), static_cast<std::streamsize>(sizeof(data_type) * host.size()));
     must(cnn_memcpy_h2d(params, host.data(), sizeof(data_type) * host.size(), stream), "cnn_memcpy_h2d");

@@ -77,9 +77,34 @@ AlexNet::~AlexNet() {
     }
 }
 
+// One cnn_conv2d_prepare_filters call for all convolutions (instead of one small re-layout launch inside every forward
+// and backward call); possible once every layer has seen its input shape, i.e. from the second forward pass on.
+void AlexNet::prepare_filters() {
+    std::vector<Conv2D*> convs;
+    for (auto& layer : layers_sequence)
+        if (auto* c = dynamic_cast<Conv2D*>(layer.get())) convs.push_back(c);
+    for (auto* c : convs)
+        if (!c->shape_known()) return;
+    if (convs.empty() || convs.size() > 6) return;
+    std::vector<cnn_conv2d_desc> descs;
+    std::vector<const float*> w, b;
+    std::vector<void*> f(convs.size()), g(convs.size());
+    for (size_t i = 0; i < convs.size(); ++i) {
+        descs.push_back(convs[i]->current_desc());
+        w.push_back(convs[i]->filters_dev());
+        b.push_back(convs[i]->bias_dev());
+        convs[i]->prepared_buffers(&f[i], &g[i]);
+    }
+    must(cnn_conv2d_prepare_filters((int)convs.size(), descs.data(), w.data(), b.data(), f.data(), g.data(), stream),
+         "cnn_conv2d_prepare_filters");
+    for (auto* c : convs) c->set_prepared(true);
+    filters_prepared = true;
+}
+
 std::vector<tensor> AlexNet::forward(const std::vector<tensor>& input) {
     assert(input.size() > 0);
     if (print_info) input[0]->print_shape();
+    if (fuse_layers && !filters_prepared) prepare_filters();
     std::vector<tensor> output(input);
     for (const auto& layer : layers_sequence) {
         output = layer->forward(output);
@@ -98,8 +123,15 @@ void AlexNet::backward(std::vector<tensor>& delta_start) {
     must(cnn_amd_side_stream_join(stream), "cnn_amd_side_stream_join");
 }
 
+void AlexNet::parameters_changed() {
+    filters_prepared = false;  // re-prepared at the start of the next forward pass
+    for (auto& layer : layers_sequence)
+        if (auto* c = dynamic_cast<Conv2D*>(layer.get())) c->set_prepared(false);
+}
+
 void AlexNet::update_gradients(const data_type learning_rate, const data_type grad_scale) {
     must(cnn_sgd_update(param_arena, grad_arena, n_params, learning_rate, grad_scale, stream), "cnn_sgd_update");
+    parameters_changed();
 }
 
 void AlexNet::save_weights(const std::filesystem::path& save_path) const {
@@ -115,6 +147,7 @@ void AlexNet::load_weights(const std::filesystem::path& checkpoint_path) {
         return;
     }
     std::ifstream reader(checkpoint_path.c_str(), std::ios::binary);
+    parameters_changed();
     for (auto& layer : layers_sequence) layer->load_weights(reader);
     std::cout << "load weights from" << checkpoint_path.string() << std::endl;
     reader.close();

@@ -22,6 +22,9 @@ class AlexNetHip:
         # fuse: Conv2D+ReLU forward and MaxPool2D+ReLU backward run as one kernel each (bit-identical results, every
         # layer's output tensor is still written); fuse=False issues the reference's one-call-per-layer sequence
         self.fuse = fuse
+        # prepared filters: with fuse=True the per-call filter re-layout kernels (8 per step) are replaced by
+        # cnn_conv2d_prepare_filters (2 launches) whenever the parameters changed
+        self._prep_valid = False
         self.B, self.classes, self.H, self.W, self.dev = batch, classes, H, W, device
         f32 = dict(dtype=torch.float32, device=device)
         self.convs, self.conv_in_hw, self.conv_out_hw = [], [], []
@@ -58,6 +61,10 @@ class AlexNetHip:
         self.d_conv = [torch.empty((batch, self.CHANS[l]) + self.conv_in_hw[l], **f32) for l in range(4)]
         self.d_pool = torch.empty((batch, 16) + self.conv_out_hw[0], **f32)
         self.x = None
+        import os
+
+        self.use_prep = fuse and not os.environ.get("CNN_AMD_NO_PREPARED")  # (A/B switch for measurements)
+        self.prep = [c.prepared_buffers(device) for c in self.convs] if self.use_prep else None
 
     # ---- parameter views (reference layouts) ----
     def conv_w(self, l, arena=None):
@@ -81,6 +88,13 @@ class AlexNetHip:
         flat = np.ascontiguousarray(flat, dtype=np.float32)
         assert flat.size == self.n_params, (flat.size, self.n_params)
         self.params.copy_(self.torch.from_numpy(flat))
+        self._prep_valid = False
+
+    def _prepare(self):
+        if not self._prep_valid:
+            capi.prepare_filters(self.convs, [self.conv_w(l) for l in range(4)], [self.conv_b(l) for l in range(4)],
+                                 [p[0] for p in self.prep], [p[1] for p in self.prep])
+            self._prep_valid = True
 
     def load_checkpoint(self, path):
         self.load_params(np.fromfile(path, dtype=np.float32))
@@ -89,9 +103,13 @@ class AlexNetHip:
     def forward(self, x, record=True):
         self.x = x
         cur = x
+        if self.use_prep:
+            self._prepare()
         for l in range(4):
-            if self.fuse:
+            if self.fuse and not self.use_prep:
                 self.convs[l].forward_relu(cur, self.conv_w(l), self.conv_b(l), self.conv_out[l], self.relu_out[l])
+            elif self.fuse:
+                self.convs[l].forward_prepared(cur, self.prep[l][0], self.conv_b(l), self.conv_out[l], self.relu_out[l])
             else:
                 self.convs[l].forward(cur, self.conv_w(l), self.conv_b(l), self.conv_out[l])
                 capi.check(capi.load().cnn_relu_forward(capi._ptr(self.conv_out[l]), capi._ptr(self.relu_out[l]),
@@ -132,14 +150,19 @@ class AlexNetHip:
                 capi.relu_backward(self.relu_out[l], cur)  # in place on the upstream delta (relu.cpp:37-39)
             lin = self.x if l == 0 else (self.pool_out if l == 1 else self.relu_out[l - 1])
             # Conv2D::backward in one call: weight/bias gradient on the library's side stream, concurrently with dgrad
-            self.convs[l].backward(lin, cur, self.conv_w(l), div, self.conv_w(l, g), self.conv_b(l, g), self.d_conv[l],
-                                   defer_join=True)
+            if self.use_prep:
+                self.convs[l].backward_prepared(lin, cur, self.prep[l][1], div, self.conv_w(l, g), self.conv_b(l, g),
+                                                self.d_conv[l], defer_join=True)
+            else:
+                self.convs[l].backward(lin, cur, self.conv_w(l), div, self.conv_w(l, g), self.conv_b(l, g), self.d_conv[l],
+                                       defer_join=True)
             cur = self.d_conv[l]
         capi.side_stream_join()  # all weight gradients are in the arena before SGD / all-reduce read it
 
     # ---- alexnet.cpp:62-65 (+ the data-parallel mean) ----
     def update(self, lr, grad_scale=1.0):
         capi.sgd_update(self.params, self.grads, lr, grad_scale)
+        self._prep_valid = False
 
     def train_step(self, x, labels, lr, dist=None, world=1):
         """one iteration of cnn.cpp:79-90.  Under data parallelism every rank holds B local samples: local grads are

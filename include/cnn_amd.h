@@ -132,6 +132,26 @@ int cnn_linear_forward(const float* x, const float* w, const float* bias, float*
 int cnn_linear_backward(const float* x, const float* dy, const float* w, float* gw, float* gb, float* dx, int B,
                         int in, int out, float divisor, void* stream);
 
+/* ---- optional: filter preparation hoisted out of the per-layer calls ----------------------------------
+ * cnn_conv2d_forward / cnn_conv2d_backward_data re-arrange the filters for their kernels in a small launch of their own
+ * on every call, because the filters may have changed (Conv2D::update_gradients, conv2d.cpp:205-217).  A caller that
+ * knows WHEN they change -- once per SGD step -- can re-arrange the filters of all layers with one or two launches and
+ * pass the results in; outputs are bit-identical to the plain calls.
+ *   fwd[i] / dgrad[i]: device buffers of cnn_conv2d_prepared_bytes(&descs[i]) bytes each (NULL entries / arrays skip that
+ *   mode); they must be re-prepared after every change of w[i] / bias[i].  At most 6 layers per call. */
+size_t cnn_conv2d_prepared_bytes(const cnn_conv2d_desc* d);
+int cnn_conv2d_prepare_filters(int n, const cnn_conv2d_desc* descs, const float* const* w, const float* const* bias,
+                               void* const* fwd, void* const* dgrad, void* stream);
+/* cnn_conv2d_forward / _forward_relu (y_relu nullable) from prepared filters */
+int cnn_conv2d_forward_prepared(const cnn_conv2d_desc* d, const float* x, const void* prepared_fwd, const float* bias,
+                                float* y, float* y_relu, void* stream);
+int cnn_conv2d_backward_data_prepared(const cnn_conv2d_desc* d, const float* dy, const void* prepared_dgrad, float* dx,
+                                      void* stream);
+/* cnn_conv2d_backward with the data gradient from prepared filters; workspace: cnn_conv2d_workspace_bytes(d) */
+int cnn_conv2d_backward_prepared(const cnn_conv2d_desc* d, const float* x, const float* dy, const void* prepared_dgrad,
+                                 float* gw, float* gb, float* dx, float divisor, void* workspace, size_t workspace_bytes,
+                                 void* stream, int defer_join);
+
 /* ---- BatchNorm2D : batchnorm2d.cpp:24-95 (forward), :98-158 (backward) ------------------------------- */
 /* Per-channel statistics over (B,H,W) of an NCHW tensor; gamma/beta/moving_mean/moving_var/saved_* are [C].
  * training != 0 (the reference's !no_grad branch, :46-80): two-pass batch mean and BIASED variance are written to

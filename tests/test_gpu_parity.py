@@ -422,3 +422,36 @@ def test_whole_net_fused_equals_unfused(T):
         assert T.equal(a.conv_out[l], b.conv_out[l]) and T.equal(a.relu_out[l], b.relu_out[l])
         assert T.equal(a.d_conv[l], b.d_conv[l])
     assert T.equal(a.d_pool, b.d_pool)
+
+
+def test_prepared_filters_match_plain_calls(T):
+    """cnn_conv2d_prepare_filters + *_prepared == the plain calls, bit for bit, for every kernel family of the net
+    (packed first layer, packed 16-channel dgrad, implicit GEMM with and without whole-image staging)"""
+    from cnn_amd import capi
+
+    cases = [(3, 3, 224, 224, 16, 3, 2, 0), (3, 16, 55, 55, 32, 3, 2, 0), (3, 32, 27, 27, 64, 3, 2, 0), (3, 64, 13, 13, 128, 3, 2, 0),
+             (2, 8, 12, 12, 8, 3, 1, 0), (2, 6, 10, 10, 40, 3, 1, 1)]
+    convs = [capi.Conv2d(*c) for c in cases]
+    data = [_conv_inputs(c, 500 + 7 * i) for i, c in enumerate(cases)]
+    xs, ws, bs = [dev(T, d[0]) for d in data], [dev(T, d[1]) for d in data], [dev(T, d[2]) for d in data]
+    dys = [dev(T, d[3]) for d in data]
+    bufs = [c.prepared_buffers() for c in convs]
+    capi.prepare_filters(convs, ws, bs, [b[0] for b in bufs], [b[1] for b in bufs])
+    for c, x, w, b, dy, (pf, pd) in zip(convs, xs, ws, bs, dys, bufs):
+        y0 = c.forward(x, w, b)
+        r0 = capi.relu_forward(y0)
+        y1, r1 = T.full_like(y0, 7.0), T.full_like(y0, 7.0)
+        c.forward_prepared(x, pf, b, y1, r1)
+        assert T.equal(y0, y1) and T.equal(r0, r1)
+        y2 = T.full_like(y0, 7.0)
+        c.forward_prepared(x, pf, b, y2, None)
+        assert T.equal(y0, y2)
+        dx0 = c.backward_data(dy, w)
+        dx1 = T.full_like(dx0, 7.0)
+        c.backward_data_prepared(dy, pd, dx1)
+        assert T.equal(dx0, dx1)
+        gw0, gb0, dx2 = c.backward(x, dy, w, 3.0)
+        gw1, gb1, dx3 = T.empty_like(gw0), T.empty_like(gb0), T.full_like(dx0, 7.0)
+        c.backward_prepared(x, dy, pd, 3.0, gw1, gb1, dx3)
+        T.cuda.synchronize()
+        assert T.equal(gw0, gw1) and T.equal(gb0, gb1) and T.equal(dx2, dx3) and T.equal(dx0, dx3)
