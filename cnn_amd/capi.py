@@ -62,6 +62,10 @@ SIGNATURES = {
     "cnn_batchnorm2d_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "cnn_batchnorm2d_forward": (C.c_int, [_P] * 8 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, _P, C.c_size_t, _P]),
     "cnn_batchnorm2d_backward": (C.c_int, [_P] * 7 + [C.c_int] * 4 + [C.c_float, _P, C.c_size_t, _P]),
+    "cnn_batchnorm2d_partial_sums": (C.c_int, [_P, _P, C.c_float, _P] + [C.c_int] * 4 + [_P, C.c_size_t, _P]),
+    "cnn_batchnorm2d_forward_from_sums": (C.c_int, [_P] * 10 + [C.c_float] + [C.c_int] * 4 + [C.c_float, C.c_float, _P]),
+    "cnn_batchnorm2d_backward_sums": (C.c_int, [_P] * 6 + [C.c_int] * 4 + [C.c_float, _P, C.c_size_t, _P]),
+    "cnn_batchnorm2d_backward_from_sums": (C.c_int, [_P] * 6 + [C.c_float, _P, _P] + [C.c_int] * 4 + [C.c_float, _P]),
     "cnn_sgd_update": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P]),
     "cnn_softmax_xent": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "cnn_device_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
@@ -376,6 +380,42 @@ class BatchNorm2d:
                                              self.eps, self.momentum, 1 if training else 0, _ptr(self.ws), self.ws_bytes,
                                              _stream()), "cnn_batchnorm2d_forward")
         return y
+
+    # ---- sync-BN: the batch is sharded over `world` data-parallel ranks; `allreduce(t)` sums a small tensor in place ----
+    def forward_sync(self, x, gamma, beta, moving_mean, moving_var, y, allreduce, global_count):
+        """training forward over the GLOBAL batch (batchnorm2d.cpp:46-80): two tiny all-reduces of [C] sums"""
+        import torch
+
+        _need_gpu(x, y, gamma, beta, moving_mean, moving_var)
+        L = load()
+        s1 = torch.empty(self.C, dtype=torch.float32, device=x.device)
+        s2 = torch.empty_like(s1)
+        dims = (self.B, self.C, self.H, self.W)
+        check(L.cnn_batchnorm2d_partial_sums(_ptr(x), None, 0.0, _ptr(s1), *dims, _ptr(self.ws), self.ws_bytes, _stream()), "bn sums 1")
+        allreduce(s1)
+        check(L.cnn_batchnorm2d_partial_sums(_ptr(x), _ptr(s1), float(global_count), _ptr(s2), *dims, _ptr(self.ws), self.ws_bytes,
+                                             _stream()), "bn sums 2")
+        allreduce(s2)
+        check(L.cnn_batchnorm2d_forward_from_sums(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(moving_mean), _ptr(moving_var),
+                                                  _ptr(self.saved_mean), _ptr(self.saved_var), _ptr(s1), _ptr(s2), float(global_count),
+                                                  *dims, self.eps, self.momentum, _stream()), "cnn_batchnorm2d_forward_from_sums")
+        return y
+
+    def backward_sync(self, x, dy, gamma, ggamma, gbeta, allreduce, global_count):
+        """dy -> dx in place; ggamma / gbeta come out as the full-batch sums on every rank (one [C][4] all-reduce)"""
+        import torch
+
+        _need_gpu(x, dy, gamma, ggamma, gbeta)
+        L = load()
+        s4 = torch.empty(self.C * 4, dtype=torch.float32, device=x.device)
+        dims = (self.B, self.C, self.H, self.W)
+        check(L.cnn_batchnorm2d_backward_sums(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(self.saved_mean), _ptr(self.saved_var), _ptr(s4),
+                                              *dims, self.eps, _ptr(self.ws), self.ws_bytes, _stream()), "cnn_batchnorm2d_backward_sums")
+        allreduce(s4)
+        check(L.cnn_batchnorm2d_backward_from_sums(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(self.saved_mean), _ptr(self.saved_var), _ptr(s4),
+                                                   float(global_count), _ptr(ggamma), _ptr(gbeta), *dims, self.eps, _stream()),
+              "cnn_batchnorm2d_backward_from_sums")
+        return dy
 
     def backward(self, x, dy, gamma, ggamma, gbeta):
         """dy -> dx in place (batchnorm2d.cpp:149-155)"""

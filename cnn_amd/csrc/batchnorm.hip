@@ -95,10 +95,11 @@ __device__ inline void block_store_partials(float (&acc)[NS], float* __restrict_
 
 // MODE 0: sum x            (batchnorm2d.cpp:48-55)
 // MODE 1: sum (x - u)^2    (batchnorm2d.cpp:57-63); u = (sum of part_in) / L, block g == 0 also publishes saved_mean
+// MODE 2: like 1, but around mean = gsum[c] / count with gsum the ALL-REDUCED channel sums of a sharded batch (sync-BN)
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void bn_stats(const float* __restrict__ x, const float* __restrict__ part_in,
                                                    float* __restrict__ part_out, float* __restrict__ saved_mean,
-                                                   Geo q) {
+                                                   Geo q, float count) {
     const int c = blockIdx.y, g = blockIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(kBlock) void bn_stats(const float* __restrict__ x, 
         u = sum_partials(part_in + (size_t)c * q.G, q.G, 1, lane) / (float)((long long)q.B * q.HW);
         if (g == 0 && threadIdx.x == 0) saved_mean[c] = u;
     }
+    if (MODE == 2) u = part_in[c] / count;
     float acc[1] = {0.f};
     for (long long un = (long long)g * kWaves + wave; un < q.units; un += (long long)q.G * kWaves) {
         long long g0, g1;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void bn_stats(const float* __restrict__ x, 
             },
             [&](long long e) {
                 const float v = x[e];
-                acc[0] += MODE == 0 ? v : (v - u) * (v - u);
+                acc[0] += MODE == 0 ? v : (v - u) * (v - u);  // MODE 1 / 2
             });
     }
     block_store_partials<1>(acc, part_out, q.G);
@@ -142,6 +144,9 @@ struct BnApply {
     const float* part;  // training: partial sums of (x-u)^2
     float eps, momentum;
     int training;
+    const float* gsum_x;   // sync-BN: all-reduced channel sums of x and of (x-mean)^2, with the global element count
+    const float* gsum_sq;
+    float count;
 };
 
 // y = gamma * ((x - u) * var_inv) + beta  (batchnorm2d.cpp:69-77 / 84-92), moving statistics (:79-80)
@@ -152,8 +157,14 @@ __global__ __launch_bounds__(kBlock) void bn_apply(BnApply a, Geo q) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     float u, var;
     if (a.training) {
-        u = a.saved_mean[c];
-        var = sum_partials(a.part + (size_t)c * q.G, q.G, 1, lane) / (float)((long long)q.B * q.HW);
+        if (a.gsum_x != nullptr) {
+            u = a.gsum_x[c] / a.count;
+            var = a.gsum_sq[c] / a.count;
+            if (g == 0 && threadIdx.x == 0) a.saved_mean[c] = u;
+        } else {
+            u = a.saved_mean[c];
+            var = sum_partials(a.part + (size_t)c * q.G, q.G, 1, lane) / (float)((long long)q.B * q.HW);
+        }
         if (g == 0 && threadIdx.x == 0) {
             a.saved_var[c] = var;
             a.moving_mean[c] = (1.f - a.momentum) * a.moving_mean[c] + a.momentum * u;
@@ -229,20 +240,22 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply(const float* __restrict__
                                                        const float* __restrict__ saved_mean,
                                                        const float* __restrict__ saved_var,
                                                        const float* __restrict__ part, float* __restrict__ ggamma,
-                                                       float* __restrict__ gbeta, float eps, Geo q) {
+                                                       float* __restrict__ gbeta, float eps, Geo q,
+                                                       const float* __restrict__ gsums, float count) {
 #pragma clang fp contract(off)
     const int c = blockIdx.y, g = blockIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const float L = (float)((long long)q.B * q.HW);
+    // gsums (sync-BN): the four ALL-REDUCED channel sums [C][4] and the global element count replace the local ones
+    const float L = gsums ? count : (float)((long long)q.B * q.HW);
     const float u = saved_mean[c];
     const float var_inv = 1.f / sqrtf(saved_var[c] + eps);
     const float gm = gamma[c];
     const float* pc = part + (size_t)c * q.G * 4;
-    const float s_gg = sum_partials(pc + 0, q.G, 4, lane);
-    const float s_gb = sum_partials(pc + 1, q.G, 4, lane);
-    const float var_g = sum_partials(pc + 2, q.G, 4, lane);
-    const float s_xc = sum_partials(pc + 3, q.G, 4, lane);
+    const float s_gg = gsums ? gsums[c * 4 + 0] : sum_partials(pc + 0, q.G, 4, lane);
+    const float s_gb = gsums ? gsums[c * 4 + 1] : sum_partials(pc + 1, q.G, 4, lane);
+    const float var_g = gsums ? gsums[c * 4 + 2] : sum_partials(pc + 2, q.G, 4, lane);
+    const float s_xc = gsums ? gsums[c * 4 + 3] : sum_partials(pc + 3, q.G, 4, lane);
     const float inv = var_g / L;
     // u_g = sum [ (dy*gamma)*(-var_inv) + inv*(-2)*(x-u) ]  (batchnorm2d.cpp:139-146), from the channel sums
     const float u_g = (s_gb * gm) * (-var_inv) + inv * -2.f * s_xc;
@@ -267,6 +280,16 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply(const float* __restrict__
                 *(float4*)(dy + e) = d;
             },
             [&](long long e) { dy[e] = (dy[e] * gm) * var_inv + inv2 * (x[e] - u) + u_term; });
+    }
+}
+
+// out[c*NS + k] = sum over the G partial slots of channel c (same fixed tree as the in-kernel re-reduction)
+__global__ __launch_bounds__(kWave) void bn_reduce_partials(const float* __restrict__ part, float* __restrict__ out, int G,
+                                                            int NS) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    for (int k = 0; k < NS; ++k) {
+        const float v = sum_partials(part + (size_t)c * G * NS + k, G, NS, lane);
+        if (lane == 0) out[c * NS + k] = v;
     }
 }
 
@@ -313,15 +336,16 @@ int cnn_batchnorm2d_forward(const float* x, float* y, const float* gamma, const 
     CNN_REQUIRE(aligned16(x) && aligned16(y), "cnn_batchnorm2d_forward: x / y must be 16-byte aligned");
     hipStream_t s = as_stream(stream);
     const dim3 grid(q.G, C);
-    BnApply a{x, y, gamma, beta, moving_mean, moving_var, saved_mean, saved_var, nullptr, eps, momentum, training ? 1 : 0};
+    BnApply a{x, y, gamma, beta, moving_mean, moving_var, saved_mean, saved_var, nullptr, eps, momentum, training ? 1 : 0,
+              nullptr, nullptr, 0.f};
     if (training) {
         CNN_REQUIRE(saved_mean && saved_var, "cnn_batchnorm2d_forward: training needs saved_mean / saved_var");
         CNN_REQUIRE(workspace && workspace_bytes >= cnn_batchnorm2d_workspace_bytes(B, C, H, W),
                     "cnn_batchnorm2d_forward: workspace too small (%zu bytes)", workspace_bytes);
         float* p0 = (float*)workspace;
         float* p1 = p0 + (size_t)C * q.G * 4;
-        CNN_KLAUNCH(s, "bn_stats<0>", (bn_stats<0><<<grid, kBlock, 0, s>>>(x, nullptr, p0, nullptr, q)), BN_TAG);
-        CNN_KLAUNCH(s, "bn_stats<1>", (bn_stats<1><<<grid, kBlock, 0, s>>>(x, p0, p1, saved_mean, q)), BN_TAG);
+        CNN_KLAUNCH(s, "bn_stats<0>", (bn_stats<0><<<grid, kBlock, 0, s>>>(x, nullptr, p0, nullptr, q, 0.f)), BN_TAG);
+        CNN_KLAUNCH(s, "bn_stats<1>", (bn_stats<1><<<grid, kBlock, 0, s>>>(x, p0, p1, saved_mean, q, 0.f)), BN_TAG);
         a.part = p1;
     }
     CNN_KLAUNCH(s, "bn_apply", (bn_apply<<<grid, kBlock, 0, s>>>(a, q)), BN_TAG);
@@ -344,7 +368,79 @@ int cnn_batchnorm2d_backward(const float* x, float* dy, const float* gamma, cons
     CNN_KLAUNCH(s, "bn_bwd_stats",
                 (bn_bwd_stats<<<grid, kBlock, 0, s>>>(x, dy, gamma, saved_mean, saved_var, part, eps, q)), BN_TAG);
     CNN_KLAUNCH(s, "bn_bwd_apply",
-                (bn_bwd_apply<<<grid, kBlock, 0, s>>>(x, dy, gamma, saved_mean, saved_var, part, ggamma, gbeta, eps, q)),
+                (bn_bwd_apply<<<grid, kBlock, 0, s>>>(x, dy, gamma, saved_mean, saved_var, part, ggamma, gbeta, eps, q, nullptr, 0.f)),
+                BN_TAG);
+    return CNN_AMD_OK;
+}
+
+/* ---- the same arithmetic with the batch sharded over data-parallel ranks (sync-BN): see include/cnn_amd.h ---- */
+int cnn_batchnorm2d_partial_sums(const float* x, const float* sum_x, float count, float* out, int B, int C, int H, int W,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    Geo q;
+    int rc = make_geo(B, C, H, W, &q);
+    if (rc != CNN_AMD_OK) return rc;
+    CNN_REQUIRE(x && out && aligned16(x), "cnn_batchnorm2d_partial_sums: null / unaligned pointer");
+    CNN_REQUIRE(sum_x == nullptr || count > 0.f, "cnn_batchnorm2d_partial_sums: count must be positive");
+    CNN_REQUIRE(workspace && workspace_bytes >= cnn_batchnorm2d_workspace_bytes(B, C, H, W),
+                "cnn_batchnorm2d_partial_sums: workspace too small (%zu bytes)", workspace_bytes);
+    hipStream_t s = as_stream(stream);
+    const dim3 grid(q.G, C);
+    float* part = (float*)workspace;
+    if (sum_x == nullptr)
+        CNN_KLAUNCH(s, "bn_stats<0>", (bn_stats<0><<<grid, kBlock, 0, s>>>(x, nullptr, part, nullptr, q, 0.f)), BN_TAG);
+    else
+        CNN_KLAUNCH(s, "bn_stats<2>", (bn_stats<2><<<grid, kBlock, 0, s>>>(x, sum_x, part, nullptr, q, count)), BN_TAG);
+    CNN_KLAUNCH(s, "bn_reduce_partials", (bn_reduce_partials<<<C, kWave, 0, s>>>(part, out, q.G, 1)), BN_TAG);
+    return CNN_AMD_OK;
+}
+
+int cnn_batchnorm2d_forward_from_sums(const float* x, float* y, const float* gamma, const float* beta, float* moving_mean,
+                                      float* moving_var, float* saved_mean, float* saved_var, const float* sum_x,
+                                      const float* sum_sq, float count, int B, int C, int H, int W, float eps, float momentum,
+                                      void* stream) {
+    Geo q;
+    int rc = make_geo(B, C, H, W, &q);
+    if (rc != CNN_AMD_OK) return rc;
+    CNN_REQUIRE(x && y && gamma && beta && moving_mean && moving_var && saved_mean && saved_var && sum_x && sum_sq,
+                "cnn_batchnorm2d_forward_from_sums: null pointer");
+    CNN_REQUIRE(aligned16(x) && aligned16(y) && count > 0.f, "cnn_batchnorm2d_forward_from_sums: unaligned x / y or count <= 0");
+    hipStream_t s = as_stream(stream);
+    BnApply a{x, y, gamma, beta, moving_mean, moving_var, saved_mean, saved_var, nullptr, eps, momentum, 1, sum_x, sum_sq, count};
+    CNN_KLAUNCH(s, "bn_apply/sync", (bn_apply<<<dim3(q.G, C), kBlock, 0, s>>>(a, q)), BN_TAG);
+    return CNN_AMD_OK;
+}
+
+int cnn_batchnorm2d_backward_sums(const float* x, const float* dy, const float* gamma, const float* saved_mean,
+                                  const float* saved_var, float* sums4, int B, int C, int H, int W, float eps, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    Geo q;
+    int rc = make_geo(B, C, H, W, &q);
+    if (rc != CNN_AMD_OK) return rc;
+    CNN_REQUIRE(x && dy && gamma && saved_mean && saved_var && sums4, "cnn_batchnorm2d_backward_sums: null pointer");
+    CNN_REQUIRE(aligned16(x) && aligned16(dy), "cnn_batchnorm2d_backward_sums: x / dy must be 16-byte aligned");
+    CNN_REQUIRE(workspace && workspace_bytes >= cnn_batchnorm2d_workspace_bytes(B, C, H, W),
+                "cnn_batchnorm2d_backward_sums: workspace too small (%zu bytes)", workspace_bytes);
+    hipStream_t s = as_stream(stream);
+    float* part = (float*)workspace;
+    CNN_KLAUNCH(s, "bn_bwd_stats",
+                (bn_bwd_stats<<<dim3(q.G, C), kBlock, 0, s>>>(x, dy, gamma, saved_mean, saved_var, part, eps, q)), BN_TAG);
+    CNN_KLAUNCH(s, "bn_reduce_partials", (bn_reduce_partials<<<C, kWave, 0, s>>>(part, sums4, q.G, 4)), BN_TAG);
+    return CNN_AMD_OK;
+}
+
+int cnn_batchnorm2d_backward_from_sums(const float* x, float* dy, const float* gamma, const float* saved_mean,
+                                       const float* saved_var, const float* sums4, float count, float* ggamma, float* gbeta,
+                                       int B, int C, int H, int W, float eps, void* stream) {
+    Geo q;
+    int rc = make_geo(B, C, H, W, &q);
+    if (rc != CNN_AMD_OK) return rc;
+    CNN_REQUIRE(x && dy && gamma && saved_mean && saved_var && sums4 && ggamma && gbeta,
+                "cnn_batchnorm2d_backward_from_sums: null pointer");
+    CNN_REQUIRE(aligned16(x) && aligned16(dy) && count > 0.f, "cnn_batchnorm2d_backward_from_sums: unaligned x / dy or count <= 0");
+    hipStream_t s = as_stream(stream);
+    CNN_KLAUNCH(s, "bn_bwd_apply/sync",
+                (bn_bwd_apply<<<dim3(q.G, C), kBlock, 0, s>>>(x, dy, gamma, saved_mean, saved_var, sums4, ggamma, gbeta, eps, q,
+                                                             sums4, count)),
                 BN_TAG);
     return CNN_AMD_OK;
 }

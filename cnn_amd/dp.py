@@ -37,3 +37,46 @@ def allreduce_grads(grads, dist, world):
     if world > 1:
         dist.all_reduce(grads)
     return 1.0 / world
+
+
+def sum_allreduce(dist, world):
+    """the `allreduce(t)` callable cnn_amd.capi.BatchNorm2d.forward_sync / backward_sync expect: in-place SUM of a small
+    per-channel tensor over all ranks (no-op for one rank)"""
+
+    def allreduce(t):
+        if world > 1:
+            dist.all_reduce(t)
+        return t
+
+    return allreduce
+
+
+def syncbn_reference_protocol(x, dy, gamma, beta, allreduce, global_count, eps=1e-5):
+    """numpy statement of the sync-BN exchange (include/cnn_amd.h, cnn_batchnorm2d_partial_sums ...): what each rank
+    computes between the three collectives.  Used by the gloo test to pin the protocol against the full-batch oracle;
+    the HIP entry points follow the same steps (tests/test_gpu_batchnorm.py)."""
+    import numpy as np
+    import torch
+
+    ax = (0, 2, 3)
+    s1 = torch.from_numpy(x.sum(axis=ax, dtype=np.float32))
+    allreduce(s1)
+    mean = (s1.numpy() / np.float32(global_count)).astype(np.float32)
+    xc = x - mean[None, :, None, None]
+    s2 = torch.from_numpy((xc * xc).sum(axis=ax, dtype=np.float32))
+    allreduce(s2)
+    var = (s2.numpy() / np.float32(global_count)).astype(np.float32)
+    inv = (1.0 / np.sqrt(var + np.float32(eps))).astype(np.float32)
+    norm = xc * inv[None, :, None, None]
+    y = gamma[None, :, None, None] * norm + beta[None, :, None, None]
+    g = gamma[None, :, None, None]
+    s4 = np.stack([(dy * norm).sum(axis=ax), dy.sum(axis=ax), ((dy * g) * xc * np.float32(-0.5) * (inv ** 3)[None, :, None, None]).sum(axis=ax),
+                   xc.sum(axis=ax)], axis=1).astype(np.float32)
+    t4 = torch.from_numpy(s4)
+    allreduce(t4)
+    s4 = t4.numpy()
+    L = np.float32(global_count)
+    inv_v = s4[:, 2] / L
+    u_g = (s4[:, 1] * gamma) * (-inv) + inv_v * np.float32(-2) * s4[:, 3]
+    dx = (dy * g) * inv[None, :, None, None] + (inv_v * 2)[None, :, None, None] * xc + (u_g / L)[None, :, None, None]
+    return y.astype(np.float32), dx.astype(np.float32), s4[:, 0].copy(), s4[:, 1].copy(), mean, var

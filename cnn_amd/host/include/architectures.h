@@ -80,7 +80,7 @@ private:
     bool prepared_active = false;
     const int in_channels, out_channels, kernel_size, stride;
     const int params_for_one_kernel;
-    const int padding = 0;
+    const int padding;  // extension: the reference has no padding (conv2d.cpp:41-42 keeps it at 0)
     std::default_random_engine seed;
     // device state: weights [Co][Ci][k][k] then bias [Co], same order as the checkpoint (conv2d.cpp:220-226)
     data_type* params = nullptr;
@@ -98,8 +98,9 @@ private:
     data_type* b_dev() const { return params + (size_t)out_channels * params_for_one_kernel; }
 
 public:
+    // (the trailing _padding argument is an extension for VGG / ResNet-shaped stacks; default = the reference's 0)
     Conv2D(std::string _name, const int _in_channels = 3, const int _out_channels = 16, const int _kernel_size = 3,
-           const int _stride = 2);
+           const int _stride = 2, const int _padding = 0);
     ~Conv2D() override;
     std::vector<tensor> forward(const std::vector<tensor>& input) override;
     std::vector<tensor> backward(std::vector<tensor>& delta) override;

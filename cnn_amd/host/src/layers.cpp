@@ -91,10 +91,10 @@ std::vector<tensor> Layer::get_output() const {
 // ---------------------------------------------------------------------------------------------------------------
 // Conv2D
 Conv2D::Conv2D(std::string _name, const int _in_channels, const int _out_channels, const int _kernel_size,
-               const int _stride)
+               const int _stride, const int _padding)
     : Layer(_name), in_channels(_in_channels), out_channels(_out_channels), kernel_size(_kernel_size), stride(_stride),
-      params_for_one_kernel(_in_channels * _kernel_size * _kernel_size) {
-    assert(_kernel_size >= 1 && _in_channels > 0 && _out_channels > 0 && _stride > 0);
+      params_for_one_kernel(_in_channels * _kernel_size * _kernel_size), padding(_padding) {
+    assert(_kernel_size >= 1 && _in_channels > 0 && _out_channels > 0 && _stride > 0 && _padding >= 0);
     const size_t n = param_count();
     params = (data_type*)dev_alloc(sizeof(data_type) * n);
     grads = (data_type*)dev_alloc(sizeof(data_type) * n);

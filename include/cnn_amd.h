@@ -172,6 +172,30 @@ int cnn_batchnorm2d_backward(const float* x, float* dy, const float* gamma, cons
                              const float* saved_var, float* ggamma, float* gbeta, int B, int C, int H, int W, float eps,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* BatchNorm2D with the batch SHARDED over data-parallel processes ("sync-BN"): the reference normalises over the whole
+ * batch (batchnorm2d.cpp:46-63), so each rank computes per-channel partial sums, the caller all-reduces (sum) the small
+ * vectors between the calls, and the apply kernels use the GLOBAL element count `count` = B_global*H*W.  Training step:
+ *   cnn_batchnorm2d_partial_sums(x, NULL, 0, s1)              all-reduce s1[C]     (sum of x)
+ *   cnn_batchnorm2d_partial_sums(x, s1, count, s2)            all-reduce s2[C]     (sum of (x - s1/count)^2: two-pass)
+ *   cnn_batchnorm2d_forward_from_sums(..., s1, s2, count)     mean / biased variance -> saved_*, moving_*, y
+ *   cnn_batchnorm2d_backward_sums(x, dy, ..., sums4)          all-reduce sums4[C][4]
+ *   cnn_batchnorm2d_backward_from_sums(..., sums4, count)     dy -> dx in place; ggamma / gbeta = the FULL-batch sums
+ *                                                             (identical on every rank: exclude them from the gradient
+ *                                                             all-reduce or divide by the world size afterwards)
+ * With one process this is the arithmetic of cnn_batchnorm2d_forward / _backward.  Evaluation needs no exchange. */
+int cnn_batchnorm2d_partial_sums(const float* x, const float* sum_x, float count, float* out, int B, int C, int H, int W,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+int cnn_batchnorm2d_forward_from_sums(const float* x, float* y, const float* gamma, const float* beta, float* moving_mean,
+                                      float* moving_var, float* saved_mean, float* saved_var, const float* sum_x,
+                                      const float* sum_sq, float count, int B, int C, int H, int W, float eps,
+                                      float momentum, void* stream);
+int cnn_batchnorm2d_backward_sums(const float* x, const float* dy, const float* gamma, const float* saved_mean,
+                                  const float* saved_var, float* sums4, int B, int C, int H, int W, float eps,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+int cnn_batchnorm2d_backward_from_sums(const float* x, float* dy, const float* gamma, const float* saved_mean,
+                                       const float* saved_var, const float* sums4, float count, float* ggamma,
+                                       float* gbeta, int B, int C, int H, int W, float eps, void* stream);
+
 /* ---- SGD step : conv2d.cpp:205-217, linear.cpp:95-102 ---------------------------------------------- */
 /* p -= lr * (g * grad_scale) over one flat parameter arena.  grad_scale = 1 reproduces the reference exactly
  * (two roundings, no FMA); grad_scale = 1/G folds the data-parallel mean after an all-reduce(sum) over G ranks

@@ -45,6 +45,21 @@ def main():
         err = np.abs(new_params - full.params).max() / np.abs(full.params).max()
         assert err < 1e-5, err
         print(f"DP_OK world={world} err={err:.2e}")
+    # ---- sync-BN exchange (BatchNorm couples samples in forward AND backward) over the same collective ----
+    Bn, C = 8, 5
+    xb = (uniform01(60, (Bn, C, 6, 7)) * 3 - 1).astype(np.float32)
+    dyb = (uniform01(61, (Bn, C, 6, 7)) * 2 - 1).astype(np.float32)
+    gamma = (uniform01(62, (C,)) + 0.5).astype(np.float32)
+    beta = uniform01(63, (C,)).astype(np.float32)
+    lo, hi = dp.shard_bounds(Bn, rank, world)
+    y, dx, gg, gb, mean, var = dp.syncbn_reference_protocol(xb[lo:hi], dyb[lo:hi], gamma, beta, dp.sum_allreduce(dist, world),
+                                                            Bn * 6 * 7)
+    y_o, _, sm_o, sv_o, _, _ = O.batchnorm_forward(xb, gamma, beta, np.zeros(C, np.float32), np.zeros(C, np.float32))
+    dx_o, gg_o, gb_o = O.batchnorm_backward(xb, dyb, gamma, sm_o, sv_o)
+    for got, ref in ((y, y_o[lo:hi]), (dx, dx_o[lo:hi]), (gg, gg_o), (gb, gb_o), (mean, sm_o), (var, sv_o)):
+        assert np.abs(got - ref).max() <= 1e-4 * max(1e-6, np.abs(ref).max()), "sync-BN shard differs from the full-batch oracle"
+    if rank == 0:
+        print(f"SYNCBN_OK world={world}")
     dist.barrier()
     dist.destroy_process_group()
 

@@ -25,6 +25,7 @@ def test_sharded_step_equals_full_batch_step(world):
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert f"DP_OK world={world}" in out.stdout
+    assert f"SYNCBN_OK world={world}" in out.stdout
 
 
 def test_shard_bounds():

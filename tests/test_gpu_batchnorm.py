@@ -147,3 +147,90 @@ def test_batchnorm_rejects_bad_arguments(T):
     rc = L.cnn_batchnorm2d_forward(capi._ptr(x), capi._ptr(x), capi._ptr(v), capi._ptr(v), capi._ptr(v), capi._ptr(v),
                                    capi._ptr(v), capi._ptr(v), 2, 3, 4, 4, 1e-5, 0.1, 1, None, 0, None)
     assert rc != 0 and b"workspace" in L.cnn_amd_last_error()
+
+
+@pytest.mark.parametrize("shape,splits", [((6, 16, 27, 27), (2, 4)), ((5, 3, 7, 9), (1, 3, 1)), ((4, 32, 13, 13), (4,))],
+                         ids=["two_ranks", "three_uneven_ranks", "one_rank"])
+def test_sync_batchnorm_sharded_batch_equals_full_batch_oracle(T, shape, splits):
+    """the split-phase (sync-BN) entry points with the batch sharded over simulated ranks -- per-rank partial sums, summed
+    like an all-reduce -- reproduce the reference's full-batch BatchNorm2D forward and backward (batchnorm2d.cpp:24-158)"""
+    from cnn_amd import capi
+
+    B, C, H, W = shape
+    assert sum(splits) == B
+    x = (uniform_pm1(90, shape) * 2 + 0.25).astype(np.float32)
+    gamma = (uniform_pm1(91, (C,)) + 1.5).astype(np.float32)
+    beta = uniform_pm1(92, (C,)).astype(np.float32)
+    mm0 = uniform_pm1(93, (C,)).astype(np.float32)
+    mv0 = (uniform_pm1(94, (C,)) + 1.5).astype(np.float32)
+    dy = uniform_pm1(95, shape).astype(np.float32)
+    y_o, _, sm_o, sv_o, mm_o, mv_o = O.batchnorm_forward(x, gamma, beta, mm0, mv0)
+    dx_o, gg_o, gb_o = O.batchnorm_backward(x, dy, gamma, sm_o, sv_o)
+
+    # "ranks": shards of the batch, each with its own layer object / buffers; the all-reduce is emulated by summing the
+    # rank tensors of one collective call and writing the total back into each of them
+    bounds = np.cumsum((0,) + tuple(splits))
+    ranks = []
+    for r, n in enumerate(splits):
+        sl = slice(bounds[r], bounds[r + 1])
+        ranks.append(dict(bn=capi.BatchNorm2d(n, C, H, W), x=dev(T, x[sl]), dy=dev(T, dy[sl]), y=T.empty((n, C, H, W), device="cuda"),
+                          g=dev(T, gamma), b=dev(T, beta), mm=dev(T, mm0), mv=dev(T, mv0), gg=T.empty(C, device="cuda"),
+                          gb=T.empty(C, device="cuda")))
+    count = float(B * H * W)
+
+    L = capi.load()
+    s1 = [T.empty(C, device="cuda") for _ in ranks]
+    s2 = [T.empty(C, device="cuda") for _ in ranks]
+    s4 = [T.empty(4 * C, device="cuda") for _ in ranks]
+
+    def allreduce(ts):
+        tot = T.stack(ts).sum(dim=0)
+        for t in ts:
+            t.copy_(tot)
+
+    def dims(rk):
+        return (rk["bn"].B, C, H, W)
+
+    for rk, t in zip(ranks, s1):
+        capi.check(L.cnn_batchnorm2d_partial_sums(capi._ptr(rk["x"]), None, 0.0, capi._ptr(t), *dims(rk), capi._ptr(rk["bn"].ws),
+                                                  rk["bn"].ws_bytes, None), "sums1")
+    allreduce(s1)
+    for rk, t1, t2 in zip(ranks, s1, s2):
+        capi.check(L.cnn_batchnorm2d_partial_sums(capi._ptr(rk["x"]), capi._ptr(t1), count, capi._ptr(t2), *dims(rk),
+                                                  capi._ptr(rk["bn"].ws), rk["bn"].ws_bytes, None), "sums2")
+    allreduce(s2)
+    for rk, t1, t2 in zip(ranks, s1, s2):
+        bn = rk["bn"]
+        capi.check(L.cnn_batchnorm2d_forward_from_sums(capi._ptr(rk["x"]), capi._ptr(rk["y"]), capi._ptr(rk["g"]), capi._ptr(rk["b"]),
+                                                       capi._ptr(rk["mm"]), capi._ptr(rk["mv"]), capi._ptr(bn.saved_mean),
+                                                       capi._ptr(bn.saved_var), capi._ptr(t1), capi._ptr(t2), count, *dims(rk), bn.eps,
+                                                       bn.momentum, None), "fwd")
+    y = np.concatenate([host(rk["y"]) for rk in ranks])
+    assert_close(y, y_o, what="y over the sharded batch")
+    for rk in ranks:  # every rank holds the GLOBAL statistics
+        assert_close(host(rk["bn"].saved_mean), sm_o, what="mean")
+        assert_close(host(rk["bn"].saved_var), sv_o, what="var")
+        assert_close(host(rk["mm"]), mm_o, what="moving mean")
+        assert_close(host(rk["mv"]), mv_o, what="moving var")
+    for rk, t in zip(ranks, s4):
+        bn = rk["bn"]
+        capi.check(L.cnn_batchnorm2d_backward_sums(capi._ptr(rk["x"]), capi._ptr(rk["dy"]), capi._ptr(rk["g"]), capi._ptr(bn.saved_mean),
+                                                   capi._ptr(bn.saved_var), capi._ptr(t), *dims(rk), bn.eps, capi._ptr(bn.ws), bn.ws_bytes,
+                                                   None), "bwd sums")
+    allreduce(s4)
+    for rk, t in zip(ranks, s4):
+        bn = rk["bn"]
+        capi.check(L.cnn_batchnorm2d_backward_from_sums(capi._ptr(rk["x"]), capi._ptr(rk["dy"]), capi._ptr(rk["g"]),
+                                                        capi._ptr(bn.saved_mean), capi._ptr(bn.saved_var), capi._ptr(t), count,
+                                                        capi._ptr(rk["gg"]), capi._ptr(rk["gb"]), *dims(rk), bn.eps, None), "bwd")
+    dx = np.concatenate([host(rk["dy"]) for rk in ranks])
+    assert_close(dx, dx_o, what="dx over the sharded batch")
+    for rk in ranks:  # full-batch sums on every rank (batchnorm2d.cpp:123-124: not divided by the batch)
+        assert_close(host(rk["gg"]), gg_o, what="gamma grad")
+        assert_close(host(rk["gb"]), gb_o, what="beta grad")
+    if len(splits) == 1:  # one rank: the same arithmetic as the fused single-device entry points
+        bn = capi.BatchNorm2d(B, C, H, W)
+        xd, gd, bd = dev(T, x), dev(T, gamma), dev(T, beta)
+        mm, mv, y1 = dev(T, mm0), dev(T, mv0), T.empty(shape, device="cuda")
+        bn.forward(xd, gd, bd, mm, mv, y1, training=True)
+        assert T.equal(y1, ranks[0]["y"]) and T.equal(mm, ranks[0]["mm"]) and T.equal(mv, ranks[0]["mv"])

@@ -24,6 +24,7 @@ def test_reference_headers_surface():
                    "virtual std::vector<tensor> backward(std::vector<tensor>& delta) = 0;",
                    "virtual void update_gradients(const data_type learning_rate = 1e-4)",
                    "Conv2D(std::string _name, const int _in_channels = 3, const int _out_channels = 16, const int _kernel_size = 3,",
+                   "const int _stride = 2, const int _padding = 0);",
                    "MaxPool2D(std::string _name, const int _kernel_size = 2, const int _step = 2)", "ReLU(std::string _name)",
                    "LinearLayer(std::string _name, const int _in_channels, const int _out_channels);", "class WithoutGrad",
                    "extern bool no_grad;", "extern data_type random_times;", "int get_params_num() const;"):
