@@ -304,7 +304,7 @@ __global__ void pack_dgrad_weights_s2(const float* __restrict__ w, float* __rest
     pack_dgrad_s2_body(w, wp, CI, CO, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
-template <int CI, int CB, int PX, int DBG = 0>  // PX grid pixels per lane: the broadcast weight reads are shared by both
+template <int CI, int CB, int PX>  // PX grid pixels per lane (1 in production; 2 shares the weight reads but gains nothing)
 __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_s2(const float* __restrict__ dy, const v2f* __restrict__ wp,
                                                            float* __restrict__ dx, int B, int CO, int H, int W, int Ho,
                                                            int Wo, int items_per_img, unsigned m_ipi, unsigned m_row) {
@@ -321,9 +321,8 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_s2(const float* __restri
     // (broadcast ds_reads): 9*CI floats per channel are too many to stream through SGPRs without a scalar-load round
     // trip per group
     extern __shared__ __attribute__((aligned(16))) float wlds[];
-    if (!(DBG & 16)) for (int i = threadIdx.x; i < CO * 9 * HP; i += kBlock) ((v2f*)wlds)[i] = wp[i];
+    for (int i = threadIdx.x; i < CO * 9 * HP; i += kBlock) ((v2f*)wlds)[i] = wp[i];
     __syncthreads();
-    if (DBG & 32) return;
     for (int it = blockIdx.x * kWaves + wave; it < items; it += gridDim.x * kWaves) {
         const int b = fast_div(it, m_ipi, items_per_img);
         const int soff = b * CO * plane * 4;
@@ -358,7 +357,6 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_s2(const float* __restri
                 const int so = soff + (cg + u) * plane * 4;
 #pragma unroll
                 for (int x = 0; x < PX; ++x) {
-                    if constexpr (DBG & 1) { dv[u][x][0] = dv[u][x][1] = dv[u][x][2] = dv[u][x][3] = (float)so; continue; }
                     dv[u][x][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)v00[x], so, 0));
                     dv[u][x][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)v01[x], so, 0));
                     dv[u][x][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)v10[x], so, 0));
@@ -381,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_s2(const float* __restri
                     const int u = st / (9 * NQ), g = (st / NQ) % 9, jb = (st % NQ) * QP;
                     if (st + 1 < CB * 9 * NQ) {
 #pragma unroll
-                        for (int j = 0; j < QP; ++j) wnxt[j] = (DBG & 2) ? v2f{1.f + st, 2.f + j} : q[(st + 1) * QP + j];
+                        for (int j = 0; j < QP; ++j) wnxt[j] = q[(st + 1) * QP + j];
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -389,8 +387,7 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_s2(const float* __restri
 #pragma unroll
                         for (int x = 0; x < PX; ++x) {
                             const float d = dv[u][x][gtap[g]];
-                            if constexpr (DBG & 4) { if (j == 0) A[x][gcls[g]][jb] += wcur[0] + v2f{d, d}; }
-                            else A[x][gcls[g]][jb + j] = __builtin_elementwise_fma(wcur[j], v2f{d, d}, A[x][gcls[g]][jb + j]);
+                            A[x][gcls[g]][jb + j] = __builtin_elementwise_fma(wcur[j], v2f{d, d}, A[x][gcls[g]][jb + j]);
                         }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -402,7 +399,6 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_s2(const float* __restri
 #pragma unroll
         for (int x = 0; x < PX; ++x) {
             if (!live[x]) continue;
-            if ((DBG & 8) && A[x][0][0].x != 123.25f) continue;
             float* dxb = dx + (size_t)b * CI * H * W;
 #pragma unroll
             for (int j = 0; j < HP; ++j)
@@ -561,9 +557,13 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __
         tap_ok[i] = r < 27;
         tap_off[i] = ((ci * H + kx) * W + ky) * 4;
     }
+    // each workgroup walks a CONTIGUOUS range of items: vertically neighbouring items share two of their three input
+    // rows, which then come from this CU's L1 / this XCD's L2 instead of HBM (a strided assignment fetched x 2.5x)
+    const long long per = (items + gridDim.x - 1) / gridDim.x;
+    const long long it_end = (blockIdx.x + 1) * per < items ? (blockIdx.x + 1) * per : items;
     float lx[kWgDepth][kWgX], ldy[kWgDepth][4];
     auto issue = [&](long long it, float(&ax)[kWgX], float(&ad)[4]) {
-        const bool inr = it < items;
+        const bool inr = it < it_end;
         const int iti = inr ? (int)it : 0;
         const int b = fast_div(iti, m_ipi, items_per_img);
         const int n = (iti - b * items_per_img) * 64 + lane;
@@ -588,8 +588,8 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __
 #pragma unroll
         for (int j = 0; j < NP; ++j) A[c][j] = v2f{0.f, 0.f};
     }
-    const long long stride = gridDim.x;
-    long long it = blockIdx.x;
+    const long long stride = 1;
+    long long it = blockIdx.x * per;
 #pragma unroll
     for (int dd = 0; dd < kWgDepth; ++dd) issue(it + dd * stride, lx[dd], ldy[dd]);
     int k = 0;
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __
         ++k;
         it += stride;
     };
-    while (it < items) {  // (up to kWgDepth-1 trailing consume() calls see all-zero items)
+    while (it < it_end) {  // (up to kWgDepth-1 trailing consume() calls see all-zero items)
 #pragma unroll
         for (int dd = 0; dd < kWgDepth; ++dd) consume(lx[dd], ldy[dd]);
     }
@@ -645,110 +645,6 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
         if (lane == 0) out[c * 28 + 27] = t;
-    }
-}
-
-// Variant without LDS and without barriers: wave w owns taps 7w .. 7w+6 for ALL 16 output channels (7 x 8 channel
-// pairs of running sums); it loads its 7 patch rows and the 16 dy rows itself (the dy rows are shared by the four waves
-// of a workgroup through L1).  The waves are independent, so each keeps kDepth items of loads in flight.
-template <int kDepth>
-__global__ __launch_bounds__(kBlock) void conv_wgrad_pk2_3_16_3_2(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                  float* __restrict__ slabs, int B, int H, int W, int Ho,
-                                                                  int Wo, int items_per_img, unsigned m_ipi, unsigned m_row) {
-    constexpr int CI = 3, CO = 16, NT = 7;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long items = (long long)B * items_per_img;
-    const int plane = Ho * Wo;
-    const __amdgpu_buffer_rsrc_t rx =
-        __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * CI * H * W * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rd =
-        __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * CO * plane * 4u), 0x00020000);
-    int tap_off[NT];
-    bool tap_ok[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int r = wave * NT + i;
-        const int ci = r / 9, kx = (r - ci * 9) / 3, ky = r - ci * 9 - kx * 3;
-        tap_ok[i] = r < 27;
-        tap_off[i] = ((ci * H + kx) * W + ky) * 4;
-    }
-    float lx[kDepth][NT], ld[kDepth][CO];
-    auto issue = [&](long long it, float(&ax)[NT], float(&ad)[CO]) {  // branch-free, see conv_wgrad_pk
-        const bool inr = it < items;
-        const int iti = inr ? (int)it : 0;
-        const int b = fast_div(iti, m_ipi, items_per_img);
-        const int n = (iti - b * items_per_img) * 64 + lane;
-        const bool live = inr && n < plane;
-        const int p = fast_div(live ? n : 0, m_row, Wo), q = (live ? n : 0) - p * Wo;
-        const unsigned vx = live ? (unsigned)(2 * p * W + 2 * q) * 4u : kBufOOB;
-        const unsigned vd = live ? (unsigned)n * 4u : kBufOOB;
-        const int sx = b * CI * H * W * 4, sd = b * CO * plane * 4;
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-            ax[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(tap_ok[i] ? vx : kBufOOB), sx + tap_off[i], 0));
-#pragma unroll
-        for (int c = 0; c < CO; ++c)
-            ad[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, (int)vd, sd + c * plane * 4, 0));
-    };
-    v2f A[NT][CO / 2], bs[CO / 2];
-#pragma unroll
-    for (int j = 0; j < CO / 2; ++j) {
-        bs[j] = v2f{0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < NT; ++i) A[i][j] = v2f{0.f, 0.f};
-    }
-    const long long stride = gridDim.x;
-    long long it = blockIdx.x;
-#pragma unroll
-    for (int dd = 0; dd < kDepth; ++dd) issue(it + dd * stride, lx[dd], ld[dd]);
-    auto consume = [&](float(&ax)[NT], float(&ad)[CO]) {
-        float xv[NT];
-        v2f dv[CO / 2];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) xv[i] = ax[i];
-#pragma unroll
-        for (int j = 0; j < CO / 2; ++j) dv[j] = v2f{ad[2 * j], ad[2 * j + 1]};
-        issue(it + kDepth * stride, ax, ad);
-#pragma unroll
-        for (int j = 0; j < CO / 2; ++j) bs[j] += dv[j];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const v2f pv = {xv[i], xv[i]};
-#pragma unroll
-            for (int j = 0; j < CO / 2; ++j) A[i][j] = __builtin_elementwise_fma(dv[j], pv, A[i][j]);
-        }
-        it += stride;
-    };
-    while (it < items) {
-#pragma unroll
-        for (int dd = 0; dd < kDepth; ++dd) consume(lx[dd], ld[dd]);
-    }
-    float* out = slabs + (size_t)blockIdx.x * CO * 28;
-    auto wsum = [&](float v) {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-        return v;
-    };
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int t = wave * NT + i;
-#pragma unroll
-        for (int j = 0; j < CO / 2; ++j) {
-            const float a = wsum(A[i][j].x), b2 = wsum(A[i][j].y);
-            if (lane == 0 && t < 27) {
-                out[(2 * j) * 28 + t] = a;
-                out[(2 * j + 1) * 28 + t] = b2;
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < CO / 2; ++j) {
-        const float a = wsum(bs[j].x), b2 = wsum(bs[j].y);
-        if (lane == 0 && wave == 0) {
-            out[(2 * j) * 28 + 27] = a;
-            out[(2 * j + 1) * 28 + 27] = b2;
-        }
     }
 }
 
@@ -808,44 +704,33 @@ bool direct_dgrad_pk_ok(const cnn_conv2d_desc* d) {
 int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes,
                       hipStream_t s, bool prepared) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
-    const long long rows = (long long)d->B * ((d->H + d->s - 1) / d->s);
-    const int dbg = getenv("CNN_AMD_DBG") ? atoi(getenv("CNN_AMD_DBG")) : 0;
     if (ws != nullptr && ws_bytes >= 16 * 32 * sizeof(float) && direct_dgrad_pk_ok(d)) {
         if (!prepared)
             CNN_KLAUNCH(s, "pack_dgrad_weights", (pack_dgrad_weights_3_16_3_2<<<1, 64, 0, s>>>(w, (float*)ws)), CONV_TAG(d));
-        const int cb = getenv("CNN_AMD_DG_UNROLL") ? atoi(getenv("CNN_AMD_DG_UNROLL")) : 4;
-        const int UVg = ((d->H + 1) / 2) * ((d->W + 1) / 2);
+        const int V = (d->W + 1) / 2, UVg = ((d->H + 1) / 2) * V;
         const int ipi = (UVg + 63) / 64;
         const long long witems = (long long)d->B * ipi;
-#define PK_LAUNCH(U)                                                                                                   \
-    CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>",                                                                         \
-                (conv_dgrad_pk_3_16_3_2<U><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, Wo, ipi, div_magic(ipi), div_magic((d->W + 1) / 2))), \
+        // CNN_AMD_DBG = 4 / 8 / 12 (tuning only): compile-time ablations without the FMAs / the stores / both, the source
+        // of the breakdown in DESIGN.md section 6
+        const int dbg = getenv("CNN_AMD_DBG") ? atoi(getenv("CNN_AMD_DBG")) : 0;
+#define PK_LAUNCH(DBG_)                                                                                              \
+    CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>",                                                                       \
+                (conv_dgrad_pk_3_16_3_2<4, DBG_><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, \
+                                                                                     Wo, ipi, div_magic(ipi), div_magic(V))), \
                 CONV_TAG(d))
-        if (dbg == 4) {
-            CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>", (conv_dgrad_pk_3_16_3_2<4, 4><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, Wo, ipi, div_magic(ipi), div_magic((d->W + 1) / 2))), CONV_TAG(d));
-        } else if (dbg == 8) {
-            CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>", (conv_dgrad_pk_3_16_3_2<4, 8><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, Wo, ipi, div_magic(ipi), div_magic((d->W + 1) / 2))), CONV_TAG(d));
-        } else if (dbg == 12) {
-            CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>", (conv_dgrad_pk_3_16_3_2<4, 12><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, Wo, ipi, div_magic(ipi), div_magic((d->W + 1) / 2))), CONV_TAG(d));
-        } else
-        if (cb == 2) PK_LAUNCH(2);
-        else if (cb == 4) PK_LAUNCH(4);
-        else if (cb == 16) PK_LAUNCH(16);
-        else PK_LAUNCH(8);
+        if (dbg == 4) PK_LAUNCH(4);
+        else if (dbg == 8) PK_LAUNCH(8);
+        else if (dbg == 12) PK_LAUNCH(12);
+        else PK_LAUNCH(0);  // 4 dy channels per load batch (2: 91.5 us, 4: 91.0, 8: 92.5, 16: SGPR spills)
 #undef PK_LAUNCH
         return CNN_AMD_OK;
     }
     CNN_REQUIRE(!prepared, "internal: prepared dgrad without a packed kernel");
-    const int un = getenv("CNN_AMD_DG_UNROLL") ? atoi(getenv("CNN_AMD_DG_UNROLL")) : 4;
-#define DG_LAUNCH(U)                                                                                                  \
-    CNN_KLAUNCH(s, "conv_direct_dgrad<3,16,3,2>",                                                                    \
-                (conv_direct_dgrad<3, 16, 3, 2, U><<<wave_grid(rows), kBlock, 0, s>>>(dy, w, dx, d->B, d->H, d->W, Ho, Wo, dbg)), \
-                CONV_TAG(d))
-    if (un == 1) DG_LAUNCH(1);
-    else if (un == 2) DG_LAUNCH(2);
-    else if (un == 8) DG_LAUNCH(8);
-    else DG_LAUNCH(4);
-#undef DG_LAUNCH
+    // fallback (dy tensor >= 2 GiB or no workspace): the plain row kernel
+    const long long rows = (long long)d->B * ((d->H + d->s - 1) / d->s);
+    CNN_KLAUNCH(s, "conv_direct_dgrad<3,16,3,2>",
+                (conv_direct_dgrad<3, 16, 3, 2, 4><<<wave_grid(rows), kBlock, 0, s>>>(dy, w, dx, d->B, d->H, d->W, Ho, Wo, 0)),
+                CONV_TAG(d));
     return CNN_AMD_OK;
 }
 
@@ -867,32 +752,27 @@ int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float
         CNN_KLAUNCH(s, "pack_dgrad_weights", (pack_dgrad_weights_s2<<<(total + 255) / 256, 256, 0, s>>>(w, (float*)ws, d->Ci, d->Co)),
                     CONV_TAG(d));
     const int V = (d->W + 1) / 2, UVg = ((d->H + 1) / 2) * V;
-    const int px = getenv("CNN_AMD_PK_PX") ? atoi(getenv("CNN_AMD_PK_PX")) : 1;
-    const int ipi = (UVg + 64 * px - 1) / (64 * px);
+    const int ipi = (UVg + 63) / 64;
     const long long witems = (long long)d->B * ipi;
-    const size_t wl = (size_t)total * sizeof(float);  // <= 64 KiB by pk_dgrad_s2_supported()
-#define PKS2(CI_, PX_, CB_)                                                                                                  \
-    CNN_KLAUNCH(s, "conv_dgrad_pk_s2<" #CI_ ">",                                                                        \
-                (conv_dgrad_pk_s2<CI_, CB_, PX_><<<wave_grid(witems), kBlock, wl, s>>>(dy, (const v2f*)ws, dx, d->B, d->Co, d->H, d->W, \
-                                                                                    Ho, Wo, ipi, div_magic(ipi), div_magic(V))), \
-                CONV_TAG(d))
-    const int cb = getenv("CNN_AMD_PK_CB") ? atoi(getenv("CNN_AMD_PK_CB")) : 4;
-    const int dbgk = getenv("CNN_AMD_DBG") ? atoi(getenv("CNN_AMD_DBG")) : 0;
-#define PKS2D(D_) CNN_KLAUNCH(s, "conv_dgrad_pk_s2<16>", (conv_dgrad_pk_s2<16, 4, 1, D_><<<wave_grid(witems), kBlock, wl, s>>>(dy, (const v2f*)ws, dx, d->B, d->Co, d->H, d->W, Ho, Wo, ipi, div_magic(ipi), div_magic(V))), CONV_TAG(d))
-    if (dbgk == 1) PKS2D(1); else if (dbgk == 2) PKS2D(2); else if (dbgk == 4) PKS2D(4); else if (dbgk == 8) PKS2D(8); else if (dbgk == 15) PKS2D(15); else if (dbgk == 11) PKS2D(11); else if (dbgk == 9) PKS2D(9); else if (dbgk == 31) PKS2D(31); else if (dbgk == 47) PKS2D(47); else if (dbgk == 63) PKS2D(63); else
-    if (d->Ci == 16 && px == 1 && cb == 2) PKS2(16, 1, 2);
-    else if (d->Ci == 16 && px == 1 && cb == 1) PKS2(16, 1, 1);
-    else if (d->Ci == 16 && px == 1) PKS2(16, 1, 4);
-    else if (d->Ci == 16) PKS2(16, 2, 4);
-    else {
+    const size_t wl = (size_t)total * sizeof(float);
+    // (two pixels per lane, other batch sizes: no gain -- the loop is bound by the LDS-read / FMA interleave)
+    if (d->Ci == 16) {
+        CNN_KLAUNCH(s, "conv_dgrad_pk_s2<16>",
+                    (conv_dgrad_pk_s2<16, 4, 1><<<wave_grid(witems), kBlock, wl, s>>>(dy, (const v2f*)ws, dx, d->B, d->Co, d->H, d->W, Ho,
+                                                                                     Wo, ipi, div_magic(ipi), div_magic(V))),
+                    CONV_TAG(d));
+    } else {  // opt-in (CNN_AMD_PK_DGRAD=1): 32 input channels, slower than the implicit GEMM (71 vs 56 us)
         static thread_local bool attr_set = false;
         if (!attr_set) {
-            CNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_dgrad_pk_s2<32, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            CNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_dgrad_pk_s2<32, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              160 * 1024));
             attr_set = true;
         }
-        PKS2(32, 1, 4);
+        CNN_KLAUNCH(s, "conv_dgrad_pk_s2<32>",
+                    (conv_dgrad_pk_s2<32, 4, 1><<<wave_grid(witems), kBlock, wl, s>>>(dy, (const v2f*)ws, dx, d->B, d->Co, d->H, d->W, Ho,
+                                                                                     Wo, ipi, div_magic(ipi), div_magic(V))),
+                    CONV_TAG(d));
     }
-#undef PKS2
     return CNN_AMD_OK;
 }
 
@@ -932,7 +812,7 @@ int direct_wgrad_slots(const cnn_conv2d_desc* d) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
     if ((long long)d->B * 16 * Ho * Wo * 4 >= (1ll << 31) - 16 || (long long)d->B * 3 * d->H * d->W * 4 >= (1ll << 31) - 16) return 0;
     const long long items = (long long)d->B * ((Ho * Wo + 63) / 64);
-    const long long cap = (long long)kNumCU * (getenv("CNN_AMD_WG_BPC") ? atoi(getenv("CNN_AMD_WG_BPC")) : 2);  // resident workgroups per CU (~200 VGPRs)
+    const long long cap = (long long)kNumCU * 2;  // two resident workgroups per CU (~200 VGPRs each); 1 or 3 measured slower
     return (int)(items < cap ? items : cap);
 }
 
@@ -940,30 +820,11 @@ int direct_wgrad_slots(const cnn_conv2d_desc* d) {
 int direct_conv_wgrad(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
     const int ipi = (Ho * Wo + 63) / 64;
-    const int depth = getenv("CNN_AMD_WG_DEPTH") ? atoi(getenv("CNN_AMD_WG_DEPTH")) : 3;
-#define WG_LAUNCH(D)                                                                                                      \
-    CNN_KLAUNCH(s, "conv_wgrad_pk<3,16,3,2>",                                                                            \
-                (conv_wgrad_pk_3_16_3_2<D><<<direct_wgrad_slots(d), kBlock, 0, s>>>(x, dy, slabs, d->B, d->H, d->W, Ho, Wo, ipi, div_magic(ipi), div_magic(Wo))), \
-                CONV_TAG(d))
-    if (getenv("CNN_AMD_WG_V2")) {
-        const int v = atoi(getenv("CNN_AMD_WG_V2"));
-#define WG2_LAUNCH(D)                                                                                                     \
-    CNN_KLAUNCH(s, "conv_wgrad_pk2<3,16,3,2>",                                                                           \
-                (conv_wgrad_pk2_3_16_3_2<D><<<direct_wgrad_slots(d), kBlock, 0, s>>>(x, dy, slabs, d->B, d->H, d->W, Ho, Wo, ipi, div_magic(ipi), div_magic(Wo))), \
-                CONV_TAG(d))
-        if (v == 1) WG2_LAUNCH(1);
-        else if (v == 3) WG2_LAUNCH(3);
-        else if (v == 4) WG2_LAUNCH(4);
-        else WG2_LAUNCH(2);
-#undef WG2_LAUNCH
-        return CNN_AMD_OK;
-    }
-    if (depth == 2) WG_LAUNCH(2);
-    else if (depth == 3) WG_LAUNCH(3);
-    else if (depth == 5) WG_LAUNCH(5);
-    else if (depth == 6) WG_LAUNCH(6);
-    else WG_LAUNCH(4);
-#undef WG_LAUNCH
+    // three items of loads in flight per workgroup (2: 117 us, 3: 115 us, 4+: the extra registers cost more than they hide)
+    CNN_KLAUNCH(s, "conv_wgrad_pk<3,16,3,2>",
+                (conv_wgrad_pk_3_16_3_2<3><<<direct_wgrad_slots(d), kBlock, 0, s>>>(x, dy, slabs, d->B, d->H, d->W, Ho, Wo, ipi,
+                                                                                   div_magic(ipi), div_magic(Wo))),
+                CONV_TAG(d));
     return CNN_AMD_OK;
 }
 
