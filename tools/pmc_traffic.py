@@ -29,6 +29,9 @@ def canonical(name):
     m = re.match(r"(conv_(?:dgrad|fwd|wgrad)_pk2?)_3_16_3_2(<.*>)?$", name)
     if m:
         return f"{m.group(1)}<3,16,3,2>"
+    m = re.match(r"conv_dgrad_pk_s2<(\d+),\d+,\d+>$", name)
+    if m:
+        return f"conv_dgrad_pk_s2<{m.group(1)}>"
     m = re.match(r"(conv_direct_(?:fwd|dgrad))<(\d+,\d+,\d+,\d+)(,\d+)?>$", name)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
