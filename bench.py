@@ -194,7 +194,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     B = args.batch
-    net = AlexNetHip(B, 3)
+    # defer_input_grad: conv_layer_1's data gradient (no consumer) is launched one forward pass later on a second stream;
+    # barrier() flushes it, so the timed region contains exactly K of them (cnn_amd/pynet.py)
+    net = AlexNetHip(B, 3, defer_input_grad=True)
     rs = np.random.RandomState(1234)  # identical init on every rank: replicas stay in lock-step without a broadcast
     net.load_params((rs.standard_normal(net.n_params) * 0.1).astype(np.float32))
     g = torch.Generator(device="cuda").manual_seed(100 + rank)  # each rank has its own shard of the global batch
@@ -206,6 +208,7 @@ def main():
         net.train_step(x, labels, lr, dist, world)
 
     def barrier():
+        net.flush()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -15,7 +15,7 @@ from . import capi
 class AlexNetHip:
     CHANS = [3, 16, 32, 64, 128]
 
-    def __init__(self, batch, classes=3, H=224, W=224, device="cuda", fuse=True):
+    def __init__(self, batch, classes=3, H=224, W=224, device="cuda", fuse=True, defer_input_grad=False):
         import torch
 
         self.torch = torch
@@ -65,6 +65,21 @@ class AlexNetHip:
 
         self.use_prep = fuse and not os.environ.get("CNN_AMD_NO_PREPARED")  # (A/B switch for measurements)
         self.prep = [c.prepared_buffers(device) for c in self.convs] if self.use_prep else None
+        # The data gradient of conv_layer_1 (the delta w.r.t. the input image, conv2d.cpp:168-199) has no consumer: nothing
+        # waits for it.  It is still computed every step, but as a DEFERRED launch on a second stream that is released
+        # in the next forward pass once the HBM-bound layers are through (after conv_layer_2), so that this HBM-bound
+        # kernel overlaps the latency/compute-bound layers 3-4 instead of fighting conv1's weight gradient for bandwidth.
+        # flush() launches a still-pending one (end of training / before timing ends).  Needs its own copy of the
+        # prepared filters of the step it belongs to (two buffers, alternating), because SGD runs in between.
+        # Opt-in (defer_input_grad=True, what bench.py uses): callers that read d_conv[0] must flush() first.
+        self.defer_dx0 = bool(defer_input_grad) and self.use_prep and not os.environ.get("CNN_AMD_NO_DEFER_DX0")
+        if self.defer_dx0:
+            self.side_b = torch.cuda.Stream(device=device)
+            self.ev_release, self.ev_b_done = torch.cuda.Event(), torch.cuda.Event()
+            self.prep0_dgrad = [self.prep[0][1], self.convs[0].prepared_buffers(device)[1]]
+            self.parity = 0
+            self.pending_dx0 = None   # prepared-filter buffer of the step whose conv1 dgrad has not been launched yet
+            self.b_in_flight = False
 
     # ---- parameter views (reference layouts) ----
     def conv_w(self, l, arena=None):
@@ -92,9 +107,37 @@ class AlexNetHip:
 
     def _prepare(self):
         if not self._prep_valid:
+            dg = [p[1] for p in self.prep]
+            if self.defer_dx0:
+                self.parity ^= 1
+                dg[0] = self.prep0_dgrad[self.parity]
             capi.prepare_filters(self.convs, [self.conv_w(l) for l in range(4)], [self.conv_b(l) for l in range(4)],
-                                 [p[0] for p in self.prep], [p[1] for p in self.prep])
+                                 [p[0] for p in self.prep], dg)
             self._prep_valid = True
+
+    def _launch_pending_dx0(self, gated):
+        """conv_layer_1's data gradient of the PREVIOUS backward pass, on the second stream"""
+        if not self.defer_dx0 or self.pending_dx0 is None:
+            return
+        torch = self.torch
+        main = torch.cuda.current_stream()
+        self.ev_release.record(main)
+        with torch.cuda.stream(self.side_b):
+            self.side_b.wait_event(self.ev_release)  # gated: not before this point of the main stream
+            self.convs[0].backward_data_prepared(self.d_pool, self.pending_dx0, self.d_conv[0])
+            self.ev_b_done.record(self.side_b)
+        self.pending_dx0 = None
+        self.b_in_flight = True
+        if not gated:
+            main.wait_event(self.ev_b_done)
+            self.b_in_flight = False
+
+    def flush(self):
+        """make sure every deferred kernel has been launched and is ordered before later work on the current stream"""
+        self._launch_pending_dx0(gated=False)
+        if self.defer_dx0 and self.b_in_flight:
+            self.torch.cuda.current_stream().wait_event(self.ev_b_done)
+            self.b_in_flight = False
 
     def load_checkpoint(self, path):
         self.load_params(np.fromfile(path, dtype=np.float32))
@@ -121,6 +164,11 @@ class AlexNetHip:
                                                              capi._ptr(self.pool_mask) if record else None, self.B, 16, hh,
                                                              ww, 2, 2, capi._stream()), "cnn_maxpool2d_forward")
                 cur = self.pool_out
+            if l == 1:
+                # release point of the deferred conv1 data gradient, measured (images/s at batch 256, same box): no
+                # deferral 261.0k | before conv1 ~249k | after max_pool_1 ~257k | after conv_layer_2 269.3k | after
+                # conv_layer_3 264.5k -- it then overlaps the latency-bound layers 3-4, the linear layer and the loss
+                self._launch_pending_dx0(gated=True)
         capi.linear_forward(cur.view(self.B, self.lin_in), self.lin_w(), self.lin_b(), self.logits)
         return self.logits
 
@@ -141,6 +189,8 @@ class AlexNetHip:
         for l in (3, 2, 1, 0):
             if l == 0:
                 hh, ww = self.conv_out_hw[0]
+                if self.defer_dx0:
+                    self.flush()  # the previous step's deferred dgrad reads d_pool, which is rewritten next
                 if self.fuse:  # pool backward + relu_layer_1 backward in one pass
                     capi.maxpool_backward_relu(cur, self.pool_mask, self.pool_out, (self.B, 16, hh, ww), 2, 2, self.d_pool)
                 else:
@@ -150,7 +200,11 @@ class AlexNetHip:
                 capi.relu_backward(self.relu_out[l], cur)  # in place on the upstream delta (relu.cpp:37-39)
             lin = self.x if l == 0 else (self.pool_out if l == 1 else self.relu_out[l - 1])
             # Conv2D::backward in one call: weight/bias gradient on the library's side stream, concurrently with dgrad
-            if self.use_prep:
+            if self.defer_dx0 and l == 0:
+                # weight / bias gradient now (SGD needs it); the data gradient is launched in the next forward pass
+                self.convs[0].backward_weight(lin, cur, div, self.conv_w(0, g), self.conv_b(0, g))
+                self.pending_dx0 = self.prep0_dgrad[self.parity]
+            elif self.use_prep:
                 self.convs[l].backward_prepared(lin, cur, self.prep[l][1], div, self.conv_w(l, g), self.conv_b(l, g),
                                                 self.d_conv[l], defer_join=True)
             else:

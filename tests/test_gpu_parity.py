@@ -455,3 +455,26 @@ def test_prepared_filters_match_plain_calls(T):
         c.backward_prepared(x, dy, pd, 3.0, gw1, gb1, dx3)
         T.cuda.synchronize()
         assert T.equal(gw0, gw1) and T.equal(gb0, gb1) and T.equal(dx2, dx3) and T.equal(dx0, dx3)
+
+
+def test_deferred_input_gradient_is_bit_identical(T):
+    """pynet(defer_input_grad=True) launches conv_layer_1's data gradient one forward pass later on a second stream;
+    after flush() every tensor, including that gradient, equals the in-order run bit for bit"""
+    from cnn_amd.pynet import AlexNetHip
+
+    B = 4
+    x = dev(T, uniform01(330, (B, 3, 224, 224)))
+    labels = dev(T, (np.arange(B) % 3).astype(np.int32))
+    nets = [AlexNetHip(B, 3, defer_input_grad=d) for d in (True, False)]
+    p0 = normal_scaled(331, (nets[0].n_params,))
+    for n in nets:
+        n.load_params(p0)
+    for step in range(3):
+        for n in nets:
+            n.train_step(x, labels, 1e-3)
+        a, b = nets
+        assert a.pending_dx0 is not None  # still to be launched
+        a.flush()
+        T.cuda.synchronize()
+        assert T.equal(a.params, b.params) and T.equal(a.grads, b.grads) and T.equal(a.d_conv[0], b.d_conv[0]), step
+        assert T.equal(a.d_pool, b.d_pool) and T.equal(a.d_conv[1], b.d_conv[1])
