@@ -183,6 +183,7 @@ constexpr unsigned kBufOOB = 0x7ffffffcu;
 // n / d for the small non-negative operands of the item -> (image, pixel) -> (row, column) decodes below, without the ~40
 // instruction integer-division sequence: magic = 2^32 / d + 1 (host side), one correction step covers the rounding
 __device__ __forceinline__ int fast_div(int n, unsigned magic, int d) {
+    if (d == 1) return n;  // (2^32 / 1 does not fit the 32-bit magic)
     int q = (int)__umulhi((unsigned)n, magic);
     if (q * d > n) --q;
     return q;

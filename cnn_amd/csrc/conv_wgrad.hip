@@ -17,6 +17,8 @@ namespace cnn_amd {
 size_t igemm_workspace_floats(const cnn_conv2d_desc* d);  // conv_igemm.hip
 int direct_wgrad_slots(const cnn_conv2d_desc* d);          // conv_direct.hip: thin first layer, packed VALU kernel
 int direct_conv_wgrad(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
+int wgrad_rd_slots(const cnn_conv2d_desc* d);  // conv_wgrad_rd.hip: register-direct MFMA kernel (3x3, stride 1/2, pad 0)
+int wgrad_rd_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
 }
 
 namespace {
@@ -530,6 +532,14 @@ int launch_w(const WPlan& pl, hipStream_t s, const cnn_conv2d_desc* d, int* nspl
                   : launch_w2<MF, MA, NB, WM, WN, WK, false, false>(pl, s, d, nsplit_used);
 }
 
+// when to prefer the register-direct kernel (conv_wgrad_rd.hip); CNN_AMD_WGRAD_RD=0/1 forces it off / on
+bool rd_wanted(const cnn_conv2d_desc* d) {
+    if (direct_wgrad_slots(d) > 0) return false;
+    const char* e = getenv("CNN_AMD_WGRAD_RD");
+    if (e) return atoi(e) != 0 && wgrad_rd_slots(d) > 0;
+    return false;
+}
+
 int check_desc(const char* who, const cnn_conv2d_desc* d) {
     CNN_REQUIRE(d != nullptr, "%s: desc is null", who);
     CNN_REQUIRE(d->B > 0 && d->Ci > 0 && d->H > 0 && d->W > 0 && d->Co > 0 && d->k > 0 && d->s > 0 && d->pad >= 0,
@@ -554,6 +564,9 @@ size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d) {
     const size_t dw = ds ? (size_t)(ds + (ds + 63) / 64) * 16 * 28 : 0;  // slabs + stage-1 scratch of the direct kernel
     size_t m = wg > ig ? wg : ig;
     if (dw > m) m = dw;
+    const int rs = wgrad_rd_slots(d);
+    const size_t rw = rs ? (size_t)(rs + (rs + 63) / 64) * d->Co * (d->Ci * 9 + 1) : 0;
+    if (rw > m) m = rw;
     return (m + 64) * sizeof(float);
 }
 
@@ -573,6 +586,17 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
             float gb_dummy_unused = 0.f;
             (void)gb_dummy_unused;
             return reduce_slabs(sd, (const float*)ws, ds, n, (float*)ws + (size_t)ds * n, gw, divisor, tagd, 27, gb);
+        }
+    }
+    if (rd_wanted(d)) {
+        const int rs = wgrad_rd_slots(d);
+        const size_t n = (size_t)d->Co * (d->Ci * 9 + 1), need_r = (size_t)(rs + (rs + 63) / 64) * n * sizeof(float);
+        if (rs > 0 && ws_bytes >= need_r) {
+            hipStream_t sr = as_stream(stream);
+            if (int rc = wgrad_rd_launch(d, x, dy, (float*)ws, sr)) return rc;
+            char tagr[160];
+            snprintf(tagr, sizeof(tagr), CONV_TAG(d));
+            return reduce_slabs(sr, (const float*)ws, rs, n, (float*)ws + (size_t)rs * n, gw, divisor, tagr, d->Ci * 9, gb);
         }
     }
     WPlan pl;
