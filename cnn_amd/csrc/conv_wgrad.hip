@@ -532,12 +532,13 @@ int launch_w(const WPlan& pl, hipStream_t s, const cnn_conv2d_desc* d, int* nspl
                   : launch_w2<MF, MA, NB, WM, WN, WK, false, false>(pl, s, d, nsplit_used);
 }
 
-// when to prefer the register-direct kernel (conv_wgrad_rd.hip); CNN_AMD_WGRAD_RD=0/1 forces it off / on
+// the register-direct kernel (conv_wgrad_rd.hip) takes every geometry it covers except the thin first layer (packed VALU
+// kernel); CNN_AMD_WGRAD_RD=0 sends those layers through the LDS-staged kernel below instead (A/B measurements)
 bool rd_wanted(const cnn_conv2d_desc* d) {
     if (direct_wgrad_slots(d) > 0) return false;
     const char* e = getenv("CNN_AMD_WGRAD_RD");
-    if (e) return atoi(e) != 0 && wgrad_rd_slots(d) > 0;
-    return false;
+    if (e && atoi(e) == 0) return false;
+    return wgrad_rd_slots(d) > 0;
 }
 
 int check_desc(const char* who, const cnn_conv2d_desc* d) {

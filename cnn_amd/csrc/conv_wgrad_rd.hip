@@ -6,15 +6,24 @@
 // The reduction index (pixels) may be visited in any order as long as the A and B operand of an MFMA step agree.  The
 // pixels are cut into RUNS of RL (16 or 8) consecutive pixels of one output row; a chunk is two consecutive runs, k-slot
 // kg of MFMA step t <-> pixel t of run 2*chunk + kg (the two runs may lie in different rows or images: all addressing is
-// per lane).  With q0 the first pixel of the lane's run:  Lane (m = lane%32, kg = lane/32) of the A operand then needs dy[co_m][p][q0+16kg .. +15]:
-// 16 CONSECUTIVE floats (four 16-byte loads), and lane (n, kg) of the B operand needs x[ci_n][s*p+kx_n][s*(q0+16kg+t)+ky_n]:
-// for stride 2 every second float of a 32-float window (eight 16-byte loads; even / odd element chosen per lane).
-// Every lane therefore streams its own short contiguous runs from L1/L2 straight into MFMA operand registers; tails of
-// rows are handled by guarded loads (A = 0 for missing pixels, so whatever B holds there is multiplied by 0).
-//   per 32-pixel chunk and wave: 4 + 8*NT 16-byte loads for 16*NT MFMAs (NT = 32-column tiles per wave).
-// Column Ntot of the output is the fused bias gradient (B operand = 1).  The four waves of a workgroup split its chunk
-// range and are summed in a fixed order through LDS at the end; reduce_slabs() (conv_wgrad.hip) adds the workgroups.
+// per lane).  With q0 the first pixel of the lane's run, lane (m = lane%32, kg = lane/32) of the A operand needs
+// dy[co_m][p][q0 .. q0+RL-1]: RL CONSECUTIVE floats (16-byte loads), and lane (n, kg) of the B operand needs
+// x[ci_n][s*p+kx_n][s*(q0+t)+ky_n]: for stride 2 every second float of a 2*RL-float window (even / odd element chosen
+// per lane).  Every lane therefore streams its own short contiguous windows from L1/L2 straight into MFMA operand
+// registers:  per chunk and wave  RL/4 + S*RL/4*NT 16-byte loads for RL*NT MFMAs (NT = 32-column tiles per wave).
+//
+// Pipelined path (all but the last few chunks of the tensors): the loads are unconditional -- a window may run over the
+// end of its row into whatever follows, those k-slots are masked to zero on both operands -- and software-pipelined by
+// hand with two window buffers: the window of tile nt+1 (behind the last tile: the next chunk's A run and first window)
+// is in flight while the MFMAs of tile nt issue.  Measured on the north-star shape: 8.44 M shader cycles per workgroup
+// against 7.88 M cycles of pure MFMA issue (93 %); a per-tile ring of NT buffers was slower (9.12 M).
+// Guarded path: element-wise guarded loads for the chunks whose windows could leave the allocation.
+//
+// The bias gradient (sum of dy) is accumulated on the VALU from the A registers (no ones-column: Ci*9 = 576 columns are
+// exactly 18 tiles).  The four waves of a workgroup split its chunk range and are summed in a fixed order through LDS at
+// the end; reduce_slabs() (conv_wgrad.hip) adds the workgroups' slabs.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -27,16 +36,23 @@ struct __attribute__((packed, aligned(4))) f4u {
     float x, y, z, w;
 };
 
+// Loads may not cross this (it might write memory) and the MFMAs that consume `reg` may not rise above it: pins the
+// hand-made software pipeline (instruction selection otherwise sinks every prefetch down to its first use, and
+// __builtin_amdgcn_sched_barrier only binds the later machine scheduler).
+#define RD_PIPE_FENCE(reg) asm volatile("" : "+v"(reg) : : "memory")
+
 struct RdParams {
     const float* x;
     const float* dy;
     float* slabs;  // [gridDim.x][Co][pitch]
     int B, Ci, H, W, Co, Ho, Wo;
-    int Ntot, pitch;  // Ci*9, Ntot + 1 (the bias column)
+    int Ntot, pitch;  // Ci*9, Ntot + 1 (column Ntot = bias gradient)
     int rpr;          // runs per output row
     int runs_total;   // B * Ho * rpr
     int chunks_total, chunks_per_block;  // chunk = 2 runs
     unsigned m_rows, m_rpr;  // magic multipliers: run -> (image*Ho + p, segment) and -> image
+    int chunks_fast;  // chunks [0, chunks_fast) may over-read their windows without leaving x / dy (host-checked)
+    int dbg;          // CNN_AMD_RD_DBG=9: workgroup 0 prints its shader-cycle count and the clock it ran at
 };
 
 __device__ __forceinline__ int fdiv(int n, unsigned magic, int d) {
@@ -63,23 +79,23 @@ __device__ __forceinline__ f4u load4(const float* __restrict__ p, int nvalid) {
 
 template <int S, int NT, int RL>
 __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
-    constexpr int WL = S * RL;  // floats of x a lane needs per chunk
-    __shared__ float red[32][NT * 32 + 1];
+    constexpr int WL = S * RL;  // floats of x a lane needs per chunk and tile
+    __shared__ float red[32][NT * 32 + 1];  // (+1: bank padding; the column doubles as the bias-gradient slot)
     const int lane = threadIdx.x & 63, m = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int co = blockIdx.z * 32 + m;
     const int nbase = blockIdx.y * NT * 32;
+    const int nt_live = (p.Ntot - nbase + 31) / 32;  // tiles of this group that hold at least one column (block-uniform)
 
     // per-lane column description for every N tile: offset of the filter tap inside an image, window shift, parity
     int xoff[NT], shift[NT];
-    bool par[NT], ones[NT], nvalid_col[NT];
+    bool par[NT], nvalid_col[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = nbase + nt * 32 + m;
         const int nn = n < p.Ntot ? n : 0;
         const int ci = nn / 9, kx = (nn - ci * 9) / 3, ky = nn - ci * 9 - kx * 3;
         nvalid_col[nt] = n < p.Ntot;
-        ones[nt] = n == p.Ntot;
         shift[nt] = S == 2 ? (ky == 2 ? 2 : 0) : ky;
         par[nt] = S == 2 && ky == 1;
         xoff[nt] = (ci * p.H + kx) * p.W + shift[nt];
@@ -90,6 +106,8 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    float bsum = 0.f;  // this lane's share of sum(dy[co]) (both k-groups see disjoint pixels)
+    const long long dbg_t0 = p.dbg == 9 ? clock64() : 0, dbg_w0 = p.dbg == 9 ? wall_clock64() : 0;
 
     // this wave's contiguous chunk range
     const int c_lo = blockIdx.x * p.chunks_per_block;
@@ -98,7 +116,110 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
     const int w_lo = c_lo + wave * per_wave, w_hi = w_lo + per_wave < c_hi ? w_lo + per_wave : c_hi;
     const size_t img_x = (size_t)p.Ci * p.H * p.W;
 
-    for (int ch = w_lo; ch < w_hi; ++ch) {
+    auto add_bias = [&](const float (&a)[RL]) {
+        float s4[RL / 4];
+#pragma unroll
+        for (int j = 0; j < RL / 4; ++j) s4[j] = (a[4 * j] + a[4 * j + 1]) + (a[4 * j + 2] + a[4 * j + 3]);
+        float s = s4[0];
+#pragma unroll
+        for (int j = 1; j < RL / 4; ++j) s += s4[j];
+        bsum += s;
+    };
+
+    // ---- pipelined path
+    const int f_hi = w_hi < p.chunks_fast ? w_hi : p.chunks_fast;
+    int s_lo = w_lo;
+    if (w_lo < f_hi) {
+        s_lo = f_hi;
+        const int co_c = co < p.Co ? co : 0;
+        unsigned cur_x = 0, nxt_x = 0, nxt_a = 0;
+        int cur_nv = 0, nxt_nv = 0, cur_nb = 0, nxt_nb = 0;  // live pixels of the lane's run: A side (0 for co >= Co) / B side
+        auto locate = [&](int ch, unsigned& aoff, unsigned& xb, int& nv, int& nb) {
+            const int run = 2 * ch + kg;
+            const bool rlive = run < p.runs_total;
+            const int runc = rlive ? run : 0;
+            const int rowi = fdiv(runc, p.m_rpr, p.rpr), seg = runc - rowi * p.rpr;
+            const int b = fdiv(rowi, p.m_rows, p.Ho), pr = rowi - b * p.Ho;
+            const int q0 = seg * RL;
+            int npix = p.Wo - q0;
+            npix = npix > RL ? RL : npix;
+            nb = rlive ? npix : 0;
+            nv = co < p.Co ? nb : 0;
+            aoff = (unsigned)(((b * p.Co + co_c) * p.Ho + pr) * p.Wo + q0);
+            xb = (unsigned)(b * (p.Ci * p.H * p.W) + (S * pr) * p.W + S * q0);
+        };
+        // one tile's MFMAs: k-slot t <-> pixel t of the lane's run
+        auto tile_mfma = [&](int nt, const float (&a)[RL], const f4u (&win)[WL / 4]) {
+#pragma unroll
+            for (int t = 0; t < RL; ++t) {
+                const int e = S == 2 ? 2 * t : t;  // window element of pixel t (even phase)
+                const f4u& q = win[e / 4];
+                float bv;
+                if (S == 2) {
+                    const float ev = (e & 3) == 0 ? q.x : q.z, od = (e & 3) == 0 ? q.y : q.w;
+                    bv = par[nt] ? od : ev;
+                } else {
+                    bv = (e & 3) == 0 ? q.x : (e & 3) == 1 ? q.y : (e & 3) == 2 ? q.z : q.w;
+                }
+                bv = t < cur_nb ? bv : 0.f;  // what lies behind the run is not the reference's to read (may be Inf / NaN)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bv, acc[nt], 0, 0, 0);
+            }
+        };
+        f4u abuf[RL / 4], wb[2][WL / 4];
+        {
+            unsigned a0;
+            locate(w_lo, a0, cur_x, cur_nv, cur_nb);
+#pragma unroll
+            for (int j = 0; j < RL / 4; ++j) abuf[j] = *(const f4u*)(p.dy + a0 + 4 * j);
+#pragma unroll
+            for (int j = 0; j < WL / 4; ++j) wb[0][j] = *(const f4u*)(p.x + (cur_x + (unsigned)xoff[0]) + 4 * j);
+        }
+        auto body = [&](auto PC, int ch_next) {
+            constexpr int P = decltype(PC)::value;
+            locate(ch_next, nxt_a, nxt_x, nxt_nv, nxt_nb);
+            float a[RL];
+#pragma unroll
+            for (int j = 0; j < RL / 4; ++j) {
+                a[4 * j] = 4 * j < cur_nv ? abuf[j].x : 0.f;
+                a[4 * j + 1] = 4 * j + 1 < cur_nv ? abuf[j].y : 0.f;
+                a[4 * j + 2] = 4 * j + 2 < cur_nv ? abuf[j].z : 0.f;
+                a[4 * j + 3] = 4 * j + 3 < cur_nv ? abuf[j].w : 0.f;
+            }
+            add_bias(a);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int bi = (P + nt) & 1;
+                if (nt + 1 < NT) {
+#pragma unroll
+                    for (int j = 0; j < WL / 4; ++j)
+                        wb[bi ^ 1][j] = *(const f4u*)(p.x + (cur_x + (unsigned)xoff[nt + 1 < NT ? nt + 1 : 0]) + 4 * j);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < RL / 4; ++j) abuf[j] = *(const f4u*)(p.dy + nxt_a + 4 * j);
+#pragma unroll
+                    for (int j = 0; j < WL / 4; ++j) wb[bi ^ 1][j] = *(const f4u*)(p.x + (nxt_x + (unsigned)xoff[0]) + 4 * j);
+                }
+                RD_PIPE_FENCE(a[0]);
+                if (nt < nt_live) tile_mfma(nt, a, wb[bi]);
+            }
+            cur_x = nxt_x;
+            cur_nv = nxt_nv;
+            cur_nb = nxt_nb;
+        };
+        int ch = w_lo;
+        if (NT & 1) {  // an odd tile count flips the buffer parity from chunk to chunk
+            for (; ch + 1 < f_hi; ch += 2) {
+                body(std::integral_constant<int, 0>(), ch + 1);
+                body(std::integral_constant<int, 1>(), ch + 2 < f_hi ? ch + 2 : ch + 1);
+            }
+            if (ch < f_hi) body(std::integral_constant<int, 0>(), ch);
+        } else {
+            for (; ch < f_hi; ++ch) body(std::integral_constant<int, 0>(), ch + 1 < f_hi ? ch + 1 : ch);
+        }
+    }
+
+    // ---- guarded path: the few chunks at the very end of the tensors (and tensors too small for the pipelined path)
+    for (int ch = s_lo; ch < w_hi; ++ch) {
         const int run = 2 * ch + kg;  // this lane's run
         const bool rlive = run < p.runs_total;
         const int runc = rlive ? run : 0;
@@ -119,14 +240,17 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
                 a[4 * j] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
             }
         }
+        add_bias(a);
         const float* ximg = p.x + (size_t)b * img_x + (size_t)(S * pr) * p.W + S * q0;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+            if (nt >= nt_live) continue;
             // ---- B operand: the lane's window of its filter tap's input row
             float w[WL];
             const int col = S * q0 + shift[nt];
             int rem = p.W - col;  // floats left in the input row
-            rem = (nvalid_col[nt] && npix > 0) ? (rem < 0 ? 0 : rem) : 0;
+            rem = rem < S * npix ? rem : S * npix;  // floats behind the run's last pixel are never multiplied by a live A
+            rem = nvalid_col[nt] ? (rem < 0 ? 0 : rem) : 0;
             const float* src = ximg + xoff[nt];
 #pragma unroll
             for (int j = 0; j < WL / 4; ++j) {
@@ -135,14 +259,14 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
             }
 #pragma unroll
             for (int t = 0; t < RL; ++t) {
-                float bv = S == 2 ? (par[nt] ? w[2 * t + 1] : w[2 * t]) : w[t];
-                bv = ones[nt] ? 1.f : bv;
+                const float bv = S == 2 ? (par[nt] ? w[2 * t + 1] : w[2 * t]) : w[t];
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bv, acc[nt], 0, 0, 0);
             }
         }
     }
 
     // ---- sum the four waves in a fixed order, then one slab per workgroup
+    const float bsum2 = bsum + __shfl_xor(bsum, 32, 64);  // the two k-groups of channel co
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
@@ -153,15 +277,21 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
                     float* dst = &red[row][nt * 32 + m];
                     *dst = (w == 0) ? acc[nt][r] : *dst + acc[nt][r];
                 }
+            if (kg == 0) red[m][NT * 32] = (w == 0) ? bsum2 : red[m][NT * 32] + bsum2;
         }
         __syncthreads();
     }
+    if (p.dbg == 9 && threadIdx.x == 0 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0)
+        printf("wgrad_rd block 0: %lld shader cycles in %lld ticks of 10 ns -> %.0f MHz\n", clock64() - dbg_t0, wall_clock64() - dbg_w0,
+               (double)(clock64() - dbg_t0) / ((double)(wall_clock64() - dbg_w0) / 100.0));
     float* slab = p.slabs + (size_t)blockIdx.x * p.Co * p.pitch;
     for (int i = threadIdx.x; i < 32 * NT * 32; i += 256) {
         const int row = i / (NT * 32), col = i - row * (NT * 32);
         const int c2 = blockIdx.z * 32 + row, n2 = nbase + col;
-        if (c2 < p.Co && n2 < p.pitch) slab[(size_t)c2 * p.pitch + n2] = red[row][col];
+        if (c2 < p.Co && n2 < p.Ntot) slab[(size_t)c2 * p.pitch + n2] = red[row][col];
     }
+    if (blockIdx.y == 0 && threadIdx.x < 32 && blockIdx.z * 32 + threadIdx.x < p.Co)
+        slab[(size_t)(blockIdx.z * 32 + threadIdx.x) * p.pitch + p.Ntot] = red[threadIdx.x][NT * 32];
 }
 
 inline unsigned magic_of(int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
@@ -187,11 +317,19 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl) {
     p.runs_total = (int)runs;
     if (runs >= (1ll << 30) || (long long)p.B * p.Ci * p.H * p.W >= (1ll << 40)) return false;
     p.chunks_total = (int)chunks;
-    const int tiles = (p.pitch + 31) / 32;
-    pl->nt = tiles >= 5 ? 5 : tiles;  // 5 x 16 accumulator registers per wave
-    if (tiles > 5 && tiles % 5 != 0 && tiles % 4 == 0) pl->nt = 4;
-    if (tiles > 5 && tiles % 5 != 0 && tiles % 4 != 0 && tiles % 3 == 0) pl->nt = 3;
-    pl->ngroups = (tiles + pl->nt - 1) / pl->nt;
+    // tiles per wave: the largest of 6..3 that divides the tile count (no dead tiles, equal groups), else 5
+    const int tiles = (p.Ntot + 31) / 32;
+    const int nt_max = (d->s == 2 && pl->rl == 16) ? 5 : 6;  // (64-register window pairs: 6 tiles would not fit 256 VGPRs)
+    int nt = tiles <= nt_max ? tiles : 0;
+    for (int c = nt_max; !nt && c >= 3; --c)
+        if (tiles % c == 0) nt = c;
+    if (!nt) nt = 5;
+    if (const char* e = getenv("CNN_AMD_RD_NT")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= nt_max) nt = v;
+    }
+    pl->nt = nt;
+    pl->ngroups = (tiles + nt - 1) / nt;
     pl->mtiles = (p.Co + 31) / 32;
     const int env = getenv("CNN_AMD_RD_BLOCKS") ? atoi(getenv("CNN_AMD_RD_BLOCKS")) : 0;
     long long want = (env > 0 ? env : 2 * kNumCU) / ((long long)pl->ngroups * pl->mtiles);
@@ -201,6 +339,22 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl) {
     pl->kblocks = (int)((chunks + p.chunks_per_block - 1) / p.chunks_per_block);
     p.m_rows = magic_of(p.Ho);
     p.m_rpr = magic_of(p.rpr);
+    // runs whose (over-reading) windows stay inside the tensors: addresses grow with the run index, so scan from the end
+    const long long x_total = (long long)p.B * p.Ci * p.H * p.W, dy_total = (long long)p.B * p.Co * p.Ho * p.Wo;
+    long long r_unsafe = 0;
+    if (x_total < (1ll << 31) && dy_total < (1ll << 31)) {
+        const long long xoff_bound = ((long long)(p.Ci - 1) * p.H + 2) * p.W + 2;
+        r_unsafe = runs;
+        while (r_unsafe > 0) {
+            const long long r = r_unsafe - 1, rowi = r / p.rpr, seg = r % p.rpr, b = rowi / p.Ho, pr = rowi % p.Ho;
+            const long long xb = b * p.Ci * p.H * p.W + d->s * pr * p.W + d->s * seg * pl->rl;
+            const long long ab = ((b * p.Co + p.Co - 1) * p.Ho + pr) * p.Wo + seg * pl->rl;
+            if (xb + xoff_bound + d->s * pl->rl <= x_total && ab + pl->rl <= dy_total) break;
+            --r_unsafe;
+        }
+    }
+    p.dbg = getenv("CNN_AMD_RD_DBG") ? atoi(getenv("CNN_AMD_RD_DBG")) : 0;
+    p.chunks_fast = getenv("CNN_AMD_RD_SLOW") ? 0 : (int)(r_unsafe / 2);  // (CNN_AMD_RD_SLOW: tests force the guarded path)
     return true;
 }
 
@@ -223,16 +377,21 @@ int wgrad_rd_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, f
     const dim3 grid(pl.kblocks, pl.ngroups, pl.mtiles);
     char name[64];
     snprintf(name, sizeof(name), "wgrad_rd<%d,%d,%d>", d->s, pl.nt, pl.rl);
-#define RD(S_, NT_)                                                                                              \
-    do {                                                                                                         \
-        if (pl.rl == 16) CNN_KLAUNCH(s, name, (wgrad_rd_kernel<S_, NT_, 16><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d)); \
-        else CNN_KLAUNCH(s, name, (wgrad_rd_kernel<S_, NT_, 8><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d));         \
-    } while (0)
-    if (d->s == 2) {
-        if (pl.nt == 5) RD(2, 5); else if (pl.nt == 4) RD(2, 4); else if (pl.nt == 3) RD(2, 3); else if (pl.nt == 2) RD(2, 2); else RD(2, 1);
-    } else {
-        if (pl.nt == 5) RD(1, 5); else if (pl.nt == 4) RD(1, 4); else if (pl.nt == 3) RD(1, 3); else if (pl.nt == 2) RD(1, 2); else RD(1, 1);
+#define RD(S_, NT_, RL_) CNN_KLAUNCH(s, name, (wgrad_rd_kernel<S_, NT_, RL_><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d))
+#define RD_NT(S_, RL_)                                                     \
+    switch (pl.nt) {                                                       \
+        case 1: RD(S_, 1, RL_); break;                                     \
+        case 2: RD(S_, 2, RL_); break;                                     \
+        case 3: RD(S_, 3, RL_); break;                                     \
+        case 4: RD(S_, 4, RL_); break;                                     \
+        case 5: RD(S_, 5, RL_); break;                                     \
+        default: RD(S_, (S_ == 2 && RL_ == 16 ? 5 : 6), RL_); break;       \
     }
+    if (d->s == 2 && pl.rl == 16) { RD_NT(2, 16) }
+    else if (d->s == 2) { RD_NT(2, 8) }
+    else if (pl.rl == 16) { RD_NT(1, 16) }
+    else { RD_NT(1, 8) }
+#undef RD_NT
 #undef RD
     return CNN_AMD_OK;
 }

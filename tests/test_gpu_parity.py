@@ -109,6 +109,59 @@ def test_conv2d_im2col_fallback_vs_oracle(T, case):
     assert_close(host(conv.backward_data_im2col(dyd, wd)), dx_ref, REL_TOL, "im2col data grad")
 
 
+RD_CASES = [
+    (1, 1, 3, 3, 1, 3, 1, 0),        # one output pixel
+    (1, 4, 5, 5, 3, 3, 2, 0),        # whole tensor smaller than one window: guarded path only
+    (2, 7, 20, 37, 33, 3, 1, 0),     # Co = 33 (two row tiles), 64 columns (two tiles)
+    (3, 18, 21, 35, 16, 3, 2, 0),    # 163 columns: six tiles -> 3-tile groups, ragged row tails
+    (2, 40, 9, 9, 70, 3, 1, 0),      # runs of 8 pixels, 361 columns -> 4-tile groups
+    (4, 12, 19, 19, 8, 3, 2, 0),     # Wo = 9: a full run and a 1-pixel tail per row, 109 columns -> 4 tiles
+    (1, 2, 40, 70, 5, 3, 2, 0),      # one image: the last rows take the guarded path
+]
+
+
+@pytest.mark.parametrize("slow", [False, True], ids=["pipelined", "guarded"])
+@pytest.mark.parametrize("case", RD_CASES + [CONV_CASES[1], CONV_CASES[6], CONV_CASES[7]], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_conv2d_wgrad_register_direct(T, case, slow, monkeypatch):
+    """conv_wgrad_rd.hip: the pipelined over-reading path and the guarded path agree with the oracle and, bit for bit,
+    with each other (same MFMA order); the LDS-staged kernel (CNN_AMD_WGRAD_RD=0) is held to the same tolerance"""
+    from cnn_amd import capi
+
+    x, w, b, dy = _conv_inputs(case, 400)
+    _, gw_ref, gb_ref, _ = _oracle_conv(case, x, w, b, dy)
+    conv = capi.Conv2d(*case)
+    xd, dyd = dev(T, x), dev(T, dy)
+    if slow:
+        monkeypatch.setenv("CNN_AMD_RD_SLOW", "1")
+    gw, gb = conv.backward_weight(xd, dyd, float(case[0]))
+    assert_close(host(gw), gw_ref, REL_TOL, "weight grad")
+    assert_close(host(gb), gb_ref, REL_TOL, "bias grad")
+    if slow:
+        monkeypatch.delenv("CNN_AMD_RD_SLOW")
+        gw2, gb2 = conv.backward_weight(xd, dyd, float(case[0]))
+        assert np.array_equal(host(gw), host(gw2)) and np.array_equal(host(gb), host(gb2))
+        monkeypatch.setenv("CNN_AMD_WGRAD_RD", "0")
+        gw3, gb3 = conv.backward_weight(xd, dyd, float(case[0]))
+        assert_close(host(gw3), gw_ref, REL_TOL, "LDS-staged weight grad")
+        assert_close(host(gb3), gb_ref, REL_TOL, "LDS-staged bias grad")
+
+
+def test_conv2d_wgrad_ignores_non_finite_unused_columns(T):
+    """W = 56, stride 2: input column 55 is read by no output pixel (conv2d.cpp:127-146 never touches it), so an Inf
+    there must not leak into the gradient through a zero-weighted over-read"""
+    from cnn_amd import capi
+
+    case = (2, 4, 10, 56, 6, 3, 2, 0)
+    x, w, b, dy = _conv_inputs(case, 410)
+    _, gw_ref, gb_ref, _ = _oracle_conv(case, x, w, b, dy)
+    x2 = x.copy()
+    x2[:, :, :, 55] = np.inf
+    x2[:, :, 9, :] = np.inf  # row 9 likewise: Ho = 4 reads rows 0..8
+    gw, gb = capi.Conv2d(*case).backward_weight(dev(T, x2), dev(T, dy), float(case[0]))
+    assert np.all(np.isfinite(host(gw)))
+    assert_close(host(gw), gw_ref, REL_TOL, "weight grad")
+
+
 def test_conv2d_dgrad_uncovered_rows_are_zero(T):
     from cnn_amd import capi
 
