@@ -1,0 +1,363 @@
+// conv_fwd_rd.hip -- "register-direct" Conv2D forward (cpu/src/conv2d.cpp:60-113) for the mid-size 3x3 layers of the
+// reference net (stride 1 or 2, no padding, even Ci <= 64): the GEMM
+//     y[co][pixel] = bias[co] + sum_{ci,kx,ky} w[co][ci][kx][ky] * x[ci][s*p + kx][s*q + ky]
+// on v_mfma_f32_32x32x2_f32 with M = output channels and N = 32 consecutive output pixels (linear (b,p,q) order):
+//   * A operand (filters): the workgroup's Co-slice of w sits in LDS for the whole kernel, laid out so that a step's
+//     32 channels are 32 consecutive floats (conflict-free ds_read with immediate offsets);
+//   * B operand (input): k-slot kg of the MFMA handles the input channels [kg*Ci/2, (kg+1)*Ci/2), so lane (pixel n, kg)
+//     needs x[ci][s*p+kx][s*q + 0..2] -- THREE CONSECUTIVE floats per (ci,kx): one 12-byte load straight into the
+//     operand registers feeds three MFMA steps; across lanes the addresses advance by s floats (coalesced).
+//     All per-step offsets are wave-uniform (scalar base + one per-lane offset for the whole tile): no address VALU.
+//   * no LDS staging of the input, no barriers after the filter upload; the loads are software-pipelined by hand one
+//     channel group ahead of the MFMAs (RD_PIPE_FENCE as in conv_wgrad_rd.hip).
+// The accumulators start from the bias, the epilogue stores rows of 32 consecutive pixels (128-byte segments) and,
+// for the fused Conv+ReLU entry, max(y, 0) to the second tensor.
+#include <cstdlib>
+
+#include "common.h"
+
+using namespace cnn_amd;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct __attribute__((packed, aligned(4))) f3u {
+    float x, y, z;
+};
+
+#define RD_PIPE_FENCE(reg) asm volatile("" : "+v"(reg) : : "memory")
+
+struct FwdRdParams {
+    const float* x;
+    const float* w;     // [Co][Ci][3][3]
+    const float* img;   // prepared LDS images (fwd_rd_prepare_batch), one per channel group -- or null: transpose from w
+    const float* bias;  // [Co]
+    float* y;
+    float* y2;  // relu(y), or null
+    int B, H, W, Co, Ho, Wo, HoWo;
+    int pixels, tiles;       // B*Ho*Wo, ceil(pixels / 32)
+    unsigned m_howo, m_wo;   // magic multipliers
+    int dbg;                 // CNN_AMD_FWD_RD_DBG=1: workgroup 0 prints its phase cycle counts
+};
+
+__device__ __forceinline__ int fdiv(int n, unsigned magic, int d) {
+    if (d == 1) return n;
+    int q = (int)__umulhi((unsigned)n, magic);
+    if (q * d > n) --q;
+    return q;
+}
+
+// S stride, CI input channels (even), MT 32-channel output tiles per wave, NW waves per workgroup, UC channels per group
+template <int S, int CI, int MT, int NW, int UC>
+__global__ __launch_bounds__(NW * 64) void conv_fwd_rd_kernel(const FwdRdParams p) {
+    constexpr int CH = CI / 2;      // channels per k-slot
+    constexpr int G = CH / UC;      // pipeline groups per tile
+    constexpr int CB = MT * 32;     // output channels per workgroup
+    constexpr int CBP = CB + 1;     // LDS row pitch (odd: the transposing upload below is bank-conflict free)
+    static_assert(CH % UC == 0 && (CH / UC) % 2 == 0, "an even number of groups per tile (the two buffers swap per group)");
+    extern __shared__ float lw[];   // [CI*9][CBP]: lw[k][c] = w[co0 + c][k]
+    const int lane = threadIdx.x & 63, n = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int co0 = blockIdx.y * CB;
+    const long long dbg_t0 = p.dbg ? clock64() : 0;
+
+    constexpr int IMG = (CI * 9 * CBP + CB + 3) / 4 * 4;  // floats of one channel group's LDS image: filters, then bias
+    if (p.img) {
+        // prepared image: a straight 16-byte copy
+        const float4* src = (const float4*)(p.img + (size_t)blockIdx.y * IMG);
+        constexpr int N4 = IMG / 4, NTH = NW * 64, U = 5;
+        for (int base = threadIdx.x; base < N4; base += NTH * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = src[base + u * NTH < N4 ? base + u * NTH : 0];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (base + u * NTH < N4) ((float4*)lw)[base + u * NTH] = v[u];
+        }
+    } else {
+        // filter slice -> LDS, transposed; loads batched so that a workgroup pays a handful of L2 round trips, not one
+        // per element (the slice is one contiguous piece of w)
+        constexpr int TOT = CB * CI * 9, NTH = NW * 64, U = 9;
+        static_assert(TOT % (NTH * U) == 0, "upload batches");
+        const float* wsrc = p.w + (size_t)co0 * CI * 9;
+        const int live_floats = (p.Co - co0 < CB ? p.Co - co0 : CB) * CI * 9;  // channels beyond Co read as 0
+        for (int base = threadIdx.x; base < TOT; base += NTH * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = base + u * NTH;
+                v[u] = wsrc[e < live_floats ? e : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = base + u * NTH, cl = e / (CI * 9), r = e - cl * (CI * 9);
+                lw[r * CBP + cl] = e < live_floats ? v[u] : 0.f;
+            }
+        }
+        float* lbias = lw + CI * 9 * CBP;
+        if (threadIdx.x < CB) lbias[threadIdx.x] = co0 + threadIdx.x < p.Co ? p.bias[co0 + threadIdx.x] : 0.f;
+    }
+    __syncthreads();
+    f32x16 bias_r[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias_r[mt][r] = lw[CI * 9 * CBP + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
+
+    const long long dbg_t1 = p.dbg ? clock64() : 0;
+    const float* lwl = lw + (kg * CH * 9) * CBP + n;  // this lane's A column
+    const unsigned plane = (unsigned)(p.H * p.W);
+    const int tstep = gridDim.x * NW;
+
+    auto locate = [&](int tile, unsigned& xoff, unsigned& yoff, bool& live) {
+        const int pi = tile * 32 + n;
+        live = pi < p.pixels;
+        const int pic = live ? pi : p.pixels - 1;
+        const int b = fdiv(pic, p.m_howo, p.HoWo), rem = pic - b * p.HoWo;
+        const int pr = fdiv(rem, p.m_wo, p.Wo), q = rem - pr * p.Wo;
+        xoff = (unsigned)((b * CI + kg * CH) * (int)plane + (S * pr) * p.W + S * q);
+        yoff = (unsigned)((b * p.Co + co0 + 4 * kg) * p.HoWo + rem);
+    };
+    auto load_group = [&](f3u (&buf)[UC * 3], int g, unsigned xoff) {
+#pragma unroll
+        for (int u = 0; u < UC; ++u)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float* base = p.x + ((size_t)(g * UC + u) * plane + (size_t)kx * p.W);  // wave-uniform
+                buf[u * 3 + kx] = *(const f3u*)(base + xoff);
+            }
+    };
+
+    int tile = blockIdx.x * NW + wave;
+    if (tile >= p.tiles) return;
+    unsigned xoff, yoff, nxoff = 0, nyoff = 0;
+    bool live, nlive = false;
+    locate(tile, xoff, yoff, live);
+    auto load_filters = [&](float (&a)[MT * UC * 9], int g) {
+#pragma unroll
+        for (int i = 0; i < UC * 9; ++i)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[i * MT + mt] = lwl[(g * UC * 9 + i) * CBP + mt * 32];
+    };
+    // input windows: a ring of NB groups, requested NB-1 groups (~1150 MFMA cycles each) ahead -- with one or two waves
+    // per SIMD nothing else covers an HBM / Infinity-Cache miss; filter values: two buffers (LDS latency only)
+    constexpr int NB = 4;
+    static_assert(G % NB == 0, "the ring index must line up from tile to tile");
+    f3u xb[NB][UC * 3];
+    float ab[2][MT * UC * 9];
+    {
+        const bool more0 = tile + tstep < p.tiles;
+        if (more0) locate(tile + tstep, nxoff, nyoff, nlive);
+#pragma unroll
+        for (int g = 0; g < NB - 1; ++g) {
+            if (g < G) load_group(xb[g], g, xoff);
+            else if (more0) load_group(xb[g], g - G, nxoff);
+        }
+    }
+    load_filters(ab[0], 0);
+    for (; tile < p.tiles; tile += tstep) {
+        const bool more = tile + tstep < p.tiles;
+        if (more) locate(tile + tstep, nxoff, nyoff, nlive);
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = bias_r[mt];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int bi = g & 1, ri = g % NB, gp = g + NB - 1;  // gp: the group requested now
+            if (gp < G) load_group(xb[gp % NB], gp, xoff);
+            else if (more) load_group(xb[gp % NB], gp - G, nxoff);
+            load_filters(ab[bi ^ 1], g + 1 < G ? g + 1 : 0);
+            RD_PIPE_FENCE(ab[bi][0]);
+#pragma unroll
+            for (int u = 0; u < UC; ++u)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const f3u v = xb[ri][u * 3 + kx];
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const float bv = ky == 0 ? v.x : ky == 1 ? v.y : v.z;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[bi][((u * 3 + kx) * 3 + ky) * MT + mt], bv, acc[mt], 0, 0, 0);
+                    }
+                }
+        }
+        const long long dbg_t2 = p.dbg ? clock64() : 0;
+        // ---- epilogue: rows of 32 consecutive pixels
+        if (live) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rowl = mt * 32 + (r & 3) + 8 * (r >> 2);  // (+ 4*kg is inside yoff)
+                    if (co0 + rowl + 4 * kg < p.Co) {
+                        const size_t o = (size_t)yoff + (size_t)rowl * p.HoWo;
+                        const float v = acc[mt][r];
+                        p.y[o] = v;
+                        if (p.y2) p.y2[o] = v > 0.f ? v : 0.f;
+                    }
+                }
+        }
+        if (p.dbg && threadIdx.x == 0 && (blockIdx.x | blockIdx.y) == 0)
+            printf("conv_fwd_rd wg 0: upload %lld, to end of MFMAs %lld, stores issued %lld cycles after start\n", dbg_t1 - dbg_t0,
+                   dbg_t2 - dbg_t0, clock64() - dbg_t0);
+        xoff = nxoff;
+        yoff = nyoff;
+        live = nlive;
+    }
+}
+
+inline unsigned magic_of(int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
+
+struct FwdRdPlan {
+    FwdRdParams p;
+    int s, ci, mt, nw, cgroups, blocks_x;
+    size_t lds, img_floats;
+};
+
+bool make_plan(const cnn_conv2d_desc* d, FwdRdPlan* pl) {
+    if (d->k != 3 || d->pad != 0 || (d->s != 1 && d->s != 2)) return false;
+    if (d->Ci != 16 && d->Ci != 32 && d->Ci != 64) return false;
+    if (const char* e = getenv("CNN_AMD_FWD_RD"))
+        if (atoi(e) == 0) return false;
+    FwdRdParams& p = pl->p;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Co = d->Co;
+    p.Ho = cnn_conv2d_out_dim(d->H, 3, d->s, 0);
+    p.Wo = cnn_conv2d_out_dim(d->W, 3, d->s, 0);
+    if (p.Ho <= 0 || p.Wo <= 0) return false;
+    p.HoWo = p.Ho * p.Wo;
+    const long long pixels = (long long)d->B * p.HoWo;
+    if (pixels >= (1ll << 30) || (long long)d->B * d->Ci * d->H * d->W >= (1ll << 31) || pixels * d->Co >= (1ll << 31)) return false;
+    p.pixels = (int)pixels;
+    p.tiles = (int)((pixels + 31) / 32);
+    p.m_howo = magic_of(p.HoWo);
+    p.m_wo = magic_of(p.Wo);
+    p.dbg = getenv("CNN_AMD_FWD_RD_DBG") ? atoi(getenv("CNN_AMD_FWD_RD_DBG")) : 0;
+    pl->s = d->s;
+    pl->ci = d->Ci;
+    const int mtiles = (d->Co + 31) / 32;
+    // output tiles per wave: keep the filter slice within LDS and the grid above one wave per SIMD
+    // two tiles per wave halve the input reads, but only pay once every wave slot still gets a few items
+    int mt = mtiles >= 2 && (long long)p.tiles * ((mtiles + 1) / 2) >= 4 * 4 * kNumCU ? 2 : 1;
+    if ((size_t)(mt * 32 + 1) * d->Ci * 9 * 4 > 96 * 1024) mt = 1;
+    if (const char* e = getenv("CNN_AMD_FWD_RD_MT")) mt = atoi(e) == 2 && mtiles >= 2 ? 2 : 1;
+    pl->mt = mt;
+    pl->cgroups = (mtiles + mt - 1) / mt;
+    pl->img_floats = ((size_t)(mt * 32 + 1) * d->Ci * 9 + mt * 32 + 3) / 4 * 4;  // filters + bias, whole float4s
+    pl->lds = pl->img_floats * sizeof(float);
+    pl->nw = pl->lds > 80 * 1024 ? 8 : 4;  // a filter slice that allows one workgroup per CU gets 8 waves
+    const int env = getenv("CNN_AMD_FWD_RD_BLOCKS") ? atoi(getenv("CNN_AMD_FWD_RD_BLOCKS")) : 0;
+    long long bx = (env > 0 ? env : (pl->nw == 8 ? kNumCU : 2 * kNumCU)) / pl->cgroups;
+    const long long need = (p.tiles + pl->nw - 1) / pl->nw;
+    if (bx > need) bx = need;
+    if (bx < 1) bx = 1;
+    pl->blocks_x = (int)bx;
+    return true;
+}
+
+template <int S, int CI, int MT, int NW>
+int launch(const FwdRdPlan& pl, hipStream_t s, const char* name, const cnn_conv2d_desc* d) {
+    auto kern = conv_fwd_rd_kernel<S, CI, MT, NW, 2>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const dim3 grid(pl.blocks_x, pl.cgroups);
+    CNN_KLAUNCH(s, name, (kern<<<grid, NW * 64, pl.lds, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W,
+                d->Co, d->k, d->s, d->pad);
+    return CNN_AMD_OK;
+}
+
+struct FwdRdPrepJob {
+    const float* w;
+    const float* bias;
+    float* img;
+    int Co, Ci, cb, img_floats, cgroups;
+};
+struct FwdRdPrepBatch {
+    FwdRdPrepJob job[6];
+};
+
+// one workgroup column per job: img[g][k*CBP + c] = w[g*cb + c][k], then the group's bias
+__global__ __launch_bounds__(256) void fwd_rd_prepare_kernel(const FwdRdPrepBatch pb) {
+    const FwdRdPrepJob j = pb.job[blockIdx.y];
+    const int K = j.Ci * 9, cbp = j.cb + 1, total = j.cgroups * j.img_floats;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int g = i / j.img_floats, o = i - g * j.img_floats;
+        float v = 0.f;
+        if (o < K * cbp) {
+            const int k = o / cbp, c = o - k * cbp, co = g * j.cb + c;
+            if (c < j.cb && co < j.Co) v = j.w[(size_t)co * K + k];
+        } else if (o < K * cbp + j.cb) {
+            const int co = g * j.cb + (o - K * cbp);
+            if (co < j.Co) v = j.bias[co];
+        }
+        j.img[i] = v;
+    }
+}
+
+}  // namespace
+
+namespace cnn_amd {
+
+bool fwd_rd_supported(const cnn_conv2d_desc* d) {
+    FwdRdPlan pl;
+    return make_plan(d, &pl);
+}
+
+// floats of the prepared filter images of a layer (0: not an RD layer)
+size_t fwd_rd_prepared_floats(const cnn_conv2d_desc* d) {
+    FwdRdPlan pl;
+    return make_plan(d, &pl) ? pl.img_floats * pl.cgroups : 0;
+}
+
+// prepares every layer of the batch this file covers (one launch); sets their bits in *done
+int fwd_rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, const float* const* bias, void* const* fwd,
+                         hipStream_t s, unsigned* done) {
+    FwdRdPrepBatch pb;
+    int jobs = 0;
+    size_t most = 0;
+    for (int i = 0; i < n && i < 6; ++i) {
+        FwdRdPlan pl;
+        if (!fwd || !fwd[i] || (*done >> i & 1u) || !make_plan(&descs[i], &pl)) continue;
+        CNN_REQUIRE(w[i] && bias[i], "cnn_conv2d_prepare_filters: filters / bias of layer %d are null", i);
+        FwdRdPrepJob& j = pb.job[jobs++];
+        j.w = w[i]; j.bias = bias[i]; j.img = (float*)fwd[i];
+        j.Co = descs[i].Co; j.Ci = descs[i].Ci; j.cb = pl.mt * 32; j.img_floats = (int)pl.img_floats; j.cgroups = pl.cgroups;
+        if (pl.img_floats * pl.cgroups > most) most = pl.img_floats * pl.cgroups;
+        *done |= 1u << i;
+    }
+    if (jobs) {
+        unsigned gx = (unsigned)((most + 255) / 256);
+        if (gx > 512) gx = 512;
+        CNN_KLAUNCH(s, "fwd_rd_prepare", (fwd_rd_prepare_kernel<<<dim3(gx, jobs), 256, 0, s>>>(pb)), "jobs=%d", jobs);
+    }
+    return CNN_AMD_OK;
+}
+
+// w == nullptr: `img` holds the prepared images
+int fwd_rd_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* img, const float* bias, float* y,
+                   float* y_relu, hipStream_t s) {
+    FwdRdPlan pl;
+    if (!make_plan(d, &pl)) return fail(CNN_AMD_E_BADARG, "conv_fwd_rd: geometry not covered");
+    pl.p.x = x; pl.p.w = w; pl.p.img = w ? nullptr : img; pl.p.bias = bias; pl.p.y = y; pl.p.y2 = y_relu;
+    char name[64];
+    snprintf(name, sizeof(name), "conv_fwd_rd<%d,%d,%d>/fwd%s", d->s, d->Ci, pl.mt, y_relu ? "+relu" : "");
+#define GO(S_, CI_)                                                                                  \
+    do {                                                                                             \
+        if (pl.mt == 2 && pl.nw == 8) return launch<S_, CI_, 2, 8>(pl, s, name, d);                  \
+        if (pl.mt == 2) return launch<S_, CI_, 2, 4>(pl, s, name, d);                                \
+        if (pl.nw == 8) return launch<S_, CI_, 1, 8>(pl, s, name, d);                                \
+        return launch<S_, CI_, 1, 4>(pl, s, name, d);                                                \
+    } while (0)
+    if (d->s == 2) {
+        if (d->Ci == 16) GO(2, 16); else if (d->Ci == 32) GO(2, 32); else GO(2, 64);
+    } else {
+        if (d->Ci == 16) GO(1, 16); else if (d->Ci == 32) GO(1, 32); else GO(1, 64);
+    }
+#undef GO
+    return CNN_AMD_OK;
+}
+
+}  // namespace cnn_amd

@@ -1249,6 +1249,12 @@ int direct_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const
                          void* const* fwd, void* const* dgrad, hipStream_t s, unsigned* fwd_done, unsigned* dgrad_done);
 bool direct_prepared_fwd_ok(const cnn_conv2d_desc* d);
 bool direct_prepared_dgrad_ok(const cnn_conv2d_desc* d);
+bool fwd_rd_supported(const cnn_conv2d_desc* d);  // conv_fwd_rd.hip: register-direct forward of the mid-size 3x3 layers
+size_t fwd_rd_prepared_floats(const cnn_conv2d_desc* d);
+int fwd_rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, const float* const* bias, void* const* fwd,
+                         hipStream_t s, unsigned* done);
+int fwd_rd_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* img, const float* bias, float* y,
+                   float* y_relu, hipStream_t s);
 bool pk_dgrad_s2_supported(const cnn_conv2d_desc* d);  // conv_direct.hip: packed VALU dgrad for small stride-2 layers
 size_t pk_dgrad_s2_workspace_floats(const cnn_conv2d_desc* d);
 int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, hipStream_t s, bool prepared);
@@ -1260,6 +1266,7 @@ size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
     if (make_plan("ws", d, MODE_DGRAD, &b) == CNN_AMD_OK && b.a_floats > n) n = b.a_floats;
     if (direct_conv_supported(d) && n < 1024) n = 1024;  // packed filter copies of the direct kernels (conv_direct.hip)
     if (pk_dgrad_s2_supported(d) && n < pk_dgrad_s2_workspace_floats(d)) n = pk_dgrad_s2_workspace_floats(d);
+    if (fwd_rd_prepared_floats(d) > n) n = fwd_rd_prepared_floats(d);
     return n;
 }
 }  // namespace cnn_amd
@@ -1271,6 +1278,8 @@ static int conv2d_forward_impl(const char* who, const cnn_conv2d_desc* d, const 
     if (int rc = check_desc(who, d)) return rc;
     CNN_REQUIRE(x && (w || prepared) && bias && y, "%s: null pointer", who);
     if (direct_conv_supported(d)) return direct_conv_forward(d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream), prepared);
+    if (fwd_rd_supported(d))
+        return fwd_rd_forward(d, x, prepared ? nullptr : w, prepared ? (const float*)ws : nullptr, bias, y, y_relu, as_stream(stream));
     Plan pl;
     if (int rc = make_plan(who, d, MODE_FWD, &pl)) return rc;
     return run_plan(pl, d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream), who, prepared);
@@ -1316,6 +1325,7 @@ int cnn_conv2d_prepare_filters(int n, const cnn_conv2d_desc* descs, const float*
     hipStream_t s = as_stream(stream);
     unsigned fdone = 0, ddone = 0;
     if (int rc = direct_prepare_batch(n, descs, w, bias, fwd, dgrad, s, &fdone, &ddone)) return rc;
+    if (int rc = fwd_rd_prepare_batch(n, descs, w, bias, fwd, s, &fdone)) return rc;
     PrepBatch pb;
     pb.n = 0;
     long long most = 0;

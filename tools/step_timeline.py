@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Timeline of one steady-state train step from a rocprofv3 --kernel-trace CSV: start offset, duration and queue of every
+kernel between two consecutive sgd_vec launches (the last kernel of a step), plus how long the GPU was busy / idle.
+usage: step_timeline.py <bench_kernel_trace.csv> [step_index_from_end=3]"""
+import csv
+import re
+import sys
+
+rows = []
+for r in csv.DictReader(open(sys.argv[1])):
+    name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+    name = re.sub(r"^void ", "", name).split("(")[0]
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
+rows.sort()
+ends = [i for i, r in enumerate(rows) if r[2].startswith("sgd_vec")]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+lo, hi = ends[-k - 1] + 1, ends[-k] + 1
+step = rows[lo:hi]
+t0 = rows[ends[-k - 1]][1]
+print(f"step of {len(step)} kernels, {(step[-1][1] - t0) / 1e3:.1f} us from the end of the previous sgd_vec to the end of this one")
+busy_until, idle = t0, 0
+for s, e, name, q, st in step:
+    if s > busy_until:
+        idle += s - busy_until
+    busy_until = max(busy_until, e)
+    print(f"{(s - t0) / 1e3:8.1f} us  +{(e - s) / 1e3:7.1f} us  q{q:>2} s{st:>2}  {name[:90]}")
+print(f"GPU idle (no kernel resident) {idle / 1e3:.1f} us")
