@@ -196,7 +196,7 @@ def main():
     B = args.batch
     # defer_input_grad: conv_layer_1's data gradient (no consumer) is launched one forward pass later on a second stream;
     # barrier() flushes it, so the timed region contains exactly K of them (cnn_amd/pynet.py)
-    net = AlexNetHip(B, 3, defer_input_grad=True)
+    net = AlexNetHip(B, 3, defer_input_grad=True, fuse_pool=not os.environ.get("CNN_AMD_NO_POOL_FUSION"))
     rs = np.random.RandomState(1234)  # identical init on every rank: replicas stay in lock-step without a broadcast
     net.load_params((rs.standard_normal(net.n_params) * 0.1).astype(np.float32))
     g = torch.Generator(device="cuda").manual_seed(100 + rank)  # each rank has its own shard of the global batch

@@ -37,6 +37,9 @@ SIGNATURES = {
     "cnn_conv2d_workspace_bytes": (C.c_size_t, [_D]),
     "cnn_conv2d_forward": (C.c_int, [_D, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_forward_relu": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cnn_conv2d_relu_maxpool2_supported": (C.c_int, [_D]),
+    "cnn_conv2d_relu_maxpool2_forward": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cnn_conv2d_relu_maxpool2_forward_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P]),
     "cnn_conv2d_prepared_bytes": (C.c_size_t, [_D]),
     "cnn_conv2d_prepare_filters": (C.c_int, [C.c_int, _D, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                              C.POINTER(C.c_void_p), _P]),
@@ -162,6 +165,22 @@ class Conv2d:
         check(self.lib.cnn_conv2d_forward_relu(C.byref(self.desc), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(y_relu),
                                                _ptr(self.ws), self.ws_bytes, _stream()), "cnn_conv2d_forward_relu")
         return y_relu
+
+    def relu_maxpool2_supported(self):
+        return bool(self.lib.cnn_conv2d_relu_maxpool2_supported(C.byref(self.desc)))
+
+    def relu_maxpool2_forward(self, x, w, bias, pooled, mask=None, prepared_fwd=None):
+        """Conv2D -> ReLU -> MaxPool2D(2,2) in one kernel: writes pooled (and mask); from prepared filters when given"""
+        _need_gpu(x, pooled)
+        if prepared_fwd is not None:
+            check(self.lib.cnn_conv2d_relu_maxpool2_forward_prepared(C.byref(self.desc), _ptr(x), _ptr(prepared_fwd), _ptr(pooled),
+                                                                     _ptr(mask) if mask is not None else None, _stream()),
+                  "cnn_conv2d_relu_maxpool2_forward_prepared")
+        else:
+            check(self.lib.cnn_conv2d_relu_maxpool2_forward(C.byref(self.desc), _ptr(x), _ptr(w), _ptr(bias), _ptr(pooled),
+                                                            _ptr(mask) if mask is not None else None, _ptr(self.ws), self.ws_bytes,
+                                                            _stream()), "cnn_conv2d_relu_maxpool2_forward")
+        return pooled
 
     def backward_weight(self, x, dy, divisor, gw=None, gb=None, want_bias=True):
         import torch

@@ -522,6 +522,103 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_pk_3_16_3_2(const float* __re
     }
 }
 
+// ---- Conv2D -> ReLU -> MaxPool2D(2, 2) of the reference's first block (alexnet.cpp:12-15) in one kernel --------------
+// The separate kernels move 558 MB (conv reads x, writes y and relu(y)) + 250 MB (pool reads relu(y), writes pooled and
+// mask); nothing downstream reads y or relu(y) again (the backward pass needs pooled + mask only, see
+// cnn_maxpool2d_backward_relu), so this kernel writes ONLY pooled and mask: 154 MB in, 100 MB out.
+// Lane pairs (2i, 2i+1) own one pooling window: lane j of the pair computes the conv outputs of window column j for both
+// window rows (5 input rows x 3 floats x 3 channels = 45 loads for 2 x 27 taps), in exactly the tap order of
+// conv_fwd_pk_3_16_3_2 (bit-identical y), applies bias and ReLU, swaps values with its neighbour through DPP and the
+// even lane scans the window in the reference's order (pool2d.cpp:67-75: first maximum wins, strict '<').
+__global__ __launch_bounds__(kBlock) void conv_fwd_pool_pk_3_16_3_2(const float* __restrict__ x, const v2f* __restrict__ wp,
+                                                                    float* __restrict__ pooled, int32_t* __restrict__ mask,
+                                                                    int B, int H, int W, int Ho, int Wo, int PHo, int PWo,
+                                                                    int items_per_img, unsigned m_ipi, unsigned m_prow) {
+    constexpr int CI = 3, CO = 16, K = 3;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long items = (long long)B * items_per_img;
+    const int half = 2 * PHo * PWo;  // window columns per image
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * CI * H * W * 4u), 0x00020000);
+    const int out_bytes = (int)((unsigned)B * CO * PHo * PWo * 4u);
+    const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc((void*)pooled, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)(mask ? mask : (int32_t*)pooled), 0, out_bytes, 0x00020000);
+    for (int it = blockIdx.x * kWaves + wave; it < (int)items; it += gridDim.x * kWaves) {
+        const int b = fast_div(it, m_ipi, items_per_img);
+        const int n2 = (it - b * items_per_img) * 64 + lane;
+        const bool live = n2 < half;
+        const int pp = (live ? n2 : 0) >> 1, j = n2 & 1;
+        const int ph = fast_div(pp, m_prow, PWo), pw = pp - ph * PWo;
+        const int q = 2 * pw + j;  // conv column; conv rows 2ph and 2ph + 1
+        const unsigned vo = live ? (unsigned)(4 * ph * W + 2 * q) * 4u : kBufOOB;  // x[.][4ph][2q]
+        float patch[CI][5][K];
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int so = (((b * CI + ci) * H + r) * W) * 4;  // wave-uniform
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky)
+                    patch[ci][r][ky] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)vo, so + 4 * ky, 0));
+            }
+        v2f acc0[CO / 2], acc1[CO / 2];
+#pragma unroll
+        for (int c = 0; c < CO / 2; ++c) acc0[c] = acc1[c] = v2f{0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < CI * K * K; ++t) {
+            asm volatile("" ::: "memory");  // stream the weight s_loads tap by tap (see conv_dgrad_pk)
+            const int ci = t / 9, kx = (t - ci * 9) / 3, ky = t - ci * 9 - kx * 3;
+            const v2f* qw = wp + t * (CO / 2);
+            const v2f p0 = {patch[ci][kx][ky], patch[ci][kx][ky]}, p1 = {patch[ci][kx + 2][ky], patch[ci][kx + 2][ky]};
+#pragma unroll
+            for (int c = 0; c < CO / 2; ++c) {
+                acc0[c] = __builtin_elementwise_fma(qw[c], p0, acc0[c]);
+                acc1[c] = __builtin_elementwise_fma(qw[c], p1, acc1[c]);
+            }
+        }
+        asm volatile("" ::: "memory");
+        const v2f* qb = wp + CI * K * K * (CO / 2);
+        // (all selects first, ONE branch around the stores: a branch per channel made hipcc keep 16 exec masks in SGPRs
+        //  and spill the weight registers through v_writelane -- 3098 lane moves in the first version of this kernel)
+        float bestv[CO];
+        int offv[CO];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            const float bsv = (c & 1) ? qb[c / 2].y : qb[c / 2].x;
+            float a = ((c & 1) ? acc0[c / 2].y : acc0[c / 2].x) + bsv;  // conv row 2ph
+            float d = ((c & 1) ? acc1[c / 2].y : acc1[c / 2].x) + bsv;  // conv row 2ph + 1
+            a = a >= 0.f ? a : 0.f;  // relu.cpp:21-26
+            d = d >= 0.f ? d : 0.f;
+            const float pa = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0xB1, 0xf, 0xf, true));
+            const float pd = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d), 0xB1, 0xf, 0xf, true));
+            float best = a;
+            int off = 0;
+            const bool c1 = best < pa;
+            best = c1 ? pa : best; off = c1 ? 1 : off;
+            const bool c2 = best < d;
+            best = c2 ? d : best; off = c2 ? Wo : off;
+            const bool c3 = best < pd;
+            best = c3 ? pd : best; off = c3 ? Wo + 1 : off;
+            bestv[c] = best;
+            offv[c] = off;
+        }
+        // raw buffer stores: one per-lane byte offset + a scalar channel offset (64-bit per-channel pointers in SGPR pairs
+        // were the other half of the spills); lanes that own no window store out of range = nowhere
+        const unsigned so_lane = (live && j == 0) ? (unsigned)(ph * PWo + pw) * 4u : kBufOOB;
+        const int mbase = 2 * ph * Wo + 2 * pw;
+        const int PP4 = PHo * PWo * 4;
+        const int soff = b * CO * PP4;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, bestv[c]), rpool, (int)so_lane, soff + c * PP4, 0);
+        if (mask) {
+#pragma unroll
+            for (int c = 0; c < CO; ++c)
+                __builtin_amdgcn_raw_buffer_store_b32(c * Ho * Wo + mbase + offv[c], rmask, (int)so_lane, soff + c * PP4, 0);
+        }
+    }
+}
+
 // ---- packed-math weight + bias gradient for the same layer ----------------------------------------------------------
 // gw[co][t] = sum_pixels dy[co][pixel] * patch[t][pixel], t = (ci,kx,ky); gb[co] = sum_pixels dy[co][pixel]
 // (conv2d.cpp:117-159 without the 1/B, which the slab reduction applies).  K = 27 is far too thin for MFMA tiles, so
@@ -694,6 +791,29 @@ int direct_conv_forward(const cnn_conv2d_desc* d, const float* x, const float* w
     const long long rows = (long long)d->B * Ho;
     CNN_KLAUNCH(s, y_relu ? "conv_direct_fwd<3,16,3,2>+relu" : "conv_direct_fwd<3,16,3,2>",
                 (conv_direct_fwd<3, 16, 3, 2><<<wave_grid(rows), kBlock, 0, s>>>(x, w, bias, y, y_relu, d->B, d->H, d->W, Ho, Wo)),
+                CONV_TAG(d));
+    return CNN_AMD_OK;
+}
+
+// Conv2D -> ReLU -> MaxPool2D(2,2) fused (see conv_fwd_pool_pk_3_16_3_2)
+bool direct_conv_pool_supported(const cnn_conv2d_desc* d) {
+    const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
+    return direct_conv_supported(d) && direct_fwd_pk_ok(d) && Ho >= 2 && Wo >= 2 && (long long)16 * Ho * Wo < (1ll << 31) &&
+           (long long)d->B * 16 * (Ho / 2) * (Wo / 2) * 4 < (1ll << 31) - 16 && !getenv("CNN_AMD_NO_POOL_FUSION");
+}
+int direct_conv_pool_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* pooled,
+                             int32_t* mask, void* ws, size_t ws_bytes, hipStream_t s, bool prepared) {
+    CNN_REQUIRE(direct_conv_pool_supported(d), "cnn_conv2d_relu_maxpool2_forward: geometry not covered (3->16 channels, 3x3 stride 2)");
+    CNN_REQUIRE(ws != nullptr && ws_bytes >= 28 * 16 * sizeof(float), "cnn_conv2d_relu_maxpool2_forward: workspace too small");
+    const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
+    const int PHo = Ho / 2, PWo = Wo / 2;
+    if (!prepared)
+        CNN_KLAUNCH(s, "pack_fwd_weights", (pack_fwd_weights_3_16_3_2<<<1, 256, 0, s>>>(w, bias, (float*)ws)), CONV_TAG(d));
+    const int ipi = (2 * PHo * PWo + 63) / 64;
+    const long long witems = (long long)d->B * ipi;
+    CNN_KLAUNCH(s, "conv_fwd_pool_pk<3,16,3,2>",
+                (conv_fwd_pool_pk_3_16_3_2<<<wave_grid(witems), kBlock, 0, s>>>(x, (const v2f*)ws, pooled, mask, d->B, d->H, d->W, Ho, Wo,
+                                                                               PHo, PWo, ipi, div_magic(ipi), div_magic(PWo))),
                 CONV_TAG(d));
     return CNN_AMD_OK;
 }

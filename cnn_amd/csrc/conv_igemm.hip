@@ -1249,6 +1249,9 @@ int direct_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const
                          void* const* fwd, void* const* dgrad, hipStream_t s, unsigned* fwd_done, unsigned* dgrad_done);
 bool direct_prepared_fwd_ok(const cnn_conv2d_desc* d);
 bool direct_prepared_dgrad_ok(const cnn_conv2d_desc* d);
+bool direct_conv_pool_supported(const cnn_conv2d_desc* d);  // conv_direct.hip: Conv -> ReLU -> MaxPool(2,2) in one kernel
+int direct_conv_pool_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* pooled,
+                             int32_t* mask, void* ws, size_t ws_bytes, hipStream_t s, bool prepared);
 bool fwd_rd_supported(const cnn_conv2d_desc* d);  // conv_fwd_rd.hip: register-direct forward of the mid-size 3x3 layers
 size_t fwd_rd_prepared_floats(const cnn_conv2d_desc* d);
 int fwd_rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, const float* const* bias, void* const* fwd,
@@ -1311,6 +1314,27 @@ int cnn_conv2d_forward_relu(const cnn_conv2d_desc* d, const float* x, const floa
 int cnn_conv2d_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws,
                              size_t ws_bytes, void* stream) {
     return conv2d_backward_data_impl("cnn_conv2d_backward_data", d, dy, w, dx, ws, ws_bytes, stream, false);
+}
+
+/* ---- Conv2D -> ReLU -> MaxPool2D(2,2) ---- */
+int cnn_conv2d_relu_maxpool2_supported(const cnn_conv2d_desc* d) {
+    if (check_desc("cnn_conv2d_relu_maxpool2_supported", d)) return 0;
+    return direct_conv_pool_supported(d) ? 1 : 0;
+}
+
+int cnn_conv2d_relu_maxpool2_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* pooled,
+                                     int32_t* mask, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = check_desc("cnn_conv2d_relu_maxpool2_forward", d)) return rc;
+    CNN_REQUIRE(x && w && bias && pooled, "cnn_conv2d_relu_maxpool2_forward: null pointer");
+    return direct_conv_pool_forward(d, x, w, bias, pooled, mask, ws, ws_bytes, as_stream(stream), false);
+}
+
+int cnn_conv2d_relu_maxpool2_forward_prepared(const cnn_conv2d_desc* d, const float* x, const void* prepared_fwd, float* pooled,
+                                              int32_t* mask, void* stream) {
+    if (int rc = check_desc("cnn_conv2d_relu_maxpool2_forward_prepared", d)) return rc;
+    CNN_REQUIRE(x && prepared_fwd && pooled, "cnn_conv2d_relu_maxpool2_forward_prepared: null pointer");
+    return direct_conv_pool_forward(d, x, nullptr, nullptr, pooled, mask, (void*)prepared_fwd, cnn_conv2d_prepared_bytes(d),
+                                    as_stream(stream), true);
 }
 
 /* ---- filter preparation hoisted out of the per-layer calls ---- */

@@ -15,7 +15,7 @@ from . import capi
 class AlexNetHip:
     CHANS = [3, 16, 32, 64, 128]
 
-    def __init__(self, batch, classes=3, H=224, W=224, device="cuda", fuse=True, defer_input_grad=False):
+    def __init__(self, batch, classes=3, H=224, W=224, device="cuda", fuse=True, defer_input_grad=False, fuse_pool=False):
         import torch
 
         self.torch = torch
@@ -64,6 +64,9 @@ class AlexNetHip:
         import os
 
         self.use_prep = fuse and not os.environ.get("CNN_AMD_NO_PREPARED")  # (A/B switch for measurements)
+        # conv_layer_1 -> relu_layer_1 -> max_pool_1 as one kernel: conv_out[0] / relu_out[0] are then NOT written (nothing in
+        # the step reads them: the backward pass of that block works from pool_out + pool_mask)
+        self.fuse_pool = bool(fuse_pool) and self.use_prep and self.convs[0].relu_maxpool2_supported()
         self.prep = [c.prepared_buffers(device) for c in self.convs] if self.use_prep else None
         # The data gradient of conv_layer_1 (the delta w.r.t. the input image, conv2d.cpp:168-199) has no consumer: nothing
         # waits for it.  It is still computed every step, but as a DEFERRED launch on a second stream that is released
@@ -149,6 +152,11 @@ class AlexNetHip:
         if self.use_prep:
             self._prepare()
         for l in range(4):
+            if l == 0 and self.fuse_pool:
+                self.convs[0].relu_maxpool2_forward(cur, None, None, self.pool_out, self.pool_mask if record else None,
+                                                    prepared_fwd=self.prep[0][0])
+                cur = self.pool_out
+                continue
             if self.fuse and not self.use_prep:
                 self.convs[l].forward_relu(cur, self.conv_w(l), self.conv_b(l), self.conv_out[l], self.relu_out[l])
             elif self.fuse:

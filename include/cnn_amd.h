@@ -70,6 +70,16 @@ int cnn_conv2d_forward(const cnn_conv2d_desc* d, const float* x, const float* w,
 int cnn_conv2d_forward_relu(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
                             float* y_relu, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The reference's first block Conv2D -> ReLU -> MaxPool2D(2, 2) (alexnet.cpp:12-15; conv2d.cpp:69-92, relu.cpp:21-26,
+ * pool2d.cpp:53-87) in ONE kernel: pooled [B][Co][Ho/2][Wo/2] and mask (same meaning as cnn_maxpool2d_forward: flat index
+ * into the sample's Co*Ho*Wo of the window's first maximum; may be NULL) are bit-identical to cnn_conv2d_forward_relu +
+ * cnn_maxpool2d_forward, but the convolution / ReLU outputs are NOT materialised -- nothing downstream needs them: the
+ * backward pass takes pooled + mask (cnn_maxpool2d_backward_relu, cnn_conv2d_backward_*_pooled2).
+ * Covered geometry: cnn_conv2d_relu_maxpool2_supported(d) != 0 (the thin 3 -> 16 channel 3x3 stride-2 layer). */
+int cnn_conv2d_relu_maxpool2_supported(const cnn_conv2d_desc* d);
+int cnn_conv2d_relu_maxpool2_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias,
+                                     float* pooled, int32_t* mask, void* workspace, size_t workspace_bytes, void* stream);
+
 /* replaces conv2d.cpp:117-159: gw = (sum_b sum_pq dy*x)/divisor, gb = (sum_b sum_pq dy)/divisor.
  * The reference divides by the batch size per sample and accumulates (:148,:157); pass divisor = B of the
  * WHOLE batch (per-rank shard size under data parallelism, see cnn_sgd_update).  gb may be NULL.
@@ -147,6 +157,9 @@ int cnn_conv2d_forward_prepared(const cnn_conv2d_desc* d, const float* x, const 
                                 float* y, float* y_relu, void* stream);
 int cnn_conv2d_backward_data_prepared(const cnn_conv2d_desc* d, const float* dy, const void* prepared_dgrad, float* dx,
                                       void* stream);
+/* cnn_conv2d_relu_maxpool2_forward from prepared filters (the bias is part of the prepared buffer) */
+int cnn_conv2d_relu_maxpool2_forward_prepared(const cnn_conv2d_desc* d, const float* x, const void* prepared_fwd,
+                                              float* pooled, int32_t* mask, void* stream);
 /* cnn_conv2d_backward with the data gradient from prepared filters; workspace: cnn_conv2d_workspace_bytes(d) */
 int cnn_conv2d_backward_prepared(const cnn_conv2d_desc* d, const float* x, const float* dy, const void* prepared_dgrad,
                                  float* gw, float* gb, float* dx, float divisor, void* workspace, size_t workspace_bytes,

@@ -531,3 +531,49 @@ def test_deferred_input_gradient_is_bit_identical(T):
         T.cuda.synchronize()
         assert T.equal(a.params, b.params) and T.equal(a.grads, b.grads) and T.equal(a.d_conv[0], b.d_conv[0]), step
         assert T.equal(a.d_pool, b.d_pool) and T.equal(a.d_conv[1], b.d_conv[1])
+
+
+@pytest.mark.parametrize("shape", [(2, 224, 224), (3, 37, 41), (1, 9, 9), (2, 12, 20), (5, 7, 5)], ids=lambda s: "B%d_%dx%d" % s)
+@pytest.mark.parametrize("prepared", [False, True], ids=["plain", "prepared"])
+def test_conv_relu_maxpool_fusion_is_bit_identical(T, shape, prepared):
+    """cnn_conv2d_relu_maxpool2_forward == cnn_conv2d_forward_relu + cnn_maxpool2d_forward (pooled values AND argmax mask),
+    including windows with ties (ReLU zeros), odd output sizes (last conv row / column outside every window) and NaN / -0"""
+    from cnn_amd import capi
+
+    B, H, W = shape
+    case = (B, 3, H, W, 16, 3, 2, 0)
+    x, w, b, _ = _conv_inputs(case, 500)
+    x = x - 0.5  # negative pre-activations: plenty of all-zero windows after the ReLU (first-maximum tie rule)
+    if H > 20:
+        x[0, :, 4:9, 4:9] = np.nan
+        x[-1, 1, 10, 11] = np.inf
+    conv = capi.Conv2d(*case)
+    assert conv.relu_maxpool2_supported()
+    xd, wd, bd = dev(T, x), dev(T, w), dev(T, b)
+    Ho, Wo = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    y, r = T.empty((B, 16, Ho, Wo), device="cuda"), T.empty((B, 16, Ho, Wo), device="cuda")
+    conv.forward_relu(xd, wd, bd, y, r)
+    pooled_ref, mask_ref = capi.maxpool_forward(r, 2, 2)
+    pooled = T.full_like(pooled_ref, 7.0)
+    mask = T.full_like(mask_ref, -1)
+    prep = None
+    if prepared:
+        pf, pd = conv.prepared_buffers("cuda")
+        capi.prepare_filters([conv], [wd], [bd], [pf], [pd])
+        prep = pf
+    conv.relu_maxpool2_forward(xd, wd, bd, pooled, mask, prepared_fwd=prep)
+    assert np.array_equal(host(pooled).view(np.uint32), host(pooled_ref).view(np.uint32))
+    assert np.array_equal(host(mask), host(mask_ref))
+    pooled2 = T.full_like(pooled_ref, 7.0)  # no_grad path: mask = NULL
+    conv.relu_maxpool2_forward(xd, wd, bd, pooled2, None, prepared_fwd=prep)
+    assert np.array_equal(host(pooled2).view(np.uint32), host(pooled_ref).view(np.uint32))
+
+
+def test_conv_relu_maxpool_fusion_rejects_other_layers(T):
+    from cnn_amd import capi
+
+    conv = capi.Conv2d(2, 16, 20, 20, 32, 3, 2, 0)
+    assert not conv.relu_maxpool2_supported()
+    with pytest.raises(capi.CnnAmdError):
+        conv.relu_maxpool2_forward(T.zeros((2, 16, 20, 20), device="cuda"), T.zeros((32, 16, 3, 3), device="cuda"),
+                                   T.zeros(32, device="cuda"), T.zeros((2, 32, 4, 4), device="cuda"))
