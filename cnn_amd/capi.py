@@ -40,6 +40,9 @@ SIGNATURES = {
     "cnn_conv2d_relu_maxpool2_supported": (C.c_int, [_D]),
     "cnn_conv2d_relu_maxpool2_forward": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_relu_maxpool2_forward_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P]),
+    "cnn_conv2d_backward_weight_pooled2": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P]),
+    "cnn_conv2d_backward_data_pooled2": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cnn_conv2d_backward_data_pooled2_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "cnn_conv2d_prepared_bytes": (C.c_size_t, [_D]),
     "cnn_conv2d_prepare_filters": (C.c_int, [C.c_int, _D, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                              C.POINTER(C.c_void_p), _P]),
@@ -181,6 +184,25 @@ class Conv2d:
                                                             _ptr(mask) if mask is not None else None, _ptr(self.ws), self.ws_bytes,
                                                             _stream()), "cnn_conv2d_relu_maxpool2_forward")
         return pooled
+
+    def backward_weight_pooled2(self, x, dpool, mask, pooled, divisor, gw, gb):
+        """weight / bias gradient with dy = relu_backward(maxpool_backward(dpool)) rebuilt on the fly"""
+        _need_gpu(x, dpool, mask, pooled, gw, gb)
+        check(self.lib.cnn_conv2d_backward_weight_pooled2(C.byref(self.desc), _ptr(x), _ptr(dpool), _ptr(mask), _ptr(pooled), _ptr(gw),
+                                                          _ptr(gb), float(divisor), _ptr(self.ws), self.ws_bytes, _stream()),
+              "cnn_conv2d_backward_weight_pooled2")
+        return gw, gb
+
+    def backward_data_pooled2(self, dpool, mask, pooled, w, dx, prepared_dgrad=None):
+        _need_gpu(dpool, mask, pooled, dx)
+        if prepared_dgrad is not None:
+            check(self.lib.cnn_conv2d_backward_data_pooled2_prepared(C.byref(self.desc), _ptr(dpool), _ptr(mask), _ptr(pooled),
+                                                                     _ptr(prepared_dgrad), _ptr(dx), _stream()),
+                  "cnn_conv2d_backward_data_pooled2_prepared")
+        else:
+            check(self.lib.cnn_conv2d_backward_data_pooled2(C.byref(self.desc), _ptr(dpool), _ptr(mask), _ptr(pooled), _ptr(w), _ptr(dx),
+                                                            _ptr(self.ws), self.ws_bytes, _stream()), "cnn_conv2d_backward_data_pooled2")
+        return dx
 
     def backward_weight(self, x, dy, divisor, gw=None, gb=None, want_bias=True):
         import torch

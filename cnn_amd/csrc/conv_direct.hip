@@ -285,6 +285,138 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_3_16_3_2(const float* __
     }
 }
 
+// ---- conv_layer_1's data gradient straight from the pooled domain ------------------------------------------------------
+// The delta of the convolution output, dy = ReLU::backward(MaxPool2D::backward(dpool)), has at most one non-zero per 2x2
+// pooling window and is fully described by (dpool, mask, pooled).  Each lane owns a 4x4 block of dx (= the 2x2 blocks
+// hh = 2bh + {0,1}, ww = 2bw + {0,1} of conv_dgrad_pk_3_16_3_2) for all three input channels; the 3x3 dy neighbourhood it
+// needs (rows 2bh-1 .. 2bh+1, columns 2bw-1 .. 2bw+1) lies in the four windows (bh-1 | bh) x (bw-1 | bw): three loads per
+// window and channel (12 for four 2x2 blocks instead of the 16 dy loads of the unfused kernel), the same packed FMAs in
+// the same order (bit-identical dx), one weight s_load per FOUR blocks, 16-byte stores.
+template <int CB>
+__global__ __launch_bounds__(kBlock) void conv_dgrad_pool_pk_3_16_3_2(const float* __restrict__ dpool, const int32_t* __restrict__ pmask,
+                                                                      const float* __restrict__ pooled, const v2f* __restrict__ wp,
+                                                                      float* __restrict__ dx, int B, int H, int W, int Ho, int Wo,
+                                                                      int items_per_img, unsigned m_ipi, unsigned m_row) {
+    constexpr int CO = 16, CI = 3;
+    const int U = (H + 1) / 2, V = (W + 1) / 2, U2 = (U + 1) / 2, V2 = (V + 1) / 2;
+    const int PHo = Ho / 2, PWo = Wo / 2, pplane = PHo * PWo, plane = Ho * Wo;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long items = (long long)B * items_per_img;
+    const int pbytes = (int)((unsigned)B * CO * pplane * 4u);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dpool, 0, pbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)pmask, 0, pbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)pooled, 0, pbytes, 0x00020000);
+    for (int it = blockIdx.x * kWaves + wave; it < (int)items; it += gridDim.x * kWaves) {
+        const int b = fast_div(it, m_ipi, items_per_img);
+        const int n = (it - b * items_per_img) * 64 + lane;
+        const bool live = n < U2 * V2;
+        const int bh = fast_div(live ? n : 0, m_row, V2), bw = (live ? n : 0) - bh * V2;
+        // windows (bh-1 | bh) x (bw-1 | bw); a window that does not exist gets an out-of-range offset and reads as 0
+        const bool r0 = live && bh >= 1 && bh - 1 < PHo, r1 = live && bh < PHo, c0 = bw >= 1 && bw - 1 < PWo, c1 = bw < PWo;
+        const unsigned o = (unsigned)(bh * PWo + bw) * 4u;
+        unsigned vw[4];
+        vw[0] = (r0 && c0) ? o - (unsigned)PWo * 4u - 4u : kBufOOB;
+        vw[1] = (r0 && c1) ? o - (unsigned)PWo * 4u : kBufOOB;
+        vw[2] = (r1 && c0) ? o - 4u : kBufOOB;
+        vw[3] = (r1 && c1) ? o : kBufOOB;
+        const int e00 = (2 * bh - 1) * Wo + (2 * bw - 1);  // flat index (within a channel) of D[0][0]
+        const int soff = b * CO * pplane * 4;
+        v2f acc[4][6];
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[sb][k] = v2f{0.f, 0.f};
+#pragma unroll 1
+        for (int cg = 0; cg < CO; cg += CB) {
+            float g[CB][4], pl[CB][4];
+            int mk[CB][4];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int so = soff + (cg + u) * pplane * 4;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    g[u][w] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, (int)vw[w], so, 0));
+                    mk[u][w] = __builtin_amdgcn_raw_buffer_load_b32(rm, (int)vw[w], so, 0);
+                    pl[u][w] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (int)vw[w], so, 0));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                // D[i][j] = dy[co][2bh-1+i][2bw-1+j]: window row (i+1)/2, window column (j+1)/2 of the four above
+                float D[3][3];
+                const int cbase = (cg + u) * plane + e00;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) g[u][w] = (pl[u][w] <= 0.f) ? 0.f : g[u][w];  // relu.cpp:38
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int w = ((i + 1) >> 1) * 2 + ((j + 1) >> 1);
+                        D[i][j] = (mk[u][w] == cbase + i * Wo + j) ? g[u][w] : 0.f;  // pool2d.cpp:96-107
+                    }
+                asm volatile("" ::: "memory");  // (keeps the weight s_loads of all channels from being hoisted, see above)
+                const v2f* q = wp + (cg + u) * 16;
+#pragma unroll
+                for (int sb = 0; sb < 4; ++sb) {
+                    const int sr = sb >> 1, sc = sb & 1;
+                    const v2f a = {D[sr + 1][sc + 1], D[sr + 1][sc + 1]}, bq = {D[sr + 1][sc], D[sr + 1][sc]},
+                              c = {D[sr][sc + 1], D[sr][sc + 1]}, e = {D[sr][sc], D[sr][sc]};
+                    v2f& P0 = acc[sb][0]; v2f& P1 = acc[sb][1]; v2f& P2 = acc[sb][2]; v2f& P3 = acc[sb][3];
+                    v2f& Q0 = acc[sb][4]; v2f& Q1 = acc[sb][5];
+                    P0 = __builtin_elementwise_fma(q[0], a, P0);
+                    P1 = __builtin_elementwise_fma(q[1], a, P1);
+                    P2 = __builtin_elementwise_fma(q[2], a, P2);
+                    P3 = __builtin_elementwise_fma(q[3], a, P3);
+                    Q0 = __builtin_elementwise_fma(q[4], a, Q0);
+                    Q1 = __builtin_elementwise_fma(q[5], a, Q1);
+                    P0 = __builtin_elementwise_fma(q[6], bq, P0);
+                    P2 = __builtin_elementwise_fma(q[7], bq, P2);
+                    Q0 = __builtin_elementwise_fma(q[8], bq, Q0);
+                    Q1 = __builtin_elementwise_fma(q[9], bq, Q1);
+                    P0 = __builtin_elementwise_fma(q[10], c, P0);
+                    P1 = __builtin_elementwise_fma(q[11], c, P1);
+                    Q0 = __builtin_elementwise_fma(q[12], c, Q0);
+                    P0 = __builtin_elementwise_fma(q[13], e, P0);
+                    Q0 = __builtin_elementwise_fma(q[14], e, Q0);
+                }
+            }
+        }
+        if (!live) continue;
+        // dx[ci][4bh + 2sr + ph][4bw + 2sc + pw]: one row of the 4x4 block = the (pw0, pw1) pairs of sub-blocks sc = 0, 1
+        float* dxb = dx + (size_t)b * CI * H * W;
+        const bool quad = (W & 3) == 0;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int sr = rr >> 1, ph = rr & 1, h = 4 * bh + rr;
+                float v[4];
+#pragma unroll
+                for (int sc = 0; sc < 2; ++sc) {
+                    const v2f* A = acc[sr * 2 + sc];
+                    if (ci == 2) {
+                        v[2 * sc] = ph ? A[5].x : A[4].x;
+                        v[2 * sc + 1] = ph ? A[5].y : A[4].y;
+                    } else {
+                        const v2f lo = ph ? A[2] : A[0], hi = ph ? A[3] : A[1];
+                        v[2 * sc] = ci ? lo.y : lo.x;
+                        v[2 * sc + 1] = ci ? hi.y : hi.x;
+                    }
+                }
+                if (h >= H) continue;
+                float* row = dxb + ((size_t)ci * H + h) * W + 4 * (size_t)bw;
+                if (quad) {
+                    *(float4*)row = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (4 * bw + k < W) row[k] = v[k];
+                }
+            }
+    }
+}
+
 // ---- the same recipe for wider stride-2 3x3 layers (even CI): data gradient ---------------------------------------------
 // On gfx950 the packed fp32 VALU rate equals the fp32 MFMA rate (157 TFLOP/s), and for the reference net's small layers
 // the MFMA kernels spend most of their time staging operands through LDS.  Here the weights stream through SGPR pairs
@@ -628,8 +760,13 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_pool_pk_3_16_3_2(const float*
 // registers as 14 float pairs per channel (v_pk_fma_f32: patch pair x broadcast dy) + a bias sum.  At the end every wave
 // reduces its sums across lanes and writes one slab row set; reduce_slabs() adds the slabs in a fixed order.
 constexpr int kWgX = 7;       // patch rows each wave stages per item (4 x 7 = 28 >= 27 taps; the 28th is the zero pad)
-template <int kWgDepth>  // items in flight per workgroup
+// POOLED: the delta of the convolution output is not in memory; it is rebuilt on the fly from the pooled domain as
+//     dy[co][n] = (mask[window] == co*Ho*Wo + n  &&  !(pooled[window] <= 0)) ? dpool[window] : 0,   window = (p/2, q/2)
+// = MaxPool2D::backward (pool2d.cpp:96-107) followed by ReLU::backward (relu.cpp:35-40): three 4-byte loads per lane and
+// channel instead of one, but the 202 MB delta tensor is neither written nor read.  `dy` then holds dpool.
+template <int kWgDepth, bool POOLED>  // items in flight per workgroup
 __global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 const int32_t* __restrict__ pmask, const float* __restrict__ pooled,
                                                                  float* __restrict__ slabs, int B, int H, int W, int Ho,
                                                                  int Wo, int items_per_img, unsigned m_ipi, unsigned m_row) {
     constexpr int CI = 3, CO = 16, NP = 14;  // NP float pairs cover the 27 taps (+1 zero pad)
@@ -640,8 +777,11 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __
     const int plane = Ho * Wo;
     const __amdgpu_buffer_rsrc_t rx =
         __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * CI * H * W * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rd =
-        __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * CO * plane * 4u), 0x00020000);
+    const int PHo = Ho / 2, PWo = Wo / 2, pplane = PHo * PWo;
+    const int dy_bytes = (int)((unsigned)B * CO * (POOLED ? pplane : plane) * 4u);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)(POOLED ? (const void*)pmask : (const void*)dy), 0, dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(POOLED ? pooled : dy), 0, dy_bytes, 0x00020000);
     // wave w stages taps 7w .. 7w+6 of x (tap 27 does not exist: it reads out of range = the zero pad) and loads the dy
     // rows of ITS output channels 4w .. 4w+3, which never go through LDS.  Everything below is branch-free on purpose
     // (an item past the end reads out of range = 0 and adds nothing): with straight-line code hipcc counts the outstanding
@@ -659,8 +799,9 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __
     // rows, which then come from this CU's L1 / this XCD's L2 instead of HBM (a strided assignment fetched x 2.5x)
     const long long per = (items + gridDim.x - 1) / gridDim.x;
     const long long it_end = (blockIdx.x + 1) * per < items ? (blockIdx.x + 1) * per : items;
-    float lx[kWgDepth][kWgX], ldy[kWgDepth][4];
-    auto issue = [&](long long it, float(&ax)[kWgX], float(&ad)[4]) {
+    constexpr int ND = POOLED ? 13 : 4;  // POOLED: dpool[4] | mask[4] | pooled[4] | expected flat index of this lane's pixel
+    float lx[kWgDepth][kWgX], ldy[kWgDepth][ND];
+    auto issue = [&](long long it, float(&ax)[kWgX], float(&ad)[ND]) {
         const bool inr = it < it_end;
         const int iti = inr ? (int)it : 0;
         const int b = fast_div(iti, m_ipi, items_per_img);
@@ -668,14 +809,28 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __
         const bool live = inr && n < plane;
         const int p = fast_div(live ? n : 0, m_row, Wo), q = (live ? n : 0) - p * Wo;
         const unsigned vx = live ? (unsigned)(2 * p * W + 2 * q) * 4u : kBufOOB;
-        const unsigned vd = live ? (unsigned)n * 4u : kBufOOB;
-        const int sx = b * CI * H * W * 4, sd = (b * CO + 4 * wave) * plane * 4;
+        const int sx = b * CI * H * W * 4;
 #pragma unroll
         for (int i = 0; i < kWgX; ++i)
             ax[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(tap_ok[i] ? vx : kBufOOB), sx + tap_off[i], 0));
+        if constexpr (POOLED) {
+            const bool win = live && (p >> 1) < PHo && (q >> 1) < PWo;  // pixels outside every window have no delta
+            const unsigned vd = win ? (unsigned)((p >> 1) * PWo + (q >> 1)) * 4u : kBufOOB;
+            const int sd = (b * CO + 4 * wave) * pplane * 4;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            ad[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, (int)vd, sd + c * plane * 4, 0));
+            for (int c = 0; c < 4; ++c) {
+                ad[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, (int)vd, sd + c * pplane * 4, 0));
+                ad[4 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, (int)vd, sd + c * pplane * 4, 0));
+                ad[8 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (int)vd, sd + c * pplane * 4, 0));
+            }
+            ad[12] = __builtin_bit_cast(float, 4 * wave * plane + n);
+        } else {
+            const unsigned vd = live ? (unsigned)n * 4u : kBufOOB;
+            const int sd = (b * CO + 4 * wave) * plane * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                ad[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, (int)vd, sd + c * plane * 4, 0));
+        }
     };
 
     v2f A[4][NP];
@@ -691,13 +846,21 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __
 #pragma unroll
     for (int dd = 0; dd < kWgDepth; ++dd) issue(it + dd * stride, lx[dd], ldy[dd]);
     int k = 0;
-    auto consume = [&](float(&ax)[kWgX], float(&ad)[4]) {  // item `it`: registers -> LDS, refill the register set, accumulate
+    auto consume = [&](float(&ax)[kWgX], float(&ad)[ND]) {  // item `it`: registers -> LDS, refill the register set, accumulate
         float(*st)[64] = stage[k & 1];
 #pragma unroll
         for (int i = 0; i < kWgX; ++i) st[wave * kWgX + i][lane] = ax[i];
         float d[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) d[c] = ad[c];
+        for (int c = 0; c < 4; ++c) {
+            if constexpr (POOLED) {
+                const int want = __builtin_bit_cast(int, ad[12]) + c * plane;
+                const bool hit = __builtin_bit_cast(int, ad[4 + c]) == want;  // (a lane without a window loaded zeros: d = 0 anyway)
+                d[c] = (hit && !(ad[8 + c] <= 0.f)) ? ad[c] : 0.f;
+            } else {
+                d[c] = ad[c];
+            }
+        }
         // LDS-only barrier: __syncthreads() would also drain the global loads that are deliberately still in flight (its
         // fence covers every address space -> s_waitcnt vmcnt(0)).  One barrier per item: the buffer written now was last
         // read two items ago.
@@ -856,6 +1019,24 @@ int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w,
 }
 
 
+// conv_layer_1's data gradient from the pooled domain (see conv_dgrad_pool_pk_3_16_3_2)
+int direct_conv_dgrad_pooled(const cnn_conv2d_desc* d, const float* dpool, const int32_t* mask, const float* pooled, const float* w,
+                             float* dx, void* ws, size_t ws_bytes, hipStream_t s, bool prepared) {
+    CNN_REQUIRE(direct_conv_pool_supported(d) && direct_dgrad_pk_ok(d), "cnn_conv2d_backward_data_pooled2: geometry not covered");
+    CNN_REQUIRE(ws != nullptr && ws_bytes >= 16 * 32 * sizeof(float), "cnn_conv2d_backward_data_pooled2: workspace too small");
+    const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
+    if (!prepared)
+        CNN_KLAUNCH(s, "pack_dgrad_weights", (pack_dgrad_weights_3_16_3_2<<<1, 64, 0, s>>>(w, (float*)ws)), CONV_TAG(d));
+    const int U = (d->H + 1) / 2, V = (d->W + 1) / 2, U2 = (U + 1) / 2, V2 = (V + 1) / 2;
+    const int ipi = (U2 * V2 + 63) / 64;
+    const long long witems = (long long)d->B * ipi;
+    CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>+pool",
+                (conv_dgrad_pool_pk_3_16_3_2<2><<<wave_grid(witems), kBlock, 0, s>>>(dpool, mask, pooled, (const v2f*)ws, dx, d->B, d->H, d->W,
+                                                                                    Ho, Wo, ipi, div_magic(ipi), div_magic(V2))),
+                CONV_TAG(d));
+    return CNN_AMD_OK;
+}
+
 // Packed VALU data gradient for k = 3, stride 2, pad 0 layers with 16 input channels (conv_layer_2 of the reference net).
 bool pk_dgrad_s2_supported(const cnn_conv2d_desc* d) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
@@ -943,8 +1124,20 @@ int direct_conv_wgrad(const cnn_conv2d_desc* d, const float* x, const float* dy,
     const int ipi = (Ho * Wo + 63) / 64;
     // three items of loads in flight per workgroup (2: 117 us, 3: 115 us, 4+: the extra registers cost more than they hide)
     CNN_KLAUNCH(s, "conv_wgrad_pk<3,16,3,2>",
-                (conv_wgrad_pk_3_16_3_2<3><<<direct_wgrad_slots(d), kBlock, 0, s>>>(x, dy, slabs, d->B, d->H, d->W, Ho, Wo, ipi,
-                                                                                   div_magic(ipi), div_magic(Wo))),
+                (conv_wgrad_pk_3_16_3_2<3, false><<<direct_wgrad_slots(d), kBlock, 0, s>>>(x, dy, nullptr, nullptr, slabs, d->B, d->H, d->W,
+                                                                                          Ho, Wo, ipi, div_magic(ipi), div_magic(Wo))),
+                CONV_TAG(d));
+    return CNN_AMD_OK;
+}
+
+// the same slabs from the pooled domain (dpool, mask, pooled of the 2x2 / stride-2 pool behind this layer's ReLU)
+int direct_conv_wgrad_pooled(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask, const float* pooled,
+                             float* slabs, hipStream_t s) {
+    const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
+    const int ipi = (Ho * Wo + 63) / 64;
+    CNN_KLAUNCH(s, "conv_wgrad_pk<3,16,3,2>+pool",
+                (conv_wgrad_pk_3_16_3_2<3, true><<<direct_wgrad_slots(d), kBlock, 0, s>>>(x, dpool, mask, pooled, slabs, d->B, d->H, d->W,
+                                                                                         Ho, Wo, ipi, div_magic(ipi), div_magic(Wo))),
                 CONV_TAG(d));
     return CNN_AMD_OK;
 }

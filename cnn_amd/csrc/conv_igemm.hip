@@ -1252,6 +1252,8 @@ bool direct_prepared_dgrad_ok(const cnn_conv2d_desc* d);
 bool direct_conv_pool_supported(const cnn_conv2d_desc* d);  // conv_direct.hip: Conv -> ReLU -> MaxPool(2,2) in one kernel
 int direct_conv_pool_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* pooled,
                              int32_t* mask, void* ws, size_t ws_bytes, hipStream_t s, bool prepared);
+int direct_conv_dgrad_pooled(const cnn_conv2d_desc* d, const float* dpool, const int32_t* mask, const float* pooled, const float* w,
+                             float* dx, void* ws, size_t ws_bytes, hipStream_t s, bool prepared);
 bool fwd_rd_supported(const cnn_conv2d_desc* d);  // conv_fwd_rd.hip: register-direct forward of the mid-size 3x3 layers
 size_t fwd_rd_prepared_floats(const cnn_conv2d_desc* d);
 int fwd_rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, const float* const* bias, void* const* fwd,
@@ -1334,6 +1336,21 @@ int cnn_conv2d_relu_maxpool2_forward_prepared(const cnn_conv2d_desc* d, const fl
     if (int rc = check_desc("cnn_conv2d_relu_maxpool2_forward_prepared", d)) return rc;
     CNN_REQUIRE(x && prepared_fwd && pooled, "cnn_conv2d_relu_maxpool2_forward_prepared: null pointer");
     return direct_conv_pool_forward(d, x, nullptr, nullptr, pooled, mask, (void*)prepared_fwd, cnn_conv2d_prepared_bytes(d),
+                                    as_stream(stream), true);
+}
+
+int cnn_conv2d_backward_data_pooled2(const cnn_conv2d_desc* d, const float* dpool, const int32_t* mask, const float* pooled,
+                                     const float* w, float* dx, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = check_desc("cnn_conv2d_backward_data_pooled2", d)) return rc;
+    CNN_REQUIRE(dpool && mask && pooled && w && dx, "cnn_conv2d_backward_data_pooled2: null pointer");
+    return direct_conv_dgrad_pooled(d, dpool, mask, pooled, w, dx, ws, ws_bytes, as_stream(stream), false);
+}
+
+int cnn_conv2d_backward_data_pooled2_prepared(const cnn_conv2d_desc* d, const float* dpool, const int32_t* mask, const float* pooled,
+                                              const void* prepared_dgrad, float* dx, void* stream) {
+    if (int rc = check_desc("cnn_conv2d_backward_data_pooled2_prepared", d)) return rc;
+    CNN_REQUIRE(dpool && mask && pooled && prepared_dgrad && dx, "cnn_conv2d_backward_data_pooled2_prepared: null pointer");
+    return direct_conv_dgrad_pooled(d, dpool, mask, pooled, nullptr, dx, (void*)prepared_dgrad, cnn_conv2d_prepared_bytes(d),
                                     as_stream(stream), true);
 }
 

@@ -17,6 +17,9 @@ namespace cnn_amd {
 size_t igemm_workspace_floats(const cnn_conv2d_desc* d);  // conv_igemm.hip
 int direct_wgrad_slots(const cnn_conv2d_desc* d);          // conv_direct.hip: thin first layer, packed VALU kernel
 int direct_conv_wgrad(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
+bool direct_conv_pool_supported(const cnn_conv2d_desc* d);
+int direct_conv_wgrad_pooled(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask, const float* pooled,
+                             float* slabs, hipStream_t s);
 int wgrad_rd_slots(const cnn_conv2d_desc* d);  // conv_wgrad_rd.hip: register-direct MFMA kernel (3x3, stride 1/2, pad 0)
 int wgrad_rd_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
 }
@@ -569,6 +572,25 @@ size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d) {
     const size_t rw = rs ? (size_t)(rs + (rs + 63) / 64) * d->Co * (d->Ci * 9 + 1) : 0;
     if (rw > m) m = rw;
     return (m + 64) * sizeof(float);
+}
+
+/* weight / bias gradient of the first block when its convolution delta exists only as (dpool, mask, pooled) */
+int cnn_conv2d_backward_weight_pooled2(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask,
+                                       const float* pooled, float* gw, float* gb, float divisor, void* ws, size_t ws_bytes,
+                                       void* stream) {
+    if (int rc = check_desc("cnn_conv2d_backward_weight_pooled2", d)) return rc;
+    CNN_REQUIRE(x && dpool && mask && pooled && gw, "cnn_conv2d_backward_weight_pooled2: null pointer");
+    CNN_REQUIRE(divisor != 0.f, "cnn_conv2d_backward_weight_pooled2: divisor is 0");
+    const int ds = direct_wgrad_slots(d);
+    CNN_REQUIRE(ds > 0 && direct_conv_pool_supported(d), "cnn_conv2d_backward_weight_pooled2: geometry not covered");
+    const size_t n = 16 * 28, need_d = (size_t)(ds + (ds + 63) / 64) * n * sizeof(float);
+    CNN_REQUIRE(ws != nullptr && ws_bytes >= need_d, "cnn_conv2d_backward_weight_pooled2: workspace too small (%zu < %zu bytes)", ws_bytes,
+                need_d);
+    hipStream_t sd = as_stream(stream);
+    if (int rc = direct_conv_wgrad_pooled(d, x, dpool, mask, pooled, (float*)ws, sd)) return rc;
+    char tagd[160];
+    snprintf(tagd, sizeof(tagd), CONV_TAG(d));
+    return reduce_slabs(sd, (const float*)ws, ds, n, (float*)ws + (size_t)ds * n, gw, divisor, tagd, 27, gb);
 }
 
 int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const float* dy, float* gw, float* gb,

@@ -67,6 +67,14 @@ class AlexNetHip:
         # conv_layer_1 -> relu_layer_1 -> max_pool_1 as one kernel: conv_out[0] / relu_out[0] are then NOT written (nothing in
         # the step reads them: the backward pass of that block works from pool_out + pool_mask)
         self.fuse_pool = bool(fuse_pool) and self.use_prep and self.convs[0].relu_maxpool2_supported()
+        # ... and its backward pass rebuilds the convolution delta from (d pool_out, pool_mask, pool_out) inside the conv1
+        # weight / data gradient kernels: no MaxPool2D::backward / ReLU::backward kernel, no d_pool tensor.  The deferred
+        # data gradient (below) then still needs pool_out / pool_mask of ITS step while the next forward pass is already
+        # writing new ones: two sets, alternating.
+        self.pool_sets = [(self.pool_out, self.pool_mask)]
+        if self.fuse_pool and defer_input_grad:
+            self.pool_sets.append((torch.empty_like(self.pool_out), torch.empty_like(self.pool_mask)))
+        self.pool_cur = 0
         self.prep = [c.prepared_buffers(device) for c in self.convs] if self.use_prep else None
         # The data gradient of conv_layer_1 (the delta w.r.t. the input image, conv2d.cpp:168-199) has no consumer: nothing
         # waits for it.  It is still computed every step, but as a DEFERRED launch on a second stream that is released
@@ -127,7 +135,11 @@ class AlexNetHip:
         self.ev_release.record(main)
         with torch.cuda.stream(self.side_b):
             self.side_b.wait_event(self.ev_release)  # gated: not before this point of the main stream
-            self.convs[0].backward_data_prepared(self.d_pool, self.pending_dx0, self.d_conv[0])
+            if self.fuse_pool:
+                prep_dg, dpool, mask, pooled = self.pending_dx0
+                self.convs[0].backward_data_pooled2(dpool, mask, pooled, None, self.d_conv[0], prepared_dgrad=prep_dg)
+            else:
+                self.convs[0].backward_data_prepared(self.d_pool, self.pending_dx0, self.d_conv[0])
             self.ev_b_done.record(self.side_b)
         self.pending_dx0 = None
         self.b_in_flight = True
@@ -153,6 +165,8 @@ class AlexNetHip:
             self._prepare()
         for l in range(4):
             if l == 0 and self.fuse_pool:
+                self.pool_cur = (self.pool_cur + 1) % len(self.pool_sets)
+                self.pool_out, self.pool_mask = self.pool_sets[self.pool_cur]
                 self.convs[0].relu_maxpool2_forward(cur, None, None, self.pool_out, self.pool_mask if record else None,
                                                     prepared_fwd=self.prep[0][0])
                 cur = self.pool_out
@@ -195,6 +209,17 @@ class AlexNetHip:
                              self.lin_b(g), self.d_lin)
         cur = self.d_lin.view(self.relu_out[3].shape)
         for l in (3, 2, 1, 0):
+            if l == 1 and self.fuse_pool and self.defer_dx0:
+                self.flush()  # the previous step's deferred dgrad reads d_conv[1] (= d pool_out), which is rewritten next
+            if l == 0 and self.fuse_pool:
+                # conv_layer_1 from the pooled domain: cur = d pool_out
+                self.convs[0].backward_weight_pooled2(self.x, cur, self.pool_mask, self.pool_out, div, self.conv_w(0, g), self.conv_b(0, g))
+                if self.defer_dx0:
+                    self.pending_dx0 = (self.prep0_dgrad[self.parity], cur, self.pool_mask, self.pool_out)
+                else:
+                    self.convs[0].backward_data_pooled2(cur, self.pool_mask, self.pool_out, None, self.d_conv[0],
+                                                        prepared_dgrad=self.prep[0][1])
+                break
             if l == 0:
                 hh, ww = self.conv_out_hw[0]
                 if self.defer_dx0:

@@ -80,6 +80,17 @@ int cnn_conv2d_relu_maxpool2_supported(const cnn_conv2d_desc* d);
 int cnn_conv2d_relu_maxpool2_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias,
                                      float* pooled, int32_t* mask, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Conv2D::backward of that block when the delta of the convolution output exists only in the pooled domain:
+ *   dy = ReLU::backward(MaxPool2D::backward(dpool))   (relu.cpp:35-40, pool2d.cpp:96-107)
+ * is rebuilt on the fly from dpool (delta of the pool output), mask and pooled (both as written by the forward call), so
+ * the Co*Ho*Wo delta tensor is never written or read.  Results are bit-identical to cnn_maxpool2d_backward_relu followed by
+ * cnn_conv2d_backward_weight / cnn_conv2d_backward_data. */
+int cnn_conv2d_backward_weight_pooled2(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask,
+                                       const float* pooled, float* gw, float* gb, float divisor, void* workspace,
+                                       size_t workspace_bytes, void* stream);
+int cnn_conv2d_backward_data_pooled2(const cnn_conv2d_desc* d, const float* dpool, const int32_t* mask, const float* pooled,
+                                     const float* w, float* dx, void* workspace, size_t workspace_bytes, void* stream);
+
 /* replaces conv2d.cpp:117-159: gw = (sum_b sum_pq dy*x)/divisor, gb = (sum_b sum_pq dy)/divisor.
  * The reference divides by the batch size per sample and accumulates (:148,:157); pass divisor = B of the
  * WHOLE batch (per-rank shard size under data parallelism, see cnn_sgd_update).  gb may be NULL.
@@ -160,6 +171,8 @@ int cnn_conv2d_backward_data_prepared(const cnn_conv2d_desc* d, const float* dy,
 /* cnn_conv2d_relu_maxpool2_forward from prepared filters (the bias is part of the prepared buffer) */
 int cnn_conv2d_relu_maxpool2_forward_prepared(const cnn_conv2d_desc* d, const float* x, const void* prepared_fwd,
                                               float* pooled, int32_t* mask, void* stream);
+int cnn_conv2d_backward_data_pooled2_prepared(const cnn_conv2d_desc* d, const float* dpool, const int32_t* mask,
+                                              const float* pooled, const void* prepared_dgrad, float* dx, void* stream);
 /* cnn_conv2d_backward with the data gradient from prepared filters; workspace: cnn_conv2d_workspace_bytes(d) */
 int cnn_conv2d_backward_prepared(const cnn_conv2d_desc* d, const float* x, const float* dy, const void* prepared_dgrad,
                                  float* gw, float* gb, float* dx, float divisor, void* workspace, size_t workspace_bytes,

@@ -577,3 +577,63 @@ def test_conv_relu_maxpool_fusion_rejects_other_layers(T):
     with pytest.raises(capi.CnnAmdError):
         conv.relu_maxpool2_forward(T.zeros((2, 16, 20, 20), device="cuda"), T.zeros((32, 16, 3, 3), device="cuda"),
                                    T.zeros(32, device="cuda"), T.zeros((2, 32, 4, 4), device="cuda"))
+
+
+@pytest.mark.parametrize("shape", [(2, 224, 224), (3, 37, 41), (1, 9, 9), (2, 12, 20), (5, 7, 5), (2, 30, 26)], ids=lambda s: "B%d_%dx%d" % s)
+def test_conv_backward_from_pooled_domain_is_bit_identical(T, shape):
+    """cnn_conv2d_backward_{weight,data}_pooled2 == cnn_maxpool2d_backward_relu + cnn_conv2d_backward_{weight,data}"""
+    from cnn_amd import capi
+
+    B, H, W = shape
+    case = (B, 3, H, W, 16, 3, 2, 0)
+    x, w, b, _ = _conv_inputs(case, 600)
+    x = x - 0.5
+    conv = capi.Conv2d(*case)
+    xd, wd, bd = dev(T, x), dev(T, w), dev(T, b)
+    Ho, Wo = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    PHo, PWo = Ho // 2, Wo // 2
+    pooled = T.empty((B, 16, PHo, PWo), device="cuda")
+    mask = T.empty((B, 16, PHo, PWo), dtype=T.int32, device="cuda")
+    conv.relu_maxpool2_forward(xd, wd, bd, pooled, mask)
+    dpool = dev(T, uniform_pm1(601, (B, 16, PHo, PWo)))
+    dy = capi.maxpool_backward_relu(dpool, mask, pooled, (B, 16, Ho, Wo), 2, 2)
+    gw_ref, gb_ref = conv.backward_weight(xd, dy, float(B))
+    dx_ref = conv.backward_data(dy, wd)
+    gw, gb = T.full_like(gw_ref, 7.0), T.full_like(gb_ref, 7.0)
+    conv.backward_weight_pooled2(xd, dpool, mask, pooled, float(B), gw, gb)
+    assert np.array_equal(host(gw), host(gw_ref)) and np.array_equal(host(gb), host(gb_ref))
+    dx = T.full_like(dx_ref, 7.0)
+    conv.backward_data_pooled2(dpool, mask, pooled, wd, dx)
+    assert np.array_equal(host(dx), host(dx_ref))
+    pf, pd = conv.prepared_buffers("cuda")
+    capi.prepare_filters([conv], [wd], [bd], [pf], [pd])
+    dx2 = T.full_like(dx_ref, 7.0)
+    conv.backward_data_pooled2(dpool, mask, pooled, None, dx2, prepared_dgrad=pd)
+    assert np.array_equal(host(dx2), host(dx_ref))
+
+
+@pytest.mark.parametrize("defer", [False, True], ids=["in_order", "deferred_dx0"])
+def test_pool_fused_net_is_bit_identical(T, defer):
+    """pynet(fuse_pool=True): conv_layer_1 / relu_layer_1 / max_pool_1 as one forward kernel and their backward pass from
+    the pooled domain; after every step the parameters, gradients, pool tensors and every delta that is still materialised
+    equal the kernel-per-layer run bit for bit (different inputs per step: the two pool buffer sets must not mix)"""
+    from cnn_amd.pynet import AlexNetHip
+
+    B = 4
+    labels = dev(T, (np.arange(B) % 3).astype(np.int32))
+    nets = [AlexNetHip(B, 3, defer_input_grad=defer, fuse_pool=fp) for fp in (True, False)]
+    assert nets[0].fuse_pool and not nets[1].fuse_pool
+    p0 = normal_scaled(341, (nets[0].n_params,))
+    for n in nets:
+        n.load_params(p0)
+    for step in range(4):
+        x = dev(T, uniform01(340 + step, (B, 3, 224, 224)))
+        for n in nets:
+            n.train_step(x, labels, 1e-3)
+        a, b = nets
+        for n in nets:
+            n.flush()
+        T.cuda.synchronize()
+        assert T.equal(a.params, b.params) and T.equal(a.grads, b.grads), step
+        assert T.equal(a.pool_out, b.pool_out) and T.equal(a.pool_mask, b.pool_mask)
+        assert T.equal(a.d_conv[0], b.d_conv[0]) and T.equal(a.d_conv[1], b.d_conv[1]) and T.equal(a.logits, b.logits)
