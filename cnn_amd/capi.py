@@ -49,6 +49,9 @@ SIGNATURES = {
     "cnn_conv2d_forward_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "cnn_conv2d_backward_data_prepared": (C.c_int, [_D, _P, _P, _P, _P]),
     "cnn_conv2d_backward_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P, C.c_int]),
+    "cnn_conv2d_backward_prepared_relu": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P, C.c_int]),
+    "cnn_conv2d_backward_data_relu": (C.c_int, [_D, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cnn_conv2d_backward_data_relu_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P]),
     "cnn_conv2d_backward_weight": (C.c_int, [_D, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P]),
     "cnn_conv2d_backward_data": (C.c_int, [_D, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_backward_workspace_bytes": (C.c_size_t, [_D]),
@@ -65,6 +68,7 @@ SIGNATURES = {
     "cnn_relu_backward": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "cnn_linear_forward": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "cnn_linear_backward": (C.c_int, [_P] * 6 + [C.c_int] * 3 + [C.c_float, _P]),
+    "cnn_linear_backward_relu": (C.c_int, [_P] * 6 + [C.c_int] * 3 + [C.c_float, _P]),
     "cnn_batchnorm2d_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "cnn_batchnorm2d_forward": (C.c_int, [_P] * 8 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, _P, C.c_size_t, _P]),
     "cnn_batchnorm2d_backward": (C.c_int, [_P] * 7 + [C.c_int] * 4 + [C.c_float, _P, C.c_size_t, _P]),
@@ -268,12 +272,25 @@ class Conv2d:
               "cnn_conv2d_backward_data_prepared")
         return dx
 
-    def backward_prepared(self, x, dy, prepared_dgrad, divisor, gw, gb, dx, defer_join=False):
+    def backward_prepared(self, x, dy, prepared_dgrad, divisor, gw, gb, dx, defer_join=False, relu_below=None):
+        """relu_below: output of the ReLU layer in front of this convolution (= x when that layer feeds it directly); its
+        backward pass is applied to dx inside the data-gradient kernel"""
         _need_gpu(x, dy, prepared_dgrad, gw, gb, dx)
-        check(self.lib.cnn_conv2d_backward_prepared(C.byref(self.desc), _ptr(x), _ptr(dy), _ptr(prepared_dgrad), _ptr(gw), _ptr(gb),
-                                                    _ptr(dx), float(divisor), _ptr(self.ws), self.ws_bytes, _stream(),
-                                                    1 if defer_join else 0), "cnn_conv2d_backward_prepared")
+        check(self.lib.cnn_conv2d_backward_prepared_relu(C.byref(self.desc), _ptr(x), _ptr(dy), _ptr(prepared_dgrad),
+                                                         _ptr(relu_below) if relu_below is not None else None, _ptr(gw), _ptr(gb),
+                                                         _ptr(dx), float(divisor), _ptr(self.ws), self.ws_bytes, _stream(),
+                                                         1 if defer_join else 0), "cnn_conv2d_backward_prepared")
         return gw, gb, dx
+
+    def backward_data_relu(self, dy, w, relu_below, dx, prepared_dgrad=None):
+        _need_gpu(dy, relu_below, dx)
+        if prepared_dgrad is not None:
+            check(self.lib.cnn_conv2d_backward_data_relu_prepared(C.byref(self.desc), _ptr(dy), _ptr(prepared_dgrad), _ptr(relu_below),
+                                                                  _ptr(dx), _stream()), "cnn_conv2d_backward_data_relu_prepared")
+        else:
+            check(self.lib.cnn_conv2d_backward_data_relu(C.byref(self.desc), _ptr(dy), _ptr(w), _ptr(relu_below), _ptr(dx),
+                                                         _ptr(self.ws), self.ws_bytes, _stream()), "cnn_conv2d_backward_data_relu")
+        return dx
 
     # ---- im2col functional fallback (parity cross-check only) ----
     def _iws(self, device):
@@ -383,7 +400,8 @@ def linear_forward(x, w, bias, y=None):
     return y
 
 
-def linear_backward(x, dy, w, divisor, gw=None, gb=None, dx=None):
+def linear_backward(x, dy, w, divisor, gw=None, gb=None, dx=None, relu_below=False):
+    """relu_below: x is a ReLU layer's output; its backward pass is applied to dx in the same kernel"""
     import torch
 
     _need_gpu(x, dy, w, gw, gb, dx)
@@ -395,8 +413,9 @@ def linear_backward(x, dy, w, divisor, gw=None, gb=None, dx=None):
         gb = torch.empty((n_out,), dtype=torch.float32, device=x.device)
     if dx is None:
         dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    check(load().cnn_linear_backward(_ptr(x), _ptr(dy), _ptr(w), _ptr(gw), _ptr(gb), _ptr(dx), B, n_in, n_out,
-                                     float(divisor), _stream()), "cnn_linear_backward")
+    fn = load().cnn_linear_backward_relu if relu_below else load().cnn_linear_backward
+    check(fn(_ptr(x), _ptr(dy), _ptr(w), _ptr(gw), _ptr(gb), _ptr(dx), B, n_in, n_out, float(divisor), _stream()),
+          "cnn_linear_backward")
     return gw, gb, dx
 
 

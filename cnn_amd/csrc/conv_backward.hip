@@ -72,6 +72,12 @@ int cnn_conv2d_backward(const cnn_conv2d_desc* d, const float* x, const float* d
 int cnn_conv2d_backward_prepared(const cnn_conv2d_desc* d, const float* x, const float* dy, const void* prepared_dgrad,
                                  float* gw, float* gb, float* dx, float divisor, void* ws, size_t ws_bytes, void* stream,
                                  int defer_join) {
+    return cnn_conv2d_backward_prepared_relu(d, x, dy, prepared_dgrad, nullptr, gw, gb, dx, divisor, ws, ws_bytes, stream, defer_join);
+}
+
+int cnn_conv2d_backward_prepared_relu(const cnn_conv2d_desc* d, const float* x, const float* dy, const void* prepared_dgrad,
+                                      const float* relu_below, float* gw, float* gb, float* dx, float divisor, void* ws,
+                                      size_t ws_bytes, void* stream, int defer_join) {
     CNN_REQUIRE(d && x && dy && prepared_dgrad && gw && dx && ws, "cnn_conv2d_backward_prepared: null pointer");
     SideStream* side = nullptr;
     if (int rc = get_side(&side)) return rc;
@@ -79,7 +85,9 @@ int cnn_conv2d_backward_prepared(const cnn_conv2d_desc* d, const float* x, const
     CNN_HIP_CHECK(hipEventRecord(side->fork, main));
     CNN_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
     if (int rc = cnn_conv2d_backward_weight(d, x, dy, gw, gb, divisor, ws, ws_bytes, side->stream)) return rc;
-    if (int rc = cnn_conv2d_backward_data_prepared(d, dy, prepared_dgrad, dx, main)) return rc;
+    if (int rc = relu_below ? cnn_conv2d_backward_data_relu_prepared(d, dy, prepared_dgrad, relu_below, dx, main)
+                            : cnn_conv2d_backward_data_prepared(d, dy, prepared_dgrad, dx, main))
+        return rc;
     if (!defer_join) {
         CNN_HIP_CHECK(hipEventRecord(side->join, side->stream));
         CNN_HIP_CHECK(hipStreamWaitEvent(main, side->join, 0));

@@ -37,7 +37,8 @@ struct IgemmParams {
     const float* A;     // prepared weights
     const float* bias;  // [M] or nullptr
     float* Y;
-    float* Y2;          // forward only, nullable: relu(Y) (the ReLU layer behind the convolution, relu.cpp:25)
+    float* Y2;          // nullable. forward: second output relu(Y) (the ReLU layer behind the convolution, relu.cpp:25);
+                        // dgrad: INPUT, the output of the ReLU layer in front -- dx is stored as (Y2 <= 0 ? 0 : dx), relu.cpp:38
     int B, C, XH, XW;   // input tensor
     int U, V;           // output grid per image
     int su;             // grid stride in input coordinates
@@ -210,8 +211,12 @@ __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[M
                         const int cls = m / p.c_out, ci = m - cls * p.c_out;
                         const int ph = cls / p.s_out;
                         const int h = u * p.s_out + ph, w = v * p.s_out + (cls - ph * p.s_out);
-                        if (h < p.OH && w < p.OW)
-                            p.Y[(((size_t)b * p.c_out + ci) * p.OH + h) * p.OW + w] = acc[ma][nb][r];
+                        if (h < p.OH && w < p.OW) {
+                            const size_t o = (((size_t)b * p.c_out + ci) * p.OH + h) * p.OW + w;
+                            float val = acc[ma][nb][r];
+                            if constexpr (R2) val = (p.Y2[o] <= 0.f) ? 0.f : val;  // fused ReLU::backward of the layer in front
+                            p.Y[o] = val;
+                        }
                     }
                 }
             }
@@ -1107,7 +1112,7 @@ int launch_cfg3(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
     }
     char name[96];
     snprintf(name, sizeof(name), "igemm_kernel<%d,%d,%d,%d,%d,%d>%s", MF, MA, NB, WM, WN, CK,
-             pl.p.mode == MODE_FWD ? (R2 ? "/fwd+relu" : "/fwd") : "/dgrad");
+             pl.p.mode == MODE_FWD ? (R2 ? "/fwd+relu" : "/fwd") : (R2 ? "/dgrad+relu" : "/dgrad"));
     CNN_KLAUNCH(s, name, (kern<<<dim3(pl.grid_x, pl.grid_y), 64 * WM * WN, pl.lds_bytes, s>>>(pl.p)), CONV_TAG(d));
     return CNN_AMD_OK;
 }
@@ -1129,16 +1134,14 @@ int launch_dma_xm2(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
     char name[96];
     snprintf(name, sizeof(name), "igemm_dma_kernel<%d,%d,%d,%d,%d,%d%s>%s", MF, MA, NB, WM, WN, S,
              XM == 0 ? "" : (XM == 1 ? ",img" : (XM == 2 ? ",img+mask" : ",img+mask+skip")),
-             pl.p.mode == MODE_FWD ? (R2 ? "/fwd+relu" : "/fwd") : "/dgrad");
+             pl.p.mode == MODE_FWD ? (R2 ? "/fwd+relu" : "/fwd") : (R2 ? "/dgrad+relu" : "/dgrad"));
     CNN_KLAUNCH(s, name, (kern<<<dim3(pl.grid_x, pl.grid_y), 64 * WM * WN, pl.lds_bytes, s>>>(pl.p)), CONV_TAG(d));
     return CNN_AMD_OK;
 }
 
 template <int MF, int MA, int NB, int WM, int WN, int S, int XM>
 int launch_dma_xm(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
-    if constexpr (XM != 3) {  // (XM == 3 is a dgrad-only variant)
-        if (pl.p.Y2 != nullptr) return launch_dma_xm2<MF, MA, NB, WM, WN, S, XM, true>(pl, s, d);
-    }
+    if (pl.p.Y2 != nullptr) return launch_dma_xm2<MF, MA, NB, WM, WN, S, XM, true>(pl, s, d);
     return launch_dma_xm2<MF, MA, NB, WM, WN, S, XM, false>(pl, s, d);
 }
 
@@ -1290,16 +1293,22 @@ static int conv2d_forward_impl(const char* who, const cnn_conv2d_desc* d, const 
     return run_plan(pl, d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream), who, prepared);
 }
 
+// relu_below (nullable): output of the ReLU layer whose input gradient dx is -- fuses that layer's backward pass
 static int conv2d_backward_data_impl(const char* who, const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx,
-                                     void* ws, size_t ws_bytes, void* stream, bool prepared) {
+                                     void* ws, size_t ws_bytes, void* stream, bool prepared, const float* relu_below = nullptr) {
     if (int rc = check_desc(who, d)) return rc;
     CNN_REQUIRE(dy && (w || prepared) && dx, "%s: null pointer", who);
-    if (direct_conv_supported(d)) return direct_conv_dgrad(d, dy, w, dx, ws, ws_bytes, as_stream(stream), prepared);
-    if (pk_dgrad_s2_supported(d) && ws != nullptr && ws_bytes >= pk_dgrad_s2_workspace_floats(d) * sizeof(float))
-        return pk_dgrad_s2(d, dy, w, dx, ws, as_stream(stream), prepared);
+    const bool packed = direct_conv_supported(d) ||
+                        (pk_dgrad_s2_supported(d) && ws != nullptr && ws_bytes >= pk_dgrad_s2_workspace_floats(d) * sizeof(float));
+    if (packed) {  // the packed VALU kernels have no masked epilogue: same result from the separate ReLU kernel
+        const int rc = direct_conv_supported(d) ? direct_conv_dgrad(d, dy, w, dx, ws, ws_bytes, as_stream(stream), prepared)
+                                                : pk_dgrad_s2(d, dy, w, dx, ws, as_stream(stream), prepared);
+        if (rc || !relu_below) return rc;
+        return cnn_relu_backward(relu_below, dx, (size_t)d->B * d->Ci * d->H * d->W, stream);
+    }
     Plan pl;
     if (int rc = make_plan(who, d, MODE_DGRAD, &pl)) return rc;
-    return run_plan(pl, d, dy, w, nullptr, dx, nullptr, ws, ws_bytes, as_stream(stream), who, prepared);
+    return run_plan(pl, d, dy, w, nullptr, dx, const_cast<float*>(relu_below), ws, ws_bytes, as_stream(stream), who, prepared);
 }
 
 int cnn_conv2d_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
@@ -1401,6 +1410,22 @@ int cnn_conv2d_forward_prepared(const cnn_conv2d_desc* d, const float* x, const 
     CNN_REQUIRE(!direct_conv_supported(d) || direct_prepared_fwd_ok(d), "cnn_conv2d_forward_prepared: no prepared path for this layer");
     return conv2d_forward_impl("cnn_conv2d_forward_prepared", d, x, nullptr, bias, y, y_relu, (void*)prepared_fwd,
                                cnn_conv2d_prepared_bytes(d), stream, true);
+}
+
+int cnn_conv2d_backward_data_relu(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* relu_below, float* dx,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    CNN_REQUIRE(relu_below, "cnn_conv2d_backward_data_relu: null pointer");
+    return conv2d_backward_data_impl("cnn_conv2d_backward_data_relu", d, dy, w, dx, ws, ws_bytes, stream, false, relu_below);
+}
+
+int cnn_conv2d_backward_data_relu_prepared(const cnn_conv2d_desc* d, const float* dy, const void* prepared_dgrad,
+                                           const float* relu_below, float* dx, void* stream) {
+    CNN_REQUIRE(prepared_dgrad != nullptr && relu_below != nullptr, "cnn_conv2d_backward_data_relu_prepared: null pointer");
+    if (int rc = check_desc("cnn_conv2d_backward_data_relu_prepared", d)) return rc;
+    CNN_REQUIRE(!direct_conv_supported(d) || direct_prepared_dgrad_ok(d),
+                "cnn_conv2d_backward_data_relu_prepared: no prepared path for this layer");
+    return conv2d_backward_data_impl("cnn_conv2d_backward_data_relu_prepared", d, dy, nullptr, dx, (void*)prepared_dgrad,
+                                     cnn_conv2d_prepared_bytes(d), stream, true, relu_below);
 }
 
 int cnn_conv2d_backward_data_prepared(const cnn_conv2d_desc* d, const float* dy, const void* prepared_dgrad, float* dx,

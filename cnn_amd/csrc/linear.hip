@@ -119,7 +119,10 @@ __global__ __launch_bounds__(kBlock) void linear_bwd_x(const float* __restrict__
 // sample groups each walk B / kFG samples -- per (sample, neuron): one coalesced x load, the sample's dy row (broadcast),
 // gW partial sums in registers and the finished dx element written straight away -- and are combined through LDS in a
 // fixed order.  Workgroup 0 also reduces the bias gradient.  x is read once, dx written once (linear.cpp:56-90).
+// RELU: x is the output of the ReLU layer feeding this layer; dx is stored as (x <= 0 ? 0 : dx) = that layer's backward pass
+// (relu.cpp:38) -- the mask value is the x element this thread has loaded anyway.
 constexpr int kFG = 16;
+template <bool RELU>
 __global__ __launch_bounds__(kNeur * kFG) void linear_bwd_fused(const float* __restrict__ x, const float* __restrict__ dy,
                                                                const float* __restrict__ w, float* __restrict__ gw,
                                                                float* __restrict__ gb, float* __restrict__ dx, int B,
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(kNeur * kFG) void linear_bwd_fused(const float* __r
                 acc[j] += xv * dj;
                 s += dj * wr[j];
             }
-        if (live) dx[(size_t)b * in + i] = s;
+        if (live) dx[(size_t)b * in + i] = (RELU && xv <= 0.f) ? 0.f : s;
         if (blockIdx.x == 0 && il < out) bsum += d[il];  // lane j of every group: bias partial of output j
     }
 #pragma unroll
@@ -185,16 +188,21 @@ int cnn_linear_forward(const float* x, const float* w, const float* bias, float*
     return CNN_AMD_OK;
 }
 
-int cnn_linear_backward(const float* x, const float* dy, const float* w, float* gw, float* gb, float* dx, int B,
-                        int in, int out, float divisor, void* stream) {
+static int linear_backward_impl(const float* x, const float* dy, const float* w, float* gw, float* gb, float* dx, int B,
+                                int in, int out, float divisor, void* stream, bool relu_below) {
     CNN_REQUIRE(dy != nullptr, "cnn_linear_backward: dy is null");
     CNN_REQUIRE(B > 0 && in > 0 && out > 0, "cnn_linear_backward: B=%d in=%d out=%d", B, in, out);
     CNN_REQUIRE(B <= 65535, "cnn_linear_backward: B=%d exceeds the grid.y limit", B);
     hipStream_t s = as_stream(stream);
     if (gw && gb && dx && x && w && out <= kOutTile) {
-        CNN_KLAUNCH(s, "linear_bwd_fused",
-                    (linear_bwd_fused<<<ceil_div(in, kNeur), kNeur * kFG, 0, s>>>(x, dy, w, gw, gb, dx, B, in, out, divisor)),
-                    "B%d in%d out%d", B, in, out);
+        if (relu_below)
+            CNN_KLAUNCH(s, "linear_bwd_fused+relu",
+                        (linear_bwd_fused<true><<<ceil_div(in, kNeur), kNeur * kFG, 0, s>>>(x, dy, w, gw, gb, dx, B, in, out, divisor)),
+                        "B%d in%d out%d", B, in, out);
+        else
+            CNN_KLAUNCH(s, "linear_bwd_fused",
+                        (linear_bwd_fused<false><<<ceil_div(in, kNeur), kNeur * kFG, 0, s>>>(x, dy, w, gw, gb, dx, B, in, out, divisor)),
+                        "B%d in%d out%d", B, in, out);
         return CNN_AMD_OK;
     }
     if (gw) {
@@ -211,7 +219,19 @@ int cnn_linear_backward(const float* x, const float* dy, const float* w, float* 
         dim3 grid(ceil_div(in, kBlock) > 64 ? 64 : ceil_div(in, kBlock), B);
         CNN_KLAUNCH(s, "linear_bwd_x", (linear_bwd_x<<<grid, kBlock, 0, s>>>(dy, w, dx, in, out)), "B%d in%d out%d", B, in, out);
     }
+    if (relu_below && dx) return cnn_relu_backward(x, dx, (size_t)B * in, stream);  // (same result from the separate kernel)
     return CNN_AMD_OK;
+}
+
+int cnn_linear_backward(const float* x, const float* dy, const float* w, float* gw, float* gb, float* dx, int B,
+                        int in, int out, float divisor, void* stream) {
+    return linear_backward_impl(x, dy, w, gw, gb, dx, B, in, out, divisor, stream, false);
+}
+
+int cnn_linear_backward_relu(const float* x, const float* dy, const float* w, float* gw, float* gb, float* dx, int B,
+                             int in, int out, float divisor, void* stream) {
+    CNN_REQUIRE(x && dx, "cnn_linear_backward_relu: null pointer");
+    return linear_backward_impl(x, dy, w, gw, gb, dx, B, in, out, divisor, stream, true);
 }
 
 }  // extern "C"

@@ -64,6 +64,7 @@ class AlexNetHip:
         import os
 
         self.use_prep = fuse and not os.environ.get("CNN_AMD_NO_PREPARED")  # (A/B switch for measurements)
+        self._no_fbr = bool(os.environ.get("CNN_AMD_NO_BWD_RELU_FUSION"))  # (likewise)
         # conv_layer_1 -> relu_layer_1 -> max_pool_1 as one kernel: conv_out[0] / relu_out[0] are then NOT written (nothing in
         # the step reads them: the backward pass of that block works from pool_out + pool_mask)
         self.fuse_pool = bool(fuse_pool) and self.use_prep and self.convs[0].relu_maxpool2_supported()
@@ -205,8 +206,11 @@ class AlexNetHip:
     def backward(self, delta, divisor=None):
         div = float(self.B if divisor is None else divisor)
         g = self.grads
+        # fuse_bwd_relu: every ReLU::backward runs inside the kernel that PRODUCES its delta (the linear backward for
+        # relu_layer_4, the data gradient of conv_layer_{l+1} for relu_layer_l)
+        fbr = self.use_prep and not self._no_fbr
         capi.linear_backward(self.relu_out[3].view(self.B, self.lin_in), delta, self.lin_w(), div, self.lin_w(g),
-                             self.lin_b(g), self.d_lin)
+                             self.lin_b(g), self.d_lin, relu_below=fbr)
         cur = self.d_lin.view(self.relu_out[3].shape)
         for l in (3, 2, 1, 0):
             if l == 1 and self.fuse_pool and self.defer_dx0:
@@ -229,7 +233,7 @@ class AlexNetHip:
                 else:
                     capi.maxpool_backward(cur, self.pool_mask, (self.B, 16, hh, ww), 2, 2, self.d_pool)
                 cur = self.d_pool
-            if not (self.fuse and l == 0):
+            if not (self.fuse and l == 0) and not fbr:
                 capi.relu_backward(self.relu_out[l], cur)  # in place on the upstream delta (relu.cpp:37-39)
             lin = self.x if l == 0 else (self.pool_out if l == 1 else self.relu_out[l - 1])
             # Conv2D::backward in one call: weight/bias gradient on the library's side stream, concurrently with dgrad
@@ -238,8 +242,9 @@ class AlexNetHip:
                 self.convs[0].backward_weight(lin, cur, div, self.conv_w(0, g), self.conv_b(0, g))
                 self.pending_dx0 = self.prep0_dgrad[self.parity]
             elif self.use_prep:
+                # lin is relu_out[l-1] for l >= 2: its ReLU::backward is fused into this data gradient
                 self.convs[l].backward_prepared(lin, cur, self.prep[l][1], div, self.conv_w(l, g), self.conv_b(l, g),
-                                                self.d_conv[l], defer_join=True)
+                                                self.d_conv[l], defer_join=True, relu_below=lin if (fbr and l >= 2) else None)
             else:
                 self.convs[l].backward(lin, cur, self.conv_w(l), div, self.conv_w(l, g), self.conv_b(l, g), self.d_conv[l],
                                        defer_join=True)

@@ -102,6 +102,11 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
  * stride handled by output-parity classes; input rows/cols no window covers come out 0 like the reference. */
 int cnn_conv2d_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws,
                              size_t ws_bytes, void* stream);
+/* Conv2D data gradient followed by the ReLU::backward (relu.cpp:35-40) of the ReLU layer in front of this convolution:
+ * relu_below = that layer's forward output (same shape as dx); dx = (relu_below <= 0 ? 0 : dx), applied in the kernel's
+ * store epilogue.  Bit-identical to cnn_conv2d_backward_data + cnn_relu_backward(relu_below, dx). */
+int cnn_conv2d_backward_data_relu(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* relu_below,
+                                  float* dx, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Conv2D::backward (conv2d.cpp:97-202) in one call: the weight/bias-gradient kernels run on an internal side stream
  * CONCURRENTLY with the data-gradient kernels (fork/join by events on `stream`; hipGraph-capturable).  Same results as
@@ -152,6 +157,10 @@ int cnn_linear_forward(const float* x, const float* w, const float* bias, float*
 /* linear.cpp:56-90: gW = (x^T dy)/divisor (assigned), gb = (sum_b dy)/divisor, dx = dy W^T; any output may be NULL */
 int cnn_linear_backward(const float* x, const float* dy, const float* w, float* gw, float* gb, float* dx, int B,
                         int in, int out, float divisor, void* stream);
+/* Linear::backward followed by the ReLU::backward (relu.cpp:35-40) of the ReLU layer whose OUTPUT is this layer's input x:
+ * dx = (x <= 0 ? 0 : dx).  Bit-identical to cnn_linear_backward + cnn_relu_backward(x, dx). */
+int cnn_linear_backward_relu(const float* x, const float* dy, const float* w, float* gw, float* gb, float* dx, int B,
+                             int in, int out, float divisor, void* stream);
 
 /* ---- optional: filter preparation hoisted out of the per-layer calls ----------------------------------
  * cnn_conv2d_forward / cnn_conv2d_backward_data re-arrange the filters for their kernels in a small launch of their own
@@ -173,10 +182,16 @@ int cnn_conv2d_relu_maxpool2_forward_prepared(const cnn_conv2d_desc* d, const fl
                                               float* pooled, int32_t* mask, void* stream);
 int cnn_conv2d_backward_data_pooled2_prepared(const cnn_conv2d_desc* d, const float* dpool, const int32_t* mask,
                                               const float* pooled, const void* prepared_dgrad, float* dx, void* stream);
+int cnn_conv2d_backward_data_relu_prepared(const cnn_conv2d_desc* d, const float* dy, const void* prepared_dgrad,
+                                           const float* relu_below, float* dx, void* stream);
 /* cnn_conv2d_backward with the data gradient from prepared filters; workspace: cnn_conv2d_workspace_bytes(d) */
 int cnn_conv2d_backward_prepared(const cnn_conv2d_desc* d, const float* x, const float* dy, const void* prepared_dgrad,
                                  float* gw, float* gb, float* dx, float divisor, void* workspace, size_t workspace_bytes,
                                  void* stream, int defer_join);
+/* ... and with the ReLU::backward of the layer in front fused into the data gradient (relu_below nullable) */
+int cnn_conv2d_backward_prepared_relu(const cnn_conv2d_desc* d, const float* x, const float* dy, const void* prepared_dgrad,
+                                      const float* relu_below, float* gw, float* gb, float* dx, float divisor,
+                                      void* workspace, size_t workspace_bytes, void* stream, int defer_join);
 
 /* ---- BatchNorm2D : batchnorm2d.cpp:24-95 (forward), :98-158 (backward) ------------------------------- */
 /* Per-channel statistics over (B,H,W) of an NCHW tensor; gamma/beta/moving_mean/moving_var/saved_* are [C].

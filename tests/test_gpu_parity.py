@@ -637,3 +637,40 @@ def test_pool_fused_net_is_bit_identical(T, defer):
         assert T.equal(a.params, b.params) and T.equal(a.grads, b.grads), step
         assert T.equal(a.pool_out, b.pool_out) and T.equal(a.pool_mask, b.pool_mask)
         assert T.equal(a.d_conv[0], b.d_conv[0]) and T.equal(a.d_conv[1], b.d_conv[1]) and T.equal(a.logits, b.logits)
+
+
+@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 5, 6, 7, 9, 10, 11, 13)], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_conv2d_backward_data_relu_fusion_is_bit_identical(T, case):
+    """cnn_conv2d_backward_data_relu == cnn_conv2d_backward_data + cnn_relu_backward, every kernel family, plain and prepared"""
+    from cnn_amd import capi
+
+    x, w, b, dy = _conv_inputs(case, 700)
+    relu_below = np.maximum(x - 0.5, 0).astype(np.float32)  # a ReLU output with plenty of exact zeros
+    relu_below[0, 0, 0, :3] = [np.nan, -0.0, 0.0]
+    conv = capi.Conv2d(*case)
+    wd, dyd, rd = dev(T, w), dev(T, dy), dev(T, relu_below)
+    dx_ref = conv.backward_data(dyd, wd)
+    capi.relu_backward(rd, dx_ref)
+    dx = T.full_like(dx_ref, 7.0)
+    conv.backward_data_relu(dyd, wd, rd, dx)
+    assert np.array_equal(host(dx).view(np.uint32), host(dx_ref).view(np.uint32))
+    pf, pd = conv.prepared_buffers("cuda")
+    capi.prepare_filters([conv], [wd], [dev(T, b)], [pf], [pd])
+    dx2 = T.full_like(dx_ref, 7.0)
+    conv.backward_data_relu(dyd, None, rd, dx2, prepared_dgrad=pd)
+    assert np.array_equal(host(dx2).view(np.uint32), host(dx_ref).view(np.uint32))
+
+
+@pytest.mark.parametrize("B,n_in,n_out", [(4, 4608, 3), (3, 70, 5), (2, 33, 20)])
+def test_linear_backward_relu_fusion_is_bit_identical(T, B, n_in, n_out):
+    from cnn_amd import capi
+
+    x = np.maximum(uniform_pm1(710, (B, n_in)), 0).astype(np.float32)
+    x[0, :3] = [np.nan, -0.0, 0.0]
+    w, dy = normal_scaled(711, (n_in, n_out)), uniform_pm1(712, (B, n_out))
+    xd, wd, dyd = dev(T, x), dev(T, w), dev(T, dy)
+    gw0, gb0, dx0 = capi.linear_backward(xd, dyd, wd, float(B))
+    capi.relu_backward(xd, dx0)
+    gw1, gb1, dx1 = capi.linear_backward(xd, dyd, wd, float(B), relu_below=True)
+    for a, b2 in ((gw0, gw1), (gb0, gb1), (dx0, dx1)):  # (bit patterns: the NaN in x makes a NaN gradient row)
+        assert np.array_equal(host(a).view(np.uint32), host(b2).view(np.uint32))
