@@ -40,6 +40,7 @@ SIGNATURES = {
     "cnn_conv2d_relu_maxpool2_supported": (C.c_int, [_D]),
     "cnn_conv2d_relu_maxpool2_forward": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_relu_maxpool2_forward_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P]),
+    "cnn_conv2d_backward_pooled2_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P, C.c_int]),
     "cnn_conv2d_backward_weight_pooled2": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P]),
     "cnn_conv2d_backward_data_pooled2": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_backward_data_pooled2_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P, _P]),

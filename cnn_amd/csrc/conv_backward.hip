@@ -95,4 +95,24 @@ int cnn_conv2d_backward_prepared_relu(const cnn_conv2d_desc* d, const float* x, 
     return CNN_AMD_OK;
 }
 
+/* Conv2D::backward of the pool-fused first block: weight / bias gradient on the side stream, data gradient on `stream`,
+ * both rebuilt from the pooled domain (cnn_conv2d_backward_weight_pooled2 / _data_pooled2_prepared) */
+int cnn_conv2d_backward_pooled2_prepared(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask,
+                                         const float* pooled, const void* prepared_dgrad, float* gw, float* gb, float* dx,
+                                         float divisor, void* ws, size_t ws_bytes, void* stream, int defer_join) {
+    CNN_REQUIRE(d && x && dpool && mask && pooled && prepared_dgrad && gw && dx && ws, "cnn_conv2d_backward_pooled2_prepared: null pointer");
+    SideStream* side = nullptr;
+    if (int rc = get_side(&side)) return rc;
+    hipStream_t main = as_stream(stream);
+    CNN_HIP_CHECK(hipEventRecord(side->fork, main));
+    CNN_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+    if (int rc = cnn_conv2d_backward_weight_pooled2(d, x, dpool, mask, pooled, gw, gb, divisor, ws, ws_bytes, side->stream)) return rc;
+    if (int rc = cnn_conv2d_backward_data_pooled2_prepared(d, dpool, mask, pooled, prepared_dgrad, dx, main)) return rc;
+    if (!defer_join) {
+        CNN_HIP_CHECK(hipEventRecord(side->join, side->stream));
+        CNN_HIP_CHECK(hipStreamWaitEvent(main, side->join, 0));
+    }
+    return CNN_AMD_OK;
+}
+
 }  // extern "C"

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(kBlock) void linear_fwd(const float* __restrict__ x
         float acc[kOutTile];
 #pragma unroll
         for (int j = 0; j < kOutTile; ++j) acc[j] = 0.f;
+#pragma unroll 6  // (six independent x / W loads in flight per thread: the loop is latency-, not bandwidth-bound)
         for (int i = threadIdx.x; i < in; i += kBlock) {
             const float xv = xb[i];
             const float* wr = w + (size_t)i * out + j0;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(kNeur * kFG) void linear_bwd_fused(const float* __r
         acc[j] = 0.f;
         wr[j] = (live && j < out) ? w[(size_t)i * out + j] : 0.f;
     }
-#pragma unroll 4
+#pragma unroll 8
     for (int b = bb; b < be; ++b) {
         const float xv = live ? x[(size_t)b * in + i] : 0.f;
         const float* d = dy + (size_t)b * out;

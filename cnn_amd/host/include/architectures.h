@@ -24,6 +24,11 @@ extern void* stream;            // hipStream_t all layers enqueue on (addition; 
 // addition: let the AlexNet container run Conv2D+ReLU forward and MaxPool2D+ReLU backward as one kernel each
 // (bit-identical results, every layer's output / delta tensor is still produced); false = one kernel per layer call
 extern bool fuse_layers;
+// Opt-in (default off): run Conv2D -> ReLU -> MaxPool2D(2,2) blocks as ONE kernel and their backward passes from the pooled
+// domain.  Unlike fuse_layers this changes something observable: in such a pass the block's Conv2D and ReLU layers do not
+// write their own output tensors (get_output() of those two layers is stale); everything else -- the pool's output, all
+// gradients, every later layer -- is bit-identical.
+extern bool fuse_pool_block;
 
 class WithoutGrad final {
 public:
@@ -71,10 +76,14 @@ public:
 };
 
 class ReLU;
+class MaxPool2D;
 
 class Conv2D : public Layer {
 private:
     ReLU* fused_relu = nullptr;  // the ReLU layer right behind this convolution (set by the container), or null
+    MaxPool2D* fused_pool = nullptr;  // ... and the MaxPool2D(2,2) behind that ReLU: Conv -> ReLU -> MaxPool in one kernel
+    ReLU* relu_below = nullptr;       // the ReLU layer whose output is this layer's input: its backward pass is fused in
+    bool pool_fused_pass = false;     // this pass' forward went through the pooled kernel: backward receives d(pool output)
     void* prep_fwd = nullptr;    // prepared filters (forward / data gradient layouts)
     void* prep_dgrad = nullptr;
     bool prepared_active = false;
@@ -109,6 +118,8 @@ public:
     void load_weights(std::ifstream& reader) override;
     int get_params_num() const;
     void set_fused_relu(ReLU* relu) { fused_relu = relu; }  // addition (see architectures::fuse_layers)
+    void set_fused_pool(MaxPool2D* pool) { fused_pool = pool; }
+    void set_relu_below(ReLU* relu) { relu_below = relu; }
     // additions: filter re-layout hoisted out of forward / backward (cnn_conv2d_prepare_filters); the container prepares
     // all layers with one call after every parameter change and switches the layers to the *_prepared entry points
     bool shape_known() const { return batch > 0; }
@@ -128,12 +139,19 @@ private:
     int* mask = nullptr;  // device int32 [B][C*Ho*Wo], flat indices into the sample's C*H*W (pool2d.cpp:81)
     int in_C = 0, in_H = 0, in_W = 0, batch = 0;
     ReLU* fused_relu_below = nullptr;  // the ReLU layer whose output is this pool's input (set by the container), or null
+    bool forward_done = false;       // this pass' output + mask were written by the producing Conv2D kernel
+    bool backward_passthrough = false;  // ... and the delta stays in the pooled domain for that Conv2D's backward
 
 public:
     MaxPool2D(std::string _name, const int _kernel_size = 2, const int _step = 2)
         : Layer(_name), kernel_size(_kernel_size), step(_step), padding(0) {}
     ~MaxPool2D() override;
     void set_fused_relu_below(ReLU* relu) { fused_relu_below = relu; }  // addition (see architectures::fuse_layers)
+    // additions used by Conv2D when the container fused Conv2D -> ReLU -> this pool into one kernel
+    bool fusable_2x2() const { return kernel_size == 2 && step == 2; }
+    void fused_forward_target(int B, int C, int H, int W, bool record, data_type** pooled, int** mask_out);  // arms forward_done
+    const data_type* pooled_dev() const { return out_buf.base; }
+    const int* mask_dev() const { return mask; }
     std::vector<tensor> forward(const std::vector<tensor>& input) override;
     std::vector<tensor> backward(std::vector<tensor>& delta) override;
 };
@@ -149,6 +167,7 @@ public:
     // additions used by Conv2D / MaxPool2D when the container fused this layer into their kernels
     data_type* fused_forward_target(int B, int C, int H, int W);  // output arena (allocated on first use); arms forward_done
     void fused_backward_done() { backward_done = true; }
+    void fused_forward_skipped(int B, int C, int H, int W);  // pool-fused pass: the output is never materialised
     std::vector<tensor> forward(const std::vector<tensor>& input) override;
     std::vector<tensor> backward(std::vector<tensor>& delta) override;
 };
@@ -165,8 +184,10 @@ private:
     const data_type* saved_input = nullptr;
     std::vector<tensor> saved_input_tensors;
     int batch = 0;
+    ReLU* relu_below = nullptr;  // the ReLU layer whose output is this layer's input: its backward pass is fused in
 
 public:
+    void set_relu_below(ReLU* relu) { relu_below = relu; }  // addition (see architectures::fuse_layers)
     LinearLayer(std::string _name, const int _in_channels, const int _out_channels);
     ~LinearLayer() override;
     std::vector<tensor> forward(const std::vector<tensor>& input) override;

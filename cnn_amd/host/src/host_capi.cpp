@@ -56,6 +56,7 @@ float* cnnh_net_grads_device(void* hv) { return ((Handle*)hv)->net->grads_device
 void cnnh_set_stream(void* hip_stream) { architectures::stream = hip_stream; }
 void cnnh_set_no_grad(int on) { architectures::no_grad = on != 0; }
 void cnnh_set_fuse_layers(int on) { architectures::fuse_layers = on != 0; }
+void cnnh_set_fuse_pool_block(int on) { architectures::fuse_pool_block = on != 0; }
 
 void cnnh_net_set_params(void* hv, const float* host) {
     Handle* h = (Handle*)hv;

@@ -15,6 +15,7 @@ data_type architectures::random_times = 10.f;  // architectures.cpp:6
 bool architectures::no_grad = false;           // architectures.cpp:8
 void* architectures::stream = nullptr;
 bool architectures::fuse_layers = true;
+bool architectures::fuse_pool_block = false;
 
 // ---------------------------------------------------------------------------------------------------------------
 BatchBuffer::~BatchBuffer() {
@@ -175,6 +176,19 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
     }
     cnn_conv2d_desc d{B, in_channels, H, W, out_channels, kernel_size, stride, padding};
     const bool prepared = prepared_active && fuse_layers && B == batch;
+    pool_fused_pass = false;
+    if (prepared && fuse_pool_block && fused_relu != nullptr && fused_pool != nullptr && fused_pool->fusable_2x2() &&
+        cnn_conv2d_relu_maxpool2_supported(&d)) {
+        // Conv2D -> ReLU -> MaxPool2D(2,2) in one kernel: only the pool's output and mask are written; this layer's and the
+        // ReLU's output tensors are NOT materialised in such a pass (their backward passes run from the pooled domain)
+        data_type* pooled = nullptr;
+        int* pmask = nullptr;
+        fused_pool->fused_forward_target(B, out_channels, out_H, out_W, !no_grad, &pooled, &pmask);
+        fused_relu->fused_forward_skipped(B, out_channels, out_H, out_W);
+        must(cnn_conv2d_relu_maxpool2_forward_prepared(&d, x, prep_fwd, pooled, pmask, stream), "cnn_conv2d_relu_maxpool2_forward_prepared");
+        pool_fused_pass = !no_grad;
+        return output;
+    }
     if (fused_relu != nullptr && fuse_layers) {  // the ReLU behind this layer gets its output from the same kernel
         data_type* y_relu = fused_relu->fused_forward_target(B, out_channels, out_H, out_W);
         if (prepared)
@@ -204,11 +218,23 @@ std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
         workspace = dev_alloc(need);
         workspace_bytes = need;
     }
-    if (prepared_active && fuse_layers && B == batch)
-        must(cnn_conv2d_backward_prepared(&d, saved_input, dy, prep_dgrad, grads, grads + (size_t)out_channels * params_for_one_kernel,
-                                          delta_buf.base, (float)B, workspace, workspace_bytes, stream, /*defer_join=*/1),
-             "cnn_conv2d_backward_prepared");
-    else
+    if (pool_fused_pass) {
+        // dy is the delta of the POOL output (the pool and the ReLU passed it through untouched)
+        assert(prepared_active && fused_pool != nullptr && B == batch);
+        must(cnn_conv2d_backward_pooled2_prepared(&d, saved_input, dy, fused_pool->mask_dev(), fused_pool->pooled_dev(), prep_dgrad, grads,
+                                                  grads + (size_t)out_channels * params_for_one_kernel, delta_buf.base, (float)B,
+                                                  workspace, workspace_bytes, stream, /*defer_join=*/1),
+             "cnn_conv2d_backward_pooled2_prepared");
+        pool_fused_pass = false;
+    } else if (prepared_active && fuse_layers && B == batch) {
+        // relu_below: this layer's input IS that ReLU's output, so its backward mask is applied in the data-gradient epilogue
+        const data_type* rb = relu_below != nullptr ? saved_input : nullptr;
+        must(cnn_conv2d_backward_prepared_relu(&d, saved_input, dy, prep_dgrad, rb, grads,
+                                               grads + (size_t)out_channels * params_for_one_kernel, delta_buf.base, (float)B,
+                                               workspace, workspace_bytes, stream, /*defer_join=*/1),
+             "cnn_conv2d_backward_prepared_relu");
+        if (rb) relu_below->fused_backward_done();
+    } else
         must(cnn_conv2d_backward(&d, saved_input, dy, w_dev(), grads, grads + (size_t)out_channels * params_for_one_kernel,
                                  delta_buf.base, (float)B, workspace, workspace_bytes, stream, /*defer_join=*/1),
              "cnn_conv2d_backward");  // joined in update_gradients / AlexNet::backward
@@ -247,7 +273,28 @@ MaxPool2D::~MaxPool2D() {
     if (mask) cnn_device_free(mask);
 }
 
+void MaxPool2D::fused_forward_target(int B, int C, int H, int W, bool record, data_type** pooled, int** mask_out) {
+    const int out_H = cnn_maxpool2d_out_dim(H, kernel_size, step), out_W = cnn_maxpool2d_out_dim(W, kernel_size, step);
+    if (out_buf.empty()) {
+        out_buf.allocate(B, C, out_H, out_W, name + "_output");
+        output = out_buf.views;
+        batch = B;
+    }
+    assert(B <= batch);
+    in_C = C; in_H = H; in_W = W;
+    if (record && mask == nullptr) mask = (int*)dev_alloc(sizeof(int) * (size_t)batch * C * out_H * out_W);
+    *pooled = out_buf.base;
+    *mask_out = record ? mask : nullptr;
+    forward_done = true;
+    backward_passthrough = record;
+}
+
 std::vector<tensor> MaxPool2D::forward(const std::vector<tensor>& input) {
+    if (forward_done) {  // written by the producing convolution's kernel in this pass
+        forward_done = false;
+        return output;
+    }
+    backward_passthrough = false;
     const int B = (int)input.size();
     const int C = input[0]->C, H = input[0]->H, W = input[0]->W;
     const int out_H = cnn_maxpool2d_out_dim(H, kernel_size, step), out_W = cnn_maxpool2d_out_dim(W, kernel_size, step);
@@ -267,6 +314,11 @@ std::vector<tensor> MaxPool2D::forward(const std::vector<tensor>& input) {
 }
 
 std::vector<tensor> MaxPool2D::backward(std::vector<tensor>& delta) {
+    if (backward_passthrough) {  // the producing Conv2D's backward kernels consume the pooled-domain delta directly
+        backward_passthrough = false;
+        if (fused_relu_below != nullptr) fused_relu_below->fused_backward_done();
+        return delta;
+    }
     const int B = (int)delta.size();
     assert(mask != nullptr && "backward without a recorded forward (no_grad?)");
     if (delta_buf.empty()) delta_buf.allocate(batch, in_C, in_H, in_W, name + "_delta");
@@ -292,6 +344,10 @@ data_type* ReLU::fused_forward_target(int B, int C, int H, int W) {
     assert((size_t)B <= out_buf.views.size() && out_buf.sample_len == (size_t)C * H * W);
     forward_done = true;
     return out_buf.base;
+}
+
+void ReLU::fused_forward_skipped(int B, int C, int H, int W) {
+    fused_forward_target(B, C, H, W);  // (keeps the layer's output tensors in place for the pass-through; not written)
 }
 
 std::vector<tensor> ReLU::forward(const std::vector<tensor>& input) {
@@ -523,9 +579,16 @@ std::vector<tensor> LinearLayer::backward(std::vector<tensor>& delta) {
     if (delta_buf.empty())
         delta_buf.allocate(batch, std::get<0>(delta_shape), std::get<1>(delta_shape), std::get<2>(delta_shape),
                            "linear_delta");
-    must(cnn_linear_backward(saved_input, dy, params, grads, grads + (size_t)in_channels * out_channels, delta_buf.base, B,
-                             in_channels, out_channels, (float)B, stream),
-         "cnn_linear_backward");
+    if (relu_below != nullptr && fuse_layers) {  // the input IS that ReLU's output: its backward mask in the same kernel
+        must(cnn_linear_backward_relu(saved_input, dy, params, grads, grads + (size_t)in_channels * out_channels, delta_buf.base, B,
+                                      in_channels, out_channels, (float)B, stream),
+             "cnn_linear_backward_relu");
+        relu_below->fused_backward_done();
+    } else {
+        must(cnn_linear_backward(saved_input, dy, params, grads, grads + (size_t)in_channels * out_channels, delta_buf.base, B,
+                                 in_channels, out_channels, (float)B, stream),
+             "cnn_linear_backward");
+    }
     grads_ready = true;
     return delta_buf.views;
 }

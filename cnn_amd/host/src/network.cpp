@@ -38,6 +38,19 @@ void AlexNet::build(int num_classes, bool batch_norm) {
         if (auto* pool = dynamic_cast<MaxPool2D*>(next->get())) {
             if (auto* relu = dynamic_cast<ReLU*>(it->get())) pool->set_fused_relu_below(relu);
         }
+        // ReLU -> Conv2D / LinearLayer: the ReLU's backward pass runs inside the consumer's data-gradient kernel
+        if (auto* relu = dynamic_cast<ReLU*>(it->get())) {
+            if (auto* conv = dynamic_cast<Conv2D*>(next->get())) conv->set_relu_below(relu);
+            if (auto* lin = dynamic_cast<LinearLayer*>(next->get())) lin->set_relu_below(relu);
+        }
+        // Conv2D -> ReLU -> MaxPool2D: one forward kernel, backward from the pooled domain
+        auto next2 = std::next(next);
+        if (next2 != layers_sequence.end()) {
+            auto* conv = dynamic_cast<Conv2D*>(it->get());
+            auto* relu = dynamic_cast<ReLU*>(next->get());
+            auto* pool = dynamic_cast<MaxPool2D*>(next2->get());
+            if (conv && relu && pool) conv->set_fused_pool(pool);
+        }
     }
     n_params = 0;
     for (const auto& layer : layers_sequence) n_params += layer->param_count();

@@ -184,6 +184,11 @@ int cnn_conv2d_backward_data_pooled2_prepared(const cnn_conv2d_desc* d, const fl
                                               const float* pooled, const void* prepared_dgrad, float* dx, void* stream);
 int cnn_conv2d_backward_data_relu_prepared(const cnn_conv2d_desc* d, const float* dy, const void* prepared_dgrad,
                                            const float* relu_below, float* dx, void* stream);
+/* cnn_conv2d_backward_weight_pooled2 (side stream) + cnn_conv2d_backward_data_pooled2_prepared in one call, like
+ * cnn_conv2d_backward_prepared */
+int cnn_conv2d_backward_pooled2_prepared(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask,
+                                         const float* pooled, const void* prepared_dgrad, float* gw, float* gb, float* dx,
+                                         float divisor, void* workspace, size_t workspace_bytes, void* stream, int defer_join);
 /* cnn_conv2d_backward with the data gradient from prepared filters; workspace: cnn_conv2d_workspace_bytes(d) */
 int cnn_conv2d_backward_prepared(const cnn_conv2d_desc* d, const float* x, const float* dy, const void* prepared_dgrad,
                                  float* gw, float* gb, float* dx, float divisor, void* workspace, size_t workspace_bytes,

@@ -206,3 +206,31 @@ def test_host_net_layer_fusion_is_bit_identical():
     for a, b in zip(res[0][1:], res[1][1:]):
         assert np.array_equal(a, b)
     assert res[0][0] == res[1][0]
+
+
+@pytest.mark.gpu
+def test_host_net_pool_block_fusion_is_bit_identical():
+    """architectures::fuse_pool_block (opt-in): Conv2D -> ReLU -> MaxPool2D as one kernel, backward from the pooled domain;
+    parameters, gradients, losses, the pool's output and the last block's output equal the default run bit for bit (the
+    first block's Conv2D / ReLU outputs are not materialised in that mode and are not compared)"""
+    from cnn_amd import hostapi
+
+    B = 3
+    x = uniform01(70, (B, 3, 224, 224))
+    labels = np.array([0, 2, 1], np.int32)
+    p0 = normal_scaled(71, (111267,))
+    res = []
+    for on in (1, 0):
+        hostapi.load().cnnh_set_fuse_pool_block(on)
+        try:
+            net = hostapi.HostAlexNet(3)
+            net.set_params(p0)
+            losses = [net.train_step_host(x, labels, 1e-3)[0] for _ in range(3)]
+            res.append((losses, net.get_params(), net.get_grads(), net.layer_output("max_pool_1", (B, 16, 55, 55)),
+                        net.layer_output("relu_layer_4", (B, 128, 6, 6)), net.forward_host(x)))
+            net.close()
+        finally:
+            hostapi.load().cnnh_set_fuse_pool_block(0)
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert np.array_equal(a, b)
+    assert res[0][0] == res[1][0]
