@@ -37,8 +37,18 @@ def algorithmic_work(key):
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         flops = 2.0 * B * Co * Ho * Wo * Ci * k * k
         x_b, y_b, w_b = 4.0 * B * Ci * H * W, 4.0 * B * Co * Ho * Wo, 4.0 * Co * Ci * k * k
-        if kernel.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel", "wgrad_rd", "conv_direct", "conv_dgrad_pk", "conv_fwd_pk", "conv_wgrad_pk")):
-            fused = y_b if (kernel.endswith("+relu") or ",relu" in kernel) else 0.0  # fused ReLU: a second output tensor
+        if kernel.endswith("+pool") or kernel.startswith("conv_fwd_pool_pk"):
+            # first block in the pooled domain: the Co*Ho*Wo tensors are never touched.  pooled-domain tensor = B*Co*(Ho/2)*(Wo/2)
+            pd_b = 4.0 * B * Co * (Ho // 2) * (Wo // 2)
+            fl = 2.0 * B * Co * (2 * (Ho // 2)) * (2 * (Wo // 2)) * Ci * k * k  # conv pixels inside a pooling window
+            if kernel.startswith("conv_fwd_pool_pk"):
+                return x_b + 2 * pd_b + w_b, fl          # x, w -> pooled + mask
+            return x_b + 3 * pd_b + w_b, fl               # wgrad: x + (dpool, mask, pooled) -> gw ; dgrad: the three -> dx
+        if kernel.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel", "wgrad_rd", "conv_direct", "conv_dgrad_pk", "conv_fwd_pk",
+                              "conv_wgrad_pk", "conv_fwd_rd")):
+            fused = y_b if (kernel.endswith("/fwd+relu") or ",relu" in kernel or kernel.endswith(">+relu")) else 0.0  # second output tensor
+            if kernel.endswith("/dgrad+relu"):
+                fused = x_b  # fused ReLU::backward: the mask tensor (shape of dx) is read
             return x_b + y_b + w_b + fused, flops  # fwd: x,w -> y ; dgrad: dy,w -> dx ; wgrad: x,dy -> gw
         if kernel.startswith("bias_grad_partial"):
             return y_b, B * Co * Ho * Wo

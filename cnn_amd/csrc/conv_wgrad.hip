@@ -22,6 +22,9 @@ int direct_conv_wgrad_pooled(const cnn_conv2d_desc* d, const float* x, const flo
                              float* slabs, hipStream_t s);
 int wgrad_rd_slots(const cnn_conv2d_desc* d);  // conv_wgrad_rd.hip: register-direct MFMA kernel (3x3, stride 1/2, pad 0)
 int wgrad_rd_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
+int wgrad_rd_pooled_slots(const cnn_conv2d_desc* d);
+int wgrad_rd_launch_pooled(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask, const float* pooled,
+                           float* slabs, hipStream_t s);
 }
 
 namespace {
@@ -537,8 +540,16 @@ int launch_w(const WPlan& pl, hipStream_t s, const cnn_conv2d_desc* d, int* nspl
 
 // the register-direct kernel (conv_wgrad_rd.hip) takes every geometry it covers except the thin first layer (packed VALU
 // kernel); CNN_AMD_WGRAD_RD=0 sends those layers through the LDS-staged kernel below instead (A/B measurements)
+// The thin first layer (3 -> 16 channels) stays on the packed VALU kernel unless CNN_AMD_WG_POOL_RD=1: the MFMA kernel is
+// faster on a materialised delta (102 vs 123 us at batch 256) but slower from the pooled domain (196 vs 145 us: three
+// 16-byte loads per window triple from 32 different channel planes per wave), and that is the variant the train step uses;
+// both variants switch together so that the fused and unfused paths keep identical summation orders.
+bool first_layer_rd() {
+    const char* e = getenv("CNN_AMD_WG_POOL_RD");
+    return e && atoi(e) != 0;
+}
 bool rd_wanted(const cnn_conv2d_desc* d) {
-    if (direct_wgrad_slots(d) > 0) return false;
+    if (direct_wgrad_slots(d) > 0 && !first_layer_rd()) return false;
     const char* e = getenv("CNN_AMD_WGRAD_RD");
     if (e && atoi(e) == 0) return false;
     return wgrad_rd_slots(d) > 0;
@@ -571,6 +582,9 @@ size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d) {
     const int rs = wgrad_rd_slots(d);
     const size_t rw = rs ? (size_t)(rs + (rs + 63) / 64) * d->Co * (d->Ci * 9 + 1) : 0;
     if (rw > m) m = rw;
+    const int rps = wgrad_rd_pooled_slots(d);
+    const size_t rpw = rps ? (size_t)(rps + (rps + 63) / 64) * d->Co * (d->Ci * 9 + 1) : 0;
+    if (rpw > m) m = rpw;
     return (m + 64) * sizeof(float);
 }
 
@@ -587,6 +601,14 @@ int cnn_conv2d_backward_weight_pooled2(const cnn_conv2d_desc* d, const float* x,
     CNN_REQUIRE(ws != nullptr && ws_bytes >= need_d, "cnn_conv2d_backward_weight_pooled2: workspace too small (%zu < %zu bytes)", ws_bytes,
                 need_d);
     hipStream_t sd = as_stream(stream);
+    // MFMA register-direct kernel (CNN_AMD_WG_POOL_RD=0: the packed VALU kernel): same slab layout, [16][27 | 1]
+    const int rs = first_layer_rd() ? wgrad_rd_pooled_slots(d) : 0;
+    if (rs > 0 && ws_bytes >= (size_t)(rs + (rs + 63) / 64) * n * sizeof(float)) {
+        if (int rc = wgrad_rd_launch_pooled(d, x, dpool, mask, pooled, (float*)ws, sd)) return rc;
+        char tagr[160];
+        snprintf(tagr, sizeof(tagr), CONV_TAG(d));
+        return reduce_slabs(sd, (const float*)ws, rs, n, (float*)ws + (size_t)rs * n, gw, divisor, tagr, 27, gb);
+    }
     if (int rc = direct_conv_wgrad_pooled(d, x, dpool, mask, pooled, (float*)ws, sd)) return rc;
     char tagd[160];
     snprintf(tagd, sizeof(tagd), CONV_TAG(d));
@@ -599,7 +621,7 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
     CNN_REQUIRE(x && dy && gw, "cnn_conv2d_backward_weight: null pointer");
     CNN_REQUIRE(divisor != 0.f, "cnn_conv2d_backward_weight: divisor is 0");
     CNN_REQUIRE(ws != nullptr, "cnn_conv2d_backward_weight: workspace is null");
-    if (const int ds = direct_wgrad_slots(d)) {
+    if (const int ds = rd_wanted(d) ? 0 : direct_wgrad_slots(d)) {
         const size_t n = 16 * 28, need_d = (size_t)(ds + (ds + 63) / 64) * n * sizeof(float);
         if (ws_bytes >= need_d) {
             hipStream_t sd = as_stream(stream);

@@ -43,7 +43,10 @@ struct __attribute__((packed, aligned(4))) f4u {
 
 struct RdParams {
     const float* x;
-    const float* dy;
+    const float* dy;       // POOLED kernels: dpool, the delta of the 2x2 / stride-2 pool output behind this layer's ReLU
+    const int* pmask;      // POOLED: the pool's argmax mask and forward output; dy[co][p][q] is rebuilt as
+    const float* pooled;   //   (pmask[w] == co*Ho*Wo + p*Wo + q && !(pooled[w] <= 0)) ? dpool[w] : 0,  w = window (p/2, q/2)
+    int PHo, PWo;
     float* slabs;  // [gridDim.x][Co][pitch]
     int B, Ci, H, W, Co, Ho, Wo;
     int Ntot, pitch;  // Ci*9, Ntot + 1 (column Ntot = bias gradient)
@@ -77,7 +80,7 @@ __device__ __forceinline__ f4u load4(const float* __restrict__ p, int nvalid) {
     return v;
 }
 
-template <int S, int NT, int RL>
+template <int S, int NT, int RL, bool POOLED>
 __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
     constexpr int WL = S * RL;  // floats of x a lane needs per chunk and tile
     __shared__ float red[32][NT * 32 + 1];  // (+1: bank padding; the column doubles as the bias-gradient slot)
@@ -134,7 +137,8 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
         const int co_c = co < p.Co ? co : 0;
         unsigned cur_x = 0, nxt_x = 0, nxt_a = 0;
         int cur_nv = 0, nxt_nv = 0, cur_nb = 0, nxt_nb = 0;  // live pixels of the lane's run: A side (0 for co >= Co) / B side
-        auto locate = [&](int ch, unsigned& aoff, unsigned& xb, int& nv, int& nb) {
+        int cur_e = 0, nxt_e = 0;  // POOLED: flat index (within the sample) of the first pixel of the lane's run, channel co
+        auto locate = [&](int ch, unsigned& aoff, unsigned& xb, int& nv, int& nb, int& eidx) {
             const int run = 2 * ch + kg;
             const bool rlive = run < p.runs_total;
             const int runc = rlive ? run : 0;
@@ -145,8 +149,46 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
             npix = npix > RL ? RL : npix;
             nb = rlive ? npix : 0;
             nv = co < p.Co ? nb : 0;
-            aoff = (unsigned)(((b * p.Co + co_c) * p.Ho + pr) * p.Wo + q0);
+            if constexpr (POOLED) {
+                int inwin = 2 * p.PWo - q0;  // pixels of the run that lie inside a pooling window (none in an uncovered row)
+                inwin = (pr >> 1) < p.PHo ? (inwin < 0 ? 0 : inwin) : 0;
+                nv = nv < inwin ? nv : inwin;
+                aoff = (unsigned)(((b * p.Co + co_c) * p.PHo + (pr >> 1)) * p.PWo + (q0 >> 1));
+                eidx = (co_c * p.Ho + pr) * p.Wo + q0;
+            } else {
+                aoff = (unsigned)(((b * p.Co + co_c) * p.Ho + pr) * p.Wo + q0);
+                eidx = 0;
+            }
             xb = (unsigned)(b * (p.Ci * p.H * p.W) + (S * pr) * p.W + S * q0);
+        };
+        constexpr int NA = POOLED ? 3 * (RL / 8) : RL / 4;  // 16-byte pieces of the A side: dy run | dpool, mask, pooled of RL/2 windows
+        auto load_a = [&](f4u (&buf)[NA], unsigned aoff) {
+            if constexpr (POOLED) {
+#pragma unroll
+                for (int j = 0; j < RL / 8; ++j) {
+                    buf[j] = *(const f4u*)(p.dy + aoff + 4 * j);
+                    buf[RL / 8 + j] = *(const f4u*)((const float*)p.pmask + aoff + 4 * j);
+                    buf[2 * (RL / 8) + j] = *(const f4u*)(p.pooled + aoff + 4 * j);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < RL / 4; ++j) buf[j] = *(const f4u*)(p.dy + aoff + 4 * j);
+            }
+        };
+        auto f4_at = [](const f4u& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; };
+        // A registers of the current run: live pixels only, POOLED: MaxPool2D::backward + ReLU::backward on the fly
+        auto build_a = [&](float (&a)[RL], const f4u (&buf)[NA]) {
+#pragma unroll
+            for (int t = 0; t < RL; ++t) {
+                if constexpr (POOLED) {
+                    const int w = t >> 1;
+                    const float g = f4_at(buf[w / 4], w & 3), pl = f4_at(buf[2 * (RL / 8) + w / 4], w & 3);
+                    const int mk = __builtin_bit_cast(int, f4_at(buf[RL / 8 + w / 4], w & 3));
+                    a[t] = (t < cur_nv && mk == cur_e + t && !(pl <= 0.f)) ? g : 0.f;
+                } else {
+                    a[t] = t < cur_nv ? f4_at(buf[t / 4], t & 3) : 0.f;
+                }
+            }
         };
         // one tile's MFMAs: k-slot t <-> pixel t of the lane's run
         auto tile_mfma = [&](int nt, const float (&a)[RL], const f4u (&win)[WL / 4]) {
@@ -165,26 +207,19 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bv, acc[nt], 0, 0, 0);
             }
         };
-        f4u abuf[RL / 4], wb[2][WL / 4];
+        f4u abuf[NA], wb[2][WL / 4];
         {
             unsigned a0;
-            locate(w_lo, a0, cur_x, cur_nv, cur_nb);
-#pragma unroll
-            for (int j = 0; j < RL / 4; ++j) abuf[j] = *(const f4u*)(p.dy + a0 + 4 * j);
+            locate(w_lo, a0, cur_x, cur_nv, cur_nb, cur_e);
+            load_a(abuf, a0);
 #pragma unroll
             for (int j = 0; j < WL / 4; ++j) wb[0][j] = *(const f4u*)(p.x + (cur_x + (unsigned)xoff[0]) + 4 * j);
         }
         auto body = [&](auto PC, int ch_next) {
             constexpr int P = decltype(PC)::value;
-            locate(ch_next, nxt_a, nxt_x, nxt_nv, nxt_nb);
+            locate(ch_next, nxt_a, nxt_x, nxt_nv, nxt_nb, nxt_e);
             float a[RL];
-#pragma unroll
-            for (int j = 0; j < RL / 4; ++j) {
-                a[4 * j] = 4 * j < cur_nv ? abuf[j].x : 0.f;
-                a[4 * j + 1] = 4 * j + 1 < cur_nv ? abuf[j].y : 0.f;
-                a[4 * j + 2] = 4 * j + 2 < cur_nv ? abuf[j].z : 0.f;
-                a[4 * j + 3] = 4 * j + 3 < cur_nv ? abuf[j].w : 0.f;
-            }
+            build_a(a, abuf);
             add_bias(a);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -194,8 +229,7 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
                     for (int j = 0; j < WL / 4; ++j)
                         wb[bi ^ 1][j] = *(const f4u*)(p.x + (cur_x + (unsigned)xoff[nt + 1 < NT ? nt + 1 : 0]) + 4 * j);
                 } else {
-#pragma unroll
-                    for (int j = 0; j < RL / 4; ++j) abuf[j] = *(const f4u*)(p.dy + nxt_a + 4 * j);
+                    load_a(abuf, nxt_a);
 #pragma unroll
                     for (int j = 0; j < WL / 4; ++j) wb[bi ^ 1][j] = *(const f4u*)(p.x + (nxt_x + (unsigned)xoff[0]) + 4 * j);
                 }
@@ -205,6 +239,7 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
             cur_x = nxt_x;
             cur_nv = nxt_nv;
             cur_nb = nxt_nb;
+            cur_e = nxt_e;
         };
         int ch = w_lo;
         if (NT & 1) {  // an odd tile count flips the buffer parity from chunk to chunk
@@ -230,7 +265,28 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
         npix = npix < 0 ? 0 : (npix > RL ? RL : npix);
         // ---- A operand: RL consecutive dy values of channel co
         float a[RL];
-        {
+        if constexpr (POOLED) {
+            const bool rowok = co < p.Co && (pr >> 1) < p.PHo;
+            const int cc = co < p.Co ? co : 0;
+            int inwin = 2 * p.PWo - q0;
+            inwin = inwin < 0 ? 0 : inwin;
+            const int nv = rowok ? (npix < inwin ? npix : inwin) : 0;
+            const int nwin = (nv + 1) >> 1;  // windows the run's live pixels touch
+            const size_t o = (((size_t)b * p.Co + cc) * p.PHo + (rowok ? (pr >> 1) : 0)) * p.PWo + (q0 >> 1);
+            const int e0 = (cc * p.Ho + pr) * p.Wo + q0;
+#pragma unroll
+            for (int j = 0; j < RL / 8; ++j) {
+                const f4u g = load4(p.dy + o + 4 * j, nwin - 4 * j), mk = load4((const float*)p.pmask + o + 4 * j, nwin - 4 * j),
+                          pl = load4(p.pooled + o + 4 * j, nwin - 4 * j);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int t = 8 * j + i, w = i >> 1;
+                    const float gv = w == 0 ? g.x : w == 1 ? g.y : w == 2 ? g.z : g.w, pv = w == 0 ? pl.x : w == 1 ? pl.y : w == 2 ? pl.z : pl.w;
+                    const int mv = __builtin_bit_cast(int, w == 0 ? mk.x : w == 1 ? mk.y : w == 2 ? mk.z : mk.w);
+                    a[t] = (t < nv && mv == e0 + t && !(pv <= 0.f)) ? gv : 0.f;
+                }
+            }
+        } else {
             const bool rowok = co < p.Co;
             const float* src = p.dy + (((size_t)b * p.Co + (rowok ? co : 0)) * p.Ho + pr) * p.Wo + q0;
             const int nv = rowok ? npix : 0;
@@ -301,7 +357,7 @@ struct RdPlan {
     int nt, ngroups, mtiles, kblocks, rl;
 };
 
-bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl) {
+bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
     if (d->k != 3 || d->pad != 0 || (d->s != 1 && d->s != 2)) return false;
     RdParams& p = pl->p;
     p.B = d->B; p.Ci = d->Ci; p.H = d->H; p.W = d->W; p.Co = d->Co;
@@ -310,6 +366,9 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl) {
     if (p.Ho <= 0 || p.Wo <= 0) return false;
     p.Ntot = d->Ci * 9;
     p.pitch = p.Ntot + 1;
+    p.PHo = p.Ho / 2; p.PWo = p.Wo / 2;
+    p.pmask = nullptr; p.pooled = nullptr;
+    if (pooled && (p.PHo < 1 || p.PWo < 1 || d->Ci * 9 > 32)) return false;  // (POOLED kernels exist for one column tile)
     pl->rl = p.Wo <= 8 ? 8 : 16;
     p.rpr = (p.Wo + pl->rl - 1) / pl->rl;
     const long long runs = (long long)p.B * p.Ho * p.rpr;
@@ -340,7 +399,8 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl) {
     p.m_rows = magic_of(p.Ho);
     p.m_rpr = magic_of(p.rpr);
     // runs whose (over-reading) windows stay inside the tensors: addresses grow with the run index, so scan from the end
-    const long long x_total = (long long)p.B * p.Ci * p.H * p.W, dy_total = (long long)p.B * p.Co * p.Ho * p.Wo;
+    const long long x_total = (long long)p.B * p.Ci * p.H * p.W;
+    const long long dy_total = pooled ? (long long)p.B * p.Co * p.PHo * p.PWo : (long long)p.B * p.Co * p.Ho * p.Wo;
     long long r_unsafe = 0;
     if (x_total < (1ll << 31) && dy_total < (1ll << 31)) {
         const long long xoff_bound = ((long long)(p.Ci - 1) * p.H + 2) * p.W + 2;
@@ -348,8 +408,9 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl) {
         while (r_unsafe > 0) {
             const long long r = r_unsafe - 1, rowi = r / p.rpr, seg = r % p.rpr, b = rowi / p.Ho, pr = rowi % p.Ho;
             const long long xb = b * p.Ci * p.H * p.W + d->s * pr * p.W + d->s * seg * pl->rl;
-            const long long ab = ((b * p.Co + p.Co - 1) * p.Ho + pr) * p.Wo + seg * pl->rl;
-            if (xb + xoff_bound + d->s * pl->rl <= x_total && ab + pl->rl <= dy_total) break;
+            const long long ab = pooled ? ((b * p.Co + p.Co - 1) * p.PHo + (pr >> 1)) * p.PWo + (seg * pl->rl >> 1)
+                                        : ((b * p.Co + p.Co - 1) * p.Ho + pr) * p.Wo + seg * pl->rl;
+            if (xb + xoff_bound + d->s * pl->rl <= x_total && ab + (pooled ? pl->rl / 2 : pl->rl) <= dy_total) break;
             --r_unsafe;
         }
     }
@@ -377,7 +438,7 @@ int wgrad_rd_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, f
     const dim3 grid(pl.kblocks, pl.ngroups, pl.mtiles);
     char name[64];
     snprintf(name, sizeof(name), "wgrad_rd<%d,%d,%d>", d->s, pl.nt, pl.rl);
-#define RD(S_, NT_, RL_) CNN_KLAUNCH(s, name, (wgrad_rd_kernel<S_, NT_, RL_><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d))
+#define RD(S_, NT_, RL_) CNN_KLAUNCH(s, name, (wgrad_rd_kernel<S_, NT_, RL_, false><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d))
 #define RD_NT(S_, RL_)                                                     \
     switch (pl.nt) {                                                       \
         case 1: RD(S_, 1, RL_); break;                                     \
@@ -393,6 +454,26 @@ int wgrad_rd_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, f
     else { RD_NT(1, 8) }
 #undef RD_NT
 #undef RD
+    return CNN_AMD_OK;
+}
+
+// the same from the pooled domain (first block: Ci*9 <= 32 columns); 0 slots = not covered
+int wgrad_rd_pooled_slots(const cnn_conv2d_desc* d) {
+    RdPlan pl;
+    if (d->s != 2 || !make_rd_plan(d, &pl, true) || pl.nt != 1 || pl.ngroups != 1) return 0;
+    return pl.kblocks;
+}
+
+int wgrad_rd_launch_pooled(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask, const float* pooled,
+                           float* slabs, hipStream_t s) {
+    RdPlan pl;
+    if (wgrad_rd_pooled_slots(d) == 0 || !make_rd_plan(d, &pl, true)) return fail(CNN_AMD_E_BADARG, "wgrad_rd+pool: geometry not covered");
+    pl.p.x = x; pl.p.dy = dpool; pl.p.pmask = mask; pl.p.pooled = pooled; pl.p.slabs = slabs;
+    const dim3 grid(pl.kblocks, pl.ngroups, pl.mtiles);
+    char name[64];
+    snprintf(name, sizeof(name), "wgrad_rd<%d,%d,%d>+pool", d->s, pl.nt, pl.rl);
+    if (pl.rl == 16) CNN_KLAUNCH(s, name, (wgrad_rd_kernel<2, 1, 16, true><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d));
+    else CNN_KLAUNCH(s, name, (wgrad_rd_kernel<2, 1, 8, true><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d));
     return CNN_AMD_OK;
 }
 

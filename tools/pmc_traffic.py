@@ -26,6 +26,16 @@ def canonical(name):
     m = re.match(r"(igemm_kernel|wgrad_kernel)<(\d+,\d+,\d+,\d+,\d+,\d+),(true|false),(true|false)>$", name)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
+    if name.startswith("conv_fwd_pool_pk_3_16_3_2"):
+        return "conv_fwd_pool_pk<3,16,3,2>"
+    if name.startswith("conv_dgrad_pool_pk_3_16_3_2"):
+        return "conv_dgrad_pk<3,16,3,2>+pool"
+    m = re.match(r"conv_wgrad_pk_3_16_3_2<\d+,(true|false)>$", name)
+    if m:
+        return "conv_wgrad_pk<3,16,3,2>" + ("+pool" if m.group(1) == "true" else "")
+    m = re.match(r"conv_fwd_rd_kernel<(\d+),(\d+),(\d+),\d+,\d+>$", name)
+    if m:
+        return f"conv_fwd_rd<{m.group(1)},{m.group(2)},{m.group(3)}>"
     m = re.match(r"wgrad_rd_kernel(<\d+,\d+,\d+>)$", name)
     if m:
         return f"wgrad_rd{m.group(1)}"
