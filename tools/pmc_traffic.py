@@ -36,9 +36,9 @@ def canonical(name):
     m = re.match(r"conv_fwd_rd_kernel<(\d+),(\d+),(\d+),\d+,\d+>$", name)
     if m:
         return f"conv_fwd_rd<{m.group(1)},{m.group(2)},{m.group(3)}>"
-    m = re.match(r"wgrad_rd_kernel(<\d+,\d+,\d+>)$", name)
+    m = re.match(r"wgrad_rd_kernel<(\d+,\d+,\d+),(true|false)>$", name)
     if m:
-        return f"wgrad_rd{m.group(1)}"
+        return f"wgrad_rd<{m.group(1)}>" + ("+pool" if m.group(2) == "true" else "")
     m = re.match(r"(conv_(?:dgrad|fwd|wgrad)_pk2?)_3_16_3_2(<.*>)?$", name)
     if m:
         return f"{m.group(1)}<3,16,3,2>"
