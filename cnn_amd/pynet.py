@@ -65,6 +65,7 @@ class AlexNetHip:
 
         self.use_prep = fuse and not os.environ.get("CNN_AMD_NO_PREPARED")  # (A/B switch for measurements)
         self._no_fbr = bool(os.environ.get("CNN_AMD_NO_BWD_RELU_FUSION"))  # (likewise)
+        self._dx0_release = int(os.environ.get("CNN_AMD_DX0_RELEASE", "2"))  # conv layer after whose forward the deferred dgrad starts
         # conv_layer_1 -> relu_layer_1 -> max_pool_1 as one kernel: conv_out[0] / relu_out[0] are then NOT written (nothing in
         # the step reads them: the backward pass of that block works from pool_out + pool_mask)
         self.fuse_pool = bool(fuse_pool) and self.use_prep and self.convs[0].relu_maxpool2_supported()
@@ -187,7 +188,7 @@ class AlexNetHip:
                                                              capi._ptr(self.pool_mask) if record else None, self.B, 16, hh,
                                                              ww, 2, 2, capi._stream()), "cnn_maxpool2d_forward")
                 cur = self.pool_out
-            if l == 1:
+            if l == self._dx0_release:
                 # release point of the deferred conv1 data gradient, measured (images/s at batch 256, same box): no
                 # deferral 261.0k | before conv1 ~249k | after max_pool_1 ~257k | after conv_layer_2 269.3k | after
                 # conv_layer_3 264.5k -- it then overlaps the latency-bound layers 3-4, the linear layer and the loss
