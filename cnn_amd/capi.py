@@ -192,20 +192,22 @@ class Conv2d:
 
     def backward_weight_pooled2(self, x, dpool, mask, pooled, divisor, gw, gb):
         """weight / bias gradient with dy = relu_backward(maxpool_backward(dpool)) rebuilt on the fly"""
-        _need_gpu(x, dpool, mask, pooled, gw, gb)
-        check(self.lib.cnn_conv2d_backward_weight_pooled2(C.byref(self.desc), _ptr(x), _ptr(dpool), _ptr(mask), _ptr(pooled), _ptr(gw),
+        _need_gpu(x, dpool, mask, gw, gb)  # pooled=None: dpool already carries the ReLU mask
+        check(self.lib.cnn_conv2d_backward_weight_pooled2(C.byref(self.desc), _ptr(x), _ptr(dpool), _ptr(mask),
+                                                          _ptr(pooled) if pooled is not None else None, _ptr(gw),
                                                           _ptr(gb), float(divisor), _ptr(self.ws), self.ws_bytes, _stream()),
               "cnn_conv2d_backward_weight_pooled2")
         return gw, gb
 
     def backward_data_pooled2(self, dpool, mask, pooled, w, dx, prepared_dgrad=None):
-        _need_gpu(dpool, mask, pooled, dx)
+        _need_gpu(dpool, mask, dx)
+        pooled_p = _ptr(pooled) if pooled is not None else None
         if prepared_dgrad is not None:
-            check(self.lib.cnn_conv2d_backward_data_pooled2_prepared(C.byref(self.desc), _ptr(dpool), _ptr(mask), _ptr(pooled),
+            check(self.lib.cnn_conv2d_backward_data_pooled2_prepared(C.byref(self.desc), _ptr(dpool), _ptr(mask), pooled_p,
                                                                      _ptr(prepared_dgrad), _ptr(dx), _stream()),
                   "cnn_conv2d_backward_data_pooled2_prepared")
         else:
-            check(self.lib.cnn_conv2d_backward_data_pooled2(C.byref(self.desc), _ptr(dpool), _ptr(mask), _ptr(pooled), _ptr(w), _ptr(dx),
+            check(self.lib.cnn_conv2d_backward_data_pooled2(C.byref(self.desc), _ptr(dpool), _ptr(mask), pooled_p, _ptr(w), _ptr(dx),
                                                             _ptr(self.ws), self.ws_bytes, _stream()), "cnn_conv2d_backward_data_pooled2")
         return dx
 

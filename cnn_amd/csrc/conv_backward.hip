@@ -100,7 +100,7 @@ int cnn_conv2d_backward_prepared_relu(const cnn_conv2d_desc* d, const float* x, 
 int cnn_conv2d_backward_pooled2_prepared(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask,
                                          const float* pooled, const void* prepared_dgrad, float* gw, float* gb, float* dx,
                                          float divisor, void* ws, size_t ws_bytes, void* stream, int defer_join) {
-    CNN_REQUIRE(d && x && dpool && mask && pooled && prepared_dgrad && gw && dx && ws, "cnn_conv2d_backward_pooled2_prepared: null pointer");
+    CNN_REQUIRE(d && x && dpool && mask && prepared_dgrad && gw && dx && ws, "cnn_conv2d_backward_pooled2_prepared: null pointer");
     SideStream* side = nullptr;
     if (int rc = get_side(&side)) return rc;
     hipStream_t main = as_stream(stream);

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_3_16_3_2(const float* __
 // needs (rows 2bh-1 .. 2bh+1, columns 2bw-1 .. 2bw+1) lies in the four windows (bh-1 | bh) x (bw-1 | bw): three loads per
 // window and channel (12 for four 2x2 blocks instead of the 16 dy loads of the unfused kernel), the same packed FMAs in
 // the same order (bit-identical dx), one weight s_load per FOUR blocks, 16-byte stores.
-template <int CB>
+template <int CB, bool RM>  // RM: apply the ReLU mask from `pooled` (false: dpool is pre-masked, `pooled` is not read)
 __global__ __launch_bounds__(kBlock) void conv_dgrad_pool_pk_3_16_3_2(const float* __restrict__ dpool, const int32_t* __restrict__ pmask,
                                                                       const float* __restrict__ pooled, const v2f* __restrict__ wp,
                                                                       float* __restrict__ dx, int B, int H, int W, int Ho, int Wo,
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pool_pk_3_16_3_2(const floa
     const int pbytes = (int)((unsigned)B * CO * pplane * 4u);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dpool, 0, pbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)pmask, 0, pbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)pooled, 0, pbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(RM ? pooled : dpool), 0, pbytes, 0x00020000);
     for (int it = blockIdx.x * kWaves + wave; it < (int)items; it += gridDim.x * kWaves) {
         const int b = fast_div(it, m_ipi, items_per_img);
         const int n = (it - b * items_per_img) * 64 + lane;
@@ -338,7 +338,8 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pool_pk_3_16_3_2(const floa
                 for (int w = 0; w < 4; ++w) {
                     g[u][w] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, (int)vw[w], so, 0));
                     mk[u][w] = __builtin_amdgcn_raw_buffer_load_b32(rm, (int)vw[w], so, 0);
-                    pl[u][w] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (int)vw[w], so, 0));
+                    if constexpr (RM) pl[u][w] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (int)vw[w], so, 0));
+                    else pl[u][w] = 1.f;
                 }
             }
 #pragma unroll
@@ -439,8 +440,9 @@ __global__ void pack_dgrad_weights_s2(const float* __restrict__ w, float* __rest
 
 template <int CI, int CB, int PX>  // PX grid pixels per lane (1 in production; 2 shares the weight reads but gains nothing)
 __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_s2(const float* __restrict__ dy, const v2f* __restrict__ wp,
-                                                           float* __restrict__ dx, int B, int CO, int H, int W, int Ho,
-                                                           int Wo, int items_per_img, unsigned m_ipi, unsigned m_row) {
+                                                           float* __restrict__ dx, const float* __restrict__ relu_below, int B,
+                                                           int CO, int H, int W, int Ho, int Wo, int items_per_img,
+                                                           unsigned m_ipi, unsigned m_row) {
     constexpr int HP = CI / 2;
     const int U = (H + 1) / 2, V = (W + 1) / 2;
     const int UV = U * V;
@@ -541,10 +543,16 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_s2(const float* __restri
                     for (int ph = 0; ph < 2; ++ph) {
                         const int ci = 2 * j + half, h = 2 * hh[x] + ph;
                         if (h >= H) continue;
-                        const float v0 = half ? A[x][ph * 2 + 0][j].y : A[x][ph * 2 + 0][j].x;
-                        const float v1 = half ? A[x][ph * 2 + 1][j].y : A[x][ph * 2 + 1][j].x;
+                        float v0 = half ? A[x][ph * 2 + 0][j].y : A[x][ph * 2 + 0][j].x;
+                        float v1 = half ? A[x][ph * 2 + 1][j].y : A[x][ph * 2 + 1][j].x;
                         float* row = dxb + ((size_t)ci * H + h) * W + (size_t)ww[x] * 2;
-                        if (pair || ww[x] * 2 + 1 < W) {
+                        const bool two = pair || ww[x] * 2 + 1 < W;
+                        if (relu_below) {  // fused ReLU::backward of the layer in front (relu.cpp:38): mask by its output
+                            const float* mrow = relu_below + (row - dx);
+                            v0 = (mrow[0] <= 0.f) ? 0.f : v0;
+                            if (two) v1 = (mrow[1] <= 0.f) ? 0.f : v1;
+                        }
+                        if (two) {
                             *(f2u*)row = f2u{v0, v1};
                         } else {
                             row[0] = v0;
@@ -764,7 +772,7 @@ constexpr int kWgX = 7;       // patch rows each wave stages per item (4 x 7 = 2
 //     dy[co][n] = (mask[window] == co*Ho*Wo + n  &&  !(pooled[window] <= 0)) ? dpool[window] : 0,   window = (p/2, q/2)
 // = MaxPool2D::backward (pool2d.cpp:96-107) followed by ReLU::backward (relu.cpp:35-40): three 4-byte loads per lane and
 // channel instead of one, but the 202 MB delta tensor is neither written nor read.  `dy` then holds dpool.
-template <int kWgDepth, bool POOLED>  // items in flight per workgroup
+template <int kWgDepth, int POOLED>  // items in flight per workgroup; POOLED: 0 dy | 1 pooled domain | 2 ... with dpool pre-masked
 __global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __restrict__ x, const float* __restrict__ dy,
                                                                  const int32_t* __restrict__ pmask, const float* __restrict__ pooled,
                                                                  float* __restrict__ slabs, int B, int H, int W, int Ho,
@@ -781,7 +789,8 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __
     const int dy_bytes = (int)((unsigned)B * CO * (POOLED ? pplane : plane) * 4u);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)(POOLED ? (const void*)pmask : (const void*)dy), 0, dy_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(POOLED ? pooled : dy), 0, dy_bytes, 0x00020000);
+    constexpr bool relu_mask = POOLED == 1;  // (2: dpool already carries the ReLU mask, `pooled` is not read)
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(relu_mask ? pooled : dy), 0, dy_bytes, 0x00020000);
     // wave w stages taps 7w .. 7w+6 of x (tap 27 does not exist: it reads out of range = the zero pad) and loads the dy
     // rows of ITS output channels 4w .. 4w+3, which never go through LDS.  Everything below is branch-free on purpose
     // (an item past the end reads out of range = 0 and adds nothing): with straight-line code hipcc counts the outstanding
@@ -821,7 +830,8 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __
             for (int c = 0; c < 4; ++c) {
                 ad[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, (int)vd, sd + c * pplane * 4, 0));
                 ad[4 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, (int)vd, sd + c * pplane * 4, 0));
-                ad[8 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (int)vd, sd + c * pplane * 4, 0));
+                if constexpr (relu_mask) ad[8 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (int)vd, sd + c * pplane * 4, 0));
+                else ad[8 + c] = 1.f;
             }
             ad[12] = __builtin_bit_cast(float, 4 * wave * plane + n);
         } else {
@@ -1030,10 +1040,16 @@ int direct_conv_dgrad_pooled(const cnn_conv2d_desc* d, const float* dpool, const
     const int U = (d->H + 1) / 2, V = (d->W + 1) / 2, U2 = (U + 1) / 2, V2 = (V + 1) / 2;
     const int ipi = (U2 * V2 + 63) / 64;
     const long long witems = (long long)d->B * ipi;
-    CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>+pool",
-                (conv_dgrad_pool_pk_3_16_3_2<2><<<wave_grid(witems), kBlock, 0, s>>>(dpool, mask, pooled, (const v2f*)ws, dx, d->B, d->H, d->W,
-                                                                                    Ho, Wo, ipi, div_magic(ipi), div_magic(V2))),
-                CONV_TAG(d));
+    if (pooled)
+        CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>+pool",
+                    (conv_dgrad_pool_pk_3_16_3_2<2, true><<<wave_grid(witems), kBlock, 0, s>>>(dpool, mask, pooled, (const v2f*)ws, dx, d->B, d->H,
+                                                                                              d->W, Ho, Wo, ipi, div_magic(ipi), div_magic(V2))),
+                    CONV_TAG(d));
+    else
+        CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>+pool",
+                    (conv_dgrad_pool_pk_3_16_3_2<2, false><<<wave_grid(witems), kBlock, 0, s>>>(dpool, mask, nullptr, (const v2f*)ws, dx, d->B, d->H,
+                                                                                               d->W, Ho, Wo, ipi, div_magic(ipi), div_magic(V2))),
+                    CONV_TAG(d));
     return CNN_AMD_OK;
 }
 
@@ -1047,7 +1063,8 @@ bool pk_dgrad_s2_supported(const cnn_conv2d_desc* d) {
 }
 size_t pk_dgrad_s2_workspace_floats(const cnn_conv2d_desc* d) { return (size_t)d->Co * 9 * d->Ci; }
 
-int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, hipStream_t s, bool prepared) {
+int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, hipStream_t s, bool prepared,
+                const float* relu_below) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
     const int total = d->Co * 9 * d->Ci;
     if (!prepared)
@@ -1059,8 +1076,8 @@ int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float
     const size_t wl = (size_t)total * sizeof(float);
     // (two pixels per lane, other batch sizes: no gain -- the loop is bound by the LDS-read / FMA interleave)
     if (d->Ci == 16) {
-        CNN_KLAUNCH(s, "conv_dgrad_pk_s2<16>",
-                    (conv_dgrad_pk_s2<16, 4, 1><<<wave_grid(witems), kBlock, wl, s>>>(dy, (const v2f*)ws, dx, d->B, d->Co, d->H, d->W, Ho,
+        CNN_KLAUNCH(s, relu_below ? "conv_dgrad_pk_s2<16>+relu" : "conv_dgrad_pk_s2<16>",
+                    (conv_dgrad_pk_s2<16, 4, 1><<<wave_grid(witems), kBlock, wl, s>>>(dy, (const v2f*)ws, dx, relu_below, d->B, d->Co, d->H, d->W, Ho,
                                                                                      Wo, ipi, div_magic(ipi), div_magic(V))),
                     CONV_TAG(d));
     } else {  // opt-in (CNN_AMD_PK_DGRAD=1): 32 input channels, slower than the implicit GEMM (71 vs 56 us)
@@ -1070,8 +1087,8 @@ int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float
                                               160 * 1024));
             attr_set = true;
         }
-        CNN_KLAUNCH(s, "conv_dgrad_pk_s2<32>",
-                    (conv_dgrad_pk_s2<32, 4, 1><<<wave_grid(witems), kBlock, wl, s>>>(dy, (const v2f*)ws, dx, d->B, d->Co, d->H, d->W, Ho,
+        CNN_KLAUNCH(s, relu_below ? "conv_dgrad_pk_s2<32>+relu" : "conv_dgrad_pk_s2<32>",
+                    (conv_dgrad_pk_s2<32, 4, 1><<<wave_grid(witems), kBlock, wl, s>>>(dy, (const v2f*)ws, dx, relu_below, d->B, d->Co, d->H, d->W, Ho,
                                                                                      Wo, ipi, div_magic(ipi), div_magic(V))),
                     CONV_TAG(d));
     }
@@ -1124,7 +1141,7 @@ int direct_conv_wgrad(const cnn_conv2d_desc* d, const float* x, const float* dy,
     const int ipi = (Ho * Wo + 63) / 64;
     // three items of loads in flight per workgroup (2: 117 us, 3: 115 us, 4+: the extra registers cost more than they hide)
     CNN_KLAUNCH(s, "conv_wgrad_pk<3,16,3,2>",
-                (conv_wgrad_pk_3_16_3_2<3, false><<<direct_wgrad_slots(d), kBlock, 0, s>>>(x, dy, nullptr, nullptr, slabs, d->B, d->H, d->W,
+                (conv_wgrad_pk_3_16_3_2<3, 0><<<direct_wgrad_slots(d), kBlock, 0, s>>>(x, dy, nullptr, nullptr, slabs, d->B, d->H, d->W,
                                                                                           Ho, Wo, ipi, div_magic(ipi), div_magic(Wo))),
                 CONV_TAG(d));
     return CNN_AMD_OK;
@@ -1135,10 +1152,16 @@ int direct_conv_wgrad_pooled(const cnn_conv2d_desc* d, const float* x, const flo
                              float* slabs, hipStream_t s) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
     const int ipi = (Ho * Wo + 63) / 64;
-    CNN_KLAUNCH(s, "conv_wgrad_pk<3,16,3,2>+pool",
-                (conv_wgrad_pk_3_16_3_2<3, true><<<direct_wgrad_slots(d), kBlock, 0, s>>>(x, dpool, mask, pooled, slabs, d->B, d->H, d->W,
-                                                                                         Ho, Wo, ipi, div_magic(ipi), div_magic(Wo))),
-                CONV_TAG(d));
+    if (pooled)
+        CNN_KLAUNCH(s, "conv_wgrad_pk<3,16,3,2>+pool",
+                    (conv_wgrad_pk_3_16_3_2<3, 1><<<direct_wgrad_slots(d), kBlock, 0, s>>>(x, dpool, mask, pooled, slabs, d->B, d->H, d->W,
+                                                                                          Ho, Wo, ipi, div_magic(ipi), div_magic(Wo))),
+                    CONV_TAG(d));
+    else
+        CNN_KLAUNCH(s, "conv_wgrad_pk<3,16,3,2>+pool",
+                    (conv_wgrad_pk_3_16_3_2<3, 2><<<direct_wgrad_slots(d), kBlock, 0, s>>>(x, dpool, mask, nullptr, slabs, d->B, d->H, d->W,
+                                                                                          Ho, Wo, ipi, div_magic(ipi), div_magic(Wo))),
+                    CONV_TAG(d));
     return CNN_AMD_OK;
 }
 

@@ -1265,7 +1265,8 @@ int fwd_rd_forward(const cnn_conv2d_desc* d, const float* x, const float* w, con
                    float* y_relu, hipStream_t s);
 bool pk_dgrad_s2_supported(const cnn_conv2d_desc* d);  // conv_direct.hip: packed VALU dgrad for small stride-2 layers
 size_t pk_dgrad_s2_workspace_floats(const cnn_conv2d_desc* d);
-int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, hipStream_t s, bool prepared);
+int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, hipStream_t s, bool prepared,
+                const float* relu_below);
 // scratch floats the forward / dgrad plans need (used by cnn_conv2d_workspace_bytes in conv_wgrad.hip)
 size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
     Plan a, b;
@@ -1298,14 +1299,13 @@ static int conv2d_backward_data_impl(const char* who, const cnn_conv2d_desc* d, 
                                      void* ws, size_t ws_bytes, void* stream, bool prepared, const float* relu_below = nullptr) {
     if (int rc = check_desc(who, d)) return rc;
     CNN_REQUIRE(dy && (w || prepared) && dx, "%s: null pointer", who);
-    const bool packed = direct_conv_supported(d) ||
-                        (pk_dgrad_s2_supported(d) && ws != nullptr && ws_bytes >= pk_dgrad_s2_workspace_floats(d) * sizeof(float));
-    if (packed) {  // the packed VALU kernels have no masked epilogue: same result from the separate ReLU kernel
-        const int rc = direct_conv_supported(d) ? direct_conv_dgrad(d, dy, w, dx, ws, ws_bytes, as_stream(stream), prepared)
-                                                : pk_dgrad_s2(d, dy, w, dx, ws, as_stream(stream), prepared);
+    if (direct_conv_supported(d)) {  // the first-layer kernels have no masked epilogue: same result from the ReLU kernel
+        const int rc = direct_conv_dgrad(d, dy, w, dx, ws, ws_bytes, as_stream(stream), prepared);
         if (rc || !relu_below) return rc;
         return cnn_relu_backward(relu_below, dx, (size_t)d->B * d->Ci * d->H * d->W, stream);
     }
+    if (pk_dgrad_s2_supported(d) && ws != nullptr && ws_bytes >= pk_dgrad_s2_workspace_floats(d) * sizeof(float))
+        return pk_dgrad_s2(d, dy, w, dx, ws, as_stream(stream), prepared, relu_below);
     Plan pl;
     if (int rc = make_plan(who, d, MODE_DGRAD, &pl)) return rc;
     return run_plan(pl, d, dy, w, nullptr, dx, const_cast<float*>(relu_below), ws, ws_bytes, as_stream(stream), who, prepared);
@@ -1351,14 +1351,14 @@ int cnn_conv2d_relu_maxpool2_forward_prepared(const cnn_conv2d_desc* d, const fl
 int cnn_conv2d_backward_data_pooled2(const cnn_conv2d_desc* d, const float* dpool, const int32_t* mask, const float* pooled,
                                      const float* w, float* dx, void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_desc("cnn_conv2d_backward_data_pooled2", d)) return rc;
-    CNN_REQUIRE(dpool && mask && pooled && w && dx, "cnn_conv2d_backward_data_pooled2: null pointer");
+    CNN_REQUIRE(dpool && mask && w && dx, "cnn_conv2d_backward_data_pooled2: null pointer");
     return direct_conv_dgrad_pooled(d, dpool, mask, pooled, w, dx, ws, ws_bytes, as_stream(stream), false);
 }
 
 int cnn_conv2d_backward_data_pooled2_prepared(const cnn_conv2d_desc* d, const float* dpool, const int32_t* mask, const float* pooled,
                                               const void* prepared_dgrad, float* dx, void* stream) {
     if (int rc = check_desc("cnn_conv2d_backward_data_pooled2_prepared", d)) return rc;
-    CNN_REQUIRE(dpool && mask && pooled && prepared_dgrad && dx, "cnn_conv2d_backward_data_pooled2_prepared: null pointer");
+    CNN_REQUIRE(dpool && mask && prepared_dgrad && dx, "cnn_conv2d_backward_data_pooled2_prepared: null pointer");
     return direct_conv_dgrad_pooled(d, dpool, mask, pooled, nullptr, dx, (void*)prepared_dgrad, cnn_conv2d_prepared_bytes(d),
                                     as_stream(stream), true);
 }

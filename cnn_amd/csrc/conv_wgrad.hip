@@ -593,7 +593,7 @@ int cnn_conv2d_backward_weight_pooled2(const cnn_conv2d_desc* d, const float* x,
                                        const float* pooled, float* gw, float* gb, float divisor, void* ws, size_t ws_bytes,
                                        void* stream) {
     if (int rc = check_desc("cnn_conv2d_backward_weight_pooled2", d)) return rc;
-    CNN_REQUIRE(x && dpool && mask && pooled && gw, "cnn_conv2d_backward_weight_pooled2: null pointer");
+    CNN_REQUIRE(x && dpool && mask && gw, "cnn_conv2d_backward_weight_pooled2: null pointer");
     CNN_REQUIRE(divisor != 0.f, "cnn_conv2d_backward_weight_pooled2: divisor is 0");
     const int ds = direct_wgrad_slots(d);
     CNN_REQUIRE(ds > 0 && direct_conv_pool_supported(d), "cnn_conv2d_backward_weight_pooled2: geometry not covered");

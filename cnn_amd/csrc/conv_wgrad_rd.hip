@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
                 for (int j = 0; j < RL / 8; ++j) {
                     buf[j] = *(const f4u*)(p.dy + aoff + 4 * j);
                     buf[RL / 8 + j] = *(const f4u*)((const float*)p.pmask + aoff + 4 * j);
-                    buf[2 * (RL / 8) + j] = *(const f4u*)(p.pooled + aoff + 4 * j);
+                    buf[2 * (RL / 8) + j] = p.pooled ? *(const f4u*)(p.pooled + aoff + 4 * j) : f4u{1.f, 1.f, 1.f, 1.f};
                 }
             } else {
 #pragma unroll
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
 #pragma unroll
             for (int j = 0; j < RL / 8; ++j) {
                 const f4u g = load4(p.dy + o + 4 * j, nwin - 4 * j), mk = load4((const float*)p.pmask + o + 4 * j, nwin - 4 * j),
-                          pl = load4(p.pooled + o + 4 * j, nwin - 4 * j);
+                          pl = p.pooled ? load4(p.pooled + o + 4 * j, nwin - 4 * j) : f4u{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int t = 8 * j + i, w = i >> 1;

@@ -218,11 +218,13 @@ class AlexNetHip:
                 self.flush()  # the previous step's deferred dgrad reads d_conv[1] (= d pool_out), which is rewritten next
             if l == 0 and self.fuse_pool:
                 # conv_layer_1 from the pooled domain: cur = d pool_out
-                self.convs[0].backward_weight_pooled2(self.x, cur, self.pool_mask, self.pool_out, div, self.conv_w(0, g), self.conv_b(0, g))
+                # (with fbr the ReLU mask was already applied by conv_layer_2's data gradient: pooled = None)
+                pooled = None if fbr else self.pool_out
+                self.convs[0].backward_weight_pooled2(self.x, cur, self.pool_mask, pooled, div, self.conv_w(0, g), self.conv_b(0, g))
                 if self.defer_dx0:
-                    self.pending_dx0 = (self.prep0_dgrad[self.parity], cur, self.pool_mask, self.pool_out)
+                    self.pending_dx0 = (self.prep0_dgrad[self.parity], cur, self.pool_mask, pooled)
                 else:
-                    self.convs[0].backward_data_pooled2(cur, self.pool_mask, self.pool_out, None, self.d_conv[0],
+                    self.convs[0].backward_data_pooled2(cur, self.pool_mask, pooled, None, self.d_conv[0],
                                                         prepared_dgrad=self.prep[0][1])
                 break
             if l == 0:
@@ -243,9 +245,12 @@ class AlexNetHip:
                 self.convs[0].backward_weight(lin, cur, div, self.conv_w(0, g), self.conv_b(0, g))
                 self.pending_dx0 = self.prep0_dgrad[self.parity]
             elif self.use_prep:
-                # lin is relu_out[l-1] for l >= 2: its ReLU::backward is fused into this data gradient
+                # lin is relu_out[l-1] for l >= 2: its ReLU::backward is fused into this data gradient; for l == 1 in a pool-fused
+                # net lin = pool_out, and masking d(pool_out) by (pool_out <= 0) IS relu_layer_1's backward pass in the pooled
+                # domain (at an argmax position the ReLU output equals the pooled value)
                 self.convs[l].backward_prepared(lin, cur, self.prep[l][1], div, self.conv_w(l, g), self.conv_b(l, g),
-                                                self.d_conv[l], defer_join=True, relu_below=lin if (fbr and l >= 2) else None)
+                                                self.d_conv[l], defer_join=True,
+                                                relu_below=lin if (fbr and (l >= 2 or (l == 1 and self.fuse_pool))) else None)
             else:
                 self.convs[l].backward(lin, cur, self.conv_w(l), div, self.conv_w(l, g), self.conv_b(l, g), self.d_conv[l],
                                        defer_join=True)

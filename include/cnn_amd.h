@@ -84,7 +84,8 @@ int cnn_conv2d_relu_maxpool2_forward(const cnn_conv2d_desc* d, const float* x, c
  *   dy = ReLU::backward(MaxPool2D::backward(dpool))   (relu.cpp:35-40, pool2d.cpp:96-107)
  * is rebuilt on the fly from dpool (delta of the pool output), mask and pooled (both as written by the forward call), so
  * the Co*Ho*Wo delta tensor is never written or read.  Results are bit-identical to cnn_maxpool2d_backward_relu followed by
- * cnn_conv2d_backward_weight / cnn_conv2d_backward_data. */
+ * cnn_conv2d_backward_weight / cnn_conv2d_backward_data.  pooled == NULL: dpool already carries the ReLU mask
+ * ((pooled <= 0) ? 0 : dpool, e.g. from cnn_conv2d_backward_data_relu(..., relu_below = pooled, ...) of the next layer). */
 int cnn_conv2d_backward_weight_pooled2(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask,
                                        const float* pooled, float* gw, float* gb, float divisor, void* workspace,
                                        size_t workspace_bytes, void* stream);

@@ -610,6 +610,12 @@ def test_conv_backward_from_pooled_domain_is_bit_identical(T, shape):
     dx2 = T.full_like(dx_ref, 7.0)
     conv.backward_data_pooled2(dpool, mask, pooled, None, dx2, prepared_dgrad=pd)
     assert np.array_equal(host(dx2), host(dx_ref))
+    # pooled = None: the caller has applied the ReLU mask to dpool already
+    dmasked = T.where(pooled <= 0, T.zeros_like(dpool), dpool)
+    gw3, gb3, dx3 = T.full_like(gw_ref, 7.0), T.full_like(gb_ref, 7.0), T.full_like(dx_ref, 7.0)
+    conv.backward_weight_pooled2(xd, dmasked, mask, None, float(B), gw3, gb3)
+    conv.backward_data_pooled2(dmasked, mask, None, wd, dx3)
+    assert np.array_equal(host(gw3), host(gw_ref)) and np.array_equal(host(gb3), host(gb_ref)) and np.array_equal(host(dx3), host(dx_ref))
 
 
 @pytest.mark.parametrize("defer", [False, True], ids=["in_order", "deferred_dx0"])
@@ -636,7 +642,9 @@ def test_pool_fused_net_is_bit_identical(T, defer):
         T.cuda.synchronize()
         assert T.equal(a.params, b.params) and T.equal(a.grads, b.grads), step
         assert T.equal(a.pool_out, b.pool_out) and T.equal(a.pool_mask, b.pool_mask)
-        assert T.equal(a.d_conv[0], b.d_conv[0]) and T.equal(a.d_conv[1], b.d_conv[1]) and T.equal(a.logits, b.logits)
+        assert T.equal(a.d_conv[0], b.d_conv[0]) and T.equal(a.logits, b.logits)
+        # d(pool output): the fused net applies relu_layer_1's backward mask where that delta is produced
+        assert T.equal(a.d_conv[1], T.where(b.pool_out <= 0, T.zeros_like(b.d_conv[1]), b.d_conv[1]))
 
 
 @pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 5, 6, 7, 9, 10, 11, 13)], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
