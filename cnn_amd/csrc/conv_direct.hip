@@ -535,29 +535,40 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_s2(const float* __restri
         for (int x = 0; x < PX; ++x) {
             if (!live[x]) continue;
             float* dxb = dx + (size_t)b * CI * H * W;
+            const bool two = pair || ww[x] * 2 + 1 < W;
+            // fused ReLU::backward of the layer in front (relu.cpp:38): the mask values of one channel pair (4 row
+            // segments) are fetched together, then applied and stored -- a load per store would serialise 2*CI round trips
 #pragma unroll
-            for (int j = 0; j < HP; ++j)
+            for (int j = 0; j < HP; ++j) {
+                float m0[4], m1[4];
+                if (relu_below) {
 #pragma unroll
-                for (int half = 0; half < 2; ++half)
-#pragma unroll
-                    for (int ph = 0; ph < 2; ++ph) {
-                        const int ci = 2 * j + half, h = 2 * hh[x] + ph;
-                        if (h >= H) continue;
-                        float v0 = half ? A[x][ph * 2 + 0][j].y : A[x][ph * 2 + 0][j].x;
-                        float v1 = half ? A[x][ph * 2 + 1][j].y : A[x][ph * 2 + 1][j].x;
-                        float* row = dxb + ((size_t)ci * H + h) * W + (size_t)ww[x] * 2;
-                        const bool two = pair || ww[x] * 2 + 1 < W;
-                        if (relu_below) {  // fused ReLU::backward of the layer in front (relu.cpp:38): mask by its output
-                            const float* mrow = relu_below + (row - dx);
-                            v0 = (mrow[0] <= 0.f) ? 0.f : v0;
-                            if (two) v1 = (mrow[1] <= 0.f) ? 0.f : v1;
-                        }
-                        if (two) {
-                            *(f2u*)row = f2u{v0, v1};
-                        } else {
-                            row[0] = v0;
-                        }
+                    for (int k = 0; k < 4; ++k) {
+                        const int ci = 2 * j + (k >> 1), h = 2 * hh[x] + (k & 1);
+                        const float* mrow = relu_below + ((size_t)b * CI * H * W + ((size_t)ci * H + (h < H ? h : 0)) * W + (size_t)ww[x] * 2);
+                        m0[k] = mrow[0];
+                        m1[k] = two ? mrow[1] : 1.f;
                     }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int half = k >> 1, ph = k & 1;
+                    const int ci = 2 * j + half, h = 2 * hh[x] + ph;
+                    if (h >= H) continue;
+                    float v0 = half ? A[x][ph * 2 + 0][j].y : A[x][ph * 2 + 0][j].x;
+                    float v1 = half ? A[x][ph * 2 + 1][j].y : A[x][ph * 2 + 1][j].x;
+                    if (relu_below) {
+                        v0 = (m0[k] <= 0.f) ? 0.f : v0;
+                        v1 = (m1[k] <= 0.f) ? 0.f : v1;
+                    }
+                    float* row = dxb + ((size_t)ci * H + h) * W + (size_t)ww[x] * 2;
+                    if (two) {
+                        *(f2u*)row = f2u{v0, v1};
+                    } else {
+                        row[0] = v0;
+                    }
+                }
+            }
         }
     }
 }
