@@ -1,0 +1,356 @@
+// conv_dgrad_rd.hip -- "register-direct" Conv2D data gradient (cpu/src/conv2d.cpp:168-199) for the 3x3 / stride-2 /
+// pad-0 layers with Co in {64, 128} and Ci a multiple of 32 (conv_layer_3 / _4 of the reference net):
+//     dx[ci][h][w] = sum_{co,kx,ky : (h-kx), (w-ky) even} dy[co][(h-kx)/2][(w-ky)/2] * w[co][ci][kx][ky].
+// A grid pixel (u,v) owns the 2x2 block dx[.][2u+ph][2v+pw] (its four parity classes).  Class (ph,pw) only sees the taps
+// kx = ph + 2jr, ky = pw + 2jc, i.e. the dy values D[jr][jc] = dy[co][u-jr][v-jc], jr,jc in {0,1}:
+//     class (0,0): 4 taps | (0,1): 2 | (1,0): 2 | (1,1): 1      = the 9 filter taps, no structurally-zero products.
+// GEMM per class on v_mfma_f32_32x32x2_f32: M = 32 input channels ci, N = 32 consecutive grid pixels, K = (co, tap);
+// k-slot kg of the MFMA owns the dy channels [kg*Co/2, (kg+1)*Co/2).
+//   * B operand: lane (pixel, kg) loads, per dy channel, TWO 8-byte pairs (rows u and u-1, columns v-1 | v) straight into
+//     registers: 2 loads feed the 9 MFMA steps of all four classes (the implicit-GEMM kernel re-stages dy through LDS per
+//     class and multiplies the 7/16 empty (class, tap) slots it cannot skip inside a tile);
+//   * A operand: lane (ci, kg) needs w[co][ci][0..8] -- NINE CONSECUTIVE floats of the reference's own filter layout per dy
+//     channel: two 16-byte loads + one 4-byte load straight from L1/L2 (the filters are L2-resident) feed the 9 steps.
+//     Neither operand touches LDS: no upload phase, no barrier, no re-laid-out filter copy;
+//   * borders (u-1 < 0, v-1 < 0, u >= Ho, v >= Wo) are handled by clamped addresses + per-lane select codes, the optional
+//     ReLU::backward of the layer in front (relu.cpp:35-40) in the store epilogue; stores are 8-byte (pw = 0,1) pairs,
+//     contiguous across the wave.
+// Software pipeline: a ring of 4 channel groups (2 dy channels each) of both operands in flight, pinned by RD_PIPE_FENCE
+// (see conv_wgrad_rd.hip).
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+using namespace cnn_amd;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct __attribute__((packed, aligned(4))) f2u {
+    float x, y;
+};
+struct __attribute__((packed, aligned(4))) f4u {
+    float x, y, z, w;
+};
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+struct Taps {  // the 9 filter taps of one (co, ci)
+    v4f a, b;
+    float c;
+};
+
+#define RD_PIPE_FENCE(reg) asm volatile("" : "+v"(reg) : : "memory")
+
+struct DgRdParams {
+    const float* dy;
+    const float* w;     // [Co][Ci][3][3] (the prepared buffer of this kernel is a verbatim copy)
+    const float* relu_below;  // nullable: dx = (relu_below <= 0) ? 0 : dx
+    float* dx;
+    int B, Ci, H, W, Ho, Wo, U, V, UV;
+    int pixels, tiles;       // B*U*V, ceil(pixels / 32)
+    unsigned m_uv, m_v;      // magic multipliers
+    int dbg;                 // CNN_AMD_DGRAD_RD_DBG=1: workgroup 0 prints its phase cycle counts
+};
+
+__device__ __forceinline__ int fdiv(int n, unsigned magic, int d) {
+    if (d == 1) return n;
+    int q = (int)__umulhi((unsigned)n, magic);
+    if (q * d > n) --q;
+    return q;
+}
+
+// CO dy channels (even), NW waves per workgroup, UC dy channels per pipeline group
+template <int CO, int NW, int UC, int NB>
+__global__ __launch_bounds__(NW * 64) void conv_dgrad_rd_s2_kernel(const DgRdParams p) {
+    constexpr int CH = CO / 2;   // dy channels per k-slot
+    constexpr int G = CH / UC;   // pipeline groups per tile
+    static_assert(CH % UC == 0 && G % NB == 0, "ring index must line up from tile to tile");
+    const int lane = threadIdx.x & 63, n = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ci0 = blockIdx.y * 32;
+    // this lane's filter column: w[kg*CH + .][ci0 + n][.]  (a lane beyond Ci reads channel ci0: its rows are not stored)
+    const unsigned wlane = (unsigned)((kg * CH * p.Ci + ci0 + (ci0 + n < p.Ci ? n : 0)) * 9);
+    const unsigned plane = (unsigned)(p.Ho * p.Wo);
+    const int tstep = gridDim.x * NW;
+
+    // per tile and lane: offsets of the row-u and row-(u-1) pairs, select codes for columns v and v-1 (0 none, 1 first,
+    // 2 second element of the pair), row validity, and the dx offset of the 2x2 block
+    struct Loc {
+        unsigned o0, o1;   // element offsets into dy (channel kg*CH), rows u and u-1, pair start column
+        bool s0, s1;       // D[.][0] (column v) / D[.][1] (column v-1) is the SECOND element of the loaded pair
+        bool v00, v01, v10, v11;  // D[jr][jc] exists (row and column inside dy)
+        unsigned xo;       // element offset of dx[b][ci0][2u][2v]
+        int u, v;
+        bool live;
+    };
+    auto locate = [&](int tile, Loc& L) {
+        const int pi = tile * 32 + n;
+        L.live = pi < p.pixels;
+        const int pic = L.live ? pi : p.pixels - 1;
+        const int b = fdiv(pic, p.m_uv, p.UV), rem = pic - b * p.UV;
+        const int u = fdiv(rem, p.m_v, p.V), v = rem - u * p.V;
+        L.u = u; L.v = v;
+        int cs = v - 1;  // pair start column, clamped so that both elements lie inside the row
+        cs = cs < 0 ? 0 : (cs > p.Wo - 2 ? p.Wo - 2 : cs);
+        L.s0 = v != cs;
+        L.s1 = v - 1 != cs;
+        const bool cv0 = v < p.Wo, cv1 = v >= 1 && v - 1 < p.Wo;
+        const bool r0 = L.live && u < p.Ho, r1 = L.live && u >= 1 && u - 1 < p.Ho;
+        L.v00 = r0 && cv0; L.v01 = r0 && cv1; L.v10 = r1 && cv0; L.v11 = r1 && cv1;
+        const int ur0 = u < p.Ho ? u : p.Ho - 1, ur1 = u >= 1 ? (u - 1 < p.Ho ? u - 1 : p.Ho - 1) : 0;
+        const unsigned cb = (unsigned)((b * CO + kg * CH) * (int)plane);
+        L.o0 = cb + (unsigned)(ur0 * p.Wo + cs);
+        L.o1 = cb + (unsigned)(ur1 * p.Wo + cs);
+        L.xo = (unsigned)(((b * p.Ci + ci0) * p.H + 2 * u) * p.W + 2 * v);
+    };
+    // one channel group = UC dy channels: 2 pairs of dy + 9 filter taps (16 + 16 + 4 bytes) each.  (Issuing these loads
+    // through inline asm with hand-counted s_waitcnt -- hipcc drains the queue, vmcnt(0), at the top of every ring turn --
+    // changed nothing measurable and is unsafe: the compiler may move a "defined" destination register before the data
+    // has arrived.)
+    auto load_group = [&](v2f (&buf)[UC * 2], int g, unsigned o0, unsigned o1) {
+#pragma unroll
+        for (int uu = 0; uu < UC; ++uu) {
+            const float* base = p.dy + (size_t)(g * UC + uu) * plane;  // wave-uniform
+            const f2u q0 = *(const f2u*)(base + o0), q1 = *(const f2u*)(base + o1);
+            buf[uu * 2 + 0] = v2f{q0.x, q0.y};
+            buf[uu * 2 + 1] = v2f{q1.x, q1.y};
+        }
+    };
+    auto load_filters = [&](Taps (&a)[UC], int g) {
+#pragma unroll
+        for (int uu = 0; uu < UC; ++uu) {
+            const float* base = p.w + (size_t)(g * UC + uu) * p.Ci * 9;  // wave-uniform
+            const f4u qa = *(const f4u*)(base + wlane), qb = *(const f4u*)(base + wlane + 4);
+            a[uu].a = v4f{qa.x, qa.y, qa.z, qa.w};
+            a[uu].b = v4f{qb.x, qb.y, qb.z, qb.w};
+            a[uu].c = base[wlane + 8];
+        }
+    };
+    // (two selects per value; a 3-way code here made hipcc emit a divergent switch -- ~40 branches per channel)
+    auto pick = [](const v2f& v, bool second, bool valid) {
+        const float t = second ? v.y : v.x;
+        return valid ? t : 0.f;
+    };
+
+    int tile = blockIdx.x * NW + wave;
+    if (tile >= p.tiles) return;
+    const long long dbg_t0 = p.dbg ? clock64() : 0;
+    Loc cur, nxt;
+    locate(tile, cur);
+    nxt = cur;
+    v2f xb[NB][UC * 2];
+    Taps ab[NB][UC];
+    {
+        const bool more0 = tile + tstep < p.tiles;
+        if (more0) locate(tile + tstep, nxt);
+#pragma unroll
+        for (int g = 0; g < NB - 1; ++g) {  // (G >= NB: these are groups of the first tile)
+            load_group(xb[g], g, cur.o0, cur.o1);
+            load_filters(ab[g], g);
+        }
+    }
+    for (; tile < p.tiles; tile += tstep) {
+        const bool more = tile + tstep < p.tiles;
+        if (more) locate(tile + tstep, nxt);
+        f32x16 acc[4];  // classes (ph,pw) = 00, 01, 10, 11
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        // (a run-time loop over ring turns: fully unrolled, hipcc kept hundreds of addresses live -- 432 to 512 VGPRs.  The
+        //  request for group g+3 is branch-free: behind the tile's last group it simply addresses the next tile.)
+#pragma unroll 1
+        for (int g0 = 0; g0 < G; g0 += NB) {
+#pragma unroll
+            for (int ri = 0; ri < NB; ++ri) {
+                const int g = g0 + ri, gp = g + NB - 1, rp = (ri + NB - 1) % NB;
+                const bool wrap = gp >= G;
+                const int gq = wrap ? gp - G : gp;
+                load_group(xb[rp], gq, wrap ? nxt.o0 : cur.o0, wrap ? nxt.o1 : cur.o1);
+                load_filters(ab[rp], gq);
+                RD_PIPE_FENCE(ab[ri][0].c);
+#pragma unroll
+                for (int uu = 0; uu < UC; ++uu) {
+                    const v2f p0 = xb[ri][uu * 2 + 0], p1 = xb[ri][uu * 2 + 1];
+                    const float d00 = pick(p0, cur.s0, cur.v00), d01 = pick(p0, cur.s1, cur.v01);  // D[0][jc]
+                    const float d10 = pick(p1, cur.s0, cur.v10), d11 = pick(p1, cur.s1, cur.v11);  // D[1][jc]
+                    const Taps& t9 = ab[ri][uu];
+                    const float a[9] = {t9.a.x, t9.a.y, t9.a.z, t9.a.w, t9.b.x, t9.b.y, t9.b.z, t9.b.w, t9.c};  // taps kx*3 + ky
+                    // class (0,0): taps (0,0) D00, (0,2) D01, (2,0) D10, (2,2) D11
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], d00, acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], d01, acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[6], d10, acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8], d11, acc[0], 0, 0, 0);
+                    // class (0,1): taps (0,1) D00, (2,1) D10
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], d00, acc[1], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[7], d10, acc[1], 0, 0, 0);
+                    // class (1,0): taps (1,0) D00, (1,2) D01
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], d00, acc[2], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[5], d01, acc[2], 0, 0, 0);
+                    // class (1,1): tap (1,1) D00
+                    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4], d00, acc[3], 0, 0, 0);
+                }
+            }
+        }
+        const long long dbg_t1 = p.dbg ? clock64() : 0;
+        // ---- epilogue: dx[ci][2u + ph][2v .. 2v+1]
+        if (cur.live) {
+            const bool w1 = 2 * cur.v + 1 < p.W, h1 = 2 * cur.u + 1 < p.H;
+            // 8 accumulator rows at a time: all mask values of the batch are requested before the first one is used (a
+            // load per store would serialise 32 round trips)
+#pragma unroll
+            for (int rb = 0; rb < 16; rb += 8) {
+                float m0[8][2], m1[8][2];
+                if (p.relu_below) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int r = rb + i, rowl = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                        const size_t o = (size_t)cur.xo + (size_t)(ci0 + rowl < p.Ci ? rowl : 0) * p.H * p.W;
+#pragma unroll
+                        for (int ph = 0; ph < 2; ++ph) {
+                            const size_t oo = o + (size_t)((ph == 1 && h1) ? p.W : 0);
+                            m0[i][ph] = p.relu_below[oo];
+                            m1[i][ph] = w1 ? p.relu_below[oo + 1] : 1.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = rb + i, rowl = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    if (ci0 + rowl >= p.Ci) continue;
+                    const size_t o = (size_t)cur.xo + (size_t)rowl * p.H * p.W;
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph) {
+                        if (ph == 1 && !h1) continue;
+                        const size_t oo = o + (size_t)ph * p.W;
+                        float v0 = acc[ph * 2][r], v1 = acc[ph * 2 + 1][r];
+                        if (p.relu_below) {
+                            v0 = (m0[i][ph] <= 0.f) ? 0.f : v0;
+                            v1 = (m1[i][ph] <= 0.f) ? 0.f : v1;
+                        }
+                        if (w1) *(f2u*)(p.dx + oo) = f2u{v0, v1};
+                        else p.dx[oo] = v0;
+                    }
+                }
+            }
+        }
+        if (p.dbg && threadIdx.x == 0 && (blockIdx.x | blockIdx.y) == 0)
+            printf("conv_dgrad_rd wg 0: MFMA loop done %lld, stores drained %lld cycles after start\n", dbg_t1 - dbg_t0, clock64() - dbg_t0);
+        cur = nxt;
+    }
+}
+
+inline unsigned magic_of(int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
+
+struct DgRdPlan {
+    DgRdParams p;
+    int co, nw, cgroups, blocks_x;
+    size_t lds, img_floats;
+};
+
+bool make_plan(const cnn_conv2d_desc* d, DgRdPlan* pl) {
+    if (d->k != 3 || d->pad != 0 || d->s != 2) return false;
+    if ((d->Co != 64 && d->Co != 128) || d->Ci % 32 != 0) return false;
+    if (const char* e = getenv("CNN_AMD_DGRAD_RD"))
+        if (atoi(e) == 0) return false;
+    DgRdParams& p = pl->p;
+    p.B = d->B; p.Ci = d->Ci; p.H = d->H; p.W = d->W;
+    p.Ho = cnn_conv2d_out_dim(d->H, 3, 2, 0);
+    p.Wo = cnn_conv2d_out_dim(d->W, 3, 2, 0);
+    if (p.Ho < 1 || p.Wo < 2) return false;
+    p.U = (d->H + 1) / 2; p.V = (d->W + 1) / 2; p.UV = p.U * p.V;
+    const long long pixels = (long long)d->B * p.UV;
+    if (pixels >= (1ll << 30) || (long long)d->B * d->Ci * d->H * d->W >= (1ll << 31) || (long long)d->B * d->Co * p.Ho * p.Wo >= (1ll << 31))
+        return false;
+    p.pixels = (int)pixels;
+    p.tiles = (int)((pixels + 31) / 32);
+    p.m_uv = magic_of(p.UV);
+    p.m_v = magic_of(p.V);
+    p.dbg = getenv("CNN_AMD_DGRAD_RD_DBG") ? atoi(getenv("CNN_AMD_DGRAD_RD_DBG")) : 0;
+    pl->co = d->Co;
+    pl->cgroups = d->Ci / 32;
+    pl->img_floats = (size_t)d->Co * d->Ci * 9;  // (prepared buffer = a verbatim copy of w)
+    pl->lds = 0;
+    pl->nw = 4;
+    const long long bx = 2 * kNumCU / pl->cgroups;
+    const long long need = (p.tiles + pl->nw - 1) / pl->nw;
+    pl->blocks_x = (int)(bx < 1 ? 1 : (bx > need ? need : bx));
+    return true;
+}
+
+template <int CO, int NW>
+int launch(const DgRdPlan& pl, hipStream_t s, const char* name, const cnn_conv2d_desc* d) {
+    const int var = getenv("CNN_AMD_DGRAD_RD_VAR") ? atoi(getenv("CNN_AMD_DGRAD_RD_VAR")) : 0;
+    auto kern = var == 1 ? conv_dgrad_rd_s2_kernel<CO, NW, 1, 4> : var == 2 ? conv_dgrad_rd_s2_kernel<CO, NW, 1, 8> : var == 3 ? conv_dgrad_rd_s2_kernel<CO, NW, 2, 2> : conv_dgrad_rd_s2_kernel<CO, NW, 2, 4>;
+    const dim3 grid(pl.blocks_x, pl.cgroups);
+    CNN_KLAUNCH(s, name, (kern<<<grid, NW * 64, pl.lds, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W,
+                d->Co, d->k, d->s, d->pad);
+    return CNN_AMD_OK;
+}
+
+struct DgRdPrepJob {
+    const float* w;
+    float* img;
+    int Co, Ci, cgroups;
+};
+struct DgRdPrepBatch {
+    DgRdPrepJob job[6];
+};
+
+// the prepared buffer of this kernel is a verbatim copy of the filters (they are read in the reference's own layout)
+__global__ __launch_bounds__(256) void dgrad_rd_prepare_kernel(const DgRdPrepBatch pb) {
+    const DgRdPrepJob j = pb.job[blockIdx.y];
+    const int total = j.Co * j.Ci * 9;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) j.img[i] = j.w[i];
+}
+
+}  // namespace
+
+namespace cnn_amd {
+
+bool dgrad_rd_supported(const cnn_conv2d_desc* d) {
+    DgRdPlan pl;
+    return make_plan(d, &pl);
+}
+
+size_t dgrad_rd_prepared_floats(const cnn_conv2d_desc* d) {
+    DgRdPlan pl;
+    return make_plan(d, &pl) ? pl.img_floats : 0;
+}
+
+// prepares every layer of the batch this file covers (one launch); sets their bits in *done
+int dgrad_rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, void* const* dgrad, hipStream_t s,
+                           unsigned* done) {
+    DgRdPrepBatch pb;
+    int jobs = 0;
+    size_t most = 0;
+    for (int i = 0; i < n && i < 6; ++i) {
+        DgRdPlan pl;
+        if (!dgrad || !dgrad[i] || (*done >> i & 1u) || !make_plan(&descs[i], &pl)) continue;
+        CNN_REQUIRE(w[i] != nullptr, "cnn_conv2d_prepare_filters: filters of layer %d are null", i);
+        pb.job[jobs++] = DgRdPrepJob{w[i], (float*)dgrad[i], descs[i].Co, descs[i].Ci, pl.cgroups};
+        if (pl.img_floats > most) most = pl.img_floats;
+        *done |= 1u << i;
+    }
+    if (jobs) {
+        unsigned gx = (unsigned)((most + 255) / 256);
+        if (gx > 512) gx = 512;
+        CNN_KLAUNCH(s, "dgrad_rd_prepare", (dgrad_rd_prepare_kernel<<<dim3(gx, jobs), 256, 0, s>>>(pb)), "jobs=%d", jobs);
+    }
+    return CNN_AMD_OK;
+}
+
+// w == nullptr: `img` holds the prepared images
+int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* img, const float* relu_below,
+                           float* dx, hipStream_t s) {
+    DgRdPlan pl;
+    if (!make_plan(d, &pl)) return fail(CNN_AMD_E_BADARG, "conv_dgrad_rd: geometry not covered");
+    pl.p.dy = dy; pl.p.w = w ? w : img; pl.p.relu_below = relu_below; pl.p.dx = dx;
+    char name[64];
+    snprintf(name, sizeof(name), "conv_dgrad_rd<2,%d>/dgrad%s", d->Co, relu_below ? "+relu" : "");
+    if (d->Co == 64) return launch<64, 4>(pl, s, name, d);
+    return launch<128, 4>(pl, s, name, d);
+}
+
+}  // namespace cnn_amd

@@ -1257,6 +1257,12 @@ int direct_conv_pool_forward(const cnn_conv2d_desc* d, const float* x, const flo
                              int32_t* mask, void* ws, size_t ws_bytes, hipStream_t s, bool prepared);
 int direct_conv_dgrad_pooled(const cnn_conv2d_desc* d, const float* dpool, const int32_t* mask, const float* pooled, const float* w,
                              float* dx, void* ws, size_t ws_bytes, hipStream_t s, bool prepared);
+bool dgrad_rd_supported(const cnn_conv2d_desc* d);  // conv_dgrad_rd.hip: register-direct data gradient, 3x3 stride 2, Co 64 / 128
+size_t dgrad_rd_prepared_floats(const cnn_conv2d_desc* d);
+int dgrad_rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, void* const* dgrad, hipStream_t s,
+                           unsigned* done);
+int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* img, const float* relu_below,
+                           float* dx, hipStream_t s);
 bool fwd_rd_supported(const cnn_conv2d_desc* d);  // conv_fwd_rd.hip: register-direct forward of the mid-size 3x3 layers
 size_t fwd_rd_prepared_floats(const cnn_conv2d_desc* d);
 int fwd_rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, const float* const* bias, void* const* fwd,
@@ -1276,6 +1282,7 @@ size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
     if (direct_conv_supported(d) && n < 1024) n = 1024;  // packed filter copies of the direct kernels (conv_direct.hip)
     if (pk_dgrad_s2_supported(d) && n < pk_dgrad_s2_workspace_floats(d)) n = pk_dgrad_s2_workspace_floats(d);
     if (fwd_rd_prepared_floats(d) > n) n = fwd_rd_prepared_floats(d);
+    if (dgrad_rd_prepared_floats(d) > n) n = dgrad_rd_prepared_floats(d);
     return n;
 }
 }  // namespace cnn_amd
@@ -1306,6 +1313,8 @@ static int conv2d_backward_data_impl(const char* who, const cnn_conv2d_desc* d, 
     }
     if (pk_dgrad_s2_supported(d) && ws != nullptr && ws_bytes >= pk_dgrad_s2_workspace_floats(d) * sizeof(float))
         return pk_dgrad_s2(d, dy, w, dx, ws, as_stream(stream), prepared, relu_below);
+    if (dgrad_rd_supported(d))
+        return dgrad_rd_backward_data(d, dy, prepared ? nullptr : w, prepared ? (const float*)ws : nullptr, relu_below, dx, as_stream(stream));
     Plan pl;
     if (int rc = make_plan(who, d, MODE_DGRAD, &pl)) return rc;
     return run_plan(pl, d, dy, w, nullptr, dx, const_cast<float*>(relu_below), ws, ws_bytes, as_stream(stream), who, prepared);
@@ -1376,6 +1385,7 @@ int cnn_conv2d_prepare_filters(int n, const cnn_conv2d_desc* descs, const float*
     unsigned fdone = 0, ddone = 0;
     if (int rc = direct_prepare_batch(n, descs, w, bias, fwd, dgrad, s, &fdone, &ddone)) return rc;
     if (int rc = fwd_rd_prepare_batch(n, descs, w, bias, fwd, s, &fdone)) return rc;
+    if (int rc = dgrad_rd_prepare_batch(n, descs, w, dgrad, s, &ddone)) return rc;
     PrepBatch pb;
     pb.n = 0;
     long long most = 0;
