@@ -939,6 +939,7 @@ inline unsigned wave_grid(long long rows) {
 }  // namespace
 
 namespace cnn_amd {
+bool dgrad_rd_supported(const cnn_conv2d_desc* d);  // conv_dgrad_rd.hip (takes precedence over the packed stride-2 kernel)
 
 #define CONV_TAG(d) "B%d Ci%d %dx%d Co%d k%d s%d p%d", (d)->B, (d)->Ci, (d)->H, (d)->W, (d)->Co, (d)->k, (d)->s, (d)->pad
 
@@ -1122,7 +1123,7 @@ int direct_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const
         if (direct_conv_supported(d) && direct_dgrad_pk_ok(d) && dgrad && dgrad[i] && pb.n < 8) {
             pb.j[pb.n++] = PackJob{1, w[i], nullptr, (float*)dgrad[i], 3, 16};
             *dgrad_done |= 1u << i;
-        } else if (!direct_conv_supported(d) && pk_dgrad_s2_supported(d) && dgrad && dgrad[i] && pb.n < 8) {
+        } else if (!direct_conv_supported(d) && pk_dgrad_s2_supported(d) && !dgrad_rd_supported(d) && dgrad && dgrad[i] && pb.n < 8) {
             pb.j[pb.n++] = PackJob{2, w[i], nullptr, (float*)dgrad[i], d->Ci, d->Co};
             *dgrad_done |= 1u << i;
         }
@@ -1133,7 +1134,7 @@ int direct_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const
 // can this layer's forward / data gradient run from prepared filters?
 bool direct_prepared_fwd_ok(const cnn_conv2d_desc* d) { return direct_conv_supported(d) && direct_fwd_pk_ok(d); }
 bool direct_prepared_dgrad_ok(const cnn_conv2d_desc* d) {
-    return (direct_conv_supported(d) && direct_dgrad_pk_ok(d)) || (!direct_conv_supported(d) && pk_dgrad_s2_supported(d));
+    return (direct_conv_supported(d) && direct_dgrad_pk_ok(d)) || (!direct_conv_supported(d) && pk_dgrad_s2_supported(d) && !dgrad_rd_supported(d));
 }
 
 // number of slabs (workgroups) the packed weight-gradient kernel writes; 0 when the geometry / sizes rule it out

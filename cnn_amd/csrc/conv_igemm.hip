@@ -1311,10 +1311,10 @@ static int conv2d_backward_data_impl(const char* who, const cnn_conv2d_desc* d, 
         if (rc || !relu_below) return rc;
         return cnn_relu_backward(relu_below, dx, (size_t)d->B * d->Ci * d->H * d->W, stream);
     }
-    if (pk_dgrad_s2_supported(d) && ws != nullptr && ws_bytes >= pk_dgrad_s2_workspace_floats(d) * sizeof(float))
-        return pk_dgrad_s2(d, dy, w, dx, ws, as_stream(stream), prepared, relu_below);
     if (dgrad_rd_supported(d))
         return dgrad_rd_backward_data(d, dy, prepared ? nullptr : w, prepared ? (const float*)ws : nullptr, relu_below, dx, as_stream(stream));
+    if (pk_dgrad_s2_supported(d) && ws != nullptr && ws_bytes >= pk_dgrad_s2_workspace_floats(d) * sizeof(float))
+        return pk_dgrad_s2(d, dy, w, dx, ws, as_stream(stream), prepared, relu_below);
     Plan pl;
     if (int rc = make_plan(who, d, MODE_DGRAD, &pl)) return rc;
     return run_plan(pl, d, dy, w, nullptr, dx, const_cast<float*>(relu_below), ws, ws_bytes, as_stream(stream), who, prepared);
@@ -1395,7 +1395,7 @@ int cnn_conv2d_prepare_filters(int n, const cnn_conv2d_desc* descs, const float*
         for (int mode = 0; mode < 2; ++mode) {
             void* out = mode == MODE_FWD ? (fwd ? fwd[i] : nullptr) : (dgrad ? dgrad[i] : nullptr);
             if (!out || ((mode == MODE_FWD ? fdone : ddone) >> i & 1u)) continue;
-            CNN_REQUIRE(!direct_conv_supported(&descs[i]) && !(mode == MODE_DGRAD && pk_dgrad_s2_supported(&descs[i])),
+            CNN_REQUIRE(!direct_conv_supported(&descs[i]) && !(mode == MODE_DGRAD && pk_dgrad_s2_supported(&descs[i]) && !dgrad_rd_supported(&descs[i])),
                         "cnn_conv2d_prepare_filters: layer %d has no prepared path for this mode", i);
             Plan pl;
             if (int rc = make_plan("cnn_conv2d_prepare_filters", &descs[i], mode, &pl)) return rc;
