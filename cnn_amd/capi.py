@@ -199,6 +199,15 @@ class Conv2d:
               "cnn_conv2d_backward_weight_pooled2")
         return gw, gb
 
+    def backward_pooled2_prepared(self, x, dpool, mask, pooled, prepared_dgrad, divisor, gw, gb, dx, defer_join=False):
+        """weight gradient (library side stream) and data gradient (current stream) of the pool-fused block in one call"""
+        _need_gpu(x, dpool, mask, prepared_dgrad, gw, gb, dx)
+        check(self.lib.cnn_conv2d_backward_pooled2_prepared(C.byref(self.desc), _ptr(x), _ptr(dpool), _ptr(mask),
+                                                            _ptr(pooled) if pooled is not None else None, _ptr(prepared_dgrad), _ptr(gw),
+                                                            _ptr(gb), _ptr(dx), float(divisor), _ptr(self.ws), self.ws_bytes, _stream(),
+                                                            1 if defer_join else 0), "cnn_conv2d_backward_pooled2_prepared")
+        return gw, gb, dx
+
     def backward_data_pooled2(self, dpool, mask, pooled, w, dx, prepared_dgrad=None):
         _need_gpu(dpool, mask, dx)
         pooled_p = _ptr(pooled) if pooled is not None else None

@@ -220,12 +220,12 @@ class AlexNetHip:
                 # conv_layer_1 from the pooled domain: cur = d pool_out
                 # (with fbr the ReLU mask was already applied by conv_layer_2's data gradient: pooled = None)
                 pooled = None if fbr else self.pool_out
-                self.convs[0].backward_weight_pooled2(self.x, cur, self.pool_mask, pooled, div, self.conv_w(0, g), self.conv_b(0, g))
                 if self.defer_dx0:
+                    self.convs[0].backward_weight_pooled2(self.x, cur, self.pool_mask, pooled, div, self.conv_w(0, g), self.conv_b(0, g))
                     self.pending_dx0 = (self.prep0_dgrad[self.parity], cur, self.pool_mask, pooled)
-                else:
-                    self.convs[0].backward_data_pooled2(cur, self.pool_mask, pooled, None, self.d_conv[0],
-                                                        prepared_dgrad=self.prep[0][1])
+                else:  # both gradients now, concurrently (weight gradient on the library's side stream)
+                    self.convs[0].backward_pooled2_prepared(self.x, cur, self.pool_mask, pooled, self.prep[0][1], div,
+                                                            self.conv_w(0, g), self.conv_b(0, g), self.d_conv[0], defer_join=True)
                 break
             if l == 0:
                 hh, ww = self.conv_out_hw[0]
