@@ -37,17 +37,18 @@ def algorithmic_work(key):
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         flops = 2.0 * B * Co * Ho * Wo * Ci * k * k
         x_b, y_b, w_b = 4.0 * B * Ci * H * W, 4.0 * B * Co * Ho * Wo, 4.0 * Co * Ci * k * k
-        if kernel.endswith("+pool") or kernel.startswith("conv_fwd_pool_pk"):
+        if kernel.endswith(("+pool", "+poolm")) or kernel.startswith("conv_fwd_pool_pk"):
             # first block in the pooled domain: the Co*Ho*Wo tensors are never touched.  pooled-domain tensor = B*Co*(Ho/2)*(Wo/2)
             pd_b = 4.0 * B * Co * (Ho // 2) * (Wo // 2)
             fl = 2.0 * B * Co * (2 * (Ho // 2)) * (2 * (Wo // 2)) * Ci * k * k  # conv pixels inside a pooling window
             if kernel.startswith("conv_fwd_pool_pk"):
                 return x_b + 2 * pd_b + w_b, fl          # x, w -> pooled + mask
-            return x_b + 3 * pd_b + w_b, fl               # wgrad: x + (dpool, mask, pooled) -> gw ; dgrad: the three -> dx
+            nt = 2 if kernel.endswith("+poolm") else 3    # "+poolm": dpool arrives pre-masked, the pooled tensor is not read
+            return x_b + nt * pd_b + w_b, fl              # wgrad: x + (dpool, mask[, pooled]) -> gw ; dgrad: those -> dx
         if kernel.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel", "wgrad_rd", "conv_direct", "conv_dgrad_pk", "conv_fwd_pk",
-                              "conv_wgrad_pk", "conv_fwd_rd")):
+                              "conv_wgrad_pk", "conv_fwd_rd", "conv_dgrad_rd")):
             fused = y_b if (kernel.endswith("/fwd+relu") or ",relu" in kernel or kernel.endswith(">+relu")) else 0.0  # second output tensor
-            if kernel.endswith("/dgrad+relu"):
+            if "dgrad" in kernel and kernel.endswith("+relu"):
                 fused = x_b  # fused ReLU::backward: the mask tensor (shape of dx) is read
             return x_b + y_b + w_b + fused, flops  # fwd: x,w -> y ; dgrad: dy,w -> dx ; wgrad: x,dy -> gw
         if kernel.startswith("bias_grad_partial"):
@@ -174,8 +175,8 @@ def conv_ns_bench(torch, capi, reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE configs 2/3: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-ns", action="store_true")

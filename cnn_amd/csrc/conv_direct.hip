@@ -1058,7 +1058,7 @@ int direct_conv_dgrad_pooled(const cnn_conv2d_desc* d, const float* dpool, const
                                                                                               d->W, Ho, Wo, ipi, div_magic(ipi), div_magic(V2))),
                     CONV_TAG(d));
     else
-        CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>+pool",
+        CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>+poolm",
                     (conv_dgrad_pool_pk_3_16_3_2<2, false><<<wave_grid(witems), kBlock, 0, s>>>(dpool, mask, nullptr, (const v2f*)ws, dx, d->B, d->H,
                                                                                                d->W, Ho, Wo, ipi, div_magic(ipi), div_magic(V2))),
                     CONV_TAG(d));
@@ -1170,7 +1170,7 @@ int direct_conv_wgrad_pooled(const cnn_conv2d_desc* d, const float* x, const flo
                                                                                           Ho, Wo, ipi, div_magic(ipi), div_magic(Wo))),
                     CONV_TAG(d));
     else
-        CNN_KLAUNCH(s, "conv_wgrad_pk<3,16,3,2>+pool",
+        CNN_KLAUNCH(s, "conv_wgrad_pk<3,16,3,2>+poolm",
                     (conv_wgrad_pk_3_16_3_2<3, 2><<<direct_wgrad_slots(d), kBlock, 0, s>>>(x, dpool, mask, nullptr, slabs, d->B, d->H, d->W,
                                                                                           Ho, Wo, ipi, div_magic(ipi), div_magic(Wo))),
                     CONV_TAG(d));

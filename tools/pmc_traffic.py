@@ -28,11 +28,15 @@ def canonical(name):
         return f"{m.group(1)}<{m.group(2)}>"
     if name.startswith("conv_fwd_pool_pk_3_16_3_2"):
         return "conv_fwd_pool_pk<3,16,3,2>"
-    if name.startswith("conv_dgrad_pool_pk_3_16_3_2"):
-        return "conv_dgrad_pk<3,16,3,2>+pool"
-    m = re.match(r"conv_wgrad_pk_3_16_3_2<\d+,(true|false)>$", name)
+    m = re.match(r"conv_dgrad_pool_pk_3_16_3_2<\d+,(true|false)>$", name)
     if m:
-        return "conv_wgrad_pk<3,16,3,2>" + ("+pool" if m.group(1) == "true" else "")
+        return "conv_dgrad_pk<3,16,3,2>" + ("+pool" if m.group(1) == "true" else "+poolm")
+    m = re.match(r"conv_wgrad_pk_3_16_3_2<\d+,(\d+)>$", name)
+    if m:
+        return "conv_wgrad_pk<3,16,3,2>" + {"0": "", "1": "+pool", "2": "+poolm"}[m.group(1)]
+    m = re.match(r"conv_dgrad_rd_s2_kernel<(\d+),\d+,\d+,\d+>$", name)
+    if m:
+        return f"conv_dgrad_rd<2,{m.group(1)}>"
     m = re.match(r"conv_fwd_rd_kernel<(\d+),(\d+),(\d+),\d+,\d+>$", name)
     if m:
         return f"conv_fwd_rd<{m.group(1)},{m.group(2)},{m.group(3)}>"
