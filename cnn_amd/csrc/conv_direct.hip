@@ -143,6 +143,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // two adjacent floats stored with ONE dwordx2 even when only 4-byte aligned (odd row pitch): global memory accesses may
 // be unaligned on gfx950, and hipcc emits global_store_dwordx2 for this type
 struct __attribute__((packed, aligned(4))) f2u { float x, y; };
+struct __attribute__((packed, aligned(4))) f3u { float x, y, z; };
 
 __device__ void pack_dgrad_3_16_3_2_body(const float* __restrict__ w, float* __restrict__ wp, int tid) {
     const int co = tid;
@@ -681,6 +682,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_pk_3_16_3_2(const float* __re
 // window rows (5 input rows x 3 floats x 3 channels = 45 loads for 2 x 27 taps), in exactly the tap order of
 // conv_fwd_pk_3_16_3_2 (bit-identical y), applies bias and ReLU, swaps values with its neighbour through DPP and the
 // even lane scans the window in the reference's order (pool2d.cpp:67-75: first maximum wins, strict '<').
+template <int DBG>  // tuning ablations: 1 no FMAs, 2 one weight fetch for all taps
 __global__ __launch_bounds__(kBlock) void conv_fwd_pool_pk_3_16_3_2(const float* __restrict__ x, const v2f* __restrict__ wp,
                                                                     float* __restrict__ pooled, int32_t* __restrict__ mask,
                                                                     int B, int H, int W, int Ho, int Wo, int PHo, int PWo,
@@ -702,26 +704,37 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_pool_pk_3_16_3_2(const float*
         const int pp = (live ? n2 : 0) >> 1, j = n2 & 1;
         const int ph = fast_div(pp, m_prow, PWo), pw = pp - ph * PWo;
         const int q = 2 * pw + j;  // conv column; conv rows 2ph and 2ph + 1
-        const unsigned vo = live ? (unsigned)(4 * ph * W + 2 * q) * 4u : kBufOOB;  // x[.][4ph][2q]
+        // x[.][4ph + r][2q .. 2q+2]: ONE 12-byte load per input row (the wave reads one contiguous run, neighbouring lanes
+        // overlap by a float) -- 15 instead of 45 load instructions per item (68 -> 59 us with 8 + 4 bytes, -> this).  Plain global loads (scalar row
+        // base + per-lane offset): every address of a live lane is inside the image (4ph + 4 <= H - 1, 2q + 2 <= W - 1), a
+        // lane that owns no window re-reads element 0 and stores nothing.  (Raw buffer loads of mixed width at one offset
+        // are mis-lowered by hipcc, tools/probes/bufvec_probe.cpp.)
+        const unsigned vo = live ? (unsigned)(4 * ph * W + 2 * q) : 0u;  // x[.][4ph][2q], in floats
         float patch[CI][5][K];
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
-                const int so = (((b * CI + ci) * H + r) * W) * 4;  // wave-uniform
-#pragma unroll
-                for (int ky = 0; ky < K; ++ky)
-                    patch[ci][r][ky] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)vo, so + 4 * ky, 0));
+                const float* rowp = x + (size_t)((b * CI + ci) * H + r) * W;  // wave-uniform
+                const f3u pr = *(const f3u*)(rowp + vo);
+                patch[ci][r][0] = pr.x;
+                patch[ci][r][1] = pr.y;
+                patch[ci][r][2] = pr.z;
             }
         v2f acc0[CO / 2], acc1[CO / 2];
 #pragma unroll
         for (int c = 0; c < CO / 2; ++c) acc0[c] = acc1[c] = v2f{0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < CI * K * K; ++t) {
-            asm volatile("" ::: "memory");  // stream the weight s_loads tap by tap (see conv_dgrad_pk)
+            if (DBG != 2 || t == 0) asm volatile("" ::: "memory");  // stream the weight s_loads tap by tap (see conv_dgrad_pk)
             const int ci = t / 9, kx = (t - ci * 9) / 3, ky = t - ci * 9 - kx * 3;
-            const v2f* qw = wp + t * (CO / 2);
+            const v2f* qw = wp + (DBG == 2 ? 0 : t) * (CO / 2);
             const v2f p0 = {patch[ci][kx][ky], patch[ci][kx][ky]}, p1 = {patch[ci][kx + 2][ky], patch[ci][kx + 2][ky]};
+            if (DBG == 1) {
+                acc0[t & 7] += p0;
+                acc1[t & 7] += p1;
+                continue;
+            }
 #pragma unroll
             for (int c = 0; c < CO / 2; ++c) {
                 acc0[c] = __builtin_elementwise_fma(qw[c], p0, acc0[c]);
@@ -996,10 +1009,16 @@ int direct_conv_pool_forward(const cnn_conv2d_desc* d, const float* x, const flo
         CNN_KLAUNCH(s, "pack_fwd_weights", (pack_fwd_weights_3_16_3_2<<<1, 256, 0, s>>>(w, bias, (float*)ws)), CONV_TAG(d));
     const int ipi = (2 * PHo * PWo + 63) / 64;
     const long long witems = (long long)d->B * ipi;
-    CNN_KLAUNCH(s, "conv_fwd_pool_pk<3,16,3,2>",
-                (conv_fwd_pool_pk_3_16_3_2<<<wave_grid(witems), kBlock, 0, s>>>(x, (const v2f*)ws, pooled, mask, d->B, d->H, d->W, Ho, Wo,
-                                                                               PHo, PWo, ipi, div_magic(ipi), div_magic(PWo))),
-                CONV_TAG(d));
+    const int dbg = getenv("CNN_AMD_DBG") ? atoi(getenv("CNN_AMD_DBG")) : 0;
+#define FP_LAUNCH(DBG_)                                                                                                        \
+    CNN_KLAUNCH(s, "conv_fwd_pool_pk<3,16,3,2>",                                                                               \
+                (conv_fwd_pool_pk_3_16_3_2<DBG_><<<wave_grid(witems), kBlock, 0, s>>>(x, (const v2f*)ws, pooled, mask, d->B, d->H, d->W, Ho, \
+                                                                                     Wo, PHo, PWo, ipi, div_magic(ipi), div_magic(PWo))),    \
+                CONV_TAG(d))
+    if (dbg == 1) FP_LAUNCH(1);
+    else if (dbg == 2) FP_LAUNCH(2);
+    else FP_LAUNCH(0);
+#undef FP_LAUNCH
     return CNN_AMD_OK;
 }
 
