@@ -692,9 +692,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_pool_pk_3_16_3_2(const float*
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long items = (long long)B * items_per_img;
     const int half = 2 * PHo * PWo;  // window columns per image
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * CI * H * W * 4u), 0x00020000);
-    const int out_bytes = (int)((unsigned)B * CO * PHo * PWo * 4u);
+        const int out_bytes = (int)((unsigned)B * CO * PHo * PWo * 4u);
     const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc((void*)pooled, 0, out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)(mask ? mask : (int32_t*)pooled), 0, out_bytes, 0x00020000);
     for (int it = blockIdx.x * kWaves + wave; it < (int)items; it += gridDim.x * kWaves) {
@@ -807,8 +805,6 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long items = (long long)B * items_per_img;
     const int plane = Ho * Wo;
-    const __amdgpu_buffer_rsrc_t rx =
-        __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * CI * H * W * 4u), 0x00020000);
     const int PHo = Ho / 2, PWo = Wo / 2, pplane = PHo * PWo;
     const int dy_bytes = (int)((unsigned)B * CO * (POOLED ? pplane : plane) * 4u);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
@@ -819,33 +815,36 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __
     // rows of ITS output channels 4w .. 4w+3, which never go through LDS.  Everything below is branch-free on purpose
     // (an item past the end reads out of range = 0 and adds nothing): with straight-line code hipcc counts the outstanding
     // loads (s_waitcnt vmcnt(N > 0)) instead of draining the queue at every control-flow merge.
-    int tap_off[kWgX];
-    bool tap_ok[kWgX];
+    // x: wave w fetches the input rows (ci,kx) = 3w .. 3w+2 with ONE 12-byte load each (taps ky = 0..2; plain global loads,
+    // scalar row base + per-lane offset: a live lane's addresses are inside the image, the others re-read element 0 and
+    // meet dy = 0).  9 rows for 4 waves: wave 3 repeats row 8 (same values into the same LDS slots) so that the code stays
+    // free of wave-dependent branches.  12 instead of 27 input load instructions per item.
+    int row_id[3], row_off[3];
 #pragma unroll
-    for (int i = 0; i < kWgX; ++i) {
-        const int r = wave * kWgX + i;
-        const int ci = r / 9, kx = (r - ci * 9) / 3, ky = r - ci * 9 - kx * 3;
-        tap_ok[i] = r < 27;
-        tap_off[i] = ((ci * H + kx) * W + ky) * 4;
+    for (int i = 0; i < 3; ++i) {
+        const int r = wave * 3 + i < 9 ? wave * 3 + i : 8;
+        row_id[i] = r;
+        row_off[i] = ((r / 3) * H + (r % 3)) * W;
     }
+    if (threadIdx.x < 64) stage[0][27][threadIdx.x] = stage[1][27][threadIdx.x] = 0.f;  // tap 27 = the zero pad of the 14th pair
     // each workgroup walks a CONTIGUOUS range of items: vertically neighbouring items share two of their three input
     // rows, which then come from this CU's L1 / this XCD's L2 instead of HBM (a strided assignment fetched x 2.5x)
     const long long per = (items + gridDim.x - 1) / gridDim.x;
     const long long it_end = (blockIdx.x + 1) * per < items ? (blockIdx.x + 1) * per : items;
     constexpr int ND = POOLED ? 13 : 4;  // POOLED: dpool[4] | mask[4] | pooled[4] | expected flat index of this lane's pixel
-    float lx[kWgDepth][kWgX], ldy[kWgDepth][ND];
-    auto issue = [&](long long it, float(&ax)[kWgX], float(&ad)[ND]) {
+    f3u lx[kWgDepth][3];
+    float ldy[kWgDepth][ND];
+    auto issue = [&](long long it, f3u(&ax)[3], float(&ad)[ND]) {
         const bool inr = it < it_end;
         const int iti = inr ? (int)it : 0;
         const int b = fast_div(iti, m_ipi, items_per_img);
         const int n = (iti - b * items_per_img) * 64 + lane;
         const bool live = inr && n < plane;
         const int p = fast_div(live ? n : 0, m_row, Wo), q = (live ? n : 0) - p * Wo;
-        const unsigned vx = live ? (unsigned)(2 * p * W + 2 * q) * 4u : kBufOOB;
-        const int sx = b * CI * H * W * 4;
+        const unsigned vx = live ? (unsigned)(2 * p * W + 2 * q) : 0u;  // x[.][2p][2q], in floats
+        const float* xb = x + (size_t)b * CI * H * W;
 #pragma unroll
-        for (int i = 0; i < kWgX; ++i)
-            ax[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(tap_ok[i] ? vx : kBufOOB), sx + tap_off[i], 0));
+        for (int i = 0; i < 3; ++i) ax[i] = *(const f3u*)(xb + row_off[i] + vx);
         if constexpr (POOLED) {
             const bool win = live && (p >> 1) < PHo && (q >> 1) < PWo;  // pixels outside every window have no delta
             const unsigned vd = win ? (unsigned)((p >> 1) * PWo + (q >> 1)) * 4u : kBufOOB;
@@ -880,10 +879,14 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __
 #pragma unroll
     for (int dd = 0; dd < kWgDepth; ++dd) issue(it + dd * stride, lx[dd], ldy[dd]);
     int k = 0;
-    auto consume = [&](float(&ax)[kWgX], float(&ad)[ND]) {  // item `it`: registers -> LDS, refill the register set, accumulate
+    auto consume = [&](f3u(&ax)[3], float(&ad)[ND]) {  // item `it`: registers -> LDS, refill the register set, accumulate
         float(*st)[64] = stage[k & 1];
 #pragma unroll
-        for (int i = 0; i < kWgX; ++i) st[wave * kWgX + i][lane] = ax[i];
+        for (int i = 0; i < 3; ++i) {
+            st[row_id[i] * 3 + 0][lane] = ax[i].x;
+            st[row_id[i] * 3 + 1][lane] = ax[i].y;
+            st[row_id[i] * 3 + 2][lane] = ax[i].z;
+        }
         float d[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
