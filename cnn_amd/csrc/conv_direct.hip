@@ -625,26 +625,24 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_pk_3_16_3_2(const float* __re
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long items = (long long)B * items_per_img;
     const int plane = Ho * Wo;
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * CI * H * W * 4u), 0x00020000);
     for (int it = blockIdx.x * kWaves + wave; it < (int)items; it += gridDim.x * kWaves) {
         const int b = fast_div(it, m_ipi, items_per_img);
         const int n = (it - b * items_per_img) * 64 + lane;
         const bool live = n < plane;
         const int p = fast_div(live ? n : 0, m_row, Wo), q = (live ? n : 0) - p * Wo;
-        const unsigned vo = live ? (unsigned)(2 * p * W + 2 * q) * 4u : kBufOOB;  // x[.][2p][2q]
+        // x[.][2p + kx][2q .. 2q+2]: ONE 12-byte load per input row (plain global loads, scalar row base + per-lane offset;
+        // a live lane's addresses are inside the image, the others re-read element 0 and store nothing)
+        const unsigned vo = live ? (unsigned)(2 * p * W + 2 * q) : 0u;  // x[.][2p][2q], in floats
         float patch[CI * K * K];
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
-                const int so = (((b * CI + ci) * H + kx) * W) * 4;  // wave-uniform
-                const int l0 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)vo, so, 0);
-                const int l1 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)vo, so + 4, 0);
-                const int hi = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)vo, so + 8, 0);
-                patch[(ci * K + kx) * K + 0] = __builtin_bit_cast(float, l0);
-                patch[(ci * K + kx) * K + 1] = __builtin_bit_cast(float, l1);
-                patch[(ci * K + kx) * K + 2] = __builtin_bit_cast(float, hi);
+                const float* rowp = x + (size_t)((b * CI + ci) * H + kx) * W;  // wave-uniform
+                const f3u pr = *(const f3u*)(rowp + vo);
+                patch[(ci * K + kx) * K + 0] = pr.x;
+                patch[(ci * K + kx) * K + 1] = pr.y;
+                patch[(ci * K + kx) * K + 2] = pr.z;
             }
         v2f acc[CO / 2];
 #pragma unroll
