@@ -31,6 +31,7 @@ SIGNATURES = {
     "cnn_amd_last_error": (C.c_char_p, []),
     "cnn_amd_device_arch": (C.c_char_p, []),
     "cnn_amd_kernel_timing_enable": (C.c_int, [C.c_int, C.c_char_p]),
+    "cnn_amd_kernel_timing_sampling": (C.c_int, [C.c_int]),
     "cnn_amd_kernel_timing_report": (C.c_longlong, [C.c_char_p, C.c_size_t]),
     "cnn_conv2d_out_dim": (C.c_int, [C.c_int] * 4),
     "cnn_maxpool2d_out_dim": (C.c_int, [C.c_int] * 3),
@@ -526,8 +527,9 @@ def softmax_xent(logits, labels, want_probs=True):
     return probs, delta, loss
 
 
-def kernel_timing(mode, filter_key=""):
-    """0 = off, 1 = every kernel, 2 = only keys containing filter_key"""
+def kernel_timing(mode, filter_key="", every=1):
+    """0 = off, 1 = every kernel, 2 = only keys containing filter_key (and of those only every `every`-th launch)"""
+    check(load().cnn_amd_kernel_timing_sampling(int(every)), "cnn_amd_kernel_timing_sampling")
     check(load().cnn_amd_kernel_timing_enable(int(mode), filter_key.encode()), "cnn_amd_kernel_timing_enable")
 
 

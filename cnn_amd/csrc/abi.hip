@@ -28,6 +28,8 @@ struct KRecord {
 };
 struct KTimer {
     int mode = 0;
+    int every = 1;       // mode 2: bracket only every `every`-th matching launch (an event pair costs the stream two ~6 us bubbles)
+    long long seen = 0;
     std::string filter;
     std::vector<KRecord> recs;
     bool open = false;
@@ -52,6 +54,7 @@ void ktimer_begin(hipStream_t s, const char* kernel, const char* fmt, ...) {
     std::lock_guard<std::mutex> lk(t.mu);
     t.open = false;
     if (t.mode == 2 && key.find(t.filter) == std::string::npos) return;
+    if (t.mode == 2 && (t.seen++ % t.every) != 0) return;
     KRecord r;
     r.key = key;
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
@@ -104,6 +107,15 @@ int cnn_amd_kernel_timing_enable(int mode, const char* filter) {
     CNN_REQUIRE(mode >= 0 && mode <= 2, "cnn_amd_kernel_timing_enable: mode %d", mode);
     t.mode = mode;
     t.filter = filter ? filter : "";
+    t.seen = 0;
+    return CNN_AMD_OK;
+}
+
+int cnn_amd_kernel_timing_sampling(int every) {
+    KTimer& t = kt();
+    std::lock_guard<std::mutex> lk(t.mu);
+    CNN_REQUIRE(every >= 1, "cnn_amd_kernel_timing_sampling: every = %d", every);
+    t.every = every;
     return CNN_AMD_OK;
 }
 

@@ -213,6 +213,8 @@ class AlexNetHip:
         capi.linear_backward(self.relu_out[3].view(self.B, self.lin_in), delta, self.lin_w(), div, self.lin_w(g),
                              self.lin_b(g), self.d_lin, relu_below=fbr)
         cur = self.d_lin.view(self.relu_out[3].shape)
+        if self._dx0_release >= 4:  # (tuning) release the deferred conv1 data gradient here: it overlaps conv 4-3 data gradients
+            self._launch_pending_dx0(gated=True)
         for l in (3, 2, 1, 0):
             if l == 1 and self.fuse_pool and self.defer_dx0:
                 self.flush()  # the previous step's deferred dgrad reads d_conv[1] (= d pool_out), which is rewritten next

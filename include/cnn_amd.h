@@ -40,6 +40,9 @@ const char* cnn_amd_device_arch(void);
 /* ---- measurement: per-kernel durations from HIP events recorded on the launch stream --------------------- */
 /* mode 0 = off, 1 = time every kernel launch, 2 = only launches whose "<kernel>|<geometry>" key contains filter */
 int cnn_amd_kernel_timing_enable(int mode, const char* filter);
+/* mode 2 only: bracket every `every`-th matching launch instead of each one (the two event records around a kernel leave
+ * ~6 us bubbles on its stream); the report then counts the sampled launches. */
+int cnn_amd_kernel_timing_sampling(int every);
 /* device-synchronises; writes "<kernel>|<geometry>\t<launches>\t<total_ms>\n" lines (host buffer) and clears
  * the records; returns bytes needed (records are kept when cap is too small), -1 on error */
 long long cnn_amd_kernel_timing_report(char* buf, size_t cap);
