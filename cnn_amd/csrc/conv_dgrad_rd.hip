@@ -44,7 +44,8 @@ struct Taps {  // the 9 filter taps of one (co, ci)
 
 struct DgRdParams {
     const float* dy;
-    const float* w;     // [Co][Ci][3][3] (the prepared buffer of this kernel is a verbatim copy)
+    const float* w;     // [Co][Ci][3][3], or with tr != 0 the prepared transposed copy [Co][9][Ci]
+    int tr;
     const float* relu_below;  // nullable: dx = (relu_below <= 0) ? 0 : dx
     float* dx;
     int B, Ci, H, W, Ho, Wo, U, V, UV;
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_rd_s2_kernel(const DgRdPar
     const int ci0 = blockIdx.y * 32;
     // this lane's filter column: w[kg*CH + .][ci0 + n][.]  (a lane beyond Ci reads channel ci0: its rows are not stored)
     const unsigned wlane = (unsigned)((kg * CH * p.Ci + ci0 + (ci0 + n < p.Ci ? n : 0)) * 9);
+    const unsigned wlane_tr = (unsigned)(kg * CH * p.Ci * 9 + ci0 + (ci0 + n < p.Ci ? n : 0));
     const unsigned plane = (unsigned)(p.Ho * p.Wo);
     const int tstep = gridDim.x * NW;
 
@@ -121,10 +123,19 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_rd_s2_kernel(const DgRdPar
 #pragma unroll
         for (int uu = 0; uu < UC; ++uu) {
             const float* base = p.w + (size_t)(g * UC + uu) * p.Ci * 9;  // wave-uniform
-            const f4u qa = *(const f4u*)(base + wlane), qb = *(const f4u*)(base + wlane + 4);
-            a[uu].a = v4f{qa.x, qa.y, qa.z, qa.w};
-            a[uu].b = v4f{qb.x, qb.y, qb.z, qb.w};
-            a[uu].c = base[wlane + 8];
+            if (p.tr) {  // prepared [co][tap][ci]: the 32 lanes of a k-slot read 32 consecutive floats per tap
+                float t[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) t[k] = base[wlane_tr + k * p.Ci];
+                a[uu].a = v4f{t[0], t[1], t[2], t[3]};
+                a[uu].b = v4f{t[4], t[5], t[6], t[7]};
+                a[uu].c = t[8];
+            } else {
+                const f4u qa = *(const f4u*)(base + wlane), qb = *(const f4u*)(base + wlane + 4);
+                a[uu].a = v4f{qa.x, qa.y, qa.z, qa.w};
+                a[uu].b = v4f{qb.x, qb.y, qb.z, qb.w};
+                a[uu].c = base[wlane + 8];
+            }
         }
     };
     // (two selects per value; a 3-way code here made hipcc emit a divergent switch -- ~40 branches per channel)
@@ -300,12 +311,21 @@ struct DgRdPrepBatch {
     DgRdPrepJob job[6];
 };
 
-// the prepared buffer of this kernel is a verbatim copy of the filters (they are read in the reference's own layout)
-__global__ __launch_bounds__(256) void dgrad_rd_prepare_kernel(const DgRdPrepBatch pb) {
+// prepared buffer: img[(co*9 + tap)*Ci + ci] = w[(co*Ci + ci)*9 + tap]  (CNN_AMD_DGRAD_RD_NOTR: a verbatim copy)
+__global__ __launch_bounds__(256) void dgrad_rd_prepare_kernel(const DgRdPrepBatch pb, int tr) {
     const DgRdPrepJob j = pb.job[blockIdx.y];
     const int total = j.Co * j.Ci * 9;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) j.img[i] = j.w[i];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        if (tr) {
+            const int ci = i % j.Ci, r = i / j.Ci, tap = r % 9, co = r / 9;
+            j.img[i] = j.w[((size_t)co * j.Ci + ci) * 9 + tap];
+        } else {
+            j.img[i] = j.w[i];
+        }
+    }
 }
+
+inline int prepared_transposed() { return getenv("CNN_AMD_DGRAD_RD_NOTR") ? 0 : 1; }
 
 }  // namespace
 
@@ -338,7 +358,7 @@ int dgrad_rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* con
     if (jobs) {
         unsigned gx = (unsigned)((most + 255) / 256);
         if (gx > 512) gx = 512;
-        CNN_KLAUNCH(s, "dgrad_rd_prepare", (dgrad_rd_prepare_kernel<<<dim3(gx, jobs), 256, 0, s>>>(pb)), "jobs=%d", jobs);
+        CNN_KLAUNCH(s, "dgrad_rd_prepare", (dgrad_rd_prepare_kernel<<<dim3(gx, jobs), 256, 0, s>>>(pb, prepared_transposed())), "jobs=%d", jobs);
     }
     return CNN_AMD_OK;
 }
@@ -348,7 +368,7 @@ int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const floa
                            float* dx, hipStream_t s) {
     DgRdPlan pl;
     if (!make_plan(d, &pl)) return fail(CNN_AMD_E_BADARG, "conv_dgrad_rd: geometry not covered");
-    pl.p.dy = dy; pl.p.w = w ? w : img; pl.p.relu_below = relu_below; pl.p.dx = dx;
+    pl.p.dy = dy; pl.p.w = w ? w : img; pl.p.tr = w ? 0 : prepared_transposed(); pl.p.relu_below = relu_below; pl.p.dx = dx;
     char name[64];
     snprintf(name, sizeof(name), "conv_dgrad_rd<2,%d>/dgrad%s", d->Co, relu_below ? "+relu" : "");
     if (d->Co == 32) return launch<32, 4>(pl, s, name, d);
