@@ -302,29 +302,6 @@ int launch(const DgRdPlan& pl, hipStream_t s, const char* name, const cnn_conv2d
     return CNN_AMD_OK;
 }
 
-struct DgRdPrepJob {
-    const float* w;
-    float* img;
-    int Co, Ci, cgroups;
-};
-struct DgRdPrepBatch {
-    DgRdPrepJob job[6];
-};
-
-// prepared buffer: img[(co*9 + tap)*Ci + ci] = w[(co*Ci + ci)*9 + tap]  (CNN_AMD_DGRAD_RD_NOTR: a verbatim copy)
-__global__ __launch_bounds__(256) void dgrad_rd_prepare_kernel(const DgRdPrepBatch pb, int tr) {
-    const DgRdPrepJob j = pb.job[blockIdx.y];
-    const int total = j.Co * j.Ci * 9;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        if (tr) {
-            const int ci = i % j.Ci, r = i / j.Ci, tap = r % 9, co = r / 9;
-            j.img[i] = j.w[((size_t)co * j.Ci + ci) * 9 + tap];
-        } else {
-            j.img[i] = j.w[i];
-        }
-    }
-}
-
 inline int prepared_transposed() { return getenv("CNN_AMD_DGRAD_RD_NOTR") ? 0 : 1; }
 
 }  // namespace
@@ -341,26 +318,14 @@ size_t dgrad_rd_prepared_floats(const cnn_conv2d_desc* d) {
     return make_plan(d, &pl) ? pl.img_floats : 0;
 }
 
-// prepares every layer of the batch this file covers (one launch); sets their bits in *done
-int dgrad_rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, void* const* dgrad, hipStream_t s,
-                           unsigned* done) {
-    DgRdPrepBatch pb;
-    int jobs = 0;
-    size_t most = 0;
-    for (int i = 0; i < n && i < 6; ++i) {
-        DgRdPlan pl;
-        if (!dgrad || !dgrad[i] || (*done >> i & 1u) || !make_plan(&descs[i], &pl)) continue;
-        CNN_REQUIRE(w[i] != nullptr, "cnn_conv2d_prepare_filters: filters of layer %d are null", i);
-        pb.job[jobs++] = DgRdPrepJob{w[i], (float*)dgrad[i], descs[i].Co, descs[i].Ci, pl.cgroups};
-        if (pl.img_floats > most) most = pl.img_floats;
-        *done |= 1u << i;
-    }
-    if (jobs) {
-        unsigned gx = (unsigned)((most + 255) / 256);
-        if (gx > 512) gx = 512;
-        CNN_KLAUNCH(s, "dgrad_rd_prepare", (dgrad_rd_prepare_kernel<<<dim3(gx, jobs), 256, 0, s>>>(pb, prepared_transposed())), "jobs=%d", jobs);
-    }
-    return CNN_AMD_OK;
+// prepared buffer of layer d: a re-ordered copy of the filters, tr = 1: img[(co*9 + tap)*Ci + ci] = w[(co*Ci + ci)*9 + tap],
+// tr = 0: verbatim.  The copy itself runs inside conv_fwd_rd.hip's prepare kernel (one launch for both kernel families).
+// returns 0 when the layer is not covered
+int dgrad_rd_prepare_layout(const cnn_conv2d_desc* d, int* transposed) {
+    DgRdPlan pl;
+    if (!make_plan(d, &pl)) return 0;
+    *transposed = prepared_transposed();
+    return 1;
 }
 
 // w == nullptr: `img` holds the prepared images

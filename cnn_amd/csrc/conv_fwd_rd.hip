@@ -270,18 +270,32 @@ int launch(const FwdRdPlan& pl, hipStream_t s, const char* name, const cnn_conv2
 }
 
 struct FwdRdPrepJob {
+    int kind;  // 0: forward LDS image of this file | 1: data-gradient filter copy of conv_dgrad_rd.hip (transposed or verbatim)
     const float* w;
     const float* bias;
     float* img;
-    int Co, Ci, cb, img_floats, cgroups;
+    int Co, Ci, cb, img_floats, cgroups, tr;
 };
 struct FwdRdPrepBatch {
-    FwdRdPrepJob job[6];
+    FwdRdPrepJob job[12];
 };
 
-// one workgroup column per job: img[g][k*CBP + c] = w[g*cb + c][k], then the group's bias
+// one workgroup column per job.  kind 0: img[g][k*CBP + c] = w[g*cb + c][k], then the group's bias;
+// kind 1: img[(co*9 + tap)*Ci + ci] = w[(co*Ci + ci)*9 + tap] (tr) or a verbatim copy
 __global__ __launch_bounds__(256) void fwd_rd_prepare_kernel(const FwdRdPrepBatch pb) {
     const FwdRdPrepJob j = pb.job[blockIdx.y];
+    if (j.kind == 1) {
+        const int total = j.Co * j.Ci * 9;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+            if (j.tr) {
+                const int ci = i % j.Ci, r = i / j.Ci, tap = r % 9, co = r / 9;
+                j.img[i] = j.w[((size_t)co * j.Ci + ci) * 9 + tap];
+            } else {
+                j.img[i] = j.w[i];
+            }
+        }
+        return;
+    }
     const int K = j.Ci * 9, cbp = j.cb + 1, total = j.cgroups * j.img_floats;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int g = i / j.img_floats, o = i - g * j.img_floats;
@@ -312,26 +326,40 @@ size_t fwd_rd_prepared_floats(const cnn_conv2d_desc* d) {
     return make_plan(d, &pl) ? pl.img_floats * pl.cgroups : 0;
 }
 
-// prepares every layer of the batch this file covers (one launch); sets their bits in *done
-int fwd_rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, const float* const* bias, void* const* fwd,
-                         hipStream_t s, unsigned* done) {
+int dgrad_rd_prepare_layout(const cnn_conv2d_desc* d, int* transposed);  // conv_dgrad_rd.hip
+
+// prepares, in ONE launch, the forward images of every layer this file covers and the data-gradient filter copies of the
+// layers conv_dgrad_rd.hip covers; sets their bits in *fdone / *ddone
+int rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, const float* const* bias, void* const* fwd,
+                     void* const* dgrad, hipStream_t s, unsigned* fdone, unsigned* ddone) {
     FwdRdPrepBatch pb;
     int jobs = 0;
     size_t most = 0;
     for (int i = 0; i < n && i < 6; ++i) {
         FwdRdPlan pl;
-        if (!fwd || !fwd[i] || (*done >> i & 1u) || !make_plan(&descs[i], &pl)) continue;
-        CNN_REQUIRE(w[i] && bias[i], "cnn_conv2d_prepare_filters: filters / bias of layer %d are null", i);
-        FwdRdPrepJob& j = pb.job[jobs++];
-        j.w = w[i]; j.bias = bias[i]; j.img = (float*)fwd[i];
-        j.Co = descs[i].Co; j.Ci = descs[i].Ci; j.cb = pl.mt * 32; j.img_floats = (int)pl.img_floats; j.cgroups = pl.cgroups;
-        if (pl.img_floats * pl.cgroups > most) most = pl.img_floats * pl.cgroups;
-        *done |= 1u << i;
+        if (fwd && fwd[i] && !(*fdone >> i & 1u) && make_plan(&descs[i], &pl)) {
+            CNN_REQUIRE(w[i] && bias[i], "cnn_conv2d_prepare_filters: filters / bias of layer %d are null", i);
+            FwdRdPrepJob& j = pb.job[jobs++];
+            j.kind = 0; j.w = w[i]; j.bias = bias[i]; j.img = (float*)fwd[i];
+            j.Co = descs[i].Co; j.Ci = descs[i].Ci; j.cb = pl.mt * 32; j.img_floats = (int)pl.img_floats; j.cgroups = pl.cgroups; j.tr = 0;
+            if (pl.img_floats * pl.cgroups > most) most = pl.img_floats * pl.cgroups;
+            *fdone |= 1u << i;
+        }
+        int tr = 0;
+        if (dgrad && dgrad[i] && !(*ddone >> i & 1u) && dgrad_rd_prepare_layout(&descs[i], &tr)) {
+            CNN_REQUIRE(w[i] != nullptr, "cnn_conv2d_prepare_filters: filters of layer %d are null", i);
+            FwdRdPrepJob& j = pb.job[jobs++];
+            j.kind = 1; j.w = w[i]; j.bias = nullptr; j.img = (float*)dgrad[i];
+            j.Co = descs[i].Co; j.Ci = descs[i].Ci; j.cb = 0; j.img_floats = 0; j.cgroups = 0; j.tr = tr;
+            const size_t nf = (size_t)descs[i].Co * descs[i].Ci * 9;
+            if (nf > most) most = nf;
+            *ddone |= 1u << i;
+        }
     }
     if (jobs) {
         unsigned gx = (unsigned)((most + 255) / 256);
         if (gx > 512) gx = 512;
-        CNN_KLAUNCH(s, "fwd_rd_prepare", (fwd_rd_prepare_kernel<<<dim3(gx, jobs), 256, 0, s>>>(pb)), "jobs=%d", jobs);
+        CNN_KLAUNCH(s, "rd_prepare", (fwd_rd_prepare_kernel<<<dim3(gx, jobs), 256, 0, s>>>(pb)), "jobs=%d", jobs);
     }
     return CNN_AMD_OK;
 }

@@ -1259,14 +1259,12 @@ int direct_conv_dgrad_pooled(const cnn_conv2d_desc* d, const float* dpool, const
                              float* dx, void* ws, size_t ws_bytes, hipStream_t s, bool prepared);
 bool dgrad_rd_supported(const cnn_conv2d_desc* d);  // conv_dgrad_rd.hip: register-direct data gradient, 3x3 stride 2, Co 64 / 128
 size_t dgrad_rd_prepared_floats(const cnn_conv2d_desc* d);
-int dgrad_rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, void* const* dgrad, hipStream_t s,
-                           unsigned* done);
 int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* img, const float* relu_below,
                            float* dx, hipStream_t s);
 bool fwd_rd_supported(const cnn_conv2d_desc* d);  // conv_fwd_rd.hip: register-direct forward of the mid-size 3x3 layers
 size_t fwd_rd_prepared_floats(const cnn_conv2d_desc* d);
-int fwd_rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, const float* const* bias, void* const* fwd,
-                         hipStream_t s, unsigned* done);
+int rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, const float* const* bias, void* const* fwd,
+                     void* const* dgrad, hipStream_t s, unsigned* fdone, unsigned* ddone);
 int fwd_rd_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* img, const float* bias, float* y,
                    float* y_relu, hipStream_t s);
 bool pk_dgrad_s2_supported(const cnn_conv2d_desc* d);  // conv_direct.hip: packed VALU dgrad for small stride-2 layers
@@ -1384,8 +1382,7 @@ int cnn_conv2d_prepare_filters(int n, const cnn_conv2d_desc* descs, const float*
     hipStream_t s = as_stream(stream);
     unsigned fdone = 0, ddone = 0;
     if (int rc = direct_prepare_batch(n, descs, w, bias, fwd, dgrad, s, &fdone, &ddone)) return rc;
-    if (int rc = fwd_rd_prepare_batch(n, descs, w, bias, fwd, s, &fdone)) return rc;
-    if (int rc = dgrad_rd_prepare_batch(n, descs, w, dgrad, s, &ddone)) return rc;
+    if (int rc = rd_prepare_batch(n, descs, w, bias, fwd, dgrad, s, &fdone, &ddone)) return rc;
     PrepBatch pb;
     pb.n = 0;
     long long most = 0;
