@@ -162,7 +162,7 @@ def conv_ns_bench(torch, capi, reps=5):
     out = {"shape": "B256 64->128 k3 s1 112x112->110x110", "gflop": round(flops / 1e9, 2), "peak_tflops": PEAK_MFMA_F32_TFLOPS}
     for key, (cnt, ms) in rep.items():
         name = key.split("|")[0]
-        if name.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel", "wgrad_rd", "conv_fwd_rd")):
+        if name.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel", "wgrad_rd", "conv_fwd_rd", "conv_dgrad_rd")):
             tf = flops / (ms / 1e3 / cnt) / 1e12
             tag = "fwd" if name.endswith(("/fwd", "/fwd+relu")) else ("dgrad" if name.endswith("/dgrad") else "wgrad")
             out[tag] = {"kernel": name, "avg_ms": round(ms / cnt, 4), "tflops": round(tf, 2),

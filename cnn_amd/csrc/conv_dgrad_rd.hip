@@ -252,16 +252,165 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_rd_s2_kernel(const DgRdPar
     }
 }
 
+// ---- stride 1 (the north-star shape): dx[ci][h][w] = sum_{co,kx,ky} dy[co][h-kx][w-ky] * w[co][ci][kx][ky] --------------------
+// One class, nine taps per dy channel: lane (pixel, kg) loads three 12-byte windows (rows h, h-1, h-2; columns w-2 .. w,
+// clamped into the row at the borders) that feed the 9 MFMA steps of MT output tiles; lane (ci, kg) reads the nine taps of
+// each tile from the prepared [co][tap][ci] copy (32 consecutive floats per k-slot) or, unprepared, from w itself.
+struct __attribute__((packed, aligned(4))) f3u {
+    float x, y, z;
+};
+template <int CO, int MT, int NB>
+__global__ __launch_bounds__(256) void conv_dgrad_rd_s1_kernel(const DgRdParams p) {
+    constexpr int CH = CO / 2, G = CH;  // one dy channel per pipeline group
+    static_assert(G % NB == 0, "ring index must line up from tile to tile");
+    const int lane = threadIdx.x & 63, n = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ci0 = blockIdx.y * 32 * MT;
+    unsigned wl[MT], wl_tr[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int c = ci0 + mt * 32 + n < p.Ci ? ci0 + mt * 32 + n : ci0;
+        wl[mt] = (unsigned)((kg * CH * p.Ci + c) * 9);
+        wl_tr[mt] = (unsigned)(kg * CH * p.Ci * 9 + c);
+    }
+    const unsigned plane = (unsigned)(p.Ho * p.Wo);
+    const int tstep = gridDim.x * 4;
+    struct Loc {
+        unsigned o[3];     // element offsets into dy (channel kg*CH): rows h, h-1, h-2 (clamped), window start column
+        bool isy[3], isz[3], ok[3][3];  // column w-ky is element y / z of the window; D[kx][ky] exists
+        unsigned xo;       // element offset of dx[b][ci0][h][w]
+        bool live;
+    };
+    auto locate = [&](int tile, Loc& L) {
+        const int pi = tile * 32 + n;
+        L.live = pi < p.pixels;
+        const int pic = L.live ? pi : p.pixels - 1;
+        const int b = fdiv(pic, p.m_uv, p.UV), rem = pic - b * p.UV;  // UV = H*W, V = W here
+        const int h = fdiv(rem, p.m_v, p.V), w = rem - h * p.V;
+        int cs = w - 2;
+        cs = cs < 0 ? 0 : (cs > p.Wo - 3 ? p.Wo - 3 : cs);
+        bool cok[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int e = w - ky - cs;  // element of the window that holds column w - ky
+            cok[ky] = w - ky >= 0 && w - ky < p.Wo;
+            L.isy[ky] = e == 1;
+            L.isz[ky] = e == 2;
+        }
+        const unsigned cb = (unsigned)((b * CO + kg * CH) * (int)plane);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int r = h - kx;
+            const bool rok = L.live && r >= 0 && r < p.Ho;
+            const int rc = r < 0 ? 0 : (r >= p.Ho ? p.Ho - 1 : r);
+            L.o[kx] = cb + (unsigned)(rc * p.Wo + cs);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) L.ok[kx][ky] = rok && cok[ky];
+        }
+        L.xo = (unsigned)((b * p.Ci + ci0) * p.UV + rem);
+    };
+    struct Grp {
+        f3u win[3];
+        float a[MT][9];
+    };
+    auto load_group = [&](Grp& g, int co_i, const unsigned (&o)[3]) {
+        const float* base = p.dy + (size_t)co_i * plane;  // wave-uniform
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) g.win[kx] = *(const f3u*)(base + o[kx]);
+        const float* wb = p.w + (size_t)co_i * p.Ci * 9;  // wave-uniform
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (p.tr) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) g.a[mt][k] = wb[wl_tr[mt] + k * p.Ci];
+            } else {
+                const f4u qa = *(const f4u*)(wb + wl[mt]), qb = *(const f4u*)(wb + wl[mt] + 4);
+                g.a[mt][0] = qa.x; g.a[mt][1] = qa.y; g.a[mt][2] = qa.z; g.a[mt][3] = qa.w;
+                g.a[mt][4] = qb.x; g.a[mt][5] = qb.y; g.a[mt][6] = qb.z; g.a[mt][7] = qb.w;
+                g.a[mt][8] = wb[wl[mt] + 8];
+            }
+        }
+    };
+
+    int tile = blockIdx.x * 4 + wave;
+    if (tile >= p.tiles) return;
+    Loc cur, nxt;
+    locate(tile, cur);
+    nxt = cur;
+    Grp ring[NB];
+    {
+        if (tile + tstep < p.tiles) locate(tile + tstep, nxt);
+#pragma unroll
+        for (int g = 0; g < NB - 1; ++g) load_group(ring[g], g, cur.o);
+    }
+    for (; tile < p.tiles; tile += tstep) {
+        const bool more = tile + tstep < p.tiles;
+        if (more) locate(tile + tstep, nxt);
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+#pragma unroll 1
+        for (int g0 = 0; g0 < G; g0 += NB) {
+#pragma unroll
+            for (int ri = 0; ri < NB; ++ri) {
+                const int g = g0 + ri, gp = g + NB - 1, rp = (ri + NB - 1) % NB;
+                const bool wrap = gp >= G;
+                const unsigned oo[3] = {wrap ? nxt.o[0] : cur.o[0], wrap ? nxt.o[1] : cur.o[1], wrap ? nxt.o[2] : cur.o[2]};
+                load_group(ring[rp], wrap ? gp - G : gp, oo);
+                RD_PIPE_FENCE(ring[ri].a[0][0]);
+                (void)g;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const f3u v = ring[ri].win[kx];
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        float d = cur.isz[ky] ? v.z : (cur.isy[ky] ? v.y : v.x);
+                        d = cur.ok[kx][ky] ? d : 0.f;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[ri].a[mt][kx * 3 + ky], d, acc[mt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (cur.live) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float m[16];
+                if (p.relu_below) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rowl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                        m[r] = p.relu_below[(size_t)cur.xo + (size_t)(ci0 + rowl < p.Ci ? rowl : 0) * p.UV];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rowl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    if (ci0 + rowl >= p.Ci) continue;
+                    float v = acc[mt][r];
+                    if (p.relu_below) v = (m[r] <= 0.f) ? 0.f : v;
+                    p.dx[(size_t)cur.xo + (size_t)rowl * p.UV] = v;
+                }
+            }
+        }
+        cur = nxt;
+    }
+}
+
 inline unsigned magic_of(int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
 
 struct DgRdPlan {
     DgRdParams p;
-    int co, nw, cgroups, blocks_x;
+    int co, nw, cgroups, blocks_x, mt;
     size_t lds, img_floats;
 };
 
 bool make_plan(const cnn_conv2d_desc* d, DgRdPlan* pl) {
-    if (d->k != 3 || d->pad != 0 || d->s != 2) return false;
+    if (d->k != 3 || d->pad != 0 || (d->s != 2 && d->s != 1)) return false;
+    if (d->s == 1 && ((d->Co != 64 && d->Co != 128) || d->Ci % 32 != 0)) return false;
     if ((d->Co != 32 && d->Co != 64 && d->Co != 128) || d->Ci % 16 != 0) return false;  // (Ci = 16: half of the 32 MFMA rows idle)
     // Co = 32 / Ci = 16 (conv_layer_2): measured 117 us against 95 us for the packed VALU kernel -> opt-in only
     if (d->Co == 32 && !(getenv("CNN_AMD_DGRAD_RD32") && atoi(getenv("CNN_AMD_DGRAD_RD32")) != 0)) return false;
@@ -269,10 +418,12 @@ bool make_plan(const cnn_conv2d_desc* d, DgRdPlan* pl) {
         if (atoi(e) == 0) return false;
     DgRdParams& p = pl->p;
     p.B = d->B; p.Ci = d->Ci; p.H = d->H; p.W = d->W;
-    p.Ho = cnn_conv2d_out_dim(d->H, 3, 2, 0);
-    p.Wo = cnn_conv2d_out_dim(d->W, 3, 2, 0);
-    if (p.Ho < 1 || p.Wo < 2) return false;
-    p.U = (d->H + 1) / 2; p.V = (d->W + 1) / 2; p.UV = p.U * p.V;
+    p.Ho = cnn_conv2d_out_dim(d->H, 3, d->s, 0);
+    p.Wo = cnn_conv2d_out_dim(d->W, 3, d->s, 0);
+    if (p.Ho < 1 || p.Wo < (d->s == 1 ? 3 : 2)) return false;
+    if (d->s == 1) { p.U = d->H; p.V = d->W; }          // every dx pixel is a grid pixel
+    else { p.U = (d->H + 1) / 2; p.V = (d->W + 1) / 2; }
+    p.UV = p.U * p.V;
     const long long pixels = (long long)d->B * p.UV;
     if (pixels >= (1ll << 30) || (long long)d->B * d->Ci * d->H * d->W >= (1ll << 31) || (long long)d->B * d->Co * p.Ho * p.Wo >= (1ll << 31))
         return false;
@@ -282,7 +433,9 @@ bool make_plan(const cnn_conv2d_desc* d, DgRdPlan* pl) {
     p.m_v = magic_of(p.V);
     p.dbg = getenv("CNN_AMD_DGRAD_RD_DBG") ? atoi(getenv("CNN_AMD_DGRAD_RD_DBG")) : 0;
     pl->co = d->Co;
-    pl->cgroups = (d->Ci + 31) / 32;
+    pl->mt = (d->s == 1 && d->Ci % 64 == 0) ? 2 : 1;  // stride 1: two 32-channel tiles per wave share the dy windows
+    if (const char* e = getenv("CNN_AMD_DGRAD_RD_MT")) pl->mt = (atoi(e) == 2 && d->s == 1 && d->Ci % 64 == 0) ? 2 : 1;
+    pl->cgroups = (d->Ci + 32 * pl->mt - 1) / (32 * pl->mt);
     pl->img_floats = (size_t)d->Co * d->Ci * 9;  // (prepared buffer = a verbatim copy of w)
     pl->lds = 0;
     pl->nw = 4;
@@ -328,14 +481,39 @@ int dgrad_rd_prepare_layout(const cnn_conv2d_desc* d, int* transposed) {
     return 1;
 }
 
-// w == nullptr: `img` holds the prepared images
+// [co][ci][tap] -> [co][tap][ci] into the caller's workspace (the unprepared entry points)
+__global__ __launch_bounds__(256) void dgrad_rd_transpose_kernel(const float* __restrict__ w, float* __restrict__ img, int Co, int Ci) {
+    const int total = Co * Ci * 9;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int ci = i % Ci, r = i / Ci, tap = r % 9, co = r / 9;
+        img[i] = w[((size_t)co * Ci + ci) * 9 + tap];
+    }
+}
+
+// w == nullptr: `img` holds the prepared filters; otherwise `ws` (>= Co*Ci*9 floats, may be null) receives the transposed copy
 int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* img, const float* relu_below,
-                           float* dx, hipStream_t s) {
+                           float* dx, void* ws, size_t ws_bytes, hipStream_t s) {
     DgRdPlan pl;
     if (!make_plan(d, &pl)) return fail(CNN_AMD_E_BADARG, "conv_dgrad_rd: geometry not covered");
     pl.p.dy = dy; pl.p.w = w ? w : img; pl.p.tr = w ? 0 : prepared_transposed(); pl.p.relu_below = relu_below; pl.p.dx = dx;
+    if (w && ws && ws_bytes >= pl.img_floats * sizeof(float) && prepared_transposed()) {
+        const unsigned gx = (unsigned)((pl.img_floats + 255) / 256);
+        CNN_KLAUNCH(s, "dgrad_rd_transpose", (dgrad_rd_transpose_kernel<<<gx > 512 ? 512 : gx, 256, 0, s>>>(w, (float*)ws, d->Co, d->Ci)),
+                    "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad);
+        pl.p.w = (const float*)ws;
+        pl.p.tr = 1;
+    }
     char name[64];
     snprintf(name, sizeof(name), "conv_dgrad_rd<2,%d>/dgrad%s", d->Co, relu_below ? "+relu" : "");
+    if (d->s == 1) {
+        const dim3 grid(pl.blocks_x, pl.cgroups);
+        snprintf(name, sizeof(name), "conv_dgrad_rd<1,%d,%d>/dgrad%s", d->Co, pl.mt, relu_below ? "+relu" : "");
+#define S1(CO_, MT_) CNN_KLAUNCH(s, name, (conv_dgrad_rd_s1_kernel<CO_, MT_, 4><<<grid, 256, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", \
+                                 d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad)
+        if (d->Co == 64 && pl.mt == 2) S1(64, 2); else if (d->Co == 64) S1(64, 1); else if (pl.mt == 2) S1(128, 2); else S1(128, 1);
+#undef S1
+        return CNN_AMD_OK;
+    }
     if (d->Co == 32) return launch<32, 4>(pl, s, name, d);
     if (d->Co == 64) return launch<64, 4>(pl, s, name, d);
     return launch<128, 4>(pl, s, name, d);

@@ -1260,7 +1260,7 @@ int direct_conv_dgrad_pooled(const cnn_conv2d_desc* d, const float* dpool, const
 bool dgrad_rd_supported(const cnn_conv2d_desc* d);  // conv_dgrad_rd.hip: register-direct data gradient, 3x3 stride 2, Co 64 / 128
 size_t dgrad_rd_prepared_floats(const cnn_conv2d_desc* d);
 int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* img, const float* relu_below,
-                           float* dx, hipStream_t s);
+                           float* dx, void* ws, size_t ws_bytes, hipStream_t s);
 bool fwd_rd_supported(const cnn_conv2d_desc* d);  // conv_fwd_rd.hip: register-direct forward of the mid-size 3x3 layers
 size_t fwd_rd_prepared_floats(const cnn_conv2d_desc* d);
 int rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, const float* const* bias, void* const* fwd,
@@ -1310,7 +1310,8 @@ static int conv2d_backward_data_impl(const char* who, const cnn_conv2d_desc* d, 
         return cnn_relu_backward(relu_below, dx, (size_t)d->B * d->Ci * d->H * d->W, stream);
     }
     if (dgrad_rd_supported(d))
-        return dgrad_rd_backward_data(d, dy, prepared ? nullptr : w, prepared ? (const float*)ws : nullptr, relu_below, dx, as_stream(stream));
+        return dgrad_rd_backward_data(d, dy, prepared ? nullptr : w, prepared ? (const float*)ws : nullptr, relu_below, dx,
+                                      prepared ? nullptr : ws, prepared ? 0 : ws_bytes, as_stream(stream));
     if (pk_dgrad_s2_supported(d) && ws != nullptr && ws_bytes >= pk_dgrad_s2_workspace_floats(d) * sizeof(float))
         return pk_dgrad_s2(d, dy, w, dx, ws, as_stream(stream), prepared, relu_below);
     Plan pl;
