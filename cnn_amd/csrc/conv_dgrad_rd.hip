@@ -259,9 +259,9 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_rd_s2_kernel(const DgRdPar
 struct __attribute__((packed, aligned(4))) f3u {
     float x, y, z;
 };
-template <int CO, int MT, int NB>
+template <int CO, int MT, int NB, int UC>
 __global__ __launch_bounds__(256) void conv_dgrad_rd_s1_kernel(const DgRdParams p) {
-    constexpr int CH = CO / 2, G = CH;  // one dy channel per pipeline group
+    constexpr int CH = CO / 2, G = CH / UC;  // UC dy channels per pipeline group
     static_assert(G % NB == 0, "ring index must line up from tile to tile");
     const int lane = threadIdx.x & 63, n = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -310,24 +310,28 @@ __global__ __launch_bounds__(256) void conv_dgrad_rd_s1_kernel(const DgRdParams 
         L.xo = (unsigned)((b * p.Ci + ci0) * p.UV + rem);
     };
     struct Grp {
-        f3u win[3];
-        float a[MT][9];
+        f3u win[UC][3];
+        float a[UC][MT][9];
     };
-    auto load_group = [&](Grp& g, int co_i, const unsigned (&o)[3]) {
-        const float* base = p.dy + (size_t)co_i * plane;  // wave-uniform
+    auto load_group = [&](Grp& g, int gi, const unsigned (&o)[3]) {
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) g.win[kx] = *(const f3u*)(base + o[kx]);
-        const float* wb = p.w + (size_t)co_i * p.Ci * 9;  // wave-uniform
+        for (int u = 0; u < UC; ++u) {
+            const int co_i = gi * UC + u;
+            const float* base = p.dy + (size_t)co_i * plane;  // wave-uniform
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (p.tr) {
+            for (int kx = 0; kx < 3; ++kx) g.win[u][kx] = *(const f3u*)(base + o[kx]);
+            const float* wb = p.w + (size_t)co_i * p.Ci * 9;  // wave-uniform
 #pragma unroll
-                for (int k = 0; k < 9; ++k) g.a[mt][k] = wb[wl_tr[mt] + k * p.Ci];
-            } else {
-                const f4u qa = *(const f4u*)(wb + wl[mt]), qb = *(const f4u*)(wb + wl[mt] + 4);
-                g.a[mt][0] = qa.x; g.a[mt][1] = qa.y; g.a[mt][2] = qa.z; g.a[mt][3] = qa.w;
-                g.a[mt][4] = qb.x; g.a[mt][5] = qb.y; g.a[mt][6] = qb.z; g.a[mt][7] = qb.w;
-                g.a[mt][8] = wb[wl[mt] + 8];
+            for (int mt = 0; mt < MT; ++mt) {
+                if (p.tr) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) g.a[u][mt][k] = wb[wl_tr[mt] + k * p.Ci];
+                } else {
+                    const f4u qa = *(const f4u*)(wb + wl[mt]), qb = *(const f4u*)(wb + wl[mt] + 4);
+                    g.a[u][mt][0] = qa.x; g.a[u][mt][1] = qa.y; g.a[u][mt][2] = qa.z; g.a[u][mt][3] = qa.w;
+                    g.a[u][mt][4] = qb.x; g.a[u][mt][5] = qb.y; g.a[u][mt][6] = qb.z; g.a[u][mt][7] = qb.w;
+                    g.a[u][mt][8] = wb[wl[mt] + 8];
+                }
             }
         }
     };
@@ -359,20 +363,22 @@ __global__ __launch_bounds__(256) void conv_dgrad_rd_s1_kernel(const DgRdParams 
                 const bool wrap = gp >= G;
                 const unsigned oo[3] = {wrap ? nxt.o[0] : cur.o[0], wrap ? nxt.o[1] : cur.o[1], wrap ? nxt.o[2] : cur.o[2]};
                 load_group(ring[rp], wrap ? gp - G : gp, oo);
-                RD_PIPE_FENCE(ring[ri].a[0][0]);
+                RD_PIPE_FENCE(ring[ri].a[0][0][0]);
                 (void)g;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const f3u v = ring[ri].win[kx];
+                for (int u = 0; u < UC; ++u)
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        float d = cur.isz[ky] ? v.z : (cur.isy[ky] ? v.y : v.x);
-                        d = cur.ok[kx][ky] ? d : 0.f;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const f3u v = ring[ri].win[u][kx];
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[ri].a[mt][kx * 3 + ky], d, acc[mt], 0, 0, 0);
+                        for (int ky = 0; ky < 3; ++ky) {
+                            float d = cur.isz[ky] ? v.z : (cur.isy[ky] ? v.y : v.x);
+                            d = cur.ok[kx][ky] ? d : 0.f;
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+                                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[ri].a[u][mt][kx * 3 + ky], d, acc[mt], 0, 0, 0);
+                        }
                     }
-                }
             }
         }
         if (cur.live) {
@@ -508,9 +514,13 @@ int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const floa
     if (d->s == 1) {
         const dim3 grid(pl.blocks_x, pl.cgroups);
         snprintf(name, sizeof(name), "conv_dgrad_rd<1,%d,%d>/dgrad%s", d->Co, pl.mt, relu_below ? "+relu" : "");
-#define S1(CO_, MT_) CNN_KLAUNCH(s, name, (conv_dgrad_rd_s1_kernel<CO_, MT_, 4><<<grid, 256, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", \
-                                 d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad)
-        if (d->Co == 64 && pl.mt == 2) S1(64, 2); else if (d->Co == 64) S1(64, 1); else if (pl.mt == 2) S1(128, 2); else S1(128, 1);
+#define S1(CO_, MT_, UC_) CNN_KLAUNCH(s, name, (conv_dgrad_rd_s1_kernel<CO_, MT_, 4, UC_><<<grid, 256, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", \
+                                      d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad)
+        const int uc = getenv("CNN_AMD_DGRAD_RD_UC") ? atoi(getenv("CNN_AMD_DGRAD_RD_UC")) : 1;
+        if (d->Co == 64 && pl.mt == 2) S1(64, 2, 1);
+        else if (d->Co == 64) { if (uc == 2) S1(64, 1, 2); else S1(64, 1, 1); }
+        else if (pl.mt == 2) S1(128, 2, 1);
+        else { if (uc == 2) S1(128, 1, 2); else S1(128, 1, 1); }
 #undef S1
         return CNN_AMD_OK;
     }
