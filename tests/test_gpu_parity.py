@@ -684,3 +684,30 @@ def test_linear_backward_relu_fusion_is_bit_identical(T, B, n_in, n_out):
     gw1, gb1, dx1 = capi.linear_backward(xd, dyd, wd, float(B), relu_below=True)
     for a, b2 in ((gw0, gw1), (gb0, gb1), (dx0, dx1)):  # (bit patterns: the NaN in x makes a NaN gradient row)
         assert np.array_equal(host(a).view(np.uint32), host(b2).view(np.uint32))
+
+
+def test_pool_fused_net_full_batch_is_bit_identical(T):
+    """BASELINE configs[1] at its full batch (256 x 3 x 224 x 224): the bench configuration (pool-fused block, deferred conv1
+    data gradient, fused ReLU backward, register-direct kernels) against the kernel-per-layer sequence, bit for bit, and the
+    loss against a finite range (the oracle needs ~4 s per image batch of 16 here, so it is not run at this size)"""
+    from cnn_amd.pynet import AlexNetHip
+
+    B = 256
+    g = T.Generator(device="cuda").manual_seed(77)
+    x = T.rand((B, 3, 224, 224), generator=g, device="cuda")
+    labels = dev(T, (np.arange(B) % 3).astype(np.int32))
+    fused = AlexNetHip(B, 3, defer_input_grad=True, fuse_pool=True)
+    plain = AlexNetHip(B, 3, fuse=False)
+    p0 = normal_scaled(342, (fused.n_params,))
+    for n in (fused, plain):
+        n.load_params(p0)
+    for step in range(2):
+        for n in (fused, plain):
+            n.train_step(x, labels, 1e-3)
+            n.flush()
+        T.cuda.synchronize()
+        assert T.equal(fused.params, plain.params) and T.equal(fused.grads, plain.grads), step
+        assert T.equal(fused.pool_out, plain.pool_out) and T.equal(fused.pool_mask, plain.pool_mask)
+        assert T.equal(fused.d_conv[0], plain.d_conv[0]) and T.equal(fused.logits, plain.logits)
+    loss = float(fused.loss_sum.item()) / B
+    assert np.isfinite(loss) and 0.0 < loss < 20.0
