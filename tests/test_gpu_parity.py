@@ -330,6 +330,43 @@ def test_whole_net_train_steps_vs_oracle(T):
         assert_close(host(net.params), onet.params, REL_TOL, f"step{step} params")
 
 
+def test_bench_configuration_train_steps_vs_oracle(T):
+    """the configuration bench.py runs (pool-fused first block, deferred conv1 data gradient, fused ReLU backward,
+    prepared filters, register-direct kernels) against the oracle: two full train steps at B=4"""
+    from cnn_amd.pynet import AlexNetHip
+
+    B = 4
+    x = uniform01(22, (B, 3, 224, 224))
+    labels = (np.arange(B) % 3).astype(np.int32)
+    onet = O.Net(B, 3)
+    p0 = normal_scaled(23, (onet.n_params,))
+    onet.params[:] = p0
+    net = AlexNetHip(B, 3, defer_input_grad=True, fuse_pool=True)
+    assert net.fuse_pool and net.defer_dx0
+    net.load_params(p0)
+    xd, ld = dev(T, x), dev(T, labels)
+    for step in range(2):
+        net.train_step(xd, ld, 1e-3)
+        net.flush()
+        ologits = onet.forward(x)
+        oloss, odelta = O.cross_entropy_backward(O.softmax(ologits), labels)
+        onet.backward(odelta)
+        assert_close(host(net.pool_out), onet.pool_out(), REL_TOL, f"step{step} pool out")
+        assert np.mean(host(net.pool_mask) != onet.pool_mask()) < 1e-3
+        for l in (1, 2, 3):
+            assert_close(host(net.conv_out[l]), onet.conv_out(l), REL_TOL, f"step{step} conv{l} out")
+        assert_close(host(net.logits), ologits, REL_TOL, f"step{step} logits")
+        assert np.isclose(float(host(net.loss_sum)[0]) / B, oloss, rtol=1e-4)
+        assert_close(host(net.d_conv[0]), onet.d_conv(0), 2e-4, f"step{step} d_conv0")
+        for l in (2, 3):
+            assert_close(host(net.d_conv[l]), onet.d_conv(l), REL_TOL, f"step{step} d_conv{l}")
+        g, og = host(net.grads), onet.grads
+        for name, lo, hi in _param_slices(net):
+            assert_close(g[lo:hi], og[lo:hi], 2e-4, f"step{step} grad {name}")
+        onet.update(1e-3)
+        assert_close(host(net.params), onet.params, REL_TOL, f"step{step} params")
+
+
 def _param_slices(net):
     out = []
     for l in range(4):
