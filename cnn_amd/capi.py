@@ -39,6 +39,7 @@ SIGNATURES = {
     "cnn_conv2d_forward": (C.c_int, [_D, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_forward_relu": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_relu_maxpool2_supported": (C.c_int, [_D]),
+    "cnn_conv2d_relu_only_supported": (C.c_int, [_D]),
     "cnn_conv2d_relu_maxpool2_forward": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_relu_maxpool2_forward_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P]),
     "cnn_conv2d_backward_pooled2_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P, C.c_int]),
@@ -272,9 +273,14 @@ class Conv2d:
         n = int(self.lib.cnn_conv2d_prepared_bytes(C.byref(self.desc)))
         return torch.empty(n, dtype=torch.uint8, device=device), torch.empty(n, dtype=torch.uint8, device=device)
 
+    def relu_only_supported(self):
+        return bool(self.lib.cnn_conv2d_relu_only_supported(C.byref(self.desc)))
+
     def forward_prepared(self, x, prepared_fwd, bias, y, y_relu=None):
-        _need_gpu(x, prepared_fwd, bias, y)
-        check(self.lib.cnn_conv2d_forward_prepared(C.byref(self.desc), _ptr(x), _ptr(prepared_fwd), _ptr(bias), _ptr(y),
+        """y may be None (with y_relu) on layers where relu_only_supported(): the pre-activation tensor is then not written"""
+        _need_gpu(x, prepared_fwd, bias)
+        check(self.lib.cnn_conv2d_forward_prepared(C.byref(self.desc), _ptr(x), _ptr(prepared_fwd), _ptr(bias),
+                                                   _ptr(y) if y is not None else None,
                                                    _ptr(y_relu) if y_relu is not None else None, _stream()),
               "cnn_conv2d_forward_prepared")
         return y

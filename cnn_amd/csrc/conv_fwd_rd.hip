@@ -32,7 +32,7 @@ struct FwdRdParams {
     const float* w;     // [Co][Ci][3][3]
     const float* img;   // prepared LDS images (fwd_rd_prepare_batch), one per channel group -- or null: transpose from w
     const float* bias;  // [Co]
-    float* y;
+    float* y;   // nullable when y2 is given (pre-activation not wanted)
     float* y2;  // relu(y), or null
     int B, H, W, Co, Ho, Wo, HoWo;
     int pixels, tiles;       // B*Ho*Wo, ceil(pixels / 32)
@@ -193,8 +193,8 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_rd_kernel(const FwdRdParams 
                     if (co0 + rowl + 4 * kg < p.Co) {
                         const size_t o = (size_t)yoff + (size_t)rowl * p.HoWo;
                         const float v = acc[mt][r];
-                        p.y[o] = v;
-                        if (p.y2) p.y2[o] = v > 0.f ? v : 0.f;
+                        if (p.y) p.y[o] = v;
+                        if (p.y2) p.y2[o] = v >= 0.f ? v : 0.f;  // relu.cpp:21-26 (keeps -0.0, NaN -> 0)
                     }
                 }
         }

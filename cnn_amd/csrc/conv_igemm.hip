@@ -1290,7 +1290,8 @@ extern "C" {
 static int conv2d_forward_impl(const char* who, const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias,
                                float* y, float* y_relu, void* ws, size_t ws_bytes, void* stream, bool prepared = false) {
     if (int rc = check_desc(who, d)) return rc;
-    CNN_REQUIRE(x && (w || prepared) && bias && y, "%s: null pointer", who);
+    // y may be NULL when only the ReLU output is wanted and the layer runs on the register-direct forward kernel
+    CNN_REQUIRE(x && (w || prepared) && bias && (y || (y_relu && fwd_rd_supported(d))), "%s: null pointer", who);
     if (direct_conv_supported(d)) return direct_conv_forward(d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream), prepared);
     if (fwd_rd_supported(d))
         return fwd_rd_forward(d, x, prepared ? nullptr : w, prepared ? (const float*)ws : nullptr, bias, y, y_relu, as_stream(stream));
@@ -1333,6 +1334,11 @@ int cnn_conv2d_forward_relu(const cnn_conv2d_desc* d, const float* x, const floa
 int cnn_conv2d_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws,
                              size_t ws_bytes, void* stream) {
     return conv2d_backward_data_impl("cnn_conv2d_backward_data", d, dy, w, dx, ws, ws_bytes, stream, false);
+}
+
+int cnn_conv2d_relu_only_supported(const cnn_conv2d_desc* d) {
+    if (check_desc("cnn_conv2d_relu_only_supported", d)) return 0;
+    return (!direct_conv_supported(d) && fwd_rd_supported(d)) ? 1 : 0;
 }
 
 /* ---- Conv2D -> ReLU -> MaxPool2D(2,2) ---- */

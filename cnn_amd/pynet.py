@@ -73,6 +73,7 @@ class AlexNetHip:
         # weight / data gradient kernels: no MaxPool2D::backward / ReLU::backward kernel, no d_pool tensor.  The deferred
         # data gradient (below) then still needs pool_out / pool_mask of ITS step while the next forward pass is already
         # writing new ones: two sets, alternating.
+        self._relu_only = [c.relu_only_supported() for c in self.convs] if self.fuse_pool else [False] * 4
         self.pool_sets = [(self.pool_out, self.pool_mask)]
         if self.fuse_pool and defer_input_grad:
             self.pool_sets.append((torch.empty_like(self.pool_out), torch.empty_like(self.pool_mask)))
@@ -176,7 +177,9 @@ class AlexNetHip:
             if self.fuse and not self.use_prep:
                 self.convs[l].forward_relu(cur, self.conv_w(l), self.conv_b(l), self.conv_out[l], self.relu_out[l])
             elif self.fuse:
-                self.convs[l].forward_prepared(cur, self.prep[l][0], self.conv_b(l), self.conv_out[l], self.relu_out[l])
+                # (opt-in with fuse_pool: pre-activations nobody reads are not written either)
+                y = None if (self.fuse_pool and self._relu_only[l]) else self.conv_out[l]
+                self.convs[l].forward_prepared(cur, self.prep[l][0], self.conv_b(l), y, self.relu_out[l])
             else:
                 self.convs[l].forward(cur, self.conv_w(l), self.conv_b(l), self.conv_out[l])
                 capi.check(capi.load().cnn_relu_forward(capi._ptr(self.conv_out[l]), capi._ptr(self.relu_out[l]),

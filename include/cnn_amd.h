@@ -72,6 +72,9 @@ int cnn_conv2d_forward(const cnn_conv2d_desc* d, const float* x, const float* w,
  * saves the ReLU kernel's re-read of y.  Bit-identical to cnn_conv2d_forward + cnn_relu_forward. */
 int cnn_conv2d_forward_relu(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
                             float* y_relu, void* workspace, size_t workspace_bytes, void* stream);
+/* != 0: cnn_conv2d_forward_relu / cnn_conv2d_forward_prepared accept y == NULL for this layer and then write ONLY y_relu
+ * (a training step never reads the pre-activation tensor: ReLU::backward masks by its own output, relu.cpp:35-40). */
+int cnn_conv2d_relu_only_supported(const cnn_conv2d_desc* d);
 
 /* The reference's first block Conv2D -> ReLU -> MaxPool2D(2, 2) (alexnet.cpp:12-15; conv2d.cpp:69-92, relu.cpp:21-26,
  * pool2d.cpp:53-87) in ONE kernel: pooled [B][Co][Ho/2][Wo/2] and mask (same meaning as cnn_maxpool2d_forward: flat index
