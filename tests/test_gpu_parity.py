@@ -58,6 +58,8 @@ CONV_CASES = [
     (1, 3, 224, 224, 64, 7, 2, 3),   # the ResNet stem at full resolution (row staging of 230-float rows)
     (3, 32, 9, 11, 64, 3, 1, 0),     # stride-1 register-direct data gradient: one tile of 32 channels, borders everywhere
     (2, 64, 8, 7, 128, 3, 1, 0),     # ... two tiles per wave
+    (2, 32, 28, 30, 64, 3, 2, 0),    # stride-2 register-direct data gradient on even sizes (last input row / column uncovered)
+    (1, 96, 9, 12, 128, 3, 2, 0),    # ... three 32-channel groups, tiny image
 ]
 
 
@@ -692,7 +694,7 @@ def test_pool_fused_net_is_bit_identical(T, defer):
         assert T.equal(a.d_conv[1], T.where(b.pool_out <= 0, T.zeros_like(b.d_conv[1]), b.d_conv[1]))
 
 
-@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 13)] + [(3, 32, 9, 11, 64, 3, 1, 0)], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 13)] + [(3, 32, 9, 11, 64, 3, 1, 0), (2, 32, 28, 30, 64, 3, 2, 0), (1, 96, 9, 12, 128, 3, 2, 0)], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
 def test_conv2d_backward_data_relu_fusion_is_bit_identical(T, case):
     """cnn_conv2d_backward_data_relu == cnn_conv2d_backward_data + cnn_relu_backward, every kernel family, plain and prepared"""
     from cnn_amd import capi
