@@ -81,6 +81,8 @@ SIGNATURES = {
     "cnn_batchnorm2d_backward_from_sums": (C.c_int, [_P] * 6 + [C.c_float, _P, _P] + [C.c_int] * 4 + [C.c_float, _P]),
     "cnn_sgd_update": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P]),
     "cnn_softmax_xent": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "cnn_linear_forward_softmax_xent": (C.c_int, [_P] * 8 + [C.c_int] * 3 + [_P]),
+    "cnn_loss_from_terms": (C.c_int, [_P, _P, C.c_int, _P]),
     "cnn_device_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "cnn_device_free": (C.c_int, [_P]),
     "cnn_memcpy_h2d": (C.c_int, [_P, _P, C.c_size_t, _P]),

@@ -1,6 +1,8 @@
 // linear.hip -- LinearLayer forward / backward (cpu/src/linear.cpp:33-43, 56-90).  W is [in][out] row-major.
 // The reference net's layer is 4608 -> 3: a skinny contraction that is HBM-bound on x (4*in bytes per sample),
 // so these are wave-reduction / streaming kernels, not MFMA tiles.
+#include <cfloat>
+
 #include "common.h"
 
 using namespace cnn_amd;
@@ -50,6 +52,80 @@ __global__ __launch_bounds__(kBlock) void linear_fwd(const float* __restrict__ x
             y[(size_t)b * out + j0 + threadIdx.x] = s + bias[j0 + threadIdx.x];
         }
         __syncthreads();
+    }
+}
+
+// func.cpp:6-12
+__device__ __forceinline__ float clamped_exp_l(float v) {
+    if (v >= 88.f) return FLT_MAX;
+    if (v <= -50.f) return 0.f;
+    return expf(v);
+}
+
+// linear_fwd (out <= kOutTile) + the sample's softmax / cross-entropy (func.cpp:16-33, 60-71) in the same workgroup:
+// probs (nullable), delta = probs - onehot, and the sample's loss term log(p[label]) into loss_terms[b].  The ordered sum
+// over samples (the reference's order) is a separate, on-demand reduction: cnn_loss_from_terms.
+__global__ __launch_bounds__(kBlock) void linear_fwd_softmax_xent(const float* __restrict__ x, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, const int32_t* __restrict__ labels,
+                                                                  float* __restrict__ y, float* __restrict__ probs,
+                                                                  float* __restrict__ delta, float* __restrict__ loss_terms, int in,
+                                                                  int out) {
+    __shared__ float part[kBlock / kWave][kOutTile];
+    __shared__ float logit[kOutTile];
+    const int b = blockIdx.x;
+    const float* xb = x + (size_t)b * in;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[kOutTile];
+#pragma unroll
+    for (int j = 0; j < kOutTile; ++j) acc[j] = 0.f;
+#pragma unroll 6
+    for (int i = threadIdx.x; i < in; i += kBlock) {
+        const float xv = xb[i];
+        const float* wr = w + (size_t)i * out;
+#pragma unroll
+        for (int j = 0; j < kOutTile; ++j)
+            if (j < out) acc[j] += xv * wr[j];
+    }
+#pragma unroll
+    for (int j = 0; j < kOutTile; ++j) {
+        const float s = wave_sum(acc[j]);
+        if (lane == 0) part[wave][j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < out) {
+        float s = 0.f;
+        for (int wv = 0; wv < kBlock / kWave; ++wv) s += part[wv][threadIdx.x];
+        s += bias[threadIdx.x];
+        y[(size_t)b * out + threadIdx.x] = s;
+        logit[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // the reference's sequential per-sample arithmetic (same as softmax_xent_kernel)
+        float mx = logit[0];
+        for (int i = 1; i < out; ++i)
+            if (logit[i] > mx) mx = logit[i];
+        float sum = 0.f;
+        for (int i = 0; i < out; ++i) sum += clamped_exp_l(logit[i] - mx);
+        const int label = labels[b];
+        float term = 0.f;
+        for (int i = 0; i < out; ++i) {
+            float pr = clamped_exp_l(logit[i] - mx) / sum;
+            if (isnan(pr)) pr = 0.f;
+            const float yv = (i == label) ? 1.f : 0.f;
+            if (probs) probs[(size_t)b * out + i] = pr;
+            delta[(size_t)b * out + i] = pr - yv;
+            term += logf(pr) * yv;
+        }
+        loss_terms[b] = term;
+    }
+}
+
+// loss_sum[0] = -(terms[0] + terms[1] + ...) in ascending sample order (func.cpp:60-71)
+__global__ void loss_from_terms(const float* __restrict__ terms, float* __restrict__ loss_sum, int B) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float running = 0.f;
+        for (int i = 0; i < B; ++i) running += terms[i];
+        loss_sum[0] = -running;
     }
 }
 
@@ -221,6 +297,25 @@ static int linear_backward_impl(const float* x, const float* dy, const float* w,
         CNN_KLAUNCH(s, "linear_bwd_x", (linear_bwd_x<<<grid, kBlock, 0, s>>>(dy, w, dx, in, out)), "B%d in%d out%d", B, in, out);
     }
     if (relu_below && dx) return cnn_relu_backward(x, dx, (size_t)B * in, stream);  // (same result from the separate kernel)
+    return CNN_AMD_OK;
+}
+
+int cnn_linear_forward_softmax_xent(const float* x, const float* w, const float* bias, const int32_t* labels, float* logits,
+                                    float* probs, float* delta, float* loss_terms, int B, int in, int out, void* stream) {
+    CNN_REQUIRE(x && w && bias && labels && logits && delta && loss_terms, "cnn_linear_forward_softmax_xent: null pointer");
+    CNN_REQUIRE(B > 0 && in > 0 && out > 0 && out <= kOutTile, "cnn_linear_forward_softmax_xent: B=%d in=%d out=%d (out <= %d)", B, in, out,
+                kOutTile);
+    hipStream_t s = as_stream(stream);
+    CNN_KLAUNCH(s, "linear_fwd+softmax_xent",
+                (linear_fwd_softmax_xent<<<B, kBlock, 0, s>>>(x, w, bias, labels, logits, probs, delta, loss_terms, in, out)),
+                "B%d in%d out%d", B, in, out);
+    return CNN_AMD_OK;
+}
+
+int cnn_loss_from_terms(const float* loss_terms, float* loss_sum, int B, void* stream) {
+    CNN_REQUIRE(loss_terms && loss_sum && B > 0, "cnn_loss_from_terms: bad arguments");
+    hipStream_t s = as_stream(stream);
+    CNN_KLAUNCH(s, "loss_from_terms", (loss_from_terms<<<1, 64, 0, s>>>(loss_terms, loss_sum, B)), "B=%d", B);
     return CNN_AMD_OK;
 }
 

@@ -56,7 +56,9 @@ class AlexNetHip:
         self.logits = torch.empty((batch, classes), **f32)
         self.probs = torch.empty((batch, classes), **f32)
         self.delta = torch.empty((batch, classes), **f32)
-        self.loss_sum = torch.zeros(1, **f32)
+        self._loss_sum = torch.zeros(1, **f32)
+        self.loss_terms = torch.zeros(batch, **f32)  # fused head: per-sample log(p[label]); summed on demand (loss_sum)
+        self._loss_from_terms = False
         self.d_lin = torch.empty((batch, self.lin_in), **f32)
         self.d_conv = [torch.empty((batch, self.CHANS[l]) + self.conv_in_hw[l], **f32) for l in range(4)]
         self.d_pool = torch.empty((batch, 16) + self.conv_out_hw[0], **f32)
@@ -65,6 +67,7 @@ class AlexNetHip:
 
         self.use_prep = fuse and not os.environ.get("CNN_AMD_NO_PREPARED")  # (A/B switch for measurements)
         self._no_fbr = bool(os.environ.get("CNN_AMD_NO_BWD_RELU_FUSION"))  # (likewise)
+        self._no_head_fusion = bool(os.environ.get("CNN_AMD_NO_HEAD_FUSION"))
         self._dx0_release = int(os.environ.get("CNN_AMD_DX0_RELEASE", "2"))  # conv layer after whose forward the deferred dgrad starts
         # conv_layer_1 -> relu_layer_1 -> max_pool_1 as one kernel: conv_out[0] / relu_out[0] are then NOT written (nothing in
         # the step reads them: the backward pass of that block works from pool_out + pool_mask)
@@ -94,6 +97,16 @@ class AlexNetHip:
             self.parity = 0
             self.pending_dx0 = None   # prepared-filter buffer of the step whose conv1 dgrad has not been launched yet
             self.b_in_flight = False
+
+    @property
+    def loss_sum(self):
+        """-sum_b log(p[b][label_b]) of the last step (1-element device tensor).  With the fused head the ordered sum over the
+        per-sample terms is computed here, i.e. only when somebody asks for the loss value."""
+        if self._loss_from_terms:
+            capi.check(capi.load().cnn_loss_from_terms(capi._ptr(self.loss_terms), capi._ptr(self._loss_sum), self.B, capi._stream()),
+                       "cnn_loss_from_terms")
+            self._loss_from_terms = False
+        return self._loss_sum
 
     # ---- parameter views (reference layouts) ----
     def conv_w(self, l, arena=None):
@@ -161,8 +174,11 @@ class AlexNetHip:
         self.load_params(np.fromfile(path, dtype=np.float32))
 
     # ---- alexnet.cpp:35-46 ----
-    def forward(self, x, record=True):
+    def forward(self, x, record=True, labels=None):
+        """labels (device int32 [B], optional): with fused kernels the loss head runs inside the last layer's forward kernel
+        and loss_backward_seed() becomes a no-op for this pass"""
         self.x = x
+        self._head_done = False
         cur = x
         if self.use_prep:
             self._prepare()
@@ -196,13 +212,25 @@ class AlexNetHip:
                 # deferral 261.0k | before conv1 ~249k | after max_pool_1 ~257k | after conv_layer_2 269.3k | after
                 # conv_layer_3 264.5k -- it then overlaps the latency-bound layers 3-4, the linear layer and the loss
                 self._launch_pending_dx0(gated=True)
+        if labels is not None and self.use_prep and self.classes <= 8 and not self._no_head_fusion:
+            capi.check(capi.load().cnn_linear_forward_softmax_xent(capi._ptr(cur), capi._ptr(self.lin_w()), capi._ptr(self.lin_b()),
+                                                                   capi._ptr(labels), capi._ptr(self.logits), capi._ptr(self.probs),
+                                                                   capi._ptr(self.delta), capi._ptr(self.loss_terms), self.B,
+                                                                   self.lin_in, self.classes, capi._stream()),
+                       "cnn_linear_forward_softmax_xent")
+            self._head_done = True
+            self._loss_from_terms = True
+            return self.logits
         capi.linear_forward(cur.view(self.B, self.lin_in), self.lin_w(), self.lin_b(), self.logits)
         return self.logits
 
     # ---- func.cpp:16-73 on the device ----
     def loss_backward_seed(self, labels):
+        if getattr(self, "_head_done", False):  # done by forward(labels=...)
+            return self.delta
+        self._loss_from_terms = False
         capi.check(capi.load().cnn_softmax_xent(capi._ptr(self.logits), capi._ptr(labels), capi._ptr(self.probs),
-                                                capi._ptr(self.delta), capi._ptr(self.loss_sum), self.B, self.classes,
+                                                capi._ptr(self.delta), capi._ptr(self._loss_sum), self.B, self.classes,
                                                 capi._stream()), "cnn_softmax_xent")
         return self.delta
 
@@ -270,7 +298,7 @@ class AlexNetHip:
     def train_step(self, x, labels, lr, dist=None, world=1):
         """one iteration of cnn.cpp:79-90.  Under data parallelism every rank holds B local samples: local grads are
         (1/B)*sum_local, all-reduce(sum) over `world` ranks, then x(1/world) folded into the SGD kernel."""
-        self.forward(x)
+        self.forward(x, labels=labels)
         self.loss_backward_seed(labels)
         self.backward(self.delta)
         from .dp import allreduce_grads

@@ -261,6 +261,13 @@ int cnn_sgd_update(float* params, const float* grads, size_t n, float lr, float 
  * probs / loss_sum may be NULL. */
 int cnn_softmax_xent(const float* logits, const int32_t* labels, float* probs, float* delta, float* loss_sum,
                      int B, int classes, void* stream);
+/* LinearLayer::forward of the last layer + cnn_softmax_xent in ONE kernel (out <= 8): logits, probs (nullable), delta as
+ * above, and the per-sample loss term log(probs[b][label_b]) into loss_terms[b]; cnn_loss_from_terms adds the terms in
+ * ascending sample order (the reference's order) whenever the loss value is actually wanted.  Bit-identical to
+ * cnn_linear_forward + cnn_softmax_xent. */
+int cnn_linear_forward_softmax_xent(const float* x, const float* w, const float* bias, const int32_t* labels, float* logits,
+                                    float* probs, float* delta, float* loss_terms, int B, int in, int out, void* stream);
+int cnn_loss_from_terms(const float* loss_terms, float* loss_sum, int B, void* stream);
 
 /* ---- device memory / transfer helpers (the host layer classes use only these) ------------------------ */
 int cnn_device_alloc(void** ptr, size_t bytes);

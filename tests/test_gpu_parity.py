@@ -756,3 +756,26 @@ def test_pool_fused_net_full_batch_is_bit_identical(T):
         assert T.equal(fused.d_conv[0], plain.d_conv[0]) and T.equal(fused.logits, plain.logits)
     loss = float(fused.loss_sum.item()) / B
     assert np.isfinite(loss) and 0.0 < loss < 20.0
+
+
+@pytest.mark.parametrize("B,n_in,n_out", [(256, 4608, 3), (5, 70, 8), (3, 33, 1)])
+def test_linear_forward_softmax_xent_fusion_is_bit_identical(T, B, n_in, n_out):
+    """cnn_linear_forward_softmax_xent + cnn_loss_from_terms == cnn_linear_forward + cnn_softmax_xent (logits, probs, delta, loss)"""
+    from cnn_amd import capi
+
+    x = dev(T, uniform_pm1(720, (B, n_in)))
+    w, b = dev(T, normal_scaled(721, (n_in, n_out))), dev(T, normal_scaled(722, (n_out,)))
+    labels = dev(T, (np.arange(B) % n_out).astype(np.int32))
+    logits0 = capi.linear_forward(x, w, b)
+    probs0, delta0, loss0 = T.empty_like(logits0), T.empty_like(logits0), T.zeros(1, device="cuda")
+    lib = capi.load()
+    capi.check(lib.cnn_softmax_xent(capi._ptr(logits0), capi._ptr(labels), capi._ptr(probs0), capi._ptr(delta0), capi._ptr(loss0), B, n_out,
+                                    capi._stream()), "cnn_softmax_xent")
+    logits1, probs1, delta1 = T.full_like(logits0, 7.0), T.full_like(logits0, 7.0), T.full_like(logits0, 7.0)
+    terms, loss1 = T.zeros(B, device="cuda"), T.zeros(1, device="cuda")
+    capi.check(lib.cnn_linear_forward_softmax_xent(capi._ptr(x), capi._ptr(w), capi._ptr(b), capi._ptr(labels), capi._ptr(logits1),
+                                                   capi._ptr(probs1), capi._ptr(delta1), capi._ptr(terms), B, n_in, n_out, capi._stream()),
+               "cnn_linear_forward_softmax_xent")
+    capi.check(lib.cnn_loss_from_terms(capi._ptr(terms), capi._ptr(loss1), B, capi._stream()), "cnn_loss_from_terms")
+    for a, c in ((logits0, logits1), (probs0, probs1), (delta0, delta1), (loss0, loss1)):
+        assert np.array_equal(host(a).view(np.uint32), host(c).view(np.uint32))
