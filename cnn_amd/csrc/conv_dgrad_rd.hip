@@ -62,7 +62,9 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic, int d) {
 }
 
 // CO dy channels (even), NW waves per workgroup, UC dy channels per pipeline group
-template <int CO, int NW, int UC, int NB>
+// HALF (Ci = 16): the 32 MFMA rows hold 16 channels x TWO parity classes -- rows 0-15 class (ph,0), rows 16-31 class (ph,1) --
+// so a dy channel takes 4 + 2 = 6 MFMA steps on two accumulators instead of 9 steps on four half-empty ones
+template <int CO, int NW, int UC, int NB, bool HALF = false>
 __global__ __launch_bounds__(NW * 64) void conv_dgrad_rd_s2_kernel(const DgRdParams p) {
     constexpr int CH = CO / 2;   // dy channels per k-slot
     constexpr int G = CH / UC;   // pipeline groups per tile
@@ -71,8 +73,10 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_rd_s2_kernel(const DgRdPar
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ci0 = blockIdx.y * 32;
     // this lane's filter column: w[kg*CH + .][ci0 + n][.]  (a lane beyond Ci reads channel ci0: its rows are not stored)
-    const unsigned wlane = (unsigned)((kg * CH * p.Ci + ci0 + (ci0 + n < p.Ci ? n : 0)) * 9);
-    const unsigned wlane_tr = (unsigned)(kg * CH * p.Ci * 9 + ci0 + (ci0 + n < p.Ci ? n : 0));
+    const int nci = HALF ? (n & 15) : n;       // channel row of this lane inside the tile
+    const bool upper = HALF && n >= 16;        // HALF: this lane's MFMA row belongs to the pw = 1 class
+    const unsigned wlane = (unsigned)((kg * CH * p.Ci + ci0 + (ci0 + nci < p.Ci ? nci : 0)) * 9);
+    const unsigned wlane_tr = (unsigned)(kg * CH * p.Ci * 9 + ci0 + (ci0 + nci < p.Ci ? nci : 0));
     const unsigned plane = (unsigned)(p.Ho * p.Wo);
     const int tstep = gridDim.x * NW;
 
@@ -164,9 +168,10 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_rd_s2_kernel(const DgRdPar
     for (; tile < p.tiles; tile += tstep) {
         const bool more = tile + tstep < p.tiles;
         if (more) locate(tile + tstep, nxt);
-        f32x16 acc[4];  // classes (ph,pw) = 00, 01, 10, 11
+        constexpr int NACC = HALF ? 2 : 4;
+        f32x16 acc[NACC];  // classes (ph,pw) = 00, 01, 10, 11; HALF: ph = 0, 1 (pw in the row halves)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < NACC; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
         // (a run-time loop over ring turns: fully unrolled, hipcc kept hundreds of addresses live -- 432 to 512 VGPRs.  The
@@ -188,6 +193,17 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_rd_s2_kernel(const DgRdPar
                     const float d10 = pick(p1, cur.s0, cur.v10), d11 = pick(p1, cur.s1, cur.v11);  // D[1][jc]
                     const Taps& t9 = ab[ri][uu];
                     const float a[9] = {t9.a.x, t9.a.y, t9.a.z, t9.a.w, t9.b.x, t9.b.y, t9.b.z, t9.b.w, t9.c};  // taps kx*3 + ky
+                    if constexpr (HALF) {
+                        // rows 0-15 | 16-31:  D00: taps (0,0) | (0,1);  D10: (2,0) | (2,1);  D01: (0,2) | -;  D11: (2,2) | -
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(upper ? a[1] : a[0], d00, acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(upper ? a[7] : a[6], d10, acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(upper ? 0.f : a[2], d01, acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(upper ? 0.f : a[8], d11, acc[0], 0, 0, 0);
+                        //                     D00: taps (1,0) | (1,1);  D01: (1,2) | -
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(upper ? a[4] : a[3], d00, acc[1], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(upper ? 0.f : a[5], d01, acc[1], 0, 0, 0);
+                        continue;
+                    }
                     // class (0,0): taps (0,0) D00, (0,2) D01, (2,0) D10, (2,2) D11
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], d00, acc[0], 0, 0, 0);
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], d01, acc[0], 0, 0, 0);
@@ -197,16 +213,52 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_rd_s2_kernel(const DgRdPar
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], d00, acc[1], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[7], d10, acc[1], 0, 0, 0);
                     // class (1,0): taps (1,0) D00, (1,2) D01
-                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], d00, acc[2], 0, 0, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[5], d01, acc[2], 0, 0, 0);
+                    acc[NACC - 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], d00, acc[NACC - 2], 0, 0, 0);
+                    acc[NACC - 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[5], d01, acc[NACC - 2], 0, 0, 0);
                     // class (1,1): tap (1,1) D00
-                    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4], d00, acc[3], 0, 0, 0);
+                    acc[NACC - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4], d00, acc[NACC - 1], 0, 0, 0);
                 }
             }
         }
         const long long dbg_t1 = p.dbg ? clock64() : 0;
         // ---- epilogue: dx[ci][2u + ph][2v .. 2v+1]
-        if (cur.live) {
+        if constexpr (HALF) {
+            if (cur.live) {  // accumulator register r (< 8) = channel row, r + 8 = the same channel's pw = 1 value
+                const bool w1 = 2 * cur.v + 1 < p.W, h1 = 2 * cur.u + 1 < p.H;
+                float m0[8][2], m1[8][2];
+                if (p.relu_below) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int rowl = (i & 3) + 8 * (i >> 2) + 4 * kg;
+                        const size_t o = (size_t)cur.xo + (size_t)(ci0 + rowl < p.Ci ? rowl : 0) * p.H * p.W;
+#pragma unroll
+                        for (int ph = 0; ph < 2; ++ph) {
+                            const size_t oo = o + (size_t)((ph == 1 && h1) ? p.W : 0);
+                            m0[i][ph] = p.relu_below[oo];
+                            m1[i][ph] = w1 ? p.relu_below[oo + 1] : 1.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int rowl = (i & 3) + 8 * (i >> 2) + 4 * kg;
+                    if (ci0 + rowl >= p.Ci) continue;
+                    const size_t o = (size_t)cur.xo + (size_t)rowl * p.H * p.W;
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph) {
+                        if (ph == 1 && !h1) continue;
+                        const size_t oo = o + (size_t)ph * p.W;
+                        float v0 = acc[ph][i], v1 = acc[ph][i + 8];
+                        if (p.relu_below) {
+                            v0 = (m0[i][ph] <= 0.f) ? 0.f : v0;
+                            v1 = (m1[i][ph] <= 0.f) ? 0.f : v1;
+                        }
+                        if (w1) *(f2u*)(p.dx + oo) = f2u{v0, v1};
+                        else p.dx[oo] = v0;
+                    }
+                }
+            }
+        } else if (cur.live) {
             const bool w1 = 2 * cur.v + 1 < p.W, h1 = 2 * cur.u + 1 < p.H;
             // 8 accumulator rows at a time: all mask values of the batch are requested before the first one is used (a
             // load per store would serialise 32 round trips)
@@ -522,6 +574,14 @@ int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const floa
         else if (pl.mt == 2) S1(128, 2, 1);
         else { if (uc == 2) S1(128, 1, 2); else S1(128, 1, 1); }
 #undef S1
+        return CNN_AMD_OK;
+    }
+    if (d->Ci == 16) {  // two classes per MFMA tile
+        const dim3 grid(pl.blocks_x, pl.cgroups);
+#define SH(CO_) CNN_KLAUNCH(s, name, (conv_dgrad_rd_s2_kernel<CO_, 4, 2, 4, true><<<grid, 256, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", \
+                            d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad)
+        if (d->Co == 32) SH(32); else if (d->Co == 64) SH(64); else SH(128);
+#undef SH
         return CNN_AMD_OK;
     }
     if (d->Co == 32) return launch<32, 4>(pl, s, name, d);

@@ -716,6 +716,31 @@ def test_conv2d_backward_data_relu_fusion_is_bit_identical(T, case):
     assert np.array_equal(host(dx2).view(np.uint32), host(dx_ref).view(np.uint32))
 
 
+@pytest.mark.parametrize("case", [(2, 16, 13, 13, 32, 3, 2, 0), (3, 16, 28, 27, 64, 3, 2, 0), (1, 16, 111, 111, 32, 3, 2, 0),
+                                  (2, 16, 9, 10, 128, 3, 2, 0), (2, 24, 12, 12, 32, 3, 2, 0)], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_conv2d_dgrad_register_direct_opt_in_tiles(T, case, monkeypatch):
+    """conv_dgrad_rd.hip behind CNN_AMD_DGRAD_RD32=1: the Co = 32 instantiation and, for Ci = 16, the tile that packs two
+    parity classes into one 32-row MFMA operand -- oracle parity plus bit-identity of the fused ReLU' epilogue"""
+    from cnn_amd import capi
+
+    monkeypatch.setenv("CNN_AMD_DGRAD_RD32", "1")
+    x, w, b, dy = _conv_inputs(case, 730)
+    _, _, _, dx_ref = _oracle_conv(case, x, w, b, dy)
+    relu_below = np.maximum(x - 0.3, 0).astype(np.float32)
+    conv = capi.Conv2d(*case)
+    wd, dyd, rd = dev(T, w), dev(T, dy), dev(T, relu_below)
+    dx = conv.backward_data(dyd, wd)
+    assert_close(host(dx), dx_ref, REL_TOL, "data grad")
+    masked = dx.clone()
+    capi.relu_backward(rd, masked)
+    pf, pd = conv.prepared_buffers("cuda")
+    capi.prepare_filters([conv], [wd], [dev(T, b)], [pf], [pd])
+    for prepared in (None, pd):
+        dx2 = T.full_like(dx, 7.0)
+        conv.backward_data_relu(dyd, None if prepared is not None else wd, rd, dx2, prepared_dgrad=prepared)
+        assert np.array_equal(host(dx2).view(np.uint32), host(masked).view(np.uint32))
+
+
 @pytest.mark.parametrize("B,n_in,n_out", [(4, 4608, 3), (3, 70, 5), (2, 33, 20)])
 def test_linear_backward_relu_fusion_is_bit_identical(T, B, n_in, n_out):
     from cnn_amd import capi
