@@ -38,7 +38,7 @@ __global__ __launch_bounds__(kBlock) void linear_fwd(const float* __restrict__ x
             const float* wr = w + (size_t)i * out + j0;
 #pragma unroll
             for (int j = 0; j < kOutTile; ++j)
-                if (j < nj) acc[j] += xv * wr[j];
+                if (j < nj) acc[j] = __builtin_fmaf(xv, wr[j], acc[j]);
         }
 #pragma unroll
         for (int j = 0; j < kOutTile; ++j) {
@@ -55,6 +55,8 @@ __global__ __launch_bounds__(kBlock) void linear_fwd(const float* __restrict__ x
     }
 }
 
+struct __attribute__((packed, aligned(4))) w3 { float a, b, c; };  // one W row of a 3-output layer: a single 12-byte load
+
 // func.cpp:6-12
 __device__ __forceinline__ float clamped_exp_l(float v) {
     if (v >= 88.f) return FLT_MAX;
@@ -65,6 +67,7 @@ __device__ __forceinline__ float clamped_exp_l(float v) {
 // linear_fwd (out <= kOutTile) + the sample's softmax / cross-entropy (func.cpp:16-33, 60-71) in the same workgroup:
 // probs (nullable), delta = probs - onehot, and the sample's loss term log(p[label]) into loss_terms[b].  The ordered sum
 // over samples (the reference's order) is a separate, on-demand reduction: cnn_loss_from_terms.
+template <bool BATCH>
 __global__ __launch_bounds__(kBlock) void linear_fwd_softmax_xent(const float* __restrict__ x, const float* __restrict__ w,
                                                                   const float* __restrict__ bias, const int32_t* __restrict__ labels,
                                                                   float* __restrict__ y, float* __restrict__ probs,
@@ -78,13 +81,35 @@ __global__ __launch_bounds__(kBlock) void linear_fwd_softmax_xent(const float* _
     float acc[kOutTile];
 #pragma unroll
     for (int j = 0; j < kOutTile; ++j) acc[j] = 0.f;
+    int i = threadIdx.x;
+    if (BATCH && out == 3) {
+        // the reference net's head: every load of 18 iterations (one 4-byte x value + one 12-byte W row each) is issued before
+        // the first FMA -- in the train step this kernel shares the chip with an HBM-bound kernel, and each dependent round
+        // trip costs microseconds there.  Same products, same order as the generic loop below.
+        constexpr int U = 18;
+        for (; i + (U - 1) * kBlock < in; i += U * kBlock) {
+            float xv[U];
+            w3 wv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                xv[u] = xb[i + u * kBlock];
+                wv[u] = *reinterpret_cast<const w3*>(w + (size_t)(i + u * kBlock) * 3);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc[0] = __builtin_fmaf(xv[u], wv[u].a, acc[0]);  // explicit: contraction must not depend on the loop shape
+                acc[1] = __builtin_fmaf(xv[u], wv[u].b, acc[1]);
+                acc[2] = __builtin_fmaf(xv[u], wv[u].c, acc[2]);
+            }
+        }
+    }
 #pragma unroll 6
-    for (int i = threadIdx.x; i < in; i += kBlock) {
+    for (; i < in; i += kBlock) {
         const float xv = xb[i];
         const float* wr = w + (size_t)i * out;
 #pragma unroll
         for (int j = 0; j < kOutTile; ++j)
-            if (j < out) acc[j] += xv * wr[j];
+            if (j < out) acc[j] = __builtin_fmaf(xv, wr[j], acc[j]);
     }
 #pragma unroll
     for (int j = 0; j < kOutTile; ++j) {
@@ -306,9 +331,15 @@ int cnn_linear_forward_softmax_xent(const float* x, const float* w, const float*
     CNN_REQUIRE(B > 0 && in > 0 && out > 0 && out <= kOutTile, "cnn_linear_forward_softmax_xent: B=%d in=%d out=%d (out <= %d)", B, in, out,
                 kOutTile);
     hipStream_t s = as_stream(stream);
-    CNN_KLAUNCH(s, "linear_fwd+softmax_xent",
-                (linear_fwd_softmax_xent<<<B, kBlock, 0, s>>>(x, w, bias, labels, logits, probs, delta, loss_terms, in, out)),
-                "B%d in%d out%d", B, in, out);
+    const char* e = getenv("CNN_AMD_NO_HEAD_BATCH");  // A/B switch: the plain 6-deep loop for every layer width
+    if (e && atoi(e) != 0)
+        CNN_KLAUNCH(s, "linear_fwd+softmax_xent",
+                    (linear_fwd_softmax_xent<false><<<B, kBlock, 0, s>>>(x, w, bias, labels, logits, probs, delta, loss_terms, in, out)),
+                    "B%d in%d out%d", B, in, out);
+    else
+        CNN_KLAUNCH(s, "linear_fwd+softmax_xent",
+                    (linear_fwd_softmax_xent<true><<<B, kBlock, 0, s>>>(x, w, bias, labels, logits, probs, delta, loss_terms, in, out)),
+                    "B%d in%d out%d", B, in, out);
     return CNN_AMD_OK;
 }
 
