@@ -458,20 +458,180 @@ __global__ __launch_bounds__(256) void conv_dgrad_rd_s1_kernel(const DgRdParams 
     }
 }
 
+// ---- Ci = 16 (conv_layer_2 of the reference net): the WHOLE filter bank as MFMA A operands in registers -----------------
+// v_mfma_f32_16x16x4_f32: M = the 16 input channels, N = 16 consecutive grid pixels, K = 4.  Per parity class the K axis is
+//     (0,0): the 4 taps of one dy channel        -> CO   MFMA steps, A = w[co][ci][2jr][2jc],          k = 2jr + jc
+//     (0,1): 2 taps (jr) x 2 dy channels          -> CO/2 steps,      A = w[2p + (k>>1)][ci][2(k&1)][1]
+//     (1,0): 2 taps (jc) x 2 dy channels          -> CO/2 steps,      A = w[2p + (k>>1)][ci][1][2(k&1)]
+//     (1,1): 1 tap x 4 dy channels                -> CO/4 steps,      A = w[4q + k][ci][1][1]
+// = 2.25 CO steps per 16 pixels with no zero padding in M, N or K, and the 9*CO*16 filter values are exactly 2.25*CO lane
+// registers (72 for CO = 32) that a wave loads ONCE from the reference's own layout -- no LDS, no prepared copy, no filter
+// traffic in the loop.  The only streamed operand is dy: one 4-byte buffer load per MFMA step and lane (k-slot k of a lane
+// selects its tap / channel; out-of-range taps read 0 through an out-of-range buffer offset).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kM16OOB = 0x7ffffffcu;
+
+template <int CO, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdParams p) {
+    constexpr int CI = 16, C4 = CO / 4, NA = CO * 9 / 4;
+    constexpr int NB = 4;  // ring of granules (one 4-channel step: 9 loads, 9 MFMAs); three granules in flight
+    static_assert(C4 % NB == 0, "static ring indices");
+    const int lane = threadIdx.x & 63;
+    const int n = lane & 15, k = lane >> 4;
+    const int wave_id = blockIdx.x * NW + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * NW;
+    const int groups = (p.pixels + 15) >> 4;
+    if (wave_id >= groups) return;
+    float wa[NA];  // [0, CO): class (0,0) | [CO, 1.5 CO): (0,1) | [1.5 CO, 2 CO): (1,0) | [2 CO, 2.25 CO): (1,1)
+    if (p.tr == 2) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) wa[j] = p.w[j * 64 + lane];
+    } else {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) wa[j] = p.w[m16_filter_index(j, lane, CO)];
+    }
+    const int plane = p.Ho * p.Wo;
+    const size_t hw = (size_t)p.H * p.W;
+    const unsigned chs = (unsigned)hw * 4u;
+    const bool odd = (p.W & 1) != 0;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)p.B * CO * plane * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dx, 0, (int)((unsigned)p.B * CI * (unsigned)hw * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t mrs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.relu_below ? p.relu_below : p.dx), 0, (int)((unsigned)p.B * CI * (unsigned)hw * 4u), 0x00020000);
+    struct Loc {
+        unsigned o00, o01, o10, o11;  // dy byte offsets of this lane's k-slot per class (or out of range: reads 0)
+        unsigned p0, p1;              // dx byte offsets of the (pw = 0,1) pairs of rows 2u, 2u+1, channel 4k (or out of range: no store)
+        unsigned s0, s1;              // ... of the single element in the last column of an odd W
+    };
+    auto locate = [&](int g, Loc& L) {
+        const int pix = g * 16 + n;
+        const bool live = g < groups && pix < p.pixels;
+        const int pp = live ? pix : 0;
+        const int b = fdiv(pp, p.m_uv, p.UV);
+        const int rem = pp - b * p.UV;
+        const int u = fdiv(rem, p.m_v, p.V);
+        const int v = rem - u * p.V;
+        const unsigned base = (unsigned)(b * CO * plane + u * p.Wo + v) * 4u;
+        // D[jr][jc] = dy[co][u-jr][v-jc] of dy channel (step base + cosub)
+        auto off = [&](int jr, int jc, int cosub) -> unsigned {
+            const bool ok = live && u - jr >= 0 && u - jr < p.Ho && v - jc >= 0 && v - jc < p.Wo;
+            return ok ? base - (unsigned)(jr * p.Wo + jc) * 4u + (unsigned)(cosub * plane) * 4u : kM16OOB;
+        };
+        L.o00 = off(k >> 1, k & 1, 0);
+        L.o01 = off(k & 1, 0, k >> 1);
+        L.o10 = off(0, k & 1, k >> 1);
+        L.o11 = off(0, 0, k);
+        const unsigned xb = (unsigned)(((size_t)b * CI + 4 * k) * hw + (size_t)(2 * u) * p.W + 2 * v) * 4u;
+        const unsigned x0 = live ? xb : kM16OOB, x1 = (live && 2 * u + 1 < p.H) ? xb + (unsigned)p.W * 4u : kM16OOB;
+        const bool w1 = 2 * v + 1 < p.W;
+        L.p0 = w1 ? x0 : kM16OOB;
+        L.p1 = w1 ? x1 : kM16OOB;
+        L.s0 = w1 ? kM16OOB : x0;
+        L.s1 = w1 ? kM16OOB : x1;
+    };
+    auto load_g = [&](float (&buf)[9], int c4, const Loc& L) {
+        const int so = c4 * 4 * plane * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) buf[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)L.o00, so + c * plane * 4, 0));
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            buf[4 + pr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)L.o01, so + 2 * pr * plane * 4, 0));
+            buf[6 + pr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)L.o10, so + 2 * pr * plane * 4, 0));
+        }
+        buf[8] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)L.o11, so, 0));
+    };
+    Loc cur, nxt;
+    locate(wave_id, cur);
+    float ring[NB][9];
+#pragma unroll
+    for (int i = 0; i < NB - 1; ++i) load_g(ring[i], i, cur);
+    for (int g = wave_id; g < groups; g += nwaves) {
+        locate(g + nwaves, nxt);  // (behind the last group: every offset out of range)
+        // the fused ReLU::backward mask (relu.cpp:38) of this group's 8 output pairs is requested now and used in the epilogue
+        v2f mk[4][2];
+        float ms[4][2];
+        if (p.relu_below) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mk[r][0] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(mrs, (int)cur.p0, (int)(r * chs), 0));
+                mk[r][1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(mrs, (int)cur.p1, (int)(r * chs), 0));
+                if (odd) {
+                    ms[r][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, (int)cur.s0, (int)(r * chs), 0));
+                    ms[r][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, (int)cur.s1, (int)(r * chs), 0));
+                }
+            }
+        }
+        f32x4 acc[4];  // classes (ph,pw) = 00, 01, 10, 11; register r of lane (n, k) = channel 4k + r of pixel n
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c4 = 0; c4 < C4; ++c4) {
+            // request granule c4+3 (from c4 = C4-3 on: the first three of the next group), then consume granule c4
+            const int gn = c4 + NB - 1;
+            load_g(ring[gn % NB], gn % C4, gn < C4 ? cur : nxt);
+            RD_PIPE_FENCE(ring[c4 % NB][0]);
+            const float* bv = ring[c4 % NB];
+            // issue order pinned: an accumulator is reused every other step at the earliest (a dependent MFMA waits 40 cycles,
+            // an independent one issues after 32; hipcc's own order put the four class-(0,0) steps back to back)
+#define M16_STEP(ACC, A_, B_)                                              \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(A_, B_, ACC, 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0)
+            M16_STEP(acc[1], wa[CO + 2 * c4 + 0], bv[4]);
+            M16_STEP(acc[0], wa[4 * c4 + 0], bv[0]);
+            M16_STEP(acc[2], wa[CO + CO / 2 + 2 * c4 + 0], bv[6]);
+            M16_STEP(acc[0], wa[4 * c4 + 1], bv[1]);
+            M16_STEP(acc[3], wa[2 * CO + c4], bv[8]);
+            M16_STEP(acc[0], wa[4 * c4 + 2], bv[2]);
+            M16_STEP(acc[1], wa[CO + 2 * c4 + 1], bv[5]);
+            M16_STEP(acc[0], wa[4 * c4 + 3], bv[3]);
+            M16_STEP(acc[2], wa[CO + CO / 2 + 2 * c4 + 1], bv[7]);
+#undef M16_STEP
+        }
+        // epilogue, branch-free per lane: buffer stores whose offset is out of range for dead lanes / the row behind the tensor
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                float v0 = acc[ph * 2][r], v1 = acc[ph * 2 + 1][r];
+                float vs = v0;
+                if (p.relu_below) {
+                    v0 = (mk[r][ph].x <= 0.f) ? 0.f : v0;
+                    v1 = (mk[r][ph].y <= 0.f) ? 0.f : v1;
+                    if (odd) vs = (ms[r][ph] <= 0.f) ? 0.f : vs;
+                }
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v2f{v0, v1}), xrs, (int)(ph ? cur.p1 : cur.p0), (int)(r * chs), 0);
+                if (odd) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vs), xrs, (int)(ph ? cur.s1 : cur.s0), (int)(r * chs), 0);
+            }
+        cur = nxt;
+    }
+}
+
 inline unsigned magic_of(int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
 
 struct DgRdPlan {
     DgRdParams p;
     int co, nw, cgroups, blocks_x, mt;
+    bool m16;  // Ci = 16: conv_dgrad_m16_s2_kernel (filters from the reference layout: the prepared copy is verbatim)
     size_t lds, img_floats;
 };
+
+inline bool m16_wanted(const cnn_conv2d_desc* d) {
+    if (d->s != 2 || d->Ci != 16 || d->Co != 32) return false;
+    if ((long long)d->B * d->Co * cnn_conv2d_out_dim(d->H, 3, 2, 0) * cnn_conv2d_out_dim(d->W, 3, 2, 0) >= (1ll << 29) ||
+        (long long)d->B * d->Ci * d->H * d->W >= (1ll << 29))
+        return false;  // (32-bit buffer offsets)
+    const char* e = getenv("CNN_AMD_DGRAD_M16");
+    return !(e && atoi(e) == 0);
+}
 
 bool make_plan(const cnn_conv2d_desc* d, DgRdPlan* pl) {
     if (d->k != 3 || d->pad != 0 || (d->s != 2 && d->s != 1)) return false;
     if (d->s == 1 && ((d->Co != 64 && d->Co != 128) || d->Ci % 32 != 0)) return false;
     if ((d->Co != 32 && d->Co != 64 && d->Co != 128) || d->Ci % 16 != 0) return false;  // (Ci = 16: half of the 32 MFMA rows idle)
     // Co = 32 / Ci = 16 (conv_layer_2): measured 117 us against 95 us for the packed VALU kernel -> opt-in only
-    if (d->Co == 32 && !(getenv("CNN_AMD_DGRAD_RD32") && atoi(getenv("CNN_AMD_DGRAD_RD32")) != 0)) return false;
+    pl->m16 = m16_wanted(d);
+    if (d->Co == 32 && !pl->m16 && !(getenv("CNN_AMD_DGRAD_RD32") && atoi(getenv("CNN_AMD_DGRAD_RD32")) != 0)) return false;
     if (const char* e = getenv("CNN_AMD_DGRAD_RD"))
         if (atoi(e) == 0) return false;
     DgRdParams& p = pl->p;
@@ -500,6 +660,12 @@ bool make_plan(const cnn_conv2d_desc* d, DgRdPlan* pl) {
     const long long bx = 2 * kNumCU / pl->cgroups;
     const long long need = (p.tiles + pl->nw - 1) / pl->nw;
     pl->blocks_x = (int)(bx < 1 ? 1 : (bx > need ? need : bx));
+    if (pl->m16) {  // persistent waves over 16-pixel groups
+        int per_cu = getenv("CNN_AMD_DGRAD_M16_WG") ? atoi(getenv("CNN_AMD_DGRAD_M16_WG")) : 2;
+        if (per_cu < 1 || per_cu > 8) per_cu = 2;
+        const long long g = (pixels + 15) / 16, needg = (g + pl->nw - 1) / pl->nw;
+        pl->blocks_x = (int)(needg < (long long)per_cu * kNumCU ? needg : (long long)per_cu * kNumCU);
+    }
     return true;
 }
 
@@ -535,7 +701,7 @@ size_t dgrad_rd_prepared_floats(const cnn_conv2d_desc* d) {
 int dgrad_rd_prepare_layout(const cnn_conv2d_desc* d, int* transposed) {
     DgRdPlan pl;
     if (!make_plan(d, &pl)) return 0;
-    *transposed = prepared_transposed();
+    *transposed = pl.m16 ? 2 : prepared_transposed();
     return 1;
 }
 
@@ -554,6 +720,13 @@ int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const floa
     DgRdPlan pl;
     if (!make_plan(d, &pl)) return fail(CNN_AMD_E_BADARG, "conv_dgrad_rd: geometry not covered");
     pl.p.dy = dy; pl.p.w = w ? w : img; pl.p.tr = w ? 0 : prepared_transposed(); pl.p.relu_below = relu_below; pl.p.dx = dx;
+    if (pl.m16) {
+        pl.p.tr = w ? 0 : 2;  // prepared: lane-major operand order (m16_filter_index); otherwise gathered from the reference layout
+        CNN_KLAUNCH(s, relu_below ? "conv_dgrad_rd<2,32,m16>/dgrad+relu" : "conv_dgrad_rd<2,32,m16>/dgrad",
+                    (conv_dgrad_m16_s2_kernel<32, 4><<<pl.blocks_x, 256, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H,
+                    d->W, d->Co, d->k, d->s, d->pad);
+        return CNN_AMD_OK;
+    }
     if (w && ws && ws_bytes >= pl.img_floats * sizeof(float) && prepared_transposed()) {
         const unsigned gx = (unsigned)((pl.img_floats + 255) / 256);
         CNN_KLAUNCH(s, "dgrad_rd_transpose", (dgrad_rd_transpose_kernel<<<gx > 512 ? 512 : gx, 256, 0, s>>>(w, (float*)ws, d->Co, d->Ci)),

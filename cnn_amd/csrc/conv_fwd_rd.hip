@@ -281,13 +281,15 @@ struct FwdRdPrepBatch {
 };
 
 // one workgroup column per job.  kind 0: img[g][k*CBP + c] = w[g*cb + c][k], then the group's bias;
-// kind 1: img[(co*9 + tap)*Ci + ci] = w[(co*Ci + ci)*9 + tap] (tr) or a verbatim copy
+// kind 1: img[(co*9 + tap)*Ci + ci] = w[(co*Ci + ci)*9 + tap] (tr = 1), the m16 lane-major order (tr = 2) or a verbatim copy
 __global__ __launch_bounds__(256) void fwd_rd_prepare_kernel(const FwdRdPrepBatch pb) {
     const FwdRdPrepJob j = pb.job[blockIdx.y];
     if (j.kind == 1) {
         const int total = j.Co * j.Ci * 9;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-            if (j.tr) {
+            if (j.tr == 2) {  // lane-major MFMA A operands of the Ci = 16 data-gradient kernel
+                j.img[i] = j.w[m16_filter_index(i >> 6, i & 63, j.Co)];
+            } else if (j.tr) {
                 const int ci = i % j.Ci, r = i / j.Ci, tap = r % 9, co = r / 9;
                 j.img[i] = j.w[((size_t)co * j.Ci + ci) * 9 + tap];
             } else {

@@ -717,7 +717,7 @@ def test_conv2d_backward_data_relu_fusion_is_bit_identical(T, case):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 13, 13, 32, 3, 2, 0), (3, 16, 28, 27, 64, 3, 2, 0), (1, 16, 111, 111, 32, 3, 2, 0),
-                                  (2, 16, 9, 10, 128, 3, 2, 0), (2, 24, 12, 12, 32, 3, 2, 0)], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+                                  (2, 16, 9, 10, 128, 3, 2, 0), (2, 24, 12, 12, 32, 3, 2, 0), (3, 16, 12, 14, 32, 3, 2, 0), (5, 16, 5, 6, 32, 3, 2, 0)], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
 def test_conv2d_dgrad_register_direct_opt_in_tiles(T, case, monkeypatch):
     """conv_dgrad_rd.hip behind CNN_AMD_DGRAD_RD32=1: the Co = 32 instantiation and, for Ci = 16, the tile that packs two
     parity classes into one 32-row MFMA operand -- oracle parity plus bit-identity of the fused ReLU' epilogue"""
