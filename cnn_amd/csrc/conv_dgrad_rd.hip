@@ -500,8 +500,8 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdPa
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.relu_below ? p.relu_below : p.dx), 0, (int)((unsigned)p.B * CI * (unsigned)hw * 4u), 0x00020000);
     struct Loc {
         unsigned o00, o01, o10, o11;  // dy byte offsets of this lane's k-slot per class (or out of range: reads 0)
-        unsigned p0, p1;              // dx byte offsets of the (pw = 0,1) pairs of rows 2u, 2u+1, channel 4k (or out of range: no store)
-        unsigned s0, s1;              // ... of the single element in the last column of an odd W
+        unsigned x0, x1;              // dx byte offsets of rows 2u, 2u+1 at column 2v, channel 4k (or out of range: no store)
+        bool w1;                      // column 2v+1 exists (false only in the last column of an odd W)
     };
     auto locate = [&](int g, Loc& L) {
         const int pix = g * 16 + n;
@@ -522,12 +522,9 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdPa
         L.o10 = off(0, k & 1, k >> 1);
         L.o11 = off(0, 0, k);
         const unsigned xb = (unsigned)(((size_t)b * CI + 4 * k) * hw + (size_t)(2 * u) * p.W + 2 * v) * 4u;
-        const unsigned x0 = live ? xb : kM16OOB, x1 = (live && 2 * u + 1 < p.H) ? xb + (unsigned)p.W * 4u : kM16OOB;
-        const bool w1 = 2 * v + 1 < p.W;
-        L.p0 = w1 ? x0 : kM16OOB;
-        L.p1 = w1 ? x1 : kM16OOB;
-        L.s0 = w1 ? kM16OOB : x0;
-        L.s1 = w1 ? kM16OOB : x1;
+        L.x0 = live ? xb : kM16OOB;
+        L.x1 = (live && 2 * u + 1 < p.H) ? xb + (unsigned)p.W * 4u : kM16OOB;
+        L.w1 = 2 * v + 1 < p.W;
     };
     auto load_g = [&](float (&buf)[9], int c4, const Loc& L) {
         const int so = c4 * 4 * plane * 4;
@@ -548,17 +545,14 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdPa
     for (int g = wave_id; g < groups; g += nwaves) {
         locate(g + nwaves, nxt);  // (behind the last group: every offset out of range)
         // the fused ReLU::backward mask (relu.cpp:38) of this group's 8 output pairs is requested now and used in the epilogue
+        // (a lane in the last column of an odd W reads the pair one element to the left and uses its second half)
         v2f mk[4][2];
-        float ms[4][2];
         if (p.relu_below) {
+            const unsigned m0 = (cur.w1 || cur.x0 == kM16OOB) ? cur.x0 : cur.x0 - 4u, m1 = (cur.w1 || cur.x1 == kM16OOB) ? cur.x1 : cur.x1 - 4u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                mk[r][0] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(mrs, (int)cur.p0, (int)(r * chs), 0));
-                mk[r][1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(mrs, (int)cur.p1, (int)(r * chs), 0));
-                if (odd) {
-                    ms[r][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, (int)cur.s0, (int)(r * chs), 0));
-                    ms[r][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, (int)cur.s1, (int)(r * chs), 0));
-                }
+                mk[r][0] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(mrs, (int)m0, (int)(r * chs), 0));
+                mk[r][1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(mrs, (int)m1, (int)(r * chs), 0));
             }
         }
         f32x4 acc[4];  // classes (ph,pw) = 00, 01, 10, 11; register r of lane (n, k) = channel 4k + r of pixel n
@@ -588,20 +582,21 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdPa
 #undef M16_STEP
         }
         // epilogue, branch-free per lane: buffer stores whose offset is out of range for dead lanes / the row behind the tensor
+        const unsigned pp0 = cur.w1 ? cur.x0 : kM16OOB, pp1 = cur.w1 ? cur.x1 : kM16OOB;  // (pw = 0,1) pairs
+        const unsigned ss0 = cur.w1 ? kM16OOB : cur.x0, ss1 = cur.w1 ? kM16OOB : cur.x1;  // single element, last column of an odd W
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
                 float v0 = acc[ph * 2][r], v1 = acc[ph * 2 + 1][r];
-                float vs = v0;
                 if (p.relu_below) {
-                    v0 = (mk[r][ph].x <= 0.f) ? 0.f : v0;
+                    const float k0 = cur.w1 ? mk[r][ph].x : mk[r][ph].y;
+                    v0 = (k0 <= 0.f) ? 0.f : v0;
                     v1 = (mk[r][ph].y <= 0.f) ? 0.f : v1;
-                    if (odd) vs = (ms[r][ph] <= 0.f) ? 0.f : vs;
                 }
                 typedef unsigned u2 __attribute__((ext_vector_type(2)));
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v2f{v0, v1}), xrs, (int)(ph ? cur.p1 : cur.p0), (int)(r * chs), 0);
-                if (odd) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vs), xrs, (int)(ph ? cur.s1 : cur.s0), (int)(r * chs), 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v2f{v0, v1}), xrs, (int)(ph ? pp1 : pp0), (int)(r * chs), 0);
+                if (odd) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), xrs, (int)(ph ? ss1 : ss0), (int)(r * chs), 0);
             }
         cur = nxt;
     }

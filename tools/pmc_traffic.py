@@ -34,9 +34,12 @@ def canonical(name):
     m = re.match(r"conv_wgrad_pk_3_16_3_2<\d+,(\d+)>$", name)
     if m:
         return "conv_wgrad_pk<3,16,3,2>" + {"0": "", "1": "+pool", "2": "+poolm"}[m.group(1)]
-    m = re.match(r"conv_dgrad_rd_s2_kernel<(\d+),\d+,\d+,\d+>$", name)
+    m = re.match(r"conv_dgrad_rd_s2_kernel<(\d+),\d+,\d+,\d+(,(true|false))?>$", name)
     if m:
         return f"conv_dgrad_rd<2,{m.group(1)}>"
+    m = re.match(r"conv_dgrad_m16_s2_kernel<(\d+),\d+>$", name)
+    if m:
+        return f"conv_dgrad_rd<2,{m.group(1)},m16>"
     m = re.match(r"conv_fwd_rd_kernel<(\d+),(\d+),(\d+),\d+,\d+>$", name)
     if m:
         return f"conv_fwd_rd<{m.group(1)},{m.group(2)},{m.group(3)}>"
