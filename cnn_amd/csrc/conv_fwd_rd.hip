@@ -207,11 +207,122 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_rd_kernel(const FwdRdParams 
     }
 }
 
+// ---- small layers (conv_layer_3 / _4 of the reference net): a wave owns 16 output channels and keeps ALL their filters as
+// MFMA A operands in registers --------------------------------------------------------------------------------------------
+// With 13x13 or 6x6 output maps the kernel above has one or two 32-pixel tiles per wave: the LDS upload of the filter slice
+// (5.6 us), the exposed load latency of a lone wave per SIMD and the 16-row epilogue are 3/4 of its 35 us.  Here
+// v_mfma_f32_16x16x4_f32 runs M = 16 output channels (one slice per wave, Co/16 slices side by side in a workgroup so that
+// their input reads hit L1), N = 16 consecutive output pixels, K = 4 input channels of one tap: k-slot k of step
+// j = (c4, kx, ky) is channel 4 c4 + k, so a lane's input address is its pixel base + k planes + a wave-uniform offset, and
+// one 12-byte row load feeds the three ky steps.  The CI*9/4 A registers (144 for CI = 64) are loaded once per wave from the
+// prepared lane-major copy img[(slice*NA + j)*64 + lane] (m16f_filter_index), or gathered from the reference layout.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int m16f_filter_index(int i, int Ci) {
+    const int NA = Ci * 9 / 4;
+    const int lane = i & 63, j = (i >> 6) % NA, slice = (i >> 6) / NA;
+    return ((16 * slice + (lane & 15)) * Ci + 4 * (j / 9) + (lane >> 4)) * 9 + j % 9;
+}
+
+template <int S, int CI, int NW, bool PREP, int NB>  // NB: ring of granules (one c4: three 12-byte loads, nine MFMA steps), NB-1 in flight
+__global__ __launch_bounds__(NW * 64) void conv_fwd_m16_kernel(const FwdRdParams p) {
+    constexpr int C4 = CI / 4, NA = C4 * 9;
+    static_assert(C4 % NB == 0, "static ring indices");
+    const int lane = threadIdx.x & 63;
+    const int n = lane & 15, k = lane >> 4;
+    const int slices = p.Co >> 4, parts = p.tiles;  // (tiles: pixel partitions, set by the host)
+    const int wid = blockIdx.x * NW + (threadIdx.x >> 6);
+    const int slice = wid % slices, part = wid / slices;
+    const int groups = (p.pixels + 15) >> 4;
+    if (part >= parts || part >= groups) return;
+    float wa[NA];
+    if constexpr (PREP) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) wa[j] = p.img[(slice * NA + j) * 64 + lane];
+    } else {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) wa[j] = p.w[((16 * slice + n) * CI + 4 * (j / 9) + k) * 9 + j % 9];
+    }
+    float bs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bs[r] = p.bias[16 * slice + 4 * k + r];
+    const long long dbg_t0 = p.dbg ? clock64() : 0;
+    long long dbg_t1 = 0;
+    int dbg_groups = 0;
+    const unsigned plane = (unsigned)(p.H * p.W);
+    auto locate = [&](int g, unsigned& xoff, unsigned& yoff, bool& live) {
+        const int pi = g * 16 + n;
+        live = g < groups && pi < p.pixels;
+        const int pic = live ? pi : p.pixels - 1;  // (dead lanes read the last pixel's window and store nothing)
+        const int b = fdiv(pic, p.m_howo, p.HoWo), rem = pic - b * p.HoWo;
+        const int pr = fdiv(rem, p.m_wo, p.Wo), q = rem - pr * p.Wo;
+        xoff = (unsigned)((b * CI + k) * (int)plane + (S * pr) * p.W + S * q);
+        yoff = (unsigned)((b * p.Co + 16 * slice + 4 * k) * p.HoWo + rem);
+    };
+    // (12-byte loads through a pointer: hipcc lowers __builtin_amdgcn_raw_buffer_load_b96 to ONE dword load here)
+    auto load_g = [&](f3u (&buf)[3], int c4, unsigned xoff) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float* base = p.x + ((size_t)(c4 * 4) * plane + (size_t)kx * p.W);  // wave-uniform
+            buf[kx] = *(const f3u*)(base + xoff);
+        }
+    };
+    unsigned xoff, yoff, nxoff, nyoff;
+    bool live, nlive;
+    locate(part, xoff, yoff, live);
+    f3u xb[NB][3];
+#pragma unroll
+    for (int i = 0; i < NB - 1; ++i) load_g(xb[i], i, xoff);
+    for (int g = part; g < groups; g += parts) {
+        locate(g + parts, nxoff, nyoff, nlive);
+        constexpr int NACC = 2;  // partial sums, used round-robin (a dependent MFMA waits for the previous write-back)
+        f32x4 acc[NACC];
+        acc[0] = f32x4{bs[0], bs[1], bs[2], bs[3]};
+#pragma unroll
+        for (int a = 1; a < NACC; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c4 = 0; c4 < C4; ++c4) {
+            const int gn = c4 + NB - 1;  // requested now (from c4 = C4-3 on: the first granules of the next group)
+            load_g(xb[gn % NB], gn % C4, gn < C4 ? xoff : nxoff);
+            RD_PIPE_FENCE(xb[c4 % NB][0].x);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const f3u v = xb[c4 % NB][i / 3];
+                const float bv = i % 3 == 0 ? v.x : i % 3 == 1 ? v.y : v.z;
+                const int a = (c4 * 9 + i) % NACC;
+                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c4 * 9 + i], bv, acc[a], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[0][r] + acc[1][r];
+                const size_t o = (size_t)yoff + (size_t)r * p.HoWo;
+                if (p.y) p.y[o] = v;
+                if (p.y2) p.y2[o] = v >= 0.f ? v : 0.f;  // relu.cpp:21-26 (keeps -0.0, NaN -> 0)
+            }
+        }
+        xoff = nxoff;
+        yoff = nyoff;
+        live = nlive;
+        if (p.dbg) {
+            if (!dbg_groups) dbg_t1 = clock64();
+            ++dbg_groups;
+        }
+    }
+    if (p.dbg && threadIdx.x == 0 && blockIdx.x == 0)
+        printf("conv_fwd_m16 wg 0: first group done %lld, all %d groups %lld cycles after the filter loads were issued\n", dbg_t1 - dbg_t0, dbg_groups,
+               clock64() - dbg_t0);
+}
+
 inline unsigned magic_of(int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
 
 struct FwdRdPlan {
     FwdRdParams p;
     int s, ci, mt, nw, cgroups, blocks_x;
+    bool m16;  // conv_fwd_m16_kernel (small layers); its prepared image is a Co*Ci*9-float permutation of the filters
+    int m16_blocks, m16_parts;
     size_t lds, img_floats;
 };
 
@@ -252,6 +363,20 @@ bool make_plan(const cnn_conv2d_desc* d, FwdRdPlan* pl) {
     if (bx > need) bx = need;
     if (bx < 1) bx = 1;
     pl->blocks_x = (int)bx;
+    // small layers: fewer than four 32-pixel wave tiles per SIMD for the kernel above
+    const bool m16_ok = d->Co % 16 == 0 && (long long)d->B * d->Ci * d->H * d->W < (1ll << 29);  // (32-bit buffer offsets)
+    pl->m16 = m16_ok && (long long)p.tiles * mtiles < 4 * 4 * kNumCU;
+    if (const char* e = getenv("CNN_AMD_FWD_M16")) pl->m16 = m16_ok && atoi(e) != 0;
+    if (pl->m16) {
+        const int slices = d->Co / 16, groups = (int)((pixels + 15) / 16);
+        int per_simd = getenv("CNN_AMD_FWD_M16_WAVES") ? atoi(getenv("CNN_AMD_FWD_M16_WAVES")) : 1;  // (measured: 1 beats 2-4)
+        if (per_simd < 1 || per_simd > 8) per_simd = 1;
+        int parts = per_simd * 4 * kNumCU / slices;
+        if (parts < 1) parts = 1;
+        if (parts > groups) parts = groups;
+        pl->m16_parts = parts;
+        pl->m16_blocks = (parts * slices + 3) / 4;
+    }
     return true;
 }
 
@@ -270,7 +395,7 @@ int launch(const FwdRdPlan& pl, hipStream_t s, const char* name, const cnn_conv2
 }
 
 struct FwdRdPrepJob {
-    int kind;  // 0: forward LDS image of this file | 1: data-gradient filter copy of conv_dgrad_rd.hip (transposed or verbatim)
+    int kind;  // 0: forward LDS image of this file | 1: data-gradient filter copy of conv_dgrad_rd.hip | 2: conv_fwd_m16_kernel's A operands
     const float* w;
     const float* bias;
     float* img;
@@ -284,6 +409,11 @@ struct FwdRdPrepBatch {
 // kind 1: img[(co*9 + tap)*Ci + ci] = w[(co*Ci + ci)*9 + tap] (tr = 1), the m16 lane-major order (tr = 2) or a verbatim copy
 __global__ __launch_bounds__(256) void fwd_rd_prepare_kernel(const FwdRdPrepBatch pb) {
     const FwdRdPrepJob j = pb.job[blockIdx.y];
+    if (j.kind == 2) {  // conv_fwd_m16_kernel: lane-major A operands
+        const int total = j.Co * j.Ci * 9;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) j.img[i] = j.w[m16f_filter_index(i, j.Ci)];
+        return;
+    }
     if (j.kind == 1) {
         const int total = j.Co * j.Ci * 9;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
@@ -325,7 +455,9 @@ bool fwd_rd_supported(const cnn_conv2d_desc* d) {
 // floats of the prepared filter images of a layer (0: not an RD layer)
 size_t fwd_rd_prepared_floats(const cnn_conv2d_desc* d) {
     FwdRdPlan pl;
-    return make_plan(d, &pl) ? pl.img_floats * pl.cgroups : 0;
+    if (!make_plan(d, &pl)) return 0;
+    const size_t a = pl.img_floats * pl.cgroups, b = (size_t)d->Co * d->Ci * 9;  // (LDS images | the m16 permutation)
+    return a > b ? a : b;
 }
 
 int dgrad_rd_prepare_layout(const cnn_conv2d_desc* d, int* transposed);  // conv_dgrad_rd.hip
@@ -342,7 +474,7 @@ int rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w,
         if (fwd && fwd[i] && !(*fdone >> i & 1u) && make_plan(&descs[i], &pl)) {
             CNN_REQUIRE(w[i] && bias[i], "cnn_conv2d_prepare_filters: filters / bias of layer %d are null", i);
             FwdRdPrepJob& j = pb.job[jobs++];
-            j.kind = 0; j.w = w[i]; j.bias = bias[i]; j.img = (float*)fwd[i];
+            j.kind = pl.m16 ? 2 : 0; j.w = w[i]; j.bias = bias[i]; j.img = (float*)fwd[i];
             j.Co = descs[i].Co; j.Ci = descs[i].Ci; j.cb = pl.mt * 32; j.img_floats = (int)pl.img_floats; j.cgroups = pl.cgroups; j.tr = 0;
             if (pl.img_floats * pl.cgroups > most) most = pl.img_floats * pl.cgroups;
             *fdone |= 1u << i;
@@ -373,6 +505,23 @@ int fwd_rd_forward(const cnn_conv2d_desc* d, const float* x, const float* w, con
     if (!make_plan(d, &pl)) return fail(CNN_AMD_E_BADARG, "conv_fwd_rd: geometry not covered");
     pl.p.x = x; pl.p.w = w; pl.p.img = w ? nullptr : img; pl.p.bias = bias; pl.p.y = y; pl.p.y2 = y_relu;
     char name[64];
+    if (pl.m16) {
+        pl.p.tiles = pl.m16_parts;
+        snprintf(name, sizeof(name), "conv_fwd_rd<%d,%d,m16>/fwd%s", d->s, d->Ci, y_relu ? "+relu" : "");
+#define M16(S_, CI_)                                                                                                                   \
+    do {                                                                                                                               \
+        if (pl.p.img)                                                                                                                  \
+            CNN_KLAUNCH(s, name, (conv_fwd_m16_kernel<S_, CI_, 4, true, 4><<<pl.m16_blocks, 256, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", \
+                        d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad);                                                           \
+        else                                                                                                                           \
+            CNN_KLAUNCH(s, name, (conv_fwd_m16_kernel<S_, CI_, 4, false, 4><<<pl.m16_blocks, 256, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", \
+                        d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad);                                                           \
+    } while (0)
+        if (d->s == 2) { if (d->Ci == 16) M16(2, 16); else if (d->Ci == 32) M16(2, 32); else M16(2, 64); }
+        else { if (d->Ci == 16) M16(1, 16); else if (d->Ci == 32) M16(1, 32); else M16(1, 64); }
+#undef M16
+        return CNN_AMD_OK;
+    }
     snprintf(name, sizeof(name), "conv_fwd_rd<%d,%d,%d>/fwd%s", d->s, d->Ci, pl.mt, y_relu ? "+relu" : "");
 #define GO(S_, CI_)                                                                                  \
     do {                                                                                             \

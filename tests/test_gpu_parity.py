@@ -716,6 +716,41 @@ def test_conv2d_backward_data_relu_fusion_is_bit_identical(T, case):
     assert np.array_equal(host(dx2).view(np.uint32), host(dx_ref).view(np.uint32))
 
 
+FWD_FAMILY_CASES = [
+    (3, 32, 27, 27, 64, 3, 2, 0), (5, 64, 13, 13, 128, 3, 2, 0), (2, 16, 55, 55, 32, 3, 2, 0), (3, 32, 9, 11, 64, 3, 1, 0),
+    (2, 64, 8, 7, 128, 3, 1, 0), (1, 16, 5, 4, 16, 3, 1, 0), (7, 16, 7, 9, 48, 3, 2, 0), (2, 32, 28, 30, 80, 3, 2, 0),
+]
+
+
+@pytest.mark.parametrize("family", ["lds", "m16"])
+@pytest.mark.parametrize("case", FWD_FAMILY_CASES, ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_conv2d_forward_kernel_families(T, case, family, monkeypatch):
+    """conv_fwd_rd.hip has two forward kernels (LDS filter slice + 32x32x2 tiles | filters in registers + 16x16x4 tiles,
+    picked by layer size): each one forced on every shape, from the reference filter layout and from the prepared images,
+    pre-activation and fused ReLU outputs, against the oracle"""
+    from cnn_amd import capi
+
+    monkeypatch.setenv("CNN_AMD_FWD_M16", "1" if family == "m16" else "0")
+    x, w, b, dy = _conv_inputs(case, 740)
+    y_ref = _oracle_conv(case, x, w, b, dy)[0]
+    conv = capi.Conv2d(*case)
+    xd, wd, bd = dev(T, x), dev(T, w), dev(T, b)
+    y = conv.forward(xd, wd, bd)
+    assert_close(host(y), y_ref, REL_TOL, "forward")
+    pf, pd = conv.prepared_buffers("cuda")
+    capi.prepare_filters([conv], [wd], [bd], [pf], [pd])
+    y2, yr = T.full_like(y, 7.0), T.full_like(y, 7.0)
+    conv.forward_prepared(xd, pf, bd, y2, yr)
+    assert np.array_equal(host(y2).view(np.uint32), host(y).view(np.uint32)), "prepared == unprepared, bit for bit"
+    relu_ref = host(y).copy()
+    relu_ref[~(relu_ref >= 0)] = 0  # relu.cpp:21-26
+    assert np.array_equal(host(yr).view(np.uint32), relu_ref.view(np.uint32))
+    if conv.relu_only_supported():
+        yr2 = T.full_like(y, 7.0)
+        conv.forward_prepared(xd, pf, bd, None, yr2)
+        assert np.array_equal(host(yr2).view(np.uint32), relu_ref.view(np.uint32))
+
+
 @pytest.mark.parametrize("case", [(2, 16, 13, 13, 32, 3, 2, 0), (3, 16, 28, 27, 64, 3, 2, 0), (1, 16, 111, 111, 32, 3, 2, 0),
                                   (2, 16, 9, 10, 128, 3, 2, 0), (2, 24, 12, 12, 32, 3, 2, 0), (3, 16, 12, 14, 32, 3, 2, 0), (5, 16, 5, 6, 32, 3, 2, 0)], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
 def test_conv2d_dgrad_register_direct_opt_in_tiles(T, case, monkeypatch):
