@@ -46,16 +46,11 @@ void ktimer_end(hipStream_t s);
         if (!(cond)) return ::cnn_amd::fail(CNN_AMD_E_BADARG, __VA_ARGS__); \
     } while (0)
 
-// conv_dgrad_rd.hip's Ci = 16 kernel keeps the whole filter bank as MFMA A operands: register j (0 .. 2.25*Co - 1) of lane l
-// holds w[m16_filter_index(j, l, Co)] ([Co][16][3][3] layout).  The prepared copy is img[j*64 + l] (one coalesced load per j).
-__host__ __device__ inline int m16_filter_index(int j, int lane, int Co) {
-    const int n = lane & 15, k = lane >> 4;
-    int co, tap;
-    if (j < Co) { co = j; tap = (2 * (k >> 1)) * 3 + 2 * (k & 1); }                                      // class (0,0): k = 2jr + jc
-    else if (j < Co + Co / 2) { co = 2 * (j - Co) + (k >> 1); tap = (2 * (k & 1)) * 3 + 1; }           // class (0,1): k = (channel, jr)
-    else if (j < 2 * Co) { co = 2 * (j - Co - Co / 2) + (k >> 1); tap = 3 + 2 * (k & 1); }            // class (1,0): k = (channel, jc)
-    else { co = 4 * (j - 2 * Co) + k; tap = 4; }                                                        // class (1,1): k = channel
-    return (co * 16 + n) * 9 + tap;
+// conv_dgrad_rd.hip's m16 kernel keeps the filters of a 16-input-channel slice as MFMA A operands: register j = c4*9 + tap
+// (0 .. 2.25*Co - 1) of lane l = (ci = l & 15, k = l >> 4) holds w[4*c4 + k][16*slice + ci][tap] ([Co][Ci][3][3] layout).
+// The prepared copy is img[(slice*NA + j)*64 + l], NA = 2.25*Co (one coalesced load per j).
+__host__ __device__ inline int m16_filter_index(int j, int lane, int Ci, int slice) {
+    return ((4 * (j / 9) + (lane >> 4)) * Ci + 16 * slice + (lane & 15)) * 9 + j % 9;
 }
 
 constexpr int kWave = 64;          // CDNA wavefront

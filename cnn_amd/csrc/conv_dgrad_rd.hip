@@ -459,49 +459,52 @@ __global__ __launch_bounds__(256) void conv_dgrad_rd_s1_kernel(const DgRdParams 
 }
 
 // ---- Ci = 16 (conv_layer_2 of the reference net): the WHOLE filter bank as MFMA A operands in registers -----------------
-// v_mfma_f32_16x16x4_f32: M = the 16 input channels, N = 16 consecutive grid pixels, K = 4.  Per parity class the K axis is
-//     (0,0): the 4 taps of one dy channel        -> CO   MFMA steps, A = w[co][ci][2jr][2jc],          k = 2jr + jc
-//     (0,1): 2 taps (jr) x 2 dy channels          -> CO/2 steps,      A = w[2p + (k>>1)][ci][2(k&1)][1]
-//     (1,0): 2 taps (jc) x 2 dy channels          -> CO/2 steps,      A = w[2p + (k>>1)][ci][1][2(k&1)]
-//     (1,1): 1 tap x 4 dy channels                -> CO/4 steps,      A = w[4q + k][ci][1][1]
-// = 2.25 CO steps per 16 pixels with no zero padding in M, N or K, and the 9*CO*16 filter values are exactly 2.25*CO lane
-// registers (72 for CO = 32) that a wave loads ONCE from the reference's own layout -- no LDS, no prepared copy, no filter
-// traffic in the loop.  The only streamed operand is dy: one 4-byte buffer load per MFMA step and lane (k-slot k of a lane
-// selects its tap / channel; out-of-range taps read 0 through an out-of-range buffer offset).
+// v_mfma_f32_16x16x4_f32: M = 16 input channels (one slice of Ci per wave), N = 16 consecutive grid pixels, K = 4 dy channels
+// of ONE filter tap: step (c4, tap) multiplies A = w[4 c4 + k][ci][tap] with B = D_tap of channel 4 c4 + k, where the tap picks
+// the class it belongs to ((0,0): taps 0 2 6 8 <- D00 D01 D10 D11 | (0,1): 1 7 <- D00 D10 | (1,0): 3 5 <- D00 D01 | (1,1): 4 <- D00)
+// = 2.25 CO steps per 16 pixels with no zero padding in M, N or K.  The 9*CO*16 filter values of a slice are exactly 2.25*CO
+// lane registers (72 for CO = 32, 144 for 64) that a wave loads ONCE -- no LDS and no filter traffic in the loop.  The only
+// streamed operand is dy: per 4 channels (9 steps) a lane loads TWO 8-byte pairs (rows u and u-1, columns v-1 | v) of its
+// channel; rows outside the image read 0 through an out-of-range buffer offset, border columns shift the pair and pick.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kM16OOB = 0x7ffffffcu;
 
-template <int CO, int NW>
+template <int CO, int NW, bool PREP>
 __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdParams p) {
-    constexpr int CI = 16, C4 = CO / 4, NA = CO * 9 / 4;
-    constexpr int NB = 4;  // ring of granules (one 4-channel step: 9 loads, 9 MFMAs); three granules in flight
+    constexpr int C4 = CO / 4, NA = CO * 9 / 4;
+    constexpr int NB = 4;  // ring of granules (4 dy channels: two 8-byte loads, 9 MFMA steps); three granules in flight
     static_assert(C4 % NB == 0, "static ring indices");
     const int lane = threadIdx.x & 63;
     const int n = lane & 15, k = lane >> 4;
-    const int wave_id = blockIdx.x * NW + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * NW;
+    // Ci = 16*slices: a wave owns one 16-channel slice; the slices of a pixel group sit side by side in a workgroup (their dy
+    // reads hit L1)
+    const int slices = p.Ci >> 4;
+    const int wid = blockIdx.x * NW + (threadIdx.x >> 6);
+    const int slice = wid % slices, wave_id = wid / slices;
+    const int nwaves = p.tiles;  // (tiles: pixel partitions, set by the host)
     const int groups = (p.pixels + 15) >> 4;
-    if (wave_id >= groups) return;
-    float wa[NA];  // [0, CO): class (0,0) | [CO, 1.5 CO): (0,1) | [1.5 CO, 2 CO): (1,0) | [2 CO, 2.25 CO): (1,1)
-    if (p.tr == 2) {
+    if (wave_id >= nwaves || wave_id >= groups) return;
+    float wa[NA];  // [c4*9 + tap]
+    if constexpr (PREP) {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) wa[j] = p.w[j * 64 + lane];
+        for (int j = 0; j < NA; ++j) wa[j] = p.w[(slice * NA + j) * 64 + lane];
     } else {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) wa[j] = p.w[m16_filter_index(j, lane, CO)];
+        for (int j = 0; j < NA; ++j) wa[j] = p.w[m16_filter_index(j, lane, p.Ci, slice)];
     }
     const int plane = p.Ho * p.Wo;
     const size_t hw = (size_t)p.H * p.W;
     const unsigned chs = (unsigned)hw * 4u;
     const bool odd = (p.W & 1) != 0;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)p.B * CO * plane * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dx, 0, (int)((unsigned)p.B * CI * (unsigned)hw * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dx, 0, (int)((unsigned)p.B * p.Ci * (unsigned)hw * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t mrs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.relu_below ? p.relu_below : p.dx), 0, (int)((unsigned)p.B * CI * (unsigned)hw * 4u), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.relu_below ? p.relu_below : p.dx), 0, (int)((unsigned)p.B * p.Ci * (unsigned)hw * 4u), 0x00020000);
     struct Loc {
-        unsigned o00, o01, o10, o11;  // dy byte offsets of this lane's k-slot per class (or out of range: reads 0)
-        unsigned x0, x1;              // dx byte offsets of rows 2u, 2u+1 at column 2v, channel 4k (or out of range: no store)
-        bool w1;                      // column 2v+1 exists (false only in the last column of an odd W)
+        unsigned o0, o1;  // dy byte offsets of this lane's pair in rows u, u-1 (channel k of a granule), or out of range: reads 0
+        bool ca, cb;      // column case: a: pair = (v-1, v) | b: v = 0, pair = (0, 1) | neither: v = Wo, pair = (Wo-2, Wo-1)
+        unsigned x0, x1;  // dx byte offsets of rows 2u, 2u+1 at column 2v, channel 4k (or out of range: no store)
+        bool w1;          // column 2v+1 exists (false only in the last column of an odd W)
     };
     auto locate = [&](int g, Loc& L) {
         const int pix = g * 16 + n;
@@ -511,35 +514,25 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdPa
         const int rem = pp - b * p.UV;
         const int u = fdiv(rem, p.m_v, p.V);
         const int v = rem - u * p.V;
-        const unsigned base = (unsigned)(b * CO * plane + u * p.Wo + v) * 4u;
-        // D[jr][jc] = dy[co][u-jr][v-jc] of dy channel (step base + cosub)
-        auto off = [&](int jr, int jc, int cosub) -> unsigned {
-            const bool ok = live && u - jr >= 0 && u - jr < p.Ho && v - jc >= 0 && v - jc < p.Wo;
-            return ok ? base - (unsigned)(jr * p.Wo + jc) * 4u + (unsigned)(cosub * plane) * 4u : kM16OOB;
-        };
-        L.o00 = off(k >> 1, k & 1, 0);
-        L.o01 = off(k & 1, 0, k >> 1);
-        L.o10 = off(0, k & 1, k >> 1);
-        L.o11 = off(0, 0, k);
-        const unsigned xb = (unsigned)(((size_t)b * CI + 4 * k) * hw + (size_t)(2 * u) * p.W + 2 * v) * 4u;
+        L.cb = v == 0;
+        L.ca = !L.cb && v < p.Wo;
+        const int cs = L.ca ? v - 1 : (L.cb ? 0 : p.Wo - 2);  // (v <= Wo always: V = Wo + 1)
+        const unsigned base = (unsigned)((b * CO + k) * plane + u * p.Wo + cs) * 4u;
+        L.o0 = (live && u < p.Ho) ? base : kM16OOB;
+        L.o1 = (live && u >= 1) ? base - (unsigned)p.Wo * 4u : kM16OOB;
+        const unsigned xb = (unsigned)(((size_t)b * p.Ci + 16 * slice + 4 * k) * hw + (size_t)(2 * u) * p.W + 2 * v) * 4u;
         L.x0 = live ? xb : kM16OOB;
         L.x1 = (live && 2 * u + 1 < p.H) ? xb + (unsigned)p.W * 4u : kM16OOB;
         L.w1 = 2 * v + 1 < p.W;
     };
-    auto load_g = [&](float (&buf)[9], int c4, const Loc& L) {
+    auto load_g = [&](v2f (&buf)[2], int c4, const Loc& L) {
         const int so = c4 * 4 * plane * 4;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) buf[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)L.o00, so + c * plane * 4, 0));
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            buf[4 + pr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)L.o01, so + 2 * pr * plane * 4, 0));
-            buf[6 + pr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)L.o10, so + 2 * pr * plane * 4, 0));
-        }
-        buf[8] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)L.o11, so, 0));
+        buf[0] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)L.o0, so, 0));
+        buf[1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)L.o1, so, 0));
     };
     Loc cur, nxt;
     locate(wave_id, cur);
-    float ring[NB][9];
+    v2f ring[NB][2];
 #pragma unroll
     for (int i = 0; i < NB - 1; ++i) load_g(ring[i], i, cur);
     for (int g = wave_id; g < groups; g += nwaves) {
@@ -564,21 +557,24 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdPa
             const int gn = c4 + NB - 1;
             load_g(ring[gn % NB], gn % C4, gn < C4 ? cur : nxt);
             RD_PIPE_FENCE(ring[c4 % NB][0]);
-            const float* bv = ring[c4 % NB];
+            const v2f r0 = ring[c4 % NB][0], r1 = ring[c4 % NB][1];
+            const float d00 = cur.ca ? r0.y : (cur.cb ? r0.x : 0.f), d01 = cur.ca ? r0.x : (cur.cb ? 0.f : r0.y);  // D[0][jc]
+            const float d10 = cur.ca ? r1.y : (cur.cb ? r1.x : 0.f), d11 = cur.ca ? r1.x : (cur.cb ? 0.f : r1.y);  // D[1][jc]
+            const float* a = &wa[c4 * 9];
             // issue order pinned: an accumulator is reused every other step at the earliest (a dependent MFMA waits 40 cycles,
             // an independent one issues after 32; hipcc's own order put the four class-(0,0) steps back to back)
 #define M16_STEP(ACC, A_, B_)                                              \
     ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(A_, B_, ACC, 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0)
-            M16_STEP(acc[1], wa[CO + 2 * c4 + 0], bv[4]);
-            M16_STEP(acc[0], wa[4 * c4 + 0], bv[0]);
-            M16_STEP(acc[2], wa[CO + CO / 2 + 2 * c4 + 0], bv[6]);
-            M16_STEP(acc[0], wa[4 * c4 + 1], bv[1]);
-            M16_STEP(acc[3], wa[2 * CO + c4], bv[8]);
-            M16_STEP(acc[0], wa[4 * c4 + 2], bv[2]);
-            M16_STEP(acc[1], wa[CO + 2 * c4 + 1], bv[5]);
-            M16_STEP(acc[0], wa[4 * c4 + 3], bv[3]);
-            M16_STEP(acc[2], wa[CO + CO / 2 + 2 * c4 + 1], bv[7]);
+            M16_STEP(acc[1], a[1], d00);
+            M16_STEP(acc[0], a[0], d00);
+            M16_STEP(acc[2], a[3], d00);
+            M16_STEP(acc[0], a[2], d01);
+            M16_STEP(acc[3], a[4], d00);
+            M16_STEP(acc[0], a[6], d10);
+            M16_STEP(acc[1], a[7], d10);
+            M16_STEP(acc[0], a[8], d11);
+            M16_STEP(acc[2], a[5], d01);
 #undef M16_STEP
         }
         // epilogue, branch-free per lane: buffer stores whose offset is out of range for dead lanes / the row behind the tensor
@@ -612,12 +608,15 @@ struct DgRdPlan {
 };
 
 inline bool m16_wanted(const cnn_conv2d_desc* d) {
-    if (d->s != 2 || d->Ci != 16 || d->Co != 32) return false;
+    // (Ci, Co) = (16, 32) | (32, 64): 72 | 144 filter registers per wave
+    if (d->s != 2 || !((d->Ci == 16 && d->Co == 32) || (d->Ci == 32 && d->Co == 64))) return false;
     if ((long long)d->B * d->Co * cnn_conv2d_out_dim(d->H, 3, 2, 0) * cnn_conv2d_out_dim(d->W, 3, 2, 0) >= (1ll << 29) ||
         (long long)d->B * d->Ci * d->H * d->W >= (1ll << 29))
         return false;  // (32-bit buffer offsets)
     const char* e = getenv("CNN_AMD_DGRAD_M16");
-    return !(e && atoi(e) == 0);
+    if (e && atoi(e) == 0) return false;
+    if (d->Ci == 32 && e && atoi(e) == 1) return false;  // (=1: only the Ci = 16 shape, for A/B runs)
+    return true;
 }
 
 bool make_plan(const cnn_conv2d_desc* d, DgRdPlan* pl) {
@@ -658,8 +657,12 @@ bool make_plan(const cnn_conv2d_desc* d, DgRdPlan* pl) {
     if (pl->m16) {  // persistent waves over 16-pixel groups
         int per_cu = getenv("CNN_AMD_DGRAD_M16_WG") ? atoi(getenv("CNN_AMD_DGRAD_M16_WG")) : 2;
         if (per_cu < 1 || per_cu > 8) per_cu = 2;
-        const long long g = (pixels + 15) / 16, needg = (g + pl->nw - 1) / pl->nw;
-        pl->blocks_x = (int)(needg < (long long)per_cu * kNumCU ? needg : (long long)per_cu * kNumCU);
+        const int slices = d->Ci / 16;
+        const long long g = (pixels + 15) / 16;
+        long long parts = (long long)per_cu * kNumCU * pl->nw / slices;  // pixel partitions: waves / slices
+        if (parts > g) parts = g;
+        p.tiles = (int)parts;
+        pl->blocks_x = (int)((parts * slices + pl->nw - 1) / pl->nw);
     }
     return true;
 }
@@ -717,9 +720,14 @@ int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const floa
     pl.p.dy = dy; pl.p.w = w ? w : img; pl.p.tr = w ? 0 : prepared_transposed(); pl.p.relu_below = relu_below; pl.p.dx = dx;
     if (pl.m16) {
         pl.p.tr = w ? 0 : 2;  // prepared: lane-major operand order (m16_filter_index); otherwise gathered from the reference layout
-        CNN_KLAUNCH(s, relu_below ? "conv_dgrad_rd<2,32,m16>/dgrad+relu" : "conv_dgrad_rd<2,32,m16>/dgrad",
-                    (conv_dgrad_m16_s2_kernel<32, 4><<<pl.blocks_x, 256, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H,
-                    d->W, d->Co, d->k, d->s, d->pad);
+        char nm[64];
+        snprintf(nm, sizeof(nm), "conv_dgrad_rd<2,%d,m16>/dgrad%s", d->Co, relu_below ? "+relu" : "");
+#define M16(CO_, PREP_)                                                                                                              \
+    CNN_KLAUNCH(s, nm, (conv_dgrad_m16_s2_kernel<CO_, 4, PREP_><<<pl.blocks_x, 256, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, \
+                d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad)
+        if (d->Co == 32) { if (pl.p.tr == 2) M16(32, true); else M16(32, false); }
+        else { if (pl.p.tr == 2) M16(64, true); else M16(64, false); }
+#undef M16
         return CNN_AMD_OK;
     }
     if (w && ws && ws_bytes >= pl.img_floats * sizeof(float) && prepared_transposed()) {
