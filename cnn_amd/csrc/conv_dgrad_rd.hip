@@ -469,7 +469,9 @@ __global__ __launch_bounds__(256) void conv_dgrad_rd_s1_kernel(const DgRdParams 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kM16OOB = 0x7ffffffcu;
 
-template <int CO, int NW, bool PREP>
+// KS > 1 (Co = KS*CO): the dy channels are split over KS waves of a workgroup (NW = slices*KS waves: one pixel partition per
+// workgroup); wave `half` 1.. hands its partial sums to wave 0 of the same slice through LDS (one barrier per pixel group).
+template <int CO, int NW, bool PREP, int KS>
 __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdParams p) {
     constexpr int C4 = CO / 4, NA = CO * 9 / 4;
     constexpr int NB = 4;  // ring of granules (4 dy channels: two 8-byte loads, 9 MFMA steps); three granules in flight
@@ -480,23 +482,23 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdPa
     // reads hit L1)
     const int slices = p.Ci >> 4;
     const int wid = blockIdx.x * NW + (threadIdx.x >> 6);
-    const int slice = wid % slices, wave_id = wid / slices;
+    const int slice = wid % slices, half = KS > 1 ? (wid / slices) % KS : 0, wave_id = wid / (slices * KS);
     const int nwaves = p.tiles;  // (tiles: pixel partitions, set by the host)
     const int groups = (p.pixels + 15) >> 4;
     if (wave_id >= nwaves || wave_id >= groups) return;
     float wa[NA];  // [c4*9 + tap]
     if constexpr (PREP) {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) wa[j] = p.w[(slice * NA + j) * 64 + lane];
+        for (int j = 0; j < NA; ++j) wa[j] = p.w[((half * slices + slice) * NA + j) * 64 + lane];
     } else {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) wa[j] = p.w[m16_filter_index(j, lane, p.Ci, slice)];
+        for (int j = 0; j < NA; ++j) wa[j] = p.w[half * CO * p.Ci * 9 + m16_filter_index(j, lane, p.Ci, slice)];
     }
     const int plane = p.Ho * p.Wo;
     const size_t hw = (size_t)p.H * p.W;
     const unsigned chs = (unsigned)hw * 4u;
     const bool odd = (p.W & 1) != 0;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)p.B * CO * plane * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)p.B * CO * KS * plane * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dx, 0, (int)((unsigned)p.B * p.Ci * (unsigned)hw * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t mrs =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.relu_below ? p.relu_below : p.dx), 0, (int)((unsigned)p.B * p.Ci * (unsigned)hw * 4u), 0x00020000);
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdPa
         L.cb = v == 0;
         L.ca = !L.cb && v < p.Wo;
         const int cs = L.ca ? v - 1 : (L.cb ? 0 : p.Wo - 2);  // (v <= Wo always: V = Wo + 1)
-        const unsigned base = (unsigned)((b * CO + k) * plane + u * p.Wo + cs) * 4u;
+        const unsigned base = (unsigned)((b * CO * KS + half * CO + k) * plane + u * p.Wo + cs) * 4u;
         L.o0 = (live && u < p.Ho) ? base : kM16OOB;
         L.o1 = (live && u >= 1) ? base - (unsigned)p.Wo * 4u : kM16OOB;
         const unsigned xb = (unsigned)(((size_t)b * p.Ci + 16 * slice + 4 * k) * hw + (size_t)(2 * u) * p.W + 2 * v) * 4u;
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdPa
         // the fused ReLU::backward mask (relu.cpp:38) of this group's 8 output pairs is requested now and used in the epilogue
         // (a lane in the last column of an odd W reads the pair one element to the left and uses its second half)
         v2f mk[4][2];
-        if (p.relu_below) {
+        if (p.relu_below && half == 0) {
             const unsigned m0 = (cur.w1 || cur.x0 == kM16OOB) ? cur.x0 : cur.x0 - 4u, m1 = (cur.w1 || cur.x1 == kM16OOB) ? cur.x1 : cur.x1 - 4u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -577,6 +579,27 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdPa
             M16_STEP(acc[2], a[5], d01);
 #undef M16_STEP
         }
+        if constexpr (KS > 1) {
+            __shared__ float red[2][KS - 1][NW / KS][16][64];  // two buffers, alternating per pixel group: one barrier per group
+            const int rb = ((g - wave_id) / nwaves) & 1;
+            if (half > 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[rb][half - 1][slice][c * 4 + r][lane] = acc[c][r];
+            }
+            __syncthreads();
+            if (half > 0) {
+                cur = nxt;
+                continue;
+            }
+#pragma unroll
+            for (int h = 0; h < KS - 1; ++h)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[c][r] += red[rb][h][slice][c * 4 + r][lane];
+        }
         // epilogue, branch-free per lane: buffer stores whose offset is out of range for dead lanes / the row behind the tensor
         const unsigned pp0 = cur.w1 ? cur.x0 : kM16OOB, pp1 = cur.w1 ? cur.x1 : kM16OOB;  // (pw = 0,1) pairs
         const unsigned ss0 = cur.w1 ? kM16OOB : cur.x0, ss1 = cur.w1 ? kM16OOB : cur.x1;  // single element, last column of an odd W
@@ -608,14 +631,15 @@ struct DgRdPlan {
 };
 
 inline bool m16_wanted(const cnn_conv2d_desc* d) {
-    // (Ci, Co) = (16, 32) | (32, 64): 72 | 144 filter registers per wave
-    if (d->s != 2 || !((d->Ci == 16 && d->Co == 32) || (d->Ci == 32 && d->Co == 64))) return false;
+    // (Ci, Co) = (16, 32) | (32, 64) | (64, 128: dy channels split over two waves): 72 | 144 | 144 filter registers per wave
+    if (d->s != 2 || !((d->Ci == 16 && d->Co == 32) || (d->Ci == 32 && d->Co == 64) || (d->Ci == 64 && d->Co == 128))) return false;
     if ((long long)d->B * d->Co * cnn_conv2d_out_dim(d->H, 3, 2, 0) * cnn_conv2d_out_dim(d->W, 3, 2, 0) >= (1ll << 29) ||
         (long long)d->B * d->Ci * d->H * d->W >= (1ll << 29))
         return false;  // (32-bit buffer offsets)
     const char* e = getenv("CNN_AMD_DGRAD_M16");
     if (e && atoi(e) == 0) return false;
-    if (d->Ci == 32 && e && atoi(e) == 1) return false;  // (=1: only the Ci = 16 shape, for A/B runs)
+    if (d->Ci >= 32 && e && atoi(e) == 1) return false;  // (=1: only the Ci = 16 shape, =2: not the split Co = 128 shape; for A/B runs)
+    if (d->Ci == 64 && e && atoi(e) == 2) return false;
     return true;
 }
 
@@ -660,9 +684,10 @@ bool make_plan(const cnn_conv2d_desc* d, DgRdPlan* pl) {
         const int slices = d->Ci / 16;
         const long long g = (pixels + 15) / 16;
         long long parts = (long long)per_cu * kNumCU * pl->nw / slices;  // pixel partitions: waves / slices
+        if (d->Co == 128) parts = (getenv("CNN_AMD_DGRAD_M16_WG") ? per_cu : 1) * kNumCU;  // one 8-wave workgroup (4 slices x 2 halves) per partition
         if (parts > g) parts = g;
         p.tiles = (int)parts;
-        pl->blocks_x = (int)((parts * slices + pl->nw - 1) / pl->nw);
+        pl->blocks_x = d->Co == 128 ? (int)parts : (int)((parts * slices + pl->nw - 1) / pl->nw);
     }
     return true;
 }
@@ -722,11 +747,12 @@ int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const floa
         pl.p.tr = w ? 0 : 2;  // prepared: lane-major operand order (m16_filter_index); otherwise gathered from the reference layout
         char nm[64];
         snprintf(nm, sizeof(nm), "conv_dgrad_rd<2,%d,m16>/dgrad%s", d->Co, relu_below ? "+relu" : "");
-#define M16(CO_, PREP_)                                                                                                              \
-    CNN_KLAUNCH(s, nm, (conv_dgrad_m16_s2_kernel<CO_, 4, PREP_><<<pl.blocks_x, 256, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, \
-                d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad)
-        if (d->Co == 32) { if (pl.p.tr == 2) M16(32, true); else M16(32, false); }
-        else { if (pl.p.tr == 2) M16(64, true); else M16(64, false); }
+#define M16(CO_, PREP_, NW_, KS_)                                                                                                        \
+    CNN_KLAUNCH(s, nm, (conv_dgrad_m16_s2_kernel<CO_, NW_, PREP_, KS_><<<pl.blocks_x, NW_ * 64, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", \
+                d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad)
+        if (d->Co == 32) { if (pl.p.tr == 2) M16(32, true, 4, 1); else M16(32, false, 4, 1); }
+        else if (d->Co == 64) { if (pl.p.tr == 2) M16(64, true, 4, 1); else M16(64, false, 4, 1); }
+        else { if (pl.p.tr == 2) M16(64, true, 8, 2); else M16(64, false, 8, 2); }
 #undef M16
         return CNN_AMD_OK;
     }

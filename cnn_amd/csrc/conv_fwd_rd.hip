@@ -418,8 +418,10 @@ __global__ __launch_bounds__(256) void fwd_rd_prepare_kernel(const FwdRdPrepBatc
         const int total = j.Co * j.Ci * 9;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
             if (j.tr == 2) {  // lane-major MFMA A operands of the Ci = 16 data-gradient kernel
-                const int na = j.Co * 9 / 4, jj = (i >> 6) % na, slice = (i >> 6) / na;
-                j.img[i] = j.w[m16_filter_index(jj, i & 63, j.Ci, slice)];
+                // (Co = 128: two halves of 64 dy channels, [half][slice][j][lane])
+                const int coh = j.Co > 64 ? j.Co / 2 : j.Co, na = coh * 9 / 4, slices = j.Ci / 16;
+                const int jj = (i >> 6) % na, blk = (i >> 6) / na, slice = blk % slices, half = blk / slices;
+                j.img[i] = j.w[half * coh * j.Ci * 9 + m16_filter_index(jj, i & 63, j.Ci, slice)];
             } else if (j.tr) {
                 const int ci = i % j.Ci, r = i / j.Ci, tap = r % 9, co = r / 9;
                 j.img[i] = j.w[((size_t)co * j.Ci + ci) * 9 + tap];
