@@ -8,6 +8,8 @@ using namespace cnn_amd;
 
 namespace cnn_amd {
 size_t igemm_workspace_floats(const cnn_conv2d_desc* d);  // conv_igemm.hip
+void wgrad_defer_reduce(bool on);                          // conv_wgrad.hip: with defer_join the final slab reductions of the
+int wgrad_flush_reduces(hipStream_t s);                    // weight gradients run in one launch just before the join
 }
 
 namespace {
@@ -43,6 +45,7 @@ size_t cnn_conv2d_backward_workspace_bytes(const cnn_conv2d_desc* d) {
 int cnn_amd_side_stream_join(void* stream) {
     SideStream* side = nullptr;
     if (int rc = get_side(&side)) return rc;
+    if (int rc = wgrad_flush_reduces(side->stream)) return rc;
     CNN_HIP_CHECK(hipEventRecord(side->join, side->stream));
     CNN_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), side->join, 0));
     return CNN_AMD_OK;
@@ -60,7 +63,10 @@ int cnn_conv2d_backward(const cnn_conv2d_desc* d, const float* x, const float* d
     char* base = (char*)ws;
     CNN_HIP_CHECK(hipEventRecord(side->fork, main));
     CNN_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
-    if (int rc = cnn_conv2d_backward_weight(d, x, dy, gw, gb, divisor, base + dbytes, ws_bytes - dbytes, side->stream)) return rc;
+    wgrad_defer_reduce(defer_join != 0);
+    const int rcw = cnn_conv2d_backward_weight(d, x, dy, gw, gb, divisor, base + dbytes, ws_bytes - dbytes, side->stream);
+    wgrad_defer_reduce(false);
+    if (rcw) return rcw;
     if (int rc = cnn_conv2d_backward_data(d, dy, w, dx, base, dbytes, main)) return rc;
     if (!defer_join) {
         CNN_HIP_CHECK(hipEventRecord(side->join, side->stream));
@@ -84,7 +90,10 @@ int cnn_conv2d_backward_prepared_relu(const cnn_conv2d_desc* d, const float* x, 
     hipStream_t main = as_stream(stream);
     CNN_HIP_CHECK(hipEventRecord(side->fork, main));
     CNN_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
-    if (int rc = cnn_conv2d_backward_weight(d, x, dy, gw, gb, divisor, ws, ws_bytes, side->stream)) return rc;
+    wgrad_defer_reduce(defer_join != 0);
+    const int rcw = cnn_conv2d_backward_weight(d, x, dy, gw, gb, divisor, ws, ws_bytes, side->stream);
+    wgrad_defer_reduce(false);
+    if (rcw) return rcw;
     if (int rc = relu_below ? cnn_conv2d_backward_data_relu_prepared(d, dy, prepared_dgrad, relu_below, dx, main)
                             : cnn_conv2d_backward_data_prepared(d, dy, prepared_dgrad, dx, main))
         return rc;
@@ -106,7 +115,10 @@ int cnn_conv2d_backward_pooled2_prepared(const cnn_conv2d_desc* d, const float* 
     hipStream_t main = as_stream(stream);
     CNN_HIP_CHECK(hipEventRecord(side->fork, main));
     CNN_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
-    if (int rc = cnn_conv2d_backward_weight_pooled2(d, x, dpool, mask, pooled, gw, gb, divisor, ws, ws_bytes, side->stream)) return rc;
+    wgrad_defer_reduce(defer_join != 0);
+    const int rcw = cnn_conv2d_backward_weight_pooled2(d, x, dpool, mask, pooled, gw, gb, divisor, ws, ws_bytes, side->stream);
+    wgrad_defer_reduce(false);
+    if (rcw) return rcw;
     if (int rc = cnn_conv2d_backward_data_pooled2_prepared(d, dpool, mask, pooled, prepared_dgrad, dx, main)) return rc;
     if (!defer_join) {
         CNN_HIP_CHECK(hipEventRecord(side->join, side->stream));

@@ -344,10 +344,89 @@ __global__ __launch_bounds__(kRedElems * kRedLanes) void slab_reduce(const float
     }
 }
 
+// ---- deferred final reductions ---------------------------------------------------------------------------------------------
+// Conv2D::backward with defer_join (conv_backward.hip) runs the weight-gradient kernels of several layers on one side stream.
+// Their 6 us slab reductions take 20-90 us each when they share the chip with a large kernel and used to sit BETWEEN the
+// layers' gradient kernels; between wgrad_defer_reduce(true) and the join they are only recorded, and
+// wgrad_flush_reduces() runs them all in ONE launch just before the join event (same summation order: bit-identical).
+struct RedJob {
+    const float* in;
+    float* out;
+    float* out_b;
+    int nslots, split_n;
+    unsigned n;
+    float divisor;
+};
+constexpr int kMaxRedJobs = 8;
+struct RedBatch {
+    RedJob job[kMaxRedJobs];
+};
+struct PendingReduces {
+    RedBatch batch;
+    int count = 0;
+    bool defer = false;
+};
+PendingReduces& pending_reduces() {
+    static thread_local PendingReduces p;
+    return p;
+}
+
+__global__ __launch_bounds__(kRedElems * kRedLanes) void slab_reduce_batch(const RedBatch rb) {
+    __shared__ float red[kRedLanes][kRedElems];
+    const RedJob j = rb.job[blockIdx.y];
+    if ((size_t)blockIdx.x * kRedElems >= j.n) return;
+    const int e = threadIdx.x & (kRedElems - 1), sl = threadIdx.x / kRedElems;
+    const size_t i = (size_t)blockIdx.x * kRedElems + e, n = j.n;
+    float acc = 0.f;
+    if (i < n) {  // (the loop of slab_reduce's final stage: same order, same rounding)
+        int s = sl;
+        for (; s + 3 * kRedLanes < j.nslots; s += 4 * kRedLanes) {
+            const float v0 = j.in[(size_t)s * n + i], v1 = j.in[(size_t)(s + kRedLanes) * n + i];
+            const float v2 = j.in[(size_t)(s + 2 * kRedLanes) * n + i], v3 = j.in[(size_t)(s + 3 * kRedLanes) * n + i];
+            acc += v0; acc += v1; acc += v2; acc += v3;
+        }
+        for (; s < j.nslots; s += kRedLanes) acc += j.in[(size_t)s * n + i];
+    }
+    red[sl][e] = acc;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < kRedLanes; ++k) t += red[k][e];
+        if (j.split_n > 0) {
+            const size_t row = i / (j.split_n + 1), col = i - row * (j.split_n + 1);
+            if (col < (size_t)j.split_n) j.out[row * j.split_n + col] = t / j.divisor;
+            else if (j.out_b) j.out_b[row] = t / j.divisor;
+        } else {
+            j.out[i] = t / j.divisor;
+        }
+    }
+}
+
+int flush_reduces(hipStream_t s) {
+    PendingReduces& p = pending_reduces();
+    if (p.count == 0) return CNN_AMD_OK;
+    unsigned most = 0;
+    for (int i = 0; i < p.count; ++i) most = p.batch.job[i].n > most ? p.batch.job[i].n : most;
+    const int jobs = p.count;
+    p.count = 0;
+    CNN_KLAUNCH(s, "slab_reduce/batch", (slab_reduce_batch<<<dim3((most + kRedElems - 1) / kRedElems, jobs), kRedElems * kRedLanes, 0, s>>>(p.batch)),
+                "jobs=%d", jobs);
+    return CNN_AMD_OK;
+}
+
 // sums `nslots` slabs of n floats held in `slabs` into dst (divided by divisor); `tmp` holds >= ceil(nslots/64)*n
 int reduce_slabs(hipStream_t s, const float* slabs, int nslots, size_t n, float* tmp, float* dst, float divisor,
                  const char* tag, int split_n = 0, float* dst_b = nullptr) {
     const unsigned gx = (unsigned)((n + kRedElems - 1) / kRedElems);
+    PendingReduces& pend = pending_reduces();
+    if (pend.defer && !(nslots > 512 || (nslots > 64 && n > 65536)) && n < (1ull << 31)) {
+        if (pend.count == kMaxRedJobs)
+            if (int rc = flush_reduces(s)) return rc;
+        RedJob& j = pend.batch.job[pend.count++];
+        j.in = slabs; j.out = dst; j.out_b = dst_b; j.nslots = nslots; j.split_n = split_n; j.n = (unsigned)n; j.divisor = divisor;
+        return CNN_AMD_OK;
+    }
     // two stages only when one workgroup per 32 elements would walk too many slabs (small slabs are launch-bound: one
     // launch of up to 512 slots x 8 slot-lanes beats two)
     if (nslots > 512 || (nslots > 64 && n > 65536)) {
@@ -566,6 +645,15 @@ int check_desc(const char* who, const cnn_conv2d_desc* d) {
 }
 
 }  // namespace
+
+namespace cnn_amd {
+// conv_backward.hip: record (true) / launch immediately (false) the final slab reductions of this thread's weight gradients
+void wgrad_defer_reduce(bool on) {
+    static const bool off = getenv("CNN_AMD_NO_DEFER_REDUCE") && atoi(getenv("CNN_AMD_NO_DEFER_REDUCE")) != 0;
+    pending_reduces().defer = on && !off;
+}
+int wgrad_flush_reduces(hipStream_t s) { return flush_reduces(s); }
+}  // namespace cnn_amd
 
 extern "C" {
 
