@@ -45,9 +45,16 @@ size_t cnn_conv2d_backward_workspace_bytes(const cnn_conv2d_desc* d) {
 int cnn_amd_side_stream_join(void* stream) {
     SideStream* side = nullptr;
     if (int rc = get_side(&side)) return rc;
-    if (int rc = wgrad_flush_reduces(side->stream)) return rc;
+    // the recorded reductions: on the side stream in front of the join (concurrent with the caller's last kernels: starved,
+    // ~100 us instead of 8, but off the critical path: 491k vs 480k images/s) or, with CNN_AMD_REDUCE_ON_MAIN=1, on the
+    // caller's stream behind it
+    static const bool on_side = !(getenv("CNN_AMD_REDUCE_ON_MAIN") && atoi(getenv("CNN_AMD_REDUCE_ON_MAIN")) != 0);
+    if (on_side)
+        if (int rc = wgrad_flush_reduces(side->stream)) return rc;
     CNN_HIP_CHECK(hipEventRecord(side->join, side->stream));
     CNN_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), side->join, 0));
+    if (!on_side)
+        if (int rc = wgrad_flush_reduces(as_stream(stream))) return rc;
     return CNN_AMD_OK;
 }
 
