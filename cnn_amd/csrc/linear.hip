@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kNeur * kFG) void linear_bwd_fused(const float* __r
         acc[j] = 0.f;
         wr[j] = (live && j < out) ? w[(size_t)i * out + j] : 0.f;
     }
-#pragma unroll 8
+#pragma unroll 16  // (B = 256: all 16 x loads of a thread in flight at once -- the kernel shares the chip with an HBM-bound one)
     for (int b = bb; b < be; ++b) {
         const float xv = live ? x[(size_t)b * in + i] : 0.f;
         const float* d = dy + (size_t)b * out;
