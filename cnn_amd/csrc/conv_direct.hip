@@ -1072,14 +1072,20 @@ int direct_conv_dgrad_pooled(const cnn_conv2d_desc* d, const float* dpool, const
     const int U = (d->H + 1) / 2, V = (d->W + 1) / 2, U2 = (U + 1) / 2, V2 = (V + 1) / 2;
     const int ipi = (U2 * V2 + 63) / 64;
     const long long witems = (long long)d->B * ipi;
+    // CNN_AMD_DX0_GRID=n: at most n workgroups (grid-stride over the rest) -- this HBM-bound kernel usually runs BESIDE the
+    // latency-bound head of the net (deferred launch, cnn_amd/pynet.py); a smaller grid leaves wave slots and memory queues
+    // to those kernels
+    unsigned grid = wave_grid(witems);
+    if (const char* e = getenv("CNN_AMD_DX0_GRID"))
+        if (atoi(e) > 0 && (unsigned)atoi(e) < grid) grid = (unsigned)atoi(e);
     if (pooled)
         CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>+pool",
-                    (conv_dgrad_pool_pk_3_16_3_2<2, true><<<wave_grid(witems), kBlock, 0, s>>>(dpool, mask, pooled, (const v2f*)ws, dx, d->B, d->H,
+                    (conv_dgrad_pool_pk_3_16_3_2<2, true><<<grid, kBlock, 0, s>>>(dpool, mask, pooled, (const v2f*)ws, dx, d->B, d->H,
                                                                                               d->W, Ho, Wo, ipi, div_magic(ipi), div_magic(V2))),
                     CONV_TAG(d));
     else
         CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>+poolm",
-                    (conv_dgrad_pool_pk_3_16_3_2<2, false><<<wave_grid(witems), kBlock, 0, s>>>(dpool, mask, nullptr, (const v2f*)ws, dx, d->B, d->H,
+                    (conv_dgrad_pool_pk_3_16_3_2<2, false><<<grid, kBlock, 0, s>>>(dpool, mask, nullptr, (const v2f*)ws, dx, d->B, d->H,
                                                                                                d->W, Ho, Wo, ipi, div_magic(ipi), div_magic(V2))),
                     CONV_TAG(d));
     return CNN_AMD_OK;
