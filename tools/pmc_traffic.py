@@ -37,9 +37,12 @@ def canonical(name):
     m = re.match(r"conv_dgrad_rd_s2_kernel<(\d+),\d+,\d+,\d+(,(true|false))?>$", name)
     if m:
         return f"conv_dgrad_rd<2,{m.group(1)}>"
-    m = re.match(r"conv_dgrad_m16_s2_kernel<(\d+),\d+>$", name)
+    m = re.match(r"conv_dgrad_m16_s2_kernel<(\d+),\d+,(true|false),(\d+)>$", name)
+    if m:  # (CO per wave, NW, prepared, dy-channel split)
+        return f"conv_dgrad_rd<2,{int(m.group(1)) * int(m.group(3))},m16>"
+    m = re.match(r"conv_fwd_m16_kernel<(\d+),(\d+),\d+,(true|false),\d+>$", name)
     if m:
-        return f"conv_dgrad_rd<2,{m.group(1)},m16>"
+        return f"conv_fwd_rd<{m.group(1)},{m.group(2)},m16>"
     m = re.match(r"conv_fwd_rd_kernel<(\d+),(\d+),(\d+),\d+,\d+>$", name)
     if m:
         return f"conv_fwd_rd<{m.group(1)},{m.group(2)},{m.group(3)}>"
