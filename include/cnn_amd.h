@@ -123,7 +123,8 @@ size_t cnn_conv2d_backward_workspace_bytes(const cnn_conv2d_desc* d);
  * call's half of ws) belong to the side stream until cnn_amd_side_stream_join(stream) -- lets the weight gradients of
  * layer L overlap the whole backward of layers L-1.. (the caller joins once, before it reads the gradient arena).  With
  * defer_join = 1 the final reduction of the layer's partial gradient slabs (held in ws) is only recorded; the join launches
- * the recorded reductions of the calling thread in one batch: ws must not be reused, and gw/gb are undefined, until then. */
+ * the recorded reductions of the calling thread in one batch (join from the thread that made the calls): ws must not be
+ * reused, and gw/gb are undefined, until then. */
 int cnn_conv2d_backward(const cnn_conv2d_desc* d, const float* x, const float* dy, const float* w, float* gw, float* gb,
                         float* dx, float divisor, void* ws, size_t ws_bytes, void* stream, int defer_join);
 int cnn_amd_side_stream_join(void* stream);
