@@ -224,28 +224,33 @@ __host__ __device__ inline int m16f_filter_index(int i, int Ci) {
     return ((16 * slice + (lane & 15)) * Ci + 4 * (j / 9) + (lane >> 4)) * 9 + j % 9;
 }
 
-template <int S, int CI, int NW, bool PREP, int NB>  // NB: ring of granules (one c4: three 12-byte loads, nine MFMA steps), NB-1 in flight
+// NB: ring of granules (one c4: three 12-byte loads, nine MFMA steps per slice), NB-1 in flight; MS: 16-channel slices per wave
+// (2 where the registers allow: every input load then feeds two MFMA chains and the per-group overhead is paid half as often)
+template <int S, int CI, int NW, bool PREP, int NB, int MS>
 __global__ __launch_bounds__(NW * 64) void conv_fwd_m16_kernel(const FwdRdParams p) {
     constexpr int C4 = CI / 4, NA = C4 * 9;
     static_assert(C4 % NB == 0, "static ring indices");
     const int lane = threadIdx.x & 63;
     const int n = lane & 15, k = lane >> 4;
-    const int slices = p.Co >> 4, parts = p.tiles;  // (tiles: pixel partitions, set by the host)
+    const int slices = (p.Co >> 4) / MS, parts = p.tiles;  // (wave slices of 16*MS channels; tiles: pixel partitions, set by the host)
     const int wid = blockIdx.x * NW + (threadIdx.x >> 6);
     const int slice = wid % slices, part = wid / slices;
     const int groups = (p.pixels + 15) >> 4;
     if (part >= parts || part >= groups) return;
-    float wa[NA];
-    if constexpr (PREP) {
+    float wa[MS][NA], bs[MS][4];
 #pragma unroll
-        for (int j = 0; j < NA; ++j) wa[j] = p.img[(slice * NA + j) * 64 + lane];
-    } else {
+    for (int m = 0; m < MS; ++m) {
+        const int sl = slice * MS + m;  // 16-channel slice
+        if constexpr (PREP) {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) wa[j] = p.w[((16 * slice + n) * CI + 4 * (j / 9) + k) * 9 + j % 9];
+            for (int j = 0; j < NA; ++j) wa[m][j] = p.img[(sl * NA + j) * 64 + lane];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) wa[m][j] = p.w[((16 * sl + n) * CI + 4 * (j / 9) + k) * 9 + j % 9];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bs[m][r] = p.bias[16 * sl + 4 * k + r];
     }
-    float bs[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bs[r] = p.bias[16 * slice + 4 * k + r];
     const long long dbg_t0 = p.dbg ? clock64() : 0;
     long long dbg_t1 = 0;
     int dbg_groups = 0;
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_m16_kernel(const FwdRdParams
         const int b = fdiv(pic, p.m_howo, p.HoWo), rem = pic - b * p.HoWo;
         const int pr = fdiv(rem, p.m_wo, p.Wo), q = rem - pr * p.Wo;
         xoff = (unsigned)((b * CI + k) * (int)plane + (S * pr) * p.W + S * q);
-        yoff = (unsigned)((b * p.Co + 16 * slice + 4 * k) * p.HoWo + rem);
+        yoff = (unsigned)((b * p.Co + 16 * MS * slice + 4 * k) * p.HoWo + rem);
     };
     // (12-byte loads through a pointer: hipcc lowers __builtin_amdgcn_raw_buffer_load_b96 to ONE dword load here)
     auto load_g = [&](f3u (&buf)[3], int c4, unsigned xoff) {
@@ -276,10 +281,13 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_m16_kernel(const FwdRdParams
     for (int g = part; g < groups; g += parts) {
         locate(g + parts, nxoff, nyoff, nlive);
         constexpr int NACC = 2;  // partial sums, used round-robin (a dependent MFMA waits for the previous write-back)
-        f32x4 acc[NACC];
-        acc[0] = f32x4{bs[0], bs[1], bs[2], bs[3]};
+        f32x4 acc[MS][NACC];
 #pragma unroll
-        for (int a = 1; a < NACC; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < MS; ++m) {
+            acc[m][0] = f32x4{bs[m][0], bs[m][1], bs[m][2], bs[m][3]};
+#pragma unroll
+            for (int a = 1; a < NACC; ++a) acc[m][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int c4 = 0; c4 < C4; ++c4) {
             const int gn = c4 + NB - 1;  // requested now (from c4 = C4-3 on: the first granules of the next group)
@@ -290,15 +298,19 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_m16_kernel(const FwdRdParams
                 const f3u v = xb[c4 % NB][i / 3];
                 const float bv = i % 3 == 0 ? v.x : i % 3 == 1 ? v.y : v.z;
                 const int a = (c4 * 9 + i) % NACC;
-                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c4 * 9 + i], bv, acc[a], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MS; ++m) {
+                    acc[m][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][c4 * 9 + i], bv, acc[m][a], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         if (live) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = acc[0][r] + acc[1][r];
-                const size_t o = (size_t)yoff + (size_t)r * p.HoWo;
+            for (int mr = 0; mr < MS * 4; ++mr) {
+                const int m = mr >> 2, r = mr & 3;
+                const float v = acc[m][0][r] + acc[m][1][r];
+                const size_t o = (size_t)yoff + (size_t)(16 * m + r) * p.HoWo;
                 if (p.y) p.y[o] = v;
                 if (p.y2) p.y2[o] = v >= 0.f ? v : 0.f;  // relu.cpp:21-26 (keeps -0.0, NaN -> 0)
             }
@@ -322,7 +334,7 @@ struct FwdRdPlan {
     FwdRdParams p;
     int s, ci, mt, nw, cgroups, blocks_x;
     bool m16;  // conv_fwd_m16_kernel (small layers); its prepared image is a Co*Ci*9-float permutation of the filters
-    int m16_blocks, m16_parts;
+    int m16_blocks, m16_parts, m16_ms;
     size_t lds, img_floats;
 };
 
@@ -365,11 +377,16 @@ bool make_plan(const cnn_conv2d_desc* d, FwdRdPlan* pl) {
     pl->blocks_x = (int)bx;
     // small layers: fewer than four 32-pixel wave tiles per SIMD for the kernel above
     const bool m16_ok = d->Co % 16 == 0 && (long long)d->B * d->Ci * d->H * d->W < (1ll << 29);  // (32-bit buffer offsets)
-    pl->m16 = m16_ok && (long long)p.tiles * mtiles < 4 * 4 * kNumCU;
+    // ... and the thin Ci = 16 layers (conv_layer_2: 27.7 vs 33 us on the kernel above), unless CNN_AMD_FWD_M16_THIN=0
+    const bool thin = d->Ci == 16 && d->Co % 32 == 0 && !(getenv("CNN_AMD_FWD_M16_THIN") && atoi(getenv("CNN_AMD_FWD_M16_THIN")) == 0);
+    pl->m16 = m16_ok && ((long long)p.tiles * mtiles < 4 * 4 * kNumCU || thin);
     if (const char* e = getenv("CNN_AMD_FWD_M16")) pl->m16 = m16_ok && atoi(e) != 0;
     if (pl->m16) {
-        const int slices = d->Co / 16, groups = (int)((pixels + 15) / 16);
-        int per_simd = getenv("CNN_AMD_FWD_M16_WAVES") ? atoi(getenv("CNN_AMD_FWD_M16_WAVES")) : 1;  // (measured: 1 beats 2-4)
+        // two slices per wave where 2 * Ci*9/4 filter registers fit beside the rest (Ci <= 32)
+        pl->m16_ms = (d->Co % 32 == 0 && d->Ci <= 32 && !(getenv("CNN_AMD_FWD_M16_MS") && atoi(getenv("CNN_AMD_FWD_M16_MS")) == 1)) ? 2 : 1;
+        const int slices = d->Co / 16 / pl->m16_ms, groups = (int)((pixels + 15) / 16);
+        // waves per SIMD, measured: Ci >= 32: 1 beats 2-4 (the filter preamble is per wave); Ci = 16: 2 (29.8 / 27.7 / 33.5 us for 1 / 2 / 3)
+        int per_simd = getenv("CNN_AMD_FWD_M16_WAVES") ? atoi(getenv("CNN_AMD_FWD_M16_WAVES")) : (d->Ci == 16 ? 2 : 1);
         if (per_simd < 1 || per_simd > 8) per_simd = 1;
         int parts = per_simd * 4 * kNumCU / slices;
         if (parts < 1) parts = 1;
@@ -511,17 +528,22 @@ int fwd_rd_forward(const cnn_conv2d_desc* d, const float* x, const float* w, con
     if (pl.m16) {
         pl.p.tiles = pl.m16_parts;
         snprintf(name, sizeof(name), "conv_fwd_rd<%d,%d,m16>/fwd%s", d->s, d->Ci, y_relu ? "+relu" : "");
-#define M16(S_, CI_)                                                                                                                   \
-    do {                                                                                                                               \
-        if (pl.p.img)                                                                                                                  \
-            CNN_KLAUNCH(s, name, (conv_fwd_m16_kernel<S_, CI_, 4, true, 4><<<pl.m16_blocks, 256, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", \
-                        d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad);                                                           \
-        else                                                                                                                           \
-            CNN_KLAUNCH(s, name, (conv_fwd_m16_kernel<S_, CI_, 4, false, 4><<<pl.m16_blocks, 256, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", \
-                        d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad);                                                           \
+#define M16K(S_, CI_, PREP_, MS_)                                                                                                            \
+    CNN_KLAUNCH(s, name, (conv_fwd_m16_kernel<S_, CI_, 4, PREP_, 4, MS_><<<pl.m16_blocks, 256, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", \
+                d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad)
+#define M16(S_, CI_)                                                          \
+    do {                                                                      \
+        if (pl.m16_ms == 2 && CI_ <= 32) {                                    \
+            if (pl.p.img) M16K(S_, (CI_ <= 32 ? CI_ : 32), true, 2);         \
+            else M16K(S_, (CI_ <= 32 ? CI_ : 32), false, 2);                 \
+        } else {                                                              \
+            if (pl.p.img) M16K(S_, CI_, true, 1);                             \
+            else M16K(S_, CI_, false, 1);                                     \
+        }                                                                     \
     } while (0)
         if (d->s == 2) { if (d->Ci == 16) M16(2, 16); else if (d->Ci == 32) M16(2, 32); else M16(2, 64); }
         else { if (d->Ci == 16) M16(1, 16); else if (d->Ci == 32) M16(1, 32); else M16(1, 64); }
+#undef M16K
 #undef M16
         return CNN_AMD_OK;
     }
