@@ -80,6 +80,16 @@ SIGNATURES = {
     "cnn_batchnorm2d_backward_sums": (C.c_int, [_P] * 6 + [C.c_int] * 4 + [C.c_float, _P, C.c_size_t, _P]),
     "cnn_batchnorm2d_backward_from_sums": (C.c_int, [_P] * 6 + [C.c_float, _P, _P] + [C.c_int] * 4 + [C.c_float, _P]),
     "cnn_sgd_update": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P]),
+    "cnn_comm_available": (C.c_int, []),
+    "cnn_comm_version": (C.c_int, []),
+    "cnn_comm_unique_id": (C.c_int, [_P]),
+    "cnn_comm_init_rank": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, _P]),
+    "cnn_comm_init_all": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]),
+    "cnn_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "cnn_comm_destroy": (C.c_int, [_P]),
+    "cnn_comm_group_start": (C.c_int, []),
+    "cnn_comm_group_end": (C.c_int, []),
+    "cnn_allreduce_grads": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "cnn_softmax_xent": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "cnn_linear_forward_softmax_xent": (C.c_int, [_P] * 8 + [C.c_int] * 3 + [_P]),
     "cnn_loss_from_terms": (C.c_int, [_P, _P, C.c_int, _P]),
@@ -90,6 +100,14 @@ SIGNATURES = {
     "cnn_memcpy_d2d": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "cnn_memset_zero": (C.c_int, [_P, C.c_size_t, _P]),
     "cnn_stream_synchronize": (C.c_int, [_P]),
+    "cnn_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "cnn_stream_destroy": (C.c_int, [_P]),
+    "cnn_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "cnn_event_destroy": (C.c_int, [_P]),
+    "cnn_event_record": (C.c_int, [_P, _P]),
+    "cnn_stream_wait_event": (C.c_int, [_P, _P]),
+    "cnn_host_alloc_pinned": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "cnn_host_free_pinned": (C.c_int, [_P]),
 }
 
 

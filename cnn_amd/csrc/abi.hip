@@ -195,5 +195,46 @@ int cnn_stream_synchronize(void* stream) {
     CNN_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
     return CNN_AMD_OK;
 }
+int cnn_stream_create(void** stream) {
+    CNN_REQUIRE(stream != nullptr, "cnn_stream_create: null pointer");
+    hipStream_t s = nullptr;
+    CNN_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return CNN_AMD_OK;
+}
+int cnn_stream_destroy(void* stream) {
+    if (stream) CNN_HIP_CHECK(hipStreamDestroy(as_stream(stream)));
+    return CNN_AMD_OK;
+}
+int cnn_event_create(void** event) {
+    CNN_REQUIRE(event != nullptr, "cnn_event_create: null pointer");
+    hipEvent_t e = nullptr;
+    CNN_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event = e;
+    return CNN_AMD_OK;
+}
+int cnn_event_destroy(void* event) {
+    if (event) CNN_HIP_CHECK(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+    return CNN_AMD_OK;
+}
+int cnn_event_record(void* event, void* stream) {
+    CNN_REQUIRE(event != nullptr, "cnn_event_record: null event");
+    CNN_HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(event), as_stream(stream)));
+    return CNN_AMD_OK;
+}
+int cnn_stream_wait_event(void* stream, void* event) {
+    CNN_REQUIRE(event != nullptr, "cnn_stream_wait_event: null event");
+    CNN_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), reinterpret_cast<hipEvent_t>(event), 0));
+    return CNN_AMD_OK;
+}
+int cnn_host_alloc_pinned(void** ptr, size_t bytes) {
+    CNN_REQUIRE(ptr != nullptr, "cnn_host_alloc_pinned: ptr is null");
+    CNN_HIP_CHECK(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return CNN_AMD_OK;
+}
+int cnn_host_free_pinned(void* ptr) {
+    if (ptr) CNN_HIP_CHECK(hipHostFree(ptr));
+    return CNN_AMD_OK;
+}
 
 }  // extern "C"

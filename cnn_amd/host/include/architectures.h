@@ -219,8 +219,12 @@ private:
     int in_H = 0, in_W = 0, batch = 0;
     void* workspace = nullptr;
     size_t workspace_bytes = 0;
+    void* comm = nullptr;        // RCCL communicator: statistics over the GLOBAL batch (sync-BN), see Sequential::set_comm
+    int comm_world = 1;
+    data_type* sync_sums = nullptr;  // [C] + [C] + [C][4] all-reduce operands
 
 public:
+    void set_comm(void* rccl_comm, int world) { comm = rccl_comm; comm_world = world; }
     BatchNorm2D(std::string _name, const int _out_channels, const data_type _eps = 1e-5, const data_type _momentum = 0.1);
     ~BatchNorm2D() override;
     std::vector<tensor> forward(const std::vector<tensor>& input) override;
@@ -232,45 +236,96 @@ public:
     void bind_arena(data_type* params_dev, data_type* grads_dev) override;
 };
 
-// The reference's fixed network (alexnet.cpp:10-33) as a sequential container.  Dropout / grad_cam are outside this
-// build's scope.
-class AlexNet {
+// The reference's model container is a strictly sequential std::list<std::shared_ptr<Layer>> (architectures.h:200) that
+// forward walks front to back (alexnet.cpp:41-42), backward back to front (:53-55), update / save / load front to back
+// (:63-64, :73-74, :86-87).  Sequential is that container for ANY layer list (the reference hard-wires one list in
+// AlexNet's constructor); AlexNet below is the reference's list on top of it.  Additions over the reference's container:
+//   * one flat parameter / gradient arena in checkpoint order (= layer order), so the SGD step is one kernel, a .model
+//     file one copy and the data-parallel exchange one (or a few bucketed) all-reduce(s);
+//   * fusion wiring between neighbouring layers (architectures::fuse_layers / fuse_pool_block);
+//   * filter preparation hoisted out of the per-layer calls (cnn_conv2d_prepare_filters), redone after every parameter change;
+//   * an optional RCCL communicator (set_comm): the batch is then sharded over `world` replicas, BatchNorm2D layers
+//     normalise over the GLOBAL batch (sync-BN) and update_gradients() sums the gradient arena over the replicas first.
+class Sequential {
 public:
     bool print_info = false;
 
-private:
+protected:
     std::list<std::shared_ptr<Layer> > layers_sequence;
     data_type* param_arena = nullptr;  // every layer's parameters in checkpoint order
     data_type* grad_arena = nullptr;
     size_t n_params = 0;
-    bool owns_arena = true;
+    bool owns_arena = false;
+    bool finalized = false;
     bool filters_prepared = false;  // the layers' prepared filters match the current parameters
+    void* comm = nullptr;           // RCCL communicator (cnn_comm_*), not owned
+    int comm_world = 1;
+    void* comm_stream = nullptr;    // the exchange runs on its own stream, gated by events
+    void* ev_grads = nullptr;
+    void* ev_comm = nullptr;
+    bool grads_reduced = false;     // this step's gradient arena has been summed over the replicas
+    void wire();
+    void bind(data_type* p, data_type* g);
     void prepare_filters();
 
+public:
+    Sequential() = default;
+    virtual ~Sequential();
+    Sequential(const Sequential&) = delete;
+    Sequential& operator=(const Sequential&) = delete;
+    // append a layer (takes ownership); all add() calls come before finalize()
+    Sequential& add(Layer* layer);
+    // wires the fusions and moves every layer's parameters into ONE arena (owned, or caller-provided device buffers of
+    // num_params() floats each, e.g. so that a framework can own / all-reduce them)
+    void finalize();
+    void finalize(data_type* params_dev, data_type* grads_dev);
+    std::vector<tensor> forward(const std::vector<tensor>& input);
+    void backward(std::vector<tensor>& delta_start);
+    void update_gradients(const data_type learning_rate = 1e-4);
+    // one SGD kernel over the flat arena; grad_scale folds the 1/G of a data-parallel all-reduce(sum) done by the caller
+    void update_gradients(const data_type learning_rate, const data_type grad_scale);
+    void save_weights(const std::filesystem::path& save_path) const;
+    void load_weights(const std::filesystem::path& checkpoint_path);
+    // additions
+    size_t num_params() const;
+    data_type* params_device() const { return param_arena; }
+    data_type* grads_device() const { return grad_arena; }
+    // MUST be called after writing the parameter arena from outside (memcpy, collective, ...): the convolutions keep
+    // re-arranged copies of their filters between update_gradients() calls
+    void parameters_changed();
+    const std::list<std::shared_ptr<Layer> >& layers() const { return layers_sequence; }
+    // data parallelism over `world` replicas of this container (one per GPU), comm from cnn_comm_init_rank / _init_all:
+    // backward() then leaves LOCAL gradients in the arena, update_gradients(lr) all-reduces them (RCCL, fp32 sum, on a
+    // communication stream) and applies lr * (1/world) * sum.  Pass comm = nullptr to switch it off again.
+    void set_comm(void* rccl_comm, int world);
+    // sums the gradient arena over the replicas now (idempotent per backward pass); update_gradients(lr) calls it
+    void allreduce_gradients();
+};
+
+// The reference's fixed network (alexnet.cpp:10-33).  forward / backward / update_gradients / save_weights / load_weights are
+// declared on AlexNet itself like in the reference (architectures.h:203-213), so cpu/src/alexnet.cpp -- which DEFINES them --
+// compiles against this header unchanged up to its OpenCV-typed grad_cam (:95, out of scope: SURVEY.md section 8f).
+class AlexNet : public Sequential {
 public:
     AlexNet(const int num_classes = 3, const bool batch_norm = false);
     // addition: adopt caller-provided device arenas (e.g. torch tensors) so the gradient arena can be all-reduced
     AlexNet(const int num_classes, data_type* params_dev, data_type* grads_dev, const bool batch_norm = false);
-    ~AlexNet();
     std::vector<tensor> forward(const std::vector<tensor>& input);
     void backward(std::vector<tensor>& delta_start);
-    // one SGD kernel over the flat arena; grad_scale folds the 1/G of a data-parallel all-reduce(sum)
-    void update_gradients(const data_type learning_rate = 1e-4, const data_type grad_scale = 1.f);
+    void update_gradients(const data_type learning_rate = 1e-4);
+    void update_gradients(const data_type learning_rate, const data_type grad_scale);
     void save_weights(const std::filesystem::path& save_path) const;
     void load_weights(const std::filesystem::path& checkpoint_path);
-    // additions
-    size_t num_params() const { return n_params; }
-    data_type* params_device() const { return param_arena; }
-    // MUST be called after writing the parameter arena from outside (memcpy, collective, ...): the convolutions keep
-    // re-arranged copies of their filters between update_gradients() calls
-    void parameters_changed();
-    data_type* grads_device() const { return grad_arena; }
-    const std::list<std::shared_ptr<Layer> >& layers() const { return layers_sequence; }
-
-private:
-    void build(int num_classes, bool batch_norm);
-    void bind(data_type* p, data_type* g);
 };
+
+// BASELINE.json configs[3] / [4] as layer lists of the reference's own layer types (mirrored by cnn_amd/stacks.py):
+// VGG-11-shaped: eight 3x3 stride-1 pad-1 convolutions 3->64->128->256->256->512->512->512->512, ReLU after each,
+// MaxPool2D(2,2) after convolutions 1, 2, 4, 6, 8, LinearLayer(512*7*7 -> classes) for 224x224 inputs.
+void build_vgg11(Sequential& net, const int num_classes = 3, const bool batch_norm = false);
+// ResNet-18-shaped: the convolution shapes of ResNet-18 as a strictly sequential list (no residual adds: alexnet.cpp:41):
+// 7x7 s2 p3 stem, MaxPool2D(2,2), four stages of four convolutions (3x3 s1 p1 inside a stage; stage entries 3x3 s2 p1,
+// 1x1 s2, 3x3 s2 p1), BatchNorm2D + ReLU after every convolution, LinearLayer(512*7*7 -> classes).
+void build_resnet18(Sequential& net, const int num_classes = 3, const bool batch_norm = true);
 
 }  // namespace architectures
 

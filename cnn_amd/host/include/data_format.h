@@ -11,7 +11,16 @@
 #ifndef CNN_AMD_DATA_FORMAT_H
 #define CNN_AMD_DATA_FORMAT_H
 
+// The reference's translation units get the C / C++ standard headers below transitively through <opencv2/core.hpp>
+// (cpu/include/data_format.h:7) and rely on it: cpu/src/alexnet.cpp:37 uses assert, cpu/src/func.cpp:8,10 FLT_MAX and
+// std::exp without including anything themselves.  OpenCV is not part of this build, so this header provides them.
+#include <algorithm>
+#include <cassert>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
 #include <memory>
+#include <sstream>
 #include <string>
 #include <tuple>
 #include <vector>

@@ -2,7 +2,8 @@
 #include <cassert>
 #include <cfloat>
 #include <cmath>
-#include <sstream>
+#include <algorithm>
+#include <cstdio>
 
 #include "func.h"
 
@@ -66,10 +67,9 @@ std::pair<data_type, std::vector<tensor> > cross_entroy_backward(const std::vect
     return std::make_pair(loss, delta);
 }
 
+// func.cpp:75-81: fixed-point rendering with `precision` decimals (the drivers build checkpoint file names with it)
 std::string float_to_string(const float value, const int precision) {
-    std::stringstream buffer;
-    buffer.precision(precision);
-    buffer.setf(std::ios::fixed);
-    buffer << value;
-    return buffer.str();
+    char text[64];
+    const int n = std::snprintf(text, sizeof(text), "%.*f", precision < 0 ? 0 : precision, static_cast<double>(value));
+    return std::string(text, n < 0 ? 0 : std::min<size_t>((size_t)n, sizeof(text) - 1));
 }

@@ -14,8 +14,9 @@ using cnn_amd_host::must;
 
 namespace {
 struct Handle {
-    AlexNet* net;
+    Sequential* net;
     int classes;
+    int in_C = 3;
     std::vector<tensor> host_input;     // B host tensors the caller's images are copied into (cnn.cpp's DataLoader role)
     std::vector<tensor> device_input;   // zero-copy views of a caller-owned contiguous device batch
     std::vector<tensor> last_output;
@@ -45,6 +46,58 @@ void* cnnh_net_create_ex(int classes, float* params_dev, float* grads_dev, int b
                                        : new AlexNet(classes, batch_norm != 0);
     return h;
 }
+// ---- generic layer lists: cnnh_seq_create, cnnh_seq_add_* in layer order, cnnh_seq_finalize; afterwards every cnnh_net_*
+// entry point works on the handle.  (The layer kinds / argument orders are the reference's constructors, architectures.h:69,
+// 96, 109, 131, 167.)
+void* cnnh_seq_create(int in_channels, int classes) {
+    Handle* h = new Handle();
+    h->classes = classes;
+    h->in_C = in_channels;
+    h->net = new Sequential();
+    return h;
+}
+void cnnh_seq_add_conv(void* hv, const char* name, int ci, int co, int k, int stride, int pad) {
+    ((Handle*)hv)->net->add(new Conv2D(name, ci, co, k, stride, pad));
+}
+void cnnh_seq_add_bn(void* hv, const char* name, int channels) { ((Handle*)hv)->net->add(new BatchNorm2D(name, channels)); }
+void cnnh_seq_add_relu(void* hv, const char* name) { ((Handle*)hv)->net->add(new ReLU(name)); }
+void cnnh_seq_add_pool(void* hv, const char* name, int k, int step) { ((Handle*)hv)->net->add(new MaxPool2D(name, k, step)); }
+void cnnh_seq_add_linear(void* hv, const char* name, int n_in, int n_out) { ((Handle*)hv)->net->add(new LinearLayer(name, n_in, n_out)); }
+void cnnh_seq_finalize(void* hv, float* params_dev, float* grads_dev) {
+    Handle* h = (Handle*)hv;
+    if (params_dev && grads_dev)
+        h->net->finalize(params_dev, grads_dev);
+    else
+        h->net->finalize();
+}
+// the two BASELINE stacks from the C++ builders (network.cpp); the Python side checks them against cnn_amd/stacks.py
+void* cnnh_stack_create(const char* which, int classes, int batch_norm) {
+    Handle* h = new Handle();
+    h->classes = classes;
+    h->net = new Sequential();
+    const std::string w(which);
+    if (w == "vgg11")
+        build_vgg11(*h->net, classes, batch_norm != 0);
+    else if (w == "resnet18")
+        build_resnet18(*h->net, classes, batch_norm != 0);
+    else {
+        delete h->net;
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+// "<name>:<param_count>\n" per layer, in order; returns bytes needed
+size_t cnnh_net_describe(void* hv, char* buf, size_t cap) {
+    std::string out;
+    for (const auto& layer : ((Handle*)hv)->net->layers()) out += layer->name + ":" + std::to_string(layer->param_count()) + "\n";
+    if (buf && out.size() + 1 <= cap) std::memcpy(buf, out.c_str(), out.size() + 1);
+    return out.size() + 1;
+}
+// data parallelism: RCCL communicator from cnn_comm_init_rank / cnn_comm_init_all (include/cnn_amd.h)
+void cnnh_net_set_comm(void* hv, void* comm, int world) { ((Handle*)hv)->net->set_comm(comm, world); }
+void cnnh_net_allreduce_gradients(void* hv) { ((Handle*)hv)->net->allreduce_gradients(); }
+
 void cnnh_net_destroy(void* hv) {
     Handle* h = (Handle*)hv;
     delete h->net;
@@ -85,8 +138,8 @@ void cnnh_net_save_checkpoint(void* hv, const char* path) { ((Handle*)hv)->net->
 // logits_out [B][classes]
 void cnnh_net_forward_host(void* hv, const float* x, int B, int H, int W, float* logits_out) {
     Handle* h = (Handle*)hv;
-    auto& in = host_batch(h, B, 3, H, W);
-    const size_t len = (size_t)3 * H * W;
+    auto& in = host_batch(h, B, h->in_C, H, W);
+    const size_t len = (size_t)h->in_C * H * W;
     for (int b = 0; b < B; ++b) std::memcpy(in[b]->data, x + len * b, sizeof(float) * len);
     h->last_output = h->net->forward(in);
     for (int b = 0; b < B; ++b) std::memcpy(logits_out + (size_t)b * h->classes, h->last_output[b]->data, sizeof(float) * h->classes);
@@ -95,8 +148,8 @@ void cnnh_net_forward_host(void* hv, const float* x, int B, int H, int W, float*
 // one iteration of cnn.cpp:79-90 on HOST images: forward, softmax, one_hot, cross_entroy_backward, backward, SGD
 float cnnh_net_train_step_host(void* hv, const float* x, const int* labels, int B, int H, int W, float lr, float* probs_out) {
     Handle* h = (Handle*)hv;
-    auto& in = host_batch(h, B, 3, H, W);
-    const size_t len = (size_t)3 * H * W;
+    auto& in = host_batch(h, B, h->in_C, H, W);
+    const size_t len = (size_t)h->in_C * H * W;
     for (int b = 0; b < B; ++b) std::memcpy(in[b]->data, x + len * b, sizeof(float) * len);
     const auto output = h->net->forward(in);
     const auto probs = softmax(output);
@@ -114,9 +167,9 @@ float cnnh_net_train_step_device(void* hv, float* x_dev, const int* labels, int 
     Handle* h = (Handle*)hv;
     if ((int)h->device_input.size() != B || h->device_input[0]->dev != x_dev) {
         h->device_input.clear();
-        const size_t len = (size_t)3 * H * W;
+        const size_t len = (size_t)h->in_C * H * W;
         for (int b = 0; b < B; ++b)
-            h->device_input.emplace_back(Tensor3D::device_view(3, H, W, x_dev + len * b, "input_" + std::to_string(b)));
+            h->device_input.emplace_back(Tensor3D::device_view(h->in_C, H, W, x_dev + len * b, "input_" + std::to_string(b)));
     }
     const auto output = h->net->forward(h->device_input);
     const auto probs = softmax(output);
@@ -126,6 +179,8 @@ float cnnh_net_train_step_device(void* hv, float* x_dev, const int* labels, int 
     return loss_delta.first;
 }
 void cnnh_net_update(void* hv, float lr, float grad_scale) { ((Handle*)hv)->net->update_gradients(lr, grad_scale); }
+// Sequential::update_gradients(lr): with a communicator set, all-reduce + lr/world; otherwise the plain step
+void cnnh_net_update_auto(void* hv, float lr) { ((Handle*)hv)->net->update_gradients(lr); }
 
 // host copy of a layer's last output through Layer::get_output() (the Grad-CAM contract, alexnet.cpp:97,105)
 int cnnh_net_layer_output(void* hv, const char* layer_name, float* out, size_t cap_floats) {

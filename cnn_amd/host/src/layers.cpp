@@ -414,6 +414,7 @@ BatchNorm2D::~BatchNorm2D() {
         cnn_device_free(grads);
     }
     cnn_device_free(saved_stats);
+    if (sync_sums) cnn_device_free(sync_sums);
     if (workspace) cnn_device_free(workspace);
 }
 
@@ -455,6 +456,23 @@ std::vector<tensor> BatchNorm2D::forward(const std::vector<tensor>& input) {
         saved_input_tensors = input;
     }
     const int C = out_channels;
+    if (!no_grad && comm != nullptr && comm_world > 1) {
+        // the batch is sharded over comm_world replicas: the reference normalises over the WHOLE batch (batchnorm2d.cpp:46-63),
+        // so the per-channel sums are exchanged (two [C] all-reduces: mean first, then the squared deviations around the
+        // GLOBAL mean -- still the reference's two-pass variance); equal shards assumed (count = B * world * H * W)
+        if (!sync_sums) sync_sums = (data_type*)dev_alloc(sizeof(data_type) * 6 * C);
+        const float count = (float)((double)B * comm_world * H * W);
+        data_type* s1 = sync_sums;
+        data_type* s2 = sync_sums + C;
+        must(cnn_batchnorm2d_partial_sums(x, nullptr, 0.f, s1, B, C, H, W, workspace, workspace_bytes, stream), "cnn_batchnorm2d_partial_sums");
+        must(cnn_allreduce_grads(comm, s1, (size_t)C, stream), "cnn_allreduce_grads");
+        must(cnn_batchnorm2d_partial_sums(x, s1, count, s2, B, C, H, W, workspace, workspace_bytes, stream), "cnn_batchnorm2d_partial_sums");
+        must(cnn_allreduce_grads(comm, s2, (size_t)C, stream), "cnn_allreduce_grads");
+        must(cnn_batchnorm2d_forward_from_sums(x, out_buf.base, params, params + C, params + 2 * C, params + 3 * C, saved_stats,
+                                               saved_stats + C, s1, s2, count, B, C, H, W, eps, momentum, stream),
+             "cnn_batchnorm2d_forward_from_sums");
+        return output;
+    }
     must(cnn_batchnorm2d_forward(x, out_buf.base, params, params + C, params + 2 * C, params + 3 * C, saved_stats,
                                  saved_stats + C, B, C, H, W, eps, momentum, no_grad ? 0 : 1, workspace, workspace_bytes,
                                  stream),
@@ -470,9 +488,22 @@ std::vector<tensor> BatchNorm2D::backward(std::vector<tensor>& delta) {
     const int C = out_channels;
     const bool in_place = delta[0]->on_device();
     data_type* d = batch_device_pointer_mut(delta, delta_stage, name + "_dy");
-    must(cnn_batchnorm2d_backward(saved_input, d, params, saved_stats, saved_stats + C, grads, grads + C, B, C, in_H, in_W,
-                                  eps, workspace, workspace_bytes, stream),
-         "cnn_batchnorm2d_backward");
+    if (comm != nullptr && comm_world > 1) {
+        // sync-BN: one [C][4] all-reduce; gamma / beta gradients come out as the FULL-batch sums on every replica (the arena
+        // all-reduce + the 1/world of the SGD step leave them unchanged: world * sum / world)
+        const float count = (float)((double)B * comm_world * in_H * in_W);
+        data_type* s4 = sync_sums + 2 * C;
+        must(cnn_batchnorm2d_backward_sums(saved_input, d, params, saved_stats, saved_stats + C, s4, B, C, in_H, in_W, eps, workspace,
+                                           workspace_bytes, stream),
+             "cnn_batchnorm2d_backward_sums");
+        must(cnn_allreduce_grads(comm, s4, (size_t)4 * C, stream), "cnn_allreduce_grads");
+        must(cnn_batchnorm2d_backward_from_sums(saved_input, d, params, saved_stats, saved_stats + C, s4, count, grads, grads + C, B, C,
+                                                in_H, in_W, eps, stream),
+             "cnn_batchnorm2d_backward_from_sums");
+    } else
+        must(cnn_batchnorm2d_backward(saved_input, d, params, saved_stats, saved_stats + C, grads, grads + C, B, C, in_H, in_W,
+                                      eps, workspace, workspace_bytes, stream),
+             "cnn_batchnorm2d_backward");
     if (!in_place || d == delta_stage.base) {  // host (or scattered) deltas were staged: write the result back
         const size_t len = out_buf.sample_len;
         for (int b = 0; b < B; ++b) {

@@ -1,5 +1,6 @@
-// network.cpp -- the reference's AlexNet container (cpu/src/alexnet.cpp:10-90) over the device layers, plus the
-// flat parameter / gradient arena that makes the SGD step one kernel and the data-parallel exchange one all-reduce.
+// network.cpp -- the reference's model container (cpu/src/alexnet.cpp:10-90: a std::list of Layers walked in order) for any
+// layer list, plus the flat parameter / gradient arena that makes the SGD step one kernel and the data-parallel exchange
+// one all-reduce, the fusion wiring between neighbouring layers, and the BASELINE workloads as layer lists.
 #include <cassert>
 #include <iostream>
 #include <iterator>
@@ -11,30 +12,32 @@ using namespace architectures;
 using cnn_amd_host::dev_alloc;
 using cnn_amd_host::must;
 
-void AlexNet::build(int num_classes, bool batch_norm) {
-    // alexnet.cpp:12-31: every convolution is 3x3 with the constructor's default stride 2; one MaxPool(2,2);
-    // batch_norm inserts a BatchNorm2D between each convolution and its ReLU (:13,17,20,23)
-    layers_sequence.emplace_back(new Conv2D("conv_layer_1", 3, 16, 3));
-    if (batch_norm) layers_sequence.emplace_back(new BatchNorm2D("bn_layer_1", 16));
-    layers_sequence.emplace_back(new ReLU("relu_layer_1"));
-    layers_sequence.emplace_back(new MaxPool2D("max_pool_1", 2, 2));
-    layers_sequence.emplace_back(new Conv2D("conv_layer_2", 16, 32, 3));
-    if (batch_norm) layers_sequence.emplace_back(new BatchNorm2D("bn_layer_2", 32));
-    layers_sequence.emplace_back(new ReLU("relu_layer_2"));
-    layers_sequence.emplace_back(new Conv2D("conv_layer_3", 32, 64, 3));
-    if (batch_norm) layers_sequence.emplace_back(new BatchNorm2D("bn_layer_3", 64));
-    layers_sequence.emplace_back(new ReLU("relu_layer_3"));
-    layers_sequence.emplace_back(new Conv2D("conv_layer_4", 64, 128, 3));
-    if (batch_norm) layers_sequence.emplace_back(new BatchNorm2D("bn_layer_4", 128));
-    layers_sequence.emplace_back(new ReLU("relu_layer_4"));
-    layers_sequence.emplace_back(new LinearLayer("linear_1", 6 * 6 * 128, num_classes));
-    // fusion wiring (architectures::fuse_layers): Conv2D -> ReLU forward, ReLU -> MaxPool2D backward
+// ---------------------------------------------------------------------------------------------------------------
+// Sequential
+Sequential& Sequential::add(Layer* layer) {
+    assert(!finalized && "Sequential::add after finalize()");
+    layers_sequence.emplace_back(layer);
+    return *this;
+}
+
+size_t Sequential::num_params() const {
+    if (finalized) return n_params;
+    size_t n = 0;
+    for (const auto& layer : layers_sequence) n += layer->param_count();
+    return n;
+}
+
+// fusion wiring (architectures::fuse_layers): neighbouring layers that can share a kernel get to know each other; whether a
+// fused kernel is actually used is decided per call by the layers (geometry support, fuse_layers / fuse_pool_block flags)
+void Sequential::wire() {
     for (auto it = layers_sequence.begin(); it != layers_sequence.end(); ++it) {
         auto next = std::next(it);
         if (next == layers_sequence.end()) break;
+        // Conv2D -> ReLU: the ReLU's output is written by the convolution kernel's epilogue
         if (auto* relu = dynamic_cast<ReLU*>(next->get())) {
             if (auto* conv = dynamic_cast<Conv2D*>(it->get())) conv->set_fused_relu(relu);
         }
+        // ReLU -> MaxPool2D: the ReLU's backward pass runs inside the pool's backward kernel
         if (auto* pool = dynamic_cast<MaxPool2D*>(next->get())) {
             if (auto* relu = dynamic_cast<ReLU*>(it->get())) pool->set_fused_relu_below(relu);
         }
@@ -43,7 +46,7 @@ void AlexNet::build(int num_classes, bool batch_norm) {
             if (auto* conv = dynamic_cast<Conv2D*>(next->get())) conv->set_relu_below(relu);
             if (auto* lin = dynamic_cast<LinearLayer*>(next->get())) lin->set_relu_below(relu);
         }
-        // Conv2D -> ReLU -> MaxPool2D: one forward kernel, backward from the pooled domain
+        // Conv2D -> ReLU -> MaxPool2D: one forward kernel, backward from the pooled domain (opt-in: fuse_pool_block)
         auto next2 = std::next(next);
         if (next2 != layers_sequence.end()) {
             auto* conv = dynamic_cast<Conv2D*>(it->get());
@@ -52,11 +55,9 @@ void AlexNet::build(int num_classes, bool batch_norm) {
             if (conv && relu && pool) conv->set_fused_pool(pool);
         }
     }
-    n_params = 0;
-    for (const auto& layer : layers_sequence) n_params += layer->param_count();
 }
 
-void AlexNet::bind(data_type* p, data_type* g) {
+void Sequential::bind(data_type* p, data_type* g) {
     param_arena = p;
     grad_arena = g;
     size_t off = 0;  // checkpoint order == layer order (alexnet.cpp:73-74)
@@ -67,57 +68,71 @@ void AlexNet::bind(data_type* p, data_type* g) {
     }
 }
 
-AlexNet::AlexNet(const int num_classes, const bool batch_norm) {
-    build(num_classes, batch_norm);
+void Sequential::finalize() {
+    assert(!finalized);
+    wire();
+    n_params = 0;
+    for (const auto& layer : layers_sequence) n_params += layer->param_count();
     owns_arena = true;
-    data_type* p = (data_type*)dev_alloc(sizeof(data_type) * n_params);
-    data_type* g = (data_type*)dev_alloc(sizeof(data_type) * n_params);
+    data_type* p = (data_type*)dev_alloc(sizeof(data_type) * (n_params ? n_params : 1));
+    data_type* g = (data_type*)dev_alloc(sizeof(data_type) * (n_params ? n_params : 1));
     must(cnn_memset_zero(g, sizeof(data_type) * n_params, stream), "cnn_memset_zero");
     bind(p, g);
+    finalized = true;
 }
 
-AlexNet::AlexNet(const int num_classes, data_type* params_dev, data_type* grads_dev, const bool batch_norm) {
-    build(num_classes, batch_norm);
+void Sequential::finalize(data_type* params_dev, data_type* grads_dev) {
+    assert(!finalized && params_dev && grads_dev);
+    wire();
+    n_params = 0;
+    for (const auto& layer : layers_sequence) n_params += layer->param_count();
     owns_arena = false;
     bind(params_dev, grads_dev);
+    finalized = true;
 }
 
-AlexNet::~AlexNet() {
+Sequential::~Sequential() {
     layers_sequence.clear();
     if (owns_arena) {
         cnn_device_free(param_arena);
         cnn_device_free(grad_arena);
     }
+    if (comm_stream) cnn_stream_destroy(comm_stream);
+    if (ev_grads) cnn_event_destroy(ev_grads);
+    if (ev_comm) cnn_event_destroy(ev_comm);
 }
 
-// One cnn_conv2d_prepare_filters call for all convolutions (instead of one small re-layout launch inside every forward
-// and backward call); possible once every layer has seen its input shape, i.e. from the second forward pass on.
-void AlexNet::prepare_filters() {
+// cnn_conv2d_prepare_filters for all convolutions (instead of one small re-layout launch inside every forward and backward
+// call), at most 6 layers per call; possible once every layer has seen its input shape, i.e. from the second forward pass on.
+void Sequential::prepare_filters() {
     std::vector<Conv2D*> convs;
     for (auto& layer : layers_sequence)
         if (auto* c = dynamic_cast<Conv2D*>(layer.get())) convs.push_back(c);
     for (auto* c : convs)
         if (!c->shape_known()) return;
-    if (convs.empty() || convs.size() > 6) return;
-    std::vector<cnn_conv2d_desc> descs;
-    std::vector<const float*> w, b;
-    std::vector<void*> f(convs.size()), g(convs.size());
-    for (size_t i = 0; i < convs.size(); ++i) {
-        descs.push_back(convs[i]->current_desc());
-        w.push_back(convs[i]->filters_dev());
-        b.push_back(convs[i]->bias_dev());
-        convs[i]->prepared_buffers(&f[i], &g[i]);
+    for (size_t first = 0; first < convs.size(); first += 6) {
+        const size_t n = std::min<size_t>(6, convs.size() - first);
+        std::vector<cnn_conv2d_desc> descs;
+        std::vector<const float*> w, b;
+        std::vector<void*> f(n), g(n);
+        for (size_t i = 0; i < n; ++i) {
+            Conv2D* c = convs[first + i];
+            descs.push_back(c->current_desc());
+            w.push_back(c->filters_dev());
+            b.push_back(c->bias_dev());
+            c->prepared_buffers(&f[i], &g[i]);
+        }
+        must(cnn_conv2d_prepare_filters((int)n, descs.data(), w.data(), b.data(), f.data(), g.data(), stream),
+             "cnn_conv2d_prepare_filters");
     }
-    must(cnn_conv2d_prepare_filters((int)convs.size(), descs.data(), w.data(), b.data(), f.data(), g.data(), stream),
-         "cnn_conv2d_prepare_filters");
     for (auto* c : convs) c->set_prepared(true);
     filters_prepared = true;
 }
 
-std::vector<tensor> AlexNet::forward(const std::vector<tensor>& input) {
+std::vector<tensor> Sequential::forward(const std::vector<tensor>& input) {
     assert(input.size() > 0);
     if (print_info) input[0]->print_shape();
-    if (fuse_layers && !filters_prepared) prepare_filters();
+    if (finalized && fuse_layers && !filters_prepared) prepare_filters();
     std::vector<tensor> output(input);
     for (const auto& layer : layers_sequence) {
         output = layer->forward(output);
@@ -126,7 +141,7 @@ std::vector<tensor> AlexNet::forward(const std::vector<tensor>& input) {
     return output;
 }
 
-void AlexNet::backward(std::vector<tensor>& delta_start) {
+void Sequential::backward(std::vector<tensor>& delta_start) {
     if (print_info) delta_start[0]->print_shape();
     for (auto layer = layers_sequence.rbegin(); layer != layers_sequence.rend(); ++layer) {
         delta_start = (*layer)->backward(delta_start);
@@ -134,27 +149,68 @@ void AlexNet::backward(std::vector<tensor>& delta_start) {
     }
     // the layers' weight gradients were computed on the library's side stream: order them before whatever follows
     must(cnn_amd_side_stream_join(stream), "cnn_amd_side_stream_join");
+    grads_reduced = false;
 }
 
-void AlexNet::parameters_changed() {
+void Sequential::parameters_changed() {
     filters_prepared = false;  // re-prepared at the start of the next forward pass
     for (auto& layer : layers_sequence)
         if (auto* c = dynamic_cast<Conv2D*>(layer.get())) c->set_prepared(false);
 }
 
-void AlexNet::update_gradients(const data_type learning_rate, const data_type grad_scale) {
+void Sequential::set_comm(void* rccl_comm, int world) {
+    assert(world >= 1);
+    comm = rccl_comm;
+    comm_world = rccl_comm ? world : 1;
+    for (auto& layer : layers_sequence)
+        if (auto* bn = dynamic_cast<BatchNorm2D*>(layer.get())) bn->set_comm(comm, comm_world);
+    if (comm && !comm_stream) {
+        must(cnn_stream_create(&comm_stream), "cnn_stream_create");
+        must(cnn_event_create(&ev_grads), "cnn_event_create");
+        must(cnn_event_create(&ev_comm), "cnn_event_create");
+    }
+}
+
+// C1 of SURVEY.md section 2.1: ONE in-place fp32 sum over the flat gradient arena (RCCL over xGMI), on the communication
+// stream, fenced against the compute stream by two events
+void Sequential::allreduce_gradients() {
+    if (!comm || comm_world <= 1 || grads_reduced) return;
+    assert(finalized && "data parallelism needs the flat gradient arena: call finalize()");
+    must(cnn_event_record(ev_grads, stream), "cnn_event_record");
+    must(cnn_stream_wait_event(comm_stream, ev_grads), "cnn_stream_wait_event");
+    must(cnn_allreduce_grads(comm, grad_arena, n_params, comm_stream), "cnn_allreduce_grads");
+    must(cnn_event_record(ev_comm, comm_stream), "cnn_event_record");
+    must(cnn_stream_wait_event(stream, ev_comm), "cnn_stream_wait_event");
+    grads_reduced = true;
+}
+
+void Sequential::update_gradients(const data_type learning_rate) {
+    if (!finalized) {  // plain list of stand-alone layers: the reference's loop (alexnet.cpp:62-65)
+        for (auto& layer : layers_sequence) layer->update_gradients(learning_rate);
+        return;
+    }
+    if (comm && comm_world > 1) {
+        allreduce_gradients();
+        update_gradients(learning_rate, 1.f / (data_type)comm_world);
+    } else {
+        update_gradients(learning_rate, 1.f);
+    }
+}
+
+void Sequential::update_gradients(const data_type learning_rate, const data_type grad_scale) {
+    assert(finalized && "the grad_scale form works on the flat arena: call finalize()");
     must(cnn_sgd_update(param_arena, grad_arena, n_params, learning_rate, grad_scale, stream), "cnn_sgd_update");
     parameters_changed();
 }
 
-void AlexNet::save_weights(const std::filesystem::path& save_path) const {
+void Sequential::save_weights(const std::filesystem::path& save_path) const {
     std::ofstream writer(save_path.c_str(), std::ios::binary);
     for (const auto& layer : layers_sequence) layer->save_weights(writer);
     std::cout << "weights have been saved to " << save_path.string() << std::endl;
     writer.close();
 }
 
-void AlexNet::load_weights(const std::filesystem::path& checkpoint_path) {
+void Sequential::load_weights(const std::filesystem::path& checkpoint_path) {
     if (!std::filesystem::exists(checkpoint_path)) {  // alexnet.cpp:81-84: report and carry on
         std::cout << "checkpoint file  " << checkpoint_path << " does not exist !\n";
         return;
@@ -164,4 +220,90 @@ void AlexNet::load_weights(const std::filesystem::path& checkpoint_path) {
     for (auto& layer : layers_sequence) layer->load_weights(reader);
     std::cout << "load weights from" << checkpoint_path.string() << std::endl;
     reader.close();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// AlexNet: the reference's list (alexnet.cpp:12-31)
+namespace {
+void build_alexnet(Sequential& net, int num_classes, bool batch_norm) {
+    // every convolution is 3x3 with the constructor's default stride 2; one MaxPool(2,2); batch_norm inserts a BatchNorm2D
+    // between each convolution and its ReLU (alexnet.cpp:13,17,20,23)
+    const int chans[5] = {3, 16, 32, 64, 128};
+    for (int l = 1; l <= 4; ++l) {
+        const std::string id = std::to_string(l);
+        net.add(new Conv2D("conv_layer_" + id, chans[l - 1], chans[l], 3));
+        if (batch_norm) net.add(new BatchNorm2D("bn_layer_" + id, chans[l]));
+        net.add(new ReLU("relu_layer_" + id));
+        if (l == 1) net.add(new MaxPool2D("max_pool_1", 2, 2));
+    }
+    net.add(new LinearLayer("linear_1", 6 * 6 * 128, num_classes));
+}
+}  // namespace
+
+AlexNet::AlexNet(const int num_classes, const bool batch_norm) {
+    build_alexnet(*this, num_classes, batch_norm);
+    finalize();
+}
+
+AlexNet::AlexNet(const int num_classes, data_type* params_dev, data_type* grads_dev, const bool batch_norm) {
+    build_alexnet(*this, num_classes, batch_norm);
+    finalize(params_dev, grads_dev);
+}
+
+std::vector<tensor> AlexNet::forward(const std::vector<tensor>& input) { return Sequential::forward(input); }
+void AlexNet::backward(std::vector<tensor>& delta_start) { Sequential::backward(delta_start); }
+void AlexNet::update_gradients(const data_type learning_rate) { Sequential::update_gradients(learning_rate); }
+void AlexNet::update_gradients(const data_type learning_rate, const data_type grad_scale) {
+    Sequential::update_gradients(learning_rate, grad_scale);
+}
+void AlexNet::save_weights(const std::filesystem::path& save_path) const { Sequential::save_weights(save_path); }
+void AlexNet::load_weights(const std::filesystem::path& checkpoint_path) { Sequential::load_weights(checkpoint_path); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// BASELINE.json configs[3] / [4] (mirrored by cnn_amd/stacks.py, which the parity tests build the oracle from)
+namespace {
+struct StackBuilder {
+    Sequential& net;
+    bool batch_norm;
+    int C = 3, H = 224, W = 224, n_conv = 0, n_pool = 0;
+    void conv(int co, int k, int s, int pad) {
+        const std::string id = std::to_string(++n_conv);
+        net.add(new Conv2D("conv_layer_" + id, C, co, k, s, pad));
+        if (batch_norm) net.add(new BatchNorm2D("bn_layer_" + id, co));
+        net.add(new ReLU("relu_layer_" + id));
+        C = co;
+        H = cnn_conv2d_out_dim(H, k, s, pad);
+        W = cnn_conv2d_out_dim(W, k, s, pad);
+    }
+    void pool(int k, int step) {
+        net.add(new MaxPool2D("max_pool_" + std::to_string(++n_pool), k, step));
+        H = cnn_maxpool2d_out_dim(H, k, step);
+        W = cnn_maxpool2d_out_dim(W, k, step);
+    }
+    void linear(int out) { net.add(new LinearLayer("linear_1", C * H * W, out)); }
+};
+}  // namespace
+
+void architectures::build_vgg11(Sequential& net, const int num_classes, const bool batch_norm) {
+    StackBuilder b{net, batch_norm};
+    const int chans[8] = {64, 128, 256, 256, 512, 512, 512, 512};
+    for (int i = 1; i <= 8; ++i) {
+        b.conv(chans[i - 1], 3, 1, 1);
+        if (i == 1 || i == 2 || i == 4 || i == 6 || i == 8) b.pool(2, 2);
+    }
+    b.linear(num_classes);
+}
+
+void architectures::build_resnet18(Sequential& net, const int num_classes, const bool batch_norm) {
+    StackBuilder b{net, batch_norm};
+    b.conv(64, 7, 2, 3);
+    b.pool(2, 2);
+    for (int i = 0; i < 4; ++i) b.conv(64, 3, 1, 1);
+    b.conv(128, 3, 2, 1);
+    for (int i = 0; i < 3; ++i) b.conv(128, 3, 1, 1);
+    b.conv(256, 1, 2, 0);
+    for (int i = 0; i < 3; ++i) b.conv(256, 3, 1, 1);
+    b.conv(512, 3, 2, 1);
+    for (int i = 0; i < 3; ++i) b.conv(512, 3, 1, 1);
+    b.linear(num_classes);
 }

@@ -16,6 +16,18 @@ _I = C.POINTER(C.c_int)
 SIGNATURES = {
     "cnnh_net_create": (C.c_void_p, [C.c_int, C.c_void_p, C.c_void_p]),
     "cnnh_net_create_ex": (C.c_void_p, [C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "cnnh_seq_create": (C.c_void_p, [C.c_int, C.c_int]),
+    "cnnh_seq_add_conv": (None, [C.c_void_p, C.c_char_p] + [C.c_int] * 5),
+    "cnnh_seq_add_bn": (None, [C.c_void_p, C.c_char_p, C.c_int]),
+    "cnnh_seq_add_relu": (None, [C.c_void_p, C.c_char_p]),
+    "cnnh_seq_add_pool": (None, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    "cnnh_seq_add_linear": (None, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    "cnnh_seq_finalize": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cnnh_stack_create": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int]),
+    "cnnh_net_describe": (C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "cnnh_net_set_comm": (None, [C.c_void_p, C.c_void_p, C.c_int]),
+    "cnnh_net_allreduce_gradients": (None, [C.c_void_p]),
+    "cnnh_net_update_auto": (None, [C.c_void_p, C.c_float]),
     "cnnh_net_destroy": (None, [C.c_void_p]),
     "cnnh_net_num_params": (C.c_size_t, [C.c_void_p]),
     "cnnh_net_params_device": (C.c_void_p, [C.c_void_p]),
@@ -56,17 +68,34 @@ def _fp(a):
     return a.ctypes.data_as(_F)
 
 
-class HostAlexNet:
-    """architectures::AlexNet (cnn_amd/host) behind a handle."""
+class HostNet:
+    """architectures::Sequential / AlexNet (cnn_amd/host) behind a handle: the C++ Layer API a reference user links against."""
 
-    def __init__(self, classes=3, params=None, grads=None, batch_norm=False):
-        self.lib = load()
+    h = None
+
+    def _adopt(self, handle, classes, params, grads):
         self.classes = classes
         self._keep = (params, grads)  # torch tensors that own the arenas, if any
-        p = C.c_void_p(params.data_ptr()) if params is not None else None
-        g = C.c_void_p(grads.data_ptr()) if grads is not None else None
-        self.h = C.c_void_p(self.lib.cnnh_net_create_ex(classes, p, g, 1 if batch_norm else 0))
+        self.h = C.c_void_p(handle)
         self.n_params = int(self.lib.cnnh_net_num_params(self.h))
+
+    def describe(self):
+        """[(layer name, parameter count)] in layer order"""
+        n = int(self.lib.cnnh_net_describe(self.h, None, 0))
+        buf = C.create_string_buffer(n)
+        self.lib.cnnh_net_describe(self.h, buf, n)
+        return [(ln.rsplit(":", 1)[0], int(ln.rsplit(":", 1)[1])) for ln in buf.value.decode().splitlines()]
+
+    def set_comm(self, comm, world):
+        """comm: the void* of cnn_comm_init_rank / cnn_comm_init_all (int or ctypes.c_void_p), or None"""
+        self.lib.cnnh_net_set_comm(self.h, comm, int(world))
+
+    def allreduce_gradients(self):
+        self.lib.cnnh_net_allreduce_gradients(self.h)
+
+    def update_auto(self, lr):
+        """Sequential::update_gradients(lr): all-reduce + lr/world when a communicator is set"""
+        self.lib.cnnh_net_update_auto(self.h, float(lr))
 
     def close(self):
         if self.h:
@@ -131,3 +160,78 @@ class HostAlexNet:
         if rc != 0:
             raise KeyError(f"layer {name}: rc={rc}")
         return out
+
+
+class HostAlexNet(HostNet):
+    """architectures::AlexNet: the reference's fixed list (alexnet.cpp:10-33)"""
+
+    def __init__(self, classes=3, params=None, grads=None, batch_norm=False):
+        self.lib = load()
+        p = C.c_void_p(params.data_ptr()) if params is not None else None
+        g = C.c_void_p(grads.data_ptr()) if grads is not None else None
+        self._adopt(self.lib.cnnh_net_create_ex(classes, p, g, 1 if batch_norm else 0), classes, params, grads)
+
+
+def _layer_names(spec):
+    """the naming scheme of network.cpp's StackBuilder / the reference (conv_layer_N, bn_layer_N, relu_layer_N, max_pool_N)"""
+    names, n_conv, n_pool, n_lin = [], 0, 0, 0
+    for item in spec:
+        kind = item[0]
+        if kind == "conv":
+            n_conv += 1
+            names.append(f"conv_layer_{n_conv}")
+        elif kind == "bn":
+            names.append(f"bn_layer_{n_conv}")
+        elif kind == "relu":
+            names.append(f"relu_layer_{n_conv}")
+        elif kind == "pool":
+            n_pool += 1
+            names.append(f"max_pool_{n_pool}")
+        else:
+            n_lin += 1
+            names.append(f"linear_{n_lin}")
+    return names
+
+
+class HostSequential(HostNet):
+    """architectures::Sequential built from a cnn_amd.stacks spec (any list of the reference's layer types)"""
+
+    def __init__(self, spec, in_shape=(3, 224, 224), params=None, grads=None):
+        from . import stacks
+
+        self.lib = load()
+        self.spec = list(spec)
+        self.layout = stacks.walk(self.spec, *in_shape)
+        self.names = _layer_names(self.spec)
+        classes = self.layout[-1]["out"][0]
+        h = C.c_void_p(self.lib.cnnh_seq_create(in_shape[0], classes))
+        for name, item, ent in zip(self.names, self.spec, self.layout):
+            nm = name.encode()
+            if item[0] == "conv":
+                self.lib.cnnh_seq_add_conv(h, nm, ent["in"][0], item[1], item[2], item[3], item[4])
+            elif item[0] == "bn":
+                self.lib.cnnh_seq_add_bn(h, nm, ent["in"][0])
+            elif item[0] == "relu":
+                self.lib.cnnh_seq_add_relu(h, nm)
+            elif item[0] == "pool":
+                self.lib.cnnh_seq_add_pool(h, nm, item[1], item[2])
+            else:
+                self.lib.cnnh_seq_add_linear(h, nm, ent["n_in"], ent["n_out"])
+        p = C.c_void_p(params.data_ptr()) if params is not None else None
+        g = C.c_void_p(grads.data_ptr()) if grads is not None else None
+        self.lib.cnnh_seq_finalize(h, p, g)
+        self._adopt(h.value, classes, params, grads)
+        assert self.n_params == sum(e["params"] for e in self.layout)
+
+
+class HostStack(HostNet):
+    """architectures::build_vgg11 / build_resnet18 (network.cpp) -- the C++ side's own builders of the BASELINE stacks"""
+
+    def __init__(self, which, classes=3, batch_norm=False):
+        self.lib = load()
+        h = self.lib.cnnh_stack_create(which.encode(), classes, 1 if batch_norm else 0)
+        if not h:
+            raise KeyError(which)
+        hh = C.c_void_p(h)
+        self.lib.cnnh_seq_finalize(hh, None, None)
+        self._adopt(h, classes, None, None)

@@ -29,7 +29,8 @@ enum {
     CNN_AMD_OK = 0,
     CNN_AMD_E_BADARG = 1,    /* null pointer / non-positive dimension / unsupported geometry */
     CNN_AMD_E_WORKSPACE = 2, /* ws too small for this call */
-    CNN_AMD_E_HIP = 1000     /* 1000 + hipError_t */
+    CNN_AMD_E_HIP = 1000,    /* 1000 + hipError_t */
+    CNN_AMD_E_COMM = 2000    /* 2000 + ncclResult_t (RCCL); 2000 itself = librccl could not be loaded */
 };
 
 int cnn_amd_abi_version(void);
@@ -258,6 +259,31 @@ int cnn_batchnorm2d_backward_from_sums(const float* x, float* dy, const float* g
  * whose kernels each divided by their local batch. */
 int cnn_sgd_update(float* params, const float* grads, size_t n, float lr, float grad_scale, void* stream);
 
+/* ---- data-parallel gradient exchange (new: the reference is single-process) -------------
+ * The batch is sharded over G replicas (one per GPU); the only cross-sample coupling of the path is the batch mean inside
+ * the weight / bias gradients (conv2d.cpp:148,157; linear.cpp:62,70).  Every replica's kernels divide by their LOCAL batch,
+ * cnn_allreduce_grads sums the flat gradient arena (or one bucket of it) in place over the replicas -- RCCL ncclAllReduce,
+ * fp32 sum, over xGMI -- and cnn_sgd_update(..., grad_scale = 1/G) folds the rest: exactly the reference's (1/B) * sum over the
+ * whole batch up to summation order.  BatchNorm2D gamma / beta gradients computed by the sync-BN entry points are already
+ * full-batch sums on every replica; summing them over G and scaling by 1/G leaves them unchanged, so they ride in the same
+ * arena.  librccl is bound at run time (dlopen("librccl.so.1")): libcnn_amd.so has no link-time dependency on it.
+ *   one process per GPU : rank 0 calls cnn_comm_unique_id, ships the 128 bytes to the other ranks by any means (the test
+ *                         harness uses torch.distributed's store), every rank calls cnn_comm_init_rank on its device;
+ *   one process, n GPUs : cnn_comm_init_all (ncclCommInitAll), one host thread per device or cnn_comm_group_start/_end
+ *                         around the per-device calls. */
+#define CNN_COMM_ID_BYTES 128
+int cnn_comm_available(void); /* != 0: librccl was found and bound */
+int cnn_comm_version(void);   /* ncclGetVersion code, 0 when unavailable */
+int cnn_comm_unique_id(void* id_out /* host, CNN_COMM_ID_BYTES */);
+int cnn_comm_init_rank(void** comm, int world, int rank, const void* id /* host, CNN_COMM_ID_BYTES */);
+int cnn_comm_init_all(void** comms /* [ndev] */, int ndev, const int* devices /* NULL = 0..ndev-1 */);
+int cnn_comm_info(void* comm, int* world, int* rank);
+int cnn_comm_destroy(void* comm);
+int cnn_comm_group_start(void);
+int cnn_comm_group_end(void);
+/* in-place sum of n floats over all ranks of comm, enqueued on `stream` */
+int cnn_allreduce_grads(void* comm, float* grads, size_t n, void* stream);
+
 /* ---- loss glue : func.cpp:16-73 (caller side of the path; keeps the step on the device) -------------- */
 /* probs = softmax(logits) with the reference's clamped exp and NaN->0; delta = probs - onehot(labels);
  * loss_sum[0] = -sum_b log(probs[b][label_b])  (the caller divides by the global batch, func.cpp:67,71).
@@ -280,6 +306,18 @@ int cnn_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stre
 int cnn_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 int cnn_memset_zero(void* dst_dev, size_t bytes, void* stream);
 int cnn_stream_synchronize(void* stream);
+/* streams / events for callers that overlap independent work themselves (the communication stream of the data-parallel
+ * exchange, the staging stream of cnn_batch_upload_async); streams are non-blocking w.r.t. the default stream, events carry
+ * no timing.  The host layer classes use only these, never the HIP runtime directly. */
+int cnn_stream_create(void** stream);
+int cnn_stream_destroy(void* stream);
+int cnn_event_create(void** event);
+int cnn_event_destroy(void* event);
+int cnn_event_record(void* event, void* stream);
+int cnn_stream_wait_event(void* stream, void* event);
+/* page-locked host memory (async H2D / D2H copies are only asynchronous from / to pinned buffers) */
+int cnn_host_alloc_pinned(void** ptr, size_t bytes);
+int cnn_host_free_pinned(void* ptr);
 
 #ifdef __cplusplus
 }

@@ -33,9 +33,13 @@
 #define ORACLE_REAL float
 #define SUF(name) name
 #define REAL_SQRT(v) sqrtf(v) /* std::sqrt(data_type) is the float overload */
+#define REAL_EXP(v) expf(v)   /* std::exp(data_type), func.cpp:10: the float overload */
+#define REAL_LOG(v) logf(v)   /* std::log(data_type), func.cpp:65 */
 #else
 #define SUF(name) name##_f64
 #define REAL_SQRT(v) sqrt(v)
+#define REAL_EXP(v) exp(v)
+#define REAL_LOG(v) log(v)
 #endif
 typedef ORACLE_REAL real;
 
@@ -56,9 +60,11 @@ void SUF(oracle_conv2d_forward)(const real* x, const real* w, const real* bias, 
     const int r = (k - 1) / 2;
     const int Ho = conv_out_dim(H, k, s), Wo = conv_out_dim(W, k, s);
     const int plane = H * W, oplane = Ho * Wo, win = k * k;
+    /* (threads split the independent (b, o) planes; every output element stays one sequential sum) */
+#pragma omp parallel for collapse(2) schedule(dynamic)
     for (int b = 0; b < B; ++b) {
-        const real* xb = x + (size_t)b * Ci * plane;
         for (int o = 0; o < Co; ++o) {
+            const real* xb = x + (size_t)b * Ci * plane;
             real* yo = y + ((size_t)b * Co + o) * oplane;
             const real* wo = w + (size_t)o * Ci * win;
             int cnt = 0;
@@ -98,8 +104,10 @@ void SUF(oracle_conv2d_backward)(const real* x, const real* dy, const real* w, r
     if (gw) memset(gw, 0, sizeof(real) * (size_t)Co * Ci * win);
     if (gb) memset(gb, 0, sizeof(real) * (size_t)Co);
     if (gw || gb) {
-        for (int b = 0; b < B; ++b) {
-            for (int o = 0; o < Co; ++o) {
+        /* (threads split the output channels: each gw[o] / gb[o] still accumulates its samples in ascending b) */
+#pragma omp parallel for schedule(dynamic)
+        for (int o = 0; o < Co; ++o) {
+            for (int b = 0; b < B; ++b) {
                 const real* od = dy + ((size_t)b * Co + o) * oplane;
                 if (gw) {
                     for (int i = 0; i < Ci; ++i) {
@@ -128,7 +136,11 @@ void SUF(oracle_conv2d_backward)(const real* x, const real* dy, const real* w, r
     }
     if (dx) {
         memset(dx, 0, sizeof(real) * (size_t)B * Ci * plane);
+        /* (threads split (sample, input channel): each dx element still receives its contributions in ascending o, then
+         * in window order -- the reference's o -> window -> i nest visits a fixed (i, element) in exactly that order) */
+#pragma omp parallel for collapse(2) schedule(dynamic)
         for (int b = 0; b < B; ++b) {
+          for (int i = 0; i < Ci; ++i) {
             real* dxb = dx + (size_t)b * Ci * plane;
             for (int o = 0; o < Co; ++o) {
                 const real* od = dy + ((size_t)b * Co + o) * oplane;
@@ -136,7 +148,7 @@ void SUF(oracle_conv2d_backward)(const real* x, const real* dy, const real* w, r
                 int cnt = 0;
                 for (int cx = r; cx < H - r; cx += s) {
                     for (int cy = r; cy < W - r; cy += s) {
-                        for (int i = 0; i < Ci; ++i) {
+                        {
                             real* xi = dxb + (size_t)i * plane + cx * W + cy;
                             const real* wi = wo + i * win;
                             int t = 0;
@@ -148,9 +160,23 @@ void SUF(oracle_conv2d_backward)(const real* x, const real* dy, const real* w, r
                     }
                 }
             }
+          }
         }
     }
 }
+
+/* Threads used by the convolution loop nests above (test infrastructure only: big parity cases finish in seconds on the GPU
+ * box's host cores).  The split never changes the order in which any single result element is accumulated, so the output is
+ * bit-identical for every thread count (tests/test_oracle_golden.py checks that); bench.py's cpu_baseline pins it to 1, the
+ * reference being single-threaded. */
+#ifdef _OPENMP
+#include <omp.h>
+void SUF(oracle_set_threads)(int n) { omp_set_num_threads(n > 0 ? n : omp_get_num_procs()); }
+int SUF(oracle_get_threads)(void) { return omp_get_max_threads(); }
+#else
+void SUF(oracle_set_threads)(int n) { (void)n; }
+int SUF(oracle_get_threads)(void) { return 1; }
+#endif
 
 /* conv2d.cpp:205-217 and linear.cpp:95-102:  p -= lr * g */
 void SUF(oracle_sgd_update)(real* p, const real* g, size_t n, real lr) {
@@ -382,7 +408,7 @@ void SUF(oracle_batchnorm_backward)(const real* x, real* dy, const real* gamma, 
 static real clamped_exp(real v) {
     if (v >= 88) return (real)FLT_MAX;
     if (v <= -50) return 0;
-    return (real)exp((double)v);
+    return REAL_EXP(v);
 }
 
 /* func.cpp:16-37: max-subtracted softmax (max = first maximum, data_format.cpp:37-48), NaN -> 0 */
@@ -411,7 +437,7 @@ real SUF(oracle_cross_entropy_backward)(const real* probs, const int* labels, re
         for (int i = 0; i < n; ++i) {
             const real yv = (labels[b] == i) ? 1 : 0;
             delta[(size_t)b * n + i] = probs[(size_t)b * n + i] - yv;
-            loss += (real)log((double)probs[(size_t)b * n + i]) * yv;
+            loss += REAL_LOG(probs[(size_t)b * n + i]) * yv;
         }
     return (real)(loss * (-1.0) / B);
 }

@@ -43,6 +43,8 @@ def _declare(L):
         sig("oracle_conv2d_forward", None, P, P, P, P, I, I, I, I, I, I, I)
         sig("oracle_conv2d_backward", None, P, P, P, P, P, P, I, I, I, I, I, I, I)
         sig("oracle_sgd_update", None, P, P, C.c_size_t, real)
+        sig("oracle_set_threads", None, I)
+        sig("oracle_get_threads", I)
         sig("oracle_maxpool_forward", None, P, P, IP, I, I, I, I, I, I)
         sig("oracle_maxpool_backward", None, P, IP, P, I, I, I, I, I, I)
         sig("oracle_relu_forward", None, P, P, C.c_size_t)
@@ -84,6 +86,34 @@ def _c(a, dt):
 
 def conv_out_dim(h, k, s):
     return (h - k) // s + 1
+
+
+def set_threads(n):
+    """threads of the convolution loop nests (0 = all host cores).  Results are bit-identical for every count (the split never
+    reorders a single element's accumulation); the timed cpu_baseline uses 1 like the single-threaded reference."""
+    lib().oracle_set_threads(int(n))
+
+
+def get_threads():
+    return int(lib().oracle_get_threads())
+
+
+def _pad_hw(x, p):
+    """Tensor3D::pad(p) (data_format.cpp:139-150) on every sample / channel: zero border of p rows / columns"""
+    return x if p == 0 else np.pad(x, ((0, 0), (0, 0), (p, p), (p, p)))
+
+
+def conv2d_forward_padded(x, w, bias, stride, pad, f64=False):
+    """the padding extension's oracle (SURVEY.md 8c): the reference convolution on the Tensor3D::pad(p)-ed input"""
+    return conv2d_forward(_pad_hw(x, pad), w, bias, stride, f64=f64)
+
+
+def conv2d_backward_padded(x, dy, w, stride, pad, f64=False, need=(True, True, True)):
+    """... and its backward pass with the data gradient cropped back to the unpadded frame"""
+    gw, gb, dx = conv2d_backward(_pad_hw(x, pad), dy, w, stride, f64=f64, need=need)
+    if dx is not None and pad:
+        dx = np.ascontiguousarray(dx[:, :, pad:-pad, pad:-pad])
+    return gw, gb, dx
 
 
 def conv2d_forward(x, w, bias, stride, f64=False):
@@ -386,4 +416,136 @@ class BnNet:
             gw, gb, d = conv2d_backward(self.t["in"][l], d, self.p(f"w{l}").reshape(co, ci, 3, 3), 2)
             g[self.slices[f"w{l}"]], g[self.slices[f"b{l}"]] = gw.ravel(), gb
         self.params[:] = sgd_update(self.params, g, lr)  # the moving_* slots have zero gradient
+        return loss, probs
+
+
+class SeqNet:
+    """Any strictly sequential list of the reference's layer types (the container of alexnet.cpp:35-65 for an arbitrary
+    layers_sequence) composed from the oracle's layer functions; `spec` is a cnn_amd.stacks-style list of tuples
+    ("conv", Co, k, s, pad) | ("bn",) | ("relu",) | ("pool", k, step) | ("linear", out).  Parameters / gradients are one flat
+    vector in checkpoint order (alexnet.cpp:73-74: conv w then b, BN gamma beta moving_mean moving_var, linear W then b).
+    Keeps every layer's forward output (self.acts[i]) and input delta (self.deltas[i]) of the last step for per-layer checks."""
+
+    def __init__(self, spec, in_shape=(3, 224, 224), f64=False):
+        self.spec = list(spec)
+        self.f64 = f64
+        self.dt = np.float64 if f64 else np.float32
+        C_, H, W = in_shape
+        self.layers, off = [], 0
+        for item in self.spec:
+            kind = item[0]
+            ent = {"kind": kind, "in": (C_, H, W), "off": off}
+            if kind == "conv":
+                _, co, k, s, p = item
+                ent.update(Co=co, k=k, s=s, pad=p, n=co * C_ * k * k + co)
+                C_, H, W = co, (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+            elif kind == "bn":
+                ent.update(n=4 * C_)
+            elif kind == "relu":
+                ent.update(n=0)
+            elif kind == "pool":
+                _, k, st = item
+                ent.update(k=k, step=st, n=0)
+                H, W = (H - k) // st + 1, (W - k) // st + 1
+            elif kind == "linear":
+                ent.update(n_in=C_ * H * W, n_out=item[1], n=C_ * H * W * item[1] + item[1])
+                C_, H, W = item[1], 1, 1
+            else:
+                raise ValueError(kind)
+            ent["out"] = (C_, H, W)
+            ent["params"] = ent["n"]  # (same key as cnn_amd.stacks.walk)
+            off += ent["n"]
+            self.layers.append(ent)
+        self.n_params = off
+        self.classes = C_
+        self.params = np.zeros(off, self.dt)
+        self.grads = np.zeros(off, self.dt)
+        for e in self.layers:  # batchnorm2d.cpp:18-20: gamma = 1, everything else 0
+            if e["kind"] == "bn":
+                self.params[e["off"] : e["off"] + e["in"][0]] = 1
+
+    def _p(self, e, a=None):
+        a = self.params if a is None else a
+        return a[e["off"] : e["off"] + e["n"]]
+
+    def forward(self, x, training=True):
+        f64 = self.f64
+        cur = _c(x, self.dt)
+        B = cur.shape[0]
+        self.acts, self.inputs, self.aux = [], [], []
+        for e in self.layers:
+            self.inputs.append(cur)
+            k = e["kind"]
+            aux = None
+            if k == "conv":
+                ci, co, kk = e["in"][0], e["Co"], e["k"]
+                p = self._p(e)
+                cur = conv2d_forward_padded(cur, p[: co * ci * kk * kk].reshape(co, ci, kk, kk), p[co * ci * kk * kk :], e["s"], e["pad"], f64=f64)
+            elif k == "bn":
+                c = e["in"][0]
+                p = self._p(e)
+                y, _, sm, sv, mm, mv = batchnorm_forward(cur, p[:c], p[c : 2 * c], p[2 * c : 3 * c], p[3 * c :], training=training, f64=f64)
+                if training:
+                    p[2 * c : 3 * c], p[3 * c :] = mm, mv
+                aux = (sm, sv)
+                cur = y
+            elif k == "relu":
+                cur = relu_forward(cur, f64=f64)
+            elif k == "pool":
+                cur, aux = maxpool_forward(cur, e["k"], e["step"], f64=f64)
+            else:
+                p = self._p(e)
+                ni, no = e["n_in"], e["n_out"]
+                cur = linear_forward(cur.reshape(B, ni), p[: ni * no].reshape(ni, no), p[ni * no :], f64=f64)
+            self.acts.append(cur)
+            self.aux.append(aux)
+        return cur
+
+    def backward(self, delta, masks_from=None):
+        """masks_from (optional): {layer index: tensor} -- the ReLU OUTPUT (for a ReLU layer) or the pool INPUT (for a MaxPool2D
+        layer) of ANOTHER implementation's forward pass on the same inputs.  ReLU::backward (relu.cpp:37) and
+        MaxPool2D::backward (pool2d.cpp:105) then take their pass / route decisions from those tensors instead of this net's
+        own: the two backward passes being compared make the same discrete decisions, so what remains is continuous in the
+        inputs and can be held to a tight tolerance (a pre-activation within rounding distance of 0 otherwise resolves
+        differently in any two fp32 implementations and moves whole gradients by O(1 / (B*H*W)))."""
+        f64 = self.f64
+        masks_from = masks_from or {}
+        g = self.grads
+        g[:] = 0
+        d = _c(delta, self.dt)
+        self.deltas = [None] * len(self.layers)
+        for idx in range(len(self.layers) - 1, -1, -1):
+            e, xin = self.layers[idx], self.inputs[idx]
+            k = e["kind"]
+            if k == "linear":
+                p = self._p(e)
+                ni, no = e["n_in"], e["n_out"]
+                gw, gb, d = linear_backward(xin.reshape(xin.shape[0], ni), d, p[: ni * no].reshape(ni, no), f64=f64)
+                self._p(e, g)[: ni * no], self._p(e, g)[ni * no :] = gw.ravel(), gb
+                d = d.reshape(xin.shape)
+            elif k == "relu":
+                d = relu_backward(masks_from.get(idx, self.acts[idx]), d, f64=f64)
+            elif k == "pool":
+                mask = maxpool_forward(masks_from[idx], e["k"], e["step"], f64=f64)[1] if idx in masks_from else self.aux[idx]
+                d = maxpool_backward(d, mask, xin.shape, e["k"], e["step"], f64=f64)
+            elif k == "bn":
+                c = e["in"][0]
+                p = self._p(e)
+                d, gg, gbeta = batchnorm_backward(xin, d, p[:c], self.aux[idx][0], self.aux[idx][1], f64=f64)
+                self._p(e, g)[:c], self._p(e, g)[c : 2 * c] = gg, gbeta
+            else:
+                ci, co, kk = e["in"][0], e["Co"], e["k"]
+                p = self._p(e)
+                gw, gb, d = conv2d_backward_padded(xin, d, p[: co * ci * kk * kk].reshape(co, ci, kk, kk), e["s"], e["pad"], f64=f64)
+                self._p(e, g)[: co * ci * kk * kk], self._p(e, g)[co * ci * kk * kk :] = gw.ravel(), gb
+            self.deltas[idx] = d
+        return d
+
+    def train_step(self, x, labels, lr):
+        """one iteration of cnn.cpp:79-90; -> (loss, probs)"""
+        logits = self.forward(x, training=True)
+        probs = softmax(logits, f64=self.f64)
+        loss, delta = cross_entropy_backward(probs, labels, f64=self.f64)
+        self.backward(delta)
+        self.params[:] = sgd_update(self.params, self.grads, lr, f64=self.f64)  # BN moving_* slots have zero gradient
         return loss, probs

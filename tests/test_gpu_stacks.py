@@ -1,0 +1,203 @@
+"""GPU parity of the BASELINE configs[3] / [4] workloads: the VGG-11-shaped and ResNet-18-shaped layer lists (cnn_amd/stacks.py,
+cnn_amd/host/src/network.cpp) run through the C++ Layer API (architectures::Sequential -> C ABI -> HIP kernels) against the same
+lists composed from the oracle's layer functions (oracle.pyoracle.SeqNet), plus full-batch properties the oracle is too slow for."""
+import numpy as np
+import pytest
+
+from cnn_amd import stacks as S
+from oracle import pyoracle as O
+from tests.util import REL_TOL, assert_close, assert_close_arbitrated, he_init, rel_err, uniform01
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    from cnn_amd import capi
+
+    arch = capi.load().cnn_amd_device_arch().decode()
+    assert arch == "gfx950", f"built for gfx950, running on {arch}"
+    O.set_threads(0)  # (checker only: order-preserving thread split, bit-identical to 1 thread)
+    yield torch
+    O.set_threads(1)
+
+
+def _slices(layout):
+    """(name, lo, hi, layer index) of every parameter block in the flat checkpoint-order arena"""
+    out, off, n = [], 0, 0
+    for idx, e in enumerate(layout):
+        if e["kind"] == "conv":
+            n += 1
+            nw = e["Co"] * e["in"][0] * e["k"] ** 2
+            out += [(f"conv{n}.w", off, off + nw, idx), (f"conv{n}.b", off + nw, off + e["params"], idx)]
+        elif e["kind"] == "bn":
+            c = e["in"][0]
+            out += [(f"bn{n}.gamma", off, off + c, idx), (f"bn{n}.beta", off + c, off + 2 * c, idx)]
+        elif e["kind"] == "linear":
+            nw = e["n_in"] * e["n_out"]
+            out += [("linear.w", off, off + nw, idx), ("linear.b", off + nw, off + e["params"], idx)]
+        off += e["params"]
+    return out
+
+
+@pytest.mark.parametrize("which", ["vgg11", "resnet18"])
+def test_cpp_builders_match_the_python_layer_lists(T, which):
+    """architectures::build_vgg11 / build_resnet18 (network.cpp) == cnn_amd/stacks.py (what the oracle is composed from)"""
+    from cnn_amd import hostapi
+
+    spec = S.STACKS[which]()
+    layout = S.walk(spec)
+    net = hostapi.HostStack(which, 3, batch_norm=(which == "resnet18"))
+    want = list(zip(hostapi._layer_names(spec), [e["params"] for e in layout]))
+    assert net.describe() == want
+    assert net.n_params == sum(e["params"] for e in layout)
+    net.close()
+
+
+# (name, input resolution, batch): the full 224x224 geometry at the smallest batch the task names, plus a ragged low-resolution
+# case whose spatial sizes are odd everywhere (border handling of every padded / strided layer)
+STACK_CASES = [("vgg11", 224, 2), ("resnet18", 224, 2), ("vgg11", 75, 3), ("resnet18", 97, 3)]
+
+
+@pytest.mark.parametrize("which,res,B", STACK_CASES, ids=lambda v: str(v))
+def test_stack_train_steps_vs_oracle(T, which, res, B):
+    """two full train steps (cnn.cpp:79-90) of the whole stack: logits, loss, every parameter gradient and the post-SGD
+    parameters against the oracle; gradients fp64-arbitrated (tests/util.py)"""
+    from cnn_amd import hostapi
+
+    spec = S.STACKS[which]()
+    in_shape = (3, res, res)
+    onet = O.SeqNet(spec, in_shape)
+    onet64 = O.SeqNet(spec, in_shape, f64=True)
+    p0 = he_init(onet.layers, 40 + res)
+    onet.params[:] = p0
+    onet64.params[:] = p0
+    net = hostapi.HostSequential(spec, in_shape)
+    assert net.n_params == onet.n_params
+    net.set_params(p0)
+    x = uniform01(41 + res, (B,) + in_shape)
+    labels = (np.arange(B) % 3).astype(np.int32)
+    xd = T.from_numpy(x).cuda()
+    lr = 1e-3
+    names = hostapi._layer_names(spec)
+    for step in range(2):
+        loss = net.train_step_device(xd, labels, lr, do_update=False)
+        g = net.get_grads()
+        p_before = net.get_params()
+        ologits = onet.forward(x)
+        oloss, odelta = O.cross_entropy_backward(O.softmax(ologits), labels)
+        l64 = onet64.forward(x)
+        _, d64 = O.cross_entropy_backward(O.softmax(l64, f64=True), labels, f64=True)
+        logits = net.layer_output("linear_1", (B, 3))
+        assert_close_arbitrated(logits, ologits, l64, REL_TOL, 2.0, f"{which} step{step} logits")
+        assert abs(loss - oloss) <= 1e-4 * max(1.0, abs(oloss)), (loss, oloss)
+        # forward: every ReLU output and every pool output through Layer::get_output() (alexnet.cpp:97,105 contract)
+        masks_from, flipped, total = {}, 0, 0
+        for idx, e in enumerate(onet.layers):
+            if e["kind"] not in ("relu", "pool"):
+                continue
+            got = net.layer_output(names[idx], (B,) + e["out"])
+            assert_close_arbitrated(got, onet.acts[idx], onet64.acts[idx], REL_TOL, 2.0, f"{which} step{step} {names[idx]} output")
+            if e["kind"] == "relu":
+                masks_from[idx] = got
+                flipped += int(np.count_nonzero((got <= 0) != (onet.acts[idx] <= 0)))
+                total += got.size
+                if idx + 1 < len(onet.layers) and onet.layers[idx + 1]["kind"] == "pool":
+                    masks_from[idx + 1] = got  # the pool's input IS this ReLU's output
+        # the discrete decisions (ReLU pass / block) agree except for pre-activations within rounding distance of zero
+        assert flipped <= max(2, 2e-5 * total), (flipped, total)
+        # backward: the oracle takes its ReLU' / MaxPool' decisions from the HIP forward tensors (SeqNet.backward), so both sides
+        # differentiate the SAME piecewise-linear function; 1e-4 tensor-normalised, fp64-arbitrated (tests/util.py)
+        onet.backward(odelta, masks_from=masks_from)
+        onet64.backward(d64, masks_from=masks_from)
+        for name, lo, hi, idx in _slices(onet.layers):
+            assert_close_arbitrated(g[lo:hi], onet.grads[lo:hi], onet64.grads[lo:hi], REL_TOL, 2.0, f"{which} step{step} grad {name}")
+        off = 0
+        for e in onet.layers:  # BatchNorm2D moving statistics, updated by the forward pass (batchnorm2d.cpp:78-79)
+            if e["kind"] == "bn":
+                c = e["in"][0]
+                sl = slice(off + 2 * c, off + 4 * c)
+                assert_close_arbitrated(p_before[sl], onet.params[sl], onet64.params[sl], REL_TOL, 2.0, f"{which} step{step} moving statistics")
+            off += e["params"]
+        net.update(lr, 1.0)
+        got = net.get_params()
+        # the SGD step itself is bit-exact given the gradients (test_sgd_bit_exact_and_scaled): check it on the HIP gradients
+        assert np.array_equal(got, O.sgd_update(p_before, g, lr)), f"{which} step{step}: p - lr*g is not bit-exact"
+        # the second step starts from IDENTICAL parameters again (prepared filters, fused paths): without this the last-bit
+        # differences of step 1's update would be amplified through 8-17 layers
+        onet.params[:] = got
+        onet64.params[:] = got
+    net.close()
+
+
+@pytest.mark.parametrize("which", ["vgg11", "resnet18"])
+def test_stack_full_batch_fused_equals_unfused(T, which):
+    """BASELINE batch (128 / 64 per GPU): the container with fuse_layers (fused Conv+ReLU, ReLU' in the data gradients, prepared
+    filters) is bit-identical to one-kernel-per-layer-call, and finite"""
+    from cnn_amd import hostapi
+
+    B = S.DEFAULT_BATCH[which]
+    spec = S.STACKS[which]()
+    layout = S.walk(spec)
+    p0 = he_init(layout, 50)
+    x = T.rand((B, 3, 224, 224), generator=T.Generator(device="cuda").manual_seed(5), device="cuda")
+    labels = (np.arange(B) % 3).astype(np.int32)
+    res = []
+    for fuse in (1, 0):
+        hostapi.load().cnnh_set_fuse_layers(fuse)
+        try:
+            net = hostapi.HostSequential(spec)
+            net.set_params(p0)
+            losses = [net.train_step_device(x, labels, 1e-3) for _ in range(2)]  # 2nd step runs from prepared filters
+            res.append((losses, net.get_grads(), net.get_params()))
+            net.close()
+        finally:
+            hostapi.load().cnnh_set_fuse_layers(1)
+    (l1, g1, p1), (l0, g0, p0_) = res
+    assert np.all(np.isfinite(g1)) and np.all(np.isfinite(p1)) and np.all(np.isfinite(l1))
+    assert l1 == l0
+    assert np.array_equal(g1, g0) and np.array_equal(p1, p0_)
+
+
+# every distinct convolution geometry of the two stacks at the BASELINE batch: MFMA path == im2col functional fallback
+def _distinct_geoms():
+    seen, out = set(), []
+    for which in ("vgg11", "resnet18"):
+        for g in S.conv_geometries(which):
+            key = (S.DEFAULT_BATCH[which],) + g
+            if key not in seen:
+                seen.add(key)
+                out.append(key)
+    return out
+
+
+@pytest.mark.parametrize("case", _distinct_geoms(), ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_stack_layers_full_batch_mfma_equals_im2col(T, case):
+    from cnn_amd import capi
+
+    B, Ci, H, W, Co, k, s, pad = case
+    g = T.Generator(device="cuda").manual_seed(7)
+    conv = capi.Conv2d(*case)
+    x = T.rand((B, Ci, H, W), generator=g, device="cuda")
+    w = T.randn((Co, Ci, k, k), generator=g, device="cuda") * float(np.sqrt(2.0 / (Ci * k * k)))
+    b = T.randn((Co,), generator=g, device="cuda") * 0.1
+    dy = T.rand(conv.out_shape(), generator=g, device="cuda") * 2 - 1
+
+    def err(a, ref):  # tests/util.rel_err on the device (the tensors are up to 1.6 GB)
+        return float((a - ref).abs().max() / ref.abs().max())
+
+    y = conv.forward(x, w, b)
+    yr = conv.forward_im2col(x, w, b)
+    assert err(y, yr) <= REL_TOL
+    del y, yr
+    dx = conv.backward_data(dy, w)
+    dxr = conv.backward_data_im2col(dy, w)
+    assert err(dx, dxr) <= REL_TOL
+    del dx, dxr
+    gw, gb = conv.backward_weight(x, dy, float(B))
+    gwr, gbr = conv.backward_weight_im2col(x, dy, float(B))
+    assert err(gw, gwr) <= REL_TOL
+    assert err(gb, gbr) <= REL_TOL

@@ -39,3 +39,39 @@ def assert_close(a, ref, tol=REL_TOL, what=""):
     e = rel_err(a, ref)
     assert e <= tol, f"{what}: tensor-normalised error {e:.3e} > {tol:.1e}"
     return e
+
+
+def assert_close_arbitrated(a, ref32, ref64, tol=REL_TOL, k=2.0, what=""):
+    """Deep-network gradients: the fp32 oracle itself drifts from the exact result (the reference's sequential sums, SURVEY.md
+    H3), so a fixed 1e-4 against IT can fail for an implementation that is no worse.  fp64 arbitration: pass when the HIP
+    result is within `tol` of the fp32 oracle, OR no further from the fp64 restatement of the same loop nests than k x the
+    fp32 oracle is (both tensor-normalised by the fp64 tensor)."""
+    assert np.asarray(a).shape == np.asarray(ref32).shape == np.asarray(ref64).shape, what
+    e = rel_err(a, ref32)
+    if e <= tol:
+        return e
+    e_hip, e_ora = rel_err(a, ref64), rel_err(ref32, ref64)
+    assert e_hip <= max(k * e_ora, tol), (f"{what}: {e:.3e} from the fp32 oracle (> {tol:.1e}) and {e_hip:.3e} from fp64 truth, "
+                                          f"while the fp32 oracle is {e_ora:.3e} from it (allowed {k} x)")
+    return e
+
+
+def he_init(layout, seed):
+    """seeded parameters for a cnn_amd.stacks / oracle.SeqNet layout, flat in checkpoint order: N(0, 2/fan_in) filters and
+    matrices (keeps activations O(1) through 8-17 layers; the reference's N(0,1)/10 would overflow the deep stacks), small
+    biases, BatchNorm2D gamma ~ 1, beta ~ 0, moving statistics 0 (batchnorm2d.cpp:18-20)."""
+    rs = np.random.RandomState(seed)
+    parts = []
+    for e in layout:
+        kind = e["kind"]
+        if kind == "conv":
+            ci, co, k = e["in"][0], e["Co"], e["k"]
+            parts.append(rs.standard_normal(co * ci * k * k) * np.sqrt(2.0 / (ci * k * k)))
+            parts.append(rs.standard_normal(co) * 0.05)
+        elif kind == "bn":
+            c = e["in"][0]
+            parts += [1.0 + 0.1 * rs.standard_normal(c), 0.1 * rs.standard_normal(c), np.zeros(c), np.zeros(c)]
+        elif kind == "linear":
+            parts.append(rs.standard_normal(e["n_in"] * e["n_out"]) * np.sqrt(1.0 / e["n_in"]))
+            parts.append(rs.standard_normal(e["n_out"]) * 0.05)
+    return np.concatenate(parts).astype(np.float32) if parts else np.zeros(0, np.float32)
