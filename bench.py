@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""bench.py -- images/sec of one full train step of the reference network on the HIP path (MI355X).
+"""bench.py -- images/sec of one full train step of a BASELINE workload on the HIP path (MI355X).
 
 A "step" = one iteration of cpu/src/cnn.cpp:79-90 on one batch of synthetic 224x224x3 fp32 images already resident
 in HBM: forward, softmax + cross-entropy, backward, [RCCL all-reduce of the flat gradient arena], SGD.
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 20 --warmup 5                      # the reference net, BASELINE configs[1] (the metric's config)
+    python bench.py --config vgg11 | resnet18                           # configs[3] / [4]: through the C++ Layer API
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 Prints ONE JSON line on rank 0 (contract in the task brief) with two extra objects:
@@ -172,22 +173,175 @@ def conv_ns_bench(torch, capi, reps=5):
     return out
 
 
+def cpu_baseline_stack(name, budget_s=25.0):
+    """the oracle's layer functions composed into the VGG-11 / ResNet-18-shaped list (oracle.pyoracle.SeqNet), 1 thread"""
+    import numpy as np
+
+    from cnn_amd import stacks
+    from oracle import pyoracle as O
+
+    O.set_threads(1)
+    batch = 1 if name == "vgg11" else 2  # (BatchNorm2D needs more than one sample to be meaningful)
+    spec = stacks.STACKS[name]()
+    net = O.SeqNet(spec)
+    net.params[:] = stacks.he_init(stacks.walk(spec), 1234)
+    rs = np.random.RandomState(0)
+    x = rs.rand(batch, 3, 224, 224).astype(np.float32)
+    labels = (np.arange(batch) % 3).astype(np.int32)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        net.train_step(x, labels, 1e-3)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or steps >= 8:
+            break
+    return {"value": round(steps * batch / el, 3), "unit": "images/sec", "cores": 1, "kind": "port", "host_cores": os.cpu_count(),
+            "sample": f"{steps} full train step(s) of the {name}-shaped stack at batch {batch}, 224x224x3 (no warm-up: one step is "
+                      f"~{el / steps:.0f} s); oracle/cnn_oracle.c layer functions composed by oracle/pyoracle.py SeqNet, built -O2 "
+                      f"without FMA like cpu/CMakeLists.txt:5"}
+
+
+def init_comm(capi, torch, dist, world, rank):
+    """RCCL communicator for the C-ABI exchange (cnn_allreduce_grads): rank 0 creates the 128-byte id, torch.distributed
+    ships it (plumbing), every rank joins with cnn_comm_init_rank on its own device.  -> (comm, description)"""
+    import ctypes as C
+
+    lib = capi.load()
+    if not lib.cnn_comm_available():
+        raise capi.CnnAmdError("librccl could not be bound by libcnn_amd.so: " + lib.cnn_amd_last_error().decode())
+    raw = (C.c_char * 128)()
+    if rank == 0:
+        capi.check(lib.cnn_comm_unique_id(raw), "cnn_comm_unique_id")
+    buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).cuda()
+    dist.broadcast(buf, 0)
+    ident = buf.cpu().numpy().tobytes()
+    comm = C.c_void_p()
+    capi.check(lib.cnn_comm_init_rank(C.byref(comm), world, rank, ident), "cnn_comm_init_rank")
+    w, r = C.c_int(), C.c_int()
+    capi.check(lib.cnn_comm_info(comm, C.byref(w), C.byref(r)), "cnn_comm_info")
+    assert (w.value, r.value) == (world, rank), (w.value, r.value, world, rank)
+    # one exchange up front, checked against torch.distributed's own all-reduce of the same values
+    probe = torch.arange(1024, device="cuda", dtype=torch.float32) * (rank + 1)
+    ref = probe.clone()
+    capi.check(lib.cnn_allreduce_grads(comm, capi._ptr(probe), probe.numel(), capi._stream()), "cnn_allreduce_grads")
+    dist.all_reduce(ref)
+    torch.cuda.synchronize()
+    assert torch.equal(probe, ref), "cnn_allreduce_grads disagrees with torch.distributed.all_reduce"
+    return comm, {"ranks": w.value, "rccl_version": int(lib.cnn_comm_version()), "entry": "cnn_allreduce_grads (include/cnn_amd.h)",
+                  "NCCL_ALGO": os.environ.get("NCCL_ALGO", "default"), "NCCL_PROTO": os.environ.get("NCCL_PROTO", "default")}
+
+
+class CommAllreduce:
+    """what cnn_amd.dp.allreduce_grads takes in place of torch.distributed: an in-place sum through the C ABI, on the current stream"""
+
+    def __init__(self, capi, comm):
+        self.capi, self.comm = capi, comm
+
+    def all_reduce(self, t):
+        self.capi.check(self.capi.load().cnn_allreduce_grads(self.comm, self.capi._ptr(t), t.numel(), self.capi._stream()),
+                        "cnn_allreduce_grads")
+
+
+def make_runner(config, api, batch, torch, capi, world, rank, comm, pool_block=True):
+    """-> dict(step, flush, loss, ...): one train step (cnn.cpp:79-90) of a BASELINE workload on a device-resident synthetic
+    batch.  api "pynet": Python driver -> C ABI (reference net only); api "layer": the C++ Layer API
+    (architectures::Sequential::train_step, cnn_amd/host) -> C ABI."""
+    import numpy as np
+
+    from cnn_amd import stacks
+
+    B = batch or stacks.DEFAULT_BATCH[config]
+    g = torch.Generator(device="cuda").manual_seed(100 + rank)  # each rank has its own shard of the global batch
+    x = torch.rand((B, 3, 224, 224), generator=g, device="cuda")
+    labels = (torch.arange(B, device="cuda") % 3).to(torch.int32)
+    lr = 1e-3
+    rs = np.random.RandomState(1234)  # identical init on every rank: replicas stay in lock-step without a broadcast
+    if config == "alexnet" and api == "pynet":
+        from cnn_amd.pynet import AlexNetHip
+
+        # defer_input_grad: conv_layer_1's data gradient (no consumer) is launched one forward pass later on a second stream;
+        # flush() launches a pending one, so the timed region contains exactly K of them (cnn_amd/pynet.py)
+        net = AlexNetHip(B, 3, defer_input_grad=True, fuse_pool=pool_block and not os.environ.get("CNN_AMD_NO_POOL_FUSION"))
+        net.load_params((rs.standard_normal(net.n_params) * 0.1).astype(np.float32))
+        handle = CommAllreduce(capi, comm) if world > 1 else None
+        return dict(step=lambda: net.train_step(x, labels, lr, handle, world), flush=net.flush, B=B, n_params=net.n_params,
+                    loss=lambda: float(net.loss_sum.item()) / B, keep=(net, x, labels), close=lambda: None,
+                    api="python driver (cnn_amd/pynet.py) -> C ABI; first block pool-fused, conv_layer_1 data gradient deferred")
+    from cnn_amd import hostapi
+
+    lib = hostapi.load()
+    lib.cnnh_set_fuse_pool_block(1 if (pool_block and config == "alexnet") else 0)
+    if config == "alexnet":
+        net = hostapi.HostAlexNet(3)
+        net.set_params((rs.standard_normal(net.n_params) * 0.1).astype(np.float32))
+    else:
+        spec = stacks.STACKS[config]()
+        net = hostapi.HostSequential(spec)
+        net.set_params(stacks.he_init(net.layout, 1234))
+    if world > 1:
+        net.set_comm(comm, world)  # Sequential::update_gradients all-reduces the arena; BatchNorm2D layers run as sync-BN
+
+    def close():
+        net.close()
+        lib.cnnh_set_fuse_pool_block(0)
+
+    return dict(step=lambda: net.train_step(x, labels, lr), flush=lambda: None, B=B, n_params=net.n_params, loss=net.last_loss,
+                keep=(net, x, labels), close=close,
+                api="C++ Layer API (architectures::Sequential::train_step, cnn_amd/host) -> C ABI"
+                    + ("; fuse_pool_block on (conv_layer_1 / relu_layer_1 outputs not materialised)" if (pool_block and config == "alexnet")
+                       else "; every Layer::get_output() valid"))
+
+
+WORKLOADS = {
+    "alexnet": "reference AlexNet-style net (cpu/src/alexnet.cpp:10-33: 4x Conv3x3/s2 + ReLU, one MaxPool2x2, Linear 4608->3), "
+               "full train step (fwd + softmax/CE + bwd + SGD), 224x224x3 fp32, BASELINE configs[1]",
+    "vgg11": "VGG-11-shaped stack of the reference's layer types (8x Conv3x3/s1/p1 3->64->128->256->256->512->512->512->512 + ReLU, "
+             "MaxPool2x2 after convs 1,2,4,6,8, Linear 25088->3), full train step, 224x224x3 fp32, BASELINE configs[3]",
+    "resnet18": "ResNet-18-shaped sequential stack (7x7/s2 stem, MaxPool2x2, 16 convs in 4 stages: 3x3/s1/p1 + stage entries 3x3/s2, "
+                "1x1/s2, 3x3/s2; BatchNorm2D + ReLU after every conv; Linear 25088->3), full train step, 224x224x3 fp32, "
+                "BASELINE configs[4] (batch 512 over 8 GPUs = 64 per GPU)",
+}
+
+
+def timed_steps(torch, step, barrier, steps, warmup):
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE configs 2/3: 256)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=["alexnet", "vgg11", "resnet18"], default="alexnet",
+                    help="alexnet = BASELINE configs[1] (the metric's configuration), vgg11 = configs[3], resnet18 = configs[4]")
+    ap.add_argument("--api", choices=["pynet", "layer"], default=None,
+                    help="pynet: Python driver -> C ABI (alexnet only, default there); layer: C++ Layer API -> C ABI")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256 / 128 / 64 for alexnet / vgg11 / resnet18)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-ns", action="store_true")
+    ap.add_argument("--no-layer-api", action="store_true", help="skip the extra C++ Layer API legs of the default config")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
     args = ap.parse_args()
+    small = args.config == "alexnet"
+    if args.steps is None:
+        args.steps = 100 if small else 10
+    if args.warmup is None:
+        args.warmup = 20 if small else 3
+    api = args.api or ("pynet" if small else "layer")
+    if api == "pynet" and not small:
+        raise SystemExit("--api pynet drives the reference net only; the stacks run through the C++ Layer API")
 
     import numpy as np
     import torch
 
-    from cnn_amd import capi
-    from cnn_amd.pynet import AlexNetHip
+    from cnn_amd import capi, stacks
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -198,28 +352,18 @@ def main():
     torch.cuda.set_device(local)
     arch = capi.load().cnn_amd_device_arch().decode()
     assert arch == "gfx950", f"libcnn_amd.so targets gfx950, device reports {arch}"
-    dist = None
+    dist, comm, comm_info = None, None, None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # plumbing: rendezvous, barrier, max-over-ranks
+        comm, comm_info = init_comm(capi, torch, dist, world, rank)             # the data path's exchange: C ABI -> RCCL
 
-    B = args.batch
-    # defer_input_grad: conv_layer_1's data gradient (no consumer) is launched one forward pass later on a second stream;
-    # barrier() flushes it, so the timed region contains exactly K of them (cnn_amd/pynet.py)
-    net = AlexNetHip(B, 3, defer_input_grad=True, fuse_pool=not os.environ.get("CNN_AMD_NO_POOL_FUSION"))
-    rs = np.random.RandomState(1234)  # identical init on every rank: replicas stay in lock-step without a broadcast
-    net.load_params((rs.standard_normal(net.n_params) * 0.1).astype(np.float32))
-    g = torch.Generator(device="cuda").manual_seed(100 + rank)  # each rank has its own shard of the global batch
-    x = torch.rand((B, 3, 224, 224), generator=g, device="cuda")
-    labels = (torch.arange(B, device="cuda") % 3).to(torch.int32)
-    lr = 1e-3
-
-    def step():
-        net.train_step(x, labels, lr, dist, world)
+    run = make_runner(args.config, api, args.batch, torch, capi, world, rank, comm)
+    B, step = run["B"], run["step"]
 
     def barrier():
-        net.flush()
+        run["flush"]()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -240,7 +384,8 @@ def main():
 
     # --- timed region: exactly K steps; only the dominant kernel is event-bracketed ---
     # (every 4th launch of it: the event pair around a kernel costs its stream two ~6 us bubbles -- measured 13 us per step)
-    capi.kernel_timing(2, dominant, every=4)
+    every = 4 if small else 1
+    capi.kernel_timing(2, dominant, every=every)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -253,12 +398,14 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss = float(net.loss_sum.item()) / B
+    loss = run["loss"]()
     assert np.isfinite(loss), "training diverged: loss is not finite"
 
     out = None
     if rank == 0:
         cnt, ms = dom[dominant]
+        spec = stacks.STACKS[args.config]()
+        flops_img = stacks.train_flops_per_image(spec)
         out = {
             "metric": "images/sec (train step, 224x224x3)",
             "value": round(world * B * args.steps / elapsed, 1),
@@ -273,32 +420,57 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "reference AlexNet-style net (cpu/src/alexnet.cpp:10-33: 4x Conv3x3/s2 + ReLU, one MaxPool2x2, "
-                            "Linear 4608->3), full train step (fwd + softmax/CE + bwd + SGD), 224x224x3 fp32, BASELINE configs[1]",
+                "workload": WORKLOADS[args.config],
                 "per_gpu_batch": B,
                 "global_batch": world * B,
-                "parallelism": f"dp{world}" + (" (RCCL all-reduce of the 111267-float gradient arena per step)" if world > 1 else ""),
+                "parallelism": f"dp{world}" + (f" (RCCL all-reduce of the {run['n_params']}-float gradient arena per step)" if world > 1 else ""),
+                "driver": run["api"],
             },
-            "roofline": dict(roofline_entry(dominant, cnt, ms, with_traffic=True), sampled="every 4th launch in the timed region"),
+            "roofline": dict(roofline_entry(dominant, cnt, ms, with_traffic=True),
+                             sampled=("every 4th launch" if every == 4 else "every launch") + " in the timed region"),
+            "step_tflops": round(flops_img * B * args.steps / elapsed / 1e12, 2),
+            "step_frac_of_mfma_peak": round(flops_img * B * args.steps / elapsed / 1e12 / PEAK_MFMA_F32_TFLOPS, 4),
             "final_loss": round(loss, 5),
         }
+        if comm_info:
+            out["exchange"] = comm_info
         if args.breakdown:
             tot = sum(v[1] for v in table.values())
             for k, (c, m) in sorted(table.items(), key=lambda kv: -kv[1][1]):
                 r = roofline_entry(k, c, m)
                 print(f"{m / c:9.4f} ms x{c / 3:3.0f} {100 * m / tot:5.1f}%  {r['achieved']:>9} {r['unit']:8} {k}", file=sys.stderr)
             print(f"{tot / 3:9.4f} ms kernel total for one step (mean of 3 instrumented steps; side-stream kernels overlap in real steps)", file=sys.stderr)
+    run["close"]()
+    del run
+    torch.cuda.empty_cache()
 
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1:
-        if not args.no_conv_ns:
+        if small and api == "pynet" and not args.no_layer_api:
+            # the same workload through the boundary north_star names: the C++ Layer::forward / backward classes
+            # (architectures::AlexNet via Sequential::train_step), once with the opt-in pool-block fusion the headline uses and
+            # once with every Layer::get_output() valid
+            for key, pool in (("layer_api", True), ("layer_api_default", False)):
+                r2 = make_runner("alexnet", "layer", args.batch, torch, capi, 1, 0, None, pool_block=pool)
+
+                def sync():
+                    torch.cuda.synchronize()
+
+                el = timed_steps(torch, r2["step"], sync, args.steps, args.warmup)
+                out[key] = {"value": round(r2["B"] * args.steps / el, 1), "unit": "images/sec", "ms_per_step": round(el / args.steps * 1e3, 4),
+                            "driver": r2["api"], "final_loss": round(r2["loss"](), 5)}
+                r2["close"]()
+                del r2
+                torch.cuda.empty_cache()
+        if small and not args.no_conv_ns:
             out["conv_ns"] = conv_ns_bench(torch, capi)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline() if small else cpu_baseline_stack(args.config)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        capi.load().cnn_comm_destroy(comm)
         dist.destroy_process_group()
 
 

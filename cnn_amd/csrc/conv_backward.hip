@@ -31,6 +31,15 @@ int get_side(SideStream** out) {
     *out = &side;
     return CNN_AMD_OK;
 }
+// Layers whose two gradient kernels are each MFMA-bound and fill the chip for a long time (the VGG / ResNet-shaped stacks) gain
+// nothing from running side by side -- they just halve each other's rate and thrash each other's L2 -- so their weight
+// gradient stays on the caller's stream, behind the data gradient: no fork, no join, no event bubbles.
+bool heavy_layer(const cnn_conv2d_desc* d) {
+    const double Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
+    const double flops = 2.0 * d->B * d->Co * Ho * Wo * d->Ci * d->k * d->k;
+    static const double limit = getenv("CNN_AMD_SERIAL_BWD_GFLOP") ? atof(getenv("CNN_AMD_SERIAL_BWD_GFLOP")) * 1e9 : 2e10;
+    return flops >= limit;
+}
 size_t dgrad_region_bytes(const cnn_conv2d_desc* d) { return ((igemm_workspace_floats(d) + 63) / 64) * 64 * sizeof(float); }
 }  // namespace
 
@@ -68,6 +77,10 @@ int cnn_conv2d_backward(const cnn_conv2d_desc* d, const float* x, const float* d
     if (int rc = get_side(&side)) return rc;
     hipStream_t main = as_stream(stream);
     char* base = (char*)ws;
+    if (heavy_layer(d)) {
+        if (int rc = cnn_conv2d_backward_data(d, dy, w, dx, base, dbytes, main)) return rc;
+        return cnn_conv2d_backward_weight(d, x, dy, gw, gb, divisor, base + dbytes, ws_bytes - dbytes, main);
+    }
     CNN_HIP_CHECK(hipEventRecord(side->fork, main));
     CNN_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
     wgrad_defer_reduce(defer_join != 0);
@@ -95,6 +108,12 @@ int cnn_conv2d_backward_prepared_relu(const cnn_conv2d_desc* d, const float* x, 
     SideStream* side = nullptr;
     if (int rc = get_side(&side)) return rc;
     hipStream_t main = as_stream(stream);
+    if (heavy_layer(d)) {
+        if (int rc = relu_below ? cnn_conv2d_backward_data_relu_prepared(d, dy, prepared_dgrad, relu_below, dx, main)
+                                : cnn_conv2d_backward_data_prepared(d, dy, prepared_dgrad, dx, main))
+            return rc;
+        return cnn_conv2d_backward_weight(d, x, dy, gw, gb, divisor, ws, ws_bytes, main);
+    }
     CNN_HIP_CHECK(hipEventRecord(side->fork, main));
     CNN_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
     wgrad_defer_reduce(defer_join != 0);

@@ -1,6 +1,7 @@
 // conv_wgrad_rd.hip -- "register-direct" Conv2D weight / bias gradient (cpu/src/conv2d.cpp:117-159) for 3x3 filters,
-// stride 1 or 2, no padding: the same batched outer-product GEMM as conv_wgrad.hip
-//     gw[co][n] = sum_{b,p,q} dy[b][co][p][q] * x[b][ci_n][s*p + kx_n][s*q + ky_n],   n = (ci,kx,ky),
+// stride 1 or 2, padding 0 (the reference) or 1 (the VGG / ResNet-shaped stacks): the same batched outer-product GEMM as
+// conv_wgrad.hip
+//     gw[co][n] = sum_{b,p,q} dy[b][co][p][q] * x[b][ci_n][s*p + kx_n - pad][s*q + ky_n - pad],   n = (ci,kx,ky),
 // on v_mfma_f32_32x32x2_f32, but WITHOUT staging operands through LDS and without barriers in the main loop.
 //
 // The reduction index (pixels) may be visited in any order as long as the A and B operand of an MFMA step agree.  The
@@ -18,6 +19,12 @@
 // is in flight while the MFMAs of tile nt issue.  Measured on the north-star shape: 8.44 M shader cycles per workgroup
 // against 7.88 M cycles of pure MFMA issue (93 %); a per-tile ring of NT buffers was slower (9.12 M).
 // Guarded path: element-wise guarded loads for the chunks whose windows could leave the allocation.
+// Padding (PAD = 1): the windows keep their addresses -- a tap row above / below the image is the last / first row of the
+// neighbouring channel plane (mapped memory) -- and every (lane, tile, chunk) gets a live range [lo, hi) of k-slots: empty
+// for a row outside the image, clipped where the window starts one column left of the image or runs over its right edge;
+// one compare + select per MFMA step like the pad-0 kernels' `t < nb`.  Only output row 0 (and the first run of row 1) of
+// image 0 could read in front of the allocation (x[0][0][-1][..], x[0][0][0][-1]): those chunks take the guarded path
+// (RdParams::chunks_head), like the last rows of the tensor do for both paddings.
 //
 // The bias gradient (sum of dy) is accumulated on the VALU from the A registers (no ones-column: Ci*9 = 576 columns are
 // exactly 18 tiles).  The four waves of a workgroup split its chunk range and are summed in a fixed order through LDS at
@@ -54,7 +61,8 @@ struct RdParams {
     int runs_total;   // B * Ho * rpr
     int chunks_total, chunks_per_block;  // chunk = 2 runs
     unsigned m_rows, m_rpr;  // magic multipliers: run -> (image*Ho + p, segment) and -> image
-    int chunks_fast;  // chunks [0, chunks_fast) may over-read their windows without leaving x / dy (host-checked)
+    int chunks_fast;  // chunks [chunks_head, chunks_fast) may over-read their windows without leaving x / dy (host-checked)
+    int chunks_head;  // chunks [0, chunks_head) could read in FRONT of x (padding): guarded path
     int dbg;          // CNN_AMD_RD_DBG=9: workgroup 0 prints its shader-cycle count and the clock it ran at
 };
 
@@ -80,8 +88,9 @@ __device__ __forceinline__ f4u load4(const float* __restrict__ p, int nvalid) {
     return v;
 }
 
-template <int S, int NT, int RL, bool POOLED>
-__global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
+template <int S, int NT, int RL, bool POOLED, int PAD>
+__device__ __forceinline__ void wgrad_rd_body(const RdParams& p) {
+    static_assert(PAD == 0 || (PAD == 1 && !POOLED), "padding 0 or 1; the pooled-domain first block is unpadded");
     constexpr int WL = S * RL;  // floats of x a lane needs per chunk and tile
     __shared__ float red[32][NT * 32 + 1];  // (+1: bank padding; the column doubles as the bias-gradient slot)
     const int lane = threadIdx.x & 63, m = lane & 31, kg = lane >> 5;
@@ -91,17 +100,26 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
     const int nt_live = (p.Ntot - nbase + 31) / 32;  // tiles of this group that hold at least one column (block-uniform)
 
     // per-lane column description for every N tile: offset of the filter tap inside an image, window shift, parity
+    // column of pixel t in the input row: S*(q0+t) + cc, cc = ky - PAD; row: S*pr + dk, dk = kx - PAD.
+    // (kx, ky) of all NT tiles live in ONE register, 4 bits per tile (the padded kernels sit at the 256-register limit of two
+    // waves per SIMD: per-tile arrays for them cost 12 registers and the second wave)
     int xoff[NT], shift[NT];
     bool par[NT], nvalid_col[NT];
+    unsigned taps = 0;
+    auto dk_of = [&](int nt) { return (int)((taps >> (4 * nt)) & 3u) - PAD; };
+    auto cc_of = [&](int nt) { return (int)((taps >> (4 * nt + 2)) & 3u) - PAD; };
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = nbase + nt * 32 + m;
         const int nn = n < p.Ntot ? n : 0;
         const int ci = nn / 9, kx = (nn - ci * 9) / 3, ky = nn - ci * 9 - kx * 3;
         nvalid_col[nt] = n < p.Ntot;
-        shift[nt] = S == 2 ? (ky == 2 ? 2 : 0) : ky;
-        par[nt] = S == 2 && ky == 1;
-        xoff[nt] = (ci * p.H + kx) * p.W + shift[nt];
+        taps |= (unsigned)(kx | (ky << 2)) << (4 * nt);
+        const int c = ky - PAD;
+        // stride 2: the window starts at the even column 2*q0 + shift and pixel t is its element 2t (+1 when c is odd)
+        shift[nt] = S == 2 ? (c < 0 ? -2 : (c == 2 ? 2 : 0)) : c;
+        par[nt] = S == 2 && (c & 1);
+        xoff[nt] = (ci * p.H + kx - PAD) * p.W + shift[nt];
     }
 
     f32x16 acc[NT];
@@ -129,16 +147,107 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
         bsum += s;
     };
 
+    // ---- guarded path (defined below the pipelined one): chunks [lo, hi) of this wave
+    auto guarded = [&](int g_lo, int g_hi) {
+    for (int ch = g_lo; ch < g_hi; ++ch) {
+        const int run = 2 * ch + kg;  // this lane's run
+        const bool rlive = run < p.runs_total;
+        const int runc = rlive ? run : 0;
+        const int rowi = fdiv(runc, p.m_rpr, p.rpr), seg = runc - rowi * p.rpr;  // rowi = b*Ho + pr
+        const int b = fdiv(rowi, p.m_rows, p.Ho), pr = rowi - b * p.Ho;
+        const int q0 = seg * RL;
+        int npix = rlive ? p.Wo - q0 : 0;  // valid pixels of this lane's run
+        npix = npix < 0 ? 0 : (npix > RL ? RL : npix);
+        // ---- A operand: RL consecutive dy values of channel co
+        float a[RL];
+        if constexpr (POOLED) {
+            const bool rowok = co < p.Co && (pr >> 1) < p.PHo;
+            const int cc_ = co < p.Co ? co : 0;
+            int inwin = 2 * p.PWo - q0;
+            inwin = inwin < 0 ? 0 : inwin;
+            const int nv = rowok ? (npix < inwin ? npix : inwin) : 0;
+            const int nwin = (nv + 1) >> 1;  // windows the run's live pixels touch
+            const size_t o = (((size_t)b * p.Co + cc_) * p.PHo + (rowok ? (pr >> 1) : 0)) * p.PWo + (q0 >> 1);
+            const int e0 = (cc_ * p.Ho + pr) * p.Wo + q0;
+#pragma unroll
+            for (int j = 0; j < RL / 8; ++j) {
+                const f4u g = load4(p.dy + o + 4 * j, nwin - 4 * j), mk = load4((const float*)p.pmask + o + 4 * j, nwin - 4 * j),
+                          pl = p.pooled ? load4(p.pooled + o + 4 * j, nwin - 4 * j) : f4u{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int t = 8 * j + i, w = i >> 1;
+                    const float gv = w == 0 ? g.x : w == 1 ? g.y : w == 2 ? g.z : g.w, pv = w == 0 ? pl.x : w == 1 ? pl.y : w == 2 ? pl.z : pl.w;
+                    const int mv = __builtin_bit_cast(int, w == 0 ? mk.x : w == 1 ? mk.y : w == 2 ? mk.z : mk.w);
+                    a[t] = (t < nv && mv == e0 + t && !(pv <= 0.f)) ? gv : 0.f;
+                }
+            }
+        } else {
+            const bool rowok = co < p.Co;
+            const float* src = p.dy + (((size_t)b * p.Co + (rowok ? co : 0)) * p.Ho + pr) * p.Wo + q0;
+            const int nv = rowok ? npix : 0;
+#pragma unroll
+            for (int j = 0; j < RL / 4; ++j) {
+                const f4u v = load4(src + 4 * j, nv - 4 * j);
+                a[4 * j] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
+            }
+        }
+        add_bias(a);
+        const float* ximg = p.x + (size_t)b * img_x + (size_t)(S * pr) * p.W + S * q0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nt >= nt_live) continue;
+            // ---- B operand: the lane's window of its filter tap's input row
+            float w[WL];
+            if constexpr (PAD > 0) {
+                // element-wise: pixel t reads column S*(q0+t) + cc of row S*pr + dk, zero outside the image
+                const int cc_nt = cc_of(nt);
+                const bool rowv = nvalid_col[nt] && (unsigned)(S * pr + dk_of(nt)) < (unsigned)p.H;
+                const float* src = ximg + (ptrdiff_t)(xoff[nt] - shift[nt]);  // (row, column S*q0) of the tap's input row
+#pragma unroll
+                for (int t = 0; t < RL; ++t) {
+                    const int col = S * (q0 + t) + cc_nt;
+                    const bool ok = rowv && t < npix && (unsigned)col < (unsigned)p.W;
+                    const float v = ok ? src[S * t + cc_nt] : 0.f;
+                    w[S == 2 ? 2 * t + (par[nt] ? 1 : 0) : t] = v;
+                    if (S == 2) w[2 * t + (par[nt] ? 0 : 1)] = 0.f;
+                }
+            } else {
+            const int col = S * q0 + shift[nt];
+            int rem = p.W - col;  // floats left in the input row
+            rem = rem < S * npix ? rem : S * npix;  // floats behind the run's last pixel are never multiplied by a live A
+            rem = nvalid_col[nt] ? (rem < 0 ? 0 : rem) : 0;
+            const float* src = ximg + xoff[nt];
+#pragma unroll
+            for (int j = 0; j < WL / 4; ++j) {
+                const f4u v = load4(src + 4 * j, rem - 4 * j);
+                w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+            }
+            }
+#pragma unroll
+            for (int t = 0; t < RL; ++t) {
+                const float bv = S == 2 ? (par[nt] ? w[2 * t + 1] : w[2 * t]) : w[t];
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bv, acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    };
+
+    // ---- head: the chunk(s) whose windows could start in front of x (PAD only)
+    const int h_hi = w_hi < p.chunks_head ? w_hi : p.chunks_head;
+    if (w_lo < h_hi) guarded(w_lo, h_hi);
+    const int p_lo = w_lo > h_hi ? w_lo : h_hi;
+
     // ---- pipelined path
     const int f_hi = w_hi < p.chunks_fast ? w_hi : p.chunks_fast;
-    int s_lo = w_lo;
-    if (w_lo < f_hi) {
+    int s_lo = p_lo;
+    if (p_lo < f_hi) {
         s_lo = f_hi;
         const int co_c = co < p.Co ? co : 0;
         unsigned cur_x = 0, nxt_x = 0, nxt_a = 0;
         int cur_nv = 0, nxt_nv = 0, cur_nb = 0, nxt_nb = 0;  // live pixels of the lane's run: A side (0 for co >= Co) / B side
         int cur_e = 0, nxt_e = 0;  // POOLED: flat index (within the sample) of the first pixel of the lane's run, channel co
-        auto locate = [&](int ch, unsigned& aoff, unsigned& xb, int& nv, int& nb, int& eidx) {
+        unsigned cur_pq = 0, nxt_pq = 0;  // PAD: output row (<< 16) | first column of the lane's run
+        auto locate = [&](int ch, unsigned& aoff, unsigned& xb, int& nv, int& nb, int& eidx, unsigned& pq_out) {
             const int run = 2 * ch + kg;
             const bool rlive = run < p.runs_total;
             const int runc = rlive ? run : 0;
@@ -160,6 +269,7 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
                 eidx = 0;
             }
             xb = (unsigned)(b * (p.Ci * p.H * p.W) + (S * pr) * p.W + S * q0);
+            pq_out = ((unsigned)pr << 16) | (unsigned)q0;
         };
         constexpr int NA = POOLED ? 3 * (RL / 8) : RL / 4;  // 16-byte pieces of the A side: dy run | dpool, mask, pooled of RL/2 windows
         auto load_a = [&](f4u (&buf)[NA], unsigned aoff) {
@@ -192,6 +302,18 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
         };
         // one tile's MFMAs: k-slot t <-> pixel t of the lane's run
         auto tile_mfma = [&](int nt, const float (&a)[RL], const f4u (&win)[WL / 4]) {
+            // live k-slots of this lane's window: [lo, lo + span)
+            int lo = 0, span = cur_nb;
+            if constexpr (PAD > 0) {
+                // a tap row outside the image still reads MAPPED memory (the neighbouring channel / image; the first and last
+                // rows of the whole tensor are the guarded path's) and is masked as a whole
+                const int c0 = S * (int)(cur_pq & 0xffffu) + cc_of(nt);  // column of pixel 0
+                lo = c0 < 0 ? 1 : 0;                                     // (c0 >= -PAD = -1)
+                int hi = S == 1 ? p.W - c0 : (p.W - c0 + 1) >> 1;        // pixels whose column is < W
+                hi = hi < cur_nb ? hi : cur_nb;
+                const bool rowv = (unsigned)(S * (int)(cur_pq >> 16) + dk_of(nt)) < (unsigned)p.H;
+                span = rowv ? hi - lo : 0;
+            }
 #pragma unroll
             for (int t = 0; t < RL; ++t) {
                 const int e = S == 2 ? 2 * t : t;  // window element of pixel t (even phase)
@@ -203,21 +325,23 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
                 } else {
                     bv = (e & 3) == 0 ? q.x : (e & 3) == 1 ? q.y : (e & 3) == 2 ? q.z : q.w;
                 }
-                bv = t < cur_nb ? bv : 0.f;  // what lies behind the run is not the reference's to read (may be Inf / NaN)
+                // what lies behind the run (or outside the image) is not the reference's to read (may be Inf / NaN)
+                if constexpr (PAD > 0) bv = (unsigned)(t - lo) < (unsigned)span ? bv : 0.f;
+                else bv = t < cur_nb ? bv : 0.f;
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bv, acc[nt], 0, 0, 0);
             }
         };
         f4u abuf[NA], wb[2][WL / 4];
         {
             unsigned a0;
-            locate(w_lo, a0, cur_x, cur_nv, cur_nb, cur_e);
+            locate(p_lo, a0, cur_x, cur_nv, cur_nb, cur_e, cur_pq);
             load_a(abuf, a0);
 #pragma unroll
             for (int j = 0; j < WL / 4; ++j) wb[0][j] = *(const f4u*)(p.x + (cur_x + (unsigned)xoff[0]) + 4 * j);
         }
         auto body = [&](auto PC, int ch_next) {
             constexpr int P = decltype(PC)::value;
-            locate(ch_next, nxt_a, nxt_x, nxt_nv, nxt_nb, nxt_e);
+            locate(ch_next, nxt_a, nxt_x, nxt_nv, nxt_nb, nxt_e, nxt_pq);
             float a[RL];
             build_a(a, abuf);
             add_bias(a);
@@ -240,8 +364,9 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
             cur_nv = nxt_nv;
             cur_nb = nxt_nb;
             cur_e = nxt_e;
+            cur_pq = nxt_pq;
         };
-        int ch = w_lo;
+        int ch = p_lo;
         if (NT & 1) {  // an odd tile count flips the buffer parity from chunk to chunk
             for (; ch + 1 < f_hi; ch += 2) {
                 body(std::integral_constant<int, 0>(), ch + 1);
@@ -253,73 +378,8 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
         }
     }
 
-    // ---- guarded path: the few chunks at the very end of the tensors (and tensors too small for the pipelined path)
-    for (int ch = s_lo; ch < w_hi; ++ch) {
-        const int run = 2 * ch + kg;  // this lane's run
-        const bool rlive = run < p.runs_total;
-        const int runc = rlive ? run : 0;
-        const int rowi = fdiv(runc, p.m_rpr, p.rpr), seg = runc - rowi * p.rpr;  // rowi = b*Ho + pr
-        const int b = fdiv(rowi, p.m_rows, p.Ho), pr = rowi - b * p.Ho;
-        const int q0 = seg * RL;
-        int npix = rlive ? p.Wo - q0 : 0;  // valid pixels of this lane's run
-        npix = npix < 0 ? 0 : (npix > RL ? RL : npix);
-        // ---- A operand: RL consecutive dy values of channel co
-        float a[RL];
-        if constexpr (POOLED) {
-            const bool rowok = co < p.Co && (pr >> 1) < p.PHo;
-            const int cc = co < p.Co ? co : 0;
-            int inwin = 2 * p.PWo - q0;
-            inwin = inwin < 0 ? 0 : inwin;
-            const int nv = rowok ? (npix < inwin ? npix : inwin) : 0;
-            const int nwin = (nv + 1) >> 1;  // windows the run's live pixels touch
-            const size_t o = (((size_t)b * p.Co + cc) * p.PHo + (rowok ? (pr >> 1) : 0)) * p.PWo + (q0 >> 1);
-            const int e0 = (cc * p.Ho + pr) * p.Wo + q0;
-#pragma unroll
-            for (int j = 0; j < RL / 8; ++j) {
-                const f4u g = load4(p.dy + o + 4 * j, nwin - 4 * j), mk = load4((const float*)p.pmask + o + 4 * j, nwin - 4 * j),
-                          pl = p.pooled ? load4(p.pooled + o + 4 * j, nwin - 4 * j) : f4u{1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int t = 8 * j + i, w = i >> 1;
-                    const float gv = w == 0 ? g.x : w == 1 ? g.y : w == 2 ? g.z : g.w, pv = w == 0 ? pl.x : w == 1 ? pl.y : w == 2 ? pl.z : pl.w;
-                    const int mv = __builtin_bit_cast(int, w == 0 ? mk.x : w == 1 ? mk.y : w == 2 ? mk.z : mk.w);
-                    a[t] = (t < nv && mv == e0 + t && !(pv <= 0.f)) ? gv : 0.f;
-                }
-            }
-        } else {
-            const bool rowok = co < p.Co;
-            const float* src = p.dy + (((size_t)b * p.Co + (rowok ? co : 0)) * p.Ho + pr) * p.Wo + q0;
-            const int nv = rowok ? npix : 0;
-#pragma unroll
-            for (int j = 0; j < RL / 4; ++j) {
-                const f4u v = load4(src + 4 * j, nv - 4 * j);
-                a[4 * j] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
-            }
-        }
-        add_bias(a);
-        const float* ximg = p.x + (size_t)b * img_x + (size_t)(S * pr) * p.W + S * q0;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            if (nt >= nt_live) continue;
-            // ---- B operand: the lane's window of its filter tap's input row
-            float w[WL];
-            const int col = S * q0 + shift[nt];
-            int rem = p.W - col;  // floats left in the input row
-            rem = rem < S * npix ? rem : S * npix;  // floats behind the run's last pixel are never multiplied by a live A
-            rem = nvalid_col[nt] ? (rem < 0 ? 0 : rem) : 0;
-            const float* src = ximg + xoff[nt];
-#pragma unroll
-            for (int j = 0; j < WL / 4; ++j) {
-                const f4u v = load4(src + 4 * j, rem - 4 * j);
-                w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
-            }
-#pragma unroll
-            for (int t = 0; t < RL; ++t) {
-                const float bv = S == 2 ? (par[nt] ? w[2 * t + 1] : w[2 * t]) : w[t];
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bv, acc[nt], 0, 0, 0);
-            }
-        }
-    }
+    // ---- tail: the few chunks at the very end of the tensors (and tensors too small for the pipelined path)
+    guarded(s_lo, w_hi);
 
     // ---- sum the four waves in a fixed order, then one slab per workgroup
     const float bsum2 = bsum + __shfl_xor(bsum, 32, 64);  // the two k-groups of channel co
@@ -350,6 +410,17 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
         slab[(size_t)(blockIdx.z * 32 + threadIdx.x) * p.pitch + p.Ntot] = red[threadIdx.x][NT * 32];
 }
 
+template <int S, int NT, int RL, bool POOLED>
+__global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
+    wgrad_rd_body<S, NT, RL, POOLED, 0>(p);
+}
+// The padded variants carry a few more live values per tile; without a register budget hipcc takes 290 registers for six
+// tiles and the kernel drops to ONE wave per SIMD (62 instead of 100+ TFLOP/s): two waves per SIMD = 256 registers, enforced.
+template <int S, int NT, int RL>
+__global__ __launch_bounds__(256, 2) void wgrad_rd_kernel_p1(const RdParams p) {
+    wgrad_rd_body<S, NT, RL, false, 1>(p);
+}
+
 inline unsigned magic_of(int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
 
 struct RdPlan {
@@ -358,11 +429,12 @@ struct RdPlan {
 };
 
 bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
-    if (d->k != 3 || d->pad != 0 || (d->s != 1 && d->s != 2)) return false;
+    if (d->k != 3 || d->pad < 0 || d->pad > 1 || (d->s != 1 && d->s != 2)) return false;
+    if (pooled && d->pad != 0) return false;
     RdParams& p = pl->p;
     p.B = d->B; p.Ci = d->Ci; p.H = d->H; p.W = d->W; p.Co = d->Co;
-    p.Ho = cnn_conv2d_out_dim(d->H, 3, d->s, 0);
-    p.Wo = cnn_conv2d_out_dim(d->W, 3, d->s, 0);
+    p.Ho = cnn_conv2d_out_dim(d->H, 3, d->s, d->pad);
+    p.Wo = cnn_conv2d_out_dim(d->W, 3, d->s, d->pad);
     if (p.Ho <= 0 || p.Wo <= 0) return false;
     p.Ntot = d->Ci * 9;
     p.pitch = p.Ntot + 1;
@@ -378,7 +450,8 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
     p.chunks_total = (int)chunks;
     // tiles per wave: the largest of 6..3 that divides the tile count (no dead tiles, equal groups), else 5
     const int tiles = (p.Ntot + 31) / 32;
-    const int nt_max = (d->s == 2 && pl->rl == 16) ? 5 : 6;  // (64-register window pairs: 6 tiles would not fit 256 VGPRs)
+    // (stride 2, runs of 16: 64-register window pairs -- 6 tiles do not fit 256 VGPRs, and with padding not 5 either)
+    const int nt_max = (d->s == 2 && pl->rl == 16) ? (d->pad ? 4 : 5) : 6;
     int nt = tiles <= nt_max ? tiles : 0;
     for (int c = nt_max; !nt && c >= 3; --c)
         if (tiles % c == 0) nt = c;
@@ -391,8 +464,19 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
     pl->ngroups = (tiles + nt - 1) / nt;
     pl->mtiles = (p.Co + 31) / 32;
     const int env = getenv("CNN_AMD_RD_BLOCKS") ? atoi(getenv("CNN_AMD_RD_BLOCKS")) : 0;
-    long long want = (env > 0 ? env : 2 * kNumCU) / ((long long)pl->ngroups * pl->mtiles);
+    const long long colblocks = (long long)pl->ngroups * pl->mtiles, slots = env > 0 ? env : 2 * kNumCU;
+    long long want = slots / colblocks;
     if (want < 1) want = 1;
+    if (env <= 0 && colblocks * want * 8 < slots * 7) {
+        // wide layers (Ci*9/32/NT column groups x Co/32 row tiles is already comparable to the chip): pick the split whose
+        // workgroup count fills whole rounds of the resident slots best (384 column blocks alone would leave a quarter idle)
+        double best = 0;
+        for (long long k = 1; k <= 8; ++k) {
+            const long long blocks = colblocks * k, rounds = (blocks + slots - 1) / slots;
+            const double fill = (double)blocks / (double)(rounds * slots);
+            if (fill > best + 1e-9) { best = fill; want = k; }
+        }
+    }
     if (want > chunks) want = chunks;
     p.chunks_per_block = (int)((chunks + want - 1) / want);
     pl->kblocks = (int)((chunks + p.chunks_per_block - 1) / p.chunks_per_block);
@@ -416,6 +500,9 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
     }
     p.dbg = getenv("CNN_AMD_RD_DBG") ? atoi(getenv("CNN_AMD_RD_DBG")) : 0;
     p.chunks_fast = getenv("CNN_AMD_RD_SLOW") ? 0 : (int)(r_unsafe / 2);  // (CNN_AMD_RD_SLOW: tests force the guarded path)
+    // padded layers: the first run of output rows 0 and 1 of image 0 reads input row 0 from column -1 (or -2): x[-1] lies in
+    // front of the allocation, so the chunks up to run `rpr` (first run of row 1) take the guarded path
+    p.chunks_head = d->pad > 0 ? p.rpr / 2 + 1 : 0;
     return true;
 }
 
@@ -437,8 +524,12 @@ int wgrad_rd_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, f
     pl.p.x = x; pl.p.dy = dy; pl.p.slabs = slabs;
     const dim3 grid(pl.kblocks, pl.ngroups, pl.mtiles);
     char name[64];
-    snprintf(name, sizeof(name), "wgrad_rd<%d,%d,%d>", d->s, pl.nt, pl.rl);
-#define RD(S_, NT_, RL_) CNN_KLAUNCH(s, name, (wgrad_rd_kernel<S_, NT_, RL_, false><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d))
+    snprintf(name, sizeof(name), d->pad ? "wgrad_rd<%d,%d,%d,p1>" : "wgrad_rd<%d,%d,%d>", d->s, pl.nt, pl.rl);
+#define RD(S_, NT_, RL_)                                                                                                   \
+    do {                                                                                                                   \
+        if (d->pad == 0) CNN_KLAUNCH(s, name, (wgrad_rd_kernel<S_, NT_, RL_, false><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d)); \
+        else CNN_KLAUNCH(s, name, (wgrad_rd_kernel_p1<S_, NT_, RL_><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d));               \
+    } while (0)
 #define RD_NT(S_, RL_)                                                     \
     switch (pl.nt) {                                                       \
         case 1: RD(S_, 1, RL_); break;                                     \

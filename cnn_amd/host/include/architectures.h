@@ -29,6 +29,11 @@ extern bool fuse_layers;
 // write their own output tensors (get_output() of those two layers is stale); everything else -- the pool's output, all
 // gradients, every later layer -- is bit-identical.
 extern bool fuse_pool_block;
+// addition: LinearLayer::forward normally copies its (tiny) output to the host right away, because the reference's callers
+// read `output[b]->data` directly (softmax, func.cpp:24-28; argmax, cnn.cpp:92) -- one blocking D2H per forward pass.  While
+// this flag is set the copy is skipped (Layer::get_output() / Tensor3D::sync_to_host() still materialise it on demand):
+// Sequential::train_step sets it around its forward pass, so a train step never waits for the device.
+extern bool lazy_host_sync;
 
 class WithoutGrad final {
 public:
@@ -188,6 +193,12 @@ private:
 
 public:
     void set_relu_below(ReLU* relu) { relu_below = relu; }  // addition (see architectures::fuse_layers)
+    // addition: forward + softmax + cross-entropy delta in ONE kernel (cnn_linear_forward_softmax_xent, out_channels <= 8):
+    // labels_dev int32 [B]; delta_dev [B][out] receives p - onehot (func.cpp:56-73), loss_terms_dev [B] log p[label]
+    bool loss_head_supported() const { return out_channels <= 8; }
+    std::vector<tensor> forward_loss_head(const std::vector<tensor>& input, const int* labels_dev, data_type* probs_dev,
+                                          data_type* delta_dev, data_type* loss_terms_dev);
+    int out_features() const { return out_channels; }
     LinearLayer(std::string _name, const int _in_channels, const int _out_channels);
     ~LinearLayer() override;
     std::vector<tensor> forward(const std::vector<tensor>& input) override;
@@ -300,6 +311,21 @@ public:
     void set_comm(void* rccl_comm, int world);
     // sums the gradient arena over the replicas now (idempotent per backward pass); update_gradients(lr) calls it
     void allreduce_gradients();
+    // One iteration of the reference's training loop (cnn.cpp:79-90: forward, softmax, cross_entroy_backward, backward,
+    // update_gradients) that never leaves the device: the loss glue of func.cpp:16-73 runs as a kernel (fused into the last
+    // LinearLayer's forward kernel when it has <= 8 outputs), nothing is copied back, the host never blocks.  labels_dev:
+    // int32 [B] on the device.  The last layer must be a LinearLayer (the logits).  last_loss() fetches the loss of the most
+    // recent step (-(1/B) * sum log p[label], func.cpp:67,71) -- the only call here that synchronises.
+    void train_step(const std::vector<tensor>& input, const int* labels_dev, const data_type learning_rate);
+    data_type last_loss();
+    const data_type* last_probs_device() const { return loss_probs.base; }
+
+private:
+    BatchBuffer loss_probs, loss_delta, logits_stage;   // [B][classes] each
+    data_type* loss_terms = nullptr;      // [B] log p[label] (fused head) ...
+    data_type* loss_sum = nullptr;        // ... or the ordered sum (unfused head); [1]
+    bool loss_in_terms = false;
+    int loss_batch = 0, loss_last_B = 0;
 };
 
 // The reference's fixed network (alexnet.cpp:10-33).  forward / backward / update_gradients / save_weights / load_weights are

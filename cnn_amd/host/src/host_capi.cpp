@@ -178,6 +178,19 @@ float cnnh_net_train_step_device(void* hv, float* x_dev, const int* labels, int 
     if (do_update) h->net->update_gradients(lr);
     return loss_delta.first;
 }
+// Sequential::train_step: the whole iteration on the device (device-side loss, no read-back, the host never blocks);
+// labels_dev int32 [B] on the device.  cnnh_net_last_loss fetches the loss of the latest step (synchronises).
+void cnnh_net_train_step_device_loss(void* hv, float* x_dev, const int* labels_dev, int B, int H, int W, float lr) {
+    Handle* h = (Handle*)hv;
+    if ((int)h->device_input.size() != B || h->device_input[0]->dev != x_dev) {
+        h->device_input.clear();
+        const size_t len = (size_t)h->in_C * H * W;
+        for (int b = 0; b < B; ++b)
+            h->device_input.emplace_back(Tensor3D::device_view(h->in_C, H, W, x_dev + len * b, "input_" + std::to_string(b)));
+    }
+    h->net->train_step(h->device_input, labels_dev, lr);
+}
+float cnnh_net_last_loss(void* hv) { return ((Handle*)hv)->net->last_loss(); }
 void cnnh_net_update(void* hv, float lr, float grad_scale) { ((Handle*)hv)->net->update_gradients(lr, grad_scale); }
 // Sequential::update_gradients(lr): with a communicator set, all-reduce + lr/world; otherwise the plain step
 void cnnh_net_update_auto(void* hv, float lr) { ((Handle*)hv)->net->update_gradients(lr); }

@@ -16,6 +16,7 @@ bool architectures::no_grad = false;           // architectures.cpp:8
 void* architectures::stream = nullptr;
 bool architectures::fuse_layers = true;
 bool architectures::fuse_pool_block = false;
+bool architectures::lazy_host_sync = false;
 
 // ---------------------------------------------------------------------------------------------------------------
 BatchBuffer::~BatchBuffer() {
@@ -592,6 +593,7 @@ std::vector<tensor> LinearLayer::forward(const std::vector<tensor>& input) {
     must(cnn_linear_forward(x, params, params + (size_t)in_channels * out_channels, out_buf.base, B, in_channels,
                             out_channels, stream),
          "cnn_linear_forward");
+    if (lazy_host_sync) return output;  // materialised on demand (Layer::get_output / Tensor3D::sync_to_host)
     // the callers read the logits on the host right away (softmax, func.cpp:24-28; argmax, cnn.cpp:92): one D2H
     std::vector<data_type> host((size_t)B * out_channels);
     must(cnn_memcpy_d2h(host.data(), out_buf.base, sizeof(data_type) * host.size(), stream), "cnn_memcpy_d2h");
@@ -600,6 +602,26 @@ std::vector<tensor> LinearLayer::forward(const std::vector<tensor>& input) {
         if (!output[b]->data) output[b]->data = new data_type[out_channels];
         std::memcpy(output[b]->data, host.data() + (size_t)b * out_channels, sizeof(data_type) * out_channels);
     }
+    return output;
+}
+
+std::vector<tensor> LinearLayer::forward_loss_head(const std::vector<tensor>& input, const int* labels_dev, data_type* probs_dev,
+                                                   data_type* delta_dev, data_type* loss_terms_dev) {
+    const int B = (int)input.size();
+    delta_shape = input[0]->get_shape();
+    assert(input[0]->get_length() == in_channels && loss_head_supported());
+    if (out_buf.empty()) {
+        out_buf.allocate(B, out_channels, 1, 1, name + "_output");
+        output = out_buf.views;
+        batch = B;
+    }
+    assert(B <= batch);
+    const data_type* x = batch_device_pointer(input, in_stage, name);
+    saved_input = x;
+    saved_input_tensors = input;
+    must(cnn_linear_forward_softmax_xent(x, params, params + (size_t)in_channels * out_channels, labels_dev, out_buf.base, probs_dev,
+                                         delta_dev, loss_terms_dev, B, in_channels, out_channels, stream),
+         "cnn_linear_forward_softmax_xent");
     return output;
 }
 

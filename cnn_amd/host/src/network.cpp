@@ -97,6 +97,8 @@ Sequential::~Sequential() {
         cnn_device_free(param_arena);
         cnn_device_free(grad_arena);
     }
+    if (loss_terms) cnn_device_free(loss_terms);
+    if (loss_sum) cnn_device_free(loss_sum);
     if (comm_stream) cnn_stream_destroy(comm_stream);
     if (ev_grads) cnn_event_destroy(ev_grads);
     if (ev_comm) cnn_event_destroy(ev_comm);
@@ -201,6 +203,58 @@ void Sequential::update_gradients(const data_type learning_rate, const data_type
     assert(finalized && "the grad_scale form works on the flat arena: call finalize()");
     must(cnn_sgd_update(param_arena, grad_arena, n_params, learning_rate, grad_scale, stream), "cnn_sgd_update");
     parameters_changed();
+}
+
+// cnn.cpp:79-90 without leaving the device
+void Sequential::train_step(const std::vector<tensor>& input, const int* labels_dev, const data_type learning_rate) {
+    assert(!input.empty() && labels_dev != nullptr && !layers_sequence.empty());
+    auto* head = dynamic_cast<LinearLayer*>(layers_sequence.back().get());
+    assert(head != nullptr && "train_step: the last layer must be a LinearLayer (the logits)");
+    const int B = (int)input.size();
+    const int classes = head->out_features();
+    if (loss_delta.empty() || loss_batch < B) {
+        assert(loss_delta.empty() && "train_step: batch larger than the first call's");
+        loss_probs.allocate(B, classes, 1, 1, "probs");
+        loss_delta.allocate(B, classes, 1, 1, "loss_delta");
+        loss_terms = (data_type*)dev_alloc(sizeof(data_type) * B);
+        loss_sum = (data_type*)dev_alloc(sizeof(data_type));
+        loss_batch = B;
+    }
+    if (print_info) input[0]->print_shape();
+    if (finalized && fuse_layers && !filters_prepared) prepare_filters();
+    const bool was_lazy = lazy_host_sync;
+    lazy_host_sync = true;
+    std::vector<tensor> output(input);
+    const bool fused_head = fuse_layers && head->loss_head_supported();
+    for (const auto& layer : layers_sequence) {
+        if (layer.get() == head && fused_head)
+            output = head->forward_loss_head(output, labels_dev, loss_probs.base, loss_delta.base, loss_terms);
+        else
+            output = layer->forward(output);
+        if (print_info) output[0]->print_shape();
+    }
+    lazy_host_sync = was_lazy;
+    if (!fused_head) {
+        const data_type* logits = batch_device_pointer(output, logits_stage, "logits");
+        must(cnn_softmax_xent(logits, labels_dev, loss_probs.base, loss_delta.base, loss_sum, B, classes, stream), "cnn_softmax_xent");
+    }
+    loss_in_terms = fused_head;
+    loss_last_B = B;
+    std::vector<tensor> delta(loss_delta.views.begin(), loss_delta.views.begin() + B);
+    backward(delta);
+    update_gradients(learning_rate);
+}
+
+data_type Sequential::last_loss() {
+    assert(loss_batch > 0 && "last_loss before the first train_step");
+    if (loss_in_terms) {  // ordered sum over the per-sample terms (the reference's order, func.cpp:60-71)
+        must(cnn_loss_from_terms(loss_terms, loss_sum, loss_last_B, stream), "cnn_loss_from_terms");
+        loss_in_terms = false;
+    }
+    data_type host = 0;
+    must(cnn_memcpy_d2h(&host, loss_sum, sizeof(data_type), stream), "cnn_memcpy_d2h");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+    return host / (data_type)loss_last_B;
 }
 
 void Sequential::save_weights(const std::filesystem::path& save_path) const {

@@ -45,6 +45,8 @@ SIGNATURES = {
     "cnnh_net_train_step_host": (C.c_float, [C.c_void_p, _F, _I, C.c_int, C.c_int, C.c_int, C.c_float, _F]),
     "cnnh_net_train_step_device": (C.c_float, [C.c_void_p, C.c_void_p, _I, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]),
     "cnnh_net_update": (None, [C.c_void_p, C.c_float, C.c_float]),
+    "cnnh_net_train_step_device_loss": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]),
+    "cnnh_net_last_loss": (C.c_float, [C.c_void_p]),
     "cnnh_net_layer_output": (C.c_int, [C.c_void_p, C.c_char_p, _F, C.c_size_t]),
 }
 
@@ -153,6 +155,16 @@ class HostNet:
 
     def update(self, lr, grad_scale=1.0):
         self.lib.cnnh_net_update(self.h, float(lr), float(grad_scale))
+
+    def train_step(self, x_dev, labels_dev, lr):
+        """Sequential::train_step: forward, device-side softmax / cross-entropy, backward, [all-reduce], SGD -- nothing is read
+        back and the host never blocks.  x_dev float32 [B][C][H][W], labels_dev int32 [B], both device tensors."""
+        B, _, H, W = x_dev.shape
+        self.lib.cnnh_net_train_step_device_loss(self.h, C.c_void_p(x_dev.data_ptr()), C.c_void_p(labels_dev.data_ptr()), B, H, W,
+                                                 float(lr))
+
+    def last_loss(self):
+        return float(self.lib.cnnh_net_last_loss(self.h))
 
     def layer_output(self, name, shape):
         out = np.empty(shape, np.float32)

@@ -121,6 +121,14 @@ RD_CASES = [
     (2, 40, 9, 9, 70, 3, 1, 0),      # runs of 8 pixels, 361 columns -> 4-tile groups
     (4, 12, 19, 19, 8, 3, 2, 0),     # Wo = 9: a full run and a 1-pixel tail per row, 109 columns -> 4 tiles
     (1, 2, 40, 70, 5, 3, 2, 0),      # one image: the last rows take the guarded path
+    # padding 1 (VGG / ResNet-shaped stacks): border rows fetched from the centre row and masked, per-window live ranges
+    (1, 1, 3, 3, 1, 3, 1, 1),        # 3x3 image: every tap row / column leaves the image somewhere
+    (2, 7, 20, 37, 33, 3, 1, 1),     # stride 1: rows of 16 + 16 + 5 pixels, two row tiles
+    (3, 18, 21, 35, 16, 3, 2, 1),    # stride 2, odd sizes: window starts at column -2, last pixel inside
+    (2, 5, 8, 8, 40, 3, 2, 1),       # stride 2, even sizes (column 8 = first one outside), runs of 8
+    (2, 40, 9, 9, 70, 3, 1, 1),      # runs of 8 pixels (Wo = 9 -> a 1-pixel tail run whose window starts inside)
+    (2, 3, 30, 34, 64, 3, 1, 1),     # first VGG layer shape class: 27 columns, one tile
+    (3, 130, 7, 7, 96, 3, 1, 1),     # 1170 columns: 37 tiles -> groups of 5 with dead tiles, three row tiles
 ]
 
 

@@ -57,21 +57,7 @@ def assert_close_arbitrated(a, ref32, ref64, tol=REL_TOL, k=2.0, what=""):
 
 
 def he_init(layout, seed):
-    """seeded parameters for a cnn_amd.stacks / oracle.SeqNet layout, flat in checkpoint order: N(0, 2/fan_in) filters and
-    matrices (keeps activations O(1) through 8-17 layers; the reference's N(0,1)/10 would overflow the deep stacks), small
-    biases, BatchNorm2D gamma ~ 1, beta ~ 0, moving statistics 0 (batchnorm2d.cpp:18-20)."""
-    rs = np.random.RandomState(seed)
-    parts = []
-    for e in layout:
-        kind = e["kind"]
-        if kind == "conv":
-            ci, co, k = e["in"][0], e["Co"], e["k"]
-            parts.append(rs.standard_normal(co * ci * k * k) * np.sqrt(2.0 / (ci * k * k)))
-            parts.append(rs.standard_normal(co) * 0.05)
-        elif kind == "bn":
-            c = e["in"][0]
-            parts += [1.0 + 0.1 * rs.standard_normal(c), 0.1 * rs.standard_normal(c), np.zeros(c), np.zeros(c)]
-        elif kind == "linear":
-            parts.append(rs.standard_normal(e["n_in"] * e["n_out"]) * np.sqrt(1.0 / e["n_in"]))
-            parts.append(rs.standard_normal(e["n_out"]) * 0.05)
-    return np.concatenate(parts).astype(np.float32) if parts else np.zeros(0, np.float32)
+    """seeded parameters for a cnn_amd.stacks / oracle.SeqNet layout (see cnn_amd.stacks.he_init)"""
+    from cnn_amd.stacks import he_init as impl
+
+    return impl(layout, seed)
