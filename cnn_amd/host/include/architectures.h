@@ -88,6 +88,8 @@ private:
     ReLU* fused_relu = nullptr;  // the ReLU layer right behind this convolution (set by the container), or null
     MaxPool2D* fused_pool = nullptr;  // ... and the MaxPool2D(2,2) behind that ReLU: Conv -> ReLU -> MaxPool in one kernel
     ReLU* relu_below = nullptr;       // the ReLU layer whose output is this layer's input: its backward pass is fused in
+    MaxPool2D* pool_below = nullptr;  // the MaxPool2D whose output is this layer's input, when that pool closes a fusable
+                                      // Conv2D -> ReLU -> MaxPool2D(2,2) block (fuse_pool_block): see backward()
     bool pool_fused_pass = false;     // this pass' forward went through the pooled kernel: backward receives d(pool output)
     void* prep_fwd = nullptr;    // prepared filters (forward / data gradient layouts)
     void* prep_dgrad = nullptr;
@@ -125,6 +127,7 @@ public:
     void set_fused_relu(ReLU* relu) { fused_relu = relu; }  // addition (see architectures::fuse_layers)
     void set_fused_pool(MaxPool2D* pool) { fused_pool = pool; }
     void set_relu_below(ReLU* relu) { relu_below = relu; }
+    void set_pool_below(MaxPool2D* pool) { pool_below = pool; }
     // additions: filter re-layout hoisted out of forward / backward (cnn_conv2d_prepare_filters); the container prepares
     // all layers with one call after every parameter change and switches the layers to the *_prepared entry points
     bool shape_known() const { return batch > 0; }
@@ -146,6 +149,7 @@ private:
     ReLU* fused_relu_below = nullptr;  // the ReLU layer whose output is this pool's input (set by the container), or null
     bool forward_done = false;       // this pass' output + mask were written by the producing Conv2D kernel
     bool backward_passthrough = false;  // ... and the delta stays in the pooled domain for that Conv2D's backward
+    bool delta_premasked = false;    // ... and the layer behind already applied the block's ReLU::backward to that delta
 
 public:
     MaxPool2D(std::string _name, const int _kernel_size = 2, const int _step = 2)
@@ -157,6 +161,14 @@ public:
     void fused_forward_target(int B, int C, int H, int W, bool record, data_type** pooled, int** mask_out);  // arms forward_done
     const data_type* pooled_dev() const { return out_buf.base; }
     const int* mask_dev() const { return mask; }
+    // pool-fused pass: the delta of this pool's output passes through untouched (the block's Conv2D consumes it).  The layer
+    // BEHIND the pool can then fold the block's ReLU::backward into its own data-gradient epilogue -- in the pooled domain
+    // d(pool_out) masked by (pool_out <= 0) IS that ReLU's backward pass (at an argmax position the ReLU output equals the
+    // pooled value, everywhere else the delta is 0 either way) -- and says so here; the block's Conv2D then skips the
+    // `pooled` tensor in its two gradient kernels.
+    bool passthrough_armed() const { return backward_passthrough; }
+    void set_delta_premasked() { delta_premasked = true; }
+    bool take_delta_premasked() { const bool v = delta_premasked; delta_premasked = false; return v; }
     std::vector<tensor> forward(const std::vector<tensor>& input) override;
     std::vector<tensor> backward(std::vector<tensor>& delta) override;
 };

@@ -192,8 +192,12 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
     }
     if (fused_relu != nullptr && fuse_layers) {  // the ReLU behind this layer gets its output from the same kernel
         data_type* y_relu = fused_relu->fused_forward_target(B, out_channels, out_H, out_W);
+        // fuse_pool_block (opt-in, "train steps only"): the pre-activation tensor is not written either where the kernel
+        // supports it -- ReLU::backward masks by the ReLU's own output (relu.cpp:35-40), nothing in a train step reads it
+        const bool relu_only = prepared && fuse_pool_block && !no_grad && cnn_conv2d_relu_only_supported(&d) != 0;
         if (prepared)
-            must(cnn_conv2d_forward_prepared(&d, x, prep_fwd, b_dev(), out_buf.base, y_relu, stream), "cnn_conv2d_forward_prepared");
+            must(cnn_conv2d_forward_prepared(&d, x, prep_fwd, b_dev(), relu_only ? nullptr : out_buf.base, y_relu, stream),
+                 "cnn_conv2d_forward_prepared");
         else
             must(cnn_conv2d_forward_relu(&d, x, w_dev(), b_dev(), out_buf.base, y_relu, workspace, workspace_bytes, stream),
                  "cnn_conv2d_forward_relu");
@@ -222,19 +226,25 @@ std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
     if (pool_fused_pass) {
         // dy is the delta of the POOL output (the pool and the ReLU passed it through untouched)
         assert(prepared_active && fused_pool != nullptr && B == batch);
-        must(cnn_conv2d_backward_pooled2_prepared(&d, saved_input, dy, fused_pool->mask_dev(), fused_pool->pooled_dev(), prep_dgrad, grads,
+        // (pooled = NULL: the layer behind the pool already applied this block's ReLU::backward to dy, see below)
+        const data_type* pooled = fused_pool->take_delta_premasked() ? nullptr : fused_pool->pooled_dev();
+        must(cnn_conv2d_backward_pooled2_prepared(&d, saved_input, dy, fused_pool->mask_dev(), pooled, prep_dgrad, grads,
                                                   grads + (size_t)out_channels * params_for_one_kernel, delta_buf.base, (float)B,
                                                   workspace, workspace_bytes, stream, /*defer_join=*/1),
              "cnn_conv2d_backward_pooled2_prepared");
         pool_fused_pass = false;
     } else if (prepared_active && fuse_layers && B == batch) {
-        // relu_below: this layer's input IS that ReLU's output, so its backward mask is applied in the data-gradient epilogue
-        const data_type* rb = relu_below != nullptr ? saved_input : nullptr;
+        // relu_below: this layer's input IS that ReLU's output, so its backward mask is applied in the data-gradient epilogue.
+        // pool_below in a pool-fused pass: this layer's input is the POOL output and its delta stays in the pooled domain;
+        // masking it by (pool_out <= 0) is the block's ReLU::backward (MaxPool2D::passthrough_armed)
+        const bool pooled_mask = relu_below == nullptr && pool_below != nullptr && pool_below->passthrough_armed();
+        const data_type* rb = (relu_below != nullptr || pooled_mask) ? saved_input : nullptr;
+        if (pooled_mask) pool_below->set_delta_premasked();
         must(cnn_conv2d_backward_prepared_relu(&d, saved_input, dy, prep_dgrad, rb, grads,
                                                grads + (size_t)out_channels * params_for_one_kernel, delta_buf.base, (float)B,
                                                workspace, workspace_bytes, stream, /*defer_join=*/1),
              "cnn_conv2d_backward_prepared_relu");
-        if (rb) relu_below->fused_backward_done();
+        if (rb && relu_below) relu_below->fused_backward_done();
     } else
         must(cnn_conv2d_backward(&d, saved_input, dy, w_dev(), grads, grads + (size_t)out_channels * params_for_one_kernel,
                                  delta_buf.base, (float)B, workspace, workspace_bytes, stream, /*defer_join=*/1),

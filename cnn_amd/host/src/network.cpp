@@ -52,7 +52,13 @@ void Sequential::wire() {
             auto* conv = dynamic_cast<Conv2D*>(it->get());
             auto* relu = dynamic_cast<ReLU*>(next->get());
             auto* pool = dynamic_cast<MaxPool2D*>(next2->get());
-            if (conv && relu && pool) conv->set_fused_pool(pool);
+            if (conv && relu && pool) {
+                conv->set_fused_pool(pool);
+                // ... and the convolution BEHIND such a block may fold the block's ReLU::backward into its data gradient
+                auto next3 = std::next(next2);
+                if (next3 != layers_sequence.end())
+                    if (auto* behind = dynamic_cast<Conv2D*>(next3->get())) behind->set_pool_below(pool);
+            }
         }
     }
 }

@@ -234,3 +234,42 @@ def test_host_net_pool_block_fusion_is_bit_identical():
     for a, b in zip(res[0][1:], res[1][1:]):
         assert np.array_equal(a, b)
     assert res[0][0] == res[1][0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pool_block", [0, 1], ids=["all_outputs_valid", "fuse_pool_block"])
+def test_host_train_step_on_device_matches_the_reference_loop(pool_block):
+    """Sequential::train_step (cnn.cpp:79-90 with the loss glue of func.cpp:16-73 as a kernel, nothing read back) against the
+    reference's own loop through the same classes (forward -> host softmax / cross_entroy_backward -> backward -> update) and
+    against the oracle, three steps; also with the opt-in pool-block fusion bench.py's layer_api leg runs"""
+    import torch
+
+    from cnn_amd import hostapi
+    from oracle import pyoracle as O
+
+    B = 4
+    x = uniform01(60, (B, 3, 224, 224))
+    labels = (np.arange(B) % 3).astype(np.int32)
+    p0 = normal_scaled(61, (111267,))
+    onet = O.Net(B, 3)
+    onet.params[:] = p0
+    xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    hostapi.load().cnnh_set_fuse_pool_block(pool_block)
+    try:
+        dev_net, ref_net = hostapi.HostAlexNet(3), hostapi.HostAlexNet(3)
+        dev_net.set_params(p0)
+        ref_net.set_params(p0)
+        for step in range(3):
+            dev_net.train_step(xd, ld, 1e-3)
+            loss = dev_net.last_loss()
+            ref_loss = ref_net.train_step_device(xd, labels, 1e-3)
+            oloss, _ = onet.train_step(x, labels, 1e-3)
+            assert abs(loss - ref_loss) <= 2e-6 * max(1.0, abs(ref_loss)), (step, loss, ref_loss)
+            assert abs(loss - oloss) <= 1e-4 * max(1.0, abs(oloss)), (step, loss, oloss)
+            # (host expf vs device expf may differ in the last bit of the probabilities: everything else is the same kernels)
+            assert_close(dev_net.get_params(), ref_net.get_params(), 1e-6, f"step {step}: device-loss step vs host-loss loop")
+            assert_close(dev_net.get_params(), onet.params, REL_TOL, f"step {step}: params vs oracle")
+        dev_net.close()
+        ref_net.close()
+    finally:
+        hostapi.load().cnnh_set_fuse_pool_block(0)
