@@ -954,6 +954,10 @@ inline unsigned wave_grid(long long rows) {
 
 namespace cnn_amd {
 bool dgrad_rd_supported(const cnn_conv2d_desc* d);  // conv_dgrad_rd.hip (takes precedence over the packed stride-2 kernel)
+// conv_wgrad_win.hip: the window-major MFMA weight gradient of this layer (default; CNN_AMD_WG_WIN=0: the packed VALU kernel below)
+int win_wgrad_slots(const cnn_conv2d_desc* d);
+int win_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, const int32_t* mask, const float* pooled, float* slabs,
+                     hipStream_t s);
 
 #define CONV_TAG(d) "B%d Ci%d %dx%d Co%d k%d s%d p%d", (d)->B, (d)->Ci, (d)->H, (d)->W, (d)->Co, (d)->k, (d)->s, (d)->pad
 
@@ -1166,6 +1170,7 @@ bool direct_prepared_dgrad_ok(const cnn_conv2d_desc* d) {
 // number of slabs (workgroups) the packed weight-gradient kernel writes; 0 when the geometry / sizes rule it out
 int direct_wgrad_slots(const cnn_conv2d_desc* d) {
     if (!direct_conv_supported(d) || getenv("CNN_AMD_WG_NOPK")) return 0;
+    if (const int ws = win_wgrad_slots(d)) return ws;
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
     if ((long long)d->B * 16 * Ho * Wo * 4 >= (1ll << 31) - 16 || (long long)d->B * 3 * d->H * d->W * 4 >= (1ll << 31) - 16) return 0;
     const long long items = (long long)d->B * ((Ho * Wo + 63) / 64);
@@ -1175,6 +1180,7 @@ int direct_wgrad_slots(const cnn_conv2d_desc* d) {
 
 // writes direct_wgrad_slots(d) slabs of 16 x 28 floats ([27 weight sums | 1 bias sum] per output channel)
 int direct_conv_wgrad(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s) {
+    if (win_wgrad_slots(d) > 0) return win_wgrad_launch(d, x, dy, nullptr, nullptr, slabs, s);
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
     const int ipi = (Ho * Wo + 63) / 64;
     // three items of loads in flight per workgroup (2: 117 us, 3: 115 us, 4+: the extra registers cost more than they hide)
@@ -1188,6 +1194,7 @@ int direct_conv_wgrad(const cnn_conv2d_desc* d, const float* x, const float* dy,
 // the same slabs from the pooled domain (dpool, mask, pooled of the 2x2 / stride-2 pool behind this layer's ReLU)
 int direct_conv_wgrad_pooled(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask, const float* pooled,
                              float* slabs, hipStream_t s) {
+    if (win_wgrad_slots(d) > 0) return win_wgrad_launch(d, x, dpool, mask, pooled, slabs, s);
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
     const int ipi = (Ho * Wo + 63) / 64;
     if (pooled)

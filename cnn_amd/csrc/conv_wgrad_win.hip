@@ -1,0 +1,404 @@
+// conv_wgrad_win.hip -- weight / bias gradient (cpu/src/conv2d.cpp:117-159) of the thin first layer
+// Conv2D(3 -> 16, 3x3, stride 2, pad 0) (alexnet.cpp:12), from the delta of its output (POOLED = 0) or straight from the pooled
+// domain of the Conv2D -> ReLU -> MaxPool2D(2,2) block (POOLED = 1 / 2: dy = ReLU'(MaxPool'(dpool)) rebuilt on the fly, see
+// cnn_conv2d_backward_weight_pooled2 in include/cnn_amd.h).  HBM-bound: x (B*3*H*W) + dy (or dpool + mask [+ pooled]) are read
+// once, 16 x 28 sums come out.  It replaces conv_direct.hip's packed VALU kernel, which was bound by LOAD INSTRUCTIONS (27
+// row segments of 256 B per 64 pixels) at 2.0 - 2.3 TB/s.
+//
+//   gw[co][(ci,kx,ky)] = sum_{b,p,q} dy[b][co][p][q] * x[b][ci][2p+kx][2q+ky]         gb[co] = sum dy[b][co][p][q]
+//
+// as a GEMM on v_mfma_f32_16x16x4_f32: M = 16 = Co exactly, N = the 27 (ci,kx,ky) columns in two 16-wide tiles, K = pixels.
+// The unit of work is a STRIP: one row of 2x2 pixel windows (= pooling windows) of one image, up to 32 windows wide: conv
+// rows 2wr, 2wr+1 <- input rows 4wr .. 4wr+4.  A wave owns a contiguous range of strips (vertically neighbouring strips
+// share an input row: L2) and, per strip,
+//   * moves the 3 x 5 input row segments (<= 132 floats each) and the strip's delta operands HBM -> LDS with
+//     global_load_lds (16-byte DMA for x: 8 instructions per strip instead of 90+ load instructions), into the second of two
+//     private buffers while it computes on the first -- no VGPR round trip, no barrier, no other wave involved;
+//   * runs groups of 4 windows: k-slot k of an MFMA step is window 4g+k, the four steps of a group are the window's pixels
+//     (pr,pc).  A operand (lane = co, k): the pixel's delta; pooled domain: (mask == flat index of the pixel) ? dpool : 0 from
+//     ONE dpool / mask value per window, staged window-major ([window][co]: conflict-free).  B operand (lane = column, k):
+//     x[ci][4wr + 2pr + kx][4(4g+k) + 2pc + ky], read as ds_read2_b32 (pc = 0 | 1) at a per-lane base + an immediate.
+// Four accumulators (tile x pr) keep dependent MFMAs two issues apart.  The waves of a workgroup are summed in a fixed order
+// through LDS into one 16 x 28 slab per workgroup ([27 weight sums | bias sum]); reduce_slabs() (conv_wgrad.hip) adds the slabs
+// and divides.  Plain and pooled variants visit the same strips in the same order with the same operand values, so the fused
+// and unfused paths stay bit-identical (tests/test_gpu_parity.py).
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+using namespace cnn_amd;
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CI = 3, CO = 16, XR = 5;  // input rows per window row: 4wr .. 4wr+4
+constexpr int kSW = 16;                 // windows per strip (at most): four groups of four
+constexpr int kGroups = kSW / 4;
+constexpr int XP = 4 * kSW + 4;         // floats per staged input row segment: columns 4*wc_lo .. 4*wc_lo + 4*SW (+ pad to 16 B)
+constexpr int XROWS = CI * XR;          // 15 staged rows ...
+constexpr int XBUF = (XROWS + 1) * XP;  // ... + one row of 1.0f: the "column" whose sums are the bias gradient (never overwritten)
+constexpr int kWaves = 8;               // two waves per SIMD: one wave's LDS / VALU latency hides behind the other's MFMAs
+// delta operands of a strip: plain 2 rows x 2*SW columns x 16 channels; pooled domain 2 (dpool, mask) or 3 (+ pooled) tensors
+// x SW windows x 16 channels
+__host__ __device__ constexpr int abuf_floats(int pooled) { return pooled == 0 ? 2 * 2 * kSW * CO : (pooled == 1 ? 3 : 2) * kSW * CO; }
+__host__ __device__ constexpr int buf_floats(int pooled) { return XBUF + abuf_floats(pooled); }
+// strips in flight per wave: the train step's variant (POOLED = 2, 6.4 KB per strip) affords three buffers in 160 KB of LDS
+// (two strips on their way while one is consumed), the others two
+__host__ __device__ constexpr int num_bufs(int pooled) { return pooled == 2 ? 3 : 2; }
+
+struct WinParams {
+    const float* x;
+    const float* dy;       // POOLED: dpool
+    const int* pmask;
+    const float* pooled;
+    float* slabs;          // [gridDim.x][16][28]
+    int B, H, W, Ho, Wo;
+    int PHo, PWo;          // pooled-domain size (Ho/2, Wo/2)
+    int WR, WC;            // window grid: ceil(Ho/2) x ceil(Wo/2)
+    int nseg, SW;          // column segments per window row, windows per segment (multiple of 4, <= kSW)
+    int strips_total, strips_per_wave;
+    int dbg;  // CNN_AMD_WIN_DBG (tuning): 1 = no MFMA groups, 2 = no staging
+};
+
+// POOLED: 0 dy | 1 pooled domain (dpool, mask, pooled) | 2 pooled domain with dpool already ReLU-masked (pooled not read)
+// DMA16: x rows are 16-byte aligned (W % 4 == 0, base aligned): 16-byte DMA; otherwise 4 bytes per lane
+template <int POOLED, bool DMA16>
+__global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinParams p) {
+    constexpr int BUF = buf_floats(POOLED), NBUF = num_bufs(POOLED);
+    constexpr int NT = POOLED == 1 ? 3 : 2;  // pooled-domain tensors
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = lane & 15, k = lane >> 4;  // MFMA lane coordinates: (row / column index, k-slot)
+    float* const wbuf = lds + wave * NBUF * BUF;
+#pragma unroll
+    for (int nb = 0; nb < NBUF; ++nb)
+        for (int i = lane; i < XP; i += 64) wbuf[nb * BUF + XROWS * XP + i] = 1.f;  // the ones row of every buffer
+
+    // ---- per-lane constants of the B operand: column (ci,kx,ky) of tile t.  Column 27 reads the ones row (its sums are the
+    // bias gradient: D[co][27] = sum of the deltas); columns 28..31 repeat it (discarded).
+    int bbase[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int col = n0 + 16 * t;
+        const int cc = col < 27 ? col : 26;
+        const int ci = cc / 9, kx = (cc - ci * 9) / 3, ky = cc - ci * 9 - kx * 3;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) bbase[t][pr] = col < 27 ? (ci * XR + 2 * pr + kx) * XP + 4 * k + ky : XROWS * XP + 4 * k;
+    }
+    const int co = n0;  // A operand: this lane's output channel
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) acc[t][pr] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int gw = blockIdx.x * kWaves + wave;
+    const int s_lo = gw * p.strips_per_wave;
+    const int s_hi = s_lo + p.strips_per_wave < p.strips_total ? s_lo + p.strips_per_wave : p.strips_total;
+
+    // strip s -> (image b, column segment, window row wr): consecutive strips walk DOWN one column segment of one image
+    auto strip_of = [&](int s, int& b, int& wr, int& wc_lo, int& sw) {
+        b = s / (p.nseg * p.WR);
+        const int r = s - b * (p.nseg * p.WR);
+        const int seg = r / p.WR;
+        wr = r - seg * p.WR;
+        wc_lo = seg * p.SW;
+        sw = p.WC - wc_lo < p.SW ? p.WC - wc_lo : p.SW;
+    };
+
+    // ---- HBM -> LDS for one strip (asynchronous: completion = vmcnt).  Every instruction is issued by every strip (the wait
+    // below counts instructions): a lane whose element lies outside the image / the row re-reads a valid element of the same
+    // row instead, and the compute path ignores that slot (EDGE).  Returns true for the ONE strip kind that stages its delta
+    // operands with 4-byte instead of 16-byte DMA (see below).
+    auto stage = [&](int s, float* buf) -> bool {
+        int b, wr, wc_lo, sw;
+        strip_of(s, b, wr, wc_lo, sw);
+        // x: rows 4wr .. 4wr+4 of the three channels, columns 4*wc_lo .. 4*wc_lo + 4*sw (inclusive), clipped to the image
+        {
+            const int ncols = (p.W - 4 * wc_lo) < (4 * sw + 4) ? (p.W - 4 * wc_lo) : (4 * sw + 4);
+            const int nrows = (p.H - 4 * wr) < XR ? (p.H - 4 * wr) : XR;
+            const float* src = p.x + ((size_t)b * CI * p.H + 4 * wr) * p.W + 4 * wc_lo;
+            constexpr int CH = DMA16 ? 4 : 1;               // floats per lane and instruction
+            constexpr int PER_ROW = XP / CH;                 // 17 chunks (or 68 floats) per staged row
+            constexpr int TOTAL = XROWS * PER_ROW;
+#pragma unroll
+            for (int i = 0; i < (TOTAL + 63) / 64; ++i) {
+                const int f = 64 * i + lane;
+                const int row = f / PER_ROW, c = (f - row * PER_ROW) * CH;  // staged row (ci*5 + r5), first column of the chunk
+                const int ci = row / XR, r5 = row - ci * XR;
+                const int rr = r5 < nrows ? r5 : 0, cq = c < ncols ? c : 0;  // (outside the image: a valid element instead)
+                if (f < TOTAL) {  // (lanes behind the last row would overwrite the ones row)
+                    if constexpr (DMA16)
+                        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + ((size_t)ci * p.H + rr) * p.W + cq), (lds_void_ptr)(buf + 64 * i * CH), 16, 0, 0);
+                    else
+                        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + ((size_t)ci * p.H + rr) * p.W + cq), (lds_void_ptr)(buf + 64 * i * CH), 4, 0, 0);
+                }
+            }
+        }
+        float* const abuf = buf + XBUF;
+        if constexpr (POOLED) {
+            // one dpool / mask (/ pooled) value per window and channel; per tensor: float index (group*16 + co)*4 + window % 4.
+            // Fast path: lane (co = lane & 15, g = lane >> 4) moves the 4 windows of its group with ONE 16-byte DMA per tensor
+            // (rows of the pooled domain follow each other in memory, so a chunk that runs over its row end reads the next row's
+            // first elements: valid memory, ignored slots) -- except in the very last row of the tensors, where it would leave the
+            // allocation: that strip moves single windows (lane = 4*co + window % 4, one instruction per group).
+            const bool rowok = wr < p.PHo;
+            const int nv = rowok ? (p.PWo - wc_lo < sw ? p.PWo - wc_lo : sw) : 0;
+            const bool last_row = b == p.B - 1 && wr >= p.PHo - 1 && wc_lo + kSW > p.PWo;
+            if (!last_row) {
+                const int g = lane >> 4;
+                const size_t off = (((size_t)b * CO + co) * p.PHo + (rowok ? wr : 0)) * p.PWo + wc_lo + (4 * g < nv ? 4 * g : 0);
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.dy + off), (lds_void_ptr)(abuf), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)((const float*)p.pmask + off), (lds_void_ptr)(abuf + kSW * CO), 16, 0, 0);
+                if constexpr (POOLED == 1) __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.pooled + off), (lds_void_ptr)(abuf + 2 * kSW * CO), 16, 0, 0);
+                return false;
+            }
+            const int c4 = lane >> 2, e = lane & 3;
+            const size_t rowbase = (((size_t)b * CO + c4) * p.PHo + (rowok ? wr : 0)) * p.PWo + wc_lo;
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) {
+                const size_t off = rowbase + (4 * g + e < nv ? 4 * g + e : 0);
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.dy + off), (lds_void_ptr)(abuf + 64 * g), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)((const float*)p.pmask + off), (lds_void_ptr)(abuf + kSW * CO + 64 * g), 4, 0, 0);
+                if constexpr (POOLED == 1) __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.pooled + off), (lds_void_ptr)(abuf + 2 * kSW * CO + 64 * g), 4, 0, 0);
+            }
+            return true;
+        } else {
+            // dy rows 2wr, 2wr+1, columns 2*wc_lo .. 2*wc_lo + 2*sw - 1, column-major per row: float index (pr*2*SW + column) * 16 + co
+            const int j = lane >> 4;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int prow = 2 * wr + pr;
+                const bool rowok = prow < p.Ho;
+                const size_t rowbase = (((size_t)b * CO + co) * p.Ho + (rowok ? prow : 0)) * p.Wo + 2 * wc_lo;
+                const int nv = rowok ? (p.Wo - 2 * wc_lo < 2 * sw ? p.Wo - 2 * wc_lo : 2 * sw) : 0;
+#pragma unroll
+                for (int i = 0; i < 2 * kSW / 4; ++i) {
+                    const int c = 4 * i + j;
+                    __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.dy + rowbase + (c < nv ? c : 0)), (lds_void_ptr)(abuf + (pr * 2 * kSW + 4 * i) * CO), 4, 0, 0);
+                }
+            }
+            return false;
+        }
+    };
+    // DMA instructions per strip: what `s_waitcnt vmcnt(N)` has to leave in flight when the NEXT strip is already on its way
+    constexpr int NX = (XROWS * (XP / (DMA16 ? 4 : 1)) + 63) / 64;
+    constexpr int N_FAST = NX + (POOLED ? NT : 2 * (2 * kSW / 4)), N_SLOW = NX + NT * kGroups;
+
+    // ---- the strip's MFMA groups.  EDGE: the strip touches the last window row / column of the layer, where a window's pixels
+    // may lie outside the output (delta 0, and their x values are not the reference's to read: both operands are forced to 0);
+    // everywhere else every pixel of every window is live and the selects are compiled out.
+    struct Ops {
+        float a0, a1, a2;   // POOLED: dpool, mask bits, pooled | plain: unused
+        float av[2][2];     // plain: the four deltas of the window
+        float bv[2][2][2];  // [tile][pr][pc]
+    };
+    auto compute = [&](auto EDGE_C, int wr, int wc_lo, int sw, const float* buf) {
+        constexpr bool EDGE = decltype(EDGE_C)::value;
+        const float* const xb = buf;
+        const float* const ab = buf + XBUF;
+        const int groups = (sw + 3) >> 2;
+        const bool rowv0 = 2 * wr < p.Ho, rowv1 = 2 * wr + 1 < p.Ho;
+        int nv;  // windows of this strip that carry a delta at all (pooled: inside the pooled domain)
+        if constexpr (POOLED) nv = wr < p.PHo ? (p.PWo - wc_lo < sw ? p.PWo - wc_lo : sw) : 0;
+        else nv = sw;
+        const int e_lane = co * p.Ho * p.Wo + 2 * wr * p.Wo + 2 * (wc_lo + k);  // flat index of pixel (0,0) of window 4*0 + k
+        auto load_ops = [&](int g, Ops& o) {
+            const int w = 4 * g + k;
+            if constexpr (POOLED) {
+                o.a0 = ab[64 * g + 4 * co + k];
+                o.a1 = ab[kSW * CO + 64 * g + 4 * co + k];
+                if constexpr (POOLED == 1) o.a2 = ab[2 * kSW * CO + 64 * g + 4 * co + k];
+                (void)w;
+            } else {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) o.av[pr][pc] = ab[(pr * 2 * kSW + 2 * w + pc) * CO + co];
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const float* src = xb + bbase[t][pr] + 16 * g;
+                    o.bv[t][pr][0] = src[0];
+                    o.bv[t][pr][1] = src[2];
+                }
+        };
+        auto run_group = [&](int g, const Ops& o) {
+            const int w = 4 * g + k;  // this lane's window inside the strip
+            const bool winv = w < nv;
+            const int q0 = 2 * (wc_lo + w);  // conv column of the window's pc = 0 pixel
+            float av[2][2];
+            if constexpr (POOLED) {
+                float dp = o.a0;
+                if constexpr (POOLED == 1) dp = (o.a2 <= 0.f) ? 0.f : dp;  // ReLU::backward in the pooled domain (relu.cpp:37)
+                if (EDGE) dp = winv ? dp : 0.f;                             // (a window outside the pooled domain: stale LDS)
+                const int d = __builtin_bit_cast(int, o.a1) - (e_lane + 8 * g);  // mask - flat index of pixel (0,0)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) av[pr][pc] = (d == pr * p.Wo + pc) ? dp : 0.f;  // MaxPool2D::backward (pool2d.cpp:105)
+            } else {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        const bool ok = !EDGE || (winv && (pr ? rowv1 : rowv0) && q0 + pc < p.Wo);
+                        av[pr][pc] = ok ? o.av[pr][pc] : 0.f;
+                    }
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) {
+                    const bool ok = !EDGE || (winv && (pr ? rowv1 : rowv0) && q0 + pc < p.Wo);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        acc[t][pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pr][pc], ok ? o.bv[t][pr][pc] : 0.f, acc[t][pr], 0, 0, 0);
+                }
+        };
+        // software pipeline: the LDS reads of group g+1 are issued in front of the MFMAs of group g
+        Ops ops[2];
+        load_ops(0, ops[0]);
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+            if (g < groups) {
+                if (g + 1 < kGroups && g + 1 < groups) load_ops(g + 1, ops[(g + 1) & 1]);
+                run_group(g, ops[g & 1]);
+            }
+        }
+    };
+
+    if (s_lo < s_hi) {
+        // NBUF - 1 strips ahead: strip s is consumed from buffer s % NBUF while s+1 (.. s+NBUF-1) are on their way
+        bool slow_next = false;  // kind of the most recently staged strip that is still in flight behind strip s
+        stage(s_lo, wbuf);
+        if (NBUF == 3 && s_lo + 1 < s_hi && p.dbg != 2) slow_next = stage(s_lo + 1, wbuf + BUF);
+        int cur = 0;
+        for (int s = s_lo; s < s_hi; ++s) {
+            // strip s has landed once at most the instructions of strip s+1 are outstanding
+            if (NBUF == 3 && s + 1 < s_hi && p.dbg != 2) {
+                if (slow_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_SLOW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_FAST) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (s + NBUF - 1 < s_hi && p.dbg != 2) {
+                int nb = cur + NBUF - 1;
+                nb = nb >= NBUF ? nb - NBUF : nb;
+                slow_next = stage(s + NBUF - 1, wbuf + nb * BUF);
+            }
+            if (p.dbg != 1) {
+                int b, wr, wc_lo, sw;
+                strip_of(s, b, wr, wc_lo, sw);
+                const bool edge = 2 * wr + 1 >= p.Ho || 2 * (wc_lo + ((sw + 3) & ~3)) > p.Wo || 4 * wr + XR > p.H || 4 * (wc_lo + sw) + 4 > p.W ||
+                                  (POOLED && (wr >= p.PHo || wc_lo + ((sw + 3) & ~3) > p.PWo));
+                if (edge) compute(std::true_type(), wr, wc_lo, sw, wbuf + cur * BUF);
+                else compute(std::false_type(), wr, wc_lo, sw, wbuf + cur * BUF);
+            }
+            cur = cur + 1 == NBUF ? 0 : cur + 1;
+        }
+    }
+
+    // ---- the eight waves in a fixed order -> one slab per workgroup
+    __syncthreads();
+    float(*red)[CO][33] = reinterpret_cast<float(*)[CO][33]>(lds);  // [wave][co][column | 27: bias]   (the staging buffers are dead)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = acc[t][0][r] + acc[t][1][r];
+            const int col = n0 + 16 * t;
+            if (col < 28) red[wave][4 * k + r][col] = v;  // D[row = 4*(lane>>4) + r][column = lane & 15]
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CO * 28; i += kWaves * 64) {
+        const int c2 = i / 28, col = i - c2 * 28;
+        float v = red[0][c2][col];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) v += red[w][c2][col];
+        p.slabs[(size_t)blockIdx.x * CO * 28 + i] = v;
+    }
+}
+
+}  // namespace
+
+namespace cnn_amd {
+
+#define CONV_TAG(d) "B%d Ci%d %dx%d Co%d k%d s%d p%d", (d)->B, (d)->Ci, (d)->H, (d)->W, (d)->Co, (d)->k, (d)->s, (d)->pad
+
+namespace {
+bool make_win_params(const cnn_conv2d_desc* d, WinParams* p, int* grid) {
+    if (d->Ci != 3 || d->Co != 16 || d->k != 3 || d->s != 2 || d->pad != 0) return false;
+    const char* e = getenv("CNN_AMD_WG_WIN");
+    if (e && atoi(e) == 0) return false;
+    p->B = d->B; p->H = d->H; p->W = d->W;
+    p->Ho = cnn_conv2d_out_dim(d->H, 3, 2, 0);
+    p->Wo = cnn_conv2d_out_dim(d->W, 3, 2, 0);
+    if (p->Ho < 1 || p->Wo < 1) return false;
+    if ((long long)CO * p->Ho * p->Wo >= (1ll << 31)) return false;  // (the pool mask is an int32 flat index)
+    p->PHo = p->Ho / 2; p->PWo = p->Wo / 2;
+    p->WR = (p->Ho + 1) / 2; p->WC = (p->Wo + 1) / 2;
+    p->nseg = (p->WC + kSW - 1) / kSW;
+    p->SW = (((p->WC + p->nseg - 1) / p->nseg) + 3) / 4 * 4;  // balanced segments, whole groups of 4 windows
+    const long long strips = (long long)d->B * p->WR * p->nseg;
+    if (strips >= (1ll << 30)) return false;
+    p->strips_total = (int)strips;
+    // one workgroup (8 waves, 135 KB of LDS) per CU
+    long long g = (strips + kWaves - 1) / kWaves;
+    if (g > kNumCU) g = kNumCU;
+    *grid = (int)g;
+    p->strips_per_wave = (int)((strips + g * kWaves - 1) / (g * kWaves));
+    p->dbg = getenv("CNN_AMD_WIN_DBG") ? atoi(getenv("CNN_AMD_WIN_DBG")) : 0;
+    return true;
+}
+
+template <int POOLED>
+int launch_win(const cnn_conv2d_desc* d, WinParams& p, int grid, hipStream_t s, const char* name) {
+    const bool dma16 = (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(p.x) % 16 == 0);
+    const size_t lds_bytes = (size_t)kWaves * num_bufs(POOLED) * buf_floats(POOLED) * sizeof(float);
+    static bool attr_set[64][2] = {};  // (per template instance = per POOLED; indexed by device)
+    int dev = 0;
+    CNN_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_set[dev][dma16]) {
+        if (dma16)
+            CNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<POOLED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        else
+            CNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<POOLED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set[dev][dma16] = true;
+    }
+    if (dma16)
+        CNN_KLAUNCH(s, name, (conv_wgrad_win_kernel<POOLED, true><<<grid, kWaves * 64, lds_bytes, s>>>(p)), CONV_TAG(d));
+    else
+        CNN_KLAUNCH(s, name, (conv_wgrad_win_kernel<POOLED, false><<<grid, kWaves * 64, lds_bytes, s>>>(p)), CONV_TAG(d));
+    return CNN_AMD_OK;
+}
+}  // namespace
+
+// number of 16 x 28 slabs (= workgroups) the window kernel writes; 0 = geometry not covered / switched off (CNN_AMD_WG_WIN=0)
+int win_wgrad_slots(const cnn_conv2d_desc* d) {
+    WinParams p;
+    int grid = 0;
+    return make_win_params(d, &p, &grid) ? grid : 0;
+}
+
+// pooled == nullptr && mask != nullptr: dpool is pre-masked; mask == nullptr: dy is the materialised delta of the conv output
+int win_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, const int32_t* mask, const float* pooled, float* slabs,
+                     hipStream_t s) {
+    WinParams p;
+    int grid = 0;
+    if (!make_win_params(d, &p, &grid)) return fail(CNN_AMD_E_BADARG, "conv_wgrad_win: geometry not covered");
+    p.x = x; p.dy = dy; p.pmask = mask; p.pooled = pooled; p.slabs = slabs;
+    if (mask == nullptr) return launch_win<0>(d, p, grid, s, "conv_wgrad_win<3,16,3,2>");
+    if (pooled != nullptr) return launch_win<1>(d, p, grid, s, "conv_wgrad_win<3,16,3,2>+pool");
+    return launch_win<2>(d, p, grid, s, "conv_wgrad_win<3,16,3,2>+poolm");
+}
+
+}  // namespace cnn_amd
