@@ -36,6 +36,7 @@ SIGNATURES = {
     "cnn_conv2d_out_dim": (C.c_int, [C.c_int] * 4),
     "cnn_maxpool2d_out_dim": (C.c_int, [C.c_int] * 3),
     "cnn_conv2d_workspace_bytes": (C.c_size_t, [_D]),
+    "cnn_conv2d_autotune": (C.c_int, [_D, _P]),
     "cnn_conv2d_forward": (C.c_int, [_D, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_forward_relu": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_relu_maxpool2_supported": (C.c_int, [_D]),
@@ -178,6 +179,10 @@ class Conv2d:
     def out_shape(self):
         d = self.desc
         return (d.B, d.Co, self.Ho, self.Wo)
+
+    def autotune(self):
+        """cnn_conv2d_autotune: measure and pin the implicit-GEMM tile of this geometry (synchronises; once per process)"""
+        check(self.lib.cnn_conv2d_autotune(C.byref(self.desc), _stream()), "cnn_conv2d_autotune")
 
     def forward(self, x, w, bias, y=None):
         import torch

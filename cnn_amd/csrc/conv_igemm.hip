@@ -23,6 +23,9 @@
 // Roofline: MFMA-bound for the 64->128 112x112 shape (190 FLOP/B); HBM-bound for Ci = 3.
 #include <cstdlib>
 
+#include <map>
+#include <mutex>
+
 #include "common.h"
 
 using namespace cnn_amd;
@@ -918,6 +921,31 @@ void dgrad_window(int k, int s, int pad, int* r0, int* TR) {
     *TR = dmax - dmin + 1;
 }
 
+// ---- measured tile choice (cnn_conv2d_autotune) ---------------------------------------------------------------------------
+// The rules in make_plan were tuned on the reference net's layers; on other geometries (the VGG / ResNet-shaped stacks) a
+// different tile is often 1.3 - 2.6x faster (tools/sweep_igemm.py).  cnn_conv2d_autotune times a short candidate list ONCE per
+// (geometry, mode) with scratch buffers of its own and pins the winner for this process; make_plan consults that table.
+struct TuneKey {
+    int v[9];
+    bool operator<(const TuneKey& o) const {
+        for (int i = 0; i < 9; ++i)
+            if (v[i] != o.v[i]) return v[i] < o.v[i];
+        return false;
+    }
+};
+TuneKey tune_key(const cnn_conv2d_desc* d, int mode) { return TuneKey{{d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad, mode}}; }
+std::mutex& tune_mutex() {
+    static std::mutex m;
+    return m;
+}
+std::map<TuneKey, int>& tune_table() {
+    static std::map<TuneKey, int> t;
+    return t;
+}
+thread_local int g_forced_cfg = -1;  // >= 0: make_plan must use exactly this configuration (the tuner's probe runs)
+// candidates: the rule-based default (-1) plus the tiles that won somewhere in tools/sweep_igemm.py
+const int kTuneCandidates[] = {-1, 200, 201, 206, 208, 226, 222, 224, 215, 216, 219, 225, 0, 1, 22};
+
 int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, bool allow_dma = true, int shrink = 0) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
     CNN_REQUIRE(Ho > 0 && Wo > 0, "%s: empty output", who);
@@ -987,9 +1015,18 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
         else if (p.M > 16) { pl->cfg = c4 ? CFG_M32_S_C4 : CFG_M32_S; pl->MF = 32; pl->MT = 32; pl->NPIX = 128; pl->CK = c4 ? 4 : 8; }
         else { pl->cfg = CFG_M16_CK4; pl->MF = 16; pl->MT = 16; pl->NPIX = 256; pl->CK = 4; }
     }
-    // tuning override (debug only): CNN_AMD_IGEMM_CFG=<cfg id>
-    if (const char* ov = getenv("CNN_AMD_IGEMM_CFG")) {
-        const int c = atoi(ov);
+    // overrides: CNN_AMD_IGEMM_CFG=<cfg id> (debug only) > the tuner's probe > the tuner's pinned choice for this geometry
+    int override_cfg = -1;
+    if (const char* ov = getenv("CNN_AMD_IGEMM_CFG")) override_cfg = atoi(ov);
+    else if (g_forced_cfg >= 0) override_cfg = g_forced_cfg;
+    else if (shrink == 0 && allow_dma) {
+        std::lock_guard<std::mutex> lk(tune_mutex());
+        auto it = tune_table().find(tune_key(d, mode));
+        if (it != tune_table().end()) override_cfg = it->second;
+    }
+    const bool pinned = override_cfg >= 0;
+    if (pinned) {
+        const int c = override_cfg;
         struct { int cfg, MF, MT, NPIX, CK; } tab[] = {
             {CFG_M128_L, 32, 128, 256, 8}, {CFG_M128, 32, 128, 128, 8}, {CFG_M128_S, 32, 128, 64, 8},
             {CFG_M64, 32, 64, 256, 8}, {CFG_M64_S, 32, 64, 64, 8}, {CFG_M32, 32, 32, 512, 8}, {CFG_M32_S, 32, 32, 128, 8},
@@ -1060,9 +1097,9 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
             p.run_mode = vec ? 1 : 2;
         }
     }
-    if (pl->lds_bytes > 160 * 1024 && pl->dma && allow_dma && !getenv("CNN_AMD_IGEMM_CFG"))
+    if (pl->lds_bytes > 160 * 1024 && pl->dma && allow_dma && !pinned)
         return make_plan(who, d, mode, pl, false);  // two buffers do not fit: single-buffered kernel
-    if (pl->lds_bytes > 160 * 1024 && shrink < 2 && !getenv("CNN_AMD_IGEMM_CFG"))
+    if (pl->lds_bytes > 160 * 1024 && shrink < 2 && !pinned)
         return make_plan(who, d, mode, pl, false, shrink + 1);
     CNN_REQUIRE(pl->lds_bytes <= 160 * 1024, "%s: tile needs %zu B of LDS (> 160 KiB): k=%d W=%d not supported", who,
                 pl->lds_bytes, d->k, d->W);
@@ -1267,16 +1304,24 @@ int rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w,
                      void* const* dgrad, hipStream_t s, unsigned* fdone, unsigned* ddone);
 int fwd_rd_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* img, const float* bias, float* y,
                    float* y_relu, hipStream_t s);
+bool thin_dgrad_supported(const cnn_conv2d_desc* d);   // conv_dgrad_thin.hip: VALU data gradient of thin (Ci = 3) stride-1 layers
+int thin_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* relu_below, float* dx, hipStream_t s);
 bool pk_dgrad_s2_supported(const cnn_conv2d_desc* d);  // conv_direct.hip: packed VALU dgrad for small stride-2 layers
 size_t pk_dgrad_s2_workspace_floats(const cnn_conv2d_desc* d);
 int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, hipStream_t s, bool prepared,
                 const float* relu_below);
 // scratch floats the forward / dgrad plans need (used by cnn_conv2d_workspace_bytes in conv_wgrad.hip)
 size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
-    Plan a, b;
     size_t n = 0;
-    if (make_plan("ws", d, MODE_FWD, &a) == CNN_AMD_OK) n = a.a_floats;
-    if (make_plan("ws", d, MODE_DGRAD, &b) == CNN_AMD_OK && b.a_floats > n) n = b.a_floats;
+    // the largest re-arranged filter image any tile the tuner may pin would need (the caller sizes its buffers once)
+    for (int c : kTuneCandidates)
+        for (int mode = 0; mode < 2; ++mode) {
+            Plan pl;
+            g_forced_cfg = c;
+            const int rc = make_plan("ws", d, mode, &pl);
+            g_forced_cfg = -1;
+            if (rc == CNN_AMD_OK && pl.a_floats > n) n = pl.a_floats;
+        }
     if (direct_conv_supported(d) && n < 1024) n = 1024;  // packed filter copies of the direct kernels (conv_direct.hip)
     if (pk_dgrad_s2_supported(d) && n < pk_dgrad_s2_workspace_floats(d)) n = pk_dgrad_s2_workspace_floats(d);
     if (fwd_rd_prepared_floats(d) > n) n = fwd_rd_prepared_floats(d);
@@ -1310,6 +1355,8 @@ static int conv2d_backward_data_impl(const char* who, const cnn_conv2d_desc* d, 
         if (rc || !relu_below) return rc;
         return cnn_relu_backward(relu_below, dx, (size_t)d->B * d->Ci * d->H * d->W, stream);
     }
+    if (thin_dgrad_supported(d))  // (its "prepared" image is a verbatim copy of w)
+        return thin_dgrad(d, dy, prepared ? (const float*)ws : w, relu_below, dx, as_stream(stream));
     if (dgrad_rd_supported(d))
         return dgrad_rd_backward_data(d, dy, prepared ? nullptr : w, prepared ? (const float*)ws : nullptr, relu_below, dx,
                                       prepared ? nullptr : ws, prepared ? 0 : ws_bytes, as_stream(stream));
@@ -1318,6 +1365,84 @@ static int conv2d_backward_data_impl(const char* who, const cnn_conv2d_desc* d, 
     Plan pl;
     if (int rc = make_plan(who, d, MODE_DGRAD, &pl)) return rc;
     return run_plan(pl, d, dy, w, nullptr, dx, const_cast<float*>(relu_below), ws, ws_bytes, as_stream(stream), who, prepared);
+}
+
+int cnn_conv2d_autotune(const cnn_conv2d_desc* d, void* stream) {
+    if (int rc = check_desc("cnn_conv2d_autotune", d)) return rc;
+    if (const char* e = getenv("CNN_AMD_IGEMM_AUTOTUNE"))
+        if (atoi(e) == 0) return CNN_AMD_OK;
+    if (getenv("CNN_AMD_IGEMM_CFG")) return CNN_AMD_OK;
+    hipStream_t s = as_stream(stream);
+    for (int mode = 0; mode < 2; ++mode) {
+        // geometries that never reach the implicit GEMM in this mode
+        if (direct_conv_supported(d)) continue;
+        if (mode == MODE_FWD && fwd_rd_supported(d)) continue;
+        if (mode == MODE_DGRAD && (dgrad_rd_supported(d) || pk_dgrad_s2_supported(d) || thin_dgrad_supported(d))) continue;
+        {
+            std::lock_guard<std::mutex> lk(tune_mutex());
+            if (tune_table().count(tune_key(d, mode))) continue;
+        }
+        const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
+        const size_t nx = (size_t)d->B * d->Ci * d->H * d->W, ny = (size_t)d->B * d->Co * Ho * Wo, nw = (size_t)d->Co * d->Ci * d->k * d->k;
+        const size_t na = igemm_workspace_floats(d) + 64;
+        float *bx = nullptr, *by = nullptr, *bw = nullptr, *ba = nullptr, *bb = nullptr;
+        auto release = [&]() {
+            (void)hipFree(bx); (void)hipFree(by); (void)hipFree(bw); (void)hipFree(ba); (void)hipFree(bb);
+        };
+        if (hipMalloc(&bx, nx * 4) != hipSuccess || hipMalloc(&by, ny * 4) != hipSuccess || hipMalloc(&bw, nw * 4) != hipSuccess ||
+            hipMalloc(&ba, na * 4) != hipSuccess || hipMalloc(&bb, (size_t)(d->Co + d->Ci) * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            release();
+            return CNN_AMD_OK;  // no room to measure: keep the rule-based choice
+        }
+        // (zeros: MFMA / LDS / DMA timing does not depend on the values)
+        (void)hipMemsetAsync(bx, 0, nx * 4, s); (void)hipMemsetAsync(by, 0, ny * 4, s); (void)hipMemsetAsync(bw, 0, nw * 4, s);
+        (void)hipMemsetAsync(bb, 0, (size_t)(d->Co + d->Ci) * 4, s);
+        const float* X = mode == MODE_FWD ? bx : by;  // forward reads x, the data gradient reads dy
+        float* Y = mode == MODE_FWD ? by : bx;
+        hipEvent_t e0, e1;
+        CNN_HIP_CHECK(hipEventCreate(&e0));
+        CNN_HIP_CHECK(hipEventCreate(&e1));
+        int best = -1;
+        float best_ms = 1e30f;
+        for (int c : kTuneCandidates) {
+            Plan pl;
+            g_forced_cfg = c;
+            int rc = make_plan("cnn_conv2d_autotune", d, mode, &pl);
+            if (rc == CNN_AMD_OK && c >= 0 && pl.cfg != c) rc = CNN_AMD_E_BADARG;  // not applicable to this geometry
+            float ms = 1e30f;
+            if (rc == CNN_AMD_OK) {
+                rc = run_plan(pl, d, X, bw, bb, Y, nullptr, ba, na * 4, s, "cnn_conv2d_autotune");  // warm-up (and first-use setup)
+                if (rc == CNN_AMD_OK) {
+                    (void)hipEventRecord(e0, s);
+                    rc = run_plan(pl, d, X, bw, bb, Y, nullptr, ba, na * 4, s, "cnn_conv2d_autotune");
+                    (void)hipEventRecord(e1, s);
+                    if (rc == CNN_AMD_OK && hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+                }
+            }
+            g_forced_cfg = -1;
+            if (rc != CNN_AMD_OK) {
+                (void)hipGetLastError();
+                continue;
+            }
+            // the rule-based default keeps its place unless something is clearly faster (noise: a few per cent)
+            if (best_ms > 1e29f || ms < best_ms * 0.97f) {
+                best = c;
+                best_ms = ms;
+            }
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        release();
+        if (best >= 0) {
+            std::lock_guard<std::mutex> lk(tune_mutex());
+            tune_table()[tune_key(d, mode)] = best;
+        } else {
+            std::lock_guard<std::mutex> lk(tune_mutex());
+            tune_table()[tune_key(d, mode)] = -1;  // measured: the default stays
+        }
+    }
+    return CNN_AMD_OK;
 }
 
 int cnn_conv2d_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
@@ -1399,6 +1524,12 @@ int cnn_conv2d_prepare_filters(int n, const cnn_conv2d_desc* descs, const float*
         for (int mode = 0; mode < 2; ++mode) {
             void* out = mode == MODE_FWD ? (fwd ? fwd[i] : nullptr) : (dgrad ? dgrad[i] : nullptr);
             if (!out || ((mode == MODE_FWD ? fdone : ddone) >> i & 1u)) continue;
+            if (mode == MODE_DGRAD && !direct_conv_supported(&descs[i]) && thin_dgrad_supported(&descs[i])) {
+                // conv_dgrad_thin.hip reads the reference layout: its prepared image is a verbatim copy
+                CNN_HIP_CHECK(hipMemcpyAsync(out, w[i], sizeof(float) * (size_t)descs[i].Co * descs[i].Ci * descs[i].k * descs[i].k,
+                                             hipMemcpyDeviceToDevice, s));
+                continue;
+            }
             CNN_REQUIRE(!direct_conv_supported(&descs[i]) && !(mode == MODE_DGRAD && pk_dgrad_s2_supported(&descs[i]) && !dgrad_rd_supported(&descs[i])),
                         "cnn_conv2d_prepare_filters: layer %d has no prepared path for this mode", i);
             Plan pl;

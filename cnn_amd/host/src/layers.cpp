@@ -165,6 +165,10 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
         out_buf.allocate(B, out_channels, out_H, out_W, name + "_output");
         output = out_buf.views;
         batch = B;
+        // the shape is known now: let the library measure which tile its implicit-GEMM kernels should use for it (once per
+        // geometry and process, before any filter preparation)
+        cnn_conv2d_desc d0{B, in_channels, H, W, out_channels, kernel_size, stride, padding};
+        must(cnn_conv2d_autotune(&d0, stream), "cnn_conv2d_autotune");
     }
     assert(B <= batch && "batch larger than the first forward's (conv2d.cpp:47 has the same restriction)");
     in_H = H;

@@ -64,6 +64,14 @@ typedef struct {
 /* scratch needed by ANY of the three MFMA entry points below for this geometry */
 size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d);
 
+/* Optional, once per geometry and process: times a short list of implicit-GEMM tile shapes for the forward and the data-gradient
+ * kernels of this geometry on the device (scratch buffers of its own, zeros; SYNCHRONISES) and pins the fastest for every
+ * later call with the same desc -- the built-in rules were tuned on the reference net's layers, other geometries gain up to
+ * 2.6x (tools/sweep_igemm.py).  Call it BEFORE cnn_conv2d_prepare_filters / the first forward of the layer (the re-arranged
+ * filter image depends on the tile); geometries served by the specialised kernels are left alone.  CNN_AMD_IGEMM_AUTOTUNE=0
+ * turns it into a no-op.  The host Conv2D layer calls it when it first sees its input shape. */
+int cnn_conv2d_autotune(const cnn_conv2d_desc* d, void* stream);
+
 /* replaces Conv2D::forward's loop nest (conv2d.cpp:69-92): y = bias + valid cross-correlation.
  * Implicit GEMM on v_mfma_f32_32x32x2_f32 / 16x16x4_f32, input rows + filter slabs staged in LDS. */
 int cnn_conv2d_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,

@@ -58,6 +58,8 @@ CONV_CASES = [
     (1, 3, 224, 224, 64, 7, 2, 3),   # the ResNet stem at full resolution (row staging of 230-float rows)
     (3, 32, 9, 11, 64, 3, 1, 0),     # stride-1 register-direct data gradient: one tile of 32 channels, borders everywhere
     (2, 64, 8, 7, 128, 3, 1, 0),     # ... two tiles per wave
+    (3, 3, 70, 130, 24, 3, 1, 1),    # thin-input data gradient (conv_dgrad_thin.hip): three column segments, ragged last band
+    (2, 3, 9, 5, 7, 3, 1, 0),        # ... without padding, image smaller than one patch
     (2, 32, 28, 30, 64, 3, 2, 0),    # stride-2 register-direct data gradient on even sizes (last input row / column uncovered)
     (1, 96, 9, 12, 128, 3, 2, 0),    # ... three 32-channel groups, tiny image
 ]

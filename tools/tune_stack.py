@@ -27,6 +27,8 @@ for (Ci, H, W, Co, k, s, pad) in conv_geometries(name):
         print(f"== {case}  (same as above)")
         continue
     conv = capi.Conv2d(*case)
+    if not os.environ.get("TUNE_NO_AUTOTUNE"):
+        conv.autotune()
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.rand((batch, Ci, H, W), generator=g, device="cuda")
     w = torch.randn((Co, Ci, k, k), generator=g, device="cuda") * 0.1
