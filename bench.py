@@ -202,44 +202,18 @@ def cpu_baseline_stack(name, budget_s=25.0):
 
 
 def init_comm(capi, torch, dist, world, rank):
-    """RCCL communicator for the C-ABI exchange (cnn_allreduce_grads): rank 0 creates the 128-byte id, torch.distributed
-    ships it (plumbing), every rank joins with cnn_comm_init_rank on its own device.  -> (comm, description)"""
-    import ctypes as C
+    """the data path's exchange (cnn_amd.dp.RcclComm: C ABI -> RCCL), checked once against torch.distributed's own all-reduce"""
+    from cnn_amd.dp import RcclComm
 
-    lib = capi.load()
-    if not lib.cnn_comm_available():
-        raise capi.CnnAmdError("librccl could not be bound by libcnn_amd.so: " + lib.cnn_amd_last_error().decode())
-    raw = (C.c_char * 128)()
-    if rank == 0:
-        capi.check(lib.cnn_comm_unique_id(raw), "cnn_comm_unique_id")
-    buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).cuda()
-    dist.broadcast(buf, 0)
-    ident = buf.cpu().numpy().tobytes()
-    comm = C.c_void_p()
-    capi.check(lib.cnn_comm_init_rank(C.byref(comm), world, rank, ident), "cnn_comm_init_rank")
-    w, r = C.c_int(), C.c_int()
-    capi.check(lib.cnn_comm_info(comm, C.byref(w), C.byref(r)), "cnn_comm_info")
-    assert (w.value, r.value) == (world, rank), (w.value, r.value, world, rank)
-    # one exchange up front, checked against torch.distributed's own all-reduce of the same values
+    comm = RcclComm(dist, world, rank)
     probe = torch.arange(1024, device="cuda", dtype=torch.float32) * (rank + 1)
     ref = probe.clone()
-    capi.check(lib.cnn_allreduce_grads(comm, capi._ptr(probe), probe.numel(), capi._stream()), "cnn_allreduce_grads")
+    comm.all_reduce(probe)
     dist.all_reduce(ref)
     torch.cuda.synchronize()
     assert torch.equal(probe, ref), "cnn_allreduce_grads disagrees with torch.distributed.all_reduce"
-    return comm, {"ranks": w.value, "rccl_version": int(lib.cnn_comm_version()), "entry": "cnn_allreduce_grads (include/cnn_amd.h)",
+    return comm, {"ranks": world, "rccl_version": comm.version, "entry": "cnn_allreduce_grads (include/cnn_amd.h)",
                   "NCCL_ALGO": os.environ.get("NCCL_ALGO", "default"), "NCCL_PROTO": os.environ.get("NCCL_PROTO", "default")}
-
-
-class CommAllreduce:
-    """what cnn_amd.dp.allreduce_grads takes in place of torch.distributed: an in-place sum through the C ABI, on the current stream"""
-
-    def __init__(self, capi, comm):
-        self.capi, self.comm = capi, comm
-
-    def all_reduce(self, t):
-        self.capi.check(self.capi.load().cnn_allreduce_grads(self.comm, self.capi._ptr(t), t.numel(), self.capi._stream()),
-                        "cnn_allreduce_grads")
 
 
 def make_runner(config, api, batch, torch, capi, world, rank, comm, pool_block=True):
@@ -263,7 +237,7 @@ def make_runner(config, api, batch, torch, capi, world, rank, comm, pool_block=T
         # flush() launches a pending one, so the timed region contains exactly K of them (cnn_amd/pynet.py)
         net = AlexNetHip(B, 3, defer_input_grad=True, fuse_pool=pool_block and not os.environ.get("CNN_AMD_NO_POOL_FUSION"))
         net.load_params((rs.standard_normal(net.n_params) * 0.1).astype(np.float32))
-        handle = CommAllreduce(capi, comm) if world > 1 else None
+        handle = comm if world > 1 else None
         return dict(step=lambda: net.train_step(x, labels, lr, handle, world), flush=net.flush, B=B, n_params=net.n_params,
                     loss=lambda: float(net.loss_sum.item()) / B, keep=(net, x, labels), close=lambda: None,
                     api="python driver (cnn_amd/pynet.py) -> C ABI; first block pool-fused, conv_layer_1 data gradient deferred")
@@ -279,7 +253,7 @@ def make_runner(config, api, batch, torch, capi, world, rank, comm, pool_block=T
         net = hostapi.HostSequential(spec)
         net.set_params(stacks.he_init(net.layout, 1234))
     if world > 1:
-        net.set_comm(comm, world)  # Sequential::update_gradients all-reduces the arena; BatchNorm2D layers run as sync-BN
+        net.set_comm(comm.handle, world)  # Sequential::update_gradients all-reduces the arena; BatchNorm2D layers run as sync-BN
 
     def close():
         net.close()
@@ -470,7 +444,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
-        capi.load().cnn_comm_destroy(comm)
+        comm.destroy()
         dist.destroy_process_group()
 
 

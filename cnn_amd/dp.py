@@ -1,5 +1,6 @@
 """Data-parallel glue: one process per GPU, the batch sharded by sample, ONE all-reduce of the flat gradient arena
-per step (RCCL over xGMI when the backend is "nccl"; gloo on CPU for the tests).
+per step -- RCCL over xGMI through the C ABI (RcclComm -> cnn_allreduce_grads) on the GPU path; a torch.distributed
+handle (gloo) on CPU for the tests.
 
 The reference has no parallelism at all; the only cross-sample coupling on the path is the
 batch mean inside the weight / bias gradients (conv2d.cpp:148,157; linear.cpp:62,70).  Each rank's kernels divide by
@@ -39,6 +40,48 @@ def allreduce_grads(grads, dist, world):
     return 1.0 / world
 
 
+class RcclComm:
+    """The data path's exchange: an RCCL communicator owned through the C ABI (cnn_comm_* / cnn_allreduce_grads in
+    include/cnn_amd.h), one rank per process / GPU.  torch.distributed is only the courier of the 128-byte id (any
+    rendezvous would do).  `all_reduce(t)` has the signature allreduce_grads() expects, so an instance stands in for the
+    torch.distributed handle; `.handle` is the void* architectures::Sequential::set_comm takes."""
+
+    def __init__(self, dist, world, rank, device="cuda"):
+        import ctypes as C
+
+        import torch
+
+        from . import capi
+
+        self.capi, self.world, self.rank = capi, world, rank
+        lib = capi.load()
+        if not lib.cnn_comm_available():
+            raise capi.CnnAmdError("librccl could not be bound by libcnn_amd.so: " + lib.cnn_amd_last_error().decode())
+        raw = (C.c_char * 128)()
+        if rank == 0:
+            capi.check(lib.cnn_comm_unique_id(raw), "cnn_comm_unique_id")
+        buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).to(device)
+        if world > 1:
+            dist.broadcast(buf, 0)
+        self.handle = C.c_void_p()
+        capi.check(lib.cnn_comm_init_rank(C.byref(self.handle), world, rank, buf.cpu().numpy().tobytes()), "cnn_comm_init_rank")
+        w, r = C.c_int(), C.c_int()
+        capi.check(lib.cnn_comm_info(self.handle, C.byref(w), C.byref(r)), "cnn_comm_info")
+        assert (w.value, r.value) == (world, rank), (w.value, r.value, world, rank)
+        self.version = int(lib.cnn_comm_version())
+
+    def all_reduce(self, t):
+        """in-place fp32 sum over all ranks, enqueued on the current stream"""
+        self.capi.check(self.capi.load().cnn_allreduce_grads(self.handle, self.capi._ptr(t), t.numel(), self.capi._stream()),
+                        "cnn_allreduce_grads")
+        return t
+
+    def destroy(self):
+        if self.handle:
+            self.capi.load().cnn_comm_destroy(self.handle)
+            self.handle = None
+
+
 def sum_allreduce(dist, world):
     """the `allreduce(t)` callable cnn_amd.capi.BatchNorm2d.forward_sync / backward_sync expect: in-place SUM of a small
     per-channel tensor over all ranks (no-op for one rank)"""
@@ -49,34 +92,3 @@ def sum_allreduce(dist, world):
         return t
 
     return allreduce
-
-
-def syncbn_reference_protocol(x, dy, gamma, beta, allreduce, global_count, eps=1e-5):
-    """numpy statement of the sync-BN exchange (include/cnn_amd.h, cnn_batchnorm2d_partial_sums ...): what each rank
-    computes between the three collectives.  Used by the gloo test to pin the protocol against the full-batch oracle;
-    the HIP entry points follow the same steps (tests/test_gpu_batchnorm.py)."""
-    import numpy as np
-    import torch
-
-    ax = (0, 2, 3)
-    s1 = torch.from_numpy(x.sum(axis=ax, dtype=np.float32))
-    allreduce(s1)
-    mean = (s1.numpy() / np.float32(global_count)).astype(np.float32)
-    xc = x - mean[None, :, None, None]
-    s2 = torch.from_numpy((xc * xc).sum(axis=ax, dtype=np.float32))
-    allreduce(s2)
-    var = (s2.numpy() / np.float32(global_count)).astype(np.float32)
-    inv = (1.0 / np.sqrt(var + np.float32(eps))).astype(np.float32)
-    norm = xc * inv[None, :, None, None]
-    y = gamma[None, :, None, None] * norm + beta[None, :, None, None]
-    g = gamma[None, :, None, None]
-    s4 = np.stack([(dy * norm).sum(axis=ax), dy.sum(axis=ax), ((dy * g) * xc * np.float32(-0.5) * (inv ** 3)[None, :, None, None]).sum(axis=ax),
-                   xc.sum(axis=ax)], axis=1).astype(np.float32)
-    t4 = torch.from_numpy(s4)
-    allreduce(t4)
-    s4 = t4.numpy()
-    L = np.float32(global_count)
-    inv_v = s4[:, 2] / L
-    u_g = (s4[:, 1] * gamma) * (-inv) + inv_v * np.float32(-2) * s4[:, 3]
-    dx = (dy * g) * inv[None, :, None, None] + (inv_v * 2)[None, :, None, None] * xc + (u_g / L)[None, :, None, None]
-    return y.astype(np.float32), dx.astype(np.float32), s4[:, 0].copy(), s4[:, 1].copy(), mean, var

@@ -70,7 +70,7 @@ void cnnh_seq_finalize(void* hv, float* params_dev, float* grads_dev) {
     else
         h->net->finalize();
 }
-// the two BASELINE stacks from the C++ builders (network.cpp); the Python side checks them against cnn_amd/stacks.py
+// the two BASELINE stacks from the C++ builders (sequential.cpp); the Python side checks them against cnn_amd/stacks.py
 void* cnnh_stack_create(const char* which, int classes, int batch_norm) {
     Handle* h = new Handle();
     h->classes = classes;

@@ -185,7 +185,7 @@ class HostAlexNet(HostNet):
 
 
 def _layer_names(spec):
-    """the naming scheme of network.cpp's StackBuilder / the reference (conv_layer_N, bn_layer_N, relu_layer_N, max_pool_N)"""
+    """the naming scheme of sequential.cpp's StackBuilder / the reference (conv_layer_N, bn_layer_N, relu_layer_N, max_pool_N)"""
     names, n_conv, n_pool, n_lin = [], 0, 0, 0
     for item in spec:
         kind = item[0]
@@ -237,7 +237,7 @@ class HostSequential(HostNet):
 
 
 class HostStack(HostNet):
-    """architectures::build_vgg11 / build_resnet18 (network.cpp) -- the C++ side's own builders of the BASELINE stacks"""
+    """architectures::build_vgg11 / build_resnet18 (sequential.cpp) -- the C++ side's own builders of the BASELINE stacks"""
 
     def __init__(self, which, classes=3, batch_norm=False):
         self.lib = load()

@@ -17,6 +17,34 @@ from oracle import pyoracle as O  # noqa: E402
 from tests.util import normal_scaled, uniform01  # noqa: E402
 
 
+def syncbn_reference_protocol(x, dy, gamma, beta, allreduce, global_count, eps=1e-5):
+    """numpy statement of the sync-BN exchange (include/cnn_amd.h, cnn_batchnorm2d_partial_sums ...): what each rank
+    computes between the three collectives.  Used by the gloo test to pin the protocol against the full-batch oracle;
+    the HIP entry points follow the same steps (tests/test_gpu_batchnorm.py)."""
+    ax = (0, 2, 3)
+    s1 = torch.from_numpy(x.sum(axis=ax, dtype=np.float32))
+    allreduce(s1)
+    mean = (s1.numpy() / np.float32(global_count)).astype(np.float32)
+    xc = x - mean[None, :, None, None]
+    s2 = torch.from_numpy((xc * xc).sum(axis=ax, dtype=np.float32))
+    allreduce(s2)
+    var = (s2.numpy() / np.float32(global_count)).astype(np.float32)
+    inv = (1.0 / np.sqrt(var + np.float32(eps))).astype(np.float32)
+    norm = xc * inv[None, :, None, None]
+    y = gamma[None, :, None, None] * norm + beta[None, :, None, None]
+    g = gamma[None, :, None, None]
+    s4 = np.stack([(dy * norm).sum(axis=ax), dy.sum(axis=ax), ((dy * g) * xc * np.float32(-0.5) * (inv ** 3)[None, :, None, None]).sum(axis=ax),
+                   xc.sum(axis=ax)], axis=1).astype(np.float32)
+    t4 = torch.from_numpy(s4)
+    allreduce(t4)
+    s4 = t4.numpy()
+    L = np.float32(global_count)
+    inv_v = s4[:, 2] / L
+    u_g = (s4[:, 1] * gamma) * (-inv) + inv_v * np.float32(-2) * s4[:, 3]
+    dx = (dy * g) * inv[None, :, None, None] + (inv_v * 2)[None, :, None, None] * xc + (u_g / L)[None, :, None, None]
+    return y.astype(np.float32), dx.astype(np.float32), s4[:, 0].copy(), s4[:, 1].copy(), mean, var
+
+
 def main():
     world, rank, _ = dp.env_world()
     dist = dp.init_process_group("gloo")
@@ -52,7 +80,7 @@ def main():
     gamma = (uniform01(62, (C,)) + 0.5).astype(np.float32)
     beta = uniform01(63, (C,)).astype(np.float32)
     lo, hi = dp.shard_bounds(Bn, rank, world)
-    y, dx, gg, gb, mean, var = dp.syncbn_reference_protocol(xb[lo:hi], dyb[lo:hi], gamma, beta, dp.sum_allreduce(dist, world),
+    y, dx, gg, gb, mean, var = syncbn_reference_protocol(xb[lo:hi], dyb[lo:hi], gamma, beta, dp.sum_allreduce(dist, world),
                                                             Bn * 6 * 7)
     y_o, _, sm_o, sv_o, _, _ = O.batchnorm_forward(xb, gamma, beta, np.zeros(C, np.float32), np.zeros(C, np.float32))
     dx_o, gg_o, gb_o = O.batchnorm_backward(xb, dyb, gamma, sm_o, sv_o)

@@ -1,0 +1,122 @@
+"""The data-parallel exchange behind the C ABI (cnn_comm_* / cnn_allreduce_grads -> RCCL): what can be checked on one GPU, and
+the two-replica run of the C++ container that needs two (skipped cleanly on a 1-GPU box)."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from cnn_amd import stacks as S
+from tests.util import he_init, uniform01
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    return torch
+
+
+def test_rccl_is_bound_and_a_one_rank_communicator_works(T):
+    """RCCL is loaded through libcnn_amd.so (dlopen by soname), a 1-rank communicator initialises on this device and the in-place
+    sum over it is the identity; nccl_smoke-style sanity that the driver's GPU test run exercises the exchange entry points"""
+    from cnn_amd import capi
+    from cnn_amd.dp import RcclComm
+
+    lib = capi.load()
+    assert lib.cnn_comm_available() == 1
+    assert lib.cnn_comm_version() >= 20000  # RCCL 2.x
+    comm = RcclComm(None, 1, 0)
+    x = T.arange(100003, device="cuda", dtype=T.float32) * 0.5 - 7.0
+    ref = x.clone()
+    comm.all_reduce(x)
+    T.cuda.synchronize()
+    assert T.equal(x, ref)
+    w, r = C.c_int(), C.c_int()
+    capi.check(lib.cnn_comm_info(comm.handle, C.byref(w), C.byref(r)), "cnn_comm_info")
+    assert (w.value, r.value) == (1, 0)
+    assert lib.cnn_allreduce_grads(None, capi._ptr(x), 4, None) != 0 and b"null" in lib.cnn_amd_last_error()
+    comm.destroy()
+
+
+def test_container_with_a_one_rank_communicator_equals_the_plain_step(T):
+    """Sequential::set_comm(world = 1): the exchange path is a no-op and BatchNorm2D takes the single-process statistics"""
+    from cnn_amd import hostapi
+    from cnn_amd.dp import RcclComm
+
+    spec = S.alexnet(3, batch_norm=True)
+    layout = S.walk(spec)
+    p0 = he_init(layout, 81)
+    B = 4
+    x = T.from_numpy(uniform01(82, (B, 3, 224, 224))).cuda()
+    labels = T.from_numpy((np.arange(B) % 3).astype(np.int32)).cuda()
+    comm = RcclComm(None, 1, 0)
+    outs = []
+    for use_comm in (False, True):
+        net = hostapi.HostSequential(spec)
+        net.set_params(p0)
+        if use_comm:
+            net.set_comm(comm.handle, 1)
+        for _ in range(2):
+            net.train_step(x, labels, 1e-3)
+        outs.append((net.last_loss(), net.get_params()))
+        net.close()
+    comm.destroy()
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_two_replicas_of_the_cpp_container_equal_the_full_batch_step(T):
+    """configs[2] / [4] in miniature: two replicas of the C++ container (one per GPU, one host thread each, ncclCommInitAll via
+    cnn_comm_init_all) train on the two halves of a batch -- BatchNorm2D as sync-BN, gradient arena all-reduced by
+    Sequential::update_gradients -- and end up with the parameters of ONE replica stepping on the whole batch."""
+    if T.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's 1-GPU test box has one)")
+    from cnn_amd import capi, hostapi
+
+    lib = capi.load()
+    spec = S.alexnet(3, batch_norm=True)
+    layout = S.walk(spec)
+    p0 = he_init(layout, 91)
+    GB, lr, steps = 8, 1e-3, 2
+    x = uniform01(92, (GB, 3, 224, 224))
+    labels = (np.arange(GB) % 3).astype(np.int32)
+    comms = (C.c_void_p * 2)()
+    capi.check(lib.cnn_comm_init_all(comms, 2, None), "cnn_comm_init_all")
+    results, errors = [None, None], []
+
+    def replica(rank):
+        try:
+            T.cuda.set_device(rank)
+            xs = T.from_numpy(x[rank * 4:(rank + 1) * 4]).cuda()
+            ls = T.from_numpy(labels[rank * 4:(rank + 1) * 4]).cuda()
+            net = hostapi.HostSequential(spec)
+            net.set_params(p0)
+            net.set_comm(C.c_void_p(comms[rank]), 2)
+            for _ in range(steps):
+                net.train_step(xs, ls, lr)
+            T.cuda.synchronize()
+            results[rank] = net.get_params()
+            net.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=replica, args=(r,)) for r in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    T.cuda.set_device(0)
+    full = hostapi.HostSequential(spec)
+    full.set_params(p0)
+    xf, lf = T.from_numpy(x).cuda(), T.from_numpy(labels).cuda()
+    for _ in range(steps):
+        full.train_step(xf, lf, lr)
+    want = full.get_params()
+    full.close()
+    for c in comms:
+        lib.cnn_comm_destroy(C.c_void_p(c))
+    assert np.array_equal(results[0], results[1]), "replicas diverged"
+    err = np.abs(results[0] - want).max() / np.abs(want).max()
+    assert err <= 1e-5, err

@@ -1,5 +1,5 @@
 """GPU parity of the BASELINE configs[3] / [4] workloads: the VGG-11-shaped and ResNet-18-shaped layer lists (cnn_amd/stacks.py,
-cnn_amd/host/src/network.cpp) run through the C++ Layer API (architectures::Sequential -> C ABI -> HIP kernels) against the same
+cnn_amd/host/src/sequential.cpp) run through the C++ Layer API (architectures::Sequential -> C ABI -> HIP kernels) against the same
 lists composed from the oracle's layer functions (oracle.pyoracle.SeqNet), plus full-batch properties the oracle is too slow for."""
 import numpy as np
 import pytest
@@ -45,7 +45,7 @@ def _slices(layout):
 
 @pytest.mark.parametrize("which", ["vgg11", "resnet18"])
 def test_cpp_builders_match_the_python_layer_lists(T, which):
-    """architectures::build_vgg11 / build_resnet18 (network.cpp) == cnn_amd/stacks.py (what the oracle is composed from)"""
+    """architectures::build_vgg11 / build_resnet18 (sequential.cpp) == cnn_amd/stacks.py (what the oracle is composed from)"""
     from cnn_amd import hostapi
 
     spec = S.STACKS[which]()

@@ -127,3 +127,65 @@ def test_net_param_layout_matches_checkpoint_order():
     net = O.Net(2, 3)
     sizes = [16 * 27 + 16, 32 * 144 + 32, 64 * 288 + 64, 128 * 576 + 128, 4608 * 3 + 3]
     assert net.n_params == sum(sizes) == 111267 and net.lin_in == 4608
+
+
+def test_oracle_thread_split_is_bit_identical():
+    """oracle_set_threads: the OpenMP split of the convolution loop nests never reorders one element's accumulation, so every
+    thread count gives the same bits (the big parity cases run on all host cores, cpu_baseline on one)"""
+    rs = np.random.RandomState(5)
+    x = rs.rand(3, 5, 12, 11).astype(np.float32)
+    w = (rs.standard_normal((7, 5, 3, 3)) * 0.2).astype(np.float32)
+    b = rs.standard_normal(7).astype(np.float32)
+    dy = (rs.rand(3, 7, 5, 5) * 2 - 1).astype(np.float32)
+    out = []
+    for n in (1, 3, 0):
+        O.set_threads(n)
+        out.append((O.conv2d_forward(x, w, b, 2),) + O.conv2d_backward(x, dy, w, 2))
+    O.set_threads(1)
+    for other in out[1:]:
+        for a, c in zip(out[0], other):
+            assert np.array_equal(a, c)
+
+
+def test_seqnet_composition_equals_the_c_level_reference_net():
+    """oracle.pyoracle.SeqNet (any layer list, composed from the layer functions) == Net (the C-level walk of alexnet.cpp:10-65)
+    on the reference's own list, bit for bit; mask-synchronised backward with the net's OWN tensors changes nothing"""
+    from cnn_amd import stacks as S
+
+    B = 2
+    rs = np.random.RandomState(6)
+    x = rs.rand(B, 3, 224, 224).astype(np.float32)
+    labels = np.array([2, 0], np.int32)
+    a, b = O.Net(B, 3), O.SeqNet(S.alexnet())
+    p0 = (rs.standard_normal(a.n_params) * 0.1).astype(np.float32)
+    assert a.n_params == b.n_params == 111267
+    a.params[:] = p0
+    b.params[:] = p0
+    la, _ = a.train_step(x, labels, 1e-3)
+    logits = b.forward(x)
+    loss, delta = O.cross_entropy_backward(O.softmax(logits), labels)
+    masks = {i: b.acts[i] for i, e in enumerate(b.layers) if e["kind"] == "relu"}
+    masks.update({i: b.inputs[i] for i, e in enumerate(b.layers) if e["kind"] == "pool"})
+    b.backward(delta, masks_from=masks)
+    assert loss == la
+    assert np.array_equal(a.grads, b.grads)
+    # the padding extension of the composite: reference convolution on the Tensor3D::pad-ed input, gradient cropped
+    xs = rs.rand(2, 3, 6, 7).astype(np.float32)
+    ws = rs.standard_normal((4, 3, 3, 3)).astype(np.float32)
+    y = O.conv2d_forward_padded(xs, ws, np.zeros(4, np.float32), 1, 1)
+    assert y.shape == (2, 4, 6, 7)
+    _, _, dx = O.conv2d_backward_padded(xs, np.ones_like(y), ws, 1, 1)
+    assert dx.shape == xs.shape
+
+
+def test_stack_layer_lists():
+    from cnn_amd import stacks as S
+
+    assert sum(e["params"] for e in S.walk(S.alexnet())) == 111267  # the shipped checkpoints: 445 068 bytes
+    v = S.walk(S.vgg11())
+    assert [e["out"] for e in v if e["kind"] == "pool"] == [(64, 112, 112), (128, 56, 56), (256, 28, 28), (512, 14, 14), (512, 7, 7)]
+    assert abs(S.train_flops_per_image(S.vgg11()) / 1e9 - 44.913) < 1e-3  # SURVEY.md 8(d): 44.9 GFLOP per image and train step
+    r = S.walk(S.resnet18())
+    assert sum(e["kind"] == "conv" for e in r) == 17 and sum(e["kind"] == "bn" for e in r) == 17
+    assert r[-1]["n_in"] == 512 * 7 * 7
+    assert {(e["k"], e["s"]) for e in r if e["kind"] == "conv"} == {(7, 2), (3, 1), (3, 2), (1, 2)}
