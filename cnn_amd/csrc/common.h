@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 
@@ -52,6 +53,25 @@ void ktimer_end(hipStream_t s);
 __host__ __device__ inline int m16_filter_index(int j, int lane, int Ci, int slice) {
     return ((4 * (j / 9) + (lane >> 4)) * Ci + 16 * slice + (lane & 15)) * 9 + j % 9;
 }
+
+// "has this per-function attribute been set on the CURRENT device yet" (hipFuncSetAttribute is per device): one atomic flag per
+// device and call site.  (racing threads may both set it: setting the attribute twice is
+// harmless, never setting it on a second device -- or launching before it is set -- is not): needed() until mark().
+struct DeviceOnce {
+    std::atomic<unsigned char> done[64];
+    static int device() {
+        int dev = 0;
+        return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) ? dev : -1;
+    }
+    bool needed() const {
+        const int dev = device();
+        return dev < 0 || done[dev].load(std::memory_order_acquire) == 0;
+    }
+    void mark() {
+        const int dev = device();
+        if (dev >= 0) done[dev].store(1, std::memory_order_release);
+    }
+};
 
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kNumCU = 256;        // MI355X

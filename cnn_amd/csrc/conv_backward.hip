@@ -19,9 +19,12 @@ struct SideStream {
     int device = -1;
 };
 int get_side(SideStream** out) {
-    static thread_local SideStream side;
+    // one side stream per (host thread, device): a thread that alternates between devices keeps both (re-creating on every
+    // switch leaked a stream + two events each time)
+    static thread_local SideStream sides[16];
     int dev = 0;
     CNN_HIP_CHECK(hipGetDevice(&dev));
+    SideStream& side = sides[(dev >= 0 ? dev : 0) % 16];
     if (side.stream == nullptr || side.device != dev) {
         CNN_HIP_CHECK(hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking));
         CNN_HIP_CHECK(hipEventCreateWithFlags(&side.fork, hipEventDisableTiming));

@@ -1123,11 +1123,11 @@ int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float
                                                                                      Wo, ipi, div_magic(ipi), div_magic(V))),
                     CONV_TAG(d));
     } else {  // opt-in (CNN_AMD_PK_DGRAD=1): 32 input channels, slower than the implicit GEMM (71 vs 56 us)
-        static thread_local bool attr_set = false;
-        if (!attr_set) {
+        static DeviceOnce attr_once;
+        if (attr_once.needed()) {
             CNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_dgrad_pk_s2<32, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                               160 * 1024));
-            attr_set = true;
+            attr_once.mark();
         }
         CNN_KLAUNCH(s, relu_below ? "conv_dgrad_pk_s2<32>+relu" : "conv_dgrad_pk_s2<32>",
                     (conv_dgrad_pk_s2<32, 4, 1><<<wave_grid(witems), kBlock, wl, s>>>(dy, (const v2f*)ws, dx, relu_below, d->B, d->Co, d->H, d->W, Ho,

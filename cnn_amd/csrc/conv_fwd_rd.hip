@@ -400,10 +400,10 @@ bool make_plan(const cnn_conv2d_desc* d, FwdRdPlan* pl) {
 template <int S, int CI, int MT, int NW>
 int launch(const FwdRdPlan& pl, hipStream_t s, const char* name, const cnn_conv2d_desc* d) {
     auto kern = conv_fwd_rd_kernel<S, CI, MT, NW, 2>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.needed()) {
         CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_once.mark();
     }
     const dim3 grid(pl.blocks_x, pl.cgroups);
     CNN_KLAUNCH(s, name, (kern<<<grid, NW * 64, pl.lds, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W,

@@ -1163,10 +1163,10 @@ int launch_cfg2(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
 template <int MF, int MA, int NB, int WM, int WN, int S, int XM, bool R2>
 int launch_dma_xm2(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
     auto kern = igemm_dma_kernel<MF, MA, NB, WM, WN, S, XM, R2>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.needed()) {
         CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_once.mark();
     }
     char name[96];
     snprintf(name, sizeof(name), "igemm_dma_kernel<%d,%d,%d,%d,%d,%d%s>%s", MF, MA, NB, WM, WN, S,

@@ -579,10 +579,10 @@ template <int MF, int MA, int NB, int WM, int WN, int WK, bool NARROW, bool PC>
 int launch_w2(const WPlan& pl, hipStream_t s, const cnn_conv2d_desc* d, int* nsplit_used) {
     auto kern = wgrad_kernel<MF, MA, NB, WM, WN, WK, NARROW, PC>;
     constexpr int kThreads = 64 * WM * WN * WK * (PC ? 2 : 1);
-    static thread_local bool attr_set = false;
-    if (pl.lds_bytes > 48 * 1024 && !attr_set) {
+    static DeviceOnce attr_once;
+    if (pl.lds_bytes > 48 * 1024 && attr_once.needed()) {
         CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_once.mark();
     }
     // split count = exactly the number of workgroups the chip holds at once (registers + LDS): a larger grid would run a
     // second, partly empty round.  The plan's nsplit is the upper bound the workspace was sized for.

@@ -364,15 +364,13 @@ template <int POOLED>
 int launch_win(const cnn_conv2d_desc* d, WinParams& p, int grid, hipStream_t s, const char* name) {
     const bool dma16 = (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(p.x) % 16 == 0);
     const size_t lds_bytes = (size_t)kWaves * num_bufs(POOLED) * buf_floats(POOLED) * sizeof(float);
-    static bool attr_set[64][2] = {};  // (per template instance = per POOLED; indexed by device)
-    int dev = 0;
-    CNN_HIP_CHECK(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr_set[dev][dma16]) {
+    static DeviceOnce attr_once[2];  // (per template instance = per POOLED)
+    if (attr_once[dma16].needed()) {
         if (dma16)
             CNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<POOLED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         else
             CNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<POOLED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set[dev][dma16] = true;
+        attr_once[dma16].mark();
     }
     if (dma16)
         CNN_KLAUNCH(s, name, (conv_wgrad_win_kernel<POOLED, true><<<grid, kWaves * 64, lds_bytes, s>>>(p)), CONV_TAG(d));

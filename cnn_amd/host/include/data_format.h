@@ -67,7 +67,9 @@ public:
 private:
     struct ViewTag {};
     Tensor3D(ViewTag, int _C, int _H, int _W, data_type* dev_ptr, const std::string& _name);
-    bool owns_host = true;
+    // the host-side helpers below read `data`: a device view that has not been copied back yet is synced first (a Layer's
+    // output tensors are such views: softmax() on them, max(), print() ... just work)
+    void ensure_host() const;
 };
 using tensor = std::shared_ptr<Tensor3D>;
 

@@ -1,6 +1,8 @@
 // layers.cpp -- Conv2D / MaxPool2D / ReLU / LinearLayer with the reference's interface
 // (cpu/include/architectures.h:49-138); every body is a call into the C ABI of libcnn_amd.so.
 #include <cassert>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 
@@ -171,6 +173,13 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
         must(cnn_conv2d_autotune(&d0, stream), "cnn_conv2d_autotune");
     }
     assert(B <= batch && "batch larger than the first forward's (conv2d.cpp:47 has the same restriction)");
+    // shape-static like the reference (conv2d.cpp:47-60 caches its offsets on the first call): the buffers and the prepared
+    // filters were sized for the first input shape -- a different one would overrun DEVICE memory, so it is fatal here
+    if ((in_H && in_H != H) || (in_W && in_W != W) || input[0]->C != in_channels) {
+        std::fprintf(stderr, "cnn_amd host: %s: input %dx%dx%d after a first forward with %dx%dx%d (layers are shape-static)\n", name.c_str(),
+                     input[0]->C, H, W, in_channels, in_H, in_W);
+        std::abort();
+    }
     in_H = H;
     in_W = W;
     ensure_workspace(B, H, W);
@@ -319,6 +328,10 @@ std::vector<tensor> MaxPool2D::forward(const std::vector<tensor>& input) {
         batch = B;
     }
     assert(B <= batch);
+    if (in_C && (in_C != C || in_H != H || in_W != W)) {  // (the output / mask buffers were sized by the first shape)
+        std::fprintf(stderr, "cnn_amd host: %s: input shape changed after the first forward (layers are shape-static)\n", name.c_str());
+        std::abort();
+    }
     in_C = C; in_H = H; in_W = W;
     if (!no_grad && mask == nullptr)  // pool2d.cpp:23-31 (allocated lazily so a no_grad first call is not fatal)
         mask = (int*)dev_alloc(sizeof(int) * (size_t)batch * C * out_H * out_W);
@@ -376,6 +389,10 @@ std::vector<tensor> ReLU::forward(const std::vector<tensor>& input) {
         output = out_buf.views;
     }
     assert((size_t)B <= out_buf.views.size());
+    if (out_buf.sample_len != (size_t)input[0]->get_length()) {
+        std::fprintf(stderr, "cnn_amd host: %s: input shape changed after the first forward (layers are shape-static)\n", name.c_str());
+        std::abort();
+    }
     const data_type* x = batch_device_pointer(input, in_stage, name);
     must(cnn_relu_forward(x, out_buf.base, out_buf.sample_len * B, stream), "cnn_relu_forward");
     return output;
@@ -457,6 +474,10 @@ std::vector<tensor> BatchNorm2D::forward(const std::vector<tensor>& input) {
         batch = B;
     }
     assert(B <= batch);
+    if ((in_H && in_H != H) || (in_W && in_W != W)) {
+        std::fprintf(stderr, "cnn_amd host: %s: input shape changed after the first forward (layers are shape-static)\n", name.c_str());
+        std::abort();
+    }
     in_H = H;
     in_W = W;
     const size_t need = cnn_batchnorm2d_workspace_bytes(B, out_channels, H, W);

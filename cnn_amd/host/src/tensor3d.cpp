@@ -64,6 +64,7 @@ void Tensor3D::read_from_opencv_mat(const uchar* const img_ptr) {
 
 // data_format.cpp:85-105 without cv::Mat: saturate_cast<uchar>(255 * v) = round-to-nearest, clamped
 std::vector<uchar> Tensor3D::opecv_mat(const int CH) const {
+    ensure_host();
     const int length = H * W;
     std::vector<uchar> out((size_t)length * CH);
     auto sat = [](data_type v) {
@@ -75,15 +76,23 @@ std::vector<uchar> Tensor3D::opecv_mat(const int CH) const {
     return out;
 }
 
+void Tensor3D::ensure_host() const {
+    if (dev != nullptr && data == nullptr) const_cast<Tensor3D*>(this)->sync_to_host();
+}
+
 void Tensor3D::set_zero() {
     if (data) std::memset(data, 0, sizeof(data_type) * (size_t)get_length());
     if (dev) must(cnn_memset_zero(dev, sizeof(data_type) * (size_t)get_length(), architectures::stream), "cnn_memset_zero");
 }
 
-data_type Tensor3D::max() const { return data[argmax()]; }
+data_type Tensor3D::max() const {
+    ensure_host();
+    return data[argmax()];
+}
 
 // first maximum, strict '>' (data_format.cpp:37-48)
 int Tensor3D::argmax() const {
+    ensure_host();
     if (data == nullptr) return 0;
     const int length = get_length();
     int best = 0;
@@ -92,9 +101,13 @@ int Tensor3D::argmax() const {
     return best;
 }
 
-data_type Tensor3D::min() const { return data[argmin()]; }
+data_type Tensor3D::min() const {
+    ensure_host();
+    return data[argmin()];
+}
 
 int Tensor3D::argmin() const {
+    ensure_host();
     if (data == nullptr) return 0;
     const int length = get_length();
     int best = 0;
@@ -104,12 +117,14 @@ int Tensor3D::argmin() const {
 }
 
 void Tensor3D::div(const data_type times) {
+    ensure_host();
     const int length = get_length();
     for (int i = 0; i < length; ++i) data[i] /= times;
 }
 
 void Tensor3D::normalize(const std::vector<data_type> mean, const std::vector<data_type> std_div) {
     if (C != 3) return;
+    ensure_host();
     const int plane = H * W;
     for (int ch = 0; ch < C; ++ch)
         for (int i = 0; i < plane; ++i) data[ch * plane + i] = (data[ch * plane + i] - mean[ch]) / std_div[ch];
@@ -121,6 +136,7 @@ std::tuple<int, int, int> Tensor3D::get_shape() const { return std::make_tuple(C
 void Tensor3D::print_shape() const { std::cout << name << "  ==>  " << C << " x " << H << " x " << W << "\n"; }
 
 void Tensor3D::print(const int _C) const {
+    ensure_host();
     std::cout << name << "  content is : ";
     const int start = _C * H * W;
     for (int i = 0; i < H; ++i) {
@@ -131,6 +147,7 @@ void Tensor3D::print(const int _C) const {
 }
 
 std::shared_ptr<Tensor3D> Tensor3D::rot180() const {
+    ensure_host();
     std::shared_ptr<Tensor3D> rot(new Tensor3D(C, H, W, name + "_rot180"));
     const int plane = H * W;
     for (int c = 0; c < C; ++c)
@@ -139,6 +156,7 @@ std::shared_ptr<Tensor3D> Tensor3D::rot180() const {
 }
 
 std::shared_ptr<Tensor3D> Tensor3D::pad(const int padding) const {
+    ensure_host();
     const int nW = W + 2 * padding, nH = H + 2 * padding;
     std::shared_ptr<Tensor3D> padded(new Tensor3D(C, nH, nW, name + "_pad"));
     std::memset(padded->data, 0, sizeof(data_type) * (size_t)C * nH * nW);
