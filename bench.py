@@ -201,6 +201,43 @@ def cpu_baseline_stack(name, budget_s=25.0):
                       f"without FMA like cpu/CMakeLists.txt:5"}
 
 
+def staged_input_bench(torch, capi, args):
+    """the host-buffer variant of the boundary (the reference's DataLoader hands over host tensors, pipeline.cpp:129-140): every
+    step's batch is uploaded from a pinned slot by the double-buffered stager while the previous step computes"""
+    import numpy as np
+
+    from cnn_amd import hostapi
+
+    B = args.batch or 256
+    hostapi.load().cnnh_set_fuse_pool_block(1)
+    net = hostapi.HostAlexNet(3)
+    rs = np.random.RandomState(1234)
+    net.set_params((rs.standard_normal(net.n_params) * 0.1).astype(np.float32))
+    labels = (torch.arange(B, device="cuda") % 3).to(torch.int32)
+    nbytes = B * 3 * 224 * 224 * 4
+    stager = capi.BatchStager(nbytes, depth=2)
+    for _ in range(2):  # synthetic images in both pinned slots (a real loader would decode into them)
+        host, slot = stager.acquire()
+        host[:] = rs.rand(host.size).astype(np.float32)
+        stager.submit(slot)
+
+    def step():
+        host, slot = stager.acquire()   # (the producer would fill `host` here)
+        dev = stager.submit(slot)       # H2D on the copy stream
+        stager.wait(slot)               # the compute stream waits for it
+        net.train_step_ptr(dev, labels, B, 224, 224, 1e-3)
+        stager.release(slot)
+
+    el = timed_steps(torch, step, torch.cuda.synchronize, args.steps, args.warmup)
+    loss = net.last_loss()
+    stager.close()
+    net.close()
+    hostapi.load().cnnh_set_fuse_pool_block(0)
+    return {"value": round(B * args.steps / el, 1), "unit": "images/sec", "ms_per_step": round(el / args.steps * 1e3, 4),
+            "h2d_GBps": round(nbytes * args.steps / el / 1e9, 1), "final_loss": round(loss, 5),
+            "note": "every batch uploaded from pinned host memory (cnn_batch_stager_*, 2 slots, copy stream overlapped with compute)"}
+
+
 def init_comm(capi, torch, dist, world, rank):
     """the data path's exchange (cnn_amd.dp.RcclComm: C ABI -> RCCL), checked once against torch.distributed's own all-reduce"""
     from cnn_amd.dp import RcclComm
@@ -301,6 +338,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-ns", action="store_true")
     ap.add_argument("--no-layer-api", action="store_true", help="skip the extra C++ Layer API legs of the default config")
+    ap.add_argument("--staged-input", action="store_true",
+                    help="also time the reference net with every batch coming from (pinned) HOST memory through cnn_batch_stager_* "
+                         "-- the PCIe-inclusive rate, reported beside `value`, never as it")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
     args = ap.parse_args()
     small = args.config == "alexnet"
@@ -437,6 +477,8 @@ def main():
                 r2["close"]()
                 del r2
                 torch.cuda.empty_cache()
+        if small and args.staged_input:
+            out["pcie_inclusive"] = staged_input_bench(torch, capi, args)
         if small and not args.no_conv_ns:
             out["conv_ns"] = conv_ns_bench(torch, capi)
         if not args.no_cpu_baseline:

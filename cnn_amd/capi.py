@@ -70,6 +70,14 @@ SIGNATURES = {
     "cnn_maxpool2d_backward_relu": (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 6 + [_P]),
     "cnn_relu_forward": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "cnn_relu_backward": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "cnn_dropout_forward": (C.c_int, [_P, _P] + [C.c_int] * 6 + [C.c_float, _P]),
+    "cnn_dropout_backward": (C.c_int, [_P] + [C.c_int] * 5 + [_P]),
+    "cnn_batch_stager_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.c_int]),
+    "cnn_batch_stager_destroy": (C.c_int, [_P]),
+    "cnn_batch_stager_acquire": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "cnn_batch_stager_submit": (C.c_int, [_P, C.c_int, C.POINTER(C.c_void_p)]),
+    "cnn_batch_stager_wait": (C.c_int, [_P, C.c_int, _P]),
+    "cnn_batch_stager_release": (C.c_int, [_P, C.c_int, _P]),
     "cnn_linear_forward": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "cnn_linear_backward": (C.c_int, [_P] * 6 + [C.c_int] * 3 + [C.c_float, _P]),
     "cnn_linear_backward_relu": (C.c_int, [_P] * 6 + [C.c_int] * 3 + [C.c_float, _P]),
@@ -586,3 +594,59 @@ def kernel_timing_report():
 def side_stream_join():
     """order the library's side stream (deferred weight gradients) before the current stream"""
     check(load().cnn_amd_side_stream_join(_stream()), "cnn_amd_side_stream_join")
+
+
+class BatchStager:
+    """cnn_batch_stager_*: `depth` pinned host slots + device buffers, uploads on a copy stream of its own, ordered by events"""
+
+    def __init__(self, batch_bytes, depth=2):
+        self.lib = load()
+        self.h = C.c_void_p()
+        self.bytes = int(batch_bytes)
+        check(self.lib.cnn_batch_stager_create(C.byref(self.h), self.bytes, depth), "cnn_batch_stager_create")
+
+    def acquire(self):
+        """-> (numpy float32 view of the pinned slot to fill, slot index); blocks until the slot is free"""
+        import numpy as np
+
+        host, slot = C.c_void_p(), C.c_int()
+        check(self.lib.cnn_batch_stager_acquire(self.h, C.byref(host), C.byref(slot)), "cnn_batch_stager_acquire")
+        buf = (C.c_float * (self.bytes // 4)).from_address(host.value)
+        return np.ctypeslib.as_array(buf), slot.value
+
+    def submit(self, slot):
+        """enqueue the upload; -> device pointer (int) of the slot's device buffer"""
+        dev = C.c_void_p()
+        check(self.lib.cnn_batch_stager_submit(self.h, slot, C.byref(dev)), "cnn_batch_stager_submit")
+        return dev.value
+
+    def wait(self, slot):
+        check(self.lib.cnn_batch_stager_wait(self.h, slot, _stream()), "cnn_batch_stager_wait")
+
+    def release(self, slot):
+        check(self.lib.cnn_batch_stager_release(self.h, slot, _stream()), "cnn_batch_stager_release")
+
+    def close(self):
+        if self.h:
+            self.lib.cnn_batch_stager_destroy(self.h)
+            self.h = None
+
+
+def dropout_forward(x, p, training=True, y=None):
+    """Dropout::forward (dropout.cpp:7-55): channels 0 .. int(p*C)-1 zeroed in training, x * (1-p) otherwise"""
+    import torch
+
+    _need_gpu(x, y)
+    B, Cc, H, W = x.shape
+    if y is None:
+        y = torch.empty_like(x)
+    check(load().cnn_dropout_forward(_ptr(x), _ptr(y), B, Cc, H, W, int(p * Cc), 1 if training else 0, 1.0 - p, _stream()), "cnn_dropout_forward")
+    return y
+
+
+def dropout_backward(dy, p):
+    """in place on dy (dropout.cpp:57-69)"""
+    _need_gpu(dy)
+    B, Cc, H, W = dy.shape
+    check(load().cnn_dropout_backward(_ptr(dy), B, Cc, H, W, int(p * Cc), _stream()), "cnn_dropout_backward")
+    return dy

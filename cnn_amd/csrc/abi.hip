@@ -237,4 +237,88 @@ int cnn_host_free_pinned(void* ptr) {
     return CNN_AMD_OK;
 }
 
+// ---- input staging -------------------------------------------------------------------------------------------------
+namespace {
+struct Stager {
+    size_t bytes = 0;
+    int depth = 0, next = 0;
+    hipStream_t copy = nullptr;
+    std::vector<void*> host, dev;
+    std::vector<hipEvent_t> uploaded, consumed;
+    std::vector<char> in_use;  // consumed[i] has been recorded at least once
+};
+}  // namespace
+
+int cnn_batch_stager_create(void** stager, size_t batch_bytes, int depth) {
+    CNN_REQUIRE(stager && batch_bytes > 0 && depth >= 2 && depth <= 16, "cnn_batch_stager_create: bad arguments (depth 2..16)");
+    Stager* st = new Stager();
+    st->bytes = batch_bytes;
+    st->depth = depth;
+    st->host.assign(depth, nullptr); st->dev.assign(depth, nullptr);
+    st->uploaded.assign(depth, nullptr); st->consumed.assign(depth, nullptr);
+    st->in_use.assign(depth, 0);
+    *stager = st;
+    CNN_HIP_CHECK(hipStreamCreateWithFlags(&st->copy, hipStreamNonBlocking));
+    for (int i = 0; i < depth; ++i) {
+        CNN_HIP_CHECK(hipHostMalloc(&st->host[i], batch_bytes, hipHostMallocDefault));
+        CNN_HIP_CHECK(hipMalloc(&st->dev[i], batch_bytes));
+        CNN_HIP_CHECK(hipEventCreateWithFlags(&st->uploaded[i], hipEventDisableTiming));
+        CNN_HIP_CHECK(hipEventCreateWithFlags(&st->consumed[i], hipEventDisableTiming));
+    }
+    return CNN_AMD_OK;
+}
+
+int cnn_batch_stager_destroy(void* stager) {
+    Stager* st = static_cast<Stager*>(stager);
+    if (!st) return CNN_AMD_OK;
+    if (st->copy) (void)hipStreamSynchronize(st->copy);
+    for (int i = 0; i < st->depth; ++i) {
+        if (st->host[i]) (void)hipHostFree(st->host[i]);
+        if (st->dev[i]) (void)hipFree(st->dev[i]);
+        if (st->uploaded[i]) (void)hipEventDestroy(st->uploaded[i]);
+        if (st->consumed[i]) (void)hipEventDestroy(st->consumed[i]);
+    }
+    if (st->copy) (void)hipStreamDestroy(st->copy);
+    delete st;
+    return CNN_AMD_OK;
+}
+
+int cnn_batch_stager_acquire(void* stager, void** pinned_host, int* slot) {
+    Stager* st = static_cast<Stager*>(stager);
+    CNN_REQUIRE(st && pinned_host && slot, "cnn_batch_stager_acquire: null pointer");
+    const int i = st->next;
+    st->next = (st->next + 1) % st->depth;
+    // the previous upload out of this slot must have left the host buffer, and its consumer must be done with the device one
+    CNN_HIP_CHECK(hipEventSynchronize(st->uploaded[i]));
+    if (st->in_use[i]) CNN_HIP_CHECK(hipEventSynchronize(st->consumed[i]));
+    *pinned_host = st->host[i];
+    *slot = i;
+    return CNN_AMD_OK;
+}
+
+int cnn_batch_stager_submit(void* stager, int slot, void** device_ptr) {
+    Stager* st = static_cast<Stager*>(stager);
+    CNN_REQUIRE(st && device_ptr && slot >= 0 && slot < st->depth, "cnn_batch_stager_submit: bad arguments");
+    if (st->in_use[slot]) CNN_HIP_CHECK(hipStreamWaitEvent(st->copy, st->consumed[slot], 0));
+    CNN_HIP_CHECK(hipMemcpyAsync(st->dev[slot], st->host[slot], st->bytes, hipMemcpyHostToDevice, st->copy));
+    CNN_HIP_CHECK(hipEventRecord(st->uploaded[slot], st->copy));
+    *device_ptr = st->dev[slot];
+    return CNN_AMD_OK;
+}
+
+int cnn_batch_stager_wait(void* stager, int slot, void* stream) {
+    Stager* st = static_cast<Stager*>(stager);
+    CNN_REQUIRE(st && slot >= 0 && slot < st->depth, "cnn_batch_stager_wait: bad arguments");
+    CNN_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), st->uploaded[slot], 0));
+    return CNN_AMD_OK;
+}
+
+int cnn_batch_stager_release(void* stager, int slot, void* stream) {
+    Stager* st = static_cast<Stager*>(stager);
+    CNN_REQUIRE(st && slot >= 0 && slot < st->depth, "cnn_batch_stager_release: bad arguments");
+    CNN_HIP_CHECK(hipEventRecord(st->consumed[slot], as_stream(stream)));
+    st->in_use[slot] = 1;
+    return CNN_AMD_OK;
+}
+
 }  // extern "C"

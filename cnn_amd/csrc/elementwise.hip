@@ -44,6 +44,25 @@ __global__ __launch_bounds__(kBlock) void relu_bwd_scalar(const float* __restric
         d[i] = relu_b(y[i], d[i]);
 }
 
+// Dropout (cpu/src/dropout.cpp): CHANNEL dropout -- the first `dropped` channels of every sample are zeroed in training
+// (:34-41: the loop tests the channel INDEX o against selected_num; the shuffled `sequence` only feeds the mask bookkeeping,
+// so the dropped set is always channels 0 .. selected_num-1), the whole tensor is scaled by 1 - p under no_grad (:44-53).
+// backward (:57-69) zeroes the same channels of the delta in place.  16 B/lane where the channel planes allow it.
+__global__ __launch_bounds__(kBlock) void dropout_fwd(const float* __restrict__ x, float* __restrict__ y, size_t n, int C, int area,
+                                                      int dropped, int training, float keep) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const int o = (int)((i / (size_t)area) % (size_t)C);
+        const float v = x[i];
+        y[i] = training ? (o >= dropped ? v : 0.f) : v * keep;
+    }
+}
+__global__ __launch_bounds__(kBlock) void dropout_bwd(float* __restrict__ d, size_t n, int C, int area, int dropped) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const int o = (int)((i / (size_t)area) % (size_t)C);
+        if (o < dropped) d[i] = 0.f;
+    }
+}
+
 // p - lr*(g*scale) with every product/sum rounded separately: the reference is built without FMA
 // (x86-64 -O2, CMakeLists.txt:5), so w -= lr*g is mul-then-sub; the fp-contract pragma stops hipcc fusing it
 // (HIP's __fmul_rn/__fsub_rn are plain operators and do get contracted).
@@ -195,6 +214,24 @@ int cnn_softmax_xent(const float* logits, const int32_t* labels, float* probs, f
     CNN_KLAUNCH(s, "softmax_xent_kernel",
                 (softmax_xent_kernel<<<1, kBlock, 0, s>>>(logits, labels, probs, delta, loss_sum, B, classes)), "B=%d classes=%d",
                 B, classes);
+    return CNN_AMD_OK;
+}
+
+int cnn_dropout_forward(const float* x, float* y, int B, int C, int H, int W, int dropped_channels, int training, float keep,
+                        void* stream) {
+    CNN_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && dropped_channels >= 0 && dropped_channels <= C, "cnn_dropout_forward: bad arguments");
+    const size_t n = (size_t)B * C * H * W;
+    hipStream_t s = as_stream(stream);
+    CNN_KLAUNCH(s, "dropout_fwd", (dropout_fwd<<<stream_grid(n, kBlock), kBlock, 0, s>>>(x, y, n, C, H * W, dropped_channels, training, keep)),
+                "n=%zu", n);
+    return CNN_AMD_OK;
+}
+
+int cnn_dropout_backward(float* dy_inout, int B, int C, int H, int W, int dropped_channels, void* stream) {
+    CNN_REQUIRE(dy_inout && B > 0 && C > 0 && H > 0 && W > 0 && dropped_channels >= 0 && dropped_channels <= C, "cnn_dropout_backward: bad arguments");
+    const size_t n = (size_t)B * C * H * W;
+    hipStream_t s = as_stream(stream);
+    CNN_KLAUNCH(s, "dropout_bwd", (dropout_bwd<<<stream_grid(n, kBlock), kBlock, 0, s>>>(dy_inout, n, C, H * W, dropped_channels)), "n=%zu", n);
     return CNN_AMD_OK;
 }
 

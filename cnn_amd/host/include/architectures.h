@@ -259,6 +259,26 @@ public:
     void bind_arena(data_type* params_dev, data_type* grads_dev) override;
 };
 
+// architectures.h:177-191 / dropout.cpp: CHANNEL dropout.  The reference keeps it out of its network (alexnet.cpp:28, "poor at
+// test time", README.md:16) but ships the layer; same constructor, generator (seed 1314) and bookkeeping.  Training zeroes the
+// first int(p * C) channels of every sample (dropout.cpp:34-41 tests the channel index, the shuffled sequence only fills the
+// mask), no_grad scales by 1 - p; backward zeroes the same channels of the delta in place and hands it back.
+class Dropout : public Layer {
+private:
+    data_type p;
+    int selected_num = 0;
+    std::vector<int> sequence;
+    std::default_random_engine drop;
+    std::vector<int> mask;
+    BatchBuffer out_buf, in_stage, delta_stage;
+    int in_C = 0, in_H = 0, in_W = 0;
+
+public:
+    Dropout(std::string _name, const data_type _p = 0.5) : Layer(_name), p(_p), drop(1314) {}
+    std::vector<tensor> forward(const std::vector<tensor>& input) override;
+    std::vector<tensor> backward(std::vector<tensor>& delta) override;
+};
+
 // The reference's model container is a strictly sequential std::list<std::shared_ptr<Layer>> (architectures.h:200) that
 // forward walks front to back (alexnet.cpp:41-42), backward back to front (:53-55), update / save / load front to back
 // (:63-64, :73-74, :86-87).  Sequential is that container for ANY layer list (the reference hard-wires one list in

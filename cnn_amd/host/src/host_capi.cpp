@@ -3,6 +3,7 @@
 // cross_entroy_backward) from Python.  Not part of the drop-in boundary (that is include/cnn_amd.h).
 #include <cstring>
 #include <filesystem>
+#include <map>
 #include <vector>
 
 #include "architectures.h"
@@ -19,6 +20,7 @@ struct Handle {
     int in_C = 3;
     std::vector<tensor> host_input;     // B host tensors the caller's images are copied into (cnn.cpp's DataLoader role)
     std::vector<tensor> device_input;   // zero-copy views of a caller-owned contiguous device batch
+    std::map<const float*, std::vector<tensor> > device_inputs;  // ... one set per batch buffer (a staged input alternates between a few)
     std::vector<tensor> last_output;
 };
 std::vector<tensor>& host_batch(Handle* h, int B, int C, int H, int W) {
@@ -60,6 +62,7 @@ void cnnh_seq_add_conv(void* hv, const char* name, int ci, int co, int k, int st
     ((Handle*)hv)->net->add(new Conv2D(name, ci, co, k, stride, pad));
 }
 void cnnh_seq_add_bn(void* hv, const char* name, int channels) { ((Handle*)hv)->net->add(new BatchNorm2D(name, channels)); }
+void cnnh_seq_add_dropout(void* hv, const char* name, float p) { ((Handle*)hv)->net->add(new Dropout(name, p)); }
 void cnnh_seq_add_relu(void* hv, const char* name) { ((Handle*)hv)->net->add(new ReLU(name)); }
 void cnnh_seq_add_pool(void* hv, const char* name, int k, int step) { ((Handle*)hv)->net->add(new MaxPool2D(name, k, step)); }
 void cnnh_seq_add_linear(void* hv, const char* name, int n_in, int n_out) { ((Handle*)hv)->net->add(new LinearLayer(name, n_in, n_out)); }
@@ -182,13 +185,13 @@ float cnnh_net_train_step_device(void* hv, float* x_dev, const int* labels, int 
 // labels_dev int32 [B] on the device.  cnnh_net_last_loss fetches the loss of the latest step (synchronises).
 void cnnh_net_train_step_device_loss(void* hv, float* x_dev, const int* labels_dev, int B, int H, int W, float lr) {
     Handle* h = (Handle*)hv;
-    if ((int)h->device_input.size() != B || h->device_input[0]->dev != x_dev) {
-        h->device_input.clear();
+    auto& views = h->device_inputs[x_dev];
+    if ((int)views.size() != B) {
+        views.clear();
         const size_t len = (size_t)h->in_C * H * W;
-        for (int b = 0; b < B; ++b)
-            h->device_input.emplace_back(Tensor3D::device_view(h->in_C, H, W, x_dev + len * b, "input_" + std::to_string(b)));
+        for (int b = 0; b < B; ++b) views.emplace_back(Tensor3D::device_view(h->in_C, H, W, x_dev + len * b, "input_" + std::to_string(b)));
     }
-    h->net->train_step(h->device_input, labels_dev, lr);
+    h->net->train_step(views, labels_dev, lr);
 }
 float cnnh_net_last_loss(void* hv) { return ((Handle*)hv)->net->last_loss(); }
 void cnnh_net_update(void* hv, float lr, float grad_scale) { ((Handle*)hv)->net->update_gradients(lr, grad_scale); }

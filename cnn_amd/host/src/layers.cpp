@@ -1,5 +1,6 @@
 // layers.cpp -- Conv2D / MaxPool2D / ReLU / LinearLayer with the reference's interface
 // (cpu/include/architectures.h:49-138); every body is a call into the C ABI of libcnn_amd.so.
+#include <algorithm>
 #include <cassert>
 #include <cstdio>
 #include <cstdlib>
@@ -572,6 +573,51 @@ void BatchNorm2D::load_weights(std::ifstream& reader) {
     reader.read(reinterpret_cast<char*>(host.data()), static_cast<std::streamsize>(sizeof(data_type) * host.size()));
     must(cnn_memcpy_h2d(params, host.data(), sizeof(data_type) * host.size(), stream), "cnn_memcpy_h2d");
     must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Dropout (dropout.cpp)
+std::vector<tensor> Dropout::forward(const std::vector<tensor>& input) {
+    const int B = (int)input.size();
+    const int C = input[0]->C, H = input[0]->H, W = input[0]->W;
+    if (sequence.empty()) {  // dropout.cpp:13-23
+        sequence.assign(C, 0);
+        for (int o = 0; o < C; ++o) sequence[o] = o;
+        selected_num = int(p * C);
+        assert(C > selected_num);
+        mask.assign(C, 0);
+        out_buf.allocate(B, C, H, W, name + "_output");
+        output = out_buf.views;
+        in_C = C; in_H = H; in_W = W;
+    }
+    assert((size_t)B <= out_buf.views.size() && C == in_C && H == in_H && W == in_W);
+    std::shuffle(sequence.begin(), sequence.end(), drop);  // dropout.cpp:26 (the draw happens in both modes)
+    if (!no_grad)
+        for (int i = 0; i < C; ++i) mask[i] = i >= selected_num ? sequence[i] : -1;  // dropout.cpp:31-33
+    const data_type* x = batch_device_pointer(input, in_stage, name);
+    must(cnn_dropout_forward(x, out_buf.base, B, C, H, W, selected_num, no_grad ? 0 : 1, 1 - p, stream), "cnn_dropout_forward");
+    return output;
+}
+
+// dropout.cpp:57-69: in place on the caller's delta
+std::vector<tensor> Dropout::backward(std::vector<tensor>& delta) {
+    const int B = (int)delta.size();
+    const bool in_place = delta[0]->on_device();
+    data_type* d = batch_device_pointer_mut(delta, delta_stage, name + "_dy");
+    int dropped = 0;
+    for (int o = 0; o < in_C; ++o) dropped += mask[o] == -1;  // (= selected_num after a training forward, 0 before any)
+    must(cnn_dropout_backward(d, B, in_C, in_H, in_W, dropped, stream), "cnn_dropout_backward");
+    if (!in_place || d == delta_stage.base) {  // host (or scattered) deltas were staged: write the result back
+        const size_t len = out_buf.sample_len;
+        for (int b = 0; b < B; ++b) {
+            if (delta[b]->on_device())
+                must(cnn_memcpy_d2d(delta[b]->dev, d + len * b, sizeof(data_type) * len, stream), "cnn_memcpy_d2d");
+            else
+                must(cnn_memcpy_d2h(delta[b]->data, d + len * b, sizeof(data_type) * len, stream), "cnn_memcpy_d2h");
+        }
+        must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+    }
+    return delta;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -20,6 +20,7 @@ SIGNATURES = {
     "cnnh_seq_add_conv": (None, [C.c_void_p, C.c_char_p] + [C.c_int] * 5),
     "cnnh_seq_add_bn": (None, [C.c_void_p, C.c_char_p, C.c_int]),
     "cnnh_seq_add_relu": (None, [C.c_void_p, C.c_char_p]),
+    "cnnh_seq_add_dropout": (None, [C.c_void_p, C.c_char_p, C.c_float]),
     "cnnh_seq_add_pool": (None, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "cnnh_seq_add_linear": (None, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "cnnh_seq_finalize": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -163,6 +164,10 @@ class HostNet:
         self.lib.cnnh_net_train_step_device_loss(self.h, C.c_void_p(x_dev.data_ptr()), C.c_void_p(labels_dev.data_ptr()), B, H, W,
                                                  float(lr))
 
+    def train_step_ptr(self, x_ptr, labels_dev, B, H, W, lr):
+        """train_step on a raw device pointer (e.g. a capi.BatchStager slot)"""
+        self.lib.cnnh_net_train_step_device_loss(self.h, C.c_void_p(x_ptr), C.c_void_p(labels_dev.data_ptr()), B, H, W, float(lr))
+
     def last_loss(self):
         return float(self.lib.cnnh_net_last_loss(self.h))
 
@@ -199,6 +204,8 @@ def _layer_names(spec):
         elif kind == "pool":
             n_pool += 1
             names.append(f"max_pool_{n_pool}")
+        elif kind == "dropout":
+            names.append(f"dropout_layer_{n_conv}")
         else:
             n_lin += 1
             names.append(f"linear_{n_lin}")
@@ -227,6 +234,8 @@ class HostSequential(HostNet):
                 self.lib.cnnh_seq_add_relu(h, nm)
             elif item[0] == "pool":
                 self.lib.cnnh_seq_add_pool(h, nm, item[1], item[2])
+            elif item[0] == "dropout":
+                self.lib.cnnh_seq_add_dropout(h, nm, float(item[1]))
             else:
                 self.lib.cnnh_seq_add_linear(h, nm, ent["n_in"], ent["n_out"])
         p = C.c_void_p(params.data_ptr()) if params is not None else None

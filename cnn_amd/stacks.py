@@ -7,6 +7,7 @@ A spec is a list of tuples
     ("bn",)                        BatchNorm2D(name, C)                        architectures.h:167
     ("relu",)                      ReLU(name)                                  architectures.h:109
     ("pool", k, step)              MaxPool2D(name, k, step)                    architectures.h:96
+    ("dropout", p)                 Dropout(name, p)                            architectures.h:188
     ("linear", out)                LinearLayer(name, C*H*W, out)               architectures.h:131
 Channel / spatial sizes follow from the input shape (walk()).
 """
@@ -93,6 +94,8 @@ def walk(spec, C=3, H=224, W=224):
             ent.update(params=4 * C)
         elif kind == "relu":
             ent.update(params=0)
+        elif kind == "dropout":
+            ent.update(p=item[1], params=0)
         elif kind == "pool":
             _, k, st = item
             ent.update(k=k, step=st, params=0)

@@ -169,6 +169,14 @@ int cnn_relu_forward(const float* x, float* y, size_t n, void* stream);
 /* relu.cpp:35-40: dy = (y <= 0) ? 0 : dy, IN PLACE on the caller's delta */
 int cnn_relu_backward(const float* y, float* dy_inout, size_t n, void* stream);
 
+/* ---- Dropout : dropout.cpp (row n4 of SURVEY.md 8f; the reference keeps it out of its net, alexnet.cpp:28) -------------
+ * Channel dropout as the reference implements it: training (dropout.cpp:34-41) zeroes channels 0 .. dropped_channels-1 of every
+ * sample (dropped_channels = int(p * C), :18; the shuffled sequence never reaches the data path) and copies the rest; under
+ * no_grad (:44-53) y = x * keep with keep = 1 - p.  backward (:57-69) zeroes the same channels of the delta IN PLACE. */
+int cnn_dropout_forward(const float* x, float* y, int B, int C, int H, int W, int dropped_channels, int training, float keep,
+                        void* stream);
+int cnn_dropout_backward(float* dy_inout, int B, int C, int H, int W, int dropped_channels, void* stream);
+
 /* ---- LinearLayer : linear.cpp ---------------------------------------------------------------------- */
 /* linear.cpp:33-43: y[b][j] = (sum_i x[b][i]*W[i*out+j]) + bias[j] */
 int cnn_linear_forward(const float* x, const float* w, const float* bias, float* y, int B, int in, int out,
@@ -323,6 +331,22 @@ int cnn_event_create(void** event);
 int cnn_event_destroy(void* event);
 int cnn_event_record(void* event, void* stream);
 int cnn_stream_wait_event(void* stream, void* event);
+/* ---- input staging (row n4: what DataLoader::generate_batch's host buffers -- pipeline.cpp:112-140 -- need in front of a device
+ * consumer).  A stager owns `depth` (>= 2) page-locked host slots and as many device buffers of batch_bytes each, a copy stream
+ * and the events that order producer -> H2D -> consumer -> producer:
+ *   acquire(&host, &slot)   the pinned slot to fill next; BLOCKS (host) until the consumer released it from its previous use
+ *   submit(slot, &dev)      enqueue the H2D copy of that slot on the stager's own stream; dev = its device buffer
+ *   wait(slot, stream)      make `stream` wait for that copy (enqueue only)
+ *   release(slot, stream)   `stream` is done reading the device buffer: the slot may be overwritten once it gets there
+ * so that the upload of batch i+1 overlaps the kernels of batch i.  A batch of 256 x 3 x 224 x 224 floats is 154 MB: ~2.4 ms
+ * over PCIe Gen5 x16, i.e. the PCIe-inclusive ceiling of the reference net is ~10^5 images/s per GPU (bench.py --staged-input). */
+int cnn_batch_stager_create(void** stager, size_t batch_bytes, int depth);
+int cnn_batch_stager_destroy(void* stager);
+int cnn_batch_stager_acquire(void* stager, void** pinned_host, int* slot);
+int cnn_batch_stager_submit(void* stager, int slot, void** device_ptr);
+int cnn_batch_stager_wait(void* stager, int slot, void* stream);
+int cnn_batch_stager_release(void* stager, int slot, void* stream);
+
 /* page-locked host memory (async H2D / D2H copies are only asynchronous from / to pinned buffers) */
 int cnn_host_alloc_pinned(void** ptr, size_t bytes);
 int cnn_host_free_pinned(void* ptr);

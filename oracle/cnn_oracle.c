@@ -255,6 +255,31 @@ void SUF(oracle_relu_backward)(const real* y, real* dy, size_t n) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Dropout  (cpu/src/dropout.cpp) -- channel dropout; commented out of the reference net (alexnet.cpp:28)
+ * ---------------------------------------------------------------------------------------- */
+
+/* dropout.cpp:7-55.  selected_num = int(p * C) (:18).  Training (:30-41): the loop tests the channel INDEX o against
+ * selected_num -- channels o >= selected_num are copied, the others zeroed; the shuffled `sequence` (:26) only fills `mask`
+ * (:33) and never selects data, so the dropped set is always channels 0 .. selected_num-1.  no_grad (:44-53): y = x * (1 - p). */
+void SUF(oracle_dropout_forward)(const real* x, real* y, int B, int C, int area, real p, int training) {
+    const int selected = (int)(p * C);
+    const real prob = 1 - p;
+    for (int b = 0; b < B; ++b)
+        for (int o = 0; o < C; ++o) {
+            const real* src = x + ((size_t)b * C + o) * area;
+            real* dst = y + ((size_t)b * C + o) * area;
+            for (int i = 0; i < area; ++i) dst[i] = training ? (o >= selected ? src[i] : 0) : src[i] * prob;
+        }
+}
+
+/* dropout.cpp:57-69: channels with mask[o] == -1 (o < selected_num, :33) get a zero delta, in place */
+void SUF(oracle_dropout_backward)(real* dy, int B, int C, int area, real p) {
+    const int selected = (int)(p * C);
+    for (int b = 0; b < B; ++b)
+        for (int o = 0; o < selected; ++o) memset(dy + ((size_t)b * C + o) * area, 0, sizeof(real) * (size_t)area);
+}
+
+/* ------------------------------------------------------------------------------------------
  * LinearLayer  (cpu/src/linear.cpp); W stored [in][out] row-major (linear.cpp:40)
  * ---------------------------------------------------------------------------------------- */
 

@@ -49,6 +49,8 @@ def _declare(L):
         sig("oracle_maxpool_backward", None, P, IP, P, I, I, I, I, I, I)
         sig("oracle_relu_forward", None, P, P, C.c_size_t)
         sig("oracle_relu_backward", None, P, P, C.c_size_t)
+        sig("oracle_dropout_forward", None, P, P, I, I, I, real, I)
+        sig("oracle_dropout_backward", None, P, I, I, I, real)
         sig("oracle_linear_forward", None, P, P, P, P, I, I, I)
         sig("oracle_linear_backward", None, P, P, P, P, P, P, I, I, I)
         sig("oracle_batchnorm_forward", None, P, P, P, P, P, P, P, P, P, I, I, I, I, real, real, I)
@@ -176,6 +178,23 @@ def relu_backward(y, dy, f64=False):
     dy = np.array(dy, dtype=dt, order="C", copy=True)
     getattr(lib(), "oracle_relu_backward" + suf)(_p(y, ct), _p(dy, ct), y.size)
     return dy
+
+
+def dropout_forward(x, p, training=True, f64=False):
+    dt, ct, suf = _dt(f64)
+    x = _c(x, dt)
+    B, Cc, H, W = x.shape
+    y = np.empty_like(x)
+    getattr(lib(), "oracle_dropout_forward" + suf)(_p(x, ct), _p(y, ct), B, Cc, H * W, ct(p), 1 if training else 0)
+    return y
+
+
+def dropout_backward(dy, p, f64=False):
+    dt, ct, suf = _dt(f64)
+    d = np.array(dy, dtype=dt, order="C", copy=True)
+    B, Cc, H, W = d.shape
+    getattr(lib(), "oracle_dropout_backward" + suf)(_p(d, ct), B, Cc, H * W, ct(p))
+    return d
 
 
 def linear_forward(x, w, bias, f64=False):
@@ -443,6 +462,8 @@ class SeqNet:
                 ent.update(n=4 * C_)
             elif kind == "relu":
                 ent.update(n=0)
+            elif kind == "dropout":
+                ent.update(p=item[1], n=0)
             elif kind == "pool":
                 _, k, st = item
                 ent.update(k=k, step=st, n=0)
@@ -491,6 +512,8 @@ class SeqNet:
                 cur = y
             elif k == "relu":
                 cur = relu_forward(cur, f64=f64)
+            elif k == "dropout":
+                cur = dropout_forward(cur, e["p"], training=training, f64=f64)
             elif k == "pool":
                 cur, aux = maxpool_forward(cur, e["k"], e["step"], f64=f64)
             else:
@@ -523,6 +546,8 @@ class SeqNet:
                 gw, gb, d = linear_backward(xin.reshape(xin.shape[0], ni), d, p[: ni * no].reshape(ni, no), f64=f64)
                 self._p(e, g)[: ni * no], self._p(e, g)[ni * no :] = gw.ravel(), gb
                 d = d.reshape(xin.shape)
+            elif k == "dropout":
+                d = dropout_backward(d, e["p"], f64=f64)
             elif k == "relu":
                 d = relu_backward(masks_from.get(idx, self.acts[idx]), d, f64=f64)
             elif k == "pool":

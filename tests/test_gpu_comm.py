@@ -120,3 +120,27 @@ def test_two_replicas_of_the_cpp_container_equal_the_full_batch_step(T):
     assert np.array_equal(results[0], results[1]), "replicas diverged"
     err = np.abs(results[0] - want).max() / np.abs(want).max()
     assert err <= 1e-5, err
+
+
+def test_batch_stager_orders_producer_upload_and_consumer(T):
+    """cnn_batch_stager_* (row n4): pinned slots uploaded on the stager's copy stream arrive intact, in order, while the consumer
+    of the previous batch is still running; a slot is not handed back to the producer before its consumer released it"""
+    from cnn_amd import capi
+
+    n = 1 << 20
+    stager = capi.BatchStager(n * 4, depth=2)
+    outs = []
+    for i in range(7):
+        host, slot = stager.acquire()
+        host[:] = np.arange(n, dtype=np.float32) * 0.5 - i  # negative for i > 0: ReLU makes the consumer's result data-dependent
+        dev = stager.submit(slot)
+        stager.wait(slot)
+        y = T.empty(n, device="cuda")
+        capi.check(capi.load().cnn_relu_forward(dev, capi._ptr(y), n, capi._stream()), "cnn_relu_forward")
+        stager.release(slot)
+        outs.append(y)
+    T.cuda.synchronize()
+    for i, y in enumerate(outs):
+        want = np.maximum(np.arange(n, dtype=np.float32) * 0.5 - i, 0)
+        assert np.array_equal(y.cpu().numpy(), want), i
+    stager.close()

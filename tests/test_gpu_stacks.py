@@ -201,3 +201,38 @@ def test_stack_layers_full_batch_mfma_equals_im2col(T, case):
     gwr, gbr = conv.backward_weight_im2col(x, dy, float(B))
     assert err(gw, gwr) <= REL_TOL
     assert err(gb, gbr) <= REL_TOL
+
+
+def test_dropout_layer_and_a_list_that_uses_it(T):
+    """Dropout (dropout.cpp; row n4): the two kernels bit-exact against the oracle, and a layer list that contains the layer --
+    the position the reference's own (commented-out) line alexnet.cpp:28 puts it: behind a convolution -- through the C++
+    container, train step and no_grad forward"""
+    from cnn_amd import capi, hostapi
+
+    x = uniform01(120, (3, 10, 7, 5)) * 2 - 1
+    xd = T.from_numpy(x).cuda()
+    for p in (0.4, 0.5, 0.05):
+        assert np.array_equal(capi.dropout_forward(xd, p, True).cpu().numpy(), O.dropout_forward(x, p, True))
+        assert np.array_equal(capi.dropout_forward(xd, p, False).cpu().numpy(), O.dropout_forward(x, p, False))
+        assert np.array_equal(capi.dropout_backward(xd.clone(), p).cpu().numpy(), O.dropout_backward(x, p))
+    spec = [("conv", 8, 3, 2, 0), ("dropout", 0.4), ("relu",), ("pool", 2, 2), ("conv", 12, 3, 1, 1), ("relu",), ("linear", 3)]
+    in_shape = (3, 31, 29)
+    onet = O.SeqNet(spec, in_shape)
+    p0 = he_init(onet.layers, 121)
+    onet.params[:] = p0
+    net = hostapi.HostSequential(spec, in_shape)
+    net.set_params(p0)
+    B = 4
+    xb = uniform01(122, (B,) + in_shape)
+    labels = (np.arange(B) % 3).astype(np.int32)
+    loss = net.train_step_device(T.from_numpy(xb).cuda(), labels, 1e-2)
+    oloss, _ = onet.train_step(xb, labels, 1e-2)
+    assert abs(loss - oloss) <= 1e-5 * max(1.0, abs(oloss))
+    assert_close(net.get_params(), onet.params, REL_TOL, "params after a step through Dropout")
+    hostapi.load().cnnh_set_no_grad(1)
+    try:
+        logits = net.forward_host(xb)
+    finally:
+        hostapi.load().cnnh_set_no_grad(0)
+    assert_close(logits, onet.forward(xb, training=False), REL_TOL, "no_grad forward (x * (1 - p))")
+    net.close()
