@@ -307,6 +307,12 @@ protected:
     void* ev_grads = nullptr;
     void* ev_comm = nullptr;
     bool grads_reduced = false;     // this step's gradient arena has been summed over the replicas
+    std::vector<size_t> layer_offsets;  // arena offset of every layer's parameter block (finalize)
+    // big arenas (the VGG / ResNet-shaped stacks: 37 - 45 MB) are exchanged in BUCKETS while the backward pass is still running:
+    // layers are walked back to front, so finished gradients form a growing suffix of the arena; every >= bucket_floats of it
+    // go out on the communication stream behind an event.  Small arenas (the reference net: 445 KB, latency-bound) stay one call.
+    size_t bucket_floats = (size_t)2 << 20;
+    void flush_bucket(size_t lo, size_t hi);
     void wire();
     void bind(data_type* p, data_type* g);
     void prepare_filters();

@@ -4,6 +4,7 @@
 // (class AlexNet itself lives in alexnet.cpp -- the one file of this directory the reference's own cpu/src/alexnet.cpp can
 // replace, see INTEGRATION.md.)
 #include <cassert>
+#include <cstdlib>
 #include <iostream>
 #include <iterator>
 
@@ -69,8 +70,10 @@ void Sequential::bind(data_type* p, data_type* g) {
     param_arena = p;
     grad_arena = g;
     size_t off = 0;  // checkpoint order == layer order (alexnet.cpp:73-74)
+    layer_offsets.clear();
     for (auto& layer : layers_sequence) {
         const size_t n = layer->param_count();
+        layer_offsets.push_back(off);
         if (n) layer->bind_arena(p + off, g + off);
         off += n;
     }
@@ -151,15 +154,39 @@ std::vector<tensor> Sequential::forward(const std::vector<tensor>& input) {
     return output;
 }
 
+// gradients [lo, hi) of the arena are final in `stream` order: send them off on the communication stream
+void Sequential::flush_bucket(size_t lo, size_t hi) {
+    if (hi <= lo) return;
+    must(cnn_amd_side_stream_join(stream), "cnn_amd_side_stream_join");  // (weight gradients of light layers run on the side stream)
+    must(cnn_event_record(ev_grads, stream), "cnn_event_record");
+    must(cnn_stream_wait_event(comm_stream, ev_grads), "cnn_stream_wait_event");
+    must(cnn_allreduce_grads(comm, grad_arena + lo, hi - lo, comm_stream), "cnn_allreduce_grads");
+}
+
 void Sequential::backward(std::vector<tensor>& delta_start) {
     if (print_info) delta_start[0]->print_shape();
+    static const bool force_buckets = std::getenv("CNN_AMD_DP_FORCE_BUCKETS") != nullptr;  // (tests: exercise the path with one rank)
+    const bool bucketed = finalized && comm != nullptr && (comm_world > 1 || force_buckets) && n_params >= 2 * bucket_floats;
+    size_t pending_hi = n_params, idx = layers_sequence.size();
     for (auto layer = layers_sequence.rbegin(); layer != layers_sequence.rend(); ++layer) {
         delta_start = (*layer)->backward(delta_start);
         if (print_info) delta_start[0]->print_shape();
+        --idx;
+        if (bucketed && (*layer)->param_count() > 0 && pending_hi - layer_offsets[idx] >= bucket_floats) {
+            flush_bucket(layer_offsets[idx], pending_hi);
+            pending_hi = layer_offsets[idx];
+        }
+    }
+    grads_reduced = false;
+    if (bucketed) {
+        flush_bucket(0, pending_hi);
+        must(cnn_event_record(ev_comm, comm_stream), "cnn_event_record");
+        must(cnn_stream_wait_event(stream, ev_comm), "cnn_stream_wait_event");
+        grads_reduced = true;
+        return;
     }
     // the layers' weight gradients were computed on the library's side stream: order them before whatever follows
     must(cnn_amd_side_stream_join(stream), "cnn_amd_side_stream_join");
-    grads_reduced = false;
 }
 
 void Sequential::parameters_changed() {

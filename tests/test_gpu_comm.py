@@ -68,6 +68,39 @@ def test_container_with_a_one_rank_communicator_equals_the_plain_step(T):
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
 
 
+def test_bucketed_exchange_path_with_one_rank(T, monkeypatch):
+    """the bucketed all-reduce of big arenas (Sequential::backward: buckets go out on the communication stream while the backward
+    pass is still running) exercised on one GPU: with a 1-rank communicator every bucket's sum is the identity, so the step must
+    equal the plain one bit for bit -- ordering bugs (a bucket sent before its gradients are final) would show"""
+    import subprocess
+    import sys
+    import os
+
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from cnn_amd import hostapi, stacks as S
+from cnn_amd.dp import RcclComm
+spec = S.vgg11()
+p0 = S.he_init(S.walk(spec, 3, 64, 64), 7)
+x = torch.rand((4, 3, 64, 64), generator=torch.Generator(device='cuda').manual_seed(3), device='cuda')
+labels = (torch.arange(4, device='cuda') %% 3).to(torch.int32)
+comm = RcclComm(None, 1, 0)
+res = []
+for use in (0, 1):
+    net = hostapi.HostSequential(spec, (3, 64, 64))
+    net.set_params(p0)
+    if use: net.set_comm(comm.handle, 1)
+    for _ in range(2): net.train_step(x, labels, 1e-3)
+    res.append(net.get_params()); net.close()
+assert np.array_equal(res[0], res[1]), float(np.abs(res[0]-res[1]).max())
+print('BUCKETS_OK')
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CNN_AMD_DP_FORCE_BUCKETS="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "BUCKETS_OK" in out.stdout, out.stdout[-1000:] + out.stderr[-3000:]
+
+
 def test_two_replicas_of_the_cpp_container_equal_the_full_batch_step(T):
     """configs[2] / [4] in miniature: two replicas of the C++ container (one per GPU, one host thread each, ncclCommInitAll via
     cnn_comm_init_all) train on the two halves of a batch -- BatchNorm2D as sync-BN, gradient arena all-reduced by
