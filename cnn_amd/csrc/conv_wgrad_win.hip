@@ -119,6 +119,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
     auto stage = [&](int s, float* buf) -> bool {
         int b, wr, wc_lo, sw;
         strip_of(s, b, wr, wc_lo, sw);
+        const bool chained = s > s_lo && wr > 0;  // this wave consumed strip s-1 = (b, same segment, wr-1) just before
         // x: rows 4wr .. 4wr+4 of the three channels, columns 4*wc_lo .. 4*wc_lo + 4*sw (inclusive), clipped to the image
         {
             const int ncols = (p.W - 4 * wc_lo) < (4 * sw + 4) ? (p.W - 4 * wc_lo) : (4 * sw + 4);
@@ -133,7 +134,9 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
                 const int row = f / PER_ROW, c = (f - row * PER_ROW) * CH;  // staged row (ci*5 + r5), first column of the chunk
                 const int ci = row / XR, r5 = row - ci * XR;
                 const int rr = r5 < nrows ? r5 : 0, cq = c < ncols ? c : 0;  // (outside the image: a valid element instead)
-                if (f < TOTAL) {  // (lanes behind the last row would overwrite the ones row)
+                // (lanes behind the last row would overwrite the ones row; row 0 of a strip that continues the previous one
+                // -- same image, same column segment, next window row -- is that strip's row 4: copied LDS -> LDS below)
+                if (f < TOTAL && !(chained && r5 == 0)) {
                     if constexpr (DMA16)
                         __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + ((size_t)ci * p.H + rr) * p.W + cq), (lds_void_ptr)(buf + 64 * i * CH), 16, 0, 0);
                     else
@@ -290,20 +293,32 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (s + NBUF - 1 < s_hi && p.dbg != 2) {
-                int nb = cur + NBUF - 1;
-                nb = nb >= NBUF ? nb - NBUF : nb;
-                slow_next = stage(s + NBUF - 1, wbuf + nb * BUF);
-            }
+            int b, wr, wc_lo, sw;
+            strip_of(s, b, wr, wc_lo, sw);
+            int nb = cur + NBUF - 1;  // the buffer of strip s-1, which the next stage() call re-uses
+            nb = nb >= NBUF ? nb - NBUF : nb;
+            if (s + NBUF - 1 < s_hi && p.dbg != 2) slow_next = stage(s + NBUF - 1, wbuf + nb * BUF);
             if (p.dbg != 1) {
-                int b, wr, wc_lo, sw;
-                strip_of(s, b, wr, wc_lo, sw);
                 const bool edge = 2 * wr + 1 >= p.Ho || 2 * (wc_lo + ((sw + 3) & ~3)) > p.Wo || 4 * wr + XR > p.H || 4 * (wc_lo + sw) + 4 > p.W ||
                                   (POOLED && (wr >= p.PHo || wc_lo + ((sw + 3) & ~3) > p.PWo));
                 if (edge) compute(std::true_type(), wr, wc_lo, sw, wbuf + cur * BUF);
                 else compute(std::false_type(), wr, wc_lo, sw, wbuf + cur * BUF);
             }
-            cur = cur + 1 == NBUF ? 0 : cur + 1;
+            const int nxt = cur + 1 == NBUF ? 0 : cur + 1;
+            if (s + 1 < s_hi && wr + 1 < p.WR && p.dbg != 2) {
+                // strip s+1 continues this one (same image, same column segment, next window row): its input row 0 is this
+                // strip's row 4 -- handed over LDS -> LDS (3 channels x 17 16-byte chunks; its DMA leaves row 0 alone) instead of a
+                // second trip to L2 / HBM (the re-read rows were 25 % extra fetch traffic).  Issued behind this strip's MFMAs:
+                // the next stage() call, which re-uses THIS buffer, comes after the dependent ds_write.
+                const float* from = wbuf + cur * BUF;
+                float* to = wbuf + nxt * BUF;
+                if (lane < CI * (XP / 4)) {
+                    const int ci = lane / (XP / 4), ch = lane - ci * (XP / 4);
+                    const float4 v = *(const float4*)(from + (ci * XR + 4) * XP + 4 * ch);
+                    *(float4*)(to + (ci * XR) * XP + 4 * ch) = v;
+                }
+            }
+            cur = nxt;
         }
     }
 

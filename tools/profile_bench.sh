@@ -1,12 +1,28 @@
 #!/bin/bash
-# rocprofv3 capture of the default bench.py run (kernel trace + stats), then HBM-traffic PMC passes (separate runs).
-# usage (on the GPU box, from the repo root): bash tools/profile_bench.sh <tag>
-TAG=${1:-r01}
+# rocprofv3 captures of bench.py for a round: kernel trace + stats of the three BASELINE workloads, then the HBM-traffic PMC
+# passes of the headline configuration (separate runs, as MI355X_MICROARCH.md prescribes; never combined with other trace domains).
+# usage (on the GPU box, from the repo root): bash tools/profile_bench.sh <tag>     -> gpurun_out/prof_<tag>/
+TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch --output-format csv -- $BENCH --no-conv-ns > /dev/null 2> $OUT/pmc_fetch.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o write --output-format csv -- $BENCH --no-conv-ns > /dev/null 2> $OUT/pmc_write.log
-ls -R $OUT | head -30
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch --output-format csv -- $BENCH --no-conv-ns --no-layer-api > /dev/null 2> $OUT/pmc_fetch.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o write --output-format csv -- $BENCH --no-conv-ns --no-layer-api > /dev/null 2> $OUT/pmc_write.log
+for CFG in vgg11 resnet18; do
+  rocprofv3 --kernel-trace --stats -d $OUT/trace_$CFG -o bench --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_${CFG}_under_rocprof.json 2> $OUT/trace_$CFG.log
+done
+cd $GRAFT_REPO_ROOT
+python tools/pmc_traffic.py $OUT $OUT/hbm_traffic.json
+python tools/step_timeline.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) 3 > $OUT/step_timeline.txt
+# plain (unprofiled) runs of the same commands: the numbers the profiles are read against
+python bench.py --steps 100 --warmup 20 --staged-input --breakdown > $OUT/bench_alexnet.json 2> $OUT/bench_alexnet_breakdown.txt
+python bench.py --config vgg11 --breakdown > $OUT/bench_vgg11.json 2> $OUT/bench_vgg11_breakdown.txt
+python bench.py --config resnet18 --breakdown > $OUT/bench_resnet18.json 2> $OUT/bench_resnet18_breakdown.txt
+bash tools/run_tune.sh > /dev/null 2>&1; cp gpurun_out/tune_layers.log $OUT/layers_isolated.txt
+(python tools/tune_stack.py vgg11; python tools/tune_stack.py resnet18) > $OUT/stack_layers_isolated.txt 2>&1
+# large raw traces stay out of the merge-back (64 MiB cap): keep the per-kernel stats and drop the per-launch traces
+find $OUT -name "*kernel_trace.csv" -size +8M -delete
+find $OUT -name "*counter_collection.csv" -size +8M -delete
+ls -R $OUT | head -60
