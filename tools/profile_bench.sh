@@ -15,7 +15,9 @@ for CFG in vgg11 resnet18; do
 done
 cd $GRAFT_REPO_ROOT
 python tools/pmc_traffic.py $OUT $OUT/hbm_traffic.json
-python tools/step_timeline.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) 3 > $OUT/step_timeline.txt
+# timeline of one steady-state step of the HEADLINE leg (no layer-api / conv_ns legs in that process)
+(cd /tmp && rocprofv3 --kernel-trace -d $OUT/trace_step -o step --output-format csv -- $BENCH --no-conv-ns --no-layer-api > /dev/null 2> $OUT/trace_step.log)
+python tools/step_timeline.py $(find $OUT/trace_step -name "*kernel_trace.csv" | head -1) 3 > $OUT/step_timeline.txt
 # plain (unprofiled) runs of the same commands: the numbers the profiles are read against
 python bench.py --steps 100 --warmup 20 --staged-input --breakdown > $OUT/bench_alexnet.json 2> $OUT/bench_alexnet_breakdown.txt
 python bench.py --config vgg11 --breakdown > $OUT/bench_vgg11.json 2> $OUT/bench_vgg11_breakdown.txt
