@@ -551,7 +551,12 @@ class SeqNet:
             elif k == "relu":
                 d = relu_backward(masks_from.get(idx, self.acts[idx]), d, f64=f64)
             elif k == "pool":
-                mask = maxpool_forward(masks_from[idx], e["k"], e["step"], f64=f64)[1] if idx in masks_from else self.aux[idx]
+                if idx in masks_from and masks_from[idx].dtype == np.int32:
+                    mask = masks_from[idx]  # the other implementation's argmax mask itself
+                elif idx in masks_from:
+                    mask = maxpool_forward(masks_from[idx], e["k"], e["step"], f64=f64)[1]  # ... or its pool INPUT
+                else:
+                    mask = self.aux[idx]
                 d = maxpool_backward(d, mask, xin.shape, e["k"], e["step"], f64=f64)
             elif k == "bn":
                 c = e["in"][0]
