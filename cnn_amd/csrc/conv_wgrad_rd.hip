@@ -63,6 +63,12 @@ struct RdParams {
     unsigned m_rows, m_rpr;  // magic multipliers: run -> (image*Ho + p, segment) and -> image
     int chunks_fast;  // chunks [chunks_head, chunks_fast) may over-read their windows without leaving x / dy (host-checked)
     int chunks_head;  // chunks [0, chunks_head) could read in FRONT of x (padding): guarded path
+    // FLAT (stride 1, pad 1, Wo == W): runs are cut from the FLATTENED pixel index of an image instead of row by row -- both
+    // operands stay contiguous across a row end (dy row p+1 follows row p, and so does the input window) -- so a 28- or 56-wide
+    // row no longer wastes the tail of its last run (87.5 % -> 100 % live k-slots).  Then Ho = 1, Wo = H*W for the addressing
+    // and W / H / m_w (magic of W) describe the real rows for the masks.
+    int flat;
+    unsigned m_w;
     int dbg;          // CNN_AMD_RD_DBG=9: workgroup 0 prints its shader-cycle count and the clock it ran at
 };
 
@@ -88,8 +94,9 @@ __device__ __forceinline__ f4u load4(const float* __restrict__ p, int nvalid) {
     return v;
 }
 
-template <int S, int NT, int RL, bool POOLED, int PAD>
+template <int S, int NT, int RL, bool POOLED, int PAD, bool FLAT = false>
 __device__ __forceinline__ void wgrad_rd_body(const RdParams& p) {
+    static_assert(!FLAT || (S == 1 && PAD == 1 && RL == 16), "flattened runs: stride 1, pad 1, runs of 16");
     static_assert(PAD == 0 || (PAD == 1 && !POOLED), "padding 0 or 1; the pooled-domain first block is unpadded");
     constexpr int WL = S * RL;  // floats of x a lane needs per chunk and tile
     __shared__ float red[32][NT * 32 + 1];  // (+1: bank padding; the column doubles as the bias-gradient slot)
@@ -205,8 +212,14 @@ __device__ __forceinline__ void wgrad_rd_body(const RdParams& p) {
                 const float* src = ximg + (ptrdiff_t)(xoff[nt] - shift[nt]);  // (row, column S*q0) of the tap's input row
 #pragma unroll
                 for (int t = 0; t < RL; ++t) {
-                    const int col = S * (q0 + t) + cc_nt;
-                    const bool ok = rowv && t < npix && (unsigned)col < (unsigned)p.W;
+                    bool ok;
+                    if constexpr (FLAT) {  // flattened runs: pixel t is (pt, qt) of the image
+                        const int pt = fdiv(q0 + t, p.m_w, p.W), qt = q0 + t - pt * p.W;
+                        ok = nvalid_col[nt] && t < npix && (unsigned)(pt + dk_of(nt)) < (unsigned)p.H && (unsigned)(qt + cc_nt) < (unsigned)p.W;
+                    } else {
+                        const int col = S * (q0 + t) + cc_nt;
+                        ok = rowv && t < npix && (unsigned)col < (unsigned)p.W;
+                    }
                     const float v = ok ? src[S * t + cc_nt] : 0.f;
                     w[S == 2 ? 2 * t + (par[nt] ? 1 : 0) : t] = v;
                     if (S == 2) w[2 * t + (par[nt] ? 0 : 1)] = 0.f;
@@ -302,17 +315,34 @@ __device__ __forceinline__ void wgrad_rd_body(const RdParams& p) {
         };
         // one tile's MFMAs: k-slot t <-> pixel t of the lane's run
         auto tile_mfma = [&](int nt, const float (&a)[RL], const f4u (&win)[WL / 4]) {
-            // live k-slots of this lane's window: [lo, lo + span)
+            // live k-slots of this lane's window: a range [lo, lo + span) -- or, with flattened runs, one bit per pixel of the run
+            unsigned vm = 0;
             int lo = 0, span = cur_nb;
             if constexpr (PAD > 0) {
-                // a tap row outside the image still reads MAPPED memory (the neighbouring channel / image; the first and last
-                // rows of the whole tensor are the guarded path's) and is masked as a whole
-                const int c0 = S * (int)(cur_pq & 0xffffu) + cc_of(nt);  // column of pixel 0
-                lo = c0 < 0 ? 1 : 0;                                     // (c0 >= -PAD = -1)
-                int hi = S == 1 ? p.W - c0 : (p.W - c0 + 1) >> 1;        // pixels whose column is < W
-                hi = hi < cur_nb ? hi : cur_nb;
-                const bool rowv = (unsigned)(S * (int)(cur_pq >> 16) + dk_of(nt)) < (unsigned)p.H;
-                span = rowv ? hi - lo : 0;
+                const int dk = dk_of(nt), cc = cc_of(nt);
+                if constexpr (FLAT) {
+                    // flattened runs: the run starts at pixel (p0, q0) and may cross ONE row end (RL <= W)
+                    const int f0 = (int)(cur_pq & 0xffffu);
+                    const int p0 = fdiv(f0, p.m_w, p.W), q0 = f0 - p0 * p.W;
+                    const int wrap = p.W - q0;  // first k-slot of the next row
+                    const unsigned first = wrap >= RL ? (1u << RL) - 1u : (1u << wrap) - 1u;
+                    const bool r0 = (unsigned)(p0 + dk) < (unsigned)p.H, r1 = (unsigned)(p0 + 1 + dk) < (unsigned)p.H;
+                    const unsigned rows = (r0 ? first : 0u) | (r1 ? (((1u << RL) - 1u) & ~first) : 0u);
+                    // the one pixel whose window column leaves the image: column 0 for cc = -1, column W-1 for cc = +1
+                    unsigned bad = 0u;
+                    if (cc < 0) bad = q0 == 0 ? 1u : (wrap < RL ? 1u << wrap : 0u);
+                    else if (cc > 0) bad = wrap - 1 < RL ? 1u << (wrap - 1) : 0u;
+                    vm = ((1u << cur_nb) - 1u) & rows & ~bad;
+                } else {
+                    // a tap row outside the image still reads MAPPED memory (the neighbouring channel / image; the first and last
+                    // rows of the whole tensor are the guarded path's) and is masked as a whole
+                    const int c0 = S * (int)(cur_pq & 0xffffu) + cc;         // column of pixel 0
+                    lo = c0 < 0 ? 1 : 0;                                     // (c0 >= -PAD = -1)
+                    int hi = S == 1 ? p.W - c0 : (p.W - c0 + 1) >> 1;        // pixels whose column is < W
+                    hi = hi < cur_nb ? hi : cur_nb;
+                    const bool rowv = (unsigned)(S * (int)(cur_pq >> 16) + dk) < (unsigned)p.H;
+                    span = rowv ? hi - lo : 0;
+                }
             }
 #pragma unroll
             for (int t = 0; t < RL; ++t) {
@@ -326,7 +356,8 @@ __device__ __forceinline__ void wgrad_rd_body(const RdParams& p) {
                     bv = (e & 3) == 0 ? q.x : (e & 3) == 1 ? q.y : (e & 3) == 2 ? q.z : q.w;
                 }
                 // what lies behind the run (or outside the image) is not the reference's to read (may be Inf / NaN)
-                if constexpr (PAD > 0) bv = (unsigned)(t - lo) < (unsigned)span ? bv : 0.f;
+                if constexpr (FLAT) bv = (vm & (1u << t)) ? bv : 0.f;
+                else if constexpr (PAD > 0) bv = (unsigned)(t - lo) < (unsigned)span ? bv : 0.f;
                 else bv = t < cur_nb ? bv : 0.f;
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bv, acc[nt], 0, 0, 0);
             }
@@ -416,9 +447,9 @@ __global__ __launch_bounds__(256) void wgrad_rd_kernel(const RdParams p) {
 }
 // The padded variants carry a few more live values per tile; without a register budget hipcc takes 290 registers for six
 // tiles and the kernel drops to ONE wave per SIMD (62 instead of 100+ TFLOP/s): two waves per SIMD = 256 registers, enforced.
-template <int S, int NT, int RL>
+template <int S, int NT, int RL, bool FLAT>
 __global__ __launch_bounds__(256, 2) void wgrad_rd_kernel_p1(const RdParams p) {
-    wgrad_rd_body<S, NT, RL, false, 1>(p);
+    wgrad_rd_body<S, NT, RL, false, 1, FLAT>(p);
 }
 
 inline unsigned magic_of(int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
@@ -436,6 +467,14 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
     p.Ho = cnn_conv2d_out_dim(d->H, 3, d->s, d->pad);
     p.Wo = cnn_conv2d_out_dim(d->W, 3, d->s, d->pad);
     if (p.Ho <= 0 || p.Wo <= 0) return false;
+    // flattened runs (see RdParams::flat): worth it when the rows do not divide into whole runs of 16
+    p.flat = 0;
+    p.m_w = magic_of(d->W);
+    if (!pooled && d->s == 1 && d->pad == 1 && d->W >= 16 && d->W % 16 != 0 && (long long)d->H * d->W < 65536 && !getenv("CNN_AMD_RD_NOFLAT")) {
+        p.flat = 1;
+        p.Wo = d->H * d->W;  // one "row" per image
+        p.Ho = 1;
+    }
     p.Ntot = d->Ci * 9;
     p.pitch = p.Ntot + 1;
     p.PHo = p.Ho / 2; p.PWo = p.Wo / 2;
@@ -502,7 +541,7 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
     p.chunks_fast = getenv("CNN_AMD_RD_SLOW") ? 0 : (int)(r_unsafe / 2);  // (CNN_AMD_RD_SLOW: tests force the guarded path)
     // padded layers: the first run of output rows 0 and 1 of image 0 reads input row 0 from column -1 (or -2): x[-1] lies in
     // front of the allocation, so the chunks up to run `rpr` (first run of row 1) take the guarded path
-    p.chunks_head = d->pad > 0 ? p.rpr / 2 + 1 : 0;
+    p.chunks_head = d->pad > 0 ? (p.flat ? ((d->W + 1) / pl->rl + 2) / 2 + 1 : p.rpr / 2 + 1) : 0;
     return true;
 }
 
@@ -524,11 +563,13 @@ int wgrad_rd_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, f
     pl.p.x = x; pl.p.dy = dy; pl.p.slabs = slabs;
     const dim3 grid(pl.kblocks, pl.ngroups, pl.mtiles);
     char name[64];
-    snprintf(name, sizeof(name), d->pad ? "wgrad_rd<%d,%d,%d,p1>" : "wgrad_rd<%d,%d,%d>", d->s, pl.nt, pl.rl);
+    snprintf(name, sizeof(name), d->pad ? (pl.p.flat ? "wgrad_rd<%d,%d,%d,p1,flat>" : "wgrad_rd<%d,%d,%d,p1>") : "wgrad_rd<%d,%d,%d>", d->s, pl.nt, pl.rl);
 #define RD(S_, NT_, RL_)                                                                                                   \
     do {                                                                                                                   \
         if (d->pad == 0) CNN_KLAUNCH(s, name, (wgrad_rd_kernel<S_, NT_, RL_, false><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d)); \
-        else CNN_KLAUNCH(s, name, (wgrad_rd_kernel_p1<S_, NT_, RL_><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d));               \
+        else if (S_ == 1 && RL_ == 16 && pl.p.flat)                                                                       \
+            CNN_KLAUNCH(s, name, (wgrad_rd_kernel_p1<S_, NT_, RL_, (S_ == 1 && RL_ == 16)><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d)); \
+        else CNN_KLAUNCH(s, name, (wgrad_rd_kernel_p1<S_, NT_, RL_, false><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d));        \
     } while (0)
 #define RD_NT(S_, RL_)                                                     \
     switch (pl.nt) {                                                       \

@@ -131,6 +131,9 @@ RD_CASES = [
     (2, 40, 9, 9, 70, 3, 1, 1),      # runs of 8 pixels (Wo = 9 -> a 1-pixel tail run whose window starts inside)
     (2, 3, 30, 34, 64, 3, 1, 1),     # first VGG layer shape class: 27 columns, one tile
     (3, 130, 7, 7, 96, 3, 1, 1),     # 1170 columns: 37 tiles -> groups of 5 with dead tiles, three row tiles
+    (2, 5, 28, 28, 40, 3, 1, 1),     # flattened runs (W = 28: a run of 16 crosses a row end; 784 = 49 whole runs per image)
+    (1, 6, 19, 21, 8, 3, 1, 1),      # ... ragged: 399 pixels = 24 runs + 15, wraps at every position
+    (2, 3, 56, 56, 16, 3, 1, 1),     # ... 27 columns, rows of 3.5 runs
 ]
 
 

@@ -52,7 +52,7 @@ def canonical(name):
     m = re.match(r"conv_wgrad_win_kernel<(\d),(true|false)>$", name)
     if m:
         return "conv_wgrad_win<3,16,3,2>" + {"0": "", "1": "+pool", "2": "+poolm"}[m.group(1)]
-    m = re.match(r"wgrad_rd_kernel_p1<(\d+,\d+,\d+)>$", name)
+    m = re.match(r"wgrad_rd_kernel_p1<(\d+,\d+,\d+),(true|false)>$", name)
     if m:
         return f"wgrad_rd<{m.group(1)},p1>"
     if name.startswith("conv_dgrad_thin_s1k3"):
