@@ -29,7 +29,12 @@
 
 using namespace cnn_amd;
 
+#ifndef CNN_WIN_EXPERIMENT
+#define CNN_WIN_EXPERIMENT 0
+#endif
 namespace {
+__device__ unsigned long long g_prof[256 * 8][8];
+constexpr int kExp = CNN_WIN_EXPERIMENT;  // timing experiments only (3: no LDS operand reads, 4: no MFMAs); 0 in the product
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
@@ -62,6 +67,7 @@ struct WinParams {
     int nseg, SW;          // column segments per window row, windows per segment (multiple of 4, <= kSW)
     int strips_total, strips_per_wave;
     int dbg;  // CNN_AMD_WIN_DBG (tuning): 1 = no MFMA groups, 2 = no staging
+    int lockstep;  // the waves of a workgroup start every strip together (only when every wave has the same number of strips)
 };
 
 // POOLED: 0 dy | 1 pooled domain (dpool, mask, pooled) | 2 pooled domain with dpool already ReLU-masked (pooled not read)
@@ -102,45 +108,106 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
     const int s_lo = gw * p.strips_per_wave;
     const int s_hi = s_lo + p.strips_per_wave < p.strips_total ? s_lo + p.strips_per_wave : p.strips_total;
 
-    // strip s -> (image b, column segment, window row wr): consecutive strips walk DOWN one column segment of one image
-    auto strip_of = [&](int s, int& b, int& wr, int& wc_lo, int& sw) {
-        b = s / (p.nseg * p.WR);
-        const int r = s - b * (p.nseg * p.WR);
-        const int seg = r / p.WR;
-        wr = r - seg * p.WR;
+    // strip s -> (image b, column segment, window row wr): consecutive strips walk DOWN one column segment of one image.
+    // A wave decodes its first strip once and then ADVANCES two cursors (the strip being staged, the strip being computed):
+    // re-deriving everything from s cost ~300 scalar / vector instructions per strip -- more issue time than the strip's 32 MFMAs.
+    struct Cur {
+        int s, b, seg, wr;
+    };
+    auto decode = [&](int s) {
+        Cur c;
+        c.s = s;
+        c.b = s / (p.nseg * p.WR);
+        const int r = s - c.b * (p.nseg * p.WR);
+        c.seg = r / p.WR;
+        c.wr = r - c.seg * p.WR;
+        return c;
+    };
+    auto advance = [&](Cur& c) {
+        ++c.s;
+        if (++c.wr == p.WR) {
+            c.wr = 0;
+            if (++c.seg == p.nseg) {
+                c.seg = 0;
+                ++c.b;
+            }
+        }
+    };
+    auto seg_geom = [&](int seg, int& wc_lo, int& sw) {
         wc_lo = seg * p.SW;
         sw = p.WC - wc_lo < p.SW ? p.WC - wc_lo : p.SW;
+    };
+
+    // per-lane DMA source offsets (floats) of the current staging COLUMN (image-independent, window-row-independent): x relative
+    // to the strip's first element x[b][0][4wr][4wc_lo], the pooled-domain operands relative to T[b][0][wr][wc_lo].  Columns clipped
+    // by the image's right edge are clamped here; strips clipped by its bottom edge take the slow path below.
+    constexpr int CHX = DMA16 ? 4 : 1;
+    constexpr int PER_ROW = XP / CHX;
+    constexpr int TOTALX = XROWS * PER_ROW;
+    constexpr int NX = (TOTALX + 63) / 64;
+    unsigned gx[NX];
+    unsigned ga = 0;
+    unsigned row0_bits = 0, live_bits = 0;  // per DMA instruction i: this lane's chunk is in staged row r5 == 0 / exists at all
+    int col_seg = -1;
+    auto setup_column = [&](int seg) {
+        int wc_lo, sw;
+        seg_geom(seg, wc_lo, sw);
+        const int ncols = (p.W - 4 * wc_lo) < (4 * sw + 4) ? (p.W - 4 * wc_lo) : (4 * sw + 4);
+        row0_bits = live_bits = 0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int f = 64 * i + lane;
+            const int row = f / PER_ROW, c = (f - row * PER_ROW) * CHX;
+            const int ci = row / XR, r5 = row - ci * XR;
+            gx[i] = (unsigned)((ci * p.H + r5) * p.W + (c < ncols ? c : 0));
+            if (f < TOTALX) live_bits |= 1u << i;
+            if (r5 == 0) row0_bits |= 1u << i;
+        }
+        if constexpr (POOLED) {
+            const int nv = p.PWo - wc_lo < sw ? p.PWo - wc_lo : sw;
+            const int g = lane >> 4;
+            ga = (unsigned)((co * p.PHo) * p.PWo + (4 * g < nv ? 4 * g : 0));
+        }
+        col_seg = seg;
     };
 
     // ---- HBM -> LDS for one strip (asynchronous: completion = vmcnt).  Every instruction is issued by every strip (the wait
     // below counts instructions): a lane whose element lies outside the image / the row re-reads a valid element of the same
     // row instead, and the compute path ignores that slot (EDGE).  Returns true for the ONE strip kind that stages its delta
     // operands with 4-byte instead of 16-byte DMA (see below).
-    auto stage = [&](int s, float* buf) -> bool {
-        int b, wr, wc_lo, sw;
-        strip_of(s, b, wr, wc_lo, sw);
+    auto stage = [&](const Cur& cu, float* buf) -> bool {
+        const int s = cu.s, b = cu.b, wr = cu.wr;
+        int wc_lo, sw;
+        seg_geom(cu.seg, wc_lo, sw);
         const bool chained = s > s_lo && wr > 0;  // this wave consumed strip s-1 = (b, same segment, wr-1) just before
+        if (col_seg != cu.seg) setup_column(cu.seg);
+        const int nrows = (p.H - 4 * wr) < XR ? (p.H - 4 * wr) : XR;
         // x: rows 4wr .. 4wr+4 of the three channels, columns 4*wc_lo .. 4*wc_lo + 4*sw (inclusive), clipped to the image
-        {
-            const int ncols = (p.W - 4 * wc_lo) < (4 * sw + 4) ? (p.W - 4 * wc_lo) : (4 * sw + 4);
-            const int nrows = (p.H - 4 * wr) < XR ? (p.H - 4 * wr) : XR;
-            const float* src = p.x + ((size_t)b * CI * p.H + 4 * wr) * p.W + 4 * wc_lo;
-            constexpr int CH = DMA16 ? 4 : 1;               // floats per lane and instruction
-            constexpr int PER_ROW = XP / CH;                 // 17 chunks (or 68 floats) per staged row
-            constexpr int TOTAL = XROWS * PER_ROW;
+        if (nrows == XR) {
+            const float* src = p.x + ((size_t)b * CI * p.H + 4 * wr) * p.W + 4 * wc_lo;  // wave-uniform
 #pragma unroll
-            for (int i = 0; i < (TOTAL + 63) / 64; ++i) {
+            for (int i = 0; i < NX; ++i) {
+                if ((live_bits >> i & 1u) && !(chained && (row0_bits >> i & 1u))) {
+                    if constexpr (DMA16) __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + gx[i]), (lds_void_ptr)(buf + 64 * i * CHX), 16, 0, 0);
+                    else __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + gx[i]), (lds_void_ptr)(buf + 64 * i * CHX), 4, 0, 0);
+                }
+            }
+        } else {
+            const int ncols = (p.W - 4 * wc_lo) < (4 * sw + 4) ? (p.W - 4 * wc_lo) : (4 * sw + 4);
+            const float* src = p.x + ((size_t)b * CI * p.H + 4 * wr) * p.W + 4 * wc_lo;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
                 const int f = 64 * i + lane;
-                const int row = f / PER_ROW, c = (f - row * PER_ROW) * CH;  // staged row (ci*5 + r5), first column of the chunk
+                const int row = f / PER_ROW, c = (f - row * PER_ROW) * CHX;  // staged row (ci*5 + r5), first column of the chunk
                 const int ci = row / XR, r5 = row - ci * XR;
                 const int rr = r5 < nrows ? r5 : 0, cq = c < ncols ? c : 0;  // (outside the image: a valid element instead)
                 // (lanes behind the last row would overwrite the ones row; row 0 of a strip that continues the previous one
-                // -- same image, same column segment, next window row -- is that strip's row 4: copied LDS -> LDS below)
-                if (f < TOTAL && !(chained && r5 == 0)) {
+                // -- same image, same column segment, next window row -- is that strip's row 4: handed over LDS -> LDS)
+                if (f < TOTALX && !(chained && r5 == 0)) {
                     if constexpr (DMA16)
-                        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + ((size_t)ci * p.H + rr) * p.W + cq), (lds_void_ptr)(buf + 64 * i * CH), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + ((size_t)ci * p.H + rr) * p.W + cq), (lds_void_ptr)(buf + 64 * i * CHX), 16, 0, 0);
                     else
-                        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + ((size_t)ci * p.H + rr) * p.W + cq), (lds_void_ptr)(buf + 64 * i * CH), 4, 0, 0);
+                        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + ((size_t)ci * p.H + rr) * p.W + cq), (lds_void_ptr)(buf + 64 * i * CHX), 4, 0, 0);
                 }
             }
         }
@@ -154,9 +221,16 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
             const bool rowok = wr < p.PHo;
             const int nv = rowok ? (p.PWo - wc_lo < sw ? p.PWo - wc_lo : sw) : 0;
             const bool last_row = b == p.B - 1 && wr >= p.PHo - 1 && wc_lo + kSW > p.PWo;
-            if (!last_row) {
+            if (!last_row && rowok) {
+                const size_t abase = (((size_t)b * CO) * p.PHo + wr) * p.PWo + wc_lo;  // wave-uniform; ga: this lane's (co, group)
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.dy + abase + ga), (lds_void_ptr)(abuf), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)((const float*)p.pmask + abase + ga), (lds_void_ptr)(abuf + kSW * CO), 16, 0, 0);
+                if constexpr (POOLED == 1) __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.pooled + abase + ga), (lds_void_ptr)(abuf + 2 * kSW * CO), 16, 0, 0);
+                return false;
+            }
+            if (!last_row) {  // a window row outside the pooled domain: any valid row will do (the compute path ignores it)
                 const int g = lane >> 4;
-                const size_t off = (((size_t)b * CO + co) * p.PHo + (rowok ? wr : 0)) * p.PWo + wc_lo + (4 * g < nv ? 4 * g : 0);
+                const size_t off = (((size_t)b * CO + co) * p.PHo) * p.PWo + wc_lo + (4 * g < nv ? 4 * g : 0);
                 __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.dy + off), (lds_void_ptr)(abuf), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((gbl_void_ptr)((const float*)p.pmask + off), (lds_void_ptr)(abuf + kSW * CO), 16, 0, 0);
                 if constexpr (POOLED == 1) __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.pooled + off), (lds_void_ptr)(abuf + 2 * kSW * CO), 16, 0, 0);
@@ -191,7 +265,6 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
         }
     };
     // DMA instructions per strip: what `s_waitcnt vmcnt(N)` has to leave in flight when the NEXT strip is already on its way
-    constexpr int NX = (XROWS * (XP / (DMA16 ? 4 : 1)) + 63) / 64;
     constexpr int N_FAST = NX + (POOLED ? NT : 2 * (2 * kSW / 4)), N_SLOW = NX + NT * kGroups;
 
     // ---- the strip's MFMA groups.  EDGE: the strip touches the last window row / column of the layer, where a window's pixels
@@ -202,7 +275,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
         float av[2][2];     // plain: the four deltas of the window
         float bv[2][2][2];  // [tile][pr][pc]
     };
-    auto compute = [&](auto EDGE_C, int wr, int wc_lo, int sw, const float* buf) {
+    auto compute = [&](auto EDGE_C, int wr, int wc_lo, int sw, const float* buf, bool mid_barrier) {
         constexpr bool EDGE = decltype(EDGE_C)::value;
         const float* const xb = buf;
         const float* const ab = buf + XBUF;
@@ -214,6 +287,12 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
         const int e_lane = co * p.Ho * p.Wo + 2 * wr * p.Wo + 2 * (wc_lo + k);  // flat index of pixel (0,0) of window 4*0 + k
         auto load_ops = [&](int g, Ops& o) {
             const int w = 4 * g + k;
+            if constexpr (kExp == 3) {  // (experiment: MFMA issue alone)
+                o.a0 = o.a1 = o.a2 = (float)lane;
+                for (int t = 0; t < 2; ++t) for (int pr = 0; pr < 2; ++pr) o.bv[t][pr][0] = o.bv[t][pr][1] = (float)(lane + g);
+                for (int pr = 0; pr < 2; ++pr) for (int pc = 0; pc < 2; ++pc) o.av[pr][pc] = 1.f;
+                return;
+            }
             if constexpr (POOLED) {
                 o.a0 = ab[64 * g + 4 * co + k];
                 o.a1 = ab[kSW * CO + 64 * g + 4 * co + k];
@@ -263,8 +342,10 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
                 for (int pc = 0; pc < 2; ++pc) {
                     const bool ok = !EDGE || (winv && (pr ? rowv1 : rowv0) && q0 + pc < p.Wo);
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
-                        acc[t][pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pr][pc], ok ? o.bv[t][pr][pc] : 0.f, acc[t][pr], 0, 0, 0);
+                    for (int t = 0; t < 2; ++t) {
+                        if constexpr (kExp == 4) acc[t][pr][0] += av[pr][pc] * o.bv[t][pr][pc];  // (experiment: everything but the MFMAs)
+                        else acc[t][pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pr][pc], ok ? o.bv[t][pr][pc] : 0.f, acc[t][pr], 0, 0, 0);
+                    }
                 }
         };
         // software pipeline: the LDS reads of group g+1 are issued in front of the MFMAs of group g
@@ -276,49 +357,98 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
                 if (g + 1 < kGroups && g + 1 < groups) load_ops(g + 1, ops[(g + 1) & 1]);
                 run_group(g, ops[g & 1]);
             }
+            if (g == 1 && mid_barrier) __builtin_amdgcn_s_barrier();  // (skewed lockstep, see the strip loop)
         }
     };
 
     if (s_lo < s_hi) {
         // NBUF - 1 strips ahead: strip s is consumed from buffer s % NBUF while s+1 (.. s+NBUF-1) are on their way
         bool slow_next = false;  // kind of the most recently staged strip that is still in flight behind strip s
-        stage(s_lo, wbuf);
-        if (NBUF == 3 && s_lo + 1 < s_hi && p.dbg != 2) slow_next = stage(s_lo + 1, wbuf + BUF);
+        Cur sc = decode(s_lo), cc = sc;  // staging cursor / compute cursor
+        stage(sc, wbuf);
+        advance(sc);
+        if (NBUF == 3 && sc.s < s_hi && p.dbg < 2) {
+            slow_next = stage(sc, wbuf + BUF);
+            advance(sc);
+        }
         int cur = 0;
-        for (int s = s_lo; s < s_hi; ++s) {
+        unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, tq = 0;
+        auto tick = [&](int i) {
+            if constexpr (kExp == 6) {
+                const unsigned long long now = __builtin_readcyclecounter();
+                if (i >= 0) tp[i] += now - tq;
+                tq = now;
+            }
+        };
+        for (; cc.s < s_hi; advance(cc)) {
+            const int s = cc.s, wr = cc.wr;
+            tick(-1);
+            // lockstep: one workgroup barrier per strip keeps the eight waves -- eight neighbouring runs of the image -- within a strip
+            // of each other, so the delta rows' 128-byte lines are fetched once (L2 hit for the other waves).  Skewed (2): the second
+            // wave of every SIMD takes ITS barrier half-way through its MFMAs, so that one wave's MFMAs cover the other's DMA issue /
+            // LDS latency instead of both waves of a SIMD stalling and computing together.
+            const bool late = p.lockstep == 2 && wave >= kWaves / 2;
+            if (p.lockstep && !late) __builtin_amdgcn_s_barrier();
+            tick(0);
             // strip s has landed once at most the instructions of strip s+1 are outstanding
-            if (NBUF == 3 && s + 1 < s_hi && p.dbg != 2) {
+            if (NBUF == 3 && s + 1 < s_hi && p.dbg < 2) {
                 if (slow_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_SLOW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_FAST) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            int b, wr, wc_lo, sw;
-            strip_of(s, b, wr, wc_lo, sw);
+            tick(1);
+            int wc_lo, sw;
+            seg_geom(cc.seg, wc_lo, sw);
             int nb = cur + NBUF - 1;  // the buffer of strip s-1, which the next stage() call re-uses
             nb = nb >= NBUF ? nb - NBUF : nb;
-            if (s + NBUF - 1 < s_hi && p.dbg != 2) slow_next = stage(s + NBUF - 1, wbuf + nb * BUF);
+            if (s + NBUF - 1 < s_hi && p.dbg < 2) {
+                if (NBUF == 2) {  // (two buffers: the staging cursor runs one strip ahead, not two)
+                    slow_next = stage(sc, wbuf + nb * BUF);
+                    advance(sc);
+                } else {
+                    slow_next = stage(sc, wbuf + nb * BUF);
+                    advance(sc);
+                }
+            }
+            tick(2);
             if (p.dbg != 1) {
                 const bool edge = 2 * wr + 1 >= p.Ho || 2 * (wc_lo + ((sw + 3) & ~3)) > p.Wo || 4 * wr + XR > p.H || 4 * (wc_lo + sw) + 4 > p.W ||
                                   (POOLED && (wr >= p.PHo || wc_lo + ((sw + 3) & ~3) > p.PWo));
-                if (edge) compute(std::true_type(), wr, wc_lo, sw, wbuf + cur * BUF);
-                else compute(std::false_type(), wr, wc_lo, sw, wbuf + cur * BUF);
+                if (edge) compute(std::true_type(), wr, wc_lo, sw, wbuf + cur * BUF, late);
+                else compute(std::false_type(), wr, wc_lo, sw, wbuf + cur * BUF, late);
+            } else if (late) {
+                __builtin_amdgcn_s_barrier();
             }
+            if constexpr (kExp == 6) asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
+            tick(3);
             const int nxt = cur + 1 == NBUF ? 0 : cur + 1;
-            if (s + 1 < s_hi && wr + 1 < p.WR && p.dbg != 2) {
+            if (s + 1 < s_hi && wr + 1 < p.WR && p.dbg < 2) {
                 // strip s+1 continues this one (same image, same column segment, next window row): its input row 0 is this
                 // strip's row 4 -- handed over LDS -> LDS (3 channels x 17 16-byte chunks; its DMA leaves row 0 alone) instead of a
                 // second trip to L2 / HBM (the re-read rows were 25 % extra fetch traffic).  Issued behind this strip's MFMAs:
                 // the next stage() call, which re-uses THIS buffer, comes after the dependent ds_write.
                 const float* from = wbuf + cur * BUF;
                 float* to = wbuf + nxt * BUF;
+                // (inline asm: for a compiler-visible LDS access the waitcnt pass inserts s_waitcnt vmcnt(0) -- it cannot tell that the
+                // in-flight LDS-DMA writes of the strips ahead land elsewhere -- which drained the whole prefetch pipeline once per strip)
                 if (lane < CI * (XP / 4)) {
                     const int ci = lane / (XP / 4), ch = lane - ci * (XP / 4);
-                    const float4 v = *(const float4*)(from + (ci * XR + 4) * XP + 4 * ch);
-                    *(float4*)(to + (ci * XR) * XP + 4 * ch) = v;
+                    const unsigned a_from = (unsigned)(uintptr_t)(lds_void_ptr)(from + (ci * XR + 4) * XP + 4 * ch);
+                    const unsigned a_to = (unsigned)(uintptr_t)(lds_void_ptr)(to + (ci * XR) * XP + 4 * ch);
+                    f32x4 v;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b128 %2, %0\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(v)
+                                 : "v"(a_from), "v"(a_to)
+                                 : "memory");
                 }
             }
             cur = nxt;
+            tick(4);
+        }
+        if constexpr (kExp == 6) {
+            if (lane == 0 && blockIdx.x < 256)
+                for (int i = 0; i < 5; ++i) g_prof[blockIdx.x * 8 + wave][i] = tp[i];
         }
     }
 
@@ -372,6 +502,12 @@ bool make_win_params(const cnn_conv2d_desc* d, WinParams* p, int* grid) {
     *grid = (int)g;
     p->strips_per_wave = (int)((strips + g * kWaves - 1) / (g * kWaves));
     p->dbg = getenv("CNN_AMD_WIN_DBG") ? atoi(getenv("CNN_AMD_WIN_DBG")) : 0;
+    {
+        // default on: the eight waves of a workgroup walk eight neighbouring column-segment runs; in step they share the delta rows'
+        // 128-byte lines in L2 (PMC: 1.37x -> 1.02x of the algorithmic fetch).  Needs the same trip count in every wave.
+        const char* e = getenv("CNN_AMD_WIN_LOCKSTEP");
+        p->lockstep = ((!e || atoi(e) != 0) && strips == (long long)g * kWaves * p->strips_per_wave) ? (e ? atoi(e) : 1) : 0;
+    }
     return true;
 }
 
@@ -391,6 +527,21 @@ int launch_win(const cnn_conv2d_desc* d, WinParams& p, int grid, hipStream_t s, 
         CNN_KLAUNCH(s, name, (conv_wgrad_win_kernel<POOLED, true><<<grid, kWaves * 64, lds_bytes, s>>>(p)), CONV_TAG(d));
     else
         CNN_KLAUNCH(s, name, (conv_wgrad_win_kernel<POOLED, false><<<grid, kWaves * 64, lds_bytes, s>>>(p)), CONV_TAG(d));
+    if constexpr (kExp == 6) {  // per-phase cycle counters of the strip loop (timing experiments only)
+        static unsigned long long h[256 * 8][8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h));
+        const char* names[5] = {"barrier", "dma wait", "stage issue", "compute", "hand-over"};
+        for (int w = 0; w < 8; ++w) {
+            fprintf(stderr, "[win prof %s] wave %d:", name, w);
+            for (int i = 0; i < 5; ++i) {
+                double sum = 0;
+                for (int g = 0; g < grid && g < 256; ++g) sum += (double)h[g * 8 + w][i];
+                fprintf(stderr, "  %s %.0f", names[i], sum / (grid < 256 ? grid : 256) / p.strips_per_wave);
+            }
+            fprintf(stderr, "  (cycles per strip)\n");
+        }
+    }
     return CNN_AMD_OK;
 }
 }  // namespace
