@@ -45,6 +45,8 @@ SIGNATURES = {
     "cnn_conv2d_relu_maxpool2_forward_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P]),
     "cnn_conv2d_backward_pooled2_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P, C.c_int]),
     "cnn_conv2d_backward_weight_pooled2": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P]),
+    "cnn_conv2d_backward_weight_pooled2_sgd": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, C.c_float, C.c_float, _P, _P, _P,
+                                                          C.c_size_t, _P]),
     "cnn_conv2d_backward_data_pooled2": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_backward_data_pooled2_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "cnn_conv2d_prepared_bytes": (C.c_size_t, [_D]),
@@ -61,6 +63,8 @@ SIGNATURES = {
     "cnn_conv2d_backward_workspace_bytes": (C.c_size_t, [_D]),
     "cnn_conv2d_backward": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P, C.c_int]),
     "cnn_amd_side_stream_join": (C.c_int, [_P]),
+    "cnn_amd_side_stream_get": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "cnn_amd_flush_reduces": (C.c_int, [_P]),
     "cnn_conv2d_im2col_workspace_bytes": (C.c_size_t, [_D]),
     "cnn_conv2d_forward_im2col": (C.c_int, [_D, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_backward_weight_im2col": (C.c_int, [_D, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P]),
@@ -232,6 +236,18 @@ class Conv2d:
                                                           _ptr(pooled) if pooled is not None else None, _ptr(gw),
                                                           _ptr(gb), float(divisor), _ptr(self.ws), self.ws_bytes, _stream()),
               "cnn_conv2d_backward_weight_pooled2")
+        return gw, gb
+
+    def backward_weight_pooled2_sgd(self, x, dpool, mask, pooled, divisor, gw, gb, w, bias, lr, grad_scale, prepared_fwd, prepared_dgrad):
+        """backward_weight_pooled2 + this layer's SGD step + its re-prepared filters (one extra launch)"""
+        _need_gpu(x, dpool, mask, gw, gb, w, bias)
+        check(self.lib.cnn_conv2d_backward_weight_pooled2_sgd(C.byref(self.desc), _ptr(x), _ptr(dpool), _ptr(mask),
+                                                              _ptr(pooled) if pooled is not None else None, _ptr(gw), _ptr(gb),
+                                                              float(divisor), _ptr(w), _ptr(bias), float(lr), float(grad_scale),
+                                                              _ptr(prepared_fwd) if prepared_fwd is not None else None,
+                                                              _ptr(prepared_dgrad) if prepared_dgrad is not None else None,
+                                                              _ptr(self.ws), self.ws_bytes, _stream()),
+              "cnn_conv2d_backward_weight_pooled2_sgd")
         return gw, gb
 
     def backward_pooled2_prepared(self, x, dpool, mask, pooled, prepared_dgrad, divisor, gw, gb, dx, defer_join=False):
@@ -589,6 +605,20 @@ def kernel_timing_report():
         key, cnt, ms = line.rsplit("\t", 2)
         out[key] = (int(cnt), float(ms))
     return out
+
+
+def side_stream():
+    """the library's side stream of this thread / device as a torch stream (work queued there runs behind the deferred weight gradients)"""
+    import torch
+
+    out = C.c_void_p()
+    check(load().cnn_amd_side_stream_get(C.byref(out)), "cnn_amd_side_stream_get")
+    return torch.cuda.ExternalStream(out.value)
+
+
+def flush_reduces():
+    """launch the recorded weight-gradient slab reductions on the CURRENT stream now (see cnn_amd_flush_reduces)"""
+    check(load().cnn_amd_flush_reduces(_stream()), "cnn_amd_flush_reduces")
 
 
 def side_stream_join():

@@ -73,6 +73,17 @@ struct DeviceOnce {
     }
 };
 
+// SGD on one element (alexnet.cpp:62-65, conv2d.cpp / linear.cpp update_gradients):
+// p - lr*(g*scale) with every product/sum rounded separately: the reference is built without FMA
+// (x86-64 -O2, CMakeLists.txt:5), so w -= lr*g is mul-then-sub; the fp-contract pragma stops hipcc fusing it
+// (HIP's __fmul_rn/__fsub_rn are plain operators and do get contracted).
+__device__ __forceinline__ float sgd_one(float p, float g, float lr, float scale, bool scaled) {
+#pragma clang fp contract(off)
+    const float gs = scaled ? g * scale : g;
+    const float step = lr * gs;
+    return p - step;
+}
+
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kNumCU = 256;        // MI355X
 constexpr int kNumXCD = 8;

@@ -54,6 +54,14 @@ size_t cnn_conv2d_backward_workspace_bytes(const cnn_conv2d_desc* d) {
     return dgrad_region_bytes(d) + w;
 }
 
+int cnn_amd_side_stream_get(void** side_stream) {
+    CNN_REQUIRE(side_stream != nullptr, "cnn_amd_side_stream_get: null pointer");
+    SideStream* side = nullptr;
+    if (int rc = get_side(&side)) return rc;
+    *side_stream = (void*)side->stream;
+    return CNN_AMD_OK;
+}
+
 int cnn_amd_side_stream_join(void* stream) {
     SideStream* side = nullptr;
     if (int rc = get_side(&side)) return rc;

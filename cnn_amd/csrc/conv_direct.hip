@@ -613,6 +613,82 @@ __global__ void pack_batch(const PackBatch pb) {
     else pack_dgrad_s2_body(jb.w, jb.out, jb.CI, jb.CO, tid, nt);
 }
 
+// ---- end of a single-rank train step for THIS layer in one launch: slab reduction -> gradient -> SGD -> re-packed filters -------
+// The three things that otherwise follow the first layer's weight-gradient kernel one launch each (slab_reduce, sgd_vec over the
+// arena, pack_batch before the next forward pass: ~6 us each, the chip idle in between) for 16 x 28 numbers.  One workgroup, so
+// that nothing has to be synchronised across workgroups:
+//   1. g[i] = (sum over slots of slabs[slot][i]) / divisor in slab_reduce_batch's order (conv_wgrad.hip: eight slot-lanes per
+//      element, each adding its slots in ascending order, then the eight partial sums in order) -- bit-identical to the unfused path;
+//   2. gw / gb receive the gradient (they stay readable), w / bias the SGD step (sgd_one: cnn_sgd_update's arithmetic);
+//   3. the forward / data-gradient filter images of the updated filters (pack_fwd_3_16_3_2_body / pack_dgrad_3_16_3_2_body), read
+//      from the LDS copy of the new values.
+constexpr int kFinThreads = 1024, kFinLanes = 8, kFinN = 16 * 28;
+__global__ __launch_bounds__(kFinThreads) void first_layer_finish(const float* __restrict__ slabs, int nslots, float divisor,
+                                                                  float* __restrict__ gw, float* __restrict__ gb, float* __restrict__ w,
+                                                                  float* __restrict__ bias, float lr, float scale, int scaled,
+                                                                  float* __restrict__ fwd_img, float* __restrict__ dgrad_img) {
+    __shared__ float red[kFinLanes][kFinN];
+    __shared__ float wl[16 * 27], bl[16];
+    constexpr int PAIRS = kFinLanes * kFinN, PER = (PAIRS + kFinThreads - 1) / kFinThreads;  // (element, slot-lane) pairs per thread
+    float acc[PER];
+    int idx[PER], sl[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int pr = threadIdx.x + q * kFinThreads;
+        acc[q] = 0.f;
+        sl[q] = pr / kFinN;
+        idx[q] = pr - sl[q] * kFinN;
+    }
+    const bool last_live = threadIdx.x + (PER - 1) * kFinThreads < PAIRS;
+    if (!last_live) idx[PER - 1] = 0, sl[PER - 1] = 0;  // (loads something valid, stores nothing)
+    // branch-free batches: every load of kBatch slot rounds is issued before the first add (the adds keep their order)
+    constexpr int kBatch = 8;
+    for (int s0 = 0; s0 < nslots; s0 += kBatch * kFinLanes) {
+        float v[kBatch][PER];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u)
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int s = s0 + u * kFinLanes + sl[q];
+                v[u][q] = slabs[(size_t)(s < nslots ? s : 0) * kFinN + idx[q]];
+            }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u)
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const float sum = acc[q] + v[u][q];
+                acc[q] = (s0 + u * kFinLanes + sl[q] < nslots) ? sum : acc[q];
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (q + 1 < PER || last_live) red[sl[q]][idx[q]] = acc[q];
+    __syncthreads();
+    if (threadIdx.x < kFinN) {
+        const int i = threadIdx.x;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < kFinLanes; ++k) t += red[k][i];
+        const float g = t / divisor;
+        const int row = i / 28, col = i - row * 28;
+        if (col < 27) {
+            const int j = row * 27 + col;
+            gw[j] = g;
+            const float v = sgd_one(w[j], g, lr, scale, scaled != 0);
+            w[j] = v;
+            wl[j] = v;
+        } else {
+            if (gb) gb[row] = g;
+            const float v = bias ? sgd_one(bias[row], g, lr, scale, scaled != 0) : 0.f;
+            if (bias) bias[row] = v;
+            bl[row] = v;
+        }
+    }
+    __syncthreads();
+    if (fwd_img) pack_fwd_3_16_3_2_body(wl, bl, fwd_img, threadIdx.x, kFinThreads);
+    if (dgrad_img) pack_dgrad_3_16_3_2_body(wl, dgrad_img, threadIdx.x);
+}
+
 typedef int v2i __attribute__((ext_vector_type(2)));
 
 template <bool RELU>
@@ -1207,6 +1283,19 @@ int direct_conv_wgrad_pooled(const cnn_conv2d_desc* d, const float* x, const flo
                     (conv_wgrad_pk_3_16_3_2<3, 2><<<direct_wgrad_slots(d), kBlock, 0, s>>>(x, dpool, mask, nullptr, slabs, d->B, d->H, d->W,
                                                                                           Ho, Wo, ipi, div_magic(ipi), div_magic(Wo))),
                     CONV_TAG(d));
+    return CNN_AMD_OK;
+}
+
+// see first_layer_finish; slabs: the [nslots][16][28] output of direct_conv_wgrad*(), images as cnn_conv2d_prepare_filters writes them
+int direct_first_layer_finish(const cnn_conv2d_desc* d, const float* slabs, int nslots, float divisor, float* gw, float* gb, float* w,
+                              float* bias, float lr, float grad_scale, void* fwd_img, void* dgrad_img, hipStream_t s) {
+    CNN_REQUIRE(direct_conv_supported(d), "first_layer_finish: geometry not covered");
+    CNN_REQUIRE(!fwd_img || direct_fwd_pk_ok(d), "first_layer_finish: this layer has no packed forward kernel");
+    CNN_REQUIRE(!dgrad_img || direct_dgrad_pk_ok(d), "first_layer_finish: this layer has no packed data-gradient kernel");
+    CNN_KLAUNCH(s, "first_layer_finish",
+                (first_layer_finish<<<1, kFinThreads, 0, s>>>(slabs, nslots, divisor, gw, gb, w, bias, lr, grad_scale, grad_scale != 1.0f ? 1 : 0,
+                                                              (float*)fwd_img, (float*)dgrad_img)),
+                CONV_TAG(d));
     return CNN_AMD_OK;
 }
 

@@ -20,6 +20,8 @@ int direct_conv_wgrad(const cnn_conv2d_desc* d, const float* x, const float* dy,
 bool direct_conv_pool_supported(const cnn_conv2d_desc* d);
 int direct_conv_wgrad_pooled(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask, const float* pooled,
                              float* slabs, hipStream_t s);
+int direct_first_layer_finish(const cnn_conv2d_desc* d, const float* slabs, int nslots, float divisor, float* gw, float* gb, float* w,
+                              float* bias, float lr, float grad_scale, void* fwd_img, void* dgrad_img, hipStream_t s);
 int wgrad_rd_slots(const cnn_conv2d_desc* d);  // conv_wgrad_rd.hip: register-direct MFMA kernel (3x3, stride 1/2, pad 0)
 int wgrad_rd_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
 int wgrad_rd_pooled_slots(const cnn_conv2d_desc* d);
@@ -702,6 +704,34 @@ int cnn_conv2d_backward_weight_pooled2(const cnn_conv2d_desc* d, const float* x,
     snprintf(tagd, sizeof(tagd), CONV_TAG(d));
     return reduce_slabs(sd, (const float*)ws, ds, n, (float*)ws + (size_t)ds * n, gw, divisor, tagd, 27, gb);
 }
+
+int cnn_conv2d_backward_weight_pooled2_sgd(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask,
+                                           const float* pooled, float* gw, float* gb, float divisor, float* w, float* bias, float lr,
+                                           float grad_scale, void* fwd_prepared, void* dgrad_prepared, void* ws, size_t ws_bytes,
+                                           void* stream) {
+    if (int rc = check_desc("cnn_conv2d_backward_weight_pooled2_sgd", d)) return rc;
+    CNN_REQUIRE(x && dpool && mask && gw && gb && w && bias, "cnn_conv2d_backward_weight_pooled2_sgd: null pointer");
+    CNN_REQUIRE(divisor != 0.f, "cnn_conv2d_backward_weight_pooled2_sgd: divisor is 0");
+    const int ds = direct_wgrad_slots(d);
+    CNN_REQUIRE(ds > 0 && direct_conv_pool_supported(d), "cnn_conv2d_backward_weight_pooled2_sgd: geometry not covered");
+    const size_t n = 16 * 28;
+    hipStream_t sd = as_stream(stream);
+    int slots = ds;
+    const int rs = first_layer_rd() ? wgrad_rd_pooled_slots(d) : 0;
+    if (rs > 0 && ws != nullptr && ws_bytes >= (size_t)rs * n * sizeof(float)) {
+        slots = rs;
+        if (int rc = wgrad_rd_launch_pooled(d, x, dpool, mask, pooled, (float*)ws, sd)) return rc;
+    } else {
+        CNN_REQUIRE(ws != nullptr && ws_bytes >= (size_t)ds * n * sizeof(float),
+                    "cnn_conv2d_backward_weight_pooled2_sgd: workspace too small (%zu < %zu bytes)", ws_bytes, (size_t)ds * n * sizeof(float));
+        if (int rc = direct_conv_wgrad_pooled(d, x, dpool, mask, pooled, (float*)ws, sd)) return rc;
+    }
+    // (more than 512 slabs would go through a two-stage reduction in the unfused path: a different summation order)
+    CNN_REQUIRE(slots <= 512, "cnn_conv2d_backward_weight_pooled2_sgd: %d slabs", slots);
+    return direct_first_layer_finish(d, (const float*)ws, slots, divisor, gw, gb, w, bias, lr, grad_scale, fwd_prepared, dgrad_prepared, sd);
+}
+
+int cnn_amd_flush_reduces(void* stream) { return flush_reduces(as_stream(stream)); }
 
 int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const float* dy, float* gw, float* gb,
                                float divisor, void* ws, size_t ws_bytes, void* stream) {

@@ -63,15 +63,7 @@ __global__ __launch_bounds__(kBlock) void dropout_bwd(float* __restrict__ d, siz
     }
 }
 
-// p - lr*(g*scale) with every product/sum rounded separately: the reference is built without FMA
-// (x86-64 -O2, CMakeLists.txt:5), so w -= lr*g is mul-then-sub; the fp-contract pragma stops hipcc fusing it
-// (HIP's __fmul_rn/__fsub_rn are plain operators and do get contracted).
-__device__ __forceinline__ float sgd_one(float p, float g, float lr, float scale, bool scaled) {
-#pragma clang fp contract(off)
-    const float gs = scaled ? g * scale : g;
-    const float step = lr * gs;
-    return p - step;
-}
+// sgd_one(): common.h
 // (the <= 3 trailing elements of an arena whose length is not a multiple of 4 ride along in workgroup 0)
 __global__ __launch_bounds__(kBlock) void sgd_vec(float4* __restrict__ p, const float4* __restrict__ g, size_t n4,
                                                   size_t n, float lr, float scale, bool scaled) {

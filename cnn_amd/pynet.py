@@ -97,6 +97,16 @@ class AlexNetHip:
             self.parity = 0
             self.pending_dx0 = None   # prepared-filter buffer of the step whose conv1 dgrad has not been launched yet
             self.b_in_flight = False
+        # Single-rank steps (train_step without a process group) end without a tail of small launches: the slab reductions, the
+        # SGD step and the re-prepared filters of conv_layer_2..4 and the linear layer are queued on the library's side stream as
+        # soon as their gradients are complete and run UNDER conv_layer_1's weight-gradient kernel; that kernel is followed by
+        # one small launch (reduction + SGD + filter images of conv_layer_1) and the next forward pass starts right behind it.
+        # Before: slab_reduce, sgd_vec, pack_batch, rd_prepare one after the other, ~35 us of a 490 us step with the chip idle.
+        self.early_update = self.defer_dx0 and self.fuse_pool and not os.environ.get("CNN_AMD_NO_EARLY_UPDATE")
+        self._side = None
+        self._updated = False
+        if self.early_update:
+            self.ev_early = torch.cuda.Event()
 
     @property
     def loss_sum(self):
@@ -235,7 +245,22 @@ class AlexNetHip:
         return self.delta
 
     # ---- alexnet.cpp:49-59; `divisor` is the batch size the gradients are averaged over on THIS rank ----
-    def backward(self, delta, divisor=None):
+    def _early_update(self, lr, scale):
+        """side stream: reductions, SGD and filter images of everything behind conv_layer_1 (see __init__)"""
+        torch = self.torch
+        self.ev_early.record(torch.cuda.current_stream())  # their readers (the data gradients of layers 2-4) are queued
+        if self._side is None:
+            self._side = capi.side_stream()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(self.ev_early)
+            capi.flush_reduces()
+            lo = self.w_off[1]
+            capi.sgd_update(self.params[lo:], self.grads[lo:], lr, scale)
+            capi.prepare_filters(self.convs[1:], [self.conv_w(l) for l in (1, 2, 3)], [self.conv_b(l) for l in (1, 2, 3)],
+                                 [p[0] for p in self.prep[1:]], [p[1] for p in self.prep[1:]])
+
+    def backward(self, delta, divisor=None, sgd=None):
+        """sgd = (lr, grad_scale): the single-rank train step -- parameters are updated and filters re-prepared inside the pass"""
         div = float(self.B if divisor is None else divisor)
         g = self.grads
         # fuse_bwd_relu: every ReLU::backward runs inside the kernel that PRODUCES its delta (the linear backward for
@@ -253,7 +278,17 @@ class AlexNetHip:
                 # conv_layer_1 from the pooled domain: cur = d pool_out
                 # (with fbr the ReLU mask was already applied by conv_layer_2's data gradient: pooled = None)
                 pooled = None if fbr else self.pool_out
-                if self.defer_dx0:
+                if self.defer_dx0 and sgd is not None and self.early_update:
+                    self._early_update(*sgd)
+                    nxt = self.parity ^ 1  # (the deferred data gradient of THIS step still reads the filters of this step)
+                    self.convs[0].backward_weight_pooled2_sgd(self.x, cur, self.pool_mask, pooled, div, self.conv_w(0, g), self.conv_b(0, g),
+                                                              self.conv_w(0), self.conv_b(0), sgd[0], sgd[1], self.prep[0][0],
+                                                              self.prep0_dgrad[nxt])
+                    self.pending_dx0 = (self.prep0_dgrad[self.parity], cur, self.pool_mask, pooled)
+                    self.parity = nxt
+                    self._updated = True
+                    self._prep_valid = True
+                elif self.defer_dx0:
                     self.convs[0].backward_weight_pooled2(self.x, cur, self.pool_mask, pooled, div, self.conv_w(0, g), self.conv_b(0, g))
                     self.pending_dx0 = (self.prep0_dgrad[self.parity], cur, self.pool_mask, pooled)
                 else:  # both gradients now, concurrently (weight gradient on the library's side stream)
@@ -292,6 +327,9 @@ class AlexNetHip:
 
     # ---- alexnet.cpp:62-65 (+ the data-parallel mean) ----
     def update(self, lr, grad_scale=1.0):
+        if self._updated:  # backward(sgd=...) has done it
+            self._updated = False
+            return
         capi.sgd_update(self.params, self.grads, lr, grad_scale)
         self._prep_valid = False
 
@@ -300,7 +338,10 @@ class AlexNetHip:
         (1/B)*sum_local, all-reduce(sum) over `world` ranks, then x(1/world) folded into the SGD kernel."""
         self.forward(x, labels=labels)
         self.loss_backward_seed(labels)
-        self.backward(self.delta)
         from .dp import allreduce_grads
 
+        if dist is None and world == 1 and self.early_update and self._prep_valid:
+            self.backward(self.delta, sgd=(lr, 1.0))
+        else:
+            self.backward(self.delta)
         self.update(lr, allreduce_grads(self.grads, dist, world))

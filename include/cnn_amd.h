@@ -106,6 +106,14 @@ int cnn_conv2d_backward_weight_pooled2(const cnn_conv2d_desc* d, const float* x,
                                        size_t workspace_bytes, void* stream);
 int cnn_conv2d_backward_data_pooled2(const cnn_conv2d_desc* d, const float* dpool, const int32_t* mask, const float* pooled,
                                      const float* w, float* dx, void* workspace, size_t workspace_bytes, void* stream);
+/* cnn_conv2d_backward_weight_pooled2 followed -- in ONE more launch instead of three -- by this layer's share of the end of a
+ * single-rank train step: gw/gb as above, then w/bias -= lr * (grad_scale * gw/gb) (cnn_sgd_update's arithmetic, alexnet.cpp:62-65
+ * -> conv2d.cpp update_gradients) and the layer's prepared filters (cnn_conv2d_prepare_filters images of the UPDATED w/bias;
+ * either may be NULL).  Bit-identical to the three separate calls.  workspace as for cnn_conv2d_backward_weight_pooled2. */
+int cnn_conv2d_backward_weight_pooled2_sgd(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask,
+                                           const float* pooled, float* gw, float* gb, float divisor, float* w, float* bias, float lr,
+                                           float grad_scale, void* fwd_prepared, void* dgrad_prepared, void* workspace,
+                                           size_t workspace_bytes, void* stream);
 
 /* replaces conv2d.cpp:117-159: gw = (sum_b sum_pq dy*x)/divisor, gb = (sum_b sum_pq dy)/divisor.
  * The reference divides by the batch size per sample and accumulates (:148,:157); pass divisor = B of the
@@ -137,6 +145,13 @@ size_t cnn_conv2d_backward_workspace_bytes(const cnn_conv2d_desc* d);
 int cnn_conv2d_backward(const cnn_conv2d_desc* d, const float* x, const float* dy, const float* w, float* gw, float* gb,
                         float* dx, float divisor, void* ws, size_t ws_bytes, void* stream, int defer_join);
 int cnn_amd_side_stream_join(void* stream);
+/* For callers that schedule more work behind the deferred weight gradients (e.g. the SGD step and the re-prepared filters of the
+ * layers whose gradients are complete, while the first layers' backward kernels still run on `stream`):
+ *   cnn_amd_side_stream_get   the side stream (hipStream_t) of the calling thread on the current device;
+ *   cnn_amd_flush_reduces     launches the recorded slab reductions of the calling thread on `stream` NOW -- normally the side
+ *                             stream -- instead of at the join (gw/gb of those layers are then ordered on that stream). */
+int cnn_amd_side_stream_get(void** side_stream);
+int cnn_amd_flush_reduces(void* stream);
 
 /* im2col + plain tiled GEMM: functional fallback kept ONLY for parity checks of the three calls above */
 size_t cnn_conv2d_im2col_workspace_bytes(const cnn_conv2d_desc* d);

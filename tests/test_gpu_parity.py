@@ -711,6 +711,54 @@ def test_conv_backward_from_pooled_domain_is_bit_identical(T, shape):
     assert np.array_equal(host(gw3), host(gw_ref)) and np.array_equal(host(gb3), host(gb_ref)) and np.array_equal(host(dx3), host(dx_ref))
 
 
+@pytest.mark.parametrize("shape", [(256, 224, 224), (2, 224, 224), (3, 37, 41), (5, 7, 5)], ids=lambda s: "B%d_%dx%d" % s)
+@pytest.mark.parametrize("scale", [1.0, 0.5])
+def test_first_layer_weight_gradient_sgd_prepare_fusion_is_bit_identical(T, shape, scale):
+    """cnn_conv2d_backward_weight_pooled2_sgd == cnn_conv2d_backward_weight_pooled2 + cnn_sgd_update (on w and bias) +
+    cnn_conv2d_prepare_filters: gradients, updated parameters and both filter images, bit for bit"""
+    from cnn_amd import capi
+
+    B, H, W = shape
+    case = (B, 3, H, W, 16, 3, 2, 0)
+    x, w, b, _ = _conv_inputs(case, 610)
+    conv = capi.Conv2d(*case)
+    xd, wd, bd = dev(T, x - 0.5), dev(T, w), dev(T, b)
+    Ho, Wo = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    PHo, PWo = Ho // 2, Wo // 2
+    pooled = T.empty((B, 16, PHo, PWo), device="cuda")
+    mask = T.empty((B, 16, PHo, PWo), dtype=T.int32, device="cuda")
+    conv.relu_maxpool2_forward(xd, wd, bd, pooled, mask)
+    dpool = dev(T, uniform_pm1(611, (B, 16, PHo, PWo)))
+    lr = 0.05
+    # reference: three calls
+    gw_ref, gb_ref = T.empty_like(wd), T.empty_like(bd)
+    conv.backward_weight_pooled2(xd, dpool, mask, pooled, float(B), gw_ref, gb_ref)
+    w_ref, b_ref = wd.clone(), bd.clone()
+    capi.sgd_update(w_ref.view(-1), gw_ref.view(-1), lr, scale)
+    capi.sgd_update(b_ref, gb_ref, lr, scale)
+    pf_ref, pd_ref = conv.prepared_buffers("cuda")
+    pf_ref.zero_(); pd_ref.zero_()
+    capi.prepare_filters([conv], [w_ref], [b_ref], [pf_ref], [pd_ref])
+    # fused
+    gw, gb, w2, b2 = T.full_like(wd, 7.0), T.full_like(bd, 7.0), wd.clone(), bd.clone()
+    pf, pd = conv.prepared_buffers("cuda")
+    pf.zero_(); pd.zero_()
+    conv.backward_weight_pooled2_sgd(xd, dpool, mask, pooled, float(B), gw, gb, w2, b2, lr, scale, pf, pd)
+    T.cuda.synchronize()
+    u32 = lambda t: host(t).view(np.uint32)
+    assert np.array_equal(u32(gw), u32(gw_ref)) and np.array_equal(u32(gb), u32(gb_ref))
+    assert np.array_equal(u32(w2), u32(w_ref)) and np.array_equal(u32(b2), u32(b_ref))
+    assert not np.array_equal(u32(w2), u32(wd))
+    nf, nd = 28 * 16, 16 * 32  # floats of the two images (conv_direct.hip: [tap | bias][co], [co][32])
+    assert np.array_equal(host(pf).view(np.uint32).ravel()[:nf], host(pf_ref).view(np.uint32).ravel()[:nf])
+    assert np.array_equal(host(pd).view(np.uint32).ravel()[:nd], host(pd_ref).view(np.uint32).ravel()[:nd])
+    # the images are usable: forward from the new image == forward with the new raw filters
+    y1 = T.empty_like(pooled); y2 = T.empty_like(pooled)
+    conv.relu_maxpool2_forward(xd, None, None, y1, None, prepared_fwd=pf)
+    conv.relu_maxpool2_forward(xd, w_ref, b_ref, y2, None)
+    assert T.equal(y1, y2)
+
+
 @pytest.mark.parametrize("defer", [False, True], ids=["in_order", "deferred_dx0"])
 def test_pool_fused_net_is_bit_identical(T, defer):
     """pynet(fuse_pool=True): conv_layer_1 / relu_layer_1 / max_pool_1 as one forward kernel and their backward pass from
