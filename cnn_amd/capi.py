@@ -65,6 +65,8 @@ SIGNATURES = {
     "cnn_amd_side_stream_join": (C.c_int, [_P]),
     "cnn_amd_side_stream_get": (C.c_int, [C.POINTER(C.c_void_p)]),
     "cnn_amd_flush_reduces": (C.c_int, [_P]),
+    "cnn_amd_publish_next_kernel": (C.c_int, [_P]),
+    "cnn_amd_wait_published": (C.c_int, [_P]),
     "cnn_conv2d_im2col_workspace_bytes": (C.c_size_t, [_D]),
     "cnn_conv2d_forward_im2col": (C.c_int, [_D, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_backward_weight_im2col": (C.c_int, [_D, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P]),
@@ -619,6 +621,16 @@ def side_stream():
 def flush_reduces():
     """launch the recorded weight-gradient slab reductions on the CURRENT stream now (see cnn_amd_flush_reduces)"""
     check(load().cnn_amd_flush_reduces(_stream()), "cnn_amd_flush_reduces")
+
+
+def publish_next_kernel():
+    """the next library kernel on the current stream publishes its completion (see cnn_amd_publish_next_kernel)"""
+    check(load().cnn_amd_publish_next_kernel(_stream()), "cnn_amd_publish_next_kernel")
+
+
+def wait_published(stream=None):
+    """`stream` (a torch stream; default: the current one) waits for the published kernel"""
+    check(load().cnn_amd_wait_published(C.c_void_p(stream.cuda_stream) if stream is not None else _stream()), "cnn_amd_wait_published")
 
 
 def side_stream_join():

@@ -20,6 +20,55 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// ---- published kernels (common.h) ---------------------------------------------------------------------------------------------
+PublishState& publish_state() {
+    static thread_local PublishState st;
+    return st;
+}
+namespace {
+int publish_events(PublishState& p) {
+    int dev = 0;
+    CNN_HIP_CHECK(hipGetDevice(&dev));
+    if (p.ev[0] == nullptr || p.device != dev) {  // (a thread that moves to another device gets fresh events; the old pair is kept alive)
+        CNN_HIP_CHECK(hipEventCreateWithFlags(&p.ev[0], hipEventDisableTiming));
+        CNN_HIP_CHECK(hipEventCreateWithFlags(&p.ev[1], hipEventDisableTiming));
+        p.device = dev;
+        p.valid = false;
+    }
+    return CNN_AMD_OK;
+}
+thread_local bool g_just_published = false;
+}  // namespace
+
+hipEvent_t publish_take(hipStream_t s) {
+    PublishState& p = publish_state();
+    if (!p.armed || p.stream != s) return nullptr;
+    p.cur ^= 1;
+    p.armed = false;
+    p.valid = true;
+    p.stale = false;
+    g_just_published = true;
+    return p.ev[p.cur];
+}
+
+int publish_after_launch(hipStream_t s) {
+    PublishState& p = publish_state();
+    if (p.armed && p.stream == s) {  // launched by a site without launch_pub(): the marker packet after all
+        p.cur ^= 1;
+        CNN_HIP_CHECK(hipEventRecord(p.ev[p.cur], s));
+        p.armed = false;
+        p.valid = true;
+        p.stale = false;
+        g_just_published = false;
+        return CNN_AMD_OK;
+    }
+    if (p.valid && p.stream == s) {
+        if (g_just_published) g_just_published = false;
+        else p.stale = true;
+    }
+    return CNN_AMD_OK;
+}
+
 // ---- per-kernel event timing -----------------------------------------------------------------------------
 namespace {
 struct KRecord {
@@ -318,6 +367,21 @@ int cnn_batch_stager_release(void* stager, int slot, void* stream) {
     CNN_REQUIRE(st && slot >= 0 && slot < st->depth, "cnn_batch_stager_release: bad arguments");
     CNN_HIP_CHECK(hipEventRecord(st->consumed[slot], as_stream(stream)));
     st->in_use[slot] = 1;
+    return CNN_AMD_OK;
+}
+
+int cnn_amd_publish_next_kernel(void* stream) {
+    PublishState& p = publish_state();
+    if (int rc = publish_events(p)) return rc;
+    p.armed = true;
+    p.stream = as_stream(stream);
+    return CNN_AMD_OK;
+}
+
+int cnn_amd_wait_published(void* stream) {
+    PublishState& p = publish_state();
+    CNN_REQUIRE(p.valid && !p.armed, "cnn_amd_wait_published: %s", p.armed ? "the armed kernel has not been launched yet" : "nothing has been published");
+    CNN_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), p.ev[p.cur], 0));
     return CNN_AMD_OK;
 }
 

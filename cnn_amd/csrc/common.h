@@ -1,6 +1,7 @@
 // common.h -- shared host-side helpers for the libcnn_amd.so translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <atomic>
 #include <cstdarg>
@@ -32,6 +33,37 @@ bool ktimer_active();
 void ktimer_begin(hipStream_t s, const char* kernel, const char* fmt, ...);
 void ktimer_end(hipStream_t s);
 
+// ---- "published" kernels: a cross-stream dependency without a marker packet on the producing stream -------------------------
+// hipEventRecord between two kernels of one stream costs that stream ~4.5 us (measured, tools/micro/event_gap.hip: the marker
+// packet has to retire before the next dispatch); an event attached to the producing kernel's OWN dispatch packet
+// (hipExtLaunchKernelGGL's stopEvent) costs ~1.7 us and releases the waiting stream ~4 us sooner.  cnn_amd_publish_next_kernel(stream)
+// arms the calling thread: the next kernel the library launches on `stream` carries the event -- through launch_pub() at the launch
+// sites that sit in front of a fork in the train step, through a plain hipEventRecord behind any other launch (same meaning,
+// old cost).  Consumers: cnn_amd_wait_published(), and the fork of cnn_conv2d_backward*(defer_join = 2).
+struct PublishState {
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int cur = 0, device = -1;
+    bool armed = false;   // the next launch on `stream` publishes
+    bool valid = false;   // ev[cur] marks the completion of the last published kernel ...
+    bool stale = false;   // ... but the library has launched something else on that stream since
+    hipStream_t stream = nullptr;
+};
+PublishState& publish_state();                   // per host thread (abi.hip)
+hipEvent_t publish_take(hipStream_t s);          // armed for s: the event to attach (state -> published), else nullptr
+int publish_after_launch(hipStream_t s);         // bookkeeping behind EVERY launch (fallback record / staleness)
+inline bool publish_busy() {
+    const PublishState& p = publish_state();
+    return p.armed || (p.valid && !p.stale);
+}
+
+// kernel launch that can carry the published event (use inside CNN_KLAUNCH instead of kernel<<<...>>>(...))
+template <typename... KArgs, typename... Args>
+inline void launch_pub(void (*kern)(KArgs...), dim3 grid, dim3 block, unsigned shmem, hipStream_t s, Args&&... args) {
+    hipEvent_t ev = publish_take(s);
+    if (ev) hipExtLaunchKernelGGL(kern, grid, block, shmem, s, nullptr, ev, 0, static_cast<KArgs>(args)...);
+    else hipLaunchKernelGGL(kern, grid, block, shmem, s, static_cast<KArgs>(args)...);
+}
+
 // launch `expr` (a kernel<<<...>>>(...) expression), timed when profiling is on; `...` = printf-style geometry tag
 #define CNN_KLAUNCH(stream, kernel_name, expr, ...)                                         \
     do {                                                                                    \
@@ -40,6 +72,8 @@ void ktimer_end(hipStream_t s);
         expr;                                                                               \
         if (t__) ::cnn_amd::ktimer_end(stream);                                             \
         CNN_LAUNCH_CHECK();                                                                 \
+        if (::cnn_amd::publish_busy())                                                      \
+            if (int prc__ = ::cnn_amd::publish_after_launch(stream)) return prc__;          \
     } while (0)
 
 #define CNN_REQUIRE(cond, ...)                                             \

@@ -43,6 +43,18 @@ bool heavy_layer(const cnn_conv2d_desc* d) {
     static const double limit = getenv("CNN_AMD_SERIAL_BWD_GFLOP") ? atof(getenv("CNN_AMD_SERIAL_BWD_GFLOP")) * 1e9 : 2e10;
     return flops >= limit;
 }
+// the side stream waits for everything queued on `main` so far.  When the last thing the library launched on `main` is a published
+// kernel (common.h) its dispatch event is that point already: no marker packet on the critical stream.
+int fork_side(SideStream* side, hipStream_t main) {
+    const PublishState& p = publish_state();
+    if (p.valid && !p.stale && p.stream == main) {
+        CNN_HIP_CHECK(hipStreamWaitEvent(side->stream, p.ev[p.cur], 0));
+        return CNN_AMD_OK;
+    }
+    CNN_HIP_CHECK(hipEventRecord(side->fork, main));
+    CNN_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+    return CNN_AMD_OK;
+}
 size_t dgrad_region_bytes(const cnn_conv2d_desc* d) { return ((igemm_workspace_floats(d) + 63) / 64) * 64 * sizeof(float); }
 }  // namespace
 
@@ -92,8 +104,7 @@ int cnn_conv2d_backward(const cnn_conv2d_desc* d, const float* x, const float* d
         if (int rc = cnn_conv2d_backward_data(d, dy, w, dx, base, dbytes, main)) return rc;
         return cnn_conv2d_backward_weight(d, x, dy, gw, gb, divisor, base + dbytes, ws_bytes - dbytes, main);
     }
-    CNN_HIP_CHECK(hipEventRecord(side->fork, main));
-    CNN_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+    if (int rc = fork_side(side, main)) return rc;
     wgrad_defer_reduce(defer_join != 0);
     const int rcw = cnn_conv2d_backward_weight(d, x, dy, gw, gb, divisor, base + dbytes, ws_bytes - dbytes, side->stream);
     wgrad_defer_reduce(false);
@@ -125,8 +136,7 @@ int cnn_conv2d_backward_prepared_relu(const cnn_conv2d_desc* d, const float* x, 
             return rc;
         return cnn_conv2d_backward_weight(d, x, dy, gw, gb, divisor, ws, ws_bytes, main);
     }
-    CNN_HIP_CHECK(hipEventRecord(side->fork, main));
-    CNN_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+    if (int rc = fork_side(side, main)) return rc;
     wgrad_defer_reduce(defer_join != 0);
     const int rcw = cnn_conv2d_backward_weight(d, x, dy, gw, gb, divisor, ws, ws_bytes, side->stream);
     wgrad_defer_reduce(false);
@@ -150,8 +160,7 @@ int cnn_conv2d_backward_pooled2_prepared(const cnn_conv2d_desc* d, const float* 
     SideStream* side = nullptr;
     if (int rc = get_side(&side)) return rc;
     hipStream_t main = as_stream(stream);
-    CNN_HIP_CHECK(hipEventRecord(side->fork, main));
-    CNN_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+    if (int rc = fork_side(side, main)) return rc;
     wgrad_defer_reduce(defer_join != 0);
     const int rcw = cnn_conv2d_backward_weight_pooled2(d, x, dpool, mask, pooled, gw, gb, divisor, ws, ws_bytes, side->stream);
     wgrad_defer_reduce(false);

@@ -748,7 +748,7 @@ int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const floa
         char nm[64];
         snprintf(nm, sizeof(nm), "conv_dgrad_rd<2,%d,m16>/dgrad%s", d->Co, relu_below ? "+relu" : "");
 #define M16(CO_, PREP_, NW_, KS_)                                                                                                        \
-    CNN_KLAUNCH(s, nm, (conv_dgrad_m16_s2_kernel<CO_, NW_, PREP_, KS_><<<pl.blocks_x, NW_ * 64, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", \
+    CNN_KLAUNCH(s, nm, (launch_pub(conv_dgrad_m16_s2_kernel<CO_, NW_, PREP_, KS_>, dim3(pl.blocks_x), dim3(NW_ * 64), 0, s, pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", \
                 d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad)
         if (d->Co == 32) { if (pl.p.tr == 2) M16(32, true, 4, 1); else M16(32, false, 4, 1); }
         else if (d->Co == 64) { if (pl.p.tr == 2) M16(64, true, 4, 1); else M16(64, false, 4, 1); }

@@ -529,7 +529,7 @@ int fwd_rd_forward(const cnn_conv2d_desc* d, const float* x, const float* w, con
         pl.p.tiles = pl.m16_parts;
         snprintf(name, sizeof(name), "conv_fwd_rd<%d,%d,m16>/fwd%s", d->s, d->Ci, y_relu ? "+relu" : "");
 #define M16K(S_, CI_, PREP_, MS_)                                                                                                            \
-    CNN_KLAUNCH(s, name, (conv_fwd_m16_kernel<S_, CI_, 4, PREP_, 4, MS_><<<pl.m16_blocks, 256, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", \
+    CNN_KLAUNCH(s, name, (launch_pub(conv_fwd_m16_kernel<S_, CI_, 4, PREP_, 4, MS_>, dim3(pl.m16_blocks), dim3(256), 0, s, pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", \
                 d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad)
 #define M16(S_, CI_)                                                          \
     do {                                                                      \

@@ -299,11 +299,11 @@ static int linear_backward_impl(const float* x, const float* dy, const float* w,
     if (gw && gb && dx && x && w && out <= kOutTile) {
         if (relu_below)
             CNN_KLAUNCH(s, "linear_bwd_fused+relu",
-                        (linear_bwd_fused<true><<<ceil_div(in, kNeur), kNeur * kFG, 0, s>>>(x, dy, w, gw, gb, dx, B, in, out, divisor)),
+                        (launch_pub(linear_bwd_fused<true>, dim3(ceil_div(in, kNeur)), dim3(kNeur * kFG), 0, s, x, dy, w, gw, gb, dx, B, in, out, divisor)),
                         "B%d in%d out%d", B, in, out);
         else
             CNN_KLAUNCH(s, "linear_bwd_fused",
-                        (linear_bwd_fused<false><<<ceil_div(in, kNeur), kNeur * kFG, 0, s>>>(x, dy, w, gw, gb, dx, B, in, out, divisor)),
+                        (launch_pub(linear_bwd_fused<false>, dim3(ceil_div(in, kNeur)), dim3(kNeur * kFG), 0, s, x, dy, w, gw, gb, dx, B, in, out, divisor)),
                         "B%d in%d out%d", B, in, out);
         return CNN_AMD_OK;
     }

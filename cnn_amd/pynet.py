@@ -105,6 +105,7 @@ class AlexNetHip:
         self.early_update = self.defer_dx0 and self.fuse_pool and not os.environ.get("CNN_AMD_NO_EARLY_UPDATE")
         self._side = None
         self._updated = False
+        self._publish = not os.environ.get("CNN_AMD_NO_PUBLISH")  # (A/B switch: plain event records at the forks)
         if self.early_update:
             self.ev_early = torch.cuda.Event()
 
@@ -152,15 +153,19 @@ class AlexNetHip:
                                  [p[0] for p in self.prep], dg)
             self._prep_valid = True
 
-    def _launch_pending_dx0(self, gated):
+    def _launch_pending_dx0(self, gated, published=False):
         """conv_layer_1's data gradient of the PREVIOUS backward pass, on the second stream"""
         if not self.defer_dx0 or self.pending_dx0 is None:
             return
         torch = self.torch
         main = torch.cuda.current_stream()
-        self.ev_release.record(main)
+        if published:  # the kernel just launched carries the event (capi.publish_next_kernel): no marker packet on the main stream
+            capi.wait_published(self.side_b)
+        else:
+            self.ev_release.record(main)
         with torch.cuda.stream(self.side_b):
-            self.side_b.wait_event(self.ev_release)  # gated: not before this point of the main stream
+            if not published:
+                self.side_b.wait_event(self.ev_release)  # gated: not before this point of the main stream
             if self.fuse_pool:
                 prep_dg, dpool, mask, pooled = self.pending_dx0
                 self.convs[0].backward_data_pooled2(dpool, mask, pooled, None, self.d_conv[0], prepared_dgrad=prep_dg)
@@ -193,6 +198,9 @@ class AlexNetHip:
         if self.use_prep:
             self._prepare()
         for l in range(4):
+            release_here = self.defer_dx0 and l == self._dx0_release and self.pending_dx0 is not None and self._publish
+            if release_here:
+                capi.publish_next_kernel()  # this layer's forward kernel releases the deferred data gradient
             if l == 0 and self.fuse_pool:
                 self.pool_cur = (self.pool_cur + 1) % len(self.pool_sets)
                 self.pool_out, self.pool_mask = self.pool_sets[self.pool_cur]
@@ -221,7 +229,7 @@ class AlexNetHip:
                 # release point of the deferred conv1 data gradient, measured (images/s at batch 256, same box): no
                 # deferral 261.0k | before conv1 ~249k | after max_pool_1 ~257k | after conv_layer_2 269.3k | after
                 # conv_layer_3 264.5k -- it then overlaps the latency-bound layers 3-4, the linear layer and the loss
-                self._launch_pending_dx0(gated=True)
+                self._launch_pending_dx0(gated=True, published=release_here)
         if labels is not None and self.use_prep and self.classes <= 8 and not self._no_head_fusion:
             capi.check(capi.load().cnn_linear_forward_softmax_xent(capi._ptr(cur), capi._ptr(self.lin_w()), capi._ptr(self.lin_b()),
                                                                    capi._ptr(labels), capi._ptr(self.logits), capi._ptr(self.probs),
@@ -248,11 +256,16 @@ class AlexNetHip:
     def _early_update(self, lr, scale):
         """side stream: reductions, SGD and filter images of everything behind conv_layer_1 (see __init__)"""
         torch = self.torch
-        self.ev_early.record(torch.cuda.current_stream())  # their readers (the data gradients of layers 2-4) are queued
         if self._side is None:
             self._side = capi.side_stream()
+        # behind their readers (the data gradients of layers 2-4): conv_layer_2's data gradient is the published kernel
+        if self._publish:
+            capi.wait_published(self._side)
+        else:
+            self.ev_early.record(torch.cuda.current_stream())
         with torch.cuda.stream(self._side):
-            self._side.wait_event(self.ev_early)
+            if not self._publish:
+                self._side.wait_event(self.ev_early)
             capi.flush_reduces()
             lo = self.w_off[1]
             capi.sgd_update(self.params[lo:], self.grads[lo:], lr, scale)
@@ -266,6 +279,9 @@ class AlexNetHip:
         # fuse_bwd_relu: every ReLU::backward runs inside the kernel that PRODUCES its delta (the linear backward for
         # relu_layer_4, the data gradient of conv_layer_{l+1} for relu_layer_l)
         fbr = self.use_prep and not self._no_fbr
+        pub = self._publish and self.use_prep
+        if pub:
+            capi.publish_next_kernel()  # (each data-gradient kernel is the fork point of the next layer's weight gradient)
         capi.linear_backward(self.relu_out[3].view(self.B, self.lin_in), delta, self.lin_w(), div, self.lin_w(g),
                              self.lin_b(g), self.d_lin, relu_below=fbr)
         cur = self.d_lin.view(self.relu_out[3].shape)
@@ -313,6 +329,8 @@ class AlexNetHip:
                 self.convs[0].backward_weight(lin, cur, div, self.conv_w(0, g), self.conv_b(0, g))
                 self.pending_dx0 = self.prep0_dgrad[self.parity]
             elif self.use_prep:
+                if pub:
+                    capi.publish_next_kernel()
                 # lin is relu_out[l-1] for l >= 2: its ReLU::backward is fused into this data gradient; for l == 1 in a pool-fused
                 # net lin = pool_out, and masking d(pool_out) by (pool_out <= 0) IS relu_layer_1's backward pass in the pooled
                 # domain (at an argmax position the ReLU output equals the pooled value)

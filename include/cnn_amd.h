@@ -152,6 +152,16 @@ int cnn_amd_side_stream_join(void* stream);
  *                             stream -- instead of at the join (gw/gb of those layers are then ordered on that stream). */
 int cnn_amd_side_stream_get(void** side_stream);
 int cnn_amd_flush_reduces(void* stream);
+/* Cross-stream dependencies without a marker packet on the producing stream (an event recorded BETWEEN two kernels costs that
+ * stream ~4.5 us on this hardware; an event carried by the producing kernel's own dispatch ~1.7 us):
+ *   cnn_amd_publish_next_kernel(stream)  the next kernel this thread launches on `stream` through the library publishes its
+ *                                        completion (forward, data-gradient and linear-backward kernels of the reference net
+ *                                        carry it in their dispatch packet; any other kernel is followed by a plain event record);
+ *   cnn_amd_wait_published(other)        `other` waits for that kernel = cnn_event_record + cnn_stream_wait_event.
+ * cnn_conv2d_backward*() use the published kernel as their fork point when it is the last thing the library launched on
+ * `stream`: the caller asserts that nothing else the weight gradient depends on was queued on that stream behind it. */
+int cnn_amd_publish_next_kernel(void* stream);
+int cnn_amd_wait_published(void* stream);
 
 /* im2col + plain tiled GEMM: functional fallback kept ONLY for parity checks of the three calls above */
 size_t cnn_conv2d_im2col_workspace_bytes(const cnn_conv2d_desc* d);
