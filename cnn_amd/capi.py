@@ -65,6 +65,7 @@ SIGNATURES = {
     "cnn_amd_side_stream_join": (C.c_int, [_P]),
     "cnn_amd_side_stream_get": (C.c_int, [C.POINTER(C.c_void_p)]),
     "cnn_amd_flush_reduces": (C.c_int, [_P]),
+    "cnn_grad_cam": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "cnn_amd_publish_next_kernel": (C.c_int, [_P]),
     "cnn_amd_wait_published": (C.c_int, [_P]),
     "cnn_conv2d_im2col_workspace_bytes": (C.c_size_t, [_D]),
@@ -607,6 +608,18 @@ def kernel_timing_report():
         key, cnt, ms = line.rsplit("\t", 2)
         out[key] = (int(cnt), float(ms))
     return out
+
+
+def grad_cam(feature):
+    """AlexNet::grad_cam's arithmetic on a [B][C][H][W] feature map: (normalised cam [B][H][W], uint8 image [H][W] of plane 0)"""
+    import torch
+
+    _need_gpu(feature)
+    B, Cc, H, W = feature.shape
+    cam = torch.empty((B, H, W), dtype=torch.float32, device=feature.device)
+    img = torch.empty((H, W), dtype=torch.uint8, device=feature.device)
+    check(load().cnn_grad_cam(_ptr(feature), B, Cc, H, W, _ptr(cam), _ptr(img), _stream()), "cnn_grad_cam")
+    return cam, img
 
 
 def side_stream():

@@ -136,6 +136,75 @@ __global__ __launch_bounds__(kBlock) void softmax_xent_kernel(const float* __res
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+
+// ---- AlexNet::grad_cam (alexnet.cpp:107-140) on a [B][C][H][W] feature map -------------------------------------------------
+// weights[b][o] = (sum_i fea[b][o][i]) / area, sequential in i (:111-119; the reference takes the channel mean of the FEATURE MAP,
+// not of a gradient); cam[b][i] = sum_o weights[b][o] * fea[b][o][i], sequential in o, multiply-then-add (:124-131); ReLU as
+// `if (v < 0) v = 0` (:134).  One workgroup per sample: thread t owns channels t, t+256, ... in the first phase, pixels in the second.
+__global__ __launch_bounds__(kBlock) void grad_cam_maps(const float* __restrict__ fea, float* __restrict__ cam, int C, int area) {
+    extern __shared__ float wts[];
+    const float* fb = fea + (size_t)blockIdx.x * C * area;
+    for (int o = threadIdx.x; o < C; o += kBlock) {
+        const float* f = fb + (size_t)o * area;
+        float m = 0.f;
+        for (int i = 0; i < area; ++i) m += f[i];
+        wts[o] = m / area;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < area; i += kBlock) {
+#pragma clang fp contract(off)
+        float acc = 0.f;
+        for (int o = 0; o < C; ++o) {
+            const float prod = wts[o] * fb[(size_t)o * area + i];
+            acc = acc + prod;
+        }
+        if (acc < 0.f) acc = 0.f;
+        cam[(size_t)blockIdx.x * area + i] = acc;
+    }
+}
+// min-max normalisation over the WHOLE [B][H][W] tensor (:136-139; Tensor3D::min/max = first extremum with strict comparisons,
+// data_format.cpp:37-62: a NaN is only ever returned from element 0) and the 8-bit image of the first plane (opecv_mat(1),
+// data_format.cpp:98-103: saturate_cast<uchar>(255 * v) = round to nearest even, clamped)
+__global__ __launch_bounds__(kBlock) void grad_cam_normalise(float* __restrict__ cam, unsigned char* __restrict__ image, size_t n, int area) {
+    __shared__ float smin[kBlock], smax[kBlock];
+    const float first = cam[0];
+    float lo = INFINITY, hi = -INFINITY;
+    for (size_t i = threadIdx.x; i < n; i += kBlock) {
+        const float v = cam[i];
+        if (v < lo) lo = v;
+        if (v > hi) hi = v;
+    }
+    smin[threadIdx.x] = lo;
+    smax[threadIdx.x] = hi;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            if (smin[threadIdx.x + off] < smin[threadIdx.x]) smin[threadIdx.x] = smin[threadIdx.x + off];
+            if (smax[threadIdx.x + off] > smax[threadIdx.x]) smax[threadIdx.x] = smax[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    // element 0 is the start value of both scans: a NaN there survives every comparison; all-NaN tails leave +-inf, which the
+    // reference cannot produce (it starts from element 0) -- fall back to element 0 then
+    float mn = smin[0], mx = smax[0];
+    if (first != first) mn = mx = first;
+    else {
+        if (!(mn <= first)) mn = first;
+        if (!(mx >= first)) mx = first;
+    }
+    const float res = mx - mn;
+    __syncthreads();
+    for (size_t i = threadIdx.x; i < n; i += kBlock) {
+        const float v = (cam[i] - mn) / res;
+        cam[i] = v;
+        if (image && i < (size_t)area) {
+            const float sv = 255.f * v;
+            int r = (sv != sv) ? 0 : (sv >= 255.5f ? 255 : (sv <= -0.5f ? 0 : __float2int_rn(sv)));
+            image[i] = (unsigned char)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -224,6 +293,18 @@ int cnn_dropout_backward(float* dy_inout, int B, int C, int H, int W, int droppe
     const size_t n = (size_t)B * C * H * W;
     hipStream_t s = as_stream(stream);
     CNN_KLAUNCH(s, "dropout_bwd", (dropout_bwd<<<stream_grid(n, kBlock), kBlock, 0, s>>>(dy_inout, n, C, H * W, dropped_channels)), "n=%zu", n);
+    return CNN_AMD_OK;
+}
+
+
+int cnn_grad_cam(const float* feature, int B, int C, int H, int W, float* cam, unsigned char* image, void* stream) {
+    CNN_REQUIRE(feature && cam, "cnn_grad_cam: null pointer");
+    CNN_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && (long long)H * W < (1ll << 31), "cnn_grad_cam: B=%d C=%d H=%d W=%d", B, C, H, W);
+    CNN_REQUIRE((size_t)C * sizeof(float) <= 64 * 1024, "cnn_grad_cam: C=%d channels exceed the 64 KB weight table", C);
+    hipStream_t s = as_stream(stream);
+    const int area = H * W;
+    CNN_KLAUNCH(s, "grad_cam_maps", (grad_cam_maps<<<B, kBlock, (size_t)C * sizeof(float), s>>>(feature, cam, C, area)), "B%d C%d %dx%d", B, C, H, W);
+    CNN_KLAUNCH(s, "grad_cam_normalise", (grad_cam_normalise<<<1, kBlock, 0, s>>>(cam, image, (size_t)B * area, area)), "n=%zu", (size_t)B * area);
     return CNN_AMD_OK;
 }
 

@@ -335,6 +335,10 @@ public:
     void update_gradients(const data_type learning_rate, const data_type grad_scale);
     void save_weights(const std::filesystem::path& save_path) const;
     void load_weights(const std::filesystem::path& checkpoint_path);
+    // alexnet.cpp:95-142 (cv::Mat -> the H*W 8-bit pixels of that matrix, row-major; see cnn_grad_cam).  Like the reference it
+    // assumes a forward pass with gradients enabled has just run, walks backward() down to the named layer and reads that
+    // layer's get_output(); `cam_out` (optional) receives the normalised [B][H][W] map the picture is taken from.
+    std::vector<uchar> grad_cam(const std::string& layer_name, std::vector<data_type>* cam_out = nullptr) const;
     // additions
     size_t num_params() const;
     data_type* params_device() const { return param_arena; }

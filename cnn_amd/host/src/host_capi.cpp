@@ -216,4 +216,18 @@ int cnnh_net_layer_output(void* hv, const char* layer_name, float* out, size_t c
     return 1;
 }
 
+// Sequential::grad_cam (alexnet.cpp:95-142): image_out H*W bytes, cam_out (nullable) B*H*W floats; returns 0, or 1 for an unknown layer
+int cnnh_net_grad_cam(void* hv, const char* layer_name, unsigned char* image_out, size_t image_cap, float* cam_out, size_t cam_cap) {
+    Handle* h = (Handle*)hv;
+    bool found = false;
+    for (const auto& layer : h->net->layers()) found = found || layer->name == layer_name;
+    if (!found) return 1;
+    std::vector<float> cam;
+    const std::vector<uchar> img = h->net->grad_cam(layer_name, cam_out ? &cam : nullptr);
+    if (img.size() > image_cap || (cam_out && cam.size() > cam_cap)) return 2;
+    std::memcpy(image_out, img.data(), img.size());
+    if (cam_out) std::memcpy(cam_out, cam.data(), sizeof(float) * cam.size());
+    return 0;
+}
+
 }  // extern "C"

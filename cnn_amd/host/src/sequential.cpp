@@ -189,6 +189,39 @@ void Sequential::backward(std::vector<tensor>& delta_start) {
     must(cnn_amd_side_stream_join(stream), "cnn_amd_side_stream_join");
 }
 
+std::vector<uchar> Sequential::grad_cam(const std::string& layer_name, std::vector<data_type>* cam_out) const {
+    // alexnet.cpp:97-102: from the logits down to (not including) the named layer.  The reference computes this delta and never
+    // uses it (its channel weights are means of the FEATURE MAP, :111-119); the walk is kept for its side effects on the layers.
+    std::vector<tensor> delta = layers_sequence.back()->get_output();
+    auto layer = layers_sequence.rbegin();
+    for (; layer != layers_sequence.rend(); ++layer) {
+        if ((*layer)->name == layer_name) break;
+        delta = (*layer)->backward(delta);
+    }
+    assert(layer != layers_sequence.rend() && "grad_cam: no layer of that name");
+    must(cnn_amd_side_stream_join(stream), "cnn_amd_side_stream_join");
+    assert(!fuse_pool_block && "grad_cam reads Layer::get_output() of a convolution: not materialised under fuse_pool_block");
+    const std::vector<tensor> feature_map = (*layer)->get_output();  // alexnet.cpp:105
+    const int B = (int)feature_map.size(), C = feature_map[0]->C, H = feature_map[0]->H, W = feature_map[0]->W;
+    BatchBuffer staging;
+    const data_type* fea = batch_device_pointer(feature_map, staging, "grad_cam");
+    void* cam_dev = nullptr;
+    void* img_dev = nullptr;
+    must(cnn_device_alloc(&cam_dev, sizeof(data_type) * (size_t)B * H * W), "cnn_device_alloc");
+    must(cnn_device_alloc(&img_dev, (size_t)H * W), "cnn_device_alloc");
+    must(cnn_grad_cam(fea, B, C, H, W, (data_type*)cam_dev, (unsigned char*)img_dev, stream), "cnn_grad_cam");
+    std::vector<uchar> image((size_t)H * W);
+    must(cnn_memcpy_d2h(image.data(), img_dev, image.size(), stream), "cnn_memcpy_d2h");
+    if (cam_out) {
+        cam_out->resize((size_t)B * H * W);
+        must(cnn_memcpy_d2h(cam_out->data(), cam_dev, sizeof(data_type) * cam_out->size(), stream), "cnn_memcpy_d2h");
+    }
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+    must(cnn_device_free(cam_dev), "cnn_device_free");
+    must(cnn_device_free(img_dev), "cnn_device_free");
+    return image;
+}
+
 void Sequential::parameters_changed() {
     filters_prepared = false;  // re-prepared at the start of the next forward pass
     for (auto& layer : layers_sequence)

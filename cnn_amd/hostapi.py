@@ -49,6 +49,7 @@ SIGNATURES = {
     "cnnh_net_train_step_device_loss": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]),
     "cnnh_net_last_loss": (C.c_float, [C.c_void_p]),
     "cnnh_net_layer_output": (C.c_int, [C.c_void_p, C.c_char_p, _F, C.c_size_t]),
+    "cnnh_net_grad_cam": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, _F, C.c_size_t]),
 }
 
 
@@ -177,6 +178,18 @@ class HostNet:
         if rc != 0:
             raise KeyError(f"layer {name}: rc={rc}")
         return out
+
+
+    def grad_cam(self, layer_name, shape):
+        """Sequential::grad_cam (alexnet.cpp:95-142) after a forward pass with gradients enabled; shape = (B, H, W) of the layer's
+        feature map.  Returns (uint8 image [H][W] -- the reference's cv::Mat --, normalised cam [B][H][W])"""
+        B, H, W = shape
+        img = np.empty((H, W), np.uint8)
+        cam = np.empty((B, H, W), np.float32)
+        rc = self.lib.cnnh_net_grad_cam(self.h, layer_name.encode(), img.ctypes.data_as(C.c_void_p), img.size, _fp(cam), cam.size)
+        if rc != 0:
+            raise KeyError(f"grad_cam({layer_name}): rc={rc}")
+        return img, cam
 
 
 class HostAlexNet(HostNet):

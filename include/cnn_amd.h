@@ -300,6 +300,12 @@ int cnn_batchnorm2d_backward_from_sums(const float* x, float* dy, const float* g
  * whose kernels each divided by their local batch. */
 int cnn_sgd_update(float* params, const float* grads, size_t n, float lr, float grad_scale, void* stream);
 
+/* AlexNet::grad_cam (alexnet.cpp:107-140) from the feature map of the chosen layer, [B][C][H][W] on the device:
+ *   weights[b][o] = mean_i feature[b][o][i];  cam[b] = ReLU(sum_o weights[b][o] * feature[b][o]);  cam = (cam - min) / (max - min)
+ * with min / max over the whole [B][H][W] tensor (:136-139).  cam: [B][H][W] floats (output).  image (nullable): H*W bytes, the 8-bit
+ * picture of the FIRST plane -- what the reference returns as cv::Mat through Tensor3D::opecv_mat(1) (data_format.cpp:98-103). */
+int cnn_grad_cam(const float* feature, int B, int C, int H, int W, float* cam, unsigned char* image, void* stream);
+
 /* ---- data-parallel gradient exchange (new: the reference is single-process) -------------
  * The batch is sharded over G replicas (one per GPU); the only cross-sample coupling of the path is the batch mean inside
  * the weight / bias gradients (conv2d.cpp:148,157; linear.cpp:62,70).  Every replica's kernels divide by their LOCAL batch,

@@ -280,6 +280,55 @@ void SUF(oracle_dropout_backward)(real* dy, int B, int C, int area, real p) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * AlexNet::grad_cam  (cpu/src/alexnet.cpp:95-142) -- the arithmetic behind the returned picture.  PARITY UNPINNED: the function
+ * returns cv::Mat and cannot be built here, and the reference holds no vector for it; this follows the loops line by line.
+ * ---------------------------------------------------------------------------------------- */
+
+/* alexnet.cpp:107-140 on the feature map [B][C][H][W] of the chosen layer.  :111-119 weights[b][o] = (sum_i fea)/area -- the
+ * channel mean of the FEATURE MAP (the delta computed in :97-102 is not used); :121-131 cam[b][i] = sum_o w * fea, in o order;
+ * :133-134 ReLU `if (v < 0) v = 0`; :136-139 min-max normalisation over the whole [B][H][W] tensor with Tensor3D::min / max
+ * (data_format.cpp:37-62: first extremum, strict comparisons).  image (nullable): opecv_mat(1) of the result = the first plane as
+ * saturate_cast<uchar>(255 * v) (data_format.cpp:98-103; cvRound = lrint, clamped; NaN -> 0). */
+void SUF(oracle_grad_cam)(const real* fea, int B, int C, int H, int W, real* cam, unsigned char* image) {
+    const int area = H * W;
+    real* weights = (real*)malloc(sizeof(real) * (size_t)B * C);
+    for (int b = 0; b < B; ++b)
+        for (int o = 0; o < C; ++o) {
+            const real* f = fea + ((size_t)b * C + o) * area;
+            real mean_value = 0;
+            for (int i = 0; i < area; ++i) mean_value += f[i];
+            weights[b * C + o] = mean_value / area;
+        }
+    const size_t length = (size_t)B * area;
+    memset(cam, 0, sizeof(real) * length);
+    for (int b = 0; b < B; ++b) {
+        real* c = cam + (size_t)b * area;
+        for (int o = 0; o < C; ++o) {
+            const real w = weights[b * C + o];
+            const real* f = fea + ((size_t)b * C + o) * area;
+            for (int i = 0; i < area; ++i) c[i] += w * f[i];
+        }
+    }
+    free(weights);
+    for (size_t i = 0; i < length; ++i)
+        if (cam[i] < 0) cam[i] = 0;
+    size_t lo = 0, hi = 0;
+    for (size_t i = 1; i < length; ++i) {
+        if (cam[i] < cam[lo]) lo = i;
+        if (cam[i] > cam[hi]) hi = i;
+    }
+    const real min_value = cam[lo], max_value = cam[hi];
+    const real res_value = max_value - min_value;
+    for (size_t i = 0; i < length; ++i) cam[i] = (cam[i] - min_value) / res_value;
+    if (image)
+        for (int i = 0; i < area; ++i) {
+            const real sv = 255 * cam[i];
+            long r = (sv != sv) ? 0 : lrint((double)sv);
+            image[i] = (unsigned char)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
  * LinearLayer  (cpu/src/linear.cpp); W stored [in][out] row-major (linear.cpp:40)
  * ---------------------------------------------------------------------------------------- */
 

@@ -51,6 +51,7 @@ def _declare(L):
         sig("oracle_relu_backward", None, P, P, C.c_size_t)
         sig("oracle_dropout_forward", None, P, P, I, I, I, real, I)
         sig("oracle_dropout_backward", None, P, I, I, I, real)
+        sig("oracle_grad_cam", None, P, I, I, I, I, P, C.c_void_p)
         sig("oracle_linear_forward", None, P, P, P, P, I, I, I)
         sig("oracle_linear_backward", None, P, P, P, P, P, P, I, I, I)
         sig("oracle_batchnorm_forward", None, P, P, P, P, P, P, P, P, P, I, I, I, I, real, real, I)
@@ -195,6 +196,17 @@ def dropout_backward(dy, p, f64=False):
     B, Cc, H, W = d.shape
     getattr(lib(), "oracle_dropout_backward" + suf)(_p(d, ct), B, Cc, H * W, ct(p))
     return d
+
+
+def grad_cam(feature, f64=False):
+    """(normalised cam [B][H][W], uint8 image [H][W] of plane 0) -- alexnet.cpp:107-140"""
+    dt, ct, suf = _dt(f64)
+    f = _c(feature, dt)
+    B, Cc, H, W = f.shape
+    cam = np.empty((B, H, W), dtype=dt)
+    img = np.empty((H, W), dtype=np.uint8)
+    getattr(lib(), "oracle_grad_cam" + suf)(_p(f, ct), B, Cc, H, W, _p(cam, ct), img.ctypes.data_as(C.c_void_p))
+    return cam, img
 
 
 def linear_forward(x, w, bias, f64=False):

@@ -933,3 +933,26 @@ def test_linear_forward_softmax_xent_fusion_is_bit_identical(T, B, n_in, n_out):
     capi.check(lib.cnn_loss_from_terms(capi._ptr(terms), capi._ptr(loss1), B, capi._stream()), "cnn_loss_from_terms")
     for a, c in ((logits0, logits1), (probs0, probs1), (delta0, delta1), (loss0, loss1)):
         assert np.array_equal(host(a).view(np.uint32), host(c).view(np.uint32))
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 13, 13), (4, 64, 13, 13), (3, 128, 6, 6), (2, 16, 111, 111), (5, 7, 3, 5)], ids=lambda s: "B%d_C%d_%dx%d" % s)
+def test_grad_cam_matches_oracle_bit_for_bit(T, shape):
+    """cnn_grad_cam == the restatement of alexnet.cpp:107-140: same summation orders, so the normalised map and the 8-bit picture
+    are identical (also with negative maps, a constant plane, and a NaN in element 0)"""
+    from cnn_amd import capi
+    from oracle import pyoracle as O
+
+    rng = np.random.default_rng(11)
+    f = (rng.standard_normal(shape) * 0.5 + 0.1).astype(np.float32)
+    for variant in range(3):
+        g = f.copy()
+        if variant == 1:
+            g[0, 0] = -3.0  # a plane that drives sample 0 negative in places
+        if variant == 2:
+            g[0, :, 0, 0] = np.nan
+        cam_o, img_o = O.grad_cam(g)
+        cam, img = capi.grad_cam(dev(T, g))
+        got = host(cam)
+        same = (got.view(np.uint32) == cam_o.view(np.uint32)) | (np.isnan(got) & np.isnan(cam_o))  # (NaN payloads are not compared)
+        assert same.all(), (variant, int((~same).sum()))
+        assert np.array_equal(host(img), img_o), variant

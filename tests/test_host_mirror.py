@@ -278,3 +278,30 @@ def test_host_train_step_on_device_matches_the_reference_loop(pool_block):
         ref_net.close()
     finally:
         hostapi.load().cnnh_set_fuse_pool_block(0)
+
+
+@pytest.mark.gpu
+def test_host_grad_cam_on_the_readme_images(golden_dir):
+    """Sequential::grad_cam("conv_layer_3") -- grad_cam.cpp:73-80's call -- on the README images with the shipped checkpoint:
+    the picture equals the oracle's arithmetic (alexnet.cpp:107-140) on that layer's get_output(), the backward walk of
+    alexnet.cpp:97-102 runs (its side effects only), and the layer's output is unchanged by it"""
+    from cnn_amd import hostapi
+    from oracle import pyoracle as O
+
+    imgs = np.load(os.path.join(golden_dir, "readme_kat_images_u8.npy"))
+    ckpt = os.path.join(golden_dir, "readme_kat_checkpoint.model")
+    x = np.ascontiguousarray((imgs.astype(np.float32) * np.float32(1.0) / np.float32(255)).transpose(0, 3, 1, 2))
+    for batch in (x[:1], x):  # grad_cam.cpp feeds one image; a batch normalises over all its maps together
+        net = hostapi.HostAlexNet(3)
+        net.load_checkpoint(ckpt)
+        net.forward_host(batch)  # gradients enabled (grad_cam.cpp:56)
+        B = batch.shape[0]
+        fea = net.layer_output("conv_layer_3", (B, 64, 13, 13))
+        img, cam = net.grad_cam("conv_layer_3", (B, 13, 13))
+        cam_o, img_o = O.grad_cam(fea)
+        assert np.array_equal(cam.view(np.uint32), cam_o.view(np.uint32)) and np.array_equal(img, img_o)
+        assert img.max() == 255 or B > 1  # one image: its own maximum maps to 255
+        assert np.array_equal(net.layer_output("conv_layer_3", (B, 64, 13, 13)), fea)
+        with pytest.raises(KeyError):
+            net.grad_cam("no_such_layer", (B, 13, 13))
+        net.close()

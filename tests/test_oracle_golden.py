@@ -189,3 +189,28 @@ def test_stack_layer_lists():
     assert sum(e["kind"] == "conv" for e in r) == 17 and sum(e["kind"] == "bn" for e in r) == 17
     assert r[-1]["n_in"] == 512 * 7 * 7
     assert {(e["k"], e["s"]) for e in r if e["kind"] == "conv"} == {(7, 2), (3, 1), (3, 2), (1, 2)}
+
+
+def test_oracle_grad_cam_restatement():
+    """alexnet.cpp:107-140 (PARITY UNPINNED: the reference cannot be built and holds no vector for it): the fp32 restatement
+    against an independent numpy statement in fp64, its own fp64 build, and the properties the loops guarantee"""
+    from oracle import pyoracle as O
+
+    rng = np.random.default_rng(7)
+    f = (rng.standard_normal((3, 64, 13, 13)) * 0.5 + 0.2).astype(np.float32)
+    cam, img = O.grad_cam(f)
+    cam64, img64 = O.grad_cam(f, f64=True)
+    w = f.astype(np.float64).mean(axis=(2, 3))
+    ref = np.maximum((w[:, :, None, None] * f).sum(1), 0)
+    ref = (ref - ref.min()) / (ref.max() - ref.min())
+    assert np.abs(cam64 - ref).max() < 1e-12 and np.abs(cam - ref).max() < 1e-5
+    assert cam.min() == 0.0 and cam.max() == 1.0  # min-max normalised over the WHOLE batch tensor (:136-139)
+    assert np.abs(img.astype(int) - np.rint(255 * ref[0]).astype(int)).max() <= 1 and np.abs(img.astype(int) - img64.astype(int)).max() <= 1
+    # the weights are channel means of the feature map itself (:111-119), so scaling the map by a > 0 leaves the picture alone
+    cam2, img2 = O.grad_cam((f * np.float32(4.0)))
+    assert np.abs(cam2 - cam).max() < 1e-6 and np.array_equal(img2, img)
+    # a NaN in element 0 of the map poisons min and max (Tensor3D::min/max start from element 0): everything becomes NaN -> pixel 0
+    g = f.copy()
+    g[0, :, 0, 0] = np.nan
+    camn, imgn = O.grad_cam(g)
+    assert np.isnan(camn).all() and (imgn == 0).all()
