@@ -88,6 +88,7 @@ private:
     ReLU* fused_relu = nullptr;  // the ReLU layer right behind this convolution (set by the container), or null
     MaxPool2D* fused_pool = nullptr;  // ... and the MaxPool2D(2,2) behind that ReLU: Conv -> ReLU -> MaxPool in one kernel
     ReLU* relu_below = nullptr;       // the ReLU layer whose output is this layer's input: its backward pass is fused in
+    bool publish_backward = false;
     MaxPool2D* pool_below = nullptr;  // the MaxPool2D whose output is this layer's input, when that pool closes a fusable
                                       // Conv2D -> ReLU -> MaxPool2D(2,2) block (fuse_pool_block): see backward()
     bool pool_fused_pass = false;     // this pass' forward went through the pooled kernel: backward receives d(pool output)
@@ -128,6 +129,9 @@ public:
     void set_fused_pool(MaxPool2D* pool) { fused_pool = pool; }
     void set_relu_below(ReLU* relu) { relu_below = relu; }
     void set_pool_below(MaxPool2D* pool) { pool_below = pool; }
+    // addition: the layer that consumes this layer's data gradient next is a convolution (only fused-away layers in between):
+    // the data-gradient kernel then publishes its completion (cnn_amd_publish_next_kernel) for that layer's weight-gradient fork
+    void set_publish_backward(bool on) { publish_backward = on; }
     // additions: filter re-layout hoisted out of forward / backward (cnn_conv2d_prepare_filters); the container prepares
     // all layers with one call after every parameter change and switches the layers to the *_prepared entry points
     bool shape_known() const { return batch > 0; }
@@ -202,9 +206,11 @@ private:
     std::vector<tensor> saved_input_tensors;
     int batch = 0;
     ReLU* relu_below = nullptr;  // the ReLU layer whose output is this layer's input: its backward pass is fused in
+    bool publish_backward = false;
 
 public:
     void set_relu_below(ReLU* relu) { relu_below = relu; }  // addition (see architectures::fuse_layers)
+    void set_publish_backward(bool on) { publish_backward = on; }  // (see Conv2D::set_publish_backward)
     // addition: forward + softmax + cross-entropy delta in ONE kernel (cnn_linear_forward_softmax_xent, out_channels <= 8):
     // labels_dev int32 [B]; delta_dev [B][out] receives p - onehot (func.cpp:56-73), loss_terms_dev [B] log p[label]
     bool loss_head_supported() const { return out_channels <= 8; }

@@ -254,6 +254,7 @@ std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
         const bool pooled_mask = relu_below == nullptr && pool_below != nullptr && pool_below->passthrough_armed();
         const data_type* rb = (relu_below != nullptr || pooled_mask) ? saved_input : nullptr;
         if (pooled_mask) pool_below->set_delta_premasked();
+        if (publish_backward && rb != nullptr) must(cnn_amd_publish_next_kernel(stream), "cnn_amd_publish_next_kernel");
         must(cnn_conv2d_backward_prepared_relu(&d, saved_input, dy, prep_dgrad, rb, grads,
                                                grads + (size_t)out_channels * params_for_one_kernel, delta_buf.base, (float)B,
                                                workspace, workspace_bytes, stream, /*defer_join=*/1),
@@ -714,6 +715,7 @@ std::vector<tensor> LinearLayer::backward(std::vector<tensor>& delta) {
         delta_buf.allocate(batch, std::get<0>(delta_shape), std::get<1>(delta_shape), std::get<2>(delta_shape),
                            "linear_delta");
     if (relu_below != nullptr && fuse_layers) {  // the input IS that ReLU's output: its backward mask in the same kernel
+        if (publish_backward) must(cnn_amd_publish_next_kernel(stream), "cnn_amd_publish_next_kernel");
         must(cnn_linear_backward_relu(saved_input, dy, params, grads, grads + (size_t)in_channels * out_channels, delta_buf.base, B,
                                       in_channels, out_channels, (float)B, stream),
              "cnn_linear_backward_relu");

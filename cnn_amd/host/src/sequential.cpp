@@ -49,6 +49,17 @@ void Sequential::wire() {
             if (auto* conv = dynamic_cast<Conv2D*>(next->get())) conv->set_relu_below(relu);
             if (auto* lin = dynamic_cast<LinearLayer*>(next->get())) lin->set_relu_below(relu);
         }
+        // Conv2D -> ReLU -> {Conv2D, LinearLayer} (or Conv2D -> ReLU -> MaxPool2D -> Conv2D): the data gradient of the upper layer is
+        // the last kernel in front of the lower convolution's weight-gradient fork whenever the ReLU (and pool) backward passes are
+        // fused away -- it then carries the fork event in its own dispatch packet (cnn_amd_publish_next_kernel)
+        if (dynamic_cast<Conv2D*>(it->get()) && dynamic_cast<ReLU*>(next->get())) {
+            auto after = std::next(next);
+            if (after != layers_sequence.end() && dynamic_cast<MaxPool2D*>(after->get())) after = std::next(after);
+            if (after != layers_sequence.end()) {
+                if (auto* conv = dynamic_cast<Conv2D*>(after->get())) conv->set_publish_backward(true);
+                if (auto* lin = dynamic_cast<LinearLayer*>(after->get())) lin->set_publish_backward(true);
+            }
+        }
         // Conv2D -> ReLU -> MaxPool2D: one forward kernel, backward from the pooled domain (opt-in: fuse_pool_block)
         auto next2 = std::next(next);
         if (next2 != layers_sequence.end()) {
