@@ -122,6 +122,14 @@ constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kNumCU = 256;        // MI355X
 constexpr int kNumXCD = 8;
 
+// Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2: neighbouring tiles of an image -- which share
+// halo rows -- would sit on eight different L2s and fetch those rows eight times.  This gives XCD x the x-th CONTIGUOUS eighth of
+// the logical ids instead (same bijection as the implicit GEMM's tile map).  nb = gridDim.x.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned bid, unsigned nb) {
+    const unsigned q = nb / kNumXCD, r = nb % kNumXCD, xcd = bid % kNumXCD, k = bid / kNumXCD;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 inline unsigned ceil_div(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 // grid for HBM-bound streaming kernels: enough workgroups to fill 256 CUs x 8, grid-stride the rest

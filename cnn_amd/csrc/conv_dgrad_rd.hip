@@ -481,7 +481,7 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdPa
     // Ci = 16*slices: a wave owns one 16-channel slice; the slices of a pixel group sit side by side in a workgroup (their dy
     // reads hit L1)
     const int slices = p.Ci >> 4;
-    const int wid = blockIdx.x * NW + (threadIdx.x >> 6);
+    const int wid = xcd_swizzle(blockIdx.x, gridDim.x) * NW + (threadIdx.x >> 6);
     const int slice = wid % slices, half = KS > 1 ? (wid / slices) % KS : 0, wave_id = wid / (slices * KS);
     const int nwaves = p.tiles;  // (tiles: pixel partitions, set by the host)
     const int groups = (p.pixels + 15) >> 4;

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_3_16_3_2(const float* __
     const int plane = Ho * Wo;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * CO * plane * 4u), 0x00020000);
-    for (int it = blockIdx.x * kWaves + wave; it < (int)items; it += gridDim.x * kWaves) {
+    for (int it = xcd_swizzle(blockIdx.x, gridDim.x) * kWaves + wave; it < (int)items; it += gridDim.x * kWaves) {
         const int b = fast_div(it, m_ipi, items_per_img);
         const int n = (it - b * items_per_img) * 64 + lane;
         const bool live = n < UV;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pool_pk_3_16_3_2(const floa
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dpool, 0, pbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)pmask, 0, pbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(RM ? pooled : dpool), 0, pbytes, 0x00020000);
-    for (int it = blockIdx.x * kWaves + wave; it < (int)items; it += gridDim.x * kWaves) {
+    for (int it = xcd_swizzle(blockIdx.x, gridDim.x) * kWaves + wave; it < (int)items; it += gridDim.x * kWaves) {
         const int b = fast_div(it, m_ipi, items_per_img);
         const int n = (it - b * items_per_img) * 64 + lane;
         const bool live = n < U2 * V2;
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pk_s2(const float* __restri
     extern __shared__ __attribute__((aligned(16))) float wlds[];
     for (int i = threadIdx.x; i < CO * 9 * HP; i += kBlock) ((v2f*)wlds)[i] = wp[i];
     __syncthreads();
-    for (int it = blockIdx.x * kWaves + wave; it < items; it += gridDim.x * kWaves) {
+    for (int it = xcd_swizzle(blockIdx.x, gridDim.x) * kWaves + wave; it < items; it += gridDim.x * kWaves) {
         const int b = fast_div(it, m_ipi, items_per_img);
         const int soff = b * CO * plane * 4;
         int hh[PX], ww[PX];
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_pk_3_16_3_2(const float* __re
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long items = (long long)B * items_per_img;
     const int plane = Ho * Wo;
-    for (int it = blockIdx.x * kWaves + wave; it < (int)items; it += gridDim.x * kWaves) {
+    for (int it = xcd_swizzle(blockIdx.x, gridDim.x) * kWaves + wave; it < (int)items; it += gridDim.x * kWaves) {
         const int b = fast_div(it, m_ipi, items_per_img);
         const int n = (it - b * items_per_img) * 64 + lane;
         const bool live = n < plane;
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_pool_pk_3_16_3_2(const float*
         const int out_bytes = (int)((unsigned)B * CO * PHo * PWo * 4u);
     const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc((void*)pooled, 0, out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)(mask ? mask : (int32_t*)pooled), 0, out_bytes, 0x00020000);
-    for (int it = blockIdx.x * kWaves + wave; it < (int)items; it += gridDim.x * kWaves) {
+    for (int it = xcd_swizzle(blockIdx.x, gridDim.x) * kWaves + wave; it < (int)items; it += gridDim.x * kWaves) {
         const int b = fast_div(it, m_ipi, items_per_img);
         const int n2 = (it - b * items_per_img) * 64 + lane;
         const bool live = n2 < half;

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_m16_kernel(const FwdRdParams
     const int lane = threadIdx.x & 63;
     const int n = lane & 15, k = lane >> 4;
     const int slices = (p.Co >> 4) / MS, parts = p.tiles;  // (wave slices of 16*MS channels; tiles: pixel partitions, set by the host)
-    const int wid = blockIdx.x * NW + (threadIdx.x >> 6);
+    const int wid = xcd_swizzle(blockIdx.x, gridDim.x) * NW + (threadIdx.x >> 6);  // (neighbouring pixel partitions share input rows)
     const int slice = wid % slices, part = wid / slices;
     const int groups = (p.pixels + 15) >> 4;
     if (part >= parts || part >= groups) return;

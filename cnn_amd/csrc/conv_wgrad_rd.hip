@@ -519,6 +519,9 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
     if (want > chunks) want = chunks;
     p.chunks_per_block = (int)((chunks + want - 1) / want);
     pl->kblocks = (int)((chunks + p.chunks_per_block - 1) / p.chunks_per_block);
+    // (measured and dropped: a split with kblocks % 8 == 0 puts the colblocks workgroups of one pixel range -- same x / dy data,
+    // linear ids kblocks apart -- on ONE XCD: conv_layer_4 then fetches 17 MB instead of 84 MB, and the step gets 4 % SLOWER: the
+    // operands fit the Infinity Cache, and eight L2s pulling them in parallel beat one L2 serving twelve workgroups)
     p.m_rows = magic_of(p.Ho);
     p.m_rpr = magic_of(p.rpr);
     // runs whose (over-reading) windows stay inside the tensors: addresses grow with the run index, so scan from the end
