@@ -126,6 +126,9 @@ constexpr int kNumXCD = 8;
 // halo rows -- would sit on eight different L2s and fetch those rows eight times.  This gives XCD x the x-th CONTIGUOUS eighth of
 // the logical ids instead (same bijection as the implicit GEMM's tile map).  nb = gridDim.x.
 __device__ __forceinline__ unsigned xcd_swizzle(unsigned bid, unsigned nb) {
+#ifdef CNN_NO_XCD_SWIZZLE  // (A/B builds only)
+    return bid;
+#endif
     const unsigned q = nb / kNumXCD, r = nb % kNumXCD, xcd = bid % kNumXCD, k = bid / kNumXCD;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
