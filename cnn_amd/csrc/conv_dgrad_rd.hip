@@ -466,6 +466,9 @@ __global__ __launch_bounds__(256) void conv_dgrad_rd_s1_kernel(const DgRdParams 
 // lane registers (72 for CO = 32, 144 for 64) that a wave loads ONCE -- no LDS and no filter traffic in the loop.  The only
 // streamed operand is dy: per 4 channels (9 steps) a lane loads TWO 8-byte pairs (rows u and u-1, columns v-1 | v) of its
 // channel; rows outside the image read 0 through an out-of-range buffer offset, border columns shift the pair and pick.
+#ifndef CNN_M16_DGRAD_NB
+#define CNN_M16_DGRAD_NB 4
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kM16OOB = 0x7ffffffcu;
 
@@ -474,7 +477,7 @@ constexpr unsigned kM16OOB = 0x7ffffffcu;
 template <int CO, int NW, bool PREP, int KS>
 __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdParams p) {
     constexpr int C4 = CO / 4, NA = CO * 9 / 4;
-    constexpr int NB = 4;  // ring of granules (4 dy channels: two 8-byte loads, 9 MFMA steps); three granules in flight
+    constexpr int NB = CNN_M16_DGRAD_NB;  // ring of granules (4 dy channels: two 8-byte loads, 9 MFMA steps); NB - 1 granules in flight
     static_assert(C4 % NB == 0, "static ring indices");
     const int lane = threadIdx.x & 63;
     const int n = lane & 15, k = lane >> 4;
