@@ -47,6 +47,7 @@ constexpr int XP = 4 * kSW + 4;         // floats per staged input row segment: 
 constexpr int XROWS = CI * XR;          // 15 staged rows ...
 constexpr int XBUF = (XROWS + 1) * XP;  // ... + one row of 1.0f: the "column" whose sums are the bias gradient (never overwritten)
 constexpr int kWaves = 8;               // two waves per SIMD: one wave's LDS / VALU latency hides behind the other's MFMAs
+constexpr int kProd = 4;                // SPEC: one extra DMA-only wave per SIMD (see the kernel)
 // delta operands of a strip: plain 2 rows x 2*SW columns x 16 channels; pooled domain 2 (dpool, mask) or 3 (+ pooled) tensors
 // x SW windows x 16 channels
 __host__ __device__ constexpr int abuf_floats(int pooled) { return pooled == 0 ? 2 * 2 * kSW * CO : (pooled == 1 ? 3 : 2) * kSW * CO; }
@@ -68,22 +69,33 @@ struct WinParams {
     int strips_total, strips_per_wave;
     int dbg;  // CNN_AMD_WIN_DBG (tuning): 1 = no MFMA groups, 2 = no staging
     int lockstep;  // the waves of a workgroup start every strip together (only when every wave has the same number of strips)
+    int spec;      // host: launch the wave-specialised instance (same precondition)
+    int spec_slack;  // (tuning) strips a producer may run ahead of the OTHER SIMDs' consumers beyond the buffer depth
 };
 
 // POOLED: 0 dy | 1 pooled domain (dpool, mask, pooled) | 2 pooled domain with dpool already ReLU-masked (pooled not read)
 // DMA16: x rows are 16-byte aligned (W % 4 == 0, base aligned): 16-byte DMA; otherwise 4 bytes per lane
-template <int POOLED, bool DMA16>
-__global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinParams p) {
+// SPEC ("wave specialisation"): a wave that is blocked while the memory pipeline takes its DMA burst cannot issue MFMAs, and with
+// every wave doing both jobs the two phases barely overlapped (staging-only 52 us + MFMA-only 48 us ~ the 70 us measured).  With SPEC
+// the eight MFMA waves never issue a DMA: four extra waves (one per SIMD, each feeding the two MFMA waves of its SIMD) run stage()
+// for them and hand strips over through LDS flags -- ready[c][buffer] = strip index once its DMA has landed (the producer's counted
+// s_waitcnt), done[c] = strips consumed (buffer free).  A producer never runs more than NBUF strips ahead of the SLOWEST consumer of
+// the workgroup, which also keeps the eight runs close enough for the shared delta lines to stay in L2 (the job of the lock-step
+// barrier in the non-SPEC kernel).
+template <int POOLED, bool DMA16, bool SPEC>
+__global__ __launch_bounds__((kWaves + (SPEC ? kProd : 0)) * 64) void conv_wgrad_win_kernel(const WinParams p) {
     constexpr int BUF = buf_floats(POOLED), NBUF = num_bufs(POOLED);
     constexpr int NT = POOLED == 1 ? 3 : 2;  // pooled-domain tensors
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n0 = lane & 15, k = lane >> 4;  // MFMA lane coordinates: (row / column index, k-slot)
-    float* const wbuf = lds + wave * NBUF * BUF;
+    float* const wbuf = lds + (wave < kWaves ? wave : 0) * NBUF * BUF;
+    if (wave < kWaves) {
 #pragma unroll
-    for (int nb = 0; nb < NBUF; ++nb)
-        for (int i = lane; i < XP; i += 64) wbuf[nb * BUF + XROWS * XP + i] = 1.f;  // the ones row of every buffer
+        for (int nb = 0; nb < NBUF; ++nb)
+            for (int i = lane; i < XP; i += 64) wbuf[nb * BUF + XROWS * XP + i] = 1.f;  // the ones row of every buffer
+    }
 
     // ---- per-lane constants of the B operand: column (ci,kx,ky) of tile t.  Column 27 reads the ones row (its sums are the
     // bias gradient: D[co][27] = sum of the deltas); columns 28..31 repeat it (discarded).
@@ -104,7 +116,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) acc[t][pr] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int gw = blockIdx.x * kWaves + wave;
+    const int gw = blockIdx.x * kWaves + (wave < kWaves ? wave : 0);
     const int s_lo = gw * p.strips_per_wave;
     const int s_hi = s_lo + p.strips_per_wave < p.strips_total ? s_lo + p.strips_per_wave : p.strips_total;
 
@@ -145,42 +157,50 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
     constexpr int PER_ROW = XP / CHX;
     constexpr int TOTALX = XROWS * PER_ROW;
     constexpr int NX = (TOTALX + 63) / 64;
-    unsigned gx[NX];
-    unsigned ga = 0;
-    unsigned row0_bits = 0, live_bits = 0;  // per DMA instruction i: this lane's chunk is in staged row r5 == 0 / exists at all
-    int col_seg = -1;
-    auto setup_column = [&](int seg) {
+    struct ColState {
+        unsigned gx[NX];
+        unsigned ga;
+        int col_seg;
+    };
+    // per DMA instruction i: this lane's chunk is in staged row r5 == 0 / exists at all (lane constants)
+    unsigned row0_bits = 0, live_bits = 0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int f = 64 * i + lane;
+        const int row = f / PER_ROW;
+        if (f < TOTALX) live_bits |= 1u << i;
+        if (row % XR == 0) row0_bits |= 1u << i;
+    }
+    auto setup_column = [&](int seg, ColState& cs) {
         int wc_lo, sw;
         seg_geom(seg, wc_lo, sw);
         const int ncols = (p.W - 4 * wc_lo) < (4 * sw + 4) ? (p.W - 4 * wc_lo) : (4 * sw + 4);
-        row0_bits = live_bits = 0;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int f = 64 * i + lane;
             const int row = f / PER_ROW, c = (f - row * PER_ROW) * CHX;
             const int ci = row / XR, r5 = row - ci * XR;
-            gx[i] = (unsigned)((ci * p.H + r5) * p.W + (c < ncols ? c : 0));
-            if (f < TOTALX) live_bits |= 1u << i;
-            if (r5 == 0) row0_bits |= 1u << i;
+            cs.gx[i] = (unsigned)((ci * p.H + r5) * p.W + (c < ncols ? c : 0));
         }
+        cs.ga = 0;
         if constexpr (POOLED) {
             const int nv = p.PWo - wc_lo < sw ? p.PWo - wc_lo : sw;
             const int g = lane >> 4;
-            ga = (unsigned)((co * p.PHo) * p.PWo + (4 * g < nv ? 4 * g : 0));
+            cs.ga = (unsigned)((co * p.PHo) * p.PWo + (4 * g < nv ? 4 * g : 0));
         }
-        col_seg = seg;
+        cs.col_seg = seg;
     };
 
     // ---- HBM -> LDS for one strip (asynchronous: completion = vmcnt).  Every instruction is issued by every strip (the wait
     // below counts instructions): a lane whose element lies outside the image / the row re-reads a valid element of the same
     // row instead, and the compute path ignores that slot (EDGE).  Returns true for the ONE strip kind that stages its delta
     // operands with 4-byte instead of 16-byte DMA (see below).
-    auto stage = [&](const Cur& cu, float* buf) -> bool {
+    auto stage = [&](const Cur& cu, float* buf, ColState& cs, int first_strip) -> bool {
         const int s = cu.s, b = cu.b, wr = cu.wr;
         int wc_lo, sw;
         seg_geom(cu.seg, wc_lo, sw);
-        const bool chained = s > s_lo && wr > 0;  // this wave consumed strip s-1 = (b, same segment, wr-1) just before
-        if (col_seg != cu.seg) setup_column(cu.seg);
+        const bool chained = s > first_strip && wr > 0;  // the consumer took strip s-1 = (b, same segment, wr-1) just before
+        if (cs.col_seg != cu.seg) setup_column(cu.seg, cs);
         const int nrows = (p.H - 4 * wr) < XR ? (p.H - 4 * wr) : XR;
         // x: rows 4wr .. 4wr+4 of the three channels, columns 4*wc_lo .. 4*wc_lo + 4*sw (inclusive), clipped to the image
         if (nrows == XR) {
@@ -188,8 +208,8 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 if ((live_bits >> i & 1u) && !(chained && (row0_bits >> i & 1u))) {
-                    if constexpr (DMA16) __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + gx[i]), (lds_void_ptr)(buf + 64 * i * CHX), 16, 0, 0);
-                    else __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + gx[i]), (lds_void_ptr)(buf + 64 * i * CHX), 4, 0, 0);
+                    if constexpr (DMA16) __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + cs.gx[i]), (lds_void_ptr)(buf + 64 * i * CHX), 16, 0, 0);
+                    else __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + cs.gx[i]), (lds_void_ptr)(buf + 64 * i * CHX), 4, 0, 0);
                 }
             }
         } else {
@@ -223,9 +243,9 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
             const bool last_row = b == p.B - 1 && wr >= p.PHo - 1 && wc_lo + kSW > p.PWo;
             if (!last_row && rowok) {
                 const size_t abase = (((size_t)b * CO) * p.PHo + wr) * p.PWo + wc_lo;  // wave-uniform; ga: this lane's (co, group)
-                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.dy + abase + ga), (lds_void_ptr)(abuf), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gbl_void_ptr)((const float*)p.pmask + abase + ga), (lds_void_ptr)(abuf + kSW * CO), 16, 0, 0);
-                if constexpr (POOLED == 1) __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.pooled + abase + ga), (lds_void_ptr)(abuf + 2 * kSW * CO), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.dy + abase + cs.ga), (lds_void_ptr)(abuf), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)((const float*)p.pmask + abase + cs.ga), (lds_void_ptr)(abuf + kSW * CO), 16, 0, 0);
+                if constexpr (POOLED == 1) __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.pooled + abase + cs.ga), (lds_void_ptr)(abuf + 2 * kSW * CO), 16, 0, 0);
                 return false;
             }
             if (!last_row) {  // a window row outside the pooled domain: any valid row will do (the compute path ignores it)
@@ -361,14 +381,121 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
         }
     };
 
-    if (s_lo < s_hi) {
+    // LDS -> LDS: strip s+1 continues strip s (same image, same column segment, next window row): its input row 0 is this strip's
+    // row 4 (3 channels x 17 16-byte chunks; its DMA leaves row 0 alone) instead of a second trip to L2 / HBM (the re-read rows
+    // were 25 % extra fetch traffic).  Inline asm: for a compiler-visible LDS access the waitcnt pass inserts s_waitcnt vmcnt(0)
+    // -- it cannot tell that the in-flight LDS-DMA writes land elsewhere -- which drained the whole prefetch pipeline once per strip.
+    auto hand_over = [&](const float* from, float* to) {
+        if (lane < CI * (XP / 4)) {
+            const int ci = lane / (XP / 4), ch = lane - ci * (XP / 4);
+            const unsigned a_from = (unsigned)(uintptr_t)(lds_void_ptr)(from + (ci * XR + 4) * XP + 4 * ch);
+            const unsigned a_to = (unsigned)(uintptr_t)(lds_void_ptr)(to + (ci * XR) * XP + 4 * ch);
+            f32x4 v;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b128 %2, %0\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(v)
+                         : "v"(a_from), "v"(a_to)
+                         : "memory");
+        }
+    };
+    auto edge_strip = [&](int wr, int wc_lo, int sw) {
+        return 2 * wr + 1 >= p.Ho || 2 * (wc_lo + ((sw + 3) & ~3)) > p.Wo || 4 * wr + XR > p.H || 4 * (wc_lo + sw) + 4 > p.W ||
+               (POOLED && (wr >= p.PHo || wc_lo + ((sw + 3) & ~3) > p.PWo));
+    };
+
+    if constexpr (SPEC) {
+        // (host: every wave of the grid has exactly strips_per_wave strips)
+        const int n = p.strips_per_wave;
+        int* const flags = reinterpret_cast<int*>(lds + kWaves * NBUF * BUF);  // ready[kWaves][NBUF], done[kWaves]
+        if (threadIdx.x < kWaves * NBUF) flags[threadIdx.x] = -1;
+        if (threadIdx.x < kWaves) flags[kWaves * NBUF + threadIdx.x] = 0;
+        __syncthreads();
+        const unsigned flags_lds = (unsigned)(uintptr_t)(lds_void_ptr)flags;
+        if (wave >= kWaves) {
+            // ---------------- producer: DMA for MFMA waves cA and cB (the two on this wave's SIMD) ----------------
+            const int cA = wave - kWaves, cB = cA + kProd;
+            const int fA = (blockIdx.x * kWaves + cA) * n, fB = (blockIdx.x * kWaves + cB) * n;
+            Cur ca = decode(fA), cb = decode(fB);
+            ColState stA, stB;
+            stA.col_seg = stB.col_seg = -1;
+            float* const bufA = lds + cA * NBUF * BUF;
+            float* const bufB = lds + cB * NBUF * BUF;
+            // (flag traffic in inline asm: a compiler-visible LDS access behind LDS-DMA gets an s_waitcnt vmcnt(0) in front)
+            auto lds_load = [&](unsigned addr) {
+                int v;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+                return v;
+            };
+            auto publish = [&](int c, int strip) {
+                if (lane == 0) {
+                    const unsigned addr = flags_lds + 4u * (unsigned)(c * NBUF + strip % NBUF);
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(strip) : "memory");
+                }
+            };
+            int buf = 0;
+            for (int r = 0; r < n; ++r) {
+                if (r >= NBUF) {
+                    // buffer r % NBUF is free once strip r - NBUF has been consumed -- by EVERY consumer of the workgroup
+                    while (true) {
+                        const int who = lane & (kWaves - 1);
+                        int d = lds_load(flags_lds + 4u * (unsigned)(kWaves * NBUF + who));
+                        if (who != cA && who != cB) d += p.spec_slack;  // (own consumers: the buffer; the others: drift only)
+#pragma unroll
+                        for (int o = 1; o < kWaves; o <<= 1) {
+                            const int e = __shfl_xor(d, o, 64);
+                            d = e < d ? e : d;
+                        }
+                        if (__builtin_amdgcn_readfirstlane(d) >= r - NBUF + 1) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                const bool slA = stage(ca, bufA + buf * BUF, stA, fA);
+                advance(ca);
+                const bool slB = stage(cb, bufB + buf * BUF, stB, fB);
+                advance(cb);
+                if (r >= 1) {  // the strips of round r-1 have landed once at most this round's instructions are outstanding
+                    if (slA && slB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * N_SLOW) : "memory");
+                    else if (slA || slB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_FAST + N_SLOW) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * N_FAST) : "memory");
+                    publish(cA, r - 1);
+                    publish(cB, r - 1);
+                }
+                buf = buf + 1 == NBUF ? 0 : buf + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            publish(cA, n - 1);
+            publish(cB, n - 1);
+        } else {
+            // ---------------- consumer: MFMA groups only ----------------
+            volatile int* const ready = flags + wave * NBUF;
+            volatile int* const done = flags + kWaves * NBUF + wave;
+            Cur cc = decode(s_lo);
+            int cur = 0;
+            for (int i = 0; i < n; ++i, advance(cc)) {
+                while (ready[cur] != i) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");  // (the operand reads below stay behind the flag)
+                int wc_lo, sw;
+                seg_geom(cc.seg, wc_lo, sw);
+                if (p.dbg != 1) {
+                    if (edge_strip(cc.wr, wc_lo, sw)) compute(std::true_type(), cc.wr, wc_lo, sw, wbuf + cur * BUF, false);
+                    else compute(std::false_type(), cc.wr, wc_lo, sw, wbuf + cur * BUF, false);
+                }
+                const int nxt = cur + 1 == NBUF ? 0 : cur + 1;
+                if (i + 1 < n && cc.wr + 1 < p.WR) hand_over(wbuf + cur * BUF, wbuf + nxt * BUF);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of this buffer is done: hand it back
+                if (lane == 0) *done = i + 1;
+                cur = nxt;
+            }
+        }
+    } else if (s_lo < s_hi) {
         // NBUF - 1 strips ahead: strip s is consumed from buffer s % NBUF while s+1 (.. s+NBUF-1) are on their way
         bool slow_next = false;  // kind of the most recently staged strip that is still in flight behind strip s
         Cur sc = decode(s_lo), cc = sc;  // staging cursor / compute cursor
-        stage(sc, wbuf);
+        ColState own;
+        own.col_seg = -1;
+        stage(sc, wbuf, own, s_lo);
         advance(sc);
         if (NBUF == 3 && sc.s < s_hi && p.dbg < 2) {
-            slow_next = stage(sc, wbuf + BUF);
+            slow_next = stage(sc, wbuf + BUF, own, s_lo);
             advance(sc);
         }
         int cur = 0;
@@ -404,17 +531,16 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
             nb = nb >= NBUF ? nb - NBUF : nb;
             if (s + NBUF - 1 < s_hi && p.dbg < 2) {
                 if (NBUF == 2) {  // (two buffers: the staging cursor runs one strip ahead, not two)
-                    slow_next = stage(sc, wbuf + nb * BUF);
+                    slow_next = stage(sc, wbuf + nb * BUF, own, s_lo);
                     advance(sc);
                 } else {
-                    slow_next = stage(sc, wbuf + nb * BUF);
+                    slow_next = stage(sc, wbuf + nb * BUF, own, s_lo);
                     advance(sc);
                 }
             }
             tick(2);
             if (p.dbg != 1) {
-                const bool edge = 2 * wr + 1 >= p.Ho || 2 * (wc_lo + ((sw + 3) & ~3)) > p.Wo || 4 * wr + XR > p.H || 4 * (wc_lo + sw) + 4 > p.W ||
-                                  (POOLED && (wr >= p.PHo || wc_lo + ((sw + 3) & ~3) > p.PWo));
+                const bool edge = edge_strip(wr, wc_lo, sw);
                 if (edge) compute(std::true_type(), wr, wc_lo, sw, wbuf + cur * BUF, late);
                 else compute(std::false_type(), wr, wc_lo, sw, wbuf + cur * BUF, late);
             } else if (late) {
@@ -423,26 +549,7 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
             if constexpr (kExp == 6) asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
             tick(3);
             const int nxt = cur + 1 == NBUF ? 0 : cur + 1;
-            if (s + 1 < s_hi && wr + 1 < p.WR && p.dbg < 2) {
-                // strip s+1 continues this one (same image, same column segment, next window row): its input row 0 is this
-                // strip's row 4 -- handed over LDS -> LDS (3 channels x 17 16-byte chunks; its DMA leaves row 0 alone) instead of a
-                // second trip to L2 / HBM (the re-read rows were 25 % extra fetch traffic).  Issued behind this strip's MFMAs:
-                // the next stage() call, which re-uses THIS buffer, comes after the dependent ds_write.
-                const float* from = wbuf + cur * BUF;
-                float* to = wbuf + nxt * BUF;
-                // (inline asm: for a compiler-visible LDS access the waitcnt pass inserts s_waitcnt vmcnt(0) -- it cannot tell that the
-                // in-flight LDS-DMA writes of the strips ahead land elsewhere -- which drained the whole prefetch pipeline once per strip)
-                if (lane < CI * (XP / 4)) {
-                    const int ci = lane / (XP / 4), ch = lane - ci * (XP / 4);
-                    const unsigned a_from = (unsigned)(uintptr_t)(lds_void_ptr)(from + (ci * XR + 4) * XP + 4 * ch);
-                    const unsigned a_to = (unsigned)(uintptr_t)(lds_void_ptr)(to + (ci * XR) * XP + 4 * ch);
-                    f32x4 v;
-                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b128 %2, %0\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(v)
-                                 : "v"(a_from), "v"(a_to)
-                                 : "memory");
-                }
-            }
+            if (s + 1 < s_hi && wr + 1 < p.WR && p.dbg < 2) hand_over(wbuf + cur * BUF, wbuf + nxt * BUF);  // (behind this strip's MFMAs)
             cur = nxt;
             tick(4);
         }
@@ -461,10 +568,10 @@ __global__ __launch_bounds__(kWaves * 64) void conv_wgrad_win_kernel(const WinPa
         for (int r = 0; r < 4; ++r) {
             const float v = acc[t][0][r] + acc[t][1][r];
             const int col = n0 + 16 * t;
-            if (col < 28) red[wave][4 * k + r][col] = v;  // D[row = 4*(lane>>4) + r][column = lane & 15]
+            if (col < 28 && wave < kWaves) red[wave][4 * k + r][col] = v;  // D[row = 4*(lane>>4) + r][column = lane & 15]
         }
     __syncthreads();
-    for (int i = threadIdx.x; i < CO * 28; i += kWaves * 64) {
+    for (int i = threadIdx.x; i < CO * 28; i += blockDim.x) {
         const int c2 = i / 28, col = i - c2 * 28;
         float v = red[0][c2][col];
 #pragma unroll
@@ -507,27 +614,25 @@ bool make_win_params(const cnn_conv2d_desc* d, WinParams* p, int* grid) {
         // 128-byte lines in L2 (PMC: 1.37x -> 1.02x of the algorithmic fetch).  Needs the same trip count in every wave.
         const char* e = getenv("CNN_AMD_WIN_LOCKSTEP");
         p->lockstep = ((!e || atoi(e) != 0) && strips == (long long)g * kWaves * p->strips_per_wave) ? (e ? atoi(e) : 1) : 0;
+        const char* sp = getenv("CNN_AMD_WIN_SPEC");
+        p->spec = ((!sp || atoi(sp) != 0) && strips == (long long)g * kWaves * p->strips_per_wave && p->dbg < 2) ? 1 : 0;
+        p->spec_slack = getenv("CNN_AMD_WIN_SLACK") ? atoi(getenv("CNN_AMD_WIN_SLACK")) : 0;
     }
     return true;
 }
 
-template <int POOLED>
-int launch_win(const cnn_conv2d_desc* d, WinParams& p, int grid, hipStream_t s, const char* name) {
-    const bool dma16 = (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(p.x) % 16 == 0);
-    const size_t lds_bytes = (size_t)kWaves * num_bufs(POOLED) * buf_floats(POOLED) * sizeof(float);
-    static DeviceOnce attr_once[2];  // (per template instance = per POOLED)
-    if (attr_once[dma16].needed()) {
-        if (dma16)
-            CNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<POOLED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        else
-            CNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<POOLED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_once[dma16].mark();
+template <int POOLED, bool DMA16, bool SPEC>
+int launch_win3(const cnn_conv2d_desc* d, WinParams& p, int grid, hipStream_t s, const char* name) {
+    const size_t lds_bytes = (size_t)kWaves * num_bufs(POOLED) * buf_floats(POOLED) * sizeof(float) + (SPEC ? 256 : 0);
+    static DeviceOnce attr_once;  // (per template instance)
+    if (attr_once.needed()) {
+        CNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<POOLED, DMA16, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds_bytes));
+        attr_once.mark();
     }
-    if (dma16)
-        CNN_KLAUNCH(s, name, (conv_wgrad_win_kernel<POOLED, true><<<grid, kWaves * 64, lds_bytes, s>>>(p)), CONV_TAG(d));
-    else
-        CNN_KLAUNCH(s, name, (conv_wgrad_win_kernel<POOLED, false><<<grid, kWaves * 64, lds_bytes, s>>>(p)), CONV_TAG(d));
-    if constexpr (kExp == 6) {  // per-phase cycle counters of the strip loop (timing experiments only)
+    constexpr int threads = (kWaves + (SPEC ? kProd : 0)) * 64;
+    CNN_KLAUNCH(s, name, (conv_wgrad_win_kernel<POOLED, DMA16, SPEC><<<grid, threads, lds_bytes, s>>>(p)), CONV_TAG(d));
+    if constexpr (kExp == 6 && !SPEC) {  // per-phase cycle counters of the strip loop (timing experiments only)
         static unsigned long long h[256 * 8][8];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h));
@@ -543,6 +648,14 @@ int launch_win(const cnn_conv2d_desc* d, WinParams& p, int grid, hipStream_t s, 
         }
     }
     return CNN_AMD_OK;
+}
+
+template <int POOLED>
+int launch_win(const cnn_conv2d_desc* d, WinParams& p, int grid, hipStream_t s, const char* name) {
+    const bool dma16 = (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(p.x) % 16 == 0);
+    // (wave specialisation needs the three-buffer ring: with two, a producer cannot run ahead -- measured 150 vs 119 us)
+    if (dma16) return (p.spec && num_bufs(POOLED) == 3) ? launch_win3<POOLED, true, POOLED == 2>(d, p, grid, s, name) : launch_win3<POOLED, true, false>(d, p, grid, s, name);
+    return launch_win3<POOLED, false, false>(d, p, grid, s, name);  // (4-byte DMA: too many instructions per strip for counted waits on pairs)
 }
 }  // namespace
 
