@@ -1304,6 +1304,8 @@ int rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w,
                      void* const* dgrad, hipStream_t s, unsigned* fdone, unsigned* ddone);
 int fwd_rd_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* img, const float* bias, float* y,
                    float* y_relu, hipStream_t s);
+bool stem_fwd_supported(const cnn_conv2d_desc* d);     // conv_stem.hip: Ci = 3, 7x7, stride 2, pad 3 forward on its own MFMA kernel
+int stem_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, float* y_relu, hipStream_t s);
 bool thin_dgrad_supported(const cnn_conv2d_desc* d);   // conv_dgrad_thin.hip: VALU data gradient of thin (Ci = 3) stride-1 layers
 int thin_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* relu_below, float* dx, hipStream_t s);
 bool pk_dgrad_s2_supported(const cnn_conv2d_desc* d);  // conv_direct.hip: packed VALU dgrad for small stride-2 layers
@@ -1340,6 +1342,8 @@ static int conv2d_forward_impl(const char* who, const cnn_conv2d_desc* d, const 
     if (direct_conv_supported(d)) return direct_conv_forward(d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream), prepared);
     if (fwd_rd_supported(d))
         return fwd_rd_forward(d, x, prepared ? nullptr : w, prepared ? (const float*)ws : nullptr, bias, y, y_relu, as_stream(stream));
+    if (stem_fwd_supported(d) && (y || y_relu))  // (its "prepared" image is a verbatim copy of w)
+        return stem_forward(d, x, prepared ? (const float*)ws : w, bias, y, y_relu, as_stream(stream));
     Plan pl;
     if (int rc = make_plan(who, d, MODE_FWD, &pl)) return rc;
     return run_plan(pl, d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream), who, prepared);
@@ -1376,7 +1380,7 @@ int cnn_conv2d_autotune(const cnn_conv2d_desc* d, void* stream) {
     for (int mode = 0; mode < 2; ++mode) {
         // geometries that never reach the implicit GEMM in this mode
         if (direct_conv_supported(d)) continue;
-        if (mode == MODE_FWD && fwd_rd_supported(d)) continue;
+        if (mode == MODE_FWD && (fwd_rd_supported(d) || stem_fwd_supported(d))) continue;
         if (mode == MODE_DGRAD && (dgrad_rd_supported(d) || pk_dgrad_s2_supported(d) || thin_dgrad_supported(d))) continue;
         {
             std::lock_guard<std::mutex> lk(tune_mutex());
@@ -1524,6 +1528,12 @@ int cnn_conv2d_prepare_filters(int n, const cnn_conv2d_desc* descs, const float*
         for (int mode = 0; mode < 2; ++mode) {
             void* out = mode == MODE_FWD ? (fwd ? fwd[i] : nullptr) : (dgrad ? dgrad[i] : nullptr);
             if (!out || ((mode == MODE_FWD ? fdone : ddone) >> i & 1u)) continue;
+            if (mode == MODE_FWD && !direct_conv_supported(&descs[i]) && !fwd_rd_supported(&descs[i]) && stem_fwd_supported(&descs[i])) {
+                // conv_stem.hip reads the reference layout: its prepared image is a verbatim copy
+                CNN_HIP_CHECK(hipMemcpyAsync(out, w[i], sizeof(float) * (size_t)descs[i].Co * descs[i].Ci * descs[i].k * descs[i].k,
+                                             hipMemcpyDeviceToDevice, s));
+                continue;
+            }
             if (mode == MODE_DGRAD && !direct_conv_supported(&descs[i]) && thin_dgrad_supported(&descs[i])) {
                 // conv_dgrad_thin.hip reads the reference layout: its prepared image is a verbatim copy
                 CNN_HIP_CHECK(hipMemcpyAsync(out, w[i], sizeof(float) * (size_t)descs[i].Co * descs[i].Ci * descs[i].k * descs[i].k,

@@ -56,6 +56,8 @@ CONV_CASES = [
     (2, 3, 32, 32, 16, 3, 1, 1),     # VGG first layer: 3 -> C, stride 1 pad 1
     (2, 64, 14, 14, 128, 3, 1, 1),   # VGG deep layer: 3x3 stride 1 pad 1, small image
     (1, 3, 224, 224, 64, 7, 2, 3),   # the ResNet stem at full resolution (row staging of 230-float rows)
+    (3, 3, 38, 44, 72, 7, 2, 3),     # conv_stem.hip: two channel blocks (64 + 8), 19 x 22 outputs: partial row group, one pixel tile
+    (2, 3, 20, 260, 32, 7, 2, 3),    # ... 130 output columns: two column blocks of 128
     (3, 32, 9, 11, 64, 3, 1, 0),     # stride-1 register-direct data gradient: one tile of 32 channels, borders everywhere
     (2, 64, 8, 7, 128, 3, 1, 0),     # ... two tiles per wave
     (3, 3, 70, 130, 24, 3, 1, 1),    # thin-input data gradient (conv_dgrad_thin.hip): three column segments, ragged last band
