@@ -13,6 +13,7 @@
 // Rows outside dy are skipped wave-uniformly, columns outside it selected to 0 per lane.  An optional fused ReLU::backward
 // (relu.cpp:35-40) masks dx by the output of the ReLU layer in front.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -112,6 +113,165 @@ __global__ __launch_bounds__(kThinWaves * 64) void conv_dgrad_thin_s1k3(const fl
     }
 }
 
+
+// ---- Ci = 3 under a K x K filter with stride 2 and pad (K-1)/2: the data gradient of the ResNet-shaped stack's 7x7 stem -------------
+// (implicit GEMM: M = Ci = 3 of 32 MFMA rows, 17 TFLOP/s, 0.9 ms at batch 64 -- 1.2 ms beside the weight gradient.)
+// A lane owns the 2 x 2 block of input pixels (2hh + ph, 2ww + pw) of one grid position, a wave 64 consecutive grid positions of
+// one image (rows are crossed: every lane is busy).  With stride 2 the four pixels of a block use DISJOINT tap sets -- pixel parity
+// ph takes the row taps r with r + ph odd, likewise the columns -- so every one of the 3*K*K filter values of a dy channel is used
+// exactly once per block: 147 FMAs (K = 7) on the (K+1)/2 x (K+1)/2 = 4 x 4 dy neighbourhood (rows hh-1 .. hh+2, columns
+// ww-1 .. ww+2), the filter value as a SCALAR operand straight from the reference layout (wave-uniform s_loads; the "prepared"
+// image of such a layer is a verbatim copy of w).  Two channels per turn: 32 loads in flight while the previous 294 FMAs run.
+//   dx[ci][y][x] = sum_co sum_{r,c} w[co][ci][r][c] * dy[co][(y + P - r)/2][(x + P - c)/2]   over the taps where both are integers
+template <int K>
+__global__ __launch_bounds__(kThinWaves * 64) void conv_dgrad_thin_s2(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                      const float* __restrict__ relu_below, float* __restrict__ dx, int B,
+                                                                      int Co, int H, int W, int Ho, int Wo, int U, int V, int items_per_img) {
+    constexpr int CI = 3, P = (K - 1) / 2, NB = (K + 1) / 2;  // NB x NB dy neighbourhood
+    static_assert(K % 4 == 3, "tap <-> neighbour mapping below is written for K = 3, 7, 11");
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * kThinWaves + (threadIdx.x >> 6));
+    const int b = wid / items_per_img;
+    if (b >= B) return;
+    const int n = (wid - b * items_per_img) * 64 + lane;
+    const bool live = n < U * V;
+    const int hh = (live ? n : 0) / V, ww = (live ? n : 0) - hh * V;
+    // neighbour (j, i) = dy[hh - NB/2 + 1 ... ]: row hh + 1 - NB/2 + j ... for K = 7: rows hh-1 .. hh+2.  Row tap r of parity class ph
+    // (r + ph + P even  <=>  (2hh + ph + P - r) / 2 integer) reads neighbour row j = (P + ph - r) / 2 + NB/2 - 1
+    constexpr int J0 = NB / 2 - 1;  // index of row hh - ... : oy = hh + (P + ph - r)/2 - ... ; j = oy - (hh - J0)   (K = 7: J0 = 1)
+    // byte offsets inside a channel plane; a neighbour outside dy gets an offset beyond the buffer: the raw buffer load returns 0
+    // (no per-element selects, no exec masks -- 16 loop-invariant lane masks cost 32 SGPRs and spilled)
+    constexpr unsigned kOOB = 0x7ffffffcu;
+    unsigned voff[NB][NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int oy = hh - J0 + j, ox = ww - J0 + i;
+            const bool ok = live && (unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo;
+            voff[j][i] = ok ? (unsigned)(oy * Wo + ox) * 4u : kOOB;
+        }
+    float acc[2][2][CI];
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) acc[ph][pw][ci] = 0.f;
+    const int oplane = Ho * Wo;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * Co * oplane * 4u), 0x00020000);
+    int soff = b * Co * oplane * 4;  // byte offset of dy[b][co]: wave-uniform, advanced per channel
+    const float* wc0 = w;            // wave-uniform: scalar loads
+    auto load_patch = [&](float (&v)[NB][NB], int so) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) v[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff[j][i], so, 0));
+    };
+    // The filter values are wave-uniform: s_load into SGPRs, a scalar operand of every FMA.  Left to hipcc, the s_loads of ALL 147
+    // values (x 2 channels) are pulled to the top of the unrolled block -- 300-500 SGPR spills through v_writelane; compiler fences
+    // (the loads are invariant) and scheduling barriers do not stop it, and a real loop over row pairs with a switch body costs a
+    // branch tree + an exposed s_load latency per 14 FMAs (688 us).  So the loads are issued by hand: inline-asm s_load of one
+    // (ci, r) row pair (14 values: x8 + x4 + x2) into one of two register sets, one pair ahead of the FMAs; SMEM returns out of
+    // order, so the only safe wait is lgkmcnt(0), placed where the NEXT pair has not been issued yet.
+    typedef float s8f __attribute__((ext_vector_type(8)));
+    typedef float s4f __attribute__((ext_vector_type(4)));
+    typedef float s2f __attribute__((ext_vector_type(2)));
+    struct RowPair {
+        s8f a;
+        s4f b;
+        s2f c;
+    };
+    constexpr int NPAIR = (CI * K + 1) / 2;
+    static_assert(K == 7, "row-pair loads below are x8 + x4 + x2 (+ x4 + x2 + x1 for the odd last row)");
+    auto issue = [&](auto Q, RowPair& rp, const float* wq) {
+        constexpr int q = decltype(Q)::value;
+        constexpr int off = q * 2 * K * 4;  // byte offset of row 2q
+        // (the running sums as inputs: the FMAs of the pair that last used this register set come first -- otherwise hipcc keeps
+        // every pair's values live and runs all FMAs at the end)
+#define THIN_ACCS "v"(acc[0][0][0]), "v"(acc[0][1][0]), "v"(acc[1][0][0]), "v"(acc[1][1][0]), "v"(acc[0][0][1]), "v"(acc[0][1][1]), \
+                  "v"(acc[1][0][1]), "v"(acc[1][1][1]), "v"(acc[0][0][2]), "v"(acc[0][1][2]), "v"(acc[1][0][2]), "v"(acc[1][1][2])
+        if constexpr (2 * q + 1 < CI * K) {
+            asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(rp.a) : "s"(wq), "n"(off), THIN_ACCS);
+            asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(rp.b) : "s"(wq), "n"(off + 32));
+            asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(rp.c) : "s"(wq), "n"(off + 48));
+        } else {  // the last row of a channel stands alone: exactly its 7 values (nothing behind the last channel is touched)
+            asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(rp.b) : "s"(wq), "n"(off), THIN_ACCS);
+            asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(rp.c) : "s"(wq), "n"(off + 16));
+            float last;
+            asm volatile("s_load_dword %0, %1, %2" : "=s"(last) : "s"(wq), "n"(off + 24));
+            rp.a[0] = last;
+        }
+#undef THIN_ACCS
+    };
+    auto landed = [&](RowPair& rp) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rp.a), "+s"(rp.b), "+s"(rp.c)); };
+    auto fmas = [&](auto Q, const RowPair& rp, const float (&v)[NB][NB]) {
+        constexpr int q = decltype(Q)::value;
+#pragma unroll
+        for (int e = 0; e < 2 * K; ++e) {
+            const int cr = 2 * q + e / K, c = e % K;
+            if (cr < CI * K) {
+                const int ci = cr / K, r = cr - ci * K;
+                float wv;
+                if constexpr (2 * q + 1 < CI * K) wv = e < 8 ? rp.a[e] : (e < 12 ? rp.b[e - 8] : rp.c[e - 12]);
+                else wv = e < 4 ? rp.b[e] : (e < 6 ? rp.c[e - 4] : rp.a[0]);
+                // pixel parities this tap belongs to, and the neighbour it multiplies:  y + P - r = 2 oy  with  y = 2hh + ph
+                const int ph = (r + P) & 1, pw = (c + P) & 1;
+                const int j = (P + ph - r) / 2 + J0, i = (P + pw - c) / 2 + J0;  // (numerators are even by construction)
+                acc[ph][pw][ci] = __builtin_fmaf(wv, v[j][i], acc[ph][pw][ci]);
+            }
+        }
+    };
+    auto accumulate = [&](const float (&v)[NB][NB], const float* wq) {
+        RowPair ra, rb;
+        ra.a = rb.a = s8f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        issue(std::integral_constant<int, 0>(), ra, wq);
+#define THIN_PAIR(Q, CUR, NXT)                                                                 \
+    landed(CUR);                                                                               \
+    if constexpr (Q + 1 < NPAIR) issue(std::integral_constant<int, (Q + 1 < NPAIR ? Q + 1 : Q)>(), NXT, wq); \
+    fmas(std::integral_constant<int, Q>(), CUR, v);
+        THIN_PAIR(0, ra, rb) THIN_PAIR(1, rb, ra) THIN_PAIR(2, ra, rb) THIN_PAIR(3, rb, ra) THIN_PAIR(4, ra, rb) THIN_PAIR(5, rb, ra)
+        THIN_PAIR(6, ra, rb) THIN_PAIR(7, rb, ra) THIN_PAIR(8, ra, rb) THIN_PAIR(9, rb, ra) THIN_PAIR(10, ra, rb)
+#undef THIN_PAIR
+        static_assert(NPAIR == 11, "THIN_PAIR sequence above");
+    };
+    int co = 0;
+    for (; co + 1 < Co; co += 2) {
+        float va[NB][NB], vb[NB][NB];
+        load_patch(va, soff);
+        load_patch(vb, soff + oplane * 4);
+        accumulate(va, wc0);
+        accumulate(vb, wc0 + CI * K * K);
+        soff += 2 * oplane * 4;
+        wc0 += 2 * CI * K * K;
+    }
+    if (co < Co) {
+        float va[NB][NB];
+        load_patch(va, soff);
+        accumulate(va, wc0);
+    }
+    if (live) {
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const int y = 2 * hh + ph;
+                if (y < H) {
+#pragma unroll
+                    for (int pw = 0; pw < 2; ++pw) {
+                        const int x = 2 * ww + pw;
+                        if (x < W) {
+                            const size_t o = (((size_t)b * CI + ci) * H + y) * W + x;
+                            float val = acc[ph][pw][ci];
+                            if (relu_below) val = (relu_below[o] <= 0.f) ? 0.f : val;
+                            dx[o] = val;
+                        }
+                    }
+                }
+            }
+    }
+}
+
 }  // namespace
 
 namespace cnn_amd {
@@ -121,12 +281,24 @@ namespace cnn_amd {
 bool thin_dgrad_supported(const cnn_conv2d_desc* d) {
     const char* e = getenv("CNN_AMD_DGRAD_THIN");
     if (e && atoi(e) == 0) return false;
+    if (d->Ci == 3 && d->k == 7 && d->s == 2 && d->pad == 3)  // the 7x7 stem: conv_dgrad_thin_s2
+        return (long long)d->B * d->Co * cnn_conv2d_out_dim(d->H, 7, 2, 3) * cnn_conv2d_out_dim(d->W, 7, 2, 3) < (1ll << 29) &&  // (32-bit byte offsets)
+               (long long)d->B * (((d->H + 1) / 2) * ((d->W + 1) / 2) + 63) / 64 < (1ll << 31) - 8;
     return d->Ci == 3 && d->k == 3 && d->s == 1 && d->pad >= 0 && d->pad <= 1 && (long long)d->B * ((d->H + 3) / 4) * ((d->W + 63) / 64) < (1ll << 31) - 8;
 }
 
 // w: the filters in the reference layout [Co][3][3][3] (for the *_prepared entry points: the verbatim copy cnn_conv2d_prepare_filters made)
 int thin_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* relu_below, float* dx, hipStream_t s) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
+    if (d->s == 2) {
+        const int U = (d->H + 1) / 2, V = (d->W + 1) / 2, ipi = (U * V + 63) / 64;
+        const long long nw = (long long)d->B * ipi;
+        const unsigned g2 = (unsigned)((nw + kThinWaves - 1) / kThinWaves);
+        CNN_KLAUNCH(s, relu_below ? "conv_dgrad_thin<3,k7s2>+relu" : "conv_dgrad_thin<3,k7s2>",
+                    (conv_dgrad_thin_s2<7><<<g2, kThinWaves * 64, 0, s>>>(dy, w, relu_below, dx, d->B, d->Co, d->H, d->W, Ho, Wo, U, V, ipi)),
+                    CONV_TAG(d));
+        return CNN_AMD_OK;
+    }
     const int bands = (d->H + 3) / 4, segs = (d->W + 63) / 64;
     const long long waves = (long long)d->B * bands * segs;
     const unsigned grid = (unsigned)((waves + kThinWaves - 1) / kThinWaves);
