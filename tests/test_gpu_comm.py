@@ -177,3 +177,64 @@ def test_batch_stager_orders_producer_upload_and_consumer(T):
         want = np.maximum(np.arange(n, dtype=np.float32) * 0.5 - i, 0)
         assert np.array_equal(y.cpu().numpy(), want), i
     stager.close()
+
+
+def test_published_kernels_order_another_stream(T):
+    """cnn_amd_publish_next_kernel / cnn_amd_wait_published: a second stream that waits for the published kernel sees its result --
+    both for a kernel that carries the event in its own dispatch packet (linear backward, a launch_pub site) and for one that falls
+    back to a plain event record (ReLU); waiting without anything published, or before the armed kernel was launched, is an error"""
+    from cnn_amd import capi
+
+    lib = capi.load()
+    other = T.cuda.Stream()
+    with pytest.raises(capi.CnnAmdError):
+        with T.cuda.stream(T.cuda.Stream()):  # (a fresh stream: whatever earlier tests published belongs to other streams / is consumed)
+            capi.publish_next_kernel()
+            capi.wait_published(other)  # armed, not launched yet
+    # consume the arm so that it does not leak into the next launch of this thread on that stream
+    B, n_in, n_out = 64, 4608, 3
+    x = T.rand((B, n_in), device="cuda")
+    dy = T.rand((B, n_out), device="cuda") - 0.5
+    w = T.rand((n_in, n_out), device="cuda") - 0.5
+    for kind in ("linear_bwd", "relu"):
+        for rep in range(3):
+            T.cuda.synchronize()
+            big = T.rand((1 << 24,), device="cuda") - 0.5
+            out = T.zeros_like(big)
+            gw, gb, dx = T.empty_like(w), T.empty(n_out, device="cuda"), T.zeros((B, n_in), device="cuda")
+            capi.publish_next_kernel()
+            if kind == "relu":
+                capi.check(lib.cnn_relu_forward(capi._ptr(big), capi._ptr(out), big.numel(), capi._stream()), "cnn_relu_forward")
+            else:
+                capi.linear_backward(x, dy, w, float(B), gw, gb, dx, relu_below=True)
+            capi.wait_published(other)
+            with T.cuda.stream(other):
+                got = (out.clone() if kind == "relu" else dx.clone())
+            other.synchronize()
+            T.cuda.synchronize()
+            ref = T.clamp(big, min=0) if kind == "relu" else dx
+            assert T.equal(got, ref), (kind, rep)
+
+
+def test_side_stream_handle_and_early_reduction_flush(T):
+    """cnn_amd_side_stream_get hands out the (stable) side stream of this thread; cnn_amd_flush_reduces with nothing recorded is a
+    no-op; a deferred weight gradient flushed on the side stream and joined equals the in-order call bit for bit"""
+    from cnn_amd import capi
+
+    s1, s2 = capi.side_stream(), capi.side_stream()
+    assert s1.cuda_stream != 0 and s1.cuda_stream == s2.cuda_stream
+    capi.flush_reduces()
+    case = (8, 16, 55, 55, 32, 3, 2, 0)
+    conv = capi.Conv2d(*case)
+    x = T.rand((8, 16, 55, 55), device="cuda")
+    w = T.randn((32, 16, 3, 3), device="cuda") * 0.1
+    dy = T.rand(conv.out_shape(), device="cuda") - 0.5
+    gw_ref, gb_ref, dx_ref = T.empty_like(w), T.empty(32, device="cuda"), T.empty_like(x)
+    conv.backward(x, dy, w, 8.0, gw_ref, gb_ref, dx_ref)
+    gw, gb, dx = T.full_like(w, 7.0), T.full((32,), 7.0, device="cuda"), T.empty_like(x)
+    conv.backward(x, dy, w, 8.0, gw, gb, dx, defer_join=True)
+    with T.cuda.stream(s1):
+        capi.flush_reduces()  # the recorded reduction, now, on the side stream
+    capi.side_stream_join()
+    T.cuda.synchronize()
+    assert T.equal(gw, gw_ref) and T.equal(gb, gb_ref) and T.equal(dx, dx_ref)
