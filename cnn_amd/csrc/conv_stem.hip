@@ -165,6 +165,106 @@ __global__ __launch_bounds__(SWAVES * 64, 4) void conv_stem_fwd_kernel(const Ste
     }
 }
 
+
+// ---- weight / bias gradient of the same layer (cpu/src/conv2d.cpp:117-159) ---------------------------------------------------------
+//   gw[co][ci][ky][kx] = sum_{b,oy,ox} dy[b][co][oy][ox] * x[b][ci][2oy+ky-3][2ox+kx-3],   gb[co] = sum dy[b][co][oy][ox]
+// GEMM on v_mfma_f32_16x16x4_f32: M = the 147 taps + one "tap" that reads a row of ones (its sums are the bias gradient) in ten
+// 16-row tiles, N = co in 16-column tiles, K = the pixels of ONE output row, four per step.  A workgroup item = (image, output
+// row): it stages the 7 zero-padded input rows x 3 channels (the forward kernel's row image, 22 KB) and the row's deltas
+// TRANSPOSED to [co][pixel] (pitch 132: 16-byte rows, 2-way banked reads) -- in HBM a pixel's 64 deltas are 64 cache lines apart.
+//   A (lane = tap, k = pixel 4j + kq): x[tap_off + 2 (4j + kq) + 1] -- per-lane tap offset + an immediate 32 j;
+//   B (lane = co, k = pixel):          dyT[co][4j + kq].
+// Wave w owns co tile w & 3 and five of the ten tap tiles: 5 MFMAs per 6 LDS reads, 20 accumulator registers, kept across ALL items
+// of the (persistent) workgroup; one [Co][148] slab per workgroup at the end, summed by reduce_slabs like every other weight gradient.
+constexpr int GTAPS = SKK + 1;                 // 148: taps + the ones "tap"
+static_assert((GTAPS + 15) / 16 == 10, "two groups of five tap tiles");
+constexpr int GXROWS = SCI * SK;               // 21 staged rows (+ 1 row of ones)
+constexpr int GDP = SCOLS + 4;                 // 132: pitch of the transposed delta row
+constexpr int GWAVES = 8;
+
+struct StemGradParams {
+    const float* x;
+    const float* dy;
+    float* slabs;  // [gridDim.x][Co][148]
+    int B, H, W, Co, Ho, Wo;
+    int col_blocks, items;  // items = B * Ho * col_blocks
+};
+
+__global__ __launch_bounds__(GWAVES * 64, 4) void conv_stem_wgrad_kernel(const StemGradParams p) {
+    extern __shared__ float lds[];
+    float* const Xs = lds;                               // [21][264], then one row of 1.0f
+    float* const Ds = lds + (GXROWS + 1) * SLW;          // [64][132]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, kq = lane >> 4;
+    const int co0 = blockIdx.y * 64;
+    const int ct = wave & 3, tg = wave >> 2;
+    for (int i = tid; i < SLW; i += GWAVES * 64) Xs[GXROWS * SLW + i] = 1.f;
+
+    // A: this lane's tap of each of its five tiles -> offset of x[ci][ky][kx] in the staged image (row 0 = input row 2oy-3, column 0 =
+    // input column -4); tap 147 and the padding taps behind it read the ones row
+    int a_off[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int tap = 16 * (tg * 5 + i) + m;
+        a_off[i] = (tap < SKK ? (tap / SK) * SLW + tap % SK : GXROWS * SLW) + 2 * kq + 1;  // row ci*7 + ky = tap / 7 of THIS image
+    }
+    const int b_off = (16 * ct + m) * GDP + kq;
+
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int it = blockIdx.x; it < p.items; it += gridDim.x) {
+        const int cb = it % p.col_blocks, oy = (it / p.col_blocks) % p.Ho, b = it / (p.col_blocks * p.Ho);
+        const int ox0 = cb * SCOLS;
+        const int npix = p.Wo - ox0 < SCOLS ? p.Wo - ox0 : SCOLS;
+        const int iy0 = SS * oy - SPAD, ix0 = SS * ox0 - 4;
+        __syncthreads();  // (the previous item's operands have been consumed)
+        for (int e = tid; e < GXROWS * (SLW / 4); e += GWAVES * 64) {
+            const int row = e / (SLW / 4), c4 = e - row * (SLW / 4);
+            const int ci = row / SK, rr = row - ci * SK;
+            const int iy = iy0 + rr, ix = ix0 + 4 * c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix + 3 < p.W) v = *(const float4*)(p.x + (((size_t)b * SCI + ci) * p.H + iy) * p.W + ix);
+            *(float4*)(Xs + row * SLW + 4 * c4) = v;
+        }
+        // the row's deltas, transposed: [co][pixel], zero behind the row's end (Wo % 4 == 0) and for channels beyond Co
+        for (int e = tid; e < 64 * (SCOLS / 4); e += GWAVES * 64) {
+            const int co = e / (SCOLS / 4), c4 = e - co * (SCOLS / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * c4 < npix && co0 + co < p.Co)
+                v = *(const float4*)(p.dy + (((size_t)b * p.Co + co0 + co) * p.Ho + oy) * p.Wo + ox0 + 4 * c4);
+            *(float4*)(Ds + co * GDP + 4 * c4) = v;
+        }
+        __syncthreads();
+        const int steps = (npix + 3) >> 2;
+        const float* ap = Xs;
+        const float* bp = Ds + b_off;
+        for (int j = 0; j < steps; ++j) {
+            const float bv = bp[4 * j];
+            float av[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) av[i] = ap[a_off[i] + 8 * j];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[i], 0, 0, 0);
+        }
+    }
+    // D[row = tap 4 kq + r][column = co m] -> slab[co][tap]
+    float* slab = p.slabs + (size_t)blockIdx.x * p.Co * GTAPS;
+    const int co = co0 + 16 * ct + m;
+    if (co < p.Co) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tap = 16 * (tg * 5 + i) + 4 * kq + r;
+                if (tap < GTAPS) slab[(size_t)co * GTAPS + tap] = acc[i][r];
+            }
+    }
+}
+
 }  // namespace
 
 namespace cnn_amd {
@@ -211,6 +311,42 @@ int stem_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const
         CNN_KLAUNCH(s, "conv_stem_fwd<3,7,2,3>+relu", (conv_stem_fwd_kernel<true><<<grid, SWAVES * 64, lds_bytes, s>>>(p)), CONV_TAG(d));
     else
         CNN_KLAUNCH(s, "conv_stem_fwd<3,7,2,3>", (conv_stem_fwd_kernel<false><<<grid, SWAVES * 64, lds_bytes, s>>>(p)), CONV_TAG(d));
+    return CNN_AMD_OK;
+}
+
+// ---- weight gradient: slabs of [Co][148] floats ([147 filter sums | 1 bias sum] per output channel), one per workgroup column
+int stem_wgrad_slots(const cnn_conv2d_desc* d) {
+    if (d->Ci != SCI || d->k != SK || d->s != SS || d->pad != SPAD || d->W % 8 != 0 || d->Co < 1) return 0;
+    const char* e = getenv("CNN_AMD_STEM_WGRAD");
+    if (e && atoi(e) == 0) return 0;
+    const int Ho = cnn_conv2d_out_dim(d->H, SK, SS, SPAD), Wo = cnn_conv2d_out_dim(d->W, SK, SS, SPAD);
+    const long long items = (long long)d->B * Ho * ((Wo + SCOLS - 1) / SCOLS);
+    if (items >= (1ll << 31)) return 0;
+    const int co_blocks = (d->Co + 63) / 64;
+    long long gx = 2ll * kNumCU / co_blocks;  // two workgroups per CU
+    if (gx < 1) gx = 1;
+    if (gx > items) gx = items;
+    return (int)gx;
+}
+
+int stem_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s) {
+    const int slots = stem_wgrad_slots(d);
+    CNN_REQUIRE(slots > 0, "stem_wgrad: geometry not covered");
+    StemGradParams p;
+    p.x = x; p.dy = dy; p.slabs = slabs;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Co = d->Co;
+    p.Ho = cnn_conv2d_out_dim(d->H, SK, SS, SPAD);
+    p.Wo = cnn_conv2d_out_dim(d->W, SK, SS, SPAD);
+    p.col_blocks = (p.Wo + SCOLS - 1) / SCOLS;
+    p.items = d->B * p.Ho * p.col_blocks;
+    const size_t lds_bytes = ((size_t)(GXROWS + 1) * SLW + (size_t)64 * GDP) * sizeof(float);
+    static DeviceOnce attr_once;
+    if (attr_once.needed()) {
+        CNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_stem_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_once.mark();
+    }
+    const dim3 grid((unsigned)slots, (unsigned)((d->Co + 63) / 64));
+    CNN_KLAUNCH(s, "conv_stem_wgrad<3,7,2,3>", (conv_stem_wgrad_kernel<<<grid, GWAVES * 64, lds_bytes, s>>>(p)), CONV_TAG(d));
     return CNN_AMD_OK;
 }
 

@@ -22,6 +22,8 @@ int direct_conv_wgrad_pooled(const cnn_conv2d_desc* d, const float* x, const flo
                              float* slabs, hipStream_t s);
 int direct_first_layer_finish(const cnn_conv2d_desc* d, const float* slabs, int nslots, float divisor, float* gw, float* gb, float* w,
                               float* bias, float lr, float grad_scale, void* fwd_img, void* dgrad_img, hipStream_t s);
+int stem_wgrad_slots(const cnn_conv2d_desc* d);  // conv_stem.hip: 3 -> Co, 7x7, stride 2, pad 3
+int stem_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
 int wgrad_rd_slots(const cnn_conv2d_desc* d);  // conv_wgrad_rd.hip: register-direct MFMA kernel (3x3, stride 1/2, pad 0)
 int wgrad_rd_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
 int wgrad_rd_pooled_slots(const cnn_conv2d_desc* d);
@@ -675,6 +677,9 @@ size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d) {
     const int rps = wgrad_rd_pooled_slots(d);
     const size_t rpw = rps ? (size_t)(rps + (rps + 63) / 64) * d->Co * (d->Ci * 9 + 1) : 0;
     if (rpw > m) m = rpw;
+    const int sts = stem_wgrad_slots(d);
+    const size_t stw = sts ? (size_t)(sts + (sts + 63) / 64) * d->Co * 148 : 0;
+    if (stw > m) m = stw;
     return (m + 64) * sizeof(float);
 }
 
@@ -760,6 +765,16 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
             char tagr[160];
             snprintf(tagr, sizeof(tagr), CONV_TAG(d));
             return reduce_slabs(sr, (const float*)ws, rs, n, (float*)ws + (size_t)rs * n, gw, divisor, tagr, d->Ci * 9, gb);
+        }
+    }
+    if (const int sts = stem_wgrad_slots(d)) {
+        const size_t n = (size_t)d->Co * 148, need_s = (size_t)(sts + (sts + 63) / 64) * n * sizeof(float);
+        if (ws_bytes >= need_s) {
+            hipStream_t ss = as_stream(stream);
+            if (int rc = stem_wgrad_launch(d, x, dy, (float*)ws, ss)) return rc;
+            char tags[160];
+            snprintf(tags, sizeof(tags), CONV_TAG(d));
+            return reduce_slabs(ss, (const float*)ws, sts, n, (float*)ws + (size_t)sts * n, gw, divisor, tags, 147, gb);
         }
     }
     WPlan pl;

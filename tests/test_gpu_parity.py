@@ -58,6 +58,7 @@ CONV_CASES = [
     (1, 3, 224, 224, 64, 7, 2, 3),   # the ResNet stem at full resolution (row staging of 230-float rows)
     (3, 3, 38, 44, 72, 7, 2, 3),     # conv_stem.hip: two channel blocks (64 + 8), 19 x 22 outputs: partial row group, one pixel tile
     (2, 3, 20, 260, 32, 7, 2, 3),    # ... 130 output columns: two column blocks of 128
+    (2, 3, 22, 264, 72, 7, 2, 3),    # ... W % 8 == 0: also the stem weight-gradient kernel, 132 columns (128 + 4), 64 + 8 channels
     (3, 32, 9, 11, 64, 3, 1, 0),     # stride-1 register-direct data gradient: one tile of 32 channels, borders everywhere
     (2, 64, 8, 7, 128, 3, 1, 0),     # ... two tiles per wave
     (3, 3, 70, 130, 24, 3, 1, 1),    # thin-input data gradient (conv_dgrad_thin.hip): three column segments, ragged last band
