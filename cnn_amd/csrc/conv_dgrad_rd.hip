@@ -474,7 +474,11 @@ constexpr unsigned kM16OOB = 0x7ffffffcu;
 
 // KS > 1 (Co = KS*CO): the dy channels are split over KS waves of a workgroup (NW = slices*KS waves: one pixel partition per
 // workgroup); wave `half` 1.. hands its partial sums to wave 0 of the same slice through LDS (one barrier per pixel group).
-template <int CO, int NW, bool PREP, int KS>
+// PD (pad 1, the stage entries of the ResNet-shaped stack): the same arithmetic on the zero-padded image -- grid position (u, v) owns
+// padded pixels (2u | 2u+1, 2v | 2v+1) = real pixels (2u-1 | 2u, 2v-1 | 2v); dy and the tap classes are untouched, only where dx
+// (and the fused ReLU mask) lives moves by one row and one column: pairs lose their 8-byte alignment, so four 4-byte stores per
+// channel instead of two 8-byte ones, each with its own in-image test.
+template <int CO, int NW, bool PREP, int KS, bool PD = false>
 __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdParams p) {
     constexpr int C4 = CO / 4, NA = CO * 9 / 4;
     constexpr int NB = CNN_M16_DGRAD_NB;  // ring of granules (4 dy channels: two 8-byte loads, 9 MFMA steps); NB - 1 granules in flight
@@ -510,6 +514,7 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdPa
         bool ca, cb;      // column case: a: pair = (v-1, v) | b: v = 0, pair = (0, 1) | neither: v = Wo, pair = (Wo-2, Wo-1)
         unsigned x0, x1;  // dx byte offsets of rows 2u, 2u+1 at column 2v, channel 4k (or out of range: no store)
         bool w1;          // column 2v+1 exists (false only in the last column of an odd W)
+        unsigned xq[2][2];  // PD: byte offset of dx[row 2u-1+ph][column 2v-1+pw] or out of range
     };
     auto locate = [&](int g, Loc& L) {
         const int pix = g * 16 + n;
@@ -525,10 +530,24 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdPa
         const unsigned base = (unsigned)((b * CO * KS + half * CO + k) * plane + u * p.Wo + cs) * 4u;
         L.o0 = (live && u < p.Ho) ? base : kM16OOB;
         L.o1 = (live && u >= 1) ? base - (unsigned)p.Wo * 4u : kM16OOB;
-        const unsigned xb = (unsigned)(((size_t)b * p.Ci + 16 * slice + 4 * k) * hw + (size_t)(2 * u) * p.W + 2 * v) * 4u;
-        L.x0 = live ? xb : kM16OOB;
-        L.x1 = (live && 2 * u + 1 < p.H) ? xb + (unsigned)p.W * 4u : kM16OOB;
-        L.w1 = 2 * v + 1 < p.W;
+        if constexpr (PD) {
+            const int y0 = 2 * u - 1, c0 = 2 * v - 1;
+            const int xb = (int)((((size_t)b * p.Ci + 16 * slice + 4 * k) * hw) * 4u) + (y0 * p.W + c0) * 4;  // (may be "negative": only used when valid)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                for (int pw = 0; pw < 2; ++pw) {
+                    const bool ok = live && (unsigned)(y0 + ph) < (unsigned)p.H && (unsigned)(c0 + pw) < (unsigned)p.W;
+                    L.xq[ph][pw] = ok ? (unsigned)(xb + (ph * p.W + pw) * 4) : kM16OOB;
+                }
+            L.x0 = L.x1 = kM16OOB;
+            L.w1 = true;
+        } else {
+            const unsigned xb = (unsigned)(((size_t)b * p.Ci + 16 * slice + 4 * k) * hw + (size_t)(2 * u) * p.W + 2 * v) * 4u;
+            L.x0 = live ? xb : kM16OOB;
+            L.x1 = (live && 2 * u + 1 < p.H) ? xb + (unsigned)p.W * 4u : kM16OOB;
+            L.w1 = 2 * v + 1 < p.W;
+        }
     };
     auto load_g = [&](v2f (&buf)[2], int c4, const Loc& L) {
         const int so = c4 * 4 * plane * 4;
@@ -545,6 +564,17 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdPa
         // the fused ReLU::backward mask (relu.cpp:38) of this group's 8 output pairs is requested now and used in the epilogue
         // (a lane in the last column of an odd W reads the pair one element to the left and uses its second half)
         v2f mk[4][2];
+        if constexpr (PD) {
+            if (p.relu_below && half == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph) {
+                        mk[r][ph].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, (int)cur.xq[ph][0], (int)(r * chs), 0));
+                        mk[r][ph].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, (int)cur.xq[ph][1], (int)(r * chs), 0));
+                    }
+            }
+        } else
         if (p.relu_below && half == 0) {
             const unsigned m0 = (cur.w1 || cur.x0 == kM16OOB) ? cur.x0 : cur.x0 - 4u, m1 = (cur.w1 || cur.x1 == kM16OOB) ? cur.x1 : cur.x1 - 4u;
 #pragma unroll
@@ -603,6 +633,22 @@ __global__ __launch_bounds__(NW * 64) void conv_dgrad_m16_s2_kernel(const DgRdPa
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[c][r] += red[rb][h][slice][c * 4 + r][lane];
         }
+        if constexpr (PD) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    float v0 = acc[ph * 2][r], v1 = acc[ph * 2 + 1][r];
+                    if (p.relu_below) {
+                        v0 = (mk[r][ph].x <= 0.f) ? 0.f : v0;
+                        v1 = (mk[r][ph].y <= 0.f) ? 0.f : v1;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), xrs, (int)cur.xq[ph][0], (int)(r * chs), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), xrs, (int)cur.xq[ph][1], (int)(r * chs), 0);
+                }
+            cur = nxt;
+            continue;
+        }
         // epilogue, branch-free per lane: buffer stores whose offset is out of range for dead lanes / the row behind the tensor
         const unsigned pp0 = cur.w1 ? cur.x0 : kM16OOB, pp1 = cur.w1 ? cur.x1 : kM16OOB;  // (pw = 0,1) pairs
         const unsigned ss0 = cur.w1 ? kM16OOB : cur.x0, ss1 = cur.w1 ? kM16OOB : cur.x1;  // single element, last column of an odd W
@@ -636,7 +682,8 @@ struct DgRdPlan {
 inline bool m16_wanted(const cnn_conv2d_desc* d) {
     // (Ci, Co) = (16, 32) | (32, 64) | (64, 128: dy channels split over two waves): 72 | 144 | 144 filter registers per wave
     if (d->s != 2 || !((d->Ci == 16 && d->Co == 32) || (d->Ci == 32 && d->Co == 64) || (d->Ci == 64 && d->Co == 128))) return false;
-    if ((long long)d->B * d->Co * cnn_conv2d_out_dim(d->H, 3, 2, 0) * cnn_conv2d_out_dim(d->W, 3, 2, 0) >= (1ll << 29) ||
+    if (d->pad != 0 && !(d->pad == 1 && d->Ci == 64 && d->Co == 128)) return false;  // (pad 1: only the instance the ResNet-shaped stack needs)
+    if ((long long)d->B * d->Co * cnn_conv2d_out_dim(d->H, 3, 2, d->pad) * cnn_conv2d_out_dim(d->W, 3, 2, d->pad) >= (1ll << 29) ||
         (long long)d->B * d->Ci * d->H * d->W >= (1ll << 29))
         return false;  // (32-bit buffer offsets)
     const char* e = getenv("CNN_AMD_DGRAD_M16");
@@ -647,7 +694,8 @@ inline bool m16_wanted(const cnn_conv2d_desc* d) {
 }
 
 bool make_plan(const cnn_conv2d_desc* d, DgRdPlan* pl) {
-    if (d->k != 3 || d->pad != 0 || (d->s != 2 && d->s != 1)) return false;
+    if (d->k != 3 || (d->s != 2 && d->s != 1)) return false;
+    if (d->pad != 0 && !(d->pad == 1 && d->s == 2 && m16_wanted(d))) return false;
     if (d->s == 1 && ((d->Co != 64 && d->Co != 128) || d->Ci % 32 != 0)) return false;
     if ((d->Co != 32 && d->Co != 64 && d->Co != 128) || d->Ci % 16 != 0) return false;  // (Ci = 16: half of the 32 MFMA rows idle)
     // Co = 32 / Ci = 16 (conv_layer_2): measured 117 us against 95 us for the packed VALU kernel -> opt-in only
@@ -657,11 +705,11 @@ bool make_plan(const cnn_conv2d_desc* d, DgRdPlan* pl) {
         if (atoi(e) == 0) return false;
     DgRdParams& p = pl->p;
     p.B = d->B; p.Ci = d->Ci; p.H = d->H; p.W = d->W;
-    p.Ho = cnn_conv2d_out_dim(d->H, 3, d->s, 0);
-    p.Wo = cnn_conv2d_out_dim(d->W, 3, d->s, 0);
+    p.Ho = cnn_conv2d_out_dim(d->H, 3, d->s, d->pad);
+    p.Wo = cnn_conv2d_out_dim(d->W, 3, d->s, d->pad);
     if (p.Ho < 1 || p.Wo < (d->s == 1 ? 3 : 2)) return false;
     if (d->s == 1) { p.U = d->H; p.V = d->W; }          // every dx pixel is a grid pixel
-    else { p.U = (d->H + 1) / 2; p.V = (d->W + 1) / 2; }
+    else { p.U = (d->H + 2 * d->pad + 1) / 2; p.V = (d->W + 2 * d->pad + 1) / 2; }  // (pad 1: the grid of the zero-padded image)
     p.UV = p.U * p.V;
     const long long pixels = (long long)d->B * p.UV;
     if (pixels >= (1ll << 30) || (long long)d->B * d->Ci * d->H * d->W >= (1ll << 31) || (long long)d->B * d->Co * p.Ho * p.Wo >= (1ll << 31))
@@ -755,6 +803,13 @@ int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const floa
                 d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad)
         if (d->Co == 32) { if (pl.p.tr == 2) M16(32, true, 4, 1); else M16(32, false, 4, 1); }
         else if (d->Co == 64) { if (pl.p.tr == 2) M16(64, true, 4, 1); else M16(64, false, 4, 1); }
+        else if (d->pad == 1) {
+#define M16P(PREP_)                                                                                                                        \
+    CNN_KLAUNCH(s, nm, (launch_pub(conv_dgrad_m16_s2_kernel<64, 8, PREP_, 2, true>, dim3(pl.blocks_x), dim3(8 * 64), 0, s, pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", \
+                d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad)
+            if (pl.p.tr == 2) M16P(true); else M16P(false);
+#undef M16P
+        }
         else { if (pl.p.tr == 2) M16(64, true, 8, 2); else M16(64, false, 8, 2); }
 #undef M16
         return CNN_AMD_OK;

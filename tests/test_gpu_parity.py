@@ -58,6 +58,8 @@ CONV_CASES = [
     (1, 3, 224, 224, 64, 7, 2, 3),   # the ResNet stem at full resolution (row staging of 230-float rows)
     (3, 3, 38, 44, 72, 7, 2, 3),     # conv_stem.hip: two channel blocks (64 + 8), 19 x 22 outputs: partial row group, one pixel tile
     (2, 3, 20, 260, 32, 7, 2, 3),    # ... 130 output columns: two column blocks of 128
+    (2, 64, 14, 14, 128, 3, 2, 1),   # stage entry of the ResNet-shaped stack: the 16x16x4 stride-2 data gradient with pad 1
+    (3, 64, 9, 11, 128, 3, 2, 1),    # ... odd sizes: first / last padded row and column fall outside the image
     (2, 3, 22, 264, 72, 7, 2, 3),    # ... W % 8 == 0: also the stem weight-gradient kernel, 132 columns (128 + 4), 64 + 8 channels
     (3, 32, 9, 11, 64, 3, 1, 0),     # stride-1 register-direct data gradient: one tile of 32 channels, borders everywhere
     (2, 64, 8, 7, 128, 3, 1, 0),     # ... two tiles per wave
@@ -791,7 +793,7 @@ def test_pool_fused_net_is_bit_identical(T, defer):
         assert T.equal(a.d_conv[1], T.where(b.pool_out <= 0, T.zeros_like(b.d_conv[1]), b.d_conv[1]))
 
 
-@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 13)] + [(3, 32, 9, 11, 64, 3, 1, 0), (2, 32, 28, 30, 64, 3, 2, 0), (1, 96, 9, 12, 128, 3, 2, 0)], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 13)] + [(3, 32, 9, 11, 64, 3, 1, 0), (2, 32, 28, 30, 64, 3, 2, 0), (1, 96, 9, 12, 128, 3, 2, 0), (2, 64, 14, 14, 128, 3, 2, 1), (3, 64, 9, 11, 128, 3, 2, 1)], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
 def test_conv2d_backward_data_relu_fusion_is_bit_identical(T, case):
     """cnn_conv2d_backward_data_relu == cnn_conv2d_backward_data + cnn_relu_backward, every kernel family, plain and prepared"""
     from cnn_amd import capi
