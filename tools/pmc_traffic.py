@@ -37,7 +37,7 @@ def canonical(name):
     m = re.match(r"conv_dgrad_rd_s2_kernel<(\d+),\d+,\d+,\d+(,(true|false))?>$", name)
     if m:
         return f"conv_dgrad_rd<2,{m.group(1)}>"
-    m = re.match(r"conv_dgrad_m16_s2_kernel<(\d+),\d+,(true|false),(\d+)>$", name)
+    m = re.match(r"conv_dgrad_m16_s2_kernel<(\d+),\d+,(true|false),(\d+)(?:,(?:true|false))?>$", name)
     if m:  # (CO per wave, NW, prepared, dy-channel split)
         return f"conv_dgrad_rd<2,{int(m.group(1)) * int(m.group(3))},m16>"
     m = re.match(r"conv_fwd_m16_kernel<(\d+),(\d+),\d+,(true|false),\d+>$", name)
@@ -49,7 +49,7 @@ def canonical(name):
     m = re.match(r"wgrad_rd_kernel<(\d+,\d+,\d+),(true|false)>$", name)
     if m:
         return f"wgrad_rd<{m.group(1)}>" + ("+pool" if m.group(2) == "true" else "")
-    m = re.match(r"conv_wgrad_win_kernel<(\d),(true|false)>$", name)
+    m = re.match(r"conv_wgrad_win_kernel<(\d),(true|false)(?:,(?:true|false))?>$", name)
     if m:
         return "conv_wgrad_win<3,16,3,2>" + {"0": "", "1": "+pool", "2": "+poolm"}[m.group(1)]
     m = re.match(r"wgrad_rd_kernel_p1<(\d+,\d+,\d+),(true|false)>$", name)
