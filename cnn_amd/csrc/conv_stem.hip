@@ -17,8 +17,10 @@
 // Output: y (+ bias), optionally the ReLU output as well (relu.cpp:25).  Traffic: x is read ~1.6x (38 MB), y written once (205 MB at
 // batch 64).  [gpu] batch 64: 212 us = 71 TFLOP/s (implicit GEMM: 750 us).  CNN_AMD_STEM_DBG: without the MFMA steps 93 us (the
 // 205 MB of stores + staging), without re-staging 196 us -- the MFMA loop itself runs near its 110 us floor, but a workgroup's store
-// burst + the next item's staging do not overlap the MFMAs of the other workgroup on the CU (both fall into step).  Next: issue the
-// next item's rows as LDS-DMA behind the barrier, wait for THEM, then fire the stores and compute while they drain.
+// burst + the next item's staging do not overlap the MFMAs of the other workgroup on the CU (both fall into step).  Tried: fetching
+// the next item's rows into registers behind the MFMAs, LDS-only barriers and the stores fired last (so that they drain under the
+// next item's MFMAs): 24 more live registers spill under the 128-register budget and the kernel got slower (227 us); the store
+// phase itself only reaches ~2.2 TB/s (448-byte rows: every second 128-byte segment straddles two lines); streaming stores: -2 %.
 #include "common.h"
 
 using namespace cnn_amd;
