@@ -587,6 +587,73 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
     const float* Ag = p.A + (size_t)mb * p.nchunk * a_floats;
     const int a_vec = a_floats / 4;
 
+    // ---- this wave's share of a chunk's ROW-IMAGE DMA, decoded ONCE (what changes from chunk to chunk is only the channel base
+    // cc*CK*XH*XW).  run_mode 1 / 2: every channel's rows of an image segment are one contiguous run.  run_mode 3 (padded layers
+    // with XW % 4 == 0: every 3x3 layer of the VGG / ResNet-shaped stacks): the LDS rows have a 4-float left pad and a pitch that is a
+    // multiple of 4, so a channel's row image is a sequence of 16-byte units of which unit 0 and the last one(s) of every row are pad
+    // (zeroed once, never written again) -- ONE 16-byte DMA instruction covers 64 consecutive LDS units = several rows, each lane
+    // fetching its own unit from HBM.  Before: one 4-byte DMA instruction per (channel, row), each behind an LDS read of the row
+    // table and 64-bit address arithmetic -- 7 instructions and ~3 400 - 4 900 cycles per wave and chunk right behind the barrier,
+    // where no wave has MFMAs in flight (the filter slab's 4.5 instructions: 800 cycles): 16 % of the 256->256 56x56 layer.
+    constexpr int MAXD = 8;
+    int d_lds[MAXD];        // float offset of the instruction's LDS destination inside the row image (wave-uniform)
+    unsigned d_src[MAXD];   // this lane's source element relative to the chunk's first channel plane, ~0u: lane inactive
+    int nd = 0;
+    bool desc_ok = false;
+    if (XM == 0 && p.run_mode != 0 && (unsigned long long)p.B * p.C * p.XH * p.XW < (1ull << 32)) {
+        desc_ok = true;
+        auto record = [&](int lds_off, unsigned src) {
+            if (nd < MAXD) {
+#pragma unroll
+                for (int i = 0; i < MAXD; ++i)
+                    if (i == nd) {
+                        d_lds[i] = lds_off;
+                        d_src[i] = src;
+                    }
+                ++nd;
+            } else {
+                desc_ok = false;
+            }
+        };
+        if (p.run_mode == 3) {
+            const int upr = p.LW >> 2, total = nrows * upr, per_ch = (total + 63) / 64, dcols = p.XW >> 2, pl4 = p.padL >> 2;
+            for (int j = wave; j < CK * per_ch; j += NWAVES) {
+                const int ck = j / per_ch, part = j - ck * per_ch;
+                const int u = part * 64 + lane;
+                const int rl = u / upr, cu = u - rl * upr;
+                int b, xrow;
+                if (rl < nrows0) {
+                    b = b0;
+                    xrow = u0 * p.su + p.r0 + rl;
+                } else {
+                    const int rr = rl - nrows0;
+                    b = b0 + 1 + rr / full;
+                    xrow = p.r0 + rr % full;
+                }
+                const bool on = u < total && cu >= pl4 && cu < pl4 + dcols && xrow >= 0 && xrow < p.XH;
+                const unsigned src = (unsigned)(((size_t)b * p.C * p.XH + xrow) * p.XW) + (unsigned)ck * (unsigned)(p.XH * p.XW) + (unsigned)(4 * (cu - pl4));
+                record(ck * p.chs + part * 256, on ? src : ~0u);
+            }
+        } else {
+            const int unit = (p.run_mode == 1) ? 4 : 1;
+            int lrow0 = 0;
+            for (int sg = 0; sg < nseg; ++sg) {
+                const int nr = (sg == 0) ? nrows0 : ((sg == nseg - 1) ? u1 * p.su + p.TR : full);
+                const int xrow0 = (sg == 0) ? u0 * p.su + p.r0 : p.r0;
+                const int runu = nr * p.XW / unit, per_ch = (runu + 63) / 64;
+                const unsigned gseg = (unsigned)(((size_t)(b0 + sg) * p.C * p.XH + xrow0) * p.XW);
+                for (int j = wave; j < CK * per_ch; j += NWAVES) {
+                    const int ck = j / per_ch, part = j - ck * per_ch;
+                    const int idx = part * 64 + lane;
+                    record(ck * p.chs + lrow0 * p.LW + part * 64 * unit,
+                           idx < runu ? gseg + (unsigned)ck * (unsigned)(p.XH * p.XW) + (unsigned)idx * unit : ~0u);
+                }
+                lrow0 += nr;
+            }
+        }
+        nd = __builtin_amdgcn_readfirstlane(nd);
+    }
+
     // ---- DMA of one chunk into buffer bi, issued as one burst right after the barrier (measured: spreading the issue
     //      over the taps costs more in decode math than it hides) ----
     auto issue_dma = [&](int cc, int bi) {
@@ -629,7 +696,20 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
             }
             return;
         }
-        if (p.run_mode) {
+        if (desc_ok && cc * CK + CK <= p.C && !(p.dbg & 64)) {  // (no channel padding in this chunk; 64: A/B switch)
+            const float* cbase = p.X + (size_t)cc * CK * p.XH * p.XW;
+#pragma unroll
+            for (int i = 0; i < MAXD; ++i) {
+                if (i < nd && d_src[i] != ~0u) {
+                    if (p.run_mode == 2)
+                        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(cbase + d_src[i]), (lds_void_ptr)(Xbuf + d_lds[i]), 4, 0, 0);
+                    else
+                        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(cbase + d_src[i]), (lds_void_ptr)(Xbuf + d_lds[i]), 16, 0, 0);
+                }
+            }
+            return;
+        }
+        if (p.run_mode == 1 || p.run_mode == 2) {
             // every channel's rows of one image segment are one contiguous run (HBM and LDS): moved 1 KiB per instruction
             // when rows are 16-byte multiples (run_mode 1), 256 B per instruction otherwise (run_mode 2)
             const int unit = (p.run_mode == 1) ? 4 : 1;  // floats per lane
@@ -1054,6 +1134,14 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     int padR = (p.V - 1) * p.su + p.TC - 1 + p.c0 - (p.XW - 1);
     if (padR < 0) padR = 0;
     p.LW = p.padL + p.XW + padR;
+    // DMA configurations on padded layers whose rows are 16-byte multiples: 4-float left pad, pitch a multiple of 4 floats -> the row
+    // image is staged by 16-byte DMA instructions that span several rows (run_mode 3 of igemm_dma_kernel)
+    const bool dma_cfg = pl->cfg >= CFG_D_M128;
+    const bool vecrows = dma_cfg && p.XW % 4 == 0 && p.padL > 0 && p.padL <= 4 && !(getenv("CNN_AMD_IGEMM_NOVECROWS") && atoi(getenv("CNN_AMD_IGEMM_NOVECROWS")) != 0);
+    if (vecrows) {
+        p.padL = 4;
+        p.LW = (4 + p.XW + padR + 3) & ~3;
+    }
     long long out_rows = (pl->NPIX + p.V - 2) / p.V + 1;
     if (out_rows > (long long)p.B * p.U) out_rows = (long long)p.B * p.U;
     long long nseg = (out_rows + p.U - 2) / p.U + 1;
@@ -1133,7 +1221,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     q.C = p.C; q.M = p.M; q.TR = p.TR; q.TC = p.TC; q.r0 = p.r0; q.c0 = p.c0;
     q.CK = pl->CK; q.MT = pl->MT; q.nchunk = p.nchunk; q.nmb = (int)pl->grid_y; q.kstep = pl->MF == 32 ? 2 : 4;
     q.a4 = pl->dma ? pl->CK / q.kstep : 0;
-    if (pl->xm == 0) p.run_mode = (pl->dma && !p.need_zero && p.LW == p.XW) ? ((p.XW % 4 == 0) ? 1 : 2) : 0;
+    if (pl->xm == 0) p.run_mode = (pl->dma && !p.need_zero && p.LW == p.XW) ? ((p.XW % 4 == 0) ? 1 : 2) : ((pl->dma && vecrows) ? 3 : 0);
     return CNN_AMD_OK;
 }
 
