@@ -600,7 +600,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
     unsigned d_src[MAXD];   // this lane's source element relative to the chunk's first channel plane, ~0u: lane inactive
     int nd = 0;
     bool desc_ok = false;
-    if (XM == 0 && p.run_mode != 0 && (unsigned long long)p.B * p.C * p.XH * p.XW < (1ull << 32)) {
+    if (p.run_mode != 0 && (unsigned long long)p.B * p.C * p.XH * p.XW < (1ull << 32)) {
         desc_ok = true;
         auto record = [&](int lds_off, unsigned src) {
             if (nd < MAXD) {
@@ -615,7 +615,16 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
                 desc_ok = false;
             }
         };
-        if (p.run_mode == 3) {
+        if constexpr (XM != 0) {
+            // whole images (small layers): the CK-channel block of image b0 + img is one contiguous run in HBM and in LDS
+            const int HW = p.chs, unit = (p.run_mode == 1) ? 4 : 1;
+            const int runu = CK * HW / unit, per_img = (runu + 63) / 64;
+            for (int j = wave; j < nseg * per_img; j += NWAVES) {
+                const int img = j / per_img, part = j - img * per_img;
+                const int idx = part * 64 + lane;
+                record(img * CK * HW + part * 64 * unit, idx < runu ? (unsigned)((size_t)(b0 + img) * p.C * HW) + (unsigned)idx * unit : ~0u);
+            }
+        } else if (p.run_mode == 3) {
             const int upr = p.LW >> 2, total = nrows * upr, per_ch = (total + 63) / 64, dcols = p.XW >> 2, pl4 = p.padL >> 2;
             for (int j = wave; j < CK * per_ch; j += NWAVES) {
                 const int ck = j / per_ch, part = j - ck * per_ch;
@@ -669,6 +678,19 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
             }
         }
         if (p.dbg & 1) return;
+        if (desc_ok && cc * CK + CK <= p.C && !(p.dbg & 64)) {  // (no channel padding in this chunk; 64: A/B switch)
+            const float* cbase = p.X + (size_t)cc * CK * p.XH * p.XW;
+#pragma unroll
+            for (int i = 0; i < MAXD; ++i) {
+                if (i < nd && d_src[i] != ~0u) {
+                    if (p.run_mode == 2)
+                        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(cbase + d_src[i]), (lds_void_ptr)(Xbuf + d_lds[i]), 4, 0, 0);
+                    else
+                        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(cbase + d_src[i]), (lds_void_ptr)(Xbuf + d_lds[i]), 16, 0, 0);
+                }
+            }
+            return;
+        }
         if constexpr (XM != 0) {
             // whole images: the CK-channel block of image b0+img is one contiguous run in HBM and in LDS
             const int HW = p.chs;  // == XH*XW
@@ -693,19 +715,6 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
             if (cvalid < CK) {  // channel padding of the last chunk must be finite
                 for (int img = 0; img < nseg; ++img)
                     for (int i = cvalid * HW + tid; i < CK * HW; i += NT) Xbuf[img * CK * HW + i] = 0.f;
-            }
-            return;
-        }
-        if (desc_ok && cc * CK + CK <= p.C && !(p.dbg & 64)) {  // (no channel padding in this chunk; 64: A/B switch)
-            const float* cbase = p.X + (size_t)cc * CK * p.XH * p.XW;
-#pragma unroll
-            for (int i = 0; i < MAXD; ++i) {
-                if (i < nd && d_src[i] != ~0u) {
-                    if (p.run_mode == 2)
-                        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(cbase + d_src[i]), (lds_void_ptr)(Xbuf + d_lds[i]), 4, 0, 0);
-                    else
-                        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(cbase + d_src[i]), (lds_void_ptr)(Xbuf + d_lds[i]), 16, 0, 0);
-                }
             }
             return;
         }
