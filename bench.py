@@ -140,6 +140,7 @@ def conv_ns_bench(torch, capi, reps=5):
     """Conv2d forward, 3x3, 64->128, 112x112 (pad 0 -> 110x110), batch 256: FLOPs / kernel time vs fp32-MFMA peak"""
     case = (256, 64, 112, 112, 128, 3, 1, 0)
     conv = capi.Conv2d(*case)
+    conv.autotune()  # (what Conv2D::forward does on its first call: the library measures which of its kernels / tiles runs this shape)
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.rand((256, 64, 112, 112), generator=g, device="cuda")
     w = torch.randn((128, 64, 3, 3), generator=g, device="cuda") * 0.1

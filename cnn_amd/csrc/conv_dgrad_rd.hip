@@ -24,6 +24,10 @@
 
 using namespace cnn_amd;
 
+namespace cnn_amd {
+bool igemm_preferred(const cnn_conv2d_desc* d, int mode);  // conv_igemm.hip (mode 0 forward, 1 data gradient)
+}
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -740,6 +744,8 @@ bool make_plan(const cnn_conv2d_desc* d, DgRdPlan* pl) {
         p.tiles = (int)parts;
         pl->blocks_x = d->Co == 128 ? (int)parts : (int)((parts * slices + pl->nw - 1) / pl->nw);
     }
+    // the stride-1 kernel only: cnn_conv2d_autotune may have measured the implicit GEMM faster for this geometry
+    if (!pl->m16 && d->s == 1 && cnn_amd::igemm_preferred(d, 1)) return false;
     return true;
 }
 

@@ -18,6 +18,10 @@
 
 using namespace cnn_amd;
 
+namespace cnn_amd {
+bool igemm_preferred(const cnn_conv2d_desc* d, int mode);  // conv_igemm.hip (mode 0 forward, 1 data gradient)
+}
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -394,6 +398,8 @@ bool make_plan(const cnn_conv2d_desc* d, FwdRdPlan* pl) {
         pl->m16_parts = parts;
         pl->m16_blocks = (parts * slices + 3) / 4;
     }
+    // the big-layer kernel only: cnn_conv2d_autotune may have measured the implicit GEMM faster for this geometry
+    if (!pl->m16 && cnn_amd::igemm_preferred(d, 0)) return false;
     return true;
 }
 
@@ -470,6 +476,11 @@ namespace cnn_amd {
 bool fwd_rd_supported(const cnn_conv2d_desc* d) {
     FwdRdPlan pl;
     return make_plan(d, &pl);
+}
+// covered by the small-layer (16x16x4, filters in registers) kernel: never handed to the implicit GEMM
+bool fwd_rd_small(const cnn_conv2d_desc* d) {
+    FwdRdPlan pl;
+    return make_plan(d, &pl) && pl.m16;
 }
 
 // floats of the prepared filter images of a layer (0: not an RD layer)

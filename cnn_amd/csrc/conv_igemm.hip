@@ -1031,6 +1031,11 @@ std::map<TuneKey, int>& tune_table() {
     static std::map<TuneKey, int> t;
     return t;
 }
+// geometries the register-direct kernels cover but the implicit GEMM runs faster (measured by cnn_conv2d_autotune)
+std::map<TuneKey, bool>& prefer_table() {
+    static std::map<TuneKey, bool> t;
+    return t;
+}
 thread_local int g_forced_cfg = -1;  // >= 0: make_plan must use exactly this configuration (the tuner's probe runs)
 // candidates: the rule-based default (-1) plus the tiles that won somewhere in tools/sweep_igemm.py
 const int kTuneCandidates[] = {-1, 200, 201, 206, 208, 226, 222, 224, 215, 216, 219, 225, 0, 1, 22};
@@ -1401,6 +1406,7 @@ int rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w,
                      void* const* dgrad, hipStream_t s, unsigned* fdone, unsigned* ddone);
 int fwd_rd_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* img, const float* bias, float* y,
                    float* y_relu, hipStream_t s);
+bool fwd_rd_small(const cnn_conv2d_desc* d);           // conv_fwd_rd.hip: the small-layer kernel (never replaced)
 bool stem_fwd_supported(const cnn_conv2d_desc* d);     // conv_stem.hip: Ci = 3, 7x7, stride 2, pad 3 forward on its own MFMA kernel
 int stem_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, float* y_relu, hipStream_t s);
 bool thin_dgrad_supported(const cnn_conv2d_desc* d);   // conv_dgrad_thin.hip: VALU data gradient of thin (Ci = 3) stride-1 layers
@@ -1410,6 +1416,12 @@ size_t pk_dgrad_s2_workspace_floats(const cnn_conv2d_desc* d);
 int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, hipStream_t s, bool prepared,
                 const float* relu_below);
 // scratch floats the forward / dgrad plans need (used by cnn_conv2d_workspace_bytes in conv_wgrad.hip)
+bool igemm_preferred(const cnn_conv2d_desc* d, int mode) {
+    std::lock_guard<std::mutex> lk(tune_mutex());
+    auto it = prefer_table().find(tune_key(d, mode));
+    return it != prefer_table().end() && it->second;
+}
+
 size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
     size_t n = 0;
     // the largest re-arranged filter image any tile the tuner may pin would need (the caller sizes its buffers once)
@@ -1477,8 +1489,14 @@ int cnn_conv2d_autotune(const cnn_conv2d_desc* d, void* stream) {
     for (int mode = 0; mode < 2; ++mode) {
         // geometries that never reach the implicit GEMM in this mode
         if (direct_conv_supported(d)) continue;
-        if (mode == MODE_FWD && (fwd_rd_supported(d) || stem_fwd_supported(d))) continue;
-        if (mode == MODE_DGRAD && (dgrad_rd_supported(d) || pk_dgrad_s2_supported(d) || thin_dgrad_supported(d))) continue;
+        // register-direct kernels for BIG layers (stride-1 / stride-2 3x3, pad 0, Ci <= 64; stride-1 data gradient) are measured
+        // against the implicit GEMM below; the small-layer kernels, the first-layer kernels and the stem keep their layers
+        const bool rd_fwd = mode == MODE_FWD && fwd_rd_supported(d);
+        const bool rd_dgrad = mode == MODE_DGRAD && dgrad_rd_supported(d);
+        if (rd_fwd && fwd_rd_small(d)) continue;
+        if (mode == MODE_FWD && !rd_fwd && stem_fwd_supported(d)) continue;
+        if (rd_dgrad && d->s != 1) continue;
+        if (mode == MODE_DGRAD && !rd_dgrad && (pk_dgrad_s2_supported(d) || thin_dgrad_supported(d))) continue;
         {
             std::lock_guard<std::mutex> lk(tune_mutex());
             if (tune_table().count(tune_key(d, mode))) continue;
@@ -1504,6 +1522,17 @@ int cnn_conv2d_autotune(const cnn_conv2d_desc* d, void* stream) {
         hipEvent_t e0, e1;
         CNN_HIP_CHECK(hipEventCreate(&e0));
         CNN_HIP_CHECK(hipEventCreate(&e1));
+        float rd_ms = 1e30f;
+        if (rd_fwd || rd_dgrad) {
+            for (int rep = 0; rep < 2; ++rep) {
+                (void)hipEventRecord(e0, s);
+                const int rc = rd_fwd ? fwd_rd_forward(d, X, bw, nullptr, bb, Y, nullptr, s)
+                                      : dgrad_rd_backward_data(d, X, bw, nullptr, nullptr, Y, ba, na * 4, s);
+                (void)hipEventRecord(e1, s);
+                if (rc == CNN_AMD_OK && hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&rd_ms, e0, e1);
+                else { rd_ms = 1e30f; (void)hipGetLastError(); }
+            }
+        }
         int best = -1;
         float best_ms = 1e30f;
         for (int c : kTuneCandidates) {
@@ -1535,6 +1564,11 @@ int cnn_conv2d_autotune(const cnn_conv2d_desc* d, void* stream) {
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         release();
+        if (rd_fwd || rd_dgrad) {
+            // the register-direct kernel keeps its layer unless the implicit GEMM is clearly faster
+            std::lock_guard<std::mutex> lk(tune_mutex());
+            prefer_table()[tune_key(d, mode)] = best_ms < rd_ms * 0.97f;
+        }
         if (best >= 0) {
             std::lock_guard<std::mutex> lk(tune_mutex());
             tune_table()[tune_key(d, mode)] = best;
