@@ -21,20 +21,37 @@ int fail(int code, const char* fmt, ...) {
 }
 
 // ---- published kernels (common.h) ---------------------------------------------------------------------------------------------
+namespace {
+// one state per (host thread, device), like the side streams of conv_backward.hip: a thread that alternates between devices keeps
+// both event pairs instead of leaking one per switch.  The slot is re-selected where a device query is affordable (arming);
+// launches use the slot selected last.
+struct PublishSlots {
+    PublishState st[16];
+    int cur = 0;
+};
+PublishSlots& publish_slots() {
+    static thread_local PublishSlots s;
+    return s;
+}
+}  // namespace
 PublishState& publish_state() {
-    static thread_local PublishState st;
-    return st;
+    PublishSlots& s = publish_slots();
+    return s.st[s.cur];
 }
 namespace {
-int publish_events(PublishState& p) {
+int publish_events(PublishState*& out) {
     int dev = 0;
     CNN_HIP_CHECK(hipGetDevice(&dev));
-    if (p.ev[0] == nullptr || p.device != dev) {  // (a thread that moves to another device gets fresh events; the old pair is kept alive)
+    PublishSlots& s = publish_slots();
+    s.cur = (dev >= 0 ? dev : 0) % 16;
+    PublishState& p = s.st[s.cur];
+    if (p.ev[0] == nullptr || p.device != dev) {
         CNN_HIP_CHECK(hipEventCreateWithFlags(&p.ev[0], hipEventDisableTiming));
         CNN_HIP_CHECK(hipEventCreateWithFlags(&p.ev[1], hipEventDisableTiming));
         p.device = dev;
         p.valid = false;
     }
+    out = &p;
     return CNN_AMD_OK;
 }
 thread_local bool g_just_published = false;
@@ -371,10 +388,10 @@ int cnn_batch_stager_release(void* stager, int slot, void* stream) {
 }
 
 int cnn_amd_publish_next_kernel(void* stream) {
-    PublishState& p = publish_state();
+    PublishState* p = nullptr;
     if (int rc = publish_events(p)) return rc;
-    p.armed = true;
-    p.stream = as_stream(stream);
+    p->armed = true;
+    p->stream = as_stream(stream);
     return CNN_AMD_OK;
 }
 
