@@ -407,13 +407,71 @@ __global__ __launch_bounds__(kRedElems * kRedLanes) void slab_reduce_batch(const
     }
 }
 
+// the same with FOUR consecutive elements per thread (16-byte loads, a quarter of the workgroups): every element still sees its slots
+// in the same order -> bit-identical.  The wide layers of the stacks reduce 2.4 M-element slabs: the scalar kernel launched 590 k
+// workgroups of one load per thread for a batch of eight such jobs and ran at 0.6 TB/s (dispatch-bound).
+__global__ __launch_bounds__(kRedElems * kRedLanes) void slab_reduce_batch_v4(const RedBatch rb) {
+    __shared__ float4 red[kRedLanes][kRedElems];
+    const RedJob j = rb.job[blockIdx.y];
+    if ((size_t)blockIdx.x * kRedElems * 4 >= j.n) return;
+    const int e = threadIdx.x & (kRedElems - 1), sl = threadIdx.x / kRedElems;
+    const size_t i = ((size_t)blockIdx.x * kRedElems + e) * 4, n = j.n;  // (n % 4 == 0: all four elements exist or none)
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+        int s = sl;
+        for (; s + 3 * kRedLanes < j.nslots; s += 4 * kRedLanes) {
+            const float4 v0 = *(const float4*)(j.in + (size_t)s * n + i), v1 = *(const float4*)(j.in + (size_t)(s + kRedLanes) * n + i);
+            const float4 v2 = *(const float4*)(j.in + (size_t)(s + 2 * kRedLanes) * n + i), v3 = *(const float4*)(j.in + (size_t)(s + 3 * kRedLanes) * n + i);
+            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+            acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+            acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+        }
+        for (; s < j.nslots; s += kRedLanes) {
+            const float4 v = *(const float4*)(j.in + (size_t)s * n + i);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    red[sl][e] = acc;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < kRedLanes; ++k) {
+            const float4 v = red[k][e];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const size_t ii = i + c;
+            if (j.split_n > 0) {
+                const size_t row = ii / (j.split_n + 1), col = ii - row * (j.split_n + 1);
+                if (col < (size_t)j.split_n) j.out[row * j.split_n + col] = tv[c] / j.divisor;
+                else if (j.out_b) j.out_b[row] = tv[c] / j.divisor;
+            } else {
+                j.out[ii] = tv[c] / j.divisor;
+            }
+        }
+    }
+}
+
 int flush_reduces(hipStream_t s) {
     PendingReduces& p = pending_reduces();
     if (p.count == 0) return CNN_AMD_OK;
     unsigned most = 0;
-    for (int i = 0; i < p.count; ++i) most = p.batch.job[i].n > most ? p.batch.job[i].n : most;
+    bool v4 = !(getenv("CNN_AMD_REDUCE_SCALAR") && atoi(getenv("CNN_AMD_REDUCE_SCALAR")) != 0);
+    for (int i = 0; i < p.count; ++i) {
+        most = p.batch.job[i].n > most ? p.batch.job[i].n : most;
+        if (p.batch.job[i].n % 4 != 0 || reinterpret_cast<uintptr_t>(p.batch.job[i].in) % 16 != 0) v4 = false;
+    }
     const int jobs = p.count;
     p.count = 0;
+    if (v4) {
+        CNN_KLAUNCH(s, "slab_reduce/batch", (slab_reduce_batch_v4<<<dim3((most / 4 + kRedElems - 1) / kRedElems, jobs), kRedElems * kRedLanes, 0, s>>>(p.batch)),
+                    "jobs=%d", jobs);
+        return CNN_AMD_OK;
+    }
     CNN_KLAUNCH(s, "slab_reduce/batch", (slab_reduce_batch<<<dim3((most + kRedElems - 1) / kRedElems, jobs), kRedElems * kRedLanes, 0, s>>>(p.batch)),
                 "jobs=%d", jobs);
     return CNN_AMD_OK;
