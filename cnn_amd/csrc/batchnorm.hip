@@ -16,6 +16,7 @@
 // The reference's normed_input buffer (batchnorm2d.cpp:38,71) is NOT materialised: (x-u)*var_inv is recomputed
 // from x and the saved batch statistics, which is the same arithmetic and saves a 4 B/element write + read.
 #include <cstdint>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -31,6 +32,9 @@ constexpr int kMaxG = 256;   // partial-sum slots per channel (<= 4 per lane in 
 struct Geo {
     int B, C, HW, nseg, G;
     long long units;  // per channel = B * nseg
+    // small planes (H*W <= 60: the 7x7 / 6x6 / 3x3 ends of the stacks): a plane fills only a few of a wavefront's 64 slots, so a
+    // wavefront is cut into P PARTS of 64/P lanes and each part walks its own unit; P = 1 for everything larger.
+    int P, part_shift;  // 64/P = 1 << part_shift
 };
 
 __device__ inline float wave_sum(float v) {
@@ -48,10 +52,10 @@ __device__ inline float sum_partials(const float* __restrict__ part, int G, int 
 
 // walk the unit's 16-byte slots; f4(slot_float_index) handles a full slot, f1(float_index) a single element
 template <class F4, class F1>
-__device__ inline void walk_unit(long long g0, long long g1, int lane, F4&& f4, F1&& f1) {
+__device__ inline void walk_unit(long long g0, long long g1, int lane, int stride, F4&& f4, F1&& f1) {
     const long long slot0 = g0 >> 2;
     const int nslots = (int)(((g1 + 3) >> 2) - slot0);
-    for (int t = lane; t < nslots; t += kWave) {
+    for (int t = lane; t < nslots; t += stride) {
         const long long e = (slot0 + t) << 2;
         if (e >= g0 && e + 4 <= g1) {
             f4(e);
@@ -65,7 +69,7 @@ __device__ inline void walk_unit(long long g0, long long g1, int lane, F4&& f4, 
 
 // unit u of channel c -> [g0, g1) as float indices from the tensor base
 __device__ inline void unit_range(const Geo& q, int c, long long u, long long& g0, long long& g1) {
-    const int b = (int)(u / q.nseg);
+    const int b = q.nseg == 1 ? (int)u : (int)(u / q.nseg);
     const int sg = (int)(u - (long long)b * q.nseg);
     const long long base = ((long long)b * q.C + c) * q.HW;
     const int s0 = sg * kSeg;
@@ -103,6 +107,7 @@ __global__ __launch_bounds__(kBlock) void bn_stats(const float* __restrict__ x, 
     const int c = blockIdx.y, g = blockIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int wpart = lane >> q.part_shift, stride = 1 << q.part_shift, sub = lane & (stride - 1);
     float u = 0.f;
     if (MODE == 1) {
         u = sum_partials(part_in + (size_t)c * q.G, q.G, 1, lane) / (float)((long long)q.B * q.HW);
@@ -110,11 +115,11 @@ __global__ __launch_bounds__(kBlock) void bn_stats(const float* __restrict__ x, 
     }
     if (MODE == 2) u = part_in[c] / count;
     float acc[1] = {0.f};
-    for (long long un = (long long)g * kWaves + wave; un < q.units; un += (long long)q.G * kWaves) {
+    for (long long un = ((long long)g * kWaves + wave) * q.P + wpart; un < q.units; un += (long long)q.G * kWaves * q.P) {
         long long g0, g1;
         unit_range(q, c, un, g0, g1);
         walk_unit(
-            g0, g1, lane,
+            g0, g1, sub, stride,
             [&](long long e) {
                 const float4 v = *(const float4*)(x + e);
                 if (MODE == 0) {
@@ -155,6 +160,7 @@ __global__ __launch_bounds__(kBlock) void bn_apply(BnApply a, Geo q) {
     const int c = blockIdx.y, g = blockIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int wpart = lane >> q.part_shift, stride = 1 << q.part_shift, sub = lane & (stride - 1);
     float u, var;
     if (a.training) {
         if (a.gsum_x != nullptr) {
@@ -176,11 +182,11 @@ __global__ __launch_bounds__(kBlock) void bn_apply(BnApply a, Geo q) {
     }
     const float var_inv = 1.f / sqrtf(var + a.eps);
     const float gm = a.gamma[c], bt = a.beta[c];
-    for (long long un = (long long)g * kWaves + wave; un < q.units; un += (long long)q.G * kWaves) {
+    for (long long un = ((long long)g * kWaves + wave) * q.P + wpart; un < q.units; un += (long long)q.G * kWaves * q.P) {
         long long g0, g1;
         unit_range(q, c, un, g0, g1);
         walk_unit(
-            g0, g1, lane,
+            g0, g1, sub, stride,
             [&](long long e) {
                 const float4 v = *(const float4*)(a.x + e);
                 float4 o;
@@ -204,6 +210,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_stats(const float* __restrict__
     const int c = blockIdx.y, g = blockIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int wpart = lane >> q.part_shift, stride = 1 << q.part_shift, sub = lane & (stride - 1);
     const float u = saved_mean[c];
     const float var_inv = 1.f / sqrtf(saved_var[c] + eps);
     const float var_inv_3 = var_inv * var_inv * var_inv;
@@ -216,11 +223,11 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_stats(const float* __restrict__
         acc[2] += (d * gm) * xc * -0.5f * var_inv_3;
         acc[3] += xc;
     };
-    for (long long un = (long long)g * kWaves + wave; un < q.units; un += (long long)q.G * kWaves) {
+    for (long long un = ((long long)g * kWaves + wave) * q.P + wpart; un < q.units; un += (long long)q.G * kWaves * q.P) {
         long long g0, g1;
         unit_range(q, c, un, g0, g1);
         walk_unit(
-            g0, g1, lane,
+            g0, g1, sub, stride,
             [&](long long e) {
                 const float4 v = *(const float4*)(x + e);
                 const float4 d = *(const float4*)(dy + e);
@@ -246,6 +253,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply(const float* __restrict__
     const int c = blockIdx.y, g = blockIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int wpart = lane >> q.part_shift, stride = 1 << q.part_shift, sub = lane & (stride - 1);
     // gsums (sync-BN): the four ALL-REDUCED channel sums [C][4] and the global element count replace the local ones
     const float L = gsums ? count : (float)((long long)q.B * q.HW);
     const float u = saved_mean[c];
@@ -265,11 +273,11 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply(const float* __restrict__
         gbeta[c] = s_gb;
     }
     const float inv2 = inv * 2.f;
-    for (long long un = (long long)g * kWaves + wave; un < q.units; un += (long long)q.G * kWaves) {
+    for (long long un = ((long long)g * kWaves + wave) * q.P + wpart; un < q.units; un += (long long)q.G * kWaves * q.P) {
         long long g0, g1;
         unit_range(q, c, un, g0, g1);
         walk_unit(
-            g0, g1, lane,
+            g0, g1, sub, stride,
             [&](long long e) {
                 const float4 v = *(const float4*)(x + e);
                 float4 d = *(float4*)(dy + e);
@@ -293,6 +301,119 @@ __global__ __launch_bounds__(kWave) void bn_reduce_partials(const float* __restr
     }
 }
 
+// ---- one workgroup per channel: the whole channel (B planes of H*W floats) fits LDS ----
+// The deep end of a stack (7x7 / 14x14 planes at batch 64: 12 - 50 KB per channel) is launch-latency bound on the general path
+// (3 forward / 2 backward launches of a few microseconds each, every one waiting for its predecessor): here a channel is read ONCE
+// into LDS, the statistics are block reductions in a fixed order (lane tree, then the 16 waves in order) and the apply pass runs
+// from LDS -- one launch per direction, 8 B / element forward and 12 B / element backward.
+constexpr int kChanThreads = 1024;
+constexpr int kChanWaves = kChanThreads / kWave;
+constexpr int kChanMaxElems = 16384;  // B*H*W floats of one channel: 64 KB forward, 2 x 64 KB backward
+
+template <int NS>
+__device__ inline void chan_block_sum(float (&v)[NS], float* __restrict__ red) {  // red: [kChanWaves][NS]; result in every thread
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const float w = wave_sum(v[k]);
+        if (lane == 0) red[wave * NS + k] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        float t = red[k];
+        for (int w = 1; w < kChanWaves; ++w) t += red[w * NS + k];
+        v[k] = t;
+    }
+    __syncthreads();
+}
+
+__device__ inline size_t chan_addr(const Geo& q, int c, unsigned e) {  // element e of channel c -> float index in the tensor
+    const unsigned b = e / (unsigned)q.HW;
+    return ((size_t)b * q.C + c) * q.HW + (e - b * (unsigned)q.HW);
+}
+
+// training forward (batchnorm2d.cpp:46-80): mean | biased variance around it | y, moving statistics
+__global__ __launch_bounds__(kChanThreads) void bn_fwd_channel(BnApply a, Geo q) {
+#pragma clang fp contract(off)
+    extern __shared__ float chan[];  // [n] x
+    __shared__ float red[kChanWaves];
+    const int c = blockIdx.x;
+    const unsigned n = (unsigned)(q.B * q.HW);
+    float acc[1] = {0.f};
+    for (unsigned e = threadIdx.x; e < n; e += kChanThreads) {
+        const float v = a.x[chan_addr(q, c, e)];
+        chan[e] = v;
+        acc[0] += v;
+    }
+    chan_block_sum<1>(acc, red);  // (its barrier also publishes chan[])
+    const float u = acc[0] / (float)n;
+    acc[0] = 0.f;
+    for (unsigned e = threadIdx.x; e < n; e += kChanThreads) {
+        const float d = chan[e] - u;
+        acc[0] += d * d;
+    }
+    chan_block_sum<1>(acc, red);
+    const float var = acc[0] / (float)n;
+    if (threadIdx.x == 0) {
+        a.saved_mean[c] = u;
+        a.saved_var[c] = var;
+        a.moving_mean[c] = (1.f - a.momentum) * a.moving_mean[c] + a.momentum * u;
+        a.moving_var[c] = (1.f - a.momentum) * a.moving_var[c] + a.momentum * var;
+    }
+    const float var_inv = 1.f / sqrtf(var + a.eps);
+    const float gm = a.gamma[c], bt = a.beta[c];
+    for (unsigned e = threadIdx.x; e < n; e += kChanThreads) a.y[chan_addr(q, c, e)] = gm * ((chan[e] - u) * var_inv) + bt;
+}
+
+// backward (batchnorm2d.cpp:118-155): the four channel sums of bn_bwd_stats, then bn_bwd_apply's dx in place on dy
+__global__ __launch_bounds__(kChanThreads) void bn_bwd_channel(const float* __restrict__ x, float* __restrict__ dy,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ saved_mean,
+                                                               const float* __restrict__ saved_var, float* __restrict__ ggamma,
+                                                               float* __restrict__ gbeta, float eps, Geo q) {
+#pragma clang fp contract(off)
+    extern __shared__ float chan[];  // [n] x - mean, [n] dy
+    __shared__ float red[kChanWaves * 4];
+    const int c = blockIdx.x;
+    const unsigned n = (unsigned)(q.B * q.HW);
+    float* const xc_s = chan;
+    float* const d_s = chan + n;
+    const float u = saved_mean[c];
+    const float var_inv = 1.f / sqrtf(saved_var[c] + eps);
+    const float var_inv_3 = var_inv * var_inv * var_inv;
+    const float gm = gamma[c];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (unsigned e = threadIdx.x; e < n; e += kChanThreads) {
+        const size_t at = chan_addr(q, c, e);
+        const float xc = x[at] - u, d = dy[at];
+        xc_s[e] = xc;
+        d_s[e] = d;
+        acc[0] += d * (xc * var_inv);
+        acc[1] += d;
+        acc[2] += (d * gm) * xc * -0.5f * var_inv_3;
+        acc[3] += xc;
+    }
+    chan_block_sum<4>(acc, red);
+    const float L = (float)n;
+    const float inv = acc[2] / L;
+    const float u_g = (acc[1] * gm) * (-var_inv) + inv * -2.f * acc[3];
+    const float u_term = u_g / L;
+    if (threadIdx.x == 0) {
+        ggamma[c] = acc[0];
+        gbeta[c] = acc[1];
+    }
+    const float inv2 = inv * 2.f;
+    for (unsigned e = threadIdx.x; e < n; e += kChanThreads)
+        dy[chan_addr(q, c, e)] = (d_s[e] * gm) * var_inv + inv2 * xc_s[e] + u_term;
+}
+
+// the channel kernels take a layer when a channel fits LDS and there are enough channels to spread over the chip
+bool channel_path(int B, int C, int H, int W) {
+    static const bool off = std::getenv("CNN_AMD_BN_NO_CHANNEL") != nullptr;  // (A/B switch)
+    return !off && (long long)B * H * W <= kChanMaxElems && C >= 32;
+}
+
 int make_geo(int B, int C, int H, int W, Geo* q) {
     CNN_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "batchnorm2d: bad geometry B=%d C=%d H=%d W=%d", B, C, H, W);
     CNN_REQUIRE((long long)H * W < (1ll << 30), "batchnorm2d: plane too large");
@@ -302,8 +423,12 @@ int make_geo(int B, int C, int H, int W, Geo* q) {
     q->nseg = (q->HW + kSeg - 1) / kSeg;
     q->units = (long long)B * q->nseg;
     // ~2048 workgroups over the chip (8 per CU), at most one wave per unit, at most kMaxG partial slots
+    q->P = 1;
+    q->part_shift = 6;
+    if (q->nseg == 1)  // a plane spans at most HW/4 + 2 slots
+        while (q->P < 8 && q->HW / 4 + 2 <= (kWave >> 1) / q->P) q->P *= 2, --q->part_shift;
     long long G = (2048 + C - 1) / C;
-    const long long gmax = (q->units + kWaves - 1) / kWaves;
+    const long long gmax = (q->units + kWaves * q->P - 1) / (kWaves * q->P);
     if (G > gmax) G = gmax;
     if (G > kMaxG) G = kMaxG;
     if (G < 1) G = 1;
@@ -342,6 +467,17 @@ int cnn_batchnorm2d_forward(const float* x, float* y, const float* gamma, const 
         CNN_REQUIRE(saved_mean && saved_var, "cnn_batchnorm2d_forward: training needs saved_mean / saved_var");
         CNN_REQUIRE(workspace && workspace_bytes >= cnn_batchnorm2d_workspace_bytes(B, C, H, W),
                     "cnn_batchnorm2d_forward: workspace too small (%zu bytes)", workspace_bytes);
+        if (channel_path(B, C, H, W)) {
+            const size_t lds = (size_t)B * H * W * sizeof(float);
+            static DeviceOnce attr_once;
+            if (attr_once.needed()) {
+                CNN_HIP_CHECK(hipFuncSetAttribute((const void*)bn_fwd_channel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)(kChanMaxElems * sizeof(float))));
+                attr_once.mark();
+            }
+            CNN_KLAUNCH(s, "bn_fwd_channel", (bn_fwd_channel<<<C, kChanThreads, lds, s>>>(a, q)), BN_TAG);
+            return CNN_AMD_OK;
+        }
         float* p0 = (float*)workspace;
         float* p1 = p0 + (size_t)C * q.G * 4;
         CNN_KLAUNCH(s, "bn_stats<0>", (bn_stats<0><<<grid, kBlock, 0, s>>>(x, nullptr, p0, nullptr, q, 0.f)), BN_TAG);
@@ -364,6 +500,18 @@ int cnn_batchnorm2d_backward(const float* x, float* dy, const float* gamma, cons
                 "cnn_batchnorm2d_backward: workspace too small (%zu bytes)", workspace_bytes);
     hipStream_t s = as_stream(stream);
     const dim3 grid(q.G, C);
+    if (channel_path(B, C, H, W)) {
+        const size_t lds = (size_t)B * H * W * sizeof(float) * 2;
+        static DeviceOnce attr_once;
+        if (attr_once.needed()) {
+            CNN_HIP_CHECK(hipFuncSetAttribute((const void*)bn_bwd_channel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)(kChanMaxElems * sizeof(float) * 2)));
+            attr_once.mark();
+        }
+        CNN_KLAUNCH(s, "bn_bwd_channel",
+                    (bn_bwd_channel<<<C, kChanThreads, lds, s>>>(x, dy, gamma, saved_mean, saved_var, ggamma, gbeta, eps, q)), BN_TAG);
+        return CNN_AMD_OK;
+    }
     float* part = (float*)workspace;
     CNN_KLAUNCH(s, "bn_bwd_stats",
                 (bn_bwd_stats<<<grid, kBlock, 0, s>>>(x, dy, gamma, saved_mean, saved_var, part, eps, q)), BN_TAG);

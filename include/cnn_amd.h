@@ -280,7 +280,9 @@ int cnn_batchnorm2d_backward(const float* x, float* dy, const float* gamma, cons
  *   cnn_batchnorm2d_backward_from_sums(..., sums4, count)     dy -> dx in place; ggamma / gbeta = the FULL-batch sums
  *                                                             (identical on every rank: exclude them from the gradient
  *                                                             all-reduce or divide by the world size afterwards)
- * With one process this is the arithmetic of cnn_batchnorm2d_forward / _backward.  Evaluation needs no exchange. */
+ * With one process this is the arithmetic of cnn_batchnorm2d_forward / _backward on their general path (layers whose channels
+ * fit LDS take a one-workgroup-per-channel kernel there, which sums a channel in a different order: equal within rounding).
+ * Evaluation needs no exchange. */
 int cnn_batchnorm2d_partial_sums(const float* x, const float* sum_x, float count, float* out, int B, int C, int H, int W,
                                  void* workspace, size_t workspace_bytes, void* stream);
 int cnn_batchnorm2d_forward_from_sums(const float* x, float* y, const float* gamma, const float* beta, float* moving_mean,

@@ -149,7 +149,7 @@ def test_batchnorm_rejects_bad_arguments(T):
     assert rc != 0 and b"workspace" in L.cnn_amd_last_error()
 
 
-@pytest.mark.parametrize("shape,splits", [((6, 16, 27, 27), (2, 4)), ((5, 3, 7, 9), (1, 3, 1)), ((4, 32, 13, 13), (4,))],
+@pytest.mark.parametrize("shape,splits", [((6, 16, 27, 27), (2, 4)), ((5, 3, 7, 9), (1, 3, 1)), ((4, 16, 13, 13), (4,))],
                          ids=["two_ranks", "three_uneven_ranks", "one_rank"])
 def test_sync_batchnorm_sharded_batch_equals_full_batch_oracle(T, shape, splits):
     """the split-phase (sync-BN) entry points with the batch sharded over simulated ranks -- per-rank partial sums, summed
@@ -228,7 +228,8 @@ def test_sync_batchnorm_sharded_batch_equals_full_batch_oracle(T, shape, splits)
     for rk in ranks:  # full-batch sums on every rank (batchnorm2d.cpp:123-124: not divided by the batch)
         assert_close(host(rk["gg"]), gg_o, what="gamma grad")
         assert_close(host(rk["gb"]), gb_o, what="beta grad")
-    if len(splits) == 1:  # one rank: the same arithmetic as the fused single-device entry points
+    if len(splits) == 1:  # one rank: the same arithmetic as the single-device entry points on their general path (C < 32 here;
+        # layers taken by the one-workgroup-per-channel kernels sum a channel in a different order)
         bn = capi.BatchNorm2d(B, C, H, W)
         xd, gd, bd = dev(T, x), dev(T, gamma), dev(T, beta)
         mm, mv, y1 = dev(T, mm0), dev(T, mv0), T.empty(shape, device="cuda")
