@@ -90,9 +90,11 @@ SIGNATURES = {
     "cnn_linear_backward_relu": (C.c_int, [_P] * 6 + [C.c_int] * 3 + [C.c_float, _P]),
     "cnn_batchnorm2d_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "cnn_batchnorm2d_forward": (C.c_int, [_P] * 8 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, _P, C.c_size_t, _P]),
+    "cnn_batchnorm2d_forward_relu": (C.c_int, [_P] * 9 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, _P, C.c_size_t, _P]),
     "cnn_batchnorm2d_backward": (C.c_int, [_P] * 7 + [C.c_int] * 4 + [C.c_float, _P, C.c_size_t, _P]),
     "cnn_batchnorm2d_partial_sums": (C.c_int, [_P, _P, C.c_float, _P] + [C.c_int] * 4 + [_P, C.c_size_t, _P]),
     "cnn_batchnorm2d_forward_from_sums": (C.c_int, [_P] * 10 + [C.c_float] + [C.c_int] * 4 + [C.c_float, C.c_float, _P]),
+    "cnn_batchnorm2d_forward_from_sums_relu": (C.c_int, [_P] * 11 + [C.c_float] + [C.c_int] * 4 + [C.c_float, C.c_float, _P]),
     "cnn_batchnorm2d_backward_sums": (C.c_int, [_P] * 6 + [C.c_int] * 4 + [C.c_float, _P, C.c_size_t, _P]),
     "cnn_batchnorm2d_backward_from_sums": (C.c_int, [_P] * 6 + [C.c_float, _P, _P] + [C.c_int] * 4 + [C.c_float, _P]),
     "cnn_sgd_update": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P]),
@@ -504,8 +506,16 @@ class BatchNorm2d:
         self.saved_mean = torch.zeros(channels, dtype=torch.float32, device=device)
         self.saved_var = torch.zeros(channels, dtype=torch.float32, device=device)
 
-    def forward(self, x, gamma, beta, moving_mean, moving_var, y, training=True):
+    def forward(self, x, gamma, beta, moving_mean, moving_var, y, training=True, y_relu=None):
+        """y_relu: also write relu(y) (the ReLU layer behind this one) from the same pass"""
         _need_gpu(x, y, gamma, beta, moving_mean, moving_var)
+        if y_relu is not None:
+            _need_gpu(y_relu)
+            check(load().cnn_batchnorm2d_forward_relu(_ptr(x), _ptr(y), _ptr(y_relu), _ptr(gamma), _ptr(beta), _ptr(moving_mean),
+                                                      _ptr(moving_var), _ptr(self.saved_mean), _ptr(self.saved_var), self.B, self.C,
+                                                      self.H, self.W, self.eps, self.momentum, 1 if training else 0, _ptr(self.ws),
+                                                      self.ws_bytes, _stream()), "cnn_batchnorm2d_forward_relu")
+            return y
         check(load().cnn_batchnorm2d_forward(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(moving_mean), _ptr(moving_var),
                                              _ptr(self.saved_mean), _ptr(self.saved_var), self.B, self.C, self.H, self.W,
                                              self.eps, self.momentum, 1 if training else 0, _ptr(self.ws), self.ws_bytes,

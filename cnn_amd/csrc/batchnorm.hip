@@ -140,6 +140,7 @@ __global__ __launch_bounds__(kBlock) void bn_stats(const float* __restrict__ x, 
 struct BnApply {
     const float* x;
     float* y;
+    float* y_relu;  // RELU kernels: the output of the ReLU layer behind this one (relu.cpp:25), written by the same pass
     const float* gamma;
     const float* beta;
     float* moving_mean;
@@ -155,6 +156,9 @@ struct BnApply {
 };
 
 // y = gamma * ((x - u) * var_inv) + beta  (batchnorm2d.cpp:69-77 / 84-92), moving statistics (:79-80)
+__device__ __forceinline__ float bn_relu(float v) { return v >= 0.f ? v : 0.f; }  // == elementwise.hip relu_f (relu.cpp:25)
+
+template <bool RELU>
 __global__ __launch_bounds__(kBlock) void bn_apply(BnApply a, Geo q) {
 #pragma clang fp contract(off)
     const int c = blockIdx.y, g = blockIdx.x;
@@ -195,8 +199,16 @@ __global__ __launch_bounds__(kBlock) void bn_apply(BnApply a, Geo q) {
                 o.z = gm * ((v.z - u) * var_inv) + bt;
                 o.w = gm * ((v.w - u) * var_inv) + bt;
                 *(float4*)(a.y + e) = o;
+                if (RELU) {
+                    o.x = bn_relu(o.x); o.y = bn_relu(o.y); o.z = bn_relu(o.z); o.w = bn_relu(o.w);
+                    *(float4*)(a.y_relu + e) = o;
+                }
             },
-            [&](long long e) { a.y[e] = gm * ((a.x[e] - u) * var_inv) + bt; });
+            [&](long long e) {
+                const float o = gm * ((a.x[e] - u) * var_inv) + bt;
+                a.y[e] = o;
+                if (RELU) a.y_relu[e] = bn_relu(o);
+            });
     }
 }
 
@@ -334,6 +346,7 @@ __device__ inline size_t chan_addr(const Geo& q, int c, unsigned e) {  // elemen
 }
 
 // training forward (batchnorm2d.cpp:46-80): mean | biased variance around it | y, moving statistics
+template <bool RELU>
 __global__ __launch_bounds__(kChanThreads) void bn_fwd_channel(BnApply a, Geo q) {
 #pragma clang fp contract(off)
     extern __shared__ float chan[];  // [n] x
@@ -363,7 +376,12 @@ __global__ __launch_bounds__(kChanThreads) void bn_fwd_channel(BnApply a, Geo q)
     }
     const float var_inv = 1.f / sqrtf(var + a.eps);
     const float gm = a.gamma[c], bt = a.beta[c];
-    for (unsigned e = threadIdx.x; e < n; e += kChanThreads) a.y[chan_addr(q, c, e)] = gm * ((chan[e] - u) * var_inv) + bt;
+    for (unsigned e = threadIdx.x; e < n; e += kChanThreads) {
+        const size_t at = chan_addr(q, c, e);
+        const float o = gm * ((chan[e] - u) * var_inv) + bt;
+        a.y[at] = o;
+        if (RELU) a.y_relu[at] = bn_relu(o);
+    }
 }
 
 // backward (batchnorm2d.cpp:118-155): the four channel sums of bn_bwd_stats, then bn_bwd_apply's dx in place on dy
@@ -451,17 +469,17 @@ size_t cnn_batchnorm2d_workspace_bytes(int B, int C, int H, int W) {
     return (size_t)C * q.G * 4 * sizeof(float) * 2;  // two partial-sum arenas (ping / pong)
 }
 
-int cnn_batchnorm2d_forward(const float* x, float* y, const float* gamma, const float* beta, float* moving_mean,
-                            float* moving_var, float* saved_mean, float* saved_var, int B, int C, int H, int W, float eps,
-                            float momentum, int training, void* workspace, size_t workspace_bytes, void* stream) {
+static int bn_forward_impl(const float* x, float* y, float* y_relu, const float* gamma, const float* beta, float* moving_mean,
+                           float* moving_var, float* saved_mean, float* saved_var, int B, int C, int H, int W, float eps,
+                           float momentum, int training, void* workspace, size_t workspace_bytes, void* stream) {
     Geo q;
     int rc = make_geo(B, C, H, W, &q);
     if (rc != CNN_AMD_OK) return rc;
     CNN_REQUIRE(x && y && gamma && beta && moving_mean && moving_var, "cnn_batchnorm2d_forward: null pointer");
-    CNN_REQUIRE(aligned16(x) && aligned16(y), "cnn_batchnorm2d_forward: x / y must be 16-byte aligned");
+    CNN_REQUIRE(aligned16(x) && aligned16(y) && aligned16(y_relu), "cnn_batchnorm2d_forward: x / y / y_relu must be 16-byte aligned");
     hipStream_t s = as_stream(stream);
     const dim3 grid(q.G, C);
-    BnApply a{x, y, gamma, beta, moving_mean, moving_var, saved_mean, saved_var, nullptr, eps, momentum, training ? 1 : 0,
+    BnApply a{x, y, y_relu, gamma, beta, moving_mean, moving_var, saved_mean, saved_var, nullptr, eps, momentum, training ? 1 : 0,
               nullptr, nullptr, 0.f};
     if (training) {
         CNN_REQUIRE(saved_mean && saved_var, "cnn_batchnorm2d_forward: training needs saved_mean / saved_var");
@@ -471,11 +489,16 @@ int cnn_batchnorm2d_forward(const float* x, float* y, const float* gamma, const 
             const size_t lds = (size_t)B * H * W * sizeof(float);
             static DeviceOnce attr_once;
             if (attr_once.needed()) {
-                CNN_HIP_CHECK(hipFuncSetAttribute((const void*)bn_fwd_channel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                CNN_HIP_CHECK(hipFuncSetAttribute((const void*)bn_fwd_channel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)(kChanMaxElems * sizeof(float))));
+                CNN_HIP_CHECK(hipFuncSetAttribute((const void*)bn_fwd_channel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   (int)(kChanMaxElems * sizeof(float))));
                 attr_once.mark();
             }
-            CNN_KLAUNCH(s, "bn_fwd_channel", (bn_fwd_channel<<<C, kChanThreads, lds, s>>>(a, q)), BN_TAG);
+            if (y_relu)
+                CNN_KLAUNCH(s, "bn_fwd_channel+relu", (bn_fwd_channel<true><<<C, kChanThreads, lds, s>>>(a, q)), BN_TAG);
+            else
+                CNN_KLAUNCH(s, "bn_fwd_channel", (bn_fwd_channel<false><<<C, kChanThreads, lds, s>>>(a, q)), BN_TAG);
             return CNN_AMD_OK;
         }
         float* p0 = (float*)workspace;
@@ -484,8 +507,27 @@ int cnn_batchnorm2d_forward(const float* x, float* y, const float* gamma, const 
         CNN_KLAUNCH(s, "bn_stats<1>", (bn_stats<1><<<grid, kBlock, 0, s>>>(x, p0, p1, saved_mean, q, 0.f)), BN_TAG);
         a.part = p1;
     }
-    CNN_KLAUNCH(s, "bn_apply", (bn_apply<<<grid, kBlock, 0, s>>>(a, q)), BN_TAG);
+    if (y_relu)
+        CNN_KLAUNCH(s, "bn_apply+relu", (bn_apply<true><<<grid, kBlock, 0, s>>>(a, q)), BN_TAG);
+    else
+        CNN_KLAUNCH(s, "bn_apply", (bn_apply<false><<<grid, kBlock, 0, s>>>(a, q)), BN_TAG);
     return CNN_AMD_OK;
+}
+
+int cnn_batchnorm2d_forward(const float* x, float* y, const float* gamma, const float* beta, float* moving_mean,
+                            float* moving_var, float* saved_mean, float* saved_var, int B, int C, int H, int W, float eps,
+                            float momentum, int training, void* workspace, size_t workspace_bytes, void* stream) {
+    return bn_forward_impl(x, y, nullptr, gamma, beta, moving_mean, moving_var, saved_mean, saved_var, B, C, H, W, eps, momentum,
+                           training, workspace, workspace_bytes, stream);
+}
+
+int cnn_batchnorm2d_forward_relu(const float* x, float* y, float* y_relu, const float* gamma, const float* beta,
+                                 float* moving_mean, float* moving_var, float* saved_mean, float* saved_var, int B, int C, int H,
+                                 int W, float eps, float momentum, int training, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+    CNN_REQUIRE(y_relu != nullptr, "cnn_batchnorm2d_forward_relu: null y_relu");
+    return bn_forward_impl(x, y, y_relu, gamma, beta, moving_mean, moving_var, saved_mean, saved_var, B, C, H, W, eps, momentum,
+                           training, workspace, workspace_bytes, stream);
 }
 
 int cnn_batchnorm2d_backward(const float* x, float* dy, const float* gamma, const float* saved_mean,
@@ -542,20 +584,41 @@ int cnn_batchnorm2d_partial_sums(const float* x, const float* sum_x, float count
     return CNN_AMD_OK;
 }
 
-int cnn_batchnorm2d_forward_from_sums(const float* x, float* y, const float* gamma, const float* beta, float* moving_mean,
-                                      float* moving_var, float* saved_mean, float* saved_var, const float* sum_x,
-                                      const float* sum_sq, float count, int B, int C, int H, int W, float eps, float momentum,
-                                      void* stream) {
+static int bn_forward_from_sums_impl(const float* x, float* y, float* y_relu, const float* gamma, const float* beta,
+                                     float* moving_mean, float* moving_var, float* saved_mean, float* saved_var,
+                                     const float* sum_x, const float* sum_sq, float count, int B, int C, int H, int W, float eps,
+                                     float momentum, void* stream) {
     Geo q;
     int rc = make_geo(B, C, H, W, &q);
     if (rc != CNN_AMD_OK) return rc;
     CNN_REQUIRE(x && y && gamma && beta && moving_mean && moving_var && saved_mean && saved_var && sum_x && sum_sq,
                 "cnn_batchnorm2d_forward_from_sums: null pointer");
-    CNN_REQUIRE(aligned16(x) && aligned16(y) && count > 0.f, "cnn_batchnorm2d_forward_from_sums: unaligned x / y or count <= 0");
+    CNN_REQUIRE(aligned16(x) && aligned16(y) && aligned16(y_relu) && count > 0.f,
+                "cnn_batchnorm2d_forward_from_sums: unaligned x / y / y_relu or count <= 0");
     hipStream_t s = as_stream(stream);
-    BnApply a{x, y, gamma, beta, moving_mean, moving_var, saved_mean, saved_var, nullptr, eps, momentum, 1, sum_x, sum_sq, count};
-    CNN_KLAUNCH(s, "bn_apply/sync", (bn_apply<<<dim3(q.G, C), kBlock, 0, s>>>(a, q)), BN_TAG);
+    BnApply a{x, y, y_relu, gamma, beta, moving_mean, moving_var, saved_mean, saved_var, nullptr, eps, momentum, 1, sum_x, sum_sq, count};
+    if (y_relu)
+        CNN_KLAUNCH(s, "bn_apply+relu/sync", (bn_apply<true><<<dim3(q.G, C), kBlock, 0, s>>>(a, q)), BN_TAG);
+    else
+        CNN_KLAUNCH(s, "bn_apply/sync", (bn_apply<false><<<dim3(q.G, C), kBlock, 0, s>>>(a, q)), BN_TAG);
     return CNN_AMD_OK;
+}
+
+int cnn_batchnorm2d_forward_from_sums(const float* x, float* y, const float* gamma, const float* beta, float* moving_mean,
+                                      float* moving_var, float* saved_mean, float* saved_var, const float* sum_x,
+                                      const float* sum_sq, float count, int B, int C, int H, int W, float eps, float momentum,
+                                      void* stream) {
+    return bn_forward_from_sums_impl(x, y, nullptr, gamma, beta, moving_mean, moving_var, saved_mean, saved_var, sum_x, sum_sq, count,
+                                     B, C, H, W, eps, momentum, stream);
+}
+
+int cnn_batchnorm2d_forward_from_sums_relu(const float* x, float* y, float* y_relu, const float* gamma, const float* beta,
+                                           float* moving_mean, float* moving_var, float* saved_mean, float* saved_var,
+                                           const float* sum_x, const float* sum_sq, float count, int B, int C, int H, int W,
+                                           float eps, float momentum, void* stream) {
+    CNN_REQUIRE(y_relu != nullptr, "cnn_batchnorm2d_forward_from_sums_relu: null y_relu");
+    return bn_forward_from_sums_impl(x, y, y_relu, gamma, beta, moving_mean, moving_var, saved_mean, saved_var, sum_x, sum_sq, count,
+                                     B, C, H, W, eps, momentum, stream);
 }
 
 int cnn_batchnorm2d_backward_sums(const float* x, const float* dy, const float* gamma, const float* saved_mean,

@@ -251,9 +251,11 @@ private:
     void* comm = nullptr;        // RCCL communicator: statistics over the GLOBAL batch (sync-BN), see Sequential::set_comm
     int comm_world = 1;
     data_type* sync_sums = nullptr;  // [C] + [C] + [C][4] all-reduce operands
+    ReLU* fused_relu = nullptr;      // the ReLU layer right behind this one (set by the container): its output comes from the apply pass
 
 public:
     void set_comm(void* rccl_comm, int world) { comm = rccl_comm; comm_world = world; }
+    void set_fused_relu(ReLU* relu) { fused_relu = relu; }
     BatchNorm2D(std::string _name, const int _out_channels, const data_type _eps = 1e-5, const data_type _momentum = 0.1);
     ~BatchNorm2D() override;
     std::vector<tensor> forward(const std::vector<tensor>& input) override;

@@ -494,6 +494,8 @@ std::vector<tensor> BatchNorm2D::forward(const std::vector<tensor>& input) {
         saved_input_tensors = input;
     }
     const int C = out_channels;
+    // the ReLU behind this layer gets its output from the same apply pass (both outputs are written)
+    data_type* y_relu = (fused_relu != nullptr && fuse_layers) ? fused_relu->fused_forward_target(B, C, H, W) : nullptr;
     if (!no_grad && comm != nullptr && comm_world > 1) {
         // the batch is sharded over comm_world replicas: the reference normalises over the WHOLE batch (batchnorm2d.cpp:46-63),
         // so the per-channel sums are exchanged (two [C] all-reduces: mean first, then the squared deviations around the
@@ -506,15 +508,26 @@ std::vector<tensor> BatchNorm2D::forward(const std::vector<tensor>& input) {
         must(cnn_allreduce_grads(comm, s1, (size_t)C, stream), "cnn_allreduce_grads");
         must(cnn_batchnorm2d_partial_sums(x, s1, count, s2, B, C, H, W, workspace, workspace_bytes, stream), "cnn_batchnorm2d_partial_sums");
         must(cnn_allreduce_grads(comm, s2, (size_t)C, stream), "cnn_allreduce_grads");
-        must(cnn_batchnorm2d_forward_from_sums(x, out_buf.base, params, params + C, params + 2 * C, params + 3 * C, saved_stats,
-                                               saved_stats + C, s1, s2, count, B, C, H, W, eps, momentum, stream),
-             "cnn_batchnorm2d_forward_from_sums");
+        if (y_relu)
+            must(cnn_batchnorm2d_forward_from_sums_relu(x, out_buf.base, y_relu, params, params + C, params + 2 * C, params + 3 * C,
+                                                        saved_stats, saved_stats + C, s1, s2, count, B, C, H, W, eps, momentum, stream),
+                 "cnn_batchnorm2d_forward_from_sums_relu");
+        else
+            must(cnn_batchnorm2d_forward_from_sums(x, out_buf.base, params, params + C, params + 2 * C, params + 3 * C, saved_stats,
+                                                   saved_stats + C, s1, s2, count, B, C, H, W, eps, momentum, stream),
+                 "cnn_batchnorm2d_forward_from_sums");
         return output;
     }
-    must(cnn_batchnorm2d_forward(x, out_buf.base, params, params + C, params + 2 * C, params + 3 * C, saved_stats,
-                                 saved_stats + C, B, C, H, W, eps, momentum, no_grad ? 0 : 1, workspace, workspace_bytes,
-                                 stream),
-         "cnn_batchnorm2d_forward");
+    if (y_relu)
+        must(cnn_batchnorm2d_forward_relu(x, out_buf.base, y_relu, params, params + C, params + 2 * C, params + 3 * C, saved_stats,
+                                          saved_stats + C, B, C, H, W, eps, momentum, no_grad ? 0 : 1, workspace, workspace_bytes,
+                                          stream),
+             "cnn_batchnorm2d_forward_relu");
+    else
+        must(cnn_batchnorm2d_forward(x, out_buf.base, params, params + C, params + 2 * C, params + 3 * C, saved_stats,
+                                     saved_stats + C, B, C, H, W, eps, momentum, no_grad ? 0 : 1, workspace, workspace_bytes,
+                                     stream),
+             "cnn_batchnorm2d_forward");
     return output;
 }
 

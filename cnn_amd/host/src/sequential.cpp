@@ -39,6 +39,8 @@ void Sequential::wire() {
         // Conv2D -> ReLU: the ReLU's output is written by the convolution kernel's epilogue
         if (auto* relu = dynamic_cast<ReLU*>(next->get())) {
             if (auto* conv = dynamic_cast<Conv2D*>(it->get())) conv->set_fused_relu(relu);
+            // BatchNorm2D -> ReLU: ... or by the normalisation's apply pass
+            if (auto* bn = dynamic_cast<BatchNorm2D*>(it->get())) bn->set_fused_relu(relu);
         }
         // ReLU -> MaxPool2D: the ReLU's backward pass runs inside the pool's backward kernel
         if (auto* pool = dynamic_cast<MaxPool2D*>(next->get())) {

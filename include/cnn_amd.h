@@ -263,6 +263,13 @@ int cnn_batchnorm2d_forward(const float* x, float* y, const float* gamma, const 
                             float* moving_var, float* saved_mean, float* saved_var, int B, int C, int H, int W,
                             float eps, float momentum, int training, void* workspace, size_t workspace_bytes,
                             void* stream);
+/* BatchNorm2D followed by a ReLU layer (every BN site of the ResNet-shaped stack): y as above AND y_relu = relu(y)
+ * (relu.cpp:25) from the same pass -- the ReLU layer's own kernel would read y again.  Both outputs are written, so both
+ * layers' get_output() stay valid.  y_relu: 16-byte aligned, same shape as y. */
+int cnn_batchnorm2d_forward_relu(const float* x, float* y, float* y_relu, const float* gamma, const float* beta,
+                                 float* moving_mean, float* moving_var, float* saved_mean, float* saved_var, int B, int C, int H,
+                                 int W, float eps, float momentum, int training, void* workspace, size_t workspace_bytes,
+                                 void* stream);
 /* dy is overwritten with dx IN PLACE, like the reference (:149-155).  ggamma[c] = sum dy*norm, gbeta[c] = sum dy:
  * plain sums over (B,H,W), NOT divided by the batch (:123-124).  x is the forward input, saved_* the batch
  * statistics of that forward call. */
@@ -289,6 +296,11 @@ int cnn_batchnorm2d_forward_from_sums(const float* x, float* y, const float* gam
                                       float* moving_var, float* saved_mean, float* saved_var, const float* sum_x,
                                       const float* sum_sq, float count, int B, int C, int H, int W, float eps,
                                       float momentum, void* stream);
+/* ... with the ReLU output of the layer behind it from the same pass (see cnn_batchnorm2d_forward_relu) */
+int cnn_batchnorm2d_forward_from_sums_relu(const float* x, float* y, float* y_relu, const float* gamma, const float* beta,
+                                           float* moving_mean, float* moving_var, float* saved_mean, float* saved_var,
+                                           const float* sum_x, const float* sum_sq, float count, int B, int C, int H, int W,
+                                           float eps, float momentum, void* stream);
 int cnn_batchnorm2d_backward_sums(const float* x, const float* dy, const float* gamma, const float* saved_mean,
                                   const float* saved_var, float* sums4, int B, int C, int H, int W, float eps,
                                   void* workspace, size_t workspace_bytes, void* stream);

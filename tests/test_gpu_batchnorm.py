@@ -78,6 +78,16 @@ def test_batchnorm_train_forward_backward_vs_oracle(T, shape):
     bn.backward(xd, dy2, gd, g2, b2)
     assert T.equal(y2, yd) and T.equal(dy2, dyd) and T.equal(g2, ggd) and T.equal(b2, gbd) and T.equal(mm2, mmd)
 
+    # BatchNorm2D -> ReLU from one pass (cnn_batchnorm2d_forward_relu): y unchanged bit for bit, y_relu = relu(y) (relu.cpp:25),
+    # in training and in evaluation
+    for training in (True, False):
+        y3, r3, yref = T.empty_like(xd), T.empty_like(xd), T.empty_like(xd)
+        mm3, mv3, mm4, mv4 = dev(T, mm0), dev(T, mv0), dev(T, mm0), dev(T, mv0)
+        bn.forward(xd, gd, bd, mm4, mv4, yref, training=training)
+        bn.forward(xd, gd, bd, mm3, mv3, y3, training=training, y_relu=r3)
+        assert T.equal(y3, yref) and T.equal(mm3, mm4) and T.equal(mv3, mv4)
+        assert T.equal(r3, T.where(y3 >= 0, y3, T.zeros_like(y3)))
+
 
 @pytest.mark.parametrize("shape", BN_SHAPES[:4] + BN_SHAPES[5:7], ids=lambda s: "x".join(map(str, s)))
 def test_batchnorm_eval_uses_moving_statistics(T, shape):
