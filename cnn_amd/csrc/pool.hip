@@ -4,6 +4,7 @@
 //   fwd algorithmic bytes: 4*C*(H*W + 2*Ho*Wo) per sample (input + output + int32 mask)
 //   bwd algorithmic bytes: 4*C*(2*Ho*Wo + H*W) per sample (delta + mask + dx written once, no separate memset)
 #include <cstdint>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -150,6 +151,95 @@ __global__ __launch_bounds__(kBlock) void maxpool_bwd_k2s2(const float* __restri
     }
 }
 
+// Narrow planes (Wo <= 32: the 56x56 / 28x28 / 14x14 pools of the VGG-shaped stack): one output row fills only a few of a
+// wavefront's lanes, so the wavefront is cut into 64 / LPR parts of LPR = 2^shift lanes and every part takes its own row (rows of
+// one plane are adjacent in memory, so a wavefront's accesses stay contiguous runs).  Same window order / strict '<' / mask
+// encoding as maxpool_fwd_rows<2,2> and the same outputs as maxpool_bwd_k2s2, element for element.
+__global__ __launch_bounds__(kBlock) void maxpool_fwd_k2s2_packed(const float* __restrict__ x, float* __restrict__ y,
+                                                                  int32_t* __restrict__ mask, unsigned n_rows, int C, int H,
+                                                                  int W, int Ho, int Wo, int shift) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int lpr = 1 << shift, sub = lane >> shift, l = lane & (lpr - 1);
+    const unsigned rpw = (unsigned)(kWave >> shift);
+    for (unsigned g = blockIdx.x * kWavesPerBlock + wave; g * rpw < n_rows; g += gridDim.x * kWavesPerBlock) {
+        const unsigned r = g * rpw + sub;
+        if (r >= n_rows) continue;
+        const unsigned plane = r / (unsigned)Ho;
+        const int ho = (int)(r - plane * Ho);
+        const int c = (int)(plane % (unsigned)C);
+        const float* xrow = x + (size_t)plane * H * W + (size_t)(ho * 2) * W;
+        float* yrow = y + (size_t)r * Wo;
+        int32_t* mrow = mask ? mask + (size_t)r * Wo : nullptr;
+        const int mbase = c * H * W + ho * 2 * W;
+        for (int wo = l; wo < Wo; wo += lpr) {
+            const float* win = xrow + wo * 2;
+            float best = win[0];
+            int best_off = 0;
+            float comp = win[1];
+            if (best < comp) { best = comp; best_off = 1; }
+            comp = win[W];
+            if (best < comp) { best = comp; best_off = W; }
+            comp = win[W + 1];
+            if (best < comp) { best = comp; best_off = W + 1; }
+            yrow[wo] = best;
+            if (mrow) mrow[wo] = mbase + wo * 2 + best_off;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void maxpool_bwd_k2s2_packed(const float* __restrict__ dy, const int32_t* __restrict__ mask,
+                                                                  const float* __restrict__ pooled, float* __restrict__ dx,
+                                                                  unsigned n_units, int C, int H, int W, int Ho, int Wo,
+                                                                  int shift) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int lpr = 1 << shift, sub = lane >> shift, l = lane & (lpr - 1);
+    const unsigned rpw = (unsigned)(kWave >> shift);
+    const int extra = H - 2 * Ho;
+    const unsigned upp = (unsigned)(Ho + extra);
+    for (unsigned g = blockIdx.x * kWavesPerBlock + wave; g * rpw < n_units; g += gridDim.x * kWavesPerBlock) {
+        const unsigned u = g * rpw + sub;
+        if (u >= n_units) continue;
+        const unsigned plane = u / upp;
+        const int r = (int)(u - plane * upp);
+        const int c = (int)(plane % (unsigned)C);
+        float* xplane = dx + (size_t)plane * H * W;
+        if (r >= Ho) {
+            float* row = xplane + (size_t)(2 * Ho + (r - Ho)) * W;
+            for (int w = l; w < W; w += lpr) row[w] = 0.f;
+            continue;
+        }
+        const size_t orow = ((size_t)plane * Ho + r) * Wo;
+        const float* drow = dy + orow;
+        const int32_t* mrow = mask + orow;
+        const float* prow = pooled ? pooled + orow : nullptr;
+        float* row0 = xplane + (size_t)(2 * r) * W;
+        float* row1 = row0 + W;
+        const int32_t base = c * H * W + 2 * r * W;
+        for (int wo = l; wo < Wo; wo += lpr) {
+            float d = drow[wo];
+            if (prow && prow[wo] <= 0.f) d = 0.f;
+            const int off = mrow[wo] - base - 2 * wo;
+            row0[2 * wo] = (off == 0) ? d : 0.f;
+            row0[2 * wo + 1] = (off == 1) ? d : 0.f;
+            row1[2 * wo] = (off == W) ? d : 0.f;
+            row1[2 * wo + 1] = (off == W + 1) ? d : 0.f;
+        }
+        for (int w = 2 * Wo + l; w < W; w += lpr) {
+            row0[w] = 0.f;
+            row1[w] = 0.f;
+        }
+    }
+}
+
+// lanes per row of the packed kernels: the smallest power of two >= Wo; 0 = rows are wide enough for one wavefront each
+inline int packed_shift(int Wo, long long units) {
+    static const bool off = getenv("CNN_AMD_POOL_NO_PACK") != nullptr;  // (A/B switch)
+    if (off || Wo > 32 || units >= (1ll << 31) - 64) return -1;
+    int sh = 0;
+    while ((1 << sh) < Wo) ++sh;
+    return sh;
+}
+
 inline unsigned row_grid(long long rows) {
     long long need = (rows + kWavesPerBlock - 1) / kWavesPerBlock;
     long long cap = (long long)kNumCU * 16;
@@ -176,7 +266,12 @@ int cnn_maxpool2d_forward(const float* x, float* y, int32_t* mask, int B, int C,
     const long long rows = (long long)B * C * Ho;
     hipStream_t s = as_stream(stream);
 #define POOL_TAG "B%d C%d %dx%d k%d step%d mask%d", B, C, H, W, k, step, mask ? 1 : 0
-    if (k == 2 && step == 2)
+    const int psh = (k == 2 && step == 2) ? packed_shift(Wo, rows) : -1;
+    if (psh >= 0) {
+        const long long groups = (rows + (kWave >> psh) - 1) / (kWave >> psh);
+        CNN_KLAUNCH(s, "maxpool_fwd_k2s2_packed",
+                    (maxpool_fwd_k2s2_packed<<<row_grid(groups), kBlock, 0, s>>>(x, y, mask, (unsigned)rows, C, H, W, Ho, Wo, psh)), POOL_TAG);
+    } else if (k == 2 && step == 2)
         CNN_KLAUNCH(s, "maxpool_fwd_rows<2,2>",
                     (maxpool_fwd_rows<2, 2><<<row_grid(rows), kBlock, 0, s>>>(x, y, mask, rows, C, H, W, Ho, Wo, k, step)), POOL_TAG);
     else if (k == 3 && step == 2)
@@ -197,6 +292,14 @@ static int maxpool_backward_impl(const char* who, const float* dy, const int32_t
     hipStream_t s = as_stream(stream);
     if (k == 2 && step == 2) {
         const long long units = (long long)B * C * (Ho + (H - 2 * Ho));
+        const int psh = packed_shift(Wo, units);
+        if (psh >= 0) {
+            const long long groups = (units + (kWave >> psh) - 1) / (kWave >> psh);
+            CNN_KLAUNCH(s, pooled ? "maxpool_bwd_k2s2_packed+relu" : "maxpool_bwd_k2s2_packed",
+                        (maxpool_bwd_k2s2_packed<<<row_grid(groups), kBlock, 0, s>>>(dy, mask, pooled, dx, (unsigned)units, C, H, W, Ho, Wo, psh)),
+                        POOL_TAG);
+            return CNN_AMD_OK;
+        }
         CNN_KLAUNCH(s, pooled ? "maxpool_bwd_k2s2+relu" : "maxpool_bwd_k2s2",
                     (maxpool_bwd_k2s2<<<row_grid(units), kBlock, 0, s>>>(dy, mask, pooled, dx, units, C, H, W, Ho, Wo)), POOL_TAG);
     } else
