@@ -95,6 +95,7 @@ private:
     void* prep_fwd = nullptr;    // prepared filters (forward / data gradient layouts)
     void* prep_dgrad = nullptr;
     bool prepared_active = false;
+    void* prep_event = nullptr;  // see wait_before_forward
     const int in_channels, out_channels, kernel_size, stride;
     const int params_for_one_kernel;
     const int padding;  // extension: the reference has no padding (conv2d.cpp:41-42 keeps it at 0)
@@ -140,6 +141,8 @@ public:
     const data_type* bias_dev() const { return b_dev(); }
     void prepared_buffers(void** fwd, void** dgrad);  // allocated on first use
     void set_prepared(bool on) { prepared_active = on; }
+    // the prepared images of this layer (and of every later one) are written on another stream: the next forward call waits
+    void wait_before_forward(void* event) { prep_event = event; }
     size_t param_count() const override { return (size_t)get_params_num(); }
     void bind_arena(data_type* params_dev, data_type* grads_dev) override;
 };
@@ -313,6 +316,8 @@ protected:
     int comm_world = 1;
     void* comm_stream = nullptr;    // the exchange runs on its own stream, gated by events
     void* ev_grads = nullptr;
+    void* ev_prep = nullptr;   // filter images of layers 2.. prepared on the library's side stream (prepare_filters)
+    void* ev_prep_fork = nullptr;
     void* ev_comm = nullptr;
     bool grads_reduced = false;     // this step's gradient arena has been summed over the replicas
     std::vector<size_t> layer_offsets;  // arena offset of every layer's parameter block (finalize)

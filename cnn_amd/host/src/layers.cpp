@@ -184,6 +184,10 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
     in_H = H;
     in_W = W;
     ensure_workspace(B, H, W);
+    if (prep_event != nullptr) {  // this layer's filter images come from the side stream (Sequential::prepare_filters)
+        must(cnn_stream_wait_event(stream, prep_event), "cnn_stream_wait_event");
+        prep_event = nullptr;
+    }
     const data_type* x = batch_device_pointer(input, in_stage, name);
     if (!no_grad) {  // conv2d.cpp:62: keep the input for the weight gradient
         saved_input = x;

@@ -125,6 +125,8 @@ Sequential::~Sequential() {
     if (loss_sum) cnn_device_free(loss_sum);
     if (comm_stream) cnn_stream_destroy(comm_stream);
     if (ev_grads) cnn_event_destroy(ev_grads);
+    if (ev_prep) cnn_event_destroy(ev_prep);
+    if (ev_prep_fork) cnn_event_destroy(ev_prep_fork);
     if (ev_comm) cnn_event_destroy(ev_comm);
 }
 
@@ -136,8 +138,25 @@ void Sequential::prepare_filters() {
         if (auto* c = dynamic_cast<Conv2D*>(layer.get())) convs.push_back(c);
     for (auto* c : convs)
         if (!c->shape_known()) return;
-    for (size_t first = 0; first < convs.size(); first += 6) {
-        const size_t n = std::min<size_t>(6, convs.size() - first);
+    // Deep stacks (11 M parameters in the ResNet-shaped one: 130 us of re-packing per step): only the first layer's images are
+    // prepared on the caller's stream; the rest is queued on the library's side stream and runs UNDER the first layers' forward
+    // kernels, and the second convolution's forward call waits for it (Conv2D::wait_before_forward).
+    size_t later_params = 0;
+    for (size_t i = 1; i < convs.size(); ++i) later_params += convs[i]->param_count();
+    static const bool no_async = std::getenv("CNN_AMD_SYNC_PREPARE") != nullptr;  // (A/B switch)
+    const bool async = !no_async && convs.size() >= 2 && later_params >= (size_t)1 << 20;
+    void* side = nullptr;
+    if (async) {
+        if (!ev_prep) {
+            must(cnn_event_create(&ev_prep), "cnn_event_create");
+            must(cnn_event_create(&ev_prep_fork), "cnn_event_create");
+        }
+        must(cnn_amd_side_stream_get(&side), "cnn_amd_side_stream_get");
+        must(cnn_event_record(ev_prep_fork, stream), "cnn_event_record");  // behind the SGD step / the load that changed the parameters
+        must(cnn_stream_wait_event(side, ev_prep_fork), "cnn_stream_wait_event");
+    }
+    for (size_t first = 0; first < convs.size(); first += (async && first == 0) ? 1 : 6) {
+        const size_t n = (async && first == 0) ? 1 : std::min<size_t>(6, convs.size() - first);
         std::vector<cnn_conv2d_desc> descs;
         std::vector<const float*> w, b;
         std::vector<void*> f(n), g(n);
@@ -148,8 +167,12 @@ void Sequential::prepare_filters() {
             b.push_back(c->bias_dev());
             c->prepared_buffers(&f[i], &g[i]);
         }
-        must(cnn_conv2d_prepare_filters((int)n, descs.data(), w.data(), b.data(), f.data(), g.data(), stream),
+        must(cnn_conv2d_prepare_filters((int)n, descs.data(), w.data(), b.data(), f.data(), g.data(), (async && first > 0) ? side : stream),
              "cnn_conv2d_prepare_filters");
+    }
+    if (async) {
+        must(cnn_event_record(ev_prep, side), "cnn_event_record");
+        convs[1]->wait_before_forward(ev_prep);
     }
     for (auto* c : convs) c->set_prepared(true);
     filters_prepared = true;
