@@ -32,7 +32,8 @@ def host(t):
 
 # every BN site of AlexNet(batch_norm=true) (alexnet.cpp:13,17,20,23) at a small batch + ragged / tiny / long planes
 BN_SHAPES = [(2, 16, 111, 111), (3, 32, 27, 27), (4, 64, 13, 13), (5, 128, 6, 6), (1, 1, 1, 1), (2, 3, 1, 5),
-             (1, 2, 70, 71), (7, 5, 3, 3), (2, 4, 64, 64)]
+             (1, 2, 70, 71), (7, 5, 3, 3), (2, 4, 64, 64), (64, 32, 16, 16), (65, 32, 16, 16)]  # (last two: a channel = / > the LDS limit
+             # of the one-workgroup-per-channel kernels)
 
 
 @pytest.mark.parametrize("shape", BN_SHAPES, ids=lambda s: "x".join(map(str, s)))
