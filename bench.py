@@ -282,6 +282,7 @@ def make_runner(config, api, batch, torch, capi, world, rank, comm, pool_block=T
     from cnn_amd import hostapi
 
     lib = hostapi.load()
+    pool_block = pool_block and not os.environ.get("CNN_AMD_NO_POOL_FUSION")  # (A/B switch, like the Python driver above)
     lib.cnnh_set_fuse_pool_block(1 if (pool_block and config == "alexnet") else 0)
     if config == "alexnet":
         net = hostapi.HostAlexNet(3)
