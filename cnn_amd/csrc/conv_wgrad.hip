@@ -23,6 +23,8 @@ int direct_conv_wgrad_pooled(const cnn_conv2d_desc* d, const float* x, const flo
 int direct_first_layer_finish(const cnn_conv2d_desc* d, const float* slabs, int nslots, float divisor, float* gw, float* gb, float* w,
                               float* bias, float lr, float grad_scale, void* fwd_img, void* dgrad_img, hipStream_t s);
 int stem_wgrad_slots(const cnn_conv2d_desc* d);  // conv_stem.hip: 3 -> Co, 7x7, stride 2, pad 3
+int os_wgrad_slots(const cnn_conv2d_desc* d);    // conv_wgrad_os.hip: the reference net's small 3x3 / stride-2 layers, output-stationary
+int os_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
 int stem_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
 int wgrad_rd_slots(const cnn_conv2d_desc* d);  // conv_wgrad_rd.hip: register-direct MFMA kernel (3x3, stride 1/2, pad 0)
 int wgrad_rd_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
@@ -738,6 +740,9 @@ size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d) {
     const int sts = stem_wgrad_slots(d);
     const size_t stw = sts ? (size_t)(sts + (sts + 63) / 64) * d->Co * 148 : 0;
     if (stw > m) m = stw;
+    const int oss = os_wgrad_slots(d);
+    const size_t osw = oss ? (size_t)(oss + (oss + 63) / 64) * d->Co * (d->Ci * 9 + 1) : 0;
+    if (osw > m) m = osw;
     return (m + 64) * sizeof(float);
 }
 
@@ -812,6 +817,16 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
             float gb_dummy_unused = 0.f;
             (void)gb_dummy_unused;
             return reduce_slabs(sd, (const float*)ws, ds, n, (float*)ws + (size_t)ds * n, gw, divisor, tagd, 27, gb);
+        }
+    }
+    if (const int oss = os_wgrad_slots(d)) {
+        const size_t n = (size_t)d->Co * (d->Ci * 9 + 1), need_o = (size_t)(oss + (oss + 63) / 64) * n * sizeof(float);
+        if (ws_bytes >= need_o) {
+            hipStream_t so = as_stream(stream);
+            if (int rc = os_wgrad_launch(d, x, dy, (float*)ws, so)) return rc;
+            char tago[160];
+            snprintf(tago, sizeof(tago), CONV_TAG(d));
+            return reduce_slabs(so, (const float*)ws, oss, n, (float*)ws + (size_t)oss * n, gw, divisor, tago, d->Ci * 9, gb);
         }
     }
     if (rd_wanted(d)) {
