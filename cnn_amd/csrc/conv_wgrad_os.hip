@@ -180,8 +180,12 @@ constexpr OsShape kShapes[] = {{16, 32, 55, 55, 512}, {32, 64, 27, 27, 128}, {64
 const OsShape* find_shape(const cnn_conv2d_desc* d) {
     static const bool off = getenv("CNN_AMD_WGRAD_OS") && atoi(getenv("CNN_AMD_WGRAD_OS")) == 0;
     if (off || d->k != 3 || d->s != 2 || d->pad != 0 || d->B < 1) return nullptr;
-    for (const OsShape& s : kShapes)
-        if (d->Ci == s.Ci && d->Co == s.Co && d->H == s.H && d->W == s.W) return &s;
+    static const int mask = getenv("CNN_AMD_WGRAD_OS_MASK") ? atoi(getenv("CNN_AMD_WGRAD_OS_MASK")) : 5;  // bit l = conv_layer_{l+2}; conv_layer_3 (33.7 vs 32.7 us alone) stays on the register-direct kernel: in the step 5 measured >= 7 > 3 ~ 0
+    int bit = 1;
+    for (const OsShape& s : kShapes) {
+        if ((mask & bit) && d->Ci == s.Ci && d->Co == s.Co && d->H == s.H && d->W == s.W) return &s;
+        bit <<= 1;
+    }
     return nullptr;
 }
 
