@@ -523,8 +523,9 @@ class BatchNorm2d:
         return y
 
     # ---- sync-BN: the batch is sharded over `world` data-parallel ranks; `allreduce(t)` sums a small tensor in place ----
-    def forward_sync(self, x, gamma, beta, moving_mean, moving_var, y, allreduce, global_count):
-        """training forward over the GLOBAL batch (batchnorm2d.cpp:46-80): two tiny all-reduces of [C] sums"""
+    def forward_sync(self, x, gamma, beta, moving_mean, moving_var, y, allreduce, global_count, y_relu=None):
+        """training forward over the GLOBAL batch (batchnorm2d.cpp:46-80): two tiny all-reduces of [C] sums
+        (y_relu: also write relu(y), the output of the ReLU layer behind this one)"""
         import torch
 
         _need_gpu(x, y, gamma, beta, moving_mean, moving_var)
@@ -537,6 +538,13 @@ class BatchNorm2d:
         check(L.cnn_batchnorm2d_partial_sums(_ptr(x), _ptr(s1), float(global_count), _ptr(s2), *dims, _ptr(self.ws), self.ws_bytes,
                                              _stream()), "bn sums 2")
         allreduce(s2)
+        if y_relu is not None:
+            _need_gpu(y_relu)
+            check(L.cnn_batchnorm2d_forward_from_sums_relu(_ptr(x), _ptr(y), _ptr(y_relu), _ptr(gamma), _ptr(beta), _ptr(moving_mean),
+                                                           _ptr(moving_var), _ptr(self.saved_mean), _ptr(self.saved_var), _ptr(s1), _ptr(s2),
+                                                           float(global_count), *dims, self.eps, self.momentum, _stream()),
+                  "cnn_batchnorm2d_forward_from_sums_relu")
+            return y
         check(L.cnn_batchnorm2d_forward_from_sums(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(moving_mean), _ptr(moving_var),
                                                   _ptr(self.saved_mean), _ptr(self.saved_var), _ptr(s1), _ptr(s2), float(global_count),
                                                   *dims, self.eps, self.momentum, _stream()), "cnn_batchnorm2d_forward_from_sums")

@@ -246,3 +246,8 @@ def test_sync_batchnorm_sharded_batch_equals_full_batch_oracle(T, shape, splits)
         mm, mv, y1 = dev(T, mm0), dev(T, mv0), T.empty(shape, device="cuda")
         bn.forward(xd, gd, bd, mm, mv, y1, training=True)
         assert T.equal(y1, ranks[0]["y"]) and T.equal(mm, ranks[0]["mm"]) and T.equal(mv, ranks[0]["mv"])
+        # the split-phase forward with the ReLU behind it from the same pass (cnn_batchnorm2d_forward_from_sums_relu)
+        bn2 = capi.BatchNorm2d(B, C, H, W)
+        mm2, mv2, y2, r2 = dev(T, mm0), dev(T, mv0), T.empty(shape, device="cuda"), T.empty(shape, device="cuda")
+        bn2.forward_sync(xd, gd, bd, mm2, mv2, y2, lambda t: None, count, y_relu=r2)
+        assert T.equal(y2, y1) and T.equal(mm2, mm) and T.equal(mv2, mv) and T.equal(r2, T.where(y2 >= 0, y2, T.zeros_like(y2)))
