@@ -2,8 +2,8 @@
 // parameter arena, fused / prepared kernels.  This is the ONE translation unit of cnn_amd/host/src that the reference's own
 // cpu/src/alexnet.cpp can stand in for: that file DEFINES the same members (constructor, forward, backward,
 // update_gradients(lr), save_weights, load_weights) as plain walks over layers_sequence, and compiles against
-// cnn_amd/host/include up to its OpenCV-typed grad_cam (:95).  tests/ref_style/alexnet_ref_style.cpp restates it call for
-// call and tests/test_boundary_compile.py builds and runs that variant against this one.
+// cnn_amd/host/include up to its OpenCV-typed grad_cam (:95; tests/test_boundary_compile.py compiles it where the reference tree
+// exists).  tests/caller/plain_list_caller.cpp drives the same public Layer API WITHOUT this container and ends byte-identical.
 #include <cassert>
 
 #include "architectures.h"
