@@ -30,6 +30,8 @@ SIGNATURES = {
     "cnn_amd_abi_version": (C.c_int, []),
     "cnn_amd_last_error": (C.c_char_p, []),
     "cnn_amd_device_arch": (C.c_char_p, []),
+    "cnn_amd_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "cnn_amd_get_option": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
     "cnn_amd_kernel_timing_enable": (C.c_int, [C.c_int, C.c_char_p]),
     "cnn_amd_kernel_timing_sampling": (C.c_int, [C.c_int]),
     "cnn_amd_kernel_timing_report": (C.c_longlong, [C.c_char_p, C.c_size_t]),
@@ -603,6 +605,33 @@ def softmax_xent(logits, labels, want_probs=True):
     return probs, delta, loss
 
 
+def set_option(name, value):
+    """one of the measurement switches of DESIGN.md section 10 (name with or without the CNN_AMD_ prefix); value None removes it.
+    The library reads the CNN_AMD_* environment once, at first use: later changes go through here."""
+    check(load().cnn_amd_set_option(name.encode(), None if value is None else str(value).encode()), "cnn_amd_set_option")
+
+
+def get_option(name):
+    buf = C.create_string_buffer(256)
+    return buf.value.decode() if load().cnn_amd_get_option(name.encode(), buf, 256) == 0 else None
+
+
+class option:
+    """with capi.option("RD_SLOW", 1): ...   -- sets the switch, restores the previous state on exit"""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
+
+
 def kernel_timing(mode, filter_key="", every=1):
     """0 = off, 1 = every kernel, 2 = only keys containing filter_key (and of those only every `every`-th launch)"""
     check(load().cnn_amd_kernel_timing_sampling(int(every)), "cnn_amd_kernel_timing_sampling")
@@ -705,6 +734,14 @@ class BatchStager:
             self.h = None
 
 
+def _dropout_counts(p, channels):
+    """selected_num = int(p * C) and keep = 1 - p in the reference's FLOAT arithmetic (dropout.cpp:16: data_type p times int):
+    Python doubles give a different count for some p (0.29 * 100 -> 28 here, 29 in the reference)"""
+    import numpy as np
+
+    return int(np.float32(p) * np.float32(channels)), float(np.float32(1) - np.float32(p))
+
+
 def dropout_forward(x, p, training=True, y=None):
     """Dropout::forward (dropout.cpp:7-55): channels 0 .. int(p*C)-1 zeroed in training, x * (1-p) otherwise"""
     import torch
@@ -713,7 +750,8 @@ def dropout_forward(x, p, training=True, y=None):
     B, Cc, H, W = x.shape
     if y is None:
         y = torch.empty_like(x)
-    check(load().cnn_dropout_forward(_ptr(x), _ptr(y), B, Cc, H, W, int(p * Cc), 1 if training else 0, 1.0 - p, _stream()), "cnn_dropout_forward")
+    dropped, keep = _dropout_counts(p, Cc)
+    check(load().cnn_dropout_forward(_ptr(x), _ptr(y), B, Cc, H, W, dropped, 1 if training else 0, keep, _stream()), "cnn_dropout_forward")
     return y
 
 
@@ -721,5 +759,5 @@ def dropout_backward(dy, p):
     """in place on dy (dropout.cpp:57-69)"""
     _need_gpu(dy)
     B, Cc, H, W = dy.shape
-    check(load().cnn_dropout_backward(_ptr(dy), B, Cc, H, W, int(p * Cc), _stream()), "cnn_dropout_backward")
+    check(load().cnn_dropout_backward(_ptr(dy), B, Cc, H, W, _dropout_counts(p, Cc)[0], _stream()), "cnn_dropout_backward")
     return dy

@@ -7,6 +7,8 @@
 
 #include "common.h"
 
+extern char** environ;  // (POSIX; read once by the option table below)
+
 namespace cnn_amd {
 char* error_buffer() {
     static thread_local char buf[512] = {0};
@@ -18,6 +20,54 @@ int fail(int code, const char* fmt, ...) {
     vsnprintf(error_buffer(), 512, fmt, ap);
     va_end(ap);
     return code;
+}
+
+// ---- measurement switches (common.h) ---------------------------------------------------------------------------------------
+namespace {
+struct OptionTable {
+    std::mutex mu;
+    std::map<std::string, std::string> values;
+    std::atomic<unsigned> generation{1};
+    bool env_loaded = false;
+    void load_env_locked() {
+        if (env_loaded) return;
+        env_loaded = true;
+        for (char** e = ::environ; e && *e; ++e) {
+            if (strncmp(*e, "CNN_AMD_", 8) != 0) continue;
+            const char* eq = strchr(*e, '=');
+            if (!eq) continue;
+            const std::string key(*e + 8, (size_t)(eq - (*e + 8)));
+            if (!values.count(key)) values[key] = eq + 1;  // (cnn_amd_set_option before the first query wins)
+        }
+    }
+};
+OptionTable& option_table() {
+    static OptionTable t;
+    return t;
+}
+}  // namespace
+unsigned options_generation() { return option_table().generation.load(std::memory_order_acquire); }
+bool option_lookup(const char* name, long long* ival, double* dval) {
+    OptionTable& t = option_table();
+    std::lock_guard<std::mutex> lk(t.mu);
+    t.load_env_locked();
+    auto it = t.values.find(name);
+    if (it == t.values.end()) return false;
+    *ival = atoll(it->second.c_str());
+    *dval = atof(it->second.c_str());
+    return true;
+}
+
+int num_cus() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    hipDeviceProp_t prop;
+    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cached[dev].store(n, std::memory_order_relaxed);
+    return n;
 }
 
 // ---- published kernels (common.h) ---------------------------------------------------------------------------------------------
@@ -66,6 +116,12 @@ hipEvent_t publish_take(hipStream_t s) {
     p.stale = false;
     g_just_published = true;
     return p.ev[p.cur];
+}
+
+void publish_mark_stale(hipStream_t s) {
+    PublishState& p = publish_state();
+    if (p.valid && p.stream == s) p.stale = true;
+    g_just_published = false;
 }
 
 int publish_after_launch(hipStream_t s) {
@@ -237,24 +293,28 @@ int cnn_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
     if (bytes == 0) return CNN_AMD_OK;
     CNN_REQUIRE(dst && src, "cnn_memcpy_h2d: null pointer");
     CNN_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    publish_mark_stale(as_stream(stream));
     return CNN_AMD_OK;
 }
 int cnn_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
     if (bytes == 0) return CNN_AMD_OK;
     CNN_REQUIRE(dst && src, "cnn_memcpy_d2h: null pointer");
     CNN_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    publish_mark_stale(as_stream(stream));
     return CNN_AMD_OK;
 }
 int cnn_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
     if (bytes == 0) return CNN_AMD_OK;
     CNN_REQUIRE(dst && src, "cnn_memcpy_d2d: null pointer");
     CNN_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    publish_mark_stale(as_stream(stream));
     return CNN_AMD_OK;
 }
 int cnn_memset_zero(void* dst, size_t bytes, void* stream) {
     if (bytes == 0) return CNN_AMD_OK;
     CNN_REQUIRE(dst != nullptr, "cnn_memset_zero: null pointer");
     CNN_HIP_CHECK(hipMemsetAsync(dst, 0, bytes, as_stream(stream)));
+    publish_mark_stale(as_stream(stream));
     return CNN_AMD_OK;
 }
 int cnn_stream_synchronize(void* stream) {
@@ -291,6 +351,7 @@ int cnn_event_record(void* event, void* stream) {
 int cnn_stream_wait_event(void* stream, void* event) {
     CNN_REQUIRE(event != nullptr, "cnn_stream_wait_event: null event");
     CNN_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), reinterpret_cast<hipEvent_t>(event), 0));
+    publish_mark_stale(as_stream(stream));  // (a fork taken from an earlier published kernel would miss this dependency)
     return CNN_AMD_OK;
 }
 int cnn_host_alloc_pinned(void** ptr, size_t bytes) {
@@ -376,6 +437,7 @@ int cnn_batch_stager_wait(void* stager, int slot, void* stream) {
     Stager* st = static_cast<Stager*>(stager);
     CNN_REQUIRE(st && slot >= 0 && slot < st->depth, "cnn_batch_stager_wait: bad arguments");
     CNN_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), st->uploaded[slot], 0));
+    publish_mark_stale(as_stream(stream));
     return CNN_AMD_OK;
 }
 
@@ -384,6 +446,30 @@ int cnn_batch_stager_release(void* stager, int slot, void* stream) {
     CNN_REQUIRE(st && slot >= 0 && slot < st->depth, "cnn_batch_stager_release: bad arguments");
     CNN_HIP_CHECK(hipEventRecord(st->consumed[slot], as_stream(stream)));
     st->in_use[slot] = 1;
+    return CNN_AMD_OK;
+}
+
+int cnn_amd_set_option(const char* name, const char* value) {
+    CNN_REQUIRE(name != nullptr && name[0] != 0, "cnn_amd_set_option: empty name");
+    if (strncmp(name, "CNN_AMD_", 8) == 0) name += 8;
+    OptionTable& t = option_table();
+    std::lock_guard<std::mutex> lk(t.mu);
+    t.load_env_locked();
+    if (value) t.values[name] = value;
+    else t.values.erase(name);
+    t.generation.fetch_add(1, std::memory_order_acq_rel);
+    return CNN_AMD_OK;
+}
+
+int cnn_amd_get_option(const char* name, char* value_out, size_t cap) {
+    CNN_REQUIRE(name != nullptr, "cnn_amd_get_option: null name");
+    if (strncmp(name, "CNN_AMD_", 8) == 0) name += 8;
+    OptionTable& t = option_table();
+    std::lock_guard<std::mutex> lk(t.mu);
+    t.load_env_locked();
+    auto it = t.values.find(name);
+    if (it == t.values.end()) return 1;
+    if (value_out && cap) snprintf(value_out, cap, "%s", it->second.c_str());
     return CNN_AMD_OK;
 }
 

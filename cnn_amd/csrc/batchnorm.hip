@@ -428,7 +428,7 @@ __global__ __launch_bounds__(kChanThreads) void bn_bwd_channel(const float* __re
 
 // the channel kernels take a layer when a channel fits LDS and there are enough channels to spread over the chip
 bool channel_path(int B, int C, int H, int W) {
-    static const bool off = std::getenv("CNN_AMD_BN_NO_CHANNEL") != nullptr;  // (A/B switch)
+    const bool off = CNN_OPT_SET("BN_NO_CHANNEL");  // (A/B switch)
     return !off && (long long)B * H * W <= kChanMaxElems && C >= 32;
 }
 

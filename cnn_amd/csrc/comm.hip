@@ -164,6 +164,7 @@ int cnn_allreduce_grads(void* comm, float* grads, size_t n, void* stream) {
     if (n == 0) return CNN_AMD_OK;
     CNN_RCCL_BIND(R);
     CNN_RCCL_CHECK(R, R->AllReduce(grads, grads, n, ncclFloat32, ncclSum, static_cast<ncclComm_t>(comm), as_stream(stream)));
+    publish_mark_stale(as_stream(stream));
     return CNN_AMD_OK;
 }
 

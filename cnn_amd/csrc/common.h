@@ -17,6 +17,54 @@ int fail(int code, const char* fmt, ...);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- measurement switches -------------------------------------------------------------------------------
+// The A/B switches of the kernels' planners live in ONE process-wide table (abi.hip): filled once from the CNN_AMD_* variables of the
+// environment when the library is first used, changed afterwards only through cnn_amd_set_option() (include/cnn_amd.h).  A launch
+// path never calls getenv: a site holds a static Option whose cached value is re-read from the table only when the table's
+// generation counter has moved (one relaxed atomic load per query otherwise).  Names are the variable names without "CNN_AMD_".
+unsigned options_generation();
+bool option_lookup(const char* name, long long* ival, double* dval);  // false: not set
+class Option {
+public:
+    explicit Option(const char* n) : name_(n) {}
+    bool is_set() { refresh(); return set_.load(std::memory_order_relaxed); }
+    int as_int(int dflt) { refresh(); return set_.load(std::memory_order_relaxed) ? (int)ival_.load(std::memory_order_relaxed) : dflt; }
+    double as_double(double dflt) { refresh(); return set_.load(std::memory_order_relaxed) ? dval_.load(std::memory_order_relaxed) : dflt; }
+private:
+    void refresh() {
+        const unsigned g = options_generation();
+        if (gen_.load(std::memory_order_acquire) == g) return;
+        long long iv = 0;
+        double dv = 0;
+        const bool s = option_lookup(name_, &iv, &dv);
+        ival_.store(iv, std::memory_order_relaxed);
+        dval_.store(dv, std::memory_order_relaxed);
+        set_.store(s, std::memory_order_relaxed);
+        gen_.store(g, std::memory_order_release);
+    }
+    const char* name_;
+    std::atomic<unsigned> gen_{0};  // (the table's generation starts at 1)
+    std::atomic<bool> set_{false};
+    std::atomic<long long> ival_{0};
+    std::atomic<double> dval_{0};
+};
+// one static Option per call site
+#define CNN_OPT(name) ([]() -> ::cnn_amd::Option& { static ::cnn_amd::Option o__(name); return o__; }())
+#define CNN_OPT_SET(name) (CNN_OPT(name).is_set())
+#define CNN_OPT_INT(name, dflt) (CNN_OPT(name).as_int(dflt))
+// "is it set, and to which integer" in one value: `const OptVal e = CNN_OPT_VAL("X"); if (e && atoi(e) == 0) ...`
+struct OptVal {
+    bool set;
+    int v;
+    explicit operator bool() const { return set; }
+};
+inline int atoi(const OptVal& o) { return o.v; }
+inline OptVal opt_val(Option& o) { return OptVal{o.is_set(), o.as_int(0)}; }
+#define CNN_OPT_VAL(name) (::cnn_amd::opt_val(CNN_OPT(name)))
+
+// compute units of the current device (hipDeviceProp_t::multiProcessorCount, cached per device; 256 on MI355X)
+int num_cus();
+
 #define CNN_HIP_CHECK(expr)                                                                         \
     do {                                                                                            \
         hipError_t e__ = (expr);                                                                    \
@@ -51,6 +99,7 @@ struct PublishState {
 PublishState& publish_state();                   // per host thread (abi.hip)
 hipEvent_t publish_take(hipStream_t s);          // armed for s: the event to attach (state -> published), else nullptr
 int publish_after_launch(hipStream_t s);         // bookkeeping behind EVERY launch (fallback record / staleness)
+void publish_mark_stale(hipStream_t s);         // something that is NOT a library kernel was queued on s (copies, waits, collectives)
 inline bool publish_busy() {
     const PublishState& p = publish_state();
     return p.armed || (p.valid && !p.stale);
@@ -119,7 +168,6 @@ __device__ __forceinline__ float sgd_one(float p, float g, float lr, float scale
 }
 
 constexpr int kWave = 64;          // CDNA wavefront
-constexpr int kNumCU = 256;        // MI355X
 constexpr int kNumXCD = 8;
 
 // Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2: neighbouring tiles of an image -- which share
@@ -138,7 +186,7 @@ inline unsigned ceil_div(size_t a, size_t b) { return (unsigned)((a + b - 1) / b
 // grid for HBM-bound streaming kernels: enough workgroups to fill 256 CUs x 8, grid-stride the rest
 inline unsigned stream_grid(size_t work_items, int block) {
     size_t need = (work_items + block - 1) / block;
-    size_t cap = (size_t)kNumCU * 8;
+    size_t cap = (size_t)num_cus() * 8;
     return (unsigned)(need < 1 ? 1 : (need > cap ? cap : need));
 }
 

@@ -40,7 +40,7 @@ int get_side(SideStream** out) {
 bool heavy_layer(const cnn_conv2d_desc* d) {
     const double Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
     const double flops = 2.0 * d->B * d->Co * Ho * Wo * d->Ci * d->k * d->k;
-    static const double limit = getenv("CNN_AMD_SERIAL_BWD_GFLOP") ? atof(getenv("CNN_AMD_SERIAL_BWD_GFLOP")) * 1e9 : 2e10;
+    const double limit = CNN_OPT("SERIAL_BWD_GFLOP").as_double(20.0) * 1e9;
     return flops >= limit;
 }
 // the side stream waits for everything queued on `main` so far.  When the last thing the library launched on `main` is a published
@@ -80,7 +80,7 @@ int cnn_amd_side_stream_join(void* stream) {
     // the recorded reductions: on the side stream in front of the join (concurrent with the caller's last kernels: starved,
     // ~100 us instead of 8, but off the critical path: 491k vs 480k images/s) or, with CNN_AMD_REDUCE_ON_MAIN=1, on the
     // caller's stream behind it
-    static const bool on_side = !(getenv("CNN_AMD_REDUCE_ON_MAIN") && atoi(getenv("CNN_AMD_REDUCE_ON_MAIN")) != 0);
+    const bool on_side = !((CNN_OPT_SET("REDUCE_ON_MAIN") && CNN_OPT_INT("REDUCE_ON_MAIN", 0) != 0));
     if (on_side)
         if (int rc = wgrad_flush_reduces(side->stream)) return rc;
     CNN_HIP_CHECK(hipEventRecord(side->join, side->stream));

@@ -690,7 +690,7 @@ inline bool m16_wanted(const cnn_conv2d_desc* d) {
     if ((long long)d->B * d->Co * cnn_conv2d_out_dim(d->H, 3, 2, d->pad) * cnn_conv2d_out_dim(d->W, 3, 2, d->pad) >= (1ll << 29) ||
         (long long)d->B * d->Ci * d->H * d->W >= (1ll << 29))
         return false;  // (32-bit buffer offsets)
-    const char* e = getenv("CNN_AMD_DGRAD_M16");
+    const OptVal e = CNN_OPT_VAL("DGRAD_M16");
     if (e && atoi(e) == 0) return false;
     if (d->Ci >= 32 && e && atoi(e) == 1) return false;  // (=1: only the Ci = 16 shape, =2: not the split Co = 128 shape; for A/B runs)
     if (d->Ci == 64 && e && atoi(e) == 2) return false;
@@ -704,8 +704,8 @@ bool make_plan(const cnn_conv2d_desc* d, DgRdPlan* pl) {
     if ((d->Co != 32 && d->Co != 64 && d->Co != 128) || d->Ci % 16 != 0) return false;  // (Ci = 16: half of the 32 MFMA rows idle)
     // Co = 32 / Ci = 16 (conv_layer_2): measured 117 us against 95 us for the packed VALU kernel -> opt-in only
     pl->m16 = m16_wanted(d);
-    if (d->Co == 32 && !pl->m16 && !(getenv("CNN_AMD_DGRAD_RD32") && atoi(getenv("CNN_AMD_DGRAD_RD32")) != 0)) return false;
-    if (const char* e = getenv("CNN_AMD_DGRAD_RD"))
+    if (d->Co == 32 && !pl->m16 && !((CNN_OPT_SET("DGRAD_RD32") && CNN_OPT_INT("DGRAD_RD32", 0) != 0))) return false;
+    if (const OptVal e = CNN_OPT_VAL("DGRAD_RD"))
         if (atoi(e) == 0) return false;
     DgRdParams& p = pl->p;
     p.B = d->B; p.Ci = d->Ci; p.H = d->H; p.W = d->W;
@@ -722,24 +722,24 @@ bool make_plan(const cnn_conv2d_desc* d, DgRdPlan* pl) {
     p.tiles = (int)((pixels + 31) / 32);
     p.m_uv = magic_of(p.UV);
     p.m_v = magic_of(p.V);
-    p.dbg = getenv("CNN_AMD_DGRAD_RD_DBG") ? atoi(getenv("CNN_AMD_DGRAD_RD_DBG")) : 0;
+    p.dbg = CNN_OPT_INT("DGRAD_RD_DBG", 0);
     pl->co = d->Co;
     pl->mt = (d->s == 1 && d->Ci % 64 == 0) ? 2 : 1;  // stride 1: two 32-channel tiles per wave share the dy windows
-    if (const char* e = getenv("CNN_AMD_DGRAD_RD_MT")) pl->mt = (atoi(e) == 2 && d->s == 1 && d->Ci % 64 == 0) ? 2 : 1;
+    if (const OptVal e = CNN_OPT_VAL("DGRAD_RD_MT")) pl->mt = (atoi(e) == 2 && d->s == 1 && d->Ci % 64 == 0) ? 2 : 1;
     pl->cgroups = (d->Ci + 32 * pl->mt - 1) / (32 * pl->mt);
     pl->img_floats = (size_t)d->Co * d->Ci * 9;  // (prepared buffer = a verbatim copy of w)
     pl->lds = 0;
     pl->nw = 4;
-    const long long bx = 2 * kNumCU / pl->cgroups;
+    const long long bx = 2 * num_cus() / pl->cgroups;
     const long long need = (p.tiles + pl->nw - 1) / pl->nw;
     pl->blocks_x = (int)(bx < 1 ? 1 : (bx > need ? need : bx));
     if (pl->m16) {  // persistent waves over 16-pixel groups
-        int per_cu = getenv("CNN_AMD_DGRAD_M16_WG") ? atoi(getenv("CNN_AMD_DGRAD_M16_WG")) : 2;
+        int per_cu = CNN_OPT_INT("DGRAD_M16_WG", 2);
         if (per_cu < 1 || per_cu > 8) per_cu = 2;
         const int slices = d->Ci / 16;
         const long long g = (pixels + 15) / 16;
-        long long parts = (long long)per_cu * kNumCU * pl->nw / slices;  // pixel partitions: waves / slices
-        if (d->Co == 128) parts = (getenv("CNN_AMD_DGRAD_M16_WG") ? per_cu : 1) * kNumCU;  // one 8-wave workgroup (4 slices x 2 halves) per partition
+        long long parts = (long long)per_cu * num_cus() * pl->nw / slices;  // pixel partitions: waves / slices
+        if (d->Co == 128) parts = (CNN_OPT_SET("DGRAD_M16_WG") ? per_cu : 1) * num_cus();  // one 8-wave workgroup (4 slices x 2 halves) per partition
         if (parts > g) parts = g;
         p.tiles = (int)parts;
         pl->blocks_x = d->Co == 128 ? (int)parts : (int)((parts * slices + pl->nw - 1) / pl->nw);
@@ -751,7 +751,7 @@ bool make_plan(const cnn_conv2d_desc* d, DgRdPlan* pl) {
 
 template <int CO, int NW>
 int launch(const DgRdPlan& pl, hipStream_t s, const char* name, const cnn_conv2d_desc* d) {
-    const int var = getenv("CNN_AMD_DGRAD_RD_VAR") ? atoi(getenv("CNN_AMD_DGRAD_RD_VAR")) : 0;
+    const int var = CNN_OPT_INT("DGRAD_RD_VAR", 0);
     auto kern = var == 3 ? conv_dgrad_rd_s2_kernel<CO, NW, 2, 2> : conv_dgrad_rd_s2_kernel<CO, NW, 2, 4>;
     const dim3 grid(pl.blocks_x, pl.cgroups);
     CNN_KLAUNCH(s, name, (kern<<<grid, NW * 64, pl.lds, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W,
@@ -759,7 +759,7 @@ int launch(const DgRdPlan& pl, hipStream_t s, const char* name, const cnn_conv2d
     return CNN_AMD_OK;
 }
 
-inline int prepared_transposed() { return getenv("CNN_AMD_DGRAD_RD_NOTR") ? 0 : 1; }
+inline int prepared_transposed() { return CNN_OPT_SET("DGRAD_RD_NOTR") ? 0 : 1; }
 
 }  // namespace
 
@@ -834,7 +834,7 @@ int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const floa
         snprintf(name, sizeof(name), "conv_dgrad_rd<1,%d,%d>/dgrad%s", d->Co, pl.mt, relu_below ? "+relu" : "");
 #define S1(CO_, MT_, UC_) CNN_KLAUNCH(s, name, (conv_dgrad_rd_s1_kernel<CO_, MT_, 4, UC_><<<grid, 256, 0, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", \
                                       d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad)
-        const int uc = getenv("CNN_AMD_DGRAD_RD_UC") ? atoi(getenv("CNN_AMD_DGRAD_RD_UC")) : 1;
+        const int uc = CNN_OPT_INT("DGRAD_RD_UC", 1);
         if (d->Co == 64 && pl.mt == 2) S1(64, 2, 1);
         else if (d->Co == 64) { if (uc == 2) S1(64, 1, 2); else S1(64, 1, 1); }
         else if (pl.mt == 2) S1(128, 2, 1);

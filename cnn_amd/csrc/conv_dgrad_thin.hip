@@ -279,7 +279,7 @@ namespace cnn_amd {
 #define CONV_TAG(d) "B%d Ci%d %dx%d Co%d k%d s%d p%d", (d)->B, (d)->Ci, (d)->H, (d)->W, (d)->Co, (d)->k, (d)->s, (d)->pad
 
 bool thin_dgrad_supported(const cnn_conv2d_desc* d) {
-    const char* e = getenv("CNN_AMD_DGRAD_THIN");
+    const OptVal e = CNN_OPT_VAL("DGRAD_THIN");
     if (e && atoi(e) == 0) return false;
     if (d->Ci == 3 && d->k == 7 && d->s == 2 && d->pad == 3)  // the 7x7 stem: conv_dgrad_thin_s2
         return (long long)d->B * d->Co * cnn_conv2d_out_dim(d->H, 7, 2, 3) * cnn_conv2d_out_dim(d->W, 7, 2, 3) < (1ll << 29) &&  // (32-bit byte offsets)

@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_pk_3_16_3_2(const float* __
 
 inline unsigned wave_grid(long long rows) {
     long long need = (rows + kWaves - 1) / kWaves;
-    const long long cap = (long long)kNumCU * 32;
+    const long long cap = (long long)num_cus() * 32;
     return (unsigned)(need < 1 ? 1 : (need > cap ? cap : need));
 }
 
@@ -1040,12 +1040,12 @@ int win_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, 
 // returns 1 when the geometry has a direct kernel (and it was launched), 0 when the caller must use the implicit GEMM,
 // < 0 on error
 bool direct_conv_supported(const cnn_conv2d_desc* d) {
-    return d->Ci == 3 && d->Co == 16 && d->k == 3 && d->s == 2 && d->pad == 0 && !getenv("CNN_AMD_NO_DIRECT");
+    return d->Ci == 3 && d->Co == 16 && d->k == 3 && d->s == 2 && d->pad == 0 && !CNN_OPT_SET("NO_DIRECT");
 }
 
 // prepared: `ws` already holds the packed filters (cnn_conv2d_prepare_filters); w / bias are then unused
 bool direct_fwd_pk_ok(const cnn_conv2d_desc* d) {
-    return (long long)d->B * 3 * d->H * d->W * 4 < (1ll << 31) - 16 && !getenv("CNN_AMD_FWD_NOPK");
+    return (long long)d->B * 3 * d->H * d->W * 4 < (1ll << 31) - 16 && !CNN_OPT_SET("FWD_NOPK");
 }
 int direct_conv_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
                         float* y_relu, void* ws, size_t ws_bytes, hipStream_t s, bool prepared) {
@@ -1078,7 +1078,7 @@ int direct_conv_forward(const cnn_conv2d_desc* d, const float* x, const float* w
 bool direct_conv_pool_supported(const cnn_conv2d_desc* d) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
     return direct_conv_supported(d) && direct_fwd_pk_ok(d) && Ho >= 2 && Wo >= 2 && (long long)16 * Ho * Wo < (1ll << 31) &&
-           (long long)d->B * 16 * (Ho / 2) * (Wo / 2) * 4 < (1ll << 31) - 16 && !getenv("CNN_AMD_NO_POOL_FUSION");
+           (long long)d->B * 16 * (Ho / 2) * (Wo / 2) * 4 < (1ll << 31) - 16 && !CNN_OPT_SET("NO_POOL_FUSION");
 }
 int direct_conv_pool_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* pooled,
                              int32_t* mask, void* ws, size_t ws_bytes, hipStream_t s, bool prepared) {
@@ -1090,7 +1090,7 @@ int direct_conv_pool_forward(const cnn_conv2d_desc* d, const float* x, const flo
         CNN_KLAUNCH(s, "pack_fwd_weights", (pack_fwd_weights_3_16_3_2<<<1, 256, 0, s>>>(w, bias, (float*)ws)), CONV_TAG(d));
     const int ipi = (2 * PHo * PWo + 63) / 64;
     const long long witems = (long long)d->B * ipi;
-    const int dbg = getenv("CNN_AMD_DBG") ? atoi(getenv("CNN_AMD_DBG")) : 0;
+    const int dbg = CNN_OPT_INT("DBG", 0);
 #define FP_LAUNCH(DBG_)                                                                                                        \
     CNN_KLAUNCH(s, "conv_fwd_pool_pk<3,16,3,2>",                                                                               \
                 (conv_fwd_pool_pk_3_16_3_2<DBG_><<<wave_grid(witems), kBlock, 0, s>>>(x, (const v2f*)ws, pooled, mask, d->B, d->H, d->W, Ho, \
@@ -1105,7 +1105,7 @@ int direct_conv_pool_forward(const cnn_conv2d_desc* d, const float* x, const flo
 
 bool direct_dgrad_pk_ok(const cnn_conv2d_desc* d) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
-    return (long long)d->B * 16 * Ho * Wo * 4 < (1ll << 31) - 16 && !getenv("CNN_AMD_DG_NOPK");
+    return (long long)d->B * 16 * Ho * Wo * 4 < (1ll << 31) - 16 && !CNN_OPT_SET("DG_NOPK");
 }
 int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes,
                       hipStream_t s, bool prepared) {
@@ -1118,7 +1118,7 @@ int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w,
         const long long witems = (long long)d->B * ipi;
         // CNN_AMD_DBG = 4 / 8 / 12 (tuning only): compile-time ablations without the FMAs / the stores / both, the source
         // of the breakdown in DESIGN.md section 6
-        const int dbg = getenv("CNN_AMD_DBG") ? atoi(getenv("CNN_AMD_DBG")) : 0;
+        const int dbg = CNN_OPT_INT("DBG", 0);
 #define PK_LAUNCH(DBG_)                                                                                              \
     CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>",                                                                       \
                 (conv_dgrad_pk_3_16_3_2<4, DBG_><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, \
@@ -1156,7 +1156,7 @@ int direct_conv_dgrad_pooled(const cnn_conv2d_desc* d, const float* dpool, const
     // latency-bound head of the net (deferred launch, cnn_amd/pynet.py); a smaller grid leaves wave slots and memory queues
     // to those kernels
     unsigned grid = wave_grid(witems);
-    if (const char* e = getenv("CNN_AMD_DX0_GRID"))
+    if (const OptVal e = CNN_OPT_VAL("DX0_GRID"))
         if (atoi(e) > 0 && (unsigned)atoi(e) < grid) grid = (unsigned)atoi(e);
     if (pooled)
         CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>+pool",
@@ -1174,7 +1174,7 @@ int direct_conv_dgrad_pooled(const cnn_conv2d_desc* d, const float* dpool, const
 // Packed VALU data gradient for k = 3, stride 2, pad 0 layers with 16 input channels (conv_layer_2 of the reference net).
 bool pk_dgrad_s2_supported(const cnn_conv2d_desc* d) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
-    const char* e = getenv("CNN_AMD_PK_DGRAD");
+    const OptVal e = CNN_OPT_VAL("PK_DGRAD");
     if (e && atoi(e) == 0) return false;
     return d->k == 3 && d->s == 2 && d->pad == 0 && (d->Ci == 16 || (e && d->Ci == 32)) && d->Co % 4 == 0 && d->Co * 9 * d->Ci * 4 <= 144 * 1024 &&
            (long long)d->B * d->Co * Ho * Wo * 4 < (1ll << 31) - 16 && (long long)d->B * (((d->H + 1) / 2) * ((d->W + 1) / 2) + 63) / 64 < (1ll << 30);
@@ -1245,12 +1245,12 @@ bool direct_prepared_dgrad_ok(const cnn_conv2d_desc* d) {
 
 // number of slabs (workgroups) the packed weight-gradient kernel writes; 0 when the geometry / sizes rule it out
 int direct_wgrad_slots(const cnn_conv2d_desc* d) {
-    if (!direct_conv_supported(d) || getenv("CNN_AMD_WG_NOPK")) return 0;
+    if (!direct_conv_supported(d) || CNN_OPT_SET("WG_NOPK")) return 0;
     if (const int ws = win_wgrad_slots(d)) return ws;
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
     if ((long long)d->B * 16 * Ho * Wo * 4 >= (1ll << 31) - 16 || (long long)d->B * 3 * d->H * d->W * 4 >= (1ll << 31) - 16) return 0;
     const long long items = (long long)d->B * ((Ho * Wo + 63) / 64);
-    const long long cap = (long long)kNumCU * 2;  // two resident workgroups per CU (~200 VGPRs each); 1 or 3 measured slower
+    const long long cap = (long long)num_cus() * 2;  // two resident workgroups per CU (~200 VGPRs each); 1 or 3 measured slower
     return (int)(items < cap ? items : cap);
 }
 

@@ -345,7 +345,7 @@ struct FwdRdPlan {
 bool make_plan(const cnn_conv2d_desc* d, FwdRdPlan* pl) {
     if (d->k != 3 || d->pad != 0 || (d->s != 1 && d->s != 2)) return false;
     if (d->Ci != 16 && d->Ci != 32 && d->Ci != 64) return false;
-    if (const char* e = getenv("CNN_AMD_FWD_RD"))
+    if (const OptVal e = CNN_OPT_VAL("FWD_RD"))
         if (atoi(e) == 0) return false;
     FwdRdParams& p = pl->p;
     p.B = d->B; p.H = d->H; p.W = d->W; p.Co = d->Co;
@@ -359,22 +359,22 @@ bool make_plan(const cnn_conv2d_desc* d, FwdRdPlan* pl) {
     p.tiles = (int)((pixels + 31) / 32);
     p.m_howo = magic_of(p.HoWo);
     p.m_wo = magic_of(p.Wo);
-    p.dbg = getenv("CNN_AMD_FWD_RD_DBG") ? atoi(getenv("CNN_AMD_FWD_RD_DBG")) : 0;
+    p.dbg = CNN_OPT_INT("FWD_RD_DBG", 0);
     pl->s = d->s;
     pl->ci = d->Ci;
     const int mtiles = (d->Co + 31) / 32;
     // output tiles per wave: keep the filter slice within LDS and the grid above one wave per SIMD
     // two tiles per wave halve the input reads, but only pay once every wave slot still gets a few items
-    int mt = mtiles >= 2 && (long long)p.tiles * ((mtiles + 1) / 2) >= 4 * 4 * kNumCU ? 2 : 1;
+    int mt = mtiles >= 2 && (long long)p.tiles * ((mtiles + 1) / 2) >= 4 * 4 * num_cus() ? 2 : 1;
     if ((size_t)(mt * 32 + 1) * d->Ci * 9 * 4 > 96 * 1024) mt = 1;
-    if (const char* e = getenv("CNN_AMD_FWD_RD_MT")) mt = atoi(e) == 2 && mtiles >= 2 ? 2 : 1;
+    if (const OptVal e = CNN_OPT_VAL("FWD_RD_MT")) mt = atoi(e) == 2 && mtiles >= 2 ? 2 : 1;
     pl->mt = mt;
     pl->cgroups = (mtiles + mt - 1) / mt;
     pl->img_floats = ((size_t)(mt * 32 + 1) * d->Ci * 9 + mt * 32 + 3) / 4 * 4;  // filters + bias, whole float4s
     pl->lds = pl->img_floats * sizeof(float);
     pl->nw = pl->lds > 80 * 1024 ? 8 : 4;  // a filter slice that allows one workgroup per CU gets 8 waves
-    const int env = getenv("CNN_AMD_FWD_RD_BLOCKS") ? atoi(getenv("CNN_AMD_FWD_RD_BLOCKS")) : 0;
-    long long bx = (env > 0 ? env : (pl->nw == 8 ? kNumCU : 2 * kNumCU)) / pl->cgroups;
+    const int env = CNN_OPT_INT("FWD_RD_BLOCKS", 0);
+    long long bx = (env > 0 ? env : (pl->nw == 8 ? num_cus() : 2 * num_cus())) / pl->cgroups;
     const long long need = (p.tiles + pl->nw - 1) / pl->nw;
     if (bx > need) bx = need;
     if (bx < 1) bx = 1;
@@ -382,17 +382,17 @@ bool make_plan(const cnn_conv2d_desc* d, FwdRdPlan* pl) {
     // small layers: fewer than four 32-pixel wave tiles per SIMD for the kernel above
     const bool m16_ok = d->Co % 16 == 0 && (long long)d->B * d->Ci * d->H * d->W < (1ll << 29);  // (32-bit buffer offsets)
     // ... and the thin Ci = 16 layers (conv_layer_2: 27.7 vs 33 us on the kernel above), unless CNN_AMD_FWD_M16_THIN=0
-    const bool thin = d->Ci == 16 && d->Co % 32 == 0 && !(getenv("CNN_AMD_FWD_M16_THIN") && atoi(getenv("CNN_AMD_FWD_M16_THIN")) == 0);
-    pl->m16 = m16_ok && ((long long)p.tiles * mtiles < 4 * 4 * kNumCU || thin);
-    if (const char* e = getenv("CNN_AMD_FWD_M16")) pl->m16 = m16_ok && atoi(e) != 0;
+    const bool thin = d->Ci == 16 && d->Co % 32 == 0 && !((CNN_OPT_SET("FWD_M16_THIN") && CNN_OPT_INT("FWD_M16_THIN", 0) == 0));
+    pl->m16 = m16_ok && ((long long)p.tiles * mtiles < 4 * 4 * num_cus() || thin);
+    if (const OptVal e = CNN_OPT_VAL("FWD_M16")) pl->m16 = m16_ok && atoi(e) != 0;
     if (pl->m16) {
         // two slices per wave where 2 * Ci*9/4 filter registers fit beside the rest (Ci <= 32)
-        pl->m16_ms = (d->Co % 32 == 0 && d->Ci <= 32 && !(getenv("CNN_AMD_FWD_M16_MS") && atoi(getenv("CNN_AMD_FWD_M16_MS")) == 1)) ? 2 : 1;
+        pl->m16_ms = (d->Co % 32 == 0 && d->Ci <= 32 && !((CNN_OPT_SET("FWD_M16_MS") && CNN_OPT_INT("FWD_M16_MS", 0) == 1))) ? 2 : 1;
         const int slices = d->Co / 16 / pl->m16_ms, groups = (int)((pixels + 15) / 16);
         // waves per SIMD, measured: Ci >= 32: 1 beats 2-4 (the filter preamble is per wave); Ci = 16: 2 (29.8 / 27.7 / 33.5 us for 1 / 2 / 3)
-        int per_simd = getenv("CNN_AMD_FWD_M16_WAVES") ? atoi(getenv("CNN_AMD_FWD_M16_WAVES")) : (d->Ci == 16 ? 2 : 1);
+        int per_simd = CNN_OPT_INT("FWD_M16_WAVES", (d->Ci == 16 ? 2 : 1));
         if (per_simd < 1 || per_simd > 8) per_simd = 1;
-        int parts = per_simd * 4 * kNumCU / slices;
+        int parts = per_simd * 4 * num_cus() / slices;
         if (parts < 1) parts = 1;
         if (parts > groups) parts = groups;
         pl->m16_parts = parts;

@@ -1066,28 +1066,28 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
 
     // tile choice: the widest pixel tile that still gives every CU a couple of workgroups
     auto blocks_for = [&](int MT, int NPIX) { return ((p.N + NPIX - 1) / NPIX) * ((p.M + MT - 1) / MT); };
-    const long long kWantBlocks = 2 * kNumCU;
+    const long long kWantBlocks = 2 * num_cus();
     // forward without padding: the DMA kernel can move whole multi-row runs -> worth it even for small images
     const bool unpadded = (mode == MODE_FWD && d->pad == 0);
     const bool dma_ok = allow_dma && p.TR * p.TC <= 9 && p.N < (1ll << 31) - 4096;
     // small images (whole-image staging applies, see igemm_dma_kernel XM): tiles sized for enough workgroups at the
     // batch sizes of the reference net; measured on conv_layer_3 / conv_layer_4 (alexnet.cpp:19,22) forward and dgrad
     // (only when the large MFMA tiles below would leave CUs idle: a 28x28 layer at batch 128 is a big GEMM)
-    const bool small_img = dma_ok && p.XH * p.XW <= 1024 && p.M > 32 && !getenv("CNN_AMD_IGEMM_NOIMG") &&
-                           !(p.M > 64 && blocks_for(128, 256) >= 2 * kNumCU) && !(p.M <= 64 && blocks_for(64, 128) >= 8 * kNumCU);
+    const bool small_img = dma_ok && p.XH * p.XW <= 1024 && p.M > 32 && !CNN_OPT_SET("IGEMM_NOIMG") &&
+                           !(p.M > 64 && blocks_for(128, 256) >= 2 * num_cus()) && !(p.M <= 64 && blocks_for(64, 128) >= 8 * num_cus());
     if (small_img && p.M > 64 && mode == MODE_FWD) { pl->cfg = CFG_D_M64S; pl->MF = 32; pl->MT = 64; pl->NPIX = 64; pl->CK = 8; }
     else if (small_img && p.M > 64 && p.C >= 128) { pl->cfg = CFG_D_M64S_C16; pl->MF = 32; pl->MT = 64; pl->NPIX = 64; pl->CK = 16; }
     else if (small_img && p.M > 64) { pl->cfg = CFG_D_M32; pl->MF = 32; pl->MT = 32; pl->NPIX = 128; pl->CK = 8; }
     else if (small_img && p.C >= 16) { pl->cfg = CFG_D_M64W4N1_C4; pl->MF = 32; pl->MT = 64; pl->NPIX = 128; pl->CK = 4; }
     else if (p.M > 64) {
         pl->MF = 32; pl->MT = 128; pl->CK = 8;
-        if (allow_dma && blocks_for(128, 256) >= 2 * kNumCU && p.TR * p.TC <= 9 && p.N < (1ll << 31) - 1024) { pl->cfg = CFG_D_M128; pl->NPIX = 256; }
+        if (allow_dma && blocks_for(128, 256) >= 2 * num_cus() && p.TR * p.TC <= 9 && p.N < (1ll << 31) - 1024) { pl->cfg = CFG_D_M128; pl->NPIX = 256; }
         else if (blocks_for(128, 128) >= kWantBlocks) { pl->cfg = CFG_M128; pl->NPIX = 128; }
-        else if (dma_ok && unpadded && blocks_for(128, 64) >= kNumCU / 2) { pl->cfg = CFG_D_M128S; pl->NPIX = 64; }
+        else if (dma_ok && unpadded && blocks_for(128, 64) >= num_cus() / 2) { pl->cfg = CFG_D_M128S; pl->NPIX = 64; }
         else { pl->cfg = CFG_M128_S; pl->NPIX = 64; }
     } else if (p.M > 32) {
         pl->MF = 32; pl->MT = 64; pl->CK = 8;
-        if (allow_dma && blocks_for(64, 128) >= 4 * kNumCU && p.TR * p.TC <= 9 && p.N < (1ll << 31) - 1024 && p.C >= 16) {
+        if (allow_dma && blocks_for(64, 128) >= 4 * num_cus() && p.TR * p.TC <= 9 && p.N < (1ll << 31) - 1024 && p.C >= 16) {
             pl->cfg = CFG_D_M64W4N1_C4; pl->NPIX = 128; pl->CK = 4;
         } else if (blocks_for(64, 256) >= kWantBlocks) { pl->cfg = CFG_M64; pl->NPIX = 256; }
         else { pl->cfg = CFG_M64_S; pl->NPIX = 64; }
@@ -1111,7 +1111,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     }
     // overrides: CNN_AMD_IGEMM_CFG=<cfg id> (debug only) > the tuner's probe > the tuner's pinned choice for this geometry
     int override_cfg = -1;
-    if (const char* ov = getenv("CNN_AMD_IGEMM_CFG")) override_cfg = atoi(ov);
+    if (const OptVal ov = CNN_OPT_VAL("IGEMM_CFG")) override_cfg = atoi(ov);
     else if (g_forced_cfg >= 0) override_cfg = g_forced_cfg;
     else if (shrink == 0 && allow_dma) {
         std::lock_guard<std::mutex> lk(tune_mutex());
@@ -1151,7 +1151,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     // DMA configurations on padded layers whose rows are 16-byte multiples: 4-float left pad, pitch a multiple of 4 floats -> the row
     // image is staged by 16-byte DMA instructions that span several rows (run_mode 3 of igemm_dma_kernel)
     const bool dma_cfg = pl->cfg >= CFG_D_M128;
-    const bool vecrows = dma_cfg && p.XW % 4 == 0 && p.padL > 0 && p.padL <= 4 && !(getenv("CNN_AMD_IGEMM_NOVECROWS") && atoi(getenv("CNN_AMD_IGEMM_NOVECROWS")) != 0);
+    const bool vecrows = dma_cfg && p.XW % 4 == 0 && p.padL > 0 && p.padL <= 4 && !((CNN_OPT_SET("IGEMM_NOVECROWS") && CNN_OPT_INT("IGEMM_NOVECROWS", 0) != 0));
     if (vecrows) {
         p.padL = 4;
         p.LW = (4 + p.XW + padR + 3) & ~3;
@@ -1186,7 +1186,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
                              pl->cfg == CFG_D_M32 || pl->cfg == CFG_D_M32_C4 || pl->cfg == CFG_D_M32_C16 ||
                              pl->cfg == CFG_D_M128S || pl->cfg == CFG_D_M128S_C4 || pl->cfg == CFG_D_M128S_C16 ||
                              pl->cfg == CFG_D_M64S || pl->cfg == CFG_D_M64S_C4 || pl->cfg == CFG_D_M64S_C16;
-        const char* xe = getenv("CNN_AMD_IGEMM_XM");
+        const OptVal xe = CNN_OPT_VAL("IGEMM_XM");
         const size_t lds = 2 * ((size_t)T * pl->CK * pl->MT + (size_t)nimg * pl->CK * HW) * sizeof(float);
         if (img_cfg && HW <= 1024 && lds <= 160 * 1024 && (long long)p.B * p.C * HW < (1ll << 31) && !(xe && atoi(xe) == 0)) {
             pl->xm = p.need_zero ? 2 : 1;
@@ -1207,7 +1207,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
                 pl->lds_bytes, d->k, d->W);
     p.rw_shift = 0;
     while ((1 << p.rw_shift) < p.XW && p.rw_shift < 6) ++p.rw_shift;
-    p.dbg = getenv("CNN_AMD_DBG") ? atoi(getenv("CNN_AMD_DBG")) : 0;
+    p.dbg = CNN_OPT_INT("DBG", 0);
     p.ntiles = (int)((p.N + pl->NPIX - 1) / pl->NPIX);
     pl->grid_x = (unsigned)p.ntiles;
     pl->grid_y = (unsigned)((p.M + pl->MT - 1) / pl->MT);
@@ -1229,7 +1229,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
             p.cls_mask[cls] = mk;
         }
     }
-    if (pl->xm == 2 && p.ncls > 0 && pl->CK >= 8 && !getenv("CNN_AMD_NO_TAPSKIP")) pl->xm = 3;  // (with 2 k-steps per tap the branches cost more than the skipped MFMAs)
+    if (pl->xm == 2 && p.ncls > 0 && pl->CK >= 8 && !CNN_OPT_SET("NO_TAPSKIP")) pl->xm = 3;  // (with 2 k-steps per tap the branches cost more than the skipped MFMAs)
     if (pl->xm != 3) p.ncls = 0;
     q.Co = d->Co; q.Ci = d->Ci; q.k = d->k; q.s = d->s; q.pad = d->pad; q.mode = mode;
     q.C = p.C; q.M = p.M; q.TR = p.TR; q.TC = p.TC; q.r0 = p.r0; q.c0 = p.c0;
@@ -1482,9 +1482,9 @@ static int conv2d_backward_data_impl(const char* who, const cnn_conv2d_desc* d, 
 
 int cnn_conv2d_autotune(const cnn_conv2d_desc* d, void* stream) {
     if (int rc = check_desc("cnn_conv2d_autotune", d)) return rc;
-    if (const char* e = getenv("CNN_AMD_IGEMM_AUTOTUNE"))
+    if (const OptVal e = CNN_OPT_VAL("IGEMM_AUTOTUNE"))
         if (atoi(e) == 0) return CNN_AMD_OK;
-    if (getenv("CNN_AMD_IGEMM_CFG")) return CNN_AMD_OK;
+    if (CNN_OPT_SET("IGEMM_CFG")) return CNN_AMD_OK;
     hipStream_t s = as_stream(stream);
     for (int mode = 0; mode < 2; ++mode) {
         // geometries that never reach the implicit GEMM in this mode

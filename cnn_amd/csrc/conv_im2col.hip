@@ -210,6 +210,7 @@ int cnn_conv2d_forward_im2col(const cnn_conv2d_desc* d, const float* x, const fl
                                        y + (size_t)b0 * g.Co * g.P, (long long)g.Co * g.P, g.Co, g.P, g.K, bias);
         CNN_LAUNCH_CHECK();
     }
+    publish_mark_stale(s);  // (plain <<<>>> launches: not tracked by CNN_KLAUNCH)
     return CNN_AMD_OK;
 }
 
@@ -240,6 +241,7 @@ int cnn_conv2d_backward_weight_im2col(const cnn_conv2d_desc* d, const float* x, 
         bias_grad_ref<<<g.Co, 256, 0, s>>>(dy, gb, g.B, g.Co, g.P, divisor);
         CNN_LAUNCH_CHECK();
     }
+    publish_mark_stale(s);  // (plain <<<>>> launches: not tracked by CNN_KLAUNCH)
     return CNN_AMD_OK;
 }
 
@@ -261,6 +263,7 @@ int cnn_conv2d_backward_data_im2col(const cnn_conv2d_desc* d, const float* dy, c
         col2im_kernel<<<grid1d((long long)nb * g.Ci * g.H * g.W), 256, 0, s>>>(c.col, dx, g, b0, nb);
         CNN_LAUNCH_CHECK();
     }
+    publish_mark_stale(s);  // (plain <<<>>> launches: not tracked by CNN_KLAUNCH)
     return CNN_AMD_OK;
 }
 

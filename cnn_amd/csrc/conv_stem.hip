@@ -275,7 +275,7 @@ namespace cnn_amd {
 
 bool stem_fwd_supported(const cnn_conv2d_desc* d) {
     if (d->Ci != SCI || d->k != SK || d->s != SS || d->pad != SPAD || d->W % 4 != 0 || d->Co < 1) return false;
-    const char* e = getenv("CNN_AMD_STEM_FWD");
+    const OptVal e = CNN_OPT_VAL("STEM_FWD");
     return !(e && atoi(e) == 0);
 }
 
@@ -291,7 +291,7 @@ int stem_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const
     const long long items = (long long)p.B * p.row_groups * p.col_blocks;
     CNN_REQUIRE(items < (1ll << 31) && (long long)p.B * p.Co * p.Ho * p.Wo < (1ll << 31), "stem_forward: tensor too large for 32-bit offsets");
     p.items = (int)items;
-    p.dbg = getenv("CNN_AMD_STEM_DBG") ? atoi(getenv("CNN_AMD_STEM_DBG")) : 0;
+    p.dbg = CNN_OPT_INT("STEM_DBG", 0);
     const size_t lds_bytes = ((size_t)(SKK + 1) * SAP + (size_t)SCI * SRIN * SLW) * sizeof(float);
     static DeviceOnce attr_once[2];
     const int which = y_relu ? 1 : 0;
@@ -304,10 +304,10 @@ int stem_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const
     }
     const int co_blocks = (d->Co + 63) / 64;
     // two workgroups per CU; every workgroup gets the same number of items where that is possible
-    long long gx = 2ll * kNumCU / co_blocks;
+    long long gx = 2ll * num_cus() / co_blocks;
     if (gx < 1) gx = 1;
     if (gx > items) gx = items;
-    if (const char* e = getenv("CNN_AMD_STEM_GRID")) gx = atoi(e) > 0 ? atoi(e) : gx;  // (tuning)
+    if (const OptVal e = CNN_OPT_VAL("STEM_GRID")) gx = atoi(e) > 0 ? atoi(e) : gx;  // (tuning)
     const dim3 grid((unsigned)gx, (unsigned)co_blocks);
     if (y_relu)
         CNN_KLAUNCH(s, "conv_stem_fwd<3,7,2,3>+relu", (conv_stem_fwd_kernel<true><<<grid, SWAVES * 64, lds_bytes, s>>>(p)), CONV_TAG(d));
@@ -319,13 +319,13 @@ int stem_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const
 // ---- weight gradient: slabs of [Co][148] floats ([147 filter sums | 1 bias sum] per output channel), one per workgroup column
 int stem_wgrad_slots(const cnn_conv2d_desc* d) {
     if (d->Ci != SCI || d->k != SK || d->s != SS || d->pad != SPAD || d->W % 8 != 0 || d->Co < 1) return 0;
-    const char* e = getenv("CNN_AMD_STEM_WGRAD");
+    const OptVal e = CNN_OPT_VAL("STEM_WGRAD");
     if (e && atoi(e) == 0) return 0;
     const int Ho = cnn_conv2d_out_dim(d->H, SK, SS, SPAD), Wo = cnn_conv2d_out_dim(d->W, SK, SS, SPAD);
     const long long items = (long long)d->B * Ho * ((Wo + SCOLS - 1) / SCOLS);
     if (items >= (1ll << 31)) return 0;
     const int co_blocks = (d->Co + 63) / 64;
-    long long gx = 2ll * kNumCU / co_blocks;  // two workgroups per CU
+    long long gx = 2ll * num_cus() / co_blocks;  // two workgroups per CU
     if (gx < 1) gx = 1;
     if (gx > items) gx = items;
     return (int)gx;

@@ -372,9 +372,13 @@ struct PendingReduces {
     int count = 0;
     bool defer = false;
 };
+// one list per (host thread, device): the recorded jobs belong to that device's side stream (conv_backward.hip keeps one side
+// stream per thread and device), so a thread that alternates between devices never flushes device A's pointers on device B
 PendingReduces& pending_reduces() {
-    static thread_local PendingReduces p;
-    return p;
+    static thread_local PendingReduces p[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return p[dev % 16];
 }
 
 __global__ __launch_bounds__(kRedElems * kRedLanes) void slab_reduce_batch(const RedBatch rb) {
@@ -462,7 +466,7 @@ int flush_reduces(hipStream_t s) {
     PendingReduces& p = pending_reduces();
     if (p.count == 0) return CNN_AMD_OK;
     unsigned most = 0;
-    bool v4 = !(getenv("CNN_AMD_REDUCE_SCALAR") && atoi(getenv("CNN_AMD_REDUCE_SCALAR")) != 0);
+    bool v4 = !((CNN_OPT_SET("REDUCE_SCALAR") && CNN_OPT_INT("REDUCE_SCALAR", 0) != 0));
     for (int i = 0; i < p.count; ++i) {
         most = p.batch.job[i].n > most ? p.batch.job[i].n : most;
         if (p.batch.job[i].n % 4 != 0 || reinterpret_cast<uintptr_t>(p.batch.job[i].in) % 16 != 0) v4 = false;
@@ -562,7 +566,7 @@ int make_wplan(const char* who, const cnn_conv2d_desc* d, WPlan* pl) {
     else if (p.Co > 32) { pl->cfg = W_64x320; pl->MF = 32; pl->MTB = 64; pl->NTB = 320; pl->WK = 1; pl->threads = 256; }
     else if (p.Co > 16) { pl->cfg = W_32x160; pl->MF = 32; pl->MTB = 32; pl->NTB = 160; pl->WK = 4; pl->threads = 256; }
     else { pl->cfg = W_16x32; pl->MF = 16; pl->MTB = 16; pl->NTB = 32; pl->WK = 4; pl->threads = 256; }
-    if (const char* ov = getenv("CNN_AMD_WGRAD_CFG")) {  // tuning override
+    if (const OptVal ov = CNN_OPT_VAL("WGRAD_CFG")) {  // tuning override
         const int c = atoi(ov);
         if (c == W_64x64 && p.Co > 32) { pl->cfg = c; pl->MF = 32; pl->MTB = 64; pl->NTB = 64; pl->WK = 1; }
         if (c == W_64x128 && p.Co > 32) { pl->cfg = c; pl->MF = 32; pl->MTB = 64; pl->NTB = 128; pl->WK = 1; }
@@ -576,9 +580,9 @@ int make_wplan(const char* who, const cnn_conv2d_desc* d, WPlan* pl) {
     // wave specialisation pays when the MFMA phase is long enough to hide a chunk's staging (the 128-channel tile)
     // (measured on MI355X: no gain -- with half the waves loading, the latency-bound staging takes twice as long -- so the
     //  variant stays opt-in for experiments: CNN_AMD_WGRAD_PC=1)
-    pl->pc = getenv("CNN_AMD_WGRAD_PC") ? atoi(getenv("CNN_AMD_WGRAD_PC")) : 0;
+    pl->pc = CNN_OPT_INT("WGRAD_PC", 0);
     const int nbuf = pl->pc ? 2 : 1;
-    const size_t lds_budget = getenv("CNN_AMD_WGRAD_LDS") ? (size_t)atoi(getenv("CNN_AMD_WGRAD_LDS")) * 1024
+    const size_t lds_budget = CNN_OPT_SET("WGRAD_LDS") ? (size_t)CNN_OPT_INT("WGRAD_LDS", 0) * 1024
                                                           : (pl->pc ? 150 * 1024 : kLdsBudget);
     const int kk2 = d->k * d->k;
     p.CIB = (pl->NTB + kk2 - 2) / kk2 + 1;
@@ -614,14 +618,14 @@ int make_wplan(const char* who, const cnn_conv2d_desc* d, WPlan* pl) {
     while ((1 << p.rwd_shift) < p.QCP && p.rwd_shift < 6) ++p.rwd_shift;
     p.rwx_shift = 0;
     while ((1 << p.rwx_shift) < p.LWc && p.rwx_shift < 6) ++p.rwx_shift;
-    p.dbg = getenv("CNN_AMD_DBG") ? atoi(getenv("CNN_AMD_DBG")) : 0;
+    p.dbg = CNN_OPT_INT("DBG", 0);
     p.chunks_total = (long long)p.B * p.nrc * p.ncc;
     pl->gy = (unsigned)((p.Ntot + pl->NTB - 1) / pl->NTB);
     pl->gz = (unsigned)((p.Co + pl->MTB - 1) / pl->MTB);
     int bpc = (int)((160 * 1024) / pl->lds_bytes);
     if (bpc < 1) bpc = 1;
     if (bpc > 8) bpc = 8;
-    long long want = (long long)kNumCU * bpc / ((long long)pl->gy * pl->gz);
+    long long want = (long long)num_cus() * bpc / ((long long)pl->gy * pl->gz);
     if (want < 1) want = 1;
     if (want > p.chunks_total) want = p.chunks_total;
     p.chunks_per_split = (int)((p.chunks_total + want - 1) / want);
@@ -659,7 +663,7 @@ int launch_w2(const WPlan& pl, hipStream_t s, const cnn_conv2d_desc* d, int* nsp
         occ_lds = pl.lds_bytes;
     }
     WgradParams q = pl.p;
-    long long want = (long long)occ * kNumCU / ((long long)pl.gy * pl.gz);
+    long long want = (long long)occ * num_cus() / ((long long)pl.gy * pl.gz);
     if (want < 1) want = 1;
     if (want > pl.nsplit) want = pl.nsplit;
     if (want > q.chunks_total) want = q.chunks_total;
@@ -688,12 +692,12 @@ int launch_w(const WPlan& pl, hipStream_t s, const cnn_conv2d_desc* d, int* nspl
 // 16-byte loads per window triple from 32 different channel planes per wave), and that is the variant the train step uses;
 // both variants switch together so that the fused and unfused paths keep identical summation orders.
 bool first_layer_rd() {
-    const char* e = getenv("CNN_AMD_WG_POOL_RD");
+    const OptVal e = CNN_OPT_VAL("WG_POOL_RD");
     return e && atoi(e) != 0;
 }
 bool rd_wanted(const cnn_conv2d_desc* d) {
     if (direct_wgrad_slots(d) > 0 && !first_layer_rd()) return false;
-    const char* e = getenv("CNN_AMD_WGRAD_RD");
+    const OptVal e = CNN_OPT_VAL("WGRAD_RD");
     if (e && atoi(e) == 0) return false;
     return wgrad_rd_slots(d) > 0;
 }
@@ -713,7 +717,7 @@ int check_desc(const char* who, const cnn_conv2d_desc* d) {
 namespace cnn_amd {
 // conv_backward.hip: record (true) / launch immediately (false) the final slab reductions of this thread's weight gradients
 void wgrad_defer_reduce(bool on) {
-    static const bool off = getenv("CNN_AMD_NO_DEFER_REDUCE") && atoi(getenv("CNN_AMD_NO_DEFER_REDUCE")) != 0;
+    const bool off = (CNN_OPT_SET("NO_DEFER_REDUCE") && CNN_OPT_INT("NO_DEFER_REDUCE", 0) != 0);
     pending_reduces().defer = on && !off;
 }
 int wgrad_flush_reduces(hipStream_t s) { return flush_reduces(s); }

@@ -178,9 +178,9 @@ struct OsShape {
 constexpr OsShape kShapes[] = {{16, 32, 55, 55, 512}, {32, 64, 27, 27, 128}, {64, 128, 13, 13, 32}};
 
 const OsShape* find_shape(const cnn_conv2d_desc* d) {
-    static const bool off = getenv("CNN_AMD_WGRAD_OS") && atoi(getenv("CNN_AMD_WGRAD_OS")) == 0;
+    const bool off = (CNN_OPT_SET("WGRAD_OS") && CNN_OPT_INT("WGRAD_OS", 0) == 0);
     if (off || d->k != 3 || d->s != 2 || d->pad != 0 || d->B < 1) return nullptr;
-    static const int mask = getenv("CNN_AMD_WGRAD_OS_MASK") ? atoi(getenv("CNN_AMD_WGRAD_OS_MASK")) : 5;  // bit l = conv_layer_{l+2}; conv_layer_3 (33.7 vs 32.7 us alone) stays on the register-direct kernel: in the step 5 measured >= 7 > 3 ~ 0
+    const int mask = CNN_OPT_INT("WGRAD_OS_MASK", 5);  // bit l = conv_layer_{l+2}; conv_layer_3 (33.7 vs 32.7 us alone) stays on the register-direct kernel: in the step 5 measured >= 7 > 3 ~ 0
     int bit = 1;
     for (const OsShape& s : kShapes) {
         if ((mask & bit) && d->Ci == s.Ci && d->Co == s.Co && d->H == s.H && d->W == s.W) return &s;
@@ -195,7 +195,7 @@ int launch_os(const cnn_conv2d_desc* d, const float* x, const float* dy, float* 
     OsParams p;
     p.x = x; p.dy = dy; p.slabs = slabs; p.B = d->B;
     p.units = d->B * G::UPI;
-    p.dbg = getenv("CNN_AMD_OS_DBG") ? atoi(getenv("CNN_AMD_OS_DBG")) : 0;
+    p.dbg = CNN_OPT_INT("OS_DBG", 0);
     static DeviceOnce attr_once;
     if (attr_once.needed()) {
         CNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_os_kernel<CI, CO, H, W, R>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -217,7 +217,7 @@ int os_wgrad_slots(const cnn_conv2d_desc* d) {
     const OsShape* sh = find_shape(d);
     if (!sh) return 0;
     int slots = sh->slots;
-    if (const char* e = getenv("CNN_AMD_OS_SLABS")) {
+    if (const OptVal e = CNN_OPT_VAL("OS_SLABS")) {
         const int v = atoi(e);
         if (v > 0) slots = v;
     }

@@ -470,7 +470,7 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
     // flattened runs (see RdParams::flat): worth it when the rows do not divide into whole runs of 16
     p.flat = 0;
     p.m_w = magic_of(d->W);
-    if (!pooled && d->s == 1 && d->pad == 1 && d->W >= 16 && d->W % 16 != 0 && (long long)d->H * d->W < 65536 && !getenv("CNN_AMD_RD_NOFLAT")) {
+    if (!pooled && d->s == 1 && d->pad == 1 && d->W >= 16 && d->W % 16 != 0 && (long long)d->H * d->W < 65536 && !CNN_OPT_SET("RD_NOFLAT")) {
         p.flat = 1;
         p.Wo = d->H * d->W;  // one "row" per image
         p.Ho = 1;
@@ -495,15 +495,15 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
     for (int c = nt_max; !nt && c >= 3; --c)
         if (tiles % c == 0) nt = c;
     if (!nt) nt = 5;
-    if (const char* e = getenv("CNN_AMD_RD_NT")) {
+    if (const OptVal e = CNN_OPT_VAL("RD_NT")) {
         const int v = atoi(e);
         if (v >= 1 && v <= nt_max) nt = v;
     }
     pl->nt = nt;
     pl->ngroups = (tiles + nt - 1) / nt;
     pl->mtiles = (p.Co + 31) / 32;
-    const int env = getenv("CNN_AMD_RD_BLOCKS") ? atoi(getenv("CNN_AMD_RD_BLOCKS")) : 0;
-    const long long colblocks = (long long)pl->ngroups * pl->mtiles, slots = env > 0 ? env : 2 * kNumCU;
+    const int env = CNN_OPT_INT("RD_BLOCKS", 0);
+    const long long colblocks = (long long)pl->ngroups * pl->mtiles, slots = env > 0 ? env : 2 * num_cus();
     long long want = slots / colblocks;
     if (want < 1) want = 1;
     if (env <= 0 && colblocks * want * 8 < slots * 7) {
@@ -540,8 +540,8 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
             --r_unsafe;
         }
     }
-    p.dbg = getenv("CNN_AMD_RD_DBG") ? atoi(getenv("CNN_AMD_RD_DBG")) : 0;
-    p.chunks_fast = getenv("CNN_AMD_RD_SLOW") ? 0 : (int)(r_unsafe / 2);  // (CNN_AMD_RD_SLOW: tests force the guarded path)
+    p.dbg = CNN_OPT_INT("RD_DBG", 0);
+    p.chunks_fast = CNN_OPT_SET("RD_SLOW") ? 0 : (int)(r_unsafe / 2);  // (CNN_AMD_RD_SLOW: tests force the guarded path)
     // padded layers: the first run of output rows 0 and 1 of image 0 reads input row 0 from column -1 (or -2): x[-1] lies in
     // front of the allocation, so the chunks up to run `rpr` (first run of row 1) take the guarded path
     p.chunks_head = d->pad > 0 ? (p.flat ? ((d->W + 1) / pl->rl + 2) / 2 + 1 : p.rpr / 2 + 1) : 0;

@@ -589,7 +589,7 @@ namespace cnn_amd {
 namespace {
 bool make_win_params(const cnn_conv2d_desc* d, WinParams* p, int* grid) {
     if (d->Ci != 3 || d->Co != 16 || d->k != 3 || d->s != 2 || d->pad != 0) return false;
-    const char* e = getenv("CNN_AMD_WG_WIN");
+    const OptVal e = CNN_OPT_VAL("WG_WIN");
     if (e && atoi(e) == 0) return false;
     p->B = d->B; p->H = d->H; p->W = d->W;
     p->Ho = cnn_conv2d_out_dim(d->H, 3, 2, 0);
@@ -605,18 +605,18 @@ bool make_win_params(const cnn_conv2d_desc* d, WinParams* p, int* grid) {
     p->strips_total = (int)strips;
     // one workgroup (8 waves, 135 KB of LDS) per CU
     long long g = (strips + kWaves - 1) / kWaves;
-    if (g > kNumCU) g = kNumCU;
+    if (g > num_cus()) g = num_cus();
     *grid = (int)g;
     p->strips_per_wave = (int)((strips + g * kWaves - 1) / (g * kWaves));
-    p->dbg = getenv("CNN_AMD_WIN_DBG") ? atoi(getenv("CNN_AMD_WIN_DBG")) : 0;
+    p->dbg = CNN_OPT_INT("WIN_DBG", 0);
     {
         // default on: the eight waves of a workgroup walk eight neighbouring column-segment runs; in step they share the delta rows'
         // 128-byte lines in L2 (PMC: 1.37x -> 1.02x of the algorithmic fetch).  Needs the same trip count in every wave.
-        const char* e = getenv("CNN_AMD_WIN_LOCKSTEP");
+        const OptVal e = CNN_OPT_VAL("WIN_LOCKSTEP");
         p->lockstep = ((!e || atoi(e) != 0) && strips == (long long)g * kWaves * p->strips_per_wave) ? (e ? atoi(e) : 1) : 0;
-        const char* sp = getenv("CNN_AMD_WIN_SPEC");
+        const OptVal sp = CNN_OPT_VAL("WIN_SPEC");
         p->spec = ((!sp || atoi(sp) != 0) && strips == (long long)g * kWaves * p->strips_per_wave && p->dbg < 2) ? 1 : 0;
-        p->spec_slack = getenv("CNN_AMD_WIN_SLACK") ? atoi(getenv("CNN_AMD_WIN_SLACK")) : 0;
+        p->spec_slack = CNN_OPT_INT("WIN_SLACK", 0);
     }
     return true;
 }

@@ -331,7 +331,7 @@ int cnn_linear_forward_softmax_xent(const float* x, const float* w, const float*
     CNN_REQUIRE(B > 0 && in > 0 && out > 0 && out <= kOutTile, "cnn_linear_forward_softmax_xent: B=%d in=%d out=%d (out <= %d)", B, in, out,
                 kOutTile);
     hipStream_t s = as_stream(stream);
-    const char* e = getenv("CNN_AMD_NO_HEAD_BATCH");  // A/B switch: the plain 6-deep loop for every layer width
+    const OptVal e = CNN_OPT_VAL("NO_HEAD_BATCH");  // A/B switch: the plain 6-deep loop for every layer width
     if (e && atoi(e) != 0)
         CNN_KLAUNCH(s, "linear_fwd+softmax_xent",
                     (linear_fwd_softmax_xent<false><<<B, kBlock, 0, s>>>(x, w, bias, labels, logits, probs, delta, loss_terms, in, out)),

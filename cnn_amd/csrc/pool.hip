@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void maxpool_bwd_k2s2_packed(const float* _
 
 // lanes per row of the packed kernels: the smallest power of two >= Wo; 0 = rows are wide enough for one wavefront each
 inline int packed_shift(int Wo, long long units) {
-    static const bool off = getenv("CNN_AMD_POOL_NO_PACK") != nullptr;  // (A/B switch)
+    const bool off = CNN_OPT_SET("POOL_NO_PACK");  // (A/B switch)
     if (off || Wo > 32 || units >= (1ll << 31) - 64) return -1;
     int sh = 0;
     while ((1 << sh) < Wo) ++sh;
@@ -242,7 +242,7 @@ inline int packed_shift(int Wo, long long units) {
 
 inline unsigned row_grid(long long rows) {
     long long need = (rows + kWavesPerBlock - 1) / kWavesPerBlock;
-    long long cap = (long long)kNumCU * 16;
+    long long cap = (long long)num_cus() * 16;
     return (unsigned)(need < 1 ? 1 : (need > cap ? cap : need));
 }
 

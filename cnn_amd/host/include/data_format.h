@@ -63,6 +63,13 @@ public:
     bool on_device() const { return dev != nullptr; }
     void sync_to_host();          // D2H of the view into `data` (allocated on first use); blocks until done
     void sync_to_device() const;  // H2D of `data` into the view; enqueued on architectures::stream
+    // A device view's host copy is only as fresh as the last D2H.  Every Layer::forward / backward call (anything that enqueues
+    // device work through the host classes) bumps a global epoch; the host-side readers below (max / argmax / print / div / ...,
+    // and func.h's softmax) copy back again when the view's copy is older than that -- so reading a layer's output after the
+    // NEXT pass returns that pass' values, like the reference's plain host tensors do.
+    static void device_work_enqueued();
+    void mark_host_fresh() const; // the caller just filled `data` with the view's current contents itself
+    void refresh_host() const;    // = sync_to_host() when the host copy is stale (or missing); no-op for a plain host tensor
 
 private:
     struct ViewTag {};
@@ -70,6 +77,7 @@ private:
     // the host-side helpers below read `data`: a device view that has not been copied back yet is synced first (a Layer's
     // output tensors are such views: softmax() on them, max(), print() ... just work)
     void ensure_host() const;
+    mutable unsigned long long host_epoch = 0;  // epoch of the last D2H (0 = never)
 };
 using tensor = std::shared_ptr<Tensor3D>;
 

@@ -160,6 +160,7 @@ void Conv2D::ensure_workspace(int B, int H, int W) {
 }
 
 std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
+    Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
     const int B = (int)input.size();
     const int H = input[0]->H, W = input[0]->W;
     const int out_H = cnn_conv2d_out_dim(H, kernel_size, stride, padding);
@@ -228,6 +229,7 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
 }
 
 std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
+    Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
     const int B = (int)delta.size();
     assert(saved_input != nullptr && "backward without a recorded forward (no_grad?)");
     const data_type* dy = batch_device_pointer(delta, delta_stage, name + "_dy");
@@ -320,6 +322,7 @@ void MaxPool2D::fused_forward_target(int B, int C, int H, int W, bool record, da
 }
 
 std::vector<tensor> MaxPool2D::forward(const std::vector<tensor>& input) {
+    Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
     if (forward_done) {  // written by the producing convolution's kernel in this pass
         forward_done = false;
         return output;
@@ -348,6 +351,7 @@ std::vector<tensor> MaxPool2D::forward(const std::vector<tensor>& input) {
 }
 
 std::vector<tensor> MaxPool2D::backward(std::vector<tensor>& delta) {
+    Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
     if (backward_passthrough) {  // the producing Conv2D's backward kernels consume the pooled-domain delta directly
         backward_passthrough = false;
         if (fused_relu_below != nullptr) fused_relu_below->fused_backward_done();
@@ -385,6 +389,7 @@ void ReLU::fused_forward_skipped(int B, int C, int H, int W) {
 }
 
 std::vector<tensor> ReLU::forward(const std::vector<tensor>& input) {
+    Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
     const int B = (int)input.size();
     if (forward_done) {  // written by the producing convolution's kernel in this pass
         forward_done = false;
@@ -406,6 +411,7 @@ std::vector<tensor> ReLU::forward(const std::vector<tensor>& input) {
 
 // relu.cpp:30-44: masks the caller's delta IN PLACE and hands the same tensors back
 std::vector<tensor> ReLU::backward(std::vector<tensor>& delta) {
+    Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
     const int B = (int)delta.size();
     if (backward_done) {  // masked by the pool's backward kernel in this pass
         backward_done = false;
@@ -471,6 +477,7 @@ void BatchNorm2D::bind_arena(data_type* params_dev, data_type* grads_dev) {
 }
 
 std::vector<tensor> BatchNorm2D::forward(const std::vector<tensor>& input) {
+    Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
     const int B = (int)input.size();
     const int H = input[0]->H, W = input[0]->W;
     assert(input[0]->C == out_channels);
@@ -538,6 +545,7 @@ std::vector<tensor> BatchNorm2D::forward(const std::vector<tensor>& input) {
 // batchnorm2d.cpp:98-158: gamma / beta gradients (sums over the batch, not averaged) and the data gradient written
 // IN PLACE into the caller's delta, which is handed back
 std::vector<tensor> BatchNorm2D::backward(std::vector<tensor>& delta) {
+    Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
     const int B = (int)delta.size();
     assert(saved_input != nullptr && "backward without a recorded forward (no_grad?)");
     const int C = out_channels;
@@ -596,6 +604,7 @@ void BatchNorm2D::load_weights(std::ifstream& reader) {
 // ---------------------------------------------------------------------------------------------------------------
 // Dropout (dropout.cpp)
 std::vector<tensor> Dropout::forward(const std::vector<tensor>& input) {
+    Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
     const int B = (int)input.size();
     const int C = input[0]->C, H = input[0]->H, W = input[0]->W;
     if (sequence.empty()) {  // dropout.cpp:13-23
@@ -619,6 +628,7 @@ std::vector<tensor> Dropout::forward(const std::vector<tensor>& input) {
 
 // dropout.cpp:57-69: in place on the caller's delta
 std::vector<tensor> Dropout::backward(std::vector<tensor>& delta) {
+    Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
     const int B = (int)delta.size();
     const bool in_place = delta[0]->on_device();
     data_type* d = batch_device_pointer_mut(delta, delta_stage, name + "_dy");
@@ -675,6 +685,7 @@ void LinearLayer::bind_arena(data_type* params_dev, data_type* grads_dev) {
 }
 
 std::vector<tensor> LinearLayer::forward(const std::vector<tensor>& input) {
+    Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
     const int B = (int)input.size();
     delta_shape = input[0]->get_shape();  // linear.cpp:25
     assert(input[0]->get_length() == in_channels);
@@ -700,12 +711,14 @@ std::vector<tensor> LinearLayer::forward(const std::vector<tensor>& input) {
     for (int b = 0; b < B; ++b) {
         if (!output[b]->data) output[b]->data = new data_type[out_channels];
         std::memcpy(output[b]->data, host.data() + (size_t)b * out_channels, sizeof(data_type) * out_channels);
+        output[b]->mark_host_fresh();
     }
     return output;
 }
 
 std::vector<tensor> LinearLayer::forward_loss_head(const std::vector<tensor>& input, const int* labels_dev, data_type* probs_dev,
                                                    data_type* delta_dev, data_type* loss_terms_dev) {
+    Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
     const int B = (int)input.size();
     delta_shape = input[0]->get_shape();
     assert(input[0]->get_length() == in_channels && loss_head_supported());
@@ -725,6 +738,7 @@ std::vector<tensor> LinearLayer::forward_loss_head(const std::vector<tensor>& in
 }
 
 std::vector<tensor> LinearLayer::backward(std::vector<tensor>& delta) {
+    Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
     const int B = (int)delta.size();
     assert(saved_input != nullptr && "backward without a recorded forward (no_grad?)");
     const data_type* dy = batch_device_pointer(delta, delta_stage, name + "_dy");

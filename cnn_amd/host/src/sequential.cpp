@@ -143,7 +143,7 @@ void Sequential::prepare_filters() {
     // kernels, and the second convolution's forward call waits for it (Conv2D::wait_before_forward).
     size_t later_params = 0;
     for (size_t i = 1; i < convs.size(); ++i) later_params += convs[i]->param_count();
-    static const bool no_async = std::getenv("CNN_AMD_SYNC_PREPARE") != nullptr;  // (A/B switch)
+    const bool no_async = cnn_amd_get_option("SYNC_PREPARE", nullptr, 0) == 0;  // (A/B switch, read through the library's option table)
     const bool async = !no_async && convs.size() >= 2 && later_params >= (size_t)1 << 20;
     void* side = nullptr;
     if (async) {
@@ -201,7 +201,7 @@ void Sequential::flush_bucket(size_t lo, size_t hi) {
 
 void Sequential::backward(std::vector<tensor>& delta_start) {
     if (print_info) delta_start[0]->print_shape();
-    static const bool force_buckets = std::getenv("CNN_AMD_DP_FORCE_BUCKETS") != nullptr;  // (tests: exercise the path with one rank)
+    const bool force_buckets = cnn_amd_get_option("DP_FORCE_BUCKETS", nullptr, 0) == 0;  // (tests: exercise the path with one rank)
     const bool bucketed = finalized && comm != nullptr && (comm_world > 1 || force_buckets) && n_params >= 2 * bucket_floats;
     size_t pending_hi = n_params, idx = layers_sequence.size();
     for (auto layer = layers_sequence.rbegin(); layer != layers_sequence.rend(); ++layer) {

@@ -39,9 +39,15 @@ Tensor3D::~Tensor3D() noexcept {
     data = nullptr;
 }
 
+namespace {
+unsigned long long g_device_epoch = 1;  // (the host classes are single-threaded by construction, like the reference: SURVEY 8b)
+}
+void Tensor3D::device_work_enqueued() { ++g_device_epoch; }
+
 void Tensor3D::sync_to_host() {
     if (!dev) return;
     if (!data) data = new data_type[(size_t)get_length()];
+    host_epoch = g_device_epoch;
     must(cnn_memcpy_d2h(data, dev, sizeof(data_type) * (size_t)get_length(), architectures::stream), "cnn_memcpy_d2h");
     must(cnn_stream_synchronize(architectures::stream), "cnn_stream_synchronize");
 }
@@ -77,8 +83,10 @@ std::vector<uchar> Tensor3D::opecv_mat(const int CH) const {
 }
 
 void Tensor3D::ensure_host() const {
-    if (dev != nullptr && data == nullptr) const_cast<Tensor3D*>(this)->sync_to_host();
+    if (dev != nullptr && (data == nullptr || host_epoch != g_device_epoch)) const_cast<Tensor3D*>(this)->sync_to_host();
 }
+void Tensor3D::refresh_host() const { ensure_host(); }
+void Tensor3D::mark_host_fresh() const { host_epoch = g_device_epoch; }
 
 void Tensor3D::set_zero() {
     if (data) std::memset(data, 0, sizeof(data_type) * (size_t)get_length());

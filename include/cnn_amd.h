@@ -38,6 +38,13 @@ const char* cnn_amd_last_error(void);
 /* "gfx950" when a device is present and matches, otherwise an explanatory string; never throws */
 const char* cnn_amd_device_arch(void);
 
+/* ---- measurement switches: the A/B switches of DESIGN.md section 10 (kernel-family choices, tile overrides, debug ablations).
+ * The library reads the CNN_AMD_* variables of the environment ONCE, when it is first used; afterwards this is the only way to
+ * change one (value == NULL removes it).  `name` with or without the "CNN_AMD_" prefix.  Not needed for normal use: the defaults
+ * are the product path.  cnn_amd_get_option returns 0 and copies the value when the switch is set, 1 when it is not. */
+int cnn_amd_set_option(const char* name, const char* value);
+int cnn_amd_get_option(const char* name, char* value_out, size_t cap);
+
 /* ---- measurement: per-kernel durations from HIP events recorded on the launch stream --------------------- */
 /* mode 0 = off, 1 = time every kernel launch, 2 = only launches whose "<kernel>|<geometry>" key contains filter */
 int cnn_amd_kernel_timing_enable(int mode, const char* filter);

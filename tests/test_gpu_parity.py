@@ -144,7 +144,7 @@ RD_CASES = [
 
 @pytest.mark.parametrize("slow", [False, True], ids=["pipelined", "guarded"])
 @pytest.mark.parametrize("case", RD_CASES + [CONV_CASES[1], CONV_CASES[6], CONV_CASES[7]], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
-def test_conv2d_wgrad_register_direct(T, case, slow, monkeypatch):
+def test_conv2d_wgrad_register_direct(T, case, slow, lib_option):
     """conv_wgrad_rd.hip: the pipelined over-reading path and the guarded path agree with the oracle and, bit for bit,
     with each other (same MFMA order); the LDS-staged kernel (CNN_AMD_WGRAD_RD=0) is held to the same tolerance"""
     from cnn_amd import capi
@@ -154,15 +154,15 @@ def test_conv2d_wgrad_register_direct(T, case, slow, monkeypatch):
     conv = capi.Conv2d(*case)
     xd, dyd = dev(T, x), dev(T, dy)
     if slow:
-        monkeypatch.setenv("CNN_AMD_RD_SLOW", "1")
+        lib_option("RD_SLOW", "1")
     gw, gb = conv.backward_weight(xd, dyd, float(case[0]))
     assert_close(host(gw), gw_ref, REL_TOL, "weight grad")
     assert_close(host(gb), gb_ref, REL_TOL, "bias grad")
     if slow:
-        monkeypatch.delenv("CNN_AMD_RD_SLOW")
+        lib_option("RD_SLOW", None)
         gw2, gb2 = conv.backward_weight(xd, dyd, float(case[0]))
         assert np.array_equal(host(gw), host(gw2)) and np.array_equal(host(gb), host(gb2))
-        monkeypatch.setenv("CNN_AMD_WGRAD_RD", "0")
+        lib_option("WGRAD_RD", "0")
         gw3, gb3 = conv.backward_weight(xd, dyd, float(case[0]))
         assert_close(host(gw3), gw_ref, REL_TOL, "LDS-staged weight grad")
         assert_close(host(gb3), gb_ref, REL_TOL, "LDS-staged bias grad")
@@ -823,13 +823,13 @@ FWD_FAMILY_CASES = [
 
 @pytest.mark.parametrize("family", ["lds", "m16"])
 @pytest.mark.parametrize("case", FWD_FAMILY_CASES, ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
-def test_conv2d_forward_kernel_families(T, case, family, monkeypatch):
+def test_conv2d_forward_kernel_families(T, case, family, lib_option):
     """conv_fwd_rd.hip has two forward kernels (LDS filter slice + 32x32x2 tiles | filters in registers + 16x16x4 tiles,
     picked by layer size): each one forced on every shape, from the reference filter layout and from the prepared images,
     pre-activation and fused ReLU outputs, against the oracle"""
     from cnn_amd import capi
 
-    monkeypatch.setenv("CNN_AMD_FWD_M16", "1" if family == "m16" else "0")
+    lib_option("FWD_M16", "1" if family == "m16" else "0")
     x, w, b, dy = _conv_inputs(case, 740)
     y_ref = _oracle_conv(case, x, w, b, dy)[0]
     conv = capi.Conv2d(*case)
@@ -852,12 +852,12 @@ def test_conv2d_forward_kernel_families(T, case, family, monkeypatch):
 
 @pytest.mark.parametrize("case", [(2, 16, 13, 13, 32, 3, 2, 0), (3, 16, 28, 27, 64, 3, 2, 0), (1, 16, 111, 111, 32, 3, 2, 0),
                                   (2, 16, 9, 10, 128, 3, 2, 0), (2, 24, 12, 12, 32, 3, 2, 0), (3, 16, 12, 14, 32, 3, 2, 0), (5, 16, 5, 6, 32, 3, 2, 0)], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
-def test_conv2d_dgrad_register_direct_opt_in_tiles(T, case, monkeypatch):
+def test_conv2d_dgrad_register_direct_opt_in_tiles(T, case, lib_option):
     """conv_dgrad_rd.hip behind CNN_AMD_DGRAD_RD32=1: the Co = 32 instantiation and, for Ci = 16, the tile that packs two
     parity classes into one 32-row MFMA operand -- oracle parity plus bit-identity of the fused ReLU' epilogue"""
     from cnn_amd import capi
 
-    monkeypatch.setenv("CNN_AMD_DGRAD_RD32", "1")
+    lib_option("DGRAD_RD32", "1")
     x, w, b, dy = _conv_inputs(case, 730)
     _, _, _, dx_ref = _oracle_conv(case, x, w, b, dy)
     relu_below = np.maximum(x - 0.3, 0).astype(np.float32)

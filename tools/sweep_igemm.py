@@ -31,10 +31,7 @@ for (Ci, H, W, Co, k, s, pad) in conv_geometries(name):
     for op in ("fwd", "dgrad"):
         res = []
         for cfg in CFGS:
-            if cfg is None:
-                os.environ.pop("CNN_AMD_IGEMM_CFG", None)
-            else:
-                os.environ["CNN_AMD_IGEMM_CFG"] = str(cfg)
+            capi.set_option("IGEMM_CFG", None if cfg is None else str(cfg))
             try:
                 run = (lambda: conv.forward(x, w, b, y)) if op == "fwd" else (lambda: conv.backward_data(dy, w, dx))
                 run()
@@ -50,7 +47,7 @@ for (Ci, H, W, Co, k, s, pad) in conv_geometries(name):
                 if "prep" in key:
                     continue
                 res.append((ms / cnt, cfg, key.split("|")[0]))
-        os.environ.pop("CNN_AMD_IGEMM_CFG", None)
+        capi.set_option("IGEMM_CFG", None)
         res.sort(key=lambda r: r[0])
         dflt = [r for r in res if r[1] is None][0]
         print(f"{case} {op}: default {dflt[0] * 1e3:.0f} us {flops / dflt[0] / 1e9:.1f} TF {dflt[2]} | best: " +
