@@ -4,7 +4,10 @@
 A "step" = one iteration of cpu/src/cnn.cpp:79-90 on one batch of synthetic 224x224x3 fp32 images already resident
 in HBM: forward, softmax + cross-entropy, backward, [RCCL all-reduce of the flat gradient arena], SGD.
     python bench.py --gpus 1 --steps 20 --warmup 5                      # the reference net, BASELINE configs[1] (the metric's config)
-    python bench.py --config vgg11 | resnet18                           # configs[3] / [4]: through the C++ Layer API
+    python bench.py --config vgg11 | resnet18                           # configs[3] / [4] alone, with their own CPU legs
+`value` is measured through the boundary north_star names: the C++ Layer classes (architectures::Sequential::train_step,
+cnn_amd/host) with their DEFAULT settings; the default command adds the Python driver, the every-tensor-written variant, the
+north-star convolution and a few steps of configs[3] / [4] as extra keys.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 Prints ONE JSON line on rank 0 (contract in the task brief) with two extra objects:
@@ -210,7 +213,6 @@ def staged_input_bench(torch, capi, args):
     from cnn_amd import hostapi
 
     B = args.batch or 256
-    hostapi.load().cnnh_set_fuse_pool_block(1)
     net = hostapi.HostAlexNet(3)
     rs = np.random.RandomState(1234)
     net.set_params((rs.standard_normal(net.n_params) * 0.1).astype(np.float32))
@@ -233,7 +235,6 @@ def staged_input_bench(torch, capi, args):
     loss = net.last_loss()
     stager.close()
     net.close()
-    hostapi.load().cnnh_set_fuse_pool_block(0)
     return {"value": round(B * args.steps / el, 1), "unit": "images/sec", "ms_per_step": round(el / args.steps * 1e3, 4),
             "h2d_GBps": round(nbytes * args.steps / el / 1e9, 1), "final_loss": round(loss, 5),
             "note": "every batch uploaded from pinned host memory (cnn_batch_stager_*, 2 slots, copy stream overlapped with compute)"}
@@ -256,8 +257,8 @@ def init_comm(capi, torch, dist, world, rank):
 
 def make_runner(config, api, batch, torch, capi, world, rank, comm, pool_block=True):
     """-> dict(step, flush, loss, ...): one train step (cnn.cpp:79-90) of a BASELINE workload on a device-resident synthetic
-    batch.  api "pynet": Python driver -> C ABI (reference net only); api "layer": the C++ Layer API
-    (architectures::Sequential::train_step, cnn_amd/host) -> C ABI."""
+    batch.  api "layer" (default, what `value` is measured through): the C++ Layer API -- architectures::Sequential::train_step
+    (cnn_amd/host) -> C ABI -- with its default settings; api "pynet": the Python driver -> C ABI (reference net only)."""
     import numpy as np
 
     from cnn_amd import stacks
@@ -273,7 +274,7 @@ def make_runner(config, api, batch, torch, capi, world, rank, comm, pool_block=T
 
         # defer_input_grad: conv_layer_1's data gradient (no consumer) is launched one forward pass later on a second stream;
         # flush() launches a pending one, so the timed region contains exactly K of them (cnn_amd/pynet.py)
-        net = AlexNetHip(B, 3, defer_input_grad=True, fuse_pool=pool_block and not os.environ.get("CNN_AMD_NO_POOL_FUSION"))
+        net = AlexNetHip(B, 3, defer_input_grad=True, fuse_pool=pool_block)
         net.load_params((rs.standard_normal(net.n_params) * 0.1).astype(np.float32))
         handle = comm if world > 1 else None
         return dict(step=lambda: net.train_step(x, labels, lr, handle, world), flush=net.flush, B=B, n_params=net.n_params,
@@ -282,8 +283,7 @@ def make_runner(config, api, batch, torch, capi, world, rank, comm, pool_block=T
     from cnn_amd import hostapi
 
     lib = hostapi.load()
-    pool_block = pool_block and not os.environ.get("CNN_AMD_NO_POOL_FUSION")  # (A/B switch, like the Python driver above)
-    lib.cnnh_set_fuse_pool_block(1 if (pool_block and config == "alexnet") else 0)
+    lib.cnnh_set_fuse_pool_block(1 if pool_block else 0)  # (1 = the library's default)
     if config == "alexnet":
         net = hostapi.HostAlexNet(3)
         net.set_params((rs.standard_normal(net.n_params) * 0.1).astype(np.float32))
@@ -292,17 +292,70 @@ def make_runner(config, api, batch, torch, capi, world, rank, comm, pool_block=T
         net = hostapi.HostSequential(spec)
         net.set_params(stacks.he_init(net.layout, 1234))
     if world > 1:
-        net.set_comm(comm.handle, world)  # Sequential::update_gradients all-reduces the arena; BatchNorm2D layers run as sync-BN
+        net.set_comm(comm.handle, world)  # train_step exchanges the gradient arena (two buckets for the reference net); BatchNorm2D runs as sync-BN
 
     def close():
         net.close()
-        lib.cnnh_set_fuse_pool_block(0)
+        lib.cnnh_set_fuse_pool_block(1)
 
-    return dict(step=lambda: net.train_step(x, labels, lr), flush=lambda: None, B=B, n_params=net.n_params, loss=net.last_loss,
+    return dict(step=lambda: net.train_step(x, labels, lr), flush=net.flush, B=B, n_params=net.n_params, loss=net.last_loss,
                 keep=(net, x, labels), close=close,
-                api="C++ Layer API (architectures::Sequential::train_step, cnn_amd/host) -> C ABI"
-                    + ("; fuse_pool_block on (conv_layer_1 / relu_layer_1 outputs not materialised)" if (pool_block and config == "alexnet")
-                       else "; every Layer::get_output() valid"))
+                api="C++ Layer API (architectures::Sequential::train_step, cnn_amd/host) -> C ABI, default settings"
+                    + ("" if pool_block else " except architectures::fuse_pool_block = false (every tensor written by the pass itself)"))
+
+
+def measure(run, steps, warmup, sample_every, capi, barrier, time_mod=time):
+    """the measurement protocol of one workload: 3 plain + 3 instrumented steps (which kernel dominates?), `warmup` steps, then
+    exactly `steps` timed steps between two barriers with only the dominant kernel event-bracketed -> (elapsed_s, key, launches,
+    total_ms, table)"""
+    step = run["step"]
+    for _ in range(3):
+        step()
+    barrier()
+    capi.kernel_timing(1)
+    for _ in range(3):
+        step()
+    barrier()
+    table = capi.kernel_timing_report()
+    capi.kernel_timing(0)
+    dominant = max(table.items(), key=lambda kv: kv[1][1])[0]
+    for _ in range(warmup):
+        step()
+    capi.kernel_timing(2, dominant, every=sample_every)
+    barrier()
+    t0 = time_mod.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = time_mod.perf_counter() - t0
+    dom = capi.kernel_timing_report()
+    capi.kernel_timing(0)
+    cnt, ms = dom[dominant]
+    return elapsed, dominant, cnt, ms, table
+
+
+def stack_leg(config, torch, capi, steps=5, warmup=2):
+    """BASELINE configs[3] / [4] inside the default command: a few timed steps of the stack through the C++ Layer API (no CPU leg)"""
+    from cnn_amd import stacks
+
+    run = make_runner(config, "layer", None, torch, capi, 1, 0, None)
+
+    def barrier():
+        run["flush"]()
+        torch.cuda.synchronize()
+
+    elapsed, dominant, cnt, ms, _ = measure(run, steps, warmup, 1, capi, barrier)
+    B = run["B"]
+    flops_img = stacks.train_flops_per_image(stacks.STACKS[config]())
+    tf = flops_img * B * steps / elapsed / 1e12
+    out = {"workload": WORKLOADS[config], "value": round(B * steps / elapsed, 1), "unit": "images/sec", "per_gpu_batch": B, "steps": steps,
+           "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "step_tflops": round(tf, 2),
+           "step_frac_of_mfma_peak": round(tf / PEAK_MFMA_F32_TFLOPS, 4), "roofline": roofline_entry(dominant, cnt, ms),
+           "final_loss": round(run["loss"](), 5), "driver": run["api"]}
+    run["close"]()
+    del run
+    torch.cuda.empty_cache()
+    return out
 
 
 WORKLOADS = {
@@ -335,11 +388,14 @@ def main():
     ap.add_argument("--config", choices=["alexnet", "vgg11", "resnet18"], default="alexnet",
                     help="alexnet = BASELINE configs[1] (the metric's configuration), vgg11 = configs[3], resnet18 = configs[4]")
     ap.add_argument("--api", choices=["pynet", "layer"], default=None,
-                    help="pynet: Python driver -> C ABI (alexnet only, default there); layer: C++ Layer API -> C ABI")
+                    help="layer (default): C++ Layer API (architectures::Sequential::train_step) -> C ABI; pynet: Python driver -> C ABI "
+                         "(reference net only)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256 / 128 / 64 for alexnet / vgg11 / resnet18)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-ns", action="store_true")
-    ap.add_argument("--no-layer-api", action="store_true", help="skip the extra C++ Layer API legs of the default config")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the extra legs of the default config (unfused C++ path, Python driver)")
+    ap.add_argument("--no-stacks", action="store_true", help="skip the VGG-11 / ResNet-18-shaped legs of the default config")
+    ap.add_argument("--no-pool-fusion", action="store_true", help="architectures::fuse_pool_block = false for the main leg (A/B)")
     ap.add_argument("--staged-input", action="store_true",
                     help="also time the reference net with every batch coming from (pinned) HOST memory through cnn_batch_stager_* "
                          "-- the PCIe-inclusive rate, reported beside `value`, never as it")
@@ -350,7 +406,7 @@ def main():
         args.steps = 100 if small else 10
     if args.warmup is None:
         args.warmup = 20 if small else 3
-    api = args.api or ("pynet" if small else "layer")
+    api = args.api or "layer"
     if api == "pynet" and not small:
         raise SystemExit("--api pynet drives the reference net only; the stacks run through the C++ Layer API")
 
@@ -375,8 +431,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # plumbing: rendezvous, barrier, max-over-ranks
         comm, comm_info = init_comm(capi, torch, dist, world, rank)             # the data path's exchange: C ABI -> RCCL
 
-    run = make_runner(args.config, api, args.batch, torch, capi, world, rank, comm)
-    B, step = run["B"], run["step"]
+    run = make_runner(args.config, api, args.batch, torch, capi, world, rank, comm, pool_block=not args.no_pool_fusion)
+    B = run["B"]
 
     def barrier():
         run["flush"]()
@@ -384,32 +440,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # --- untimed: three instrumented steps (after three plain ones) to find the dominant kernel, then the warm-up ---
-    for _ in range(3):
-        step()
-    barrier()
-    capi.kernel_timing(1)
-    for _ in range(3):
-        step()
-    barrier()
-    table = capi.kernel_timing_report()
-    capi.kernel_timing(0)
-    dominant = max(table.items(), key=lambda kv: kv[1][1])[0]
-    for _ in range(args.warmup):
-        step()
-
-    # --- timed region: exactly K steps; only the dominant kernel is event-bracketed ---
-    # (every 4th launch of it: the event pair around a kernel costs its stream two ~6 us bubbles -- measured 13 us per step)
+    # untimed: three plain + three instrumented steps to find the dominant kernel, then the warm-up; timed region: exactly K
+    # steps, only the dominant kernel event-bracketed (every 4th launch of it for the 0.45 ms net: the event pair around a
+    # kernel costs its stream two ~6 us bubbles -- measured 13 us per step)
     every = 4 if small else 1
-    capi.kernel_timing(2, dominant, every=every)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    dom = capi.kernel_timing_report()
-    capi.kernel_timing(0)
+    elapsed, dominant, cnt, ms, table = measure(run, args.steps, args.warmup, every, capi, barrier)
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -419,7 +454,6 @@ def main():
 
     out = None
     if rank == 0:
-        cnt, ms = dom[dominant]
         spec = stacks.STACKS[args.config]()
         flops_img = stacks.train_flops_per_image(spec)
         out = {
@@ -463,14 +497,14 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1:
-        if small and api == "pynet" and not args.no_layer_api:
-            # the same workload through the boundary north_star names: the C++ Layer::forward / backward classes
-            # (architectures::AlexNet via Sequential::train_step), once with the opt-in pool-block fusion the headline uses and
-            # once with every Layer::get_output() valid
-            for key, pool in (("layer_api", True), ("layer_api_default", False)):
-                r2 = make_runner("alexnet", "layer", args.batch, torch, capi, 1, 0, None, pool_block=pool)
+        if small and api == "layer" and not args.no_extra_legs:
+            # the same workload (a) with every tensor written by the pass itself (architectures::fuse_pool_block = false: no lazy
+            # re-materialisation, plain backward -> SGD sequence) and (b) through the Python driver over the same C ABI
+            for key, kw in (("layer_api_all_tensors_written", dict(api="layer", pool_block=False)), ("python_driver", dict(api="pynet"))):
+                r2 = make_runner("alexnet", kw["api"], args.batch, torch, capi, 1, 0, None, pool_block=kw.get("pool_block", True))
 
                 def sync():
+                    r2["flush"]()
                     torch.cuda.synchronize()
 
                 el = timed_steps(torch, r2["step"], sync, args.steps, args.warmup)
@@ -483,6 +517,9 @@ def main():
             out["pcie_inclusive"] = staged_input_bench(torch, capi, args)
         if small and not args.no_conv_ns:
             out["conv_ns"] = conv_ns_bench(torch, capi)
+        if small and not args.no_stacks and args.batch is None:
+            # BASELINE configs[3] / [4] in the same driver-run command (a few steps each; their own CPU legs: --config vgg11|resnet18)
+            out["stacks"] = {name: stack_leg(name, torch, capi) for name in ("vgg11", "resnet18")}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline() if small else cpu_baseline_stack(args.config)
     if rank == 0:

@@ -70,6 +70,7 @@ SIGNATURES = {
     "cnn_grad_cam": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "cnn_amd_publish_next_kernel": (C.c_int, [_P]),
     "cnn_amd_wait_published": (C.c_int, [_P]),
+    "cnn_amd_published_is_last": (C.c_int, [_P]),
     "cnn_conv2d_im2col_workspace_bytes": (C.c_size_t, [_D]),
     "cnn_conv2d_forward_im2col": (C.c_int, [_D, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_backward_weight_im2col": (C.c_int, [_D, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P]),
@@ -100,6 +101,10 @@ SIGNATURES = {
     "cnn_batchnorm2d_backward_sums": (C.c_int, [_P] * 6 + [C.c_int] * 4 + [C.c_float, _P, C.c_size_t, _P]),
     "cnn_batchnorm2d_backward_from_sums": (C.c_int, [_P] * 6 + [C.c_float, _P, _P] + [C.c_int] * 4 + [C.c_float, _P]),
     "cnn_sgd_update": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P]),
+    "cnn_sgd_update_keep": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P, _P]),
+    "cnn_stream_wait_event_local": (C.c_int, [_P, _P]),
+    "cnn_conv2d_backward_weight_pooled2_sgd_keep": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P,
+                                                               C.c_size_t, _P]),
     "cnn_comm_available": (C.c_int, []),
     "cnn_comm_version": (C.c_int, []),
     "cnn_comm_unique_id": (C.c_int, [_P]),

@@ -354,6 +354,11 @@ int cnn_stream_wait_event(void* stream, void* event) {
     publish_mark_stale(as_stream(stream));  // (a fork taken from an earlier published kernel would miss this dependency)
     return CNN_AMD_OK;
 }
+int cnn_stream_wait_event_local(void* stream, void* event) {
+    CNN_REQUIRE(event != nullptr, "cnn_stream_wait_event_local: null event");
+    CNN_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), reinterpret_cast<hipEvent_t>(event), 0));
+    return CNN_AMD_OK;
+}
 int cnn_host_alloc_pinned(void** ptr, size_t bytes) {
     CNN_REQUIRE(ptr != nullptr, "cnn_host_alloc_pinned: ptr is null");
     CNN_HIP_CHECK(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault));
@@ -479,6 +484,11 @@ int cnn_amd_publish_next_kernel(void* stream) {
     p->armed = true;
     p->stream = as_stream(stream);
     return CNN_AMD_OK;
+}
+
+int cnn_amd_published_is_last(void* stream) {
+    const PublishState& p = publish_state();
+    return (p.valid && !p.armed && !p.stale && p.stream == as_stream(stream)) ? 1 : 0;
 }
 
 int cnn_amd_wait_published(void* stream) {

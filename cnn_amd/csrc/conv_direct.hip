@@ -626,7 +626,8 @@ constexpr int kFinThreads = 1024, kFinLanes = 8, kFinN = 16 * 28;
 __global__ __launch_bounds__(kFinThreads) void first_layer_finish(const float* __restrict__ slabs, int nslots, float divisor,
                                                                   float* __restrict__ gw, float* __restrict__ gb, float* __restrict__ w,
                                                                   float* __restrict__ bias, float lr, float scale, int scaled,
-                                                                  float* __restrict__ fwd_img, float* __restrict__ dgrad_img) {
+                                                                  float* __restrict__ fwd_img, float* __restrict__ dgrad_img,
+                                                                  float* __restrict__ w_keep, float* __restrict__ bias_keep) {
     __shared__ float red[kFinLanes][kFinN];
     __shared__ float wl[16 * 27], bl[16];
     constexpr int PAIRS = kFinLanes * kFinN, PER = (PAIRS + kFinThreads - 1) / kFinThreads;  // (element, slot-lane) pairs per thread
@@ -674,12 +675,16 @@ __global__ __launch_bounds__(kFinThreads) void first_layer_finish(const float* _
         if (col < 27) {
             const int j = row * 27 + col;
             gw[j] = g;
-            const float v = sgd_one(w[j], g, lr, scale, scaled != 0);
+            const float old = w[j];
+            if (w_keep) w_keep[j] = old;  // (the filters the last forward pass used: Conv2D::get_output() re-materialisation)
+            const float v = sgd_one(old, g, lr, scale, scaled != 0);
             w[j] = v;
             wl[j] = v;
         } else {
             if (gb) gb[row] = g;
-            const float v = bias ? sgd_one(bias[row], g, lr, scale, scaled != 0) : 0.f;
+            const float oldb = bias ? bias[row] : 0.f;
+            if (bias && bias_keep) bias_keep[row] = oldb;
+            const float v = bias ? sgd_one(oldb, g, lr, scale, scaled != 0) : 0.f;
             if (bias) bias[row] = v;
             bl[row] = v;
         }
@@ -1288,13 +1293,14 @@ int direct_conv_wgrad_pooled(const cnn_conv2d_desc* d, const float* x, const flo
 
 // see first_layer_finish; slabs: the [nslots][16][28] output of direct_conv_wgrad*(), images as cnn_conv2d_prepare_filters writes them
 int direct_first_layer_finish(const cnn_conv2d_desc* d, const float* slabs, int nslots, float divisor, float* gw, float* gb, float* w,
-                              float* bias, float lr, float grad_scale, void* fwd_img, void* dgrad_img, hipStream_t s) {
+                              float* bias, float lr, float grad_scale, void* fwd_img, void* dgrad_img, float* w_keep, float* bias_keep,
+                              hipStream_t s) {
     CNN_REQUIRE(direct_conv_supported(d), "first_layer_finish: geometry not covered");
     CNN_REQUIRE(!fwd_img || direct_fwd_pk_ok(d), "first_layer_finish: this layer has no packed forward kernel");
     CNN_REQUIRE(!dgrad_img || direct_dgrad_pk_ok(d), "first_layer_finish: this layer has no packed data-gradient kernel");
     CNN_KLAUNCH(s, "first_layer_finish",
                 (first_layer_finish<<<1, kFinThreads, 0, s>>>(slabs, nslots, divisor, gw, gb, w, bias, lr, grad_scale, grad_scale != 1.0f ? 1 : 0,
-                                                              (float*)fwd_img, (float*)dgrad_img)),
+                                                              (float*)fwd_img, (float*)dgrad_img, w_keep, bias_keep)),
                 CONV_TAG(d));
     return CNN_AMD_OK;
 }

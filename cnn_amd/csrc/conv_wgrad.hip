@@ -21,7 +21,8 @@ bool direct_conv_pool_supported(const cnn_conv2d_desc* d);
 int direct_conv_wgrad_pooled(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask, const float* pooled,
                              float* slabs, hipStream_t s);
 int direct_first_layer_finish(const cnn_conv2d_desc* d, const float* slabs, int nslots, float divisor, float* gw, float* gb, float* w,
-                              float* bias, float lr, float grad_scale, void* fwd_img, void* dgrad_img, hipStream_t s);
+                              float* bias, float lr, float grad_scale, void* fwd_img, void* dgrad_img, float* w_keep, float* bias_keep,
+                              hipStream_t s);
 int stem_wgrad_slots(const cnn_conv2d_desc* d);  // conv_stem.hip: 3 -> Co, 7x7, stride 2, pad 3
 int os_wgrad_slots(const cnn_conv2d_desc* d);    // conv_wgrad_os.hip: the reference net's small 3x3 / stride-2 layers, output-stationary
 int os_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
@@ -781,6 +782,14 @@ int cnn_conv2d_backward_weight_pooled2_sgd(const cnn_conv2d_desc* d, const float
                                            const float* pooled, float* gw, float* gb, float divisor, float* w, float* bias, float lr,
                                            float grad_scale, void* fwd_prepared, void* dgrad_prepared, void* ws, size_t ws_bytes,
                                            void* stream) {
+    return cnn_conv2d_backward_weight_pooled2_sgd_keep(d, x, dpool, mask, pooled, gw, gb, divisor, w, bias, lr, grad_scale, fwd_prepared,
+                                                       dgrad_prepared, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+int cnn_conv2d_backward_weight_pooled2_sgd_keep(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask,
+                                                const float* pooled, float* gw, float* gb, float divisor, float* w, float* bias, float lr,
+                                                float grad_scale, void* fwd_prepared, void* dgrad_prepared, float* w_previous,
+                                                float* bias_previous, void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_desc("cnn_conv2d_backward_weight_pooled2_sgd", d)) return rc;
     CNN_REQUIRE(x && dpool && mask && gw && gb && w && bias, "cnn_conv2d_backward_weight_pooled2_sgd: null pointer");
     CNN_REQUIRE(divisor != 0.f, "cnn_conv2d_backward_weight_pooled2_sgd: divisor is 0");
@@ -800,7 +809,8 @@ int cnn_conv2d_backward_weight_pooled2_sgd(const cnn_conv2d_desc* d, const float
     }
     // (more than 512 slabs would go through a two-stage reduction in the unfused path: a different summation order)
     CNN_REQUIRE(slots <= 512, "cnn_conv2d_backward_weight_pooled2_sgd: %d slabs", slots);
-    return direct_first_layer_finish(d, (const float*)ws, slots, divisor, gw, gb, w, bias, lr, grad_scale, fwd_prepared, dgrad_prepared, sd);
+    return direct_first_layer_finish(d, (const float*)ws, slots, divisor, gw, gb, w, bias, lr, grad_scale, fwd_prepared, dgrad_prepared,
+                                     w_previous, bias_previous, sd);
 }
 
 int cnn_amd_flush_reduces(void* stream) { return flush_reduces(as_stream(stream)); }

@@ -65,26 +65,31 @@ __global__ __launch_bounds__(kBlock) void dropout_bwd(float* __restrict__ d, siz
 
 // sgd_one(): common.h
 // (the <= 3 trailing elements of an arena whose length is not a multiple of 4 ride along in workgroup 0)
+// `keep` (nullable, wave-uniform): receives the value every parameter had BEFORE the step (cnn_sgd_update_keep)
 __global__ __launch_bounds__(kBlock) void sgd_vec(float4* __restrict__ p, const float4* __restrict__ g, size_t n4,
-                                                  size_t n, float lr, float scale, bool scaled) {
+                                                  size_t n, float lr, float scale, bool scaled, float4* __restrict__ keep) {
     if (blockIdx.x == 0 && n4 * 4 + threadIdx.x < n) {
         float* ps = (float*)p;
         const float* gs = (const float*)g;
         const size_t i = n4 * 4 + threadIdx.x;
+        if (keep) ((float*)keep)[i] = ps[i];
         ps[i] = sgd_one(ps[i], gs[i], lr, scale, scaled);
     }
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (size_t)gridDim.x * kBlock) {
         float4 pv = p[i];
         const float4 gv = g[i];
+        if (keep) keep[i] = pv;
         pv.x = sgd_one(pv.x, gv.x, lr, scale, scaled); pv.y = sgd_one(pv.y, gv.y, lr, scale, scaled);
         pv.z = sgd_one(pv.z, gv.z, lr, scale, scaled); pv.w = sgd_one(pv.w, gv.w, lr, scale, scaled);
         p[i] = pv;
     }
 }
 __global__ __launch_bounds__(kBlock) void sgd_scalar(float* __restrict__ p, const float* __restrict__ g,
-                                                     size_t begin, size_t n, float lr, float scale, bool scaled) {
-    for (size_t i = begin + (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+                                                     size_t begin, size_t n, float lr, float scale, bool scaled, float* __restrict__ keep) {
+    for (size_t i = begin + (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        if (keep) keep[i] = p[i];
         p[i] = sgd_one(p[i], g[i], lr, scale, scaled);
+    }
 }
 
 // func.cpp:6-12
@@ -246,22 +251,26 @@ int cnn_relu_backward(const float* y, float* dy, size_t n, void* stream) {
 }
 
 int cnn_sgd_update(float* params, const float* grads, size_t n, float lr, float grad_scale, void* stream) {
+    return cnn_sgd_update_keep(params, grads, n, lr, grad_scale, nullptr, stream);
+}
+
+int cnn_sgd_update_keep(float* params, const float* grads, size_t n, float lr, float grad_scale, float* previous, void* stream) {
     if (n == 0) return CNN_AMD_OK;
     CNN_REQUIRE(params && grads, "cnn_sgd_update: null pointer");
     hipStream_t s = as_stream(stream);
     const bool scaled = grad_scale != 1.0f;
     size_t done = 0;
-    if (aligned16(params) && aligned16(grads) && n >= 4) {
+    if (aligned16(params) && aligned16(grads) && (previous == nullptr || aligned16(previous)) && n >= 4) {
         const size_t n4 = n / 4;
         CNN_KLAUNCH(s, "sgd_vec",
                     (sgd_vec<<<stream_grid(n4, kBlock), kBlock, 0, s>>>((float4*)params, (const float4*)grads, n4, n, lr,
-                                                                       grad_scale, scaled)),
+                                                                       grad_scale, scaled, (float4*)previous)),
                     "n=%zu", n);
         done = n;
     }
     if (done < n) {
         CNN_KLAUNCH(s, "sgd_scalar",
-                    (sgd_scalar<<<stream_grid(n - done, kBlock), kBlock, 0, s>>>(params, grads, done, n, lr, grad_scale, scaled)),
+                    (sgd_scalar<<<stream_grid(n - done, kBlock), kBlock, 0, s>>>(params, grads, done, n, lr, grad_scale, scaled, previous)),
                     "tail n=%zu", n - done);
     }
     return CNN_AMD_OK;

@@ -24,10 +24,13 @@ extern void* stream;            // hipStream_t all layers enqueue on (addition; 
 // addition: let the AlexNet container run Conv2D+ReLU forward and MaxPool2D+ReLU backward as one kernel each
 // (bit-identical results, every layer's output / delta tensor is still produced); false = one kernel per layer call
 extern bool fuse_layers;
-// Opt-in (default off): run Conv2D -> ReLU -> MaxPool2D(2,2) blocks as ONE kernel and their backward passes from the pooled
-// domain.  Unlike fuse_layers this changes something observable: in such a pass the block's Conv2D and ReLU layers do not
-// write their own output tensors (get_output() of those two layers is stale); everything else -- the pool's output, all
-// gradients, every later layer -- is bit-identical.
+// addition (default ON since round 3): inside a container, Conv2D -> ReLU -> MaxPool2D(2,2) blocks run as ONE kernel and their
+// backward passes work from the pooled domain; convolutions followed by a ReLU write only the ReLU output where the kernel
+// supports it.  The tensors that are not written in such a pass (the block's Conv2D / ReLU outputs, pre-activations) stay
+// OBSERVABLE: Layer::get_output() re-computes them on demand -- one forward launch from the recorded input with the parameters
+// the last forward pass used (the container keeps a snapshot across its SGD step) -- bit-identical to the unfused pass, so
+// the reference's contract (alexnet.cpp:97,105: every layer's output readable after forward) holds.  false = every tensor is
+// written by the pass itself.
 extern bool fuse_pool_block;
 // addition: LinearLayer::forward normally copies its (tiny) output to the host right away, because the reference's callers
 // read `output[b]->data` directly (softmax, func.cpp:24-28; argmax, cnn.cpp:92) -- one blocking D2H per forward pass.  While
@@ -94,6 +97,13 @@ private:
     bool pool_fused_pass = false;     // this pass' forward went through the pooled kernel: backward receives d(pool output)
     void* prep_fwd = nullptr;    // prepared filters (forward / data gradient layouts)
     void* prep_dgrad = nullptr;
+    void* prep_dgrad_alt = nullptr;   // second data-gradient image: a DEFERRED data gradient keeps reading the filters of its own step
+    // ---- re-materialisation of an output tensor the pass did not write (fuse_pool_block) ----
+    mutable bool out_valid = true;    // out_buf holds the last forward's output
+    const data_type* last_x = nullptr;  // device pointer of the last forward's input (recorded even under no_grad)
+    int last_B = 0;
+    const data_type* snapshot = nullptr;   // the container's copy of this layer's parameters BEFORE its latest SGD step ...
+    const bool* snapshot_active = nullptr;  // ... and whether that step came after the last forward pass
     bool prepared_active = false;
     void* prep_event = nullptr;  // see wait_before_forward
     const int in_channels, out_channels, kernel_size, stride;
@@ -145,6 +155,30 @@ public:
     void wait_before_forward(void* event) { prep_event = event; }
     size_t param_count() const override { return (size_t)get_params_num(); }
     void bind_arena(data_type* params_dev, data_type* grads_dev) override;
+    // ---- additions for fuse_pool_block ----
+    // alexnet.cpp:97,105: the output of the last forward, also when that pass fused it away (see architectures::fuse_pool_block)
+    std::vector<tensor> get_output() const override;
+    void materialize() const;  // writes the missing output tensor(s) of the last forward pass now (no-op when present)
+    void set_param_snapshot(const data_type* snap, const bool* active) { snapshot = snap; snapshot_active = active; }
+    // The pieces of Conv2D::backward a container schedules itself for the pool-fused FIRST block of a network (nothing consumes
+    // that layer's data gradient, conv2d.cpp:168-199 / alexnet.cpp:55):
+    struct DeferredDgrad {   // everything the data gradient of one pass needs, valid until that pass' buffers are rewritten
+        const void* prepared = nullptr;
+        const data_type* dpool = nullptr;
+        const int* mask = nullptr;
+        const data_type* pooled = nullptr;
+        int B = 0;
+        bool valid = false;
+    };
+    bool pool_fused_pending() const { return pool_fused_pass; }
+    // weight / bias gradient from the pooled domain on `stream`; with fused_sgd also this layer's SGD step (the old values go to
+    // the snapshot) and its filter images for the next pass in the same launch (cnn_conv2d_backward_weight_pooled2_sgd_keep).
+    // Returns what the data gradient of this pass will need (launch_deferred_dgrad).
+    DeferredDgrad backward_weight_pooled(std::vector<tensor>& delta, bool fused_sgd, data_type learning_rate, data_type grad_scale);
+    void prepare_own_filters();  // fwd image + the NEXT data-gradient image from the current parameters, on architectures::stream
+    void launch_deferred_dgrad(const DeferredDgrad& job, void* on_stream);
+    const data_type* delta_dev() const { return delta_buf.base; }  // the data gradient of the last backward pass (device)
+    size_t delta_floats() const { return delta_buf.sample_len * delta_buf.views.size(); }
 };
 
 class MaxPool2D : public Layer {
@@ -152,6 +186,12 @@ private:
     const int kernel_size, step, padding;
     BatchBuffer out_buf, delta_buf, in_stage, delta_stage;
     int* mask = nullptr;  // device int32 [B][C*Ho*Wo], flat indices into the sample's C*H*W (pool2d.cpp:81)
+    // a container that DEFERS the data gradient of the block in front (it reads pooled + mask of ITS pass while the next forward
+    // pass is already writing new ones) lets the fused forward alternate between two sets
+    BatchBuffer out_buf_alt;
+    int* mask_alt = nullptr;
+    bool alternate = false;
+    int cur_set = 0;
     int in_C = 0, in_H = 0, in_W = 0, batch = 0;
     ReLU* fused_relu_below = nullptr;  // the ReLU layer whose output is this pool's input (set by the container), or null
     bool forward_done = false;       // this pass' output + mask were written by the producing Conv2D kernel
@@ -166,8 +206,9 @@ public:
     // additions used by Conv2D when the container fused Conv2D -> ReLU -> this pool into one kernel
     bool fusable_2x2() const { return kernel_size == 2 && step == 2; }
     void fused_forward_target(int B, int C, int H, int W, bool record, data_type** pooled, int** mask_out);  // arms forward_done
-    const data_type* pooled_dev() const { return out_buf.base; }
-    const int* mask_dev() const { return mask; }
+    const data_type* pooled_dev() const { return cur_set ? out_buf_alt.base : out_buf.base; }
+    const int* mask_dev() const { return cur_set ? mask_alt : mask; }
+    void enable_alternate_sets() { alternate = true; }
     // pool-fused pass: the delta of this pool's output passes through untouched (the block's Conv2D consumes it).  The layer
     // BEHIND the pool can then fold the block's ReLU::backward into its own data-gradient epilogue -- in the pooled domain
     // d(pool_out) masked by (pool_out <= 0) IS that ReLU's backward pass (at an argmax position the ReLU output equals the
@@ -185,9 +226,15 @@ private:
     BatchBuffer out_buf, in_stage, delta_stage;
     bool forward_done = false;   // this pass' output was already written by the producing Conv2D kernel
     bool backward_done = false;  // this pass' delta was already masked by the consuming MaxPool2D kernel
+    bool out_valid = true;       // false: the pool-fused pass did not write this layer's output (get_output re-computes it)
+    const Conv2D* producer = nullptr;  // the convolution whose kernel writes this layer's output when fused
 
 public:
     ReLU(std::string _name) : Layer(_name) {}
+    std::vector<tensor> get_output() const override;
+    bool output_valid() const { return out_valid; }
+    void set_producer(const Conv2D* conv) { producer = conv; }
+    data_type* rematerialize_target() { out_valid = true; return out_buf.base; }
     // additions used by Conv2D / MaxPool2D when the container fused this layer into their kernels
     data_type* fused_forward_target(int B, int C, int H, int W);  // output arena (allocated on first use); arms forward_done
     void fused_backward_done() { backward_done = true; }
@@ -321,6 +368,21 @@ protected:
     void* ev_comm = nullptr;
     bool grads_reduced = false;     // this step's gradient arena has been summed over the replicas
     std::vector<size_t> layer_offsets;  // arena offset of every layer's parameter block (finalize)
+    // ---- fuse_pool_block support (round 3) ----
+    data_type* param_prev = nullptr;  // the parameters as they were before the latest SGD step (Conv2D::materialize)
+    bool params_stepped = false;      // ... which happened after the last forward pass
+    // the pool-fused FIRST block of the network (Conv2D -> ReLU -> MaxPool2D(2,2) at the front), if there is one: train_step
+    // defers its data gradient into the next forward pass and runs the rest of the step's tail underneath its weight gradient
+    Conv2D* block_conv = nullptr;
+    MaxPool2D* block_pool = nullptr;
+    Layer* behind_block = nullptr;     // the layer that consumes the pool's output (its backward rewrites d(pool output))
+    Layer* release_after = nullptr;    // the deferred data gradient starts behind this layer's forward kernel
+    void* defer_stream = nullptr;
+    void* ev_defer_done = nullptr;
+    void* ev_tail = nullptr;
+    Conv2D::DeferredDgrad pending_dgrad;
+    bool defer_in_flight = false;
+    bool fused_tail(std::vector<tensor>& delta, const data_type learning_rate);  // false: not applicable to this pass
     // big arenas (the VGG / ResNet-shaped stacks: 37 - 45 MB) are exchanged in BUCKETS while the backward pass is still running:
     // layers are walked back to front, so finished gradients form a growing suffix of the arena; every >= bucket_floats of it
     // go out on the communication stream behind an event.  Small arenas (the reference net: 445 KB, latency-bound) stay one call.
@@ -374,6 +436,11 @@ public:
     void train_step(const std::vector<tensor>& input, const int* labels_dev, const data_type learning_rate);
     data_type last_loss();
     const data_type* last_probs_device() const { return loss_probs.base; }
+    // train_step defers the data gradient of a pool-fused first block (no consumer: alexnet.cpp:55 discards it) into the next
+    // forward pass.  flush_deferred() launches a still-pending one and orders it before later work on architectures::stream; every
+    // other entry point of the container does that itself, a caller only needs it before timing ends or before it reads that
+    // layer's delta tensors through raw device pointers.
+    void flush_deferred();
 
 private:
     BatchBuffer loss_probs, loss_delta, logits_stage;   // [B][classes] each

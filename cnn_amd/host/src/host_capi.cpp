@@ -194,6 +194,20 @@ void cnnh_net_train_step_device_loss(void* hv, float* x_dev, const int* labels_d
     h->net->train_step(views, labels_dev, lr);
 }
 float cnnh_net_last_loss(void* hv) { return ((Handle*)hv)->net->last_loss(); }
+// the delta with respect to the network INPUT (the first layer's data gradient, conv2d.cpp:168-199; alexnet.cpp:55 discards it) of
+// the last backward pass -- after flush_deferred(), because train_step may have deferred that kernel.  0 ok, 1 no such tensor, 2 cap
+int cnnh_net_input_delta(void* hv, float* out, size_t cap_floats) {
+    Handle* h = (Handle*)hv;
+    auto* conv = dynamic_cast<Conv2D*>(h->net->layers().front().get());
+    if (conv == nullptr || conv->delta_dev() == nullptr) return 1;
+    if (conv->delta_floats() > cap_floats) return 2;
+    h->net->flush_deferred();
+    must(cnn_memcpy_d2h(out, conv->delta_dev(), sizeof(float) * conv->delta_floats(), stream), "cnn_memcpy_d2h");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+    return 0;
+}
+// Sequential::flush_deferred: a data gradient train_step deferred into the next pass is launched / ordered now
+void cnnh_net_flush(void* hv) { ((Handle*)hv)->net->flush_deferred(); }
 void cnnh_net_update(void* hv, float lr, float grad_scale) { ((Handle*)hv)->net->update_gradients(lr, grad_scale); }
 // Sequential::update_gradients(lr): with a communicator set, all-reduce + lr/world; otherwise the plain step
 void cnnh_net_update_auto(void* hv, float lr) { ((Handle*)hv)->net->update_gradients(lr); }

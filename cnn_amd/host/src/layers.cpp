@@ -18,7 +18,7 @@ data_type architectures::random_times = 10.f;  // architectures.cpp:6
 bool architectures::no_grad = false;           // architectures.cpp:8
 void* architectures::stream = nullptr;
 bool architectures::fuse_layers = true;
-bool architectures::fuse_pool_block = false;
+bool architectures::fuse_pool_block = true;
 bool architectures::lazy_host_sync = false;
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -122,6 +122,7 @@ Conv2D::~Conv2D() {
     if (workspace) cnn_device_free(workspace);
     if (prep_fwd) cnn_device_free(prep_fwd);
     if (prep_dgrad) cnn_device_free(prep_dgrad);
+    if (prep_dgrad_alt) cnn_device_free(prep_dgrad_alt);
 }
 
 void Conv2D::prepared_buffers(void** fwd, void** dgrad) {
@@ -194,6 +195,9 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
         saved_input = x;
         saved_input_tensors = input;
     }
+    last_x = x;  // (a pointer, not a copy: get_output() of a fused-away tensor re-computes it from here)
+    last_B = B;
+    out_valid = true;
     cnn_conv2d_desc d{B, in_channels, H, W, out_channels, kernel_size, stride, padding};
     const bool prepared = prepared_active && fuse_layers && B == batch;
     pool_fused_pass = false;
@@ -207,13 +211,15 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
         fused_relu->fused_forward_skipped(B, out_channels, out_H, out_W);
         must(cnn_conv2d_relu_maxpool2_forward_prepared(&d, x, prep_fwd, pooled, pmask, stream), "cnn_conv2d_relu_maxpool2_forward_prepared");
         pool_fused_pass = !no_grad;
+        out_valid = false;  // (re-computed by get_output() if anybody asks)
         return output;
     }
     if (fused_relu != nullptr && fuse_layers) {  // the ReLU behind this layer gets its output from the same kernel
         data_type* y_relu = fused_relu->fused_forward_target(B, out_channels, out_H, out_W);
-        // fuse_pool_block (opt-in, "train steps only"): the pre-activation tensor is not written either where the kernel
-        // supports it -- ReLU::backward masks by the ReLU's own output (relu.cpp:35-40), nothing in a train step reads it
+        // fuse_pool_block: the pre-activation tensor is not written either where the kernel supports it -- ReLU::backward masks
+        // by the ReLU's own output (relu.cpp:35-40), nothing in a train step reads it; get_output() re-computes it on demand
         const bool relu_only = prepared && fuse_pool_block && !no_grad && cnn_conv2d_relu_only_supported(&d) != 0;
+        out_valid = !relu_only;
         if (prepared)
             must(cnn_conv2d_forward_prepared(&d, x, prep_fwd, b_dev(), relu_only ? nullptr : out_buf.base, y_relu, stream),
                  "cnn_conv2d_forward_prepared");
@@ -274,6 +280,93 @@ std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
     return delta_buf.views;
 }
 
+// ---- fuse_pool_block: outputs the pass did not write, and the container-scheduled backward of a pool-fused first block ----
+void Conv2D::materialize() const {
+    const bool relu_missing = fused_relu != nullptr && !fused_relu->output_valid();
+    if (out_valid && !relu_missing) return;
+    assert(last_x != nullptr && "get_output() of a fused-away tensor before any forward pass");
+    // the parameters the last forward pass used: the container's snapshot when its SGD step has run since
+    const data_type* w = (snapshot != nullptr && snapshot_active != nullptr && *snapshot_active) ? snapshot : params;
+    const data_type* b = w + (size_t)out_channels * params_for_one_kernel;
+    Conv2D* self = const_cast<Conv2D*>(this);
+    self->ensure_workspace(last_B, in_H, in_W);
+    cnn_conv2d_desc d{last_B, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding};
+    // the unprepared entry points re-arrange the filters themselves: bit-identical to the prepared kernels the pass would have run
+    if (fused_relu != nullptr && fuse_layers)
+        must(cnn_conv2d_forward_relu(&d, last_x, w, b, out_buf.base, fused_relu->rematerialize_target(), workspace, workspace_bytes, stream),
+             "cnn_conv2d_forward_relu");
+    else
+        must(cnn_conv2d_forward(&d, last_x, w, b, out_buf.base, workspace, workspace_bytes, stream), "cnn_conv2d_forward");
+    out_valid = true;
+}
+
+std::vector<tensor> Conv2D::get_output() const {
+    materialize();
+    return Layer::get_output();
+}
+
+Conv2D::DeferredDgrad Conv2D::backward_weight_pooled(std::vector<tensor>& delta, bool fused_sgd, data_type learning_rate, data_type grad_scale) {
+    Tensor3D::device_work_enqueued();
+    const int B = (int)delta.size();
+    assert(pool_fused_pass && prepared_active && fused_pool != nullptr && B == batch && saved_input != nullptr);
+    const data_type* dy = batch_device_pointer(delta, delta_stage, name + "_dy");  // d(pool output)
+    cnn_conv2d_desc d{B, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding};
+    if (delta_buf.empty()) delta_buf.allocate(batch, in_channels, in_H, in_W, name + "_delta");
+    const size_t need = cnn_conv2d_backward_workspace_bytes(&d);
+    if (need > workspace_bytes) {
+        if (workspace) cnn_device_free(workspace);
+        workspace = dev_alloc(need);
+        workspace_bytes = need;
+    }
+    if (prep_dgrad_alt == nullptr) prep_dgrad_alt = dev_alloc(cnn_conv2d_prepared_bytes(&d));
+    const data_type* pooled = fused_pool->take_delta_premasked() ? nullptr : fused_pool->pooled_dev();
+    data_type* gw = grads;
+    data_type* gb = grads + (size_t)out_channels * params_for_one_kernel;
+    DeferredDgrad job;
+    job.prepared = prep_dgrad;  // the filters of THIS step
+    job.dpool = dy;
+    job.mask = fused_pool->mask_dev();
+    job.pooled = pooled;
+    job.B = B;
+    job.valid = true;
+    if (fused_sgd) {
+        // window kernel + ONE small launch: slab reduction, gw / gb, this layer's SGD step (old values -> snapshot) and the filter
+        // images of the updated filters: forward in place, data gradient into the OTHER buffer (job.prepared stays intact)
+        data_type* snap_w = const_cast<data_type*>(snapshot);
+        must(cnn_conv2d_backward_weight_pooled2_sgd_keep(&d, saved_input, dy, job.mask, pooled, gw, gb, (float)B, w_dev(), b_dev(), learning_rate,
+                                                         grad_scale, prep_fwd, prep_dgrad_alt, snap_w,
+                                                         snap_w ? snap_w + (size_t)out_channels * params_for_one_kernel : nullptr, workspace,
+                                                         workspace_bytes, stream),
+             "cnn_conv2d_backward_weight_pooled2_sgd_keep");
+        std::swap(prep_dgrad, prep_dgrad_alt);
+    } else {
+        must(cnn_conv2d_backward_weight_pooled2(&d, saved_input, dy, job.mask, pooled, gw, gb, (float)B, workspace, workspace_bytes, stream),
+             "cnn_conv2d_backward_weight_pooled2");
+    }
+    pool_fused_pass = false;
+    grads_ready = true;
+    return job;
+}
+
+void Conv2D::prepare_own_filters() {
+    cnn_conv2d_desc d = current_desc();
+    if (prep_dgrad_alt == nullptr) prep_dgrad_alt = dev_alloc(cnn_conv2d_prepared_bytes(&d));
+    const float* w = w_dev();
+    const float* b = b_dev();
+    void* f = prep_fwd;
+    void* g = prep_dgrad_alt;
+    must(cnn_conv2d_prepare_filters(1, &d, &w, &b, &f, &g, stream), "cnn_conv2d_prepare_filters");
+    std::swap(prep_dgrad, prep_dgrad_alt);
+    prepared_active = true;
+}
+
+void Conv2D::launch_deferred_dgrad(const DeferredDgrad& job, void* on_stream) {
+    assert(job.valid);
+    cnn_conv2d_desc d{job.B, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding};
+    must(cnn_conv2d_backward_data_pooled2_prepared(&d, job.dpool, job.mask, job.pooled, job.prepared, delta_buf.base, on_stream),
+         "cnn_conv2d_backward_data_pooled2_prepared");
+}
+
 void Conv2D::update_gradients(const data_type learning_rate) {
     assert(grads_ready);  // conv2d.cpp:206
     must(cnn_amd_side_stream_join(stream), "cnn_amd_side_stream_join");
@@ -303,6 +396,7 @@ int Conv2D::get_params_num() const { return (params_for_one_kernel + 1) * out_ch
 // MaxPool2D
 MaxPool2D::~MaxPool2D() {
     if (mask) cnn_device_free(mask);
+    if (mask_alt) cnn_device_free(mask_alt);
 }
 
 void MaxPool2D::fused_forward_target(int B, int C, int H, int W, bool record, data_type** pooled, int** mask_out) {
@@ -315,8 +409,14 @@ void MaxPool2D::fused_forward_target(int B, int C, int H, int W, bool record, da
     assert(B <= batch);
     in_C = C; in_H = H; in_W = W;
     if (record && mask == nullptr) mask = (int*)dev_alloc(sizeof(int) * (size_t)batch * C * out_H * out_W);
-    *pooled = out_buf.base;
-    *mask_out = record ? mask : nullptr;
+    if (alternate) {  // the deferred data gradient of the previous pass still reads the other set
+        cur_set ^= 1;
+        if (cur_set && out_buf_alt.empty()) out_buf_alt.allocate(batch, C, out_H, out_W, name + "_output");
+        if (cur_set && record && mask_alt == nullptr) mask_alt = (int*)dev_alloc(sizeof(int) * (size_t)batch * C * out_H * out_W);
+        output = cur_set ? out_buf_alt.views : out_buf.views;
+    }
+    *pooled = cur_set ? out_buf_alt.base : out_buf.base;
+    *mask_out = record ? (cur_set ? mask_alt : mask) : nullptr;
     forward_done = true;
     backward_passthrough = record;
 }
@@ -335,6 +435,10 @@ std::vector<tensor> MaxPool2D::forward(const std::vector<tensor>& input) {
         out_buf.allocate(B, C, out_H, out_W, name + "_output");
         output = out_buf.views;
         batch = B;
+    }
+    if (cur_set != 0) {  // (an unfused pass always uses the first set)
+        cur_set = 0;
+        output = out_buf.views;
     }
     assert(B <= batch);
     if (in_C && (in_C != C || in_H != H || in_W != W)) {  // (the output / mask buffers were sized by the first shape)
@@ -362,11 +466,11 @@ std::vector<tensor> MaxPool2D::backward(std::vector<tensor>& delta) {
     if (delta_buf.empty()) delta_buf.allocate(batch, in_C, in_H, in_W, name + "_delta");
     const data_type* dy = batch_device_pointer(delta, delta_stage, name + "_dy");
     if (fused_relu_below != nullptr && fuse_layers) {  // also applies the ReLU::backward of the layer in front
-        must(cnn_maxpool2d_backward_relu(dy, mask, out_buf.base, delta_buf.base, B, in_C, in_H, in_W, kernel_size, step, stream),
+        must(cnn_maxpool2d_backward_relu(dy, mask_dev(), pooled_dev(), delta_buf.base, B, in_C, in_H, in_W, kernel_size, step, stream),
              "cnn_maxpool2d_backward_relu");
         fused_relu_below->fused_backward_done();
     } else {
-        must(cnn_maxpool2d_backward(dy, mask, delta_buf.base, B, in_C, in_H, in_W, kernel_size, step, stream),
+        must(cnn_maxpool2d_backward(dy, mask_dev(), delta_buf.base, B, in_C, in_H, in_W, kernel_size, step, stream),
              "cnn_maxpool2d_backward");
     }
     return delta_buf.views;
@@ -381,11 +485,19 @@ data_type* ReLU::fused_forward_target(int B, int C, int H, int W) {
     }
     assert((size_t)B <= out_buf.views.size() && out_buf.sample_len == (size_t)C * H * W);
     forward_done = true;
+    out_valid = true;
     return out_buf.base;
 }
 
 void ReLU::fused_forward_skipped(int B, int C, int H, int W) {
     fused_forward_target(B, C, H, W);  // (keeps the layer's output tensors in place for the pass-through; not written)
+    out_valid = false;
+}
+
+// alexnet.cpp:97,105 for a layer whose output the pool-fused pass did not write: the producing convolution re-computes it
+std::vector<tensor> ReLU::get_output() const {
+    if (!out_valid && producer != nullptr) producer->materialize();
+    return Layer::get_output();
 }
 
 std::vector<tensor> ReLU::forward(const std::vector<tensor>& input) {
@@ -405,6 +517,7 @@ std::vector<tensor> ReLU::forward(const std::vector<tensor>& input) {
         std::abort();
     }
     const data_type* x = batch_device_pointer(input, in_stage, name);
+    out_valid = true;
     must(cnn_relu_forward(x, out_buf.base, out_buf.sample_len * B, stream), "cnn_relu_forward");
     return output;
 }

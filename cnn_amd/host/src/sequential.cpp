@@ -3,6 +3,7 @@
 // one all-reduce, the fusion wiring between neighbouring layers, and the BASELINE workloads as layer lists.
 // (class AlexNet itself lives in alexnet.cpp -- the one file of this directory the reference's own cpu/src/alexnet.cpp can
 // replace, see INTEGRATION.md.)
+#include <algorithm>
 #include <cassert>
 #include <cstdlib>
 #include <iostream>
@@ -38,7 +39,10 @@ void Sequential::wire() {
         if (next == layers_sequence.end()) break;
         // Conv2D -> ReLU: the ReLU's output is written by the convolution kernel's epilogue
         if (auto* relu = dynamic_cast<ReLU*>(next->get())) {
-            if (auto* conv = dynamic_cast<Conv2D*>(it->get())) conv->set_fused_relu(relu);
+            if (auto* conv = dynamic_cast<Conv2D*>(it->get())) {
+                conv->set_fused_relu(relu);
+                relu->set_producer(conv);
+            }
             // BatchNorm2D -> ReLU: ... or by the normalisation's apply pass
             if (auto* bn = dynamic_cast<BatchNorm2D*>(it->get())) bn->set_fused_relu(relu);
         }
@@ -74,9 +78,30 @@ void Sequential::wire() {
                 auto next3 = std::next(next2);
                 if (next3 != layers_sequence.end())
                     if (auto* behind = dynamic_cast<Conv2D*>(next3->get())) behind->set_pool_below(pool);
+                // the block at the very FRONT of the network: nothing consumes its data gradient (alexnet.cpp:55), train_step may
+                // defer that kernel into the next forward pass and run the step's tail under the block's weight gradient
+                if (it == layers_sequence.begin() && pool->fusable_2x2() && next3 != layers_sequence.end()) {
+                    block_conv = conv;
+                    block_pool = pool;
+                    behind_block = next3->get();
+                }
             }
         }
     }
+}
+
+// the deferred data gradient is released behind the THIRD convolution's forward kernel (or the last one of a shorter net): there
+// it overlaps the latency-bound deep layers, the linear layer and the loss instead of the HBM-bound first ones (measured on the
+// reference net)
+static Layer* pick_release_layer(const std::list<std::shared_ptr<Layer> >& layers) {
+    Layer* pick = nullptr;
+    int convs = 0;
+    for (const auto& layer : layers)
+        if (dynamic_cast<Conv2D*>(layer.get())) {
+            pick = layer.get();
+            if (++convs == 3) break;
+        }
+    return convs >= 2 ? pick : nullptr;
 }
 
 void Sequential::bind(data_type* p, data_type* g) {
@@ -88,7 +113,15 @@ void Sequential::bind(data_type* p, data_type* g) {
         const size_t n = layer->param_count();
         layer_offsets.push_back(off);
         if (n) layer->bind_arena(p + off, g + off);
+        // fuse_pool_block: Conv2D::get_output() of a fused-away tensor needs the parameters of the last forward pass -- the
+        // container keeps them across its SGD step (cnn_sgd_update_keep / ..._sgd_keep write them here)
+        if (auto* conv = dynamic_cast<Conv2D*>(layer.get())) conv->set_param_snapshot(param_prev + off, &params_stepped);
         off += n;
+    }
+    if (block_conv != nullptr) {
+        release_after = pick_release_layer(layers_sequence);
+        if (release_after == block_conv) release_after = nullptr;
+        if (release_after != nullptr) block_pool->enable_alternate_sets();
     }
 }
 
@@ -100,6 +133,7 @@ void Sequential::finalize() {
     owns_arena = true;
     data_type* p = (data_type*)dev_alloc(sizeof(data_type) * (n_params ? n_params : 1));
     data_type* g = (data_type*)dev_alloc(sizeof(data_type) * (n_params ? n_params : 1));
+    param_prev = (data_type*)dev_alloc(sizeof(data_type) * (n_params ? n_params : 1));
     must(cnn_memset_zero(g, sizeof(data_type) * n_params, stream), "cnn_memset_zero");
     bind(p, g);
     finalized = true;
@@ -111,12 +145,22 @@ void Sequential::finalize(data_type* params_dev, data_type* grads_dev) {
     n_params = 0;
     for (const auto& layer : layers_sequence) n_params += layer->param_count();
     owns_arena = false;
+    param_prev = (data_type*)dev_alloc(sizeof(data_type) * (n_params ? n_params : 1));
     bind(params_dev, grads_dev);
     finalized = true;
 }
 
 Sequential::~Sequential() {
+    if (defer_in_flight || pending_dgrad.valid) {  // (a deferred kernel may still read the layers' buffers)
+        pending_dgrad.valid = false;
+        cnn_stream_synchronize(defer_stream);
+        cnn_stream_synchronize(stream);
+    }
     layers_sequence.clear();
+    if (param_prev) cnn_device_free(param_prev);
+    if (defer_stream) cnn_stream_destroy(defer_stream);
+    if (ev_defer_done) cnn_event_destroy(ev_defer_done);
+    if (ev_tail) cnn_event_destroy(ev_tail);
     if (owns_arena) {
         cnn_device_free(param_arena);
         cnn_device_free(grad_arena);
@@ -181,13 +225,26 @@ void Sequential::prepare_filters() {
 std::vector<tensor> Sequential::forward(const std::vector<tensor>& input) {
     assert(input.size() > 0);
     if (print_info) input[0]->print_shape();
+    flush_deferred();
     if (finalized && fuse_layers && !filters_prepared) prepare_filters();
+    params_stepped = false;  // (the layers' outputs now belong to the current parameters)
     std::vector<tensor> output(input);
     for (const auto& layer : layers_sequence) {
         output = layer->forward(output);
         if (print_info) output[0]->print_shape();
     }
     return output;
+}
+
+void Sequential::flush_deferred() {
+    if (pending_dgrad.valid) {  // not released yet: run it in order on the compute stream
+        block_conv->launch_deferred_dgrad(pending_dgrad, stream);
+        pending_dgrad.valid = false;
+    }
+    if (defer_in_flight) {
+        must(cnn_stream_wait_event(stream, ev_defer_done), "cnn_stream_wait_event");
+        defer_in_flight = false;
+    }
 }
 
 // gradients [lo, hi) of the arena are final in `stream` order: send them off on the communication stream
@@ -201,6 +258,7 @@ void Sequential::flush_bucket(size_t lo, size_t hi) {
 
 void Sequential::backward(std::vector<tensor>& delta_start) {
     if (print_info) delta_start[0]->print_shape();
+    flush_deferred();
     const bool force_buckets = cnn_amd_get_option("DP_FORCE_BUCKETS", nullptr, 0) == 0;  // (tests: exercise the path with one rank)
     const bool bucketed = finalized && comm != nullptr && (comm_world > 1 || force_buckets) && n_params >= 2 * bucket_floats;
     size_t pending_hi = n_params, idx = layers_sequence.size();
@@ -228,6 +286,7 @@ void Sequential::backward(std::vector<tensor>& delta_start) {
 std::vector<uchar> Sequential::grad_cam(const std::string& layer_name, std::vector<data_type>* cam_out) const {
     // alexnet.cpp:97-102: from the logits down to (not including) the named layer.  The reference computes this delta and never
     // uses it (its channel weights are means of the FEATURE MAP, :111-119); the walk is kept for its side effects on the layers.
+    const_cast<Sequential*>(this)->flush_deferred();  // (the walk below rewrites the delta a deferred data gradient reads)
     std::vector<tensor> delta = layers_sequence.back()->get_output();
     auto layer = layers_sequence.rbegin();
     for (; layer != layers_sequence.rend(); ++layer) {
@@ -236,7 +295,6 @@ std::vector<uchar> Sequential::grad_cam(const std::string& layer_name, std::vect
     }
     assert(layer != layers_sequence.rend() && "grad_cam: no layer of that name");
     must(cnn_amd_side_stream_join(stream), "cnn_amd_side_stream_join");
-    assert(!fuse_pool_block && "grad_cam reads Layer::get_output() of a convolution: not materialised under fuse_pool_block");
     const std::vector<tensor> feature_map = (*layer)->get_output();  // alexnet.cpp:105
     const int B = (int)feature_map.size(), C = feature_map[0]->C, H = feature_map[0]->H, W = feature_map[0]->W;
     BatchBuffer staging;
@@ -259,6 +317,7 @@ std::vector<uchar> Sequential::grad_cam(const std::string& layer_name, std::vect
 }
 
 void Sequential::parameters_changed() {
+    params_stepped = false;    // (an outside write: there is no snapshot of what the last forward pass used)
     filters_prepared = false;  // re-prepared at the start of the next forward pass
     for (auto& layer : layers_sequence)
         if (auto* c = dynamic_cast<Conv2D*>(layer.get())) c->set_prepared(false);
@@ -305,8 +364,76 @@ void Sequential::update_gradients(const data_type learning_rate) {
 
 void Sequential::update_gradients(const data_type learning_rate, const data_type grad_scale) {
     assert(finalized && "the grad_scale form works on the flat arena: call finalize()");
-    must(cnn_sgd_update(param_arena, grad_arena, n_params, learning_rate, grad_scale, stream), "cnn_sgd_update");
+    // (the old values go to the snapshot: Conv2D::get_output() of a fused-away tensor re-computes it with them)
+    must(cnn_sgd_update_keep(param_arena, grad_arena, n_params, learning_rate, grad_scale, param_prev, stream), "cnn_sgd_update_keep");
     parameters_changed();
+    params_stepped = true;
+}
+
+// The end of a train step whose first block ran pool-fused, called where the backward walk reaches that
+// block's convolution; `delta` = d(pool output).  Instead of [block wgrad || block dgrad] -> join -> (all-reduce) -> SGD over the
+// arena -> filter images:
+//   * side stream, behind the data gradient of the layer behind the block (the last reader of the later layers' filter images):
+//     the recorded slab reductions of those layers, [their share of the gradient exchange,] their SGD step and filter images --
+//     all of it UNDER the block's weight-gradient kernel on the compute stream;
+//   * compute stream: the block's weight gradient; single rank: its slab reduction, SGD step and filter images are ONE more small
+//     launch; with a communicator: reduce, all-reduce of this layer's few floats, SGD, filter images;
+//   * the block's data gradient (no consumer: alexnet.cpp:55) is only RECORDED here: the next forward pass releases it on a third
+//     stream behind its release layer (flush_deferred() otherwise), with the filters and pooled-domain tensors of ITS step.
+// Arithmetic and summation orders are those of the plain sequence: parameters come out bit-identical.
+bool Sequential::fused_tail(std::vector<tensor>& delta, const data_type learning_rate) {
+    if (!finalized || !fuse_layers || block_conv == nullptr || release_after == nullptr || !block_conv->pool_fused_pending() ||
+        !filters_prepared || layer_offsets.empty() || layer_offsets[0] != 0)
+        return false;
+    if (cnn_amd_get_option("NO_FUSED_TAIL", nullptr, 0) == 0) return false;  // (A/B switch)
+    const size_t lo = block_conv->param_count();  // the block's convolution owns arena[0, lo)
+    const bool dp = comm != nullptr && comm_world > 1;
+    const data_type scale = dp ? 1.f / (data_type)comm_world : 1.f;
+    if (ev_tail == nullptr) must(cnn_event_create(&ev_tail), "cnn_event_create");
+    void* side = nullptr;
+    must(cnn_amd_side_stream_get(&side), "cnn_amd_side_stream_get");
+    if (cnn_amd_published_is_last(stream)) {  // the data gradient just launched carries the event in its dispatch packet
+        must(cnn_amd_wait_published(side), "cnn_amd_wait_published");
+    } else {
+        must(cnn_event_record(ev_tail, stream), "cnn_event_record");
+        must(cnn_stream_wait_event(side, ev_tail), "cnn_stream_wait_event");
+    }
+    must(cnn_amd_flush_reduces(side), "cnn_amd_flush_reduces");
+    if (n_params > lo) {
+        // bucket 1 of the exchange: everything behind the block is final ~one weight-gradient kernel before the step ends
+        if (dp) must(cnn_allreduce_grads(comm, grad_arena + lo, n_params - lo, side), "cnn_allreduce_grads");
+        must(cnn_sgd_update_keep(param_arena + lo, grad_arena + lo, n_params - lo, learning_rate, scale, param_prev + lo, side),
+             "cnn_sgd_update_keep");
+    }
+    std::vector<Conv2D*> later;
+    for (auto& layer : layers_sequence)
+        if (auto* c = dynamic_cast<Conv2D*>(layer.get()))
+            if (c != block_conv) later.push_back(c);
+    for (size_t first = 0; first < later.size(); first += 6) {
+        const size_t n = std::min<size_t>(6, later.size() - first);
+        std::vector<cnn_conv2d_desc> descs;
+        std::vector<const float*> w, b;
+        std::vector<void*> f(n), g(n);
+        for (size_t i = 0; i < n; ++i) {
+            Conv2D* c = later[first + i];
+            descs.push_back(c->current_desc());
+            w.push_back(c->filters_dev());
+            b.push_back(c->bias_dev());
+            c->prepared_buffers(&f[i], &g[i]);
+        }
+        must(cnn_conv2d_prepare_filters((int)n, descs.data(), w.data(), b.data(), f.data(), g.data(), side), "cnn_conv2d_prepare_filters");
+    }
+    // compute stream: the block's weight gradient (+ its share of the tail)
+    pending_dgrad = block_conv->backward_weight_pooled(delta, /*fused_sgd=*/!dp, learning_rate, scale);
+    if (dp) {  // bucket 2: this layer's few floats
+        must(cnn_allreduce_grads(comm, grad_arena, lo, stream), "cnn_allreduce_grads");
+        must(cnn_sgd_update_keep(param_arena, grad_arena, lo, learning_rate, scale, param_prev, stream), "cnn_sgd_update_keep");
+        block_conv->prepare_own_filters();
+    }
+    must(cnn_amd_side_stream_join(stream), "cnn_amd_side_stream_join");
+    grads_reduced = dp;
+    params_stepped = true;  // (filters_prepared stays true: every image above was made from the updated parameters)
+    return true;
 }
 
 // cnn.cpp:79-90 without leaving the device
@@ -325,16 +452,40 @@ void Sequential::train_step(const std::vector<tensor>& input, const int* labels_
         loss_batch = B;
     }
     if (print_info) input[0]->print_shape();
-    if (finalized && fuse_layers && !filters_prepared) prepare_filters();
+    if (finalized && fuse_layers && !filters_prepared) {
+        flush_deferred();  // (a full re-preparation rewrites filter images a pending data gradient may read)
+        prepare_filters();
+    }
+    params_stepped = false;
     const bool was_lazy = lazy_host_sync;
     lazy_host_sync = true;
     std::vector<tensor> output(input);
     const bool fused_head = fuse_layers && head->loss_head_supported();
     for (const auto& layer : layers_sequence) {
+        // the previous step's deferred data gradient starts behind this layer's forward kernel, on its own stream
+        const bool release_here = pending_dgrad.valid && layer.get() == release_after;
+        if (release_here) must(cnn_amd_publish_next_kernel(stream), "cnn_amd_publish_next_kernel");
         if (layer.get() == head && fused_head)
             output = head->forward_loss_head(output, labels_dev, loss_probs.base, loss_delta.base, loss_terms);
         else
             output = layer->forward(output);
+        if (release_here) {
+            if (defer_stream == nullptr) {
+                must(cnn_stream_create(&defer_stream), "cnn_stream_create");
+                must(cnn_event_create(&ev_defer_done), "cnn_event_create");
+            }
+            if (cnn_amd_published_is_last(stream)) {
+                must(cnn_amd_wait_published(defer_stream), "cnn_amd_wait_published");
+            } else {
+                if (ev_tail == nullptr) must(cnn_event_create(&ev_tail), "cnn_event_create");
+                must(cnn_event_record(ev_tail, stream), "cnn_event_record");
+                must(cnn_stream_wait_event(defer_stream, ev_tail), "cnn_stream_wait_event");
+            }
+            block_conv->launch_deferred_dgrad(pending_dgrad, defer_stream);
+            must(cnn_event_record(ev_defer_done, defer_stream), "cnn_event_record");
+            pending_dgrad.valid = false;
+            defer_in_flight = true;
+        }
         if (print_info) output[0]->print_shape();
     }
     lazy_host_sync = was_lazy;
@@ -345,6 +496,25 @@ void Sequential::train_step(const std::vector<tensor>& input, const int* labels_
     loss_in_terms = fused_head;
     loss_last_B = B;
     std::vector<tensor> delta(loss_delta.views.begin(), loss_delta.views.begin() + B);
+    if (pending_dgrad.valid) flush_deferred();  // (never released: no release layer in this pass)
+    if (block_conv != nullptr && block_conv->pool_fused_pending() && release_after != nullptr) {
+        // backward walk with the fused tail at the front block (see fused_tail)
+        for (auto layer = layers_sequence.rbegin(); layer != layers_sequence.rend(); ++layer) {
+            if (layer->get() == behind_block && defer_in_flight) {
+                // the deferred data gradient of the PREVIOUS step reads d(pool output), which this layer's backward rewrites (only
+                // this stream's next kernel depends on it, not the weight gradient forked off beside it)
+                must(cnn_stream_wait_event_local(stream, ev_defer_done), "cnn_stream_wait_event_local");
+                defer_in_flight = false;
+            }
+            if (layer->get() == block_conv && fused_tail(delta, learning_rate)) return;
+            delta = (*layer)->backward(delta);
+            if (print_info) delta[0]->print_shape();
+        }
+        grads_reduced = false;
+        must(cnn_amd_side_stream_join(stream), "cnn_amd_side_stream_join");
+        update_gradients(learning_rate);
+        return;
+    }
     backward(delta);
     update_gradients(learning_rate);
 }

@@ -48,6 +48,8 @@ SIGNATURES = {
     "cnnh_net_update": (None, [C.c_void_p, C.c_float, C.c_float]),
     "cnnh_net_train_step_device_loss": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]),
     "cnnh_net_last_loss": (C.c_float, [C.c_void_p]),
+    "cnnh_net_flush": (None, [C.c_void_p]),
+    "cnnh_net_input_delta": (C.c_int, [C.c_void_p, _F, C.c_size_t]),
     "cnnh_net_layer_output": (C.c_int, [C.c_void_p, C.c_char_p, _F, C.c_size_t]),
     "cnnh_net_grad_cam": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, _F, C.c_size_t]),
 }
@@ -171,6 +173,18 @@ class HostNet:
 
     def last_loss(self):
         return float(self.lib.cnnh_net_last_loss(self.h))
+
+    def input_delta(self, shape):
+        """the delta with respect to the network input of the last backward pass (the first layer's data gradient)"""
+        out = np.empty(shape, np.float32)
+        rc = self.lib.cnnh_net_input_delta(self.h, _fp(out), out.size)
+        if rc != 0:
+            raise KeyError(f"input_delta: rc={rc}")
+        return out
+
+    def flush(self):
+        """Sequential::flush_deferred(): the data gradient train_step deferred into the next pass is launched / ordered now"""
+        self.lib.cnnh_net_flush(self.h)
 
     def layer_output(self, name, shape):
         out = np.empty(shape, np.float32)

@@ -122,6 +122,14 @@ int cnn_conv2d_backward_weight_pooled2_sgd(const cnn_conv2d_desc* d, const float
                                            float grad_scale, void* fwd_prepared, void* dgrad_prepared, void* workspace,
                                            size_t workspace_bytes, void* stream);
 
+/* ... and additionally stores the filters / biases as they were BEFORE the step into w_previous [Co][Ci*k*k] / bias_previous [Co]
+ * (either may be NULL).  The host container keeps that snapshot so that Layer::get_output() of a layer whose output tensor was fused
+ * away can still be re-computed with the parameters the last forward pass used (alexnet.cpp:97,105), after the step has moved them. */
+int cnn_conv2d_backward_weight_pooled2_sgd_keep(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask,
+                                                const float* pooled, float* gw, float* gb, float divisor, float* w, float* bias, float lr,
+                                                float grad_scale, void* fwd_prepared, void* dgrad_prepared, float* w_previous,
+                                                float* bias_previous, void* workspace, size_t workspace_bytes, void* stream);
+
 /* replaces conv2d.cpp:117-159: gw = (sum_b sum_pq dy*x)/divisor, gb = (sum_b sum_pq dy)/divisor.
  * The reference divides by the batch size per sample and accumulates (:148,:157); pass divisor = B of the
  * WHOLE batch (per-rank shard size under data parallelism, see cnn_sgd_update).  gb may be NULL.
@@ -169,6 +177,9 @@ int cnn_amd_flush_reduces(void* stream);
  * `stream`: the caller asserts that nothing else the weight gradient depends on was queued on that stream behind it. */
 int cnn_amd_publish_next_kernel(void* stream);
 int cnn_amd_wait_published(void* stream);
+/* != 0: a published kernel exists on `stream` and it is the LAST thing this thread queued on that stream through the library
+ * (kernels, copies, waits, collectives) -- i.e. cnn_amd_wait_published(other) is equivalent to record + wait right now. */
+int cnn_amd_published_is_last(void* stream);
 
 /* im2col + plain tiled GEMM: functional fallback kept ONLY for parity checks of the three calls above */
 size_t cnn_conv2d_im2col_workspace_bytes(const cnn_conv2d_desc* d);
@@ -320,6 +331,8 @@ int cnn_batchnorm2d_backward_from_sums(const float* x, float* dy, const float* g
  * (two roundings, no FMA); grad_scale = 1/G folds the data-parallel mean after an all-reduce(sum) over G ranks
  * whose kernels each divided by their local batch. */
 int cnn_sgd_update(float* params, const float* grads, size_t n, float lr, float grad_scale, void* stream);
+/* the same step; previous[i] (nullable) receives params[i] as it was before (see cnn_conv2d_backward_weight_pooled2_sgd_keep) */
+int cnn_sgd_update_keep(float* params, const float* grads, size_t n, float lr, float grad_scale, float* previous, void* stream);
 
 /* AlexNet::grad_cam (alexnet.cpp:107-140) from the feature map of the chosen layer, [B][C][H][W] on the device:
  *   weights[b][o] = mean_i feature[b][o][i];  cam[b] = ReLU(sum_o weights[b][o] * feature[b][o]);  cam = (cam - min) / (max - min)
@@ -383,6 +396,10 @@ int cnn_event_create(void** event);
 int cnn_event_destroy(void* event);
 int cnn_event_record(void* event, void* stream);
 int cnn_stream_wait_event(void* stream, void* event);
+/* like cnn_stream_wait_event, for a dependency that only concerns work queued on `stream` ITSELF: the caller asserts that nothing the
+ * library forks off `stream` afterwards (the weight-gradient side stream of cnn_conv2d_backward*) depends on the event, so a fork
+ * point published by the last kernel (cnn_amd_publish_next_kernel) stays valid.  cnn_stream_wait_event invalidates it. */
+int cnn_stream_wait_event_local(void* stream, void* event);
 /* ---- input staging (row n4: what DataLoader::generate_batch's host buffers -- pipeline.cpp:112-140 -- need in front of a device
  * consumer).  A stager owns `depth` (>= 2) page-locked host slots and as many device buffers of batch_bytes each, a copy stream
  * and the events that order producer -> H2D -> consumer -> producer:

@@ -213,11 +213,73 @@ def test_host_net_layer_fusion_is_bit_identical():
     assert res[0][0] == res[1][0]
 
 
+ALEXNET_OUTPUTS = [("conv_layer_1", (16, 111, 111)), ("relu_layer_1", (16, 111, 111)), ("max_pool_1", (16, 55, 55)),
+                   ("conv_layer_2", (32, 27, 27)), ("relu_layer_2", (32, 27, 27)), ("conv_layer_3", (64, 13, 13)),
+                   ("relu_layer_3", (64, 13, 13)), ("conv_layer_4", (128, 6, 6)), ("relu_layer_4", (128, 6, 6)), ("linear_1", (3, 1, 1))]
+
+
+@pytest.mark.gpu
+def test_fused_train_step_keeps_every_output_observable_and_grad_cam_identical():
+    """Sequential::train_step with the defaults -- first block pool-fused, its data gradient deferred into the next forward pass,
+    the step's tail (reductions, SGD, filter images) under the block's weight gradient -- against the same net with
+    fuse_pool_block off (every tensor written by the pass, plain backward -> SGD sequence): after every one of four steps the
+    parameters, gradients, losses, every layer's get_output(), the delta with respect to the input image (the deferred kernel's
+    result) and Grad-CAM on conv_layer_1 (alexnet.cpp:95-142: needs the fused-away tensor, after the SGD step moved the
+    filters) are equal bit for bit"""
+    import torch
+
+    from cnn_amd import hostapi
+
+    B = 4
+    x = uniform01(160, (B, 3, 224, 224))
+    labels = (np.arange(B) % 3).astype(np.int32)
+    p0 = normal_scaled(161, (111267,))
+    xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    lib = hostapi.load()
+    nets = []
+    try:
+        for on in (1, 0):
+            lib.cnnh_set_fuse_pool_block(on)
+            net = hostapi.HostAlexNet(3)
+            net.set_params(p0)
+            nets.append(net)
+        for step in range(4):
+            got = []
+            for on, net in zip((1, 0), nets):
+                lib.cnnh_set_fuse_pool_block(on)
+                net.train_step(xd, ld, 1e-3)
+                loss = net.last_loss()
+                outs = [net.layer_output(name, (B,) + shp) for name, shp in ALEXNET_OUTPUTS]
+                if step % 2 == 1:  # (odd steps: leave the deferred kernel pending for the next forward pass to release)
+                    dx = None
+                else:
+                    dx = net.input_delta((B, 3, 224, 224))
+                img, cam = net.grad_cam("conv_layer_1", (B, 111, 111)) if step == 2 else (None, None)
+                got.append((loss, net.get_params(), net.get_grads(), outs, dx, img, cam))
+            a, b = got
+            assert a[0] == b[0], (step, a[0], b[0])
+            assert np.array_equal(a[1], b[1]), f"step {step}: parameters"
+            if step != 2:  # (Grad-CAM's backward walk rewrites the gradients, alexnet.cpp:97-102 -- in both nets alike, but the
+                assert np.array_equal(a[2], b[2]), f"step {step}: gradients"  # plain net has run the block's dgrad, not compared)
+            for (name, _), u, v in zip(ALEXNET_OUTPUTS, a[3], b[3]):
+                assert np.array_equal(u.view(np.uint32), v.view(np.uint32)), f"step {step}: get_output({name})"
+            if a[4] is not None:
+                assert np.array_equal(a[4].view(np.uint32), b[4].view(np.uint32)), f"step {step}: delta w.r.t. the input"
+            if a[5] is not None:
+                assert np.array_equal(a[5], b[5]) and np.array_equal(a[6].view(np.uint32), b[6].view(np.uint32)), "Grad-CAM(conv_layer_1)"
+                assert a[5].max() > 0
+    finally:
+        lib.cnnh_set_fuse_pool_block(1)
+        for net in nets:
+            net.close()
+
+
 @pytest.mark.gpu
 def test_host_net_pool_block_fusion_is_bit_identical():
-    """architectures::fuse_pool_block (opt-in): Conv2D -> ReLU -> MaxPool2D as one kernel, backward from the pooled domain;
-    parameters, gradients, losses, the pool's output and the last block's output equal the default run bit for bit (the
-    first block's Conv2D / ReLU outputs are not materialised in that mode and are not compared)"""
+    """architectures::fuse_pool_block (the default): Conv2D -> ReLU -> MaxPool2D as one kernel, backward from the pooled domain,
+    ReLU-only outputs behind the later convolutions; parameters, gradients, losses and EVERY layer's get_output() -- including
+    the tensors that pass did not write, which Layer::get_output() re-computes with the parameters of the last forward pass
+    although an SGD step has run since (alexnet.cpp:97,105) -- equal the run that writes every tensor, bit for bit"""
     from cnn_amd import hostapi
 
     B = 3
@@ -231,11 +293,11 @@ def test_host_net_pool_block_fusion_is_bit_identical():
             net = hostapi.HostAlexNet(3)
             net.set_params(p0)
             losses = [net.train_step_host(x, labels, 1e-3)[0] for _ in range(3)]
-            res.append((losses, net.get_params(), net.get_grads(), net.layer_output("max_pool_1", (B, 16, 55, 55)),
-                        net.layer_output("relu_layer_4", (B, 128, 6, 6)), net.forward_host(x)))
+            outs = [net.layer_output(name, (B,) + shp) for name, shp in ALEXNET_OUTPUTS]
+            res.append((losses, net.get_params(), net.get_grads(), *outs, net.forward_host(x)))
             net.close()
         finally:
-            hostapi.load().cnnh_set_fuse_pool_block(0)
+            hostapi.load().cnnh_set_fuse_pool_block(1)
     for a, b in zip(res[0][1:], res[1][1:]):
         assert np.array_equal(a, b)
     assert res[0][0] == res[1][0]
@@ -246,7 +308,8 @@ def test_host_net_pool_block_fusion_is_bit_identical():
 def test_host_train_step_on_device_matches_the_reference_loop(pool_block):
     """Sequential::train_step (cnn.cpp:79-90 with the loss glue of func.cpp:16-73 as a kernel, nothing read back) against the
     reference's own loop through the same classes (forward -> host softmax / cross_entroy_backward -> backward -> update) and
-    against the oracle, three steps; also with the opt-in pool-block fusion bench.py's layer_api leg runs"""
+    against the oracle, three steps; with the default pool-block fusion (fused step tail, deferred first-layer data gradient) and
+    without it"""
     import torch
 
     from cnn_amd import hostapi
@@ -277,7 +340,7 @@ def test_host_train_step_on_device_matches_the_reference_loop(pool_block):
         dev_net.close()
         ref_net.close()
     finally:
-        hostapi.load().cnnh_set_fuse_pool_block(0)
+        hostapi.load().cnnh_set_fuse_pool_block(1)
 
 
 @pytest.mark.gpu
