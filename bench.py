@@ -291,7 +291,7 @@ def make_runner(config, api, batch, torch, capi, world, rank, comm, pool_block=T
         spec = stacks.STACKS[config]()
         net = hostapi.HostSequential(spec)
         net.set_params(stacks.he_init(net.layout, 1234))
-    if world > 1:
+    if comm is not None and api != "pynet":
         net.set_comm(comm.handle, world)  # train_step exchanges the gradient arena (two buckets for the reference net); BatchNorm2D runs as sync-BN
 
     def close():
@@ -395,6 +395,9 @@ def main():
     ap.add_argument("--no-conv-ns", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the extra legs of the default config (unfused C++ path, Python driver)")
     ap.add_argument("--no-stacks", action="store_true", help="skip the VGG-11 / ResNet-18-shaped legs of the default config")
+    ap.add_argument("--one-rank-comm", action="store_true",
+                    help="(profiling) single process with a ONE-rank RCCL communicator and the gradient exchange forced on: the step then "
+                         "contains the all-reduce kernels of the N > 1 path (sums are identities)")
     ap.add_argument("--no-pool-fusion", action="store_true", help="architectures::fuse_pool_block = false for the main leg (A/B)")
     ap.add_argument("--staged-input", action="store_true",
                     help="also time the reference net with every batch coming from (pinned) HOST memory through cnn_batch_stager_* "
@@ -430,6 +433,13 @@ def main():
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # plumbing: rendezvous, barrier, max-over-ranks
         comm, comm_info = init_comm(capi, torch, dist, world, rank)             # the data path's exchange: C ABI -> RCCL
+    elif args.one_rank_comm:
+        from cnn_amd.dp import RcclComm
+
+        comm = RcclComm(None, 1, 0)
+        capi.set_option("DP_FORCE_EXCHANGE", "1")
+        comm_info = {"ranks": 1, "rccl_version": comm.version, "entry": "cnn_allreduce_grads (include/cnn_amd.h)",
+                     "note": "one-rank communicator, exchange forced on (profiling aid, not a scaling number)"}
 
     run = make_runner(args.config, api, args.batch, torch, capi, world, rank, comm, pool_block=not args.no_pool_fusion)
     B = run["B"]
@@ -524,8 +534,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline() if small else cpu_baseline_stack(args.config)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if comm is not None:
         comm.destroy()
+    if world > 1:
         dist.destroy_process_group()
 
 

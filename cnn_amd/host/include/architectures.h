@@ -388,6 +388,7 @@ protected:
     // go out on the communication stream behind an event.  Small arenas (the reference net: 445 KB, latency-bound) stay one call.
     size_t bucket_floats = (size_t)2 << 20;
     void flush_bucket(size_t lo, size_t hi);
+    bool exchange_active() const;
     void wire();
     void bind(data_type* p, data_type* g);
     void prepare_filters();

@@ -338,8 +338,15 @@ void Sequential::set_comm(void* rccl_comm, int world) {
 
 // C1 of SURVEY.md section 2.1: ONE in-place fp32 sum over the flat gradient arena (RCCL over xGMI), on the communication
 // stream, fenced against the compute stream by two events
+// a communicator with more than one rank -- or, for tests on one GPU, any communicator with the DP_FORCE_EXCHANGE switch set (the
+// sums are then identities and the step must equal the plain one bit for bit)
+bool Sequential::exchange_active() const {
+    if (comm == nullptr) return false;
+    return comm_world > 1 || cnn_amd_get_option("DP_FORCE_EXCHANGE", nullptr, 0) == 0;
+}
+
 void Sequential::allreduce_gradients() {
-    if (!comm || comm_world <= 1 || grads_reduced) return;
+    if (!exchange_active() || grads_reduced) return;
     assert(finalized && "data parallelism needs the flat gradient arena: call finalize()");
     must(cnn_event_record(ev_grads, stream), "cnn_event_record");
     must(cnn_stream_wait_event(comm_stream, ev_grads), "cnn_stream_wait_event");
@@ -354,7 +361,7 @@ void Sequential::update_gradients(const data_type learning_rate) {
         for (auto& layer : layers_sequence) layer->update_gradients(learning_rate);
         return;
     }
-    if (comm && comm_world > 1) {
+    if (exchange_active()) {
         allreduce_gradients();
         update_gradients(learning_rate, 1.f / (data_type)comm_world);
     } else {
@@ -387,7 +394,7 @@ bool Sequential::fused_tail(std::vector<tensor>& delta, const data_type learning
         return false;
     if (cnn_amd_get_option("NO_FUSED_TAIL", nullptr, 0) == 0) return false;  // (A/B switch)
     const size_t lo = block_conv->param_count();  // the block's convolution owns arena[0, lo)
-    const bool dp = comm != nullptr && comm_world > 1;
+    const bool dp = exchange_active();
     const data_type scale = dp ? 1.f / (data_type)comm_world : 1.f;
     if (ev_tail == nullptr) must(cnn_event_create(&ev_tail), "cnn_event_create");
     void* side = nullptr;

@@ -68,6 +68,40 @@ def test_container_with_a_one_rank_communicator_equals_the_plain_step(T):
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
 
 
+def test_two_bucket_exchange_of_the_fused_step_tail_with_one_rank(T, lib_option):
+    """the reference net's train step with a communicator (Sequential::fused_tail): bucket 1 -- everything behind conv_layer_1 --
+    is all-reduced on the side stream as soon as its reductions land, under conv_layer_1's weight gradient, followed by its SGD step
+    and filter images; bucket 2 -- conv_layer_1's 448 floats -- behind that kernel.  Forced on with ONE rank (DP_FORCE_EXCHANGE:
+    every sum is an identity): four steps must equal the plain fused step bit for bit; a bucket sent before its gradients are
+    final, or an SGD step that does not wait for its bucket, would show"""
+    from cnn_amd import hostapi
+    from cnn_amd.dp import RcclComm
+
+    B = 4
+    x = T.from_numpy(uniform01(92, (B, 3, 224, 224))).cuda()
+    labels = T.from_numpy((np.arange(B) % 3).astype(np.int32)).cuda()
+    p0 = (np.random.RandomState(93).standard_normal(111267) * 0.1).astype(np.float32)
+    comm = RcclComm(None, 1, 0)
+    outs = []
+    for use_comm in (False, True):
+        net = hostapi.HostAlexNet(3)
+        net.set_params(p0)
+        if use_comm:
+            net.set_comm(comm.handle, 1)
+            lib_option("DP_FORCE_EXCHANGE", "1")
+        losses = []
+        for _ in range(4):
+            net.train_step(x, labels, 1e-3)
+            losses.append(net.last_loss())
+        outs.append((losses, net.get_params(), net.get_grads(), net.input_delta((B, 3, 224, 224))))
+        net.close()
+        lib_option("DP_FORCE_EXCHANGE", None)
+    comm.destroy()
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert np.array_equal(a, b)
+
+
 def test_bucketed_exchange_path_with_one_rank(T, monkeypatch):
     """the bucketed all-reduce of big arenas (Sequential::backward: buckets go out on the communication stream while the backward
     pass is still running) exercised on one GPU: with a 1-rank communicator every bucket's sum is the identity, so the step must

@@ -7,17 +7,21 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+# (the default command also runs a few steps of configs[3] / [4]: the first trace therefore holds their kernels too)
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch --output-format csv -- $BENCH --no-conv-ns --no-layer-api > /dev/null 2> $OUT/pmc_fetch.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o write --output-format csv -- $BENCH --no-conv-ns --no-layer-api > /dev/null 2> $OUT/pmc_write.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch --output-format csv -- $BENCH --no-conv-ns --no-extra-legs --no-stacks > /dev/null 2> $OUT/pmc_fetch.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o write --output-format csv -- $BENCH --no-conv-ns --no-extra-legs --no-stacks > /dev/null 2> $OUT/pmc_write.log
 for CFG in vgg11 resnet18; do
   rocprofv3 --kernel-trace --stats -d $OUT/trace_$CFG -o bench --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_${CFG}_under_rocprof.json 2> $OUT/trace_$CFG.log
 done
 cd $GRAFT_REPO_ROOT
 python tools/pmc_traffic.py $OUT $OUT/hbm_traffic.json
 # timeline of one steady-state step of the HEADLINE leg (no layer-api / conv_ns legs in that process)
-(cd /tmp && rocprofv3 --kernel-trace -d $OUT/trace_step -o step --output-format csv -- $BENCH --no-conv-ns --no-layer-api > /dev/null 2> $OUT/trace_step.log)
+(cd /tmp && rocprofv3 --kernel-trace -d $OUT/trace_step -o step --output-format csv -- $BENCH --no-conv-ns --no-extra-legs --no-stacks > /dev/null 2> $OUT/trace_step.log)
 python tools/step_timeline.py $(find $OUT/trace_step -name "*kernel_trace.csv" | head -1) 3 > $OUT/step_timeline.txt
+# the same step with a ONE-rank RCCL communicator and the exchange forced on: where do the two all-reduce kernels sit?
+(cd /tmp && rocprofv3 --kernel-trace -d $OUT/trace_step_comm -o step --output-format csv -- $BENCH --no-conv-ns --no-extra-legs --no-stacks --one-rank-comm > $OUT/bench_one_rank_comm.json 2> $OUT/trace_step_comm.log)
+python tools/step_timeline.py $(find $OUT/trace_step_comm -name "*kernel_trace.csv" | head -1) 3 > $OUT/step_timeline_one_rank_comm.txt
 # plain (unprofiled) runs of the same commands: the numbers the profiles are read against
 python bench.py --steps 100 --warmup 20 --staged-input --breakdown > $OUT/bench_alexnet.json 2> $OUT/bench_alexnet_breakdown.txt
 python bench.py --config vgg11 --breakdown > $OUT/bench_vgg11.json 2> $OUT/bench_vgg11_breakdown.txt

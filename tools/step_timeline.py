@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Timeline of one steady-state train step from a rocprofv3 --kernel-trace CSV: start offset, duration and queue of every
-kernel between two consecutive sgd_vec launches (the last kernel of a step), plus how long the GPU was busy / idle.
-usage: step_timeline.py <bench_kernel_trace.csv> [step_index_from_end=3]"""
+kernel between two consecutive launches of the step's LAST kernel (first_layer_finish in the fused step tail, else sgd_vec), plus
+how long the GPU was busy / idle.
+usage: step_timeline.py <bench_kernel_trace.csv> [step_index_from_end=3] [delimiter kernel prefix]"""
 import csv
 import re
 import sys
@@ -12,12 +13,13 @@ for r in csv.DictReader(open(sys.argv[1])):
     name = re.sub(r"^void ", "", name).split("(")[0]
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
 rows.sort()
-ends = [i for i, r in enumerate(rows) if r[2].startswith("sgd_vec")]
+delim = sys.argv[3] if len(sys.argv) > 3 else ("first_layer_finish" if any(r[2].startswith("first_layer_finish") for r in rows) else "sgd_vec")
+ends = [i for i, r in enumerate(rows) if r[2].startswith(delim)]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 lo, hi = ends[-k - 1] + 1, ends[-k] + 1
 step = rows[lo:hi]
 t0 = rows[ends[-k - 1]][1]
-print(f"step of {len(step)} kernels, {(step[-1][1] - t0) / 1e3:.1f} us from the end of the previous sgd_vec to the end of this one")
+print(f"step of {len(step)} kernels, {(step[-1][1] - t0) / 1e3:.1f} us from the end of the previous {delim} to the end of this one")
 busy_until, idle = t0, 0
 for s, e, name, q, st in step:
     if s > busy_until:
