@@ -694,6 +694,162 @@ __global__ __launch_bounds__(kFinThreads) void first_layer_finish(const float* _
     if (dgrad_img) pack_dgrad_3_16_3_2_body(wl, dgrad_img, threadIdx.x);
 }
 
+// ---- the same data gradient with the pooled-domain operands staged through LDS (round 3) ----------------------------------------
+// conv_dgrad_pool_pk above is bound by its LOAD INSTRUCTIONS, not by bytes: every lane fetches the four windows around its 4x4 block
+// of dx itself -- 4 x (dpool, mask) x 16 channels = 128 four-byte loads per lane, and every window is fetched by four different
+// lanes (253 MB algorithmic, 85 us = 0.37 of the HBM peak, fetch at 1.0x because the duplicates hit L1/L2 -- but they all pass
+// through the texture-address path).  Here a workgroup item = kDR block rows x <= kDSeg block columns of one image: its
+// (kDR + 1) x 64 window tile of every channel is fetched ONCE per workgroup with coalesced row loads (raw buffer loads: a window
+// outside the pooled plane, or a slot this item does not need, is an out-of-range offset = 0 -- no pad handling), parked in LDS as
+// [array][channel][window row][slot], and the lanes pick their 2 x 2 windows with two ds_read2_b32 per array and channel
+// (consecutive lanes -> consecutive banks).  40 row loads per wave and item instead of 128 per lane; each window row is fetched by
+// at most two items.  Wave w owns block row bh0 + w, lane l block column bw0 + l; arithmetic, FMA order and stores are those of
+// conv_dgrad_pool_pk: dx is bit-identical.
+constexpr int kDR = 4;     // block rows per item = waves per workgroup
+constexpr int kDSeg = 62;  // block columns per item (slots 0 .. 62 of a 64-slot row = window columns bw0 - 1 .. bw0 + 61)
+template <bool RM>
+__global__ __launch_bounds__(kBlock) void conv_dgrad_pool_lds_3_16_3_2(const float* __restrict__ dpool, const int32_t* __restrict__ pmask,
+                                                                       const float* __restrict__ pooled, const v2f* __restrict__ wp,
+                                                                       float* __restrict__ dx, int B, int H, int W, int Ho, int Wo,
+                                                                       int ngroups, int nsegs, unsigned m_gs, unsigned m_seg) {
+    constexpr int CO = 16, CI = 3, NA = RM ? 3 : 2, ROWS = kDR + 1;
+    static_assert(kDR == kWaves, "one block row per wave");
+    __shared__ float tile[NA][CO][ROWS][64];
+    const int U = (H + 1) / 2, V = (W + 1) / 2, U2 = (U + 1) / 2, V2 = (V + 1) / 2;
+    const int PHo = Ho / 2, PWo = Wo / 2, pplane = PHo * PWo, plane = Ho * Wo;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pbytes = (int)((unsigned)B * CO * pplane * 4u);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dpool, 0, pbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)pmask, 0, pbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(RM ? pooled : dpool), 0, pbytes, 0x00020000);
+    const int item = (int)xcd_swizzle(blockIdx.x, gridDim.x);
+    const int gs = ngroups * nsegs;
+    const int b = fast_div(item, m_gs, gs);
+    const int rem = item - b * gs;
+    const int grp = fast_div(rem, m_seg, nsegs), sg = rem - grp * nsegs;
+    const int bh0 = grp * kDR, bw0 = sg * kDSeg;
+    // ---- stage: (channel, tile row) pairs dealt to the waves; slot l of a row = window column bw0 - 1 + l ----
+    {
+        const int wc = bw0 - 1 + lane;
+        const bool cok = wc >= 0 && wc < PWo && lane <= kDSeg;
+        constexpr int PER = CO * ROWS / kWaves;  // 20
+        float vd[PER], vm[PER], vp[RM ? PER : 1];
+#pragma unroll
+        for (int jj = 0; jj < PER; ++jj) {
+            const int j = jj * kWaves + wave;
+            const int ch = j / ROWS, r = j - ch * ROWS;
+            const int wr = bh0 - 1 + r;
+            const unsigned off = (cok && wr >= 0 && wr < PHo) ? (unsigned)(wr * PWo + wc) * 4u : kBufOOB;
+            const int so = (b * CO + ch) * pplane * 4;
+            vd[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, (int)off, so, 0));
+            vm[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, (int)off, so, 0));
+            if constexpr (RM) vp[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (int)off, so, 0));
+        }
+#pragma unroll
+        for (int jj = 0; jj < PER; ++jj) {
+            const int j = jj * kWaves + wave;
+            const int ch = j / ROWS, r = j - ch * ROWS;
+            tile[0][ch][r][lane] = vd[jj];
+            tile[1][ch][r][lane] = vm[jj];
+            if constexpr (RM) tile[2][ch][r][lane] = vp[jj];
+        }
+    }
+    __syncthreads();
+    const int bh = bh0 + wave, bw = bw0 + lane;
+    if (bh >= U2) return;  // (no barrier below)
+    const bool live = lane < kDSeg && bw < V2;
+    const int e00 = (2 * bh - 1) * Wo + (2 * bw - 1);  // flat index (within a channel) of D[0][0]
+    v2f acc[4][6];
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[sb][k] = v2f{0.f, 0.f};
+    const int l1 = lane < 63 ? lane + 1 : 63;  // (lane 63 is never live)
+#pragma unroll 2
+    for (int ch = 0; ch < CO; ++ch) {
+        // windows (bh-1 | bh) x (bw-1 | bw) = tile rows wave, wave + 1 x slots lane, lane + 1
+        float g[4], pl[4];
+        int mk[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int r = wave + (w >> 1), sl = (w & 1) ? l1 : lane;
+            g[w] = tile[0][ch][r][sl];
+            mk[w] = __builtin_bit_cast(int, tile[1][ch][r][sl]);
+            if constexpr (RM) pl[w] = tile[2][ch][r][sl];
+            else pl[w] = 1.f;
+        }
+        float D[3][3];
+        const int cbase = ch * plane + e00;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) g[w] = (pl[w] <= 0.f) ? 0.f : g[w];  // relu.cpp:38
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int w = ((i + 1) >> 1) * 2 + ((j + 1) >> 1);
+                D[i][j] = (mk[w] == cbase + i * Wo + j) ? g[w] : 0.f;  // pool2d.cpp:96-107
+            }
+        asm volatile("" ::: "memory");  // (keeps the weight s_loads of all channels from being hoisted, see above)
+        const v2f* q = wp + ch * 16;
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+            const int sr = sb >> 1, sc = sb & 1;
+            const v2f a = {D[sr + 1][sc + 1], D[sr + 1][sc + 1]}, bq = {D[sr + 1][sc], D[sr + 1][sc]},
+                      c = {D[sr][sc + 1], D[sr][sc + 1]}, e = {D[sr][sc], D[sr][sc]};
+            v2f& P0 = acc[sb][0]; v2f& P1 = acc[sb][1]; v2f& P2 = acc[sb][2]; v2f& P3 = acc[sb][3];
+            v2f& Q0 = acc[sb][4]; v2f& Q1 = acc[sb][5];
+            P0 = __builtin_elementwise_fma(q[0], a, P0);
+            P1 = __builtin_elementwise_fma(q[1], a, P1);
+            P2 = __builtin_elementwise_fma(q[2], a, P2);
+            P3 = __builtin_elementwise_fma(q[3], a, P3);
+            Q0 = __builtin_elementwise_fma(q[4], a, Q0);
+            Q1 = __builtin_elementwise_fma(q[5], a, Q1);
+            P0 = __builtin_elementwise_fma(q[6], bq, P0);
+            P2 = __builtin_elementwise_fma(q[7], bq, P2);
+            Q0 = __builtin_elementwise_fma(q[8], bq, Q0);
+            Q1 = __builtin_elementwise_fma(q[9], bq, Q1);
+            P0 = __builtin_elementwise_fma(q[10], c, P0);
+            P1 = __builtin_elementwise_fma(q[11], c, P1);
+            Q0 = __builtin_elementwise_fma(q[12], c, Q0);
+            P0 = __builtin_elementwise_fma(q[13], e, P0);
+            Q0 = __builtin_elementwise_fma(q[14], e, Q0);
+        }
+    }
+    if (!live) return;
+    // dx[ci][4bh + 2sr + ph][4bw + 2sc + pw]: one row of the 4x4 block = the (pw0, pw1) pairs of sub-blocks sc = 0, 1
+    float* dxb = dx + (size_t)b * CI * H * W;
+    const bool quad = (W & 3) == 0;
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int sr = rr >> 1, ph = rr & 1, h = 4 * bh + rr;
+            float v[4];
+#pragma unroll
+            for (int sc = 0; sc < 2; ++sc) {
+                const v2f* A = acc[sr * 2 + sc];
+                if (ci == 2) {
+                    v[2 * sc] = ph ? A[5].x : A[4].x;
+                    v[2 * sc + 1] = ph ? A[5].y : A[4].y;
+                } else {
+                    const v2f lo = ph ? A[2] : A[0], hi = ph ? A[3] : A[1];
+                    v[2 * sc] = ci ? lo.y : lo.x;
+                    v[2 * sc + 1] = ci ? hi.y : hi.x;
+                }
+            }
+            if (h >= H) continue;
+            float* row = dxb + ((size_t)ci * H + h) * W + 4 * (size_t)bw;
+            if (quad) {
+                *(float4*)row = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (4 * bw + k < W) row[k] = v[k];
+            }
+        }
+}
+
 typedef int v2i __attribute__((ext_vector_type(2)));
 
 template <bool RELU>
@@ -1163,6 +1319,22 @@ int direct_conv_dgrad_pooled(const cnn_conv2d_desc* d, const float* dpool, const
     unsigned grid = wave_grid(witems);
     if (const OptVal e = CNN_OPT_VAL("DX0_GRID"))
         if (atoi(e) > 0 && (unsigned)atoi(e) < grid) grid = (unsigned)atoi(e);
+    // LDS-staged variant (default; DGRAD_POOL_LDS=0: the per-lane-load kernel): one item per workgroup
+    const int ngroups = (U2 + kDR - 1) / kDR, nsegs = (V2 + kDSeg - 1) / kDSeg;
+    const long long nitems = (long long)d->B * ngroups * nsegs;
+    if (CNN_OPT_INT("DGRAD_POOL_LDS", 1) != 0 && nitems < (1ll << 31)) {
+        if (pooled)
+            CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>+pool",
+                        (conv_dgrad_pool_lds_3_16_3_2<true><<<(unsigned)nitems, kBlock, 0, s>>>(dpool, mask, pooled, (const v2f*)ws, dx, d->B, d->H, d->W, Ho,
+                                                                                                 Wo, ngroups, nsegs, div_magic(ngroups * nsegs), div_magic(nsegs))),
+                        CONV_TAG(d));
+        else
+            CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>+poolm",
+                        (conv_dgrad_pool_lds_3_16_3_2<false><<<(unsigned)nitems, kBlock, 0, s>>>(dpool, mask, nullptr, (const v2f*)ws, dx, d->B, d->H, d->W,
+                                                                                                  Ho, Wo, ngroups, nsegs, div_magic(ngroups * nsegs), div_magic(nsegs))),
+                        CONV_TAG(d));
+        return CNN_AMD_OK;
+    }
     if (pooled)
         CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>+pool",
                     (conv_dgrad_pool_pk_3_16_3_2<2, true><<<grid, kBlock, 0, s>>>(dpool, mask, pooled, (const v2f*)ws, dx, d->B, d->H,

@@ -405,6 +405,17 @@ bool Sequential::fused_tail(std::vector<tensor>& delta, const data_type learning
         must(cnn_event_record(ev_tail, stream), "cnn_event_record");
         must(cnn_stream_wait_event(side, ev_tail), "cnn_stream_wait_event");
     }
+    // DX0_AT_TAIL (A/B switch): the block's data gradient starts right here, beside its weight gradient (they read the same dpool /
+    // mask lines), on the third stream -- instead of in the next forward pass
+    const bool dgrad_now = cnn_amd_get_option("DX0_AT_TAIL", nullptr, 0) == 0;
+    if (dgrad_now) {
+        if (defer_stream == nullptr) {
+            must(cnn_stream_create(&defer_stream), "cnn_stream_create");
+            must(cnn_event_create(&ev_defer_done), "cnn_event_create");
+        }
+        if (cnn_amd_published_is_last(stream)) must(cnn_amd_wait_published(defer_stream), "cnn_amd_wait_published");
+        else must(cnn_stream_wait_event(defer_stream, ev_tail), "cnn_stream_wait_event");
+    }
     must(cnn_amd_flush_reduces(side), "cnn_amd_flush_reduces");
     if (n_params > lo) {
         // bucket 1 of the exchange: everything behind the block is final ~one weight-gradient kernel before the step ends
@@ -432,6 +443,12 @@ bool Sequential::fused_tail(std::vector<tensor>& delta, const data_type learning
     }
     // compute stream: the block's weight gradient (+ its share of the tail)
     pending_dgrad = block_conv->backward_weight_pooled(delta, /*fused_sgd=*/!dp, learning_rate, scale);
+    if (dgrad_now) {
+        block_conv->launch_deferred_dgrad(pending_dgrad, defer_stream);
+        must(cnn_event_record(ev_defer_done, defer_stream), "cnn_event_record");
+        pending_dgrad.valid = false;
+        defer_in_flight = true;
+    }
     if (dp) {  // bucket 2: this layer's few floats
         must(cnn_allreduce_grads(comm, grad_arena, lo, stream), "cnn_allreduce_grads");
         must(cnn_sgd_update_keep(param_arena, grad_arena, lo, learning_rate, scale, param_prev, stream), "cnn_sgd_update_keep");

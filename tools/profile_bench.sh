@@ -21,7 +21,7 @@ python tools/pmc_traffic.py $OUT $OUT/hbm_traffic.json
 python tools/step_timeline.py $(find $OUT/trace_step -name "*kernel_trace.csv" | head -1) 3 > $OUT/step_timeline.txt
 # the same step with a ONE-rank RCCL communicator and the exchange forced on: where do the two all-reduce kernels sit?
 (cd /tmp && rocprofv3 --kernel-trace -d $OUT/trace_step_comm -o step --output-format csv -- $BENCH --no-conv-ns --no-extra-legs --no-stacks --one-rank-comm > $OUT/bench_one_rank_comm.json 2> $OUT/trace_step_comm.log)
-python tools/step_timeline.py $(find $OUT/trace_step_comm -name "*kernel_trace.csv" | head -1) 3 > $OUT/step_timeline_one_rank_comm.txt
+python tools/step_timeline.py $(find $OUT/trace_step_comm -name "*kernel_trace.csv" | head -1) 3 start:conv_fwd_pool_pk > $OUT/step_timeline_one_rank_comm.txt
 # plain (unprofiled) runs of the same commands: the numbers the profiles are read against
 python bench.py --steps 100 --warmup 20 --staged-input --breakdown > $OUT/bench_alexnet.json 2> $OUT/bench_alexnet_breakdown.txt
 python bench.py --config vgg11 --breakdown > $OUT/bench_vgg11.json 2> $OUT/bench_vgg11_breakdown.txt

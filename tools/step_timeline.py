@@ -14,7 +14,11 @@ for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
 rows.sort()
 delim = sys.argv[3] if len(sys.argv) > 3 else ("first_layer_finish" if any(r[2].startswith("first_layer_finish") for r in rows) else "sgd_vec")
-ends = [i for i, r in enumerate(rows) if r[2].startswith(delim)]
+if delim.startswith("start:"):  # delimit by the FIRST kernel of a step instead (e.g. start:conv_fwd_pool_pk)
+    delim = delim[6:]
+    ends = [i - 1 for i, r in enumerate(rows) if r[2].startswith(delim) and i > 0]
+else:
+    ends = [i for i, r in enumerate(rows) if r[2].startswith(delim)]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 lo, hi = ends[-k - 1] + 1, ends[-k] + 1
 step = rows[lo:hi]
