@@ -69,6 +69,7 @@ SIGNATURES = {
     "cnn_amd_flush_reduces": (C.c_int, [_P]),
     "cnn_grad_cam": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "cnn_amd_publish_next_kernel": (C.c_int, [_P]),
+    "cnn_linear_forward_softmax_xent_dx": (C.c_int, [_P] * 9 + [C.c_int] * 4 + [_P]),
     "cnn_amd_wait_published": (C.c_int, [_P]),
     "cnn_amd_published_is_last": (C.c_int, [_P]),
     "cnn_conv2d_im2col_workspace_bytes": (C.c_size_t, [_D]),

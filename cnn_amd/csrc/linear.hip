@@ -67,14 +67,25 @@ __device__ __forceinline__ float clamped_exp_l(float v) {
 // linear_fwd (out <= kOutTile) + the sample's softmax / cross-entropy (func.cpp:16-33, 60-71) in the same workgroup:
 // probs (nullable), delta = probs - onehot, and the sample's loss term log(p[label]) into loss_terms[b].  The ordered sum
 // over samples (the reference's order) is a separate, on-demand reduction: cnn_loss_from_terms.
-template <bool BATCH>
+// DX != 0 (round 3): the workgroup also writes its sample's row of LinearLayer::backward's data gradient (linear.cpp:73-90),
+// dx[b][i] = sum_j delta[b][j] * W[i][j] -- it needs nothing but this sample's delta and the W rows the threads hold anyway --
+// with the arithmetic of linear_bwd_fused (same products, same order: bit-identical); DX == 2 also applies the ReLU::backward of
+// the layer in front (x <= 0 ? 0 : dx).  The critical path of a train step then has ONE head kernel between the last forward
+// convolution and the first data gradient; the weight / bias gradient of the layer (which needs every sample's delta) runs
+// beside the convolutions' weight gradients (linear_bwd_fused<.., false>).
+template <bool BATCH, int DX>
 __global__ __launch_bounds__(kBlock) void linear_fwd_softmax_xent(const float* __restrict__ x, const float* __restrict__ w,
                                                                   const float* __restrict__ bias, const int32_t* __restrict__ labels,
                                                                   float* __restrict__ y, float* __restrict__ probs,
                                                                   float* __restrict__ delta, float* __restrict__ loss_terms, int in,
-                                                                  int out) {
+                                                                  int out, float* __restrict__ dx) {
     __shared__ float part[kBlock / kWave][kOutTile];
     __shared__ float logit[kOutTile];
+    __shared__ float dl[kOutTile];
+    constexpr int UK = 18;
+    float xk[UK];  // (BATCH && out == 3 && in == UK * kBlock: the thread's x values and W rows stay in registers for the dx pass)
+    w3 wk[UK];
+    bool kept = false;
     const int b = blockIdx.x;
     const float* xb = x + (size_t)b * in;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -86,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void linear_fwd_softmax_xent(const float* _
         // the reference net's head: every load of 18 iterations (one 4-byte x value + one 12-byte W row each) is issued before
         // the first FMA -- in the train step this kernel shares the chip with an HBM-bound kernel, and each dependent round
         // trip costs microseconds there.  Same products, same order as the generic loop below.
-        constexpr int U = 18;
+        constexpr int U = UK;
         for (; i + (U - 1) * kBlock < in; i += U * kBlock) {
             float xv[U];
             w3 wv[U];
@@ -100,6 +111,14 @@ __global__ __launch_bounds__(kBlock) void linear_fwd_softmax_xent(const float* _
                 acc[0] = __builtin_fmaf(xv[u], wv[u].a, acc[0]);  // explicit: contraction must not depend on the loop shape
                 acc[1] = __builtin_fmaf(xv[u], wv[u].b, acc[1]);
                 acc[2] = __builtin_fmaf(xv[u], wv[u].c, acc[2]);
+            }
+            if (DX != 0 && in == U * kBlock) {
+                kept = true;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    xk[u] = xv[u];
+                    wk[u] = wv[u];
+                }
             }
         }
     }
@@ -139,9 +158,34 @@ __global__ __launch_bounds__(kBlock) void linear_fwd_softmax_xent(const float* _
             const float yv = (i == label) ? 1.f : 0.f;
             if (probs) probs[(size_t)b * out + i] = pr;
             delta[(size_t)b * out + i] = pr - yv;
+            if (DX != 0) dl[i] = pr - yv;
             term += logf(pr) * yv;
         }
         loss_terms[b] = term;
+    }
+    if constexpr (DX != 0) {
+        __syncthreads();
+        float* dxb = dx + (size_t)b * in;
+        if (kept) {  // out == 3, in == 18 * 256: no loads at all
+            const float d0 = dl[0], d1 = dl[1], d2 = dl[2];
+#pragma unroll
+            for (int u = 0; u < UK; ++u) {
+                float sj = 0.f;  // (linear_bwd_fused's expression, term by term)
+                sj += d0 * wk[u].a;
+                sj += d1 * wk[u].b;
+                sj += d2 * wk[u].c;
+                dxb[threadIdx.x + u * kBlock] = (DX == 2 && xk[u] <= 0.f) ? 0.f : sj;
+            }
+        } else {
+            for (int i2 = threadIdx.x; i2 < in; i2 += kBlock) {
+                const float* wr = w + (size_t)i2 * out;
+                float sj = 0.f;
+#pragma unroll
+                for (int j = 0; j < kOutTile; ++j)
+                    if (j < out) sj += dl[j] * wr[j];
+                dxb[i2] = (DX == 2 && xb[i2] <= 0.f) ? 0.f : sj;
+            }
+        }
     }
 }
 
@@ -224,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void linear_bwd_x(const float* __restrict__
 // RELU: x is the output of the ReLU layer feeding this layer; dx is stored as (x <= 0 ? 0 : dx) = that layer's backward pass
 // (relu.cpp:38) -- the mask value is the x element this thread has loaded anyway.
 constexpr int kFG = 16;
-template <bool RELU>
+template <bool RELU, bool WRITE_DX = true>  // WRITE_DX = false: weight / bias gradient only (dx came from the head kernel)
 __global__ __launch_bounds__(kNeur * kFG) void linear_bwd_fused(const float* __restrict__ x, const float* __restrict__ dy,
                                                                const float* __restrict__ w, float* __restrict__ gw,
                                                                float* __restrict__ gb, float* __restrict__ dx, int B,
@@ -253,7 +297,7 @@ __global__ __launch_bounds__(kNeur * kFG) void linear_bwd_fused(const float* __r
                 acc[j] += xv * dj;
                 s += dj * wr[j];
             }
-        if (live) dx[(size_t)b * in + i] = (RELU && xv <= 0.f) ? 0.f : s;
+        if (WRITE_DX && live) dx[(size_t)b * in + i] = (RELU && xv <= 0.f) ? 0.f : s;
         if (blockIdx.x == 0 && il < out) bsum += d[il];  // lane j of every group: bias partial of output j
     }
 #pragma unroll
@@ -296,6 +340,12 @@ static int linear_backward_impl(const float* x, const float* dy, const float* w,
     CNN_REQUIRE(B > 0 && in > 0 && out > 0, "cnn_linear_backward: B=%d in=%d out=%d", B, in, out);
     CNN_REQUIRE(B <= 65535, "cnn_linear_backward: B=%d exceeds the grid.y limit", B);
     hipStream_t s = as_stream(stream);
+    if (gw && gb && !dx && x && w && out <= kOutTile) {  // the gradients of the parameters alone, in linear_bwd_fused's summation order
+        CNN_KLAUNCH(s, "linear_bwd_fused/wb",
+                    (linear_bwd_fused<false, false><<<dim3(ceil_div(in, kNeur)), dim3(kNeur * kFG), 0, s>>>(x, dy, w, gw, gb, nullptr, B, in, out, divisor)),
+                    "B%d in%d out%d", B, in, out);
+        return CNN_AMD_OK;
+    }
     if (gw && gb && dx && x && w && out <= kOutTile) {
         if (relu_below)
             CNN_KLAUNCH(s, "linear_bwd_fused+relu",
@@ -334,11 +384,29 @@ int cnn_linear_forward_softmax_xent(const float* x, const float* w, const float*
     const OptVal e = CNN_OPT_VAL("NO_HEAD_BATCH");  // A/B switch: the plain 6-deep loop for every layer width
     if (e && atoi(e) != 0)
         CNN_KLAUNCH(s, "linear_fwd+softmax_xent",
-                    (linear_fwd_softmax_xent<false><<<B, kBlock, 0, s>>>(x, w, bias, labels, logits, probs, delta, loss_terms, in, out)),
+                    (linear_fwd_softmax_xent<false, 0><<<B, kBlock, 0, s>>>(x, w, bias, labels, logits, probs, delta, loss_terms, in, out, nullptr)),
                     "B%d in%d out%d", B, in, out);
     else
         CNN_KLAUNCH(s, "linear_fwd+softmax_xent",
-                    (linear_fwd_softmax_xent<true><<<B, kBlock, 0, s>>>(x, w, bias, labels, logits, probs, delta, loss_terms, in, out)),
+                    (linear_fwd_softmax_xent<true, 0><<<B, kBlock, 0, s>>>(x, w, bias, labels, logits, probs, delta, loss_terms, in, out, nullptr)),
+                    "B%d in%d out%d", B, in, out);
+    return CNN_AMD_OK;
+}
+
+int cnn_linear_forward_softmax_xent_dx(const float* x, const float* w, const float* bias, const int32_t* labels, float* logits,
+                                       float* probs, float* delta, float* loss_terms, float* dx, int relu_below, int B, int in, int out,
+                                       void* stream) {
+    CNN_REQUIRE(x && w && bias && labels && logits && delta && loss_terms && dx, "cnn_linear_forward_softmax_xent_dx: null pointer");
+    CNN_REQUIRE(B > 0 && in > 0 && out > 0 && out <= kOutTile, "cnn_linear_forward_softmax_xent_dx: B=%d in=%d out=%d (out <= %d)", B, in, out,
+                kOutTile);
+    hipStream_t s = as_stream(stream);
+    if (relu_below)
+        CNN_KLAUNCH(s, "linear_fwd+softmax_xent+dx+relu",
+                    (launch_pub(linear_fwd_softmax_xent<true, 2>, dim3(B), dim3(kBlock), 0, s, x, w, bias, labels, logits, probs, delta, loss_terms, in, out, dx)),
+                    "B%d in%d out%d", B, in, out);
+    else
+        CNN_KLAUNCH(s, "linear_fwd+softmax_xent+dx",
+                    (launch_pub(linear_fwd_softmax_xent<true, 1>, dim3(B), dim3(kBlock), 0, s, x, w, bias, labels, logits, probs, delta, loss_terms, in, out, dx)),
                     "B%d in%d out%d", B, in, out);
     return CNN_AMD_OK;
 }

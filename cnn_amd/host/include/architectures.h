@@ -257,6 +257,8 @@ private:
     int batch = 0;
     ReLU* relu_below = nullptr;  // the ReLU layer whose output is this layer's input: its backward pass is fused in
     bool publish_backward = false;
+    bool head_dx_done = false;   // this pass' data gradient was written by the loss-head kernel (forward_loss_head(with_dx))
+    void* ev_head = nullptr;
 
 public:
     void set_relu_below(ReLU* relu) { relu_below = relu; }  // addition (see architectures::fuse_layers)
@@ -264,8 +266,10 @@ public:
     // addition: forward + softmax + cross-entropy delta in ONE kernel (cnn_linear_forward_softmax_xent, out_channels <= 8):
     // labels_dev int32 [B]; delta_dev [B][out] receives p - onehot (func.cpp:56-73), loss_terms_dev [B] log p[label]
     bool loss_head_supported() const { return out_channels <= 8; }
+    // with_dx: the same kernel also writes this layer's data gradient (cnn_linear_forward_softmax_xent_dx: a sample's row needs only
+    // that sample's delta); backward() then only launches the weight / bias gradient, on the library's side stream
     std::vector<tensor> forward_loss_head(const std::vector<tensor>& input, const int* labels_dev, data_type* probs_dev,
-                                          data_type* delta_dev, data_type* loss_terms_dev);
+                                          data_type* delta_dev, data_type* loss_terms_dev, bool with_dx = false);
     int out_features() const { return out_channels; }
     LinearLayer(std::string _name, const int _in_channels, const int _out_channels);
     ~LinearLayer() override;

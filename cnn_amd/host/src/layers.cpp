@@ -779,6 +779,7 @@ LinearLayer::LinearLayer(std::string _name, const int _in_channels, const int _o
 }
 
 LinearLayer::~LinearLayer() {
+    if (ev_head) cnn_event_destroy(ev_head);
     if (owns_params) {
         cnn_device_free(params);
         cnn_device_free(grads);
@@ -830,7 +831,7 @@ std::vector<tensor> LinearLayer::forward(const std::vector<tensor>& input) {
 }
 
 std::vector<tensor> LinearLayer::forward_loss_head(const std::vector<tensor>& input, const int* labels_dev, data_type* probs_dev,
-                                                   data_type* delta_dev, data_type* loss_terms_dev) {
+                                                   data_type* delta_dev, data_type* loss_terms_dev, bool with_dx) {
     Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
     const int B = (int)input.size();
     delta_shape = input[0]->get_shape();
@@ -844,6 +845,19 @@ std::vector<tensor> LinearLayer::forward_loss_head(const std::vector<tensor>& in
     const data_type* x = batch_device_pointer(input, in_stage, name);
     saved_input = x;
     saved_input_tensors = input;
+    head_dx_done = false;
+    if (with_dx && B == batch) {
+        if (delta_buf.empty())
+            delta_buf.allocate(batch, std::get<0>(delta_shape), std::get<1>(delta_shape), std::get<2>(delta_shape), "linear_delta");
+        // (this kernel is now the last one in front of the next layer's weight-gradient fork: it carries the event)
+        if (publish_backward) must(cnn_amd_publish_next_kernel(stream), "cnn_amd_publish_next_kernel");
+        must(cnn_linear_forward_softmax_xent_dx(x, params, params + (size_t)in_channels * out_channels, labels_dev, out_buf.base, probs_dev,
+                                                delta_dev, loss_terms_dev, delta_buf.base, (relu_below != nullptr && fuse_layers) ? 1 : 0, B,
+                                                in_channels, out_channels, stream),
+             "cnn_linear_forward_softmax_xent_dx");
+        head_dx_done = true;
+        return output;
+    }
     must(cnn_linear_forward_softmax_xent(x, params, params + (size_t)in_channels * out_channels, labels_dev, out_buf.base, probs_dev,
                                          delta_dev, loss_terms_dev, B, in_channels, out_channels, stream),
          "cnn_linear_forward_softmax_xent");
@@ -858,6 +872,27 @@ std::vector<tensor> LinearLayer::backward(std::vector<tensor>& delta) {
     if (delta_buf.empty())
         delta_buf.allocate(batch, std::get<0>(delta_shape), std::get<1>(delta_shape), std::get<2>(delta_shape),
                            "linear_delta");
+    if (head_dx_done) {
+        // the data gradient (and the ReLU::backward in front) came out of the loss-head kernel; what is left needs every sample's
+        // delta and nobody on the critical path waits for it: weight / bias gradient on the library's side stream, like the
+        // convolutions' (ordered before the join / the step's tail)
+        head_dx_done = false;
+        void* side = nullptr;
+        must(cnn_amd_side_stream_get(&side), "cnn_amd_side_stream_get");
+        if (cnn_amd_published_is_last(stream)) {
+            must(cnn_amd_wait_published(side), "cnn_amd_wait_published");
+        } else {
+            if (ev_head == nullptr) must(cnn_event_create(&ev_head), "cnn_event_create");
+            must(cnn_event_record(ev_head, stream), "cnn_event_record");
+            must(cnn_stream_wait_event(side, ev_head), "cnn_stream_wait_event");
+        }
+        must(cnn_linear_backward(saved_input, dy, params, grads, grads + (size_t)in_channels * out_channels, nullptr, B, in_channels,
+                                 out_channels, (float)B, side),
+             "cnn_linear_backward");
+        if (relu_below != nullptr && fuse_layers) relu_below->fused_backward_done();
+        grads_ready = true;
+        return delta_buf.views;
+    }
     if (relu_below != nullptr && fuse_layers) {  // the input IS that ReLU's output: its backward mask in the same kernel
         if (publish_backward) must(cnn_amd_publish_next_kernel(stream), "cnn_amd_publish_next_kernel");
         must(cnn_linear_backward_relu(saved_input, dy, params, grads, grads + (size_t)in_channels * out_channels, delta_buf.base, B,

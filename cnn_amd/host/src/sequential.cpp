@@ -485,12 +485,13 @@ void Sequential::train_step(const std::vector<tensor>& input, const int* labels_
     lazy_host_sync = true;
     std::vector<tensor> output(input);
     const bool fused_head = fuse_layers && head->loss_head_supported();
+    const bool head_dx = fused_head && cnn_amd_get_option("NO_HEAD_DX", nullptr, 0) != 0;  // (A/B switch)
     for (const auto& layer : layers_sequence) {
         // the previous step's deferred data gradient starts behind this layer's forward kernel, on its own stream
         const bool release_here = pending_dgrad.valid && layer.get() == release_after;
         if (release_here) must(cnn_amd_publish_next_kernel(stream), "cnn_amd_publish_next_kernel");
         if (layer.get() == head && fused_head)
-            output = head->forward_loss_head(output, labels_dev, loss_probs.base, loss_delta.base, loss_terms);
+            output = head->forward_loss_head(output, labels_dev, loss_probs.base, loss_delta.base, loss_terms, head_dx);
         else
             output = layer->forward(output);
         if (release_here) {

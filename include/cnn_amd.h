@@ -377,6 +377,15 @@ int cnn_softmax_xent(const float* logits, const int32_t* labels, float* probs, f
  * cnn_linear_forward + cnn_softmax_xent. */
 int cnn_linear_forward_softmax_xent(const float* x, const float* w, const float* bias, const int32_t* labels, float* logits,
                                     float* probs, float* delta, float* loss_terms, int B, int in, int out, void* stream);
+/* ... and the data gradient of that layer in the same kernel: dx[b][i] = sum_j delta[b][j] * W[i][j] (linear.cpp:73-90; a sample's row
+ * needs only that sample's delta), relu_below != 0: followed by the ReLU::backward of the layer whose output is x (x <= 0 ? 0 : dx).
+ * Bit-identical to cnn_linear_forward_softmax_xent + the dx of cnn_linear_backward(_relu).  The layer's weight / bias gradient (which
+ * needs every sample's delta) is cnn_linear_backward(x, delta, w, gw, gb, NULL, ...): with dx == NULL it runs the same summation
+ * order as the three-output call, on any stream -- a train step then has ONE kernel between its last forward convolution and its
+ * first data gradient. */
+int cnn_linear_forward_softmax_xent_dx(const float* x, const float* w, const float* bias, const int32_t* labels, float* logits,
+                                       float* probs, float* delta, float* loss_terms, float* dx, int relu_below, int B, int in, int out,
+                                       void* stream);
 int cnn_loss_from_terms(const float* loss_terms, float* loss_sum, int B, void* stream);
 
 /* ---- device memory / transfer helpers (the host layer classes use only these) ------------------------ */

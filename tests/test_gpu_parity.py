@@ -940,6 +940,40 @@ def test_linear_forward_softmax_xent_fusion_is_bit_identical(T, B, n_in, n_out):
         assert np.array_equal(host(a).view(np.uint32), host(c).view(np.uint32))
 
 
+@pytest.mark.parametrize("relu", [0, 1], ids=["plain", "relu_below"])
+@pytest.mark.parametrize("B,n_in,n_out", [(256, 4608, 3), (7, 4608, 3), (5, 70, 8), (3, 33, 1), (4, 9216, 3)])
+def test_linear_head_with_data_gradient_is_bit_identical(T, B, n_in, n_out, relu):
+    """cnn_linear_forward_softmax_xent_dx (forward + loss head + the layer's data gradient in ONE kernel) and the parameter-only
+    cnn_linear_backward(dx = NULL) against the unfused trio cnn_linear_forward_softmax_xent + cnn_linear_backward(_relu): logits,
+    probabilities, delta, loss terms, dx, gW and gb bit for bit -- the 4608 -> 3 head with everything in registers, and the generic
+    widths (linear.cpp:33-90, func.cpp:16-73)"""
+    from cnn_amd import capi
+
+    lib = capi.load()
+    xh = uniform_pm1(820, (B, n_in))
+    if relu:
+        xh = np.maximum(xh, 0)  # a ReLU layer's output: zeros where its backward mask applies
+    x = dev(T, xh)
+    w, b = dev(T, normal_scaled(821, (n_in, n_out))), dev(T, normal_scaled(822, (n_out,)))
+    labels = dev(T, (np.arange(B) % n_out).astype(np.int32))
+    mk = lambda *shape: T.full(shape, 7.0, device="cuda")
+    logits0, probs0, delta0, terms0 = mk(B, n_out), mk(B, n_out), mk(B, n_out), mk(B)
+    capi.check(lib.cnn_linear_forward_softmax_xent(capi._ptr(x), capi._ptr(w), capi._ptr(b), capi._ptr(labels), capi._ptr(logits0),
+                                                   capi._ptr(probs0), capi._ptr(delta0), capi._ptr(terms0), B, n_in, n_out, capi._stream()),
+               "cnn_linear_forward_softmax_xent")
+    gw0, gb0, dx0 = capi.linear_backward(x, delta0, w, float(B), relu_below=bool(relu))
+    logits1, probs1, delta1, terms1, dx1 = mk(B, n_out), mk(B, n_out), mk(B, n_out), mk(B), mk(B, n_in)
+    capi.check(lib.cnn_linear_forward_softmax_xent_dx(capi._ptr(x), capi._ptr(w), capi._ptr(b), capi._ptr(labels), capi._ptr(logits1),
+                                                      capi._ptr(probs1), capi._ptr(delta1), capi._ptr(terms1), capi._ptr(dx1), relu, B, n_in, n_out,
+                                                      capi._stream()), "cnn_linear_forward_softmax_xent_dx")
+    gw1, gb1 = mk(n_in, n_out), mk(n_out)
+    capi.check(lib.cnn_linear_backward(capi._ptr(x), capi._ptr(delta1), capi._ptr(w), capi._ptr(gw1), capi._ptr(gb1), None, B, n_in, n_out,
+                                       float(B), capi._stream()), "cnn_linear_backward")
+    for name, a, c in (("logits", logits0, logits1), ("probs", probs0, probs1), ("delta", delta0, delta1), ("loss terms", terms0, terms1),
+                       ("dx", dx0, dx1), ("gW", gw0, gw1), ("gb", gb0, gb1)):
+        assert np.array_equal(host(a).view(np.uint32), host(c).view(np.uint32)), name
+
+
 @pytest.mark.parametrize("shape", [(1, 64, 13, 13), (4, 64, 13, 13), (3, 128, 6, 6), (2, 16, 111, 111), (5, 7, 3, 5)], ids=lambda s: "B%d_C%d_%dx%d" % s)
 def test_grad_cam_matches_oracle_bit_for_bit(T, shape):
     """cnn_grad_cam == the restatement of alexnet.cpp:107-140: same summation orders, so the normalised map and the 8-bit picture

@@ -213,6 +213,35 @@ def test_host_net_layer_fusion_is_bit_identical():
     assert res[0][0] == res[1][0]
 
 
+@pytest.mark.gpu
+def test_head_data_gradient_from_the_loss_kernel_is_bit_identical(lib_option):
+    """Sequential::train_step with the linear layer's data gradient written by the loss-head kernel and its weight / bias gradient
+    on the side stream (the default) against the two-kernel head (NO_HEAD_DX): parameters, gradients, losses and the delta with
+    respect to the input after each of three steps, bit for bit"""
+    import torch
+
+    from cnn_amd import hostapi
+
+    B = 4
+    x = uniform01(170, (B, 3, 224, 224))
+    labels = (np.arange(B) % 3).astype(np.int32)
+    p0 = normal_scaled(171, (111267,))
+    xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    res = []
+    for off in (None, "1"):
+        lib_option("NO_HEAD_DX", off)
+        net = hostapi.HostAlexNet(3)
+        net.set_params(p0)
+        trace = []
+        for _ in range(3):
+            net.train_step(xd, ld, 1e-3)
+            trace.append((net.last_loss(), net.get_params(), net.get_grads(), net.input_delta((B, 3, 224, 224))))
+        res.append(trace)
+        net.close()
+    for (la, pa, ga, da), (lb, pb, gb, db) in zip(*res):
+        assert la == lb and np.array_equal(pa, pb) and np.array_equal(ga, gb) and np.array_equal(da, db)
+
+
 ALEXNET_OUTPUTS = [("conv_layer_1", (16, 111, 111)), ("relu_layer_1", (16, 111, 111)), ("max_pool_1", (16, 55, 55)),
                    ("conv_layer_2", (32, 27, 27)), ("relu_layer_2", (32, 27, 27)), ("conv_layer_3", (64, 13, 13)),
                    ("relu_layer_3", (64, 13, 13)), ("conv_layer_4", (128, 6, 6)), ("relu_layer_4", (128, 6, 6)), ("linear_1", (3, 1, 1))]
