@@ -94,12 +94,15 @@ void Sequential::wire() {
 // it overlaps the latency-bound deep layers, the linear layer and the loss instead of the HBM-bound first ones (measured on the
 // reference net)
 static Layer* pick_release_layer(const std::list<std::shared_ptr<Layer> >& layers) {
+    char text[16] = {0};
+    int want = 3;  // (DX0_RELEASE=n: behind the n-th convolution instead; tuning)
+    if (cnn_amd_get_option("DX0_RELEASE", text, sizeof(text)) == 0 && std::atoi(text) >= 2) want = std::atoi(text);
     Layer* pick = nullptr;
     int convs = 0;
     for (const auto& layer : layers)
         if (dynamic_cast<Conv2D*>(layer.get())) {
             pick = layer.get();
-            if (++convs == 3) break;
+            if (++convs == want) break;
         }
     return convs >= 2 ? pick : nullptr;
 }
