@@ -398,6 +398,7 @@ def main():
     ap.add_argument("--one-rank-comm", action="store_true",
                     help="(profiling) single process with a ONE-rank RCCL communicator and the gradient exchange forced on: the step then "
                          "contains the all-reduce kernels of the N > 1 path (sums are identities)")
+    ap.add_argument("--main-priority", type=int, default=0, help="(A/B) run the step on a torch stream of this priority (-1 = high)")
     ap.add_argument("--no-pool-fusion", action="store_true", help="architectures::fuse_pool_block = false for the main leg (A/B)")
     ap.add_argument("--staged-input", action="store_true",
                     help="also time the reference net with every batch coming from (pinned) HOST memory through cnn_batch_stager_* "
@@ -441,6 +442,12 @@ def main():
         comm_info = {"ranks": 1, "rccl_version": comm.version, "entry": "cnn_allreduce_grads (include/cnn_amd.h)",
                      "note": "one-rank communicator, exchange forced on (profiling aid, not a scaling number)"}
 
+    if args.main_priority != 0:
+        from cnn_amd import hostapi
+
+        main_stream = torch.cuda.Stream(priority=args.main_priority)
+        torch.cuda.set_stream(main_stream)
+        hostapi.load().cnnh_set_stream(main_stream.cuda_stream)
     run = make_runner(args.config, api, args.batch, torch, capi, world, rank, comm, pool_block=not args.no_pool_fusion)
     B = run["B"]
 

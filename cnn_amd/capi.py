@@ -104,6 +104,7 @@ SIGNATURES = {
     "cnn_sgd_update": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P]),
     "cnn_sgd_update_keep": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P, _P]),
     "cnn_stream_wait_event_local": (C.c_int, [_P, _P]),
+    "cnn_stream_create_priority": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "cnn_conv2d_backward_weight_pooled2_sgd_keep": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P,
                                                                C.c_size_t, _P]),
     "cnn_comm_available": (C.c_int, []),

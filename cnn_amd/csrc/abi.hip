@@ -328,6 +328,15 @@ int cnn_stream_create(void** stream) {
     *stream = s;
     return CNN_AMD_OK;
 }
+int cnn_stream_create_priority(void** stream, int level) {
+    CNN_REQUIRE(stream != nullptr, "cnn_stream_create_priority: null pointer");
+    int least = 0, greatest = 0;  // (numerically: greatest priority = the smallest number)
+    CNN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t s = nullptr;
+    CNN_HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, level < 0 ? greatest : (level > 0 ? least : 0)));
+    *stream = s;
+    return CNN_AMD_OK;
+}
 int cnn_stream_destroy(void* stream) {
     if (stream) CNN_HIP_CHECK(hipStreamDestroy(as_stream(stream)));
     return CNN_AMD_OK;

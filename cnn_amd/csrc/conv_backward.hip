@@ -26,7 +26,9 @@ int get_side(SideStream** out) {
     CNN_HIP_CHECK(hipGetDevice(&dev));
     SideStream& side = sides[(dev >= 0 ? dev : 0) % 16];
     if (side.stream == nullptr || side.device != dev) {
-        CNN_HIP_CHECK(hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking));
+        void* made = nullptr;
+        if (int rc = cnn_stream_create_priority(&made, CNN_OPT_INT("SIDE_PRIO", 0))) return rc;  // (SIDE_PRIO: measurement switch)
+        side.stream = as_stream(made);
         CNN_HIP_CHECK(hipEventCreateWithFlags(&side.fork, hipEventDisableTiming));
         CNN_HIP_CHECK(hipEventCreateWithFlags(&side.join, hipEventDisableTiming));
         side.device = dev;

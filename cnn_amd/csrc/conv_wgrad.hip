@@ -426,6 +426,17 @@ __global__ __launch_bounds__(kRedElems * kRedLanes) void slab_reduce_batch_v4(co
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) {
         int s = sl;
+        // jobs with hundreds of slabs (conv_layer_2: 512 x 18 KB) were a chain of 16 dependent rounds of four loads, each round a
+        // memory round trip next to an HBM-bound kernel (48 us in the train step): sixteen loads in flight, added in the same order
+        for (; s + 15 * kRedLanes < j.nslots; s += 16 * kRedLanes) {
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = *(const float4*)(j.in + (size_t)(s + u * kRedLanes) * n + i);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+            }
+        }
         for (; s + 3 * kRedLanes < j.nslots; s += 4 * kRedLanes) {
             const float4 v0 = *(const float4*)(j.in + (size_t)s * n + i), v1 = *(const float4*)(j.in + (size_t)(s + kRedLanes) * n + i);
             const float4 v2 = *(const float4*)(j.in + (size_t)(s + 2 * kRedLanes) * n + i), v3 = *(const float4*)(j.in + (size_t)(s + 3 * kRedLanes) * n + i);

@@ -259,10 +259,16 @@ private:
     bool publish_backward = false;
     bool head_dx_done = false;   // this pass' data gradient was written by the loss-head kernel (forward_loss_head(with_dx))
     void* ev_head = nullptr;
+    void* own_stream = nullptr;  // the weight / bias gradient of such a pass runs here, beside everything else ...
+    void* ev_wb = nullptr;
+    bool wb_pending = false;     // ... until join_pending() orders it into a stream
 
 public:
     void set_relu_below(ReLU* relu) { relu_below = relu; }  // addition (see architectures::fuse_layers)
     void set_publish_backward(bool on) { publish_backward = on; }  // (see Conv2D::set_publish_backward)
+    // the weight / bias gradient of a loss-head pass may still be running on the layer's own stream: `on_stream` waits for it
+    // (containers call this before they read the gradient arena; update_gradients() of a stand-alone layer does it itself)
+    void join_pending(void* on_stream);
     // addition: forward + softmax + cross-entropy delta in ONE kernel (cnn_linear_forward_softmax_xent, out_channels <= 8):
     // labels_dev int32 [B]; delta_dev [B][out] receives p - onehot (func.cpp:56-73), loss_terms_dev [B] log p[label]
     bool loss_head_supported() const { return out_channels <= 8; }

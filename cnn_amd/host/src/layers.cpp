@@ -779,6 +779,11 @@ LinearLayer::LinearLayer(std::string _name, const int _in_channels, const int _o
 }
 
 LinearLayer::~LinearLayer() {
+    if (own_stream) {
+        cnn_stream_synchronize(own_stream);
+        cnn_stream_destroy(own_stream);
+    }
+    if (ev_wb) cnn_event_destroy(ev_wb);
     if (ev_head) cnn_event_destroy(ev_head);
     if (owns_params) {
         cnn_device_free(params);
@@ -878,7 +883,18 @@ std::vector<tensor> LinearLayer::backward(std::vector<tensor>& delta) {
         // convolutions' (ordered before the join / the step's tail)
         head_dx_done = false;
         void* side = nullptr;
-        must(cnn_amd_side_stream_get(&side), "cnn_amd_side_stream_get");
+        if (cnn_amd_get_option("LINEAR_WB_OWN_STREAM", nullptr, 0) != 0) {
+            // default: the library's side stream, in front of the convolutions' weight gradients (measured: 588-598 k images/s
+            // against 569-577 k with a stream of its own -- a fourth concurrent kernel costs the critical ones more than the
+            // earlier start of the weight-gradient chain gains)
+            must(cnn_amd_side_stream_get(&side), "cnn_amd_side_stream_get");
+        } else {
+            if (own_stream == nullptr) {
+                must(cnn_stream_create(&own_stream), "cnn_stream_create");
+                must(cnn_event_create(&ev_wb), "cnn_event_create");
+            }
+            side = own_stream;
+        }
         if (cnn_amd_published_is_last(stream)) {
             must(cnn_amd_wait_published(side), "cnn_amd_wait_published");
         } else {
@@ -889,6 +905,10 @@ std::vector<tensor> LinearLayer::backward(std::vector<tensor>& delta) {
         must(cnn_linear_backward(saved_input, dy, params, grads, grads + (size_t)in_channels * out_channels, nullptr, B, in_channels,
                                  out_channels, (float)B, side),
              "cnn_linear_backward");
+        if (side == own_stream) {
+            must(cnn_event_record(ev_wb, own_stream), "cnn_event_record");
+            wb_pending = true;
+        }
         if (relu_below != nullptr && fuse_layers) relu_below->fused_backward_done();
         grads_ready = true;
         return delta_buf.views;
@@ -908,8 +928,15 @@ std::vector<tensor> LinearLayer::backward(std::vector<tensor>& delta) {
     return delta_buf.views;
 }
 
+void LinearLayer::join_pending(void* on_stream) {
+    if (!wb_pending) return;
+    must(cnn_stream_wait_event(on_stream, ev_wb), "cnn_stream_wait_event");
+    wb_pending = false;
+}
+
 void LinearLayer::update_gradients(const data_type learning_rate) {
     assert(grads_ready);  // linear.cpp:97
+    join_pending(stream);
     must(cnn_sgd_update(params, grads, param_count(), learning_rate, 1.f, stream), "cnn_sgd_update");
 }
 

@@ -253,6 +253,8 @@ void Sequential::flush_deferred() {
 // gradients [lo, hi) of the arena are final in `stream` order: send them off on the communication stream
 void Sequential::flush_bucket(size_t lo, size_t hi) {
     if (hi <= lo) return;
+    for (auto& layer : layers_sequence)
+        if (auto* lin = dynamic_cast<LinearLayer*>(layer.get())) lin->join_pending(stream);
     must(cnn_amd_side_stream_join(stream), "cnn_amd_side_stream_join");  // (weight gradients of light layers run on the side stream)
     must(cnn_event_record(ev_grads, stream), "cnn_event_record");
     must(cnn_stream_wait_event(comm_stream, ev_grads), "cnn_stream_wait_event");
@@ -275,6 +277,8 @@ void Sequential::backward(std::vector<tensor>& delta_start) {
         }
     }
     grads_reduced = false;
+    for (auto& layer : layers_sequence)
+        if (auto* lin = dynamic_cast<LinearLayer*>(layer.get())) lin->join_pending(stream);
     if (bucketed) {
         flush_bucket(0, pending_hi);
         must(cnn_event_record(ev_comm, comm_stream), "cnn_event_record");
@@ -419,6 +423,8 @@ bool Sequential::fused_tail(std::vector<tensor>& delta, const data_type learning
         if (cnn_amd_published_is_last(stream)) must(cnn_amd_wait_published(defer_stream), "cnn_amd_wait_published");
         else must(cnn_stream_wait_event(defer_stream, ev_tail), "cnn_stream_wait_event");
     }
+    for (auto& layer : layers_sequence)  // (a loss-head pass: the linear layer's weight / bias gradient runs on its own stream)
+        if (auto* lin = dynamic_cast<LinearLayer*>(layer.get())) lin->join_pending(side);
     must(cnn_amd_flush_reduces(side), "cnn_amd_flush_reduces");
     if (n_params > lo) {
         // bucket 1 of the exchange: everything behind the block is final ~one weight-gradient kernel before the step ends
@@ -499,7 +505,9 @@ void Sequential::train_step(const std::vector<tensor>& input, const int* labels_
             output = layer->forward(output);
         if (release_here) {
             if (defer_stream == nullptr) {
-                must(cnn_stream_create(&defer_stream), "cnn_stream_create");
+                char prio[16] = {0};
+                const int level = cnn_amd_get_option("DEFER_PRIO", prio, sizeof(prio)) == 0 ? std::atoi(prio) : 0;  // (measurement switch)
+                must(cnn_stream_create_priority(&defer_stream, level), "cnn_stream_create_priority");
                 must(cnn_event_create(&ev_defer_done), "cnn_event_create");
             }
             if (cnn_amd_published_is_last(stream)) {
@@ -539,6 +547,8 @@ void Sequential::train_step(const std::vector<tensor>& input, const int* labels_
             if (print_info) delta[0]->print_shape();
         }
         grads_reduced = false;
+        for (auto& layer : layers_sequence)
+            if (auto* lin = dynamic_cast<LinearLayer*>(layer.get())) lin->join_pending(stream);
         must(cnn_amd_side_stream_join(stream), "cnn_amd_side_stream_join");
         update_gradients(learning_rate);
         return;

@@ -400,6 +400,9 @@ int cnn_stream_synchronize(void* stream);
  * exchange, the staging stream of cnn_batch_upload_async); streams are non-blocking w.r.t. the default stream, events carry
  * no timing.  The host layer classes use only these, never the HIP runtime directly. */
 int cnn_stream_create(void** stream);
+/* level < 0: the device's highest stream priority, 0: default, > 0: lowest (hipStreamCreateWithPriority; dispatch arbitration between
+ * queues, running waves are not preempted) */
+int cnn_stream_create_priority(void** stream, int level);
 int cnn_stream_destroy(void* stream);
 int cnn_event_create(void** event);
 int cnn_event_destroy(void* event);
