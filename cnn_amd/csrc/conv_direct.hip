@@ -1010,8 +1010,13 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_pool_pk_3_16_3_2(const float*
         for (int c = 0; c < CO; ++c) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, bestv[c]), rpool, (int)so_lane, soff + c * PP4, 0);
         if (mask) {
 #pragma unroll
-            for (int c = 0; c < CO; ++c)
-                __builtin_amdgcn_raw_buffer_store_b32(c * Ho * Wo + mbase + offv[c], rmask, (int)so_lane, soff + c * PP4, 0);
+            for (int c = 0; c < CO; ++c) {
+                // bit 31 = "this window's pooled value is <= 0": the block's ReLU::backward (relu.cpp:37) blocks its delta.  The
+                // pooled-domain gradient kernels compare the mask with the flat index they expect, so a marked window contributes
+                // nothing there -- the ReLU mask costs no extra tensor read anywhere in the backward pass.
+                const int marked = (c * Ho * Wo + mbase + offv[c]) | ((bestv[c] <= 0.f) ? (int)0x80000000 : 0);
+                __builtin_amdgcn_raw_buffer_store_b32(marked, rmask, (int)so_lane, soff + c * PP4, 0);
+            }
         }
     }
 }

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void maxpool_bwd_rows(const float* __restri
             bool found = false;
             for (int ho = ho_hi; ho >= ho_lo && !found; --ho)
                 for (int wo = wo_hi; wo >= wo_lo; --wo) {
-                    if (mplane[ho * Wo + wo] == self_row + w) {
+                    if ((mplane[ho * Wo + wo] & 0x7fffffff) == self_row + w) {  // (bit 31: see cnn_conv2d_relu_maxpool2_forward)
                         v = dplane[ho * Wo + wo];
                         if (pplane && pplane[ho * Wo + wo] <= 0.f) v = 0.f;
                         found = true;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void maxpool_bwd_k2s2(const float* __restri
         for (int wo = lane; wo < Wo; wo += kWave) {
             float d = drow[wo];
             if (prow && prow[wo] <= 0.f) d = 0.f;  // fused ReLU::backward (relu.cpp:38) of the layer in front
-            const int off = mrow[wo] - base - 2 * wo;  // 0, 1, W or W+1
+            const int off = (mrow[wo] & 0x7fffffff) - base - 2 * wo;  // 0, 1, W or W+1 (bit 31: see cnn_conv2d_relu_maxpool2_forward)
             row0[2 * wo] = (off == 0) ? d : 0.f;
             row0[2 * wo + 1] = (off == 1) ? d : 0.f;
             row1[2 * wo] = (off == W) ? d : 0.f;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void maxpool_bwd_k2s2_packed(const float* _
         for (int wo = l; wo < Wo; wo += lpr) {
             float d = drow[wo];
             if (prow && prow[wo] <= 0.f) d = 0.f;
-            const int off = mrow[wo] - base - 2 * wo;
+            const int off = (mrow[wo] & 0x7fffffff) - base - 2 * wo;
             row0[2 * wo] = (off == 0) ? d : 0.f;
             row0[2 * wo + 1] = (off == 1) ? d : 0.f;
             row1[2 * wo] = (off == W) ? d : 0.f;

@@ -196,7 +196,6 @@ private:
     ReLU* fused_relu_below = nullptr;  // the ReLU layer whose output is this pool's input (set by the container), or null
     bool forward_done = false;       // this pass' output + mask were written by the producing Conv2D kernel
     bool backward_passthrough = false;  // ... and the delta stays in the pooled domain for that Conv2D's backward
-    bool delta_premasked = false;    // ... and the layer behind already applied the block's ReLU::backward to that delta
 
 public:
     MaxPool2D(std::string _name, const int _kernel_size = 2, const int _step = 2)
@@ -209,14 +208,12 @@ public:
     const data_type* pooled_dev() const { return cur_set ? out_buf_alt.base : out_buf.base; }
     const int* mask_dev() const { return cur_set ? mask_alt : mask; }
     void enable_alternate_sets() { alternate = true; }
-    // pool-fused pass: the delta of this pool's output passes through untouched (the block's Conv2D consumes it).  The layer
-    // BEHIND the pool can then fold the block's ReLU::backward into its own data-gradient epilogue -- in the pooled domain
-    // d(pool_out) masked by (pool_out <= 0) IS that ReLU's backward pass (at an argmax position the ReLU output equals the
-    // pooled value, everywhere else the delta is 0 either way) -- and says so here; the block's Conv2D then skips the
-    // `pooled` tensor in its two gradient kernels.
+    // pool-fused pass: the delta of this pool's output passes through untouched (the block's Conv2D consumes it).  The block's
+    // ReLU::backward -- in the pooled domain: d(pool_out) masked by (pool_out <= 0), because at an argmax position the ReLU
+    // output equals the pooled value and everywhere else the delta is 0 either way -- is carried by the mask itself: the fused
+    // forward kernel sets bit 31 of a window's mask entry when its pooled value is <= 0, and the pooled-domain gradient kernels
+    // then never match that window.
     bool passthrough_armed() const { return backward_passthrough; }
-    void set_delta_premasked() { delta_premasked = true; }
-    bool take_delta_premasked() { const bool v = delta_premasked; delta_premasked = false; return v; }
     std::vector<tensor> forward(const std::vector<tensor>& input) override;
     std::vector<tensor> backward(std::vector<tensor>& delta) override;
 };

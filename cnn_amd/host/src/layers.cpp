@@ -252,8 +252,9 @@ std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
     if (pool_fused_pass) {
         // dy is the delta of the POOL output (the pool and the ReLU passed it through untouched)
         assert(prepared_active && fused_pool != nullptr && B == batch);
-        // (pooled = NULL: the layer behind the pool already applied this block's ReLU::backward to dy, see below)
-        const data_type* pooled = fused_pool->take_delta_premasked() ? nullptr : fused_pool->pooled_dev();
+        // (pooled = NULL: the fused forward kernel marked the windows whose pooled value is <= 0 in the mask itself -- bit 31 --, so
+        // the block's ReLU::backward needs no tensor of its own here)
+        const data_type* pooled = nullptr;
         must(cnn_conv2d_backward_pooled2_prepared(&d, saved_input, dy, fused_pool->mask_dev(), pooled, prep_dgrad, grads,
                                                   grads + (size_t)out_channels * params_for_one_kernel, delta_buf.base, (float)B,
                                                   workspace, workspace_bytes, stream, /*defer_join=*/1),
@@ -261,12 +262,12 @@ std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
         pool_fused_pass = false;
     } else if (prepared_active && fuse_layers && B == batch) {
         // relu_below: this layer's input IS that ReLU's output, so its backward mask is applied in the data-gradient epilogue.
-        // pool_below in a pool-fused pass: this layer's input is the POOL output and its delta stays in the pooled domain;
-        // masking it by (pool_out <= 0) is the block's ReLU::backward (MaxPool2D::passthrough_armed)
-        const bool pooled_mask = relu_below == nullptr && pool_below != nullptr && pool_below->passthrough_armed();
-        const data_type* rb = (relu_below != nullptr || pooled_mask) ? saved_input : nullptr;
-        if (pooled_mask) pool_below->set_delta_premasked();
-        if (publish_backward && rb != nullptr) must(cnn_amd_publish_next_kernel(stream), "cnn_amd_publish_next_kernel");
+        // pool_below in a pool-fused pass: this layer's input is the POOL output and its delta stays in the pooled domain,
+        // UNMASKED -- the block's ReLU::backward is carried by the marked pool mask (bit 31, cnn_conv2d_relu_maxpool2_forward):
+        // no second read of the pool output here (49.6 MB per step on the reference net)
+        const bool pooled_pass = relu_below == nullptr && pool_below != nullptr && pool_below->passthrough_armed();
+        const data_type* rb = relu_below != nullptr ? saved_input : nullptr;
+        if (publish_backward && (rb != nullptr || pooled_pass)) must(cnn_amd_publish_next_kernel(stream), "cnn_amd_publish_next_kernel");
         must(cnn_conv2d_backward_prepared_relu(&d, saved_input, dy, prep_dgrad, rb, grads,
                                                grads + (size_t)out_channels * params_for_one_kernel, delta_buf.base, (float)B,
                                                workspace, workspace_bytes, stream, /*defer_join=*/1),
@@ -319,7 +320,7 @@ Conv2D::DeferredDgrad Conv2D::backward_weight_pooled(std::vector<tensor>& delta,
         workspace_bytes = need;
     }
     if (prep_dgrad_alt == nullptr) prep_dgrad_alt = dev_alloc(cnn_conv2d_prepared_bytes(&d));
-    const data_type* pooled = fused_pool->take_delta_premasked() ? nullptr : fused_pool->pooled_dev();
+    const data_type* pooled = nullptr;  // (the ReLU mask rides in bit 31 of the pool mask, see Conv2D::backward)
     data_type* gw = grads;
     data_type* gb = grads + (size_t)out_channels * params_for_one_kernel;
     DeferredDgrad job;

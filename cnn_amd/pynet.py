@@ -292,8 +292,9 @@ class AlexNetHip:
                 self.flush()  # the previous step's deferred dgrad reads d_conv[1] (= d pool_out), which is rewritten next
             if l == 0 and self.fuse_pool:
                 # conv_layer_1 from the pooled domain: cur = d pool_out
-                # (with fbr the ReLU mask was already applied by conv_layer_2's data gradient: pooled = None)
-                pooled = None if fbr else self.pool_out
+                # (the fused forward kernel marked the windows with pooled <= 0 in the mask itself, bit 31: relu_layer_1's backward
+                # pass needs no tensor of its own -- pooled = None, and conv_layer_2's data gradient stays unmasked)
+                pooled = None
                 if self.defer_dx0 and sgd is not None and self.early_update:
                     self._early_update(*sgd)
                     nxt = self.parity ^ 1  # (the deferred data gradient of THIS step still reads the filters of this step)
@@ -336,7 +337,7 @@ class AlexNetHip:
                 # domain (at an argmax position the ReLU output equals the pooled value)
                 self.convs[l].backward_prepared(lin, cur, self.prep[l][1], div, self.conv_w(l, g), self.conv_b(l, g),
                                                 self.d_conv[l], defer_join=True,
-                                                relu_below=lin if (fbr and (l >= 2 or (l == 1 and self.fuse_pool))) else None)
+                                                relu_below=lin if (fbr and l >= 2) else None)
             else:
                 self.convs[l].backward(lin, cur, self.conv_w(l), div, self.conv_w(l, g), self.conv_b(l, g), self.d_conv[l],
                                        defer_join=True)

@@ -97,6 +97,10 @@ int cnn_conv2d_relu_only_supported(const cnn_conv2d_desc* d);
  * into the sample's Co*Ho*Wo of the window's first maximum; may be NULL) are bit-identical to cnn_conv2d_forward_relu +
  * cnn_maxpool2d_forward, but the convolution / ReLU outputs are NOT materialised -- nothing downstream needs them: the
  * backward pass takes pooled + mask (cnn_maxpool2d_backward_relu, cnn_conv2d_backward_*_pooled2).
+ * Bit 31 of a mask entry is additionally SET when that window's pooled value is <= 0, i.e. when the block's ReLU::backward
+ * (relu.cpp:37) blocks the window's delta: the pooled-domain gradient entry points below compare the entry with the flat index they
+ * expect and therefore skip such windows by themselves (pass pooled = NULL: no tensor is read for the ReLU mask anywhere in the
+ * backward pass); cnn_maxpool2d_backward(_relu) ignore the bit.  (mask & 0x7fffffff) is cnn_maxpool2d_forward's mask, bit for bit.
  * Covered geometry: cnn_conv2d_relu_maxpool2_supported(d) != 0 (the thin 3 -> 16 channel 3x3 stride-2 layer). */
 int cnn_conv2d_relu_maxpool2_supported(const cnn_conv2d_desc* d);
 int cnn_conv2d_relu_maxpool2_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias,

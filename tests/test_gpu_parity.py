@@ -319,7 +319,7 @@ def _count_decision_flips(net, onet, relu_layers, tag):
         flipped += int(np.count_nonzero((got <= 0) != (want <= 0)))
         total += got.size
     assert flipped <= max(2, 2e-5 * total), (tag, "ReLU flips", flipped, total)
-    mm = int(np.count_nonzero(host(net.pool_mask) != onet.pool_mask()))
+    mm = int(np.count_nonzero((host(net.pool_mask) & 0x7FFFFFFF) != onet.pool_mask()))  # (bit 31: the fused kernel's "pooled <= 0" mark)
     assert mm <= max(2, 2e-5 * onet.pool_mask().size), (tag, "pool argmax mismatches", mm, onet.pool_mask().size)
 
 
@@ -478,7 +478,7 @@ def _synced_oracle_backward(net, params, x, labels, pooled_domain=False):
     from cnn_amd import stacks as S
 
     out = []
-    masks = {4: host(net.relu_out[1]), 6: host(net.relu_out[2]), 8: host(net.relu_out[3]), 2: host(net.pool_mask)}
+    masks = {4: host(net.relu_out[1]), 6: host(net.relu_out[2]), 8: host(net.relu_out[3]), 2: host(net.pool_mask) & 0x7FFFFFFF}
     if not pooled_domain:
         masks[1] = host(net.relu_out[0])  # (pool-fused runs do not materialise relu_layer_1's output)
     for f64 in (False, True):
@@ -732,7 +732,9 @@ def test_conv_relu_maxpool_fusion_is_bit_identical(T, shape, prepared):
         prep = pf
     conv.relu_maxpool2_forward(xd, wd, bd, pooled, mask, prepared_fwd=prep)
     assert np.array_equal(host(pooled).view(np.uint32), host(pooled_ref).view(np.uint32))
-    assert np.array_equal(host(mask), host(mask_ref))
+    # the argmax part is cnn_maxpool2d_forward's mask bit for bit; bit 31 marks exactly the windows whose pooled value is <= 0
+    assert np.array_equal(host(mask) & 0x7FFFFFFF, host(mask_ref))
+    assert np.array_equal(host(mask) < 0, host(pooled_ref) <= 0)
     pooled2 = T.full_like(pooled_ref, 7.0)  # no_grad path: mask = NULL
     conv.relu_maxpool2_forward(xd, wd, bd, pooled2, None, prepared_fwd=prep)
     assert np.array_equal(host(pooled2).view(np.uint32), host(pooled_ref).view(np.uint32))
@@ -779,12 +781,18 @@ def test_conv_backward_from_pooled_domain_is_bit_identical(T, shape):
     dx2 = T.full_like(dx_ref, 7.0)
     conv.backward_data_pooled2(dpool, mask, pooled, None, dx2, prepared_dgrad=pd)
     assert np.array_equal(host(dx2), host(dx_ref))
-    # pooled = None: the caller has applied the ReLU mask to dpool already
-    dmasked = T.where(pooled <= 0, T.zeros_like(dpool), dpool)
+    # pooled = None with the MARKED mask of the fused forward kernel (bit 31 = pooled <= 0): the ReLU mask needs no tensor at all ...
     gw3, gb3, dx3 = T.full_like(gw_ref, 7.0), T.full_like(gb_ref, 7.0), T.full_like(dx_ref, 7.0)
-    conv.backward_weight_pooled2(xd, dmasked, mask, None, float(B), gw3, gb3)
-    conv.backward_data_pooled2(dmasked, mask, None, wd, dx3)
+    conv.backward_weight_pooled2(xd, dpool, mask, None, float(B), gw3, gb3)
+    conv.backward_data_pooled2(dpool, mask, None, wd, dx3)
     assert np.array_equal(host(gw3), host(gw_ref)) and np.array_equal(host(gb3), host(gb_ref)) and np.array_equal(host(dx3), host(dx_ref))
+    # ... and with a plain mask (cnn_maxpool2d_forward's) once the caller has applied the ReLU mask to dpool itself
+    plain_mask = (mask & 0x7FFFFFFF).to(T.int32)
+    dmasked = T.where(pooled <= 0, T.zeros_like(dpool), dpool)
+    gw4, gb4, dx4 = T.full_like(gw_ref, 7.0), T.full_like(gb_ref, 7.0), T.full_like(dx_ref, 7.0)
+    conv.backward_weight_pooled2(xd, dmasked, plain_mask, None, float(B), gw4, gb4)
+    conv.backward_data_pooled2(dmasked, plain_mask, None, wd, dx4)
+    assert np.array_equal(host(gw4), host(gw_ref)) and np.array_equal(host(gb4), host(gb_ref)) and np.array_equal(host(dx4), host(dx_ref))
 
 
 @pytest.mark.parametrize("shape", [(256, 224, 224), (2, 224, 224), (3, 37, 41), (5, 7, 5)], ids=lambda s: "B%d_%dx%d" % s)
@@ -858,10 +866,10 @@ def test_pool_fused_net_is_bit_identical(T, defer):
             n.flush()
         T.cuda.synchronize()
         assert T.equal(a.params, b.params) and T.equal(a.grads, b.grads), step
-        assert T.equal(a.pool_out, b.pool_out) and T.equal(a.pool_mask, b.pool_mask)
+        assert T.equal(a.pool_out, b.pool_out) and T.equal(a.pool_mask & 0x7FFFFFFF, b.pool_mask)
+        assert T.equal(a.pool_mask < 0, b.pool_out <= 0)  # (bit 31: relu_layer_1's backward mask rides in the pool mask)
         assert T.equal(a.d_conv[0], b.d_conv[0]) and T.equal(a.logits, b.logits)
-        # d(pool output): the fused net applies relu_layer_1's backward mask where that delta is produced
-        assert T.equal(a.d_conv[1], T.where(b.pool_out <= 0, T.zeros_like(b.d_conv[1]), b.d_conv[1]))
+        assert T.equal(a.d_conv[1], b.d_conv[1])  # d(pool output): conv_layer_2's plain data gradient in both nets
 
 
 @pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 13)] + [(3, 32, 9, 11, 64, 3, 1, 0), (2, 32, 28, 30, 64, 3, 2, 0), (1, 96, 9, 12, 128, 3, 2, 0), (2, 64, 14, 14, 128, 3, 2, 1), (3, 64, 9, 11, 128, 3, 2, 1)], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
@@ -982,7 +990,7 @@ def test_pool_fused_net_full_batch_is_bit_identical(T):
             n.flush()
         T.cuda.synchronize()
         assert T.equal(fused.params, plain.params) and T.equal(fused.grads, plain.grads), step
-        assert T.equal(fused.pool_out, plain.pool_out) and T.equal(fused.pool_mask, plain.pool_mask)
+        assert T.equal(fused.pool_out, plain.pool_out) and T.equal(fused.pool_mask & 0x7FFFFFFF, plain.pool_mask & 0x7FFFFFFF)
         assert T.equal(fused.d_conv[0], plain.d_conv[0]) and T.equal(fused.logits, plain.logits)
     loss = float(fused.loss_sum.item()) / B
     assert np.isfinite(loss) and 0.0 < loss < 20.0
