@@ -387,6 +387,9 @@ protected:
     void* defer_stream = nullptr;
     void* ev_defer_done = nullptr;
     void* ev_tail = nullptr;
+    void* ev_side_tail = nullptr;
+    bool side_tail_pending = false;  // the side stream still runs the previous step's tail (fused_tail, TAIL_BEHIND_BLOCK)
+    void prepare_later_filters(void* on_stream);
     Conv2D::DeferredDgrad pending_dgrad;
     bool defer_in_flight = false;
     bool fused_tail(std::vector<tensor>& delta, const data_type learning_rate);  // false: not applicable to this pass

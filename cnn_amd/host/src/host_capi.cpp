@@ -116,17 +116,20 @@ void cnnh_set_fuse_pool_block(int on) { architectures::fuse_pool_block = on != 0
 
 void cnnh_net_set_params(void* hv, const float* host) {
     Handle* h = (Handle*)hv;
+    h->net->flush_deferred();
     must(cnn_memcpy_h2d(h->net->params_device(), host, sizeof(float) * h->net->num_params(), stream), "cnn_memcpy_h2d");
     must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
     h->net->parameters_changed();
 }
 void cnnh_net_get_params(void* hv, float* host) {
     Handle* h = (Handle*)hv;
+    h->net->flush_deferred();
     must(cnn_memcpy_d2h(host, h->net->params_device(), sizeof(float) * h->net->num_params(), stream), "cnn_memcpy_d2h");
     must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
 }
 void cnnh_net_get_grads(void* hv, float* host) {
     Handle* h = (Handle*)hv;
+    h->net->flush_deferred();
     must(cnn_memcpy_d2h(host, h->net->grads_device(), sizeof(float) * h->net->num_params(), stream), "cnn_memcpy_d2h");
     must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
 }

@@ -243,6 +243,7 @@ std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
     // conv2d.cpp:117-199: weight/bias gradients (recomputed, not accumulated, averaged over the batch) and the data
     // gradient in one call; the library overlaps the two on an internal side stream
     if (delta_buf.empty()) delta_buf.allocate(batch, in_channels, in_H, in_W, name + "_delta");
+    BatchBuffer& dbuf = delta_buf;
     const size_t need = cnn_conv2d_backward_workspace_bytes(&d);
     if (need > workspace_bytes) {
         if (workspace) cnn_device_free(workspace);
@@ -256,7 +257,7 @@ std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
         // the block's ReLU::backward needs no tensor of its own here)
         const data_type* pooled = nullptr;
         must(cnn_conv2d_backward_pooled2_prepared(&d, saved_input, dy, fused_pool->mask_dev(), pooled, prep_dgrad, grads,
-                                                  grads + (size_t)out_channels * params_for_one_kernel, delta_buf.base, (float)B,
+                                                  grads + (size_t)out_channels * params_for_one_kernel, dbuf.base, (float)B,
                                                   workspace, workspace_bytes, stream, /*defer_join=*/1),
              "cnn_conv2d_backward_pooled2_prepared");
         pool_fused_pass = false;
@@ -269,16 +270,16 @@ std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
         const data_type* rb = relu_below != nullptr ? saved_input : nullptr;
         if (publish_backward && (rb != nullptr || pooled_pass)) must(cnn_amd_publish_next_kernel(stream), "cnn_amd_publish_next_kernel");
         must(cnn_conv2d_backward_prepared_relu(&d, saved_input, dy, prep_dgrad, rb, grads,
-                                               grads + (size_t)out_channels * params_for_one_kernel, delta_buf.base, (float)B,
+                                               grads + (size_t)out_channels * params_for_one_kernel, dbuf.base, (float)B,
                                                workspace, workspace_bytes, stream, /*defer_join=*/1),
              "cnn_conv2d_backward_prepared_relu");
         if (rb && relu_below) relu_below->fused_backward_done();
     } else
         must(cnn_conv2d_backward(&d, saved_input, dy, w_dev(), grads, grads + (size_t)out_channels * params_for_one_kernel,
-                                 delta_buf.base, (float)B, workspace, workspace_bytes, stream, /*defer_join=*/1),
+                                 dbuf.base, (float)B, workspace, workspace_bytes, stream, /*defer_join=*/1),
              "cnn_conv2d_backward");  // joined in update_gradients / AlexNet::backward
     grads_ready = true;
-    return delta_buf.views;
+    return dbuf.views;
 }
 
 // ---- fuse_pool_block: outputs the pass did not write, and the container-scheduled backward of a pool-fused first block ----

@@ -154,6 +154,11 @@ void Sequential::finalize(data_type* params_dev, data_type* grads_dev) {
 }
 
 Sequential::~Sequential() {
+    if (side_tail_pending) {  // (the side stream may still write the arenas freed below)
+        cnn_stream_wait_event(stream, ev_side_tail);
+        cnn_stream_synchronize(stream);
+        side_tail_pending = false;
+    }
     if (defer_in_flight || pending_dgrad.valid) {  // (a deferred kernel may still read the layers' buffers)
         pending_dgrad.valid = false;
         cnn_stream_synchronize(defer_stream);
@@ -164,6 +169,7 @@ Sequential::~Sequential() {
     if (defer_stream) cnn_stream_destroy(defer_stream);
     if (ev_defer_done) cnn_event_destroy(ev_defer_done);
     if (ev_tail) cnn_event_destroy(ev_tail);
+    if (ev_side_tail) cnn_event_destroy(ev_side_tail);
     if (owns_arena) {
         cnn_device_free(param_arena);
         cnn_device_free(grad_arena);
@@ -240,6 +246,10 @@ std::vector<tensor> Sequential::forward(const std::vector<tensor>& input) {
 }
 
 void Sequential::flush_deferred() {
+    if (side_tail_pending) {  // (the previous step's reductions / SGD / filter images of the later layers, see fused_tail)
+        must(cnn_stream_wait_event(stream, ev_side_tail), "cnn_stream_wait_event");
+        side_tail_pending = false;
+    }
     if (pending_dgrad.valid) {  // not released yet: run it in order on the compute stream
         block_conv->launch_deferred_dgrad(pending_dgrad, stream);
         pending_dgrad.valid = false;
@@ -364,6 +374,7 @@ void Sequential::allreduce_gradients() {
 }
 
 void Sequential::update_gradients(const data_type learning_rate) {
+    flush_deferred();
     if (!finalized) {  // plain list of stand-alone layers: the reference's loop (alexnet.cpp:62-65)
         for (auto& layer : layers_sequence) layer->update_gradients(learning_rate);
         return;
@@ -382,6 +393,28 @@ void Sequential::update_gradients(const data_type learning_rate, const data_type
     must(cnn_sgd_update_keep(param_arena, grad_arena, n_params, learning_rate, grad_scale, param_prev, stream), "cnn_sgd_update_keep");
     parameters_changed();
     params_stepped = true;
+}
+
+// filter images of every convolution behind the pool-fused front block, from the current parameters, on `on_stream`
+void Sequential::prepare_later_filters(void* on_stream) {
+    std::vector<Conv2D*> later;
+    for (auto& layer : layers_sequence)
+        if (auto* c = dynamic_cast<Conv2D*>(layer.get()))
+            if (c != block_conv) later.push_back(c);
+    for (size_t first = 0; first < later.size(); first += 6) {
+        const size_t n = std::min<size_t>(6, later.size() - first);
+        std::vector<cnn_conv2d_desc> descs;
+        std::vector<const float*> w, b;
+        std::vector<void*> f(n), g(n);
+        for (size_t i = 0; i < n; ++i) {
+            Conv2D* c = later[first + i];
+            descs.push_back(c->current_desc());
+            w.push_back(c->filters_dev());
+            b.push_back(c->bias_dev());
+            c->prepared_buffers(&f[i], &g[i]);
+        }
+        must(cnn_conv2d_prepare_filters((int)n, descs.data(), w.data(), b.data(), f.data(), g.data(), on_stream), "cnn_conv2d_prepare_filters");
+    }
 }
 
 // The end of a train step whose first block ran pool-fused, called where the backward walk reaches that
@@ -406,6 +439,28 @@ bool Sequential::fused_tail(std::vector<tensor>& delta, const data_type learning
     if (ev_tail == nullptr) must(cnn_event_create(&ev_tail), "cnn_event_create");
     void* side = nullptr;
     must(cnn_amd_side_stream_get(&side), "cnn_amd_side_stream_get");
+    // TAIL_BEHIND_BLOCK (single rank, own arena): the later layers' reductions / SGD / filter images do not run under the block's
+    // weight gradient but BEHIND it, and the compute stream does not wait for them here: they overlap the next step's first
+    // forward kernel, whose successor waits (train_step / flush_deferred)
+    const bool tail_behind = !dp && owns_arena && cnn_amd_get_option("TAIL_BEHIND_BLOCK", nullptr, 0) == 0;
+    if (tail_behind) {
+        if (ev_side_tail == nullptr) must(cnn_event_create(&ev_side_tail), "cnn_event_create");
+        pending_dgrad = block_conv->backward_weight_pooled(delta, /*fused_sgd=*/true, learning_rate, scale);
+        must(cnn_event_record(ev_tail, stream), "cnn_event_record");
+        must(cnn_stream_wait_event(side, ev_tail), "cnn_stream_wait_event");
+        for (auto& layer : layers_sequence)
+            if (auto* lin = dynamic_cast<LinearLayer*>(layer.get())) lin->join_pending(side);
+        must(cnn_amd_flush_reduces(side), "cnn_amd_flush_reduces");
+        if (n_params > lo)
+            must(cnn_sgd_update_keep(param_arena + lo, grad_arena + lo, n_params - lo, learning_rate, scale, param_prev + lo, side),
+                 "cnn_sgd_update_keep");
+        prepare_later_filters(side);
+        must(cnn_event_record(ev_side_tail, side), "cnn_event_record");
+        side_tail_pending = true;
+        grads_reduced = false;
+        params_stepped = true;
+        return true;
+    }
     if (cnn_amd_published_is_last(stream)) {  // the data gradient just launched carries the event in its dispatch packet
         must(cnn_amd_wait_published(side), "cnn_amd_wait_published");
     } else {
@@ -432,24 +487,7 @@ bool Sequential::fused_tail(std::vector<tensor>& delta, const data_type learning
         must(cnn_sgd_update_keep(param_arena + lo, grad_arena + lo, n_params - lo, learning_rate, scale, param_prev + lo, side),
              "cnn_sgd_update_keep");
     }
-    std::vector<Conv2D*> later;
-    for (auto& layer : layers_sequence)
-        if (auto* c = dynamic_cast<Conv2D*>(layer.get()))
-            if (c != block_conv) later.push_back(c);
-    for (size_t first = 0; first < later.size(); first += 6) {
-        const size_t n = std::min<size_t>(6, later.size() - first);
-        std::vector<cnn_conv2d_desc> descs;
-        std::vector<const float*> w, b;
-        std::vector<void*> f(n), g(n);
-        for (size_t i = 0; i < n; ++i) {
-            Conv2D* c = later[first + i];
-            descs.push_back(c->current_desc());
-            w.push_back(c->filters_dev());
-            b.push_back(c->bias_dev());
-            c->prepared_buffers(&f[i], &g[i]);
-        }
-        must(cnn_conv2d_prepare_filters((int)n, descs.data(), w.data(), b.data(), f.data(), g.data(), side), "cnn_conv2d_prepare_filters");
-    }
+    prepare_later_filters(side);
     // compute stream: the block's weight gradient (+ its share of the tail)
     pending_dgrad = block_conv->backward_weight_pooled(delta, /*fused_sgd=*/!dp, learning_rate, scale);
     if (dgrad_now) {
@@ -498,6 +536,10 @@ void Sequential::train_step(const std::vector<tensor>& input, const int* labels_
     for (const auto& layer : layers_sequence) {
         // the previous step's deferred data gradient starts behind this layer's forward kernel, on its own stream
         const bool release_here = pending_dgrad.valid && layer.get() == release_after;
+        if (side_tail_pending && layer.get() == behind_block) {  // the first layer whose parameters / filter images the side tail writes
+            must(cnn_stream_wait_event(stream, ev_side_tail), "cnn_stream_wait_event");
+            side_tail_pending = false;
+        }
         if (release_here) must(cnn_amd_publish_next_kernel(stream), "cnn_amd_publish_next_kernel");
         if (layer.get() == head && fused_head)
             output = head->forward_loss_head(output, labels_dev, loss_probs.base, loss_delta.base, loss_terms, head_dx);
@@ -550,7 +592,7 @@ void Sequential::train_step(const std::vector<tensor>& input, const int* labels_
         for (auto& layer : layers_sequence)
             if (auto* lin = dynamic_cast<LinearLayer*>(layer.get())) lin->join_pending(stream);
         must(cnn_amd_side_stream_join(stream), "cnn_amd_side_stream_join");
-        update_gradients(learning_rate);
+        update_gradients(learning_rate);  // (flush_deferred() inside: a deferred kernel still in flight is ordered here)
         return;
     }
     backward(delta);
@@ -570,6 +612,7 @@ data_type Sequential::last_loss() {
 }
 
 void Sequential::save_weights(const std::filesystem::path& save_path) const {
+    const_cast<Sequential*>(this)->flush_deferred();
     std::ofstream writer(save_path.c_str(), std::ios::binary);
     for (const auto& layer : layers_sequence) layer->save_weights(writer);
     std::cout << "weights have been saved to " << save_path.string() << std::endl;
@@ -582,6 +625,7 @@ void Sequential::load_weights(const std::filesystem::path& checkpoint_path) {
         return;
     }
     std::ifstream reader(checkpoint_path.c_str(), std::ios::binary);
+    flush_deferred();
     parameters_changed();
     for (auto& layer : layers_sequence) layer->load_weights(reader);
     std::cout << "load weights from" << checkpoint_path.string() << std::endl;
