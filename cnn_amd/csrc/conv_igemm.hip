@@ -58,6 +58,7 @@ struct IgemmParams {
     int rw_shift;       // log2(lanes per staged row): narrow rows share one wave-wide load
     int need_zero;      // the row image has pad columns / out-of-image rows -> zero it once
     int run_mode;       // DMA kernel: rows of a channel are one contiguous 16-byte-aligned run
+    int row_tail;       // run_mode 3 with XW % 4 != 0: valid floats in the LAST 16-byte unit of an input row (0: rows are whole units)
     int dbg;            // ablation bits (CNN_AMD_DBG, tuning only): 1 no X DMA, 2 no A DMA, 4 no MFMA, 8 no stores
     int tc_inv;         // 65536 / TC + 1: t / TC == (t * tc_inv) >> 16 for the small tap indices used here
     int ncls;           // dgrad: number of output-parity classes with a tap mask below (0: every tap is used by every row)
@@ -598,11 +599,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
     constexpr int MAXD = 8;
     int d_lds[MAXD];        // float offset of the instruction's LDS destination inside the row image (wave-uniform)
     unsigned d_src[MAXD];   // this lane's source element relative to the chunk's first channel plane, ~0u: lane inactive
+    unsigned d_tail = 0;    // bit i: this lane's unit of instruction i is the ragged LAST unit of an input row (row_tail != 0)
     int nd = 0;
     bool desc_ok = false;
     if (p.run_mode != 0 && (unsigned long long)p.B * p.C * p.XH * p.XW < (1ull << 32)) {
         desc_ok = true;
-        auto record = [&](int lds_off, unsigned src) {
+        auto record = [&](int lds_off, unsigned src, bool tail_unit = false) {
             if (nd < MAXD) {
 #pragma unroll
                 for (int i = 0; i < MAXD; ++i)
@@ -610,6 +612,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
                         d_lds[i] = lds_off;
                         d_src[i] = src;
                     }
+                if (tail_unit) d_tail |= 1u << nd;
                 ++nd;
             } else {
                 desc_ok = false;
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
                 record(img * CK * HW + part * 64 * unit, idx < runu ? (unsigned)((size_t)(b0 + img) * p.C * HW) + (unsigned)idx * unit : ~0u);
             }
         } else if (p.run_mode == 3) {
-            const int upr = p.LW >> 2, total = nrows * upr, per_ch = (total + 63) / 64, dcols = p.XW >> 2, pl4 = p.padL >> 2;
+            const int upr = p.LW >> 2, total = nrows * upr, per_ch = (total + 63) / 64, dcols = (p.XW + 3) >> 2, pl4 = p.padL >> 2;
             for (int j = wave; j < CK * per_ch; j += NWAVES) {
                 const int ck = j / per_ch, part = j - ck * per_ch;
                 const int u = part * 64 + lane;
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
                 }
                 const bool on = u < total && cu >= pl4 && cu < pl4 + dcols && xrow >= 0 && xrow < p.XH;
                 const unsigned src = (unsigned)(((size_t)b * p.C * p.XH + xrow) * p.XW) + (unsigned)ck * (unsigned)(p.XH * p.XW) + (unsigned)(4 * (cu - pl4));
-                record(ck * p.chs + part * 256, on ? src : ~0u);
+                record(ck * p.chs + part * 256, on ? src : ~0u, on && p.row_tail != 0 && cu == pl4 + dcols - 1);
             }
         } else {
             const int unit = (p.run_mode == 1) ? 4 : 1;
@@ -680,9 +683,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         if (p.dbg & 1) return;
         if (desc_ok && cc * CK + CK <= p.C && !(p.dbg & 64)) {  // (no channel padding in this chunk; 64: A/B switch)
             const float* cbase = p.X + (size_t)cc * CK * p.XH * p.XW;
+            // (ragged rows: the last unit of the tensor's very LAST row is fetched float by float in fix_tails -- a 16-byte DMA
+            // there would read past the end of the allocation)
+            const unsigned last_unit = p.row_tail ? (unsigned)((size_t)p.B * p.C * p.XH * p.XW - (size_t)cc * CK * p.XH * p.XW) - (unsigned)p.row_tail : ~0u;
 #pragma unroll
             for (int i = 0; i < MAXD; ++i) {
-                if (i < nd && d_src[i] != ~0u) {
+                if (i < nd && d_src[i] != ~0u && d_src[i] != last_unit) {
                     if (p.run_mode == 2)
                         __builtin_amdgcn_global_load_lds((gbl_void_ptr)(cbase + d_src[i]), (lds_void_ptr)(Xbuf + d_lds[i]), 4, 0, 0);
                     else
@@ -780,12 +786,32 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         }
     };
 
+    // ragged rows (row_tail != 0): the units this wave fetched for chunk cc have landed (its own vmcnt(0)); put zeros back into the
+    // pad columns behind the row's last valid float (they received the floats that follow the row in memory)
+    auto fix_tails = [&](int cc) {
+        float* Xbuf = smem + (cc & 1) * buf_floats + a_floats;
+        if (!(desc_ok && cc * CK + CK <= p.C) || (p.dbg & (1 | 64))) return;
+        const unsigned last_unit = (unsigned)((size_t)p.B * p.C * p.XH * p.XW - (size_t)cc * CK * p.XH * p.XW) - (unsigned)p.row_tail;
+#pragma unroll
+        for (int i = 0; i < MAXD; ++i) {
+            if (i < nd && (d_tail >> i & 1u)) {
+                float* u = Xbuf + d_lds[i] + lane * 4;
+                if (d_src[i] == last_unit) {
+                    const float* g = p.X + (size_t)cc * CK * p.XH * p.XW + d_src[i];
+                    for (int t = 0; t < p.row_tail; ++t) u[t] = g[t];
+                }
+                for (int t = p.row_tail; t < 4; ++t) u[t] = 0.f;
+            }
+        }
+    };
+
     issue_dma(0, 0);
     for (int cc = 0; cc < p.nchunk; ++cc) {
         // Every wave first waits for ITS OWN outstanding LDS-DMA (chunk cc), then the barrier publishes all of them and
         // guarantees every wave is done reading the other buffer.  The explicit wait is required: hipcc (ROCm 7.2) hoists
         // its own vmcnt(0) out of this loop, leaving the in-loop s_barrier unprotected (caught by tools/det_check.py).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (XM == 0 && p.row_tail != 0) fix_tails(cc);
         __syncthreads();
         if (cc + 1 < p.nchunk) issue_dma(cc + 1, (cc + 1) & 1);
         if (p.dbg & 4) continue;
@@ -992,7 +1018,7 @@ struct Plan {
 enum { CFG_M128_L = 100, CFG_M128 = 0, CFG_M128_S, CFG_M64, CFG_M64_S, CFG_M32, CFG_M32_S, CFG_M16_CK4, CFG_M16_CK16, CFG_M16_CK4_L, CFG_M16_CK8, CFG_M16_CK8_L, CFG_D_M128 = 200, CFG_D_M64, CFG_D_M64W4, CFG_D_M128W4, CFG_D_M128W4N2, CFG_D_M128W4_C4, CFG_D_M128_C4, CFG_D_M64W4_C4, CFG_D_M64W4N1_C4,
        CFG_D16_C4 /*209*/, CFG_D16_C4_L, CFG_D16_C16, CFG_D16_C16_L, CFG_D16_C8, CFG_D16_C8_L,
        CFG_D_M32 /*215*/, CFG_D_M32_C4, CFG_D_M64N1 /*217*/, CFG_D_M128S /*218*/, CFG_D_M128S_C4, CFG_D_M64S /*220*/, CFG_D_M64S_C4,
-       CFG_D_M32_C16 /*222*/, CFG_D_M64S_C16, CFG_D_M128S_C16, CFG_D_M64W4N1_C16, CFG_D_M64W4N1_C8 /*226*/,
+       CFG_D_M32_C16 /*222*/, CFG_D_M64S_C16, CFG_D_M128S_C16, CFG_D_M64W4N1_C16, CFG_D_M64W4N1_C8 /*226*/, CFG_D_M64N2W8 /*227*/,
        CFG_M64_S_C16 = 20, CFG_M64_S_C32, CFG_M128_S_C16, CFG_M128_S_C32, CFG_M32_S_C16 /*24*/, CFG_M64_S_C4 /*25*/, CFG_M128_S_C4 /*26*/,
        CFG_M32_S_C4 /*27*/ };
 
@@ -1038,7 +1064,10 @@ std::map<TuneKey, bool>& prefer_table() {
 }
 thread_local int g_forced_cfg = -1;  // >= 0: make_plan must use exactly this configuration (the tuner's probe runs)
 // candidates: the rule-based default (-1) plus the tiles that won somewhere in tools/sweep_igemm.py
-const int kTuneCandidates[] = {-1, 200, 201, 206, 208, 226, 222, 224, 215, 216, 219, 225, 0, 1, 22};
+// 227 (round 3): 64 output rows x 512 pixels per workgroup, every wave a 2 x 2 block of 32x32 MFMA tiles -- for M = 64 (the data
+// gradient of a 64-channel layer: the north-star shape's) the 2 x 1 tiles of 201 stage twice the bytes per MFMA that the M = 128
+// forward tile does; 2 x 2 restores the forward kernel's ratio of DMA bytes and LDS operand reads to MFMAs.  202: its 4-wave sibling.
+const int kTuneCandidates[] = {-1, 200, 201, 206, 208, 226, 222, 224, 215, 216, 219, 225, 0, 1, 22, 227, 202};
 
 int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, bool allow_dma = true, int shrink = 0) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
@@ -1134,7 +1163,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
             {CFG_D_M32, 32, 32, 128, 8}, {CFG_D_M32_C4, 32, 32, 128, 4}, {CFG_D_M64N1, 32, 64, 128, 8},
             {CFG_D_M128S, 32, 128, 64, 8}, {CFG_D_M128S_C4, 32, 128, 64, 4}, {CFG_D_M64S, 32, 64, 64, 8}, {CFG_D_M64S_C4, 32, 64, 64, 4},
             {CFG_D_M32_C16, 32, 32, 128, 16}, {CFG_D_M64S_C16, 32, 64, 64, 16}, {CFG_D_M128S_C16, 32, 128, 64, 16},
-            {CFG_D_M64W4N1_C16, 32, 64, 128, 16}, {CFG_D_M64W4N1_C8, 32, 64, 128, 8},
+            {CFG_D_M64W4N1_C16, 32, 64, 128, 16}, {CFG_D_M64W4N1_C8, 32, 64, 128, 8}, {CFG_D_M64N2W8, 32, 64, 512, 8},
             {CFG_M64_S_C16, 32, 64, 64, 16}, {CFG_M64_S_C32, 32, 64, 64, 32}, {CFG_M128_S_C16, 32, 128, 64, 16},
             {CFG_M128_S_C32, 32, 128, 64, 32}, {CFG_M32_S_C16, 32, 32, 128, 16}, {CFG_M64_S_C4, 32, 64, 64, 4},
             {CFG_M128_S_C4, 32, 128, 64, 4}, {CFG_M32_S_C4, 32, 32, 128, 4}};
@@ -1151,7 +1180,12 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     // DMA configurations on padded layers whose rows are 16-byte multiples: 4-float left pad, pitch a multiple of 4 floats -> the row
     // image is staged by 16-byte DMA instructions that span several rows (run_mode 3 of igemm_dma_kernel)
     const bool dma_cfg = pl->cfg >= CFG_D_M128;
-    const bool vecrows = dma_cfg && p.XW % 4 == 0 && p.padL > 0 && p.padL <= 4 && !((CNN_OPT_SET("IGEMM_NOVECROWS") && CNN_OPT_INT("IGEMM_NOVECROWS", 0) != 0));
+    // (round 3) rows that are NOT whole 16-byte units (the north-star data gradient: dy rows of 110 floats, pad 2) take the same
+    // path: the last unit of a row then carries XW % 4 valid floats and up to three floats of whatever follows the row in memory,
+    // which land in the right-pad columns -- the wave that issued the unit zeroes them again once its DMA has landed (the pad
+    // columns must read as zeros).  IGEMM_RAGGED_ROWS=0: the old per-row 4-byte DMA for such layers.
+    const bool ragged_ok = p.XW % 4 == 0 || CNN_OPT_INT("IGEMM_RAGGED_ROWS", 1) != 0;
+    const bool vecrows = dma_cfg && ragged_ok && p.XW >= 4 && p.padL > 0 && p.padL <= 4 && !((CNN_OPT_SET("IGEMM_NOVECROWS") && CNN_OPT_INT("IGEMM_NOVECROWS", 0) != 0));
     if (vecrows) {
         p.padL = 4;
         p.LW = (4 + p.XW + padR + 3) & ~3;
@@ -1236,6 +1270,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     q.CK = pl->CK; q.MT = pl->MT; q.nchunk = p.nchunk; q.nmb = (int)pl->grid_y; q.kstep = pl->MF == 32 ? 2 : 4;
     q.a4 = pl->dma ? pl->CK / q.kstep : 0;
     if (pl->xm == 0) p.run_mode = (pl->dma && !p.need_zero && p.LW == p.XW) ? ((p.XW % 4 == 0) ? 1 : 2) : ((pl->dma && vecrows) ? 3 : 0);
+    p.row_tail = (pl->xm == 0 && p.run_mode == 3) ? p.XW % 4 : 0;
     return CNN_AMD_OK;
 }
 
@@ -1340,6 +1375,7 @@ int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w,
         case CFG_D_M128S_C16: return launch_dma<32, 2, 1, 2, 2, 8, true>(pl, s, d);
         case CFG_D_M64W4N1_C16: return launch_dma<32, 2, 1, 1, 4, 8, true>(pl, s, d);
         case CFG_D_M64W4N1_C8: return launch_dma<32, 2, 1, 1, 4, 4, true>(pl, s, d);
+        case CFG_D_M64N2W8: return launch_dma<32, 2, 2, 1, 8, 4>(pl, s, d);
         case CFG_M64_S_C16: return launch_cfg<32, 1, 1, 2, 2, 16>(pl, s, d);
         case CFG_M64_S_C32: return launch_cfg<32, 1, 1, 2, 2, 32>(pl, s, d);
         case CFG_M128_S_C16: return launch_cfg<32, 2, 1, 2, 2, 16>(pl, s, d);

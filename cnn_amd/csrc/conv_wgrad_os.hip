@@ -221,6 +221,9 @@ int os_wgrad_slots(const cnn_conv2d_desc* d) {
         const int v = atoi(e);
         if (v > 0) slots = v;
     }
+    // (tuning, per layer: OS_SLABS2 / OS_SLABS3 / OS_SLABS4 = slabs of conv_layer_2 / _3 / _4)
+    const OptVal per = sh->H == 55 ? CNN_OPT_VAL("OS_SLABS2") : (sh->H == 27 ? CNN_OPT_VAL("OS_SLABS3") : CNN_OPT_VAL("OS_SLABS4"));
+    if (per && atoi(per) > 0) slots = atoi(per);
     const int upi = sh->H == 55 ? 9 : (sh->H == 27 ? 2 : 1);
     const long long units = (long long)d->B * upi;
     if (units >= (1ll << 30)) return 0;

@@ -203,6 +203,44 @@ def test_stack_layers_full_batch_mfma_equals_im2col(T, case):
     assert err(gb, gbr) <= REL_TOL
 
 
+@pytest.mark.parametrize("cfg", [201, 227, 200])
+@pytest.mark.parametrize("case", [(16, 64, 60, 60, 128, 3, 1, 0), (12, 64, 61, 61, 64, 3, 1, 1), (16, 128, 59, 59, 64, 3, 1, 1), (9, 64, 62, 58, 128, 3, 1, 0)],
+                         ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_dma_kernel_ragged_rows_equal_im2col(T, case, cfg, lib_option):
+    """the double-buffered DMA kernel with 16-byte row staging on rows that are NOT whole 16-byte units (run_mode 3 with a ragged
+    last unit: the north-star data gradient reads dy rows of 110 floats with pad 2): every tile family the tuner may pin, forced,
+    forward (padded layers) and data gradient, against the im2col fallback -- and bit-identical to the per-row 4-byte staging
+    (IGEMM_RAGGED_ROWS=0), which moves the same values in the same order.  Shapes include a tensor whose very last row ends the
+    allocation (the one unit that must not be fetched 16 bytes wide)."""
+    from cnn_amd import capi
+
+    B, Ci, H, W, Co, k, s, pad = case
+    g = T.Generator(device="cuda").manual_seed(9)
+    x = T.rand((B, Ci, H, W), generator=g, device="cuda")
+    w = T.randn((Co, Ci, k, k), generator=g, device="cuda") * float(np.sqrt(2.0 / (Ci * k * k)))
+    b = T.randn((Co,), generator=g, device="cuda") * 0.1
+    lib_option("IGEMM_CFG", str(cfg))
+    lib_option("FWD_RD", "0")
+    lib_option("DGRAD_RD", "0")
+    conv = capi.Conv2d(*case)
+    dy = T.rand(conv.out_shape(), generator=g, device="cuda") * 2 - 1
+
+    def err(a, ref):
+        return float((a - ref).abs().max() / ref.abs().max())
+
+    res = {}
+    for ragged in ("1", "0"):
+        lib_option("IGEMM_RAGGED_ROWS", ragged)
+        y = T.full(conv.out_shape(), 7.0, device="cuda")
+        conv.forward(x, w, b, y)
+        dx = T.full_like(x, 7.0)
+        conv.backward_data(dy, w, dx)
+        res[ragged] = (y, dx)
+    assert err(res["1"][0], conv.forward_im2col(x, w, b)) <= REL_TOL
+    assert err(res["1"][1], conv.backward_data_im2col(dy, w)) <= REL_TOL
+    assert T.equal(res["1"][0], res["0"][0]) and T.equal(res["1"][1], res["0"][1])
+
+
 def test_dropout_layer_and_a_list_that_uses_it(T):
     """Dropout (dropout.cpp; row n4): the two kernels bit-exact against the oracle, and a layer list that contains the layer --
     the position the reference's own (commented-out) line alexnet.cpp:28 puts it: behind a convolution -- through the C++
