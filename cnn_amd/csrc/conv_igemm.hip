@@ -1571,7 +1571,9 @@ int cnn_conv2d_autotune(const cnn_conv2d_desc* d, void* stream) {
         }
         int best = -1;
         float best_ms = 1e30f;
+        const int excluded = CNN_OPT_INT("TUNE_EXCLUDE", -2);  // (measurement switch: one candidate the tuner must not pick)
         for (int c : kTuneCandidates) {
+            if (c == excluded) continue;
             Plan pl;
             g_forced_cfg = c;
             int rc = make_plan("cnn_conv2d_autotune", d, mode, &pl);
