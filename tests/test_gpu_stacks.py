@@ -114,7 +114,13 @@ def test_stack_train_steps_vs_oracle(T, which, res, B):
         onet.backward(odelta, masks_from=masks_from)
         onet64.backward(d64, masks_from=masks_from)
         for name, lo, hi, idx in _slices(onet.layers):
-            assert_close_arbitrated(g[lo:hi], onet.grads[lo:hi], onet64.grads[lo:hi], REL_TOL, 2.0, f"{which} step{step} grad {name}")
+            tol = REL_TOL
+            if name == "linear.b":
+                # = mean_b(softmax(z_b) - onehot_b), a 3-element tensor: a logit error dz moves it by up to |dz| / 2 (the softmax
+                # Jacobian diag(p) - p p^T has infinity-norm <= 1/2), and the logits themselves are only held to REL_TOL * max|z|
+                # (above) -- the implicit-GEMM tiles the tuner pins differ from box to box, and with them the last bits of z
+                tol = max(REL_TOL, 0.5 * REL_TOL * float(np.abs(ologits).max()) / float(np.abs(onet.grads[lo:hi]).max()))
+            assert_close_arbitrated(g[lo:hi], onet.grads[lo:hi], onet64.grads[lo:hi], tol, 2.0, f"{which} step{step} grad {name}")
         off = 0
         for e in onet.layers:  # BatchNorm2D moving statistics, updated by the forward pass (batchnorm2d.cpp:78-79)
             if e["kind"] == "bn":
@@ -203,7 +209,7 @@ def test_stack_layers_full_batch_mfma_equals_im2col(T, case):
     assert err(gb, gbr) <= REL_TOL
 
 
-@pytest.mark.parametrize("cfg", [201, 227, 200])
+@pytest.mark.parametrize("cfg", [201, 227, 200, 202])
 @pytest.mark.parametrize("case", [(16, 64, 60, 60, 128, 3, 1, 0), (12, 64, 61, 61, 64, 3, 1, 1), (16, 128, 59, 59, 64, 3, 1, 1), (9, 64, 62, 58, 128, 3, 1, 0)],
                          ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
 def test_dma_kernel_ragged_rows_equal_im2col(T, case, cfg, lib_option):

@@ -31,6 +31,9 @@ def canonical(name):
     m = re.match(r"conv_dgrad_pool_pk_3_16_3_2<\d+,(true|false)>$", name)
     if m:
         return "conv_dgrad_pk<3,16,3,2>" + ("+pool" if m.group(1) == "true" else "+poolm")
+    m = re.match(r"conv_dgrad_pool_lds_3_16_3_2<(true|false)>$", name)
+    if m:  # (round 3: the LDS-staged kernel behind the same ABI entry point / timer key)
+        return "conv_dgrad_pk<3,16,3,2>" + ("+pool" if m.group(1) == "true" else "+poolm")
     m = re.match(r"conv_wgrad_pk_3_16_3_2<\d+,(\d+)>$", name)
     if m:
         return "conv_wgrad_pk<3,16,3,2>" + {"0": "", "1": "+pool", "2": "+poolm"}[m.group(1)]
