@@ -66,6 +66,22 @@ def main():
     ref = check.clone()
     dist.broadcast(ref, 0)
     assert torch.equal(check, ref), "replicas diverged"
+    # the fused step tail of architectures::Sequential (host/src/sequential.cpp, fused_tail) exchanges the arena in TWO buckets --
+    # everything behind conv_layer_1 first (it is final one weight-gradient kernel earlier), conv_layer_1's 448 floats last -- each
+    # followed by its own SGD range: the same sums (a ring / tree all-reduce adds an element's terms in an order that depends on where
+    # the element sits in the message, so the last bits may differ from the one-call exchange), identical on every rank
+    g2 = torch.from_numpy(net.grads.copy())
+    lo1 = 16 * 3 * 9 + 16  # conv_layer_1: filters + biases (alexnet.cpp:12, checkpoint order)
+    p2 = p0.copy()
+    for a, b in ((lo1, net.n_params), (0, lo1)):
+        part = g2[a:b].clone()
+        s2 = dp.allreduce_grads(part, dist, world)
+        p2[a:b] = O.sgd_update(p0[a:b], part.numpy() * np.float32(s2), lr)
+    assert np.abs(p2 - new_params).max() <= 1e-6 * np.abs(new_params).max(), "two-bucket exchange differs from the one-call exchange"
+    check2 = torch.from_numpy(p2.copy())
+    ref2 = check2.clone()
+    dist.broadcast(ref2, 0)
+    assert torch.equal(check2, ref2), "replicas diverged after the two-bucket exchange"
     if rank == 0:
         full = O.Net(GB, 3, Hh, Hh)
         full.params[:] = p0

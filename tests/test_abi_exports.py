@@ -48,6 +48,25 @@ def test_workspace_query_and_bad_args_do_not_need_a_gpu():
     assert isinstance(lib.cnn_amd_device_arch(), bytes)
 
 
+def test_option_table_needs_no_gpu_and_no_getenv_on_launch_paths():
+    """the measurement switches live in one table (cnn_amd_set_option / cnn_amd_get_option): set, read back, remove; names with
+    or without the CNN_AMD_ prefix; and no kernel source calls getenv any more (the table reads the environment once)"""
+    import glob
+
+    assert capi.get_option("NO_SUCH_SWITCH") is None
+    capi.set_option("CNN_AMD_TEST_SWITCH", 7)
+    assert capi.get_option("TEST_SWITCH") == "7" and capi.get_option("CNN_AMD_TEST_SWITCH") == "7"
+    with capi.option("TEST_SWITCH", "9"):
+        assert capi.get_option("TEST_SWITCH") == "9"
+    assert capi.get_option("TEST_SWITCH") == "7"
+    capi.set_option("TEST_SWITCH", None)
+    assert capi.get_option("TEST_SWITCH") is None
+    assert capi.load().cnn_amd_set_option(b"", b"1") != 0
+    for path in glob.glob(os.path.join(ROOT, "cnn_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "cnn_amd", "host", "src", "*.cpp")):
+        text = re.sub(r"//.*", "", open(path).read())
+        assert "getenv" not in text, path
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(capi, "_lib", None)
     monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libcnn_amd.so")
