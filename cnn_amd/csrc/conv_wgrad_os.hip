@@ -203,7 +203,9 @@ int launch_os(const cnn_conv2d_desc* d, const float* x, const float* dy, float* 
         attr_once.mark();
     }
     const dim3 grid((unsigned)slots, CI / kCib, CO / kCob);
-    CNN_KLAUNCH(s, "conv_wgrad_os", (conv_wgrad_os_kernel<CI, CO, H, W, R><<<grid, kThreads, G::lds_bytes, s>>>(p)),
+    char name[48];
+    snprintf(name, sizeof(name), "conv_wgrad_os<%d,%d>", CI, CO);
+    CNN_KLAUNCH(s, name, (conv_wgrad_os_kernel<CI, CO, H, W, R><<<grid, kThreads, G::lds_bytes, s>>>(p)),
                 "B%d Ci%d %dx%d Co%d k3 s2 p0 slabs%d", d->B, CI, H, W, CO, slots);
     return CNN_AMD_OK;
 }

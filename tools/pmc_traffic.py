@@ -55,6 +55,9 @@ def canonical(name):
     m = re.match(r"conv_wgrad_win_kernel<(\d),(true|false)(?:,(?:true|false))?>$", name)
     if m:
         return "conv_wgrad_win<3,16,3,2>" + {"0": "", "1": "+pool", "2": "+poolm"}[m.group(1)]
+    m = re.match(r"conv_wgrad_os_kernel<(\d+),(\d+),\d+,\d+,\d+>$", name)
+    if m:
+        return f"conv_wgrad_os<{m.group(1)},{m.group(2)}>"
     m = re.match(r"wgrad_rd_kernel_p1<(\d+,\d+,\d+),(true|false)>$", name)
     if m:
         return f"wgrad_rd<{m.group(1)},p1>"
