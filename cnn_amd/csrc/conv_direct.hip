@@ -841,7 +841,10 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pool_lds_3_16_3_2(const flo
             if (h >= H) continue;
             float* row = dxb + ((size_t)ci * H + h) * W + 4 * (size_t)bw;
             if (quad) {
-                *(float4*)row = make_float4(v[0], v[1], v[2], v[3]);
+                {  // (dx has no consumer in a train step: streaming stores keep it out of the caches the other kernels live in)
+                    typedef float nt4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(nt4{v[0], v[1], v[2], v[3]}, (nt4*)row);
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
