@@ -218,6 +218,7 @@ void cnnh_net_update_auto(void* hv, float lr) { ((Handle*)hv)->net->update_gradi
 // host copy of a layer's last output through Layer::get_output() (the Grad-CAM contract, alexnet.cpp:97,105)
 int cnnh_net_layer_output(void* hv, const char* layer_name, float* out, size_t cap_floats) {
     Handle* h = (Handle*)hv;
+    h->net->flush_deferred();  // (a re-materialising get_output() uses the layer's workspace: nothing deferred may still read it)
     for (const auto& layer : h->net->layers()) {
         if (layer->name != layer_name) continue;
         const auto ts = layer->get_output();
