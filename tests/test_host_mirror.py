@@ -297,6 +297,15 @@ def test_fused_train_step_keeps_every_output_observable_and_grad_cam_identical()
             if a[5] is not None:
                 assert np.array_equal(a[5], b[5]) and np.array_equal(a[6].view(np.uint32), b[6].view(np.uint32)), "Grad-CAM(conv_layer_1)"
                 assert a[5].max() > 0
+        # three more steps back to back, with NOTHING in between that would order the deferred kernel early (every accessor above
+        # does): each step's first-layer data gradient is released inside the next forward pass, behind the third convolution
+        for on, net in zip((1, 0), nets):
+            lib.cnnh_set_fuse_pool_block(on)
+            for _ in range(3):
+                net.train_step(xd, ld, 1e-3)
+        tail = [(net.get_params(), net.get_grads(), net.input_delta((B, 3, 224, 224)), net.last_loss()) for net in nets]
+        assert np.array_equal(tail[0][0], tail[1][0]) and np.array_equal(tail[0][1], tail[1][1]), "back-to-back steps: parameters / gradients"
+        assert np.array_equal(tail[0][2].view(np.uint32), tail[1][2].view(np.uint32)) and tail[0][3] == tail[1][3]
     finally:
         lib.cnnh_set_fuse_pool_block(1)
         for net in nets:
