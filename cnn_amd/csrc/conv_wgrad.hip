@@ -315,32 +315,39 @@ __global__ __launch_bounds__(64 * WM * WN * WK * (PC ? 2 : 1), PC ? 2 : 2) void 
 // A workgroup owns 32 consecutive elements; its 8 slot-lanes walk the group's slots with independent loads and
 // are then combined through LDS in a fixed order, so the result does not depend on scheduling.
 constexpr int kRedElems = 32, kRedLanes = 8;
+// Jobs with MANY small slabs (conv_layer_2 of the reference net: 512 slabs of 4 640 floats) gave each of their few workgroups a chain
+// of 64 dependent-ish loads per thread -- 40 us of the side stream in the train step.  Such a job runs with 32 slot-lanes x 8
+// elements per workgroup instead of 8 x 32: four times the workgroups, a quarter of the chain.  The rule is part of the summation
+// order (lane sl adds slots sl, sl + L, ...; then the L partial sums in lane order), so every reduction path applies the same one
+// (first_layer_finish's slabs have n = 448 and never qualify).
+constexpr int kRedWideLanes = 32;
+__host__ __device__ inline int red_lanes(int nslots, size_t n) { return (nslots > 256 && n >= 1024) ? kRedWideLanes : kRedLanes; }
 __global__ __launch_bounds__(kRedElems * kRedLanes) void slab_reduce(const float* __restrict__ in,
                                                                      float* __restrict__ out, int nslots, size_t n,
                                                                      int per_group, float divisor, int final_stage,
-                                                                     int split_n, float* __restrict__ out_b) {
-    __shared__ float red[kRedLanes][kRedElems];
-    const int e = threadIdx.x & (kRedElems - 1), sl = threadIdx.x / kRedElems;
-    const size_t i = (size_t)blockIdx.x * kRedElems + e;
+                                                                     int split_n, float* __restrict__ out_b, int lanes) {
+    __shared__ float red[kRedWideLanes][kRedElems];
+    const int E = (kRedElems * kRedLanes) / lanes;  // elements per workgroup: 32 (8 lanes) or 8 (32 lanes)
+    const int e = threadIdx.x % E, sl = threadIdx.x / E;
+    const size_t i = (size_t)blockIdx.x * E + e;
     const int g = blockIdx.y;
     const int s_begin = g * per_group;
     const int s_end = (s_begin + per_group < nslots) ? s_begin + per_group : nslots;
     float acc = 0.f;
     if (i < n) {
         int s = s_begin + sl;
-        for (; s + 3 * kRedLanes < s_end; s += 4 * kRedLanes) {
-            const float v0 = in[(size_t)s * n + i], v1 = in[(size_t)(s + kRedLanes) * n + i];
-            const float v2 = in[(size_t)(s + 2 * kRedLanes) * n + i], v3 = in[(size_t)(s + 3 * kRedLanes) * n + i];
+        for (; s + 3 * lanes < s_end; s += 4 * lanes) {
+            const float v0 = in[(size_t)s * n + i], v1 = in[(size_t)(s + lanes) * n + i];
+            const float v2 = in[(size_t)(s + 2 * lanes) * n + i], v3 = in[(size_t)(s + 3 * lanes) * n + i];
             acc += v0; acc += v1; acc += v2; acc += v3;
         }
-        for (; s < s_end; s += kRedLanes) acc += in[(size_t)s * n + i];
+        for (; s < s_end; s += lanes) acc += in[(size_t)s * n + i];
     }
     red[sl][e] = acc;
     __syncthreads();
     if (sl == 0 && i < n) {
         float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < kRedLanes; ++k) t += red[k][e];
+        for (int k = 0; k < lanes; ++k) t += red[k][e];
         if (final_stage && split_n > 0) {  // slab rows are [split_n weight gradients | 1 bias gradient]
             const size_t row = i / (split_n + 1), col = i - row * (split_n + 1);
             if (col < (size_t)split_n) out[row * split_n + col] = t / divisor;
@@ -383,27 +390,27 @@ PendingReduces& pending_reduces() {
 }
 
 __global__ __launch_bounds__(kRedElems * kRedLanes) void slab_reduce_batch(const RedBatch rb) {
-    __shared__ float red[kRedLanes][kRedElems];
+    __shared__ float red[kRedWideLanes][kRedElems];
     const RedJob j = rb.job[blockIdx.y];
-    if ((size_t)blockIdx.x * kRedElems >= j.n) return;
-    const int e = threadIdx.x & (kRedElems - 1), sl = threadIdx.x / kRedElems;
-    const size_t i = (size_t)blockIdx.x * kRedElems + e, n = j.n;
+    const int L = red_lanes(j.nslots, j.n), E = (kRedElems * kRedLanes) / L;
+    if ((size_t)blockIdx.x * E >= j.n) return;
+    const int e = threadIdx.x % E, sl = threadIdx.x / E;
+    const size_t i = (size_t)blockIdx.x * E + e, n = j.n;
     float acc = 0.f;
     if (i < n) {  // (the loop of slab_reduce's final stage: same order, same rounding)
         int s = sl;
-        for (; s + 3 * kRedLanes < j.nslots; s += 4 * kRedLanes) {
-            const float v0 = j.in[(size_t)s * n + i], v1 = j.in[(size_t)(s + kRedLanes) * n + i];
-            const float v2 = j.in[(size_t)(s + 2 * kRedLanes) * n + i], v3 = j.in[(size_t)(s + 3 * kRedLanes) * n + i];
+        for (; s + 3 * L < j.nslots; s += 4 * L) {
+            const float v0 = j.in[(size_t)s * n + i], v1 = j.in[(size_t)(s + L) * n + i];
+            const float v2 = j.in[(size_t)(s + 2 * L) * n + i], v3 = j.in[(size_t)(s + 3 * L) * n + i];
             acc += v0; acc += v1; acc += v2; acc += v3;
         }
-        for (; s < j.nslots; s += kRedLanes) acc += j.in[(size_t)s * n + i];
+        for (; s < j.nslots; s += L) acc += j.in[(size_t)s * n + i];
     }
     red[sl][e] = acc;
     __syncthreads();
     if (sl == 0 && i < n) {
         float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < kRedLanes; ++k) t += red[k][e];
+        for (int k = 0; k < L; ++k) t += red[k][e];
         if (j.split_n > 0) {
             const size_t row = i / (j.split_n + 1), col = i - row * (j.split_n + 1);
             if (col < (size_t)j.split_n) j.out[row * j.split_n + col] = t / j.divisor;
@@ -418,10 +425,11 @@ __global__ __launch_bounds__(kRedElems * kRedLanes) void slab_reduce_batch(const
 // in the same order -> bit-identical.  The wide layers of the stacks reduce 2.4 M-element slabs: the scalar kernel launched 590 k
 // workgroups of one load per thread for a batch of eight such jobs and ran at 0.6 TB/s (dispatch-bound).
 __global__ __launch_bounds__(kRedElems * kRedLanes) void slab_reduce_batch_v4(const RedBatch rb) {
-    __shared__ float4 red[kRedLanes][kRedElems];
+    __shared__ float4 red[kRedWideLanes][kRedElems];
     const RedJob j = rb.job[blockIdx.y];
+    const int kRedLanes = red_lanes(j.nslots, j.n), kRedElems = (::kRedElems * ::kRedLanes) / kRedLanes;  // (per job, see red_lanes)
     if ((size_t)blockIdx.x * kRedElems * 4 >= j.n) return;
-    const int e = threadIdx.x & (kRedElems - 1), sl = threadIdx.x / kRedElems;
+    const int e = threadIdx.x % kRedElems, sl = threadIdx.x / kRedElems;
     const size_t i = ((size_t)blockIdx.x * kRedElems + e) * 4, n = j.n;  // (n % 4 == 0: all four elements exist or none)
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) {
@@ -477,20 +485,23 @@ __global__ __launch_bounds__(kRedElems * kRedLanes) void slab_reduce_batch_v4(co
 int flush_reduces(hipStream_t s) {
     PendingReduces& p = pending_reduces();
     if (p.count == 0) return CNN_AMD_OK;
-    unsigned most = 0;
     bool v4 = !((CNN_OPT_SET("REDUCE_SCALAR") && CNN_OPT_INT("REDUCE_SCALAR", 0) != 0));
-    for (int i = 0; i < p.count; ++i) {
-        most = p.batch.job[i].n > most ? p.batch.job[i].n : most;
+    for (int i = 0; i < p.count; ++i)
         if (p.batch.job[i].n % 4 != 0 || reinterpret_cast<uintptr_t>(p.batch.job[i].in) % 16 != 0) v4 = false;
+    unsigned most = 0;  // workgroups along x: the job that needs the most (each job's elements per workgroup follow red_lanes)
+    for (int i = 0; i < p.count; ++i) {
+        const RedJob& j = p.batch.job[i];
+        const unsigned per = (unsigned)((kRedElems * kRedLanes) / red_lanes(j.nslots, j.n)) * (v4 ? 4u : 1u);
+        const unsigned need = (j.n + per - 1) / per;
+        most = need > most ? need : most;
     }
     const int jobs = p.count;
     p.count = 0;
     if (v4) {
-        CNN_KLAUNCH(s, "slab_reduce/batch", (slab_reduce_batch_v4<<<dim3((most / 4 + kRedElems - 1) / kRedElems, jobs), kRedElems * kRedLanes, 0, s>>>(p.batch)),
-                    "jobs=%d", jobs);
+        CNN_KLAUNCH(s, "slab_reduce/batch", (slab_reduce_batch_v4<<<dim3(most, jobs), kRedElems * kRedLanes, 0, s>>>(p.batch)), "jobs=%d", jobs);
         return CNN_AMD_OK;
     }
-    CNN_KLAUNCH(s, "slab_reduce/batch", (slab_reduce_batch<<<dim3((most + kRedElems - 1) / kRedElems, jobs), kRedElems * kRedLanes, 0, s>>>(p.batch)),
+    CNN_KLAUNCH(s, "slab_reduce/batch", (slab_reduce_batch<<<dim3(most, jobs), kRedElems * kRedLanes, 0, s>>>(p.batch)),
                 "jobs=%d", jobs);
     return CNN_AMD_OK;
 }
@@ -498,7 +509,6 @@ int flush_reduces(hipStream_t s) {
 // sums `nslots` slabs of n floats held in `slabs` into dst (divided by divisor); `tmp` holds >= ceil(nslots/64)*n
 int reduce_slabs(hipStream_t s, const float* slabs, int nslots, size_t n, float* tmp, float* dst, float divisor,
                  const char* tag, int split_n = 0, float* dst_b = nullptr) {
-    const unsigned gx = (unsigned)((n + kRedElems - 1) / kRedElems);
     PendingReduces& pend = pending_reduces();
     if (pend.defer && !(nslots > 512 || (nslots > 64 && n > 65536)) && n < (1ull << 31)) {
         if (pend.count == kMaxRedJobs)
@@ -511,13 +521,15 @@ int reduce_slabs(hipStream_t s, const float* slabs, int nslots, size_t n, float*
     // launch of up to 512 slots x 8 slot-lanes beats two)
     if (nslots > 512 || (nslots > 64 && n > 65536)) {
         const int per = 64, groups = (nslots + per - 1) / per;
+        const unsigned gx = (unsigned)((n + kRedElems - 1) / kRedElems);
         CNN_KLAUNCH(s, "slab_reduce/stage1",
-                    (slab_reduce<<<dim3(gx, groups), kRedElems * kRedLanes, 0, s>>>(slabs, tmp, nslots, n, per, 1.f, 0, 0, nullptr)), "%s", tag);
+                    (slab_reduce<<<dim3(gx, groups), kRedElems * kRedLanes, 0, s>>>(slabs, tmp, nslots, n, per, 1.f, 0, 0, nullptr, kRedLanes)), "%s", tag);
         slabs = tmp;
         nslots = groups;
     }
+    const int lanes = red_lanes(nslots, n), elems = (kRedElems * kRedLanes) / lanes;
     CNN_KLAUNCH(s, "slab_reduce/final",
-                (slab_reduce<<<dim3(gx, 1), kRedElems * kRedLanes, 0, s>>>(slabs, dst, nslots, n, nslots, divisor, 1, split_n, dst_b)), "%s", tag);
+                (slab_reduce<<<dim3((unsigned)((n + elems - 1) / elems), 1), kRedElems * kRedLanes, 0, s>>>(slabs, dst, nslots, n, nslots, divisor, 1, split_n, dst_b, lanes)), "%s", tag);
     return CNN_AMD_OK;
 }
 
