@@ -41,14 +41,16 @@ def algorithmic_work(key):
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         flops = 2.0 * B * Co * Ho * Wo * Ci * k * k
         x_b, y_b, w_b = 4.0 * B * Ci * H * W, 4.0 * B * Co * Ho * Wo, 4.0 * Co * Ci * k * k
-        if kernel.endswith(("+pool", "+poolm")) or kernel.startswith("conv_fwd_pool_pk"):
+        if kernel.endswith(("+pool", "+poolm", "+poolm8")) or kernel.startswith("conv_fwd_pool_pk"):
             # first block in the pooled domain: the Co*Ho*Wo tensors are never touched.  pooled-domain tensor = B*Co*(Ho/2)*(Wo/2)
             pd_b = 4.0 * B * Co * (Ho // 2) * (Wo // 2)
+            # the pool mask: an int32 per window, or ("...8": CNN_CONV2D_POOL_MASK_PACKED) one byte per window in 4-byte-aligned rows
+            mk_b = 1.0 * B * Co * (Ho // 2) * (((Wo // 2) + 3) & ~3) if kernel.endswith("8") else pd_b
             fl = 2.0 * B * Co * (2 * (Ho // 2)) * (2 * (Wo // 2)) * Ci * k * k  # conv pixels inside a pooling window
             if kernel.startswith("conv_fwd_pool_pk"):
-                return x_b + 2 * pd_b + w_b, fl          # x, w -> pooled + mask
-            nt = 2 if kernel.endswith("+poolm") else 3    # "+poolm": dpool arrives pre-masked, the pooled tensor is not read
-            return x_b + nt * pd_b + w_b, fl              # wgrad: x + (dpool, mask[, pooled]) -> gw ; dgrad: those -> dx
+                return x_b + pd_b + mk_b + w_b, fl       # x, w -> pooled + mask
+            nt = 1 if kernel.endswith(("+poolm", "+poolm8")) else 2    # "+poolm": the ReLU mask rides in the pool mask, the pooled tensor is not read
+            return x_b + nt * pd_b + mk_b + w_b, fl       # wgrad: x + (dpool, mask[, pooled]) -> gw ; dgrad: those -> dx
         if kernel.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel", "wgrad_rd", "conv_direct", "conv_dgrad_pk", "conv_fwd_pk",
                               "conv_wgrad_pk", "conv_wgrad_win", "conv_wgrad_os", "conv_stem", "conv_dgrad_thin", "conv_fwd_rd", "conv_dgrad_rd")):
             fused = y_b if (kernel.endswith("/fwd+relu") or ",relu" in kernel or kernel.endswith(">+relu")) else 0.0  # second output tensor

@@ -18,7 +18,10 @@ class CnnAmdError(RuntimeError):
 class ConvDesc(C.Structure):
     """mirror of cnn_conv2d_desc"""
 
-    _fields_ = [(n, C.c_int) for n in ("B", "Ci", "H", "W", "Co", "k", "s", "pad")]
+    _fields_ = [(n, C.c_int) for n in ("B", "Ci", "H", "W", "Co", "k", "s", "pad", "flags")]
+
+
+POOL_MASK_PACKED = 1  # CNN_CONV2D_POOL_MASK_PACKED (include/cnn_amd.h)
 
 
 _lib = None
@@ -42,6 +45,9 @@ SIGNATURES = {
     "cnn_conv2d_forward": (C.c_int, [_D, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_forward_relu": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_relu_maxpool2_supported": (C.c_int, [_D]),
+    "cnn_conv2d_pool_mask_packed_supported": (C.c_int, [_D]),
+    "cnn_conv2d_pool_mask_bytes": (C.c_size_t, [_D]),
+    "cnn_conv2d_pool_mask_unpack": (C.c_int, [_D, _P, _P, _P]),
     "cnn_conv2d_relu_only_supported": (C.c_int, [_D]),
     "cnn_conv2d_relu_maxpool2_forward": (C.c_int, [_D, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cnn_conv2d_relu_maxpool2_forward_prepared": (C.c_int, [_D, _P, _P, _P, _P, _P]),
@@ -229,6 +235,21 @@ class Conv2d:
 
     def relu_maxpool2_supported(self):
         return bool(self.lib.cnn_conv2d_relu_maxpool2_supported(C.byref(self.desc)))
+
+    def pool_mask_packed_supported(self):
+        return bool(self.lib.cnn_conv2d_pool_mask_packed_supported(C.byref(self.desc)))
+
+    def set_pool_mask_packed(self, on=True):
+        """desc.flags: the fused block's calls of this object write / read the packed one-byte pool mask (include/cnn_amd.h)"""
+        self.desc.flags = POOL_MASK_PACKED if on else 0
+
+    def pool_mask_bytes(self):
+        return int(self.lib.cnn_conv2d_pool_mask_bytes(C.byref(self.desc)))
+
+    def pool_mask_unpack(self, packed, mask):
+        _need_gpu(packed, mask)
+        check(self.lib.cnn_conv2d_pool_mask_unpack(C.byref(self.desc), _ptr(packed), _ptr(mask), _stream()), "cnn_conv2d_pool_mask_unpack")
+        return mask
 
     def relu_maxpool2_forward(self, x, w, bias, pooled, mask=None, prepared_fwd=None):
         """Conv2D -> ReLU -> MaxPool2D(2,2) in one kernel: writes pooled (and mask); from prepared filters when given"""

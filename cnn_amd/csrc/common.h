@@ -17,6 +17,11 @@ int fail(int code, const char* fmt, ...);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// packed pool mask (include/cnn_amd.h, CNN_CONV2D_POOL_MASK_PACKED): bytes per pooled row (rows start 4-byte aligned: the window
+// kernel moves four windows' bytes per 4-byte LDS-DMA)
+__host__ __device__ inline int pool_mask_pitch(int PWo) { return (PWo + 3) & ~3; }
+bool direct_pool_mask_packed_ok(const cnn_conv2d_desc* d);  // conv_direct.hip
+
 // ---- measurement switches -------------------------------------------------------------------------------
 // The A/B switches of the kernels' planners live in ONE process-wide table (abi.hip): filled once from the CNN_AMD_* variables of the
 // environment when the library is first used, changed afterwards only through cnn_amd_set_option() (include/cnn_amd.h).  A launch

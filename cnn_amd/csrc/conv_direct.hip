@@ -707,11 +707,13 @@ __global__ __launch_bounds__(kFinThreads) void first_layer_finish(const float* _
 // conv_dgrad_pool_pk: dx is bit-identical.
 constexpr int kDR = 4;     // block rows per item = waves per workgroup
 constexpr int kDSeg = 62;  // block columns per item (slots 0 .. 62 of a 64-slot row = window columns bw0 - 1 .. bw0 + 61)
-template <bool RM>
+// MODE: 0 = (dpool, int32 mask) | 1 = + pooled (the ReLU mask from the tensor) | 2 = (dpool, packed one-byte mask: include/cnn_amd.h)
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void conv_dgrad_pool_lds_3_16_3_2(const float* __restrict__ dpool, const int32_t* __restrict__ pmask,
                                                                        const float* __restrict__ pooled, const v2f* __restrict__ wp,
                                                                        float* __restrict__ dx, int B, int H, int W, int Ho, int Wo,
                                                                        int ngroups, int nsegs, unsigned m_gs, unsigned m_seg) {
+    constexpr bool RM = MODE == 1, PK8 = MODE == 2;
     constexpr int CO = 16, CI = 3, NA = RM ? 3 : 2, ROWS = kDR + 1;
     static_assert(kDR == kWaves, "one block row per wave");
     __shared__ float tile[NA][CO][ROWS][64];
@@ -720,8 +722,9 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pool_lds_3_16_3_2(const flo
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pbytes = (int)((unsigned)B * CO * pplane * 4u);
+    const int pitch8 = pool_mask_pitch(PWo), plane8 = PHo * pitch8;
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dpool, 0, pbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)pmask, 0, pbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)pmask, 0, PK8 ? (int)((unsigned)B * CO * plane8) : pbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(RM ? pooled : dpool), 0, pbytes, 0x00020000);
     const int item = (int)xcd_swizzle(blockIdx.x, gridDim.x);
     const int gs = ngroups * nsegs;
@@ -743,7 +746,11 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pool_lds_3_16_3_2(const flo
             const unsigned off = (cok && wr >= 0 && wr < PHo) ? (unsigned)(wr * PWo + wc) * 4u : kBufOOB;
             const int so = (b * CO + ch) * pplane * 4;
             vd[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, (int)off, so, 0));
-            vm[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, (int)off, so, 0));
+            if constexpr (PK8) {  // (a window outside the plane reads 0 = "maximum at (0,0)" with a delta of 0: contributes nothing)
+                const unsigned off8 = (off != kBufOOB) ? (unsigned)(wr * pitch8 + wc) : kBufOOB;
+                vm[jj] = __builtin_bit_cast(float, (int)__builtin_amdgcn_raw_buffer_load_b8(rm, (int)off8, (b * CO + ch) * plane8, 0));
+            } else
+                vm[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, (int)off, so, 0));
             if constexpr (RM) vp[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (int)off, so, 0));
         }
 #pragma unroll
@@ -788,7 +795,8 @@ __global__ __launch_bounds__(kBlock) void conv_dgrad_pool_lds_3_16_3_2(const flo
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int w = ((i + 1) >> 1) * 2 + ((j + 1) >> 1);
-                D[i][j] = (mk[w] == cbase + i * Wo + j) ? g[w] : 0.f;  // pool2d.cpp:96-107
+                if constexpr (PK8) D[i][j] = (mk[w] == ((i + 1) & 1) * 2 + ((j + 1) & 1)) ? g[w] : 0.f;  // (the pixel's place inside ITS window)
+                else D[i][j] = (mk[w] == cbase + i * Wo + j) ? g[w] : 0.f;  // pool2d.cpp:96-107
             }
         asm volatile("" ::: "memory");  // (keeps the weight s_loads of all channels from being hoisted, see above)
         const v2f* q = wp + ch * 16;
@@ -920,19 +928,21 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_pk_3_16_3_2(const float* __re
 // window rows (5 input rows x 3 floats x 3 channels = 45 loads for 2 x 27 taps), in exactly the tap order of
 // conv_fwd_pk_3_16_3_2 (bit-identical y), applies bias and ReLU, swaps values with its neighbour through DPP and the
 // even lane scans the window in the reference's order (pool2d.cpp:67-75: first maximum wins, strict '<').
-template <int DBG>  // tuning ablations: 1 no FMAs, 2 one weight fetch for all taps
+// PK8: the mask is the packed one-byte form (include/cnn_amd.h, CNN_CONV2D_POOL_MASK_PACKED): rows of `pitch8` bytes.
+template <int DBG, bool PK8>  // DBG: tuning ablations: 1 no FMAs, 2 one weight fetch for all taps
 __global__ __launch_bounds__(kBlock) void conv_fwd_pool_pk_3_16_3_2(const float* __restrict__ x, const v2f* __restrict__ wp,
                                                                     float* __restrict__ pooled, int32_t* __restrict__ mask,
                                                                     int B, int H, int W, int Ho, int Wo, int PHo, int PWo,
-                                                                    int items_per_img, unsigned m_ipi, unsigned m_prow) {
+                                                                    int items_per_img, unsigned m_ipi, unsigned m_prow, int pitch8) {
     constexpr int CI = 3, CO = 16, K = 3;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long items = (long long)B * items_per_img;
     const int half = 2 * PHo * PWo;  // window columns per image
-        const int out_bytes = (int)((unsigned)B * CO * PHo * PWo * 4u);
+    const int out_bytes = (int)((unsigned)B * CO * PHo * PWo * 4u);
+    const int mask_bytes = PK8 ? (int)((unsigned)B * CO * PHo * pitch8) : out_bytes;
     const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc((void*)pooled, 0, out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)(mask ? mask : (int32_t*)pooled), 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)(mask ? mask : (int32_t*)pooled), 0, mask ? mask_bytes : out_bytes, 0x00020000);
     for (int it = xcd_swizzle(blockIdx.x, gridDim.x) * kWaves + wave; it < (int)items; it += gridDim.x * kWaves) {
         const int b = fast_div(it, m_ipi, items_per_img);
         const int n2 = (it - b * items_per_img) * 64 + lane;
@@ -1011,7 +1021,7 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_pool_pk_3_16_3_2(const float*
         const int soff = b * CO * PP4;
 #pragma unroll
         for (int c = 0; c < CO; ++c) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, bestv[c]), rpool, (int)so_lane, soff + c * PP4, 0);
-        if (mask) {
+        if (mask && !PK8) {
 #pragma unroll
             for (int c = 0; c < CO; ++c) {
                 // bit 31 = "this window's pooled value is <= 0": the block's ReLU::backward (relu.cpp:37) blocks its delta.  The
@@ -1021,6 +1031,30 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_pool_pk_3_16_3_2(const float*
                 __builtin_amdgcn_raw_buffer_store_b32(marked, rmask, (int)so_lane, soff + c * PP4, 0);
             }
         }
+        if (mask && PK8) {
+            // one byte per window: 2 * (row of the maximum) + column, bit 7 = the mark above (offv is 0 | 1 | Wo | Wo + 1)
+            const unsigned so8 = (live && j == 0) ? (unsigned)(ph * pitch8 + pw) : kBufOOB;
+            const int PP1 = PHo * pitch8;
+            const int soff8 = b * CO * PP1;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                const int code = (offv[c] >= Wo ? 2 + (offv[c] - Wo) : offv[c]) | ((bestv[c] <= 0.f) ? 0x80 : 0);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)code, rmask, (int)so8, soff8 + c * PP1, 0);
+            }
+        }
+    }
+}
+
+// packed one-byte pool mask -> the int32 flat index of cnn_maxpool2d_forward (bit 7 -> bit 31), for readers outside the fused block
+__global__ __launch_bounds__(kBlock) void pool_mask_unpack_kernel(const unsigned char* __restrict__ packed, int32_t* __restrict__ mask, long long n,
+                                                                  int Co, int Ho, int Wo, int pitch8) {
+    const int PHo = Ho / 2, PWo = Wo / 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int pw = (int)(i % PWo);
+        const long long r = i / PWo;  // (b * Co + co) * PHo + ph
+        const int ph = (int)(r % PHo), co = (int)((r / PHo) % Co);
+        const int code = packed[r * pitch8 + pw];
+        mask[i] = (co * Ho * Wo + (2 * ph + ((code >> 1) & 1)) * Wo + 2 * pw + (code & 1)) | ((code & 0x80) ? (int)0x80000000 : 0);
     }
 }
 
@@ -1249,6 +1283,29 @@ bool direct_conv_pool_supported(const cnn_conv2d_desc* d) {
     return direct_conv_supported(d) && direct_fwd_pk_ok(d) && Ho >= 2 && Wo >= 2 && (long long)16 * Ho * Wo < (1ll << 31) &&
            (long long)d->B * 16 * (Ho / 2) * (Wo / 2) * 4 < (1ll << 31) - 16 && !CNN_OPT_SET("NO_POOL_FUSION");
 }
+// the packed one-byte pool mask (include/cnn_amd.h): written by conv_fwd_pool_pk<.., true>, read by the LDS-staged data gradient and
+// the window kernel only -- switches that select the older kernels of the block turn it off
+bool direct_dgrad_pk_ok(const cnn_conv2d_desc* d);
+bool direct_pool_mask_packed_ok(const cnn_conv2d_desc* d) {
+    if (!direct_conv_pool_supported(d) || win_wgrad_slots(d) <= 0 || CNN_OPT_INT("DGRAD_POOL_LDS", 1) == 0) return false;
+    if (CNN_OPT_INT("WG_POOL_RD", 0) != 0 || CNN_OPT_INT("POOL_MASK_PACKED", 1) == 0 || !direct_dgrad_pk_ok(d)) return false;
+    const int U = (d->H + 1) / 2, V = (d->W + 1) / 2, U2 = (U + 1) / 2, V2 = (V + 1) / 2;
+    return (long long)d->B * ((U2 + kDR - 1) / kDR) * ((V2 + kDSeg - 1) / kDSeg) < (1ll << 31);
+}
+size_t direct_pool_mask_bytes(const cnn_conv2d_desc* d) {
+    const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
+    if (Ho < 2 || Wo < 2) return 0;
+    if (d->flags & CNN_CONV2D_POOL_MASK_PACKED) return (size_t)d->B * d->Co * (Ho / 2) * pool_mask_pitch(Wo / 2) + 64;
+    return (size_t)d->B * d->Co * (Ho / 2) * (Wo / 2) * sizeof(int32_t);
+}
+int direct_pool_mask_unpack(const cnn_conv2d_desc* d, const void* packed, int32_t* mask, hipStream_t s) {
+    const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
+    CNN_REQUIRE(Ho >= 2 && Wo >= 2 && (long long)d->Co * Ho * Wo < (1ll << 31), "cnn_conv2d_pool_mask_unpack: geometry not covered");
+    const long long n = (long long)d->B * d->Co * (Ho / 2) * (Wo / 2);
+    CNN_KLAUNCH(s, "pool_mask_unpack", (pool_mask_unpack_kernel<<<wave_grid((n + 63) / 64), kBlock, 0, s>>>((const unsigned char*)packed, mask, n, d->Co,
+                                                                                                        Ho, Wo, pool_mask_pitch(Wo / 2))), CONV_TAG(d));
+    return CNN_AMD_OK;
+}
 int direct_conv_pool_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* pooled,
                              int32_t* mask, void* ws, size_t ws_bytes, hipStream_t s, bool prepared) {
     CNN_REQUIRE(direct_conv_pool_supported(d), "cnn_conv2d_relu_maxpool2_forward: geometry not covered (3->16 channels, 3x3 stride 2)");
@@ -1260,14 +1317,18 @@ int direct_conv_pool_forward(const cnn_conv2d_desc* d, const float* x, const flo
     const int ipi = (2 * PHo * PWo + 63) / 64;
     const long long witems = (long long)d->B * ipi;
     const int dbg = CNN_OPT_INT("DBG", 0);
-#define FP_LAUNCH(DBG_)                                                                                                        \
-    CNN_KLAUNCH(s, "conv_fwd_pool_pk<3,16,3,2>",                                                                               \
-                (conv_fwd_pool_pk_3_16_3_2<DBG_><<<wave_grid(witems), kBlock, 0, s>>>(x, (const v2f*)ws, pooled, mask, d->B, d->H, d->W, Ho, \
-                                                                                     Wo, PHo, PWo, ipi, div_magic(ipi), div_magic(PWo))),    \
+    const bool pk8 = (d->flags & CNN_CONV2D_POOL_MASK_PACKED) != 0;
+    CNN_REQUIRE(!pk8 || direct_pool_mask_packed_ok(d), "cnn_conv2d_relu_maxpool2_forward: packed pool mask not available (cnn_conv2d_pool_mask_packed_supported)");
+    const int pitch8 = pool_mask_pitch(PWo);
+#define FP_LAUNCH(DBG_, PK8_)                                                                                                  \
+    CNN_KLAUNCH(s, PK8_ ? "conv_fwd_pool_pk<3,16,3,2>+m8" : "conv_fwd_pool_pk<3,16,3,2>",                                      \
+                (conv_fwd_pool_pk_3_16_3_2<DBG_, PK8_><<<wave_grid(witems), kBlock, 0, s>>>(x, (const v2f*)ws, pooled, mask, d->B, d->H, d->W, Ho, \
+                                                                                     Wo, PHo, PWo, ipi, div_magic(ipi), div_magic(PWo), pitch8)),  \
                 CONV_TAG(d))
-    if (dbg == 1) FP_LAUNCH(1);
-    else if (dbg == 2) FP_LAUNCH(2);
-    else FP_LAUNCH(0);
+    if (pk8) FP_LAUNCH(0, true);
+    else if (dbg == 1) FP_LAUNCH(1, false);
+    else if (dbg == 2) FP_LAUNCH(2, false);
+    else FP_LAUNCH(0, false);
 #undef FP_LAUNCH
     return CNN_AMD_OK;
 }
@@ -1330,17 +1391,19 @@ int direct_conv_dgrad_pooled(const cnn_conv2d_desc* d, const float* dpool, const
     // LDS-staged variant (default; DGRAD_POOL_LDS=0: the per-lane-load kernel): one item per workgroup
     const int ngroups = (U2 + kDR - 1) / kDR, nsegs = (V2 + kDSeg - 1) / kDSeg;
     const long long nitems = (long long)d->B * ngroups * nsegs;
+    const bool pk8 = (d->flags & CNN_CONV2D_POOL_MASK_PACKED) != 0;
+    CNN_REQUIRE(!pk8 || (direct_pool_mask_packed_ok(d) && pooled == nullptr),
+                "cnn_conv2d_backward_data_pooled2: packed pool mask not available here (cnn_conv2d_pool_mask_packed_supported; pooled must be NULL)");
     if (CNN_OPT_INT("DGRAD_POOL_LDS", 1) != 0 && nitems < (1ll << 31)) {
-        if (pooled)
-            CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>+pool",
-                        (conv_dgrad_pool_lds_3_16_3_2<true><<<(unsigned)nitems, kBlock, 0, s>>>(dpool, mask, pooled, (const v2f*)ws, dx, d->B, d->H, d->W, Ho,
-                                                                                                 Wo, ngroups, nsegs, div_magic(ngroups * nsegs), div_magic(nsegs))),
-                        CONV_TAG(d));
-        else
-            CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>+poolm",
-                        (conv_dgrad_pool_lds_3_16_3_2<false><<<(unsigned)nitems, kBlock, 0, s>>>(dpool, mask, nullptr, (const v2f*)ws, dx, d->B, d->H, d->W,
-                                                                                                  Ho, Wo, ngroups, nsegs, div_magic(ngroups * nsegs), div_magic(nsegs))),
-                        CONV_TAG(d));
+#define DL_LAUNCH(MODE_, NAME_)                                                                                                          \
+    CNN_KLAUNCH(s, NAME_,                                                                                                                \
+                (conv_dgrad_pool_lds_3_16_3_2<MODE_><<<(unsigned)nitems, kBlock, 0, s>>>(dpool, mask, pooled, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, \
+                                                                                         Wo, ngroups, nsegs, div_magic(ngroups * nsegs), div_magic(nsegs))), \
+                CONV_TAG(d))
+        if (pk8) DL_LAUNCH(2, "conv_dgrad_pk<3,16,3,2>+poolm8");
+        else if (pooled) DL_LAUNCH(1, "conv_dgrad_pk<3,16,3,2>+pool");
+        else DL_LAUNCH(0, "conv_dgrad_pk<3,16,3,2>+poolm");
+#undef DL_LAUNCH
         return CNN_AMD_OK;
     }
     if (pooled)
@@ -1455,6 +1518,8 @@ int direct_conv_wgrad(const cnn_conv2d_desc* d, const float* x, const float* dy,
 // the same slabs from the pooled domain (dpool, mask, pooled of the 2x2 / stride-2 pool behind this layer's ReLU)
 int direct_conv_wgrad_pooled(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask, const float* pooled,
                              float* slabs, hipStream_t s) {
+    CNN_REQUIRE(!(d->flags & CNN_CONV2D_POOL_MASK_PACKED) || (direct_pool_mask_packed_ok(d) && pooled == nullptr),
+                "cnn_conv2d_backward_weight_pooled2: packed pool mask not available here (cnn_conv2d_pool_mask_packed_supported; pooled must be NULL)");
     if (win_wgrad_slots(d) > 0) return win_wgrad_launch(d, x, dpool, mask, pooled, slabs, s);
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, 0), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, 0);
     const int ipi = (Ho * Wo + 63) / 64;

@@ -1412,6 +1412,7 @@ int check_desc(const char* who, const cnn_conv2d_desc* d) {
                 d->s, d->pad);
     CNN_REQUIRE(d->H + 2 * d->pad >= d->k && d->W + 2 * d->pad >= d->k, "%s: kernel %d larger than padded input", who,
                 d->k);
+    CNN_REQUIRE((d->flags & ~CNN_CONV2D_POOL_MASK_PACKED) == 0, "%s: unknown desc flags 0x%x", who, (unsigned)d->flags);
     return CNN_AMD_OK;
 }
 
@@ -1428,6 +1429,8 @@ int direct_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const
 bool direct_prepared_fwd_ok(const cnn_conv2d_desc* d);
 bool direct_prepared_dgrad_ok(const cnn_conv2d_desc* d);
 bool direct_conv_pool_supported(const cnn_conv2d_desc* d);  // conv_direct.hip: Conv -> ReLU -> MaxPool(2,2) in one kernel
+size_t direct_pool_mask_bytes(const cnn_conv2d_desc* d);
+int direct_pool_mask_unpack(const cnn_conv2d_desc* d, const void* packed, int32_t* mask, hipStream_t s);
 int direct_conv_pool_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* pooled,
                              int32_t* mask, void* ws, size_t ws_bytes, hipStream_t s, bool prepared);
 int direct_conv_dgrad_pooled(const cnn_conv2d_desc* d, const float* dpool, const int32_t* mask, const float* pooled, const float* w,
@@ -1647,6 +1650,20 @@ int cnn_conv2d_relu_only_supported(const cnn_conv2d_desc* d) {
 int cnn_conv2d_relu_maxpool2_supported(const cnn_conv2d_desc* d) {
     if (check_desc("cnn_conv2d_relu_maxpool2_supported", d)) return 0;
     return direct_conv_pool_supported(d) ? 1 : 0;
+}
+
+int cnn_conv2d_pool_mask_packed_supported(const cnn_conv2d_desc* d) {
+    if (check_desc("cnn_conv2d_pool_mask_packed_supported", d)) return 0;
+    return direct_pool_mask_packed_ok(d) ? 1 : 0;
+}
+size_t cnn_conv2d_pool_mask_bytes(const cnn_conv2d_desc* d) {
+    if (check_desc("cnn_conv2d_pool_mask_bytes", d)) return 0;
+    return direct_pool_mask_bytes(d);
+}
+int cnn_conv2d_pool_mask_unpack(const cnn_conv2d_desc* d, const void* packed, int32_t* mask, void* stream) {
+    if (int rc = check_desc("cnn_conv2d_pool_mask_unpack", d)) return rc;
+    CNN_REQUIRE(packed && mask, "cnn_conv2d_pool_mask_unpack: null pointer");
+    return direct_pool_mask_unpack(d, packed, mask, as_stream(stream));
 }
 
 int cnn_conv2d_relu_maxpool2_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* pooled,

@@ -788,7 +788,7 @@ int cnn_conv2d_backward_weight_pooled2(const cnn_conv2d_desc* d, const float* x,
                 need_d);
     hipStream_t sd = as_stream(stream);
     // MFMA register-direct kernel (CNN_AMD_WG_POOL_RD=0: the packed VALU kernel): same slab layout, [16][27 | 1]
-    const int rs = first_layer_rd() ? wgrad_rd_pooled_slots(d) : 0;
+    const int rs = (first_layer_rd() && !(d->flags & CNN_CONV2D_POOL_MASK_PACKED)) ? wgrad_rd_pooled_slots(d) : 0;  // (packed mask: window kernel only)
     if (rs > 0 && ws_bytes >= (size_t)(rs + (rs + 63) / 64) * n * sizeof(float)) {
         if (int rc = wgrad_rd_launch_pooled(d, x, dpool, mask, pooled, (float*)ws, sd)) return rc;
         char tagr[160];
@@ -821,7 +821,7 @@ int cnn_conv2d_backward_weight_pooled2_sgd_keep(const cnn_conv2d_desc* d, const 
     const size_t n = 16 * 28;
     hipStream_t sd = as_stream(stream);
     int slots = ds;
-    const int rs = first_layer_rd() ? wgrad_rd_pooled_slots(d) : 0;
+    const int rs = (first_layer_rd() && !(d->flags & CNN_CONV2D_POOL_MASK_PACKED)) ? wgrad_rd_pooled_slots(d) : 0;  // (packed mask: window kernel only)
     if (rs > 0 && ws != nullptr && ws_bytes >= (size_t)rs * n * sizeof(float)) {
         slots = rs;
         if (int rc = wgrad_rd_launch_pooled(d, x, dpool, mask, pooled, (float*)ws, sd)) return rc;

@@ -50,11 +50,13 @@ constexpr int kWaves = 8;               // two waves per SIMD: one wave's LDS / 
 constexpr int kProd = 4;                // SPEC: one extra DMA-only wave per SIMD (see the kernel)
 // delta operands of a strip: plain 2 rows x 2*SW columns x 16 channels; pooled domain 2 (dpool, mask) or 3 (+ pooled) tensors
 // x SW windows x 16 channels
-__host__ __device__ constexpr int abuf_floats(int pooled) { return pooled == 0 ? 2 * 2 * kSW * CO : (pooled == 1 ? 3 : 2) * kSW * CO; }
+__host__ __device__ constexpr int abuf_floats(int pooled) {
+    return pooled == 0 ? 2 * 2 * kSW * CO : (pooled == 3 ? kSW * CO + 64 : (pooled == 1 ? 3 : 2) * kSW * CO);  // (3: dpool + 64 dwords of mask bytes)
+}
 __host__ __device__ constexpr int buf_floats(int pooled) { return XBUF + abuf_floats(pooled); }
 // strips in flight per wave: the train step's variant (POOLED = 2, 6.4 KB per strip) affords three buffers in 160 KB of LDS
 // (two strips on their way while one is consumed), the others two
-__host__ __device__ constexpr int num_bufs(int pooled) { return pooled == 2 ? 3 : 2; }
+__host__ __device__ constexpr int num_bufs(int pooled) { return pooled >= 2 ? 3 : 2; }
 
 struct WinParams {
     const float* x;
@@ -64,6 +66,7 @@ struct WinParams {
     float* slabs;          // [gridDim.x][16][28]
     int B, H, W, Ho, Wo;
     int PHo, PWo;          // pooled-domain size (Ho/2, Wo/2)
+    int pitch8;            // POOLED == 3: bytes per row of the packed mask (pool_mask_pitch)
     int WR, WC;            // window grid: ceil(Ho/2) x ceil(Wo/2)
     int nseg, SW;          // column segments per window row, windows per segment (multiple of 4, <= kSW)
     int strips_total, strips_per_wave;
@@ -74,6 +77,8 @@ struct WinParams {
 };
 
 // POOLED: 0 dy | 1 pooled domain (dpool, mask, pooled) | 2 pooled domain with dpool already ReLU-masked (pooled not read)
+//         | 3 = 2 with the packed one-byte mask (include/cnn_amd.h, CNN_CONV2D_POOL_MASK_PACKED): the four windows of a lane's group
+//           are ONE dword, moved by a 4-byte DMA into dword 16 * group + co behind the strip's dpool values
 // DMA16: x rows are 16-byte aligned (W % 4 == 0, base aligned): 16-byte DMA; otherwise 4 bytes per lane
 // SPEC ("wave specialisation"): a wave that is blocked while the memory pipeline takes its DMA burst cannot issue MFMAs, and with
 // every wave doing both jobs the two phases barely overlapped (staging-only 52 us + MFMA-only 48 us ~ the 70 us measured).  With SPEC
@@ -160,6 +165,7 @@ __global__ __launch_bounds__((kWaves + (SPEC ? kProd : 0)) * 64) void conv_wgrad
     struct ColState {
         unsigned gx[NX];
         unsigned ga;
+        unsigned gm;  // POOLED == 3: byte offset of this lane's mask dword
         int col_seg;
     };
     // per DMA instruction i: this lane's chunk is in staged row r5 == 0 / exists at all (lane constants)
@@ -183,10 +189,12 @@ __global__ __launch_bounds__((kWaves + (SPEC ? kProd : 0)) * 64) void conv_wgrad
             cs.gx[i] = (unsigned)((ci * p.H + r5) * p.W + (c < ncols ? c : 0));
         }
         cs.ga = 0;
+        cs.gm = 0;
         if constexpr (POOLED) {
             const int nv = p.PWo - wc_lo < sw ? p.PWo - wc_lo : sw;
             const int g = lane >> 4;
             cs.ga = (unsigned)((co * p.PHo) * p.PWo + (4 * g < nv ? 4 * g : 0));
+            if constexpr (POOLED == 3) cs.gm = (unsigned)((co * p.PHo) * p.pitch8 + (4 * g < nv ? 4 * g : 0));
         }
         cs.col_seg = seg;
     };
@@ -244,6 +252,11 @@ __global__ __launch_bounds__((kWaves + (SPEC ? kProd : 0)) * 64) void conv_wgrad
             if (!last_row && rowok) {
                 const size_t abase = (((size_t)b * CO) * p.PHo + wr) * p.PWo + wc_lo;  // wave-uniform; ga: this lane's (co, group)
                 __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.dy + abase + cs.ga), (lds_void_ptr)(abuf), 16, 0, 0);
+                if constexpr (POOLED == 3) {
+                    const size_t mbase = (((size_t)b * CO) * p.PHo + wr) * p.pitch8 + wc_lo;  // bytes; rows and segments start 4-byte aligned
+                    __builtin_amdgcn_global_load_lds((gbl_void_ptr)((const char*)p.pmask + mbase + cs.gm), (lds_void_ptr)(abuf + kSW * CO), 4, 0, 0);
+                    return false;
+                }
                 __builtin_amdgcn_global_load_lds((gbl_void_ptr)((const float*)p.pmask + abase + cs.ga), (lds_void_ptr)(abuf + kSW * CO), 16, 0, 0);
                 if constexpr (POOLED == 1) __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.pooled + abase + cs.ga), (lds_void_ptr)(abuf + 2 * kSW * CO), 16, 0, 0);
                 return false;
@@ -252,17 +265,28 @@ __global__ __launch_bounds__((kWaves + (SPEC ? kProd : 0)) * 64) void conv_wgrad
                 const int g = lane >> 4;
                 const size_t off = (((size_t)b * CO + co) * p.PHo) * p.PWo + wc_lo + (4 * g < nv ? 4 * g : 0);
                 __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.dy + off), (lds_void_ptr)(abuf), 16, 0, 0);
+                if constexpr (POOLED == 3) {
+                    const size_t off8 = (((size_t)b * CO + co) * p.PHo) * p.pitch8 + wc_lo + (4 * g < nv ? 4 * g : 0);
+                    __builtin_amdgcn_global_load_lds((gbl_void_ptr)((const char*)p.pmask + off8), (lds_void_ptr)(abuf + kSW * CO), 4, 0, 0);
+                    return false;
+                }
                 __builtin_amdgcn_global_load_lds((gbl_void_ptr)((const float*)p.pmask + off), (lds_void_ptr)(abuf + kSW * CO), 16, 0, 0);
                 if constexpr (POOLED == 1) __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.pooled + off), (lds_void_ptr)(abuf + 2 * kSW * CO), 16, 0, 0);
                 return false;
             }
             const int c4 = lane >> 2, e = lane & 3;
             const size_t rowbase = (((size_t)b * CO + c4) * p.PHo + (rowok ? wr : 0)) * p.PWo + wc_lo;
+            if constexpr (POOLED == 3) {  // (the packed mask's allocation carries 64 bytes of slack: its dword never leaves it)
+                const int g4 = lane >> 4;
+                const size_t off8 = (((size_t)b * CO + co) * p.PHo + (rowok ? wr : 0)) * p.pitch8 + wc_lo + (4 * g4 < nv ? 4 * g4 : 0);
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)((const char*)p.pmask + off8), (lds_void_ptr)(abuf + kSW * CO), 4, 0, 0);
+            }
 #pragma unroll
             for (int g = 0; g < kGroups; ++g) {
                 const size_t off = rowbase + (4 * g + e < nv ? 4 * g + e : 0);
                 __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.dy + off), (lds_void_ptr)(abuf + 64 * g), 4, 0, 0);
-                __builtin_amdgcn_global_load_lds((gbl_void_ptr)((const float*)p.pmask + off), (lds_void_ptr)(abuf + kSW * CO + 64 * g), 4, 0, 0);
+                if constexpr (POOLED != 3)
+                    __builtin_amdgcn_global_load_lds((gbl_void_ptr)((const float*)p.pmask + off), (lds_void_ptr)(abuf + kSW * CO + 64 * g), 4, 0, 0);
                 if constexpr (POOLED == 1) __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.pooled + off), (lds_void_ptr)(abuf + 2 * kSW * CO + 64 * g), 4, 0, 0);
             }
             return true;
@@ -285,7 +309,7 @@ __global__ __launch_bounds__((kWaves + (SPEC ? kProd : 0)) * 64) void conv_wgrad
         }
     };
     // DMA instructions per strip: what `s_waitcnt vmcnt(N)` has to leave in flight when the NEXT strip is already on its way
-    constexpr int N_FAST = NX + (POOLED ? NT : 2 * (2 * kSW / 4)), N_SLOW = NX + NT * kGroups;
+    constexpr int N_FAST = NX + (POOLED ? NT : 2 * (2 * kSW / 4)), N_SLOW = NX + (POOLED == 3 ? kGroups + 1 : NT * kGroups);
 
     // ---- the strip's MFMA groups.  EDGE: the strip touches the last window row / column of the layer, where a window's pixels
     // may lie outside the output (delta 0, and their x values are not the reference's to read: both operands are forced to 0);
@@ -315,7 +339,8 @@ __global__ __launch_bounds__((kWaves + (SPEC ? kProd : 0)) * 64) void conv_wgrad
             }
             if constexpr (POOLED) {
                 o.a0 = ab[64 * g + 4 * co + k];
-                o.a1 = ab[kSW * CO + 64 * g + 4 * co + k];
+                if constexpr (POOLED == 3) o.a1 = ab[kSW * CO + 16 * g + co];  // the group's four mask bytes of this channel
+                else o.a1 = ab[kSW * CO + 64 * g + 4 * co + k];
                 if constexpr (POOLED == 1) o.a2 = ab[2 * kSW * CO + 64 * g + 4 * co + k];
                 (void)w;
             } else {
@@ -342,11 +367,19 @@ __global__ __launch_bounds__((kWaves + (SPEC ? kProd : 0)) * 64) void conv_wgrad
                 float dp = o.a0;
                 if constexpr (POOLED == 1) dp = (o.a2 <= 0.f) ? 0.f : dp;  // ReLU::backward in the pooled domain (relu.cpp:37)
                 if (EDGE) dp = winv ? dp : 0.f;                             // (a window outside the pooled domain: stale LDS)
-                const int d = __builtin_bit_cast(int, o.a1) - (e_lane + 8 * g);  // mask - flat index of pixel (0,0)
+                if constexpr (POOLED == 3) {
+                    const int code = (__builtin_bit_cast(int, o.a1) >> (8 * k)) & 0xff;  // 2 * row + column of the maximum | 0x80: ReLU-dead
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr)
+                    for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-                    for (int pc = 0; pc < 2; ++pc) av[pr][pc] = (d == pr * p.Wo + pc) ? dp : 0.f;  // MaxPool2D::backward (pool2d.cpp:105)
+                        for (int pc = 0; pc < 2; ++pc) av[pr][pc] = (code == 2 * pr + pc) ? dp : 0.f;  // MaxPool2D::backward (pool2d.cpp:105)
+                } else {
+                    const int d = __builtin_bit_cast(int, o.a1) - (e_lane + 8 * g);  // mask - flat index of pixel (0,0)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                        for (int pc = 0; pc < 2; ++pc) av[pr][pc] = (d == pr * p.Wo + pc) ? dp : 0.f;  // MaxPool2D::backward (pool2d.cpp:105)
+                }
             } else {
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr)
@@ -597,6 +630,7 @@ bool make_win_params(const cnn_conv2d_desc* d, WinParams* p, int* grid) {
     if (p->Ho < 1 || p->Wo < 1) return false;
     if ((long long)CO * p->Ho * p->Wo >= (1ll << 31)) return false;  // (the pool mask is an int32 flat index)
     p->PHo = p->Ho / 2; p->PWo = p->Wo / 2;
+    p->pitch8 = pool_mask_pitch(p->PWo);
     p->WR = (p->Ho + 1) / 2; p->WC = (p->Wo + 1) / 2;
     p->nseg = (p->WC + kSW - 1) / kSW;
     p->SW = (((p->WC + p->nseg - 1) / p->nseg) + 3) / 4 * 4;  // balanced segments, whole groups of 4 windows
@@ -654,7 +688,7 @@ template <int POOLED>
 int launch_win(const cnn_conv2d_desc* d, WinParams& p, int grid, hipStream_t s, const char* name) {
     const bool dma16 = (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(p.x) % 16 == 0);
     // (wave specialisation needs the three-buffer ring: with two, a producer cannot run ahead -- measured 150 vs 119 us)
-    if (dma16) return (p.spec && num_bufs(POOLED) == 3) ? launch_win3<POOLED, true, POOLED == 2>(d, p, grid, s, name) : launch_win3<POOLED, true, false>(d, p, grid, s, name);
+    if (dma16) return (p.spec && num_bufs(POOLED) == 3) ? launch_win3<POOLED, true, POOLED >= 2>(d, p, grid, s, name) : launch_win3<POOLED, true, false>(d, p, grid, s, name);
     return launch_win3<POOLED, false, false>(d, p, grid, s, name);  // (4-byte DMA: too many instructions per strip for counted waits on pairs)
 }
 }  // namespace
@@ -673,6 +707,10 @@ int win_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, 
     int grid = 0;
     if (!make_win_params(d, &p, &grid)) return fail(CNN_AMD_E_BADARG, "conv_wgrad_win: geometry not covered");
     p.x = x; p.dy = dy; p.pmask = mask; p.pooled = pooled; p.slabs = slabs;
+    if (d->flags & CNN_CONV2D_POOL_MASK_PACKED) {
+        CNN_REQUIRE(mask != nullptr && pooled == nullptr, "conv_wgrad_win: packed pool mask: mask must be set, pooled must be NULL");
+        return launch_win<3>(d, p, grid, s, "conv_wgrad_win<3,16,3,2>+poolm8");
+    }
     if (mask == nullptr) return launch_win<0>(d, p, grid, s, "conv_wgrad_win<3,16,3,2>");
     if (pooled != nullptr) return launch_win<1>(d, p, grid, s, "conv_wgrad_win<3,16,3,2>+pool");
     return launch_win<2>(d, p, grid, s, "conv_wgrad_win<3,16,3,2>+poolm");

@@ -146,7 +146,7 @@ public:
     // additions: filter re-layout hoisted out of forward / backward (cnn_conv2d_prepare_filters); the container prepares
     // all layers with one call after every parameter change and switches the layers to the *_prepared entry points
     bool shape_known() const { return batch > 0; }
-    cnn_conv2d_desc current_desc() const { return cnn_conv2d_desc{batch, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding}; }
+    cnn_conv2d_desc current_desc() const { return cnn_conv2d_desc{batch, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding, 0}; }
     const data_type* filters_dev() const { return params; }
     const data_type* bias_dev() const { return b_dev(); }
     void prepared_buffers(void** fwd, void** dgrad);  // allocated on first use
@@ -168,9 +168,14 @@ public:
         const int* mask = nullptr;
         const data_type* pooled = nullptr;
         int B = 0;
+        int flags = 0;  // cnn_conv2d_desc.flags of the forward call that wrote the mask
         bool valid = false;
     };
     bool pool_fused_pending() const { return pool_fused_pass; }
+    // cnn_conv2d_desc.flags of the last pool-fused forward pass (CNN_CONV2D_POOL_MASK_PACKED where the library supports it: the
+    // block's three kernels then move one byte per pooling window instead of an int32 index -- 111 MB less per step of the reference
+    // net); the pass' backward calls must hand the mask back with the same flags
+    int pool_mask_flags = 0;
     // weight / bias gradient from the pooled domain on `stream`; with fused_sgd also this layer's SGD step (the old values go to
     // the snapshot) and its filter images for the next pass in the same launch (cnn_conv2d_backward_weight_pooled2_sgd_keep).
     // Returns what the data gradient of this pass will need (launch_deferred_dgrad).

@@ -150,7 +150,7 @@ void Conv2D::bind_arena(data_type* params_dev, data_type* grads_dev) {
 }
 
 void Conv2D::ensure_workspace(int B, int H, int W) {
-    cnn_conv2d_desc d{B, in_channels, H, W, out_channels, kernel_size, stride, padding};
+    cnn_conv2d_desc d{B, in_channels, H, W, out_channels, kernel_size, stride, padding, 0};
     const size_t need = cnn_conv2d_workspace_bytes(&d);
     if (need == 0) must(1, "cnn_conv2d_workspace_bytes");
     if (need > workspace_bytes) {
@@ -172,7 +172,7 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
         batch = B;
         // the shape is known now: let the library measure which tile its implicit-GEMM kernels should use for it (once per
         // geometry and process, before any filter preparation)
-        cnn_conv2d_desc d0{B, in_channels, H, W, out_channels, kernel_size, stride, padding};
+        cnn_conv2d_desc d0{B, in_channels, H, W, out_channels, kernel_size, stride, padding, 0};
         must(cnn_conv2d_autotune(&d0, stream), "cnn_conv2d_autotune");
     }
     assert(B <= batch && "batch larger than the first forward's (conv2d.cpp:47 has the same restriction)");
@@ -198,7 +198,7 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
     last_x = x;  // (a pointer, not a copy: get_output() of a fused-away tensor re-computes it from here)
     last_B = B;
     out_valid = true;
-    cnn_conv2d_desc d{B, in_channels, H, W, out_channels, kernel_size, stride, padding};
+    cnn_conv2d_desc d{B, in_channels, H, W, out_channels, kernel_size, stride, padding, 0};
     const bool prepared = prepared_active && fuse_layers && B == batch;
     pool_fused_pass = false;
     if (prepared && fuse_pool_block && fused_relu != nullptr && fused_pool != nullptr && fused_pool->fusable_2x2() &&
@@ -207,6 +207,8 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
         // ReLU's output tensors are NOT materialised in such a pass (their backward passes run from the pooled domain)
         data_type* pooled = nullptr;
         int* pmask = nullptr;
+        d.flags = cnn_conv2d_pool_mask_packed_supported(&d) ? CNN_CONV2D_POOL_MASK_PACKED : 0;  // (the mask buffer fits either form)
+        pool_mask_flags = d.flags;
         fused_pool->fused_forward_target(B, out_channels, out_H, out_W, !no_grad, &pooled, &pmask);
         fused_relu->fused_forward_skipped(B, out_channels, out_H, out_W);
         must(cnn_conv2d_relu_maxpool2_forward_prepared(&d, x, prep_fwd, pooled, pmask, stream), "cnn_conv2d_relu_maxpool2_forward_prepared");
@@ -239,7 +241,7 @@ std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
     const int B = (int)delta.size();
     assert(saved_input != nullptr && "backward without a recorded forward (no_grad?)");
     const data_type* dy = batch_device_pointer(delta, delta_stage, name + "_dy");
-    cnn_conv2d_desc d{B, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding};
+    cnn_conv2d_desc d{B, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding, 0};
     // conv2d.cpp:117-199: weight/bias gradients (recomputed, not accumulated, averaged over the batch) and the data
     // gradient in one call; the library overlaps the two on an internal side stream
     if (delta_buf.empty()) delta_buf.allocate(batch, in_channels, in_H, in_W, name + "_delta");
@@ -256,6 +258,7 @@ std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
         // (pooled = NULL: the fused forward kernel marked the windows whose pooled value is <= 0 in the mask itself -- bit 31 --, so
         // the block's ReLU::backward needs no tensor of its own here)
         const data_type* pooled = nullptr;
+        d.flags = pool_mask_flags;
         must(cnn_conv2d_backward_pooled2_prepared(&d, saved_input, dy, fused_pool->mask_dev(), pooled, prep_dgrad, grads,
                                                   grads + (size_t)out_channels * params_for_one_kernel, dbuf.base, (float)B,
                                                   workspace, workspace_bytes, stream, /*defer_join=*/1),
@@ -292,7 +295,7 @@ void Conv2D::materialize() const {
     const data_type* b = w + (size_t)out_channels * params_for_one_kernel;
     Conv2D* self = const_cast<Conv2D*>(this);
     self->ensure_workspace(last_B, in_H, in_W);
-    cnn_conv2d_desc d{last_B, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding};
+    cnn_conv2d_desc d{last_B, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding, 0};
     // the unprepared entry points re-arrange the filters themselves: bit-identical to the prepared kernels the pass would have run
     if (fused_relu != nullptr && fuse_layers)
         must(cnn_conv2d_forward_relu(&d, last_x, w, b, out_buf.base, fused_relu->rematerialize_target(), workspace, workspace_bytes, stream),
@@ -312,7 +315,7 @@ Conv2D::DeferredDgrad Conv2D::backward_weight_pooled(std::vector<tensor>& delta,
     const int B = (int)delta.size();
     assert(pool_fused_pass && prepared_active && fused_pool != nullptr && B == batch && saved_input != nullptr);
     const data_type* dy = batch_device_pointer(delta, delta_stage, name + "_dy");  // d(pool output)
-    cnn_conv2d_desc d{B, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding};
+    cnn_conv2d_desc d{B, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding, 0};
     if (delta_buf.empty()) delta_buf.allocate(batch, in_channels, in_H, in_W, name + "_delta");
     const size_t need = cnn_conv2d_backward_workspace_bytes(&d);
     if (need > workspace_bytes) {
@@ -330,6 +333,8 @@ Conv2D::DeferredDgrad Conv2D::backward_weight_pooled(std::vector<tensor>& delta,
     job.mask = fused_pool->mask_dev();
     job.pooled = pooled;
     job.B = B;
+    job.flags = pool_mask_flags;
+    d.flags = pool_mask_flags;
     job.valid = true;
     if (fused_sgd) {
         // window kernel + ONE small launch: slab reduction, gw / gb, this layer's SGD step (old values -> snapshot) and the filter
@@ -364,7 +369,7 @@ void Conv2D::prepare_own_filters() {
 
 void Conv2D::launch_deferred_dgrad(const DeferredDgrad& job, void* on_stream) {
     assert(job.valid);
-    cnn_conv2d_desc d{job.B, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding};
+    cnn_conv2d_desc d{job.B, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding, job.flags};
     must(cnn_conv2d_backward_data_pooled2_prepared(&d, job.dpool, job.mask, job.pooled, job.prepared, delta_buf.base, on_stream),
          "cnn_conv2d_backward_data_pooled2_prepared");
 }
@@ -410,11 +415,12 @@ void MaxPool2D::fused_forward_target(int B, int C, int H, int W, bool record, da
     }
     assert(B <= batch);
     in_C = C; in_H = H; in_W = W;
-    if (record && mask == nullptr) mask = (int*)dev_alloc(sizeof(int) * (size_t)batch * C * out_H * out_W);
+    // (sized for the int32 form; the packed one-byte form of the fused block needs at most (out_W + 3) bytes per row + 64)
+    if (record && mask == nullptr) mask = (int*)dev_alloc(sizeof(int) * (size_t)batch * C * out_H * out_W + 64);
     if (alternate) {  // the deferred data gradient of the previous pass still reads the other set
         cur_set ^= 1;
         if (cur_set && out_buf_alt.empty()) out_buf_alt.allocate(batch, C, out_H, out_W, name + "_output");
-        if (cur_set && record && mask_alt == nullptr) mask_alt = (int*)dev_alloc(sizeof(int) * (size_t)batch * C * out_H * out_W);
+        if (cur_set && record && mask_alt == nullptr) mask_alt = (int*)dev_alloc(sizeof(int) * (size_t)batch * C * out_H * out_W + 64);
         output = cur_set ? out_buf_alt.views : out_buf.views;
     }
     *pooled = cur_set ? out_buf_alt.base : out_buf.base;
@@ -449,7 +455,7 @@ std::vector<tensor> MaxPool2D::forward(const std::vector<tensor>& input) {
     }
     in_C = C; in_H = H; in_W = W;
     if (!no_grad && mask == nullptr)  // pool2d.cpp:23-31 (allocated lazily so a no_grad first call is not fatal)
-        mask = (int*)dev_alloc(sizeof(int) * (size_t)batch * C * out_H * out_W);
+        mask = (int*)dev_alloc(sizeof(int) * (size_t)batch * C * out_H * out_W + 64);
     const data_type* x = batch_device_pointer(input, in_stage, name);
     must(cnn_maxpool2d_forward(x, out_buf.base, no_grad ? nullptr : mask, B, C, H, W, kernel_size, step, stream),
          "cnn_maxpool2d_forward");

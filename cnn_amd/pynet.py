@@ -77,6 +77,12 @@ class AlexNetHip:
         # data gradient (below) then still needs pool_out / pool_mask of ITS step while the next forward pass is already
         # writing new ones: two sets, alternating.
         self._relu_only = [c.relu_only_supported() for c in self.convs] if self.fuse_pool else [False] * 4
+        # the fused block's mask as one byte per window (include/cnn_amd.h, CNN_CONV2D_POOL_MASK_PACKED) where the library's kernels
+        # read it: only the block's own calls touch pool_mask in this mode; pool_mask_int32() unpacks it for everybody else
+        self.mask_packed = self.fuse_pool and self.convs[0].pool_mask_packed_supported()
+        if self.mask_packed:
+            self.convs[0].set_pool_mask_packed()
+            self.pool_mask = torch.empty(self.convs[0].pool_mask_bytes(), dtype=torch.uint8, device=device)
         self.pool_sets = [(self.pool_out, self.pool_mask)]
         if self.fuse_pool and defer_input_grad:
             self.pool_sets.append((torch.empty_like(self.pool_out), torch.empty_like(self.pool_mask)))
@@ -120,6 +126,15 @@ class AlexNetHip:
         return self._loss_sum
 
     # ---- parameter views (reference layouts) ----
+    def pool_mask_int32(self):
+        """max_pool_1's mask in cnn_maxpool2d_forward's form (+ bit 31 of the fused kernel), whatever form the block keeps it in"""
+        import torch
+
+        if not self.mask_packed:
+            return self.pool_mask
+        out = torch.empty((self.B, 16) + self.pool_hw, dtype=torch.int32, device=self.pool_mask.device)
+        return self.convs[0].pool_mask_unpack(self.pool_mask, out)
+
     def conv_w(self, l, arena=None):
         a = self.params if arena is None else arena
         ci, co = self.CHANS[l], self.CHANS[l + 1]

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CNN_AMD_ABI_VERSION 1
+#define CNN_AMD_ABI_VERSION 2
 
 enum {
     CNN_AMD_OK = 0,
@@ -66,7 +66,11 @@ typedef struct {
     int B, Ci, H, W; /* input  batch / channels / height / width */
     int Co, k, s;    /* filters, kernel edge (any k >= 1; the reference asserts odd >= 3), stride */
     int pad;         /* zero padding on each side (extension; the reference is fixed at 0, architectures.h:59) */
+    int flags;       /* 0, or CNN_CONV2D_POOL_MASK_PACKED (ABI version 2; only the fused Conv2D -> ReLU -> MaxPool2D family reads it) */
 } cnn_conv2d_desc;
+/* flags bit: the pool mask the fused first-block entry points (cnn_conv2d_relu_maxpool2_forward*, cnn_conv2d_backward_*pooled2*)
+ * write and read is ONE BYTE per window instead of an int32 flat index -- see cnn_conv2d_pool_mask_packed_supported below */
+#define CNN_CONV2D_POOL_MASK_PACKED 1
 
 /* scratch needed by ANY of the three MFMA entry points below for this geometry */
 size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d);
@@ -103,6 +107,21 @@ int cnn_conv2d_relu_only_supported(const cnn_conv2d_desc* d);
  * backward pass); cnn_maxpool2d_backward(_relu) ignore the bit.  (mask & 0x7fffffff) is cnn_maxpool2d_forward's mask, bit for bit.
  * Covered geometry: cnn_conv2d_relu_maxpool2_supported(d) != 0 (the thin 3 -> 16 channel 3x3 stride-2 layer). */
 int cnn_conv2d_relu_maxpool2_supported(const cnn_conv2d_desc* d);
+/* The packed pool mask (d->flags & CNN_CONV2D_POOL_MASK_PACKED).  A 2x2 window's first maximum is one of FOUR pixels, so the int32
+ * flat index carries two bits of information in four bytes -- and the three kernels of the block (forward, weight gradient, data
+ * gradient) move it through HBM once each: 3 x 49.6 MB per step of the reference net at batch 256.  With the flag set the mask
+ * argument of the family is an opaque buffer of cnn_conv2d_pool_mask_bytes(d) bytes (device, 4-byte aligned) holding
+ *   byte[((b * Co + co) * (Ho/2) + ph) * pitch + pw],  pitch = ((Wo/2) + 3) & ~3,
+ *   bits 0..1 = 2 * (row of the maximum inside the window) + (its column), bit 7 = the int32 form's bit 31 (pooled value <= 0),
+ * written by cnn_conv2d_relu_maxpool2_forward(_prepared) and read by the cnn_conv2d_backward_*pooled2* calls with the SAME desc
+ * (pooled must then be NULL: bit 7 carries the block's ReLU mask).  cnn_conv2d_pool_mask_unpack converts it to the int32 form
+ * (bit 31 included) for anybody else -- cnn_maxpool2d_backward(_relu) read only that one.  Results of every call of the family are
+ * bit-identical between the two forms.  supported(d) != 0: the geometry is covered AND the kernels that read the packed form are
+ * the ones selected (measurement switches that select the older kernels turn it off); a call with the flag set otherwise fails
+ * with CNN_AMD_E_BADARG. */
+int cnn_conv2d_pool_mask_packed_supported(const cnn_conv2d_desc* d);
+size_t cnn_conv2d_pool_mask_bytes(const cnn_conv2d_desc* d); /* flag clear: B*Co*(Ho/2)*(Wo/2)*4; set: B*Co*(Ho/2)*pitch + 64 */
+int cnn_conv2d_pool_mask_unpack(const cnn_conv2d_desc* d, const void* packed, int32_t* mask, void* stream);
 int cnn_conv2d_relu_maxpool2_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias,
                                      float* pooled, int32_t* mask, void* workspace, size_t workspace_bytes, void* stream);
 

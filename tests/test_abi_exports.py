@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_host_helpers_follow_reference_shape_rules():
     lib = capi.load()
-    assert lib.cnn_amd_abi_version() == 1
+    assert lib.cnn_amd_abi_version() == 2  # (2: cnn_conv2d_desc.flags)
     # conv2d.cpp:41-42 (pad = 0): 224 -> 111 -> (pool) 55 -> 27 -> 13 -> 6
     assert [lib.cnn_conv2d_out_dim(h, 3, 2, 0) for h in (224, 55, 27, 13)] == [111, 27, 13, 6]
     assert lib.cnn_conv2d_out_dim(112, 3, 1, 0) == 110 and lib.cnn_conv2d_out_dim(112, 3, 1, 1) == 112

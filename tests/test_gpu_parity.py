@@ -319,7 +319,7 @@ def _count_decision_flips(net, onet, relu_layers, tag):
         flipped += int(np.count_nonzero((got <= 0) != (want <= 0)))
         total += got.size
     assert flipped <= max(2, 2e-5 * total), (tag, "ReLU flips", flipped, total)
-    mm = int(np.count_nonzero((host(net.pool_mask) & 0x7FFFFFFF) != onet.pool_mask()))  # (bit 31: the fused kernel's "pooled <= 0" mark)
+    mm = int(np.count_nonzero((host(net.pool_mask_int32()) & 0x7FFFFFFF) != onet.pool_mask()))  # (bit 31: the fused kernel's "pooled <= 0" mark)
     assert mm <= max(2, 2e-5 * onet.pool_mask().size), (tag, "pool argmax mismatches", mm, onet.pool_mask().size)
 
 
@@ -478,7 +478,7 @@ def _synced_oracle_backward(net, params, x, labels, pooled_domain=False):
     from cnn_amd import stacks as S
 
     out = []
-    masks = {4: host(net.relu_out[1]), 6: host(net.relu_out[2]), 8: host(net.relu_out[3]), 2: host(net.pool_mask) & 0x7FFFFFFF}
+    masks = {4: host(net.relu_out[1]), 6: host(net.relu_out[2]), 8: host(net.relu_out[3]), 2: host(net.pool_mask_int32()) & 0x7FFFFFFF}
     if not pooled_domain:
         masks[1] = host(net.relu_out[0])  # (pool-fused runs do not materialise relu_layer_1's output)
     for f64 in (False, True):
@@ -795,6 +795,69 @@ def test_conv_backward_from_pooled_domain_is_bit_identical(T, shape):
     assert np.array_equal(host(gw4), host(gw_ref)) and np.array_equal(host(gb4), host(gb_ref)) and np.array_equal(host(dx4), host(dx_ref))
 
 
+@pytest.mark.parametrize("shape", [(2, 224, 224), (16, 224, 224), (3, 37, 41), (1, 9, 9), (2, 12, 20), (5, 7, 5), (2, 30, 26), (3, 64, 132)],
+                         ids=lambda s: "B%d_%dx%d" % s)
+def test_packed_pool_mask_block_is_bit_identical(T, shape):
+    """CNN_CONV2D_POOL_MASK_PACKED (include/cnn_amd.h): the one-byte pool mask of the fused first block.  The forward call writes the
+    same pooled tensor, its mask unpacks to the int32 form bit for bit (bit 31 included), and the pooled-domain gradient calls return
+    the same bits from either form -- on ragged shapes (pitch > row length, odd output sizes, last rows of the allocation) too"""
+    from cnn_amd import capi
+
+    B, H, W = shape
+    case = (B, 3, H, W, 16, 3, 2, 0)
+    x, w, b, _ = _conv_inputs(case, 620)
+    x = x - 0.5
+    conv = capi.Conv2d(*case)
+    packed = capi.Conv2d(*case)
+    assert packed.pool_mask_packed_supported()
+    packed.set_pool_mask_packed()
+    xd, wd, bd = dev(T, x), dev(T, w), dev(T, b)
+    Ho, Wo = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    PHo, PWo = Ho // 2, Wo // 2
+    pitch = (PWo + 3) & ~3
+    assert packed.pool_mask_bytes() == B * 16 * PHo * pitch + 64 and conv.pool_mask_bytes() == B * 16 * PHo * PWo * 4
+    pooled, pooled8 = T.empty((B, 16, PHo, PWo), device="cuda"), T.full((B, 16, PHo, PWo), 7.0, device="cuda")
+    mask = T.empty((B, 16, PHo, PWo), dtype=T.int32, device="cuda")
+    mask8 = T.full((packed.pool_mask_bytes(),), 0x55, dtype=T.uint8, device="cuda")
+    conv.relu_maxpool2_forward(xd, wd, bd, pooled, mask)
+    packed.relu_maxpool2_forward(xd, wd, bd, pooled8, mask8)
+    assert np.array_equal(host(pooled8).view(np.uint32), host(pooled).view(np.uint32))
+    m8 = host(mask8)
+    rows = m8[:B * 16 * PHo * pitch].reshape(B, 16, PHo, pitch)
+    assert np.all(rows[..., PWo:] == 0x55) and np.all(m8[B * 16 * PHo * pitch:] == 0x55)  # pad bytes / slack are never written
+    assert np.all((rows[..., :PWo] & 0x7C) == 0)
+    unpacked = T.full_like(mask, -2)
+    packed.pool_mask_unpack(mask8, unpacked)
+    assert np.array_equal(host(unpacked), host(mask))
+    dpool = dev(T, uniform_pm1(621, (B, 16, PHo, PWo)))
+    gw_ref, gb_ref, dx_ref = T.empty_like(wd), T.empty_like(bd), T.empty((B, 3, H, W), device="cuda")
+    conv.backward_weight_pooled2(xd, dpool, mask, None, float(B), gw_ref, gb_ref)
+    conv.backward_data_pooled2(dpool, mask, None, wd, dx_ref)
+    gw, gb, dx = T.full_like(wd, 7.0), T.full_like(bd, 7.0), T.full_like(dx_ref, 7.0)
+    packed.backward_weight_pooled2(xd, dpool, mask8, None, float(B), gw, gb)
+    packed.backward_data_pooled2(dpool, mask8, None, wd, dx)
+    u32 = lambda t: host(t).view(np.uint32)
+    assert np.array_equal(u32(gw), u32(gw_ref)) and np.array_equal(u32(gb), u32(gb_ref)) and np.array_equal(u32(dx), u32(dx_ref))
+    # the prepared / fused-SGD members of the family
+    pf, pd = packed.prepared_buffers("cuda")
+    capi.prepare_filters([packed], [wd], [bd], [pf], [pd])
+    dx2 = T.full_like(dx_ref, 7.0)
+    packed.backward_data_pooled2(dpool, mask8, None, None, dx2, prepared_dgrad=pd)
+    assert np.array_equal(u32(dx2), u32(dx_ref))
+    w2, b2, w3, b3 = wd.clone(), bd.clone(), wd.clone(), bd.clone()
+    ga, gb_a, gc, gb_c = T.empty_like(wd), T.empty_like(bd), T.empty_like(wd), T.empty_like(bd)
+    conv.backward_weight_pooled2_sgd(xd, dpool, mask, None, float(B), ga, gb_a, w2, b2, 0.05, 1.0, None, None)
+    packed.backward_weight_pooled2_sgd(xd, dpool, mask8, None, float(B), gc, gb_c, w3, b3, 0.05, 1.0, None, None)
+    assert np.array_equal(u32(w3), u32(w2)) and np.array_equal(u32(b3), u32(b2)) and np.array_equal(u32(gc), u32(ga))
+    # pooled must be NULL with the packed form (bit 7 IS the ReLU mask), and the older kernels of the block do not read it
+    with pytest.raises(capi.CnnAmdError):
+        packed.backward_weight_pooled2(xd, dpool, mask8, pooled, float(B), gw, gb)
+    with capi.option("DGRAD_POOL_LDS", 0):
+        assert not packed.pool_mask_packed_supported()
+        with pytest.raises(capi.CnnAmdError):
+            packed.backward_data_pooled2(dpool, mask8, None, wd, dx)
+
+
 @pytest.mark.parametrize("shape", [(256, 224, 224), (2, 224, 224), (3, 37, 41), (5, 7, 5)], ids=lambda s: "B%d_%dx%d" % s)
 @pytest.mark.parametrize("scale", [1.0, 0.5])
 def test_first_layer_weight_gradient_sgd_prepare_fusion_is_bit_identical(T, shape, scale):
@@ -866,8 +929,9 @@ def test_pool_fused_net_is_bit_identical(T, defer):
             n.flush()
         T.cuda.synchronize()
         assert T.equal(a.params, b.params) and T.equal(a.grads, b.grads), step
-        assert T.equal(a.pool_out, b.pool_out) and T.equal(a.pool_mask & 0x7FFFFFFF, b.pool_mask)
-        assert T.equal(a.pool_mask < 0, b.pool_out <= 0)  # (bit 31: relu_layer_1's backward mask rides in the pool mask)
+        am = a.pool_mask_int32()  # (the fused block keeps its mask packed, one byte per window, where the library supports it)
+        assert T.equal(a.pool_out, b.pool_out) and T.equal(am & 0x7FFFFFFF, b.pool_mask)
+        assert T.equal(am < 0, b.pool_out <= 0)  # (bit 31: relu_layer_1's backward mask rides in the pool mask)
         assert T.equal(a.d_conv[0], b.d_conv[0]) and T.equal(a.logits, b.logits)
         assert T.equal(a.d_conv[1], b.d_conv[1])  # d(pool output): conv_layer_2's plain data gradient in both nets
 
@@ -990,7 +1054,7 @@ def test_pool_fused_net_full_batch_is_bit_identical(T):
             n.flush()
         T.cuda.synchronize()
         assert T.equal(fused.params, plain.params) and T.equal(fused.grads, plain.grads), step
-        assert T.equal(fused.pool_out, plain.pool_out) and T.equal(fused.pool_mask & 0x7FFFFFFF, plain.pool_mask & 0x7FFFFFFF)
+        assert T.equal(fused.pool_out, plain.pool_out) and T.equal(fused.pool_mask_int32() & 0x7FFFFFFF, plain.pool_mask_int32() & 0x7FFFFFFF)
         assert T.equal(fused.d_conv[0], plain.d_conv[0]) and T.equal(fused.logits, plain.logits)
     loss = float(fused.loss_sum.item()) / B
     assert np.isfinite(loss) and 0.0 < loss < 20.0

@@ -26,14 +26,15 @@ def canonical(name):
     m = re.match(r"(igemm_kernel|wgrad_kernel)<(\d+,\d+,\d+,\d+,\d+,\d+),(true|false),(true|false)>$", name)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
-    if name.startswith("conv_fwd_pool_pk_3_16_3_2"):
-        return "conv_fwd_pool_pk<3,16,3,2>"
+    m = re.match(r"conv_fwd_pool_pk_3_16_3_2<\d+(?:,(true|false))?>$", name)
+    if m:  # (second parameter: the packed one-byte pool mask)
+        return "conv_fwd_pool_pk<3,16,3,2>" + ("+m8" if m.group(1) == "true" else "")
     m = re.match(r"conv_dgrad_pool_pk_3_16_3_2<\d+,(true|false)>$", name)
     if m:
         return "conv_dgrad_pk<3,16,3,2>" + ("+pool" if m.group(1) == "true" else "+poolm")
-    m = re.match(r"conv_dgrad_pool_lds_3_16_3_2<(true|false)>$", name)
-    if m:  # (round 3: the LDS-staged kernel behind the same ABI entry point / timer key)
-        return "conv_dgrad_pk<3,16,3,2>" + ("+pool" if m.group(1) == "true" else "+poolm")
+    m = re.match(r"conv_dgrad_pool_lds_3_16_3_2<(\d)>$", name)
+    if m:  # (round 3: the LDS-staged kernel behind the same ABI entry point / timer key; mode 2 = packed pool mask)
+        return "conv_dgrad_pk<3,16,3,2>" + {"0": "+poolm", "1": "+pool", "2": "+poolm8"}[m.group(1)]
     m = re.match(r"conv_wgrad_pk_3_16_3_2<\d+,(\d+)>$", name)
     if m:
         return "conv_wgrad_pk<3,16,3,2>" + {"0": "", "1": "+pool", "2": "+poolm"}[m.group(1)]
@@ -54,7 +55,7 @@ def canonical(name):
         return f"wgrad_rd<{m.group(1)}>" + ("+pool" if m.group(2) == "true" else "")
     m = re.match(r"conv_wgrad_win_kernel<(\d),(true|false)(?:,(?:true|false))?>$", name)
     if m:
-        return "conv_wgrad_win<3,16,3,2>" + {"0": "", "1": "+pool", "2": "+poolm"}[m.group(1)]
+        return "conv_wgrad_win<3,16,3,2>" + {"0": "", "1": "+pool", "2": "+poolm", "3": "+poolm8"}[m.group(1)]
     m = re.match(r"conv_wgrad_os_kernel<(\d+),(\d+),\d+,\d+,\d+>$", name)
     if m:
         return f"conv_wgrad_os<{m.group(1)},{m.group(2)}>"
