@@ -1462,7 +1462,9 @@ bool igemm_preferred(const cnn_conv2d_desc* d, int mode) {
 }
 
 size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
+    static thread_local DescMemo memo;  // (independent of what the tuner has pinned: every candidate is planned regardless)
     size_t n = 0;
+    if (memo.find(d, &n)) return n;
     // the largest re-arranged filter image any tile the tuner may pin would need (the caller sizes its buffers once)
     for (int c : kTuneCandidates)
         for (int mode = 0; mode < 2; ++mode) {
@@ -1476,6 +1478,7 @@ size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
     if (pk_dgrad_s2_supported(d) && n < pk_dgrad_s2_workspace_floats(d)) n = pk_dgrad_s2_workspace_floats(d);
     if (fwd_rd_prepared_floats(d) > n) n = fwd_rd_prepared_floats(d);
     if (dgrad_rd_prepared_floats(d) > n) n = dgrad_rd_prepared_floats(d);
+    memo.put(d, n);
     return n;
 }
 }  // namespace cnn_amd

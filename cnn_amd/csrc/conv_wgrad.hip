@@ -751,6 +751,9 @@ extern "C" {
 
 size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d) {
     if (check_desc("cnn_conv2d_workspace_bytes", d)) return 0;
+    static thread_local DescMemo memo;
+    size_t known = 0;
+    if (memo.find(d, &known)) return known;
     WPlan pl;
     size_t wg = 0;
     if (make_wplan("cnn_conv2d_workspace_bytes", d, &pl) == CNN_AMD_OK) wg = pl.part_floats + pl.bias_floats + pl.tmp_floats;
@@ -771,6 +774,7 @@ size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d) {
     const int oss = os_wgrad_slots(d);
     const size_t osw = oss ? (size_t)(oss + (oss + 63) / 64) * d->Co * (d->Ci * 9 + 1) : 0;
     if (osw > m) m = osw;
+    memo.put(d, (m + 64) * sizeof(float));
     return (m + 64) * sizeof(float);
 }
 
