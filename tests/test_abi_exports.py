@@ -67,6 +67,24 @@ def test_option_table_needs_no_gpu_and_no_getenv_on_launch_paths():
         assert "getenv" not in text, path
 
 
+def test_size_queries_are_memoised_per_option_generation():
+    """cnn_conv2d_prepared_bytes / cnn_conv2d_workspace_bytes plan every implicit-GEMM tile candidate; the launch paths call them on
+    every launch, so the result is memoised per (desc, option-table generation): a switch that changes the plan must still show"""
+    import ctypes as C
+
+    lib = capi.load()
+    d = capi.ConvDesc(64, 64, 56, 56, 64, 3, 1, 1)
+    sizes = lambda: (int(lib.cnn_conv2d_workspace_bytes(C.byref(d))), int(lib.cnn_conv2d_prepared_bytes(C.byref(d))))
+    base = sizes()
+    assert base == sizes() and base[0] > 0 and base[1] > 0
+    with capi.option("IGEMM_CFG", "215"):  # one forced tile instead of the largest over all tuner candidates
+        forced = sizes()
+        assert forced[1] < base[1]
+    assert sizes() == base
+    other = capi.ConvDesc(64, 64, 56, 56, 64, 3, 1, 1, capi.POOL_MASK_PACKED)  # (flags are part of the key; this query ignores them)
+    assert int(lib.cnn_conv2d_prepared_bytes(C.byref(other))) == base[1]
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(capi, "_lib", None)
     monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libcnn_amd.so")

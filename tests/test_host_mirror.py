@@ -342,6 +342,30 @@ def test_host_net_pool_block_fusion_is_bit_identical():
 
 
 @pytest.mark.gpu
+def test_host_net_packed_pool_mask_is_bit_identical(lib_option):
+    """the host layers keep the fused first block's pool mask packed (one byte per window, include/cnn_amd.h) where the library supports
+    it; POOL_MASK_PACKED=0 makes them use the int32 form: parameters, gradients, the input delta (the deferred data gradient reads
+    the mask one step later, from the alternate set) and the losses of four steps with different inputs are the same bits"""
+    from cnn_amd import hostapi
+
+    B = 5
+    labels = np.array([0, 2, 1, 1, 0], np.int32)
+    p0 = normal_scaled(73, (111267,))
+    res = []
+    for packed in ("1", "0"):
+        lib_option("POOL_MASK_PACKED", packed)
+        net = hostapi.HostAlexNet(3)
+        net.set_params(p0)
+        losses = [net.train_step_host(uniform01(74 + i, (B, 3, 224, 224)), labels, 1e-3)[0] for i in range(4)]
+        res.append((losses, net.get_params(), net.get_grads(), net.input_delta((B, 3, 224, 224))))
+        net.close()
+    lib_option("POOL_MASK_PACKED", None)
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("pool_block", [0, 1], ids=["all_outputs_valid", "fuse_pool_block"])
 def test_host_train_step_on_device_matches_the_reference_loop(pool_block):
     """Sequential::train_step (cnn.cpp:79-90 with the loss glue of func.cpp:16-73 as a kernel, nothing read back) against the
