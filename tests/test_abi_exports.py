@@ -85,6 +85,27 @@ def test_size_queries_are_memoised_per_option_generation():
     assert int(lib.cnn_conv2d_prepared_bytes(C.byref(other))) == base[1]
 
 
+def test_packed_pool_mask_host_helpers_need_no_gpu():
+    """cnn_conv2d_desc.flags (ABI version 2): size and support queries of the packed pool mask, unknown flag bits are rejected"""
+    import ctypes as C
+
+    lib = capi.load()
+    d = capi.ConvDesc(4, 3, 224, 224, 16, 3, 2, 0)  # the reference's first layer: 111x111 -> 55x55 pooled, rows of 56 bytes
+    assert lib.cnn_conv2d_pool_mask_packed_supported(C.byref(d)) == 1
+    assert lib.cnn_conv2d_pool_mask_bytes(C.byref(d)) == 4 * 16 * 55 * 55 * 4
+    d.flags = capi.POOL_MASK_PACKED
+    assert lib.cnn_conv2d_pool_mask_bytes(C.byref(d)) == 4 * 16 * 55 * 56 + 64
+    d.flags = 2
+    assert lib.cnn_conv2d_pool_mask_bytes(C.byref(d)) == 0 and b"unknown desc flags" in lib.cnn_amd_last_error()
+    assert lib.cnn_conv2d_workspace_bytes(C.byref(d)) == 0
+    other = capi.ConvDesc(4, 16, 55, 55, 32, 3, 2, 0)  # not the fused block's geometry
+    assert lib.cnn_conv2d_pool_mask_packed_supported(C.byref(other)) == 0
+    d.flags = 0
+    with capi.option("POOL_MASK_PACKED", "0"):  # the A/B switch turns the packed form off for everybody who asks
+        assert lib.cnn_conv2d_pool_mask_packed_supported(C.byref(d)) == 0
+    assert lib.cnn_conv2d_pool_mask_packed_supported(C.byref(d)) == 1
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(capi, "_lib", None)
     monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libcnn_amd.so")
