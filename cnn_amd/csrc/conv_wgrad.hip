@@ -733,6 +733,7 @@ int check_desc(const char* who, const cnn_conv2d_desc* d) {
                 d->s, d->pad);
     CNN_REQUIRE(d->H + 2 * d->pad >= d->k && d->W + 2 * d->pad >= d->k, "%s: kernel %d larger than padded input", who,
                 d->k);
+    CNN_REQUIRE((d->flags & ~CNN_CONV2D_POOL_MASK_PACKED) == 0, "%s: unknown desc flags 0x%x", who, (unsigned)d->flags);
     return CNN_AMD_OK;
 }
 
