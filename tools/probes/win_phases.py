@@ -1,5 +1,6 @@
 """conv_layer_1's window kernel (packed mask), alone: default / staging only (WIN_DBG=1) / MFMA only (WIN_DBG=2, non-specialised
-instance) / specialisation off / slack variants.  usage: python tools/probes/win_phases.py"""
+instance) / specialisation off / slack variants.  (tools/probes/win_consumer_prof.patch adds WIN_DBG=4..7 -- consumers without any DMA,
+without the row hand-over, with every LDS read of a strip up front -- and per-phase counters under -DCNN_WIN_EXPERIMENT=6.)  usage: python tools/probes/win_phases.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -17,8 +18,7 @@ mask = torch.empty(conv.pool_mask_bytes(), dtype=torch.uint8, device="cuda")
 conv.relu_maxpool2_forward(x, w, b, pooled, mask)
 dpool = torch.rand(pooled.shape, generator=g, device="cuda") * 2 - 1
 gw, gb = torch.empty_like(w), torch.empty_like(b)
-for opts in ({}, {"WIN_DBG": "1"}, {"WIN_DBG": "2"}, {"WIN_SPEC": "0"}, {"WIN_SPEC": "0", "WIN_DBG": "1"}, {"WIN_SLACK": "2"}, {"WIN_SLACK": "4"}, {"WIN_SLACK": "8"},
-             {"WIN_SLACK": "16"}, {"WIN_SLACK": "28"}, {}):
+for opts in ({}, {"WIN_DBG": "1"}, {"WIN_DBG": "2"}, {"WIN_SPEC": "0"}, {"WIN_SPEC": "0", "WIN_DBG": "1"}, {"WIN_SLACK": "4"}, {"WIN_SLACK": "28"}, {}):
     for k, v in opts.items():
         capi.set_option(k, v)
     f = lambda: conv.backward_weight_pooled2(x, dpool, mask, None, float(B), gw, gb)
