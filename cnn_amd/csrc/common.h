@@ -21,10 +21,12 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 // implicit GEMM (34 plans) and are called by the prepared entry points and the host layers on EVERY launch -- 800+ plans per train step
 // of the reference net, most of the 0.36 ms the host needed to enqueue a 0.39 ms step.
 unsigned options_generation();
+int num_cus();
 struct DescMemo {
     struct Entry {
         cnn_conv2d_desc d;
         unsigned gen;
+        int cus;  // (the planners size their grids by the CURRENT device's CU count: a thread that changes devices must not hit)
         bool used;
         size_t value;
     };
@@ -32,8 +34,9 @@ struct DescMemo {
     int next = 0;
     bool find(const cnn_conv2d_desc* d, size_t* out) const {
         const unsigned gen = options_generation();
+        const int cus = num_cus();
         for (const Entry& x : e)
-            if (x.used && x.gen == gen && x.d.B == d->B && x.d.Ci == d->Ci && x.d.H == d->H && x.d.W == d->W && x.d.Co == d->Co && x.d.k == d->k &&
+            if (x.used && x.gen == gen && x.cus == cus && x.d.B == d->B && x.d.Ci == d->Ci && x.d.H == d->H && x.d.W == d->W && x.d.Co == d->Co && x.d.k == d->k &&
                 x.d.s == d->s && x.d.pad == d->pad && x.d.flags == d->flags) {
                 *out = x.value;
                 return true;
@@ -41,7 +44,7 @@ struct DescMemo {
         return false;
     }
     void put(const cnn_conv2d_desc* d, size_t v) {
-        e[next] = Entry{*d, options_generation(), true, v};
+        e[next] = Entry{*d, options_generation(), num_cus(), true, v};
         next = (next + 1) % 16;
     }
 };

@@ -87,6 +87,7 @@ int cnn_amd_side_stream_join(void* stream) {
         if (int rc = wgrad_flush_reduces(side->stream)) return rc;
     CNN_HIP_CHECK(hipEventRecord(side->join, side->stream));
     CNN_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), side->join, 0));
+    publish_mark_stale(as_stream(stream));  // (a fork taken from an earlier published kernel would miss the side stream's work)
     if (!on_side)
         if (int rc = wgrad_flush_reduces(as_stream(stream))) return rc;
     return CNN_AMD_OK;

@@ -172,6 +172,9 @@ public:
         bool valid = false;
     };
     bool pool_fused_pending() const { return pool_fused_pass; }
+    // will forward() of a batch of B samples run the Conv2D -> ReLU -> MaxPool2D(2,2) kernel (the pool then writes the set of
+    // buffers a deferred data gradient of the previous pass does NOT read)?  Otherwise the unfused MaxPool2D::forward rewrites set 0.
+    bool next_pass_pool_fused(int B) const;
     // cnn_conv2d_desc.flags of the last pool-fused forward pass (CNN_CONV2D_POOL_MASK_PACKED where the library supports it: the
     // block's three kernels then move one byte per pooling window instead of an int32 index -- 111 MB less per step of the reference
     // net); the pass' backward calls must hand the mask back with the same flags

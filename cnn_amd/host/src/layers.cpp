@@ -236,6 +236,14 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
     return output;
 }
 
+bool Conv2D::next_pass_pool_fused(int B) const {
+    if (!(prepared_active && fuse_layers && B == batch && fuse_pool_block && fused_relu != nullptr && fused_pool != nullptr &&
+          fused_pool->fusable_2x2()))
+        return false;
+    cnn_conv2d_desc d{B, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding, 0};
+    return cnn_conv2d_relu_maxpool2_supported(&d) != 0;
+}
+
 std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
     Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
     const int B = (int)delta.size();

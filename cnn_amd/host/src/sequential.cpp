@@ -527,6 +527,10 @@ void Sequential::train_step(const std::vector<tensor>& input, const int* labels_
         flush_deferred();  // (a full re-preparation rewrites filter images a pending data gradient may read)
         prepare_filters();
     }
+    // a data gradient deferred by the previous step reads the pool's output / mask set of THAT step.  A pass that does
+    // not run the block pool-fused (smaller batch, fuse_pool_block off) goes through MaxPool2D::forward, which always rewrites
+    // set 0 on the compute stream: nothing would order the two -- run the pending kernel first, in order.
+    if (pending_dgrad.valid && (block_conv == nullptr || !block_conv->next_pass_pool_fused((int)input.size()))) flush_deferred();
     params_stepped = false;
     const bool was_lazy = lazy_host_sync;
     lazy_host_sync = true;

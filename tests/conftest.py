@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+TESTS = os.path.join(ROOT, "tests")
+if TESTS not in sys.path:  # helper modules next to the tests (util, gradcam_picture)
+    sys.path.insert(1, TESTS)
 
 
 def pytest_configure(config):

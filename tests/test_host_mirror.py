@@ -430,3 +430,81 @@ def test_host_grad_cam_on_the_readme_images(golden_dir):
         with pytest.raises(KeyError):
             net.grad_cam("no_such_layer", (B, 13, 13))
         net.close()
+
+
+@pytest.mark.gpu
+def test_host_grad_cam_reproduces_the_reference_pictures(golden_dir):
+    """The six pictures the reference's own grad_cam.exe wrote (cpu/output/0..5.png; fixtures gradcam_kat_*) through the HIP path:
+    AlexNet::load_weights -> forward (one image, gradients on, grad_cam.cpp:56-71) -> grad_cam("conv_layer_3") -> the driver's
+    picture pipeline (tests/gradcam_picture.py).  Same bar as the oracle's CPU test: >= 99.5 % of the bytes within 2 grey levels,
+    none further than 4; conv_layer_3's 64x13x13 activations within 1e-4 of the oracle's; the 13x13 8-bit map at most 1 level
+    off the oracle's (it IS bit-identical when the activations are)."""
+    import gradcam_picture as G
+    from cnn_amd import hostapi
+    from oracle import pyoracle as O
+
+    imgs, names, exp = G.load_kat(golden_dir)
+    ckpt = os.path.join(golden_dir, "readme_kat_checkpoint.model")
+    expected_class = [0, 2, 1, 0, 1, 2]
+    net = hostapi.HostAlexNet(3)
+    net.load_checkpoint(ckpt)
+    for k in range(6):
+        x = G.to_input(imgs[k : k + 1])
+        logits = net.forward_host(x)
+        assert int(np.argmax(logits[0])) == expected_class[k]
+        fea = net.layer_output("conv_layer_3", (1, 64, 13, 13))
+        img, _ = net.grad_cam("conv_layer_3", (1, 13, 13))
+        within2, exact, worst = G.compare(G.picture(img, imgs[k]), exp[k])
+        assert within2 >= 0.995 and worst <= 4 and exact >= 0.65, (names[k], within2, exact, worst)
+        onet = O.Net(1, 3)
+        onet.load_checkpoint(ckpt)
+        onet.forward(x)
+        assert_close(fea, onet.conv_out(2), REL_TOL, f"{names[k]}: conv_layer_3 activations vs oracle")
+        _, img_o = O.grad_cam(onet.conv_out(2))
+        assert np.abs(img.astype(np.int32) - img_o.astype(np.int32)).max() <= 1
+    net.close()
+
+
+@pytest.mark.gpu
+def test_partial_batch_after_fused_steps_orders_the_deferred_data_gradient():
+    """three full-batch train steps (the last two pool-fused, their first-layer data gradient deferred into the next
+    pass) and then a SMALLER batch, which runs the block unfused -- MaxPool2D::forward rewrites buffer set 0 while the previous
+    step's deferred kernel may still read it.  train_step now runs a pending kernel first when the pass will not be pool-fused.
+    Against the same sequence with an ordering accessor after every step: parameters, gradients and the delta w.r.t. the input
+    (samples 0..2 from the partial step, sample 3 still from the last full step's deferred kernel) bit for bit; then a toggle of
+    fuse_pool_block between two full steps, same comparison."""
+    import torch
+
+    from cnn_amd import hostapi
+
+    B = 4
+    x = uniform01(180, (B, 3, 224, 224))
+    labels = (np.arange(B) % 3).astype(np.int32)
+    p0 = normal_scaled(181, (111267,))
+    xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    lib = hostapi.load()
+    res = []
+    try:
+        for ordered in (False, True):
+            net = hostapi.HostAlexNet(3)
+            net.set_params(p0)
+            for _ in range(3):
+                net.train_step(xd, ld, 1e-3)
+                if ordered:
+                    net.flush()
+            net.train_step(xd[:3], ld[:3], 1e-3)
+            part = (net.get_params(), net.get_grads(), net.input_delta((B, 3, 224, 224)), net.last_loss())
+            net.train_step(xd, ld, 1e-3)  # full again (unfused: the partial pass un-prepared nothing, but set 0 is current)
+            net.train_step(xd, ld, 1e-3)
+            if ordered:
+                net.flush()
+            lib.cnnh_set_fuse_pool_block(0)
+            net.train_step(xd, ld, 1e-3)
+            lib.cnnh_set_fuse_pool_block(1)
+            res.append(part + (net.get_params(), net.get_grads(), net.input_delta((B, 3, 224, 224)), net.last_loss()))
+            net.close()
+    finally:
+        lib.cnnh_set_fuse_pool_block(1)
+    for u, v in zip(res[0], res[1]):
+        assert np.array_equal(np.asarray(u), np.asarray(v))
+    assert np.abs(res[0][2][3]).max() > 0

@@ -214,3 +214,46 @@ def test_oracle_grad_cam_restatement():
     g[0, :, 0, 0] = np.nan
     camn, imgn = O.grad_cam(g)
     assert np.isnan(camn).all() and (imgn == 0).all()
+
+
+def test_grad_cam_pictures_match_the_reference_outputs(golden_dir):
+    """The reference's OWN Grad-CAM pictures (cpu/output/0..5.png, written by cpu/src/grad_cam.cpp:62-91 for six images of
+    datasets/images/ with the shipped checkpoint) pin oracle forward -> conv_layer_3 (64x13x13 per image) -> oracle_grad_cam
+    (alexnet.cpp:107-140): >= 99.5 % of every picture's bytes within 2 grey levels, no byte further than 4.  The picture pipeline
+    between the 13x13 map and the PNG is restated in tests/gradcam_picture.py (incl. the reference's first-channel maximum)."""
+    import gradcam_picture as G
+
+    imgs, names, exp = G.load_kat(golden_dir)
+    ckpt = os.path.join(golden_dir, "readme_kat_checkpoint.model")
+    assert names == ["dog", "bird_2", "panda", "dog_3", "panda_2", "bird"] and len(exp) == 6
+    expected_class = [0, 2, 1, 0, 1, 2]  # categories {"dog", "panda", "bird"}, grad_cam.cpp:25
+    for k in range(6):
+        net = O.Net(1, 3)  # grad_cam.cpp:51-53 feeds one image at a time
+        net.load_checkpoint(ckpt)
+        probs = O.softmax(net.forward(G.to_input(imgs[k : k + 1])))
+        assert int(probs.argmax()) == expected_class[k]
+        fea = net.conv_out(2)
+        _, cam8 = O.grad_cam(fea)
+        within2, exact, worst = G.compare(G.picture(cam8, imgs[k]), exp[k])
+        assert within2 >= 0.995 and worst <= 4 and exact >= 0.65, (names[k], within2, exact, worst)
+        # the pin has teeth: conv_layer_3's activations 2 % off in one direction per channel already breaks it
+        rs = np.random.RandomState(k)
+        bent = fea * (1 + 0.02 * rs.standard_normal((1, 64, 1, 1))).astype(np.float32)
+        _, cam_b = O.grad_cam(bent)
+        w2b, _, _ = G.compare(G.picture(cam_b, imgs[k]), exp[k])
+        assert w2b < within2, (names[k], w2b, within2)
+
+
+def test_grad_cam_picture_needs_the_first_channel_maximum(golden_dir):
+    """grad_cam.cpp:84 takes max_element over begin<float>() of a 3-channel Mat = the maximum of channel 0 only; with the maximum
+    over all channels the shipped pictures are NOT reproduced (dog_3: < 5 % of the bytes within 2) -- evidence for the restatement"""
+    import gradcam_picture as G
+
+    imgs, names, exp = G.load_kat(golden_dir)
+    k = names.index("dog_3")
+    net = O.Net(1, 3)
+    net.load_checkpoint(os.path.join(golden_dir, "readme_kat_checkpoint.model"))
+    net.forward(G.to_input(imgs[k : k + 1]))
+    _, cam8 = O.grad_cam(net.conv_out(2))
+    assert G.compare(G.picture(cam8, imgs[k], first_channel_max=False), exp[k])[0] < 0.05
+    assert G.compare(G.picture(cam8, imgs[k], first_channel_max=True), exp[k])[0] > 0.995
