@@ -10,6 +10,10 @@ cnn_amd/host) with their DEFAULT settings; the default command adds the Python d
 north-star convolution and a few steps of configs[3] / [4] as extra keys.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+Timing protocol (round 4): after the warm-up steps and >= 0.6 s of untimed steps (clock ramp), REPEATS = 7 regions of EXACTLY K steps are
+timed, each between two barriers + device synchronisations; `value` / `ms_per_step` are the MEDIAN region (max over ranks per region),
+`spread` holds the slowest / fastest region.  `reference_loop` is the same workload through the reference's own loop on the unchanged
+Layer API (cpu/src/cnn.cpp:79-90, host-side loss glue).
 Prints ONE JSON line on rank 0 (contract in the task brief) with two extra objects:
   roofline     -- the dominant kernel of the step: algorithmic bytes (or FLOPs) per launch / its average duration,
                   measured with HIP events on the launch stream DURING the timed region (only that kernel is
@@ -233,13 +237,46 @@ def staged_input_bench(torch, capi, args):
         net.train_step_ptr(dev, labels, B, 224, 224, 1e-3)
         stager.release(slot)
 
-    el = timed_steps(torch, step, torch.cuda.synchronize, args.steps, args.warmup)
+    el = median(timed_regions(step, torch.cuda.synchronize, args.steps, args.warmup, repeats=3))
     loss = net.last_loss()
     stager.close()
     net.close()
     return {"value": round(B * args.steps / el, 1), "unit": "images/sec", "ms_per_step": round(el / args.steps * 1e3, 4),
             "h2d_GBps": round(nbytes * args.steps / el / 1e9, 1), "final_loss": round(loss, 5),
             "note": "every batch uploaded from pinned host memory (cnn_batch_stager_*, 2 slots, copy stream overlapped with compute)"}
+
+
+def reference_loop_leg(torch, args):
+    """The SAME workload through the reference's own training loop on the UNCHANGED Layer API -- cpu/src/cnn.cpp:79-90:
+    network.forward(batch) -> softmax(output) -> cross_entroy_backward(probs, one_hot(labels)) -> network.backward(delta) ->
+    network.update_gradients(lr) -- with the host-side func.cpp loss glue (the logits are read back and the loss delta uploaded
+    every step, as a maintainer who drops the library into cpu/src gets it; cnnh_net_train_step_device in host/src/host_capi.cpp).
+    `value` above is architectures::Sequential::train_step, an ADDITION to that API (device-side loss, fused step tail)."""
+    import numpy as np
+
+    from cnn_amd import hostapi
+
+    B = args.batch or 256
+    net = hostapi.HostAlexNet(3)
+    rs = np.random.RandomState(1234)
+    net.set_params((rs.standard_normal(net.n_params) * 0.1).astype(np.float32))
+    g = torch.Generator(device="cuda").manual_seed(100)
+    x = torch.rand((B, 3, 224, 224), generator=g, device="cuda")
+    labels = (np.arange(B) % 3).astype(np.int32)
+    last = [0.0]
+
+    def step():
+        last[0] = net.train_step_device(x, labels, 1e-3)
+
+    regions = timed_regions(step, torch.cuda.synchronize, args.steps, args.warmup, repeats=3)
+    out = dict(leg_result(B, args.steps, regions), final_loss=round(last[0], 5),
+               driver="C++ Layer API, the reference's loop verbatim: AlexNet::forward -> softmax -> cross_entroy_backward -> "
+                      "AlexNet::backward -> AlexNet::update_gradients (cpu/src/cnn.cpp:79-90; host-side loss glue, one D2H + one H2D "
+                      "per step), default settings")
+    net.close()
+    del x
+    torch.cuda.empty_cache()
+    return out
 
 
 def init_comm(capi, torch, dist, world, rank):
@@ -280,7 +317,7 @@ def make_runner(config, api, batch, torch, capi, world, rank, comm, pool_block=T
         net.load_params((rs.standard_normal(net.n_params) * 0.1).astype(np.float32))
         handle = comm if world > 1 else None
         return dict(step=lambda: net.train_step(x, labels, lr, handle, world), flush=net.flush, B=B, n_params=net.n_params,
-                    loss=lambda: float(net.loss_sum.item()) / B, keep=(net, x, labels), close=lambda: None,
+                    loss=lambda: float(net.loss_sum.item()) / B, keep=(net, x, labels), close=lambda: None, params=None,
                     api="python driver (cnn_amd/pynet.py) -> C ABI; first block pool-fused, conv_layer_1 data gradient deferred")
     from cnn_amd import hostapi
 
@@ -301,15 +338,19 @@ def make_runner(config, api, batch, torch, capi, world, rank, comm, pool_block=T
         lib.cnnh_set_fuse_pool_block(1)
 
     return dict(step=lambda: net.train_step(x, labels, lr), flush=net.flush, B=B, n_params=net.n_params, loss=net.last_loss,
-                keep=(net, x, labels), close=close,
+                keep=(net, x, labels), close=close, params=net.get_params,
                 api="C++ Layer API (architectures::Sequential::train_step, cnn_amd/host) -> C ABI, default settings"
                     + ("" if pool_block else " except architectures::fuse_pool_block = false (every tensor written by the pass itself)"))
 
 
-def measure(run, steps, warmup, sample_every, capi, barrier, time_mod=time):
-    """the measurement protocol of one workload: 3 plain + 3 instrumented steps (which kernel dominates?), `warmup` steps, then
-    exactly `steps` timed steps between two barriers with only the dominant kernel event-bracketed -> (elapsed_s, key, launches,
-    total_ms, table)"""
+REPEATS = 7          # timed regions of exactly K steps each; `value` is their MEDIAN, `spread` their min / max
+CLOCK_WARMUP_S = 0.6  # untimed steps in front of the first region until the clocks have ramped (the driver's box was 7 % slower)
+
+
+def measure(run, steps, warmup, sample_every, capi, barrier, time_mod=time, repeats=1, clock_warmup_s=0.0):
+    """the measurement protocol of one workload: 3 plain + 3 instrumented steps (which kernel dominates?), `warmup` steps [+ steps
+    until `clock_warmup_s` have passed], then `repeats` timed regions of exactly `steps` steps, each between two barriers, with
+    only the dominant kernel event-bracketed -> (list of elapsed_s per region, key, launches, total_ms, table)"""
     step = run["step"]
     for _ in range(3):
         step()
@@ -323,17 +364,59 @@ def measure(run, steps, warmup, sample_every, capi, barrier, time_mod=time):
     dominant = max(table.items(), key=lambda kv: kv[1][1])[0]
     for _ in range(warmup):
         step()
+    if clock_warmup_s > 0:
+        barrier()
+        t0 = time_mod.perf_counter()
+        while time_mod.perf_counter() - t0 < clock_warmup_s:
+            for _ in range(max(steps, 1)):
+                step()
+            barrier()
     capi.kernel_timing(2, dominant, every=sample_every)
-    barrier()
-    t0 = time_mod.perf_counter()
-    for _ in range(steps):
-        step()
-    barrier()
-    elapsed = time_mod.perf_counter() - t0
+    regions = []
+    for _ in range(repeats):
+        barrier()
+        t0 = time_mod.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        regions.append(time_mod.perf_counter() - t0)
     dom = capi.kernel_timing_report()
     capi.kernel_timing(0)
     cnt, ms = dom[dominant]
-    return elapsed, dominant, cnt, ms, table
+    return regions, dominant, cnt, ms, table
+
+
+def median(v):
+    v = sorted(v)
+    n = len(v)
+    return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+
+
+def timed_regions(step, barrier, steps, warmup, repeats=REPEATS, clock_warmup_s=CLOCK_WARMUP_S):
+    """extra legs: `warmup` steps, clock warm-up, then `repeats` regions of `steps` steps -> list of elapsed_s"""
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < clock_warmup_s:
+        for _ in range(max(steps, 1)):
+            step()
+        barrier()
+    out = []
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        out.append(time.perf_counter() - t0)
+    return out
+
+
+def leg_result(B, steps, regions):
+    el = median(regions)
+    return {"value": round(B * steps / el, 1), "unit": "images/sec", "ms_per_step": round(el / steps * 1e3, 4),
+            "spread": {"repeats": len(regions), "min": round(B * steps / max(regions), 1), "max": round(B * steps / min(regions), 1)}}
 
 
 def stack_leg(config, torch, capi, steps=5, warmup=2):
@@ -346,12 +429,15 @@ def stack_leg(config, torch, capi, steps=5, warmup=2):
         run["flush"]()
         torch.cuda.synchronize()
 
-    elapsed, dominant, cnt, ms, _ = measure(run, steps, warmup, 1, capi, barrier)
+    regions, dominant, cnt, ms, _ = measure(run, steps, warmup, 1, capi, barrier, repeats=3)
+    elapsed = median(regions)
     B = run["B"]
     flops_img = stacks.train_flops_per_image(stacks.STACKS[config]())
     tf = flops_img * B * steps / elapsed / 1e12
     out = {"workload": WORKLOADS[config], "value": round(B * steps / elapsed, 1), "unit": "images/sec", "per_gpu_batch": B, "steps": steps,
-           "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "step_tflops": round(tf, 2),
+           "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
+           "spread": {"repeats": len(regions), "min": round(B * steps / max(regions), 1), "max": round(B * steps / min(regions), 1)},
+           "step_tflops": round(tf, 2),
            "step_frac_of_mfma_peak": round(tf / PEAK_MFMA_F32_TFLOPS, 4), "roofline": roofline_entry(dominant, cnt, ms),
            "final_loss": round(run["loss"](), 5), "driver": run["api"]}
     run["close"]()
@@ -369,17 +455,6 @@ WORKLOADS = {
                 "1x1/s2, 3x3/s2; BatchNorm2D + ReLU after every conv; Linear 25088->3), full train step, 224x224x3 fp32, "
                 "BASELINE configs[4] (batch 512 over 8 GPUs = 64 per GPU)",
 }
-
-
-def timed_steps(torch, step, barrier, steps, warmup):
-    for _ in range(warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    barrier()
-    return time.perf_counter() - t0
 
 
 def main():
@@ -405,6 +480,8 @@ def main():
     ap.add_argument("--staged-input", action="store_true",
                     help="also time the reference net with every batch coming from (pinned) HOST memory through cnn_batch_stager_* "
                          "-- the PCIe-inclusive rate, reported beside `value`, never as it")
+    ap.add_argument("--repeats", type=int, default=None,
+                    help=f"timed regions of --steps steps each; value = their median (default {REPEATS}; 3 for the stacks)")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
     args = ap.parse_args()
     small = args.config == "alexnet"
@@ -463,13 +540,30 @@ def main():
     # steps, only the dominant kernel event-bracketed (every 4th launch of it for the 0.45 ms net: the event pair around a
     # kernel costs its stream two ~6 us bubbles -- measured 13 us per step)
     every = 4 if small else 1
-    elapsed, dominant, cnt, ms, table = measure(run, args.steps, args.warmup, every, capi, barrier)
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    repeats = args.repeats or (REPEATS if small else 3)
+    regions, dominant, cnt, ms, table = measure(run, args.steps, args.warmup, every, capi, barrier, repeats=repeats,
+                                                clock_warmup_s=CLOCK_WARMUP_S if small else 0.0)
+    if world > 1:  # every region's time is the MAX over the ranks
+        t = torch.tensor(regions, device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        regions = [float(v) for v in t.tolist()]
+    elapsed = median(regions)  # `value` / `ms_per_step`: the median region of exactly K steps
     loss = run["loss"]()
     assert np.isfinite(loss), "training diverged: loss is not finite"
+    if world > 1 and run["params"] is not None:
+        # replicas start identical and apply identical reduced gradients: after ALL the steps above their parameters must be the same
+        # bits on every rank; a digest per rank, gathered and compared
+        import hashlib
+
+        digest = int.from_bytes(hashlib.sha256(run["params"]().tobytes()).digest()[:7], "little")
+        mine = torch.tensor([digest], device="cuda", dtype=torch.int64)
+        every_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every_rank, mine)
+        digests = [int(t.item()) for t in every_rank]
+        assert len(set(digests)) == 1, f"replicas diverged: parameter digests per rank {digests}"
+        assert comm_info["ranks"] == args.gpus == world
+        comm_info["param_digests_equal_on_all_ranks"] = True
+        comm_info["param_digest"] = f"{digest:014x}"
 
     out = None
     if rank == 0:
@@ -483,6 +577,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "spread": {"repeats": len(regions), "regions_of_steps": args.steps, "statistic": "median",
+                       "min": round(world * B * args.steps / max(regions), 1), "max": round(world * B * args.steps / min(regions), 1),
+                       "clock_warmup_s": CLOCK_WARMUP_S if small else 0.0},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -526,12 +623,12 @@ def main():
                     r2["flush"]()
                     torch.cuda.synchronize()
 
-                el = timed_steps(torch, r2["step"], sync, args.steps, args.warmup)
-                out[key] = {"value": round(r2["B"] * args.steps / el, 1), "unit": "images/sec", "ms_per_step": round(el / args.steps * 1e3, 4),
-                            "driver": r2["api"], "final_loss": round(r2["loss"](), 5)}
+                out[key] = dict(leg_result(r2["B"], args.steps, timed_regions(r2["step"], sync, args.steps, args.warmup, repeats=3)),
+                                driver=r2["api"], final_loss=round(r2["loss"](), 5))
                 r2["close"]()
                 del r2
                 torch.cuda.empty_cache()
+            out["reference_loop"] = reference_loop_leg(torch, args)
         if small and args.staged_input:
             out["pcie_inclusive"] = staged_input_bench(torch, capi, args)
         if small and not args.no_conv_ns:

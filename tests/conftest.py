@@ -36,3 +36,29 @@ def lib_option():
     yield set_
     for name, old in saved.items():
         capi.set_option(name, old)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """what the tolerance checks of this session measured (tests/util.py MARGINS) -> gpurun_out/parity_margins.json (merged back from
+    the GPU box by gpurun; the round's copy is committed under profiles/)"""
+    import json
+
+    try:
+        from tests import util
+    except Exception:
+        return
+    if not util.MARGINS:
+        return
+    recs = util.MARGINS
+    arb = [r for r in recs if r["branch"] == "fp64-arbitrated"]
+    summary = {"records": len(recs), "fp64_arbitrated_passes": len(arb),
+               "exact_zero_noise_checks": sum(r["branch"] == "exact-zero-noise" for r in recs),
+               "worst_plain_err_vs_fp32_oracle": max(r["plain_err_vs_fp32_oracle"] for r in recs),
+               "worst_plain_err_at_tol_1e-4": max([r["plain_err_vs_fp32_oracle"] for r in recs if r["tol"] <= 1e-4] or [0.0])}
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_margins.json"), "w") as f:
+            json.dump({"summary": summary, "records": recs}, f, indent=1)
+    except OSError:
+        pass

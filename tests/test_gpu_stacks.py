@@ -6,7 +6,7 @@ import pytest
 
 from cnn_amd import stacks as S
 from oracle import pyoracle as O
-from tests.util import REL_TOL, assert_close, assert_close_arbitrated, he_init, rel_err, uniform01
+from tests.util import REL_TOL, assert_close, assert_close_arbitrated, assert_noise_of_exact_zero, he_init, rel_err, uniform01
 
 pytestmark = pytest.mark.gpu
 
@@ -120,6 +120,13 @@ def test_stack_train_steps_vs_oracle(T, which, res, B):
                 # Jacobian diag(p) - p p^T has infinity-norm <= 1/2), and the logits themselves are only held to REL_TOL * max|z|
                 # (above) -- the implicit-GEMM tiles the tuner pins differ from box to box, and with them the last bits of z
                 tol = max(REL_TOL, 0.5 * REL_TOL * float(np.abs(ologits).max()) / float(np.abs(onet.grads[lo:hi]).max()))
+            if name.endswith(".b") and name.startswith("conv") and idx + 1 < len(onet.layers) and onet.layers[idx + 1]["kind"] == "bn":
+                # exactly 0 in exact arithmetic (BatchNorm2D removes the channel mean behind this bias): both sides hold rounding
+                # noise -- bounded against the layer's weight gradient instead of compared with each other (tests/util.py)
+                wlo = lo - onet.layers[idx]["Co"] * onet.layers[idx]["in"][0] * onet.layers[idx]["k"] ** 2
+                assert_noise_of_exact_zero(g[lo:hi], onet.grads[lo:hi], float(np.abs(onet.grads[wlo:lo]).max()), REL_TOL,
+                                           f"{which} step{step} grad {name} (exact zero in front of BatchNorm2D)")
+                continue
             assert_close_arbitrated(g[lo:hi], onet.grads[lo:hi], onet64.grads[lo:hi], tol, 2.0, f"{which} step{step} grad {name}")
         off = 0
         for e in onet.layers:  # BatchNorm2D moving statistics, updated by the forward pass (batchnorm2d.cpp:78-79)
