@@ -154,6 +154,22 @@ int cnn_conv2d_backward_prepared_relu(const cnn_conv2d_desc* d, const float* x, 
     return CNN_AMD_OK;
 }
 
+/* the weight / bias gradient half of cnn_conv2d_backward*(defer_join = 1) alone: forked off `stream` onto the side stream, final slab
+ * reduction recorded for the join -- for callers that run the data gradients of several layers as ONE kernel (conv_chain.hip) */
+int cnn_conv2d_backward_weight_side(const cnn_conv2d_desc* d, const float* x, const float* dy, float* gw, float* gb, float divisor, void* ws,
+                                    size_t ws_bytes, void* stream) {
+    CNN_REQUIRE(d && x && dy && gw && ws, "cnn_conv2d_backward_weight_side: null pointer");
+    SideStream* side = nullptr;
+    if (int rc = get_side(&side)) return rc;
+    hipStream_t main = as_stream(stream);
+    if (heavy_layer(d)) return cnn_conv2d_backward_weight(d, x, dy, gw, gb, divisor, ws, ws_bytes, main);
+    if (int rc = fork_side(side, main)) return rc;
+    wgrad_defer_reduce(true);
+    const int rcw = cnn_conv2d_backward_weight(d, x, dy, gw, gb, divisor, ws, ws_bytes, side->stream);
+    wgrad_defer_reduce(false);
+    return rcw;
+}
+
 /* Conv2D::backward of the pool-fused first block: weight / bias gradient on the side stream, data gradient on `stream`,
  * both rebuilt from the pooled domain (cnn_conv2d_backward_weight_pooled2 / _data_pooled2_prepared) */
 int cnn_conv2d_backward_pooled2_prepared(const cnn_conv2d_desc* d, const float* x, const float* dpool, const int32_t* mask,
