@@ -277,30 +277,41 @@ struct ChainFwdParams {
     int lin_in, lin_out;
 };
 
-template <int N>
+template <int N, bool DBG = false>
 __global__ __launch_bounds__(kChainThreads) void chain_fwd_kernel(const ChainFwdParams p) {
     __shared__ HeadShared sh;
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int C0 = 128 >> N;
+    long long t[6] = {0, 0, 0, 0, 0, 0};  // (DBG: s_memtime stamps of wave 0 at the phase boundaries)
+    if (DBG) t[0] = clock64();
     const float* xin = p.x + (size_t)b * C0 * p.H[0] * p.W[0];
     if constexpr (N >= 3) {
         float* out = p.a[N - 3] + (size_t)b * 32 * p.H[N - 2] * p.W[N - 2];
         chain_fwd_phase<16, 2>(xin, p.img[N - 3], p.bias[N - 3], out, p.H[N - 3], p.W[N - 3], 32, p.H[N - 2], p.W[N - 2], p.m_wo[N - 3], wave, lane);
+        if (DBG) t[1] = clock64();
         __syncthreads();
         xin = out;
     }
     if constexpr (N >= 2) {
         float* out = p.a[N - 2] + (size_t)b * 64 * p.H[N - 1] * p.W[N - 1];
+        if (DBG) t[2] = clock64();
         chain_fwd_phase<32, 2>(xin, p.img[N - 2], p.bias[N - 2], out, p.H[N - 2], p.W[N - 2], 64, p.H[N - 1], p.W[N - 1], p.m_wo[N - 2], wave, lane);
+        if (DBG) t[3] = clock64();
         __syncthreads();
         xin = out;
     }
     float* a_last = p.a[N - 1] + (size_t)b * 128 * p.H[N] * p.W[N];
+    if (DBG) t[4] = clock64();
     chain_fwd_phase<64, 1>(xin, p.img[N - 1], p.bias[N - 1], a_last, p.H[N - 1], p.W[N - 1], 128, p.H[N], p.W[N], p.m_wo[N - 1], wave, lane);
+    if (DBG) t[5] = clock64();
     __syncthreads();
+    const long long th = DBG ? clock64() : 0;
     chain_head_phase(a_last, p.lin_w, p.lin_b, p.labels, p.logits, p.probs, p.delta, p.loss_terms, p.dx_head + (size_t)b * p.lin_in, p.lin_in,
                      p.lin_out, b, sh);
+    if (DBG && (b == 0 || b == 100) && lane == 0 && (wave == 0 || wave == 7))
+        printf("chain_fwd<%d> wg %d wave %d: phase A %lld (+barrier %lld) | B %lld (+barrier %lld) | C %lld (+barrier %lld) | head %lld | total %lld ticks\n", N, b,
+               wave, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], th - t[5], (long long)clock64() - th, (long long)clock64() - t[0]);
 }
 
 // ---- data gradient of ONE stride-2 convolution for ONE sample: conv_dgrad_m16_s2_kernel's wave loop (conv_dgrad_rd.hip) -------------
@@ -542,6 +553,10 @@ int cnn_conv_chain_forward_loss_prepared(int n, const cnn_conv2d_desc* descs, co
     snprintf(name, sizeof(name), "conv_chain_fwd<%d>+head", n);
 #define CHAIN_F(N_) \
     CNN_KLAUNCH(s, name, (launch_pub(chain_fwd_kernel<N_>, dim3(B), dim3(kChainThreads), 0, s, p)), "B%d C%d %dx%d", B, descs[0].Ci, descs[0].H, descs[0].W)
+    if (CNN_OPT_INT("CHAIN_DBG", 0) != 0 && n == 3) {
+        CNN_KLAUNCH(s, name, (launch_pub(chain_fwd_kernel<3, true>, dim3(B), dim3(kChainThreads), 0, s, p)), "B%d C%d %dx%d", B, descs[0].Ci, descs[0].H, descs[0].W);
+        return CNN_AMD_OK;
+    }
     if (n == 1) CHAIN_F(1); else if (n == 2) CHAIN_F(2); else CHAIN_F(3);
 #undef CHAIN_F
     return CNN_AMD_OK;

@@ -211,6 +211,9 @@ int cnnh_net_input_delta(void* hv, float* out, size_t cap_floats) {
 }
 // Sequential::flush_deferred: a data gradient train_step deferred into the next pass is launched / ordered now
 void cnnh_net_flush(void* hv) { ((Handle*)hv)->net->flush_deferred(); }
+// how many trailing convolutions the last train_step ran as ONE sample-resident chain kernel (forward != 0: the forward chain incl. the
+// loss head; 0: the data-gradient chain); 0 = the per-layer path
+int cnnh_net_chain_layers(void* hv, int forward) { return ((Handle*)hv)->net->chain_layers(forward != 0); }
 void cnnh_net_update(void* hv, float lr, float grad_scale) { ((Handle*)hv)->net->update_gradients(lr, grad_scale); }
 // Sequential::update_gradients(lr): with a communicator set, all-reduce + lr/world; otherwise the plain step
 void cnnh_net_update_auto(void* hv, float lr) { ((Handle*)hv)->net->update_gradients(lr); }

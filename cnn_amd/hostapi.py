@@ -49,6 +49,7 @@ SIGNATURES = {
     "cnnh_net_train_step_device_loss": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]),
     "cnnh_net_last_loss": (C.c_float, [C.c_void_p]),
     "cnnh_net_flush": (None, [C.c_void_p]),
+    "cnnh_net_chain_layers": (C.c_int, [C.c_void_p, C.c_int]),
     "cnnh_net_input_delta": (C.c_int, [C.c_void_p, _F, C.c_size_t]),
     "cnnh_net_layer_output": (C.c_int, [C.c_void_p, C.c_char_p, _F, C.c_size_t]),
     "cnnh_net_grad_cam": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, _F, C.c_size_t]),

@@ -164,3 +164,95 @@ def test_chain_rejects_other_geometries(T):
     assert not capi.conv_chain_supported([capi.Conv2d(4, 16, 27, 27, 64, 3, 2, 0)], 0, 0)                                           # channels
     with capi.option("NO_CHAIN", "1"):
         assert not capi.conv_chain_supported(ok)
+
+
+ALEXNET_OUTPUTS = [("conv_layer_1", (16, 111, 111)), ("relu_layer_1", (16, 111, 111)), ("max_pool_1", (16, 55, 55)),
+                   ("conv_layer_2", (32, 27, 27)), ("relu_layer_2", (32, 27, 27)), ("conv_layer_3", (64, 13, 13)),
+                   ("relu_layer_3", (64, 13, 13)), ("conv_layer_4", (128, 6, 6)), ("relu_layer_4", (128, 6, 6)), ("linear_1", (3, 1, 1))]
+
+
+@pytest.fixture
+def lib_option():
+    from cnn_amd import capi
+
+    saved = {}
+
+    def set_(name, value):
+        if name not in saved:
+            saved[name] = capi.get_option(name)
+        capi.set_option(name, value)
+
+    yield set_
+    for name, old in saved.items():
+        capi.set_option(name, old)
+
+
+def test_train_step_with_chain_kernels_is_bit_identical_to_the_per_layer_step(T, lib_option):
+    """architectures::Sequential::train_step of the reference net with the chain kernels (forward chain / data-gradient chain over the
+    last 3, 2, 1 convolutions, and each direction alone) against the per-layer step: after every one of four steps the loss, the
+    parameters, the gradients, every layer's get_output() (alexnet.cpp:97,105) and the delta with respect to the input image, bit for
+    bit -- the chain changes WHERE the kernel boundaries are, not one product or sum"""
+    from cnn_amd import hostapi
+
+    B = 5
+    x = uniform01(4300, (B, 3, 224, 224))
+    labels = (np.arange(B) % 3).astype(np.int32)
+    p0 = normal_scaled(4301, (111267,))
+    xd, ld = dev(T, x), dev(T, labels)
+    lib_option("CHAIN_MIN_B", "1")
+
+    def run(fwd_n, bwd_n):
+        lib_option("CHAIN_FWD_N", str(fwd_n))
+        lib_option("CHAIN_BWD_N", str(bwd_n))
+        net = hostapi.HostAlexNet(3)
+        net.set_params(p0)
+        trace = []
+        for step in range(4):
+            net.train_step(xd, ld, 1e-3)
+            outs = [net.layer_output(name, (B,) + shp) for name, shp in ALEXNET_OUTPUTS] if step in (1, 3) else None
+            dx = net.input_delta((B, 3, 224, 224)) if step != 2 else None  # (step 2: the deferred kernel stays pending into step 3)
+            trace.append((net.last_loss(), net.get_params(), net.get_grads(), outs, dx))
+        net.close()
+        return trace
+
+    base = run(0, 0)
+    for fwd_n, bwd_n in ((3, 3), (2, 2), (1, 1), (3, 0), (0, 3), (3, 2), (2, 3)):
+        got = run(fwd_n, bwd_n)
+        for step, (a, b) in enumerate(zip(base, got)):
+            tag = f"chain fwd {fwd_n} / bwd {bwd_n}, step {step}"
+            assert a[0] == b[0], (tag, a[0], b[0])
+            assert np.array_equal(a[1], b[1]), tag + ": parameters"
+            assert np.array_equal(a[2], b[2]), tag + ": gradients"
+            if a[3] is not None:
+                for (name, _), u, v in zip(ALEXNET_OUTPUTS, a[3], b[3]):
+                    assert np.array_equal(u.view(np.uint32), v.view(np.uint32)), f"{tag}: get_output({name})"
+            if a[4] is not None:
+                assert np.array_equal(a[4].view(np.uint32), b[4].view(np.uint32)), tag + ": delta w.r.t. the input"
+
+
+def test_full_batch_train_steps_with_chain_kernels_vs_oracle(T, lib_option):
+    """BASELINE configs[1] at its own batch (256: one sample per compute unit, the chain kernels' design point) through the C++ classes
+    with both chains switched on (they are opt-in: DESIGN.md section 4.27), three steps, against the CPU oracle: the loss and the
+    parameters after SGD within 1e-4"""
+    from cnn_amd import hostapi
+    from tests.util import REL_TOL
+
+    lib_option("CHAIN_FWD_N", "3")
+    lib_option("CHAIN_BWD_N", "3")
+    B = 256
+    x = uniform01(4400, (B, 3, 224, 224))
+    labels = (np.arange(B) % 3).astype(np.int32)
+    onet = O.Net(B, 3)
+    p0 = normal_scaled(4401, (onet.n_params,))
+    onet.params[:] = p0
+    net = hostapi.HostAlexNet(3)
+    net.set_params(p0)
+    xd, ld = dev(T, x), dev(T, labels)
+    for step in range(3):
+        net.train_step(xd, ld, 1e-3)
+        oloss, _ = onet.train_step(x, labels, 1e-3)
+        loss = net.last_loss()
+        assert abs(loss - oloss) <= 1e-4 * max(1.0, abs(oloss)), (step, loss, oloss)
+        assert_close(net.get_params(), onet.params, REL_TOL, f"B=256 chain step {step}: parameters after SGD")
+    assert hostapi.load().cnnh_net_chain_layers(net.h, 1) == 3 and hostapi.load().cnnh_net_chain_layers(net.h, 0) == 3  # the chains DID run
+    net.close()
