@@ -123,6 +123,12 @@ SIGNATURES = {
     "cnn_comm_group_start": (C.c_int, []),
     "cnn_comm_group_end": (C.c_int, []),
     "cnn_allreduce_grads": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "cnn_comm_split": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "cnn_comm_broadcast": (C.c_int, [_P, _P, C.c_size_t, C.c_int, _P]),
+    "cnn_conv2d_autotune_workspace_bytes": (C.c_size_t, [_D]),
+    "cnn_conv2d_autotune_ws": (C.c_int, [_D, _P, C.c_size_t, _P]),
+    "cnn_conv2d_tune_export": (C.c_int, [_D, C.POINTER(C.c_int32)]),
+    "cnn_conv2d_tune_import": (C.c_int, [_D, C.POINTER(C.c_int32)]),
     "cnn_softmax_xent": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "cnn_linear_forward_softmax_xent": (C.c_int, [_P] * 8 + [C.c_int] * 3 + [_P]),
     "cnn_loss_from_terms": (C.c_int, [_P, _P, C.c_int, _P]),

@@ -27,6 +27,8 @@ struct Rccl {
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, ncclConfig_t*) = nullptr;  // (optional: RCCL >= 2.18)
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*GetVersion)(int*) = nullptr;
@@ -65,6 +67,8 @@ Rccl* rccl() {
         r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
         r.CommUserRank = (decltype(r.CommUserRank))sym("ncclCommUserRank");
         r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+        r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
+        r.CommSplit = (decltype(r.CommSplit))dlsym(r.handle, "ncclCommSplit");  // may be absent: cnn_comm_split then reports it
         r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
         r.GetVersion = (decltype(r.GetVersion))sym("ncclGetVersion");
@@ -155,6 +159,30 @@ int cnn_comm_group_start(void) {
 int cnn_comm_group_end(void) {
     CNN_RCCL_BIND(R);
     CNN_RCCL_CHECK(R, R->GroupEnd());
+    return CNN_AMD_OK;
+}
+
+// a second communicator over the same ranks (ncclCommSplit: every rank of `comm` calls it with the same color; key orders the ranks):
+// collectives on different communicators are independent queues -- the small sync-BN reductions of BatchNorm2D (batchnorm2d.cpp:46-61,
+// 129-147 couple the samples of the WHOLE batch) do not serialise behind the bucketed gradient exchange that uses `comm`
+int cnn_comm_split(void* comm, int color, int key, void** new_comm) {
+    CNN_REQUIRE(comm != nullptr && new_comm != nullptr, "cnn_comm_split: null pointer");
+    CNN_RCCL_BIND(R);
+    if (R->CommSplit == nullptr) return fail(CNN_AMD_E_COMM, "cnn_comm_split: this librccl has no ncclCommSplit");
+    ncclComm_t c = nullptr;
+    CNN_RCCL_CHECK(R, R->CommSplit(static_cast<ncclComm_t>(comm), color, key, &c, nullptr));
+    *new_comm = c;
+    return CNN_AMD_OK;
+}
+
+// `bytes` bytes at `buf` (device) of rank `root` to every rank, in place, enqueued on `stream` (e.g. rank 0's measured kernel choices:
+// cnn_conv2d_tune_export / _import)
+int cnn_comm_broadcast(void* comm, void* buf, size_t bytes, int root, void* stream) {
+    CNN_REQUIRE(comm != nullptr && buf != nullptr && root >= 0, "cnn_comm_broadcast: bad arguments");
+    if (bytes == 0) return CNN_AMD_OK;
+    CNN_RCCL_BIND(R);
+    CNN_RCCL_CHECK(R, R->Broadcast(buf, buf, bytes, ncclChar, root, static_cast<ncclComm_t>(comm), as_stream(stream)));
+    publish_mark_stale(as_stream(stream));
     return CNN_AMD_OK;
 }
 

@@ -1522,7 +1522,45 @@ static int conv2d_backward_data_impl(const char* who, const cnn_conv2d_desc* d, 
     return run_plan(pl, d, dy, w, nullptr, dx, const_cast<float*>(relu_below), ws, ws_bytes, as_stream(stream), who, prepared);
 }
 
-int cnn_conv2d_autotune(const cnn_conv2d_desc* d, void* stream) {
+// floats of scratch one measurement needs: x, y, w, the implicit GEMM's workspace / prepared image, bias + per-channel scratch
+static size_t autotune_scratch_floats(const cnn_conv2d_desc* d, size_t* nx, size_t* ny, size_t* nw, size_t* na) {
+    const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
+    *nx = ((size_t)d->B * d->Ci * d->H * d->W + 63) / 64 * 64;
+    *ny = ((size_t)d->B * d->Co * Ho * Wo + 63) / 64 * 64;
+    *nw = ((size_t)d->Co * d->Ci * d->k * d->k + 63) / 64 * 64;
+    *na = (igemm_workspace_floats(d) + 64 + 63) / 64 * 64;
+    return *nx + *ny + *nw + *na + ((size_t)(d->Co + d->Ci) + 63) / 64 * 64;
+}
+
+// does cnn_conv2d_autotune measure anything for this geometry in this mode (the specialised kernels keep their layers; a geometry is
+// measured once per process)?
+static bool autotune_applies(const cnn_conv2d_desc* d, int mode) {
+    if (direct_conv_supported(d)) return false;
+    const bool rd_fwd = mode == MODE_FWD && fwd_rd_supported(d);
+    const bool rd_dgrad = mode == MODE_DGRAD && dgrad_rd_supported(d);
+    if (rd_fwd && fwd_rd_small(d)) return false;
+    if (mode == MODE_FWD && !rd_fwd && stem_fwd_supported(d)) return false;
+    if (rd_dgrad && d->s != 1) return false;
+    if (mode == MODE_DGRAD && !rd_dgrad && (pk_dgrad_s2_supported(d) || thin_dgrad_supported(d))) return false;
+    std::lock_guard<std::mutex> lk(tune_mutex());
+    return tune_table().count(tune_key(d, mode)) == 0;
+}
+static bool autotune_enabled() {
+    if (const OptVal e = CNN_OPT_VAL("IGEMM_AUTOTUNE"))
+        if (atoi(e) == 0) return false;
+    return !CNN_OPT_SET("IGEMM_CFG");
+}
+
+// 0: nothing to measure for this geometry (cnn_conv2d_autotune_ws then needs no scratch and returns at once)
+size_t cnn_conv2d_autotune_workspace_bytes(const cnn_conv2d_desc* d) {
+    if (check_desc("cnn_conv2d_autotune_workspace_bytes", d)) return 0;
+    if (!autotune_enabled() || (!autotune_applies(d, MODE_FWD) && !autotune_applies(d, MODE_DGRAD))) return 0;
+    size_t nx, ny, nw, na;
+    return autotune_scratch_floats(d, &nx, &ny, &nw, &na) * sizeof(float);
+}
+
+// scratch == NULL: buffers of the library's own for the duration of the call (the older entry point, cnn_conv2d_autotune)
+static int autotune_impl(const cnn_conv2d_desc* d, void* scratch, size_t scratch_bytes, void* stream) {
     if (int rc = check_desc("cnn_conv2d_autotune", d)) return rc;
     if (const OptVal e = CNN_OPT_VAL("IGEMM_AUTOTUNE"))
         if (atoi(e) == 0) return CNN_AMD_OK;
@@ -1543,19 +1581,24 @@ int cnn_conv2d_autotune(const cnn_conv2d_desc* d, void* stream) {
             std::lock_guard<std::mutex> lk(tune_mutex());
             if (tune_table().count(tune_key(d, mode))) continue;
         }
-        const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
-        const size_t nx = (size_t)d->B * d->Ci * d->H * d->W, ny = (size_t)d->B * d->Co * Ho * Wo, nw = (size_t)d->Co * d->Ci * d->k * d->k;
-        const size_t na = igemm_workspace_floats(d) + 64;
+        size_t nx, ny, nw, na;
+        const size_t total = autotune_scratch_floats(d, &nx, &ny, &nw, &na);
         float *bx = nullptr, *by = nullptr, *bw = nullptr, *ba = nullptr, *bb = nullptr;
+        float* own = nullptr;
         auto release = [&]() {
-            (void)hipFree(bx); (void)hipFree(by); (void)hipFree(bw); (void)hipFree(ba); (void)hipFree(bb);
+            if (own) (void)hipFree(own);
         };
-        if (hipMalloc(&bx, nx * 4) != hipSuccess || hipMalloc(&by, ny * 4) != hipSuccess || hipMalloc(&bw, nw * 4) != hipSuccess ||
-            hipMalloc(&ba, na * 4) != hipSuccess || hipMalloc(&bb, (size_t)(d->Co + d->Ci) * 4) != hipSuccess) {
-            (void)hipGetLastError();
-            release();
-            return CNN_AMD_OK;  // no room to measure: keep the rule-based choice
+        if (scratch != nullptr) {
+            CNN_REQUIRE(scratch_bytes >= total * sizeof(float), "cnn_conv2d_autotune_ws: scratch %zu B < %zu B", scratch_bytes, total * sizeof(float));
+            bx = (float*)scratch;
+        } else {
+            if (hipMalloc(&own, total * sizeof(float)) != hipSuccess) {
+                (void)hipGetLastError();
+                return CNN_AMD_OK;  // no room to measure: keep the rule-based choice
+            }
+            bx = own;
         }
+        by = bx + nx; bw = by + ny; ba = bw + nw; bb = ba + na;
         // (zeros: MFMA / LDS / DMA timing does not depend on the values)
         (void)hipMemsetAsync(bx, 0, nx * 4, s); (void)hipMemsetAsync(by, 0, ny * 4, s); (void)hipMemsetAsync(bw, 0, nw * 4, s);
         (void)hipMemsetAsync(bb, 0, (size_t)(d->Co + d->Ci) * 4, s);
@@ -1624,6 +1667,44 @@ int cnn_conv2d_autotune(const cnn_conv2d_desc* d, void* stream) {
             std::lock_guard<std::mutex> lk(tune_mutex());
             tune_table()[tune_key(d, mode)] = -1;  // measured: the default stays
         }
+    }
+    return CNN_AMD_OK;
+}
+
+int cnn_conv2d_autotune(const cnn_conv2d_desc* d, void* stream) { return autotune_impl(d, nullptr, 0, stream); }
+
+int cnn_conv2d_autotune_ws(const cnn_conv2d_desc* d, void* scratch, size_t scratch_bytes, void* stream) {
+    if (int rc = check_desc("cnn_conv2d_autotune_ws", d)) return rc;
+    if (cnn_conv2d_autotune_workspace_bytes(d) == 0) return CNN_AMD_OK;  // (nothing to measure)
+    CNN_REQUIRE(scratch != nullptr, "cnn_conv2d_autotune_ws: null scratch");
+    return autotune_impl(d, scratch, scratch_bytes, stream);
+}
+
+// what cnn_conv2d_autotune pinned for this geometry, as four integers a caller can ship to other processes:
+// [0] forward tile, [1] data-gradient tile (-1: the rule-based default was measured best; CNN_TUNE_NONE: never measured),
+// [2] / [3] the implicit GEMM replaces the register-direct forward / data-gradient kernel (0 / 1; CNN_TUNE_NONE: never measured)
+int cnn_conv2d_tune_export(const cnn_conv2d_desc* d, int32_t out[4]) {
+    if (int rc = check_desc("cnn_conv2d_tune_export", d)) return rc;
+    CNN_REQUIRE(out != nullptr, "cnn_conv2d_tune_export: null pointer");
+    std::lock_guard<std::mutex> lk(tune_mutex());
+    for (int mode = 0; mode < 2; ++mode) {
+        const auto t = tune_table().find(tune_key(d, mode));
+        out[mode] = t == tune_table().end() ? CNN_TUNE_NONE : t->second;
+        const auto p = prefer_table().find(tune_key(d, mode));
+        out[2 + mode] = p == prefer_table().end() ? CNN_TUNE_NONE : (p->second ? 1 : 0);
+    }
+    return CNN_AMD_OK;
+}
+
+// pins another process' choices for this geometry (replicas of a data-parallel job then run the same kernels: bit-identical local
+// arithmetic on every rank); entries equal to CNN_TUNE_NONE leave the table alone.  Call it where cnn_conv2d_autotune would be called.
+int cnn_conv2d_tune_import(const cnn_conv2d_desc* d, const int32_t in[4]) {
+    if (int rc = check_desc("cnn_conv2d_tune_import", d)) return rc;
+    CNN_REQUIRE(in != nullptr, "cnn_conv2d_tune_import: null pointer");
+    std::lock_guard<std::mutex> lk(tune_mutex());
+    for (int mode = 0; mode < 2; ++mode) {
+        if (in[mode] != CNN_TUNE_NONE) tune_table()[tune_key(d, mode)] = in[mode];
+        if (in[2 + mode] != CNN_TUNE_NONE) prefer_table()[tune_key(d, mode)] = in[2 + mode] != 0;
     }
     return CNN_AMD_OK;
 }

@@ -122,6 +122,10 @@ private:
     void* workspace = nullptr;
     size_t workspace_bytes = 0;
     void ensure_workspace(int B, int H, int W);
+    // data parallelism (Sequential::set_comm): rank 0 measures the implicit-GEMM tile of this geometry, every replica pins ITS choice
+    void* comm = nullptr;
+    int comm_world = 1, comm_rank = 0;
+    void tune_geometry(const cnn_conv2d_desc& d0);
     data_type* w_dev() const { return params; }
     data_type* b_dev() const { return params + (size_t)out_channels * params_for_one_kernel; }
 
@@ -137,6 +141,7 @@ public:
     void load_weights(std::ifstream& reader) override;
     int get_params_num() const;
     void set_fused_relu(ReLU* relu) { fused_relu = relu; }  // addition (see architectures::fuse_layers)
+    void set_comm(void* rccl_comm, int world, int rank) { comm = rccl_comm; comm_world = world; comm_rank = rank; }
     void set_fused_pool(MaxPool2D* pool) { fused_pool = pool; }
     void set_relu_below(ReLU* relu) { relu_below = relu; }
     void set_pool_below(MaxPool2D* pool) { pool_below = pool; }
@@ -406,6 +411,7 @@ protected:
     bool filters_prepared = false;  // the layers' prepared filters match the current parameters
     void* comm = nullptr;           // RCCL communicator (cnn_comm_*), not owned
     int comm_world = 1;
+    void* bn_comm = nullptr;        // a second communicator over the same ranks for BatchNorm2D's sync-BN reductions (owned; cnn_comm_split)
     void* comm_stream = nullptr;    // the exchange runs on its own stream, gated by events
     void* ev_grads = nullptr;
     void* ev_prep = nullptr;   // filter images of layers 2.. prepared on the library's side stream (prepare_filters)

@@ -160,6 +160,32 @@ void Conv2D::ensure_workspace(int B, int H, int W) {
     }
 }
 
+// cnn_conv2d_autotune for a geometry this layer sees for the first time -- with the CALLER's scratch (include/cnn_amd.h: "no allocation
+// inside"), freed again right away; inside a data-parallel container only rank 0 measures and every replica pins rank 0's choice, so that
+// all of them run the same kernels (the measurement is not reproducible from box to box)
+void Conv2D::tune_geometry(const cnn_conv2d_desc& d0) {
+    const bool shared = comm != nullptr && comm_world > 1;
+    if (!shared || comm_rank == 0) {
+        const size_t need = cnn_conv2d_autotune_workspace_bytes(&d0);
+        void* scratch = nullptr;
+        if (need > 0 && cnn_device_alloc(&scratch, need) == CNN_AMD_OK) {  // (no room to measure: the rule-based tiles stay)
+            must(cnn_conv2d_autotune_ws(&d0, scratch, need, stream), "cnn_conv2d_autotune_ws");
+            must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+            cnn_device_free(scratch);
+        }
+    }
+    if (!shared) return;
+    int32_t choice[4] = {CNN_TUNE_NONE, CNN_TUNE_NONE, CNN_TUNE_NONE, CNN_TUNE_NONE};
+    if (comm_rank == 0) must(cnn_conv2d_tune_export(&d0, choice), "cnn_conv2d_tune_export");
+    void* dev = dev_alloc(sizeof(choice));
+    must(cnn_memcpy_h2d(dev, choice, sizeof(choice), stream), "cnn_memcpy_h2d");
+    must(cnn_comm_broadcast(comm, dev, sizeof(choice), 0, stream), "cnn_comm_broadcast");
+    must(cnn_memcpy_d2h(choice, dev, sizeof(choice), stream), "cnn_memcpy_d2h");
+    must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");
+    cnn_device_free(dev);
+    if (comm_rank != 0) must(cnn_conv2d_tune_import(&d0, choice), "cnn_conv2d_tune_import");
+}
+
 std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
     Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
     const int B = (int)input.size();
@@ -173,7 +199,7 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
         // the shape is known now: let the library measure which tile its implicit-GEMM kernels should use for it (once per
         // geometry and process, before any filter preparation)
         cnn_conv2d_desc d0{B, in_channels, H, W, out_channels, kernel_size, stride, padding, 0};
-        must(cnn_conv2d_autotune(&d0, stream), "cnn_conv2d_autotune");
+        tune_geometry(d0);
     }
     assert(B <= batch && "batch larger than the first forward's (conv2d.cpp:47 has the same restriction)");
     // shape-static like the reference (conv2d.cpp:47-60 caches its offsets on the first call): the buffers and the prepared

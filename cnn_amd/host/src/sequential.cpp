@@ -292,6 +292,7 @@ Sequential::~Sequential() {
     }
     if (loss_terms) cnn_device_free(loss_terms);
     if (loss_sum) cnn_device_free(loss_sum);
+    if (bn_comm) cnn_comm_destroy(bn_comm);
     if (comm_stream) cnn_stream_destroy(comm_stream);
     if (ev_grads) cnn_event_destroy(ev_grads);
     if (ev_prep) cnn_event_destroy(ev_prep);
@@ -460,8 +461,28 @@ void Sequential::set_comm(void* rccl_comm, int world) {
     assert(world >= 1);
     comm = rccl_comm;
     comm_world = rccl_comm ? world : 1;
-    for (auto& layer : layers_sequence)
-        if (auto* bn = dynamic_cast<BatchNorm2D*>(layer.get())) bn->set_comm(comm, comm_world);
+    int rank = 0;
+    if (comm != nullptr) {
+        int w = 0;
+        must(cnn_comm_info(comm, &w, &rank), "cnn_comm_info");
+        assert(w == world && "Sequential::set_comm: world does not match the communicator");
+    }
+    // BatchNorm2D's sync-BN reductions get a communicator of their own over the same ranks (cnn_comm_split): they are issued on the
+    // compute stream in the middle of the backward walk while buckets of the gradient exchange are in flight on the communication
+    // stream -- two queues instead of one.  A librccl without ncclCommSplit (or CNN_AMD_BN_OWN_COMM=0): they share `comm` as before.
+    if (bn_comm != nullptr) {
+        cnn_comm_destroy(bn_comm);
+        bn_comm = nullptr;
+    }
+    bool has_bn = false;
+    for (auto& layer : layers_sequence) has_bn = has_bn || dynamic_cast<BatchNorm2D*>(layer.get()) != nullptr;
+    char text[8] = {0};
+    const bool own = !(cnn_amd_get_option("BN_OWN_COMM", text, sizeof(text)) == 0 && std::atoi(text) == 0);
+    if (comm != nullptr && has_bn && own && cnn_comm_split(comm, 0, rank, &bn_comm) != CNN_AMD_OK) bn_comm = nullptr;
+    for (auto& layer : layers_sequence) {
+        if (auto* bn = dynamic_cast<BatchNorm2D*>(layer.get())) bn->set_comm(bn_comm ? bn_comm : comm, comm_world);
+        if (auto* conv = dynamic_cast<Conv2D*>(layer.get())) conv->set_comm(comm, comm_world, rank);
+    }
     if (comm && !comm_stream) {
         must(cnn_stream_create(&comm_stream), "cnn_stream_create");
         must(cnn_event_create(&ev_grads), "cnn_event_create");

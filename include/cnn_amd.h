@@ -82,6 +82,19 @@ size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d);
  * filter image depends on the tile); geometries served by the specialised kernels are left alone.  CNN_AMD_IGEMM_AUTOTUNE=0
  * turns it into a no-op.  The host Conv2D layer calls it when it first sees its input shape. */
 int cnn_conv2d_autotune(const cnn_conv2d_desc* d, void* stream);
+/* The same measurement with the CALLER's scratch (the header's "no allocation inside" convention; cnn_conv2d_autotune above is the
+ * older form that borrows device memory of its own for the duration of the call): scratch of cnn_conv2d_autotune_workspace_bytes(d)
+ * bytes (the geometry's input + output + filters + the kernels' workspace).  The host Conv2D layer uses this form. */
+size_t cnn_conv2d_autotune_workspace_bytes(const cnn_conv2d_desc* d);
+int cnn_conv2d_autotune_ws(const cnn_conv2d_desc* d, void* scratch, size_t scratch_bytes, void* stream);
+/* Measured choices are per process; replicas of a data-parallel job should run the SAME kernels (their reduced gradients are identical
+ * either way, their local activations then are too).  export: what this process pinned for the geometry, four integers --
+ * [0] forward tile, [1] data-gradient tile (-1 = the rule-based default measured best), [2] / [3] = 1 when the implicit GEMM replaces
+ * the register-direct forward / data-gradient kernel; CNN_TUNE_NONE = never measured.  import: pins them in another process (entries
+ * equal to CNN_TUNE_NONE leave its table alone).  Ship them with cnn_comm_broadcast; the host container does (Sequential::set_comm). */
+#define CNN_TUNE_NONE (-2147483647 - 1)
+int cnn_conv2d_tune_export(const cnn_conv2d_desc* d, int32_t out[4]);
+int cnn_conv2d_tune_import(const cnn_conv2d_desc* d, const int32_t in[4]);
 
 /* replaces Conv2D::forward's loop nest (conv2d.cpp:69-92): y = bias + valid cross-correlation.
  * Implicit GEMM on v_mfma_f32_32x32x2_f32 / 16x16x4_f32, input rows + filter slabs staged in LDS. */
@@ -393,6 +406,12 @@ int cnn_comm_group_start(void);
 int cnn_comm_group_end(void);
 /* in-place sum of n floats over all ranks of comm, enqueued on `stream` */
 int cnn_allreduce_grads(void* comm, float* grads, size_t n, void* stream);
+/* a second communicator over the same ranks (ncclCommSplit; every rank calls it with the same color, key orders the ranks): collectives
+ * on different communicators are independent queues, so BatchNorm2D's small sync-BN reductions (batchnorm2d.cpp:46-61, 129-147) need not
+ * queue behind the bucketed gradient exchange.  Fails with CNN_AMD_E_COMM when the bound librccl has no ncclCommSplit. */
+int cnn_comm_split(void* comm, int color, int key, void** new_comm);
+/* `bytes` bytes at buf (device) of rank `root` to every rank of comm, in place, enqueued on `stream` */
+int cnn_comm_broadcast(void* comm, void* buf, size_t bytes, int root, void* stream);
 
 /* ---- loss glue : func.cpp:16-73 (caller side of the path; keeps the step on the device) -------------- */
 /* probs = softmax(logits) with the reference's clamped exp and NaN->0; delta = probs - onehot(labels);

@@ -104,6 +104,33 @@ def main():
         assert np.abs(got - ref).max() <= 1e-4 * max(1e-6, np.abs(ref).max()), "sync-BN shard differs from the full-batch oracle"
     if rank == 0:
         print(f"SYNCBN_OK world={world}")
+    # ---- two communicators, the container's issue order (Sequential::set_comm: cnn_comm_split gives BatchNorm2D's sync-BN sums a
+    # communicator of their own; Sequential::backward sends buckets of the gradient arena on the communication stream WHILE the walk
+    # goes on) -- layers back to front: a BatchNorm2D layer reduces its [C][4] sums synchronously on communicator B in the middle of the
+    # walk, finished buckets go out asynchronously on communicator A; nothing on A waits for anything on B or the other way round
+    grp_a, grp_b = dist.new_group(list(range(world))), dist.new_group(list(range(world)))
+    rs = np.random.RandomState(70)
+    layers = [("bn", 5), ("conv", 300000), ("bn", 7), ("conv", 200000), ("bn", 3), ("conv", 50000)]
+    arena = [torch.from_numpy((rs.standard_normal(n).astype(np.float32) * (rank + 1))) for _, n in layers]
+    base = [a.clone() / (rank + 1) for a in arena]
+    total = sum(r + 1 for r in range(world))
+    pending, bucket = [], []
+    for idx in range(len(layers) - 1, -1, -1):
+        kind, n = layers[idx]
+        if kind == "bn":
+            dist.all_reduce(arena[idx], group=grp_b)  # the layer's backward waits for this one (it needs the global sums)
+            assert torch.allclose(arena[idx], base[idx] * total, rtol=1e-6, atol=1e-6)
+        else:
+            bucket.append(idx)
+            if sum(layers[i][1] for i in bucket) >= 250000:  # a full bucket leaves while the walk continues
+                pending += [(i, dist.all_reduce(arena[i], group=grp_a, async_op=True)) for i in bucket]
+                bucket = []
+    pending += [(i, dist.all_reduce(arena[i], group=grp_a, async_op=True)) for i in bucket]
+    for i, work in pending:
+        work.wait()
+        assert torch.allclose(arena[i], base[i] * total, rtol=1e-6, atol=1e-5)
+    if rank == 0:
+        print(f"TWO_COMMS_OK world={world}")
     dist.barrier()
     dist.destroy_process_group()
 

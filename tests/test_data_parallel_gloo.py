@@ -26,6 +26,7 @@ def test_sharded_step_equals_full_batch_step(world):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert f"DP_OK world={world}" in out.stdout
     assert f"SYNCBN_OK world={world}" in out.stdout
+    assert f"TWO_COMMS_OK world={world}" in out.stdout
 
 
 def test_shard_bounds():

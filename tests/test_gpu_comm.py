@@ -272,3 +272,77 @@ def test_side_stream_handle_and_early_reduction_flush(T):
     capi.side_stream_join()
     T.cuda.synchronize()
     assert T.equal(gw, gw_ref) and T.equal(gb, gb_ref) and T.equal(dx, dx_ref)
+
+
+def test_second_communicator_and_broadcast_with_one_rank(T):
+    """cnn_comm_split (the communicator BatchNorm2D's sync-BN reductions get inside a data-parallel container) and cnn_comm_broadcast
+    (ships rank 0's measured kernel choices): with one rank both are identities, but every call goes through RCCL -- the split
+    communicator reports the same world / rank, sums on the two communicators interleave on two streams without ordering each other"""
+    from cnn_amd import capi
+    from cnn_amd.dp import RcclComm
+
+    lib = capi.load()
+    comm = RcclComm(None, 1, 0)
+    second = C.c_void_p()
+    capi.check(lib.cnn_comm_split(comm.handle, 0, 0, C.byref(second)), "cnn_comm_split")
+    w, r = C.c_int(), C.c_int()
+    capi.check(lib.cnn_comm_info(second, C.byref(w), C.byref(r)), "cnn_comm_info")
+    assert (w.value, r.value) == (1, 0) and second.value != comm.handle.value
+    a = T.arange(1 << 20, device="cuda", dtype=T.float32)
+    b = T.arange(4096, device="cuda", dtype=T.float32) * 3
+    ra, rb = a.clone(), b.clone()
+    side = T.cuda.Stream()
+    for _ in range(8):  # a "bucket" on one stream / communicator, a small "sync-BN" sum on the other, issued alternately
+        with T.cuda.stream(side):
+            capi.check(lib.cnn_allreduce_grads(comm.handle, capi._ptr(a), a.numel(), C.c_void_p(side.cuda_stream)), "cnn_allreduce_grads")
+        capi.check(lib.cnn_allreduce_grads(second, capi._ptr(b), b.numel(), capi._stream()), "cnn_allreduce_grads")
+    buf = T.tensor([7, -1, 3, 227], device="cuda", dtype=T.int32)
+    capi.check(lib.cnn_comm_broadcast(comm.handle, capi._ptr(buf), 16, 0, capi._stream()), "cnn_comm_broadcast")
+    T.cuda.synchronize()
+    assert T.equal(a, ra) and T.equal(b, rb) and buf.tolist() == [7, -1, 3, 227]
+    assert lib.cnn_comm_broadcast(None, capi._ptr(buf), 16, 0, None) != 0
+    capi.check(lib.cnn_comm_destroy(second), "cnn_comm_destroy")
+    comm.destroy()
+
+
+def test_measured_tile_choice_travels_between_processes(T):
+    """cnn_conv2d_autotune_ws (scratch from the caller) + cnn_conv2d_tune_export / _import: what a data-parallel container ships from
+    rank 0 to the other replicas so that all of them run the same kernels.  The choice is a table entry per (geometry, mode): exported
+    after measuring, importable under another geometry's key, and a geometry that has been measured asks for no scratch again"""
+    from cnn_amd import capi
+
+    lib = capi.load()
+    d = capi.ConvDesc(2, 24, 20, 20, 40, 3, 1, 1)          # generic: implicit GEMM in both directions
+    first = capi.ConvDesc(2, 3, 224, 224, 16, 3, 2, 0)     # the reference net's first layer: specialised kernels, nothing to measure
+    assert lib.cnn_conv2d_autotune_workspace_bytes(C.byref(first)) == 0
+    capi.check(lib.cnn_conv2d_autotune_ws(C.byref(first), None, 0, capi._stream()), "cnn_conv2d_autotune_ws")  # (a no-op)
+    none = -2**31
+    out = (C.c_int32 * 4)()
+    capi.check(lib.cnn_conv2d_tune_export(C.byref(d), out), "cnn_conv2d_tune_export")
+    need = lib.cnn_conv2d_autotune_workspace_bytes(C.byref(d))
+    if list(out)[:2] == [none, none]:  # (not measured yet in this process)
+        assert need > 4 * (2 * 24 * 400 + 2 * 40 * 400 + 40 * 24 * 9)
+        assert lib.cnn_conv2d_autotune_ws(C.byref(d), None, 0, capi._stream()) != 0  # scratch is the caller's
+        scratch = T.empty(need, dtype=T.uint8, device="cuda")
+        capi.check(lib.cnn_conv2d_autotune_ws(C.byref(d), capi._ptr(scratch), need, capi._stream()), "cnn_conv2d_autotune_ws")
+        T.cuda.synchronize()
+        capi.check(lib.cnn_conv2d_tune_export(C.byref(d), out), "cnn_conv2d_tune_export")
+    assert out[0] != none and out[1] != none
+    assert lib.cnn_conv2d_autotune_workspace_bytes(C.byref(d)) == 0  # measured once per process
+    twin = capi.ConvDesc(3, 24, 20, 20, 40, 3, 1, 1)       # "another replica": same layer, its own table entry
+    got = (C.c_int32 * 4)()
+    capi.check(lib.cnn_conv2d_tune_export(C.byref(twin), got), "cnn_conv2d_tune_export")
+    if list(got)[:2] == [none, none]:
+        capi.check(lib.cnn_conv2d_tune_import(C.byref(twin), out), "cnn_conv2d_tune_import")
+        capi.check(lib.cnn_conv2d_tune_export(C.byref(twin), got), "cnn_conv2d_tune_export")
+        assert list(got) == list(out)
+        assert lib.cnn_conv2d_autotune_workspace_bytes(C.byref(twin)) == 0  # pinned: not measured again
+    # and the pinned tiles compute the same convolution (forward against the im2col fallback)
+    conv = capi.Conv2d(3, 24, 20, 20, 40, 3, 1, 1)
+    x = T.from_numpy(uniform01(97, (3, 24, 20, 20))).cuda()
+    wgt = T.from_numpy(uniform01(98, (40, 24, 3, 3)) - 0.5).cuda()
+    bias = T.from_numpy(uniform01(99, (40,))).cuda()
+    y = conv.forward(x, wgt, bias)
+    ref = conv.forward_im2col(x, wgt, bias)
+    T.cuda.synchronize()
+    assert float((y - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
