@@ -100,6 +100,7 @@ private:
     void* prep_dgrad_alt = nullptr;   // second data-gradient image: a DEFERRED data gradient keeps reading the filters of its own step
     // ---- re-materialisation of an output tensor the pass did not write (fuse_pool_block) ----
     mutable bool out_valid = true;    // out_buf holds the last forward's output
+    bool recompute_lost = false;      // see params_of_last_forward_lost()
     const data_type* last_x = nullptr;  // device pointer of the last forward's input (recorded even under no_grad)
     int last_B = 0;
     const data_type* snapshot = nullptr;   // the container's copy of this layer's parameters BEFORE its latest SGD step ...
@@ -165,6 +166,10 @@ public:
     std::vector<tensor> get_output() const override;
     void materialize() const;  // writes the missing output tensor(s) of the last forward pass now (no-op when present)
     void set_param_snapshot(const data_type* snap, const bool* active) { snapshot = snap; snapshot_active = active; }
+    // the parameters the last forward pass used are gone (written from outside, or stepped twice without a forward pass in between):
+    // an output that pass did not write can no longer be re-computed -- get_output() of it then fails loudly instead of returning a
+    // tensor the pass never produced
+    void params_of_last_forward_lost() { recompute_lost = true; }
     // The pieces of Conv2D::backward a container schedules itself for the pool-fused FIRST block of a network (nothing consumes
     // that layer's data gradient, conv2d.cpp:168-199 / alexnet.cpp:55):
     struct DeferredDgrad {   // everything the data gradient of one pass needs, valid until that pass' buffers are rewritten
@@ -484,6 +489,11 @@ public:
     // re-arranged copies of their filters between update_gradients() calls
     void parameters_changed();
     const std::list<std::shared_ptr<Layer> >& layers() const { return layers_sequence; }
+
+protected:
+    void invalidate_filter_images();  // (the part of parameters_changed() the container's own SGD step needs too)
+
+public:
     // data parallelism over `world` replicas of this container (one per GPU), comm from cnn_comm_init_rank / _init_all:
     // backward() then leaves LOCAL gradients in the arena, update_gradients(lr) all-reduces them (RCCL, fp32 sum, on a
     // communication stream) and applies lr * (1/world) * sum.  Pass comm = nullptr to switch it off again.

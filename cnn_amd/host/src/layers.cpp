@@ -224,6 +224,7 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
     last_x = x;  // (a pointer, not a copy: get_output() of a fused-away tensor re-computes it from here)
     last_B = B;
     out_valid = true;
+    recompute_lost = false;
     cnn_conv2d_desc d{B, in_channels, H, W, out_channels, kernel_size, stride, padding, 0};
     const bool prepared = prepared_active && fuse_layers && B == batch;
     pool_fused_pass = false;
@@ -324,6 +325,12 @@ void Conv2D::materialize() const {
     const bool relu_missing = fused_relu != nullptr && !fused_relu->output_valid();
     if (out_valid && !relu_missing) return;
     assert(last_x != nullptr && "get_output() of a fused-away tensor before any forward pass");
+    if (recompute_lost) {
+        std::fprintf(stderr, "cnn_amd host: %s: get_output() of a tensor the last forward pass did not write, after the parameters that pass used were "
+                             "overwritten (set from outside, or stepped twice): call forward() again, or set architectures::fuse_pool_block = false\n",
+                     name.c_str());
+        std::abort();
+    }
     // the parameters the last forward pass used: the container's snapshot when its SGD step has run since
     const data_type* w = (snapshot != nullptr && snapshot_active != nullptr && *snapshot_active) ? snapshot : params;
     const data_type* b = w + (size_t)out_channels * params_for_one_kernel;
@@ -359,6 +366,7 @@ data_type* Conv2D::chain_forward_begin(const std::vector<tensor>& input, const d
     saved_input_tensors = input;
     last_x = xp;
     last_B = B;
+    recompute_lost = false;
     out_valid = false;  // (the pre-activation tensor is not written: get_output() re-computes it, like the relu-only pass of forward())
     pool_fused_pass = false;
     *x = xp;

@@ -450,11 +450,17 @@ std::vector<uchar> Sequential::grad_cam(const std::string& layer_name, std::vect
     return image;
 }
 
-void Sequential::parameters_changed() {
-    params_stepped = false;    // (an outside write: there is no snapshot of what the last forward pass used)
+void Sequential::invalidate_filter_images() {
     filters_prepared = false;  // re-prepared at the start of the next forward pass
     for (auto& layer : layers_sequence)
         if (auto* c = dynamic_cast<Conv2D*>(layer.get())) c->set_prepared(false);
+}
+
+void Sequential::parameters_changed() {
+    params_stepped = false;    // (an outside write: there is no snapshot of what the last forward pass used)
+    invalidate_filter_images();
+    for (auto& layer : layers_sequence)
+        if (auto* c = dynamic_cast<Conv2D*>(layer.get())) c->params_of_last_forward_lost();
 }
 
 void Sequential::set_comm(void* rccl_comm, int world) {
@@ -527,8 +533,11 @@ void Sequential::update_gradients(const data_type learning_rate) {
 void Sequential::update_gradients(const data_type learning_rate, const data_type grad_scale) {
     assert(finalized && "the grad_scale form works on the flat arena: call finalize()");
     // (the old values go to the snapshot: Conv2D::get_output() of a fused-away tensor re-computes it with them)
+    if (params_stepped)  // a second step without a forward pass in between: the snapshot would now receive already-stepped values
+        for (auto& layer : layers_sequence)
+            if (auto* c = dynamic_cast<Conv2D*>(layer.get())) c->params_of_last_forward_lost();
     must(cnn_sgd_update_keep(param_arena, grad_arena, n_params, learning_rate, grad_scale, param_prev, stream), "cnn_sgd_update_keep");
-    parameters_changed();
+    invalidate_filter_images();
     params_stepped = true;
 }
 

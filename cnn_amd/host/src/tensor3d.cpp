@@ -1,4 +1,5 @@
 // tensor3d.cpp -- Tensor3D helpers (semantics of cpu/src/data_format.cpp:13-158) + device-view plumbing.
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -40,9 +41,12 @@ Tensor3D::~Tensor3D() noexcept {
 }
 
 namespace {
-unsigned long long g_device_epoch = 1;  // (the host classes are single-threaded by construction, like the reference: SURVEY 8b)
+// (the host classes are single-threaded by construction, like the reference: SURVEY 8b -- the counter itself is atomic so that two
+// threads driving two containers do not race on it; a device view's HOST copy is a cache of the device tensor: host-side edits of
+// `data` that were never uploaded are overwritten by the next refresh, see data_format.h)
+std::atomic<unsigned long long> g_device_epoch{1};
 }
-void Tensor3D::device_work_enqueued() { ++g_device_epoch; }
+void Tensor3D::device_work_enqueued() { g_device_epoch.fetch_add(1, std::memory_order_relaxed); }
 
 void Tensor3D::sync_to_host() {
     if (!dev) return;

@@ -7,6 +7,8 @@ import pytest
 
 from tests.util import REL_TOL, assert_close, assert_close_arbitrated, normal_scaled, uniform01
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_host_library_loads_and_exports():
     from cnn_amd import hostapi
@@ -508,3 +510,37 @@ def test_partial_batch_after_fused_steps_orders_the_deferred_data_gradient():
     for u, v in zip(res[0], res[1]):
         assert np.array_equal(np.asarray(u), np.asarray(v))
     assert np.abs(res[0][2][3]).max() > 0
+
+
+@pytest.mark.gpu
+def test_get_output_of_a_fused_away_tensor_fails_loudly_once_its_parameters_are_gone():
+    """a pool-fused pass does not write the first block's Conv2D / ReLU outputs; get_output() re-computes them with the
+    parameters that pass used (the container's snapshot across ITS SGD step).  When those parameters no longer exist -- the arena was
+    written from outside -- the re-computation would silently describe a pass that never happened: the call aborts with a message
+    instead.  After the next forward pass everything is observable again."""
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from cnn_amd import hostapi
+B = 4
+x = torch.rand((B, 3, 224, 224), device='cuda'); labels = (torch.arange(B, device='cuda') %% 3).to(torch.int32)
+net = hostapi.HostAlexNet(3)
+p0 = (np.random.RandomState(5).standard_normal(111267) * 0.1).astype(np.float32)
+net.set_params(p0)
+net.train_step(x, labels, 1e-3); net.train_step(x, labels, 1e-3)
+ok = net.layer_output('conv_layer_1', (B, 16, 111, 111))          # fine: the snapshot holds the parameters of that pass
+net.train_step(x, labels, 1e-3)
+net.set_params(p0)                                                   # outside write: they are gone
+if sys.argv[1] == 'forward_first':
+    net.train_step(x, labels, 1e-3)
+    net.layer_output('conv_layer_1', (B, 16, 111, 111)); print('OBSERVABLE_AGAIN')
+else:
+    net.layer_output('conv_layer_1', (B, 16, 111, 111)); print('NOT_REACHED')
+""" % ROOT
+    bad = subprocess.run([sys.executable, "-c", code, "direct"], capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "NOT_REACHED" not in bad.stdout and "did not write" in bad.stderr, bad.stdout[-500:] + bad.stderr[-1500:]
+    good = subprocess.run([sys.executable, "-c", code, "forward_first"], capture_output=True, text=True, timeout=600)
+    assert good.returncode == 0 and "OBSERVABLE_AGAIN" in good.stdout, good.stdout[-500:] + good.stderr[-1500:]
