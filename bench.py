@@ -56,7 +56,7 @@ def algorithmic_work(key):
             nt = 1 if kernel.endswith(("+poolm", "+poolm8")) else 2    # "+poolm": the ReLU mask rides in the pool mask, the pooled tensor is not read
             return x_b + nt * pd_b + mk_b + w_b, fl       # wgrad: x + (dpool, mask[, pooled]) -> gw ; dgrad: those -> dx
         if kernel.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel", "wgrad_rd", "conv_direct", "conv_dgrad_pk", "conv_fwd_pk",
-                              "conv_wgrad_pk", "conv_wgrad_win", "conv_wgrad_os", "conv_stem", "conv_dgrad_thin", "conv_fwd_rd", "conv_dgrad_rd")):
+                              "conv_wgrad_pk", "conv_wgrad_win", "conv_wgrad_os", "conv_stem", "conv_dgrad_thin", "conv_fwd_rd", "conv_dgrad_rd", "conv_1x1")):
             fused = y_b if (kernel.endswith("/fwd+relu") or ",relu" in kernel or kernel.endswith(">+relu")) else 0.0  # second output tensor
             if "dgrad" in kernel and kernel.endswith("+relu"):
                 fused = x_b  # fused ReLU::backward: the mask tensor (shape of dx) is read

@@ -1450,6 +1450,9 @@ bool stem_fwd_supported(const cnn_conv2d_desc* d);     // conv_stem.hip: Ci = 3,
 int stem_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, float* y_relu, hipStream_t s);
 bool thin_dgrad_supported(const cnn_conv2d_desc* d);   // conv_dgrad_thin.hip: VALU data gradient of thin (Ci = 3) stride-1 layers
 int thin_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* relu_below, float* dx, hipStream_t s);
+bool c11_supported(const cnn_conv2d_desc* d);          // conv_1x1.hip: 1x1 convolutions (stride 1 / 2) as plain LDS-tiled GEMMs
+int c11_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, float* y_relu, hipStream_t s);
+int c11_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* relu_below, float* dx, hipStream_t s);
 bool pk_dgrad_s2_supported(const cnn_conv2d_desc* d);  // conv_direct.hip: packed VALU dgrad for small stride-2 layers
 size_t pk_dgrad_s2_workspace_floats(const cnn_conv2d_desc* d);
 int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, hipStream_t s, bool prepared,
@@ -1475,6 +1478,7 @@ size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
             if (rc == CNN_AMD_OK && pl.a_floats > n) n = pl.a_floats;
         }
     if (direct_conv_supported(d) && n < 1024) n = 1024;  // packed filter copies of the direct kernels (conv_direct.hip)
+    if (c11_supported(d) && n < (size_t)d->Co * d->Ci) n = (size_t)d->Co * d->Ci;  // (conv_1x1.hip: the prepared image is a verbatim copy)
     if (pk_dgrad_s2_supported(d) && n < pk_dgrad_s2_workspace_floats(d)) n = pk_dgrad_s2_workspace_floats(d);
     if (fwd_rd_prepared_floats(d) > n) n = fwd_rd_prepared_floats(d);
     if (dgrad_rd_prepared_floats(d) > n) n = dgrad_rd_prepared_floats(d);
@@ -1489,8 +1493,10 @@ static int conv2d_forward_impl(const char* who, const cnn_conv2d_desc* d, const 
                                float* y, float* y_relu, void* ws, size_t ws_bytes, void* stream, bool prepared = false) {
     if (int rc = check_desc(who, d)) return rc;
     // y may be NULL when only the ReLU output is wanted and the layer runs on the register-direct forward kernel
-    CNN_REQUIRE(x && (w || prepared) && bias && (y || (y_relu && fwd_rd_supported(d))), "%s: null pointer", who);
+    CNN_REQUIRE(x && (w || prepared) && bias && (y || (y_relu && (fwd_rd_supported(d) || c11_supported(d)))), "%s: null pointer", who);
     if (direct_conv_supported(d)) return direct_conv_forward(d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream), prepared);
+    if (c11_supported(d))  // (its "prepared" image is a verbatim copy of w)
+        return c11_forward(d, x, prepared ? (const float*)ws : w, bias, y, y_relu, as_stream(stream));
     if (fwd_rd_supported(d))
         return fwd_rd_forward(d, x, prepared ? nullptr : w, prepared ? (const float*)ws : nullptr, bias, y, y_relu, as_stream(stream));
     if (stem_fwd_supported(d) && (y || y_relu))  // (its "prepared" image is a verbatim copy of w)
@@ -1510,6 +1516,8 @@ static int conv2d_backward_data_impl(const char* who, const cnn_conv2d_desc* d, 
         if (rc || !relu_below) return rc;
         return cnn_relu_backward(relu_below, dx, (size_t)d->B * d->Ci * d->H * d->W, stream);
     }
+    if (c11_supported(d))  // (its "prepared" image is a verbatim copy of w)
+        return c11_backward_data(d, dy, prepared ? (const float*)ws : w, relu_below, dx, as_stream(stream));
     if (thin_dgrad_supported(d))  // (its "prepared" image is a verbatim copy of w)
         return thin_dgrad(d, dy, prepared ? (const float*)ws : w, relu_below, dx, as_stream(stream));
     if (dgrad_rd_supported(d))
@@ -1535,7 +1543,7 @@ static size_t autotune_scratch_floats(const cnn_conv2d_desc* d, size_t* nx, size
 // does cnn_conv2d_autotune measure anything for this geometry in this mode (the specialised kernels keep their layers; a geometry is
 // measured once per process)?
 static bool autotune_applies(const cnn_conv2d_desc* d, int mode) {
-    if (direct_conv_supported(d)) return false;
+    if (direct_conv_supported(d) || c11_supported(d)) return false;
     const bool rd_fwd = mode == MODE_FWD && fwd_rd_supported(d);
     const bool rd_dgrad = mode == MODE_DGRAD && dgrad_rd_supported(d);
     if (rd_fwd && fwd_rd_small(d)) return false;
@@ -1568,7 +1576,7 @@ static int autotune_impl(const cnn_conv2d_desc* d, void* scratch, size_t scratch
     hipStream_t s = as_stream(stream);
     for (int mode = 0; mode < 2; ++mode) {
         // geometries that never reach the implicit GEMM in this mode
-        if (direct_conv_supported(d)) continue;
+        if (direct_conv_supported(d) || c11_supported(d)) continue;
         // register-direct kernels for BIG layers (stride-1 / stride-2 3x3, pad 0, Ci <= 64; stride-1 data gradient) are measured
         // against the implicit GEMM below; the small-layer kernels, the first-layer kernels and the stem keep their layers
         const bool rd_fwd = mode == MODE_FWD && fwd_rd_supported(d);
@@ -1727,7 +1735,7 @@ int cnn_conv2d_backward_data(const cnn_conv2d_desc* d, const float* dy, const fl
 
 int cnn_conv2d_relu_only_supported(const cnn_conv2d_desc* d) {
     if (check_desc("cnn_conv2d_relu_only_supported", d)) return 0;
-    return (!direct_conv_supported(d) && fwd_rd_supported(d)) ? 1 : 0;
+    return (!direct_conv_supported(d) && (fwd_rd_supported(d) || c11_supported(d))) ? 1 : 0;
 }
 
 /* ---- Conv2D -> ReLU -> MaxPool2D(2,2) ---- */
@@ -1802,6 +1810,11 @@ int cnn_conv2d_prepare_filters(int n, const cnn_conv2d_desc* descs, const float*
         for (int mode = 0; mode < 2; ++mode) {
             void* out = mode == MODE_FWD ? (fwd ? fwd[i] : nullptr) : (dgrad ? dgrad[i] : nullptr);
             if (!out || ((mode == MODE_FWD ? fdone : ddone) >> i & 1u)) continue;
+            if (!direct_conv_supported(&descs[i]) && c11_supported(&descs[i])) {
+                // conv_1x1.hip reads the reference layout in both directions: its prepared images are verbatim copies
+                CNN_HIP_CHECK(hipMemcpyAsync(out, w[i], sizeof(float) * (size_t)descs[i].Co * descs[i].Ci, hipMemcpyDeviceToDevice, s));
+                continue;
+            }
             if (mode == MODE_FWD && !direct_conv_supported(&descs[i]) && !fwd_rd_supported(&descs[i]) && stem_fwd_supported(&descs[i])) {
                 // conv_stem.hip reads the reference layout: its prepared image is a verbatim copy
                 CNN_HIP_CHECK(hipMemcpyAsync(out, w[i], sizeof(float) * (size_t)descs[i].Co * descs[i].Ci * descs[i].k * descs[i].k,

@@ -26,6 +26,8 @@ int direct_first_layer_finish(const cnn_conv2d_desc* d, const float* slabs, int 
 int stem_wgrad_slots(const cnn_conv2d_desc* d);  // conv_stem.hip: 3 -> Co, 7x7, stride 2, pad 3
 int os_wgrad_slots(const cnn_conv2d_desc* d);    // conv_wgrad_os.hip: the reference net's small 3x3 / stride-2 layers, output-stationary
 int os_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
+int c11_wgrad_slots(const cnn_conv2d_desc* d);   // conv_1x1.hip: 1x1 convolutions (stride 1 / 2): split-K GEMM over the sub-sampled plane
+int c11_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
 int stem_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
 int wgrad_rd_slots(const cnn_conv2d_desc* d);  // conv_wgrad_rd.hip: register-direct MFMA kernel (3x3, stride 1/2, pad 0)
 int wgrad_rd_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
@@ -775,6 +777,9 @@ size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d) {
     const int oss = os_wgrad_slots(d);
     const size_t osw = oss ? (size_t)(oss + (oss + 63) / 64) * d->Co * (d->Ci * 9 + 1) : 0;
     if (osw > m) m = osw;
+    const int c1s = c11_wgrad_slots(d);
+    const size_t c1w = c1s ? (size_t)(c1s + (c1s + 63) / 64) * d->Co * (d->Ci + 1) : 0;
+    if (c1w > m) m = c1w;
     memo.put(d, (m + 64) * sizeof(float));
     return (m + 64) * sizeof(float);
 }
@@ -859,6 +864,16 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
             float gb_dummy_unused = 0.f;
             (void)gb_dummy_unused;
             return reduce_slabs(sd, (const float*)ws, ds, n, (float*)ws + (size_t)ds * n, gw, divisor, tagd, 27, gb);
+        }
+    }
+    if (const int c1s = c11_wgrad_slots(d)) {
+        const size_t n = (size_t)d->Co * (d->Ci + 1), need_c = (size_t)(c1s + (c1s + 63) / 64) * n * sizeof(float);
+        if (ws_bytes >= need_c) {
+            hipStream_t sc = as_stream(stream);
+            if (int rc = c11_wgrad_launch(d, x, dy, (float*)ws, sc)) return rc;
+            char tagc[160];
+            snprintf(tagc, sizeof(tagc), CONV_TAG(d));
+            return reduce_slabs(sc, (const float*)ws, c1s, n, (float*)ws + (size_t)c1s * n, gw, divisor, tagc, d->Ci, gb);
         }
     }
     if (const int oss = os_wgrad_slots(d)) {

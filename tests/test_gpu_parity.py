@@ -67,6 +67,10 @@ CONV_CASES = [
     (2, 3, 9, 5, 7, 3, 1, 0),        # ... without padding, image smaller than one patch
     (2, 32, 28, 30, 64, 3, 2, 0),    # stride-2 register-direct data gradient on even sizes (last input row / column uncovered)
     (1, 96, 9, 12, 128, 3, 2, 0),    # ... three 32-channel groups, tiny image
+    (2, 128, 28, 28, 256, 1, 2, 0),  # conv_1x1.hip: the ResNet-shaped stack's downsample layer (1x1 stride 2) at a small batch
+    (3, 32, 9, 11, 48, 1, 2, 0),     # ... odd sizes (last row / column off the sampled grid stay 0), Co below one row block, one K chunk
+    (2, 64, 7, 7, 32, 1, 1, 0),      # ... stride 1 (no zero fill), two K chunks
+    (2, 160, 10, 9, 144, 1, 2, 0),   # ... ragged everywhere: two ci blocks (128 + 32), two co blocks (128 + 16), five K chunks
 ]
 
 
