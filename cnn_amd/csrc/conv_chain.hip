@@ -138,6 +138,93 @@ __device__ __forceinline__ void chain_fwd_phase(const float* __restrict__ xi, co
     }
 }
 
+// ---- the same phase with the filter slice held in HALVES (lean chain: <= 168 VGPRs per wave, see chain_fwd_kernel) -------------------
+// MS = 1; a wave keeps the two partial sums of ALL its pixel groups (at most GMAX) in registers and walks them twice: first with
+// the filter values of channels [0, CI/2), then with those of [CI/2, CI).  Every accumulator still receives its MFMA steps in the order
+// of chain_fwd_phase (step (c4, tap) feeds partial sum (9 c4 + tap) mod 2, c4 ascending): bit-identical.
+template <int CI, int GMAX>
+__device__ __forceinline__ void chain_fwd_phase_split(const float* __restrict__ xi, const float* __restrict__ img, const float* __restrict__ bias,
+                                                      float* __restrict__ yi, int H, int W, int Co, int Ho, int Wo, unsigned m_wo, int wave,
+                                                      int lane) {
+    constexpr int C4 = CI / 4, NA = C4 * 9, HC4 = C4 / 2, HNA = HC4 * 9, NB = 4;
+    static_assert(HC4 % NB == 0, "static ring indices");
+    const int n = lane & 15, k = lane >> 4;
+    const int slices = Co >> 4;
+    const int parts = kChainWaves / slices;
+    const int slice = wave % slices, part = wave / slices;
+    const int HoWo = Ho * Wo;
+    const int groups = (HoWo + 15) >> 4;
+    if (part >= parts || part >= groups) return;
+    const int mine = (groups - part + parts - 1) / parts;  // pixel groups of this wave: part, part + parts, ... (<= GMAX, checked by the host)
+    const unsigned plane = (unsigned)(H * W);
+    unsigned xoff[GMAX], yoff[GMAX];
+    bool live[GMAX];
+#pragma unroll
+    for (int j = 0; j < GMAX; ++j) {
+        const int g = part + j * parts;
+        const int pi = g * 16 + n;
+        live[j] = j < mine && pi < HoWo;
+        const int pic = live[j] ? pi : HoWo - 1;
+        const int pr = fdivm(pic, m_wo, Wo), q = pic - pr * Wo;
+        xoff[j] = (unsigned)(k * (int)plane + (2 * pr) * W + 2 * q);
+        yoff[j] = (unsigned)((16 * slice + 4 * k) * HoWo + pic);
+    }
+    f32x4 acc[GMAX][2];
+#pragma unroll
+    for (int j = 0; j < GMAX; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][0][r] = bias[16 * slice + 4 * k + r];
+        acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto load_g = [&](f3u(&buf)[3], int c4, unsigned xo) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float* base = xi + ((size_t)(c4 * 4) * plane + (size_t)kx * W);  // wave-uniform
+            buf[kx] = *(const f3u*)(base + xo);
+        }
+    };
+    static_assert((HC4 * 9) % 2 == 0, "the partial sum a step feeds must not depend on the half");
+#pragma nounroll
+    for (int h = 0; h < 2; ++h) {  // (a real loop: unrolled, hipcc fetches the second half's 72 filter values early and spills)
+        float wa[HNA];
+#pragma unroll
+        for (int j = 0; j < HNA; ++j) wa[j] = img[(slice * NA + h * HNA + j) * 64 + lane];
+        f3u xb[NB][3];
+#pragma unroll
+        for (int i = 0; i < NB - 1; ++i) load_g(xb[i], h * HC4 + i, xoff[0]);
+#pragma unroll
+        for (int j = 0; j < GMAX; ++j) {
+            if (j < mine) {  // (wave-uniform)
+                const unsigned nxo = xoff[j + 1 < GMAX ? j + 1 : j];  // (behind the last group: a harmless re-read)
+#pragma unroll
+                for (int c = 0; c < HC4; ++c) {
+                    const int gn = c + NB - 1;
+                    load_g(xb[gn % NB], h * HC4 + gn % HC4, gn < HC4 ? xoff[j] : nxo);
+                    CH_PIPE_FENCE(xb[c % NB][0].x);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {
+                        const f3u v = xb[c % NB][i / 3];
+                        const float bv = i % 3 == 0 ? v.x : i % 3 == 1 ? v.y : v.z;
+                        const int a = (c * 9 + i) % 2;
+                        acc[j][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c * 9 + i], bv, acc[j][a], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < GMAX; ++j) {
+        if (live[j]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[j][0][r] + acc[j][1][r];
+                yi[(size_t)yoff[j] + (size_t)r * HoWo] = v >= 0.f ? v : 0.f;  // relu.cpp:21-26
+            }
+        }
+    }
+}
+
 // func.cpp:6-12
 __device__ __forceinline__ float clamped_exp_c(float v) {
     if (v >= 88.f) return FLT_MAX;
@@ -158,39 +245,43 @@ struct HeadShared {
     float logit[8];
     float dl[8];
 };
+template <bool LEAN = false>  // LEAN: half as many loads in flight, nothing kept in registers for the dx pass (x and W are read again)
 __device__ __forceinline__ void chain_head_phase(const float* __restrict__ xb, const float* __restrict__ w, const float* __restrict__ bias,
                                                  const int32_t* __restrict__ labels, float* __restrict__ y, float* __restrict__ probs,
                                                  float* __restrict__ delta, float* __restrict__ loss_terms, float* __restrict__ dxb, int in,
                                                  int out_rt, int b, HeadShared& sh) {
     constexpr int kBlock = 256, out = 3, UK = 18, kOutTile = 8;  // (out_rt == 3: the run-time copy keeps the generic loops' code shape)
+    constexpr int U = LEAN ? 9 : UK, KEEP = LEAN ? 1 : UK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool worker = tid < kBlock;
-    float xk[UK];
-    w3 wk[UK];
+    float xk[KEEP];
+    w3 wk[KEEP];
     bool kept = false;
     float acc[3] = {0.f, 0.f, 0.f};
     if (worker) {
         int i = tid;
-        for (; i + (UK - 1) * kBlock < in; i += UK * kBlock) {
-            float xv[UK];
-            w3 wv[UK];
+        for (; i + (U - 1) * kBlock < in; i += U * kBlock) {  // (ascending i: the sums do not depend on U)
+            float xv[U];
+            w3 wv[U];
 #pragma unroll
-            for (int u = 0; u < UK; ++u) {
+            for (int u = 0; u < U; ++u) {
                 xv[u] = xb[i + u * kBlock];
                 wv[u] = *reinterpret_cast<const w3*>(w + (size_t)(i + u * kBlock) * 3);
             }
 #pragma unroll
-            for (int u = 0; u < UK; ++u) {
+            for (int u = 0; u < U; ++u) {
                 acc[0] = __builtin_fmaf(xv[u], wv[u].a, acc[0]);
                 acc[1] = __builtin_fmaf(xv[u], wv[u].b, acc[1]);
                 acc[2] = __builtin_fmaf(xv[u], wv[u].c, acc[2]);
             }
             if (in == UK * kBlock) {
                 kept = true;
+                if constexpr (!LEAN) {
 #pragma unroll
-                for (int u = 0; u < UK; ++u) {
-                    xk[u] = xv[u];
-                    wk[u] = wv[u];
+                    for (int u = 0; u < UK; ++u) {
+                        xk[u] = xv[u];
+                        wk[u] = wv[u];
+                    }
                 }
             }
         }
@@ -238,14 +329,16 @@ __device__ __forceinline__ void chain_head_phase(const float* __restrict__ xb, c
     __syncthreads();
     if (!worker) return;
     const float d0 = sh.dl[0], d1 = sh.dl[1], d2 = sh.dl[2];
-    if (kept) {  // in == 18 * 256: no loads at all
+    if (kept) {  // in == 18 * 256: no loads at all (LEAN: x and the W rows once more, same expression)
 #pragma unroll
         for (int u = 0; u < UK; ++u) {
+            const float xu = LEAN ? xb[tid + u * kBlock] : xk[LEAN ? 0 : u];
+            const w3 wu = LEAN ? *reinterpret_cast<const w3*>(w + (size_t)(tid + u * kBlock) * 3) : wk[LEAN ? 0 : u];
             float sj = 0.f;  // (linear_bwd_fused's expression, term by term)
-            sj += d0 * wk[u].a;
-            sj += d1 * wk[u].b;
-            sj += d2 * wk[u].c;
-            dxb[tid + u * kBlock] = (xk[u] <= 0.f) ? 0.f : sj;
+            sj += d0 * wu.a;
+            sj += d1 * wu.b;
+            sj += d2 * wu.c;
+            dxb[tid + u * kBlock] = (xu <= 0.f) ? 0.f : sj;
         }
     } else {
         for (int i2 = tid; i2 < in; i2 += kBlock) {  // (linear_fwd_softmax_xent's generic loop, statement by statement)
@@ -312,6 +405,36 @@ __global__ __launch_bounds__(kChainThreads) void chain_fwd_kernel(const ChainFwd
     if (DBG && (b == 0 || b == 100) && lane == 0 && (wave == 0 || wave == 7))
         printf("chain_fwd<%d> wg %d wave %d: phase A %lld (+barrier %lld) | B %lld (+barrier %lld) | C %lld (+barrier %lld) | head %lld | total %lld ticks\n", N, b,
                wave, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], th - t[5], (long long)clock64() - th, (long long)clock64() - t[0]);
+}
+
+// The LEAN forward chain: the same phases within 168 VGPRs per wave (three waves per SIMD's worth: the workgroup's two leave a third of
+// every compute unit's register file to other kernels -- two workgroups of the deferred first-layer data gradient, 88 VGPRs x 4 waves
+// each, fit beside it).  conv_layer_3's waves own ONE 16-channel slice (72 filter registers) instead of two, conv_layer_4's hold their
+// slice in halves (chain_fwd_phase_split).  Same results, bit for bit.
+template <int N>
+__global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void chain_fwd_lean_kernel(const ChainFwdParams p) {
+    __shared__ HeadShared sh;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int C0 = 128 >> N;
+    const float* xin = p.x + (size_t)b * C0 * p.H[0] * p.W[0];
+    if constexpr (N >= 3) {
+        float* out = p.a[N - 3] + (size_t)b * 32 * p.H[N - 2] * p.W[N - 2];
+        chain_fwd_phase<16, 2>(xin, p.img[N - 3], p.bias[N - 3], out, p.H[N - 3], p.W[N - 3], 32, p.H[N - 2], p.W[N - 2], p.m_wo[N - 3], wave, lane);
+        __syncthreads();
+        xin = out;
+    }
+    if constexpr (N >= 2) {
+        float* out = p.a[N - 2] + (size_t)b * 64 * p.H[N - 1] * p.W[N - 1];
+        chain_fwd_phase<32, 1>(xin, p.img[N - 2], p.bias[N - 2], out, p.H[N - 2], p.W[N - 2], 64, p.H[N - 1], p.W[N - 1], p.m_wo[N - 2], wave, lane);
+        __syncthreads();
+        xin = out;
+    }
+    float* a_last = p.a[N - 1] + (size_t)b * 128 * p.H[N] * p.W[N];
+    chain_fwd_phase_split<64, 3>(xin, p.img[N - 1], p.bias[N - 1], a_last, p.H[N - 1], p.W[N - 1], 128, p.H[N], p.W[N], p.m_wo[N - 1], wave, lane);
+    __syncthreads();
+    chain_head_phase<true>(a_last, p.lin_w, p.lin_b, p.labels, p.logits, p.probs, p.delta, p.loss_terms, p.dx_head + (size_t)b * p.lin_in, p.lin_in,
+                     p.lin_out, b, sh);
 }
 
 // ---- data gradient of ONE stride-2 convolution for ONE sample: conv_dgrad_m16_s2_kernel's wave loop (conv_dgrad_rd.hip) -------------
@@ -553,6 +676,16 @@ int cnn_conv_chain_forward_loss_prepared(int n, const cnn_conv2d_desc* descs, co
     snprintf(name, sizeof(name), "conv_chain_fwd<%d>+head", n);
 #define CHAIN_F(N_) \
     CNN_KLAUNCH(s, name, (launch_pub(chain_fwd_kernel<N_>, dim3(B), dim3(kChainThreads), 0, s, p)), "B%d C%d %dx%d", B, descs[0].Ci, descs[0].H, descs[0].W)
+    // CHAIN_LEAN=1 (measurement switch): the <= 168-VGPR instance; its last layer keeps the sums of all pixel groups of a wave in registers
+    // (at most 3 groups: output maps up to 48 pixels)
+    if (CNN_OPT_INT("CHAIN_LEAN", 0) != 0 && p.H[n] * p.W[n] <= 48) {
+        snprintf(name, sizeof(name), "conv_chain_fwd_lean<%d>+head", n);
+#define CHAIN_L(N_) \
+    CNN_KLAUNCH(s, name, (launch_pub(chain_fwd_lean_kernel<N_>, dim3(B), dim3(kChainThreads), 0, s, p)), "B%d C%d %dx%d", B, descs[0].Ci, descs[0].H, descs[0].W)
+        if (n == 1) CHAIN_L(1); else if (n == 2) CHAIN_L(2); else CHAIN_L(3);
+#undef CHAIN_L
+        return CNN_AMD_OK;
+    }
     if (CNN_OPT_INT("CHAIN_DBG", 0) != 0 && n == 3) {
         CNN_KLAUNCH(s, name, (launch_pub(chain_fwd_kernel<3, true>, dim3(B), dim3(kChainThreads), 0, s, p)), "B%d C%d %dx%d", B, descs[0].Ci, descs[0].H, descs[0].W);
         return CNN_AMD_OK;
