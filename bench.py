@@ -629,6 +629,27 @@ def main():
                 del r2
                 torch.cuda.empty_cache()
             out["reference_loop"] = reference_loop_leg(torch, args)
+            # NOT the headline: the same train_step with architectures::input_gradient = false -- the delta with respect to the input
+            # image (conv2d.cpp:168-199 for conv_layer_1; nothing consumes it, alexnet.cpp:53-55) is not computed, as in every training
+            # framework for an input that needs no gradient.  `value` above always computes it, like the reference.
+            from cnn_amd import hostapi as _h
+
+            _h.load().cnnh_set_input_gradient(0)
+            try:
+                r3 = make_runner("alexnet", "layer", args.batch, torch, capi, 1, 0, None)
+
+                def sync3():
+                    r3["flush"]()
+                    torch.cuda.synchronize()
+
+                out["without_input_gradient"] = dict(leg_result(r3["B"], args.steps, timed_regions(r3["step"], sync3, args.steps, args.warmup, repeats=3)),
+                                                     driver=r3["api"] + ", architectures::input_gradient = false (the unobserved d(loss)/d(input image) "
+                                                     "of the first layer is skipped; extra leg, never `value`)", final_loss=round(r3["loss"](), 5))
+                r3["close"]()
+                del r3
+            finally:
+                _h.load().cnnh_set_input_gradient(1)
+            torch.cuda.empty_cache()
         if small and args.staged_input:
             out["pcie_inclusive"] = staged_input_bench(torch, capi, args)
         if small and not args.no_conv_ns:

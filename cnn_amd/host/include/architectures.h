@@ -37,6 +37,12 @@ extern bool fuse_pool_block;
 // this flag is set the copy is skipped (Layer::get_output() / Tensor3D::sync_to_host() still materialise it on demand):
 // Sequential::train_step sets it around its forward pass, so a train step never waits for the device.
 extern bool lazy_host_sync;
+// addition (round 4, default TRUE = the reference's behaviour): Conv2D::backward of the network's FIRST layer computes the delta with
+// respect to the input image (conv2d.cpp:168-199) although nothing consumes it (alexnet.cpp:53-55 drops the last backward's return value).
+// false: Sequential::train_step does not compute it for a pool-fused first block -- what every training framework does for an input that
+// needs no gradient; the layer's delta tensors are then NOT valid after the step (the accessors of the C handle API report that).  Grad-CAM
+// and the plain forward / backward / update_gradients sequence are unaffected.  bench.py reports this mode as an extra, labelled leg only.
+extern bool input_gradient;
 
 class WithoutGrad final {
 public:
@@ -101,6 +107,7 @@ private:
     // ---- re-materialisation of an output tensor the pass did not write (fuse_pool_block) ----
     mutable bool out_valid = true;    // out_buf holds the last forward's output
     bool recompute_lost = false;      // see params_of_last_forward_lost()
+    bool delta_valid = true;          // see delta_computed()
     const data_type* last_x = nullptr;  // device pointer of the last forward's input (recorded even under no_grad)
     int last_B = 0;
     const data_type* snapshot = nullptr;   // the container's copy of this layer's parameters BEFORE its latest SGD step ...
@@ -196,6 +203,8 @@ public:
     void prepare_own_filters();  // fwd image + the NEXT data-gradient image from the current parameters, on architectures::stream
     void launch_deferred_dgrad(const DeferredDgrad& job, void* on_stream);
     const data_type* delta_dev() const { return delta_buf.base; }  // the data gradient of the last backward pass (device)
+    bool delta_computed() const { return delta_valid; }   // false: the last train_step skipped it (architectures::input_gradient = false)
+    void set_delta_computed(bool on) { delta_valid = on; }
     size_t delta_floats() const { return delta_buf.sample_len * delta_buf.views.size(); }
     // ---- additions for the sample-resident chains (round 4, cnn_conv_chain_*): the container runs several layers as ONE kernel and
     // asks every convolution of the chain for its pointers; the bookkeeping of forward() / backward() is done here ----

@@ -113,6 +113,7 @@ void cnnh_set_stream(void* hip_stream) { architectures::stream = hip_stream; }
 void cnnh_set_no_grad(int on) { architectures::no_grad = on != 0; }
 void cnnh_set_fuse_layers(int on) { architectures::fuse_layers = on != 0; }
 void cnnh_set_fuse_pool_block(int on) { architectures::fuse_pool_block = on != 0; }
+void cnnh_set_input_gradient(int on) { architectures::input_gradient = on != 0; }
 
 void cnnh_net_set_params(void* hv, const float* host) {
     Handle* h = (Handle*)hv;
@@ -204,6 +205,7 @@ int cnnh_net_input_delta(void* hv, float* out, size_t cap_floats) {
     auto* conv = dynamic_cast<Conv2D*>(h->net->layers().front().get());
     if (conv == nullptr || conv->delta_dev() == nullptr) return 1;
     if (conv->delta_floats() > cap_floats) return 2;
+    if (!conv->delta_computed()) return 3;  // (the last train_step ran with architectures::input_gradient = false)
     h->net->flush_deferred();
     must(cnn_memcpy_d2h(out, conv->delta_dev(), sizeof(float) * conv->delta_floats(), stream), "cnn_memcpy_d2h");
     must(cnn_stream_synchronize(stream), "cnn_stream_synchronize");

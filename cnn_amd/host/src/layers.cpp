@@ -20,6 +20,7 @@ void* architectures::stream = nullptr;
 bool architectures::fuse_layers = true;
 bool architectures::fuse_pool_block = true;
 bool architectures::lazy_host_sync = false;
+bool architectures::input_gradient = true;
 
 // ---------------------------------------------------------------------------------------------------------------
 BatchBuffer::~BatchBuffer() {
@@ -317,6 +318,7 @@ std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
                                  dbuf.base, (float)B, workspace, workspace_bytes, stream, /*defer_join=*/1),
              "cnn_conv2d_backward");  // joined in update_gradients / AlexNet::backward
     grads_ready = true;
+    delta_valid = true;
     return dbuf.views;
 }
 
@@ -460,6 +462,7 @@ void Conv2D::prepare_own_filters() {
 
 void Conv2D::launch_deferred_dgrad(const DeferredDgrad& job, void* on_stream) {
     assert(job.valid);
+    delta_valid = true;
     cnn_conv2d_desc d{job.B, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding, job.flags};
     must(cnn_conv2d_backward_data_pooled2_prepared(&d, job.dpool, job.mask, job.pooled, job.prepared, delta_buf.base, on_stream),
          "cnn_conv2d_backward_data_pooled2_prepared");

@@ -592,6 +592,8 @@ bool Sequential::fused_tail(std::vector<tensor>& delta, const data_type learning
     if (tail_behind) {
         if (ev_side_tail == nullptr) must(cnn_event_create(&ev_side_tail), "cnn_event_create");
         pending_dgrad = block_conv->backward_weight_pooled(delta, /*fused_sgd=*/true, learning_rate, scale);
+        block_conv->set_delta_computed(input_gradient);
+        if (!input_gradient) pending_dgrad.valid = false;
         must(cnn_event_record(ev_tail, stream), "cnn_event_record");
         must(cnn_stream_wait_event(side, ev_tail), "cnn_stream_wait_event");
         for (auto& layer : layers_sequence)
@@ -636,7 +638,9 @@ bool Sequential::fused_tail(std::vector<tensor>& delta, const data_type learning
     prepare_later_filters(side);
     // compute stream: the block's weight gradient (+ its share of the tail)
     pending_dgrad = block_conv->backward_weight_pooled(delta, /*fused_sgd=*/!dp, learning_rate, scale);
-    if (dgrad_now) {
+    block_conv->set_delta_computed(input_gradient);
+    if (!input_gradient) pending_dgrad.valid = false;  // (architectures::input_gradient: nobody wants d(loss) / d(input image))
+    if (dgrad_now && pending_dgrad.valid) {
         block_conv->launch_deferred_dgrad(pending_dgrad, defer_stream);
         must(cnn_event_record(ev_defer_done, defer_stream), "cnn_event_record");
         pending_dgrad.valid = false;

@@ -37,6 +37,7 @@ SIGNATURES = {
     "cnnh_set_no_grad": (None, [C.c_int]),
     "cnnh_set_fuse_layers": (None, [C.c_int]),
     "cnnh_set_fuse_pool_block": (None, [C.c_int]),
+    "cnnh_set_input_gradient": (None, [C.c_int]),
     "cnnh_net_set_params": (None, [C.c_void_p, _F]),
     "cnnh_net_get_params": (None, [C.c_void_p, _F]),
     "cnnh_net_get_grads": (None, [C.c_void_p, _F]),

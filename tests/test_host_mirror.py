@@ -544,3 +544,44 @@ else:
     assert bad.returncode != 0 and "NOT_REACHED" not in bad.stdout and "did not write" in bad.stderr, bad.stdout[-500:] + bad.stderr[-1500:]
     good = subprocess.run([sys.executable, "-c", code, "forward_first"], capture_output=True, text=True, timeout=600)
     assert good.returncode == 0 and "OBSERVABLE_AGAIN" in good.stdout, good.stdout[-500:] + good.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_train_step_without_the_input_gradient_changes_nothing_else():
+    """architectures::input_gradient = false: Sequential::train_step skips the first layer's data gradient (conv2d.cpp:168-199 for
+    conv_layer_1: no consumer, alexnet.cpp:53-55) and nothing else -- loss, parameters and gradients after each of three steps are
+    bit-identical to the default step, the input delta is reported as not computed, and the default comes back with the flag"""
+    import torch
+
+    from cnn_amd import hostapi
+
+    B = 4
+    x = uniform01(180, (B, 3, 224, 224))
+    labels = (np.arange(B) % 3).astype(np.int32)
+    p0 = normal_scaled(181, (111267,))
+    xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    lib = hostapi.load()
+    res = []
+    try:
+        for on in (1, 0):
+            lib.cnnh_set_input_gradient(on)
+            net = hostapi.HostAlexNet(3)
+            net.set_params(p0)
+            trace = []
+            for step in range(3):
+                net.train_step(xd, ld, 1e-3)
+                trace.append((net.last_loss(), net.get_params(), net.get_grads()))
+            if on:
+                assert np.abs(net.input_delta((B, 3, 224, 224))).max() > 0
+            else:
+                with pytest.raises(KeyError, match="rc=3"):
+                    net.input_delta((B, 3, 224, 224))
+                lib.cnnh_set_input_gradient(1)
+                net.train_step(xd, ld, 1e-3)
+                assert np.abs(net.input_delta((B, 3, 224, 224))).max() > 0  # computed again
+            res.append(trace)
+            net.close()
+    finally:
+        lib.cnnh_set_input_gradient(1)
+    for (la, pa, ga), (lb, pb, gb) in zip(*res):
+        assert la == lb and np.array_equal(pa, pb) and np.array_equal(ga, gb)
