@@ -231,7 +231,8 @@ __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[M
 // MF: MFMA tile edge; MA x NB tiles per wave; WM x WN waves per workgroup; CK channels per LDS chunk.
 // NARROW selects the row-staging scheme at compile time (keeping both in one kernel costs ~50 VGPRs of occupancy).
 template <int MF, int MA, int NB, int WM, int WN, int CK, bool NARROW, bool R2>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu((R2 && MA * NB == 2 && WM * WN == 4) ? 3 : 1)))
+void igemm_kernel(const IgemmParams p) {  // (round 4: the fused-ReLU epilogue of the 2-tile, 4-wave instances took 180 - 196 VGPRs against 148 - 164)
     using A_ = Acc<MF>;
     constexpr int NWAVES = WM * WN;
     constexpr int NT = 64 * NWAVES;
@@ -465,8 +466,19 @@ typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
 //     chunk costs a handful of DMA instructions with trivial addressing (row staging of 6..27-float rows is bound by
 //     instruction issue, not by bytes).  LDS image = [image][ck][XH*XW]; there are no pad columns / zero rows: XM == 2
 //     masks the B operands of taps that leave the image instead (per-lane row / column bit masks).
+// round 4: the fused-ReLU epilogue (R2) of the whole-image M = 64 tiles (MA = 2, NB = 1, four waves: the 14x14 layers of the VGG- /
+// ResNet-shaped stacks) cost 32 VGPRs more than the plain one -- 144 / 156 instead of 112 / 124: three workgroups per CU instead of four,
+// fwd+relu 1 935 us against fwd 1 405 us on 512 -> 512 14x14 at batch 128 (tools/probes/relu_epilogue.py).  The main loop does not need
+// them: these instances are held to four waves per SIMD (<= 128 VGPRs) and hipcc schedules the epilogue within that.
+// (the bound is the occupancy class the PLAIN instance compiles to: whole-image tiles with up to four k-steps per tap 108 - 124 VGPRs =
+// four waves per SIMD; with eight k-steps, and the row-image tiles, 148 - 168 = three)
+template <int MA, int NB, int WM, int WN, int S, int XM, bool R2>
+constexpr int igemm_dma_min_waves() {
+    return (R2 && MA * NB == 2 && WM * WN == 4) ? (XM != 0 ? (S <= 4 ? 4 : 3) : (S <= 2 ? 3 : 1)) : 1;  // (row-image tiles with S > 2: 176 - 200 plain)
+}
 template <int MF, int MA, int NB, int WM, int WN, int S, int XM, bool R2>  // S = k-steps per tap = channels per chunk / KSTEP
-__global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(igemm_dma_min_waves<MA, NB, WM, WN, S, XM, R2>())))
+void igemm_dma_kernel(const IgemmParams p) {
     using A_ = Acc<MF>;
     constexpr int KSTEP = A_::kStep, CK = KSTEP * S;
     typedef float avec_t __attribute__((ext_vector_type(S)));
