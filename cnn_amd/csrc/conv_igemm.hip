@@ -208,6 +208,35 @@ __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[M
             const int u = rem / p.V, v = rem - u * p.V;
 #pragma unroll
             for (int ma = 0; ma < MA; ++ma) {
+                if constexpr (R2) {
+                    // round 4: every mask value of a tile is REQUESTED before the first one is used.  The per-element form below compiled
+                    // to load -> wait -> store under a divergent branch, 16 dependent round trips per tile and lane (the ISA of the
+                    // north-star tile: "L w S b" x 64): data gradient + ReLU' 2 672 vs 2 358 us plain on 64 -> 128 112x112 at batch 128.
+                    // Lanes without a destination read element 0 (always valid) and store nothing.  Same values: bit-identical.
+                    // (in groups of 16, or of 8 for the two-tile instances that live within 128 VGPRs, see igemm_dma_min_waves)
+                    constexpr int G = (MA * NB <= 2 && A_::kRegs > 8) ? 8 : A_::kRegs;
+#pragma unroll
+                    for (int r0 = 0; r0 < A_::kRegs; r0 += G) {
+                        size_t off[G];
+                        float mk[G];
+                        unsigned okm = 0;
+#pragma unroll
+                        for (int j = 0; j < G; ++j) {
+                            const int m = mbase_wave + ma * MF + A_::row(r0 + j, lh);
+                            const int cls = m / p.c_out, ci = m - cls * p.c_out;
+                            const int ph = cls / p.s_out;
+                            const int h = u * p.s_out + ph, w = v * p.s_out + (cls - ph * p.s_out);
+                            const bool ok = (full_m || m < p.M) && h < p.OH && w < p.OW;
+                            off[j] = ok ? (((size_t)b * p.c_out + ci) * p.OH + h) * p.OW + w : 0;
+                            okm |= (unsigned)ok << j;
+                        }
+#pragma unroll
+                        for (int j = 0; j < G; ++j) mk[j] = p.Y2[off[j]];
+#pragma unroll
+                        for (int j = 0; j < G; ++j)
+                            if ((okm >> j) & 1u) p.Y[off[j]] = (mk[j] <= 0.f) ? 0.f : acc[ma][nb][r0 + j];  // fused ReLU::backward of the layer in front
+                    }
+                } else {
 #pragma unroll
                 for (int r = 0; r < A_::kRegs; ++r) {
                     const int m = mbase_wave + ma * MF + A_::row(r, lh);
@@ -217,11 +246,10 @@ __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[M
                         const int h = u * p.s_out + ph, w = v * p.s_out + (cls - ph * p.s_out);
                         if (h < p.OH && w < p.OW) {
                             const size_t o = (((size_t)b * p.c_out + ci) * p.OH + h) * p.OW + w;
-                            float val = acc[ma][nb][r];
-                            if constexpr (R2) val = (p.Y2[o] <= 0.f) ? 0.f : val;  // fused ReLU::backward of the layer in front
-                            p.Y[o] = val;
+                            p.Y[o] = acc[ma][nb][r];
                         }
                     }
+                }
                 }
             }
         }
