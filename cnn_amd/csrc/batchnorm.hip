@@ -318,11 +318,14 @@ __global__ __launch_bounds__(kWave) void bn_reduce_partials(const float* __restr
 // (3 forward / 2 backward launches of a few microseconds each, every one waiting for its predecessor): here a channel is read ONCE
 // into LDS, the statistics are block reductions in a fixed order (lane tree, then the 16 waves in order) and the apply pass runs
 // from LDS -- one launch per direction, 8 B / element forward and 12 B / element backward.
-constexpr int kChanThreads = 1024;
-constexpr int kChanWaves = kChanThreads / kWave;
+// threads per channel workgroup: 1024 (round 2) or 256 (round 4, the default).  In a train step these kernels run on the compute stream
+// while the side stream's weight-gradient workgroups occupy the CUs: a 1024-thread workgroup has to wait until a CU has 16 free wave slots
+// and its registers at once (74 - 76 us in situ for a 6 - 13 MB tensor), a 256-thread one slips in beside them.  The summation order
+// depends on the count (lane e mod T, wave tree, waves in order): results of the two differ in the last bits.
+constexpr int kChanThreadsMax = 1024;
 constexpr int kChanMaxElems = 16384;  // B*H*W floats of one channel: 64 KB forward, 2 x 64 KB backward
 
-template <int NS>
+template <int NS, int kChanWaves>
 __device__ inline void chan_block_sum(float (&v)[NS], float* __restrict__ red) {  // red: [kChanWaves][NS]; result in every thread
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
@@ -346,9 +349,10 @@ __device__ inline size_t chan_addr(const Geo& q, int c, unsigned e) {  // elemen
 }
 
 // training forward (batchnorm2d.cpp:46-80): mean | biased variance around it | y, moving statistics
-template <bool RELU>
+template <bool RELU, int kChanThreads>
 __global__ __launch_bounds__(kChanThreads) void bn_fwd_channel(BnApply a, Geo q) {
 #pragma clang fp contract(off)
+    constexpr int kChanWaves = kChanThreads / kWave;
     extern __shared__ float chan[];  // [n] x
     __shared__ float red[kChanWaves];
     const int c = blockIdx.x;
@@ -359,14 +363,14 @@ __global__ __launch_bounds__(kChanThreads) void bn_fwd_channel(BnApply a, Geo q)
         chan[e] = v;
         acc[0] += v;
     }
-    chan_block_sum<1>(acc, red);  // (its barrier also publishes chan[])
+    chan_block_sum<1, kChanWaves>(acc, red);  // (its barrier also publishes chan[])
     const float u = acc[0] / (float)n;
     acc[0] = 0.f;
     for (unsigned e = threadIdx.x; e < n; e += kChanThreads) {
         const float d = chan[e] - u;
         acc[0] += d * d;
     }
-    chan_block_sum<1>(acc, red);
+    chan_block_sum<1, kChanWaves>(acc, red);
     const float var = acc[0] / (float)n;
     if (threadIdx.x == 0) {
         a.saved_mean[c] = u;
@@ -385,12 +389,14 @@ __global__ __launch_bounds__(kChanThreads) void bn_fwd_channel(BnApply a, Geo q)
 }
 
 // backward (batchnorm2d.cpp:118-155): the four channel sums of bn_bwd_stats, then bn_bwd_apply's dx in place on dy
+template <int kChanThreads>
 __global__ __launch_bounds__(kChanThreads) void bn_bwd_channel(const float* __restrict__ x, float* __restrict__ dy,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ saved_mean,
                                                                const float* __restrict__ saved_var, float* __restrict__ ggamma,
                                                                float* __restrict__ gbeta, float eps, Geo q) {
 #pragma clang fp contract(off)
+    constexpr int kChanWaves = kChanThreads / kWave;
     extern __shared__ float chan[];  // [n] x - mean, [n] dy
     __shared__ float red[kChanWaves * 4];
     const int c = blockIdx.x;
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(kChanThreads) void bn_bwd_channel(const float* __re
         acc[2] += (d * gm) * xc * -0.5f * var_inv_3;
         acc[3] += xc;
     }
-    chan_block_sum<4>(acc, red);
+    chan_block_sum<4, kChanWaves>(acc, red);
     const float L = (float)n;
     const float inv = acc[2] / L;
     const float u_g = (acc[1] * gm) * (-var_inv) + inv * -2.f * acc[3];
@@ -425,6 +431,9 @@ __global__ __launch_bounds__(kChanThreads) void bn_bwd_channel(const float* __re
     for (unsigned e = threadIdx.x; e < n; e += kChanThreads)
         dy[chan_addr(q, c, e)] = (d_s[e] * gm) * var_inv + inv2 * xc_s[e] + u_term;
 }
+
+// BN_CHAN_THREADS=1024: the round-2 workgroup size of the channel kernels (the default; 256 measured: see kChanThreadsMax)
+int chan_threads() { return CNN_OPT_INT("BN_CHAN_THREADS", 1024) >= kChanThreadsMax ? 1024 : 256; }
 
 // the channel kernels take a layer when a channel fits LDS and there are enough channels to spread over the chip
 bool channel_path(int B, int C, int H, int W) {
@@ -489,16 +498,21 @@ static int bn_forward_impl(const float* x, float* y, float* y_relu, const float*
             const size_t lds = (size_t)B * H * W * sizeof(float);
             static DeviceOnce attr_once;
             if (attr_once.needed()) {
-                CNN_HIP_CHECK(hipFuncSetAttribute((const void*)bn_fwd_channel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)(kChanMaxElems * sizeof(float))));
-                CNN_HIP_CHECK(hipFuncSetAttribute((const void*)bn_fwd_channel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)(kChanMaxElems * sizeof(float))));
+                const int lim = (int)(kChanMaxElems * sizeof(float));
+                CNN_HIP_CHECK(hipFuncSetAttribute((const void*)bn_fwd_channel<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+                CNN_HIP_CHECK(hipFuncSetAttribute((const void*)bn_fwd_channel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+                CNN_HIP_CHECK(hipFuncSetAttribute((const void*)bn_fwd_channel<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+                CNN_HIP_CHECK(hipFuncSetAttribute((const void*)bn_fwd_channel<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
                 attr_once.mark();
             }
-            if (y_relu)
-                CNN_KLAUNCH(s, "bn_fwd_channel+relu", (bn_fwd_channel<true><<<C, kChanThreads, lds, s>>>(a, q)), BN_TAG);
-            else
-                CNN_KLAUNCH(s, "bn_fwd_channel", (bn_fwd_channel<false><<<C, kChanThreads, lds, s>>>(a, q)), BN_TAG);
+            const bool wide = chan_threads() == 1024;
+            if (y_relu) {
+                if (wide) CNN_KLAUNCH(s, "bn_fwd_channel+relu", (bn_fwd_channel<true, 1024><<<C, 1024, lds, s>>>(a, q)), BN_TAG);
+                else CNN_KLAUNCH(s, "bn_fwd_channel+relu", (bn_fwd_channel<true, 256><<<C, 256, lds, s>>>(a, q)), BN_TAG);
+            } else {
+                if (wide) CNN_KLAUNCH(s, "bn_fwd_channel", (bn_fwd_channel<false, 1024><<<C, 1024, lds, s>>>(a, q)), BN_TAG);
+                else CNN_KLAUNCH(s, "bn_fwd_channel", (bn_fwd_channel<false, 256><<<C, 256, lds, s>>>(a, q)), BN_TAG);
+            }
             return CNN_AMD_OK;
         }
         float* p0 = (float*)workspace;
@@ -546,12 +560,17 @@ int cnn_batchnorm2d_backward(const float* x, float* dy, const float* gamma, cons
         const size_t lds = (size_t)B * H * W * sizeof(float) * 2;
         static DeviceOnce attr_once;
         if (attr_once.needed()) {
-            CNN_HIP_CHECK(hipFuncSetAttribute((const void*)bn_bwd_channel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)(kChanMaxElems * sizeof(float) * 2)));
+            const int lim = (int)(kChanMaxElems * sizeof(float) * 2);
+            CNN_HIP_CHECK(hipFuncSetAttribute((const void*)bn_bwd_channel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            CNN_HIP_CHECK(hipFuncSetAttribute((const void*)bn_bwd_channel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             attr_once.mark();
         }
-        CNN_KLAUNCH(s, "bn_bwd_channel",
-                    (bn_bwd_channel<<<C, kChanThreads, lds, s>>>(x, dy, gamma, saved_mean, saved_var, ggamma, gbeta, eps, q)), BN_TAG);
+        if (chan_threads() == 1024)
+            CNN_KLAUNCH(s, "bn_bwd_channel",
+                        (bn_bwd_channel<1024><<<C, 1024, lds, s>>>(x, dy, gamma, saved_mean, saved_var, ggamma, gbeta, eps, q)), BN_TAG);
+        else
+            CNN_KLAUNCH(s, "bn_bwd_channel",
+                        (bn_bwd_channel<256><<<C, 256, lds, s>>>(x, dy, gamma, saved_mean, saved_var, ggamma, gbeta, eps, q)), BN_TAG);
         return CNN_AMD_OK;
     }
     float* part = (float*)workspace;

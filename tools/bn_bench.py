@@ -5,7 +5,10 @@ import torch
 from cnn_amd import capi
 
 B = int(os.environ.get("B", 256))
-for (C, H, W) in [(16, 111, 111), (32, 27, 27), (64, 13, 13), (128, 6, 6), (64, 112, 112)]:
+SHAPES = [(16, 111, 111), (32, 27, 27), (64, 13, 13), (128, 6, 6), (64, 112, 112)]
+if os.environ.get("SHAPES") == "resnet":  # B=64: the BN sites of the ResNet-18-shaped stack
+    SHAPES = [(64, 56, 56), (128, 28, 28), (256, 14, 14), (512, 7, 7)]
+for (C, H, W) in SHAPES:
     x = torch.randn((B, C, H, W), device="cuda")
     y, dy = torch.empty_like(x), torch.randn_like(x)
     gm, bt = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")

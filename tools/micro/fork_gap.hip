@@ -75,7 +75,15 @@ int main(int argc, char** argv) {
     const char* names[6] = {"hipEventRecord between A and B", "stopEvent on A's dispatch packet", "no fork", "hipStreamWriteValue32 + hipStreamWaitValue32",
                             "flag written by A's last wave (fences) + hipStreamWaitValue32", "write-through stores + flag by A's last wave + WaitValue32"};
     unsigned seq = 0;
-    for (int mode = 0; mode < 6; ++mode) {
+    // event flavours for modes 0 / 1 (argv[2]): 0 DisableTiming | 1 + DisableSystemFence | 2 + ReleaseToDevice | 3 both
+    const int flavour = argc > 2 ? atoi(argv[2]) : 0;
+    if (flavour) {
+        CK(hipEventDestroy(ev));
+        CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming | ((flavour & 1) ? hipEventDisableSystemFence : 0) |
+                                            ((flavour & 2) ? hipEventReleaseToDevice : 0)));
+        printf("event flavour %d\n", flavour);
+    }
+    for (int mode = 0; mode < (flavour ? 2 : 6); ++mode) {
         double gap = 0, cstart = 0, adur = 0;
         unsigned total_bad = 0;
         const int reps = 20;
