@@ -857,6 +857,57 @@ void igemm_dma_kernel(const IgemmParams p) {
         if (p.dbg & 4) continue;
         const float* As = smem + (cc & 1) * buf_floats;
         const float* Xs = As + a_floats;
+        if constexpr (XM != 3 && NB >= 7) {
+        // ---- wide pixel tiles (NB = 7 / 13 blocks of 16 pixels, round 4): B operands pipelined by one K-STEP instead of one tap -- 2 * NB
+        //      registers instead of 2 * NB * S.  Every accumulator still sees (tap, k-step) in the same order as below.
+        avec_t a_cur[MA];
+        float b_cur[NB];
+#pragma unroll
+        for (int ma = 0; ma < MA; ++ma) a_cur[ma] = *(const avec_t*)(As + a_lane + ma * MF * S);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const bool ok = (XM < 2) || ((rmask[nb] & cmask[nb] & 1u) != 0);
+            const float xv = Xs[pix_off[nb]];
+            b_cur[nb] = ok ? xv : 0.f;
+        }
+        int tr = 0, tc = 0;
+        for (int t = 0; t < T; ++t) {
+            int ntc = tc + 1, ntr = tr;
+            if (ntc == p.TC) { ntc = 0; ++ntr; }
+            const bool last = (t + 1 == T);
+            const int tap_cur = tr * p.LW + tc, tap_next = last ? 0 : ntr * p.LW + ntc;  // (after the last tap: a harmless re-read)
+            const float* a_next = As + (last ? 0 : (t + 1) * KSTEP * MT * S) + a_lane;
+            avec_t a_nxt[MA];
+#pragma unroll
+            for (int ma = 0; ma < MA; ++ma) a_nxt[ma] = *(const avec_t*)(a_next + ma * MF * S);
+#pragma unroll
+            for (int c2 = 0; c2 < S; ++c2) {
+                float b_nxt[NB];
+                const bool same = (c2 + 1 < S);
+                const int boff = same ? tap_cur + (c2 + 1) * KSTEP * p.chs : tap_next;
+                const int mr = same ? tr : ntr, mc = same ? tc : ntc;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const bool ok = (XM < 2) || (!same && last) || (((rmask[nb] >> mr) & (cmask[nb] >> mc) & 1u) != 0);
+                    const float xv = Xs[pix_off[nb] + boff];
+                    b_nxt[nb] = ok ? xv : 0.f;
+                }
+                __builtin_amdgcn_sched_barrier(0);  // reads of the next k-step stay above the MFMAs of this one
+#pragma unroll
+                for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[ma][nb] = A_::mfma(a_cur[ma][c2], b_cur[nb], acc[ma][nb]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) b_cur[nb] = b_nxt[nb];
+            }
+#pragma unroll
+            for (int ma = 0; ma < MA; ++ma) a_cur[ma] = a_nxt[ma];
+            tr = ntr;
+            tc = ntc;
+        }
+        } else
         // ---- MFMA, software pipelined by one tap ----
         if constexpr (XM != 3) {
         avec_t a_cur[MA];
@@ -1059,6 +1110,7 @@ enum { CFG_M128_L = 100, CFG_M128 = 0, CFG_M128_S, CFG_M64, CFG_M64_S, CFG_M32, 
        CFG_D16_C4 /*209*/, CFG_D16_C4_L, CFG_D16_C16, CFG_D16_C16_L, CFG_D16_C8, CFG_D16_C8_L,
        CFG_D_M32 /*215*/, CFG_D_M32_C4, CFG_D_M64N1 /*217*/, CFG_D_M128S /*218*/, CFG_D_M128S_C4, CFG_D_M64S /*220*/, CFG_D_M64S_C4,
        CFG_D_M32_C16 /*222*/, CFG_D_M64S_C16, CFG_D_M128S_C16, CFG_D_M64W4N1_C16, CFG_D_M64W4N1_C8 /*226*/, CFG_D_M64N2W8 /*227*/,
+       CFG_W26_M64_N4 /*228*/, CFG_W26_M128_N2 /*229*/,
        CFG_M64_S_C16 = 20, CFG_M64_S_C32, CFG_M128_S_C16, CFG_M128_S_C32, CFG_M32_S_C16 /*24*/, CFG_M64_S_C4 /*25*/, CFG_M128_S_C4 /*26*/,
        CFG_M32_S_C4 /*27*/ };
 
@@ -1107,7 +1159,11 @@ thread_local int g_forced_cfg = -1;  // >= 0: make_plan must use exactly this co
 // 227 (round 3): 64 output rows x 512 pixels per workgroup, every wave a 2 x 2 block of 32x32 MFMA tiles -- for M = 64 (the data
 // gradient of a 64-channel layer: the north-star shape's) the 2 x 1 tiles of 201 stage twice the bytes per MFMA that the M = 128
 // forward tile does; 2 x 2 restores the forward kernel's ratio of DMA bytes and LDS operand reads to MFMAs.  202: its 4-wave sibling.
-const int kTuneCandidates[] = {-1, 200, 201, 206, 208, 226, 222, 224, 215, 216, 219, 225, 0, 1, 22, 227, 202};
+// 228 / 229 (round 4, "wide" tiles): every wave owns 32 output rows x 13 blocks of 16 pixels (two 16x16x4 MFMA row blocks x 13 column blocks; 104
+// accumulator registers), eight waves = 64 x 832 or 128 x 416 per workgroup.  (a) 62 % more outputs per workgroup than 128 x 256 for the same filter slab:
+// fewer staged bytes and fewer chunk barriers per MFMA; (b) 13 x 16 = 208 divides the 49 * 2^k pixel counts of 7 / 14 / 28 / 56 / 112-wide
+// layers almost evenly: 64 -> 64 56x56 at batch 64 is 242 workgroups (one round of 256 CUs) instead of 392 (136 CUs run two, 120 one).
+const int kTuneCandidates[] = {-1, 200, 201, 206, 208, 226, 222, 224, 215, 216, 219, 225, 0, 1, 22, 227, 202, 228, 229};
 
 int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, bool allow_dma = true, int shrink = 0) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
@@ -1204,6 +1260,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
             {CFG_D_M128S, 32, 128, 64, 8}, {CFG_D_M128S_C4, 32, 128, 64, 4}, {CFG_D_M64S, 32, 64, 64, 8}, {CFG_D_M64S_C4, 32, 64, 64, 4},
             {CFG_D_M32_C16, 32, 32, 128, 16}, {CFG_D_M64S_C16, 32, 64, 64, 16}, {CFG_D_M128S_C16, 32, 128, 64, 16},
             {CFG_D_M64W4N1_C16, 32, 64, 128, 16}, {CFG_D_M64W4N1_C8, 32, 64, 128, 8}, {CFG_D_M64N2W8, 32, 64, 512, 8},
+            {CFG_W26_M64_N4, 16, 64, 832, 8}, {CFG_W26_M128_N2, 16, 128, 416, 8},
             {CFG_M64_S_C16, 32, 64, 64, 16}, {CFG_M64_S_C32, 32, 64, 64, 32}, {CFG_M128_S_C16, 32, 128, 64, 16},
             {CFG_M128_S_C32, 32, 128, 64, 32}, {CFG_M32_S_C16, 32, 32, 128, 16}, {CFG_M64_S_C4, 32, 64, 64, 4},
             {CFG_M128_S_C4, 32, 128, 64, 4}, {CFG_M32_S_C4, 32, 32, 128, 4}};
@@ -1416,6 +1473,8 @@ int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w,
         case CFG_D_M64W4N1_C16: return launch_dma<32, 2, 1, 1, 4, 8, true>(pl, s, d);
         case CFG_D_M64W4N1_C8: return launch_dma<32, 2, 1, 1, 4, 4, true>(pl, s, d);
         case CFG_D_M64N2W8: return launch_dma<32, 2, 2, 1, 8, 4>(pl, s, d);
+        case CFG_W26_M64_N4: return launch_dma<16, 2, 13, 2, 4, 2>(pl, s, d);
+        case CFG_W26_M128_N2: return launch_dma<16, 2, 13, 4, 2, 2>(pl, s, d);
         case CFG_M64_S_C16: return launch_cfg<32, 1, 1, 2, 2, 16>(pl, s, d);
         case CFG_M64_S_C32: return launch_cfg<32, 1, 1, 2, 2, 32>(pl, s, d);
         case CFG_M128_S_C16: return launch_cfg<32, 2, 1, 2, 2, 16>(pl, s, d);

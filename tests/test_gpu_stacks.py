@@ -216,7 +216,7 @@ def test_stack_layers_full_batch_mfma_equals_im2col(T, case):
     assert err(gb, gbr) <= REL_TOL
 
 
-@pytest.mark.parametrize("cfg", [201, 227, 200, 202])
+@pytest.mark.parametrize("cfg", [201, 227, 200, 202, 228, 229])
 @pytest.mark.parametrize("case", [(16, 64, 60, 60, 128, 3, 1, 0), (12, 64, 61, 61, 64, 3, 1, 1), (16, 128, 59, 59, 64, 3, 1, 1), (9, 64, 62, 58, 128, 3, 1, 0)],
                          ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
 def test_dma_kernel_ragged_rows_equal_im2col(T, case, cfg, lib_option):

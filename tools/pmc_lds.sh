@@ -16,7 +16,7 @@ out=os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/pmc_lds_'+os.environ.get('TAG',''
 for f in sorted(glob.glob(os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/pmc_lds_*/*/*counter_collection.csv')+glob.glob(os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/pmc_lds_*/*/*/*counter_collection.csv')):
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        agg[(r['Kernel_Name'][:60], r['Counter_Name'])].append(float(r['Counter_Value']))
+        agg[(r["Kernel_Name"][:110], r["Counter_Name"])].append(float(r['Counter_Value']))
     for k,v in sorted(agg.items()): print(k[0], k[1], round(sum(v)/len(v),1), 'x', len(v))
 PY
 cat $GRAFT_REPO_ROOT/gpurun_out/pmc_lds_$TAG.txt; cat $OUT/available.txt | tr '\n' ' '
