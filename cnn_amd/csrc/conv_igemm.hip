@@ -177,6 +177,59 @@ __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[M
     using A_ = Acc<MF>;
     const long long UV = (long long)p.U * p.V;
     const bool full_m = (mbase_wave + MA * MF <= p.M);  // wave-uniform: no per-row bounds checks in the common case
+    if constexpr (R2 && MF == 16 && NB >= 7) {
+        // wide tiles (16x16x4 blocks: 4 accumulator registers each), data gradient + ReLU': the group-of-kRegs batching below would be 26
+        // dependent rounds of 4 mask loads per lane -- here the masks of TWO column blocks x MA row blocks (16 values) are requested at once
+        if (p.mode != MODE_FWD) {
+            constexpr int NBG = 2;
+#pragma unroll
+            for (int nb0 = 0; nb0 < NB; nb0 += NBG) {
+                size_t off[NBG][MA][4];
+                float mk[NBG][MA][4];
+                unsigned okm = 0;
+#pragma unroll
+                for (int g = 0; g < NBG; ++g) {
+                    if (nb0 + g < NB) {
+                        const long long n = n_first + (nb0 + g) * MF + li;
+                        const bool okn = n <= n1;
+                        const long long nn = okn ? n : n1;
+                        const int b = (int)(nn / UV);
+                        const int rem = (int)(nn - b * UV);
+                        const int u = rem / p.V, v = rem - u * p.V;
+#pragma unroll
+                        for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int m = mbase_wave + ma * MF + A_::row(j, lh);
+                                const int cls = m / p.c_out, ci = m - cls * p.c_out;
+                                const int ph = cls / p.s_out;
+                                const int h = u * p.s_out + ph, w = v * p.s_out + (cls - ph * p.s_out);
+                                const bool ok = okn && (full_m || m < p.M) && h < p.OH && w < p.OW;
+                                off[g][ma][j] = ok ? (((size_t)b * p.c_out + ci) * p.OH + h) * p.OW + w : 0;
+                                okm |= (unsigned)ok << ((g * MA + ma) * 4 + j);
+                            }
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < NBG; ++g)
+                    if (nb0 + g < NB)
+#pragma unroll
+                        for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) mk[g][ma][j] = p.Y2[off[g][ma][j]];
+#pragma unroll
+                for (int g = 0; g < NBG; ++g)
+                    if (nb0 + g < NB)
+#pragma unroll
+                        for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if ((okm >> ((g * MA + ma) * 4 + j)) & 1u)
+                                    p.Y[off[g][ma][j]] = (mk[g][ma][j] <= 0.f) ? 0.f : acc[ma][nb0 + g][j];
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const long long n = n_first + nb * MF + li;
