@@ -63,6 +63,8 @@ struct IgemmParams {
     int tc_inv;         // 65536 / TC + 1: t / TC == (t * tc_inv) >> 16 for the small tap indices used here
     int ncls;           // dgrad: number of output-parity classes with a tap mask below (0: every tap is used by every row)
     unsigned cls_mask[16];  // dgrad: bit t set <=> class cls = m / c_out has a filter tap at window position t
+    int ksplit;         // DMA kernel: blockIdx.z = one of ksplit contiguous chunk ranges; partial sums go to Y + z * zstride (split_reduce adds them)
+    long long zstride;  // floats per partial output tensor
 };
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
@@ -98,7 +100,7 @@ struct Acc<16> {
 // Accumulators start at the bias (forward) or 0: the epilogue is then a pure store (no loads on the store path).
 template <int MF, int MA, int NB>
 __device__ __forceinline__ void init_acc(typename Acc<MF>::type (&acc)[MA][NB], const IgemmParams& p, int mbase_wave,
-                                         int lh) {
+                                         int lh, bool with_bias = true) {
     using A_ = Acc<MF>;
 #pragma unroll
     for (int ma = 0; ma < MA; ++ma) {
@@ -106,7 +108,7 @@ __device__ __forceinline__ void init_acc(typename Acc<MF>::type (&acc)[MA][NB], 
 #pragma unroll
         for (int r = 0; r < A_::kRegs; ++r) {
             const int m = mbase_wave + ma * MF + A_::row(r, lh);
-            bv[r] = (p.bias != nullptr && m < p.M) ? p.bias[m] : 0.f;
+            bv[r] = (with_bias && p.bias != nullptr && m < p.M) ? p.bias[m] : 0.f;
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -173,7 +175,7 @@ __device__ __forceinline__ void compute_chunk(const float* __restrict__ As, cons
 // dgrad: virtual channel m = (ph*s+pw)*Ci + ci of grid pixel (u,v) -> dx[b][ci][u*s+ph][v*s+pw].
 template <int MF, int MA, int NB, bool R2>
 __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[MA][NB], const IgemmParams& p,
-                                           long long n_first, long long n1, int mbase_wave, int li, int lh) {
+                                           long long n_first, long long n1, int mbase_wave, int li, int lh, float* const Yb) {  // Yb: p.Y, or this split-K range's partial tensor
     using A_ = Acc<MF>;
     const long long UV = (long long)p.U * p.V;
     const bool full_m = (mbase_wave + MA * MF <= p.M);  // wave-uniform: no per-row bounds checks in the common case
@@ -225,7 +227,7 @@ __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[M
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
                                 if ((okm >> ((g * MA + ma) * 4 + j)) & 1u)
-                                    p.Y[off[g][ma][j]] = (mk[g][ma][j] <= 0.f) ? 0.f : acc[ma][nb0 + g][j];
+                                    Yb[off[g][ma][j]] = (mk[g][ma][j] <= 0.f) ? 0.f : acc[ma][nb0 + g][j];
             }
             return;
         }
@@ -237,11 +239,14 @@ __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[M
         const int b = (int)(n / UV);
         const int rem = (int)(n - b * UV);
         if (p.mode == MODE_FWD) {
-            float* out = p.Y + ((size_t)b * p.M + mbase_wave) * UV + rem;
+            // (round 4) Y == nullptr with R2: only the ReLU output is wanted (cnn_conv2d_relu_only_supported: nothing in a train step reads
+            // the pre-activation tensor of a Conv2D -> ReLU pair; on the HBM-bound first layer of the VGG-shaped stack it is half of 3.3 GB)
+            const bool wy = !R2 || Yb != nullptr;  // wave-uniform
+            float* out = (wy ? Yb : p.Y2) + ((size_t)b * p.M + mbase_wave) * UV + rem;
             // fused ReLU::forward: the second output tensor has the same layout, so its address is the first one's plus a
             // wave-uniform distance (keeps the epilogue's register footprint that of the plain store)
             // (R2 is a compile-time variant: as a run-time branch the extra stores cost every kernel 32 VGPRs)
-            const ptrdiff_t d2 = R2 ? (p.Y2 - p.Y) : 0;
+            const ptrdiff_t d2 = (R2 && wy) ? (p.Y2 - Yb) : 0;
 #pragma unroll
             for (int ma = 0; ma < MA; ++ma) {
 #pragma unroll
@@ -252,7 +257,7 @@ __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[M
                     for (int j = 0; j < 4; ++j)
                         if (full_m || mbase_wave + row0 + j < p.M) {
                             const float v = acc[ma][nb][4 * g + j];
-                            o[(size_t)j * UV] = v;
+                            if (wy) o[(size_t)j * UV] = v;
                             if constexpr (R2) o[(size_t)j * UV + d2] = v >= 0.f ? v : 0.f;
                         }
                 }
@@ -287,7 +292,7 @@ __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[M
                         for (int j = 0; j < G; ++j) mk[j] = p.Y2[off[j]];
 #pragma unroll
                         for (int j = 0; j < G; ++j)
-                            if ((okm >> j) & 1u) p.Y[off[j]] = (mk[j] <= 0.f) ? 0.f : acc[ma][nb][r0 + j];  // fused ReLU::backward of the layer in front
+                            if ((okm >> j) & 1u) Yb[off[j]] = (mk[j] <= 0.f) ? 0.f : acc[ma][nb][r0 + j];  // fused ReLU::backward of the layer in front
                     }
                 } else {
 #pragma unroll
@@ -299,7 +304,7 @@ __device__ __forceinline__ void store_tile(const typename Acc<MF>::type (&acc)[M
                         const int h = u * p.s_out + ph, w = v * p.s_out + (cls - ph * p.s_out);
                         if (h < p.OH && w < p.OW) {
                             const size_t o = (((size_t)b * p.c_out + ci) * p.OH + h) * p.OW + w;
-                            p.Y[o] = acc[ma][nb][r];
+                            Yb[o] = acc[ma][nb][r];
                         }
                     }
                 }
@@ -524,7 +529,7 @@ void igemm_kernel(const IgemmParams p) {  // (round 4: the fused-ReLU epilogue o
         if (!(p.dbg & 4)) compute_chunk<MF, MA, NB, CK, MT>(As, Xs, pix_off, a_lane, acc, p);
     }
 
-    if (!(p.dbg & 8)) store_tile<MF, MA, NB, R2>(acc, p, n0 + wn * NB * MF, n1, mbase_wave, li, lh);
+    if (!(p.dbg & 8)) store_tile<MF, MA, NB, R2>(acc, p, n0 + wn * NB * MF, n1, mbase_wave, li, lh, p.Y);
 }
 
 // ---- double-buffered variant: HBM -> LDS by DMA (global_load_lds), one barrier per chunk -------------------------
@@ -658,7 +663,11 @@ void igemm_dma_kernel(const IgemmParams p) {
 
     typename A_::type acc[MA][NB];
     const int mbase_wave = mb * MT + wm * MA * MF;
-    init_acc<MF, MA, NB>(acc, p, mbase_wave, lh);
+    // split-K (round 4, small planes at batch 64: a 512 -> 512 7x7 layer has 32 wide tiles for 256 CUs): workgroup z of ksplit takes the
+    // chunks [c_lo, c_hi); range 0 starts from the bias, the others from 0, each stores its own partial tensor
+    const int zk = (int)blockIdx.z;
+    const int c_lo = (int)((long long)p.nchunk * zk / p.ksplit), c_hi = (int)((long long)p.nchunk * (zk + 1) / p.ksplit);
+    init_acc<MF, MA, NB>(acc, p, mbase_wave, lh, zk == 0);
 
     // taps each 32/16-row MFMA tile of this wave needs (wave-uniform); umask = their union
     unsigned tmask[MA], umask = 0;
@@ -898,15 +907,15 @@ void igemm_dma_kernel(const IgemmParams p) {
         }
     };
 
-    issue_dma(0, 0);
-    for (int cc = 0; cc < p.nchunk; ++cc) {
+    issue_dma(c_lo, c_lo & 1);
+    for (int cc = c_lo; cc < c_hi; ++cc) {
         // Every wave first waits for ITS OWN outstanding LDS-DMA (chunk cc), then the barrier publishes all of them and
         // guarantees every wave is done reading the other buffer.  The explicit wait is required: hipcc (ROCm 7.2) hoists
         // its own vmcnt(0) out of this loop, leaving the in-loop s_barrier unprotected (caught by tools/det_check.py).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (XM == 0 && p.row_tail != 0) fix_tails(cc);
         __syncthreads();
-        if (cc + 1 < p.nchunk) issue_dma(cc + 1, (cc + 1) & 1);
+        if (cc + 1 < c_hi) issue_dma(cc + 1, (cc + 1) & 1);
         if (p.dbg & 4) continue;
         const float* As = smem + (cc & 1) * buf_floats;
         const float* Xs = As + a_floats;
@@ -1080,7 +1089,7 @@ void igemm_dma_kernel(const IgemmParams p) {
         }
         }
         }
-    if (!(p.dbg & 8)) store_tile<MF, MA, NB, R2>(acc, p, (long long)n0 + (long long)wn * NB * MF, n1, mbase_wave, li, lh);
+    if (!(p.dbg & 8)) store_tile<MF, MA, NB, R2>(acc, p, (long long)n0 + (long long)wn * NB * MF, n1, mbase_wave, li, lh, p.Y + (long long)zk * p.zstride);
 }
 
 // ---- weight preparation: [Co][Ci][k][k]  ->  A[mblock][chunk][tap][ck][MT] (zero padded) -------------------
@@ -1146,6 +1155,40 @@ __global__ void igemm_prep_batch(const PrepBatch pb) {
     igemm_prep_body(pb.q[blockIdx.y], (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
 }
 
+// ---- split-K: y = P[0] + P[1] + ... + P[Z-1] in that order (P[0] carries the bias), with the epilogue the unsplit kernel would have fused:
+// forward: y (nullable) and relu(y) (nullable); data gradient: dx = (mask <= 0) ? 0 : sum when the ReLU output in front is given
+__global__ __launch_bounds__(256) void split_reduce(const float* __restrict__ part, long long zstride, int Z, size_t n4, size_t n, float* __restrict__ y,
+                                                    float* __restrict__ y2, int mode) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = *(const float4*)(part + 4 * i);
+        for (int z = 1; z < Z; ++z) {
+            const float4 w = *(const float4*)(part + (size_t)z * zstride + 4 * i);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        if (mode == MODE_FWD) {
+            if (y != nullptr) *(float4*)(y + 4 * i) = v;
+            if (y2 != nullptr) *(float4*)(y2 + 4 * i) = make_float4(v.x >= 0.f ? v.x : 0.f, v.y >= 0.f ? v.y : 0.f, v.z >= 0.f ? v.z : 0.f, v.w >= 0.f ? v.w : 0.f);
+        } else {
+            if (y2 != nullptr) {
+                const float4 m = *(const float4*)(y2 + 4 * i);
+                v = make_float4(m.x <= 0.f ? 0.f : v.x, m.y <= 0.f ? 0.f : v.y, m.z <= 0.f ? 0.f : v.z, m.w <= 0.f ? 0.f : v.w);
+            }
+            *(float4*)(y + 4 * i) = v;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - 4 * n4)) {  // (tensors whose size is not a multiple of 4)
+        const size_t i = 4 * n4 + threadIdx.x;
+        float v = part[i];
+        for (int z = 1; z < Z; ++z) v += part[(size_t)z * zstride + i];
+        if (mode == MODE_FWD) {
+            if (y != nullptr) y[i] = v;
+            if (y2 != nullptr) y2[i] = v >= 0.f ? v : 0.f;
+        } else {
+            y[i] = (y2 != nullptr && y2[i] <= 0.f) ? 0.f : v;
+        }
+    }
+}
+
 // ---- host-side planning ------------------------------------------------------------------------------------
 struct Plan {
     int cfg;  // which instantiation
@@ -1157,6 +1200,8 @@ struct Plan {
     unsigned grid_x, grid_y;
     int dma;  // double-buffered DMA-staged kernel
     int xm;   // DMA kernel staging mode: 0 rows, 1 whole images, 2 whole images + masked taps
+    int ksplit;        // > 1: split-K, partial tensors behind the filter image in the workspace (see IgemmParams::ksplit)
+    size_t out_floats;  // floats of the output tensor (= one partial tensor)
 };
 
 enum { CFG_M128_L = 100, CFG_M128 = 0, CFG_M128_S, CFG_M64, CFG_M64_S, CFG_M32, CFG_M32_S, CFG_M16_CK4, CFG_M16_CK16, CFG_M16_CK4_L, CFG_M16_CK8, CFG_M16_CK8_L, CFG_D_M128 = 200, CFG_D_M64, CFG_D_M64W4, CFG_D_M128W4, CFG_D_M128W4N2, CFG_D_M128W4_C4, CFG_D_M128_C4, CFG_D_M64W4_C4, CFG_D_M64W4N1_C4,
@@ -1164,6 +1209,7 @@ enum { CFG_M128_L = 100, CFG_M128 = 0, CFG_M128_S, CFG_M64, CFG_M64_S, CFG_M32, 
        CFG_D_M32 /*215*/, CFG_D_M32_C4, CFG_D_M64N1 /*217*/, CFG_D_M128S /*218*/, CFG_D_M128S_C4, CFG_D_M64S /*220*/, CFG_D_M64S_C4,
        CFG_D_M32_C16 /*222*/, CFG_D_M64S_C16, CFG_D_M128S_C16, CFG_D_M64W4N1_C16, CFG_D_M64W4N1_C8 /*226*/, CFG_D_M64N2W8 /*227*/,
        CFG_W26_M64_N4 /*228*/, CFG_W26_M128_N2 /*229*/,
+       CFG_W26_M128_N2_K2 /*230*/, CFG_W26_M128_N2_K4, CFG_W26_M128_N2_K8, CFG_W26_M64_N4_K2 /*233*/, CFG_W26_M64_N4_K4, CFG_W26_M64_N4_K8 /*235*/,
        CFG_M64_S_C16 = 20, CFG_M64_S_C32, CFG_M128_S_C16, CFG_M128_S_C32, CFG_M32_S_C16 /*24*/, CFG_M64_S_C4 /*25*/, CFG_M128_S_C4 /*26*/,
        CFG_M32_S_C4 /*27*/ };
 
@@ -1216,7 +1262,8 @@ thread_local int g_forced_cfg = -1;  // >= 0: make_plan must use exactly this co
 // accumulator registers), eight waves = 64 x 832 or 128 x 416 per workgroup.  (a) 62 % more outputs per workgroup than 128 x 256 for the same filter slab:
 // fewer staged bytes and fewer chunk barriers per MFMA; (b) 13 x 16 = 208 divides the 49 * 2^k pixel counts of 7 / 14 / 28 / 56 / 112-wide
 // layers almost evenly: 64 -> 64 56x56 at batch 64 is 242 workgroups (one round of 256 CUs) instead of 392 (136 CUs run two, 120 one).
-const int kTuneCandidates[] = {-1, 200, 201, 206, 208, 226, 222, 224, 215, 216, 219, 225, 0, 1, 22, 227, 202, 228, 229};
+// 230 - 235: the wide tiles with the channel range split in 2 / 4 / 8 (planes of 7x7 .. 28x28 at batch 64 give 32 .. 122 wide tiles for 256 CUs)
+const int kTuneCandidates[] = {-1, 200, 201, 206, 208, 226, 222, 224, 215, 216, 219, 225, 0, 1, 22, 227, 202, 228, 229, 230, 231, 232, 233, 234, 235};
 
 int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, bool allow_dma = true, int shrink = 0) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
@@ -1227,6 +1274,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     q = PrepParams();
     p.B = d->B;
     p.mode = mode;
+    pl->ksplit = 1;
     if (mode == MODE_FWD) {
         p.C = d->Ci; p.XH = d->H; p.XW = d->W; p.U = Ho; p.V = Wo; p.su = d->s;
         p.TR = p.TC = d->k; p.r0 = p.c0 = -d->pad; p.M = d->Co;
@@ -1299,7 +1347,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     const bool pinned = override_cfg >= 0;
     if (pinned) {
         const int c = override_cfg;
-        struct { int cfg, MF, MT, NPIX, CK; } tab[] = {
+        struct { int cfg, MF, MT, NPIX, CK, Z; } tab[] = {
             {CFG_M128_L, 32, 128, 256, 8}, {CFG_M128, 32, 128, 128, 8}, {CFG_M128_S, 32, 128, 64, 8},
             {CFG_M64, 32, 64, 256, 8}, {CFG_M64_S, 32, 64, 64, 8}, {CFG_M32, 32, 32, 512, 8}, {CFG_M32_S, 32, 32, 128, 8},
             {CFG_M16_CK4, 16, 16, 256, 4}, {CFG_M16_CK16, 16, 16, 256, 16}, {CFG_M16_CK4_L, 16, 16, 512, 4},
@@ -1314,11 +1362,23 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
             {CFG_D_M32_C16, 32, 32, 128, 16}, {CFG_D_M64S_C16, 32, 64, 64, 16}, {CFG_D_M128S_C16, 32, 128, 64, 16},
             {CFG_D_M64W4N1_C16, 32, 64, 128, 16}, {CFG_D_M64W4N1_C8, 32, 64, 128, 8}, {CFG_D_M64N2W8, 32, 64, 512, 8},
             {CFG_W26_M64_N4, 16, 64, 832, 8}, {CFG_W26_M128_N2, 16, 128, 416, 8},
+            {CFG_W26_M128_N2_K2, 16, 128, 416, 8, 2}, {CFG_W26_M128_N2_K4, 16, 128, 416, 8, 4}, {CFG_W26_M128_N2_K8, 16, 128, 416, 8, 8},
+            {CFG_W26_M64_N4_K2, 16, 64, 832, 8, 2}, {CFG_W26_M64_N4_K4, 16, 64, 832, 8, 4}, {CFG_W26_M64_N4_K8, 16, 64, 832, 8, 8},
             {CFG_M64_S_C16, 32, 64, 64, 16}, {CFG_M64_S_C32, 32, 64, 64, 32}, {CFG_M128_S_C16, 32, 128, 64, 16},
             {CFG_M128_S_C32, 32, 128, 64, 32}, {CFG_M32_S_C16, 32, 32, 128, 16}, {CFG_M64_S_C4, 32, 64, 64, 4},
             {CFG_M128_S_C4, 32, 128, 64, 4}, {CFG_M32_S_C4, 32, 32, 128, 4}};
         for (auto& t : tab)
             if (t.cfg == c && p.M <= ((p.M + t.MT - 1) / t.MT) * t.MT && (t.MT >= 32 || p.M <= 16)) {
+                if (t.Z > 1) {
+                    // split-K tiles: only where the plain tile leaves CUs without a workgroup and the split fills about one round, every
+                    // range keeps >= 2 chunks, and the partial tensors stay small (they live in the caller's workspace / prepared buffer)
+                    const long long blocks = blocks_for(t.MT, t.NPIX), chunks = (p.C + t.CK - 1) / t.CK;
+                    const long long outf = mode == MODE_FWD ? p.N * p.M : (long long)p.B * d->Ci * d->H * d->W;
+                    if (!(blocks < num_cus() && blocks * t.Z <= num_cus() + num_cus() / 4 && blocks * t.Z > num_cus() / 2 && chunks >= 2 * t.Z &&
+                          outf * t.Z <= (64ll << 20) && dma_ok))
+                        continue;
+                    pl->ksplit = t.Z;
+                }
                 pl->cfg = t.cfg; pl->MF = t.MF; pl->MT = t.MT; pl->NPIX = t.NPIX; pl->CK = t.CK;
             }
     }
@@ -1369,7 +1429,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
         const bool img_cfg = pl->cfg == CFG_D_M64W4N1_C4 || pl->cfg == CFG_D_M64W4N1_C8 || pl->cfg == CFG_D_M64W4N1_C16 ||
                              pl->cfg == CFG_D_M32 || pl->cfg == CFG_D_M32_C4 || pl->cfg == CFG_D_M32_C16 ||
                              pl->cfg == CFG_D_M128S || pl->cfg == CFG_D_M128S_C4 || pl->cfg == CFG_D_M128S_C16 ||
-                             pl->cfg == CFG_D_M64S || pl->cfg == CFG_D_M64S_C4 || pl->cfg == CFG_D_M64S_C16;
+                             pl->cfg == CFG_D_M64S || pl->cfg == CFG_D_M64S_C4 || pl->cfg == CFG_D_M64S_C16;  // (the wide tiles were measured with whole-image staging too: 14x14 k/4 192 vs 172 us, 7x7 k/8 193 vs 188 us -- rows stay)
         const OptVal xe = CNN_OPT_VAL("IGEMM_XM");
         const size_t lds = 2 * ((size_t)T * pl->CK * pl->MT + (size_t)nimg * pl->CK * HW) * sizeof(float);
         if (img_cfg && HW <= 1024 && lds <= 160 * 1024 && (long long)p.B * p.C * HW < (1ll << 31) && !(xe && atoi(xe) == 0)) {
@@ -1415,6 +1475,9 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     }
     if (pl->xm == 2 && p.ncls > 0 && pl->CK >= 8 && !CNN_OPT_SET("NO_TAPSKIP")) pl->xm = 3;  // (with 2 k-steps per tap the branches cost more than the skipped MFMAs)
     if (pl->xm != 3) p.ncls = 0;
+    pl->out_floats = mode == MODE_FWD ? (size_t)p.N * p.M : (size_t)p.B * d->Ci * d->H * d->W;
+    p.ksplit = pl->ksplit;
+    p.zstride = pl->ksplit > 1 ? (long long)((pl->out_floats + 63) / 64 * 64) : 0;
     q.Co = d->Co; q.Ci = d->Ci; q.k = d->k; q.s = d->s; q.pad = d->pad; q.mode = mode;
     q.C = p.C; q.M = p.M; q.TR = p.TR; q.TC = p.TC; q.r0 = p.r0; q.c0 = p.c0;
     q.CK = pl->CK; q.MT = pl->MT; q.nchunk = p.nchunk; q.nmb = (int)pl->grid_y; q.kstep = pl->MF == 32 ? 2 : 4;
@@ -1456,10 +1519,12 @@ int launch_dma_xm2(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
         attr_once.mark();
     }
     char name[96];
-    snprintf(name, sizeof(name), "igemm_dma_kernel<%d,%d,%d,%d,%d,%d%s>%s", MF, MA, NB, WM, WN, S,
-             XM == 0 ? "" : (XM == 1 ? ",img" : (XM == 2 ? ",img+mask" : ",img+mask+skip")),
+    char ks[16] = "";
+    if (pl.ksplit > 1) snprintf(ks, sizeof(ks), ",k/%d", pl.ksplit);
+    snprintf(name, sizeof(name), "igemm_dma_kernel<%d,%d,%d,%d,%d,%d%s%s>%s", MF, MA, NB, WM, WN, S,
+             XM == 0 ? "" : (XM == 1 ? ",img" : (XM == 2 ? ",img+mask" : ",img+mask+skip")), ks,
              pl.p.mode == MODE_FWD ? (R2 ? "/fwd+relu" : "/fwd") : (R2 ? "/dgrad+relu" : "/dgrad"));
-    CNN_KLAUNCH(s, name, (kern<<<dim3(pl.grid_x, pl.grid_y), 64 * WM * WN, pl.lds_bytes, s>>>(pl.p)), CONV_TAG(d));
+    CNN_KLAUNCH(s, name, (kern<<<dim3(pl.grid_x, pl.grid_y, pl.ksplit), 64 * WM * WN, pl.lds_bytes, s>>>(pl.p)), CONV_TAG(d));
     return CNN_AMD_OK;
 }
 
@@ -1491,8 +1556,10 @@ int launch_cfg(const Plan& pl, hipStream_t s, const cnn_conv2d_desc* d) {
 int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w, const float* bias, float* Y, float* Y2,
              void* ws, size_t ws_bytes, hipStream_t s, const char* who, bool prepared = false) {
     CNN_REQUIRE(ws != nullptr, "%s: workspace is null", who);
-    if (ws_bytes < pl.a_floats * sizeof(float))
-        return fail(CNN_AMD_E_WORKSPACE, "%s: workspace %zu B < %zu B", who, ws_bytes, pl.a_floats * sizeof(float));
+    const size_t a_al = (pl.a_floats + 63) / 64 * 64;  // (split-K: the partial tensors start 256-byte aligned behind the filter image)
+    const size_t need = pl.ksplit > 1 ? a_al + (size_t)pl.ksplit * (size_t)pl.p.zstride : pl.a_floats;
+    if (ws_bytes < need * sizeof(float))
+        return fail(CNN_AMD_E_WORKSPACE, "%s: workspace %zu B < %zu B", who, ws_bytes, need * sizeof(float));
     if (!prepared) {
         pl.q.w = w;
         pl.q.A = (float*)ws;
@@ -1503,6 +1570,26 @@ int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w,
                     (igemm_prep_weights<<<pg, 256, 0, s>>>(pl.q)), CONV_TAG(d));
     }
     pl.p.X = X; pl.p.A = (const float*)ws; pl.p.bias = bias; pl.p.Y = Y; pl.p.Y2 = Y2;
+    if (pl.ksplit > 1) {
+        // the ranges write partial tensors (plain epilogue), split_reduce adds them in range order and applies the fused epilogue
+        float* part = (float*)ws + a_al;
+        CNN_REQUIRE(reinterpret_cast<uintptr_t>(part) % 16 == 0 && (Y == nullptr || reinterpret_cast<uintptr_t>(Y) % 16 == 0) &&
+                        (Y2 == nullptr || reinterpret_cast<uintptr_t>(Y2) % 16 == 0), "%s: split-K needs 16-byte aligned tensors", who);
+        pl.p.Y = part; pl.p.Y2 = nullptr;
+        int rc;
+        switch (pl.cfg) {
+            case CFG_W26_M128_N2_K2: case CFG_W26_M128_N2_K4: case CFG_W26_M128_N2_K8: rc = launch_dma<16, 2, 13, 4, 2, 2>(pl, s, d); break;
+            default: rc = launch_dma<16, 2, 13, 2, 4, 2>(pl, s, d); break;
+        }
+        if (rc) return rc;
+        const size_t n = pl.out_floats, n4 = n / 4;
+        size_t g = (n4 + 255) / 256;
+        if (g > 4096) g = 4096;
+        if (g < 1) g = 1;
+        CNN_KLAUNCH(s, pl.p.mode == MODE_FWD ? (Y2 ? "split_reduce/fwd+relu" : "split_reduce/fwd") : (Y2 ? "split_reduce/dgrad+relu" : "split_reduce/dgrad"),
+                    (split_reduce<<<(unsigned)g, 256, 0, s>>>(part, pl.p.zstride, pl.ksplit, n4, n, Y, Y2, pl.p.mode)), CONV_TAG(d));
+        return CNN_AMD_OK;
+    }
     switch (pl.cfg) {
         case CFG_D_M128: return launch_dma<32, 4, 1, 1, 8, 4>(pl, s, d);
         case CFG_D_M64: return launch_dma<32, 2, 1, 1, 8, 4>(pl, s, d);
@@ -1526,8 +1613,8 @@ int run_plan(Plan& pl, const cnn_conv2d_desc* d, const float* X, const float* w,
         case CFG_D_M64W4N1_C16: return launch_dma<32, 2, 1, 1, 4, 8, true>(pl, s, d);
         case CFG_D_M64W4N1_C8: return launch_dma<32, 2, 1, 1, 4, 4, true>(pl, s, d);
         case CFG_D_M64N2W8: return launch_dma<32, 2, 2, 1, 8, 4>(pl, s, d);
-        case CFG_W26_M64_N4: return launch_dma<16, 2, 13, 2, 4, 2>(pl, s, d);
-        case CFG_W26_M128_N2: return launch_dma<16, 2, 13, 4, 2, 2>(pl, s, d);
+        case CFG_W26_M64_N4: case CFG_W26_M64_N4_K2: case CFG_W26_M64_N4_K4: case CFG_W26_M64_N4_K8: return launch_dma<16, 2, 13, 2, 4, 2>(pl, s, d);
+        case CFG_W26_M128_N2: case CFG_W26_M128_N2_K2: case CFG_W26_M128_N2_K4: case CFG_W26_M128_N2_K8: return launch_dma<16, 2, 13, 4, 2, 2>(pl, s, d);
         case CFG_M64_S_C16: return launch_cfg<32, 1, 1, 2, 2, 16>(pl, s, d);
         case CFG_M64_S_C32: return launch_cfg<32, 1, 1, 2, 2, 32>(pl, s, d);
         case CFG_M128_S_C16: return launch_cfg<32, 2, 1, 2, 2, 16>(pl, s, d);
@@ -1627,7 +1714,9 @@ size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
             g_forced_cfg = c;
             const int rc = make_plan("ws", d, mode, &pl);
             g_forced_cfg = -1;
-            if (rc == CNN_AMD_OK && pl.a_floats > n) n = pl.a_floats;
+            if (rc != CNN_AMD_OK || (c >= 0 && pl.cfg != c)) continue;
+            const size_t need = pl.ksplit > 1 ? (pl.a_floats + 63) / 64 * 64 + (size_t)pl.ksplit * (size_t)pl.p.zstride : pl.a_floats;
+            if (need > n) n = need;
         }
     if (direct_conv_supported(d) && n < 1024) n = 1024;  // packed filter copies of the direct kernels (conv_direct.hip)
     if (c11_supported(d) && n < (size_t)d->Co * d->Ci) n = (size_t)d->Co * d->Ci;  // (conv_1x1.hip: the prepared image is a verbatim copy)
@@ -1645,7 +1734,7 @@ static int conv2d_forward_impl(const char* who, const cnn_conv2d_desc* d, const 
                                float* y, float* y_relu, void* ws, size_t ws_bytes, void* stream, bool prepared = false) {
     if (int rc = check_desc(who, d)) return rc;
     // y may be NULL when only the ReLU output is wanted and the layer runs on the register-direct forward kernel
-    CNN_REQUIRE(x && (w || prepared) && bias && (y || (y_relu && (fwd_rd_supported(d) || c11_supported(d)))), "%s: null pointer", who);
+    CNN_REQUIRE(x && (w || prepared) && bias && (y || (y_relu && !direct_conv_supported(d) && !stem_fwd_supported(d))), "%s: null pointer", who);
     if (direct_conv_supported(d)) return direct_conv_forward(d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream), prepared);
     if (c11_supported(d))  // (its "prepared" image is a verbatim copy of w)
         return c11_forward(d, x, prepared ? (const float*)ws : w, bias, y, y_relu, as_stream(stream));
@@ -1893,7 +1982,8 @@ int cnn_conv2d_backward_data(const cnn_conv2d_desc* d, const float* dy, const fl
 
 int cnn_conv2d_relu_only_supported(const cnn_conv2d_desc* d) {
     if (check_desc("cnn_conv2d_relu_only_supported", d)) return 0;
-    return (!direct_conv_supported(d) && (fwd_rd_supported(d) || c11_supported(d))) ? 1 : 0;
+    // (round 4: the implicit GEMM's fused-ReLU epilogue too -- every kernel family behind cnn_conv2d_forward except the thin first layers')
+    return (!direct_conv_supported(d) && !stem_fwd_supported(d)) ? 1 : 0;
 }
 
 /* ---- Conv2D -> ReLU -> MaxPool2D(2,2) ---- */

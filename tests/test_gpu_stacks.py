@@ -254,6 +254,52 @@ def test_dma_kernel_ragged_rows_equal_im2col(T, case, cfg, lib_option):
     assert T.equal(res["1"][0], res["0"][0]) and T.equal(res["1"][1], res["0"][1])
 
 
+@pytest.mark.parametrize("case,cfg", [((64, 128, 28, 28, 128, 3, 1, 1), 230), ((64, 128, 28, 28, 128, 3, 1, 1), 233), ((64, 256, 14, 14, 256, 3, 1, 1), 231),
+                                      ((64, 256, 14, 14, 256, 3, 1, 1), 234), ((64, 512, 7, 7, 512, 3, 1, 1), 232), ((64, 512, 7, 7, 512, 3, 1, 1), 235)],
+                         ids=lambda c: str(c).replace(" ", ""))
+def test_split_k_wide_tiles_equal_im2col(T, case, cfg, lib_option):
+    """the wide implicit-GEMM tiles with the channel range split over blockIdx.z (small planes at batch 64): partial tensors + split_reduce
+    against the im2col fallback, forward and data gradient, and the epilogues split_reduce takes over from the unsplit kernel
+    (ReLU output, ReLU-only output, ReLU' mask) bit-identical to the separate kernels on the same sums"""
+    from cnn_amd import capi
+
+    B, Ci, H, W, Co, k, s, pad = case
+    g = T.Generator(device="cuda").manual_seed(11)
+    x = T.rand((B, Ci, H, W), generator=g, device="cuda") - 0.3
+    w = T.randn((Co, Ci, k, k), generator=g, device="cuda") * float(np.sqrt(2.0 / (Ci * k * k)))
+    b = T.randn((Co,), generator=g, device="cuda") * 0.1
+    lib_option("IGEMM_CFG", str(cfg))
+    lib_option("DGRAD_RD", "0")
+    conv = capi.Conv2d(*case)
+    dy = T.rand(conv.out_shape(), generator=g, device="cuda") * 2 - 1
+
+    def err(a, ref):
+        return float((a - ref).abs().max() / ref.abs().max())
+
+    capi.kernel_timing(1)
+    y = conv.forward(x, w, b)
+    dx = conv.backward_data(dy, w) if s == 1 else None
+    names = [key.split("|")[0] for key in capi.kernel_timing_report()]
+    capi.kernel_timing(0)
+    assert any(",k/" in n and n.endswith("/fwd") for n in names) and any(n.startswith("split_reduce") for n in names), names
+    assert err(y, conv.forward_im2col(x, w, b)) <= REL_TOL
+    y_f, r_f = T.full_like(y, 7.0), T.full_like(y, 7.0)
+    conv.forward_relu(x, w, b, y_f, r_f)
+    assert T.equal(y_f, y) and T.equal(r_f, capi.relu_forward(y))
+    pf, pd = conv.prepared_buffers("cuda")
+    capi.prepare_filters([conv], [w], [b], [pf], [pd])
+    r_only = T.full_like(y, 7.0)
+    conv.forward_prepared(x, pf, b, None, r_only)
+    assert T.equal(r_only, r_f)
+    if dx is not None:
+        assert any(",k/" in n and n.endswith("/dgrad") for n in names), names
+        assert err(dx, conv.backward_data_im2col(dy, w)) <= REL_TOL
+        relu_in = capi.relu_forward(x)  # the output of a ReLU layer in front: dx is masked where it is 0
+        dxm = T.full_like(x, 7.0)
+        conv.backward_data_relu(dy, w, relu_in, dxm)
+        assert T.equal(dxm, T.where(relu_in <= 0, T.zeros_like(dx), dx))
+
+
 def test_dropout_layer_and_a_list_that_uses_it(T):
     """Dropout (dropout.cpp; row n4): the two kernels bit-exact against the oracle, and a layer list that contains the layer --
     the position the reference's own (commented-out) line alexnet.cpp:28 puts it: behind a convolution -- through the C++
