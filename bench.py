@@ -361,7 +361,24 @@ def measure(run, steps, warmup, sample_every, capi, barrier, time_mod=time, repe
     barrier()
     table = capi.kernel_timing_report()
     capi.kernel_timing(0)
-    dominant = max(table.items(), key=lambda kv: kv[1][1])[0]
+    ranked = sorted(table.items(), key=lambda kv: -kv[1][1])
+    dominant = ranked[0][0]
+    if len(ranked) > 1 and ranked[1][1][1] >= 0.8 * ranked[0][1][1]:
+        # two kernels within 20 % of each other in the fully instrumented steps (every launch event-bracketed: that changes what
+        # overlaps what): decide between them the way the timed region measures -- plain steps, ONE kernel sampled -- so that the
+        # roofline entry does not flip between runs (reference net: the first layer's weight gradient 78 vs its data gradient 72 us
+        # instrumented, 78 vs 65 us in a plain step)
+        in_situ = {}
+        for key, _ in ranked[:2]:
+            capi.kernel_timing(2, key, every=sample_every)
+            for _ in range(max(steps, 8)):
+                step()
+            barrier()
+            rep = capi.kernel_timing_report()
+            capi.kernel_timing(0)
+            cnt, ms = rep.get(key, (0, 0.0))
+            in_situ[key] = ms / cnt if cnt else 0.0
+        dominant = max(in_situ.items(), key=lambda kv: kv[1])[0]
     for _ in range(warmup):
         step()
     if clock_warmup_s > 0:
