@@ -1875,6 +1875,7 @@ static int autotune_impl(const cnn_conv2d_desc* d, void* scratch, size_t scratch
         }
         int best = -1;
         float best_ms = 1e30f;
+        const float margin = 1.f - 0.001f * (float)CNN_OPT_INT("TUNE_MARGIN", 30);  // (per mille a later candidate has to win by; measurement switch)
         const int excluded = CNN_OPT_INT("TUNE_EXCLUDE", -2);  // (measurement switch: one candidate the tuner must not pick)
         for (int c : kTuneCandidates) {
             if (c == excluded) continue;
@@ -1902,7 +1903,7 @@ static int autotune_impl(const cnn_conv2d_desc* d, void* scratch, size_t scratch
                 continue;
             }
             // the rule-based default keeps its place unless something is clearly faster (noise: a few per cent)
-            if (best_ms > 1e29f || ms < best_ms * 0.97f) {
+            if (best_ms > 1e29f || ms < best_ms * margin) {
                 best = c;
                 best_ms = ms;
             }
