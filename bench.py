@@ -347,10 +347,12 @@ REPEATS = 7          # timed regions of exactly K steps each; `value` is their M
 CLOCK_WARMUP_S = 0.6  # untimed steps in front of the first region until the clocks have ramped (the driver's box was 7 % slower)
 
 
-def measure(run, steps, warmup, sample_every, capi, barrier, time_mod=time, repeats=1, clock_warmup_s=0.0):
+def measure(run, steps, warmup, sample_every, capi, barrier, time_mod=time, repeats=1, clock_warmup_s=0.0, agree=lambda v: v):
     """the measurement protocol of one workload: 3 plain + 3 instrumented steps (which kernel dominates?), `warmup` steps [+ steps
     until `clock_warmup_s` have passed], then `repeats` timed regions of exactly `steps` steps, each between two barriers, with
-    only the dominant kernel event-bracketed -> (list of elapsed_s per region, key, launches, total_ms, table)"""
+    only the dominant kernel event-bracketed -> (list of elapsed_s per region, key, launches, total_ms, table).
+    agree(v): rank 0's value of v on every rank (identity on one rank) -- every decision that changes HOW MANY steps a rank runs goes
+    through it: a step is a collective at N > 1, and ranks that disagree about the count would hang each other"""
     step = run["step"]
     for _ in range(3):
         step()
@@ -363,13 +365,13 @@ def measure(run, steps, warmup, sample_every, capi, barrier, time_mod=time, repe
     capi.kernel_timing(0)
     ranked = sorted(table.items(), key=lambda kv: -kv[1][1])
     dominant = ranked[0][0]
-    if len(ranked) > 1 and ranked[1][1][1] >= 0.8 * ranked[0][1][1]:
+    if agree(1 if (len(ranked) > 1 and ranked[1][1][1] >= 0.8 * ranked[0][1][1]) else 0):
         # two kernels within 20 % of each other in the fully instrumented steps (every launch event-bracketed: that changes what
         # overlaps what): decide between them the way the timed region measures -- plain steps, ONE kernel sampled -- so that the
         # roofline entry does not flip between runs (reference net: the first layer's weight gradient 78 vs its data gradient 72 us
         # instrumented, 78 vs 65 us in a plain step)
         in_situ = {}
-        for key, _ in ranked[:2]:
+        for key, _ in (ranked[:2] if len(ranked) > 1 else ranked[:1] * 2):
             capi.kernel_timing(2, key, every=sample_every)
             for _ in range(max(steps, 8)):
                 step()
@@ -384,7 +386,7 @@ def measure(run, steps, warmup, sample_every, capi, barrier, time_mod=time, repe
     if clock_warmup_s > 0:
         barrier()
         t0 = time_mod.perf_counter()
-        while time_mod.perf_counter() - t0 < clock_warmup_s:
+        while agree(1 if time_mod.perf_counter() - t0 < clock_warmup_s else 0):
             for _ in range(max(steps, 1)):
                 step()
             barrier()
@@ -558,8 +560,15 @@ def main():
     # kernel costs its stream two ~6 us bubbles -- measured 13 us per step)
     every = 4 if small else 1
     repeats = args.repeats or (REPEATS if small else 3)
+    def agree(v):  # rank 0's decision on every rank (see measure())
+        if world == 1:
+            return v
+        t = torch.tensor([int(v)], device="cuda", dtype=torch.int64)
+        dist.broadcast(t, src=0)
+        return int(t.item())
+
     regions, dominant, cnt, ms, table = measure(run, args.steps, args.warmup, every, capi, barrier, repeats=repeats,
-                                                clock_warmup_s=CLOCK_WARMUP_S if small else 0.0)
+                                                clock_warmup_s=CLOCK_WARMUP_S if small else 0.0, agree=agree)
     if world > 1:  # every region's time is the MAX over the ranks
         t = torch.tensor(regions, device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

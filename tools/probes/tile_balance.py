@@ -16,6 +16,8 @@ SHAPES = [(64, 56, 56, 64, 3, 1, 1), (128, 28, 28, 128, 3, 1, 1), (256, 14, 14, 
 if os.environ.get("SHAPES") == "vgg":  # B=128: the north-star layer and the VGG-shaped stack's
     SHAPES = [(64, 112, 112, 128, 3, 1, 0), (64, 112, 112, 128, 3, 1, 1), (128, 56, 56, 256, 3, 1, 1), (256, 56, 56, 256, 3, 1, 1), (256, 28, 28, 512, 3, 1, 1),
               (512, 28, 28, 512, 3, 1, 1), (512, 14, 14, 512, 3, 1, 1)]
+if os.environ.get("SHAPES") == "first":  # the VGG-shaped stack's first layer
+    SHAPES = [(3, 224, 224, 64, 3, 1, 1)]
 for (Ci, H, W, Co, k, s, pad) in SHAPES:
     case = (B, Ci, H, W, Co, k, s, pad)
     conv = capi.Conv2d(*case)
