@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void bn_apply(BnApply a, Geo q) {
                 o.y = gm * ((v.y - u) * var_inv) + bt;
                 o.z = gm * ((v.z - u) * var_inv) + bt;
                 o.w = gm * ((v.w - u) * var_inv) + bt;
-                *(float4*)(a.y + e) = o;
+                if (!RELU || a.y != nullptr) *(float4*)(a.y + e) = o;
                 if (RELU) {
                     o.x = bn_relu(o.x); o.y = bn_relu(o.y); o.z = bn_relu(o.z); o.w = bn_relu(o.w);
                     *(float4*)(a.y_relu + e) = o;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void bn_apply(BnApply a, Geo q) {
             },
             [&](long long e) {
                 const float o = gm * ((a.x[e] - u) * var_inv) + bt;
-                a.y[e] = o;
+                if (!RELU || a.y != nullptr) a.y[e] = o;
                 if (RELU) a.y_relu[e] = bn_relu(o);
             });
     }
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(kChanThreads) void bn_fwd_channel(BnApply a, Geo q)
     for (unsigned e = threadIdx.x; e < n; e += kChanThreads) {
         const size_t at = chan_addr(q, c, e);
         const float o = gm * ((chan[e] - u) * var_inv) + bt;
-        a.y[at] = o;
+        if (!RELU || a.y != nullptr) a.y[at] = o;
         if (RELU) a.y_relu[at] = bn_relu(o);
     }
 }
@@ -484,7 +484,8 @@ static int bn_forward_impl(const float* x, float* y, float* y_relu, const float*
     Geo q;
     int rc = make_geo(B, C, H, W, &q);
     if (rc != CNN_AMD_OK) return rc;
-    CNN_REQUIRE(x && y && gamma && beta && moving_mean && moving_var, "cnn_batchnorm2d_forward: null pointer");
+    // (round 4) y == NULL with y_relu: only the ReLU output is written (nothing in a train step reads the normalised tensor itself)
+    CNN_REQUIRE(x && (y || y_relu) && gamma && beta && moving_mean && moving_var, "cnn_batchnorm2d_forward: null pointer");
     CNN_REQUIRE(aligned16(x) && aligned16(y) && aligned16(y_relu), "cnn_batchnorm2d_forward: x / y / y_relu must be 16-byte aligned");
     hipStream_t s = as_stream(stream);
     const dim3 grid(q.G, C);
@@ -610,7 +611,7 @@ static int bn_forward_from_sums_impl(const float* x, float* y, float* y_relu, co
     Geo q;
     int rc = make_geo(B, C, H, W, &q);
     if (rc != CNN_AMD_OK) return rc;
-    CNN_REQUIRE(x && y && gamma && beta && moving_mean && moving_var && saved_mean && saved_var && sum_x && sum_sq,
+    CNN_REQUIRE(x && (y || y_relu) && gamma && beta && moving_mean && moving_var && saved_mean && saved_var && sum_x && sum_sq,
                 "cnn_batchnorm2d_forward_from_sums: null pointer");
     CNN_REQUIRE(aligned16(x) && aligned16(y) && aligned16(y_relu) && count > 0.f,
                 "cnn_batchnorm2d_forward_from_sums: unaligned x / y / y_relu or count <= 0");

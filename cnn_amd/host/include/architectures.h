@@ -366,10 +366,21 @@ private:
     int comm_world = 1;
     data_type* sync_sums = nullptr;  // [C] + [C] + [C][4] all-reduce operands
     ReLU* fused_relu = nullptr;      // the ReLU layer right behind this one (set by the container): its output comes from the apply pass
+    // ---- fuse_pool_block: a training pass with a fused ReLU behind this layer writes ONLY the ReLU output (round 4); get_output() of
+    // this layer re-computes the normalised tensor from the recorded input, the saved batch statistics and the gamma / beta of that pass
+    mutable bool out_valid = true;
+    bool recompute_lost = false;
+    int last_B = 0;
+    const data_type* snapshot = nullptr;    // the container's copy of this layer's parameters BEFORE its latest SGD step ...
+    const bool* snapshot_active = nullptr;  // ... and whether that step came after the last forward pass
 
 public:
     void set_comm(void* rccl_comm, int world) { comm = rccl_comm; comm_world = world; }
     void set_fused_relu(ReLU* relu) { fused_relu = relu; }
+    std::vector<tensor> get_output() const override;
+    void materialize() const;
+    void set_param_snapshot(const data_type* snap, const bool* active) { snapshot = snap; snapshot_active = active; }
+    void params_of_last_forward_lost() { recompute_lost = true; }
     BatchNorm2D(std::string _name, const int _out_channels, const data_type _eps = 1e-5, const data_type _momentum = 0.1);
     ~BatchNorm2D() override;
     std::vector<tensor> forward(const std::vector<tensor>& input) override;

@@ -722,6 +722,14 @@ std::vector<tensor> BatchNorm2D::forward(const std::vector<tensor>& input) {
     const int C = out_channels;
     // the ReLU behind this layer gets its output from the same apply pass (both outputs are written)
     data_type* y_relu = (fused_relu != nullptr && fuse_layers) ? fused_relu->fused_forward_target(B, C, H, W) : nullptr;
+    // fuse_pool_block: a training pass does not write the normalised tensor when the ReLU output comes from the same kernel -- nothing in a
+    // train step reads it (ReLU::backward masks by its own output, backward() below recomputes from x and the saved statistics: 589 MB of
+    // stores per step of the ResNet-18-shaped stack); get_output() re-computes it on demand
+    const bool relu_only = y_relu != nullptr && !no_grad && fuse_pool_block;
+    data_type* y_out = relu_only ? nullptr : out_buf.base;
+    out_valid = !relu_only;
+    recompute_lost = false;
+    last_B = B;
     if (!no_grad && comm != nullptr && comm_world > 1) {
         // the batch is sharded over comm_world replicas: the reference normalises over the WHOLE batch (batchnorm2d.cpp:46-63),
         // so the per-channel sums are exchanged (two [C] all-reduces: mean first, then the squared deviations around the
@@ -735,7 +743,7 @@ std::vector<tensor> BatchNorm2D::forward(const std::vector<tensor>& input) {
         must(cnn_batchnorm2d_partial_sums(x, s1, count, s2, B, C, H, W, workspace, workspace_bytes, stream), "cnn_batchnorm2d_partial_sums");
         must(cnn_allreduce_grads(comm, s2, (size_t)C, stream), "cnn_allreduce_grads");
         if (y_relu)
-            must(cnn_batchnorm2d_forward_from_sums_relu(x, out_buf.base, y_relu, params, params + C, params + 2 * C, params + 3 * C,
+            must(cnn_batchnorm2d_forward_from_sums_relu(x, y_out, y_relu, params, params + C, params + 2 * C, params + 3 * C,
                                                         saved_stats, saved_stats + C, s1, s2, count, B, C, H, W, eps, momentum, stream),
                  "cnn_batchnorm2d_forward_from_sums_relu");
         else
@@ -745,7 +753,7 @@ std::vector<tensor> BatchNorm2D::forward(const std::vector<tensor>& input) {
         return output;
     }
     if (y_relu)
-        must(cnn_batchnorm2d_forward_relu(x, out_buf.base, y_relu, params, params + C, params + 2 * C, params + 3 * C, saved_stats,
+        must(cnn_batchnorm2d_forward_relu(x, y_out, y_relu, params, params + C, params + 2 * C, params + 3 * C, saved_stats,
                                           saved_stats + C, B, C, H, W, eps, momentum, no_grad ? 0 : 1, workspace, workspace_bytes,
                                           stream),
              "cnn_batchnorm2d_forward_relu");
@@ -755,6 +763,31 @@ std::vector<tensor> BatchNorm2D::forward(const std::vector<tensor>& input) {
                                      stream),
              "cnn_batchnorm2d_forward");
     return output;
+}
+
+// the normalised tensor of a pass that wrote only the ReLU output: gamma * ((x - mean) * inv_std) + beta with the batch statistics that pass
+// saved and the gamma / beta it used (the container's snapshot once its SGD step has run) -- the evaluation entry with the saved statistics in
+// the place of the moving ones runs the training pass' arithmetic (same expression, contraction off): bit-identical to a pass that writes it
+void BatchNorm2D::materialize() const {
+    if (out_valid) return;
+    assert(saved_input != nullptr && "get_output() of a fused-away tensor before any forward pass");
+    if (recompute_lost) {
+        std::fprintf(stderr, "cnn_amd host: %s: get_output() of a tensor the last forward pass did not write, after the parameters that pass used were "
+                             "overwritten (set from outside, or stepped twice): call forward() again, or set architectures::fuse_pool_block = false\n",
+                     name.c_str());
+        std::abort();
+    }
+    const int C = out_channels;
+    const data_type* gb = (snapshot != nullptr && snapshot_active != nullptr && *snapshot_active) ? snapshot : params;
+    must(cnn_batchnorm2d_forward(saved_input, out_buf.base, gb, gb + C, saved_stats, saved_stats + C, nullptr, nullptr, last_B, C, in_H, in_W, eps,
+                                 momentum, 0, workspace, workspace_bytes, stream),
+         "cnn_batchnorm2d_forward");
+    out_valid = true;
+}
+
+std::vector<tensor> BatchNorm2D::get_output() const {
+    materialize();
+    return Layer::get_output();
 }
 
 // batchnorm2d.cpp:98-158: gamma / beta gradients (sums over the batch, not averaged) and the data gradient written

@@ -141,6 +141,7 @@ void Sequential::bind(data_type* p, data_type* g) {
         // fuse_pool_block: Conv2D::get_output() of a fused-away tensor needs the parameters of the last forward pass -- the
         // container keeps them across its SGD step (cnn_sgd_update_keep / ..._sgd_keep write them here)
         if (auto* conv = dynamic_cast<Conv2D*>(layer.get())) conv->set_param_snapshot(param_prev + off, &params_stepped);
+        if (auto* bn = dynamic_cast<BatchNorm2D*>(layer.get())) bn->set_param_snapshot(param_prev + off, &params_stepped);
         off += n;
     }
     if (block_conv != nullptr) {
@@ -459,8 +460,10 @@ void Sequential::invalidate_filter_images() {
 void Sequential::parameters_changed() {
     params_stepped = false;    // (an outside write: there is no snapshot of what the last forward pass used)
     invalidate_filter_images();
-    for (auto& layer : layers_sequence)
+    for (auto& layer : layers_sequence) {
         if (auto* c = dynamic_cast<Conv2D*>(layer.get())) c->params_of_last_forward_lost();
+        if (auto* bn = dynamic_cast<BatchNorm2D*>(layer.get())) bn->params_of_last_forward_lost();
+    }
 }
 
 void Sequential::set_comm(void* rccl_comm, int world) {
@@ -534,8 +537,10 @@ void Sequential::update_gradients(const data_type learning_rate, const data_type
     assert(finalized && "the grad_scale form works on the flat arena: call finalize()");
     // (the old values go to the snapshot: Conv2D::get_output() of a fused-away tensor re-computes it with them)
     if (params_stepped)  // a second step without a forward pass in between: the snapshot would now receive already-stepped values
-        for (auto& layer : layers_sequence)
+        for (auto& layer : layers_sequence) {
             if (auto* c = dynamic_cast<Conv2D*>(layer.get())) c->params_of_last_forward_lost();
+            if (auto* bn = dynamic_cast<BatchNorm2D*>(layer.get())) bn->params_of_last_forward_lost();
+        }
     must(cnn_sgd_update_keep(param_arena, grad_arena, n_params, learning_rate, grad_scale, param_prev, stream), "cnn_sgd_update_keep");
     invalidate_filter_images();
     params_stepped = true;

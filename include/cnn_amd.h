@@ -329,8 +329,10 @@ int cnn_batchnorm2d_forward(const float* x, float* y, const float* gamma, const 
                             float eps, float momentum, int training, void* workspace, size_t workspace_bytes,
                             void* stream);
 /* BatchNorm2D followed by a ReLU layer (every BN site of the ResNet-shaped stack): y as above AND y_relu = relu(y)
- * (relu.cpp:25) from the same pass -- the ReLU layer's own kernel would read y again.  Both outputs are written, so both
- * layers' get_output() stay valid.  y_relu: 16-byte aligned, same shape as y. */
+ * (relu.cpp:25) from the same pass -- the ReLU layer's own kernel would read y again.  y_relu: 16-byte aligned, same shape as y.
+ * y may be NULL (round 4): then only y_relu is written -- a train step never reads the normalised tensor itself (ReLU::backward masks by
+ * its own output, BatchNorm2D::backward recomputes from x and saved_*); cnn_batchnorm2d_forward(training = 0) with saved_mean / saved_var
+ * in the place of the moving statistics re-computes y bit for bit when somebody asks for it (the host layer's get_output() does). */
 int cnn_batchnorm2d_forward_relu(const float* x, float* y, float* y_relu, const float* gamma, const float* beta,
                                  float* moving_mean, float* moving_var, float* saved_mean, float* saved_var, int B, int C, int H,
                                  int W, float eps, float momentum, int training, void* workspace, size_t workspace_bytes,

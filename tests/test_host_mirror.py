@@ -585,3 +585,50 @@ def test_train_step_without_the_input_gradient_changes_nothing_else():
         lib.cnnh_set_input_gradient(1)
     for (la, pa, ga), (lb, pb, gb) in zip(*res):
         assert la == lb and np.array_equal(pa, pb) and np.array_equal(ga, gb)
+
+
+@pytest.mark.gpu
+def test_batchnorm_relu_only_pass_keeps_the_normalised_tensor_observable():
+    """round 4: with a ReLU fused behind it, BatchNorm2D's training pass writes ONLY the ReLU output (architectures::fuse_pool_block);
+    get_output() of the BatchNorm2D layer re-computes the normalised tensor from the recorded input, the saved batch statistics and the gamma /
+    beta of that pass -- also after the SGD step has moved them.  Against the same net with fuse_pool_block off (every tensor written by the pass):
+    losses, parameters (incl. the moving statistics), gradients and EVERY layer's get_output() equal bit for bit over three steps; planes of
+    both BatchNorm kernel families (channel-resident: 12x12 x 32 channels at batch 6; general: 25x25 x 8 channels)"""
+    import torch
+
+    from cnn_amd import hostapi, stacks
+
+    spec = [("conv", 8, 3, 1, 1), ("bn",), ("relu",), ("pool", 2, 2), ("conv", 32, 3, 1, 1), ("bn",), ("relu",), ("conv", 16, 3, 2, 0), ("bn",), ("relu",),
+            ("linear", 3)]
+    in_shape = (3, 25, 25)
+    B = 6
+    x = uniform01(190, (B,) + in_shape)
+    labels = (np.arange(B) % 3).astype(np.int32)
+    xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    lib = hostapi.load()
+    nets = []
+    try:
+        for on in (1, 0):
+            lib.cnnh_set_fuse_pool_block(on)
+            net = hostapi.HostSequential(spec, in_shape)
+            net.set_params(stacks.he_init(net.layout, 77))
+            nets.append(net)
+        shapes = [(name, (B,) + tuple(ent["out"])) for name, ent in zip(nets[0].names, nets[0].layout) if len(ent["out"]) == 3]
+        assert any(n.startswith("bn_layer") for n, _ in shapes)
+        for step in range(3):
+            got = []
+            for on, net in zip((1, 0), nets):
+                lib.cnnh_set_fuse_pool_block(on)
+                net.train_step(xd, ld, 1e-2)
+                got.append((net.last_loss(), net.get_params(), net.get_grads(), [net.layer_output(n, shp) for n, shp in shapes]))
+            a, b = got
+            assert a[0] == b[0], (step, a[0], b[0])
+            assert np.array_equal(a[1], b[1]), f"step {step}: parameters"
+            assert np.array_equal(a[2], b[2]), f"step {step}: gradients"
+            for (name, _), u, v in zip(shapes, a[3], b[3]):
+                assert np.array_equal(u.view(np.uint32), v.view(np.uint32)), f"step {step}: get_output({name})"
+            assert np.abs(a[3][1]).max() > 0
+    finally:
+        lib.cnnh_set_fuse_pool_block(1)
+        for net in nets:
+            net.close()
