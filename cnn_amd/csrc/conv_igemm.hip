@@ -1263,7 +1263,7 @@ thread_local int g_forced_cfg = -1;  // >= 0: make_plan must use exactly this co
 // fewer staged bytes and fewer chunk barriers per MFMA; (b) 13 x 16 = 208 divides the 49 * 2^k pixel counts of 7 / 14 / 28 / 56 / 112-wide
 // layers almost evenly: 64 -> 64 56x56 at batch 64 is 242 workgroups (one round of 256 CUs) instead of 392 (136 CUs run two, 120 one).
 // 230 - 235: the wide tiles with the channel range split in 2 / 4 / 8 (planes of 7x7 .. 28x28 at batch 64 give 32 .. 122 wide tiles for 256 CUs)
-const int kTuneCandidates[] = {-1, 200, 201, 206, 208, 226, 222, 224, 215, 216, 219, 225, 0, 1, 22, 227, 202, 228, 229, 230, 231, 232, 233, 234, 235};
+const int kTuneCandidates[] = {-1, 200, 201, 206, 207, 208, 226, 222, 224, 215, 216, 219, 225, 0, 1, 22, 227, 202, 228, 229, 230, 231, 232, 233, 234, 235};  // (207: 4-channel chunks, the 3 -> 64 first layer of the VGG-shaped stack: 1 059 -> 853 us)
 
 int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, bool allow_dma = true, int shrink = 0) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
