@@ -300,6 +300,42 @@ def test_split_k_wide_tiles_equal_im2col(T, case, cfg, lib_option):
         assert T.equal(dxm, T.where(relu_in <= 0, T.zeros_like(dx), dx))
 
 
+@pytest.mark.parametrize("case,cfgs", [((64, 64, 56, 56, 64, 3, 1, 1), (228,)), ((64, 128, 28, 28, 128, 3, 1, 1), (229, 230)), ((64, 256, 14, 14, 256, 3, 1, 1), (231, 234)),
+                                       ((64, 512, 7, 7, 512, 3, 1, 1), (232, 235)), ((128, 512, 14, 14, 512, 3, 1, 1), (228, 229))],
+                         ids=lambda c: str(c).replace(" ", ""))
+def test_wide_and_split_tiles_at_the_stacks_full_sizes(T, case, cfgs, lib_option):
+    """BASELINE configs[3] / [4] at their stated batch sizes: the layers on which the tuner pins the wide / split-K tiles, every such
+    tile forced, forward and data gradient against the rule-based tile of the same kernel family (a different summation order: 1e-5
+    tensor-normalised) -- the full-size launches (242 workgroups of 64 x 832, 32 tiles x 8 channel ranges ...) that the small-batch oracle tests
+    above do not reach -- plus linearity of the data gradient in dy at full size"""
+    from cnn_amd import capi
+
+    B, Ci, H, W, Co, k, s, pad = case
+    g = T.Generator(device="cuda").manual_seed(13)
+    x = T.rand((B, Ci, H, W), generator=g, device="cuda") - 0.4
+    w = T.randn((Co, Ci, k, k), generator=g, device="cuda") * float(np.sqrt(2.0 / (Ci * k * k)))
+    b = T.randn((Co,), generator=g, device="cuda") * 0.1
+    lib_option("DGRAD_RD", "0")
+    conv = capi.Conv2d(*case)
+    dy = T.rand(conv.out_shape(), generator=g, device="cuda") * 2 - 1
+
+    def err(a, ref):
+        return float((a - ref).abs().max() / ref.abs().max())
+
+    lib_option("IGEMM_AUTOTUNE", "0")
+    y0, dx0 = conv.forward(x, w, b), conv.backward_data(dy, w)
+    for cfg in cfgs:
+        lib_option("IGEMM_CFG", str(cfg))
+        capi.kernel_timing(1)
+        y, dx = conv.forward(x, w, b), conv.backward_data(dy, w)
+        names = [key.split("|")[0] for key in capi.kernel_timing_report()]
+        capi.kernel_timing(0)
+        assert any(n.startswith("igemm_dma_kernel<16,2,13,") for n in names), names
+        assert err(y, y0) <= 1e-5 and err(dx, dx0) <= 1e-5, (cfg, err(y, y0), err(dx, dx0))
+        dx2 = conv.backward_data(dy * 2.0, w)  # exact in floating point: every product and partial sum doubles
+        assert T.equal(dx2, dx * 2.0)
+
+
 def test_dropout_layer_and_a_list_that_uses_it(T):
     """Dropout (dropout.cpp; row n4): the two kernels bit-exact against the oracle, and a layer list that contains the layer --
     the position the reference's own (commented-out) line alexnet.cpp:28 puts it: behind a convolution -- through the C++
