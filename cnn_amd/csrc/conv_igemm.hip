@@ -1875,7 +1875,7 @@ static int autotune_impl(const cnn_conv2d_desc* d, void* scratch, size_t scratch
         }
         int best = -1;
         float best_ms = 1e30f;
-        const float margin = 1.f - 0.001f * (float)CNN_OPT_INT("TUNE_MARGIN", 30);  // (per mille a later candidate has to win by; measurement switch)
+        const float margin = 1.f - 0.001f * (float)CNN_OPT_INT("TUNE_MARGIN", 0);  // (per mille a later candidate has to win by: 30 until the timings became best-of-three; VGG-shaped step 2 156-2 161 at 30, 2 165-2 172 at 0)
         const int excluded = CNN_OPT_INT("TUNE_EXCLUDE", -2);  // (measurement switch: one candidate the tuner must not pick)
         for (int c : kTuneCandidates) {
             if (c == excluded) continue;
