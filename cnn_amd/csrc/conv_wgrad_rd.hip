@@ -470,7 +470,9 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
     // flattened runs (see RdParams::flat): worth it when the rows do not divide into whole runs of 16
     p.flat = 0;
     p.m_w = magic_of(d->W);
-    if (!pooled && d->s == 1 && d->pad == 1 && d->W >= 16 && d->W % 16 != 0 && (long long)d->H * d->W < 65536 && !CNN_OPT_SET("RD_NOFLAT")) {
+    // (measurement switch RD_RL8: rows that are whole runs of 8 but not of 16 -- 56, 24, 40 -- as runs of 8 instead of flattened runs of 16)
+    const bool rl8_rows = !pooled && d->s == 1 && d->W > 8 && d->W % 8 == 0 && d->W % 16 != 0 && CNN_OPT_INT("RD_RL8", 0) != 0;
+    if (!rl8_rows && !pooled && d->s == 1 && d->pad == 1 && d->W >= 16 && d->W % 16 != 0 && (long long)d->H * d->W < 65536 && !CNN_OPT_SET("RD_NOFLAT")) {
         p.flat = 1;
         p.Wo = d->H * d->W;  // one "row" per image
         p.Ho = 1;
@@ -480,7 +482,7 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
     p.PHo = p.Ho / 2; p.PWo = p.Wo / 2;
     p.pmask = nullptr; p.pooled = nullptr;
     if (pooled && (p.PHo < 1 || p.PWo < 1 || d->Ci * 9 > 32)) return false;  // (POOLED kernels exist for one column tile)
-    pl->rl = p.Wo <= 8 ? 8 : 16;
+    pl->rl = (p.Wo <= 8 || rl8_rows) ? 8 : 16;
     p.rpr = (p.Wo + pl->rl - 1) / pl->rl;
     const long long runs = (long long)p.B * p.Ho * p.rpr;
     const long long chunks = (runs + 1) / 2;
