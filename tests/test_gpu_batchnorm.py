@@ -251,3 +251,36 @@ def test_sync_batchnorm_sharded_batch_equals_full_batch_oracle(T, shape, splits)
         mm2, mv2, y2, r2 = dev(T, mm0), dev(T, mv0), T.empty(shape, device="cuda"), T.empty(shape, device="cuda")
         bn2.forward_sync(xd, gd, bd, mm2, mv2, y2, lambda t: None, count, y_relu=r2)
         assert T.equal(y2, y1) and T.equal(mm2, mm) and T.equal(mv2, mv) and T.equal(r2, T.where(y2 >= 0, y2, T.zeros_like(y2)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(6, 8, 25, 25), (6, 32, 12, 12), (64, 64, 56, 56)], ids=str)
+def test_batchnorm_relu_only_output_and_its_recomputation(T, shape):
+    """round 4: cnn_batchnorm2d_forward_relu / _from_sums_relu with y = NULL write ONLY relu(y) -- bit-identical to the pass that writes both,
+    statistics included -- and the evaluation entry with the saved batch statistics in the place of the moving ones re-computes y bit for bit
+    (what BatchNorm2D::get_output() of the host layer relies on); general path, channel-resident path and a full-size site of configs[4]"""
+    from cnn_amd import capi
+
+    B, C, H, W = shape
+    g = T.Generator(device="cuda").manual_seed(5)
+    x = T.rand(shape, generator=g, device="cuda") * 3 - 1
+    gamma = T.rand((C,), generator=g, device="cuda") + 0.5
+    beta = T.rand((C,), generator=g, device="cuda") - 0.5
+    for sync in (False, True):
+        res = []
+        for y_given in (True, False):
+            bn = capi.BatchNorm2d(B, C, H, W)
+            mm, mv = T.zeros(C, device="cuda"), T.zeros(C, device="cuda")
+            y = T.full(shape, 7.0, device="cuda") if y_given else None
+            r = T.full(shape, 7.0, device="cuda")
+            if sync:
+                bn.forward_sync(x, gamma, beta, mm, mv, y, lambda t: t, float(B * H * W), y_relu=r)
+            else:
+                bn.forward(x, gamma, beta, mm, mv, y, True, y_relu=r)
+            res.append((y, r, mm, mv, bn.saved_mean.clone(), bn.saved_var.clone(), bn))
+        (y, r, mm, mv, sm, sv, bn), (_, r2, mm2, mv2, sm2, sv2, _) = res
+        assert T.equal(r, T.clamp_min(y, 0)) and T.equal(r2, r)
+        assert T.equal(mm, mm2) and T.equal(mv, mv2) and T.equal(sm, sm2) and T.equal(sv, sv2)
+        again = T.full(shape, 7.0, device="cuda")
+        bn.forward(x, gamma, beta, sm.clone(), sv.clone(), again, False)  # evaluation arithmetic on the saved batch statistics
+        assert T.equal(again, y), float((again - y).abs().max())
