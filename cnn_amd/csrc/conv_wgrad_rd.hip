@@ -96,7 +96,7 @@ __device__ __forceinline__ f4u load4(const float* __restrict__ p, int nvalid) {
 
 template <int S, int NT, int RL, bool POOLED, int PAD, bool FLAT = false>
 __device__ __forceinline__ void wgrad_rd_body(const RdParams& p) {
-    static_assert(!FLAT || (S == 1 && PAD == 1 && RL == 16), "flattened runs: stride 1, pad 1, runs of 16");
+    static_assert(!FLAT || (S == 1 && PAD == 1), "flattened runs: stride 1, pad 1 (runs of 16, or of 8 for rows of 9 .. 15 pixels: RL <= W)");
     static_assert(PAD == 0 || (PAD == 1 && !POOLED), "padding 0 or 1; the pooled-domain first block is unpadded");
     constexpr int WL = S * RL;  // floats of x a lane needs per chunk and tile
     __shared__ float red[32][NT * 32 + 1];  // (+1: bank padding; the column doubles as the bias-gradient slot)
@@ -472,7 +472,11 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
     p.m_w = magic_of(d->W);
     // (measurement switch RD_RL8: rows that are whole runs of 8 but not of 16 -- 56, 24, 40 -- as runs of 8 instead of flattened runs of 16)
     const bool rl8_rows = !pooled && d->s == 1 && d->W > 8 && d->W % 8 == 0 && d->W % 16 != 0 && CNN_OPT_INT("RD_RL8", 0) != 0;
-    if (!rl8_rows && !pooled && d->s == 1 && d->pad == 1 && d->W >= 16 && d->W % 16 != 0 && (long long)d->H * d->W < 65536 && !CNN_OPT_SET("RD_NOFLAT")) {
+    // (round 4, measurement switch RD_FLAT8=1) rows of 9 .. 15 pixels (the 14x14 layers) as flattened runs of 8 -- 25 runs of 8 cover an image's 196
+    // pixels (98 % live k-slots) where one run of 16 per row of 14 leaves 12.5 % dead.  Measured: 512 -> 512 14x14 at batch 128 1 420 -> 1 372 us,
+    // 256 -> 256 14x14 at batch 64 209 -> 221 us (twice the chunks, each with half the MFMAs behind its loads): off by default
+    const bool flat8 = !pooled && d->s == 1 && d->pad == 1 && d->W > 8 && d->W < 16 && d->W % 8 != 0 && CNN_OPT_INT("RD_FLAT8", 0) != 0 && !CNN_OPT_SET("RD_NOFLAT");
+    if (flat8 || (!rl8_rows && !pooled && d->s == 1 && d->pad == 1 && d->W >= 16 && d->W % 16 != 0 && (long long)d->H * d->W < 65536 && !CNN_OPT_SET("RD_NOFLAT"))) {
         p.flat = 1;
         p.Wo = d->H * d->W;  // one "row" per image
         p.Ho = 1;
@@ -482,7 +486,7 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
     p.PHo = p.Ho / 2; p.PWo = p.Wo / 2;
     p.pmask = nullptr; p.pooled = nullptr;
     if (pooled && (p.PHo < 1 || p.PWo < 1 || d->Ci * 9 > 32)) return false;  // (POOLED kernels exist for one column tile)
-    pl->rl = (p.Wo <= 8 || rl8_rows) ? 8 : 16;
+    pl->rl = (p.Wo <= 8 || rl8_rows || flat8) ? 8 : 16;
     p.rpr = (p.Wo + pl->rl - 1) / pl->rl;
     const long long runs = (long long)p.B * p.Ho * p.rpr;
     const long long chunks = (runs + 1) / 2;
@@ -572,8 +576,8 @@ int wgrad_rd_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, f
 #define RD(S_, NT_, RL_)                                                                                                   \
     do {                                                                                                                   \
         if (d->pad == 0) CNN_KLAUNCH(s, name, (wgrad_rd_kernel<S_, NT_, RL_, false><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d)); \
-        else if (S_ == 1 && RL_ == 16 && pl.p.flat)                                                                       \
-            CNN_KLAUNCH(s, name, (wgrad_rd_kernel_p1<S_, NT_, RL_, (S_ == 1 && RL_ == 16)><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d)); \
+        else if (S_ == 1 && pl.p.flat)                                                                                     \
+            CNN_KLAUNCH(s, name, (wgrad_rd_kernel_p1<S_, NT_, RL_, (S_ == 1)><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d)); \
         else CNN_KLAUNCH(s, name, (wgrad_rd_kernel_p1<S_, NT_, RL_, false><<<grid, 256, 0, s>>>(pl.p)), CONV_TAG(d));        \
     } while (0)
 #define RD_NT(S_, RL_)                                                     \

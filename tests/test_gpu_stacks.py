@@ -336,6 +336,27 @@ def test_wide_and_split_tiles_at_the_stacks_full_sizes(T, case, cfgs, lib_option
         assert T.equal(dx2, dx * 2.0)
 
 
+@pytest.mark.parametrize("case", [(7, 24, 14, 13, 40, 3, 1, 1), (3, 16, 9, 15, 32, 3, 1, 1), (5, 32, 14, 14, 64, 3, 1, 1)], ids=str)
+def test_wgrad_flattened_runs_of_8_equal_im2col(T, case, lib_option):
+    """the weight gradient's flattened runs of 8 for rows of 9 .. 15 pixels (CNN_AMD_RD_FLAT8=1, a measurement switch: DESIGN 9) against the im2col
+    fallback, the guarded head / tail chunks included"""
+    from cnn_amd import capi
+
+    B, Ci, H, W, Co, k, s, pad = case
+    g = T.Generator(device="cuda").manual_seed(17)
+    x = T.rand((B, Ci, H, W), generator=g, device="cuda") - 0.5
+    lib_option("RD_FLAT8", "1")
+    conv = capi.Conv2d(*case)
+    dy = T.rand(conv.out_shape(), generator=g, device="cuda") * 2 - 1
+    capi.kernel_timing(1)
+    gw, gb = conv.backward_weight(x, dy, float(B))
+    names = [key.split("|")[0] for key in capi.kernel_timing_report()]
+    capi.kernel_timing(0)
+    assert any(n.endswith(",8,p1,flat>") for n in names), names
+    gwr, gbr = conv.backward_weight_im2col(x, dy, float(B))
+    assert float((gw - gwr).abs().max() / gwr.abs().max()) <= REL_TOL and float((gb - gbr).abs().max() / gbr.abs().max()) <= REL_TOL
+
+
 def test_dropout_layer_and_a_list_that_uses_it(T):
     """Dropout (dropout.cpp; row n4): the two kernels bit-exact against the oracle, and a layer list that contains the layer --
     the position the reference's own (commented-out) line alexnet.cpp:28 puts it: behind a convolution -- through the C++
