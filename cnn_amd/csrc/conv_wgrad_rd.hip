@@ -512,6 +512,10 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
     const long long colblocks = (long long)pl->ngroups * pl->mtiles, slots = env > 0 ? env : 2 * num_cus();
     long long want = slots / colblocks;
     if (want < 1) want = 1;
+    // (round 4) long pixel ranges: one round of ~500 workgroups that each run for milliseconds ends with the slowest of them -- three rounds of
+    // shorter ones balance themselves.  256 -> 256 56x56 at batch 128: 5 014 -> 4 714 us, 128 -> 256 56x56: 2 510 -> 2 406 us
+    // (tools/probes/wgrad_blocks.py, SWEEP=xcd); the batch-64 layers of the ResNet-shaped stack (< 100 chunks per workgroup) keep one round
+    if (env <= 0 && chunks / want >= 1024 && !CNN_OPT_SET("RD_ONE_ROUND")) want = 3 * slots / colblocks;
     if (env <= 0 && colblocks * want * 8 < slots * 7) {
         // wide layers (Ci*9/32/NT column groups x Co/32 row tiles is already comparable to the chip): pick the split whose
         // workgroup count fills whole rounds of the resident slots best (384 column blocks alone would leave a quarter idle)
@@ -519,7 +523,8 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
         for (long long k = 1; k <= 8; ++k) {
             const long long blocks = colblocks * k, rounds = (blocks + slots - 1) / slots;
             const double fill = (double)blocks / (double)(rounds * slots);
-            if (fill > best + 1e-9) { best = fill; want = k; }
+            // (equal fill: the finer split as long as a workgroup keeps >= 100 chunks -- 512 -> 512 14x14 at batch 128: 1 451 -> 1 387 us)
+            if (fill > best + 1e-9 || (fill > best - 1e-9 && chunks / k >= 100 && !CNN_OPT_SET("RD_ONE_ROUND"))) { best = fill; want = k; }
         }
     }
     if (want > chunks) want = chunks;
