@@ -515,7 +515,8 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
     // (round 4) long pixel ranges: one round of ~500 workgroups that each run for milliseconds ends with the slowest of them -- three rounds of
     // shorter ones balance themselves.  256 -> 256 56x56 at batch 128: 5 014 -> 4 714 us, 128 -> 256 56x56: 2 510 -> 2 406 us
     // (tools/probes/wgrad_blocks.py, SWEEP=xcd); the batch-64 layers of the ResNet-shaped stack (< 100 chunks per workgroup) keep one round
-    if (env <= 0 && chunks / want >= 1024 && !CNN_OPT_SET("RD_ONE_ROUND")) want = 3 * slots / colblocks;
+    // (not where that means > 64 pixel ranges -- 64 -> 128 112x112: 128 slabs, a two-stage reduction, 2 376 against 2 350 us)
+    if (env <= 0 && chunks / want >= 1024 && 3 * slots / colblocks <= 64 && !CNN_OPT_SET("RD_ONE_ROUND")) want = 3 * slots / colblocks;
     if (env <= 0 && colblocks * want * 8 < slots * 7) {
         // wide layers (Ci*9/32/NT column groups x Co/32 row tiles is already comparable to the chip): pick the split whose
         // workgroup count fills whole rounds of the resident slots best (384 column blocks alone would leave a quarter idle)

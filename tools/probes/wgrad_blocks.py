@@ -13,7 +13,9 @@ B = int(os.environ.get("B", 64))
 CASES = [(512, 7, 7, 512, (0, 384, 768, 1152)), (256, 14, 14, 256, (0, 96, 192, 288, 384)), (128, 28, 28, 128, (0, 120, 240, 384)), (64, 56, 56, 64, (0, 252, 384, 768))]
 if os.environ.get("SWEEP") == "xcd":  # pixel-range counts that are multiples of 8: one XCD's L2 per pixel range
     CASES = [(256, 14, 14, 256, (0, 768, 1536)), (128, 28, 28, 128, (0, 192, 384, 768)), (64, 56, 56, 64, (0, 48, 96, 192, 384, 768)), (512, 7, 7, 512, (0, 3072))]
-    if os.environ.get("B") == "128":
+    if os.environ.get("B") == "128" and os.environ.get("MORE"):
+        CASES = [(256, 56, 56, 256, (480, 0, 480, 0)), (64, 112, 112, 128, (504, 0, 504, 0, 1008, 504)), (128, 56, 56, 256, (480, 0, 480, 0))]
+    elif os.environ.get("B") == "128":
         CASES = [(512, 14, 14, 512, (0, 3072)), (512, 28, 28, 512, (0, 3072)), (256, 28, 28, 512, (0, 1536, 3072)), (256, 56, 56, 256, (0, 768, 1536)), (128, 56, 56, 256, (0, 384, 768, 1536))]
 for (Ci, H, W, Co, slots) in CASES:
     case = (B, Ci, H, W, Co, 3, 1, 1)
