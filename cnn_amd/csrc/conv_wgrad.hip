@@ -29,6 +29,8 @@ int os_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, f
 int c11_wgrad_slots(const cnn_conv2d_desc* d);   // conv_1x1.hip: 1x1 convolutions (stride 1 / 2): split-K GEMM over the sub-sampled plane
 int c11_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
 int stem_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
+int sp_wgrad_slots(const cnn_conv2d_desc* d);  // conv_wgrad_sp.hip: small planes (7x7 .. 56x56), 3x3 / stride 1 / pad 1, LDS-staged output-stationary
+int sp_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
 int wgrad_rd_slots(const cnn_conv2d_desc* d);  // conv_wgrad_rd.hip: register-direct MFMA kernel (3x3, stride 1/2, pad 0)
 int wgrad_rd_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
 int wgrad_rd_pooled_slots(const cnn_conv2d_desc* d);
@@ -777,6 +779,9 @@ size_t cnn_conv2d_workspace_bytes(const cnn_conv2d_desc* d) {
     const int oss = os_wgrad_slots(d);
     const size_t osw = oss ? (size_t)(oss + (oss + 63) / 64) * d->Co * (d->Ci * 9 + 1) : 0;
     if (osw > m) m = osw;
+    const int sps = sp_wgrad_slots(d);
+    const size_t spw = sps ? (size_t)(sps + (sps + 63) / 64) * d->Co * (d->Ci * 9 + 1) : 0;
+    if (spw > m) m = spw;
     const int c1s = c11_wgrad_slots(d);
     const size_t c1w = c1s ? (size_t)(c1s + (c1s + 63) / 64) * d->Co * (d->Ci + 1) : 0;
     if (c1w > m) m = c1w;
@@ -884,6 +889,16 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
             char tago[160];
             snprintf(tago, sizeof(tago), CONV_TAG(d));
             return reduce_slabs(so, (const float*)ws, oss, n, (float*)ws + (size_t)oss * n, gw, divisor, tago, d->Ci * 9, gb);
+        }
+    }
+    if (const int sps = sp_wgrad_slots(d)) {
+        const size_t n = (size_t)d->Co * (d->Ci * 9 + 1), need_p = (size_t)(sps + (sps + 63) / 64) * n * sizeof(float);
+        if (ws_bytes >= need_p) {
+            hipStream_t sp = as_stream(stream);
+            if (int rc = sp_wgrad_launch(d, x, dy, (float*)ws, sp)) return rc;
+            char tagp[160];
+            snprintf(tagp, sizeof(tagp), CONV_TAG(d));
+            return reduce_slabs(sp, (const float*)ws, sps, n, (float*)ws + (size_t)sps * n, gw, divisor, tagp, d->Ci * 9, gb);
         }
     }
     if (rd_wanted(d)) {

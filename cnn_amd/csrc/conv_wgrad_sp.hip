@@ -1,0 +1,406 @@
+// conv_wgrad_sp.hip -- Conv2D weight / bias gradient (cpu/src/conv2d.cpp:117-159) for 3x3 / stride-1 / pad-1 layers with SMALL
+// PLANES (7x7 ... 56x56: the deep layers of the ResNet- / VGG-shaped stacks) as an output-stationary GEMM with both operands
+// staged through LDS by DMA:
+//     gw[co][ci][kx][ky] = sum_{b,r,c} dy[b][co][r][c] * x[b][ci][r + kx - 1][c + ky - 1]        (bias gradient: sum of dy)
+//
+// Why another kernel (round 5): the register-direct kernel (conv_wgrad_rd.hip) lets every lane stream its own 16-byte windows from
+// L1 -- 64 different cache lines per load instruction, a 32-channel M tile, every x value fetched once per tap and per M tile.  With
+// K = B*Ho*Wo in the hundreds of thousands (VGG shapes at batch 128) it reaches 100 TFLOP/s; on the batch-64 layers of the
+// ResNet-shaped stack it is bound by the texture path's line rate: 40-45 TFLOP/s (profiles/r04/bench_resnet18_breakdown.txt).
+//
+// Here a workgroup of four waves (2 x 2) owns a 64 (co) x 64 (ci) x 9 (taps) tile of the gradient -- a wave 32 co x 32 ci x 9 taps
+// = nine 32x32 accumulators of v_mfma_f32_32x32x2_f32 -- and walks STAGES of the reduction dimension (pixels).  MFMA column n of the
+// tile of tap (kx, ky) is input channel ci0 + n: the B operand of lane (n, kg) is x_lds[ci n][pixel + tap offset], so the 32 lanes of
+// a ds_read_b32 hit 32 different channel planes and the nine taps of a pixel are nine reads of ONE staged plane (x is fetched from
+// HBM / L2 once per stage and tile, fully coalesced, not once per tap).  The two k-slots of an MFMA step (kg = lane / 32) are two
+// pixels a CONSTANT LDS distance apart, so all LDS addresses are one per-lane base + compile-time immediates:
+//   * PAIR (7x7 planes): a stage = two samples, kg = sample parity.  The 64-channel block of a sample is ONE contiguous run of
+//     64*49 floats in HBM and is copied as it lies (plane stride 49: odd, conflict-free reads); taps that leave the plane are not
+//     multiplied at all (361 of 441 MFMAs per sample pair remain -- 18 % of the nominal FLOPs are multiplications by padding).
+//   * HALF (14 / 28 / 56 wide planes): a stage = RU output rows of one sample (with their two halo rows of x), kg = left / right half
+//     of the row.  Rows outside the image are staged as zeros; the one tap column that leaves the image on the left (right) exists
+//     only for the kg = 0 (1) lanes and is masked there by a select.
+// A 7-pixel SEGMENT of a row is the unit of the unrolled inner loop: 7 A values, three 9-float windows of x, 63 MFMAs; the next
+// segment's operands are read while this one's MFMAs issue.  Two LDS buffers: the DMA of stage s+1 (global_load_lds, 16 bytes per
+// lane where rows are 16-byte multiples, else 4) is issued in slices between the segments of stage s; one barrier per stage.
+// Output: slabs[blockIdx.x][Co][Ci*9 + 1] like the register-direct kernel (reduce_slabs adds the pixel ranges in a fixed order);
+// the bias gradient is accumulated on the VALU from the A registers.
+#include <cstdlib>
+
+#include "common.h"
+
+using namespace cnn_amd;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+
+struct SpParams {
+    const float* x;
+    const float* dy;
+    float* slabs;  // [gridDim.x][Co][pitch]
+    int B, Ci, Co, H;
+    int Ntot, pitch;  // Ci*9, Ntot + 1 (column Ntot = bias gradient)
+    int nrb;          // HALF: row blocks per sample (H / RU)
+    int stages_total, stages_per_block;
+    int dbg;  // CNN_AMD_SP_DBG=9: workgroup 0 prints its shader-cycle count and the clock it ran at
+};
+
+// one LDS-DMA instruction through a buffer descriptor: lane l moves U floats from base + voff(l) + soff to lds + l*U.  A lane whose
+// voff lies outside the buffer moves ZEROS (probed on MI355X: tools/probes/buflds_probe.cpp) -- that is how pad floats, channels
+// behind the tensor, halo rows outside the image and the missing second sample of an odd batch are staged: every instruction runs
+// with all 64 lanes and no branch around it.
+constexpr unsigned kOob = 0x80000000u;
+template <int U>
+__device__ __forceinline__ void blds(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float* lds) {
+    if constexpr (U == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_ptr)lds, 16, (int)voff, (int)soff, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_ptr)lds, 4, (int)voff, (int)soff, 0, 0);
+}
+
+constexpr int kTile = 64;  // channels per workgroup tile, both operands
+
+template <int W, int RU, bool PAIR, int U>
+struct SpGeom {
+    static_assert(U == 1 || U == 4, "DMA unit: 4 or 16 bytes");
+    static_assert(PAIR ? W % 7 == 0 : W % 14 == 0, "rows are whole 7-pixel segments (per half)");
+    static constexpr int HALFW = PAIR ? W : W / 2;     // pixels of a row per k-group
+    static constexpr int NSEG = HALFW / 7;             // segments per row and k-group
+    static constexpr int XROWS = PAIR ? RU : RU + 2;   // staged input rows per plane (HALF: with the halo rows)
+    static constexpr int XLEN = XROWS * W, DLEN = RU * W;
+    // plane strides: odd for 4-byte units (32 lanes = 32 banks); a multiple of 4 with an odd piece count for 16-byte units (4-way)
+    static constexpr int stride_for(int len) {
+        return U == 1 ? (len | 1) : ((((len + 3) / 4) & 1) ? (len + 3) / 4 * 4 : (len + 3) / 4 * 4 + 4);
+    }
+    static constexpr int QX = PAIR ? XLEN : stride_for(XLEN);
+    static constexpr int QD = PAIR ? DLEN : stride_for(DLEN);
+    static_assert(!PAIR || ((XLEN & 1) && (kTile * XLEN) % 4 == 0), "PAIR: odd plane, 16-byte multiple per 64-channel block");
+    static constexpr int NU = PAIR ? 2 : 1;            // samples per stage
+    // DMA instructions (64 lanes x U floats) per stage
+    static constexpr int PPX = QX / U, PPD = QD / U;                     // HALF: pieces per plane (pad pieces included)
+    static constexpr int NIX = PAIR ? (kTile * XLEN / U + 63) / 64 : PPX;  // per image (PAIR: per sample)
+    static constexpr int NID = PAIR ? (kTile * DLEN / U + 63) / 64 : PPD;
+    static constexpr int NIWX = (NIX + 3) / 4, NIWD = (NID + 3) / 4;     // per wave
+    static constexpr int NIW = NU * (NIWX + NIWD);
+    // a sample's image holds whole DMA instructions: the lanes behind the last float of the block write zeros (see blds)
+    static constexpr int XS = NIX * 64 * U, DS = NID * 64 * U;           // floats per sample (HALF: == 64 planes)
+    static_assert(PAIR || (XS == kTile * QX && DS == kTile * QD), "HALF: the planes are whole instructions");
+    static constexpr int DIMG = NU * DS, XIMG = NU * XS;                 // floats; a buffer = [D image][X image]
+    static constexpr int BUF = (DIMG + XIMG + 3) & ~3;
+    static constexpr int DUMP = 2 * BUF;               // 4 waves x 64 lanes x U floats behind the buffers: where the DMA slots a wave has no
+                                                       // instruction for put their (zero) data
+    static constexpr int NSEGS = RU * NSEG;                             // segments per stage
+    static constexpr int PER_SEG = (NIW + NSEGS - 1) / NSEGS;           // DMA slots issued per segment
+    static constexpr int OP = kTile * 9 + 1;                            // epilogue: LDS row pitch (odd)
+    static constexpr size_t epi_bytes = (size_t)(32 * OP + 64) * sizeof(float);
+    static constexpr size_t buf_bytes = (size_t)(2 * BUF + 4 * 64 * U) * sizeof(float);
+    static constexpr size_t lds_bytes = buf_bytes > epi_bytes ? buf_bytes : epi_bytes;
+    static_assert(lds_bytes <= 160 * 1024, "LDS plan");
+};
+
+template <int W, int RU, bool PAIR, int U>
+__global__ __launch_bounds__(256) void wgrad_sp_kernel(const SpParams p) {
+    using G = SpGeom<W, RU, PAIR, U>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ci0 = blockIdx.y * kTile, co0 = blockIdx.z * kTile;
+    const int nci = p.Ci - ci0 < kTile ? p.Ci - ci0 : kTile, nco = p.Co - co0 < kTile ? p.Co - co0 : kTile;
+    const int H = p.H, HW = H * W;
+    const long long dbg_e0 = p.dbg == 9 ? wall_clock64() : 0;
+
+    // everything the DMA never writes (pad floats, planes of channels behind Ci / Co) reads as zero
+    for (int i = tid * 4; i < 2 * G::BUF + 4 * 64 * U; i += 1024) *(float4*)(smem + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int s_lo = blockIdx.x * p.stages_per_block;
+    const int s_hi = s_lo + p.stages_per_block < p.stages_total ? s_lo + p.stages_per_block : p.stages_total;
+
+    // ---- HALF: this wave's share of a stage's DMA, decoded once: the lane's byte offset relative to (channel ci0 / co0, staged row 0)
+    //      of the sample, bit 0 set: top halo row, bit 1: bottom halo row (x only; offsets are multiples of 4).  kOob: nothing to move
+    //      (pad piece / channel behind the tensor / no instruction for this wave).
+    unsigned dx_desc[PAIR ? 1 : G::NIWX], dd_desc[PAIR ? 1 : G::NIWD];
+    if constexpr (!PAIR) {
+        constexpr int RP = W / U;  // pieces per row
+#pragma unroll
+        for (int i = 0; i < G::NIWX; ++i) {
+            const int j = i * 4 + wave, q = j * 64 + lane;
+            const int plane = q / G::PPX, e = q - plane * G::PPX;
+            const int rowl = e / RP, colp = e - rowl * RP;
+            dx_desc[i] = (j < G::NIX && e < G::XLEN / U && plane < nci)
+                             ? ((unsigned)(plane * HW + rowl * W + colp * U) * 4u) | (rowl == 0 ? 1u : 0u) | (rowl == RU + 1 ? 2u : 0u) : kOob;
+        }
+#pragma unroll
+        for (int i = 0; i < G::NIWD; ++i) {
+            const int j = i * 4 + wave, q = j * 64 + lane;
+            const int plane = q / G::PPD, e = q - plane * G::PPD;
+            dd_desc[i] = (j < G::NID && e < G::DLEN / U && plane < nco) ? (unsigned)(plane * HW + e * U) * 4u : kOob;
+        }
+    }
+    (void)dx_desc; (void)dd_desc;
+    __syncthreads();
+    // x is addressed from one row in front of the tensor (never fetched: the top halo row of row block 0 is always masked), so that the
+    // scalar offset of a stage is never negative
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - (PAIR ? 0 : W)), 0,
+                                                                         (int)(((unsigned)p.B * p.Ci * HW + (PAIR ? 0 : W)) * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)p.B * p.Co * HW * 4u), 0x00020000);
+
+    // slot k of the DMA of a stage into buffer `buf` (k is a compile-time constant at every call site).  PAIR: `sb` = first sample of
+    // the stage; HALF: `sb` = sample, `r0` = first output row
+    float* const dump = smem + G::DUMP + wave * 64 * U;
+    auto dma_slot = [&](int k, int sb, int r0, float* buf) {
+        if constexpr (PAIR) {
+            // [sample 0: X | D][sample 1: X | D]; a sample's 64-channel block is one contiguous run, copied as it lies
+            const int u = k / (G::NIWX + G::NIWD), kk = k - u * (G::NIWX + G::NIWD);
+            const bool isx = kk < G::NIWX;
+            const int j = (isx ? kk : kk - G::NIWX) * 4 + wave;
+            const int b = sb + u;
+            const int q = j * 64 + lane;
+            const bool have = j < (isx ? G::NIX : G::NID);
+            float* d = have ? buf + (isx ? G::DIMG + u * G::XS : u * G::DS) + j * 64 * U : dump;
+            const int len = (isx ? nci : nco) * G::XLEN;  // (XLEN == DLEN: whole planes)
+            unsigned voff = (have && q * U < len) ? (unsigned)q * U * 4u : kOob;
+            voff |= b < p.B ? 0u : kOob;  // (odd batch: the last stage's second sample)
+            const unsigned soff = (unsigned)(b * (isx ? p.Ci : p.Co) + (isx ? ci0 : co0)) * (unsigned)(G::XLEN * 4);
+            blds<U>(isx ? xrs : drs, voff, soff, d);
+        } else {
+            const bool isx = k < G::NIWX;
+            const int i = isx ? k : k - G::NIWX;
+            const int j = i * 4 + wave;
+            float* d = j < (isx ? G::NIX : G::NID) ? buf + (isx ? G::DIMG : 0) + j * 64 * U : dump;
+            if (isx) {
+                // halo rows outside the image (the first / last row block of a sample) are staged as zeros
+                const unsigned desc = dx_desc[isx ? i : 0];
+                const unsigned bad = (r0 == 0 ? 1u : 0u) | (r0 + RU >= H ? 2u : 0u);
+                const unsigned voff = (desc & bad) ? kOob : desc & ~3u;
+                blds<U>(xrs, voff, (unsigned)((sb * p.Ci + ci0) * HW + r0 * W) * 4u, d);
+            } else {
+                blds<U>(drs, dd_desc[isx ? 0 : i], (unsigned)((sb * p.Co + co0) * HW + r0 * W) * 4u, d);
+            }
+        }
+    };
+
+    // ---- per-lane operand bases (floats inside a buffer)
+    // PAIR: kg = sample parity.  HALF: kg = half of the row; window element j of segment sg is column kg*HALFW + 7*sg + j - 1
+    const int a_base = PAIR ? kg * G::DS + (wm * 32 + m) * G::QD : (wm * 32 + m) * G::QD + kg * G::HALFW;
+    const int b_base = G::DIMG + (PAIR ? kg * G::XS + (wn * 32 + m) * G::QX : (wn * 32 + m) * G::QX + kg * G::HALFW - 1);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+
+    // operands of one segment: A = 7 consecutive dy values, B = three windows of x (PAIR: elements 1..7 only -- columns -1 and W
+    // do not exist and their taps are skipped)
+    struct Ops {
+        float a[7];
+        float w[3][9];
+    };
+    auto read_ops = [&](Ops& o, const float* buf, int rr, int sg) {
+        const float* ap = buf + a_base + rr * W + sg * 7;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) o.a[t] = ap[t];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xr = PAIR ? rr + kx - 1 : rr + kx;  // staged row of this tap row
+            if (PAIR && (xr < 0 || xr >= RU)) continue;
+            const float* bp = buf + b_base + xr * W + sg * 7 - (PAIR ? 1 : 0);
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                if (PAIR && ((sg == 0 && j == 0) || (sg == G::NSEG - 1 && j == 8))) continue;
+                o.w[kx][j] = bp[j];
+            }
+        }
+    };
+    // (the DMA slots of the segment are issued between its MFMAs: slot group t in front of the MFMAs of pixel t)
+    auto seg_mfma = [&](const Ops& o, int rr, int sg, auto&& slots) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            slots(t);
+            bsum += o.a[t];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                if (PAIR && (rr + kx - 1 < 0 || rr + kx - 1 >= RU)) continue;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int j = t + ky;
+                    const bool left = sg == 0 && j == 0, right = sg == G::NSEG - 1 && j == 8;
+                    if (PAIR && (left || right)) continue;
+                    float bv = o.w[kx][j];
+                    if (!PAIR && left) bv = kg == 0 ? 0.f : bv;
+                    if (!PAIR && right) bv = kg == 1 ? 0.f : bv;
+                    acc[kx * 3 + ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[t], bv, acc[kx * 3 + ky], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    const long long dbg_t0 = p.dbg == 9 ? clock64() : 0, dbg_w0 = p.dbg == 9 ? wall_clock64() : 0;
+    // stage s -> (first sample, first output row)
+    int sb = PAIR ? 2 * s_lo : s_lo / p.nrb, r0 = PAIR ? 0 : (s_lo - sb * p.nrb) * RU;
+    if (s_lo < s_hi) {
+#pragma unroll
+        for (int k = 0; k < G::NIW; ++k) dma_slot(k, sb, r0, smem + (s_lo & 1) * G::BUF);
+    }
+    constexpr int PER_T = (G::PER_SEG + 6) / 7;  // DMA slots in front of one pixel's MFMAs
+    for (int s = s_lo; s < s_hi; ++s) {
+        // every wave waits for ITS OWN outstanding DMA (stage s), then the barrier publishes them and guarantees that every wave is
+        // done reading the other buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float* cur = smem + (s & 1) * G::BUF;
+        float* nxt = smem + ((s + 1) & 1) * G::BUF;
+        // the stage behind this one (behind the last one: that one again -- a harmless reload instead of a branch around every slot)
+        int sbn = sb, r0n = r0;
+        if (s + 1 < s_hi) {
+            if (PAIR) sbn = sb + 2;
+            else if (r0 + RU < H) r0n = r0 + RU;
+            else { r0n = 0; sbn = sb + 1; }
+        }
+        Ops ops[2];
+        read_ops(ops[0], cur, 0, 0);
+#pragma unroll
+        for (int sgi = 0; sgi < G::NSEGS; ++sgi) {
+            const int rr = sgi / G::NSEG, sg = sgi % G::NSEG;
+            if (sgi + 1 < G::NSEGS) read_ops(ops[(sgi + 1) & 1], cur, (sgi + 1) / G::NSEG, (sgi + 1) % G::NSEG);
+            seg_mfma(ops[sgi & 1], rr, sg, [&](int t) {
+#pragma unroll
+                for (int k = sgi * G::PER_SEG + t * PER_T; k < sgi * G::PER_SEG + (t + 1) * PER_T && k < (sgi + 1) * G::PER_SEG && k < G::NIW; ++k)
+                    dma_slot(k, sbn, r0n, nxt);
+            });
+        }
+        sb = sbn;
+        r0 = r0n;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the reload behind the last stage)
+    const long long dbg_w1 = p.dbg == 9 ? wall_clock64() : 0;
+    const long long dbg_c1 = p.dbg == 9 ? clock64() : 0;
+
+    // ---- epilogue: the tile goes through LDS in two halves of 32 output channels, then to the slab in whole rows
+    float* slab = p.slabs + (size_t)blockIdx.x * p.Co * p.pitch;
+    float* outs = smem;                 // [32][OP]
+    float* bias_s = smem + 32 * G::OP;  // [64]
+    __syncthreads();
+    {
+        const float v = bsum + __shfl_xor(bsum, 32, 64);  // the two k-groups of channel co
+        if (wn == 0 && kg == 0) bias_s[wm * 32 + m] = v;
+    }
+    for (int h = 0; h < 2; ++h) {
+        if (wm == h) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    outs[row * G::OP + (wn * 32 + m) * 9 + t] = acc[t][r];
+                }
+        }
+        __syncthreads();
+        const int ncol = nci * 9;
+        for (int i = tid; i < 32 * kTile * 9; i += 256) {
+            const int row = i / (kTile * 9), col = i - row * (kTile * 9);
+            if (h * 32 + row < nco && col < ncol) slab[(size_t)(co0 + h * 32 + row) * p.pitch + ci0 * 9 + col] = outs[row * G::OP + col];
+        }
+        if (blockIdx.y == 0 && tid < 32 && h * 32 + tid < nco) slab[(size_t)(co0 + h * 32 + tid) * p.pitch + p.Ntot] = bias_s[h * 32 + tid];
+        __syncthreads();
+    }
+    if (p.dbg == 9 && threadIdx.x == 0 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0)
+        printf("wgrad_sp block 0: entry -> loop %lld, loop %lld (%lld shader cycles -> %.0f MHz), epilogue %lld ticks of 10 ns\n", dbg_w0 - dbg_e0,
+               dbg_w1 - dbg_w0, dbg_c1 - dbg_t0, (double)(dbg_c1 - dbg_t0) / ((double)(dbg_w1 - dbg_w0) / 100.0), wall_clock64() - dbg_w1);
+}
+
+struct SpPlan {
+    SpParams p;
+    int mode;  // 0: not covered, 7 / 14 / 28 / 56: plane width
+    int unit;  // DMA unit in floats
+    int kblocks, gy, gz;
+};
+
+constexpr int kRu14 = 7, kRu28 = 2, kRu56 = 1;
+
+bool make_sp_plan(const cnn_conv2d_desc* d, SpPlan* pl) {
+    pl->mode = 0;
+    const OptVal e = CNN_OPT_VAL("WGRAD_SP");
+    if (e && atoi(e) == 0) return false;
+    if (d->k != 3 || d->s != 1 || d->pad != 1 || d->B < 1) return false;
+    if (d->W != 7 && d->W != 14 && d->W != 28 && d->W != 56) return false;
+    // (small channel counts: the 64 x 64 tile would be mostly padding)
+    const int min_ch = e ? 1 : 32;
+    if (d->Ci < min_ch || d->Co < min_ch) return false;
+    int ru = 0;
+    if (d->W == 7) { if (d->H != 7) return false; }
+    else if (d->W == 14) ru = kRu14;
+    else if (d->W == 28) ru = kRu28;
+    else ru = kRu56;
+    if (ru && d->H % ru != 0) return false;
+    // (buffer descriptors: byte sizes below 2^31)
+    if ((long long)d->B * d->Ci * d->H * d->W >= (1ll << 29) || (long long)d->B * d->Co * d->H * d->W >= (1ll << 29)) return false;
+    if ((long long)kTile * d->H * d->W >= (1 << 27)) return false;
+    SpParams& p = pl->p;
+    p.B = d->B; p.Ci = d->Ci; p.Co = d->Co; p.H = d->H;
+    p.Ntot = d->Ci * 9; p.pitch = p.Ntot + 1;
+    p.nrb = ru ? d->H / ru : 1;
+    p.stages_total = ru ? d->B * p.nrb : (d->B + 1) / 2;
+    pl->mode = d->W;
+    // 16-byte DMA: rows of 28 / 56 floats; the 7x7 block copy needs whole 64-channel blocks
+    pl->unit = (d->W == 28 || d->W == 56 || (d->W == 7 && d->Ci % kTile == 0 && d->Co % kTile == 0)) ? 4 : 1;
+    if (const OptVal u = CNN_OPT_VAL("SP_UNIT")) {
+        if (atoi(u) == 1 && d->W != 14) pl->unit = 1;
+    }
+    pl->gy = (d->Ci + kTile - 1) / kTile;
+    pl->gz = (d->Co + kTile - 1) / kTile;
+    const int env = CNN_OPT_INT("SP_BLOCKS", 0);
+    long long want = (env > 0 ? env : num_cus()) / ((long long)pl->gy * pl->gz);  // one workgroup per CU (LDS)
+    if (want < 1) want = 1;
+    if (want > p.stages_total) want = p.stages_total;
+    p.stages_per_block = (int)((p.stages_total + want - 1) / want);
+    pl->kblocks = (p.stages_total + p.stages_per_block - 1) / p.stages_per_block;
+    p.dbg = CNN_OPT_INT("SP_DBG", 0);
+    return true;
+}
+
+template <int W, int RU, bool PAIR, int U>
+int launch_sp(const SpPlan& pl, const cnn_conv2d_desc* d, hipStream_t s) {
+    using G = SpGeom<W, RU, PAIR, U>;
+    auto kern = wgrad_sp_kernel<W, RU, PAIR, U>;
+    static DeviceOnce attr_once;
+    if (attr_once.needed()) {
+        CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes));
+        attr_once.mark();
+    }
+    const dim3 grid(pl.kblocks, pl.gy, pl.gz);
+    char name[48];
+    snprintf(name, sizeof(name), "wgrad_sp<%d,%d,%d>", W, RU, U);
+    CNN_KLAUNCH(s, name, (kern<<<grid, 256, G::lds_bytes, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k3 s1 p1 slabs%d", d->B, d->Ci, d->H, d->W, d->Co,
+                pl.kblocks);
+    return CNN_AMD_OK;
+}
+
+}  // namespace
+
+namespace cnn_amd {
+
+// number of partial slabs ([Co][Ci*9 + 1] floats each) the kernel writes, 0 when the geometry is not covered
+int sp_wgrad_slots(const cnn_conv2d_desc* d) {
+    SpPlan pl;
+    return make_sp_plan(d, &pl) ? pl.kblocks : 0;
+}
+
+int sp_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s) {
+    SpPlan pl;
+    if (!make_sp_plan(d, &pl)) return fail(CNN_AMD_E_BADARG, "wgrad_sp: geometry not covered");
+    pl.p.x = x; pl.p.dy = dy; pl.p.slabs = slabs;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+    const int unit = aligned ? pl.unit : 1;
+    switch (pl.mode) {
+        case 7: return unit == 4 ? launch_sp<7, 7, true, 4>(pl, d, s) : launch_sp<7, 7, true, 1>(pl, d, s);
+        case 14: return launch_sp<14, kRu14, false, 1>(pl, d, s);
+        case 28: return unit == 4 ? launch_sp<28, kRu28, false, 4>(pl, d, s) : launch_sp<28, kRu28, false, 1>(pl, d, s);
+        default: return unit == 4 ? launch_sp<56, kRu56, false, 4>(pl, d, s) : launch_sp<56, kRu56, false, 1>(pl, d, s);
+    }
+}
+
+}  // namespace cnn_amd

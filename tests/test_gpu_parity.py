@@ -172,6 +172,57 @@ def test_conv2d_wgrad_register_direct(T, case, slow, lib_option):
         assert_close(host(gb3), gb_ref, REL_TOL, "LDS-staged bias grad")
 
 
+SP_CASES = [
+    (2, 64, 7, 7, 64, 3, 1, 1),      # 7x7: sample pairs, whole 64-channel blocks copied as they lie (16-byte DMA)
+    (3, 64, 7, 7, 128, 3, 1, 1),     # ... odd batch: the last stage's second sample is staged as zeros; two co tiles
+    (5, 40, 7, 7, 70, 3, 1, 1),      # ... partial channel tiles (4-byte DMA), three stages
+    (2, 64, 14, 14, 128, 3, 1, 1),   # 14x14: two row blocks of 7, left / right halves of a row on the two k-slots
+    (1, 24, 14, 14, 100, 3, 1, 1),   # ... partial tiles
+    (2, 64, 28, 28, 64, 3, 1, 1),    # 28x28: 14 row blocks of 2, 16-byte DMA of 28-float rows
+    (1, 20, 28, 28, 72, 3, 1, 1),
+    (2, 64, 56, 56, 64, 3, 1, 1),    # 56x56: one output row per stage, four segments per half row
+    (1, 12, 56, 56, 40, 3, 1, 1),
+    (2, 32, 28, 14, 32, 3, 1, 1),    # planes need not be square: 28 rows of 14
+    (1, 32, 14, 28, 64, 3, 1, 1),    # ... 14 rows of 28
+    (2, 64, 3, 56, 64, 3, 1, 1),     # ... three rows of 56: every stage has a halo row outside the image
+    (70, 64, 7, 7, 64, 3, 1, 1),     # more sample pairs than one workgroup per tile: several stages per pixel range
+]
+
+
+@pytest.mark.parametrize("unit", [0, 1], ids=["dma16", "dma4"])
+@pytest.mark.parametrize("case", SP_CASES, ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_conv2d_wgrad_small_planes(T, case, unit, lib_option):
+    """conv_wgrad_sp.hip (LDS-staged output-stationary kernel for 7x7 .. 56x56 planes, cpu/src/conv2d.cpp:117-159) against the
+    oracle, with 16-byte and with 4-byte DMA staging, on pointers that are and are not 16-byte aligned"""
+    from cnn_amd import capi
+
+    lib_option("WGRAD_SP", "1")  # (also lifts the 32-channel floor of the default dispatch)
+    if unit:
+        lib_option("SP_UNIT", "1")
+    x, w, b, dy = _conv_inputs(case, 430)
+    _, gw_ref, gb_ref, _ = _oracle_conv(case, x, w, b, dy)
+    conv = capi.Conv2d(*case)
+    xd, dyd = dev(T, x), dev(T, dy)
+    capi.kernel_timing(1)
+    gw, gb = conv.backward_weight(xd, dyd, float(case[0]))
+    T.cuda.synchronize()
+    rep = capi.kernel_timing_report()
+    capi.kernel_timing(0)
+    assert any(k.startswith("wgrad_sp<") for k in rep), list(rep)
+    assert_close(host(gw), gw_ref, REL_TOL, "weight grad")
+    assert_close(host(gb), gb_ref, REL_TOL, "bias grad")
+    if unit == 0:
+        # the same tensors one float further: no 16-byte alignment -> the 4-byte DMA instance, same sums in the same order
+        xs = T.empty(xd.numel() + 1, device="cuda")[1:].view_as(xd).copy_(xd)
+        dys = T.empty(dyd.numel() + 1, device="cuda")[1:].view_as(dyd).copy_(dyd)
+        assert xs.data_ptr() % 16 != 0
+        gw2, gb2 = conv.backward_weight(xs, dys, float(case[0]))
+        assert np.array_equal(host(gw), host(gw2)) and np.array_equal(host(gb), host(gb2))
+    lib_option("WGRAD_SP", "0")
+    gw3, gb3 = conv.backward_weight(xd, dyd, float(case[0]))
+    assert_close(host(gw3), gw_ref, REL_TOL, "register-direct weight grad")
+
+
 def test_conv2d_wgrad_ignores_non_finite_unused_columns(T):
     """W = 56, stride 2: input column 55 is read by no output pixel (conv2d.cpp:127-146 never touches it), so an Inf
     there must not leak into the gradient through a zero-weighted over-read"""
