@@ -55,6 +55,11 @@ def pytest_sessionfinish(session, exitstatus):
                "exact_zero_noise_checks": sum(r["branch"] == "exact-zero-noise" for r in recs),
                "worst_plain_err_vs_fp32_oracle": max(r["plain_err_vs_fp32_oracle"] for r in recs),
                "worst_plain_err_at_tol_1e-4": max([r["plain_err_vs_fp32_oracle"] for r in recs if r["tol"] <= 1e-4] or [0.0])}
+    # nothing is filtered out: every check held to a tolerance ABOVE north_star's 1e-4 (a derived bound, tests/util.py) is listed
+    above = [r for r in recs if r["tol"] > 1e-4]
+    summary["checks_with_tol_above_1e-4"] = len(above)
+    summary["worst_err_among_tol_above_1e-4"] = max([r["plain_err_vs_fp32_oracle"] for r in above] or [0.0])
+    summary["tol_above_1e-4_records"] = [{"test": r["test"], "what": r["what"], "tol": r["tol"], "err": r["plain_err_vs_fp32_oracle"]} for r in above]
     out = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)

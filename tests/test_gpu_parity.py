@@ -155,6 +155,7 @@ def test_conv2d_wgrad_register_direct(T, case, slow, lib_option):
 
     x, w, b, dy = _conv_inputs(case, 400)
     _, gw_ref, gb_ref, _ = _oracle_conv(case, x, w, b, dy)
+    lib_option("WGRAD_SP", "0")  # (this test is about conv_wgrad_rd.hip; the small-plane kernel has test_conv2d_wgrad_small_planes)
     conv = capi.Conv2d(*case)
     xd, dyd = dev(T, x), dev(T, dy)
     if slow:

@@ -6,7 +6,8 @@ import pytest
 
 from cnn_amd import stacks as S
 from oracle import pyoracle as O
-from tests.util import REL_TOL, assert_close, assert_close_arbitrated, assert_noise_of_exact_zero, he_init, rel_err, uniform01
+from tests.util import (REL_TOL, assert_close, assert_close_arbitrated, assert_close_derived_bound, assert_noise_of_exact_zero, he_init, rel_err,
+                        uniform01)
 
 pytestmark = pytest.mark.gpu
 
@@ -127,6 +128,11 @@ def test_stack_train_steps_vs_oracle(T, which, res, B):
                 assert_noise_of_exact_zero(g[lo:hi], onet.grads[lo:hi], float(np.abs(onet.grads[wlo:lo]).max()), REL_TOL,
                                            f"{which} step{step} grad {name} (exact zero in front of BatchNorm2D)")
                 continue
+            if tol > REL_TOL:
+                # the one check of the suite held to a DERIVED bound instead of north_star's 1e-4: recorded under its own branch name, so
+                # that tests/test_zz_parity_margins.py and the session's summary list it instead of filtering it out
+                assert_close_derived_bound(g[lo:hi], onet.grads[lo:hi], tol, f"{which} step{step} grad {name} (softmax-Jacobian bound)")
+                continue
             assert_close_arbitrated(g[lo:hi], onet.grads[lo:hi], onet64.grads[lo:hi], tol, 2.0, f"{which} step{step} grad {name}")
         off = 0
         for e in onet.layers:  # BatchNorm2D moving statistics, updated by the forward pass (batchnorm2d.cpp:78-79)
@@ -143,6 +149,154 @@ def test_stack_train_steps_vs_oracle(T, which, res, B):
         # differences of step 1's update would be amplified through 8-17 layers
         onet.params[:] = got
         onet64.params[:] = got
+    net.close()
+
+
+def _decisive_bn_params(spec, in_shape, x, p0, rel_margin=1e-2):
+    """conv -> BatchNorm2D -> ReLU stacks: parameters for which NO ReLU decision can differ between two fp32 implementations -- every
+    channel in front of a ReLU is >= margin everywhere (three of four channels) or <= -margin everywhere (every fourth), set through its
+    beta on the fp64 oracle's own forward pass; margin = rel_margin x the layer's largest pre-activation.  (BatchNorm2D re-centres
+    every layer, so the shifts do not accumulate through the stack -- without it they do, and the gradients become differences of huge
+    terms: the VGG-shaped stack takes _exact_forward_params instead.)  The linear layer is rescaled so that the logits stay O(1) (a
+    saturated softmax would make every gradient vanish).  -> (params fp32, {relu layer index: margin})"""
+    net = O.SeqNet(spec, in_shape, f64=True)
+    net.params[:] = p0
+    cur = np.asarray(x, np.float64)
+    margins = {}
+    for idx, e in enumerate(net.layers):
+        kind = e["kind"]
+        nxt = net.layers[idx + 1]["kind"] if idx + 1 < len(net.layers) else None
+        p = net._p(e)
+        if kind == "conv":
+            ci, co, kk = e["in"][0], e["Co"], e["k"]
+            cur = O.conv2d_forward_padded(cur, p[: co * ci * kk * kk].reshape(co, ci, kk, kk), p[co * ci * kk * kk :], e["s"], e["pad"], f64=True)
+            assert nxt == "bn"
+        elif kind == "bn":
+            c = e["in"][0]
+            y = O.batchnorm_forward(cur, p[:c], p[c : 2 * c], p[2 * c : 3 * c], p[3 * c :], training=True, f64=True)[0]
+            if nxt == "relu":
+                lo, hi = y.min(axis=(0, 2, 3)), y.max(axis=(0, 2, 3))
+                m = rel_margin * float(np.abs(y).max())
+                sh = np.where(np.arange(c) % 4 == 3, -m - hi, m - lo)
+                margins[idx + 1] = m
+                p[c : 2 * c] += sh
+                y = y + sh[None, :, None, None]
+            cur = y
+        elif kind == "relu":
+            cur = O.relu_forward(cur, f64=True)
+        elif kind == "pool":
+            cur = O.maxpool_forward(cur, e["k"], e["step"], f64=True)[0]
+        else:
+            ni, no = e["n_in"], e["n_out"]
+            z = O.linear_forward(cur.reshape(cur.shape[0], ni), p[: ni * no].reshape(ni, no), p[ni * no :], f64=True)
+            p *= 2.0 / max(float(np.abs(z).max()), 1e-30)
+    return net.params.astype(np.float32), margins
+
+
+def _exact_forward_params(spec, in_shape, B, seed):
+    """conv -> ReLU (-> MaxPool2D) stacks: an input and parameters for which the forward pass is EXACT in fp32 whatever the summation
+    order -- inputs on a 2^-4 grid, four filter entries of +-1 per output channel (everything else 0), biases on the same grid: every
+    product and partial sum is a multiple of 2^-4 below 4^layers = 2^16 (20 of fp32's 24 bits).  Two implementations then hold
+    bit-identical activations, so every ReLU decision (zeros included) and every MaxPool2D argmax (ties included: first maximum wins,
+    pool2d.cpp:67-75) is the same, with a natural mix of passing and blocked units.  The linear layer holds ordinary floats, scaled for
+    O(1) logits.  -> (x, params fp32)"""
+    rs = np.random.RandomState(seed)
+    x = (rs.randint(0, 16, size=(B,) + tuple(in_shape)) / 16.0).astype(np.float32)
+    net = O.SeqNet(spec, in_shape, f64=True)
+    cur = x.astype(np.float64)
+    for e in net.layers:
+        p = net._p(e)
+        if e["kind"] == "conv":
+            ci, co, kk = e["in"][0], e["Co"], e["k"]
+            w = np.zeros((co, ci * kk * kk))
+            for o in range(co):
+                w[o, rs.choice(ci * kk * kk, 4, replace=False)] = rs.choice([-1.0, 1.0], 4)
+            p[: co * ci * kk * kk] = w.ravel()
+            p[co * ci * kk * kk :] = rs.randint(-2, 3, size=co) / 16.0
+            cur = O.conv2d_forward_padded(cur, w.reshape(co, ci, kk, kk), p[co * ci * kk * kk :], e["s"], e["pad"], f64=True)
+            assert float(np.abs(cur).max()) * 16 < 2 ** 23, "forward no longer exact in fp32"
+        elif e["kind"] == "relu":
+            cur = O.relu_forward(cur, f64=True)
+        elif e["kind"] == "pool":
+            cur = O.maxpool_forward(cur, e["k"], e["step"], f64=True)[0]
+        elif e["kind"] == "linear":
+            ni, no = e["n_in"], e["n_out"]
+            p[: ni * no] = rs.standard_normal(ni * no)
+            p[ni * no :] = rs.standard_normal(no) * 0.1
+            z = O.linear_forward(cur.reshape(B, ni), p[: ni * no].reshape(ni, no), p[ni * no :], f64=True)
+            p *= 2.0 / max(float(np.abs(z).max()), 1e-30)
+        else:
+            raise ValueError(e["kind"])
+    return x, net.params.astype(np.float32)
+
+
+@pytest.mark.parametrize("which", ["vgg11", "resnet18"])
+def test_stack_gradients_vs_the_oracles_own_backward(T, which):
+    """the deep-stack gradients against a backward pass the oracle runs ON ITS OWN decisions (no masks_from),
+    at north_star's plain 1e-4 (no fp64 arbitration), on inputs engineered so that no discrete decision can differ:
+    VGG-shaped stack -- a forward pass that is exact in fp32 (_exact_forward_params): the test asserts BIT-IDENTICAL ReLU / pool outputs;
+    ResNet-shaped stack -- every channel in front of a ReLU keeps a margin from 0 (_decisive_bn_params): the test asserts the margin on
+    the oracle's pre-activations and identical ReLU decisions on both sides."""
+    from cnn_amd import hostapi
+
+    B, res = 2, 224
+    spec = S.STACKS[which]()
+    in_shape = (3, res, res)
+    onet = O.SeqNet(spec, in_shape)
+    exact = which == "vgg11"
+    if exact:
+        x, p0 = _exact_forward_params(spec, in_shape, B, 63)
+        margins = {}
+    else:
+        x = uniform01(61, (B,) + in_shape)
+        p0, margins = _decisive_bn_params(spec, in_shape, x, he_init(onet.layers, 62))
+    onet.params[:] = p0
+    net = hostapi.HostSequential(spec, in_shape)
+    net.set_params(p0)
+    labels = np.array([0, 2], np.int32)
+    loss = net.train_step_device(T.from_numpy(x).cuda(), labels, 1e-3, do_update=False)
+    g = net.get_grads()
+    ologits = onet.forward(x)
+    oloss, odelta = O.cross_entropy_backward(O.softmax(ologits), labels)
+    assert abs(loss - oloss) <= 1e-4 * max(1.0, abs(oloss)), (loss, oloss)
+    assert float(np.abs(odelta).max()) > 1e-2, "saturated softmax: the gradients would vanish"
+    names = hostapi._layer_names(spec)
+    for idx, e in enumerate(onet.layers):
+        if e["kind"] not in ("relu", "pool"):
+            continue
+        got = net.layer_output(names[idx], (B,) + e["out"])
+        if exact:
+            assert np.array_equal(got, onet.acts[idx]), f"{names[idx]}: the engineered forward pass is not bit-identical"
+        elif e["kind"] == "relu":
+            pre = onet.acts[idx - 1]  # (the BatchNorm2D output in front)
+            assert float(np.abs(pre).min()) >= 0.5 * margins[idx], (names[idx], float(np.abs(pre).min()), margins[idx])
+            assert np.array_equal(got <= 0, onet.acts[idx] <= 0), names[idx]
+            assert_close(got, onet.acts[idx], REL_TOL, f"{which} own-backward {names[idx]} output")
+    if exact:
+        frac = [float(np.mean(onet.acts[i] <= 0)) for i, e in enumerate(onet.layers) if e["kind"] == "relu"]
+        assert 0.1 < min(frac) and max(frac) < 0.9, frac  # (a natural mix of passing and blocked units in every layer)
+    onet.backward(odelta)  # its own ReLU' and MaxPool' decisions
+    for name, lo, hi, idx in _slices(onet.layers):
+        if name.endswith(".b") and name.startswith("conv") and idx + 1 < len(onet.layers) and onet.layers[idx + 1]["kind"] == "bn":
+            wlo = lo - onet.layers[idx]["Co"] * onet.layers[idx]["in"][0] * onet.layers[idx]["k"] ** 2
+            assert_noise_of_exact_zero(g[lo:hi], onet.grads[lo:hi], float(np.abs(onet.grads[wlo:lo]).max()), REL_TOL,
+                                       f"{which} own-backward grad {name} (exact zero in front of BatchNorm2D)")
+            continue
+        if name == "linear.b":
+            tol = max(REL_TOL, 0.5 * REL_TOL * float(np.abs(ologits).max()) / float(np.abs(onet.grads[lo:hi]).max()))
+            if tol > REL_TOL:
+                assert_close_derived_bound(g[lo:hi], onet.grads[lo:hi], tol, f"{which} own-backward grad {name} (softmax-Jacobian bound)")
+                continue
+        if name.endswith(".beta") and not exact:
+            # all-pass / all-block channels make one more gradient an exact zero: behind this ReLU sits a 1x1 convolution followed by a
+            # BatchNorm2D, whose input delta sums to 0 over every channel plane (batchnorm2d.cpp:129-147) -- and a 1x1 filter passes
+            # that property on to every input channel (no border taps), through a ReLU' that passes (or blocks) whole channels
+            nxt = [j for j in range(idx + 1, len(onet.layers)) if onet.layers[j]["kind"] == "conv"][:1]
+            if nxt and onet.layers[nxt[0]]["k"] == 1 and onet.layers[nxt[0] + 1]["kind"] == "bn":
+                assert_noise_of_exact_zero(g[lo:hi], onet.grads[lo:hi], float(np.abs(onet.grads[lo - (hi - lo) : lo]).max()), REL_TOL,
+                                           f"{which} own-backward grad {name} (exact zero in front of a 1x1 convolution + BatchNorm2D)")
+                continue
+        assert_close(g[lo:hi], onet.grads[lo:hi], REL_TOL, f"{which} own-backward grad {name}")
     net.close()
 
 
@@ -334,6 +488,49 @@ def test_wide_and_split_tiles_at_the_stacks_full_sizes(T, case, cfgs, lib_option
         assert err(y, y0) <= 1e-5 and err(dx, dx0) <= 1e-5, (cfg, err(y, y0), err(dx, dx0))
         dx2 = conv.backward_data(dy * 2.0, w)  # exact in floating point: every product and partial sum doubles
         assert T.equal(dx2, dx * 2.0)
+        # ... and an ORACLE slice of the full-size launch: forward and data gradient are per-sample independent
+        # (conv2d.cpp:69,175), so three samples of the batch -- first, middle, last: different tiles / channel-range partials -- are
+        # compared with the oracle directly instead of transitively through the im2col fallback
+        sel = [0, B // 2, B - 1]
+        xs, dys = x[sel].cpu().numpy(), dy[sel].cpu().numpy()
+        xp = np.pad(xs, ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+        wn = w.cpu().numpy()
+        y_ref = O.conv2d_forward(xp, wn, b.cpu().numpy(), s)
+        dx_ref = O.conv2d_backward(xp, dys, wn, s)[2][:, :, pad : pad + H, pad : pad + W]
+        assert_close(y[sel].cpu().numpy(), y_ref, REL_TOL, f"cfg {cfg} full-size forward, oracle slice")
+        assert_close(dx[sel].cpu().numpy(), dx_ref, REL_TOL, f"cfg {cfg} full-size data gradient, oracle slice")
+
+
+@pytest.mark.parametrize("case", [(64, 64, 56, 56, 64, 3, 1, 1), (64, 128, 28, 28, 128, 3, 1, 1), (64, 256, 14, 14, 256, 3, 1, 1), (64, 512, 7, 7, 512, 3, 1, 1),
+                                  (128, 512, 14, 14, 512, 3, 1, 1)], ids=lambda c: str(c).replace(" ", ""))
+def test_small_plane_wgrad_at_the_stacks_full_sizes_vs_oracle(T, case):
+    """conv_wgrad_sp.hip at BASELINE configs[3] / [4]'s full batch (256 workgroups, 4 .. 256 pixel ranges): the weight gradient couples
+    all samples (conv2d.cpp:148), so the oracle slice is taken through dy -- a delta that is zero except on three samples (first,
+    middle, last: three different pixel ranges) makes the full-size launch equal to the oracle's gradient of those three samples x 3/B"""
+    from cnn_amd import capi
+
+    B, Ci, H, W, Co, k, s, pad = case
+    g = T.Generator(device="cuda").manual_seed(19)
+    x = T.rand((B, Ci, H, W), generator=g, device="cuda") - 0.3
+    conv = capi.Conv2d(*case)
+    sel = [0, B // 2, B - 1]
+    dy = T.zeros(conv.out_shape(), device="cuda")
+    dy[sel] = T.rand((3,) + tuple(conv.out_shape()[1:]), generator=g, device="cuda") * 2 - 1
+    capi.kernel_timing(1)
+    gw, gb = conv.backward_weight(x, dy, float(B))
+    names = [key.split("|")[0] for key in capi.kernel_timing_report()]
+    capi.kernel_timing(0)
+    assert any(n.startswith("wgrad_sp<") for n in names), names
+    xp = np.pad(x[sel].cpu().numpy(), ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+    gw_ref, gb_ref, _ = O.conv2d_backward(xp, dy[sel].cpu().numpy(), np.zeros((Co, Ci, k, k), np.float32), s)
+    assert_close(gw.cpu().numpy(), gw_ref * np.float32(3.0 / B), REL_TOL, "full-size weight gradient, oracle slice")
+    assert_close(gb.cpu().numpy(), gb_ref * np.float32(3.0 / B), REL_TOL, "full-size bias gradient, oracle slice")
+    # all samples live: the gradient is linear in dy (exact: every product and partial sum doubles)
+    dyf = T.rand(conv.out_shape(), generator=g, device="cuda") * 2 - 1
+    gw1, gb1 = conv.backward_weight(x, dyf, float(B))
+    gw1, gb1 = gw1.clone(), gb1.clone()
+    gw2, gb2 = conv.backward_weight(x, dyf * 2.0, float(B))
+    assert T.equal(gw2, gw1 * 2.0) and T.equal(gb2, gb1 * 2.0)
 
 
 @pytest.mark.parametrize("case", [(7, 24, 14, 13, 40, 3, 1, 1), (3, 16, 9, 15, 32, 3, 1, 1), (5, 32, 14, 14, 64, 3, 1, 1)], ids=str)
@@ -346,6 +543,7 @@ def test_wgrad_flattened_runs_of_8_equal_im2col(T, case, lib_option):
     g = T.Generator(device="cuda").manual_seed(17)
     x = T.rand((B, Ci, H, W), generator=g, device="cuda") - 0.5
     lib_option("RD_FLAT8", "1")
+    lib_option("WGRAD_SP", "0")  # (round 5: 14-wide planes with >= 32 channels go to conv_wgrad_sp.hip by default)
     conv = capi.Conv2d(*case)
     dy = T.rand(conv.out_shape(), generator=g, device="cuda") * 2 - 1
     capi.kernel_timing(1)
