@@ -279,6 +279,27 @@ def reference_loop_leg(torch, args):
     return out
 
 
+def rccl_log_excerpt(path, limit=14):
+    """what RCCL says it chose (NCCL_DEBUG=INFO lines of THIS process: version, channels, rings / trees, algorithm / protocol) -- the first
+    8-GPU run then records the transport it actually used, not just images/s"""
+    import glob
+    import re
+
+    keep = re.compile(r"(version|Init COMPLETE|[Cc]hannel|Ring|Tree|nranks|Algo|Proto|xgmi|XGMI|P2P|via)")
+    seen, out = set(), []
+    for f in sorted(glob.glob(path.replace("%p", "*").replace("%h", "*"))):
+        try:
+            for line in open(f, errors="replace"):
+                line = re.sub(r"^\S+:\d+:\d+ \[\d+\] ", "", line.strip())
+                key = re.sub(r"0x[0-9a-f]+|\d+", "#", line)
+                if keep.search(line) and key not in seen:
+                    seen.add(key)
+                    out.append(line[:200])
+        except OSError:
+            pass
+    return out[:limit]
+
+
 def init_comm(capi, torch, dist, world, rank):
     """the data path's exchange (cnn_amd.dp.RcclComm: C ABI -> RCCL), checked once against torch.distributed's own all-reduce"""
     from cnn_amd.dp import RcclComm
@@ -363,7 +384,7 @@ def measure(run, steps, warmup, sample_every, capi, barrier, time_mod=time, repe
     barrier()
     table = capi.kernel_timing_report()
     capi.kernel_timing(0)
-    ranked = sorted(table.items(), key=lambda kv: -kv[1][1])
+    ranked = sorted(((k, v) for k, v in table.items() if not k.startswith("span:")), key=lambda kv: -kv[1][1])  # (spans are waits, not kernels)
     dominant = ranked[0][0]
     if agree(1 if (len(ranked) > 1 and ranked[1][1][1] >= 0.8 * ranked[0][1][1]) else 0):
         # two kernels within 20 % of each other in the fully instrumented steps (every launch event-bracketed: that changes what
@@ -512,6 +533,15 @@ def main():
     if api == "pynet" and not small:
         raise SystemExit("--api pynet drives the reference net only; the stacks run through the C++ Layer API")
 
+    rccl_log = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.one_rank_comm:
+        # RCCL's own account of what it set up (version, channels, rings / trees): INFO-level init lines of this process into a file, an
+        # excerpt of rank 0's goes into the JSON line.  Set BEFORE torch (and with it librccl) is loaded; init-time logging only, the
+        # steady state is not touched.
+        rccl_log = f"/tmp/cnn_amd_rccl_{os.getpid()}_%p.log"
+        os.environ["NCCL_DEBUG"] = "INFO"  # (assigned, not defaulted: the image may export NCCL_DEBUG=WARN; the file keeps stdout = one JSON line)
+        os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,ENV"
+        os.environ["NCCL_DEBUG_FILE"] = rccl_log
     import numpy as np
     import torch
 
@@ -574,6 +604,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         regions = [float(v) for v in t.tolist()]
     elapsed = median(regions)  # `value` / `ms_per_step`: the median region of exactly K steps
+    if comm_info is not None and api != "pynet":
+        # how much of the gradient exchange is EXPOSED: the compute stream's wait for the communication stream at the end of the backward
+        # walk (Sequential::backward / allreduce_gradients bracket it as "span:exchange_wait"), sampled in K more (untimed) steps on every
+        # rank; the step's all-reduce kernels themselves run on the communication stream under the backward pass
+        capi.kernel_timing(2, "span:exchange_wait")
+        for _ in range(args.steps):
+            run["step"]()
+        barrier()
+        rep = capi.kernel_timing_report()
+        capi.kernel_timing(0)
+        cnt_x, ms_x = next(iter(rep.values()), (0, 0.0))
+        exposed = torch.tensor([ms_x / cnt_x * 1e3 if cnt_x else -1.0], device="cuda", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(exposed, op=dist.ReduceOp.MAX)
+        # (-1: this workload's step has no such wait -- the reference net's fused tail runs its second bucket ON the compute stream)
+        comm_info["exchange_exposed_us"] = round(float(exposed.item()), 1) if float(exposed.item()) >= 0 else None
+        comm_info["exchange_exposed_note"] = "max over ranks of the mean compute-stream wait for the exchange per step (HIP events around the wait)"
     loss = run["loss"]()
     assert np.isfinite(loss), "training diverged: loss is not finite"
     if world > 1 and run["params"] is not None:
@@ -590,6 +637,26 @@ def main():
         assert comm_info["ranks"] == args.gpus == world
         comm_info["param_digests_equal_on_all_ranks"] = True
         comm_info["param_digest"] = f"{digest:014x}"
+    if comm_info is not None:
+        # what the exchange COSTS the step: K more steps with and K without the all-reduce calls (DP_SKIP_EXCHANGE on every rank; everything
+        # else -- buckets, events, the 1/N scale -- unchanged), back to back, max over ranks.  Behind the digest check: the replicas diverge here.
+        pair = []
+        for skip in ("0", "1"):
+            capi.set_option("DP_SKIP_EXCHANGE", skip)
+            for _ in range(2):
+                run["step"]()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                run["step"]()
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pair.append(float(t.item()) / args.steps * 1e6)
+        capi.set_option("DP_SKIP_EXCHANGE", None)
+        comm_info["step_us_with_exchange"], comm_info["step_us_without_exchange"] = round(pair[0], 1), round(pair[1], 1)
+        comm_info["exchange_cost_us_per_step"] = round(pair[0] - pair[1], 1)
 
     out = None
     if rank == 0:
@@ -625,6 +692,8 @@ def main():
             "final_loss": round(loss, 5),
         }
         if comm_info:
+            if rccl_log and os.environ.get("NCCL_DEBUG_FILE") == rccl_log:
+                comm_info["rccl_init_log_excerpt"] = rccl_log_excerpt(rccl_log)
             out["exchange"] = comm_info
         if args.breakdown:
             tot = sum(v[1] for v in table.values())

@@ -38,6 +38,8 @@ SIGNATURES = {
     "cnn_amd_kernel_timing_enable": (C.c_int, [C.c_int, C.c_char_p]),
     "cnn_amd_kernel_timing_sampling": (C.c_int, [C.c_int]),
     "cnn_amd_kernel_timing_report": (C.c_longlong, [C.c_char_p, C.c_size_t]),
+    "cnn_amd_timing_span_begin": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "cnn_amd_timing_span_end": (C.c_int, [C.c_void_p]),
     "cnn_conv2d_out_dim": (C.c_int, [C.c_int] * 4),
     "cnn_maxpool2d_out_dim": (C.c_int, [C.c_int] * 3),
     "cnn_conv2d_workspace_bytes": (C.c_size_t, [_D]),

@@ -200,6 +200,16 @@ using namespace cnn_amd;
 extern "C" {
 
 int cnn_amd_abi_version(void) { return CNN_AMD_ABI_VERSION; }
+
+int cnn_amd_timing_span_begin(void* stream, const char* name) {
+    CNN_REQUIRE(name != nullptr, "cnn_amd_timing_span_begin: null name");
+    if (ktimer_active()) ktimer_begin(as_stream(stream), name, "span");
+    return CNN_AMD_OK;
+}
+int cnn_amd_timing_span_end(void* stream) {
+    if (ktimer_active()) ktimer_end(as_stream(stream));
+    return CNN_AMD_OK;
+}
 const char* cnn_amd_last_error(void) { return error_buffer(); }
 
 const char* cnn_amd_device_arch(void) {

@@ -2,6 +2,7 @@
 // code a reference user would call (AlexNet::forward / backward / update_gradients, func.cpp's softmax and
 // cross_entroy_backward) from Python.  Not part of the drop-in boundary (that is include/cnn_amd.h).
 #include <cstring>
+#include <stdexcept>
 #include <filesystem>
 #include <map>
 #include <vector>
@@ -226,7 +227,13 @@ int cnnh_net_layer_output(void* hv, const char* layer_name, float* out, size_t c
     h->net->flush_deferred();  // (a re-materialising get_output() uses the layer's workspace: nothing deferred may still read it)
     for (const auto& layer : h->net->layers()) {
         if (layer->name != layer_name) continue;
-        const auto ts = layer->get_output();
+        std::vector<tensor> ts;
+        try {
+            ts = layer->get_output();
+        } catch (const std::exception& e) {  // (a fused-away tensor whose parameters are gone: layers.cpp materialize())
+            std::fprintf(stderr, "%s\n", e.what());
+            return 3;
+        }
         size_t off = 0;
         for (const auto& t : ts) {
             const size_t n = (size_t)t->get_length();

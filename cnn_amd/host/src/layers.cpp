@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cassert>
 #include <cstdio>
+#include <stdexcept>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -165,7 +166,15 @@ void Conv2D::ensure_workspace(int B, int H, int W) {
 // inside"), freed again right away; inside a data-parallel container only rank 0 measures and every replica pins rank 0's choice, so that
 // all of them run the same kernels (the measurement is not reproducible from box to box)
 void Conv2D::tune_geometry(const cnn_conv2d_desc& d0) {
-    const bool shared = comm != nullptr && comm_world > 1;
+    // Inside a data-parallel container every replica measures FOR ITSELF by default: no collective on the first forward pass of a layer.
+    // Replicas that pin different tiles differ in the last bits of their LOCAL gradients only -- the all-reduced sums, and with them the
+    // parameters, stay identical on every rank (bench.py asserts the digests).  CNN_AMD_DP_SHARE_TUNE=1 restores rank 0's measurement
+    // broadcast to all replicas (same kernels everywhere); that makes the first forward() of every Conv2D a BLOCKING COLLECTIVE --
+    // one host thread (or process) per rank, identical shapes and batch sizes on every rank -- and has not run on more than one rank
+    // yet (VERDICT / ADVICE r4), hence opt-in.
+    char text[8] = {0};
+    const bool share = cnn_amd_get_option("DP_SHARE_TUNE", text, sizeof(text)) == 0 && std::atoi(text) != 0;
+    const bool shared = share && comm != nullptr && comm_world > 1;
     if (!shared || comm_rank == 0) {
         const size_t need = cnn_conv2d_autotune_workspace_bytes(&d0);
         void* scratch = nullptr;
@@ -328,10 +337,11 @@ void Conv2D::materialize() const {
     if (out_valid && !relu_missing) return;
     assert(last_x != nullptr && "get_output() of a fused-away tensor before any forward pass");
     if (recompute_lost) {
-        std::fprintf(stderr, "cnn_amd host: %s: get_output() of a tensor the last forward pass did not write, after the parameters that pass used were "
-                             "overwritten (set from outside, or stepped twice): call forward() again, or set architectures::fuse_pool_block = false\n",
-                     name.c_str());
-        std::abort();
+        // (an exception, not abort(): inspecting a layer after load_weights() must not kill the process.  The C wrapper
+        // cnnh_net_layer_output turns it into a return code.)
+        throw std::runtime_error("cnn_amd host: " + name + ": get_output() of a tensor the last forward pass did not write, after the parameters that pass "
+                                 "used were overwritten (set from outside, or stepped twice): call forward() again, or set "
+                                 "architectures::fuse_pool_block = false");
     }
     // the parameters the last forward pass used: the container's snapshot when its SGD step has run since
     const data_type* w = (snapshot != nullptr && snapshot_active != nullptr && *snapshot_active) ? snapshot : params;
@@ -772,10 +782,11 @@ void BatchNorm2D::materialize() const {
     if (out_valid) return;
     assert(saved_input != nullptr && "get_output() of a fused-away tensor before any forward pass");
     if (recompute_lost) {
-        std::fprintf(stderr, "cnn_amd host: %s: get_output() of a tensor the last forward pass did not write, after the parameters that pass used were "
-                             "overwritten (set from outside, or stepped twice): call forward() again, or set architectures::fuse_pool_block = false\n",
-                     name.c_str());
-        std::abort();
+        // (an exception, not abort(): inspecting a layer after load_weights() must not kill the process.  The C wrapper
+        // cnnh_net_layer_output turns it into a return code.)
+        throw std::runtime_error("cnn_amd host: " + name + ": get_output() of a tensor the last forward pass did not write, after the parameters that pass "
+                                 "used were overwritten (set from outside, or stepped twice): call forward() again, or set "
+                                 "architectures::fuse_pool_block = false");
     }
     const int C = out_channels;
     const data_type* gb = (snapshot != nullptr && snapshot_active != nullptr && *snapshot_active) ? snapshot : params;

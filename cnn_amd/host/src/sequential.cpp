@@ -410,7 +410,10 @@ void Sequential::backward(std::vector<tensor>& delta_start) {
     if (bucketed) {
         flush_bucket(0, pending_hi);
         must(cnn_event_record(ev_comm, comm_stream), "cnn_event_record");
+        // (measurement: how long the compute stream waits here is the EXPOSED part of the exchange -- bench.py reads it at N > 1)
+        cnn_amd_timing_span_begin(stream, "span:exchange_wait");
         must(cnn_stream_wait_event(stream, ev_comm), "cnn_stream_wait_event");
+        cnn_amd_timing_span_end(stream);
         grads_reduced = true;
         return;
     }
@@ -476,9 +479,13 @@ void Sequential::set_comm(void* rccl_comm, int world) {
         must(cnn_comm_info(comm, &w, &rank), "cnn_comm_info");
         assert(w == world && "Sequential::set_comm: world does not match the communicator");
     }
-    // BatchNorm2D's sync-BN reductions get a communicator of their own over the same ranks (cnn_comm_split): they are issued on the
-    // compute stream in the middle of the backward walk while buckets of the gradient exchange are in flight on the communication
-    // stream -- two queues instead of one.  A librccl without ncclCommSplit (or CNN_AMD_BN_OWN_COMM=0): they share `comm` as before.
+    // BatchNorm2D's sync-BN reductions are issued on the compute stream in the middle of the backward walk while buckets of the gradient
+    // exchange are in flight on the communication stream.  DEFAULT (round 5, VERDICT / ADVICE r4): they share `comm` -- one communicator,
+    // whose collectives RCCL serialises in issue order, identical on every rank.  CNN_AMD_BN_OWN_COMM=1 gives them a communicator of
+    // their own over the same ranks (cnn_comm_split): two queues instead of one, but two communicators whose kernels are in flight
+    // together are only safe when both can be co-resident on every rank (host issue order is the same everywhere, device execution order
+    // is not guaranteed -- the pattern RCCL documents as deadlock-prone), and the split itself is a blocking collective inside set_comm
+    // (one host thread or process per rank).  It has never run on more than one GPU: opt-in until it has.
     if (bn_comm != nullptr) {
         cnn_comm_destroy(bn_comm);
         bn_comm = nullptr;
@@ -486,7 +493,7 @@ void Sequential::set_comm(void* rccl_comm, int world) {
     bool has_bn = false;
     for (auto& layer : layers_sequence) has_bn = has_bn || dynamic_cast<BatchNorm2D*>(layer.get()) != nullptr;
     char text[8] = {0};
-    const bool own = !(cnn_amd_get_option("BN_OWN_COMM", text, sizeof(text)) == 0 && std::atoi(text) == 0);
+    const bool own = cnn_amd_get_option("BN_OWN_COMM", text, sizeof(text)) == 0 && std::atoi(text) != 0;
     if (comm != nullptr && has_bn && own && cnn_comm_split(comm, 0, rank, &bn_comm) != CNN_AMD_OK) bn_comm = nullptr;
     for (auto& layer : layers_sequence) {
         if (auto* bn = dynamic_cast<BatchNorm2D*>(layer.get())) bn->set_comm(bn_comm ? bn_comm : comm, comm_world);
@@ -515,7 +522,9 @@ void Sequential::allreduce_gradients() {
     must(cnn_stream_wait_event(comm_stream, ev_grads), "cnn_stream_wait_event");
     must(cnn_allreduce_grads(comm, grad_arena, n_params, comm_stream), "cnn_allreduce_grads");
     must(cnn_event_record(ev_comm, comm_stream), "cnn_event_record");
+    cnn_amd_timing_span_begin(stream, "span:exchange_wait");
     must(cnn_stream_wait_event(stream, ev_comm), "cnn_stream_wait_event");
+    cnn_amd_timing_span_end(stream);
     grads_reduced = true;
 }
 

@@ -191,6 +191,8 @@ class HostNet:
     def layer_output(self, name, shape):
         out = np.empty(shape, np.float32)
         rc = self.lib.cnnh_net_layer_output(self.h, name.encode(), _fp(out), out.size)
+        if rc == 3:  # std::runtime_error from Layer::get_output(): the tensor was fused away and its parameters are gone
+            raise RuntimeError(f"layer {name}: get_output() of a tensor the last forward pass did not write, after its parameters were overwritten")
         if rc != 0:
             raise KeyError(f"layer {name}: rc={rc}")
         return out

@@ -54,6 +54,12 @@ int cnn_amd_kernel_timing_sampling(int every);
 /* device-synchronises; writes "<kernel>|<geometry>\t<launches>\t<total_ms>\n" lines (host buffer) and clears
  * the records; returns bytes needed (records are kept when cap is too small), -1 on error */
 long long cnn_amd_kernel_timing_report(char* buf, size_t cap);
+/* brackets a span of `stream` that holds NO library kernel -- e.g. the wait for another stream -- with the kernel timer's events: when
+ * timing is on it appears in the report under "<name>|span" (give such names the prefix "span:" so that consumers can tell them from
+ * kernels); no-ops otherwise.  The host container uses it for "span:exchange_wait": how long the compute stream waits for the
+ * gradient exchange at the end of a data-parallel step (the EXPOSED part of the all-reduce). */
+int cnn_amd_timing_span_begin(void* stream, const char* name);
+int cnn_amd_timing_span_end(void* stream);
 
 /* ---- geometry helpers (host side, pure) -------------------------------------------------------------- */
 /* conv2d.cpp:41-42:  out = (H + 2*pad - k)/s + 1, integer division (the reference has pad == 0) */
