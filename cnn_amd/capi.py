@@ -92,6 +92,7 @@ SIGNATURES = {
     "cnn_dropout_forward": (C.c_int, [_P, _P] + [C.c_int] * 6 + [C.c_float, _P]),
     "cnn_dropout_backward": (C.c_int, [_P] + [C.c_int] * 5 + [_P]),
     "cnn_batch_stager_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.c_int]),
+    "cnn_batch_stager_create_u8": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
     "cnn_batch_stager_destroy": (C.c_int, [_P]),
     "cnn_batch_stager_acquire": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "cnn_batch_stager_submit": (C.c_int, [_P, C.c_int, C.POINTER(C.c_void_p)]),
@@ -772,18 +773,28 @@ def side_stream_join():
 class BatchStager:
     """cnn_batch_stager_*: `depth` pinned host slots + device buffers, uploads on a copy stream of its own, ordered by events"""
 
-    def __init__(self, batch_bytes, depth=2):
+    def __init__(self, batch_bytes=None, depth=2, u8_shape=None):
+        """u8_shape=(B, H, W): the slots hold interleaved BYTES [B][H][W][3] (cv::Mat CV_8UC3), submit() returns the fp32 planar batch
+        the stager's conversion kernel writes (cnn_batch_stager_create_u8)"""
         self.lib = load()
         self.h = C.c_void_p()
-        self.bytes = int(batch_bytes)
-        check(self.lib.cnn_batch_stager_create(C.byref(self.h), self.bytes, depth), "cnn_batch_stager_create")
+        self.u8 = u8_shape is not None
+        if self.u8:
+            B, H, W = (int(v) for v in u8_shape)
+            self.bytes = B * H * W * 3
+            check(self.lib.cnn_batch_stager_create_u8(C.byref(self.h), B, H, W, depth), "cnn_batch_stager_create_u8")
+        else:
+            self.bytes = int(batch_bytes)
+            check(self.lib.cnn_batch_stager_create(C.byref(self.h), self.bytes, depth), "cnn_batch_stager_create")
 
     def acquire(self):
-        """-> (numpy float32 view of the pinned slot to fill, slot index); blocks until the slot is free"""
+        """-> (numpy view of the pinned slot to fill -- float32, or uint8 for a u8 stager --, slot index); blocks until the slot is free"""
         import numpy as np
 
         host, slot = C.c_void_p(), C.c_int()
         check(self.lib.cnn_batch_stager_acquire(self.h, C.byref(host), C.byref(slot)), "cnn_batch_stager_acquire")
+        if self.u8:
+            return np.ctypeslib.as_array((C.c_ubyte * self.bytes).from_address(host.value)), slot.value
         buf = (C.c_float * (self.bytes // 4)).from_address(host.value)
         return np.ctypeslib.as_array(buf), slot.value
 

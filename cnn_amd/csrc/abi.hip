@@ -395,9 +395,37 @@ struct Stager {
     int depth = 0, next = 0;
     hipStream_t copy = nullptr;
     std::vector<void*> host, dev;
+    // u8 staging (cnn_batch_stager_create_u8): `dev` holds the uploaded bytes, `dev_f32` the converted batch submit() hands out
+    std::vector<void*> dev_f32;
+    float* lut = nullptr;  // device: lut[v] = v * 1.f / 255, computed on the host
+    int B = 0, H = 0, W = 0;
     std::vector<hipEvent_t> uploaded, consumed;
     std::vector<char> in_use;  // consumed[i] has been recorded at least once
 };
+
+// Tensor3D::read_from_opencv_mat (data_format.cpp:13-23) for a whole batch: interleaved bytes [B][H*W][3] -> planar fp32 [B][3][H*W].
+// A thread converts four consecutive pixels: 12 bytes in (three 4-byte loads), one 16-byte store into each channel plane.  The table
+// lives in LDS (no arithmetic on the device: the host's v * 1.f / 255, bit for bit).
+__global__ __launch_bounds__(256) void u8hwc_to_f32chw(const unsigned* __restrict__ src, float* __restrict__ dst, const float* __restrict__ lut_g,
+                                                       int hw4, long long quads_total) {
+    __shared__ float lut[256];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < quads_total; q += (long long)gridDim.x * 256) {
+        const long long b = q / hw4;
+        const int i4 = (int)(q - b * hw4);  // quad index inside the image
+        const unsigned w0 = src[3 * q], w1 = src[3 * q + 1], w2 = src[3 * q + 2];  // bytes p0c0 p0c1 p0c2 p1c0 | p1c1 p1c2 p2c0 p2c1 | p2c2 p3c0 p3c1 p3c2
+        float4 c0, c1, c2;
+        c0.x = lut[w0 & 255u];         c1.x = lut[(w0 >> 8) & 255u];  c2.x = lut[(w0 >> 16) & 255u];
+        c0.y = lut[w0 >> 24];          c1.y = lut[w1 & 255u];         c2.y = lut[(w1 >> 8) & 255u];
+        c0.z = lut[(w1 >> 16) & 255u]; c1.z = lut[w1 >> 24];          c2.z = lut[w2 & 255u];
+        c0.w = lut[(w2 >> 8) & 255u];  c1.w = lut[(w2 >> 16) & 255u]; c2.w = lut[w2 >> 24];
+        float* d = dst + (size_t)b * 12 * hw4 + 4 * (size_t)i4;  // image b, channel 0, pixel 4*i4
+        *(float4*)d = c0;
+        *(float4*)(d + 4 * (size_t)hw4) = c1;
+        *(float4*)(d + 8 * (size_t)hw4) = c2;
+    }
+}
 }  // namespace
 
 int cnn_batch_stager_create(void** stager, size_t batch_bytes, int depth) {
@@ -419,10 +447,39 @@ int cnn_batch_stager_create(void** stager, size_t batch_bytes, int depth) {
     return CNN_AMD_OK;
 }
 
+int cnn_batch_stager_create_u8(void** stager, int B, int H, int W, int depth) {
+    CNN_REQUIRE(stager && B > 0 && H > 0 && W > 0 && depth >= 2 && depth <= 16, "cnn_batch_stager_create_u8: bad arguments (depth 2..16)");
+    CNN_REQUIRE(((long long)H * W) % 4 == 0, "cnn_batch_stager_create_u8: H*W must be a multiple of 4 (%d x %d)", H, W);
+    Stager* st = new Stager();
+    st->bytes = (size_t)B * H * W * 3;
+    st->depth = depth;
+    st->B = B; st->H = H; st->W = W;
+    st->host.assign(depth, nullptr); st->dev.assign(depth, nullptr); st->dev_f32.assign(depth, nullptr);
+    st->uploaded.assign(depth, nullptr); st->consumed.assign(depth, nullptr);
+    st->in_use.assign(depth, 0);
+    *stager = st;
+    CNN_HIP_CHECK(hipStreamCreateWithFlags(&st->copy, hipStreamNonBlocking));
+    float table[256];
+    for (int v = 0; v < 256; ++v) table[v] = (unsigned char)v * 1.f / 255;  // data_format.cpp:19-21, the reference's own expression
+    CNN_HIP_CHECK(hipMalloc((void**)&st->lut, sizeof(table)));
+    CNN_HIP_CHECK(hipMemcpy(st->lut, table, sizeof(table), hipMemcpyHostToDevice));
+    for (int i = 0; i < depth; ++i) {
+        CNN_HIP_CHECK(hipHostMalloc(&st->host[i], st->bytes, hipHostMallocDefault));
+        CNN_HIP_CHECK(hipMalloc(&st->dev[i], st->bytes));
+        CNN_HIP_CHECK(hipMalloc(&st->dev_f32[i], st->bytes * sizeof(float)));
+        CNN_HIP_CHECK(hipEventCreateWithFlags(&st->uploaded[i], hipEventDisableTiming));
+        CNN_HIP_CHECK(hipEventCreateWithFlags(&st->consumed[i], hipEventDisableTiming));
+    }
+    return CNN_AMD_OK;
+}
+
 int cnn_batch_stager_destroy(void* stager) {
     Stager* st = static_cast<Stager*>(stager);
     if (!st) return CNN_AMD_OK;
     if (st->copy) (void)hipStreamSynchronize(st->copy);
+    if (st->lut) (void)hipFree(st->lut);
+    for (void* p : st->dev_f32)
+        if (p) (void)hipFree(p);
     for (int i = 0; i < st->depth; ++i) {
         if (st->host[i]) (void)hipHostFree(st->host[i]);
         if (st->dev[i]) (void)hipFree(st->dev[i]);
@@ -452,8 +509,15 @@ int cnn_batch_stager_submit(void* stager, int slot, void** device_ptr) {
     CNN_REQUIRE(st && device_ptr && slot >= 0 && slot < st->depth, "cnn_batch_stager_submit: bad arguments");
     if (st->in_use[slot]) CNN_HIP_CHECK(hipStreamWaitEvent(st->copy, st->consumed[slot], 0));
     CNN_HIP_CHECK(hipMemcpyAsync(st->dev[slot], st->host[slot], st->bytes, hipMemcpyHostToDevice, st->copy));
+    if (st->lut != nullptr) {  // bytes -> the fp32 planar batch, behind the copy on the same stream
+        const int hw4 = st->H * st->W / 4;
+        const long long quads = (long long)st->B * hw4;
+        u8hwc_to_f32chw<<<stream_grid((size_t)quads, 256), 256, 0, st->copy>>>((const unsigned*)st->dev[slot], (float*)st->dev_f32[slot], st->lut, hw4,
+                                                                               quads);
+        CNN_LAUNCH_CHECK();
+    }
     CNN_HIP_CHECK(hipEventRecord(st->uploaded[slot], st->copy));
-    *device_ptr = st->dev[slot];
+    *device_ptr = st->lut != nullptr ? st->dev_f32[slot] : st->dev[slot];
     return CNN_AMD_OK;
 }
 

@@ -505,6 +505,13 @@ int cnn_stream_wait_event_local(void* stream, void* event);
  * so that the upload of batch i+1 overlaps the kernels of batch i.  A batch of 256 x 3 x 224 x 224 floats is 154 MB: ~2.4 ms
  * over PCIe Gen5 x16, i.e. the PCIe-inclusive ceiling of the reference net is ~10^5 images/s per GPU (bench.py --staged-input). */
 int cnn_batch_stager_create(void** stager, size_t batch_bytes, int depth);
+/* The same for what a real input is BEFORE Tensor3D::read_from_opencv_mat (data_format.cpp:13-23): B images of H x W x 3 interleaved
+ * bytes (cv::Mat CV_8UC3, channel order as it lies -- BGR for cv::imread).  The pinned slots and the H2D copies hold BYTES (a quarter
+ * of the fp32 batch: 150 KB instead of 602 KB per 224 x 224 image); behind the copy, still on the stager's own stream, one kernel
+ * writes the batch the layers consume -- fp32, planar [B][3][H][W], data[c*H*W + i] = byte * 1.f / 255 through a 256-entry table that
+ * the HOST fills with that very expression, so the result is bit-identical to the reference's conversion.  submit() returns the fp32
+ * batch; acquire / wait / release / destroy as above. */
+int cnn_batch_stager_create_u8(void** stager, int B, int H, int W, int depth);
 int cnn_batch_stager_destroy(void* stager);
 int cnn_batch_stager_acquire(void* stager, void** pinned_host, int* slot);
 int cnn_batch_stager_submit(void* stager, int slot, void** device_ptr);

@@ -224,6 +224,50 @@ def test_conv2d_wgrad_small_planes(T, case, unit, lib_option):
     assert_close(host(gw3), gw_ref, REL_TOL, "register-direct weight grad")
 
 
+def test_u8_batch_stager_is_bit_identical_to_the_reference_conversion(T, golden_dir):
+    """row n4, cnn_batch_stager_create_u8: the bytes of a real input (the six images behind the reference's own Grad-CAM pictures and the
+    three README images, tests/golden/*_images_u8.*) are uploaded AS BYTES and converted on the device to the fp32 planar batch --
+    bit-identical to Tensor3D::read_from_opencv_mat (data_format.cpp:13-23: data[c*H*W + i] = byte * 1.f / 255), hence to what the fp32
+    stager uploads: two nets trained from the two staging paths end with the same bits"""
+    from cnn_amd import capi, hostapi
+
+    imgs = np.concatenate([np.load(os.path.join(golden_dir, "gradcam_kat_images_u8.npz"))["images"],
+                           np.load(os.path.join(golden_dir, "readme_kat_images_u8.npy"))])
+    assert imgs.shape == (9, 224, 224, 3) and imgs.dtype == np.uint8  # [B][H][W][3] bytes, as cv::Mat holds them
+    B = imgs.shape[0]
+    # the reference's expression in float32: uchar -> int -> * 1.f -> / 255 (int -> float)
+    want = (imgs.astype(np.float32) * np.float32(1.0) / np.float32(255)).transpose(0, 3, 1, 2).copy()
+    assert len(np.unique(imgs)) > 200  # (nearly every table entry is exercised)
+    st8 = capi.BatchStager(u8_shape=(B, 224, 224), depth=2)
+    st32 = capi.BatchStager(B * 3 * 224 * 224 * 4, depth=2)
+    labels = (T.arange(B, device="cuda") % 3).to(T.int32)
+    nets = [hostapi.HostAlexNet(3), hostapi.HostAlexNet(3)]
+    for net in nets:
+        net.load_checkpoint(os.path.join(golden_dir, "readme_kat_checkpoint.model"))
+    for rep in range(3):  # more submits than slots: the slots are reused
+        host8, slot8 = st8.acquire()
+        host8[:] = imgs.reshape(-1)
+        dev8 = st8.submit(slot8)
+        st8.wait(slot8)
+        got = T.empty((B, 3, 224, 224), device="cuda")
+        capi.check(capi.load().cnn_memcpy_d2d(got.data_ptr(), dev8, got.numel() * 4, capi._stream()), "cnn_memcpy_d2d")
+        nets[0].train_step_ptr(dev8, labels, B, 224, 224, 1e-3)
+        st8.release(slot8)
+        assert np.array_equal(got.cpu().numpy(), want), f"submit {rep}: the device conversion is not bit-identical"
+        host32, slot32 = st32.acquire()
+        host32[:] = want.reshape(-1)
+        dev32 = st32.submit(slot32)
+        st32.wait(slot32)
+        nets[1].train_step_ptr(dev32, labels, B, 224, 224, 1e-3)
+        st32.release(slot32)
+    T.cuda.synchronize()
+    assert nets[0].last_loss() == nets[1].last_loss() and np.array_equal(nets[0].get_params(), nets[1].get_params())
+    for net in nets:
+        net.close()
+    st8.close()
+    st32.close()
+
+
 def test_conv2d_wgrad_ignores_non_finite_unused_columns(T):
     """W = 56, stride 2: input column 55 is read by no output pixel (conv2d.cpp:127-146 never touches it), so an Inf
     there must not leak into the gradient through a zero-weighted over-read"""
