@@ -9,8 +9,9 @@
 // partial sums part[c][g][k]; the consumer kernel re-reduces the G partials with a fixed lane/xor tree in every
 // block, so results are deterministic and no finalize launch is needed.
 //
-//   forward, training: 3 launches  (sum -> mean | sum (x-u)^2 -> var | apply)     12 + 4 = 16 B / element
-//                                                                                  (x read 3x, y written once)
+//   forward, training: 2 launches  (sums around a pilot value -> mean, var | apply)  8 + 4 = 12 B / element
+//                                  (round 5: one statistics pass, bn_stats_pilot; x read 2x, y written once.  The two-pass form
+//                                   -- sum -> mean | sum (x-u)^2 -> var, 16 B / element -- stays behind CNN_AMD_BN_TWO_PASS=1)
 //   forward, eval:     1 launch   (apply with the moving statistics)               8 B / element
 //   backward:          2 launches (4 sums | in-place dx)                           8 + 12 = 20 B / element
 // The reference's normed_input buffer (batchnorm2d.cpp:38,71) is NOT materialised: (x-u)*var_inv is recomputed
@@ -137,6 +138,39 @@ __global__ __launch_bounds__(kBlock) void bn_stats(const float* __restrict__ x, 
     block_store_partials<1>(acc, part_out, q.G);
 }
 
+// ONE pass instead of two (round 5): both batch statistics from a single read of x, around a per-channel PILOT value p = the first
+// element of the channel (any member of the distribution will do): S1 = sum (x - p), S2 = sum (x - p)^2, then
+//     mean = p + S1/L        var = S2/L - (S1/L)^2           (batchnorm2d.cpp:46-61 computes the same two numbers in two passes)
+// The textbook one-pass formula E[x^2] - E[x]^2 cancels catastrophically when |mean| >> sigma; shifted by a sample of the channel
+// |S1/L| is O(sigma) whatever the channel's offset, and the subtraction costs a few ulps (measured against the oracle: <= 2e-6
+// tensor-normalised on y, tests/test_gpu_batchnorm.py, the offset cases included).  CNN_AMD_BN_TWO_PASS=1 keeps the two-pass kernels.
+__global__ __launch_bounds__(kBlock) void bn_stats_pilot(const float* __restrict__ x, float* __restrict__ part_out, Geo q) {
+    const int c = blockIdx.y, g = blockIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int wpart = lane >> q.part_shift, stride = 1 << q.part_shift, sub = lane & (stride - 1);
+    const float p = x[(size_t)c * q.HW];
+    float acc[2] = {0.f, 0.f};
+    for (long long un = ((long long)g * kWaves + wave) * q.P + wpart; un < q.units; un += (long long)q.G * kWaves * q.P) {
+        long long g0, g1;
+        unit_range(q, c, un, g0, g1);
+        walk_unit(
+            g0, g1, sub, stride,
+            [&](long long e) {
+                const float4 v = *(const float4*)(x + e);
+                const float a = v.x - p, b = v.y - p, cc = v.z - p, d = v.w - p;
+                acc[0] += (a + b) + (cc + d);
+                acc[1] += (a * a + b * b) + (cc * cc + d * d);
+            },
+            [&](long long e) {
+                const float a = x[e] - p;
+                acc[0] += a;
+                acc[1] += a * a;
+            });
+    }
+    block_store_partials<2>(acc, part_out, q.G);
+}
+
 struct BnApply {
     const float* x;
     float* y;
@@ -153,6 +187,7 @@ struct BnApply {
     const float* gsum_x;   // sync-BN: all-reduced channel sums of x and of (x-mean)^2, with the global element count
     const float* gsum_sq;
     float count;
+    const float* part2;  // training, one-pass statistics: partial sums (S1, S2) around the channel's pilot value (bn_stats_pilot)
 };
 
 // y = gamma * ((x - u) * var_inv) + beta  (batchnorm2d.cpp:69-77 / 84-92), moving statistics (:79-80)
@@ -170,6 +205,14 @@ __global__ __launch_bounds__(kBlock) void bn_apply(BnApply a, Geo q) {
         if (a.gsum_x != nullptr) {
             u = a.gsum_x[c] / a.count;
             var = a.gsum_sq[c] / a.count;
+            if (g == 0 && threadIdx.x == 0) a.saved_mean[c] = u;
+        } else if (a.part2 != nullptr) {
+            const float L = (float)((long long)q.B * q.HW);
+            const float d = sum_partials(a.part2 + (size_t)c * q.G * 2, q.G, 2, lane) / L;
+            const float m2 = sum_partials(a.part2 + (size_t)c * q.G * 2 + 1, q.G, 2, lane) / L;
+            u = a.x[(size_t)c * q.HW] + d;
+            var = m2 - d * d;
+            var = var > 0.f ? var : 0.f;
             if (g == 0 && threadIdx.x == 0) a.saved_mean[c] = u;
         } else {
             u = a.saved_mean[c];
@@ -518,9 +561,14 @@ static int bn_forward_impl(const float* x, float* y, float* y_relu, const float*
         }
         float* p0 = (float*)workspace;
         float* p1 = p0 + (size_t)C * q.G * 4;
-        CNN_KLAUNCH(s, "bn_stats<0>", (bn_stats<0><<<grid, kBlock, 0, s>>>(x, nullptr, p0, nullptr, q, 0.f)), BN_TAG);
-        CNN_KLAUNCH(s, "bn_stats<1>", (bn_stats<1><<<grid, kBlock, 0, s>>>(x, p0, p1, saved_mean, q, 0.f)), BN_TAG);
-        a.part = p1;
+        if (CNN_OPT_INT("BN_TWO_PASS", 0) != 0) {
+            CNN_KLAUNCH(s, "bn_stats<0>", (bn_stats<0><<<grid, kBlock, 0, s>>>(x, nullptr, p0, nullptr, q, 0.f)), BN_TAG);
+            CNN_KLAUNCH(s, "bn_stats<1>", (bn_stats<1><<<grid, kBlock, 0, s>>>(x, p0, p1, saved_mean, q, 0.f)), BN_TAG);
+            a.part = p1;
+        } else {
+            CNN_KLAUNCH(s, "bn_stats_pilot", (bn_stats_pilot<<<grid, kBlock, 0, s>>>(x, p0, q)), BN_TAG);
+            a.part2 = p0;
+        }
     }
     if (y_relu)
         CNN_KLAUNCH(s, "bn_apply+relu", (bn_apply<true><<<grid, kBlock, 0, s>>>(a, q)), BN_TAG);

@@ -162,7 +162,7 @@ def test_batchnorm_rejects_bad_arguments(T):
 
 @pytest.mark.parametrize("shape,splits", [((6, 16, 27, 27), (2, 4)), ((5, 3, 7, 9), (1, 3, 1)), ((4, 16, 13, 13), (4,))],
                          ids=["two_ranks", "three_uneven_ranks", "one_rank"])
-def test_sync_batchnorm_sharded_batch_equals_full_batch_oracle(T, shape, splits):
+def test_sync_batchnorm_sharded_batch_equals_full_batch_oracle(T, shape, splits, lib_option):
     """the split-phase (sync-BN) entry points with the batch sharded over simulated ranks -- per-rank partial sums, summed
     like an all-reduce -- reproduce the reference's full-batch BatchNorm2D forward and backward (batchnorm2d.cpp:24-158)"""
     from cnn_amd import capi
@@ -240,7 +240,10 @@ def test_sync_batchnorm_sharded_batch_equals_full_batch_oracle(T, shape, splits)
         assert_close(host(rk["gg"]), gg_o, what="gamma grad")
         assert_close(host(rk["gb"]), gb_o, what="beta grad")
     if len(splits) == 1:  # one rank: the same arithmetic as the single-device entry points on their general path (C < 32 here;
-        # layers taken by the one-workgroup-per-channel kernels sum a channel in a different order)
+        # layers taken by the one-workgroup-per-channel kernels sum a channel in a different order) -- in their TWO-pass form: the
+        # sharded statistics are two all-reduced sums (x, then (x - mean)^2), which is batchnorm2d.cpp:46-61's own order; the
+        # single-device default since round 5 is ONE pass around a pilot value (bn_stats_pilot), held to the oracle at 1e-4 above
+        lib_option("BN_TWO_PASS", "1")
         bn = capi.BatchNorm2d(B, C, H, W)
         xd, gd, bd = dev(T, x), dev(T, gamma), dev(T, beta)
         mm, mv, y1 = dev(T, mm0), dev(T, mv0), T.empty(shape, device="cuda")
