@@ -6,7 +6,7 @@
 //     data gradient  dxs[ci][n] = sum_co w[co][ci] * dy[co][n];  dx = 0 off the sampled grid, (relu_below <= 0 ? 0 : dxs) on it
 //     weight grad.   gw[co][ci] = (sum_n dy[co][n] * xs[ci][n]) / divisor,  gb[co] = (sum_n dy[co][n]) / divisor
 // The implicit GEMM (conv_igemm.hip) pays a chunk barrier per 8 channels of ONE tap and the generic weight-gradient kernel streams a
-// 9-tap tile shape: 24 / 9.5 / 4.3-9.6 TFLOP/s on 128 -> 256, 28x28, stride 2 at batch 64.  Here: K-chunked LDS
+// 9-tap tile shape: 24 / 9.5 / 4.3-9.6 TFLOP/s on 128 -> 256, 28x28, stride 2 at batch 64 (profiles/NOTEBOOK.md section 9).  Here: K-chunked LDS
 // GEMMs on v_mfma_f32_16x16x4_f32, 8 waves per workgroup, the next chunk's operands prefetched into registers while the current chunk's
 // MFMAs run (one barrier pair per chunk), operand tiles padded so that both MFMA operand reads are bank-conflict free.
 #include "common.h"

@@ -1347,7 +1347,7 @@ int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w,
         const int ipi = (UVg + 63) / 64;
         const long long witems = (long long)d->B * ipi;
         // CNN_AMD_DBG = 4 / 8 / 12 (tuning only): compile-time ablations without the FMAs / the stores / both, the source
-        // of the breakdown in DESIGN.md section 6
+        // of the breakdown in profiles/NOTEBOOK.md section 6
         const int dbg = CNN_OPT_INT("DBG", 0);
 #define PK_LAUNCH(DBG_)                                                                                              \
     CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>",                                                                       \
@@ -1440,7 +1440,7 @@ int pk_dgrad_s2(const cnn_conv2d_desc* d, const float* dy, const float* w, float
     const int ipi = (UVg + 63) / 64;
     const long long witems = (long long)d->B * ipi;
     const size_t wl = (size_t)total * sizeof(float);
-    // (two pixels per lane, other batch sizes: no gain -- the loop is bound by the LDS-read / FMA interleave)
+    // (two pixels per lane, other batch sizes: no gain -- the loop is bound by the LDS-read / FMA interleave, profiles/NOTEBOOK.md 9)
     if (d->Ci == 16) {
         CNN_KLAUNCH(s, relu_below ? "conv_dgrad_pk_s2<16>+relu" : "conv_dgrad_pk_s2<16>",
                     (conv_dgrad_pk_s2<16, 4, 1><<<wave_grid(witems), kBlock, wl, s>>>(dy, (const v2f*)ws, dx, relu_below, d->B, d->Co, d->H, d->W, Ho,

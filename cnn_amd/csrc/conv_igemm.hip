@@ -1407,7 +1407,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
     p.nrows_max = (int)(out_rows * p.su + nseg * (p.TR > p.su ? p.TR - p.su : 0));
     p.chs = p.nrows_max * p.LW + (p.TR - 1) * 0;  // window never leaves the rows staged for its own pixel
     // the last pixel's window may run up to TC-1 floats past its row end only inside the padded pitch -> in range.
-    if (pl->MF == 16) {  // de-conflict the four k-groups of a 16x16x4 B read (see DESIGN.md "LDS banking")
+    if (pl->MF == 16) {  // de-conflict the four k-groups of a 16x16x4 B read (see profiles/NOTEBOOK.md "LDS banking")
         const int want = (p.su & 1) ? 16 : 17;
         p.chs += ((want - p.chs % 32) + 32) % 32;
     }

@@ -114,7 +114,7 @@ static void find_chain(const std::list<std::shared_ptr<Layer> >& layers, std::ve
 
 // the deferred data gradient is released behind the THIRD convolution's forward kernel (or the last one of a shorter net): there
 // it overlaps the latency-bound deep layers, the linear layer and the loss instead of the HBM-bound first ones (measured on the
-// reference net)
+// reference net, profiles/NOTEBOOK.md section 4.4)
 static Layer* pick_release_layer(const std::list<std::shared_ptr<Layer> >& layers) {
     char text[16] = {0};
     int want = 3;  // (DX0_RELEASE=n: behind the n-th convolution instead; tuning)
@@ -154,14 +154,14 @@ void Sequential::bind(data_type* p, data_type* g) {
     if (chain_convs.empty()) chain_head = nullptr;
 }
 
-// ---- sample-resident chains ----------------------------------------------------------------------------------
+// ---- sample-resident chains (profiles/NOTEBOOK.md section 4.27) ----------------------------------------------------------------------------------
 // how many trailing convolutions one chain kernel takes for a batch of B in this pass (0: the per-layer path).  CHAIN_FWD_N / CHAIN_BWD_N
 // = 1..3 turn the forward / data-gradient chain on and cap its length (opt-in), CHAIN_MIN_B is the smallest batch that goes this way (one workgroup per sample: a small batch
 // leaves most compute units idle, the per-layer kernels spread it over the chip).
 int Sequential::chain_plan(int B, bool forward) const {
     if (chain_head == nullptr || chain_convs.empty() || !finalized || !fuse_layers || !fuse_pool_block || no_grad || !filters_prepared) return 0;
     char text[16] = {0};
-    // OFF by default (measured, DESIGN.md section 4.27: a chain kernel's 8 waves x 240 registers fill a compute unit's register file, so
+    // OFF by default (measured, profiles/NOTEBOOK.md section 4.27: a chain kernel's 8 waves x 240 registers fill a compute unit's register file, so
     // nothing runs beside it, and the per-layer path gains more from overlapping the HBM-bound first-layer data gradient and the weight
     // gradients with the small MFMA-bound layers than the chain saves in launch gaps and ramps: 585-600 k vs 639-653 k images/s)
     int cap = 0, min_b = 96;
@@ -577,7 +577,7 @@ void Sequential::prepare_later_filters(void* on_stream) {
     }
 }
 
-// The end of a train step whose first block ran pool-fused, called where the backward walk reaches that
+// The end of a train step whose first block ran pool-fused (profiles/NOTEBOOK.md section 4.13), called where the backward walk reaches that
 // block's convolution; `delta` = d(pool output).  Instead of [block wgrad || block dgrad] -> join -> (all-reduce) -> SGD over the
 // arena -> filter images:
 //   * side stream, behind the data gradient of the layer behind the block (the last reader of the later layers' filter images):

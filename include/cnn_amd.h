@@ -463,6 +463,9 @@ int cnn_loss_from_terms(const float* loss_terms, float* loss_sum, int B, void* s
  * the layers' cnn_conv2d_prepare_filters images.  Every result is BIT-IDENTICAL to the per-layer calls named above.
  * supported(n, descs, lin_in, lin_out) != 0: the chain is covered (lin_in = lin_out = 0 asks about the backward chain alone; the
  * forward chain needs lin_out == 3 and lin_in == 128 * Ho * Wo of the last layer). */
+/* (kept although measured 8-10 % SLOWER in the train step than the per-layer path -- a chain kernel owns a CU's whole register file, nothing
+ * overlaps it, profiles/NOTEBOOK.md 4.27 -- because it is the only bit-identical whole-back-half reference for future fusion work; opt-in:
+ * CHAIN_FWD_N / CHAIN_BWD_N, never on the default path) */
 int cnn_conv_chain_supported(int n, const cnn_conv2d_desc* descs, int lin_in, int lin_out);
 int cnn_conv_chain_forward_loss_prepared(int n, const cnn_conv2d_desc* descs, const float* x, const void* const* prepared_fwd,
                                          const float* const* bias, float* const* y_relu, const float* lin_w, const float* lin_bias,

@@ -232,7 +232,7 @@ def test_train_step_with_chain_kernels_is_bit_identical_to_the_per_layer_step(T,
 
 def test_full_batch_train_steps_with_chain_kernels_vs_oracle(T, lib_option):
     """BASELINE configs[1] at its own batch (256: one sample per compute unit, the chain kernels' design point) through the C++ classes
-    with both chains switched on (they are opt-in: DESIGN.md section 4.27), three steps, against the CPU oracle: the loss and the
+    with both chains switched on (they are opt-in: profiles/NOTEBOOK.md section 4.27), three steps, against the CPU oracle: the loss and the
     parameters after SGD within 1e-4"""
     from cnn_amd import hostapi
     from tests.util import REL_TOL

@@ -458,7 +458,7 @@ def test_split_k_wide_tiles_equal_im2col(T, case, cfg, lib_option):
                                        ((64, 512, 7, 7, 512, 3, 1, 1), (232, 235)), ((128, 512, 14, 14, 512, 3, 1, 1), (228, 229))],
                          ids=lambda c: str(c).replace(" ", ""))
 def test_wide_and_split_tiles_at_the_stacks_full_sizes(T, case, cfgs, lib_option):
-    """BASELINE configs[3] / [4] at their stated batch sizes: the layers on which the tuner pins the wide / split-K tiles, every such
+    """BASELINE configs[3] / [4] at their stated batch sizes: the layers on which the tuner pins the wide / split-K tiles (profiles/NOTEBOOK.md 4.30), every such
     tile forced, forward and data gradient against the rule-based tile of the same kernel family (a different summation order: 1e-5
     tensor-normalised) -- the full-size launches (242 workgroups of 64 x 832, 32 tiles x 8 channel ranges ...) that the small-batch oracle tests
     above do not reach -- plus linearity of the data gradient in dy at full size"""
@@ -535,7 +535,7 @@ def test_small_plane_wgrad_at_the_stacks_full_sizes_vs_oracle(T, case):
 
 @pytest.mark.parametrize("case", [(7, 24, 14, 13, 40, 3, 1, 1), (3, 16, 9, 15, 32, 3, 1, 1), (5, 32, 14, 14, 64, 3, 1, 1)], ids=str)
 def test_wgrad_flattened_runs_of_8_equal_im2col(T, case, lib_option):
-    """the weight gradient's flattened runs of 8 for rows of 9 .. 15 pixels (CNN_AMD_RD_FLAT8=1, a measurement switch: DESIGN 9) against the im2col
+    """the weight gradient's flattened runs of 8 for rows of 9 .. 15 pixels (CNN_AMD_RD_FLAT8=1, a measurement switch: profiles/NOTEBOOK.md 9) against the im2col
     fallback, the guarded head / tail chunks included"""
     from cnn_amd import capi
 

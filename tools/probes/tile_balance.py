@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Tile-count quantisation of the implicit GEMM at batch 64: time forward / data gradient of the ResNet-shaped stack's 3x3 layers with
+"""Tile-count quantisation of the implicit GEMM at batch 64 (profiles/NOTEBOOK.md 4.30): time forward / data gradient of the ResNet-shaped stack's 3x3 layers with
 the tuned tile and with the 13- / 7-block tiles (CNN_AMD_IGEMM_CFG), and check the results against the default tile's.
 usage: tile_balance.py [cfg ids ...]"""
 import os
