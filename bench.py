@@ -476,6 +476,53 @@ def leg_result(B, steps, regions):
             "spread": {"repeats": len(regions), "min": round(B * steps / max(regions), 1), "max": round(B * steps / min(regions), 1)}}
 
 
+def conv_kernel_alone(key, torch, capi, reps=5):
+    """The stacks run a layer's weight gradient BESIDE its data gradient (two streams), so the in-situ duration of either is the pair's.
+    This times the dominant kernel's pass ALONE -- same geometry, same kernel, nothing else on the chip -- next to the in-situ figure
+    `roofline` is computed from (never instead of it).  None when the key is not a convolution pass."""
+    m = re.match(r"B(\d+) Ci(\d+) (\d+)x(\d+) Co(\d+) k(\d+) s(\d+) p(\d+)", key.split("|", 1)[1] if "|" in key else "")
+    if not m or algorithmic_work(key)[1] <= 0:
+        return None
+    case = tuple(int(v) for v in m.groups())
+    B, Ci, H, W, Co, k, s_, pad = case
+    name = key.split("|")[0]
+    conv = capi.Conv2d(*case)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand((B, Ci, H, W), generator=g, device="cuda")
+    w = torch.randn((Co, Ci, k, k), generator=g, device="cuda") * 0.05
+    b = torch.zeros((Co,), device="cuda")
+    dy = torch.rand(conv.out_shape(), generator=g, device="cuda") * 2 - 1
+    op = "fwd" if "/fwd" in name or "_fwd" in name else ("dgrad" if "dgrad" in name else "wgrad")
+
+    def run():
+        if op == "fwd":
+            conv.forward(x, w, b)
+        elif op == "dgrad":
+            conv.backward_data(dy, w)
+        else:
+            conv.backward_weight(x, dy, float(B))
+
+    run(); run()
+    torch.cuda.synchronize()
+    capi.kernel_timing(1)
+    for _ in range(reps):
+        run()
+    rep = capi.kernel_timing_report()
+    capi.kernel_timing(0)
+    del x, w, dy
+    torch.cuda.empty_cache()
+    # the pass's main kernel (the same family as the in-situ key: the fused-epilogue variants of the step share its main loop)
+    fam = name.split("<")[0]
+    hits = [(kk, v) for kk, v in rep.items() if kk.split("<")[0] == fam]
+    if not hits:
+        return None
+    kk, (cnt, ms) = max(hits, key=lambda kv: kv[1][1])
+    us = ms / cnt * 1e3
+    tf = algorithmic_work(key)[1] / (us * 1e-6) / 1e12
+    return {"kernel": kk.split("|")[0], "avg_us": round(us, 2), "achieved": round(tf, 3), "unit": "TFLOP/s", "frac": round(tf / PEAK_MFMA_F32_TFLOPS, 4),
+            "note": "the same pass alone on the chip (in the step it shares the chip with the layer's other gradient on a second stream)"}
+
+
 def stack_leg(config, torch, capi, steps=5, warmup=2):
     """BASELINE configs[3] / [4] inside the default command: a few timed steps of the stack through the C++ Layer API (no CPU leg)"""
     from cnn_amd import stacks
@@ -500,6 +547,9 @@ def stack_leg(config, torch, capi, steps=5, warmup=2):
     run["close"]()
     del run
     torch.cuda.empty_cache()
+    alone = conv_kernel_alone(dominant, torch, capi)
+    if alone:
+        out["roofline"]["alone"] = alone
     return out
 
 
@@ -721,6 +771,10 @@ def main():
     run["close"]()
     del run
     torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not small and out is not None:
+        alone = conv_kernel_alone(dominant, torch, capi)  # (the stacks: the dominant kernel's pass alone, beside the in-situ roofline)
+        if alone:
+            out["roofline"]["alone"] = alone
 
     if world > 1:
         dist.barrier()

@@ -18,14 +18,16 @@
 //     64*49 floats in HBM and is copied as it lies (plane stride 49: odd, conflict-free reads); taps that leave the plane are not
 //     multiplied at all (361 of 441 MFMAs per sample pair remain -- 18 % of the nominal FLOPs are multiplications by padding).
 //   * HALF (14 / 28 / 56 wide planes): a stage = RU output rows of one sample (with their two halo rows of x), kg = left / right half
-//     of the row.  Rows outside the image are staged as zeros; the one tap column that leaves the image on the left (right) exists
-//     only for the kg = 0 (1) lanes and is masked there by a select.
+//     of the row.  The halo row above the image is staged as zeros, the one below it is selected away; the one tap column that leaves
+//     the image on the left (right) exists only for the kg = 0 (1) lanes and is masked there by a select.
 // A 7-pixel SEGMENT of a row is the unit of the unrolled inner loop: 7 A values, three 9-float windows of x, 63 MFMAs; the next
-// segment's operands are read while this one's MFMAs issue.  Two LDS buffers: the DMA of stage s+1 (global_load_lds, 16 bytes per
-// lane where rows are 16-byte multiples, else 4) is issued in slices between the segments of stage s; one barrier per stage.
+// segment's operands are read while this one's MFMAs issue.  Two LDS buffers: the DMA of stage s+1 (buffer_load ... lds, 16 bytes per
+// lane from 4-byte-aligned sources: rows of 7 or 14 floats are as good as rows of 28) is issued in slices between the MFMAs of stage s;
+// one barrier per stage.
 // Output: slabs[blockIdx.x][Co][Ci*9 + 1] like the register-direct kernel (reduce_slabs adds the pixel ranges in a fixed order);
 // the bias gradient is accumulated on the VALU from the A registers.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -73,9 +75,14 @@ struct SpGeom {
     static constexpr int stride_for(int len) {
         return U == 1 ? (len | 1) : ((((len + 3) / 4) & 1) ? (len + 3) / 4 * 4 : (len + 3) / 4 * 4 + 4);
     }
-    static constexpr int QX = PAIR ? XLEN : stride_for(XLEN);
+    // HALF, 16-byte units: LEAD pad floats in front of every x plane put the first row of the image (staged row 1) on a unit boundary, so
+    // that the units of the top halo row hold nothing else and can be staged as zeros for the first row block of a sample (the SOURCE
+    // of a 16-byte unit needs no alignment: probed, tools/probes/buflds16_probe.cpp -- rows of 14 floats are as good as rows of 28)
+    static constexpr int LEAD = (!PAIR && U == 4) ? (4 - W % 4) % 4 : 0;
+    static constexpr int XSPAN = LEAD + XLEN;
+    static constexpr int QX = PAIR ? XLEN : stride_for(XSPAN);
     static constexpr int QD = PAIR ? DLEN : stride_for(DLEN);
-    static_assert(!PAIR || ((XLEN & 1) && (kTile * XLEN) % 4 == 0), "PAIR: odd plane, 16-byte multiple per 64-channel block");
+    static_assert(!PAIR || (XLEN & 1), "PAIR: odd plane stride (32 lanes = 32 banks)");
     static constexpr int NU = PAIR ? 2 : 1;            // samples per stage
     // DMA instructions (64 lanes x U floats) per stage
     static constexpr int PPX = QX / U, PPD = QD / U;                     // HALF: pieces per plane (pad pieces included)
@@ -117,33 +124,32 @@ __global__ __launch_bounds__(256) void wgrad_sp_kernel(const SpParams p) {
     const int s_lo = blockIdx.x * p.stages_per_block;
     const int s_hi = s_lo + p.stages_per_block < p.stages_total ? s_lo + p.stages_per_block : p.stages_total;
 
-    // ---- HALF: this wave's share of a stage's DMA, decoded once: the lane's byte offset relative to (channel ci0 / co0, staged row 0)
-    //      of the sample, bit 0 set: top halo row, bit 1: bottom halo row (x only; offsets are multiples of 4).  kOob: nothing to move
-    //      (pad piece / channel behind the tensor / no instruction for this wave).
+    // ---- HALF: this wave's share of a stage's DMA, decoded once: the lane's byte offset from (channel ci0 / co0, first staged row) of
+    //      the sample -- for x counted from W + 4 floats in front of it, see xrs --, bit 0 set: the unit holds nothing but the top halo
+    //      row (+ lead pad).  kOob: nothing to move (pad unit / channel behind the tensor / no instruction for this wave).  A unit that
+    //      runs over the end of its plane's rows fetches what follows them in memory (or zeros behind the tensor) into pad floats.
     unsigned dx_desc[PAIR ? 1 : G::NIWX], dd_desc[PAIR ? 1 : G::NIWD];
     if constexpr (!PAIR) {
-        constexpr int RP = W / U;  // pieces per row
 #pragma unroll
         for (int i = 0; i < G::NIWX; ++i) {
             const int j = i * 4 + wave, q = j * 64 + lane;
             const int plane = q / G::PPX, e = q - plane * G::PPX;
-            const int rowl = e / RP, colp = e - rowl * RP;
-            dx_desc[i] = (j < G::NIX && e < G::XLEN / U && plane < nci)
-                             ? ((unsigned)(plane * HW + rowl * W + colp * U) * 4u) | (rowl == 0 ? 1u : 0u) | (rowl == RU + 1 ? 2u : 0u) : kOob;
+            dx_desc[i] = (j < G::NIX && e * U < G::XSPAN && plane < nci)
+                             ? ((unsigned)(plane * HW + e * U + 4 - G::LEAD) * 4u) | ((e + 1) * U <= G::LEAD + W ? 1u : 0u) : kOob;
         }
 #pragma unroll
         for (int i = 0; i < G::NIWD; ++i) {
             const int j = i * 4 + wave, q = j * 64 + lane;
             const int plane = q / G::PPD, e = q - plane * G::PPD;
-            dd_desc[i] = (j < G::NID && e < G::DLEN / U && plane < nco) ? (unsigned)(plane * HW + e * U) * 4u : kOob;
+            dd_desc[i] = (j < G::NID && e * U < G::DLEN && plane < nco) ? (unsigned)(plane * HW + e * U) * 4u : kOob;
         }
     }
     (void)dx_desc; (void)dd_desc;
     __syncthreads();
-    // x is addressed from one row in front of the tensor (never fetched: the top halo row of row block 0 is always masked), so that the
-    // scalar offset of a stage is never negative
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - (PAIR ? 0 : W)), 0,
-                                                                         (int)(((unsigned)p.B * p.Ci * HW + (PAIR ? 0 : W)) * 4u), 0x00020000);
+    // x is addressed from W + 4 floats in front of the tensor (never fetched: the units of the top halo row of row block 0 are staged as
+    // zeros), so that the scalar offset of a stage is never negative
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - (PAIR ? 0 : W + 4)), 0,
+                                                                         (int)(((unsigned)p.B * p.Ci * HW + (PAIR ? 0 : W + 4)) * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)p.B * p.Co * HW * 4u), 0x00020000);
 
     // slot k of the DMA of a stage into buffer `buf` (k is a compile-time constant at every call site).  PAIR: `sb` = first sample of
@@ -170,10 +176,11 @@ __global__ __launch_bounds__(256) void wgrad_sp_kernel(const SpParams p) {
             const int j = i * 4 + wave;
             float* d = j < (isx ? G::NIX : G::NID) ? buf + (isx ? G::DIMG : 0) + j * 64 * U : dump;
             if (isx) {
-                // halo rows outside the image (the first / last row block of a sample) are staged as zeros
+                // the halo row above the image (first row block of a sample) is staged as zeros -- and not fetched: for the first plane of
+                // the tensor it lies in front of the allocation.  The halo row BELOW the image holds whatever follows the plane in memory:
+                // its taps are selected away (seg_mfma)
                 const unsigned desc = dx_desc[isx ? i : 0];
-                const unsigned bad = (r0 == 0 ? 1u : 0u) | (r0 + RU >= H ? 2u : 0u);
-                const unsigned voff = (desc & bad) ? kOob : desc & ~3u;
+                const unsigned voff = (r0 == 0 && (desc & 1u)) ? kOob : desc & ~3u;
                 blds<U>(xrs, voff, (unsigned)((sb * p.Ci + ci0) * HW + r0 * W) * 4u, d);
             } else {
                 blds<U>(drs, dd_desc[isx ? 0 : i], (unsigned)((sb * p.Co + co0) * HW + r0 * W) * 4u, d);
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(256) void wgrad_sp_kernel(const SpParams p) {
     // ---- per-lane operand bases (floats inside a buffer)
     // PAIR: kg = sample parity.  HALF: kg = half of the row; window element j of segment sg is column kg*HALFW + 7*sg + j - 1
     const int a_base = PAIR ? kg * G::DS + (wm * 32 + m) * G::QD : (wm * 32 + m) * G::QD + kg * G::HALFW;
-    const int b_base = G::DIMG + (PAIR ? kg * G::XS + (wn * 32 + m) * G::QX : (wn * 32 + m) * G::QX + kg * G::HALFW - 1);
+    const int b_base = G::DIMG + (PAIR ? kg * G::XS + (wn * 32 + m) * G::QX : (wn * 32 + m) * G::QX + G::LEAD + kg * G::HALFW - 1);
 
     f32x16 acc[9];
 #pragma unroll
@@ -216,7 +223,10 @@ __global__ __launch_bounds__(256) void wgrad_sp_kernel(const SpParams p) {
         }
     };
     // (the DMA slots of the segment are issued between its MFMAs: slot group t in front of the MFMAs of pixel t)
-    auto seg_mfma = [&](const Ops& o, int rr, int sg, auto&& slots) {
+    // bot (HALF, wave-uniform): this stage is the last row block of its sample -- the tap row below its last output row lies outside the
+    // image and holds whatever follows the plane in memory: selected away (a select, not a product: it may be Inf / NaN).  (Skipping those
+    // MFMAs instead -- one code variant per stage kind -- was measured SLOWER: 411-512 registers with spills for the 28 / 56-wide kernels.)
+    auto seg_mfma = [&](const Ops& o, int rr, int sg, bool bot, auto&& slots) {
 #pragma unroll
         for (int t = 0; t < 7; ++t) {
             slots(t);
@@ -232,6 +242,7 @@ __global__ __launch_bounds__(256) void wgrad_sp_kernel(const SpParams p) {
                     float bv = o.w[kx][j];
                     if (!PAIR && left) bv = kg == 0 ? 0.f : bv;
                     if (!PAIR && right) bv = kg == 1 ? 0.f : bv;
+                    if (!PAIR && kx == 2 && rr == RU - 1) bv = bot ? 0.f : bv;
                     acc[kx * 3 + ky] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[t], bv, acc[kx * 3 + ky], 0, 0, 0);
                 }
             }
@@ -260,13 +271,14 @@ __global__ __launch_bounds__(256) void wgrad_sp_kernel(const SpParams p) {
             else if (r0 + RU < H) r0n = r0 + RU;
             else { r0n = 0; sbn = sb + 1; }
         }
+        const bool bot = !PAIR && r0 + RU >= H;
         Ops ops[2];
         read_ops(ops[0], cur, 0, 0);
 #pragma unroll
         for (int sgi = 0; sgi < G::NSEGS; ++sgi) {
             const int rr = sgi / G::NSEG, sg = sgi % G::NSEG;
             if (sgi + 1 < G::NSEGS) read_ops(ops[(sgi + 1) & 1], cur, (sgi + 1) / G::NSEG, (sgi + 1) % G::NSEG);
-            seg_mfma(ops[sgi & 1], rr, sg, [&](int t) {
+            seg_mfma(ops[sgi & 1], rr, sg, bot, [&](int t) {
 #pragma unroll
                 for (int k = sgi * G::PER_SEG + t * PER_T; k < sgi * G::PER_SEG + (t + 1) * PER_T && k < (sgi + 1) * G::PER_SEG && k < G::NIW; ++k)
                     dma_slot(k, sbn, r0n, nxt);
@@ -345,10 +357,10 @@ bool make_sp_plan(const cnn_conv2d_desc* d, SpPlan* pl) {
     p.nrb = ru ? d->H / ru : 1;
     p.stages_total = ru ? d->B * p.nrb : (d->B + 1) / 2;
     pl->mode = d->W;
-    // 16-byte DMA: rows of 28 / 56 floats; the 7x7 block copy needs whole 64-channel blocks
-    pl->unit = (d->W == 28 || d->W == 56 || (d->W == 7 && d->Ci % kTile == 0 && d->Co % kTile == 0)) ? 4 : 1;
+    // 16-byte DMA units everywhere (their sources need no alignment); SP_UNIT=1: the 4-byte instances (A/B, odd plane strides)
+    pl->unit = 4;
     if (const OptVal u = CNN_OPT_VAL("SP_UNIT")) {
-        if (atoi(u) == 1 && d->W != 14) pl->unit = 1;
+        if (atoi(u) == 1) pl->unit = 1;
     }
     pl->gy = (d->Ci + kTile - 1) / kTile;
     pl->gz = (d->Co + kTile - 1) / kTile;
@@ -393,11 +405,10 @@ int sp_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, f
     SpPlan pl;
     if (!make_sp_plan(d, &pl)) return fail(CNN_AMD_E_BADARG, "wgrad_sp: geometry not covered");
     pl.p.x = x; pl.p.dy = dy; pl.p.slabs = slabs;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
-    const int unit = aligned ? pl.unit : 1;
+    const int unit = pl.unit;
     switch (pl.mode) {
         case 7: return unit == 4 ? launch_sp<7, 7, true, 4>(pl, d, s) : launch_sp<7, 7, true, 1>(pl, d, s);
-        case 14: return launch_sp<14, kRu14, false, 1>(pl, d, s);
+        case 14: return unit == 4 ? launch_sp<14, kRu14, false, 4>(pl, d, s) : launch_sp<14, kRu14, false, 1>(pl, d, s);
         case 28: return unit == 4 ? launch_sp<28, kRu28, false, 4>(pl, d, s) : launch_sp<28, kRu28, false, 1>(pl, d, s);
         default: return unit == 4 ? launch_sp<56, kRu56, false, 4>(pl, d, s) : launch_sp<56, kRu56, false, 1>(pl, d, s);
     }
