@@ -187,6 +187,10 @@ SP_CASES = [
     (1, 32, 14, 28, 64, 3, 1, 1),    # ... 14 rows of 28
     (2, 64, 3, 56, 64, 3, 1, 1),     # ... three rows of 56: every stage has a halo row outside the image
     (70, 64, 7, 7, 64, 3, 1, 1),     # more sample pairs than one workgroup per tile: several stages per pixel range
+    (2, 64, 4, 112, 64, 3, 1, 1),    # 112-wide planes: 32-channel ci tiles, the two waves of a tile split a row's segments
+    (1, 40, 6, 112, 100, 3, 1, 1),   # ... partial tiles (32 + 8 input channels, 64 + 36 output channels)
+    (2, 64, 5, 112, 128, 3, 1, 0),   # ... pad 0 (the north-star geometry, conv2d.cpp:41-42): dy rows of 110 floats staged contiguously
+    (1, 24, 9, 112, 70, 3, 1, 0),    # ... partial tiles
 ]
 
 
