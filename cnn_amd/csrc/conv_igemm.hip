@@ -1678,6 +1678,9 @@ bool dgrad_rd_supported(const cnn_conv2d_desc* d);  // conv_dgrad_rd.hip: regist
 size_t dgrad_rd_prepared_floats(const cnn_conv2d_desc* d);
 int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* img, const float* relu_below,
                            float* dx, void* ws, size_t ws_bytes, hipStream_t s);
+size_t rows_workspace_floats(const cnn_conv2d_desc* d, int mode);  // conv_rows.hip (round 5): LDS-staged 3x3 / stride-1 forward and data gradient
+int rows_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t s);  // of wide planes
+int rows_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t s);
 bool fwd_rd_supported(const cnn_conv2d_desc* d);  // conv_fwd_rd.hip: register-direct forward of the mid-size 3x3 layers
 size_t fwd_rd_prepared_floats(const cnn_conv2d_desc* d);
 int rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, const float* const* bias, void* const* fwd,
@@ -1723,6 +1726,8 @@ size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
     if (pk_dgrad_s2_supported(d) && n < pk_dgrad_s2_workspace_floats(d)) n = pk_dgrad_s2_workspace_floats(d);
     if (fwd_rd_prepared_floats(d) > n) n = fwd_rd_prepared_floats(d);
     if (dgrad_rd_prepared_floats(d) > n) n = dgrad_rd_prepared_floats(d);
+    for (int mode = 0; mode < 2; ++mode)
+        if (rows_workspace_floats(d, mode) > n) n = rows_workspace_floats(d, mode);
     memo.put(d, n);
     return n;
 }
@@ -1738,6 +1743,10 @@ static int conv2d_forward_impl(const char* who, const cnn_conv2d_desc* d, const 
     if (direct_conv_supported(d)) return direct_conv_forward(d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream), prepared);
     if (c11_supported(d))  // (its "prepared" image is a verbatim copy of w)
         return c11_forward(d, x, prepared ? (const float*)ws : w, bias, y, y_relu, as_stream(stream));
+    // (round 5) plain forward of a wide 3x3 / stride-1 layer: the row kernel, when the caller's workspace holds its filter image
+    if (!prepared && y && !y_relu && rows_workspace_floats(d, MODE_FWD) > 0 && ws != nullptr &&
+        ws_bytes >= rows_workspace_floats(d, MODE_FWD) * sizeof(float))
+        return rows_forward(d, x, w, bias, y, ws, ws_bytes, as_stream(stream));
     if (fwd_rd_supported(d))
         return fwd_rd_forward(d, x, prepared ? nullptr : w, prepared ? (const float*)ws : nullptr, bias, y, y_relu, as_stream(stream));
     if (stem_fwd_supported(d) && (y || y_relu))  // (its "prepared" image is a verbatim copy of w)
@@ -1761,6 +1770,9 @@ static int conv2d_backward_data_impl(const char* who, const cnn_conv2d_desc* d, 
         return c11_backward_data(d, dy, prepared ? (const float*)ws : w, relu_below, dx, as_stream(stream));
     if (thin_dgrad_supported(d))  // (its "prepared" image is a verbatim copy of w)
         return thin_dgrad(d, dy, prepared ? (const float*)ws : w, relu_below, dx, as_stream(stream));
+    if (!prepared && !relu_below && rows_workspace_floats(d, MODE_DGRAD) > 0 && ws != nullptr &&
+        ws_bytes >= rows_workspace_floats(d, MODE_DGRAD) * sizeof(float))
+        return rows_backward_data(d, dy, w, dx, ws, ws_bytes, as_stream(stream));
     if (dgrad_rd_supported(d))
         return dgrad_rd_backward_data(d, dy, prepared ? nullptr : w, prepared ? (const float*)ws : nullptr, relu_below, dx,
                                       prepared ? nullptr : ws, prepared ? 0 : ws_bytes, as_stream(stream));

@@ -1,0 +1,369 @@
+// conv_rows.hip -- Conv2D forward (cpu/src/conv2d.cpp:69-92) and data gradient (conv2d.cpp:168-199) of 3x3 / stride-1 layers with wide
+// planes as ONE kernel family built like conv_wgrad_sp.hip (round 5): both operands staged through LDS by buffer-addressed DMA with
+// out-of-range zero fill, every LDS address a per-lane base + a compile-time immediate, the stage's code one basic block.
+//
+//     y[b][co][r][c] = bias[co] + sum_{ci,kx,ky} w[co][ci][kx][ky] * x[b][ci][r + kx - pad][c + ky - pad]
+// The data gradient of a pad-p layer is the same sum over dy with padding 2 - p, the filter transposed and flipped (prepared once per
+// call by rows_prep into the layout the kernel stages: [co tile][channel chunk][channel][tap][co]).
+//
+// GEMM view: M = output channels (A = filters), N = pixels (B = input), K = (channel, tap), on v_mfma_f32_16x16x4_f32 -- 16-pixel
+// column blocks waste 1.8 % of a 110- or 112-wide row where 32-pixel blocks waste 14 %.  A workgroup of four waves owns MT output
+// channels x RG output rows of one sample: MT = 128: waves 4 (co) x 1, RG = 2;  MT = 64: waves 2 (co) x 2 (row pairs), RG = 4.  A wave:
+// 32 co (two 16-row A blocks) x 2 rows x NB pixel blocks = 4 * NB accumulators of 4 registers.  A STAGE = 8 input channels: their RG + 2
+// input rows ([channel][row][W], rows as they lie in HBM -- no halo columns: the two taps that leave a row on the left / right are
+// selected away on the lanes concerned; rows above / below the image likewise, wave-uniform) and the 8 x 9 x MT filter block.  Two
+// buffers; the DMA of stage t+1 is issued between the MFMAs of stage t; a workgroup walks a contiguous range of (sample, row block)
+// units and the channel chunks of each, so prologue and stores overlap the next unit's staging.
+// Plane strides = 16 (mod 32): the four k-groups of a 16x16x4 operand read (two per 32-lane LDS access) hit disjoint bank halves.
+#include <cstdlib>
+
+#include "common.h"
+
+using namespace cnn_amd;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+constexpr unsigned kOob = 0x80000000u;
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float* lds) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_ptr)lds, 16, (int)voff, (int)soff, 0, 0);
+}
+
+struct RowsParams {
+    const float* x;     // input tensor [B][C][H][WI]
+    const float* wt;    // prepared filters [co tile][chunk][8][9][QW]
+    const float* bias;  // nullable (data gradient)
+    float* y;           // output tensor [B][M][HO][WO]
+    int B, C, H, M;     // C = reduction channels, M = output channels
+    int HO;
+    int nchunk;         // ceil(C / 8)
+    int nrb;            // row blocks per sample
+    int units_total, units_per_block;
+    int dbg;
+};
+
+constexpr int kCK = 8;
+
+constexpr int stride16(int len) {  // smallest stride >= len that is 16 (mod 32)
+    return len <= 16 ? 16 : (len - 16 + 31) / 32 * 32 + 16;
+}
+
+// RSEL: rows of the staged block that lie below the image hold whatever follows the plane in memory and are selected away on the B operand
+//       (wave-uniform selects, one per B value); without it they are staged as zeros like the rows above the image -- possible when the
+//       first row below the image starts on a 16-byte unit of the LDS plane (the host checks: always for rows of 4k floats)
+template <int WI, int PAD, int MT, bool RSEL = false>
+struct RowsGeom {
+    static_assert(MT == 128 || MT == 64, "output channels per workgroup");
+    static constexpr int WO = WI + 2 * PAD - 2;
+    static constexpr int NB = (WO + 15) / 16;             // 16-pixel blocks per output row
+    static constexpr int WM = MT / 32, WR = 4 / WM;       // waves over co x row pairs
+    static constexpr int RW = 2, RG = WR * RW;            // rows per wave / per workgroup
+    static constexpr int XR = RG + 2;                     // staged input rows
+    static constexpr int LEAD = (4 - (PAD * WI) % 4) % 4;  // row 0 of the image on a 16-byte unit boundary of the first row block
+    static constexpr int XSPAN = LEAD + XR * WI;
+    static constexpr int QXP = stride16(XSPAN + 4);       // x plane stride (floats)
+    static constexpr int QW = MT + 16;                    // filter row stride: 9 * QW = 16 (mod 32)
+    static_assert(QXP % 32 == 16 && (9 * QW) % 32 == 16, "bank halves");
+    static constexpr int XIMG = kCK * QXP, WIMG = kCK * 9 * QW;
+    static constexpr int NIX = (XIMG / 4 + 63) / 64, NIWT = (WIMG / 4 + 63) / 64;  // DMA instructions per stage
+    static constexpr int NIWX = (NIX + 3) / 4, NIWW = (NIWT + 3) / 4;              // per wave
+    static constexpr int NSLOT = NIWX + NIWW;
+    static constexpr int XS = NIX * 256, WS = NIWT * 256;  // image sizes in whole instructions
+    static constexpr int BUF = XS + WS;
+    static constexpr int DUMP = 2 * BUF;
+    static constexpr size_t lds_bytes = (size_t)(2 * BUF + 4 * 256) * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "LDS plan");
+    static constexpr int KSTEPS = kCK / 4;  // MFMA k-steps per tap
+};
+
+template <int WI, int PAD, int MT, bool RSEL>
+__global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
+    using G = RowsGeom<WI, PAD, MT, RSEL>;
+    constexpr int WO = G::WO, NB = G::NB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % G::WM, wr = wave / G::WM;
+    const int co0 = blockIdx.y * MT;
+    const int H = p.H, HWI = H * WI, HWO = p.HO * WO;
+
+    const int u_lo = blockIdx.x * p.units_per_block;
+    const int u_hi = u_lo + p.units_per_block < p.units_total ? u_lo + p.units_per_block : p.units_total;
+    if (u_lo >= u_hi) return;
+
+    // ---- this wave's share of a stage's x DMA, decoded once: byte offset from (first channel of the chunk, staged row 0) counted from
+    //      PAD*WI + 4 floats in front of the tensor (xrs), and the last staged row the unit touches (units of rows above the image of the
+    //      first row block are not fetched: for the first plane of the tensor they lie in front of the allocation)
+    unsigned xd_off[G::NIWX];
+    int xd_row[G::NIWX];   // last staged row the unit touches | first one << 8
+#pragma unroll
+    for (int i = 0; i < G::NIWX; ++i) {
+        const int j = i * 4 + wave, q = j * 64 + lane;
+        const int plane = q / (G::QXP / 4), e = q - plane * (G::QXP / 4);
+        const bool have = j < G::NIX && plane < kCK && e * 4 < G::XSPAN;
+        xd_off[i] = have ? (unsigned)(plane * HWI + e * 4 - G::LEAD + 4) * 4u : kOob;
+        const int first = e * 4 - G::LEAD < 0 ? 0 : (e * 4 - G::LEAD) / WI;
+        xd_row[i] = (((e + 1) * 4 - 1 - G::LEAD) / WI) | (first << 8);
+    }
+    constexpr int BACK = PAD * WI + 4;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - BACK), 0, (int)(((unsigned)p.B * p.C * HWI + BACK) * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.wt + (size_t)blockIdx.y * p.nchunk * G::WIMG), 0, (int)((unsigned)p.nchunk * G::WIMG * 4u), 0x00020000);
+
+    float* const dump = smem + G::DUMP + wave * 256;
+    // slot k of the DMA of stage (sample b, first output row r0, chunk cc) into `buf` = [x image][filter image]
+    auto dma_slot = [&](int k, int b, int r0, int cc, float* buf) {
+        if (k < G::NIWX) {
+            const int j = k * 4 + wave;
+            float* d = j < G::NIX ? buf + j * 256 : dump;
+            const int nneg = PAD - r0;      // staged rows above the image
+            const int nv = H + PAD - r0;    // first staged row below it
+            unsigned voff = xd_off[k];
+            voff = ((xd_row[k] & 255) < nneg) ? kOob : voff;
+            if (!RSEL && PAD > 0) voff = ((xd_row[k] >> 8) >= nv) ? kOob : voff;
+            blds16(xrs, voff, (unsigned)((b * p.C + cc * kCK) * HWI + r0 * WI) * 4u, d);
+        } else {
+            const int i = k - G::NIWX, j = i * 4 + wave;
+            float* d = j < G::NIWT ? buf + G::XS + j * 256 : dump;
+            const unsigned q = (unsigned)(j * 64 + lane);
+            blds16(wrs, (j < G::NIWT && q * 4 < (unsigned)G::WIMG) ? q * 16u : kOob, (unsigned)cc * (unsigned)(G::WIMG * 4), d);
+        }
+    };
+
+    // ---- per-lane operand bases (floats inside a buffer)
+    const int b_base = kq * G::QXP + G::LEAD + n - PAD + wr * G::RW * WI;
+    const int a_base = G::XS + kq * 9 * G::QW + wm * 32 + n;
+
+    f32x4 acc[2][G::RW][NB];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+            for (int rw = 0; rw < G::RW; ++rw)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[ma][rw][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+
+    const int nstages = (u_hi - u_lo) * p.nchunk;
+    int b = u_lo / p.nrb, r0 = (u_lo - b * p.nrb) * G::RG, cc = 0;
+    {
+#pragma unroll
+        for (int k = 0; k < G::NSLOT; ++k) dma_slot(k, b, r0, 0, smem);
+    }
+    // the k-steps of a stage: (tap, 4-channel group) pairs; slots are spread over them
+    constexpr int NKS = 9 * G::KSTEPS;
+    constexpr int PER_KS = (G::NSLOT + NKS - 1) / NKS;
+    for (int t = 0; t < nstages; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float* cur = smem + (t & 1) * G::BUF;
+        float* nxt = smem + ((t + 1) & 1) * G::BUF;
+        // the stage behind this one (behind the last one: that one again)
+        int bn = b, r0n = r0, ccn = cc;
+        if (t + 1 < nstages) {
+            if (cc + 1 < p.nchunk) ccn = cc + 1;
+            else {
+                ccn = 0;
+                if (r0 + G::RG < p.HO) r0n = r0 + G::RG;
+                else { r0n = 0; bn = b + 1; }
+            }
+        }
+        // rows of the staged block that lie outside the image (wave-uniform; only with padding)
+        unsigned rowbad = 0;
+        if (PAD > 0 && RSEL) {  // (rows above the image are staged as zeros in either variant)
+#pragma unroll
+            for (int i = 0; i < G::XR; ++i) rowbad |= (r0 - PAD + i >= H ? 1u : 0u) << i;
+        }
+        // operands of one k-step (tap, 4-channel group): 2 A values, RW * NB B values -- read one k-step ahead of their MFMAs
+        struct Ops {
+            float a[2];
+            float b[G::RW][NB];
+        };
+        auto read_ops = [&](Ops& o, int ks) {
+            const int tap = ks / G::KSTEPS, s = ks % G::KSTEPS, kx = tap / 3, ky = tap % 3;
+#pragma unroll
+            for (int ma = 0; ma < 2; ++ma) o.a[ma] = cur[a_base + (s * 36 + tap) * G::QW + ma * 16];
+#pragma unroll
+            for (int rw = 0; rw < G::RW; ++rw) {
+                const bool bad = PAD > 0 && RSEL && ((rowbad >> (wr * G::RW + rw + kx)) & 1u);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    float bv = cur[b_base + s * 4 * G::QXP + (rw + kx) * WI + 16 * nb + ky];
+                    // the tap columns that leave the row: pixel 16 nb + n, column 16 nb + n + ky - PAD
+                    if (PAD > 0 && 16 * nb + ky - PAD < 0) bv = (16 * nb + n + ky - PAD < 0) ? 0.f : bv;
+                    if (16 * nb + 15 + ky - PAD >= WI) bv = (16 * nb + n + ky - PAD >= WI) ? 0.f : bv;
+                    if (PAD > 0 && RSEL) bv = bad ? 0.f : bv;
+                    o.b[rw][nb] = bv;
+                }
+            }
+        };
+        Ops ops[2];
+        read_ops(ops[0], 0);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks + 1 < NKS) read_ops(ops[(ks + 1) & 1], ks + 1);
+#pragma unroll
+            for (int k = ks * PER_KS; k < (ks + 1) * PER_KS && k < G::NSLOT; ++k) dma_slot(k, bn, r0n, ccn, nxt);
+            Ops& o = ops[ks & 1];
+            // the reads above may not sink below this point (instruction selection otherwise moves every LDS read down to its first use,
+            // two MFMAs ahead of a full LDS round trip) and the MFMAs below may not rise above it
+            asm volatile("" : "+v"(o.a[0]) : : "memory");
+#pragma unroll
+            for (int rw = 0; rw < G::RW; ++rw)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int ma = 0; ma < 2; ++ma) acc[ma][rw][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[ma], o.b[rw][nb], acc[ma][rw][nb], 0, 0, 0);
+        }
+        if (cc + 1 == p.nchunk) {
+            // ---- this unit is complete: + bias, store (D[i][j]: lane (j = n, kq) holds rows i = 4 kq + r)
+#pragma unroll
+            for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + wm * 32 + ma * 16 + 4 * kq + r;
+                    const float bs = (p.bias != nullptr && co < p.M) ? p.bias[co] : 0.f;
+#pragma unroll
+                    for (int rw = 0; rw < G::RW; ++rw) {
+                        const int row = r0 + wr * G::RW + rw;
+                        float* yrow = p.y + ((size_t)b * p.M + co) * HWO + (size_t)row * WO;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            if (co < p.M && row < p.HO && 16 * nb + n < WO) yrow[16 * nb + n] = acc[ma][rw][nb][r] + bs;
+                    }
+                }
+            zero_acc();
+        }
+        b = bn; r0 = r0n; cc = ccn;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// filters -> [co tile][chunk][channel 0..7][tap][QW]; mode 0: forward (w[co][c][tap]); mode 1: data gradient (w[c][m][8 - tap])
+__global__ __launch_bounds__(256) void rows_prep(const float* __restrict__ w, float* __restrict__ wt, int Co, int Ci, int mode, int MT, int QW, int nchunk,
+                                                 int ntiles) {
+    const long long total = (long long)ntiles * nchunk * kCK * 9 * QW;
+    const int C = mode == 0 ? Ci : Co, M = mode == 0 ? Co : Ci;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int j = (int)(i % QW);
+        long long r = i / QW;
+        const int tap = (int)(r % 9); r /= 9;
+        const int cl = (int)(r % kCK); r /= kCK;
+        const int cc = (int)(r % nchunk);
+        const int tile = (int)(r / nchunk);
+        const int m = tile * MT + j, c = cc * kCK + cl;
+        float v = 0.f;
+        if (j < MT && m < M && c < C) v = mode == 0 ? w[((size_t)m * Ci + c) * 9 + tap] : w[((size_t)c * Ci + m) * 9 + (8 - tap)];
+        wt[i] = v;
+    }
+}
+
+struct RowsPlan {
+    RowsParams p;
+    int wi, pad, mt, qw, ntiles, blocks, rsel;
+    size_t wt_floats;
+};
+
+// mode 0: forward of d; mode 1: data gradient of d
+bool make_rows_plan(const cnn_conv2d_desc* d, int mode, RowsPlan* pl) {
+    const OptVal e = CNN_OPT_VAL("CONV_ROWS");
+    if (e && atoi(e) == 0) return false;
+    if (d->k != 3 || d->s != 1 || d->pad < 0 || d->pad > 1 || d->B < 1) return false;
+    const int Ho = d->H + 2 * d->pad - 2, Wo = d->W + 2 * d->pad - 2;
+    if (Ho < 1 || Wo < 1) return false;
+    const int wi = mode == 0 ? d->W : Wo, hi = mode == 0 ? d->H : Ho, pad = mode == 0 ? d->pad : 2 - d->pad;
+    const int C = mode == 0 ? d->Ci : d->Co, M = mode == 0 ? d->Co : d->Ci;
+    const int ho = mode == 0 ? Ho : d->H;
+    if (!((wi == 112 && pad <= 1) || (wi == 110 && pad == 2))) return false;  // (the instances below)
+    if (C < 16 || C % kCK != 0 || M < 32) return false;  // (whole 8-channel chunks: no plane of a stage lies behind the sample's channels)
+    if ((long long)d->B * C * hi * wi >= (1ll << 29) || (long long)d->B * M * ho * (wi + 2 * pad - 2) >= (1ll << 31)) return false;
+    RowsParams& p = pl->p;
+    p.B = d->B; p.C = C; p.H = hi; p.M = M; p.HO = ho;
+    p.nchunk = (C + kCK - 1) / kCK;
+    pl->wi = wi; pl->pad = pad;
+    // (measured on the north-star forward: the 128-channel tile -- 4 x 1 waves, two rows each -- 117 TFLOP/s; with four rows per wave (224
+    // accumulator registers) 95; as two 64-channel tiles of 2 x 2 waves 113)
+    pl->mt = M > 64 ? 128 : 64;
+    pl->qw = pl->mt + 16;
+    pl->ntiles = (M + pl->mt - 1) / pl->mt;
+    const int rg = pl->mt == 128 ? 2 : 4;
+    // zero staging of the rows below the image needs the first of them on a 16-byte unit of the plane: staged row (hi + pad - r0), r0 a
+    // multiple of rg, lead pad (4 - pad*wi % 4) % 4 in front
+    pl->rsel = 0;
+    if (pad > 0) {
+        const int lead = (4 - (pad * wi) % 4) % 4;
+        for (int r0 = 0; r0 < ho; r0 += rg)
+            if (r0 + rg + 2 - pad > hi && ((hi + pad - r0) * wi + lead) % 4 != 0) pl->rsel = 1;
+    }
+    p.nrb = (ho + rg - 1) / rg;
+    p.units_total = d->B * p.nrb;
+    const int env = CNN_OPT_INT("ROWS_BLOCKS", 0);
+    long long want = (env > 0 ? env : num_cus()) / pl->ntiles;
+    if (want < 1) want = 1;
+    if (want > p.units_total) want = p.units_total;
+    p.units_per_block = (int)((p.units_total + want - 1) / want);
+    pl->blocks = (p.units_total + p.units_per_block - 1) / p.units_per_block;
+    pl->wt_floats = (size_t)pl->ntiles * p.nchunk * kCK * 9 * pl->qw;
+    p.dbg = CNN_OPT_INT("ROWS_DBG", 0);
+    return true;
+}
+
+template <int WI, int PAD, int MT, bool RSEL>
+int launch_rows2(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, hipStream_t s) {
+    using G = RowsGeom<WI, PAD, MT, RSEL>;
+    auto kern = conv_rows_kernel<WI, PAD, MT, RSEL>;
+    static DeviceOnce attr_once;
+    if (attr_once.needed()) {
+        CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes));
+        attr_once.mark();
+    }
+    char name[48];
+    snprintf(name, sizeof(name), "conv_rows<%d,%d,%d>/%s", WI, PAD, MT, tag);
+    CNN_KLAUNCH(s, name, (kern<<<dim3(pl.blocks, pl.ntiles), 256, G::lds_bytes, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W, d->Co,
+                d->k, d->s, d->pad);
+    return CNN_AMD_OK;
+}
+
+template <int WI, int PAD, int MT>
+int launch_rows(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, hipStream_t s) {
+    if constexpr (PAD > 0 && WI % 4 != 0) {
+        if (pl.rsel) return launch_rows2<WI, PAD, MT, true>(pl, tag, d, s);
+    }
+    return launch_rows2<WI, PAD, MT, false>(pl, tag, d, s);
+}
+
+int run_rows(const cnn_conv2d_desc* d, int mode, const float* in, const float* w, const float* bias, float* out, void* ws, size_t ws_bytes, hipStream_t s) {
+    RowsPlan pl;
+    if (!make_rows_plan(d, mode, &pl)) return fail(CNN_AMD_E_BADARG, "conv_rows: geometry not covered");
+    if (ws == nullptr || ws_bytes < pl.wt_floats * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 15))
+        return fail(CNN_AMD_E_WORKSPACE, "conv_rows: workspace %zu B < %zu B", ws_bytes, pl.wt_floats * sizeof(float));
+    float* wt = (float*)ws;
+    CNN_KLAUNCH(s, "rows_prep", (rows_prep<<<stream_grid(pl.wt_floats, 256), 256, 0, s>>>(w, wt, d->Co, d->Ci, mode, pl.mt, pl.qw, pl.p.nchunk, pl.ntiles)),
+                "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad);
+    pl.p.x = in; pl.p.wt = wt; pl.p.bias = bias; pl.p.y = out;
+    const char* tag = mode == 0 ? "fwd" : "dgrad";
+    if (pl.wi == 112 && pl.pad == 0) return pl.mt == 128 ? launch_rows<112, 0, 128>(pl, tag, d, s) : launch_rows<112, 0, 64>(pl, tag, d, s);
+    if (pl.wi == 112 && pl.pad == 1) return pl.mt == 128 ? launch_rows<112, 1, 128>(pl, tag, d, s) : launch_rows<112, 1, 64>(pl, tag, d, s);
+    return pl.mt == 128 ? launch_rows<110, 2, 128>(pl, tag, d, s) : launch_rows<110, 2, 64>(pl, tag, d, s);
+}
+
+}  // namespace
+
+namespace cnn_amd {
+
+// floats of workspace the row kernel needs for its prepared filters (0: geometry not covered in that mode)
+size_t rows_workspace_floats(const cnn_conv2d_desc* d, int mode) {
+    RowsPlan pl;
+    return make_rows_plan(d, mode, &pl) ? pl.wt_floats : 0;
+}
+int rows_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t s) {
+    return run_rows(d, 0, x, w, bias, y, ws, ws_bytes, s);
+}
+int rows_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t s) {
+    return run_rows(d, 1, dy, w, nullptr, dx, ws, ws_bytes, s);
+}
+
+}  // namespace cnn_amd

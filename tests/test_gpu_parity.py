@@ -228,6 +228,38 @@ def test_conv2d_wgrad_small_planes(T, case, unit, lib_option):
     assert_close(host(gw3), gw_ref, REL_TOL, "register-direct weight grad")
 
 
+ROWS_CASES = [
+    (2, 64, 7, 112, 128, 3, 1, 0),   # the north-star geometry at a small height: forward 112-wide pad 0 (128-channel tile), data gradient 110-wide pad 2
+    (1, 40, 9, 112, 104, 3, 1, 0),   # ... partial output-channel tiles (104 of 128 forward, 40 of 64 backward), 5 / 13 channel chunks
+    (2, 64, 6, 112, 64, 3, 1, 1),    # pad 1 (VGG conv2 class): halo rows above / below, both tap columns that leave a row; 64-channel tile (2 x 2 waves)
+    (3, 32, 5, 112, 40, 3, 1, 1),    # ... ragged row blocks (5 rows in blocks of 4 / 2), four chunks
+]
+
+
+@pytest.mark.parametrize("case", ROWS_CASES, ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_conv2d_row_kernel_vs_oracle(T, case, lib_option):
+    """conv_rows.hip (round 5: LDS-staged 3x3 / stride-1 forward and data gradient of wide planes, conv2d.cpp:69-92 / 168-199) against the
+    oracle, and against the implicit GEMM it replaces on these geometries (CNN_AMD_CONV_ROWS=0)"""
+    from cnn_amd import capi
+
+    x, w, b, dy = _conv_inputs(case, 440)
+    y_ref, _, _, dx_ref = _oracle_conv(case, x, w, b, dy)
+    conv = capi.Conv2d(*case)
+    xd, wd, bd, dyd = dev(T, x), dev(T, w), dev(T, b), dev(T, dy)
+    capi.kernel_timing(1)
+    y = conv.forward(xd, wd, bd)
+    dx = conv.backward_data(dyd, wd)
+    T.cuda.synchronize()
+    names = [k.split("|")[0] for k in capi.kernel_timing_report()]
+    capi.kernel_timing(0)
+    assert sum(n.startswith("conv_rows<") for n in names) == 2, names
+    assert_close(host(y), y_ref, REL_TOL, "row kernel forward")
+    assert_close(host(dx), dx_ref, REL_TOL, "row kernel data gradient")
+    lib_option("CONV_ROWS", "0")
+    assert_close(host(conv.forward(xd, wd, bd)), y_ref, REL_TOL, "implicit GEMM forward")
+    assert_close(host(conv.backward_data(dyd, wd)), dx_ref, REL_TOL, "implicit GEMM data gradient")
+
+
 def test_u8_batch_stager_is_bit_identical_to_the_reference_conversion(T, golden_dir):
     """row n4, cnn_batch_stager_create_u8: the bytes of a real input (the six images behind the reference's own Grad-CAM pictures and the
     three README images, tests/golden/*_images_u8.*) are uploaded AS BYTES and converted on the device to the fp32 planar batch --
