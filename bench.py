@@ -55,7 +55,7 @@ def algorithmic_work(key):
                 return x_b + pd_b + mk_b + w_b, fl       # x, w -> pooled + mask
             nt = 1 if kernel.endswith(("+poolm", "+poolm8")) else 2    # "+poolm": the ReLU mask rides in the pool mask, the pooled tensor is not read
             return x_b + nt * pd_b + mk_b + w_b, fl       # wgrad: x + (dpool, mask[, pooled]) -> gw ; dgrad: those -> dx
-        if kernel.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel", "wgrad_rd", "wgrad_sp", "conv_direct", "conv_dgrad_pk", "conv_fwd_pk",
+        if kernel.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel", "wgrad_rd", "wgrad_sp", "conv_rows", "conv_direct", "conv_dgrad_pk", "conv_fwd_pk",
                               "conv_wgrad_pk", "conv_wgrad_win", "conv_wgrad_os", "conv_stem", "conv_dgrad_thin", "conv_fwd_rd", "conv_dgrad_rd", "conv_1x1")):
             fused = y_b if (kernel.endswith("/fwd+relu") or ",relu" in kernel or kernel.endswith(">+relu")) else 0.0  # second output tensor
             if "dgrad" in kernel and kernel.endswith("+relu"):
@@ -173,7 +173,7 @@ def conv_ns_bench(torch, capi, reps=5):
     out = {"shape": "B256 64->128 k3 s1 112x112->110x110", "gflop": round(flops / 1e9, 2), "peak_tflops": PEAK_MFMA_F32_TFLOPS}
     for key, (cnt, ms) in rep.items():
         name = key.split("|")[0]
-        if name.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel", "wgrad_rd", "wgrad_sp", "conv_fwd_rd", "conv_dgrad_rd")):
+        if name.startswith(("igemm_kernel", "igemm_dma_kernel", "wgrad_kernel", "wgrad_rd", "wgrad_sp", "conv_rows", "conv_fwd_rd", "conv_dgrad_rd")):
             tf = flops / (ms / 1e3 / cnt) / 1e12
             tag = "fwd" if name.endswith(("/fwd", "/fwd+relu")) else ("dgrad" if name.endswith("/dgrad") else "wgrad")
             out[tag] = {"kernel": name, "avg_ms": round(ms / cnt, 4), "tflops": round(tf, 2),

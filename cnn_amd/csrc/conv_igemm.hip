@@ -1679,8 +1679,9 @@ size_t dgrad_rd_prepared_floats(const cnn_conv2d_desc* d);
 int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* img, const float* relu_below,
                            float* dx, void* ws, size_t ws_bytes, hipStream_t s);
 size_t rows_workspace_floats(const cnn_conv2d_desc* d, int mode);  // conv_rows.hip (round 5): LDS-staged 3x3 / stride-1 forward and data gradient
-int rows_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t s);  // of wide planes
-int rows_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t s);
+int rows_prepare(const cnn_conv2d_desc* d, int mode, const float* w, float* image, hipStream_t s);                                   // of wide planes
+int rows_run(const cnn_conv2d_desc* d, int mode, const float* in, const float* image, const float* bias, float* out, float* out_relu,
+             const float* relu_below, hipStream_t s);
 bool fwd_rd_supported(const cnn_conv2d_desc* d);  // conv_fwd_rd.hip: register-direct forward of the mid-size 3x3 layers
 size_t fwd_rd_prepared_floats(const cnn_conv2d_desc* d);
 int rd_prepare_batch(int n, const cnn_conv2d_desc* descs, const float* const* w, const float* const* bias, void* const* fwd,
@@ -1743,10 +1744,13 @@ static int conv2d_forward_impl(const char* who, const cnn_conv2d_desc* d, const 
     if (direct_conv_supported(d)) return direct_conv_forward(d, x, w, bias, y, y_relu, ws, ws_bytes, as_stream(stream), prepared);
     if (c11_supported(d))  // (its "prepared" image is a verbatim copy of w)
         return c11_forward(d, x, prepared ? (const float*)ws : w, bias, y, y_relu, as_stream(stream));
-    // (round 5) plain forward of a wide 3x3 / stride-1 layer: the row kernel, when the caller's workspace holds its filter image
-    if (!prepared && y && !y_relu && rows_workspace_floats(d, MODE_FWD) > 0 && ws != nullptr &&
-        ws_bytes >= rows_workspace_floats(d, MODE_FWD) * sizeof(float))
-        return rows_forward(d, x, w, bias, y, ws, ws_bytes, as_stream(stream));
+    // (round 5) wide 3x3 / stride-1 layers: the row kernel (conv_rows.hip); the workspace / prepared buffer holds its filter image
+    if (rows_workspace_floats(d, MODE_FWD) > 0 && ws != nullptr && ws_bytes >= rows_workspace_floats(d, MODE_FWD) * sizeof(float) &&
+        (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+        if (!prepared)
+            if (int rc = rows_prepare(d, MODE_FWD, w, (float*)ws, as_stream(stream))) return rc;
+        return rows_run(d, MODE_FWD, x, (const float*)ws, bias, y, y_relu, nullptr, as_stream(stream));
+    }
     if (fwd_rd_supported(d))
         return fwd_rd_forward(d, x, prepared ? nullptr : w, prepared ? (const float*)ws : nullptr, bias, y, y_relu, as_stream(stream));
     if (stem_fwd_supported(d) && (y || y_relu))  // (its "prepared" image is a verbatim copy of w)
@@ -1770,9 +1774,12 @@ static int conv2d_backward_data_impl(const char* who, const cnn_conv2d_desc* d, 
         return c11_backward_data(d, dy, prepared ? (const float*)ws : w, relu_below, dx, as_stream(stream));
     if (thin_dgrad_supported(d))  // (its "prepared" image is a verbatim copy of w)
         return thin_dgrad(d, dy, prepared ? (const float*)ws : w, relu_below, dx, as_stream(stream));
-    if (!prepared && !relu_below && rows_workspace_floats(d, MODE_DGRAD) > 0 && ws != nullptr &&
-        ws_bytes >= rows_workspace_floats(d, MODE_DGRAD) * sizeof(float))
-        return rows_backward_data(d, dy, w, dx, ws, ws_bytes, as_stream(stream));
+    if (rows_workspace_floats(d, MODE_DGRAD) > 0 && ws != nullptr && ws_bytes >= rows_workspace_floats(d, MODE_DGRAD) * sizeof(float) &&
+        (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+        if (!prepared)
+            if (int rc = rows_prepare(d, MODE_DGRAD, w, (float*)ws, as_stream(stream))) return rc;
+        return rows_run(d, MODE_DGRAD, dy, (const float*)ws, nullptr, dx, nullptr, relu_below, as_stream(stream));
+    }
     if (dgrad_rd_supported(d))
         return dgrad_rd_backward_data(d, dy, prepared ? nullptr : w, prepared ? (const float*)ws : nullptr, relu_below, dx,
                                       prepared ? nullptr : ws, prepared ? 0 : ws_bytes, as_stream(stream));
@@ -1797,6 +1804,7 @@ static size_t autotune_scratch_floats(const cnn_conv2d_desc* d, size_t* nx, size
 // measured once per process)?
 static bool autotune_applies(const cnn_conv2d_desc* d, int mode) {
     if (direct_conv_supported(d) || c11_supported(d)) return false;
+    if (rows_workspace_floats(d, mode) > 0) return false;  // (conv_rows.hip has no tile to choose)
     const bool rd_fwd = mode == MODE_FWD && fwd_rd_supported(d);
     const bool rd_dgrad = mode == MODE_DGRAD && dgrad_rd_supported(d);
     if (rd_fwd && fwd_rd_small(d)) return false;
@@ -2061,6 +2069,16 @@ int cnn_conv2d_prepare_filters(int n, const cnn_conv2d_desc* descs, const float*
     hipStream_t s = as_stream(stream);
     unsigned fdone = 0, ddone = 0;
     if (int rc = direct_prepare_batch(n, descs, w, bias, fwd, dgrad, s, &fdone, &ddone)) return rc;
+    for (int i = 0; i < n; ++i) {  // (round 5) the row kernel's layers: the per-layer entry points look for it before the register-direct kernels too (direct_prepare_batch resets the masks: it goes first)
+        if (check_desc("cnn_conv2d_prepare_filters", &descs[i]) || direct_conv_supported(&descs[i]) || c11_supported(&descs[i])) continue;
+        for (int mode = 0; mode < 2; ++mode) {
+            void* out = mode == MODE_FWD ? (fwd ? fwd[i] : nullptr) : (dgrad ? dgrad[i] : nullptr);
+            if (!out || rows_workspace_floats(&descs[i], mode) == 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0) continue;
+            CNN_REQUIRE(w[i] != nullptr, "cnn_conv2d_prepare_filters: filters of layer %d are null", i);
+            if (int rc = rows_prepare(&descs[i], mode, w[i], (float*)out, s)) return rc;
+            (mode == MODE_FWD ? fdone : ddone) |= 1u << i;
+        }
+    }
     if (int rc = rd_prepare_batch(n, descs, w, bias, fwd, dgrad, s, &fdone, &ddone)) return rc;
     PrepBatch pb;
     pb.n = 0;

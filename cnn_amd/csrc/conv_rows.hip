@@ -35,7 +35,9 @@ struct RowsParams {
     const float* x;     // input tensor [B][C][H][WI]
     const float* wt;    // prepared filters [co tile][chunk][8][9][QW]
     const float* bias;  // nullable (data gradient)
-    float* y;           // output tensor [B][M][HO][WO]
+    float* y;           // output tensor [B][M][HO][WO] (nullable when y_relu is given: only the ReLU output is wanted)
+    float* y_relu;      // nullable: the output of the ReLU layer behind this one (relu.cpp:25), written by the same pass
+    const float* relu_below;  // nullable (data gradient): output of the ReLU layer in front -- its backward pass (relu.cpp:37) on the way out
     int B, C, H, M;     // C = reduction channels, M = output channels
     int HO;
     int nchunk;         // ceil(C / 8)
@@ -229,10 +231,15 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
 #pragma unroll
                     for (int rw = 0; rw < G::RW; ++rw) {
                         const int row = r0 + wr * G::RW + rw;
-                        float* yrow = p.y + ((size_t)b * p.M + co) * HWO + (size_t)row * WO;
+                        const size_t yoff = ((size_t)b * p.M + co) * HWO + (size_t)row * WO;
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
-                            if (co < p.M && row < p.HO && 16 * nb + n < WO) yrow[16 * nb + n] = acc[ma][rw][nb][r] + bs;
+                            if (co < p.M && row < p.HO && 16 * nb + n < WO) {
+                                float v = acc[ma][rw][nb][r] + bs;
+                                if (p.relu_below != nullptr) v = p.relu_below[yoff + 16 * nb + n] <= 0.f ? 0.f : v;
+                                if (p.y != nullptr) p.y[yoff + 16 * nb + n] = v;
+                                if (p.y_relu != nullptr) p.y_relu[yoff + 16 * nb + n] = v >= 0.f ? v : 0.f;
+                            }
                     }
                 }
             zero_acc();
@@ -335,16 +342,7 @@ int launch_rows(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, h
     return launch_rows2<WI, PAD, MT, false>(pl, tag, d, s);
 }
 
-int run_rows(const cnn_conv2d_desc* d, int mode, const float* in, const float* w, const float* bias, float* out, void* ws, size_t ws_bytes, hipStream_t s) {
-    RowsPlan pl;
-    if (!make_rows_plan(d, mode, &pl)) return fail(CNN_AMD_E_BADARG, "conv_rows: geometry not covered");
-    if (ws == nullptr || ws_bytes < pl.wt_floats * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 15))
-        return fail(CNN_AMD_E_WORKSPACE, "conv_rows: workspace %zu B < %zu B", ws_bytes, pl.wt_floats * sizeof(float));
-    float* wt = (float*)ws;
-    CNN_KLAUNCH(s, "rows_prep", (rows_prep<<<stream_grid(pl.wt_floats, 256), 256, 0, s>>>(w, wt, d->Co, d->Ci, mode, pl.mt, pl.qw, pl.p.nchunk, pl.ntiles)),
-                "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad);
-    pl.p.x = in; pl.p.wt = wt; pl.p.bias = bias; pl.p.y = out;
-    const char* tag = mode == 0 ? "fwd" : "dgrad";
+int launch_any(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, hipStream_t s) {
     if (pl.wi == 112 && pl.pad == 0) return pl.mt == 128 ? launch_rows<112, 0, 128>(pl, tag, d, s) : launch_rows<112, 0, 64>(pl, tag, d, s);
     if (pl.wi == 112 && pl.pad == 1) return pl.mt == 128 ? launch_rows<112, 1, 128>(pl, tag, d, s) : launch_rows<112, 1, 64>(pl, tag, d, s);
     return pl.mt == 128 ? launch_rows<110, 2, 128>(pl, tag, d, s) : launch_rows<110, 2, 64>(pl, tag, d, s);
@@ -354,16 +352,28 @@ int run_rows(const cnn_conv2d_desc* d, int mode, const float* in, const float* w
 
 namespace cnn_amd {
 
-// floats of workspace the row kernel needs for its prepared filters (0: geometry not covered in that mode)
+// floats of the row kernel's prepared filter image (0: geometry not covered in that mode); mode 0 = forward, 1 = data gradient
 size_t rows_workspace_floats(const cnn_conv2d_desc* d, int mode) {
     RowsPlan pl;
     return make_rows_plan(d, mode, &pl) ? pl.wt_floats : 0;
 }
-int rows_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t s) {
-    return run_rows(d, 0, x, w, bias, y, ws, ws_bytes, s);
+// the filter image of layer d in `mode` into `image` (rows_workspace_floats floats, 16-byte aligned)
+int rows_prepare(const cnn_conv2d_desc* d, int mode, const float* w, float* image, hipStream_t s) {
+    RowsPlan pl;
+    if (!make_rows_plan(d, mode, &pl)) return fail(CNN_AMD_E_BADARG, "conv_rows: geometry not covered");
+    CNN_REQUIRE(w && image && (reinterpret_cast<uintptr_t>(image) & 15) == 0, "conv_rows: filter image must be 16-byte aligned");
+    CNN_KLAUNCH(s, "rows_prep", (rows_prep<<<stream_grid(pl.wt_floats, 256), 256, 0, s>>>(w, image, d->Co, d->Ci, mode, pl.mt, pl.qw, pl.p.nchunk, pl.ntiles)),
+                "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad);
+    return CNN_AMD_OK;
 }
-int rows_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t s) {
-    return run_rows(d, 1, dy, w, nullptr, dx, ws, ws_bytes, s);
+// forward (mode 0: in = x, out = y and / or y_relu) or data gradient (mode 1: in = dy, out = dx, relu_below nullable) from a prepared image
+int rows_run(const cnn_conv2d_desc* d, int mode, const float* in, const float* image, const float* bias, float* out, float* out_relu,
+             const float* relu_below, hipStream_t s) {
+    RowsPlan pl;
+    if (!make_rows_plan(d, mode, &pl)) return fail(CNN_AMD_E_BADARG, "conv_rows: geometry not covered");
+    pl.p.x = in; pl.p.wt = image; pl.p.bias = mode == 0 ? bias : nullptr; pl.p.y = out; pl.p.y_relu = out_relu; pl.p.relu_below = relu_below;
+    const char* tag = mode == 0 ? (out_relu ? (out ? "fwd+relu" : "fwd,relu") : "fwd") : (relu_below ? "dgrad+relu" : "dgrad");
+    return launch_any(pl, tag, d, s);
 }
 
 }  // namespace cnn_amd
