@@ -55,14 +55,30 @@ constexpr int stride16(int len) {  // smallest stride >= len that is 16 (mod 32)
 // RSEL: rows of the staged block that lie below the image hold whatever follows the plane in memory and are selected away on the B operand
 //       (wave-uniform selects, one per B value); without it they are staged as zeros like the rows above the image -- possible when the
 //       first row below the image starts on a 16-byte unit of the LDS plane (the host checks: always for rows of 4k floats)
-template <int WI, int PAD, int MT, bool RSEL = false>
+// SR:   narrow planes (56, 28 wide; pad 1, so that input and output rows have one pitch): SR consecutive rows form one SUPER-ROW of
+//       SR * W = 112 pixels -- the pixel index of a 16-pixel block is flat across them (a tap is one constant offset in the staged plane
+//       whatever the row), only the lanes that sit on a row's first / last column differ, by compile-time lane masks
+// RW:   super-rows per wave
+template <int WI, int PAD, int MT, bool RSEL = false, int SR = 1, int RW_ = 2>
 struct RowsGeom {
     static_assert(MT == 128 || MT == 64, "output channels per workgroup");
     static constexpr int WO = WI + 2 * PAD - 2;
-    static constexpr int NB = (WO + 15) / 16;             // 16-pixel blocks per output row
-    static constexpr int WM = MT / 32, WR = 4 / WM;       // waves over co x row pairs
-    static constexpr int RW = 2, RG = WR * RW;            // rows per wave / per workgroup
-    static constexpr int XR = RG + 2;                     // staged input rows
+    static_assert(SR == 1 || (WO == WI && !RSEL), "super-rows: equal pitches, zero-staged halo rows");
+    static constexpr int PX = SR * WO;                    // pixels of a super-row
+    static constexpr int NB = (PX + 15) / 16;             // 16-pixel blocks per super-row
+    static constexpr int WM = MT / 32, WR = 4 / WM;       // waves over co x row groups
+    static constexpr int RW = RW_, RG = WR * RW;          // super-rows per wave / per workgroup
+    static constexpr int ROWS = RG * SR;                  // output rows per workgroup unit
+    static constexpr int XR = ROWS + 2;                   // staged input rows
+    // lanes n of block nb whose tap column ky leaves the row: column (16 nb + n) % WI + ky - PAD outside [0, WI)
+    static constexpr unsigned colmask(int nb, int ky) {
+        unsigned m = 0;
+        for (int n = 0; n < 16; ++n) {
+            const int f = 16 * nb + n, col = SR > 1 ? f % WI : f, c = col + ky - PAD;
+            if (c < 0 || c >= WI) m |= 1u << n;
+        }
+        return m;
+    }
     static constexpr int LEAD = (4 - (PAD * WI) % 4) % 4;  // row 0 of the image on a 16-byte unit boundary of the first row block
     static constexpr int XSPAN = LEAD + XR * WI;
     static constexpr int QXP = stride16(XSPAN + 4);       // x plane stride (floats)
@@ -80,9 +96,9 @@ struct RowsGeom {
     static constexpr int KSTEPS = kCK / 4;  // MFMA k-steps per tap
 };
 
-template <int WI, int PAD, int MT, bool RSEL>
+template <int WI, int PAD, int MT, bool RSEL, int SR, int RW_>
 __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
-    using G = RowsGeom<WI, PAD, MT, RSEL>;
+    using G = RowsGeom<WI, PAD, MT, RSEL, SR, RW_>;
     constexpr int WO = G::WO, NB = G::NB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kq = lane >> 4;
@@ -135,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
     };
 
     // ---- per-lane operand bases (floats inside a buffer)
-    const int b_base = kq * G::QXP + G::LEAD + n - PAD + wr * G::RW * WI;
+    const int b_base = kq * G::QXP + G::LEAD + n - PAD + wr * G::RW * SR * WI;
     const int a_base = G::XS + kq * 9 * G::QW + wm * 32 + n;
 
     f32x4 acc[2][G::RW][NB];
@@ -150,7 +166,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
     zero_acc();
 
     const int nstages = (u_hi - u_lo) * p.nchunk;
-    int b = u_lo / p.nrb, r0 = (u_lo - b * p.nrb) * G::RG, cc = 0;
+    int b = u_lo / p.nrb, r0 = (u_lo - b * p.nrb) * G::ROWS, cc = 0;
     {
 #pragma unroll
         for (int k = 0; k < G::NSLOT; ++k) dma_slot(k, b, r0, 0, smem);
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
             if (cc + 1 < p.nchunk) ccn = cc + 1;
             else {
                 ccn = 0;
-                if (r0 + G::RG < p.HO) r0n = r0 + G::RG;
+                if (r0 + G::ROWS < p.HO) r0n = r0 + G::ROWS;
                 else { r0n = 0; bn = b + 1; }
             }
         }
@@ -190,13 +206,15 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
             for (int ma = 0; ma < 2; ++ma) o.a[ma] = cur[a_base + (s * 36 + tap) * G::QW + ma * 16];
 #pragma unroll
             for (int rw = 0; rw < G::RW; ++rw) {
-                const bool bad = PAD > 0 && RSEL && ((rowbad >> (wr * G::RW + rw + kx)) & 1u);
+                const bool bad = PAD > 0 && RSEL && ((rowbad >> (wr * G::RW + rw + kx)) & 1u);  // (RSEL: SR == 1)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    float bv = cur[b_base + s * 4 * G::QXP + (rw + kx) * WI + 16 * nb + ky];
-                    // the tap columns that leave the row: pixel 16 nb + n, column 16 nb + n + ky - PAD
-                    if (PAD > 0 && 16 * nb + ky - PAD < 0) bv = (16 * nb + n + ky - PAD < 0) ? 0.f : bv;
-                    if (16 * nb + 15 + ky - PAD >= WI) bv = (16 * nb + n + ky - PAD >= WI) ? 0.f : bv;
+                    float bv = cur[b_base + s * 4 * G::QXP + (rw * SR + kx) * WI + 16 * nb + ky];
+                    // the tap columns that leave their row (a select: what lies there is the neighbouring row's data)
+                    constexpr unsigned kAll = 0xffffu;
+                    const unsigned cm = G::colmask(nb, ky);
+                    if (cm == kAll) bv = 0.f;
+                    else if (cm != 0) bv = ((cm >> n) & 1u) ? 0.f : bv;
                     if (PAD > 0 && RSEL) bv = bad ? 0.f : bv;
                     o.b[rw][nb] = bv;
                 }
@@ -221,27 +239,50 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
                     for (int ma = 0; ma < 2; ++ma) acc[ma][rw][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[ma], o.b[rw][nb], acc[ma][rw][nb], 0, 0, 0);
         }
         if (cc + 1 == p.nchunk) {
-            // ---- this unit is complete: + bias, store (D[i][j]: lane (j = n, kq) holds rows i = 4 kq + r)
+            // ---- this unit is complete: + bias, store (D[i][j]: lane (j = n, kq) holds rows i = 4 kq + r).  With a ReLU' mask: the mask
+            //      values of one 16-channel block are fetched as ONE batch of independent loads before any of them is used (a load, its
+            //      select and its store per element would be RW * NB * 8 dependent memory round trips per unit)
 #pragma unroll
-            for (int ma = 0; ma < 2; ++ma)
+            for (int ma = 0; ma < 2; ++ma) {
+                float mk[4][G::RW][NB];
+                if (p.relu_below != nullptr) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = co0 + wm * 32 + ma * 16 + 4 * kq + r;
+#pragma unroll
+                        for (int rw = 0; rw < G::RW; ++rw) {
+                            const int row0 = r0 + (wr * G::RW + rw) * SR;
+                            const size_t ybase = ((size_t)b * p.M + co) * HWO + (size_t)row0 * WO;
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb) {
+                                const int f = 16 * nb + n;
+                                const bool ok = co < p.M && f < G::PX && row0 + f / WO < p.HO;
+                                mk[r][rw][nb] = ok ? p.relu_below[ybase + f] : 1.f;
+                            }
+                        }
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = co0 + wm * 32 + ma * 16 + 4 * kq + r;
                     const float bs = (p.bias != nullptr && co < p.M) ? p.bias[co] : 0.f;
 #pragma unroll
                     for (int rw = 0; rw < G::RW; ++rw) {
-                        const int row = r0 + wr * G::RW + rw;
-                        const size_t yoff = ((size_t)b * p.M + co) * HWO + (size_t)row * WO;
+                        const int row0 = r0 + (wr * G::RW + rw) * SR;
+                        const size_t ybase = ((size_t)b * p.M + co) * HWO + (size_t)row0 * WO;  // (a super-row is PX consecutive floats of y)
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            if (co < p.M && row < p.HO && 16 * nb + n < WO) {
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const int f = 16 * nb + n;
+                            if (co < p.M && f < G::PX && row0 + f / WO < p.HO) {
                                 float v = acc[ma][rw][nb][r] + bs;
-                                if (p.relu_below != nullptr) v = p.relu_below[yoff + 16 * nb + n] <= 0.f ? 0.f : v;
-                                if (p.y != nullptr) p.y[yoff + 16 * nb + n] = v;
-                                if (p.y_relu != nullptr) p.y_relu[yoff + 16 * nb + n] = v >= 0.f ? v : 0.f;
+                                if (p.relu_below != nullptr) v = mk[r][rw][nb] <= 0.f ? 0.f : v;
+                                if (p.y != nullptr) p.y[ybase + f] = v;
+                                if (p.y_relu != nullptr) p.y_relu[ybase + f] = v >= 0.f ? v : 0.f;
                             }
+                        }
                     }
                 }
+            }
             zero_acc();
         }
         b = bn; r0 = r0n; cc = ccn;
@@ -270,7 +311,7 @@ __global__ __launch_bounds__(256) void rows_prep(const float* __restrict__ w, fl
 
 struct RowsPlan {
     RowsParams p;
-    int wi, pad, mt, qw, ntiles, blocks, rsel;
+    int wi, pad, mt, qw, ntiles, blocks, rsel, sr, rows;
     size_t wt_floats;
 };
 
@@ -284,7 +325,9 @@ bool make_rows_plan(const cnn_conv2d_desc* d, int mode, RowsPlan* pl) {
     const int wi = mode == 0 ? d->W : Wo, hi = mode == 0 ? d->H : Ho, pad = mode == 0 ? d->pad : 2 - d->pad;
     const int C = mode == 0 ? d->Ci : d->Co, M = mode == 0 ? d->Co : d->Ci;
     const int ho = mode == 0 ? Ho : d->H;
-    if (!((wi == 112 && pad <= 1) || (wi == 110 && pad == 2))) return false;  // (the instances below)
+    // (the instances below: 112-wide planes with any padding, 56- and 28-wide ones with pad 1 as super-rows of 2 / 4 rows)
+    if (!((wi == 112 && pad <= 1) || (wi == 110 && pad == 2) || ((wi == 56 || wi == 28) && pad == 1))) return false;
+    if (wi == 28 && M <= 64) return false;  // (28-wide: one super-row of 4 rows per workgroup needs the 4 x 1 wave layout)
     if (C < 16 || C % kCK != 0 || M < 32) return false;  // (whole 8-channel chunks: no plane of a stage lies behind the sample's channels)
     if ((long long)d->B * C * hi * wi >= (1ll << 29) || (long long)d->B * M * ho * (wi + 2 * pad - 2) >= (1ll << 31)) return false;
     RowsParams& p = pl->p;
@@ -296,7 +339,9 @@ bool make_rows_plan(const cnn_conv2d_desc* d, int mode, RowsPlan* pl) {
     pl->mt = M > 64 ? 128 : 64;
     pl->qw = pl->mt + 16;
     pl->ntiles = (M + pl->mt - 1) / pl->mt;
-    const int rg = pl->mt == 128 ? 2 : 4;
+    pl->sr = wi == 56 ? 2 : (wi == 28 ? 4 : 1);
+    const int rg = (pl->mt == 128 ? (wi == 28 ? 1 : 2) : 4) * pl->sr;  // output rows per workgroup unit
+    pl->rows = rg;
     // zero staging of the rows below the image needs the first of them on a 16-byte unit of the plane: staged row (hi + pad - r0), r0 a
     // multiple of rg, lead pad (4 - pad*wi % 4) % 4 in front
     pl->rsel = 0;
@@ -307,6 +352,9 @@ bool make_rows_plan(const cnn_conv2d_desc* d, int mode, RowsPlan* pl) {
     }
     p.nrb = (ho + rg - 1) / rg;
     p.units_total = d->B * p.nrb;
+    // (measured, tools/one_layer.py: with fewer than ~3 units per CU -- the batch-64 layers of the ResNet-shaped stack: 448 units -- the
+    // FORWARD pass is faster on the implicit GEMM's split-K / wide tiles (87 vs 80 TFLOP/s); the data gradient is not (76 vs 82))
+    if (mode == 0 && p.units_total < 3 * num_cus() && !CNN_OPT_SET("ROWS_ALWAYS")) return false;
     const int env = CNN_OPT_INT("ROWS_BLOCKS", 0);
     long long want = (env > 0 ? env : num_cus()) / pl->ntiles;
     if (want < 1) want = 1;
@@ -318,10 +366,11 @@ bool make_rows_plan(const cnn_conv2d_desc* d, int mode, RowsPlan* pl) {
     return true;
 }
 
-template <int WI, int PAD, int MT, bool RSEL>
+template <int WI, int PAD, int MT, bool RSEL, int SR = 1, int RW = 2>
 int launch_rows2(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, hipStream_t s) {
-    using G = RowsGeom<WI, PAD, MT, RSEL>;
-    auto kern = conv_rows_kernel<WI, PAD, MT, RSEL>;
+    using G = RowsGeom<WI, PAD, MT, RSEL, SR, RW>;
+    auto kern = conv_rows_kernel<WI, PAD, MT, RSEL, SR, RW>;
+    if (G::ROWS != pl.rows) return fail(CNN_AMD_E_BADARG, "conv_rows: plan / instance mismatch");
     static DeviceOnce attr_once;
     if (attr_once.needed()) {
         CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes));
@@ -345,7 +394,9 @@ int launch_rows(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, h
 int launch_any(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, hipStream_t s) {
     if (pl.wi == 112 && pl.pad == 0) return pl.mt == 128 ? launch_rows<112, 0, 128>(pl, tag, d, s) : launch_rows<112, 0, 64>(pl, tag, d, s);
     if (pl.wi == 112 && pl.pad == 1) return pl.mt == 128 ? launch_rows<112, 1, 128>(pl, tag, d, s) : launch_rows<112, 1, 64>(pl, tag, d, s);
-    return pl.mt == 128 ? launch_rows<110, 2, 128>(pl, tag, d, s) : launch_rows<110, 2, 64>(pl, tag, d, s);
+    if (pl.wi == 110) return pl.mt == 128 ? launch_rows<110, 2, 128>(pl, tag, d, s) : launch_rows<110, 2, 64>(pl, tag, d, s);
+    if (pl.wi == 56) return pl.mt == 128 ? launch_rows2<56, 1, 128, false, 2, 2>(pl, tag, d, s) : launch_rows2<56, 1, 64, false, 2, 2>(pl, tag, d, s);
+    return launch_rows2<28, 1, 128, false, 4, 1>(pl, tag, d, s);
 }
 
 }  // namespace

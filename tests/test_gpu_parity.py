@@ -233,6 +233,11 @@ ROWS_CASES = [
     (1, 40, 9, 112, 104, 3, 1, 0),   # ... partial output-channel tiles (104 of 128 forward, 40 of 64 backward), 5 / 13 channel chunks
     (2, 64, 6, 112, 64, 3, 1, 1),    # pad 1 (VGG conv2 class): halo rows above / below, both tap columns that leave a row; 64-channel tile (2 x 2 waves)
     (3, 32, 5, 112, 40, 3, 1, 1),    # ... ragged row blocks (5 rows in blocks of 4 / 2), four chunks
+    (2, 64, 56, 56, 64, 3, 1, 1),    # 56-wide planes: super-rows of two rows (112 flat pixels), 64-channel tiles both ways
+    (2, 64, 8, 56, 128, 3, 1, 1),    # ... 128-channel tile forward (4 x 1 waves), 64-channel tile backward
+    (1, 32, 12, 56, 72, 3, 1, 1),    # ... partial tiles, ragged units (12 rows in units of 8 / 4)
+    (2, 128, 28, 28, 128, 3, 1, 1),  # 28-wide planes: super-rows of four rows, one per workgroup unit (7 units per plane)
+    (1, 72, 10, 28, 200, 3, 1, 1),   # ... partial tiles, ragged units (10 rows in units of 4)
 ]
 
 
@@ -244,6 +249,7 @@ def test_conv2d_row_kernel_vs_oracle(T, case, lib_option):
 
     x, w, b, dy = _conv_inputs(case, 440)
     y_ref, _, _, dx_ref = _oracle_conv(case, x, w, b, dy)
+    lib_option("ROWS_ALWAYS", "1")  # (small problems: the default dispatch keeps short forward passes on the implicit GEMM)
     conv = capi.Conv2d(*case)
     xd, wd, bd, dyd = dev(T, x), dev(T, w), dev(T, b), dev(T, dy)
     capi.kernel_timing(1)

@@ -424,6 +424,7 @@ def test_split_k_wide_tiles_equal_im2col(T, case, cfg, lib_option):
     b = T.randn((Co,), generator=g, device="cuda") * 0.1
     lib_option("IGEMM_CFG", str(cfg))
     lib_option("DGRAD_RD", "0")
+    lib_option("CONV_ROWS", "0")  # (this test is about the implicit GEMM's tiles; conv_rows.hip has test_conv2d_row_kernel_vs_oracle)
     conv = capi.Conv2d(*case)
     dy = T.rand(conv.out_shape(), generator=g, device="cuda") * 2 - 1
 
@@ -470,6 +471,7 @@ def test_wide_and_split_tiles_at_the_stacks_full_sizes(T, case, cfgs, lib_option
     w = T.randn((Co, Ci, k, k), generator=g, device="cuda") * float(np.sqrt(2.0 / (Ci * k * k)))
     b = T.randn((Co,), generator=g, device="cuda") * 0.1
     lib_option("DGRAD_RD", "0")
+    lib_option("CONV_ROWS", "0")  # (the implicit GEMM's tiles)
     conv = capi.Conv2d(*case)
     dy = T.rand(conv.out_shape(), generator=g, device="cuda") * 2 - 1
 
