@@ -59,14 +59,18 @@ constexpr int stride16(int len) {  // smallest stride >= len that is 16 (mod 32)
 //       SR * W = 112 pixels -- the pixel index of a 16-pixel block is flat across them (a tap is one constant offset in the staged plane
 //       whatever the row), only the lanes that sit on a row's first / last column differ, by compile-time lane masks
 // RW:   super-rows per wave
-template <int WI, int PAD, int MT, bool RSEL = false, int SR = 1, int RW_ = 2>
+// WP:   2 = the two waves of a 32-channel co block split the super-row's pixel blocks (whole 14x14 planes as ONE super-row of 196 pixels =
+//       13 blocks: a 64-channel tile of 2 (co) x 2 (pixel halves) waves keeps 256 workgroups busy at batch 64)
+template <int WI, int PAD, int MT, bool RSEL = false, int SR = 1, int RW_ = 2, int WP = 1>
 struct RowsGeom {
     static_assert(MT == 128 || MT == 64, "output channels per workgroup");
     static constexpr int WO = WI + 2 * PAD - 2;
     static_assert(SR == 1 || (WO == WI && !RSEL), "super-rows: equal pitches, zero-staged halo rows");
     static constexpr int PX = SR * WO;                    // pixels of a super-row
     static constexpr int NB = (PX + 15) / 16;             // 16-pixel blocks per super-row
-    static constexpr int WM = MT / 32, WR = 4 / WM;       // waves over co x row groups
+    static constexpr int WM = MT / 32, WR = 4 / (WM * WP);  // waves over co x pixel halves x row groups
+    static_assert(WM * WP * WR == 4, "four waves");
+    static constexpr int NBW = (NB + WP - 1) / WP;        // pixel blocks per wave
     static constexpr int RW = RW_, RG = WR * RW;          // super-rows per wave / per workgroup
     static constexpr int ROWS = RG * SR;                  // output rows per workgroup unit
     static constexpr int XR = ROWS + 2;                   // staged input rows
@@ -96,14 +100,14 @@ struct RowsGeom {
     static constexpr int KSTEPS = kCK / 4;  // MFMA k-steps per tap
 };
 
-template <int WI, int PAD, int MT, bool RSEL, int SR, int RW_>
+template <int WI, int PAD, int MT, bool RSEL, int SR, int RW_, int WP>
 __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
-    using G = RowsGeom<WI, PAD, MT, RSEL, SR, RW_>;
-    constexpr int WO = G::WO, NB = G::NB;
+    using G = RowsGeom<WI, PAD, MT, RSEL, SR, RW_, WP>;
+    constexpr int WO = G::WO, NB = G::NBW;  // (NB: the pixel blocks of THIS wave)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % G::WM, wr = wave / G::WM;
+    const int wm = wave % G::WM, wp = (wave / G::WM) % WP, wr = wave / (G::WM * WP);
     const int co0 = blockIdx.y * MT;
     const int H = p.H, HWI = H * WI, HWO = p.HO * WO;
 
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
     };
 
     // ---- per-lane operand bases (floats inside a buffer)
-    const int b_base = kq * G::QXP + G::LEAD + n - PAD + wr * G::RW * SR * WI;
+    const int b_base = kq * G::QXP + G::LEAD + n - PAD + wr * G::RW * SR * WI + wp * G::NBW * 16;
     const int a_base = G::XS + kq * 9 * G::QW + wm * 32 + n;
 
     f32x4 acc[2][G::RW][NB];
@@ -212,9 +216,15 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
                     float bv = cur[b_base + s * 4 * G::QXP + (rw * SR + kx) * WI + 16 * nb + ky];
                     // the tap columns that leave their row (a select: what lies there is the neighbouring row's data)
                     constexpr unsigned kAll = 0xffffu;
-                    const unsigned cm = G::colmask(nb, ky);
-                    if (cm == kAll) bv = 0.f;
-                    else if (cm != 0) bv = ((cm >> n) & 1u) ? 0.f : bv;
+                    if constexpr (WP == 1) {
+                        const unsigned cm = G::colmask(nb, ky);
+                        if (cm == kAll) bv = 0.f;
+                        else if (cm != 0) bv = ((cm >> n) & 1u) ? 0.f : bv;
+                    } else {
+                        const unsigned c0 = G::colmask(nb, ky), c1 = G::colmask(G::NBW + nb, ky);
+                        if (c0 != 0 || c1 != 0) bv = (((wp ? c1 : c0) >> n) & 1u) ? 0.f : bv;
+                        (void)kAll;
+                    }
                     if (PAD > 0 && RSEL) bv = bad ? 0.f : bv;
                     o.b[rw][nb] = bv;
                 }
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
                             const size_t ybase = ((size_t)b * p.M + co) * HWO + (size_t)row0 * WO;
 #pragma unroll
                             for (int nb = 0; nb < NB; ++nb) {
-                                const int f = 16 * nb + n;
+                                const int f = 16 * (wp * G::NBW + nb) + n;
                                 const bool ok = co < p.M && f < G::PX && row0 + f / WO < p.HO;
                                 mk[r][rw][nb] = ok ? p.relu_below[ybase + f] : 1.f;
                             }
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
                         const size_t ybase = ((size_t)b * p.M + co) * HWO + (size_t)row0 * WO;  // (a super-row is PX consecutive floats of y)
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
-                            const int f = 16 * nb + n;
+                            const int f = 16 * (wp * G::NBW + nb) + n;
                             if (co < p.M && f < G::PX && row0 + f / WO < p.HO) {
                                 float v = acc[ma][rw][nb][r] + bs;
                                 if (p.relu_below != nullptr) v = mk[r][rw][nb] <= 0.f ? 0.f : v;
@@ -326,7 +336,11 @@ bool make_rows_plan(const cnn_conv2d_desc* d, int mode, RowsPlan* pl) {
     const int C = mode == 0 ? d->Ci : d->Co, M = mode == 0 ? d->Co : d->Ci;
     const int ho = mode == 0 ? Ho : d->H;
     // (the instances below: 112-wide planes with any padding, 56- and 28-wide ones with pad 1 as super-rows of 2 / 4 rows)
-    if (!((wi == 112 && pad <= 1) || (wi == 110 && pad == 2) || ((wi == 56 || wi == 28) && pad == 1))) return false;
+    // 14x14 planes with pad 1 whole: one super-row of 196 pixels per workgroup unit
+    if (!((wi == 112 && pad <= 1) || (wi == 110 && pad == 2) || ((wi == 56 || wi == 28) && pad == 1) || (wi == 14 && hi == 14 && pad == 1))) return false;
+    // (measured, 14x14: 79 / 79 TFLOP/s forward / data gradient at 64 x 256 -> 256 against the implicit GEMM's 80 / 67, but 85 / 88 against 97 /
+    // 100 at 128 x 512 -> 512: the instance stays opt-in, ROWS_14=1 or ROWS_ALWAYS)
+    if (wi == 14 && !CNN_OPT_SET("ROWS_14") && !CNN_OPT_SET("ROWS_ALWAYS")) return false;
     if (wi == 28 && M <= 64) return false;  // (28-wide: one super-row of 4 rows per workgroup needs the 4 x 1 wave layout)
     if (C < 16 || C % kCK != 0 || M < 32) return false;  // (whole 8-channel chunks: no plane of a stage lies behind the sample's channels)
     if ((long long)d->B * C * hi * wi >= (1ll << 29) || (long long)d->B * M * ho * (wi + 2 * pad - 2) >= (1ll << 31)) return false;
@@ -336,11 +350,11 @@ bool make_rows_plan(const cnn_conv2d_desc* d, int mode, RowsPlan* pl) {
     pl->wi = wi; pl->pad = pad;
     // (measured on the north-star forward: the 128-channel tile -- 4 x 1 waves, two rows each -- 117 TFLOP/s; with four rows per wave (224
     // accumulator registers) 95; as two 64-channel tiles of 2 x 2 waves 113)
-    pl->mt = M > 64 ? 128 : 64;
+    pl->mt = (M > 64 && wi != 14) ? 128 : 64;
     pl->qw = pl->mt + 16;
     pl->ntiles = (M + pl->mt - 1) / pl->mt;
-    pl->sr = wi == 56 ? 2 : (wi == 28 ? 4 : 1);
-    const int rg = (pl->mt == 128 ? (wi == 28 ? 1 : 2) : 4) * pl->sr;  // output rows per workgroup unit
+    pl->sr = wi == 56 ? 2 : (wi == 28 ? 4 : (wi == 14 ? 14 : 1));
+    const int rg = wi == 14 ? 14 : (pl->mt == 128 ? (wi == 28 ? 1 : 2) : 4) * pl->sr;  // output rows per workgroup unit
     pl->rows = rg;
     // zero staging of the rows below the image needs the first of them on a 16-byte unit of the plane: staged row (hi + pad - r0), r0 a
     // multiple of rg, lead pad (4 - pad*wi % 4) % 4 in front
@@ -366,10 +380,10 @@ bool make_rows_plan(const cnn_conv2d_desc* d, int mode, RowsPlan* pl) {
     return true;
 }
 
-template <int WI, int PAD, int MT, bool RSEL, int SR = 1, int RW = 2>
+template <int WI, int PAD, int MT, bool RSEL, int SR = 1, int RW = 2, int WP = 1>
 int launch_rows2(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, hipStream_t s) {
-    using G = RowsGeom<WI, PAD, MT, RSEL, SR, RW>;
-    auto kern = conv_rows_kernel<WI, PAD, MT, RSEL, SR, RW>;
+    using G = RowsGeom<WI, PAD, MT, RSEL, SR, RW, WP>;
+    auto kern = conv_rows_kernel<WI, PAD, MT, RSEL, SR, RW, WP>;
     if (G::ROWS != pl.rows) return fail(CNN_AMD_E_BADARG, "conv_rows: plan / instance mismatch");
     static DeviceOnce attr_once;
     if (attr_once.needed()) {
@@ -396,6 +410,7 @@ int launch_any(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, hi
     if (pl.wi == 112 && pl.pad == 1) return pl.mt == 128 ? launch_rows<112, 1, 128>(pl, tag, d, s) : launch_rows<112, 1, 64>(pl, tag, d, s);
     if (pl.wi == 110) return pl.mt == 128 ? launch_rows<110, 2, 128>(pl, tag, d, s) : launch_rows<110, 2, 64>(pl, tag, d, s);
     if (pl.wi == 56) return pl.mt == 128 ? launch_rows2<56, 1, 128, false, 2, 2>(pl, tag, d, s) : launch_rows2<56, 1, 64, false, 2, 2>(pl, tag, d, s);
+    if (pl.wi == 14) return launch_rows2<14, 1, 64, false, 14, 1, 2>(pl, tag, d, s);
     return launch_rows2<28, 1, 128, false, 4, 1>(pl, tag, d, s);
 }
 

@@ -238,6 +238,8 @@ ROWS_CASES = [
     (1, 32, 12, 56, 72, 3, 1, 1),    # ... partial tiles, ragged units (12 rows in units of 8 / 4)
     (2, 128, 28, 28, 128, 3, 1, 1),  # 28-wide planes: super-rows of four rows, one per workgroup unit (7 units per plane)
     (1, 72, 10, 28, 200, 3, 1, 1),   # ... partial tiles, ragged units (10 rows in units of 4)
+    (2, 64, 14, 14, 128, 3, 1, 1),   # 14x14 planes whole: one super-row of 196 pixels (13 blocks, split 7 + 6 between two waves)
+    (3, 40, 14, 14, 72, 3, 1, 1),    # ... partial tiles
 ]
 
 
