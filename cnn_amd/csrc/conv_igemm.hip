@@ -1873,6 +1873,11 @@ static int autotune_impl(const cnn_conv2d_desc* d, void* scratch, size_t scratch
         (void)hipMemsetAsync(bb, 0, (size_t)(d->Co + d->Ci) * 4, s);
         const float* X = mode == MODE_FWD ? bx : by;  // forward reads x, the data gradient reads dy
         float* Y = mode == MODE_FWD ? by : bx;
+        // (round 5) the data gradient is measured WITH the fused ReLU' epilogue: in a train step nearly every data gradient carries the
+        // mask of the layer below, and its loads move the ranking (64 x 256 -> 256 at 14x14: the 64-wide tile 197 us plain, 220 us masked;
+        // the split-K wide tile 198 us either way).  The output tensor doubles as the mask: every element is read, then written, by the
+        // same lane (igemm epilogue, split_reduce).  TUNE_MASKED=0: the plain epilogue as before.
+        float* Ymask = mode == MODE_DGRAD && CNN_OPT_INT("TUNE_MASKED", 1) != 0 ? Y : nullptr;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {  // (nothing to measure with: keep the rules)
             (void)hipGetLastError();
@@ -1905,12 +1910,12 @@ static int autotune_impl(const cnn_conv2d_desc* d, void* scratch, size_t scratch
             if (rc == CNN_AMD_OK && c >= 0 && pl.cfg != c) rc = CNN_AMD_E_BADARG;  // not applicable to this geometry
             float ms = 1e30f;
             if (rc == CNN_AMD_OK) {
-                rc = run_plan(pl, d, X, bw, bb, Y, nullptr, ba, na * 4, s, "cnn_conv2d_autotune");  // warm-up (first-use setup, filter image)
+                rc = run_plan(pl, d, X, bw, bb, Y, Ymask, ba, na * 4, s, "cnn_conv2d_autotune");  // warm-up (first-use setup, filter image)
                 // best of three runs on the filter image the warm-up left behind (a train step prepares the images apart from the
                 // convolutions; one run each used to decide 3 - 5 % differences by the box's noise)
                 for (int rep = 0; rep < 3 && rc == CNN_AMD_OK; ++rep) {
                     (void)hipEventRecord(e0, s);
-                    rc = run_plan(pl, d, X, bw, bb, Y, nullptr, ba, na * 4, s, "cnn_conv2d_autotune", true);
+                    rc = run_plan(pl, d, X, bw, bb, Y, Ymask, ba, na * 4, s, "cnn_conv2d_autotune", true);
                     (void)hipEventRecord(e1, s);
                     float t = 1e30f;
                     if (rc == CNN_AMD_OK && hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&t, e0, e1);

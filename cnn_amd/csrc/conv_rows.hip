@@ -24,11 +24,29 @@ using namespace cnn_amd;
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte access at any float address
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 constexpr unsigned kOob = 0x80000000u;
 __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float* lds) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_ptr)lds, 16, (int)voff, (int)soff, 0, 0);
+}
+
+// The accumulating MFMA as inline assembly, destination = addend, both in AGPRs.  Through the builtin the register allocator is free to
+// give the result another register than the addend; across the unrolled stage loop that ended in a rotation of the whole accumulator file
+// at every back edge (~100 v_accvgpr_mov / read / write per stage in the round-5 ISA, 10 - 15 % of a stage).  What the compiler's hazard
+// recogniser would have done for a builtin is written out: s_nop 1 in front (VALU / v_accvgpr_write result -> MFMA operand: 2 wait
+// states; hidden behind the previous MFMA's 8 passes), and acc_settle() before anything else reads the accumulators.
+__device__ __forceinline__ void mfma16(f32x4& c, float a, float b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// every accumulator of a[0..N) has left the MFMA pipeline (8 passes + write-back < 32 cycles; N a multiple of 7)
+template <int N>
+__device__ __forceinline__ void acc_settle(f32x4* a) {
+    static_assert(N % 7 == 0, "groups of seven");
+#pragma unroll
+    for (int i = 0; i < N; i += 7)
+        asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a[i]), "+a"(a[i + 1]), "+a"(a[i + 2]), "+a"(a[i + 3]), "+a"(a[i + 4]), "+a"(a[i + 5]), "+a"(a[i + 6]));
 }
 
 struct RowsParams {
@@ -169,8 +187,11 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
     };
     zero_acc();
 
-    const int nstages = (u_hi - u_lo) * p.nchunk;
-    int b = u_lo / p.nrb, r0 = (u_lo - b * p.nrb) * G::ROWS, cc = 0;
+    // Two nested loops -- units, then the channel chunks of a unit -- so that the stage loop carries the accumulators and nothing else
+    // happens to them inside it: written as ONE flat loop over (unit, chunk) stages with the store code behind an `if (last chunk)`, the
+    // compiler kept the accumulators in VGPRs across the back edge and copied all of them into AGPRs and back around every stage's MFMAs
+    // (224 v_accvgpr_read + 224 v_accvgpr_write per 504 MFMAs in the round-5 ISA).
+    int b = u_lo / p.nrb, r0 = (u_lo - b * p.nrb) * G::ROWS;
     {
 #pragma unroll
         for (int k = 0; k < G::NSLOT; ++k) dma_slot(k, b, r0, 0, smem);
@@ -178,21 +199,22 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
     // the k-steps of a stage: (tap, 4-channel group) pairs; slots are spread over them
     constexpr int NKS = 9 * G::KSTEPS;
     constexpr int PER_KS = (G::NSLOT + NKS - 1) / NKS;
-    for (int t = 0; t < nstages; ++t) {
+    int t = 0;  // stages so far: buffer parity
+    for (int u = u_lo; u < u_hi; ++u) {
+      // the unit behind this one (behind the last one: this one again)
+      int bu = b, r0u = r0;
+      if (u + 1 < u_hi) {
+          if (r0 + G::ROWS < p.HO) r0u = r0 + G::ROWS;
+          else { r0u = 0; bu = b + 1; }
+      }
+      for (int cc = 0; cc < p.nchunk; ++cc, ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const float* cur = smem + (t & 1) * G::BUF;
         float* nxt = smem + ((t + 1) & 1) * G::BUF;
-        // the stage behind this one (behind the last one: that one again)
-        int bn = b, r0n = r0, ccn = cc;
-        if (t + 1 < nstages) {
-            if (cc + 1 < p.nchunk) ccn = cc + 1;
-            else {
-                ccn = 0;
-                if (r0 + G::ROWS < p.HO) r0n = r0 + G::ROWS;
-                else { r0n = 0; bn = b + 1; }
-            }
-        }
+        // the stage behind this one (behind the last one of the range: that one again)
+        const bool last_cc = cc + 1 == p.nchunk;
+        const int bn = last_cc ? bu : b, r0n = last_cc ? r0u : r0, ccn = last_cc ? (u + 1 < u_hi ? 0 : cc) : cc + 1;
         // rows of the staged block that lie outside the image (wave-uniform; only with padding)
         unsigned rowbad = 0;
         if (PAD > 0 && RSEL) {  // (rows above the image are staged as zeros in either variant)
@@ -246,56 +268,74 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int ma = 0; ma < 2; ++ma) acc[ma][rw][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[ma], o.b[rw][nb], acc[ma][rw][nb], 0, 0, 0);
+                    for (int ma = 0; ma < 2; ++ma) mfma16(acc[ma][rw][nb], o.b[rw][nb], o.a[ma]);
         }
-        if (cc + 1 == p.nchunk) {
-            // ---- this unit is complete: + bias, store (D[i][j]: lane (j = n, kq) holds rows i = 4 kq + r).  With a ReLU' mask: the mask
-            //      values of one 16-channel block are fetched as ONE batch of independent loads before any of them is used (a load, its
-            //      select and its store per element would be RW * NB * 8 dependent memory round trips per unit)
+      }
+      acc_settle<2 * G::RW * NB>(&acc[0][0][0]);
+      if (p.dbg != 1) {  // (ROWS_DBG=1, measurement only: no stores)
+            // ---- this unit is complete: + bias, store.  The MFMAs ran with the PIXELS as the M operand (D[i][j]: lane (j = n, kq) holds rows
+            //      i = 4 kq + r): a lane's four registers of a tile are four CONSECUTIVE pixels of output channel n -- one 16-byte store
+            //      (and one 16-byte load of the ReLU' mask) per tile instead of four scattered dwords: 28 instead of 112 store instructions
+            //      per wave and unit (measured on the north-star forward: the stores were 15 % of the kernel).  The mask values of one
+            //      16-channel block are fetched as ONE batch of independent loads before any of them is used.
 #pragma unroll
             for (int ma = 0; ma < 2; ++ma) {
-                float mk[4][G::RW][NB];
-                if (p.relu_below != nullptr) {
+                const int co = co0 + wm * 32 + ma * 16 + n;
+                const float bs = (p.bias != nullptr && co < p.M) ? p.bias[co] : 0.f;
+                const size_t cbase = ((size_t)b * p.M + co) * HWO;
+                f32x4 mk[G::RW][NB];
+                int nval[G::RW][NB];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int co = co0 + wm * 32 + ma * 16 + 4 * kq + r;
+                for (int rw = 0; rw < G::RW; ++rw) {
+                    const int row0 = r0 + (wr * G::RW + rw) * SR;
+                    const int lim0 = (p.HO - row0) * WO, lim = lim0 < G::PX ? lim0 : G::PX;  // pixels of the super-row inside the image
 #pragma unroll
-                        for (int rw = 0; rw < G::RW; ++rw) {
-                            const int row0 = r0 + (wr * G::RW + rw) * SR;
-                            const size_t ybase = ((size_t)b * p.M + co) * HWO + (size_t)row0 * WO;
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int f = 16 * (wp * G::NBW + nb) + 4 * kq;
+                        nval[rw][nb] = co < p.M ? lim - f : 0;
+                        mk[rw][nb] = f32x4{1.f, 1.f, 1.f, 1.f};
+                        if (p.relu_below != nullptr) {
+                            const float* m = p.relu_below + cbase + (size_t)row0 * WO + f;
+                            if (nval[rw][nb] >= 4) mk[rw][nb] = *(const f32x4u*)m;
+                            else {
 #pragma unroll
-                            for (int nb = 0; nb < NB; ++nb) {
-                                const int f = 16 * (wp * G::NBW + nb) + n;
-                                const bool ok = co < p.M && f < G::PX && row0 + f / WO < p.HO;
-                                mk[r][rw][nb] = ok ? p.relu_below[ybase + f] : 1.f;
+                                for (int e = 0; e < 3; ++e)
+                                    if (e < nval[rw][nb]) mk[rw][nb][e] = m[e];
                             }
                         }
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + wm * 32 + ma * 16 + 4 * kq + r;
-                    const float bs = (p.bias != nullptr && co < p.M) ? p.bias[co] : 0.f;
+                for (int rw = 0; rw < G::RW; ++rw) {
+                    const int row0 = r0 + (wr * G::RW + rw) * SR;
 #pragma unroll
-                    for (int rw = 0; rw < G::RW; ++rw) {
-                        const int row0 = r0 + (wr * G::RW + rw) * SR;
-                        const size_t ybase = ((size_t)b * p.M + co) * HWO + (size_t)row0 * WO;  // (a super-row is PX consecutive floats of y)
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int f = 16 * (wp * G::NBW + nb) + 4 * kq;
+                        const size_t at = cbase + (size_t)row0 * WO + f;  // (a super-row is PX consecutive floats of y)
+                        f32x4 v, vr;
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            const int f = 16 * (wp * G::NBW + nb) + n;
-                            if (co < p.M && f < G::PX && row0 + f / WO < p.HO) {
-                                float v = acc[ma][rw][nb][r] + bs;
-                                if (p.relu_below != nullptr) v = mk[r][rw][nb] <= 0.f ? 0.f : v;
-                                if (p.y != nullptr) p.y[ybase + f] = v;
-                                if (p.y_relu != nullptr) p.y_relu[ybase + f] = v >= 0.f ? v : 0.f;
-                            }
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[ma][rw][nb][e] + bs;
+                            if (p.relu_below != nullptr) v[e] = mk[rw][nb][e] <= 0.f ? 0.f : v[e];
+                            vr[e] = v[e] >= 0.f ? v[e] : 0.f;
+                        }
+                        if (nval[rw][nb] >= 4) {
+                            if (p.y != nullptr) *(f32x4u*)(p.y + at) = v;
+                            if (p.y_relu != nullptr) *(f32x4u*)(p.y_relu + at) = vr;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 3; ++e)
+                                if (e < nval[rw][nb]) {
+                                    if (p.y != nullptr) p.y[at + e] = v[e];
+                                    if (p.y_relu != nullptr) p.y_relu[at + e] = vr[e];
+                                }
                         }
                     }
                 }
             }
-            zero_acc();
-        }
-        b = bn; r0 = r0n; cc = ccn;
+      }
+      zero_acc();
+      b = bu; r0 = r0u;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -387,12 +427,15 @@ int launch_rows2(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, 
     if (G::ROWS != pl.rows) return fail(CNN_AMD_E_BADARG, "conv_rows: plan / instance mismatch");
     static DeviceOnce attr_once;
     if (attr_once.needed()) {
-        CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes));
+        CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_once.mark();
     }
+    // (measurement switch ROWS_LDS=<bytes>: a larger LDS request, e.g. 90000 = never two workgroups on one CU)
+    size_t lds = G::lds_bytes;
+    if (const int want = CNN_OPT_INT("ROWS_LDS", 0); want > (int)lds && want <= 160 * 1024) lds = (size_t)want;
     char name[48];
     snprintf(name, sizeof(name), "conv_rows<%d,%d,%d>/%s", WI, PAD, MT, tag);
-    CNN_KLAUNCH(s, name, (kern<<<dim3(pl.blocks, pl.ntiles), 256, G::lds_bytes, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W, d->Co,
+    CNN_KLAUNCH(s, name, (kern<<<dim3(pl.blocks, pl.ntiles), 256, lds, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W, d->Co,
                 d->k, d->s, d->pad);
     return CNN_AMD_OK;
 }
