@@ -378,9 +378,6 @@ bool make_rows_plan(const cnn_conv2d_desc* d, int mode, RowsPlan* pl) {
     // (the instances below: 112-wide planes with any padding, 56- and 28-wide ones with pad 1 as super-rows of 2 / 4 rows)
     // 14x14 planes with pad 1 whole: one super-row of 196 pixels per workgroup unit
     if (!((wi == 112 && pad <= 1) || (wi == 110 && pad == 2) || ((wi == 56 || wi == 28) && pad == 1) || (wi == 14 && hi == 14 && pad == 1))) return false;
-    // (measured, 14x14: 79 / 79 TFLOP/s forward / data gradient at 64 x 256 -> 256 against the implicit GEMM's 80 / 67, but 85 / 88 against 97 /
-    // 100 at 128 x 512 -> 512: the instance stays opt-in, ROWS_14=1 or ROWS_ALWAYS)
-    if (wi == 14 && !CNN_OPT_SET("ROWS_14") && !CNN_OPT_SET("ROWS_ALWAYS")) return false;
     if (wi == 28 && M <= 64) return false;  // (28-wide: one super-row of 4 rows per workgroup needs the 4 x 1 wave layout)
     if (C < 16 || C % kCK != 0 || M < 32) return false;  // (whole 8-channel chunks: no plane of a stage lies behind the sample's channels)
     if ((long long)d->B * C * hi * wi >= (1ll << 29) || (long long)d->B * M * ho * (wi + 2 * pad - 2) >= (1ll << 31)) return false;
@@ -406,9 +403,10 @@ bool make_rows_plan(const cnn_conv2d_desc* d, int mode, RowsPlan* pl) {
     }
     p.nrb = (ho + rg - 1) / rg;
     p.units_total = d->B * p.nrb;
-    // (measured, tools/one_layer.py: with fewer than ~3 units per CU -- the batch-64 layers of the ResNet-shaped stack: 448 units -- the
-    // FORWARD pass is faster on the implicit GEMM's split-K / wide tiles (87 vs 80 TFLOP/s); the data gradient is not (76 vs 82))
-    if (mode == 0 && p.units_total < 3 * num_cus() && !CNN_OPT_SET("ROWS_ALWAYS")) return false;
+    // (round 5, before the accumulators stayed in AGPRs: batch-64 forward passes and 14x14 planes were faster on the implicit GEMM and were
+    // kept there; measured since, tools/one_layer.py, forward / data gradient in TFLOP/s: 64 x 64 -> 64 @ 56x56 96 / 96 against 85 / 77,
+    // 64 x 128 -> 128 @ 28x28 95 / 96 against 80 / 72, 64 x 256 -> 256 @ 14x14 94 / 94 against 73 / 67, 128 x 512 -> 512 @ 14x14 101 / 107
+    // against 97 / 101)
     const int env = CNN_OPT_INT("ROWS_BLOCKS", 0);
     long long want = (env > 0 ? env : num_cus()) / pl->ntiles;
     if (want < 1) want = 1;
