@@ -79,19 +79,39 @@ constexpr int stride16(int len) {  // smallest stride >= len that is 16 (mod 32)
 // RW:   super-rows per wave
 // WP:   2 = the two waves of a 32-channel co block split the super-row's pixel blocks (whole 14x14 planes as ONE super-row of 196 pixels =
 //       13 blocks: a 64-channel tile of 2 (co) x 2 (pixel halves) waves keeps 256 workgroups busy at batch 64)
-template <int WI, int PAD, int MT, bool RSEL = false, int SR = 1, int RW_ = 2, int WP = 1>
+// MA:   16-channel co blocks per wave (2; 1 = a wave of 16 channels: four co waves on a 64-channel tile)
+// PK:   > 1 = PACKED PLANES (7x7, pad 1): the whole planes of PK consecutive samples form one super-row of PK * 49 pixels (2 samples: 98
+//       pixels = 7 blocks, 12.5 % idle lanes).  Staged per channel as [8 guard][plane 0: 49 + 3][plane 1: 49 + 3][guard] -- every plane
+//       on a 16-byte unit -- with NO halo rows: a tap that leaves its plane at the top / bottom / left / right is selected away by a
+//       compile-time lane mask per (block, tap) (what lies there is the neighbouring plane, the pad or the guard).
+// CK:   input channels per stage (8; 16 where a stage of 8 would be short against its fixed costs: the 7x7 instance, 7 tiles per wave)
+template <int WI, int PAD, int MT, bool RSEL = false, int SR = 1, int RW_ = 2, int WP = 1, int MA_ = 2, int PK_ = 1, int CK_ = 8>
 struct RowsGeom {
+    static constexpr int CK = CK_;
+    static_assert(CK == 8 || CK == 16, "channels per stage");
     static_assert(MT == 128 || MT == 64, "output channels per workgroup");
+    static constexpr int MA = MA_, PK = PK_;
     static constexpr int WO = WI + 2 * PAD - 2;
     static_assert(SR == 1 || (WO == WI && !RSEL), "super-rows: equal pitches, zero-staged halo rows");
-    static constexpr int PX = SR * WO;                    // pixels of a super-row
+    static_assert(PK == 1 || (PAD == 1 && SR == 1 && !RSEL && RW_ == 1 && WP == 1 && MT == 16 * MA * 4), "packed planes: one super-row per workgroup");
+    static constexpr int PLANE = WI * WI, SP = (PLANE + 3) / 4 * 4, GUARD = (WI + 1 + 3) / 4 * 4;  // (packed planes)
+    static constexpr int PX = PK > 1 ? PK * PLANE : SR * WO;  // pixels of a super-row
     static constexpr int NB = (PX + 15) / 16;             // 16-pixel blocks per super-row
-    static constexpr int WM = MT / 32, WR = 4 / (WM * WP);  // waves over co x pixel halves x row groups
+    static constexpr int WM = MT / (16 * MA), WR = 4 / (WM * WP);  // waves over co x pixel halves x row groups
     static_assert(WM * WP * WR == 4, "four waves");
     static constexpr int NBW = (NB + WP - 1) / WP;        // pixel blocks per wave
     static constexpr int RW = RW_, RG = WR * RW;          // super-rows per wave / per workgroup
-    static constexpr int ROWS = RG * SR;                  // output rows per workgroup unit
+    static constexpr int ROWS = PK > 1 ? WI : RG * SR;    // output rows per workgroup unit
     static constexpr int XR = ROWS + 2;                   // staged input rows
+    // packed planes: lanes n of block nb whose tap (kx, ky) leaves the plane of its pixel
+    static constexpr unsigned tapmask(int nb, int kx, int ky) {
+        unsigned m = 0;
+        for (int n = 0; n < 16; ++n) {
+            const int f = (16 * nb + n) % PLANE, r = f / WI + kx - 1, c = f % WI + ky - 1;
+            if (r < 0 || r >= WI || c < 0 || c >= WI) m |= 1u << n;
+        }
+        return m;
+    }
     // lanes n of block nb whose tap column ky leaves the row: column (16 nb + n) % WI + ky - PAD outside [0, WI)
     static constexpr unsigned colmask(int nb, int ky) {
         unsigned m = 0;
@@ -102,11 +122,11 @@ struct RowsGeom {
         return m;
     }
     static constexpr int LEAD = (4 - (PAD * WI) % 4) % 4;  // row 0 of the image on a 16-byte unit boundary of the first row block
-    static constexpr int XSPAN = LEAD + XR * WI;
+    static constexpr int XSPAN = PK > 1 ? 2 * GUARD + PK * SP : LEAD + XR * WI;
     static constexpr int QXP = stride16(XSPAN + 4);       // x plane stride (floats)
     static constexpr int QW = MT + 16;                    // filter row stride: 9 * QW = 16 (mod 32)
     static_assert(QXP % 32 == 16 && (9 * QW) % 32 == 16, "bank halves");
-    static constexpr int XIMG = kCK * QXP, WIMG = kCK * 9 * QW;
+    static constexpr int XIMG = CK * QXP, WIMG = CK * 9 * QW;
     static constexpr int NIX = (XIMG / 4 + 63) / 64, NIWT = (WIMG / 4 + 63) / 64;  // DMA instructions per stage
     static constexpr int NIWX = (NIX + 3) / 4, NIWW = (NIWT + 3) / 4;              // per wave
     static constexpr int NSLOT = NIWX + NIWW;
@@ -115,12 +135,12 @@ struct RowsGeom {
     static constexpr int DUMP = 2 * BUF;
     static constexpr size_t lds_bytes = (size_t)(2 * BUF + 4 * 256) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS plan");
-    static constexpr int KSTEPS = kCK / 4;  // MFMA k-steps per tap
+    static constexpr int KSTEPS = CK / 4;  // MFMA k-steps per tap
 };
 
-template <int WI, int PAD, int MT, bool RSEL, int SR, int RW_, int WP>
+template <int WI, int PAD, int MT, bool RSEL, int SR, int RW_, int WP, int MA, int PK, int CK>
 __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
-    using G = RowsGeom<WI, PAD, MT, RSEL, SR, RW_, WP>;
+    using G = RowsGeom<WI, PAD, MT, RSEL, SR, RW_, WP, MA, PK, CK>;
     constexpr int WO = G::WO, NB = G::NBW;  // (NB: the pixel blocks of THIS wave)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kq = lane >> 4;
@@ -142,12 +162,21 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
     for (int i = 0; i < G::NIWX; ++i) {
         const int j = i * 4 + wave, q = j * 64 + lane;
         const int plane = q / (G::QXP / 4), e = q - plane * (G::QXP / 4);
-        const bool have = j < G::NIX && plane < kCK && e * 4 < G::XSPAN;
+        const bool have = j < G::NIX && plane < CK && e * 4 < G::XSPAN;
+        if constexpr (PK > 1) {
+            // packed planes: unit e of the staged channel = four floats of plane (e*4 - GUARD) / SP, from float (e*4 - GUARD) % SP on (the
+            // last unit of a plane carries its 49th float and three of whatever follows it in memory: the pad of the staged plane)
+            const int l = e * 4 - G::GUARD, sp = l >= 0 ? l / G::SP : -1;
+            const bool in = have && l >= 0 && sp < PK;
+            xd_off[i] = in ? (unsigned)((sp * p.C + plane) * G::PLANE + (l - sp * G::SP)) * 4u : kOob;
+            xd_row[i] = 0;
+        } else {
         xd_off[i] = have ? (unsigned)(plane * HWI + e * 4 - G::LEAD + 4) * 4u : kOob;
         const int first = e * 4 - G::LEAD < 0 ? 0 : (e * 4 - G::LEAD) / WI;
         xd_row[i] = (((e + 1) * 4 - 1 - G::LEAD) / WI) | (first << 8);
+        }
     }
-    constexpr int BACK = PAD * WI + 4;
+    constexpr int BACK = PK > 1 ? 0 : PAD * WI + 4;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - BACK), 0, (int)(((unsigned)p.B * p.C * HWI + BACK) * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.wt + (size_t)blockIdx.y * p.nchunk * G::WIMG), 0, (int)((unsigned)p.nchunk * G::WIMG * 4u), 0x00020000);
@@ -161,9 +190,11 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
             const int nneg = PAD - r0;      // staged rows above the image
             const int nv = H + PAD - r0;    // first staged row below it
             unsigned voff = xd_off[k];
-            voff = ((xd_row[k] & 255) < nneg) ? kOob : voff;
-            if (!RSEL && PAD > 0) voff = ((xd_row[k] >> 8) >= nv) ? kOob : voff;
-            blds16(xrs, voff, (unsigned)((b * p.C + cc * kCK) * HWI + r0 * WI) * 4u, d);
+            if constexpr (PK == 1) {
+                voff = ((xd_row[k] & 255) < nneg) ? kOob : voff;
+                if (!RSEL && PAD > 0) voff = ((xd_row[k] >> 8) >= nv) ? kOob : voff;
+            }
+            blds16(xrs, voff, (unsigned)((b * p.C + cc * CK) * HWI + r0 * WI) * 4u, d);
         } else {
             const int i = k - G::NIWX, j = i * 4 + wave;
             float* d = j < G::NIWT ? buf + G::XS + j * 256 : dump;
@@ -173,13 +204,13 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
     };
 
     // ---- per-lane operand bases (floats inside a buffer)
-    const int b_base = kq * G::QXP + G::LEAD + n - PAD + wr * G::RW * SR * WI + wp * G::NBW * 16;
-    const int a_base = G::XS + kq * 9 * G::QW + wm * 32 + n;
+    const int b_base = PK > 1 ? kq * G::QXP + G::GUARD - WI - 1 + n : kq * G::QXP + G::LEAD + n - PAD + wr * G::RW * SR * WI + wp * G::NBW * 16;
+    const int a_base = G::XS + kq * 9 * G::QW + wm * (16 * MA) + n;
 
-    f32x4 acc[2][G::RW][NB];
+    f32x4 acc[MA][G::RW][NB];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int ma = 0; ma < 2; ++ma)
+        for (int ma = 0; ma < MA; ++ma)
 #pragma unroll
             for (int rw = 0; rw < G::RW; ++rw)
 #pragma unroll
@@ -192,6 +223,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
     // compiler kept the accumulators in VGPRs across the back edge and copied all of them into AGPRs and back around every stage's MFMAs
     // (224 v_accvgpr_read + 224 v_accvgpr_write per 504 MFMAs in the round-5 ISA).
     int b = u_lo / p.nrb, r0 = (u_lo - b * p.nrb) * G::ROWS;
+    if constexpr (PK > 1) b *= PK;  // (packed planes: a unit = PK samples, nrb = 1)
     {
 #pragma unroll
         for (int k = 0; k < G::NSLOT; ++k) dma_slot(k, b, r0, 0, smem);
@@ -205,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
       int bu = b, r0u = r0;
       if (u + 1 < u_hi) {
           if (r0 + G::ROWS < p.HO) r0u = r0 + G::ROWS;
-          else { r0u = 0; bu = b + 1; }
+          else { r0u = 0; bu = b + PK; }
       }
       for (int cc = 0; cc < p.nchunk; ++cc, ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -223,23 +255,30 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
         }
         // operands of one k-step (tap, 4-channel group): 2 A values, RW * NB B values -- read one k-step ahead of their MFMAs
         struct Ops {
-            float a[2];
+            float a[MA];
             float b[G::RW][NB];
         };
         auto read_ops = [&](Ops& o, int ks) {
             const int tap = ks / G::KSTEPS, s = ks % G::KSTEPS, kx = tap / 3, ky = tap % 3;
 #pragma unroll
-            for (int ma = 0; ma < 2; ++ma) o.a[ma] = cur[a_base + (s * 36 + tap) * G::QW + ma * 16];
+            for (int ma = 0; ma < MA; ++ma) o.a[ma] = cur[a_base + (s * 36 + tap) * G::QW + ma * 16];
 #pragma unroll
             for (int rw = 0; rw < G::RW; ++rw) {
                 const bool bad = PAD > 0 && RSEL && ((rowbad >> (wr * G::RW + rw + kx)) & 1u);  // (RSEL: SR == 1)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    float bv = cur[b_base + s * 4 * G::QXP + (rw * SR + kx) * WI + 16 * nb + ky];
+                    // (packed planes: the pad between two staged planes moves the pixels of the later planes; per lane in a block that straddles)
+                    int xtra = 0;
+                    if constexpr (PK > 1) {
+                        constexpr int PAD3 = G::SP - G::PLANE;
+                        const int lo = (16 * nb) / G::PLANE, hi = (16 * nb + 15) / G::PLANE;
+                        xtra = lo == hi ? PAD3 * lo : PAD3 * ((16 * nb + n) / G::PLANE);
+                    }
+                    float bv = cur[b_base + s * 4 * G::QXP + (rw * SR + kx) * WI + 16 * nb + ky + xtra];
                     // the tap columns that leave their row (a select: what lies there is the neighbouring row's data)
                     constexpr unsigned kAll = 0xffffu;
                     if constexpr (WP == 1) {
-                        const unsigned cm = G::colmask(nb, ky);
+                        const unsigned cm = PK > 1 ? G::tapmask(nb, kx, ky) : G::colmask(nb, ky);
                         if (cm == kAll) bv = 0.f;
                         else if (cm != 0) bv = ((cm >> n) & 1u) ? 0.f : bv;
                     } else {
@@ -252,14 +291,18 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
                 }
             }
         };
-        Ops ops[2];
-        read_ops(ops[0], 0);
+        // read-ahead distance in k-steps: one where a k-step is 28 MFMAs (~900 cycles), two where it is 14 or 7 (a k-step of 7 MFMAs is
+        // shorter than an LDS round trip under load)
+        constexpr int D = MA * G::RW * NB >= 28 ? 1 : 2;
+        Ops ops[D + 1];
+#pragma unroll
+        for (int d = 0; d < D; ++d) read_ops(ops[d], d);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            if (ks + 1 < NKS) read_ops(ops[(ks + 1) & 1], ks + 1);
+            if (ks + D < NKS) read_ops(ops[(ks + D) % (D + 1)], ks + D);
 #pragma unroll
             for (int k = ks * PER_KS; k < (ks + 1) * PER_KS && k < G::NSLOT; ++k) dma_slot(k, bn, r0n, ccn, nxt);
-            Ops& o = ops[ks & 1];
+            Ops& o = ops[ks % (D + 1)];
             // the reads above may not sink below this point (instruction selection otherwise moves every LDS read down to its first use,
             // two MFMAs ahead of a full LDS round trip) and the MFMAs below may not rise above it
             asm volatile("" : "+v"(o.a[0]) : : "memory");
@@ -268,19 +311,74 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int ma = 0; ma < 2; ++ma) mfma16(acc[ma][rw][nb], o.b[rw][nb], o.a[ma]);
+                    for (int ma = 0; ma < MA; ++ma) mfma16(acc[ma][rw][nb], o.b[rw][nb], o.a[ma]);
         }
       }
-      acc_settle<2 * G::RW * NB>(&acc[0][0][0]);
+      acc_settle<MA * G::RW * NB>(&acc[0][0][0]);
       if (p.dbg != 1) {  // (ROWS_DBG=1, measurement only: no stores)
             // ---- this unit is complete: + bias, store.  The MFMAs ran with the PIXELS as the M operand (D[i][j]: lane (j = n, kq) holds rows
             //      i = 4 kq + r): a lane's four registers of a tile are four CONSECUTIVE pixels of output channel n -- one 16-byte store
             //      (and one 16-byte load of the ReLU' mask) per tile instead of four scattered dwords: 28 instead of 112 store instructions
             //      per wave and unit (measured on the north-star forward: the stores were 15 % of the kernel).  The mask values of one
             //      16-channel block are fetched as ONE batch of independent loads before any of them is used.
+            if constexpr (PK > 1) {
+                // packed planes: pixel f of the super-row = pixel f % 49 of sample b + f / 49; a lane's four pixels are one 16-byte access
+                // unless they straddle two planes or leave the batch
 #pragma unroll
-            for (int ma = 0; ma < 2; ++ma) {
-                const int co = co0 + wm * 32 + ma * 16 + n;
+                for (int ma = 0; ma < MA; ++ma) {
+                    const int co = co0 + wm * (16 * MA) + ma * 16 + n;
+                    const float bs = (p.bias != nullptr && co < p.M) ? p.bias[co] : 0.f;
+                    auto elem = [&](int f, int e, size_t& idx) {
+                        const int fe = f + e, se = fe / G::PLANE, pe = fe - se * G::PLANE;
+                        idx = ((size_t)(b + se) * p.M + co) * G::PLANE + pe;
+                        return co < p.M && fe < G::PX && b + se < p.B;
+                    };
+                    f32x4 mk[NB];
+                    bool whole[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int f = 16 * nb + 4 * kq, sp = f / G::PLANE, pl = f - sp * G::PLANE;
+                        whole[nb] = co < p.M && sp < PK && b + sp < p.B && pl + 3 < G::PLANE;
+                        mk[nb] = f32x4{1.f, 1.f, 1.f, 1.f};
+                        if (p.relu_below != nullptr) {
+                            size_t idx;
+                            if (whole[nb]) { (void)elem(f, 0, idx); mk[nb] = *(const f32x4u*)(p.relu_below + idx); }
+                            else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (elem(f, e, idx)) mk[nb][e] = p.relu_below[idx];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int f = 16 * nb + 4 * kq;
+                        f32x4 v, vr;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[ma][0][nb][e] + bs;
+                            if (p.relu_below != nullptr) v[e] = mk[nb][e] <= 0.f ? 0.f : v[e];
+                            vr[e] = v[e] >= 0.f ? v[e] : 0.f;
+                        }
+                        size_t idx;
+                        if (whole[nb]) {
+                            (void)elem(f, 0, idx);
+                            if (p.y != nullptr) *(f32x4u*)(p.y + idx) = v;
+                            if (p.y_relu != nullptr) *(f32x4u*)(p.y_relu + idx) = vr;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (elem(f, e, idx)) {
+                                    if (p.y != nullptr) p.y[idx] = v[e];
+                                    if (p.y_relu != nullptr) p.y_relu[idx] = vr[e];
+                                }
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+            for (int ma = 0; ma < MA; ++ma) {
+                const int co = co0 + wm * (16 * MA) + ma * 16 + n;
                 const float bs = (p.bias != nullptr && co < p.M) ? p.bias[co] : 0.f;
                 const size_t cbase = ((size_t)b * p.M + co) * HWO;
                 f32x4 mk[G::RW][NB];
@@ -333,6 +431,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
                     }
                 }
             }
+            }
       }
       zero_acc();
       b = bu; r0 = r0u;
@@ -340,19 +439,19 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// filters -> [co tile][chunk][channel 0..7][tap][QW]; mode 0: forward (w[co][c][tap]); mode 1: data gradient (w[c][m][8 - tap])
+// filters -> [co tile][chunk][channel 0..CK-1][tap][QW]; mode 0: forward (w[co][c][tap]); mode 1: data gradient (w[c][m][8 - tap])
 __global__ __launch_bounds__(256) void rows_prep(const float* __restrict__ w, float* __restrict__ wt, int Co, int Ci, int mode, int MT, int QW, int nchunk,
-                                                 int ntiles) {
-    const long long total = (long long)ntiles * nchunk * kCK * 9 * QW;
+                                                 int ntiles, int CK) {
+    const long long total = (long long)ntiles * nchunk * CK * 9 * QW;
     const int C = mode == 0 ? Ci : Co, M = mode == 0 ? Co : Ci;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int j = (int)(i % QW);
         long long r = i / QW;
         const int tap = (int)(r % 9); r /= 9;
-        const int cl = (int)(r % kCK); r /= kCK;
+        const int cl = (int)(r % CK); r /= CK;
         const int cc = (int)(r % nchunk);
         const int tile = (int)(r / nchunk);
-        const int m = tile * MT + j, c = cc * kCK + cl;
+        const int m = tile * MT + j, c = cc * CK + cl;
         float v = 0.f;
         if (j < MT && m < M && c < C) v = mode == 0 ? w[((size_t)m * Ci + c) * 9 + tap] : w[((size_t)c * Ci + m) * 9 + (8 - tap)];
         wt[i] = v;
@@ -361,7 +460,7 @@ __global__ __launch_bounds__(256) void rows_prep(const float* __restrict__ w, fl
 
 struct RowsPlan {
     RowsParams p;
-    int wi, pad, mt, qw, ntiles, blocks, rsel, sr, rows;
+    int wi, pad, mt, qw, ntiles, blocks, rsel, sr, rows, ck;
     size_t wt_floats;
 };
 
@@ -377,32 +476,34 @@ bool make_rows_plan(const cnn_conv2d_desc* d, int mode, RowsPlan* pl) {
     const int ho = mode == 0 ? Ho : d->H;
     // (the instances below: 112-wide planes with any padding, 56- and 28-wide ones with pad 1 as super-rows of 2 / 4 rows)
     // 14x14 planes with pad 1 whole: one super-row of 196 pixels per workgroup unit
-    if (!((wi == 112 && pad <= 1) || (wi == 110 && pad == 2) || ((wi == 56 || wi == 28) && pad == 1) || (wi == 14 && hi == 14 && pad == 1))) return false;
+    if (!((wi == 112 && pad <= 1) || (wi == 110 && pad == 2) || ((wi == 56 || wi == 28) && pad == 1) || ((wi == 14 || wi == 7) && hi == wi && pad == 1))) return false;
     if (wi == 28 && M <= 64) return false;  // (28-wide: one super-row of 4 rows per workgroup needs the 4 x 1 wave layout)
-    if (C < 16 || C % kCK != 0 || M < 32) return false;  // (whole 8-channel chunks: no plane of a stage lies behind the sample's channels)
+    const int ck = wi == 7 ? 16 : kCK;
+    pl->ck = ck;
+    if (C < 16 || C % ck != 0 || M < 32) return false;  // (whole 8-channel chunks: no plane of a stage lies behind the sample's channels)
     if ((long long)d->B * C * hi * wi >= (1ll << 29) || (long long)d->B * M * ho * (wi + 2 * pad - 2) >= (1ll << 31)) return false;
     RowsParams& p = pl->p;
     p.B = d->B; p.C = C; p.H = hi; p.M = M; p.HO = ho;
-    p.nchunk = (C + kCK - 1) / kCK;
+    p.nchunk = (C + ck - 1) / ck;
     pl->wi = wi; pl->pad = pad;
     // (measured on the north-star forward: the 128-channel tile -- 4 x 1 waves, two rows each -- 117 TFLOP/s; with four rows per wave (224
     // accumulator registers) 95; as two 64-channel tiles of 2 x 2 waves 113)
-    pl->mt = (M > 64 && wi != 14) ? 128 : 64;
+    pl->mt = (M > 64 && wi != 14 && wi != 7) ? 128 : 64;
     pl->qw = pl->mt + 16;
     pl->ntiles = (M + pl->mt - 1) / pl->mt;
     pl->sr = wi == 56 ? 2 : (wi == 28 ? 4 : (wi == 14 ? 14 : 1));
-    const int rg = wi == 14 ? 14 : (pl->mt == 128 ? (wi == 28 ? 1 : 2) : 4) * pl->sr;  // output rows per workgroup unit
+    const int rg = (wi == 14 || wi == 7) ? wi : (pl->mt == 128 ? (wi == 28 ? 1 : 2) : 4) * pl->sr;  // output rows per workgroup unit
     pl->rows = rg;
     // zero staging of the rows below the image needs the first of them on a 16-byte unit of the plane: staged row (hi + pad - r0), r0 a
     // multiple of rg, lead pad (4 - pad*wi % 4) % 4 in front
     pl->rsel = 0;
-    if (pad > 0) {
+    if (pad > 0 && wi != 7) {  // (7x7: no halo rows are staged at all)
         const int lead = (4 - (pad * wi) % 4) % 4;
         for (int r0 = 0; r0 < ho; r0 += rg)
             if (r0 + rg + 2 - pad > hi && ((hi + pad - r0) * wi + lead) % 4 != 0) pl->rsel = 1;
     }
     p.nrb = (ho + rg - 1) / rg;
-    p.units_total = d->B * p.nrb;
+    p.units_total = wi == 7 ? (d->B + 1) / 2 : d->B * p.nrb;  // (7x7: the planes of two samples per unit)
     // (round 5, before the accumulators stayed in AGPRs: batch-64 forward passes and 14x14 planes were faster on the implicit GEMM and were
     // kept there; measured since, tools/one_layer.py, forward / data gradient in TFLOP/s: 64 x 64 -> 64 @ 56x56 96 / 96 against 85 / 77,
     // 64 x 128 -> 128 @ 28x28 95 / 96 against 80 / 72, 64 x 256 -> 256 @ 14x14 94 / 94 against 73 / 67, 128 x 512 -> 512 @ 14x14 101 / 107
@@ -413,16 +514,16 @@ bool make_rows_plan(const cnn_conv2d_desc* d, int mode, RowsPlan* pl) {
     if (want > p.units_total) want = p.units_total;
     p.units_per_block = (int)((p.units_total + want - 1) / want);
     pl->blocks = (p.units_total + p.units_per_block - 1) / p.units_per_block;
-    pl->wt_floats = (size_t)pl->ntiles * p.nchunk * kCK * 9 * pl->qw;
+    pl->wt_floats = (size_t)pl->ntiles * p.nchunk * ck * 9 * pl->qw;
     p.dbg = CNN_OPT_INT("ROWS_DBG", 0);
     return true;
 }
 
-template <int WI, int PAD, int MT, bool RSEL, int SR = 1, int RW = 2, int WP = 1>
+template <int WI, int PAD, int MT, bool RSEL, int SR = 1, int RW = 2, int WP = 1, int MA = 2, int PK = 1, int CK = 8>
 int launch_rows2(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, hipStream_t s) {
-    using G = RowsGeom<WI, PAD, MT, RSEL, SR, RW, WP>;
-    auto kern = conv_rows_kernel<WI, PAD, MT, RSEL, SR, RW, WP>;
-    if (G::ROWS != pl.rows) return fail(CNN_AMD_E_BADARG, "conv_rows: plan / instance mismatch");
+    using G = RowsGeom<WI, PAD, MT, RSEL, SR, RW, WP, MA, PK, CK>;
+    auto kern = conv_rows_kernel<WI, PAD, MT, RSEL, SR, RW, WP, MA, PK, CK>;
+    if (G::ROWS != pl.rows || CK != pl.ck) return fail(CNN_AMD_E_BADARG, "conv_rows: plan / instance mismatch");
     static DeviceOnce attr_once;
     if (attr_once.needed()) {
         CNN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -452,6 +553,7 @@ int launch_any(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, hi
     if (pl.wi == 110) return pl.mt == 128 ? launch_rows<110, 2, 128>(pl, tag, d, s) : launch_rows<110, 2, 64>(pl, tag, d, s);
     if (pl.wi == 56) return pl.mt == 128 ? launch_rows2<56, 1, 128, false, 2, 2>(pl, tag, d, s) : launch_rows2<56, 1, 64, false, 2, 2>(pl, tag, d, s);
     if (pl.wi == 14) return launch_rows2<14, 1, 64, false, 14, 1, 2>(pl, tag, d, s);
+    if (pl.wi == 7) return launch_rows2<7, 1, 64, false, 1, 1, 1, 1, 2, 16>(pl, tag, d, s);
     return launch_rows2<28, 1, 128, false, 4, 1>(pl, tag, d, s);
 }
 
@@ -469,7 +571,7 @@ int rows_prepare(const cnn_conv2d_desc* d, int mode, const float* w, float* imag
     RowsPlan pl;
     if (!make_rows_plan(d, mode, &pl)) return fail(CNN_AMD_E_BADARG, "conv_rows: geometry not covered");
     CNN_REQUIRE(w && image && (reinterpret_cast<uintptr_t>(image) & 15) == 0, "conv_rows: filter image must be 16-byte aligned");
-    CNN_KLAUNCH(s, "rows_prep", (rows_prep<<<stream_grid(pl.wt_floats, 256), 256, 0, s>>>(w, image, d->Co, d->Ci, mode, pl.mt, pl.qw, pl.p.nchunk, pl.ntiles)),
+    CNN_KLAUNCH(s, "rows_prep", (rows_prep<<<stream_grid(pl.wt_floats, 256), 256, 0, s>>>(w, image, d->Co, d->Ci, mode, pl.mt, pl.qw, pl.p.nchunk, pl.ntiles, pl.ck)),
                 "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad);
     return CNN_AMD_OK;
 }

@@ -240,6 +240,9 @@ ROWS_CASES = [
     (1, 72, 10, 28, 200, 3, 1, 1),   # ... partial tiles, ragged units (10 rows in units of 4)
     (2, 64, 14, 14, 128, 3, 1, 1),   # 14x14 planes whole: one super-row of 196 pixels (13 blocks, split 7 + 6 between two waves)
     (3, 40, 14, 14, 72, 3, 1, 1),    # ... partial tiles
+    (4, 64, 7, 7, 128, 3, 1, 1),     # 7x7 planes packed: the planes of two samples as one super-row of 98 pixels, every out-of-plane tap a lane mask
+    (5, 48, 7, 7, 80, 3, 1, 1),      # ... odd batch (the last unit holds one sample), partial tiles, three / five 16-channel chunks
+    (1, 32, 7, 7, 32, 3, 1, 1),      # ... one sample, two chunks
 ]
 
 
@@ -251,7 +254,6 @@ def test_conv2d_row_kernel_vs_oracle(T, case, lib_option):
 
     x, w, b, dy = _conv_inputs(case, 440)
     y_ref, _, _, dx_ref = _oracle_conv(case, x, w, b, dy)
-    lib_option("ROWS_ALWAYS", "1")  # (small problems: the default dispatch keeps short forward passes on the implicit GEMM)
     conv = capi.Conv2d(*case)
     xd, wd, bd, dyd = dev(T, x), dev(T, w), dev(T, b), dev(T, dy)
     capi.kernel_timing(1)
