@@ -232,6 +232,11 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
     constexpr int NKS = 9 * G::KSTEPS;
     constexpr int PER_KS = (G::NSLOT + NKS - 1) / NKS;
     int t = 0;  // stages so far: buffer parity
+    if (p.dbg == 2) {  // (ROWS_DBG=2, experiment: workgroups start in 8 phases spread over one unit's duration)
+        const long long wait = (long long)(blockIdx.x % 8) * p.nchunk * (NKS * MA * G::RW * NB * 32) / 8;
+        const long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
     for (int u = u_lo; u < u_hi; ++u) {
       // the unit behind this one (behind the last one: this one again)
       int bu = b, r0u = r0;
@@ -240,7 +245,11 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
           else { r0u = 0; bu = b + PK; }
       }
       for (int cc = 0; cc < p.nchunk; ++cc, ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this wave's share of the stage has landed.  Stage 0 of a unit behind the first: already waited for in front of the previous unit's
+        // stores -- a wait here would also wait for THOSE to drain (vmcnt counts stores; measured on the north-star forward, where all 256
+        // workgroups store 29 MB in one burst every 8 stages: 5.6 us per unit, 8 % of the kernel); they drain under this stage's MFMAs and
+        // the next stage's wait finds them gone
+        if (cc != 0 || u == u_lo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const float* cur = smem + (t & 1) * G::BUF;
         float* nxt = smem + ((t + 1) & 1) * G::BUF;
@@ -314,6 +323,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
                     for (int ma = 0; ma < MA; ++ma) mfma16(acc[ma][rw][nb], o.b[rw][nb], o.a[ma]);
         }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the next unit's stage 0, issued early in the last stage: see above)
       acc_settle<MA * G::RW * NB>(&acc[0][0][0]);
       if (p.dbg != 1) {  // (ROWS_DBG=1, measurement only: no stores)
             // ---- this unit is complete: + bias, store.  The MFMAs ran with the PIXELS as the M operand (D[i][j]: lane (j = n, kq) holds rows
@@ -380,12 +390,71 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
             for (int ma = 0; ma < MA; ++ma) {
                 const int co = co0 + wm * (16 * MA) + ma * 16 + n;
                 const float bs = (p.bias != nullptr && co < p.M) ? p.bias[co] : 0.f;
-                const size_t cbase = ((size_t)b * p.M + co) * HWO;
+                const int bE = p.dbg == 3 ? (int)blockIdx.x : b, r0E = p.dbg == 3 ? 0 : r0;  // (ROWS_DBG=3, experiment: every unit of a workgroup stores to the same place)
+                const size_t cbase = ((size_t)bE * p.M + co) * HWO;
+                // FAST PATH (one 16-channel block of a wave whose super-rows lie inside the image -- every unit but the ragged last ones of a
+                // plane): no per-tile validity, one exec region per block (co < M), the tile offsets compile-time immediates off one per-lane
+                // base.  (The generic path below costs ~40 instructions per tile in compare / saveexec / branch sequences: measured on the
+                // north-star forward with the stores redirected to an L2-resident region, 2/3 of the epilogue's 6 us per unit was not HBM.)
+                bool all_inside = WP == 1;
+#pragma unroll
+                for (int rw = 0; rw < G::RW; ++rw) all_inside = all_inside && (p.HO - (r0E + (wr * G::RW + rw) * SR)) * WO >= G::PX;
+                if (all_inside) {  // (wave-uniform)
+                    if (co < p.M) {
+#pragma unroll
+                        for (int rw = 0; rw < G::RW; ++rw) {
+                            const size_t rbase = cbase + (size_t)(r0E + wr * G::RW * SR) * WO + 4 * kq;  // this lane's first pixel of the wave's first super-row
+                            constexpr int CNT_LAST = G::PX - 16 * (NB - 1);  // pixels of the last block (16: full)
+                            const int cnt = CNT_LAST - 4 * kq;               // ... of this lane's four (>= 4: all)
+                            auto at = [&](int nb) { return rbase + (size_t)(rw * SR * WO + 16 * nb); };
+                            f32x4 mk[NB];
+                            if (p.relu_below != nullptr) {
+#pragma unroll
+                                for (int nb = 0; nb < NB; ++nb) {
+                                    mk[nb] = f32x4{1.f, 1.f, 1.f, 1.f};
+                                    if (nb + 1 < NB || CNT_LAST == 16 || cnt >= 4) mk[nb] = *(const f32x4u*)(p.relu_below + at(nb));
+                                    else {
+#pragma unroll
+                                        for (int e = 0; e < 3; ++e)
+                                            if (e < cnt) mk[nb][e] = p.relu_below[at(nb) + e];
+                                    }
+                                }
+                            }
+                            f32x4 v[NB];
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    v[nb][e] = acc[ma][rw][nb][e] + bs;
+                                    if (p.relu_below != nullptr) v[nb][e] = mk[nb][e] <= 0.f ? 0.f : v[nb][e];
+                                }
+                            auto put = [&](float* dst, bool relu) {
+#pragma unroll
+                                for (int nb = 0; nb < NB; ++nb) {
+                                    f32x4 o = v[nb];
+                                    if (relu) {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) o[e] = o[e] >= 0.f ? o[e] : 0.f;
+                                    }
+                                    if (nb + 1 < NB || CNT_LAST == 16 || cnt >= 4) *(f32x4u*)(dst + at(nb)) = o;
+                                    else {
+#pragma unroll
+                                        for (int e = 0; e < 3; ++e)
+                                            if (e < cnt) dst[at(nb) + e] = o[e];
+                                    }
+                                }
+                            };
+                            if (p.y != nullptr) put(p.y, false);
+                            if (p.y_relu != nullptr) put(p.y_relu, true);
+                        }
+                    }
+                    continue;
+                }
                 f32x4 mk[G::RW][NB];
                 int nval[G::RW][NB];
 #pragma unroll
                 for (int rw = 0; rw < G::RW; ++rw) {
-                    const int row0 = r0 + (wr * G::RW + rw) * SR;
+                    const int row0 = r0E + (wr * G::RW + rw) * SR;
                     const int lim0 = (p.HO - row0) * WO, lim = lim0 < G::PX ? lim0 : G::PX;  // pixels of the super-row inside the image
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
@@ -405,7 +474,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
                 }
 #pragma unroll
                 for (int rw = 0; rw < G::RW; ++rw) {
-                    const int row0 = r0 + (wr * G::RW + rw) * SR;
+                    const int row0 = r0E + (wr * G::RW + rw) * SR;
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         const int f = 16 * (wp * G::NBW + nb) + 4 * kq;
