@@ -26,6 +26,10 @@ python tools/step_timeline.py $(find $OUT/trace_step_comm -name "*kernel_trace.c
 python bench.py --steps 100 --warmup 20 --staged-input --breakdown > $OUT/bench_alexnet.json 2> $OUT/bench_alexnet_breakdown.txt
 python bench.py --config vgg11 --breakdown > $OUT/bench_vgg11.json 2> $OUT/bench_vgg11_breakdown.txt
 python bench.py --config resnet18 --breakdown > $OUT/bench_resnet18.json 2> $OUT/bench_resnet18_breakdown.txt
+# the ResNet-shaped step with every backward pass serial (no weight gradient beside the data gradient): each kernel's duration ALONE on the chip, in the step's own order
+CNN_AMD_SERIAL_BWD_GFLOP=0 python bench.py --config resnet18 --breakdown > $OUT/bench_resnet18_serial.json 2> $OUT/bench_resnet18_serial_breakdown.txt
+# conv_rows / wgrad_sp on the stacks' shapes, isolated (tools/one_layer.py)
+(for c in "256 64 112 112 128 3 1 0" "128 64 112 112 128 3 1 1" "128 128 56 56 256 3 1 1" "128 256 56 56 256 3 1 1" "128 256 28 28 512 3 1 1" "128 512 28 28 512 3 1 1" "128 512 14 14 512 3 1 1" "64 64 56 56 64 3 1 1" "64 128 28 28 128 3 1 1" "64 256 14 14 256 3 1 1" "64 512 7 7 512 3 1 1"; do echo "== $c"; python tools/one_layer.py $c 3 2>&1 | grep -v "amdgpu\|prep"; done) > $OUT/rows_sp_isolated.txt 2>&1
 bash tools/run_tune.sh > /dev/null 2>&1; cp gpurun_out/tune_layers.log $OUT/layers_isolated.txt
 (python tools/tune_stack.py vgg11; python tools/tune_stack.py resnet18) > $OUT/stack_layers_isolated.txt 2>&1
 # large raw traces stay out of the merge-back (64 MiB cap): keep the per-kernel stats and drop the per-launch traces
