@@ -232,11 +232,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
     constexpr int NKS = 9 * G::KSTEPS;
     constexpr int PER_KS = (G::NSLOT + NKS - 1) / NKS;
     int t = 0;  // stages so far: buffer parity
-    if (p.dbg == 2) {  // (ROWS_DBG=2, experiment: workgroups start in 8 phases spread over one unit's duration)
-        const long long wait = (long long)(blockIdx.x % 8) * p.nchunk * (NKS * MA * G::RW * NB * 32) / 8;
-        const long long t0 = __builtin_readcyclecounter();
-        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
+    const long long dbg_c0 = p.dbg == 9 ? clock64() : 0, dbg_w0 = p.dbg == 9 ? wall_clock64() : 0;  // (ROWS_DBG=9: block 0 prints its shader clock)
     for (int u = u_lo; u < u_hi; ++u) {
       // the unit behind this one (behind the last one: this one again)
       int bu = b, r0u = r0;
@@ -506,6 +502,11 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
       b = bu; r0 = r0u;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.dbg == 9 && threadIdx.x == 0 && (blockIdx.x | blockIdx.y) == 0) {
+        const long long c = clock64() - dbg_c0, w = wall_clock64() - dbg_w0;
+        printf("conv_rows block 0: %lld shader cycles in %lld ticks of 10 ns -> %.0f MHz, %d stages of %d MFMAs per wave\n", c, w, (double)c / ((double)w / 100.0), t,
+               NKS * MA * G::RW * NB);
+    }
 }
 
 // filters -> [co tile][chunk][channel 0..CK-1][tap][QW]; mode 0: forward (w[co][c][tap]); mode 1: data gradient (w[c][m][8 - tap])
