@@ -720,7 +720,7 @@ def test_conv2d_combined_backward_matches_separate_calls(T):
             assert T.equal(gw1, gw2) and T.equal(gb1, gb2) and T.equal(dx1, dx2)
 
 
-@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 5, 6, 7, 8, 9, 10)], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 5, 6, 7, 8, 9, 10)] + ROWS_CASES, ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
 def test_conv2d_forward_relu_fusion_is_bit_identical(T, case):
     """cnn_conv2d_forward_relu == cnn_conv2d_forward + cnn_relu_forward, both outputs, every kernel family"""
     from cnn_amd import capi
@@ -1082,7 +1082,7 @@ def test_pool_fused_net_is_bit_identical(T, defer):
         assert T.equal(a.d_conv[1], b.d_conv[1])  # d(pool output): conv_layer_2's plain data gradient in both nets
 
 
-@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 13)] + [(3, 32, 9, 11, 64, 3, 1, 0), (2, 32, 28, 30, 64, 3, 2, 0), (1, 96, 9, 12, 128, 3, 2, 0), (2, 64, 14, 14, 128, 3, 2, 1), (3, 64, 9, 11, 128, 3, 2, 1)], ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 13)] + [(3, 32, 9, 11, 64, 3, 1, 0), (2, 32, 28, 30, 64, 3, 2, 0), (1, 96, 9, 12, 128, 3, 2, 0), (2, 64, 14, 14, 128, 3, 2, 1), (3, 64, 9, 11, 128, 3, 2, 1)] + ROWS_CASES, ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
 def test_conv2d_backward_data_relu_fusion_is_bit_identical(T, case):
     """cnn_conv2d_backward_data_relu == cnn_conv2d_backward_data + cnn_relu_backward, every kernel family, plain and prepared"""
     from cnn_amd import capi

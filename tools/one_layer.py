@@ -34,6 +34,8 @@ for op in which:
             conv.forward(x, w, b, y)
         elif op == "dgrad":
             conv.backward_data(dy, w, dx)
+        elif op == "dgrad_relu":  # the data gradient through the ReLU' mask of the layer in front (relu_below = x: ~all pass)
+            conv.backward_data_relu(dy, w, x, dx)
         else:
             conv.backward_weight(x, dy, float(B))
     run(); run()
