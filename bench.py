@@ -178,6 +178,26 @@ def conv_ns_bench(torch, capi, reps=5):
             tag = "fwd" if name.endswith(("/fwd", "/fwd+relu")) else ("dgrad" if name.endswith("/dgrad") else "wgrad")
             out[tag] = {"kernel": name, "avg_ms": round(ms / cnt, 4), "tflops": round(tf, 2),
                         "frac_of_mfma_peak": round(tf / PEAK_MFMA_F32_TFLOPS, 4)}
+    # HBM-side traffic per launch from the committed PMC passes of the same three launches (tools/pmc_conv_ns.sh), next to the algorithmic bytes
+    import glob
+
+    alg = 4.0 * (256 * 64 * 112 * 112 + 256 * 128 * 110 * 110 + 128 * 64 * 9)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic_conv_ns.json")), reverse=True)[:1]:
+        try:
+            kernels = json.load(open(path))["kernels"]
+        except Exception:
+            break
+        for tag in ("fwd", "dgrad", "wgrad"):
+            if tag not in out:
+                continue
+            m = re.match(r"(conv_rows|wgrad_sp)<(\d+,\d+),", out[tag]["kernel"])
+            if not m:
+                continue
+            hits = [v for k, v in kernels.items() if k.replace(" ", "").startswith(f"{m.group(1)}_kernel<{m.group(2)},")]
+            if len(hits) == 1:
+                out[tag]["algorithmic_bytes"] = alg
+                out[tag]["traffic"] = hits[0]["hbm_bytes"]
+                out[tag]["traffic_source"] = os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2 on gfx950; L2 misses: served by the Infinity Cache or HBM)"
     del x, y, dy, dx
     torch.cuda.empty_cache()
     return out

@@ -1838,6 +1838,7 @@ static int autotune_impl(const cnn_conv2d_desc* d, void* scratch, size_t scratch
     for (int mode = 0; mode < 2; ++mode) {
         // geometries that never reach the implicit GEMM in this mode
         if (direct_conv_supported(d) || c11_supported(d)) continue;
+        if (rows_workspace_floats(d, mode) > 0) continue;  // (conv_rows.hip has no tile to choose)
         // register-direct kernels for BIG layers (stride-1 / stride-2 3x3, pad 0, Ci <= 64; stride-1 data gradient) are measured
         // against the implicit GEMM below; the small-layer kernels, the first-layer kernels and the stem keep their layers
         const bool rd_fwd = mode == MODE_FWD && fwd_rd_supported(d);

@@ -32,6 +32,7 @@ CNN_AMD_SERIAL_BWD_GFLOP=0 python bench.py --config resnet18 --breakdown > $OUT/
 (for c in "256 64 112 112 128 3 1 0" "128 64 112 112 128 3 1 1" "128 128 56 56 256 3 1 1" "128 256 56 56 256 3 1 1" "128 256 28 28 512 3 1 1" "128 512 28 28 512 3 1 1" "128 512 14 14 512 3 1 1" "64 64 56 56 64 3 1 1" "64 128 28 28 128 3 1 1" "64 256 14 14 256 3 1 1" "64 512 7 7 512 3 1 1"; do echo "== $c"; python tools/one_layer.py $c 3 2>&1 | grep -v "amdgpu\|prep"; done) > $OUT/rows_sp_isolated.txt 2>&1
 bash tools/run_tune.sh > /dev/null 2>&1; cp gpurun_out/tune_layers.log $OUT/layers_isolated.txt
 (python tools/tune_stack.py vgg11; python tools/tune_stack.py resnet18) > $OUT/stack_layers_isolated.txt 2>&1
+bash tools/pmc_conv_ns.sh $TAG > $OUT/hbm_traffic_conv_ns.txt 2>&1
 # large raw traces stay out of the merge-back (64 MiB cap): keep the per-kernel stats and drop the per-launch traces
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
 find $OUT -name "*counter_collection.csv" -size +8M -delete
