@@ -486,6 +486,57 @@ __global__ __launch_bounds__(kRedElems * kRedLanes) void slab_reduce_batch_v4(co
     }
 }
 
+// (round 5) The same sums, ONE thread per four consecutive elements and no LDS: the thread walks the slots itself, eight partial sums in
+// the order of the eight slot-lanes above (partial k adds slots k, k + 8, ...; then the partials in order 0..7) -- bit-identical to
+// slab_reduce / slab_reduce_batch(_v4) for every job whose red_lanes() is 8.  The stacks' weight-gradient slabs (4 - 256 slabs of
+// 0.15 - 9.4 MB) ran at 0.5 - 2 TB/s through the workgroup-per-32-elements kernels: with 4 slabs half of a workgroup's threads held no
+// slot, every workgroup ended in a barrier and an LDS pass, and the output index cost four 64-bit divisions per thread.
+__global__ __launch_bounds__(256) void slab_reduce_flat(const RedBatch rb) {
+    const RedJob j = rb.job[blockIdx.y];
+    const unsigned n4 = j.n / 4;
+    const float4* const in4 = (const float4*)j.in;
+    for (unsigned q = blockIdx.x * 256 + threadIdx.x; q < n4; q += gridDim.x * 256) {
+        float4 part[kRedLanes];
+#pragma unroll
+        for (int k = 0; k < kRedLanes; ++k) part[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s0 = 0; s0 < j.nslots; s0 += kRedLanes) {
+            float4 v[kRedLanes];
+#pragma unroll
+            for (int u = 0; u < kRedLanes; ++u)
+                if (s0 + u < j.nslots) v[u] = in4[(size_t)(s0 + u) * n4 + q];
+#pragma unroll
+            for (int u = 0; u < kRedLanes; ++u)
+                if (s0 + u < j.nslots) {
+                    part[u].x += v[u].x; part[u].y += v[u].y; part[u].z += v[u].z; part[u].w += v[u].w;
+                }
+        }
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < kRedLanes; ++k) {
+            t.x += part[k].x; t.y += part[k].y; t.z += part[k].z; t.w += part[k].w;
+        }
+        const float tv[4] = {t.x / j.divisor, t.y / j.divisor, t.z / j.divisor, t.w / j.divisor};
+        const unsigned i = q * 4;
+        if (j.split_n > 0) {  // slab rows are [split_n weight gradients | 1 bias gradient]
+            const unsigned w = (unsigned)j.split_n + 1;
+            unsigned row = i / w, col = i - row * w;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (col < (unsigned)j.split_n) j.out[(size_t)row * j.split_n + col] = tv[c];
+                else if (j.out_b) j.out_b[row] = tv[c];
+                if (++col == w) { col = 0; ++row; }
+            }
+        } else {
+            *(float4*)(j.out + i) = make_float4(tv[0], tv[1], tv[2], tv[3]);
+        }
+    }
+}
+// a job the flat kernel takes: whole float4s, aligned, the 8-lane summation order
+inline bool flat_job(const RedJob& j) {
+    return j.n % 4 == 0 && reinterpret_cast<uintptr_t>(j.in) % 16 == 0 && red_lanes(j.nslots, j.n) == kRedLanes &&
+           (j.split_n > 0 || reinterpret_cast<uintptr_t>(j.out) % 16 == 0);
+}
+
 int flush_reduces(hipStream_t s) {
     PendingReduces& p = pending_reduces();
     if (p.count == 0) return CNN_AMD_OK;
@@ -500,7 +551,20 @@ int flush_reduces(hipStream_t s) {
         most = need > most ? need : most;
     }
     const int jobs = p.count;
+    bool flat = !CNN_OPT_SET("REDUCE_OLD") && !CNN_OPT_SET("REDUCE_SCALAR");
+    unsigned most4 = 0;
+    for (int i = 0; i < jobs; ++i) {
+        flat = flat && flat_job(p.batch.job[i]);
+        most4 = p.batch.job[i].n / 4 > most4 ? p.batch.job[i].n / 4 : most4;
+    }
     p.count = 0;
+    if (flat) {
+        unsigned gx = (most4 + 255) / 256;
+        if (gx > 8192) gx = 8192;
+        if (gx < 1) gx = 1;
+        CNN_KLAUNCH(s, "slab_reduce/batch", (slab_reduce_flat<<<dim3(gx, jobs), 256, 0, s>>>(p.batch)), "jobs=%d", jobs);
+        return CNN_AMD_OK;
+    }
     if (v4) {
         CNN_KLAUNCH(s, "slab_reduce/batch", (slab_reduce_batch_v4<<<dim3(most, jobs), kRedElems * kRedLanes, 0, s>>>(p.batch)), "jobs=%d", jobs);
         return CNN_AMD_OK;
@@ -530,6 +594,18 @@ int reduce_slabs(hipStream_t s, const float* slabs, int nslots, size_t n, float*
                     (slab_reduce<<<dim3(gx, groups), kRedElems * kRedLanes, 0, s>>>(slabs, tmp, nslots, n, per, 1.f, 0, 0, nullptr, kRedLanes)), "%s", tag);
         slabs = tmp;
         nslots = groups;
+    }
+    if (n < (1ull << 31) && !CNN_OPT_SET("REDUCE_OLD") && !CNN_OPT_SET("REDUCE_SCALAR")) {
+        RedBatch one;
+        RedJob& j = one.job[0];
+        j.in = slabs; j.out = dst; j.out_b = dst_b; j.nslots = nslots; j.split_n = split_n; j.n = (unsigned)n; j.divisor = divisor;
+        if (flat_job(j)) {
+            unsigned gx = (unsigned)((n / 4 + 255) / 256);
+            if (gx > 8192) gx = 8192;
+            if (gx < 1) gx = 1;
+            CNN_KLAUNCH(s, "slab_reduce/final", (slab_reduce_flat<<<dim3(gx, 1), 256, 0, s>>>(one)), "%s", tag);
+            return CNN_AMD_OK;
+        }
     }
     const int lanes = red_lanes(nslots, n), elems = (kRedElems * kRedLanes) / lanes;
     CNN_KLAUNCH(s, "slab_reduce/final",

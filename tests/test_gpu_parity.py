@@ -228,6 +228,23 @@ def test_conv2d_wgrad_small_planes(T, case, unit, lib_option):
     assert_close(host(gw3), gw_ref, REL_TOL, "register-direct weight grad")
 
 
+@pytest.mark.parametrize("case", [SP_CASES[i] for i in (0, 2, 3, 5, 7)] + [(4, 16, 55, 55, 32, 3, 2, 0), (3, 64, 13, 13, 128, 3, 2, 0), (2, 32, 27, 27, 64, 3, 2, 0)],
+                         ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_flat_slab_reduction_is_bit_identical_to_the_workgroup_one(T, case, lib_option):
+    """slab_reduce_flat (round 5: one thread per four elements walks the slabs itself) keeps the summation order of the workgroup-per-32-
+    elements kernels (eight slot partials, then the partials in order): weight and bias gradients bit for bit, every weight-gradient family"""
+    from cnn_amd import capi
+
+    x, w, b, dy = _conv_inputs(case, 910)
+    conv = capi.Conv2d(*case)
+    xd, dyd = dev(T, x), dev(T, dy)
+    gw1, gb1 = conv.backward_weight(xd, dyd, float(case[0]))
+    lib_option("REDUCE_OLD", "1")
+    gw0, gb0 = conv.backward_weight(xd, dyd, float(case[0]))
+    assert np.array_equal(host(gw1).view(np.uint32), host(gw0).view(np.uint32))
+    assert np.array_equal(host(gb1).view(np.uint32), host(gb0).view(np.uint32))
+
+
 ROWS_CASES = [
     (2, 64, 7, 112, 128, 3, 1, 0),   # the north-star geometry at a small height: forward 112-wide pad 0 (128-channel tile), data gradient 110-wide pad 2
     (1, 40, 9, 112, 104, 3, 1, 0),   # ... partial output-channel tiles (104 of 128 forward, 40 of 64 backward), 5 / 13 channel chunks
