@@ -287,6 +287,34 @@ def test_conv2d_row_kernel_vs_oracle(T, case, lib_option):
     assert_close(host(conv.backward_data(dyd, wd)), dx_ref, REL_TOL, "implicit GEMM data gradient")
 
 
+@pytest.mark.parametrize("case", [(8, 64, 112, 112, 128, 3, 1, 0), (16, 128, 28, 28, 128, 3, 1, 1), (9, 48, 7, 7, 80, 3, 1, 1)],
+                         ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_inline_asm_mfma_kernels_are_bit_reproducible(T, case):
+    """conv_rows.hip issues its MFMAs as inline assembly and pads the hazards itself (s_nop 1, acc_settle): a missed hazard would show as
+    rare differing bits between two runs of one launch.  Forward, both data gradients and the weight gradient, eight runs each, every
+    second one beside a second stream that keeps the chip busy (tools/rows_stress.py is the long form)"""
+    from cnn_amd import capi
+
+    x, w, b, dy = _conv_inputs(case, 977)
+    conv = capi.Conv2d(*case)
+    xd, wd, bd, dyd = dev(T, x), dev(T, w), dev(T, b), dev(T, dy)
+    side, noise = T.cuda.Stream(), T.rand((2048, 2048), device="cuda")
+    first = None
+    for rep in range(8):
+        if rep % 2:
+            with T.cuda.stream(side):
+                (noise @ noise).sum()
+        dxr = T.empty_like(xd)
+        conv.backward_data_relu(dyd, wd, xd, dxr)
+        cur = [conv.forward(xd, wd, bd), conv.backward_data(dyd, wd), dxr, *conv.backward_weight(xd, dyd, float(case[0]))]
+        T.cuda.synchronize()
+        cur = [t.clone() for t in cur]
+        if first is None:
+            first = cur
+        else:
+            assert all(T.equal(a, c) for a, c in zip(first, cur)), f"run {rep} differs from run 0"
+
+
 def test_u8_batch_stager_is_bit_identical_to_the_reference_conversion(T, golden_dir):
     """row n4, cnn_batch_stager_create_u8: the bytes of a real input (the six images behind the reference's own Grad-CAM pictures and the
     three README images, tests/golden/*_images_u8.*) are uploaded AS BYTES and converted on the device to the fp32 planar batch --
