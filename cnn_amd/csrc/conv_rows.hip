@@ -234,94 +234,94 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
     int t = 0;  // stages so far: buffer parity
     const long long dbg_c0 = p.dbg == 9 ? clock64() : 0, dbg_w0 = p.dbg == 9 ? wall_clock64() : 0;  // (ROWS_DBG=9: block 0 prints its shader clock)
     for (int u = u_lo; u < u_hi; ++u) {
-      // the unit behind this one (behind the last one: this one again)
-      int bu = b, r0u = r0;
-      if (u + 1 < u_hi) {
-          if (r0 + G::ROWS < p.HO) r0u = r0 + G::ROWS;
-          else { r0u = 0; bu = b + PK; }
-      }
-      for (int cc = 0; cc < p.nchunk; ++cc, ++t) {
-        // this wave's share of the stage has landed.  Stage 0 of a unit behind the first: already waited for in front of the previous unit's
-        // stores -- a wait here would also wait for THOSE to drain (vmcnt counts stores; measured on the north-star forward, where all 256
-        // workgroups store 29 MB in one burst every 8 stages: 5.6 us per unit, 8 % of the kernel); they drain under this stage's MFMAs and
-        // the next stage's wait finds them gone
-        if (cc != 0 || u == u_lo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const float* cur = smem + (t & 1) * G::BUF;
-        float* nxt = smem + ((t + 1) & 1) * G::BUF;
-        // the stage behind this one (behind the last one of the range: that one again)
-        const bool last_cc = cc + 1 == p.nchunk;
-        const int bn = last_cc ? bu : b, r0n = last_cc ? r0u : r0, ccn = last_cc ? (u + 1 < u_hi ? 0 : cc) : cc + 1;
-        // rows of the staged block that lie outside the image (wave-uniform; only with padding)
-        unsigned rowbad = 0;
-        if (PAD > 0 && RSEL) {  // (rows above the image are staged as zeros in either variant)
-#pragma unroll
-            for (int i = 0; i < G::XR; ++i) rowbad |= (r0 - PAD + i >= H ? 1u : 0u) << i;
+        // the unit behind this one (behind the last one: this one again)
+        int bu = b, r0u = r0;
+        if (u + 1 < u_hi) {
+            if (r0 + G::ROWS < p.HO) r0u = r0 + G::ROWS;
+            else { r0u = 0; bu = b + PK; }
         }
-        // operands of one k-step (tap, 4-channel group): 2 A values, RW * NB B values -- read one k-step ahead of their MFMAs
-        struct Ops {
-            float a[MA];
-            float b[G::RW][NB];
-        };
-        auto read_ops = [&](Ops& o, int ks) {
-            const int tap = ks / G::KSTEPS, s = ks % G::KSTEPS, kx = tap / 3, ky = tap % 3;
+        for (int cc = 0; cc < p.nchunk; ++cc, ++t) {
+            // this wave's share of the stage has landed.  Stage 0 of a unit behind the first: already waited for in front of the previous unit's
+            // stores -- a wait here would also wait for THOSE to drain (vmcnt counts stores; measured on the north-star forward, where all 256
+            // workgroups store 29 MB in one burst every 8 stages: 5.6 us per unit, 8 % of the kernel); they drain under this stage's MFMAs and
+            // the next stage's wait finds them gone
+            if (cc != 0 || u == u_lo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const float* cur = smem + (t & 1) * G::BUF;
+            float* nxt = smem + ((t + 1) & 1) * G::BUF;
+            // the stage behind this one (behind the last one of the range: that one again)
+            const bool last_cc = cc + 1 == p.nchunk;
+            const int bn = last_cc ? bu : b, r0n = last_cc ? r0u : r0, ccn = last_cc ? (u + 1 < u_hi ? 0 : cc) : cc + 1;
+            // rows of the staged block that lie outside the image (wave-uniform; only with padding)
+            unsigned rowbad = 0;
+            if (PAD > 0 && RSEL) {  // (rows above the image are staged as zeros in either variant)
 #pragma unroll
-            for (int ma = 0; ma < MA; ++ma) o.a[ma] = cur[a_base + (s * 36 + tap) * G::QW + ma * 16];
-#pragma unroll
-            for (int rw = 0; rw < G::RW; ++rw) {
-                const bool bad = PAD > 0 && RSEL && ((rowbad >> (wr * G::RW + rw + kx)) & 1u);  // (RSEL: SR == 1)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    // (packed planes: the pad between two staged planes moves the pixels of the later planes; per lane in a block that straddles)
-                    int xtra = 0;
-                    if constexpr (PK > 1) {
-                        constexpr int PAD3 = G::SP - G::PLANE;
-                        const int lo = (16 * nb) / G::PLANE, hi = (16 * nb + 15) / G::PLANE;
-                        xtra = lo == hi ? PAD3 * lo : PAD3 * ((16 * nb + n) / G::PLANE);
-                    }
-                    float bv = cur[b_base + s * 4 * G::QXP + (rw * SR + kx) * WI + 16 * nb + ky + xtra];
-                    // the tap columns that leave their row (a select: what lies there is the neighbouring row's data)
-                    constexpr unsigned kAll = 0xffffu;
-                    if constexpr (WP == 1) {
-                        const unsigned cm = PK > 1 ? G::tapmask(nb, kx, ky) : G::colmask(nb, ky);
-                        if (cm == kAll) bv = 0.f;
-                        else if (cm != 0) bv = ((cm >> n) & 1u) ? 0.f : bv;
-                    } else {
-                        const unsigned c0 = G::colmask(nb, ky), c1 = G::colmask(G::NBW + nb, ky);
-                        if (c0 != 0 || c1 != 0) bv = (((wp ? c1 : c0) >> n) & 1u) ? 0.f : bv;
-                        (void)kAll;
-                    }
-                    if (PAD > 0 && RSEL) bv = bad ? 0.f : bv;
-                    o.b[rw][nb] = bv;
-                }
+                for (int i = 0; i < G::XR; ++i) rowbad |= (r0 - PAD + i >= H ? 1u : 0u) << i;
             }
-        };
-        // read-ahead distance in k-steps: one where a k-step is 28 MFMAs (~900 cycles), two where it is 14 or 7 (a k-step of 7 MFMAs is
-        // shorter than an LDS round trip under load)
-        constexpr int D = MA * G::RW * NB >= 28 ? 1 : 2;
-        Ops ops[D + 1];
+            // operands of one k-step (tap, 4-channel group): 2 A values, RW * NB B values -- read one k-step ahead of their MFMAs
+            struct Ops {
+                float a[MA];
+                float b[G::RW][NB];
+            };
+            auto read_ops = [&](Ops& o, int ks) {
+                const int tap = ks / G::KSTEPS, s = ks % G::KSTEPS, kx = tap / 3, ky = tap % 3;
 #pragma unroll
-        for (int d = 0; d < D; ++d) read_ops(ops[d], d);
+                for (int ma = 0; ma < MA; ++ma) o.a[ma] = cur[a_base + (s * 36 + tap) * G::QW + ma * 16];
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            if (ks + D < NKS) read_ops(ops[(ks + D) % (D + 1)], ks + D);
+                for (int rw = 0; rw < G::RW; ++rw) {
+                    const bool bad = PAD > 0 && RSEL && ((rowbad >> (wr * G::RW + rw + kx)) & 1u);  // (RSEL: SR == 1)
 #pragma unroll
-            for (int k = ks * PER_KS; k < (ks + 1) * PER_KS && k < G::NSLOT; ++k) dma_slot(k, bn, r0n, ccn, nxt);
-            Ops& o = ops[ks % (D + 1)];
-            // the reads above may not sink below this point (instruction selection otherwise moves every LDS read down to its first use,
-            // two MFMAs ahead of a full LDS round trip) and the MFMAs below may not rise above it
-            asm volatile("" : "+v"(o.a[0]) : : "memory");
+                    for (int nb = 0; nb < NB; ++nb) {
+                        // (packed planes: the pad between two staged planes moves the pixels of the later planes; per lane in a block that straddles)
+                        int xtra = 0;
+                        if constexpr (PK > 1) {
+                            constexpr int PAD3 = G::SP - G::PLANE;
+                            const int lo = (16 * nb) / G::PLANE, hi = (16 * nb + 15) / G::PLANE;
+                            xtra = lo == hi ? PAD3 * lo : PAD3 * ((16 * nb + n) / G::PLANE);
+                        }
+                        float bv = cur[b_base + s * 4 * G::QXP + (rw * SR + kx) * WI + 16 * nb + ky + xtra];
+                        // the tap columns that leave their row (a select: what lies there is the neighbouring row's data)
+                        constexpr unsigned kAll = 0xffffu;
+                        if constexpr (WP == 1) {
+                            const unsigned cm = PK > 1 ? G::tapmask(nb, kx, ky) : G::colmask(nb, ky);
+                            if (cm == kAll) bv = 0.f;
+                            else if (cm != 0) bv = ((cm >> n) & 1u) ? 0.f : bv;
+                        } else {
+                            const unsigned c0 = G::colmask(nb, ky), c1 = G::colmask(G::NBW + nb, ky);
+                            if (c0 != 0 || c1 != 0) bv = (((wp ? c1 : c0) >> n) & 1u) ? 0.f : bv;
+                            (void)kAll;
+                        }
+                        if (PAD > 0 && RSEL) bv = bad ? 0.f : bv;
+                        o.b[rw][nb] = bv;
+                    }
+                }
+            };
+            // read-ahead distance in k-steps: one where a k-step is 28 MFMAs (~900 cycles), two where it is 14 or 7 (a k-step of 7 MFMAs is
+            // shorter than an LDS round trip under load)
+            constexpr int D = MA * G::RW * NB >= 28 ? 1 : 2;
+            Ops ops[D + 1];
 #pragma unroll
-            for (int rw = 0; rw < G::RW; ++rw)
+            for (int d = 0; d < D; ++d) read_ops(ops[d], d);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks + D < NKS) read_ops(ops[(ks + D) % (D + 1)], ks + D);
 #pragma unroll
-                    for (int ma = 0; ma < MA; ++ma) mfma16(acc[ma][rw][nb], o.b[rw][nb], o.a[ma]);
+                for (int k = ks * PER_KS; k < (ks + 1) * PER_KS && k < G::NSLOT; ++k) dma_slot(k, bn, r0n, ccn, nxt);
+                Ops& o = ops[ks % (D + 1)];
+                // the reads above may not sink below this point (instruction selection otherwise moves every LDS read down to its first use,
+                // two MFMAs ahead of a full LDS round trip) and the MFMAs below may not rise above it
+                asm volatile("" : "+v"(o.a[0]) : : "memory");
+#pragma unroll
+                for (int rw = 0; rw < G::RW; ++rw)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int ma = 0; ma < MA; ++ma) mfma16(acc[ma][rw][nb], o.b[rw][nb], o.a[ma]);
+            }
         }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the next unit's stage 0, issued early in the last stage: see above)
-      acc_settle<MA * G::RW * NB>(&acc[0][0][0]);
-      if (p.dbg != 1) {  // (ROWS_DBG=1, measurement only: no stores)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the next unit's stage 0, issued early in the last stage: see above)
+        acc_settle<MA * G::RW * NB>(&acc[0][0][0]);
+        if (p.dbg != 1) {  // (ROWS_DBG=1, measurement only: no stores)
             // ---- this unit is complete: + bias, store.  The MFMAs ran with the PIXELS as the M operand (D[i][j]: lane (j = n, kq) holds rows
             //      i = 4 kq + r): a lane's four registers of a tile are four CONSECUTIVE pixels of output channel n -- one 16-byte store
             //      (and one 16-byte load of the ReLU' mask) per tile instead of four scattered dwords: 28 instead of 112 store instructions
@@ -383,123 +383,123 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
                 }
             } else {
 #pragma unroll
-            for (int ma = 0; ma < MA; ++ma) {
-                const int co = co0 + wm * (16 * MA) + ma * 16 + n;
-                const float bs = (p.bias != nullptr && co < p.M) ? p.bias[co] : 0.f;
-                const int bE = p.dbg == 3 ? (int)blockIdx.x : b, r0E = p.dbg == 3 ? 0 : r0;  // (ROWS_DBG=3, experiment: every unit of a workgroup stores to the same place)
-                const size_t cbase = ((size_t)bE * p.M + co) * HWO;
-                // FAST PATH (one 16-channel block of a wave whose super-rows lie inside the image -- every unit but the ragged last ones of a
-                // plane): no per-tile validity, one exec region per block (co < M), the tile offsets compile-time immediates off one per-lane
-                // base.  (The generic path below costs ~40 instructions per tile in compare / saveexec / branch sequences: measured on the
-                // north-star forward with the stores redirected to an L2-resident region, 2/3 of the epilogue's 6 us per unit was not HBM.)
-                bool all_inside = WP == 1;
+                for (int ma = 0; ma < MA; ++ma) {
+                    const int co = co0 + wm * (16 * MA) + ma * 16 + n;
+                    const float bs = (p.bias != nullptr && co < p.M) ? p.bias[co] : 0.f;
+                    const int bE = p.dbg == 3 ? (int)blockIdx.x : b, r0E = p.dbg == 3 ? 0 : r0;  // (ROWS_DBG=3, experiment: every unit of a workgroup stores to the same place)
+                    const size_t cbase = ((size_t)bE * p.M + co) * HWO;
+                    // FAST PATH (one 16-channel block of a wave whose super-rows lie inside the image -- every unit but the ragged last ones of a
+                    // plane): no per-tile validity, one exec region per block (co < M), the tile offsets compile-time immediates off one per-lane
+                    // base.  (The generic path below costs ~40 instructions per tile in compare / saveexec / branch sequences: measured on the
+                    // north-star forward with the stores redirected to an L2-resident region, 2/3 of the epilogue's 6 us per unit was not HBM.)
+                    bool all_inside = WP == 1;
 #pragma unroll
-                for (int rw = 0; rw < G::RW; ++rw) all_inside = all_inside && (p.HO - (r0E + (wr * G::RW + rw) * SR)) * WO >= G::PX;
-                if (all_inside) {  // (wave-uniform)
-                    if (co < p.M) {
+                    for (int rw = 0; rw < G::RW; ++rw) all_inside = all_inside && (p.HO - (r0E + (wr * G::RW + rw) * SR)) * WO >= G::PX;
+                    if (all_inside) {  // (wave-uniform)
+                        if (co < p.M) {
 #pragma unroll
-                        for (int rw = 0; rw < G::RW; ++rw) {
-                            const size_t rbase = cbase + (size_t)(r0E + wr * G::RW * SR) * WO + 4 * kq;  // this lane's first pixel of the wave's first super-row
-                            constexpr int CNT_LAST = G::PX - 16 * (NB - 1);  // pixels of the last block (16: full)
-                            const int cnt = CNT_LAST - 4 * kq;               // ... of this lane's four (>= 4: all)
-                            auto at = [&](int nb) { return rbase + (size_t)(rw * SR * WO + 16 * nb); };
-                            f32x4 mk[NB];
-                            if (p.relu_below != nullptr) {
+                            for (int rw = 0; rw < G::RW; ++rw) {
+                                const size_t rbase = cbase + (size_t)(r0E + wr * G::RW * SR) * WO + 4 * kq;  // this lane's first pixel of the wave's first super-row
+                                constexpr int CNT_LAST = G::PX - 16 * (NB - 1);  // pixels of the last block (16: full)
+                                const int cnt = CNT_LAST - 4 * kq;               // ... of this lane's four (>= 4: all)
+                                auto at = [&](int nb) { return rbase + (size_t)(rw * SR * WO + 16 * nb); };
+                                f32x4 mk[NB];
+                                if (p.relu_below != nullptr) {
 #pragma unroll
-                                for (int nb = 0; nb < NB; ++nb) {
-                                    mk[nb] = f32x4{1.f, 1.f, 1.f, 1.f};
-                                    if (nb + 1 < NB || CNT_LAST == 16 || cnt >= 4) mk[nb] = *(const f32x4u*)(p.relu_below + at(nb));
-                                    else {
+                                    for (int nb = 0; nb < NB; ++nb) {
+                                        mk[nb] = f32x4{1.f, 1.f, 1.f, 1.f};
+                                        if (nb + 1 < NB || CNT_LAST == 16 || cnt >= 4) mk[nb] = *(const f32x4u*)(p.relu_below + at(nb));
+                                        else {
 #pragma unroll
-                                        for (int e = 0; e < 3; ++e)
-                                            if (e < cnt) mk[nb][e] = p.relu_below[at(nb) + e];
+                                            for (int e = 0; e < 3; ++e)
+                                                if (e < cnt) mk[nb][e] = p.relu_below[at(nb) + e];
+                                        }
                                     }
+                                }
+                                f32x4 v[NB];
+#pragma unroll
+                                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        v[nb][e] = acc[ma][rw][nb][e] + bs;
+                                        if (p.relu_below != nullptr) v[nb][e] = mk[nb][e] <= 0.f ? 0.f : v[nb][e];
+                                    }
+                                auto put = [&](float* dst, bool relu) {
+#pragma unroll
+                                    for (int nb = 0; nb < NB; ++nb) {
+                                        f32x4 o = v[nb];
+                                        if (relu) {
+#pragma unroll
+                                            for (int e = 0; e < 4; ++e) o[e] = o[e] >= 0.f ? o[e] : 0.f;
+                                        }
+                                        if (nb + 1 < NB || CNT_LAST == 16 || cnt >= 4) *(f32x4u*)(dst + at(nb)) = o;
+                                        else {
+#pragma unroll
+                                            for (int e = 0; e < 3; ++e)
+                                                if (e < cnt) dst[at(nb) + e] = o[e];
+                                        }
+                                    }
+                                };
+                                if (p.y != nullptr) put(p.y, false);
+                                if (p.y_relu != nullptr) put(p.y_relu, true);
+                            }
+                        }
+                        continue;
+                    }
+                    f32x4 mk[G::RW][NB];
+                    int nval[G::RW][NB];
+#pragma unroll
+                    for (int rw = 0; rw < G::RW; ++rw) {
+                        const int row0 = r0E + (wr * G::RW + rw) * SR;
+                        const int lim0 = (p.HO - row0) * WO, lim = lim0 < G::PX ? lim0 : G::PX;  // pixels of the super-row inside the image
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const int f = 16 * (wp * G::NBW + nb) + 4 * kq;
+                            nval[rw][nb] = co < p.M ? lim - f : 0;
+                            mk[rw][nb] = f32x4{1.f, 1.f, 1.f, 1.f};
+                            if (p.relu_below != nullptr) {
+                                const float* m = p.relu_below + cbase + (size_t)row0 * WO + f;
+                                if (nval[rw][nb] >= 4) mk[rw][nb] = *(const f32x4u*)m;
+                                else {
+#pragma unroll
+                                    for (int e = 0; e < 3; ++e)
+                                        if (e < nval[rw][nb]) mk[rw][nb][e] = m[e];
                                 }
                             }
-                            f32x4 v[NB];
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    v[nb][e] = acc[ma][rw][nb][e] + bs;
-                                    if (p.relu_below != nullptr) v[nb][e] = mk[nb][e] <= 0.f ? 0.f : v[nb][e];
-                                }
-                            auto put = [&](float* dst, bool relu) {
-#pragma unroll
-                                for (int nb = 0; nb < NB; ++nb) {
-                                    f32x4 o = v[nb];
-                                    if (relu) {
-#pragma unroll
-                                        for (int e = 0; e < 4; ++e) o[e] = o[e] >= 0.f ? o[e] : 0.f;
-                                    }
-                                    if (nb + 1 < NB || CNT_LAST == 16 || cnt >= 4) *(f32x4u*)(dst + at(nb)) = o;
-                                    else {
-#pragma unroll
-                                        for (int e = 0; e < 3; ++e)
-                                            if (e < cnt) dst[at(nb) + e] = o[e];
-                                    }
-                                }
-                            };
-                            if (p.y != nullptr) put(p.y, false);
-                            if (p.y_relu != nullptr) put(p.y_relu, true);
                         }
                     }
-                    continue;
-                }
-                f32x4 mk[G::RW][NB];
-                int nval[G::RW][NB];
 #pragma unroll
-                for (int rw = 0; rw < G::RW; ++rw) {
-                    const int row0 = r0E + (wr * G::RW + rw) * SR;
-                    const int lim0 = (p.HO - row0) * WO, lim = lim0 < G::PX ? lim0 : G::PX;  // pixels of the super-row inside the image
+                    for (int rw = 0; rw < G::RW; ++rw) {
+                        const int row0 = r0E + (wr * G::RW + rw) * SR;
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const int f = 16 * (wp * G::NBW + nb) + 4 * kq;
-                        nval[rw][nb] = co < p.M ? lim - f : 0;
-                        mk[rw][nb] = f32x4{1.f, 1.f, 1.f, 1.f};
-                        if (p.relu_below != nullptr) {
-                            const float* m = p.relu_below + cbase + (size_t)row0 * WO + f;
-                            if (nval[rw][nb] >= 4) mk[rw][nb] = *(const f32x4u*)m;
-                            else {
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const int f = 16 * (wp * G::NBW + nb) + 4 * kq;
+                            const size_t at = cbase + (size_t)row0 * WO + f;  // (a super-row is PX consecutive floats of y)
+                            f32x4 v, vr;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[e] = acc[ma][rw][nb][e] + bs;
+                                if (p.relu_below != nullptr) v[e] = mk[rw][nb][e] <= 0.f ? 0.f : v[e];
+                                vr[e] = v[e] >= 0.f ? v[e] : 0.f;
+                            }
+                            if (nval[rw][nb] >= 4) {
+                                if (p.y != nullptr) *(f32x4u*)(p.y + at) = v;
+                                if (p.y_relu != nullptr) *(f32x4u*)(p.y_relu + at) = vr;
+                            } else {
 #pragma unroll
                                 for (int e = 0; e < 3; ++e)
-                                    if (e < nval[rw][nb]) mk[rw][nb][e] = m[e];
+                                    if (e < nval[rw][nb]) {
+                                        if (p.y != nullptr) p.y[at + e] = v[e];
+                                        if (p.y_relu != nullptr) p.y_relu[at + e] = vr[e];
+                                    }
                             }
                         }
                     }
                 }
-#pragma unroll
-                for (int rw = 0; rw < G::RW; ++rw) {
-                    const int row0 = r0E + (wr * G::RW + rw) * SR;
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const int f = 16 * (wp * G::NBW + nb) + 4 * kq;
-                        const size_t at = cbase + (size_t)row0 * WO + f;  // (a super-row is PX consecutive floats of y)
-                        f32x4 v, vr;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = acc[ma][rw][nb][e] + bs;
-                            if (p.relu_below != nullptr) v[e] = mk[rw][nb][e] <= 0.f ? 0.f : v[e];
-                            vr[e] = v[e] >= 0.f ? v[e] : 0.f;
-                        }
-                        if (nval[rw][nb] >= 4) {
-                            if (p.y != nullptr) *(f32x4u*)(p.y + at) = v;
-                            if (p.y_relu != nullptr) *(f32x4u*)(p.y_relu + at) = vr;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 3; ++e)
-                                if (e < nval[rw][nb]) {
-                                    if (p.y != nullptr) p.y[at + e] = v[e];
-                                    if (p.y_relu != nullptr) p.y_relu[at + e] = vr[e];
-                                }
-                        }
-                    }
-                }
             }
-            }
-      }
-      zero_acc();
-      b = bu; r0 = r0u;
+        }
+        zero_acc();
+        b = bu; r0 = r0u;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (p.dbg == 9 && threadIdx.x == 0 && (blockIdx.x | blockIdx.y) == 0) {
