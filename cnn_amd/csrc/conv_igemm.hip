@@ -1104,11 +1104,14 @@ struct PrepParams {
     int kstep;  // MFMA k per instruction (2 for 32x32x2, 4 for 16x16x4)
 };
 
-__device__ void igemm_prep_body(const PrepParams& q, long long tid, long long nt) {
+// IDX: the index arithmetic's type -- unsigned where the image has fewer than 2^31 elements (every layer of the three workloads): the
+// chain of divisions by run-time values in 64 bits cost ~700 instructions per element (the 256 -> 512 stride-2 layer of the ResNet-shaped
+// stack: 206 us of the side stream for 2.4 M elements, beside the HBM-bound BatchNorm2D pass of the main stream)
+template <class IDX>
+__device__ void igemm_prep_body_t(const PrepParams& q, IDX tid, IDX nt, IDX total) {
     const int T = q.TR * q.TC;
-    const long long total = (long long)q.nmb * q.nchunk * T * q.CK * q.MT;
-    for (long long idx = tid; idx < total; idx += nt) {
-        long long r = idx;
+    for (IDX idx = tid; idx < total; idx += nt) {
+        IDX r = idx;
         int mm, ck, t, cc, mb;
         if (q.a4) {  // [mb][cc][tap][lh][mm][c2]  with ck = 2*c2 + lh (32x32x2: k index = lane >> 5)
             const int c2 = (int)(r % q.a4); r /= q.a4;
@@ -1140,6 +1143,12 @@ __device__ void igemm_prep_body(const PrepParams& q, long long tid, long long nt
         }
         q.A[idx] = v;
     }
+}
+
+__device__ void igemm_prep_body(const PrepParams& q, long long tid, long long nt) {
+    const long long total = (long long)q.nmb * q.nchunk * (q.TR * q.TC) * q.CK * q.MT;
+    if (total + nt < (1ll << 31)) igemm_prep_body_t<unsigned>(q, (unsigned)tid, (unsigned)nt, (unsigned)total);
+    else igemm_prep_body_t<long long>(q, tid, nt, total);
 }
 
 __global__ void igemm_prep_weights(const PrepParams q) {
