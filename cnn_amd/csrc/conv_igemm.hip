@@ -1688,7 +1688,8 @@ size_t dgrad_rd_prepared_floats(const cnn_conv2d_desc* d);
 int dgrad_rd_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* img, const float* relu_below,
                            float* dx, void* ws, size_t ws_bytes, hipStream_t s);
 size_t rows_workspace_floats(const cnn_conv2d_desc* d, int mode);  // conv_rows.hip (round 5): LDS-staged 3x3 / stride-1 forward and data gradient
-int rows_prepare(const cnn_conv2d_desc* d, int mode, const float* w, float* image, hipStream_t s);                                   // of wide planes
+int rows_prepare(const cnn_conv2d_desc* d, int mode, const float* w, float* image, hipStream_t s);
+int rows_prepare_batch(int n, const cnn_conv2d_desc* const* d, const int* mode, const float* const* w, float* const* image, hipStream_t s);                                   // of wide planes
 int rows_run(const cnn_conv2d_desc* d, int mode, const float* in, const float* image, const float* bias, float* out, float* out_relu,
              const float* relu_below, hipStream_t s);
 bool fwd_rd_supported(const cnn_conv2d_desc* d);  // conv_fwd_rd.hip: register-direct forward of the mid-size 3x3 layers
@@ -2084,15 +2085,23 @@ int cnn_conv2d_prepare_filters(int n, const cnn_conv2d_desc* descs, const float*
     hipStream_t s = as_stream(stream);
     unsigned fdone = 0, ddone = 0;
     if (int rc = direct_prepare_batch(n, descs, w, bias, fwd, dgrad, s, &fdone, &ddone)) return rc;
-    for (int i = 0; i < n; ++i) {  // (round 5) the row kernel's layers: the per-layer entry points look for it before the register-direct kernels too (direct_prepare_batch resets the masks: it goes first)
-        if (check_desc("cnn_conv2d_prepare_filters", &descs[i]) || direct_conv_supported(&descs[i]) || c11_supported(&descs[i])) continue;
-        for (int mode = 0; mode < 2; ++mode) {
-            void* out = mode == MODE_FWD ? (fwd ? fwd[i] : nullptr) : (dgrad ? dgrad[i] : nullptr);
-            if (!out || rows_workspace_floats(&descs[i], mode) == 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0) continue;
-            CNN_REQUIRE(w[i] != nullptr, "cnn_conv2d_prepare_filters: filters of layer %d are null", i);
-            if (int rc = rows_prepare(&descs[i], mode, w[i], (float*)out, s)) return rc;
-            (mode == MODE_FWD ? fdone : ddone) |= 1u << i;
+    {  // (round 5) the row kernel's layers: the per-layer entry points look for it before the register-direct kernels too (direct_prepare_batch resets the masks: it goes first); one launch for all of them
+        const cnn_conv2d_desc* rd[12];
+        int rmode[12], rn = 0;
+        const float* rw[12];
+        float* rimg[12];
+        for (int i = 0; i < n; ++i) {
+            if (check_desc("cnn_conv2d_prepare_filters", &descs[i]) || direct_conv_supported(&descs[i]) || c11_supported(&descs[i])) continue;
+            for (int mode = 0; mode < 2; ++mode) {
+                void* out = mode == MODE_FWD ? (fwd ? fwd[i] : nullptr) : (dgrad ? dgrad[i] : nullptr);
+                if (!out || rows_workspace_floats(&descs[i], mode) == 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0) continue;
+                CNN_REQUIRE(w[i] != nullptr, "cnn_conv2d_prepare_filters: filters of layer %d are null", i);
+                rd[rn] = &descs[i]; rmode[rn] = mode; rw[rn] = w[i]; rimg[rn] = (float*)out; ++rn;
+                (mode == MODE_FWD ? fdone : ddone) |= 1u << i;
+            }
         }
+        if (rn > 0)
+            if (int rc = rows_prepare_batch(rn, rd, rmode, rw, rimg, s)) return rc;
     }
     if (int rc = rd_prepare_batch(n, descs, w, bias, fwd, dgrad, s, &fdone, &ddone)) return rc;
     PrepBatch pb;

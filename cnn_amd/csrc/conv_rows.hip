@@ -510,23 +510,35 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
 }
 
 // filters -> [co tile][chunk][channel 0..CK-1][tap][QW]; mode 0: forward (w[co][c][tap]); mode 1: data gradient (w[c][m][8 - tap])
-__global__ __launch_bounds__(256) void rows_prep(const float* __restrict__ w, float* __restrict__ wt, int Co, int Ci, int mode, int MT, int QW, int nchunk,
-                                                 int ntiles, int CK) {
-    const long long total = (long long)ntiles * nchunk * CK * 9 * QW;
-    const int C = mode == 0 ? Ci : Co, M = mode == 0 ? Co : Ci;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int j = (int)(i % QW);
-        long long r = i / QW;
+struct RowsPrepJob {
+    const float* w;
+    float* wt;
+    int Co, Ci, mode, MT, QW, nchunk, ntiles, CK;
+};
+__device__ inline void rows_prep_body(const RowsPrepJob& q) {
+    // (32-bit index arithmetic: the host checks that the image has fewer than 2^31 elements; in 64 bits the division chain was most of the kernel)
+    const unsigned total = (unsigned)q.ntiles * q.nchunk * q.CK * 9 * q.QW;
+    const int C = q.mode == 0 ? q.Ci : q.Co, M = q.mode == 0 ? q.Co : q.Ci;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int j = (int)(i % (unsigned)q.QW);
+        unsigned r = i / (unsigned)q.QW;
         const int tap = (int)(r % 9); r /= 9;
-        const int cl = (int)(r % CK); r /= CK;
-        const int cc = (int)(r % nchunk);
-        const int tile = (int)(r / nchunk);
-        const int m = tile * MT + j, c = cc * CK + cl;
+        const int cl = (int)(r % q.CK); r /= q.CK;
+        const int cc = (int)(r % q.nchunk);
+        const int tile = (int)(r / q.nchunk);
+        const int m = tile * q.MT + j, c = cc * q.CK + cl;
         float v = 0.f;
-        if (j < MT && m < M && c < C) v = mode == 0 ? w[((size_t)m * Ci + c) * 9 + tap] : w[((size_t)c * Ci + m) * 9 + (8 - tap)];
-        wt[i] = v;
+        if (j < q.MT && m < M && c < C) v = q.mode == 0 ? q.w[((size_t)m * q.Ci + c) * 9 + tap] : q.w[((size_t)c * q.Ci + m) * 9 + (8 - tap)];
+        q.wt[i] = v;
     }
 }
+__global__ __launch_bounds__(256) void rows_prep(const RowsPrepJob q) { rows_prep_body(q); }
+// the images of several layers / modes in ONE launch (cnn_conv2d_prepare_filters: a ResNet-shaped step re-packs 26 images): blockIdx.y = job
+constexpr int kMaxRowsPrepJobs = 12;
+struct RowsPrepBatch {
+    RowsPrepJob job[kMaxRowsPrepJobs];
+};
+__global__ __launch_bounds__(256) void rows_prep_batch(const RowsPrepBatch b) { rows_prep_body(b.job[blockIdx.y]); }
 
 struct RowsPlan {
     RowsParams p;
@@ -550,7 +562,7 @@ bool make_rows_plan(const cnn_conv2d_desc* d, int mode, RowsPlan* pl) {
     if (wi == 28 && M <= 64) return false;  // (28-wide: one super-row of 4 rows per workgroup needs the 4 x 1 wave layout)
     const int ck = wi == 7 ? 16 : kCK;
     pl->ck = ck;
-    if (C < 16 || C % ck != 0 || M < 32) return false;  // (whole 8-channel chunks: no plane of a stage lies behind the sample's channels)
+    if (C < 16 || C % ck != 0 || M < 32 || (long long)C * M * 9 >= (1ll << 28)) return false;  // (the filter image is indexed in 32 bits)  // (whole 8-channel chunks: no plane of a stage lies behind the sample's channels)
     if ((long long)d->B * C * hi * wi >= (1ll << 29) || (long long)d->B * M * ho * (wi + 2 * pad - 2) >= (1ll << 31)) return false;
     RowsParams& p = pl->p;
     p.B = d->B; p.C = C; p.H = hi; p.M = M; p.HO = ho;
@@ -641,8 +653,28 @@ int rows_prepare(const cnn_conv2d_desc* d, int mode, const float* w, float* imag
     RowsPlan pl;
     if (!make_rows_plan(d, mode, &pl)) return fail(CNN_AMD_E_BADARG, "conv_rows: geometry not covered");
     CNN_REQUIRE(w && image && (reinterpret_cast<uintptr_t>(image) & 15) == 0, "conv_rows: filter image must be 16-byte aligned");
-    CNN_KLAUNCH(s, "rows_prep", (rows_prep<<<stream_grid(pl.wt_floats, 256), 256, 0, s>>>(w, image, d->Co, d->Ci, mode, pl.mt, pl.qw, pl.p.nchunk, pl.ntiles, pl.ck)),
+    const RowsPrepJob q{w, image, d->Co, d->Ci, mode, pl.mt, pl.qw, pl.p.nchunk, pl.ntiles, pl.ck};
+    CNN_KLAUNCH(s, "rows_prep", (rows_prep<<<stream_grid(pl.wt_floats, 256), 256, 0, s>>>(q)),
                 "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad);
+    return CNN_AMD_OK;
+}
+// the same for n (layer, mode) pairs in one launch; entries the row kernel does not cover are an error
+int rows_prepare_batch(int n, const cnn_conv2d_desc* const* d, const int* mode, const float* const* w, float* const* image, hipStream_t s) {
+    for (int first = 0; first < n; first += kMaxRowsPrepJobs) {
+        RowsPrepBatch b;
+        const int cnt = n - first < kMaxRowsPrepJobs ? n - first : kMaxRowsPrepJobs;
+        size_t most = 0;
+        for (int i = 0; i < cnt; ++i) {
+            RowsPlan pl;
+            if (!make_rows_plan(d[first + i], mode[first + i], &pl)) return fail(CNN_AMD_E_BADARG, "conv_rows: geometry not covered");
+            CNN_REQUIRE(w[first + i] && image[first + i] && (reinterpret_cast<uintptr_t>(image[first + i]) & 15) == 0, "conv_rows: filter image must be 16-byte aligned");
+            b.job[i] = RowsPrepJob{w[first + i], image[first + i], d[first + i]->Co, d[first + i]->Ci, mode[first + i], pl.mt, pl.qw, pl.p.nchunk, pl.ntiles, pl.ck};
+            most = pl.wt_floats > most ? pl.wt_floats : most;
+        }
+        unsigned gx = (unsigned)((most + 255) / 256);
+        if (gx > 2048) gx = 2048;
+        CNN_KLAUNCH(s, "rows_prep", (rows_prep_batch<<<dim3(gx, cnt), 256, 0, s>>>(b)), "jobs=%d", cnt);
+    }
     return CNN_AMD_OK;
 }
 // forward (mode 0: in = x, out = y and / or y_relu) or data gradient (mode 1: in = dy, out = dx, relu_below nullable) from a prepared image
