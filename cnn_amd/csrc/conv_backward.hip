@@ -36,13 +36,16 @@ int get_side(SideStream** out) {
     *out = &side;
     return CNN_AMD_OK;
 }
-// Layers whose two gradient kernels are each MFMA-bound and fill the chip for a long time (the VGG / ResNet-shaped stacks) gain
-// nothing from running side by side -- they just halve each other's rate and thrash each other's L2 -- so their weight
-// gradient stays on the caller's stream, behind the data gradient: no fork, no join, no event bubbles.
+// Rounds 3-4: layers whose two gradient kernels are each MFMA-bound and fill the chip for a long time (>= 20 GFLOP: the VGG-shaped stack)
+// gained nothing from running side by side -- the implicit GEMM and the register-direct weight gradient halved each other's rate and
+// thrashed each other's L2 -- so their weight gradient stayed on the caller's stream, behind the data gradient.  Round 5: with both
+// gradients LDS-staged (conv_rows / wgrad_sp: one workgroup per CU each, operands from L2 once) the pair fills each other's tails instead:
+// VGG-shaped step 2 579 -> 2 631 images/s with every layer forked (measured at limits 20 / 130 / 250 / 1000 GFLOP: 2 579 / 2 579 / 2 611 /
+// 2 631).  The switch stays (SERIAL_BWD_GFLOP=<limit>; 0 = every layer serial); the default no longer serialises any layer.
 bool heavy_layer(const cnn_conv2d_desc* d) {
     const double Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
     const double flops = 2.0 * d->B * d->Co * Ho * Wo * d->Ci * d->k * d->k;
-    const double limit = CNN_OPT("SERIAL_BWD_GFLOP").as_double(20.0) * 1e9;
+    const double limit = CNN_OPT("SERIAL_BWD_GFLOP").as_double(1e9) * 1e9;
     return flops >= limit;
 }
 // the side stream waits for everything queued on `main` so far.  When the last thing the library launched on `main` is a published
