@@ -40,13 +40,17 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 __device__ __forceinline__ void mfma16(f32x4& c, float a, float b) {
     asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
-// every accumulator of a[0..N) has left the MFMA pipeline (8 passes + write-back < 32 cycles; N a multiple of 7)
+// every accumulator of a[0..N) has left the MFMA pipeline (8 passes + write-back < 32 cycles): the wait sits in the first statement, the
+// others only tie their accumulators behind it (asm volatile statements keep their order)
 template <int N>
 __device__ __forceinline__ void acc_settle(f32x4* a) {
-    static_assert(N % 7 == 0, "groups of seven");
+    static_assert(N >= 7, "at least one group of seven");
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(a[4]), "+a"(a[5]), "+a"(a[6]));
 #pragma unroll
-    for (int i = 0; i < N; i += 7)
-        asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a[i]), "+a"(a[i + 1]), "+a"(a[i + 2]), "+a"(a[i + 3]), "+a"(a[i + 4]), "+a"(a[i + 5]), "+a"(a[i + 6]));
+    for (int i = 7; i + 7 <= N; i += 7)
+        asm volatile("" : "+a"(a[i]), "+a"(a[i + 1]), "+a"(a[i + 2]), "+a"(a[i + 3]), "+a"(a[i + 4]), "+a"(a[i + 5]), "+a"(a[i + 6]));
+#pragma unroll
+    for (int i = N - N % 7; i < N; ++i) asm volatile("" : "+a"(a[i]));
 }
 
 struct RowsParams {
