@@ -10,12 +10,13 @@ namespace cnn_amd {
 size_t igemm_workspace_floats(const cnn_conv2d_desc* d);  // conv_igemm.hip
 void wgrad_defer_reduce(bool on);                          // conv_wgrad.hip: with defer_join the final slab reductions of the
 int wgrad_flush_reduces(hipStream_t s);                    // weight gradients run in one launch just before the join
+bool thin_dgrad_supported(const cnn_conv2d_desc* d);       // conv_dgrad_thin.hip
 }
 
 namespace {
 struct SideStream {
     hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, lead = nullptr;
     int device = -1;
 };
 int get_side(SideStream** out) {
@@ -31,6 +32,7 @@ int get_side(SideStream** out) {
         side.stream = as_stream(made);
         CNN_HIP_CHECK(hipEventCreateWithFlags(&side.fork, hipEventDisableTiming));
         CNN_HIP_CHECK(hipEventCreateWithFlags(&side.join, hipEventDisableTiming));
+        CNN_HIP_CHECK(hipEventCreateWithFlags(&side.lead, hipEventDisableTiming));
         side.device = dev;
     }
     *out = &side;
@@ -143,10 +145,19 @@ int cnn_conv2d_backward_prepared_relu(const cnn_conv2d_desc* d, const float* x, 
         return cnn_conv2d_backward_weight(d, x, dy, gw, gb, divisor, ws, ws_bytes, main);
     }
     if (int rc = fork_side(side, main)) return rc;
+    // A THIN layer's data gradient (Ci = 3: a VALU kernel of thousands of small waves) takes every wave slot of the chip if it is
+    // dispatched first, and the MFMA weight gradient beside it then trickles in as those waves retire (the 7x7 stem of the ResNet-shaped
+    // stack: 490 us for a 200 us kernel).  The data gradient therefore waits for the side stream to have reached the weight gradient's
+    // launch: its workgroups take their CUs first, the VALU waves fill what is left (ResNet-shaped step 7 830 -> 7 910 images/s; the 3x3
+    // stride-1 first layer of the VGG-shaped stack, whose weight gradient is register-direct, lost 0.3 % and keeps the old order).
+    // THIN_DGRAD_LEAD=0: both at once as before.
+    const bool lead = thin_dgrad_supported(d) && d->s == 2 && CNN_OPT_INT("THIN_DGRAD_LEAD", 1) != 0;
+    if (lead) CNN_HIP_CHECK(hipEventRecord(side->lead, side->stream));
     wgrad_defer_reduce(defer_join != 0);
     const int rcw = cnn_conv2d_backward_weight(d, x, dy, gw, gb, divisor, ws, ws_bytes, side->stream);
     wgrad_defer_reduce(false);
     if (rcw) return rcw;
+    if (lead) CNN_HIP_CHECK(hipStreamWaitEvent(main, side->lead, 0));
     if (int rc = relu_below ? cnn_conv2d_backward_data_relu_prepared(d, dy, prepared_dgrad, relu_below, dx, main)
                             : cnn_conv2d_backward_data_prepared(d, dy, prepared_dgrad, dx, main))
         return rc;
