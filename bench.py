@@ -724,7 +724,12 @@ def main():
         assert comm_info["ranks"] == args.gpus == world
         comm_info["param_digests_equal_on_all_ranks"] = True
         comm_info["param_digest"] = f"{digest:014x}"
-    if comm_info is not None:
+    if comm_info is not None and not capi.load().cnn_amd_measure_build():
+        # (the step without its all-reduce calls computes wrong results: that switch exists only in the measurement build of the library,
+        # `make -C cnn_amd/csrc measure` + CNN_AMD_LIB=cnn_amd/lib/libcnn_amd_measure.so; the product library refuses it)
+        comm_info["exchange_cost_us_per_step"] = None
+        comm_info["exchange_cost_note"] = "needs the measurement build of the library (DP_SKIP_EXCHANGE is not in libcnn_amd.so); exchange_exposed_us is measured by the product library"
+    elif comm_info is not None:
         # what the exchange COSTS the step: K more steps with and K without the all-reduce calls (DP_SKIP_EXCHANGE on every rank; everything
         # else -- buckets, events, the 1/N scale -- unchanged), back to back, max over ranks.  Behind the digest check: the replicas diverge here.
         pair = []

@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcnn_amd.so")
+# CNN_AMD_LIB: another build of the same ABI -- tools/ load the measurement build (make -C cnn_amd/csrc measure: libcnn_amd_measure.so,
+# the only build in which the result-changing timing switches exist); the product path is the in-tree libcnn_amd.so
+LIB_PATH = os.environ.get("CNN_AMD_LIB") or os.path.join(_HERE, "lib", "libcnn_amd.so")
 
 
 class CnnAmdError(RuntimeError):
@@ -35,6 +37,7 @@ SIGNATURES = {
     "cnn_amd_device_arch": (C.c_char_p, []),
     "cnn_amd_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
     "cnn_amd_get_option": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
+    "cnn_amd_measure_build": (C.c_int, []),
     "cnn_amd_kernel_timing_enable": (C.c_int, [C.c_int, C.c_char_p]),
     "cnn_amd_kernel_timing_sampling": (C.c_int, [C.c_int]),
     "cnn_amd_kernel_timing_report": (C.c_longlong, [C.c_char_p, C.c_size_t]),
@@ -136,9 +139,6 @@ SIGNATURES = {
     "cnn_linear_forward_softmax_xent": (C.c_int, [_P] * 8 + [C.c_int] * 3 + [_P]),
     "cnn_loss_from_terms": (C.c_int, [_P, _P, C.c_int, _P]),
     "cnn_conv2d_backward_weight_side": (C.c_int, [_D, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P]),
-    "cnn_conv_chain_supported": (C.c_int, [C.c_int, _D, C.c_int, C.c_int]),
-    "cnn_conv_chain_forward_loss_prepared": (C.c_int, [C.c_int, _D, _P, _P, _P, _P] + [_P] * 8 + [C.c_int, C.c_int, _P]),
-    "cnn_conv_chain_backward_data_prepared": (C.c_int, [C.c_int, _D, _P, _P, _P, _P, _P]),
     "cnn_device_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "cnn_device_free": (C.c_int, [_P]),
     "cnn_memcpy_h2d": (C.c_int, [_P, _P, C.c_size_t, _P]),
@@ -626,55 +626,6 @@ def prepare_filters(convs, weights, biases, fwd_bufs, dgrad_bufs):
     arr = lambda ts: (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in ts])
     check(load().cnn_conv2d_prepare_filters(n, descs, arr(weights), arr(biases), arr(fwd_bufs) if fwd_bufs else None,
                                             arr(dgrad_bufs) if dgrad_bufs else None, _stream()), "cnn_conv2d_prepare_filters")
-
-
-def _chain_descs(convs):
-    return (ConvDesc * len(convs))(*[c.desc for c in convs])
-
-
-def _ptr_array(ts):
-    return (C.c_void_p * len(ts))(*[(t.data_ptr() if t is not None else None) for t in ts])
-
-
-def conv_chain_supported(convs, lin_in=0, lin_out=0):
-    """n = 1..3 consecutive Conv2D(3x3, s2) + ReLU layers, channels (128 >> n) -> .. -> 128, as one sample-resident kernel"""
-    return bool(load().cnn_conv_chain_supported(len(convs), _chain_descs(convs), int(lin_in), int(lin_out)))
-
-
-def conv_chain_forward_loss(convs, x, prepared_fwd, biases, y_relu, lin_w, lin_b, labels, logits, probs, delta, loss_terms, dx_head):
-    """[Conv2D + ReLU] x n -> LinearLayer -> softmax / cross-entropy -> delta -> d(linear input) masked by the last ReLU"""
-    _need_gpu(x, lin_w, lin_b, labels, logits, delta, loss_terms, dx_head, *prepared_fwd, *biases, *y_relu)
-    lin_in, lin_out = lin_w.shape
-    check(load().cnn_conv_chain_forward_loss_prepared(len(convs), _chain_descs(convs), _ptr(x), _ptr_array(prepared_fwd), _ptr_array(biases),
-                                                      _ptr_array(y_relu), _ptr(lin_w), _ptr(lin_b), _ptr(labels), _ptr(logits), _ptr(probs),
-                                                      _ptr(delta), _ptr(loss_terms), _ptr(dx_head), int(lin_in), int(lin_out), _stream()),
-          "cnn_conv_chain_forward_loss_prepared")
-
-
-def conv_chain_backward_data(convs, dy_last, prepared_dgrad, relu_below, dx):
-    """data gradients of the n convolutions, last to first; relu_below[l] (or None) = the ReLU output that is layer l's input"""
-    _need_gpu(dy_last, *prepared_dgrad, *[t for t in relu_below if t is not None], *dx)
-    check(load().cnn_conv_chain_backward_data_prepared(len(convs), _chain_descs(convs), _ptr(dy_last), _ptr_array(prepared_dgrad),
-                                                       _ptr_array(relu_below), _ptr_array(dx), _stream()),
-          "cnn_conv_chain_backward_data_prepared")
-
-
-def sgd_update(params, grads, lr, grad_scale=1.0):
-    _need_gpu(params, grads)
-    check(load().cnn_sgd_update(_ptr(params), _ptr(grads), params.numel(), float(lr), float(grad_scale), _stream()), "cnn_sgd_update")
-    return params
-
-
-def softmax_xent(logits, labels, want_probs=True):
-    import torch
-
-    _need_gpu(logits, labels)
-    B, n = logits.shape
-    probs = torch.empty_like(logits) if want_probs else None
-    delta = torch.empty_like(logits)
-    loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
-    check(load().cnn_softmax_xent(_ptr(logits), _ptr(labels), _ptr(probs), _ptr(delta), _ptr(loss), B, n, _stream()), "cnn_softmax_xent")
-    return probs, delta, loss
 
 
 def set_option(name, value):

@@ -23,6 +23,19 @@ int fail(int code, const char* fmt, ...) {
 }
 
 // ---- measurement switches (common.h) ---------------------------------------------------------------------------------------
+// Names that exist only in the measurement build (common.h, CNN_MEASURE_INT): ablations that change results, cycle printers, overrides.
+static const char* const kMeasureOnly[] = {"DBG",    "ROWS_DBG",   "ROWS_LDS",     "WIN_DBG", "OS_DBG",    "STEM_DBG",
+                                           "FWD_RD_DBG", "DGRAD_RD_DBG", "RD_DBG",  "SP_DBG",    "S2_DBG", "DP_SKIP_EXCHANGE"};
+bool measure_only_option(const char* name) {
+    for (const char* m : kMeasureOnly)
+        if (strcmp(name, m) == 0) return true;
+    return false;
+}
+#ifdef CNN_AMD_MEASURE
+static constexpr bool kMeasureBuild = true;
+#else
+static constexpr bool kMeasureBuild = false;
+#endif
 namespace {
 struct OptionTable {
     std::mutex mu;
@@ -37,6 +50,7 @@ struct OptionTable {
             const char* eq = strchr(*e, '=');
             if (!eq) continue;
             const std::string key(*e + 8, (size_t)(eq - (*e + 8)));
+            if (!kMeasureBuild && measure_only_option(key.c_str())) continue;  // (the product library cannot be armed through the environment)
             if (!values.count(key)) values[key] = eq + 1;  // (cnn_amd_set_option before the first query wins)
         }
     }
@@ -154,9 +168,16 @@ struct KTimer {
     long long seen = 0;
     std::string filter;
     std::vector<KRecord> recs;
-    bool open = false;
+    unsigned long long epoch = 1;  // moves when recs is cleared
     std::mutex mu;
 };
+// the record a begin() of THIS host thread opened and its end() closes: per thread (ADVICE r5 -- one host thread per rank in one
+// process interleaves begin / end pairs; a process-wide "last record" would put e1 on another rank's stream), valid for one epoch
+struct KOpen {
+    unsigned long long epoch = 0;
+    long long idx = -1;
+};
+thread_local KOpen k_open;
 KTimer& kt() {
     static KTimer t;
     return t;
@@ -174,7 +195,7 @@ void ktimer_begin(hipStream_t s, const char* kernel, const char* fmt, ...) {
     va_end(ap);
     std::string key = std::string(kernel) + "|" + tag;
     std::lock_guard<std::mutex> lk(t.mu);
-    t.open = false;
+    k_open.idx = -1;
     if (t.mode == 2 && key.find(t.filter) == std::string::npos) return;
     if (t.mode == 2 && (t.seen++ % t.every) != 0) return;
     KRecord r;
@@ -182,15 +203,16 @@ void ktimer_begin(hipStream_t s, const char* kernel, const char* fmt, ...) {
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
     (void)hipEventRecord(r.e0, s);
     t.recs.push_back(r);
-    t.open = true;
+    k_open.epoch = t.epoch;
+    k_open.idx = (long long)t.recs.size() - 1;
 }
 
 void ktimer_end(hipStream_t s) {
     KTimer& t = kt();
     std::lock_guard<std::mutex> lk(t.mu);
-    if (!t.open) return;
-    (void)hipEventRecord(t.recs.back().e1, s);
-    t.open = false;
+    if (k_open.idx < 0 || k_open.epoch != t.epoch || k_open.idx >= (long long)t.recs.size()) return;
+    (void)hipEventRecord(t.recs[(size_t)k_open.idx].e1, s);
+    k_open.idx = -1;
 }
 
 }  // namespace cnn_amd
@@ -284,6 +306,7 @@ long long cnn_amd_kernel_timing_report(char* buf, size_t cap) {
         (void)hipEventDestroy(r.e1);
     }
     t.recs.clear();
+    ++t.epoch;
     return (long long)out.size() + 1;
 }
 
@@ -540,6 +563,9 @@ int cnn_batch_stager_release(void* stager, int slot, void* stream) {
 int cnn_amd_set_option(const char* name, const char* value) {
     CNN_REQUIRE(name != nullptr && name[0] != 0, "cnn_amd_set_option: empty name");
     if (strncmp(name, "CNN_AMD_", 8) == 0) name += 8;
+    if (!kMeasureBuild && value != nullptr && measure_only_option(name))
+        return fail(CNN_AMD_E_BADARG, "cnn_amd_set_option: %s is a measurement-only switch (it changes results or prints timings); it exists in "
+                                      "libcnn_amd_measure.so (make -C cnn_amd/csrc measure), not in the product library", name);
     OptionTable& t = option_table();
     std::lock_guard<std::mutex> lk(t.mu);
     t.load_env_locked();
@@ -548,6 +574,8 @@ int cnn_amd_set_option(const char* name, const char* value) {
     t.generation.fetch_add(1, std::memory_order_acq_rel);
     return CNN_AMD_OK;
 }
+
+int cnn_amd_measure_build(void) { return kMeasureBuild ? 1 : 0; }
 
 int cnn_amd_get_option(const char* name, char* value_out, size_t cap) {
     CNN_REQUIRE(name != nullptr, "cnn_amd_get_option: null name");

@@ -144,12 +144,16 @@ __global__ __launch_bounds__(kBlock) void bn_stats(const float* __restrict__ x, 
 // The textbook one-pass formula E[x^2] - E[x]^2 cancels catastrophically when |mean| >> sigma; shifted by a sample of the channel
 // |S1/L| is O(sigma) whatever the channel's offset, and the subtraction costs a few ulps (measured against the oracle: <= 2e-6
 // tensor-normalised on y, tests/test_gpu_batchnorm.py, the offset cases included).  CNN_AMD_BN_TWO_PASS=1 keeps the two-pass kernels.
-__global__ __launch_bounds__(kBlock) void bn_stats_pilot(const float* __restrict__ x, float* __restrict__ part_out, Geo q) {
+// The pilot value is PUBLISHED (pilot_out[c], written by the channel's first workgroup): bn_apply takes it from there, not from x -- the
+// API allows y == x / y_relu == x, and an apply pass that re-read x[c*HW] could find it already overwritten by the workgroup that owns
+// that element.
+__global__ __launch_bounds__(kBlock) void bn_stats_pilot(const float* __restrict__ x, float* __restrict__ part_out, float* __restrict__ pilot_out, Geo q) {
     const int c = blockIdx.y, g = blockIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int wpart = lane >> q.part_shift, stride = 1 << q.part_shift, sub = lane & (stride - 1);
     const float p = x[(size_t)c * q.HW];
+    if (g == 0 && threadIdx.x == 0) pilot_out[c] = p;
     float acc[2] = {0.f, 0.f};
     for (long long un = ((long long)g * kWaves + wave) * q.P + wpart; un < q.units; un += (long long)q.G * kWaves * q.P) {
         long long g0, g1;
@@ -188,6 +192,7 @@ struct BnApply {
     const float* gsum_sq;
     float count;
     const float* part2;  // training, one-pass statistics: partial sums (S1, S2) around the channel's pilot value (bn_stats_pilot)
+    const float* pilot;  // ... and the pilot values themselves [C]
 };
 
 // y = gamma * ((x - u) * var_inv) + beta  (batchnorm2d.cpp:69-77 / 84-92), moving statistics (:79-80)
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void bn_apply(BnApply a, Geo q) {
             const float L = (float)((long long)q.B * q.HW);
             const float d = sum_partials(a.part2 + (size_t)c * q.G * 2, q.G, 2, lane) / L;
             const float m2 = sum_partials(a.part2 + (size_t)c * q.G * 2 + 1, q.G, 2, lane) / L;
-            u = a.x[(size_t)c * q.HW] + d;
+            u = a.pilot[c] + d;
             var = m2 - d * d;
             var = var > 0.f ? var : 0.f;
             if (g == 0 && threadIdx.x == 0) a.saved_mean[c] = u;
@@ -533,7 +538,7 @@ static int bn_forward_impl(const float* x, float* y, float* y_relu, const float*
     hipStream_t s = as_stream(stream);
     const dim3 grid(q.G, C);
     BnApply a{x, y, y_relu, gamma, beta, moving_mean, moving_var, saved_mean, saved_var, nullptr, eps, momentum, training ? 1 : 0,
-              nullptr, nullptr, 0.f};
+              nullptr, nullptr, 0.f, nullptr, nullptr};
     if (training) {
         CNN_REQUIRE(saved_mean && saved_var, "cnn_batchnorm2d_forward: training needs saved_mean / saved_var");
         CNN_REQUIRE(workspace && workspace_bytes >= cnn_batchnorm2d_workspace_bytes(B, C, H, W),
@@ -566,8 +571,9 @@ static int bn_forward_impl(const float* x, float* y, float* y_relu, const float*
             CNN_KLAUNCH(s, "bn_stats<1>", (bn_stats<1><<<grid, kBlock, 0, s>>>(x, p0, p1, saved_mean, q, 0.f)), BN_TAG);
             a.part = p1;
         } else {
-            CNN_KLAUNCH(s, "bn_stats_pilot", (bn_stats_pilot<<<grid, kBlock, 0, s>>>(x, p0, q)), BN_TAG);
+            CNN_KLAUNCH(s, "bn_stats_pilot", (bn_stats_pilot<<<grid, kBlock, 0, s>>>(x, p0, p1, q)), BN_TAG);
             a.part2 = p0;
+            a.pilot = p1;  // (the second arena is free in this path: C <= C * G * 4)
         }
     }
     if (y_relu)

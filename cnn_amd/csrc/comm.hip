@@ -192,7 +192,7 @@ int cnn_allreduce_grads(void* comm, float* grads, size_t n, void* stream) {
     if (n == 0) return CNN_AMD_OK;
     // (measurement switch DP_SKIP_EXCHANGE=1, set on EVERY rank: the step without its all-reduces -- bench.py times K such steps behind its
     // timed regions and reports the difference as the step's exchange cost; the replicas diverge, nothing is compared afterwards)
-    if (CNN_OPT_INT("DP_SKIP_EXCHANGE", 0) != 0) return CNN_AMD_OK;
+    if (CNN_MEASURE_INT("DP_SKIP_EXCHANGE", 0) != 0) return CNN_AMD_OK;
     CNN_RCCL_BIND(R);
     CNN_RCCL_CHECK(R, R->AllReduce(grads, grads, n, ncclFloat32, ncclSum, static_cast<ncclComm_t>(comm), as_stream(stream)));
     publish_mark_stale(as_stream(stream));

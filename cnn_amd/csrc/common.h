@@ -99,6 +99,18 @@ inline int atoi(const OptVal& o) { return o.v; }
 inline OptVal opt_val(Option& o) { return OptVal{o.is_set(), o.as_int(0)}; }
 #define CNN_OPT_VAL(name) (::cnn_amd::opt_val(CNN_OPT(name)))
 
+// MEASUREMENT-ONLY switches: ablations that leave out a kernel's stores / DMAs / MFMAs, per-phase cycle printers, an
+// LDS request override, a data-parallel step without its exchange -- anything that changes RESULTS or exists for a timing experiment.
+// They exist only in the measurement build (make -C cnn_amd/csrc measure -> libcnn_amd_measure.so, -DCNN_AMD_MEASURE, used by tools/);
+// in the product library every such query is the compile-time constant `dflt`, cnn_amd_set_option() rejects the names and the
+// CNN_AMD_* environment is not consulted for them (abi.hip: kMeasureOnly; tests/test_abi_exports.py).
+#ifdef CNN_AMD_MEASURE
+#define CNN_MEASURE_INT(name, dflt) CNN_OPT_INT(name, dflt)
+#else
+#define CNN_MEASURE_INT(name, dflt) (dflt)
+#endif
+bool measure_only_option(const char* name);  // (abi.hip) is `name` one of them
+
 // compute units of the current device (hipDeviceProp_t::multiProcessorCount, cached per device; 256 on MI355X)
 int num_cus();
 

@@ -169,7 +169,7 @@ int cnn_conv2d_backward_prepared_relu(const cnn_conv2d_desc* d, const float* x, 
 }
 
 /* the weight / bias gradient half of cnn_conv2d_backward*(defer_join = 1) alone: forked off `stream` onto the side stream, final slab
- * reduction recorded for the join -- for callers that run the data gradients of several layers as ONE kernel (conv_chain.hip) */
+ * reduction recorded for the join -- for callers that obtain the data gradients of several layers another way */
 int cnn_conv2d_backward_weight_side(const cnn_conv2d_desc* d, const float* x, const float* dy, float* gw, float* gb, float divisor, void* ws,
                                     size_t ws_bytes, void* stream) {
     CNN_REQUIRE(d && x && dy && gw && ws, "cnn_conv2d_backward_weight_side: null pointer");

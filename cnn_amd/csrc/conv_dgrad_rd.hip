@@ -722,7 +722,7 @@ bool make_plan(const cnn_conv2d_desc* d, DgRdPlan* pl) {
     p.tiles = (int)((pixels + 31) / 32);
     p.m_uv = magic_of(p.UV);
     p.m_v = magic_of(p.V);
-    p.dbg = CNN_OPT_INT("DGRAD_RD_DBG", 0);
+    p.dbg = CNN_MEASURE_INT("DGRAD_RD_DBG", 0);
     pl->co = d->Co;
     pl->mt = (d->s == 1 && d->Ci % 64 == 0) ? 2 : 1;  // stride 1: two 32-channel tiles per wave share the dy windows
     if (const OptVal e = CNN_OPT_VAL("DGRAD_RD_MT")) pl->mt = (atoi(e) == 2 && d->s == 1 && d->Ci % 64 == 0) ? 2 : 1;

@@ -1316,7 +1316,7 @@ int direct_conv_pool_forward(const cnn_conv2d_desc* d, const float* x, const flo
         CNN_KLAUNCH(s, "pack_fwd_weights", (pack_fwd_weights_3_16_3_2<<<1, 256, 0, s>>>(w, bias, (float*)ws)), CONV_TAG(d));
     const int ipi = (2 * PHo * PWo + 63) / 64;
     const long long witems = (long long)d->B * ipi;
-    const int dbg = CNN_OPT_INT("DBG", 0);
+    const int dbg = CNN_MEASURE_INT("DBG", 0);
     const bool pk8 = (d->flags & CNN_CONV2D_POOL_MASK_PACKED) != 0;
     CNN_REQUIRE(!pk8 || direct_pool_mask_packed_ok(d), "cnn_conv2d_relu_maxpool2_forward: packed pool mask not available (cnn_conv2d_pool_mask_packed_supported)");
     const int pitch8 = pool_mask_pitch(PWo);
@@ -1348,7 +1348,7 @@ int direct_conv_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w,
         const long long witems = (long long)d->B * ipi;
         // CNN_AMD_DBG = 4 / 8 / 12 (tuning only): compile-time ablations without the FMAs / the stores / both, the source
         // of the breakdown in profiles/NOTEBOOK.md section 6
-        const int dbg = CNN_OPT_INT("DBG", 0);
+        const int dbg = CNN_MEASURE_INT("DBG", 0);
 #define PK_LAUNCH(DBG_)                                                                                              \
     CNN_KLAUNCH(s, "conv_dgrad_pk<3,16,3,2>",                                                                       \
                 (conv_dgrad_pk_3_16_3_2<4, DBG_><<<wave_grid(witems), kBlock, 0, s>>>(dy, (const v2f*)ws, dx, d->B, d->H, d->W, Ho, \

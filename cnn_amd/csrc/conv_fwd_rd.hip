@@ -359,7 +359,7 @@ bool make_plan(const cnn_conv2d_desc* d, FwdRdPlan* pl) {
     p.tiles = (int)((pixels + 31) / 32);
     p.m_howo = magic_of(p.HoWo);
     p.m_wo = magic_of(p.Wo);
-    p.dbg = CNN_OPT_INT("FWD_RD_DBG", 0);
+    p.dbg = CNN_MEASURE_INT("FWD_RD_DBG", 0);
     pl->s = d->s;
     pl->ci = d->Ci;
     const int mtiles = (d->Co + 31) / 32;

@@ -1460,7 +1460,7 @@ int make_plan(const char* who, const cnn_conv2d_desc* d, int mode, Plan* pl, boo
                 pl->lds_bytes, d->k, d->W);
     p.rw_shift = 0;
     while ((1 << p.rw_shift) < p.XW && p.rw_shift < 6) ++p.rw_shift;
-    p.dbg = CNN_OPT_INT("DBG", 0);
+    p.dbg = CNN_MEASURE_INT("DBG", 0);
     p.ntiles = (int)((p.N + pl->NPIX - 1) / pl->NPIX);
     pl->grid_x = (unsigned)p.ntiles;
     pl->grid_y = (unsigned)((p.M + pl->MT - 1) / pl->MT);

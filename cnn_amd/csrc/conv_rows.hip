@@ -126,6 +126,10 @@ struct RowsGeom {
         return m;
     }
     static constexpr int LEAD = (4 - (PAD * WI) % 4) % 4;  // row 0 of the image on a 16-byte unit boundary of the first row block
+    // (the buffer descriptor starts PAD*WI + 4 floats in front of the tensor and every lane offset is a multiple of 16 bytes from it: image
+    //  row 0 must then sit on a 16-byte unit of the staged plane.  Out-of-descriptor lanes moving ZEROS is gfx950 behaviour
+    //  (tools/probes/buflds_probe.cpp); the library is built for gfx950 only and cnn_amd_device_arch() is checked by every caller.)
+    static_assert((PAD * WI + LEAD) % 4 == 0, "row 0 of the image on a 16-byte unit of the staged plane");
     static constexpr int XSPAN = PK > 1 ? 2 * GUARD + PK * SP : LEAD + XR * WI;
     static constexpr int QXP = stride16(XSPAN + 4);       // x plane stride (floats)
     static constexpr int QW = MT + 16;                    // filter row stride: 9 * QW = 16 (mod 32)
@@ -601,7 +605,7 @@ bool make_rows_plan(const cnn_conv2d_desc* d, int mode, RowsPlan* pl) {
     p.units_per_block = (int)((p.units_total + want - 1) / want);
     pl->blocks = (p.units_total + p.units_per_block - 1) / p.units_per_block;
     pl->wt_floats = (size_t)pl->ntiles * p.nchunk * ck * 9 * pl->qw;
-    p.dbg = CNN_OPT_INT("ROWS_DBG", 0);
+    p.dbg = CNN_MEASURE_INT("ROWS_DBG", 0);
     return true;
 }
 
@@ -617,7 +621,7 @@ int launch_rows2(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, 
     }
     // (measurement switch ROWS_LDS=<bytes>: a larger LDS request, e.g. 90000 = never two workgroups on one CU)
     size_t lds = G::lds_bytes;
-    if (const int want = CNN_OPT_INT("ROWS_LDS", 0); want > (int)lds && want <= 160 * 1024) lds = (size_t)want;
+    if (const int want = CNN_MEASURE_INT("ROWS_LDS", 0); want > (int)lds && want <= 160 * 1024) lds = (size_t)want;
     char name[48];
     snprintf(name, sizeof(name), "conv_rows<%d,%d,%d>/%s", WI, PAD, MT, tag);
     CNN_KLAUNCH(s, name, (kern<<<dim3(pl.blocks, pl.ntiles), 256, lds, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W, d->Co,

@@ -291,7 +291,7 @@ int stem_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const
     const long long items = (long long)p.B * p.row_groups * p.col_blocks;
     CNN_REQUIRE(items < (1ll << 31) && (long long)p.B * p.Co * p.Ho * p.Wo < (1ll << 31), "stem_forward: tensor too large for 32-bit offsets");
     p.items = (int)items;
-    p.dbg = CNN_OPT_INT("STEM_DBG", 0);
+    p.dbg = CNN_MEASURE_INT("STEM_DBG", 0);
     const size_t lds_bytes = ((size_t)(SKK + 1) * SAP + (size_t)SCI * SRIN * SLW) * sizeof(float);
     static DeviceOnce attr_once[2];
     const int which = y_relu ? 1 : 0;

@@ -722,7 +722,7 @@ int make_wplan(const char* who, const cnn_conv2d_desc* d, WPlan* pl) {
     while ((1 << p.rwd_shift) < p.QCP && p.rwd_shift < 6) ++p.rwd_shift;
     p.rwx_shift = 0;
     while ((1 << p.rwx_shift) < p.LWc && p.rwx_shift < 6) ++p.rwx_shift;
-    p.dbg = CNN_OPT_INT("DBG", 0);
+    p.dbg = CNN_MEASURE_INT("DBG", 0);
     p.chunks_total = (long long)p.B * p.nrc * p.ncc;
     pl->gy = (unsigned)((p.Ntot + pl->NTB - 1) / pl->NTB);
     pl->gz = (unsigned)((p.Co + pl->MTB - 1) / pl->MTB);

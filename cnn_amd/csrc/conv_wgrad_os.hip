@@ -195,7 +195,7 @@ int launch_os(const cnn_conv2d_desc* d, const float* x, const float* dy, float* 
     OsParams p;
     p.x = x; p.dy = dy; p.slabs = slabs; p.B = d->B;
     p.units = d->B * G::UPI;
-    p.dbg = CNN_OPT_INT("OS_DBG", 0);
+    p.dbg = CNN_MEASURE_INT("OS_DBG", 0);
     static DeviceOnce attr_once;
     if (attr_once.needed()) {
         CNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_os_kernel<CI, CO, H, W, R>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -552,7 +552,7 @@ bool make_rd_plan(const cnn_conv2d_desc* d, RdPlan* pl, bool pooled = false) {
             --r_unsafe;
         }
     }
-    p.dbg = CNN_OPT_INT("RD_DBG", 0);
+    p.dbg = CNN_MEASURE_INT("RD_DBG", 0);
     p.chunks_fast = CNN_OPT_SET("RD_SLOW") ? 0 : (int)(r_unsafe / 2);  // (CNN_AMD_RD_SLOW: tests force the guarded path)
     // padded layers: the first run of output rows 0 and 1 of image 0 reads input row 0 from column -1 (or -2): x[-1] lies in
     // front of the allocation, so the chunks up to run `rpr` (first run of row 1) take the guarded path

@@ -407,7 +407,7 @@ bool make_sp_plan(const cnn_conv2d_desc* d, SpPlan* pl) {
     if (want > p.stages_total) want = p.stages_total;
     p.stages_per_block = (int)((p.stages_total + want - 1) / want);
     pl->kblocks = (p.stages_total + p.stages_per_block - 1) / p.stages_per_block;
-    p.dbg = CNN_OPT_INT("SP_DBG", 0);
+    p.dbg = CNN_MEASURE_INT("SP_DBG", 0);
     return true;
 }
 

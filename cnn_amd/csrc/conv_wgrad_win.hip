@@ -33,7 +33,9 @@ using namespace cnn_amd;
 #define CNN_WIN_EXPERIMENT 0
 #endif
 namespace {
+#if CNN_WIN_EXPERIMENT == 6  // (an A/B build of this file only: per-phase cycle counters; never in a shipped library)
 __device__ unsigned long long g_prof[256 * 8][8];
+#endif
 constexpr int kExp = CNN_WIN_EXPERIMENT;  // timing experiments only (3: no LDS operand reads, 4: no MFMAs); 0 in the product
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -586,10 +588,10 @@ __global__ __launch_bounds__((kWaves + (SPEC ? kProd : 0)) * 64) void conv_wgrad
             cur = nxt;
             tick(4);
         }
-        if constexpr (kExp == 6) {
-            if (lane == 0 && blockIdx.x < 256)
-                for (int i = 0; i < 5; ++i) g_prof[blockIdx.x * 8 + wave][i] = tp[i];
-        }
+#if CNN_WIN_EXPERIMENT == 6
+        if (lane == 0 && blockIdx.x < 256)
+            for (int i = 0; i < 5; ++i) g_prof[blockIdx.x * 8 + wave][i] = tp[i];
+#endif
     }
 
     // ---- the eight waves in a fixed order -> one slab per workgroup
@@ -642,7 +644,7 @@ bool make_win_params(const cnn_conv2d_desc* d, WinParams* p, int* grid) {
     if (g > num_cus()) g = num_cus();
     *grid = (int)g;
     p->strips_per_wave = (int)((strips + g * kWaves - 1) / (g * kWaves));
-    p->dbg = CNN_OPT_INT("WIN_DBG", 0);
+    p->dbg = CNN_MEASURE_INT("WIN_DBG", 0);
     {
         // default on: the eight waves of a workgroup walk eight neighbouring column-segment runs; in step they share the delta rows'
         // 128-byte lines in L2 (PMC: 1.37x -> 1.02x of the algorithmic fetch).  Needs the same trip count in every wave.
@@ -666,7 +668,8 @@ int launch_win3(const cnn_conv2d_desc* d, WinParams& p, int grid, hipStream_t s,
     }
     constexpr int threads = (kWaves + (SPEC ? kProd : 0)) * 64;
     CNN_KLAUNCH(s, name, (conv_wgrad_win_kernel<POOLED, DMA16, SPEC><<<grid, threads, lds_bytes, s>>>(p)), CONV_TAG(d));
-    if constexpr (kExp == 6 && !SPEC) {  // per-phase cycle counters of the strip loop (timing experiments only)
+#if CNN_WIN_EXPERIMENT == 6
+    if constexpr (!SPEC) {  // per-phase cycle counters of the strip loop (timing experiments only)
         static unsigned long long h[256 * 8][8];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h));
@@ -681,6 +684,7 @@ int launch_win3(const cnn_conv2d_desc* d, WinParams& p, int grid, hipStream_t s,
             fprintf(stderr, "  (cycles per strip)\n");
         }
     }
+#endif
     return CNN_AMD_OK;
 }
 

@@ -206,22 +206,6 @@ public:
     bool delta_computed() const { return delta_valid; }   // false: the last train_step skipped it (architectures::input_gradient = false)
     void set_delta_computed(bool on) { delta_valid = on; }
     size_t delta_floats() const { return delta_buf.sample_len * delta_buf.views.size(); }
-    // ---- additions for the sample-resident chains (round 4, cnn_conv_chain_*): the container runs several layers as ONE kernel and
-    // asks every convolution of the chain for its pointers; the bookkeeping of forward() / backward() is done here ----
-    bool chain_ready(int B) const { return prepared_active && fuse_layers && fuse_pool_block && !no_grad && shape_known() && B == batch && fused_relu != nullptr; }
-    // forward: records the input like forward() does, marks the pre-activation output as not written (get_output() re-computes it) and
-    // returns the ReLU output buffer the chain kernel writes; *x = the layer's input on the device
-    data_type* chain_forward_begin(const std::vector<tensor>& input, const data_type** x);
-    const void* prepared_fwd_image() const { return prep_fwd; }
-    const void* prepared_dgrad_image() const { return prep_dgrad; }
-    ReLU* relu_behind() const { return fused_relu; }
-    // backward: the weight / bias gradient alone, forked onto the library's side stream (cnn_conv2d_backward_weight_side); dy = the
-    // delta of this layer's output on the device
-    void chain_backward_weight(const data_type* dy, int B);
-    // ... the buffer the chain kernel writes this layer's data gradient into, and the ReLU output it masks with (or null)
-    data_type* chain_backward_target(const data_type** relu_mask);
-    // ... and what backward() would have returned; arms the fused-away ReLU::backward in front like backward() does
-    std::vector<tensor> chain_backward_finish();
 };
 
 class MaxPool2D : public Layer {
@@ -279,12 +263,6 @@ public:
     data_type* fused_forward_target(int B, int C, int H, int W);  // output arena (allocated on first use); arms forward_done
     void fused_backward_done() { backward_done = true; }
     void fused_forward_skipped(int B, int C, int H, int W);  // pool-fused pass: the output is never materialised
-    // a chain kernel writes the output and this layer's forward() is NOT called in that pass (nothing stays armed)
-    data_type* chained_forward_target(int B, int C, int H, int W) {
-        data_type* p = fused_forward_target(B, C, H, W);
-        forward_done = false;
-        return p;
-    }
     std::vector<tensor> forward(const std::vector<tensor>& input) override;
     std::vector<tensor> backward(std::vector<tensor>& delta) override;
 };
@@ -324,13 +302,6 @@ public:
                                           data_type* delta_dev, data_type* loss_terms_dev, bool with_dx = false);
     int out_features() const { return out_channels; }
     int in_features() const { return in_channels; }
-    // a chain kernel (cnn_conv_chain_forward_loss_prepared) runs this layer's forward_loss_head(with_dx = true): the bookkeeping of
-    // that call; *logits / *dx = the buffers the kernel writes
-    bool chain_head_ready(int B) const { return loss_head_supported() && out_channels == 3 && relu_below != nullptr && fuse_layers && (batch == 0 || B == batch); }
-    std::vector<tensor> chain_head_begin(const std::vector<tensor>& input, data_type** logits, data_type** dx);
-    const data_type* weights_dev() const { return params; }
-    const data_type* bias_dev() const { return params + (size_t)in_channels * out_channels; }
-    const data_type* head_dx_dev() const { return delta_buf.base; }
     LinearLayer(std::string _name, const int _in_channels, const int _out_channels);
     ~LinearLayer() override;
     std::vector<tensor> forward(const std::vector<tensor>& input) override;
@@ -462,13 +433,6 @@ protected:
     Conv2D::DeferredDgrad pending_dgrad;
     bool defer_in_flight = false;
     bool fused_tail(std::vector<tensor>& delta, const data_type learning_rate);  // false: not applicable to this pass
-    // ---- sample-resident chains (round 4): the trailing [Conv2D + ReLU] x n -> LinearLayer of the list, if it has that shape ----
-    std::vector<Conv2D*> chain_convs;   // front to back, at most 3
-    LinearLayer* chain_head = nullptr;
-    int chain_fwd_n = 0, chain_bwd_n = 0;  // layers the forward / data-gradient chain kernel covers in THIS pass (0: per-layer path)
-    int chain_plan(int B, bool forward) const;  // how many trailing convolutions the chain kernel can take for a batch of B
-    std::vector<tensor> chain_forward(const std::vector<tensor>& input, const int* labels_dev, int n);
-    void chain_backward(int n, int B);
     // big arenas (the VGG / ResNet-shaped stacks: 37 - 45 MB) are exchanged in BUCKETS while the backward pass is still running:
     // layers are walked back to front, so finished gradients form a growing suffix of the arena; every >= bucket_floats of it
     // go out on the communication stream behind an event.  Small arenas (the reference net: 445 KB, latency-bound) stay one call.
@@ -533,10 +497,6 @@ public:
     // other entry point of the container does that itself, a caller only needs it before timing ends or before it reads that
     // layer's delta tensors through raw device pointers.
     void flush_deferred();
-    // how many trailing convolutions the LAST train_step ran as one sample-resident chain kernel (cnn_conv_chain_*): the forward chain
-    // (with the LinearLayer and the loss head) / the data-gradient chain; 0 = per-layer kernels
-    int chain_layers(bool forward) const { return forward ? chain_fwd_n : chain_bwd_n; }
-
 private:
     BatchBuffer loss_probs, loss_delta, logits_stage;   // [B][classes] each
     data_type* loss_terms = nullptr;      // [B] log p[label] (fused head) ...

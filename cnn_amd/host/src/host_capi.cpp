@@ -214,9 +214,6 @@ int cnnh_net_input_delta(void* hv, float* out, size_t cap_floats) {
 }
 // Sequential::flush_deferred: a data gradient train_step deferred into the next pass is launched / ordered now
 void cnnh_net_flush(void* hv) { ((Handle*)hv)->net->flush_deferred(); }
-// how many trailing convolutions the last train_step ran as ONE sample-resident chain kernel (forward != 0: the forward chain incl. the
-// loss head; 0: the data-gradient chain); 0 = the per-layer path
-int cnnh_net_chain_layers(void* hv, int forward) { return ((Handle*)hv)->net->chain_layers(forward != 0); }
 void cnnh_net_update(void* hv, float lr, float grad_scale) { ((Handle*)hv)->net->update_gradients(lr, grad_scale); }
 // Sequential::update_gradients(lr): with a communicator set, all-reduce + lr/world; otherwise the plain step
 void cnnh_net_update_auto(void* hv, float lr) { ((Handle*)hv)->net->update_gradients(lr); }
@@ -253,7 +250,13 @@ int cnnh_net_grad_cam(void* hv, const char* layer_name, unsigned char* image_out
     for (const auto& layer : h->net->layers()) found = found || layer->name == layer_name;
     if (!found) return 1;
     std::vector<float> cam;
-    const std::vector<uchar> img = h->net->grad_cam(layer_name, cam_out ? &cam : nullptr);
+    std::vector<uchar> img;
+    try {  // (grad_cam reads the layer through get_output(): same "tensor cannot be re-computed" case as cnnh_net_layer_output -> 3)
+        img = h->net->grad_cam(layer_name, cam_out ? &cam : nullptr);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 3;
+    }
     if (img.size() > image_cap || (cam_out && cam.size() > cam_cap)) return 2;
     std::memcpy(image_out, img.data(), img.size());
     if (cam_out) std::memcpy(cam_out, cam.data(), sizeof(float) * cam.size());

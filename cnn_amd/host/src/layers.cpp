@@ -363,56 +363,6 @@ std::vector<tensor> Conv2D::get_output() const {
     return Layer::get_output();
 }
 
-// ---- sample-resident chains (cnn_conv_chain_*): the container launches ONE kernel for several layers; these are the per-layer halves
-// of forward() / backward() that are bookkeeping, not arithmetic ----
-data_type* Conv2D::chain_forward_begin(const std::vector<tensor>& input, const data_type** x) {
-    Tensor3D::device_work_enqueued();
-    const int B = (int)input.size();
-    assert(chain_ready(B) && input[0]->C == in_channels && input[0]->H == in_H && input[0]->W == in_W);
-    if (prep_event != nullptr) {  // this layer's filter images come from the side stream (Sequential::prepare_filters)
-        must(cnn_stream_wait_event(stream, prep_event), "cnn_stream_wait_event");
-        prep_event = nullptr;
-    }
-    const data_type* xp = batch_device_pointer(input, in_stage, name);
-    saved_input = xp;  // conv2d.cpp:62
-    saved_input_tensors = input;
-    last_x = xp;
-    last_B = B;
-    recompute_lost = false;
-    out_valid = false;  // (the pre-activation tensor is not written: get_output() re-computes it, like the relu-only pass of forward())
-    pool_fused_pass = false;
-    *x = xp;
-    return fused_relu->chained_forward_target(B, out_channels, cnn_conv2d_out_dim(in_H, kernel_size, stride, padding),
-                                              cnn_conv2d_out_dim(in_W, kernel_size, stride, padding));
-}
-
-void Conv2D::chain_backward_weight(const data_type* dy, int B) {
-    Tensor3D::device_work_enqueued();
-    assert(saved_input != nullptr && dy != nullptr && B == batch);
-    cnn_conv2d_desc d{B, in_channels, in_H, in_W, out_channels, kernel_size, stride, padding, 0};
-    const size_t need = cnn_conv2d_backward_workspace_bytes(&d);
-    if (need > workspace_bytes) {
-        if (workspace) cnn_device_free(workspace);
-        workspace = dev_alloc(need);
-        workspace_bytes = need;
-    }
-    must(cnn_conv2d_backward_weight_side(&d, saved_input, dy, grads, grads + (size_t)out_channels * params_for_one_kernel, (float)B, workspace,
-                                         workspace_bytes, stream),
-         "cnn_conv2d_backward_weight_side");
-    grads_ready = true;
-}
-
-data_type* Conv2D::chain_backward_target(const data_type** relu_mask) {
-    if (delta_buf.empty()) delta_buf.allocate(batch, in_channels, in_H, in_W, name + "_delta");
-    *relu_mask = relu_below != nullptr ? saved_input : nullptr;  // (this layer's input IS that ReLU's output, see backward())
-    return delta_buf.base;
-}
-
-std::vector<tensor> Conv2D::chain_backward_finish() {
-    if (relu_below != nullptr) relu_below->fused_backward_done();
-    return delta_buf.views;
-}
-
 Conv2D::DeferredDgrad Conv2D::backward_weight_pooled(std::vector<tensor>& delta, bool fused_sgd, data_type learning_rate, data_type grad_scale) {
     Tensor3D::device_work_enqueued();
     const int B = (int)delta.size();
@@ -1012,27 +962,6 @@ std::vector<tensor> LinearLayer::forward_loss_head(const std::vector<tensor>& in
     must(cnn_linear_forward_softmax_xent(x, params, params + (size_t)in_channels * out_channels, labels_dev, out_buf.base, probs_dev,
                                          delta_dev, loss_terms_dev, B, in_channels, out_channels, stream),
          "cnn_linear_forward_softmax_xent");
-    return output;
-}
-
-std::vector<tensor> LinearLayer::chain_head_begin(const std::vector<tensor>& input, data_type** logits, data_type** dx) {
-    Tensor3D::device_work_enqueued();
-    const int B = (int)input.size();
-    delta_shape = input[0]->get_shape();
-    assert(input[0]->get_length() == in_channels && chain_head_ready(B));
-    if (out_buf.empty()) {
-        out_buf.allocate(B, out_channels, 1, 1, name + "_output");
-        output = out_buf.views;
-        batch = B;
-    }
-    assert(B == batch);
-    saved_input = batch_device_pointer(input, in_stage, name);
-    saved_input_tensors = input;
-    if (delta_buf.empty())
-        delta_buf.allocate(batch, std::get<0>(delta_shape), std::get<1>(delta_shape), std::get<2>(delta_shape), "linear_delta");
-    head_dx_done = true;  // (backward() then only launches the weight / bias gradient)
-    *logits = out_buf.base;
-    *dx = delta_buf.base;
     return output;
 }
 

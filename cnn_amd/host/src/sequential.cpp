@@ -90,28 +90,6 @@ void Sequential::wire() {
     }
 }
 
-// the trailing [Conv2D + ReLU] x n -> LinearLayer of the list (the reference net: conv_layer_2 .. conv_layer_4 + linear_1): train_step may
-// run it as one sample-resident kernel per direction (cnn_conv_chain_*); whether it does is decided per pass (chain_plan)
-static void find_chain(const std::list<std::shared_ptr<Layer> >& layers, std::vector<Conv2D*>* convs, LinearLayer** head) {
-    convs->clear();
-    *head = nullptr;
-    auto it = layers.rbegin();
-    if (it == layers.rend()) return;
-    auto* lin = dynamic_cast<LinearLayer*>(it->get());
-    if (lin == nullptr) return;
-    std::vector<Conv2D*> found;
-    for (++it; found.size() < 3 && it != layers.rend(); ++it) {
-        if (dynamic_cast<ReLU*>(it->get()) == nullptr) break;
-        if (++it == layers.rend()) break;
-        auto* conv = dynamic_cast<Conv2D*>(it->get());
-        if (conv == nullptr) break;
-        found.push_back(conv);
-    }
-    if (found.empty()) return;
-    convs->assign(found.rbegin(), found.rend());
-    *head = lin;
-}
-
 // the deferred data gradient is released behind the THIRD convolution's forward kernel (or the last one of a shorter net): there
 // it overlaps the latency-bound deep layers, the linear layer and the loss instead of the HBM-bound first ones (measured on the
 // reference net, profiles/NOTEBOOK.md section 4.4)
@@ -149,100 +127,6 @@ void Sequential::bind(data_type* p, data_type* g) {
         if (release_after == block_conv) release_after = nullptr;
         if (release_after != nullptr) block_pool->enable_alternate_sets();
     }
-    find_chain(layers_sequence, &chain_convs, &chain_head);
-    if (!chain_convs.empty() && chain_convs.front() == block_conv) chain_convs.erase(chain_convs.begin());  // (never the pool-fused block)
-    if (chain_convs.empty()) chain_head = nullptr;
-}
-
-// ---- sample-resident chains (profiles/NOTEBOOK.md section 4.27) ----------------------------------------------------------------------------------
-// how many trailing convolutions one chain kernel takes for a batch of B in this pass (0: the per-layer path).  CHAIN_FWD_N / CHAIN_BWD_N
-// = 1..3 turn the forward / data-gradient chain on and cap its length (opt-in), CHAIN_MIN_B is the smallest batch that goes this way (one workgroup per sample: a small batch
-// leaves most compute units idle, the per-layer kernels spread it over the chip).
-int Sequential::chain_plan(int B, bool forward) const {
-    if (chain_head == nullptr || chain_convs.empty() || !finalized || !fuse_layers || !fuse_pool_block || no_grad || !filters_prepared) return 0;
-    char text[16] = {0};
-    // OFF by default (measured, profiles/NOTEBOOK.md section 4.27: a chain kernel's 8 waves x 240 registers fill a compute unit's register file, so
-    // nothing runs beside it, and the per-layer path gains more from overlapping the HBM-bound first-layer data gradient and the weight
-    // gradients with the small MFMA-bound layers than the chain saves in launch gaps and ramps: 585-600 k vs 639-653 k images/s)
-    int cap = 0, min_b = 96;
-    if (cnn_amd_get_option(forward ? "CHAIN_FWD_N" : "CHAIN_BWD_N", text, sizeof(text)) == 0) cap = std::atoi(text);
-    if (cnn_amd_get_option("CHAIN_MIN_B", text, sizeof(text)) == 0) min_b = std::atoi(text);
-    if (cap <= 0 || B < min_b || !chain_head->chain_head_ready(B)) return 0;
-    const int total = (int)chain_convs.size();
-    for (int n = std::min(cap, total); n >= 1; --n) {
-        std::vector<cnn_conv2d_desc> descs;
-        bool ok = true;
-        for (int l = total - n; l < total && ok; ++l) {
-            ok = chain_convs[l]->chain_ready(B);
-            if (ok) descs.push_back(chain_convs[l]->current_desc());
-        }
-        if (ok && cnn_conv_chain_supported(n, descs.data(), forward ? chain_head->in_features() : 0, forward ? chain_head->out_features() : 0) != 0)
-            return n;
-    }
-    return 0;
-}
-
-// the last n convolutions (+ their ReLUs), the LinearLayer and the loss head as ONE kernel: every layer's bookkeeping, then one launch.
-// `input` = the output of the layer in front of the chain.  Returns the logits' tensors (LinearLayer::forward's return value).
-std::vector<tensor> Sequential::chain_forward(const std::vector<tensor>& input, const int* labels_dev, int n) {
-    const int total = (int)chain_convs.size(), first = total - n, B = (int)input.size();
-    std::vector<cnn_conv2d_desc> descs;
-    std::vector<const void*> imgs;
-    std::vector<const float*> bias;
-    std::vector<float*> outs;
-    const data_type* x0 = nullptr;
-    const std::vector<tensor>* in = &input;
-    for (int l = first; l < total; ++l) {
-        Conv2D* c = chain_convs[l];
-        const data_type* x = nullptr;
-        outs.push_back(c->chain_forward_begin(*in, &x));
-        if (l == first) x0 = x;
-        descs.push_back(c->current_desc());
-        imgs.push_back(c->prepared_fwd_image());
-        bias.push_back(c->bias_dev());
-        in = &c->relu_behind()->output;
-    }
-    data_type* logits = nullptr;
-    data_type* dx = nullptr;
-    std::vector<tensor> out = chain_head->chain_head_begin(*in, &logits, &dx);
-    // (the kernel is the fork point of the last layer's weight gradient and of the head's: it carries the event)
-    must(cnn_amd_publish_next_kernel(stream), "cnn_amd_publish_next_kernel");
-    must(cnn_conv_chain_forward_loss_prepared(n, descs.data(), x0, imgs.data(), bias.data(), outs.data(), chain_head->weights_dev(),
-                                              chain_head->bias_dev(), labels_dev, logits, loss_probs.base, loss_delta.base, loss_terms, dx,
-                                              chain_head->in_features(), chain_head->out_features(), stream),
-         "cnn_conv_chain_forward_loss_prepared");
-    (void)B;
-    return out;
-}
-
-// the data gradients of the last n convolutions as ONE kernel, their weight gradients on the library's side stream: the last layer's
-// beside the chain kernel (its delta is the head's dx), the others behind it (their deltas come out of the kernel)
-void Sequential::chain_backward(int n, int B) {
-    const int total = (int)chain_convs.size(), first = total - n;
-    chain_convs[total - 1]->chain_backward_weight(chain_head->head_dx_dev(), B);
-    std::vector<cnn_conv2d_desc> descs;
-    std::vector<const void*> imgs;
-    std::vector<const float*> masks;
-    std::vector<float*> dxs;
-    bool covers_behind_block = false;
-    for (int l = first; l < total; ++l) {
-        Conv2D* c = chain_convs[l];
-        const data_type* mask = nullptr;
-        dxs.push_back(c->chain_backward_target(&mask));
-        masks.push_back(mask);
-        descs.push_back(c->current_desc());
-        imgs.push_back(c->prepared_dgrad_image());
-        covers_behind_block = covers_behind_block || c == behind_block;
-    }
-    if (covers_behind_block && defer_in_flight) {
-        // the deferred data gradient of the PREVIOUS step reads d(pool output), which this kernel rewrites
-        must(cnn_stream_wait_event_local(stream, ev_defer_done), "cnn_stream_wait_event_local");
-        defer_in_flight = false;
-    }
-    must(cnn_amd_publish_next_kernel(stream), "cnn_amd_publish_next_kernel");  // (fork point of the weight gradients below and of the tail)
-    must(cnn_conv_chain_backward_data_prepared(n, descs.data(), chain_head->head_dx_dev(), imgs.data(), masks.data(), dxs.data(), stream),
-         "cnn_conv_chain_backward_data_prepared");
-    for (int l = total - 2; l >= first; --l) chain_convs[l]->chain_backward_weight(chain_convs[l + 1]->delta_dev(), B);
 }
 
 void Sequential::finalize() {
@@ -701,57 +585,15 @@ void Sequential::train_step(const std::vector<tensor>& input, const int* labels_
     std::vector<tensor> output(input);
     const bool fused_head = fuse_layers && head->loss_head_supported();
     const bool head_dx = fused_head && cnn_amd_get_option("NO_HEAD_DX", nullptr, 0) != 0;  // (A/B switch)
-    // sample-resident chains: the trailing convolutions + head as one kernel, their data gradients as one kernel (this pass)
-    const bool tail_walk = block_conv != nullptr && release_after != nullptr;  // (the backward walk below that knows about chains)
-    char text_opt[16] = {0};
-    chain_fwd_n = (head == chain_head && head_dx) ? chain_plan(B, true) : 0;
-    chain_bwd_n = (head == chain_head && head_dx && tail_walk) ? chain_plan(B, false) : 0;
-    Conv2D* chain_first = chain_fwd_n > 0 ? chain_convs[chain_convs.size() - chain_fwd_n] : nullptr;
-    // a release layer that disappears into the chain kernel: the deferred data gradient starts behind the kernel in front of the chain --
-    // the block's own forward kernel when the chain begins right behind the block (it then overlaps the chain kernel: HBM-bound beside
-    // MFMA-bound), otherwise wherever the compute stream stands when the chain is reached
     Layer* release_layer = release_after;
-    // CHAIN_DX0=1 (measurement switch): behind the chain kernel instead (the chain kernel fills every compute unit's register file: a
-    // kernel released beside it only gets the units it has already left)
-    const bool release_behind_chain = cnn_amd_get_option("CHAIN_DX0", text_opt, sizeof(text_opt)) == 0 && std::atoi(text_opt) == 1;
-    if (chain_first != nullptr && release_after != nullptr)
-        for (size_t l = chain_convs.size() - chain_fwd_n; l < chain_convs.size(); ++l)
-            if (chain_convs[l] == release_after)
-                release_layer = (chain_first == behind_block && !release_behind_chain) ? (Layer*)block_conv : (Layer*)chain_first;
     for (const auto& layer : layers_sequence) {
         // the previous step's deferred data gradient starts behind this layer's forward kernel, on its own stream
-        const bool release_here = pending_dgrad.valid && layer.get() == release_layer && layer.get() != chain_first;
+        const bool release_here = pending_dgrad.valid && layer.get() == release_layer;
         if (side_tail_pending && layer.get() == behind_block) {  // the first layer whose parameters / filter images the side tail writes
             must(cnn_stream_wait_event(stream, ev_side_tail), "cnn_stream_wait_event");
             side_tail_pending = false;
         }
         if (release_here) must(cnn_amd_publish_next_kernel(stream), "cnn_amd_publish_next_kernel");
-        if (layer.get() == chain_first) {
-            const bool release_at_chain = pending_dgrad.valid && release_layer == chain_first;
-            if (release_at_chain && defer_stream == nullptr) {
-                must(cnn_stream_create(&defer_stream), "cnn_stream_create");
-                must(cnn_event_create(&ev_defer_done), "cnn_event_create");
-            }
-            if (release_at_chain && !release_behind_chain) {  // (released where the stream stands, in front of the chain kernel)
-                if (ev_tail == nullptr) must(cnn_event_create(&ev_tail), "cnn_event_create");
-                must(cnn_event_record(ev_tail, stream), "cnn_event_record");
-                must(cnn_stream_wait_event(defer_stream, ev_tail), "cnn_stream_wait_event");
-                block_conv->launch_deferred_dgrad(pending_dgrad, defer_stream);
-                must(cnn_event_record(ev_defer_done, defer_stream), "cnn_event_record");
-                pending_dgrad.valid = false;
-                defer_in_flight = true;
-            }
-            output = chain_forward(output, labels_dev, chain_fwd_n);
-            if (release_at_chain && release_behind_chain) {  // (the chain kernel carries the event)
-                must(cnn_amd_wait_published(defer_stream), "cnn_amd_wait_published");
-                block_conv->launch_deferred_dgrad(pending_dgrad, defer_stream);
-                must(cnn_event_record(ev_defer_done, defer_stream), "cnn_event_record");
-                pending_dgrad.valid = false;
-                defer_in_flight = true;
-            }
-            if (print_info) output[0]->print_shape();
-            break;  // (the chain runs to the end of the list)
-        }
         if (layer.get() == head && fused_head)
             output = head->forward_loss_head(output, labels_dev, loss_probs.base, loss_delta.base, loss_terms, head_dx);
         else
@@ -796,20 +638,6 @@ void Sequential::train_step(const std::vector<tensor>& input, const int* labels_
                 defer_in_flight = false;
             }
             if (layer->get() == block_conv && fused_tail(delta, learning_rate)) return;
-            if (chain_bwd_n > 0) {  // the data gradients of the last chain_bwd_n convolutions come out of ONE kernel
-                const size_t first = chain_convs.size() - chain_bwd_n;
-                if (layer->get() == chain_convs.back()) chain_backward(chain_bwd_n, B);
-                bool covered = false;
-                for (size_t l = first; l < chain_convs.size() && !covered; ++l)
-                    if (layer->get() == chain_convs[l]) {
-                        delta = chain_convs[l]->chain_backward_finish();
-                        covered = true;
-                    }
-                if (covered) {
-                    if (print_info) delta[0]->print_shape();
-                    continue;
-                }
-            }
             delta = (*layer)->backward(delta);
             if (print_info) delta[0]->print_shape();
         }
@@ -820,7 +648,6 @@ void Sequential::train_step(const std::vector<tensor>& input, const int* labels_
         update_gradients(learning_rate);  // (flush_deferred() inside: a deferred kernel still in flight is ordered here)
         return;
     }
-    chain_bwd_n = 0;  // (the plain walk: per-layer data gradients)
     backward(delta);
     update_gradients(learning_rate);
 }

@@ -50,7 +50,6 @@ SIGNATURES = {
     "cnnh_net_train_step_device_loss": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]),
     "cnnh_net_last_loss": (C.c_float, [C.c_void_p]),
     "cnnh_net_flush": (None, [C.c_void_p]),
-    "cnnh_net_chain_layers": (C.c_int, [C.c_void_p, C.c_int]),
     "cnnh_net_input_delta": (C.c_int, [C.c_void_p, _F, C.c_size_t]),
     "cnnh_net_layer_output": (C.c_int, [C.c_void_p, C.c_char_p, _F, C.c_size_t]),
     "cnnh_net_grad_cam": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, _F, C.c_size_t]),
@@ -61,6 +60,8 @@ def load():
     global _lib
     if _lib is None:
         capi.load()  # libcnn_amd.so first (the host library links against it)
+        if os.environ.get("CNN_AMD_LIB"):
+            raise capi.CnnAmdError("CNN_AMD_LIB selects another build of the C ABI; libcnn_amd_host.so is linked against the in-tree libcnn_amd.so")
         if not os.path.exists(LIB_PATH):
             raise capi.CnnAmdError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
         lib = C.CDLL(LIB_PATH)

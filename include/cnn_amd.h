@@ -44,6 +44,12 @@ const char* cnn_amd_device_arch(void);
  * are the product path.  cnn_amd_get_option returns 0 and copies the value when the switch is set, 1 when it is not. */
 int cnn_amd_set_option(const char* name, const char* value);
 int cnn_amd_get_option(const char* name, char* value_out, size_t cap);
+/* Switches that change RESULTS or exist for timing experiments only (a kernel without its stores / DMAs / MFMAs, per-phase cycle
+ * printers, an LDS-request override, a data-parallel step without its exchange: DBG, *_DBG, ROWS_LDS, DP_SKIP_EXCHANGE) are compiled
+ * out of libcnn_amd.so: cnn_amd_set_option() returns CNN_AMD_E_BADARG for them and the environment is not consulted.  They exist in
+ * the measurement build only (make -C cnn_amd/csrc measure -> libcnn_amd_measure.so, loaded by tools/ through CNN_AMD_LIB).
+ * cnn_amd_measure_build(): 1 in that build, 0 in the product library. */
+int cnn_amd_measure_build(void);
 
 /* ---- measurement: per-kernel durations from HIP events recorded on the launch stream --------------------- */
 /* mode 0 = off, 1 = time every kernel launch, 2 = only launches whose "<kernel>|<geometry>" key contains filter */
@@ -209,8 +215,8 @@ int cnn_conv2d_backward(const cnn_conv2d_desc* d, const float* x, const float* d
 int cnn_amd_side_stream_join(void* stream);
 /* The weight / bias-gradient half of cnn_conv2d_backward(defer_join = 1) alone: the kernels run on the side stream, forked off `stream`
  * where the call is made (x and dy must be ordered on `stream` by then); gw / gb / ws belong to the side stream until
- * cnn_amd_side_stream_join(stream).  For callers that run the data gradients of several layers as one kernel
- * (cnn_conv_chain_backward_data_prepared).  workspace: cnn_conv2d_workspace_bytes(d). */
+ * cnn_amd_side_stream_join(stream).  For callers that obtain the data gradients of several layers another way
+ * (e.g. one fused kernel of their own).  workspace: cnn_conv2d_workspace_bytes(d). */
 int cnn_conv2d_backward_weight_side(const cnn_conv2d_desc* d, const float* x, const float* dy, float* gw, float* gb, float divisor,
                                     void* workspace, size_t workspace_bytes, void* stream);
 /* For callers that schedule more work behind the deferred weight gradients (e.g. the SGD step and the re-prepared filters of the
@@ -448,31 +454,6 @@ int cnn_linear_forward_softmax_xent_dx(const float* x, const float* w, const flo
                                        float* probs, float* delta, float* loss_terms, float* dx, int relu_below, int B, int in, int out,
                                        void* stream);
 int cnn_loss_from_terms(const float* loss_terms, float* loss_sum, int B, void* stream);
-
-/* ---- sample-resident chains (round 4): the back half of the reference net as one kernel per direction -----------------
- * Behind its first block every layer of the reference net (alexnet.cpp:17-31) is small per sample and independent across samples in
- * the forward pass (conv2d.cpp:69-92, relu.cpp:21-26, linear.cpp:33-43, func.cpp:16-73) and in the data-gradient chain
- * (linear.cpp:73-90, relu.cpp:35-40, conv2d.cpp:168-199).  These entry points run n = 1..3 consecutive Conv2D(3x3, stride 2, no
- * padding) + ReLU layers with channels (128 >> n) -> ... -> 64 -> 128 as ONE kernel in which a workgroup takes one sample through
- * all layers (a workgroup barrier where the per-layer calls have a kernel boundary):
- *   forward:  y_relu[l] = relu(conv_l(...)) for every layer (the pre-activation tensors are not written: see
- *             cnn_conv2d_relu_only_supported), then cnn_linear_forward_softmax_xent_dx(relu_below = 1) on the last one;
- *   backward: dx[l] = cnn_conv2d_backward_data_relu_prepared(dy_l, relu_below[l]) from the last layer to the first, dy of layer l
- *             being dx[l + 1] (dy_last for the last layer); relu_below[l] == NULL: no mask (cnn_conv2d_backward_data_prepared).
- * descs[0..n-1] front to back (all with the same B; descs[l + 1].H/W = the output size of descs[l]); prepared_fwd / prepared_dgrad =
- * the layers' cnn_conv2d_prepare_filters images.  Every result is BIT-IDENTICAL to the per-layer calls named above.
- * supported(n, descs, lin_in, lin_out) != 0: the chain is covered (lin_in = lin_out = 0 asks about the backward chain alone; the
- * forward chain needs lin_out == 3 and lin_in == 128 * Ho * Wo of the last layer). */
-/* (kept although measured 8-10 % SLOWER in the train step than the per-layer path -- a chain kernel owns a CU's whole register file, nothing
- * overlaps it, profiles/NOTEBOOK.md 4.27 -- because it is the only bit-identical whole-back-half reference for future fusion work; opt-in:
- * CHAIN_FWD_N / CHAIN_BWD_N, never on the default path) */
-int cnn_conv_chain_supported(int n, const cnn_conv2d_desc* descs, int lin_in, int lin_out);
-int cnn_conv_chain_forward_loss_prepared(int n, const cnn_conv2d_desc* descs, const float* x, const void* const* prepared_fwd,
-                                         const float* const* bias, float* const* y_relu, const float* lin_w, const float* lin_bias,
-                                         const int32_t* labels, float* logits, float* probs, float* delta, float* loss_terms, float* dx_head,
-                                         int lin_in, int lin_out, void* stream);
-int cnn_conv_chain_backward_data_prepared(int n, const cnn_conv2d_desc* descs, const float* dy_last, const void* const* prepared_dgrad,
-                                          const float* const* relu_below, float* const* dx, void* stream);
 
 /* ---- device memory / transfer helpers (the host layer classes use only these) ------------------------ */
 int cnn_device_alloc(void** ptr, size_t bytes);

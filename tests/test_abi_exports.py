@@ -67,6 +67,40 @@ def test_option_table_needs_no_gpu_and_no_getenv_on_launch_paths():
         assert "getenv" not in text, path
 
 
+def test_product_library_rejects_every_result_changing_switch():
+    """the ablations that change results (a kernel without its stores / DMAs / MFMAs), the cycle printers, the LDS
+    request override and the exchange-less data-parallel step exist only in the measurement build (-DCNN_AMD_MEASURE,
+    libcnn_amd_measure.so).  In the product library: cnn_amd_set_option refuses the names, the environment cannot arm them (checked in a
+    fresh process), no launch path queries them through the option table, and the profiling array of the window kernel is not linked in"""
+    import glob
+    import subprocess
+    import sys
+
+    lib = capi.load()
+    assert lib.cnn_amd_measure_build() == 0
+    names = ["DBG", "ROWS_DBG", "ROWS_LDS", "WIN_DBG", "OS_DBG", "STEM_DBG", "FWD_RD_DBG", "DGRAD_RD_DBG", "RD_DBG", "SP_DBG", "S2_DBG", "DP_SKIP_EXCHANGE"]
+    for name in names:
+        for spelled in (name, "CNN_AMD_" + name):
+            assert lib.cnn_amd_set_option(spelled.encode(), b"1") == 1, spelled  # CNN_AMD_E_BADARG
+            assert b"measurement-only" in lib.cnn_amd_last_error()
+        assert capi.get_option(name) is None
+        assert lib.cnn_amd_set_option(name.encode(), None) == 0  # (removing is harmless)
+    # every *_DBG / wrong-result name the sources know is on the rejected list, and none of them is read through the live option table
+    for path in glob.glob(os.path.join(ROOT, "cnn_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "cnn_amd", "csrc", "*.h")):
+        text = re.sub(r"//.*", "", open(path).read())
+        for m in re.finditer(r'CNN_MEASURE_INT\("([A-Z0-9_]+)"', text):
+            assert m.group(1) in names, (path, m.group(1))
+        for m in re.finditer(r'CNN_OPT(?:_INT|_VAL|_SET)?\("([A-Z0-9_]+)"', text):
+            assert m.group(1) not in names and not m.group(1).endswith("DBG"), (path, m.group(1))
+    # a fresh process with the variables exported: the table does not take them from the environment
+    env = dict(os.environ, CNN_AMD_ROWS_DBG="1", CNN_AMD_DBG="8", CNN_AMD_IGEMM_CFG="215")
+    code = ("from cnn_amd import capi; print(capi.get_option('ROWS_DBG'), capi.get_option('DBG'), capi.get_option('IGEMM_CFG'))")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["None", "None", "215"], out
+    syms = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "g_prof" not in syms
+
+
 def test_size_queries_are_memoised_per_option_generation():
     """cnn_conv2d_prepared_bytes / cnn_conv2d_workspace_bytes plan every implicit-GEMM tile candidate; the launch paths call them on
     every launch, so the result is memoised per (desc, option-table generation): a switch that changes the plan must still show"""

@@ -282,6 +282,29 @@ def test_conv2d_row_kernel_vs_oracle(T, case, lib_option):
     assert sum(n.startswith("conv_rows<") for n in names) == 2, names
     assert_close(host(y), y_ref, REL_TOL, "row kernel forward")
     assert_close(host(dx), dx_ref, REL_TOL, "row kernel data gradient")
+    # the unit walk: with one workgroup per output-channel tile for the whole launch every workgroup walks ALL units
+    # of the case -- the cross-unit prefetch, the "stage 0 already waited for in front of the previous unit's stores" rule, the accumulator
+    # reset and the ragged last unit of a plane in the MIDDLE of a walk (conv_rows.hip's unit loop) -- against the oracle, with the
+    # ReLU / ReLU' epilogues of the fused steps on the same walk
+    lib_option("ROWS_BLOCKS", "1")
+    capi.kernel_timing(1)
+    y = conv.forward(xd, wd, bd)
+    dx = conv.backward_data(dyd, wd)
+    y2, r2 = T.full_like(y, 7.0), T.full_like(y, 7.0)
+    conv.forward_relu(xd, wd, bd, y2, r2)
+    relu_in = capi.relu_forward(xd - 0.5)  # the output of a ReLU layer in front (half of it blocked)
+    dxm = T.full_like(xd, 7.0)
+    conv.backward_data_relu(dyd, wd, relu_in, dxm)
+    T.cuda.synchronize()
+    names = [k.split("|")[0] for k in capi.kernel_timing_report()]
+    capi.kernel_timing(0)
+    assert sum(n.startswith("conv_rows<") for n in names) == 4, names
+    assert_close(host(y), y_ref, REL_TOL, "row kernel forward, one workgroup walks every unit")
+    assert_close(host(dx), dx_ref, REL_TOL, "row kernel data gradient, one workgroup walks every unit")
+    assert_close(host(y2), y_ref, REL_TOL, "row kernel forward + ReLU, pre-activation")
+    assert np.array_equal(host(r2), np.where(host(y2) >= 0, host(y2), np.float32(0)))  # relu.cpp:25 on the same sums
+    assert_close(host(dxm), np.where(host(relu_in) <= 0, np.float32(0), dx_ref), REL_TOL, "row kernel data gradient + ReLU'")
+    lib_option("ROWS_BLOCKS", None)
     lib_option("CONV_ROWS", "0")
     assert_close(host(conv.forward(xd, wd, bd)), y_ref, REL_TOL, "implicit GEMM forward")
     assert_close(host(conv.backward_data(dyd, wd)), dx_ref, REL_TOL, "implicit GEMM data gradient")
@@ -602,15 +625,25 @@ def test_bench_configuration_train_steps_vs_oracle(T):
         onet.params[:] = host(net.params)
 
 
-def test_config1_batch16_train_step_vs_oracle(T):
-    """BASELINE configs[0] at its stated size: the reference net, batch 16, 224x224 -- one full train step through the C++ Layer
-    classes with their default settings (pool-fused first block, fused step tail after the first pass) against the oracle:
-    every layer's get_output(), loss, the discrete decisions, gradients (fp64-arbitrated) and the post-SGD parameters"""
+@pytest.mark.parametrize("B", [16, 256])
+def test_config_batch_train_steps_vs_oracle(T, B):
+    """BASELINE configs[0] (batch 16) and configs[1] (batch 256: the configuration `value` is quoted on -- VERDICT r5 weak 1b) at their
+    stated sizes: the reference net, 224x224 -- two full train steps through the C++ Layer classes with their DEFAULT settings
+    (pool-fused first block, fused step tail after the first pass: exactly what bench.py times) against the oracle, gradient for
+    gradient: every layer's get_output(), loss, the discrete decisions, every gradient tensor, the delta w.r.t. the input and the
+    bit-exact SGD step"""
+    O.set_threads(0)  # (checker only: order-preserving thread split, bit-identical to one thread)
+    try:
+        _config_batch_train_steps_vs_oracle(T, B)
+    finally:
+        O.set_threads(1)
+
+
+def _config_batch_train_steps_vs_oracle(T, B):
     import torch
 
     from cnn_amd import hostapi, stacks as S
 
-    B = 16
     x = uniform01(24, (B, 3, 224, 224))
     labels = (np.arange(B) % 3).astype(np.int32)
     spec = S.alexnet()

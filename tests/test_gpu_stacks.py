@@ -11,6 +11,10 @@ from tests.util import (REL_TOL, assert_close, assert_close_arbitrated, assert_c
 
 pytestmark = pytest.mark.gpu
 
+# the softmax-Jacobian bound of the stacks' 3-element linear.b gradient (see below) grows without limit when that gradient itself is
+# tiny (round 5 recorded a vacuous 80.4): whatever the derivation says, the check never goes above 10 x north_star's tolerance
+DERIVED_BOUND_CAP = 1e-3
+
 
 @pytest.fixture(scope="module")
 def T():
@@ -120,7 +124,7 @@ def test_stack_train_steps_vs_oracle(T, which, res, B):
                 # = mean_b(softmax(z_b) - onehot_b), a 3-element tensor: a logit error dz moves it by up to |dz| / 2 (the softmax
                 # Jacobian diag(p) - p p^T has infinity-norm <= 1/2), and the logits themselves are only held to REL_TOL * max|z|
                 # (above) -- the implicit-GEMM tiles the tuner pins differ from box to box, and with them the last bits of z
-                tol = max(REL_TOL, 0.5 * REL_TOL * float(np.abs(ologits).max()) / float(np.abs(onet.grads[lo:hi]).max()))
+                tol = min(DERIVED_BOUND_CAP, max(REL_TOL, 0.5 * REL_TOL * float(np.abs(ologits).max()) / float(np.abs(onet.grads[lo:hi]).max())))
             if name.endswith(".b") and name.startswith("conv") and idx + 1 < len(onet.layers) and onet.layers[idx + 1]["kind"] == "bn":
                 # exactly 0 in exact arithmetic (BatchNorm2D removes the channel mean behind this bias): both sides hold rounding
                 # noise -- bounded against the layer's weight gradient instead of compared with each other (tests/util.py)
@@ -283,7 +287,7 @@ def test_stack_gradients_vs_the_oracles_own_backward(T, which):
                                        f"{which} own-backward grad {name} (exact zero in front of BatchNorm2D)")
             continue
         if name == "linear.b":
-            tol = max(REL_TOL, 0.5 * REL_TOL * float(np.abs(ologits).max()) / float(np.abs(onet.grads[lo:hi]).max()))
+            tol = min(DERIVED_BOUND_CAP, max(REL_TOL, 0.5 * REL_TOL * float(np.abs(ologits).max()) / float(np.abs(onet.grads[lo:hi]).max())))
             if tol > REL_TOL:
                 assert_close_derived_bound(g[lo:hi], onet.grads[lo:hi], tol, f"{which} own-backward grad {name} (softmax-Jacobian bound)")
                 continue
@@ -501,6 +505,47 @@ def test_wide_and_split_tiles_at_the_stacks_full_sizes(T, case, cfgs, lib_option
         dx_ref = O.conv2d_backward(xp, dys, wn, s)[2][:, :, pad : pad + H, pad : pad + W]
         assert_close(y[sel].cpu().numpy(), y_ref, REL_TOL, f"cfg {cfg} full-size forward, oracle slice")
         assert_close(dx[sel].cpu().numpy(), dx_ref, REL_TOL, f"cfg {cfg} full-size data gradient, oracle slice")
+
+
+@pytest.mark.parametrize("case", [(64, 64, 56, 56, 64, 3, 1, 1), (64, 128, 28, 28, 128, 3, 1, 1), (64, 256, 14, 14, 256, 3, 1, 1), (64, 512, 7, 7, 512, 3, 1, 1),
+                                  (128, 512, 14, 14, 512, 3, 1, 1), (128, 128, 56, 56, 256, 3, 1, 1), (128, 64, 112, 112, 128, 3, 1, 1)],
+                         ids=lambda c: str(c).replace(" ", ""))
+def test_row_kernel_at_the_stacks_full_sizes_vs_oracle(T, case):
+    """the DEFAULT dispatch at BASELINE configs[3] / [4]'s full batch: these layers run on conv_rows.hip, whose
+    workgroups walk several (sample, row block) units each at these sizes (448 .. 1792 units on 256 CUs) -- forward, data gradient and
+    the data gradient with the ReLU' epilogue (relu.cpp:37 fused, the form the stacks' steps launch) against an ORACLE slice: both
+    passes are per-sample independent (conv2d.cpp:69,175), so five samples -- first, last, and three inside, i.e. first / middle /
+    last units of different workgroups' walks -- are compared with the oracle directly"""
+    from cnn_amd import capi
+
+    B, Ci, H, W, Co, k, s, pad = case
+    g = T.Generator(device="cuda").manual_seed(23)
+    x = T.rand((B, Ci, H, W), generator=g, device="cuda") - 0.4
+    w = T.randn((Co, Ci, k, k), generator=g, device="cuda") * float(np.sqrt(2.0 / (Ci * k * k)))
+    b = T.randn((Co,), generator=g, device="cuda") * 0.1
+    conv = capi.Conv2d(*case)
+    dy = T.rand(conv.out_shape(), generator=g, device="cuda") * 2 - 1
+    relu_in = capi.relu_forward(x)
+    capi.kernel_timing(1)
+    y = conv.forward(x, w, b)
+    dx = conv.backward_data(dy, w)
+    dxm = T.full_like(x, 7.0)
+    conv.backward_data_relu(dy, w, relu_in, dxm)
+    T.cuda.synchronize()
+    names = [key.split("|")[0] for key in capi.kernel_timing_report()]
+    capi.kernel_timing(0)
+    assert sum(n.startswith("conv_rows<") for n in names) == 3, names
+    sel = [0, 1, B // 2 - 1, B // 2, B - 1]
+    xs, dys = x[sel].cpu().numpy(), dy[sel].cpu().numpy()
+    xp = np.pad(xs, ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+    wn = w.cpu().numpy()
+    y_ref = O.conv2d_forward(xp, wn, b.cpu().numpy(), s)
+    dx_ref = O.conv2d_backward(xp, dys, wn, s)[2][:, :, pad : pad + H, pad : pad + W]
+    assert_close(y[sel].cpu().numpy(), y_ref, REL_TOL, "default dispatch, full-size forward, oracle slice")
+    assert_close(dx[sel].cpu().numpy(), dx_ref, REL_TOL, "default dispatch, full-size data gradient, oracle slice")
+    assert_close(dxm[sel].cpu().numpy(), np.where(xs <= 0, np.float32(0), dx_ref), REL_TOL, "default dispatch, full-size data gradient + ReLU', oracle slice")
+    # the samples the slice does not reach: the ReLU' form is the plain form masked (same sums, bit for bit), and nothing was left unwritten
+    assert T.equal(dxm, T.where(relu_in <= 0, T.zeros_like(dx), dx))
 
 
 @pytest.mark.parametrize("case", [(64, 64, 56, 56, 64, 3, 1, 1), (64, 128, 28, 28, 128, 3, 1, 1), (64, 256, 14, 14, 256, 3, 1, 1), (64, 512, 7, 7, 512, 3, 1, 1),

@@ -15,7 +15,8 @@ import pytest
 
 from tests import util
 
-MAX_FP64_BRANCH_PASSES = 6      # measured: 0 (profiles/r04, profiles/r05); head room for other tile choices, see above
+MAX_FP64_BRANCH_PASSES = 2      # measured: 0 (profiles/r04 .. r06); ADVICE r5: close to the measured value -- two tensors of head room for a box
+                                # whose tuner pins other implicit-GEMM tiles, not six
 MAX_PLAIN_ERR = 1.0e-4          # every check at north_star's tolerance, whatever its branch
 MAX_DERIVED_BOUND_CHECKS = 12   # 2 steps x 4 stack cases + the 2 own-backward tests, at most; each is a linear.b record
 
@@ -39,5 +40,5 @@ def test_arbitrated_tolerance_stays_the_exception():
     for r in above:
         print(f"   {r['what']}: err {r['plain_err_vs_fp32_oracle']:.3e} <= derived bound {r['tol']:.3e}")
         assert r["branch"] == "derived-bound" and "linear.b" in r["what"], r
-        assert r["plain_err_vs_fp32_oracle"] <= r["tol"], r
+        assert r["plain_err_vs_fp32_oracle"] <= r["tol"] <= 1e-3, r  # (the derived bound is capped: tests/test_gpu_stacks.py DERIVED_BOUND_CAP)
     assert len(above) <= MAX_DERIVED_BOUND_CHECKS, len(above)
