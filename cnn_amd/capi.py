@@ -628,6 +628,24 @@ def prepare_filters(convs, weights, biases, fwd_bufs, dgrad_bufs):
                                             arr(dgrad_bufs) if dgrad_bufs else None, _stream()), "cnn_conv2d_prepare_filters")
 
 
+def sgd_update(params, grads, lr, grad_scale=1.0):
+    _need_gpu(params, grads)
+    check(load().cnn_sgd_update(_ptr(params), _ptr(grads), params.numel(), float(lr), float(grad_scale), _stream()), "cnn_sgd_update")
+    return params
+
+
+def softmax_xent(logits, labels, want_probs=True):
+    import torch
+
+    _need_gpu(logits, labels)
+    B, n = logits.shape
+    probs = torch.empty_like(logits) if want_probs else None
+    delta = torch.empty_like(logits)
+    loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    check(load().cnn_softmax_xent(_ptr(logits), _ptr(labels), _ptr(probs), _ptr(delta), _ptr(loss), B, n, _stream()), "cnn_softmax_xent")
+    return probs, delta, loss
+
+
 def set_option(name, value):
     """one of the measurement switches of DESIGN.md section 10 (name with or without the CNN_AMD_ prefix); value None removes it.
     The library reads the CNN_AMD_* environment once, at first use: later changes go through here."""
