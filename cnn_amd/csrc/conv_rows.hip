@@ -18,40 +18,11 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "rows_common.h"
 
 using namespace cnn_amd;
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte access at any float address
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
-
-constexpr unsigned kOob = 0x80000000u;
-__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float* lds) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_ptr)lds, 16, (int)voff, (int)soff, 0, 0);
-}
-
-// The accumulating MFMA as inline assembly, destination = addend, both in AGPRs.  Through the builtin the register allocator is free to
-// give the result another register than the addend; across the unrolled stage loop that ended in a rotation of the whole accumulator file
-// at every back edge (~100 v_accvgpr_mov / read / write per stage in the round-5 ISA, 10 - 15 % of a stage).  What the compiler's hazard
-// recogniser would have done for a builtin is written out: s_nop 1 in front (VALU / v_accvgpr_write result -> MFMA operand: 2 wait
-// states; hidden behind the previous MFMA's 8 passes), and acc_settle() before anything else reads the accumulators.
-__device__ __forceinline__ void mfma16(f32x4& c, float a, float b) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
-// every accumulator of a[0..N) has left the MFMA pipeline (8 passes + write-back < 32 cycles): the wait sits in the first statement, the
-// others only tie their accumulators behind it (asm volatile statements keep their order)
-template <int N>
-__device__ __forceinline__ void acc_settle(f32x4* a) {
-    static_assert(N >= 7, "at least one group of seven");
-    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(a[4]), "+a"(a[5]), "+a"(a[6]));
-#pragma unroll
-    for (int i = 7; i + 7 <= N; i += 7)
-        asm volatile("" : "+a"(a[i]), "+a"(a[i + 1]), "+a"(a[i + 2]), "+a"(a[i + 3]), "+a"(a[i + 4]), "+a"(a[i + 5]), "+a"(a[i + 6]));
-#pragma unroll
-    for (int i = N - N % 7; i < N; ++i) asm volatile("" : "+a"(a[i]));
-}
 
 struct RowsParams {
     const float* x;     // input tensor [B][C][H][WI]
@@ -69,10 +40,6 @@ struct RowsParams {
 };
 
 constexpr int kCK = 8;
-
-constexpr int stride16(int len) {  // smallest stride >= len that is 16 (mod 32)
-    return len <= 16 ? 16 : (len - 16 + 31) / 32 * 32 + 16;
-}
 
 // RSEL: rows of the staged block that lie below the image hold whatever follows the plane in memory and are selected away on the B operand
 //       (wave-uniform selects, one per B value); without it they are staged as zeros like the rows above the image -- possible when the
@@ -517,7 +484,8 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
     }
 }
 
-// filters -> [co tile][chunk][channel 0..CK-1][tap][QW]; mode 0: forward (w[co][c][tap]); mode 1: data gradient (w[c][m][8 - tap])
+// filters -> [co tile][chunk][channel 0..CK-1][tap][QW]; mode 0: forward (w[co][c][tap]); mode 1: data gradient (w[c][m][8 - tap]); mode 2: the
+// stride-2 data gradient (w[c][m][tap]: transposed, not flipped)
 struct RowsPrepJob {
     const float* w;
     float* wt;
@@ -536,7 +504,8 @@ __device__ inline void rows_prep_body(const RowsPrepJob& q) {
         const int tile = (int)(r / q.nchunk);
         const int m = tile * q.MT + j, c = cc * q.CK + cl;
         float v = 0.f;
-        if (j < q.MT && m < M && c < C) v = q.mode == 0 ? q.w[((size_t)m * q.Ci + c) * 9 + tap] : q.w[((size_t)c * q.Ci + m) * 9 + (8 - tap)];
+        if (j < q.MT && m < M && c < C)
+            v = q.mode == 0 ? q.w[((size_t)m * q.Ci + c) * 9 + tap] : q.w[((size_t)c * q.Ci + m) * 9 + (q.mode == 1 ? 8 - tap : tap)];
         q.wt[i] = v;
     }
 }
@@ -651,18 +620,43 @@ int launch_any(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, hi
 
 namespace cnn_amd {
 
+// conv_rows_s2.hip: the stride-2 sibling is served through the same four entry points (its filter image has the same layout)
+bool s2_info(const cnn_conv2d_desc* d, int mode, int* mt, int* qw, int* nchunk, int* ntiles, size_t* wt_floats);
+int s2_run(const cnn_conv2d_desc* d, int mode, const float* in, const float* image, const float* bias, float* out, float* out_relu,
+           const float* relu_below, hipStream_t s);
+
+// the filter-image job of layer d in `mode`, whichever kernel family serves it
+static bool prep_job(const cnn_conv2d_desc* d, int mode, const float* w, float* image, RowsPrepJob* q, size_t* floats) {
+    int mt, qw, nchunk, ntiles;
+    if (s2_info(d, mode, &mt, &qw, &nchunk, &ntiles, floats)) {
+        // (stride 2, data gradient: filters transposed but NOT flipped -- the kernel picks each parity class's taps by index: mode 2)
+        *q = RowsPrepJob{w, image, d->Co, d->Ci, mode == 0 ? 0 : 2, mt, qw, nchunk, ntiles, 8};
+        return true;
+    }
+    RowsPlan pl;
+    if (!make_rows_plan(d, mode, &pl)) return false;
+    *q = RowsPrepJob{w, image, d->Co, d->Ci, mode, pl.mt, pl.qw, pl.p.nchunk, pl.ntiles, pl.ck};
+    *floats = pl.wt_floats;
+    return true;
+}
+
 // floats of the row kernel's prepared filter image (0: geometry not covered in that mode); mode 0 = forward, 1 = data gradient
 size_t rows_workspace_floats(const cnn_conv2d_desc* d, int mode) {
-    RowsPlan pl;
-    return make_rows_plan(d, mode, &pl) ? pl.wt_floats : 0;
+    static thread_local DescMemo memo[2];  // (called on every launch by the dispatch in conv_igemm.hip)
+    size_t n = 0;
+    if (memo[mode & 1].find(d, &n)) return n;
+    RowsPrepJob q;
+    if (!prep_job(d, mode, nullptr, nullptr, &q, &n)) n = 0;
+    memo[mode & 1].put(d, n);
+    return n;
 }
 // the filter image of layer d in `mode` into `image` (rows_workspace_floats floats, 16-byte aligned)
 int rows_prepare(const cnn_conv2d_desc* d, int mode, const float* w, float* image, hipStream_t s) {
-    RowsPlan pl;
-    if (!make_rows_plan(d, mode, &pl)) return fail(CNN_AMD_E_BADARG, "conv_rows: geometry not covered");
+    RowsPrepJob q;
+    size_t floats = 0;
+    if (!prep_job(d, mode, w, image, &q, &floats)) return fail(CNN_AMD_E_BADARG, "conv_rows: geometry not covered");
     CNN_REQUIRE(w && image && (reinterpret_cast<uintptr_t>(image) & 15) == 0, "conv_rows: filter image must be 16-byte aligned");
-    const RowsPrepJob q{w, image, d->Co, d->Ci, mode, pl.mt, pl.qw, pl.p.nchunk, pl.ntiles, pl.ck};
-    CNN_KLAUNCH(s, "rows_prep", (rows_prep<<<stream_grid(pl.wt_floats, 256), 256, 0, s>>>(q)),
+    CNN_KLAUNCH(s, "rows_prep", (rows_prep<<<stream_grid(floats, 256), 256, 0, s>>>(q)),
                 "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W, d->Co, d->k, d->s, d->pad);
     return CNN_AMD_OK;
 }
@@ -673,11 +667,10 @@ int rows_prepare_batch(int n, const cnn_conv2d_desc* const* d, const int* mode, 
         const int cnt = n - first < kMaxRowsPrepJobs ? n - first : kMaxRowsPrepJobs;
         size_t most = 0;
         for (int i = 0; i < cnt; ++i) {
-            RowsPlan pl;
-            if (!make_rows_plan(d[first + i], mode[first + i], &pl)) return fail(CNN_AMD_E_BADARG, "conv_rows: geometry not covered");
+            size_t floats = 0;
+            if (!prep_job(d[first + i], mode[first + i], w[first + i], image[first + i], &b.job[i], &floats)) return fail(CNN_AMD_E_BADARG, "conv_rows: geometry not covered");
             CNN_REQUIRE(w[first + i] && image[first + i] && (reinterpret_cast<uintptr_t>(image[first + i]) & 15) == 0, "conv_rows: filter image must be 16-byte aligned");
-            b.job[i] = RowsPrepJob{w[first + i], image[first + i], d[first + i]->Co, d[first + i]->Ci, mode[first + i], pl.mt, pl.qw, pl.p.nchunk, pl.ntiles, pl.ck};
-            most = pl.wt_floats > most ? pl.wt_floats : most;
+            most = floats > most ? floats : most;
         }
         unsigned gx = (unsigned)((most + 255) / 256);
         if (gx > 2048) gx = 2048;
@@ -688,6 +681,7 @@ int rows_prepare_batch(int n, const cnn_conv2d_desc* const* d, const int* mode, 
 // forward (mode 0: in = x, out = y and / or y_relu) or data gradient (mode 1: in = dy, out = dx, relu_below nullable) from a prepared image
 int rows_run(const cnn_conv2d_desc* d, int mode, const float* in, const float* image, const float* bias, float* out, float* out_relu,
              const float* relu_below, hipStream_t s) {
+    if (d->s == 2) return s2_run(d, mode, in, image, bias, out, out_relu, relu_below, s);
     RowsPlan pl;
     if (!make_rows_plan(d, mode, &pl)) return fail(CNN_AMD_E_BADARG, "conv_rows: geometry not covered");
     pl.p.x = in; pl.p.wt = image; pl.p.bias = mode == 0 ? bias : nullptr; pl.p.y = out; pl.p.y_relu = out_relu; pl.p.relu_below = relu_below;

@@ -310,6 +310,60 @@ def test_conv2d_row_kernel_vs_oracle(T, case, lib_option):
     assert_close(host(conv.backward_data(dyd, wd)), dx_ref, REL_TOL, "implicit GEMM data gradient")
 
 
+S2_CASES = [
+    (3, 16, 55, 55, 32, 3, 2, 0),     # conv_layer_2 of the reference net (alexnet.cpp:17): 27x27 outputs flat-packed in units of 7 rows; data gradient in 28x28 domains
+    (2, 32, 27, 27, 64, 3, 2, 0),     # conv_layer_3: 13x13 outputs, units of 7 rows (ragged last unit of 6)
+    (5, 64, 13, 13, 128, 3, 2, 0),    # conv_layer_4: 6x6 outputs, the planes of two samples per unit (odd batch: the last unit holds one)
+    (2, 24, 55, 55, 40, 3, 2, 0),     # ... partial channel tiles (40 of 64 forward, 24 of 32 backward), 3 / 5 channel chunks
+    (3, 40, 13, 13, 72, 3, 2, 0),
+    (2, 64, 56, 56, 128, 3, 2, 1),    # stage entries of the ResNet-shaped stack: pad 1 (halo row above / column left of the image)
+    (2, 128, 28, 28, 256, 3, 2, 1),
+    (3, 256, 14, 14, 512, 3, 2, 1),   # ... 7x7 outputs, two samples per unit, odd batch
+    (1, 72, 14, 14, 136, 3, 2, 1),    # ... partial tiles, one sample
+    (2, 8, 28, 28, 24, 3, 2, 1),      # ... one channel chunk
+]
+
+
+@pytest.mark.parametrize("case", S2_CASES, ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_conv2d_stride2_row_kernel_vs_oracle(T, case, lib_option):
+    """conv_rows_s2.hip (round 6: LDS-staged 3x3 / stride-2 forward and data gradient, conv2d.cpp:69-92 / 168-199 with the reference's
+    default stride) against the oracle: default dispatch, then with one workgroup walking every unit of the launch (the unit loop's
+    cross-unit prefetch and ragged last units in the middle of a walk), with the fused ReLU / ReLU' epilogues; and against the kernels it
+    replaces on these geometries (CNN_AMD_CONV_S2=0)"""
+    from cnn_amd import capi
+
+    x, w, b, dy = _conv_inputs(case, 540)
+    y_ref, _, _, dx_ref = _oracle_conv(case, x, w, b, dy)
+    conv = capi.Conv2d(*case)
+    xd, wd, bd, dyd = dev(T, x), dev(T, w), dev(T, b), dev(T, dy)
+    relu_in = capi.relu_forward(xd - 0.5)  # the output of a ReLU layer in front (half of it blocked)
+    for blocks in (None, "1"):
+        lib_option("S2_BLOCKS", blocks)
+        capi.kernel_timing(1)
+        y = T.full(conv.out_shape(), 7.0, device="cuda")
+        conv.forward(xd, wd, bd, y)
+        dx = T.full_like(xd, 7.0)
+        conv.backward_data(dyd, wd, dx)
+        y2, r2 = T.full_like(y, 7.0), T.full_like(y, 7.0)
+        conv.forward_relu(xd, wd, bd, y2, r2)
+        dxm = T.full_like(xd, 7.0)
+        conv.backward_data_relu(dyd, wd, relu_in, dxm)
+        T.cuda.synchronize()
+        names = [k.split("|")[0] for k in capi.kernel_timing_report()]
+        capi.kernel_timing(0)
+        assert sum(n.startswith("conv_s2<") for n in names) == 4, names
+        tag = "default grid" if blocks is None else "one workgroup walks every unit"
+        assert_close(host(y), y_ref, REL_TOL, f"stride-2 row kernel forward, {tag}")
+        assert_close(host(dx), dx_ref, REL_TOL, f"stride-2 row kernel data gradient, {tag}")
+        assert_close(host(y2), y_ref, REL_TOL, f"stride-2 row kernel forward + ReLU, pre-activation, {tag}")
+        assert np.array_equal(host(r2), np.where(host(y2) >= 0, host(y2), np.float32(0)))  # relu.cpp:25 on the same sums
+        assert_close(host(dxm), np.where(host(relu_in) <= 0, np.float32(0), dx_ref), REL_TOL, f"stride-2 row kernel data gradient + ReLU', {tag}")
+    lib_option("S2_BLOCKS", None)
+    lib_option("CONV_S2", "0")
+    assert_close(host(conv.forward(xd, wd, bd)), y_ref, REL_TOL, "replaced forward kernel")
+    assert_close(host(conv.backward_data(dyd, wd)), dx_ref, REL_TOL, "replaced data-gradient kernel")
+
+
 @pytest.mark.parametrize("case", [(8, 64, 112, 112, 128, 3, 1, 0), (16, 128, 28, 28, 128, 3, 1, 1), (9, 48, 7, 7, 80, 3, 1, 1)],
                          ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
 def test_inline_asm_mfma_kernels_are_bit_reproducible(T, case):
