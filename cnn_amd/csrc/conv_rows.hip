@@ -222,7 +222,6 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
             // the next stage's wait finds them gone
             if (cc != 0 || u == u_lo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            const float* cur = smem + (t & 1) * G::BUF;
             float* nxt = smem + ((t + 1) & 1) * G::BUF;
             // the stage behind this one (behind the last one of the range: that one again)
             const bool last_cc = cc + 1 == p.nchunk;
@@ -233,28 +232,62 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
 #pragma unroll
                 for (int i = 0; i < G::XR; ++i) rowbad |= (r0 - PAD + i >= H ? 1u : 0u) << i;
             }
-            // operands of one k-step (tap, 4-channel group): 2 A values, RW * NB B values -- read one k-step ahead of their MFMAs
+            // operands of one k-step (tap, 4-channel group): MA A values, RW * NB B values.  (round 6) Software-pipelined BY HAND: the reads of
+            // k-step ks + 2 are issued as inline assembly one or two at a time BETWEEN the MFMAs of k-step ks -- with one wave per SIMD the MFMA
+            // pipe only stays busy while this wave issues an MFMA every 32 cycles, and the compiler's placement (every ds_read of a k-step in one
+            // clump in front of its MFMAs, pinned there by an empty asm) left it idle for the 60 - 100 cycles a clump takes to issue.  LDS
+            // returns in order: before the MFMAs of k-step ks only the reads of batch ks + 1 may be in flight (s_waitcnt lgkmcnt: 4 bits).
+            const unsigned par = (unsigned)(t & 1) * (unsigned)(G::BUF * 4);
+            const unsigned bad0 = (unsigned)(b_base * 4) + par, aad = (unsigned)(a_base * 4) + par;
             struct Ops {
                 float a[MA];
                 float b[G::RW][NB];
             };
-            auto read_ops = [&](Ops& o, int ks) {
-                const int tap = ks / G::KSTEPS, s = ks % G::KSTEPS, kx = tap / 3, ky = tap % 3;
+            Ops ops[3];
+            constexpr int NRD = MA + G::RW * NB;  // reads of a batch
+            auto issue_read = [&](auto KS, auto R) {
+                constexpr int ks = decltype(KS)::value, r = decltype(R)::value;
+                constexpr int tap = ks / G::KSTEPS, s = ks % G::KSTEPS, kx = tap / 3, ky = tap % 3;
+                Ops& o = ops[ks % 3];
+                if constexpr (r < MA) {
+                    lds_rd<((s * 36 + tap) * G::QW + r * 16) * 4>(o.a[r], aad);
+                } else {
+                    constexpr int rw = (r - MA) / NB, nb = (r - MA) % NB;
+                    constexpr int imm = s * 4 * G::QXP + (rw * SR + kx) * WI + 16 * nb + ky;
+                    if constexpr (PK > 1) {
+                        // (packed planes: the pad between two staged planes moves the pixels of the later planes; per lane in a block that straddles)
+                        constexpr int PAD3 = G::SP - G::PLANE;
+                        constexpr int lo = (16 * nb) / G::PLANE, hi = (16 * nb + 15) / G::PLANE;
+                        if constexpr (lo == hi) lds_rd<(imm + PAD3 * lo) * 4>(o.b[rw][nb], bad0);
+                        else lds_rd<imm * 4>(o.b[rw][nb], bad0 + (unsigned)(PAD3 * ((16 * nb + n) / G::PLANE)) * 4u);
+                    } else {
+                        lds_rd<imm * 4>(o.b[rw][nb], bad0);
+                    }
+                }
+            };
+            auto issue_batch = [&](auto KS) { static_for<NRD>([&](auto R) { issue_read(KS, R); }); };
+            issue_batch(std::integral_constant<int, 0>());
+            issue_batch(std::integral_constant<int, 1>());
+            static_for<NKS>([&](auto KS) {
+                constexpr int ks = decltype(KS)::value;
+                constexpr int tap = ks / G::KSTEPS, kx = tap / 3, ky = tap % 3;
+                constexpr int nm = MA * G::RW * NB;               // MFMAs of a k-step
+                constexpr int nr2 = ks + 2 < NKS ? NRD : 0;       // reads of batch ks + 2, issued here
+                constexpr int rpm = (nr2 + nm - 1) / nm;
 #pragma unroll
-                for (int ma = 0; ma < MA; ++ma) o.a[ma] = cur[a_base + (s * 36 + tap) * G::QW + ma * 16];
+                for (int k = ks * PER_KS; k < (ks + 1) * PER_KS && k < G::NSLOT; ++k) dma_slot(k, bn, r0n, ccn, nxt);
+                lgkm_wait<(ks + 1 < NKS ? (NRD < 15 ? NRD : 15) : 0)>();
+                Ops& o = ops[ks % 3];
+                // (the values of this batch are defined from here on: nothing that uses them may be scheduled above the wait)
+#pragma unroll
+                for (int ma = 0; ma < MA; ++ma) asm volatile("" : "+v"(o.a[ma]));
 #pragma unroll
                 for (int rw = 0; rw < G::RW; ++rw) {
                     const bool bad = PAD > 0 && RSEL && ((rowbad >> (wr * G::RW + rw + kx)) & 1u);  // (RSEL: SR == 1)
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
-                        // (packed planes: the pad between two staged planes moves the pixels of the later planes; per lane in a block that straddles)
-                        int xtra = 0;
-                        if constexpr (PK > 1) {
-                            constexpr int PAD3 = G::SP - G::PLANE;
-                            const int lo = (16 * nb) / G::PLANE, hi = (16 * nb + 15) / G::PLANE;
-                            xtra = lo == hi ? PAD3 * lo : PAD3 * ((16 * nb + n) / G::PLANE);
-                        }
-                        float bv = cur[b_base + s * 4 * G::QXP + (rw * SR + kx) * WI + 16 * nb + ky + xtra];
+                        float bv = o.b[rw][nb];
+                        asm volatile("" : "+v"(bv));
                         // the tap columns that leave their row (a select: what lies there is the neighbouring row's data)
                         constexpr unsigned kAll = 0xffffu;
                         if constexpr (WP == 1) {
@@ -270,29 +303,16 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
                         o.b[rw][nb] = bv;
                     }
                 }
-            };
-            // read-ahead distance in k-steps: one where a k-step is 28 MFMAs (~900 cycles), two where it is 14 or 7 (a k-step of 7 MFMAs is
-            // shorter than an LDS round trip under load)
-            constexpr int D = MA * G::RW * NB >= 28 ? 1 : 2;
-            Ops ops[D + 1];
-#pragma unroll
-            for (int d = 0; d < D; ++d) read_ops(ops[d], d);
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                if (ks + D < NKS) read_ops(ops[(ks + D) % (D + 1)], ks + D);
-#pragma unroll
-                for (int k = ks * PER_KS; k < (ks + 1) * PER_KS && k < G::NSLOT; ++k) dma_slot(k, bn, r0n, ccn, nxt);
-                Ops& o = ops[ks % (D + 1)];
-                // the reads above may not sink below this point (instruction selection otherwise moves every LDS read down to its first use,
-                // two MFMAs ahead of a full LDS round trip) and the MFMAs below may not rise above it
-                asm volatile("" : "+v"(o.a[0]) : : "memory");
-#pragma unroll
-                for (int rw = 0; rw < G::RW; ++rw)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                        for (int ma = 0; ma < MA; ++ma) mfma16(acc[ma][rw][nb], o.b[rw][nb], o.a[ma]);
-            }
+                static_for<nm>([&](auto IM) {
+                    constexpr int im = decltype(IM)::value, rw = im / (NB * MA), nb = (im / MA) % NB, ma = im % MA;
+                    mfma16(acc[ma][rw][nb], o.b[rw][nb], o.a[ma]);
+                    if constexpr (nr2 > 0)
+                        static_for<rpm>([&](auto J) {
+                            constexpr int r = im * rpm + decltype(J)::value;
+                            if constexpr (r < nr2) issue_read(std::integral_constant<int, (ks + 2 < NKS ? ks + 2 : 0)>(), std::integral_constant<int, r>());
+                        });
+                });
+            });
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the next unit's stage 0, issued early in the last stage: see above)
         acc_settle<MA * G::RW * NB>(&acc[0][0][0]);
@@ -621,16 +641,16 @@ int launch_any(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, hi
 namespace cnn_amd {
 
 // conv_rows_s2.hip: the stride-2 sibling is served through the same four entry points (its filter image has the same layout)
-bool s2_info(const cnn_conv2d_desc* d, int mode, int* mt, int* qw, int* nchunk, int* ntiles, size_t* wt_floats);
+bool s2_info(const cnn_conv2d_desc* d, int mode, int* mt, int* qw, int* ck, int* nchunk, int* ntiles, size_t* wt_floats);
 int s2_run(const cnn_conv2d_desc* d, int mode, const float* in, const float* image, const float* bias, float* out, float* out_relu,
            const float* relu_below, hipStream_t s);
 
 // the filter-image job of layer d in `mode`, whichever kernel family serves it
 static bool prep_job(const cnn_conv2d_desc* d, int mode, const float* w, float* image, RowsPrepJob* q, size_t* floats) {
-    int mt, qw, nchunk, ntiles;
-    if (s2_info(d, mode, &mt, &qw, &nchunk, &ntiles, floats)) {
+    int mt, qw, ck, nchunk, ntiles;
+    if (s2_info(d, mode, &mt, &qw, &ck, &nchunk, &ntiles, floats)) {
         // (stride 2, data gradient: filters transposed but NOT flipped -- the kernel picks each parity class's taps by index: mode 2)
-        *q = RowsPrepJob{w, image, d->Co, d->Ci, mode == 0 ? 0 : 2, mt, qw, nchunk, ntiles, 8};
+        *q = RowsPrepJob{w, image, d->Co, d->Ci, mode == 0 ? 0 : 2, mt, qw, nchunk, ntiles, ck};
         return true;
     }
     RowsPlan pl;

@@ -1,6 +1,9 @@
 // rows_common.h -- device helpers shared by the LDS-staged row kernels (conv_rows.hip: stride 1; conv_rows_s2.hip: stride 2): 16-byte
 // buffer-addressed LDS DMA, the in-place accumulating 16x16x4 fp32 MFMA as inline assembly, and the filter-image job both prepare with.
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 
 namespace {
@@ -41,6 +44,28 @@ __device__ __forceinline__ void acc_settle_n(f32x4* a) {
     asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a[0]));
 #pragma unroll
     for (int i = 1; i < N; ++i) asm volatile("" : "+a"(a[i]));
+}
+
+// compile-time loops (the body gets its index as a std::integral_constant: usable as an immediate operand of inline assembly)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>()), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>());
+}
+// one LDS read with an immediate offset, in program order; the value is NOT there until an lgkm_wait that covers it (the compiler does
+// not know about the pending write: pass the register through an empty asm volatile behind the wait before anything uses it)
+template <int OFF>
+__device__ __forceinline__ void lds_rd(float& dst, unsigned addr_bytes) {
+    static_assert(OFF >= 0 && OFF < 65536, "16-bit immediate");
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr_bytes), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is four bits");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
 }
 
 constexpr int stride16(int len) {  // smallest stride >= len that is 16 (mod 32)

@@ -337,6 +337,7 @@ def test_conv2d_stride2_row_kernel_vs_oracle(T, case, lib_option):
     conv = capi.Conv2d(*case)
     xd, wd, bd, dyd = dev(T, x), dev(T, w), dev(T, b), dev(T, dy)
     relu_in = capi.relu_forward(xd - 0.5)  # the output of a ReLU layer in front (half of it blocked)
+    lib_option("CONV_S2", "2")  # (every instance, also those the default dispatch leaves to the register-direct kernels)
     for blocks in (None, "1"):
         lib_option("S2_BLOCKS", blocks)
         capi.kernel_timing(1)
