@@ -481,6 +481,66 @@ __global__ __launch_bounds__(kChanThreads) void bn_bwd_channel(const float* __re
 }
 
 // BN_CHAN_THREADS=1024: the round-2 workgroup size of the channel kernels (the default; 256 measured: see kChanThreadsMax)
+// (round 6) the same kernel with the channel held in REGISTERS instead of LDS: thread t keeps elements t, t + T, t + 2T, ... (at most EPT of
+// them) of x - mean and dy, so the element -> thread map, every thread's summation order and the block reduction are those of
+// bn_bwd_channel<T> -- bit-identical results -- but the workgroup needs 2 x EPT + ~20 registers per thread and 64 B of LDS instead of
+// 2 x B*H*W floats (100 KB for a 14x14 plane at batch 64).  In the train step these kernels run on the compute stream while the side
+// stream's weight-gradient workgroups (conv_wgrad_sp.hip: 150 KB of LDS each) sit on the CUs: the LDS version could only start on a CU
+// none of them occupied -- 92 - 120 us in the step for a 6 - 13 MB tensor that takes 10 us alone.
+template <int kChanThreads, int EPT>
+__global__ __launch_bounds__(kChanThreads) void bn_bwd_channel_reg(const float* __restrict__ x, float* __restrict__ dy,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ saved_mean,
+                                                                   const float* __restrict__ saved_var, float* __restrict__ ggamma,
+                                                                   float* __restrict__ gbeta, float eps, Geo q) {
+#pragma clang fp contract(off)
+    constexpr int kChanWaves = kChanThreads / kWave;
+    __shared__ float red[kChanWaves * 4];
+    const int c = blockIdx.x;
+    const unsigned n = (unsigned)(q.B * q.HW);
+    const float u = saved_mean[c];
+    const float var_inv = 1.f / sqrtf(saved_var[c] + eps);
+    const float var_inv_3 = var_inv * var_inv * var_inv;
+    const float gm = gamma[c];
+    float xc_r[EPT], d_r[EPT];
+    // every load of the thread is issued before the first one is used
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const unsigned e = threadIdx.x + (unsigned)i * kChanThreads;
+        const size_t at = chan_addr(q, c, e < n ? e : 0);
+        xc_r[i] = x[at];
+        d_r[i] = dy[at];
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const unsigned e = threadIdx.x + (unsigned)i * kChanThreads;
+        if (e < n) {
+            const float xc = xc_r[i] - u, d = d_r[i];
+            xc_r[i] = xc;
+            acc[0] += d * (xc * var_inv);
+            acc[1] += d;
+            acc[2] += (d * gm) * xc * -0.5f * var_inv_3;
+            acc[3] += xc;
+        }
+    }
+    chan_block_sum<4, kChanWaves>(acc, red);
+    const float L = (float)n;
+    const float inv = acc[2] / L;
+    const float u_g = (acc[1] * gm) * (-var_inv) + inv * -2.f * acc[3];
+    const float u_term = u_g / L;
+    if (threadIdx.x == 0) {
+        ggamma[c] = acc[0];
+        gbeta[c] = acc[1];
+    }
+    const float inv2 = inv * 2.f;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const unsigned e = threadIdx.x + (unsigned)i * kChanThreads;
+        if (e < n) dy[chan_addr(q, c, e)] = (d_r[i] * gm) * var_inv + inv2 * xc_r[i] + u_term;
+    }
+}
+
 int chan_threads() { return CNN_OPT_INT("BN_CHAN_THREADS", 1024) >= kChanThreadsMax ? 1024 : 256; }
 
 // the channel kernels take a layer when a channel fits LDS and there are enough channels to spread over the chip
@@ -619,6 +679,17 @@ int cnn_batchnorm2d_backward(const float* x, float* dy, const float* gamma, cons
             CNN_HIP_CHECK(hipFuncSetAttribute((const void*)bn_bwd_channel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             CNN_HIP_CHECK(hipFuncSetAttribute((const void*)bn_bwd_channel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             attr_once.mark();
+        }
+        // (round 6) register-resident channels: same results bit for bit, no LDS to wait for beside the weight gradients
+        if (chan_threads() == 1024 && CNN_OPT_INT("BN_BWD_LDS", 0) == 0) {
+            const long long nel = (long long)B * H * W;
+            if (nel <= 1024 * 4)
+                CNN_KLAUNCH(s, "bn_bwd_channel_reg", (bn_bwd_channel_reg<1024, 4><<<C, 1024, 0, s>>>(x, dy, gamma, saved_mean, saved_var, ggamma, gbeta, eps, q)), BN_TAG);
+            else if (nel <= 1024 * 8)
+                CNN_KLAUNCH(s, "bn_bwd_channel_reg", (bn_bwd_channel_reg<1024, 8><<<C, 1024, 0, s>>>(x, dy, gamma, saved_mean, saved_var, ggamma, gbeta, eps, q)), BN_TAG);
+            else
+                CNN_KLAUNCH(s, "bn_bwd_channel_reg", (bn_bwd_channel_reg<1024, 16><<<C, 1024, 0, s>>>(x, dy, gamma, saved_mean, saved_var, ggamma, gbeta, eps, q)), BN_TAG);
+            return CNN_AMD_OK;
         }
         if (chan_threads() == 1024)
             CNN_KLAUNCH(s, "bn_bwd_channel",

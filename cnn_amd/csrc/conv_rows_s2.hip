@@ -444,10 +444,13 @@ struct S2Inst {
 //                              data gradient (+ ReLU'): 65 / 36, 49 / 32, 66 / 42 alone -- these layers are HBM-bound (0.5 MFLOP per output KB) and a
 //                              kernel whose four waves per CU compute and store in lockstep leaves HBM idle while it computes: the register-direct
 //                              kernels (many small workgroups, phases naturally interleaved) keep them
+//                              IN THE STEP the forward instances lose too although they win alone (A/B on one box, 27- and 13-wide forward on:
+//                              624 k against 643 k images/s): a workgroup that owns a CU's LDS shuts out the deferred first-layer data gradient
+//                              that the step overlaps with these layers.  The reference net's layers stay where they were.
 //   ResNet-shaped, batch 64    forward 83.7 / 107 (56-wide), 88.6 / 132 (14-wide); data gradient + ReLU' 102 / 104, 161 / 168 alone
 constexpr S2Inst kInst[] = {
     // reference net behind its first block (alexnet.cpp:17-29), batch 256: 16 -> 32 @ 55, 32 -> 64 @ 27, 64 -> 128 @ 13, pad 0
-    {0, 55, 55, 0, 2, 14, 1, 8, 0}, {0, 27, 27, 0, 4, 13, 1, 8, 1}, {0, 13, 13, 0, 4, 6, 2, 16, 1},
+    {0, 55, 55, 0, 2, 14, 1, 8, 0}, {0, 27, 27, 0, 4, 13, 1, 8, 0}, {0, 13, 13, 0, 4, 6, 2, 16, 0},
     {1, 55, 55, 0, 1, 14, 1, 16, 0}, {1, 27, 27, 0, 2, 14, 1, 16, 0}, {1, 13, 13, 0, 4, 7, 2, 16, 0},
     // stage entries of the ResNet-shaped stack, batch 64: 64 -> 128 @ 56, 128 -> 256 @ 28, 256 -> 512 @ 14, pad 1
     {0, 56, 56, 1, 4, 7, 1, 8, 1}, {0, 28, 28, 1, 4, 14, 1, 8, 1}, {0, 14, 14, 1, 4, 7, 2, 16, 1},

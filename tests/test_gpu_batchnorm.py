@@ -37,7 +37,7 @@ BN_SHAPES = [(2, 16, 111, 111), (3, 32, 27, 27), (4, 64, 13, 13), (5, 128, 6, 6)
 
 
 @pytest.mark.parametrize("shape", BN_SHAPES, ids=lambda s: "x".join(map(str, s)))
-def test_batchnorm_train_forward_backward_vs_oracle(T, shape):
+def test_batchnorm_train_forward_backward_vs_oracle(T, shape, lib_option):
     from cnn_amd import capi
 
     B, C, H, W = shape
@@ -78,6 +78,13 @@ def test_batchnorm_train_forward_backward_vs_oracle(T, shape):
     g2, b2 = T.empty_like(ggd), T.empty_like(gbd)
     bn.backward(xd, dy2, gd, g2, b2)
     assert T.equal(y2, yd) and T.equal(dy2, dyd) and T.equal(g2, ggd) and T.equal(b2, gbd) and T.equal(mm2, mmd)
+    # (round 6) the one-workgroup-per-channel backward keeps its channel in registers; the LDS-resident form it replaces (same element ->
+    # thread map, same summation order) gives the same bits
+    lib_option("BN_BWD_LDS", "1")
+    dy3, g3, b3 = dev(T, dy), T.empty_like(ggd), T.empty_like(gbd)
+    bn.backward(xd, dy3, gd, g3, b3)
+    assert T.equal(dy3, dyd) and T.equal(g3, ggd) and T.equal(b3, gbd)
+    lib_option("BN_BWD_LDS", None)
 
     # BatchNorm2D -> ReLU from one pass (cnn_batchnorm2d_forward_relu): y unchanged bit for bit, y_relu = relu(y) (relu.cpp:25),
     # in training and in evaluation
