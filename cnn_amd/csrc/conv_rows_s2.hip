@@ -367,47 +367,84 @@ __global__ __launch_bounds__(256) void conv_s2_kernel(const S2Params p) {
             // block; two neighbours of one domain row are FOUR consecutive floats of a dx row (both column classes): one 16-byte store (and one
             // 16-byte load of the ReLU' mask) per pixel pair and row class.  (Scalar stores -- 64 different cache lines per instruction --
             // made the first version's epilogue three times as long as its MFMA loop.)
+            // The masks of GN blocks (4 GN 16-byte loads per lane) are fetched as ONE batch before any of them is used: written as load -> select
+            // -> store per tile the loads could not be moved above the previous tile's store (the compiler must assume y and relu_below alias),
+            // and every tile paid a full memory round trip.
+            constexpr int GN = 2;
+            struct Pair {
+                bool fast[2];
+                size_t at[2], at1[2];
+                bool ok, ok1;
+                int y[2], y1[2], x, x1;
+            };
+            auto pair_of = [&](int nb, int q) {
+                Pair g;
+                const int f = 16 * (wp * NBW + nb) + 4 * kq + 2 * q;
+                const int sp = f / G::PXS, rem = f - sp * G::PXS, r = rem / G::DW, c = rem - r * G::DW;
+                g.ok = co < p.M && f < G::PX && b + sp < p.B;
+                // the pair's second pixel: same row unless the first one is a row's last (odd domain widths only)
+                const bool same = G::DW % 2 == 0 || c + 1 < G::DW;
+                int sp1 = sp, r1 = r, c1 = c + 1;
+                if (!same) { c1 = 0; r1 = r + 1; if (r1 == RPU) { r1 = 0; sp1 = sp + 1; } }
+                g.ok1 = co < p.M && f + 1 < G::PX && b + sp1 < p.B;
+                g.x = 2 * c; g.x1 = 2 * c1;
 #pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) {
+                for (int py = 0; py < 2; ++py) {
+                    g.y[py] = 2 * (r0 + r) + py; g.y1[py] = 2 * (r0 + r1) + py;
+                    g.at[py] = ((size_t)(b + sp) * p.M + co) * OHW + (size_t)g.y[py] * G::OW + g.x;
+                    g.at1[py] = ((size_t)(b + sp1) * p.M + co) * OHW + (size_t)g.y1[py] * G::OW + g.x1;
+                    g.fast[py] = g.ok && g.ok1 && same && g.y[py] < G::OH && g.x + 3 < G::OW;
+                }
+                return g;
+            };
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int f = 16 * (wp * NBW + nb) + 4 * kq + 2 * q;
-                    const int sp = f / G::PXS, rem = f - sp * G::PXS, r = rem / G::DW, c = rem - r * G::DW;
-                    const bool ok = co < p.M && f < G::PX && b + sp < p.B;
-                    // the pair's second pixel: same row unless the first one is a row's last (odd domain widths only)
-                    const bool same = G::DW % 2 == 0 || c + 1 < G::DW;
-                    int sp1 = sp, r1 = r, c1 = c + 1;
-                    if (!same) { c1 = 0; r1 = r + 1; if (r1 == RPU) { r1 = 0; sp1 = sp + 1; } }
-                    const bool ok1 = co < p.M && f + 1 < G::PX && b + sp1 < p.B;
+            for (int nb0 = 0; nb0 < NBW; nb0 += GN) {
+                f32x4 mk[GN][2][2];
+                if (p.relu_below != nullptr) {
 #pragma unroll
-                    for (int py = 0; py < 2; ++py) {
-                        const int y = 2 * (r0 + r) + py, x = 2 * c;
-                        const size_t at = ((size_t)(b + sp) * p.M + co) * OHW + (size_t)y * G::OW + x;
-                        f32x4 v{acc[py * 2 + 0][nb][2 * q], acc[py * 2 + 1][nb][2 * q], acc[py * 2 + 0][nb][2 * q + 1], acc[py * 2 + 1][nb][2 * q + 1]};
-                        if (ok && ok1 && same && y < G::OH && x + 3 < G::OW) {
-                            if (p.relu_below != nullptr) {
-                                const f32x4 mk = *(const f32x4u*)(p.relu_below + at);
+                    for (int i = 0; i < GN; ++i)
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = mk[e] <= 0.f ? 0.f : v[e];
+                        for (int q = 0; q < 2; ++q) {
+                            if (nb0 + i >= NBW) continue;
+                            const Pair g = pair_of(nb0 + i, q);
+#pragma unroll
+                            for (int py = 0; py < 2; ++py) {
+                                mk[i][q][py] = f32x4{1.f, 1.f, 1.f, 1.f};
+                                if (g.fast[py]) mk[i][q][py] = *(const f32x4u*)(p.relu_below + g.at[py]);
                             }
-                            *(f32x4u*)(p.y + at) = v;
-                        } else {
-                            const int y1 = 2 * (r0 + r1) + py, x1 = 2 * c1;
-                            const size_t at1 = ((size_t)(b + sp1) * p.M + co) * OHW + (size_t)y1 * G::OW + x1;
+                        }
+                }
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const bool second = e >= 2;
-                                const bool good = second ? (ok1 && y1 < G::OH && x1 + (e & 1) < G::OW) : (ok && y < G::OH && x + (e & 1) < G::OW);
-                                if (good) {
-                                    const size_t a1 = (second ? at1 : at) + (e & 1);
-                                    float val = v[e];
-                                    if (p.relu_below != nullptr) val = p.relu_below[a1] <= 0.f ? 0.f : val;
-                                    p.y[a1] = val;
+                for (int i = 0; i < GN; ++i)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int nb = nb0 + i;
+                        if (nb >= NBW) continue;
+                        const Pair g = pair_of(nb, q);
+#pragma unroll
+                        for (int py = 0; py < 2; ++py) {
+                            f32x4 v{acc[py * 2 + 0][nb][2 * q], acc[py * 2 + 1][nb][2 * q], acc[py * 2 + 0][nb][2 * q + 1], acc[py * 2 + 1][nb][2 * q + 1]};
+                            if (g.fast[py]) {
+                                if (p.relu_below != nullptr) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = mk[i][q][py][e] <= 0.f ? 0.f : v[e];
+                                }
+                                *(f32x4u*)(p.y + g.at[py]) = v;
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const bool second = e >= 2;
+                                    const bool good = second ? (g.ok1 && g.y1[py] < G::OH && g.x1 + (e & 1) < G::OW) : (g.ok && g.y[py] < G::OH && g.x + (e & 1) < G::OW);
+                                    if (good) {
+                                        const size_t a1 = (second ? g.at1[py] : g.at[py]) + (e & 1);
+                                        float val = v[e];
+                                        if (p.relu_below != nullptr) val = p.relu_below[a1] <= 0.f ? 0.f : val;
+                                        p.y[a1] = val;
+                                    }
                                 }
                             }
                         }
                     }
-                }
             }
         }
         zero_acc();
@@ -451,10 +488,10 @@ struct S2Inst {
 constexpr S2Inst kInst[] = {
     // reference net behind its first block (alexnet.cpp:17-29), batch 256: 16 -> 32 @ 55, 32 -> 64 @ 27, 64 -> 128 @ 13, pad 0
     {0, 55, 55, 0, 2, 14, 1, 8, 0}, {0, 27, 27, 0, 4, 13, 1, 8, 0}, {0, 13, 13, 0, 4, 6, 2, 16, 0},
-    {1, 55, 55, 0, 1, 14, 1, 16, 0}, {1, 27, 27, 0, 2, 14, 1, 16, 0}, {1, 13, 13, 0, 4, 7, 2, 16, 0},
+    {1, 55, 55, 0, 1, 14, 1, 16, 0}, {1, 27, 27, 0, 2, 14, 1, 16, 0}, {1, 13, 13, 0, 4, 7, 1, 16, 0},
     // stage entries of the ResNet-shaped stack, batch 64: 64 -> 128 @ 56, 128 -> 256 @ 28, 256 -> 512 @ 14, pad 1
     {0, 56, 56, 1, 4, 7, 1, 8, 1}, {0, 28, 28, 1, 4, 14, 1, 8, 1}, {0, 14, 14, 1, 4, 7, 2, 16, 1},
-    {1, 56, 56, 1, 4, 4, 1, 16, 0}, {1, 28, 28, 1, 2, 14, 1, 16, 1}, {1, 14, 14, 1, 4, 7, 2, 16, 1},
+    {1, 56, 56, 1, 4, 4, 1, 16, 0}, {1, 28, 28, 1, 2, 14, 1, 16, 1}, {1, 14, 14, 1, 4, 7, 1, 16, 1},
 };
 constexpr int kNumInst = (int)(sizeof(kInst) / sizeof(kInst[0]));
 
