@@ -957,16 +957,7 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
             return reduce_slabs(sc, (const float*)ws, c1s, n, (float*)ws + (size_t)c1s * n, gw, divisor, tagc, d->Ci, gb);
         }
     }
-    if (const int oss = os_wgrad_slots(d)) {
-        const size_t n = (size_t)d->Co * (d->Ci * 9 + 1), need_o = (size_t)(oss + (oss + 63) / 64) * n * sizeof(float);
-        if (ws_bytes >= need_o) {
-            hipStream_t so = as_stream(stream);
-            if (int rc = os_wgrad_launch(d, x, dy, (float*)ws, so)) return rc;
-            char tago[160];
-            snprintf(tago, sizeof(tago), CONV_TAG(d));
-            return reduce_slabs(so, (const float*)ws, oss, n, (float*)ws + (size_t)oss * n, gw, divisor, tago, d->Ci * 9, gb);
-        }
-    }
+    // (the LDS-staged small-plane kernels first: for the reference net's stride-2 shapes they apply only when asked for, WGRAD_SP2=2)
     if (const int sps = sp_wgrad_slots(d)) {
         const size_t n = (size_t)d->Co * (d->Ci * 9 + 1), need_p = (size_t)(sps + (sps + 63) / 64) * n * sizeof(float);
         if (ws_bytes >= need_p) {
@@ -975,6 +966,16 @@ int cnn_conv2d_backward_weight(const cnn_conv2d_desc* d, const float* x, const f
             char tagp[160];
             snprintf(tagp, sizeof(tagp), CONV_TAG(d));
             return reduce_slabs(sp, (const float*)ws, sps, n, (float*)ws + (size_t)sps * n, gw, divisor, tagp, d->Ci * 9, gb);
+        }
+    }
+    if (const int oss = os_wgrad_slots(d)) {
+        const size_t n = (size_t)d->Co * (d->Ci * 9 + 1), need_o = (size_t)(oss + (oss + 63) / 64) * n * sizeof(float);
+        if (ws_bytes >= need_o) {
+            hipStream_t so = as_stream(stream);
+            if (int rc = os_wgrad_launch(d, x, dy, (float*)ws, so)) return rc;
+            char tago[160];
+            snprintf(tago, sizeof(tago), CONV_TAG(d));
+            return reduce_slabs(so, (const float*)ws, oss, n, (float*)ws + (size_t)oss * n, gw, divisor, tago, d->Ci * 9, gb);
         }
     }
     if (rd_wanted(d)) {

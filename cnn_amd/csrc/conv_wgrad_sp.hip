@@ -432,13 +432,19 @@ int launch_sp(const SpPlan& pl, const cnn_conv2d_desc* d, hipStream_t s) {
 
 namespace cnn_amd {
 
+// conv_wgrad_sp2.hip: the stride-2 sibling is served through the same two entry points
+int sp2_wgrad_slots(const cnn_conv2d_desc* d);
+int sp2_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
+
 // number of partial slabs ([Co][Ci*9 + 1] floats each) the kernel writes, 0 when the geometry is not covered
 int sp_wgrad_slots(const cnn_conv2d_desc* d) {
+    if (d->s == 2) return sp2_wgrad_slots(d);
     SpPlan pl;
     return make_sp_plan(d, &pl) ? pl.kblocks : 0;
 }
 
 int sp_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s) {
+    if (d->s == 2) return sp2_wgrad_launch(d, x, dy, slabs, s);
     SpPlan pl;
     if (!make_sp_plan(d, &pl)) return fail(CNN_AMD_E_BADARG, "wgrad_sp: geometry not covered");
     pl.p.x = x; pl.p.dy = dy; pl.p.slabs = slabs;

@@ -228,6 +228,56 @@ def test_conv2d_wgrad_small_planes(T, case, unit, lib_option):
     assert_close(host(gw3), gw_ref, REL_TOL, "register-direct weight grad")
 
 
+SP2_CASES = [
+    (2, 64, 56, 56, 128, 3, 2, 1),   # stage entry of the ResNet-shaped stack: 28 row pairs, 32-channel ci tiles, two waves split a row's four segments
+    (1, 40, 56, 56, 72, 3, 2, 1),    # ... partial tiles (32 + 8 input channels, 64 + 8 output channels)
+    (2, 128, 28, 28, 64, 3, 2, 1),   # 28-wide: rows of 14 pixels = two segments, seven row pairs per plane
+    (3, 24, 28, 28, 100, 3, 2, 1),   # ... partial tiles, odd batch
+    (2, 64, 14, 14, 128, 3, 2, 1),   # 14-wide: the whole plane per stage, 7 output rows in 8 row slots (the last one selected away)
+    (5, 72, 14, 14, 40, 3, 2, 1),    # ... partial tiles, more stages than workgroups per tile need
+    (2, 32, 27, 27, 64, 3, 2, 0),    # the reference's own geometry (pad 0, conv2d.cpp:41-42): rows of 13 = segments of 7 + 6, 13 rows in pairs
+    (3, 64, 13, 13, 128, 3, 2, 0),   # ... rows of 6, the whole plane per stage
+    (70, 64, 14, 14, 64, 3, 2, 1),   # several stages per workgroup
+]
+
+
+@pytest.mark.parametrize("case", SP2_CASES, ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_conv2d_wgrad_small_planes_stride2(T, case, lib_option):
+    """conv_wgrad_sp2.hip (the stride-2 sibling of the LDS-staged output-stationary weight gradient; cpu/src/conv2d.cpp:117-159 with the
+    window walk of conv2d.cpp:76-77) against the oracle, on 16-byte aligned and unaligned tensors, and against the kernel it replaces"""
+    from cnn_amd import capi
+
+    lib_option("WGRAD_SP2", "2")  # (every instance, any channel count)
+    x, w, b, dy = _conv_inputs(case, 470)
+    _, gw_ref, gb_ref, _ = _oracle_conv(case, x, w, b, dy)
+    conv = capi.Conv2d(*case)
+    xd, dyd = dev(T, x), dev(T, dy)
+    capi.kernel_timing(1)
+    gw, gb = conv.backward_weight(xd, dyd, float(case[0]))
+    T.cuda.synchronize()
+    rep = capi.kernel_timing_report()
+    capi.kernel_timing(0)
+    assert any(k.startswith("wgrad_sp2<") for k in rep), list(rep)
+    assert_close(host(gw), gw_ref, REL_TOL, "weight grad")
+    assert_close(host(gb), gb_ref, REL_TOL, "bias grad")
+    # the same tensors one float further: the DMA sources need 4-byte alignment only -- same sums in the same order
+    xs = T.empty(xd.numel() + 1, device="cuda")[1:].view_as(xd).copy_(xd)
+    dys = T.empty(dyd.numel() + 1, device="cuda")[1:].view_as(dyd).copy_(dyd)
+    assert xs.data_ptr() % 16 != 0
+    gw2, gb2 = conv.backward_weight(xs, dys, float(case[0]))
+    assert np.array_equal(host(gw), host(gw2)) and np.array_equal(host(gb), host(gb2))
+    # a tensor whose neighbours in memory are NaN: nothing outside it may reach a sum (rows staged past a plane's end are selected away)
+    big = T.full((xd.numel() + 4096,), float("nan"), device="cuda")
+    xn = big[2048 : 2048 + xd.numel()].view_as(xd).copy_(xd)
+    bigd = T.full((dyd.numel() + 4096,), float("nan"), device="cuda")
+    dyn = bigd[2048 : 2048 + dyd.numel()].view_as(dyd).copy_(dyd)
+    gw4, gb4 = conv.backward_weight(xn, dyn, float(case[0]))
+    assert np.array_equal(host(gw), host(gw4)) and np.array_equal(host(gb), host(gb4))
+    lib_option("WGRAD_SP2", "0")
+    gw3, gb3 = conv.backward_weight(xd, dyd, float(case[0]))
+    assert_close(host(gw3), gw_ref, REL_TOL, "the replaced kernel's weight grad")
+
+
 @pytest.mark.parametrize("case", [SP_CASES[i] for i in (0, 2, 3, 5, 7)] + [(4, 16, 55, 55, 32, 3, 2, 0), (3, 64, 13, 13, 128, 3, 2, 0), (2, 32, 27, 27, 64, 3, 2, 0)],
                          ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
 def test_flat_slab_reduction_is_bit_identical_to_the_workgroup_one(T, case, lib_option):
