@@ -243,12 +243,15 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
                 float a[MA];
                 float b[G::RW][NB];
             };
-            Ops ops[3];
             constexpr int NRD = MA + G::RW * NB;  // reads of a batch
+            // look-ahead of the operand ring: two k-steps -- or one where a batch is large (the tall units of the batch-64 layers: 50 reads = 49
+            // MFMAs = 1500 cycles of cover for the LDS latency, and three batches of 50 registers would not fit beside 196 accumulators)
+            constexpr int LA = NRD > 32 ? 1 : 2;
+            Ops ops[LA + 1];
             auto issue_read = [&](auto KS, auto R) {
                 constexpr int ks = decltype(KS)::value, r = decltype(R)::value;
                 constexpr int tap = ks / G::KSTEPS, s = ks % G::KSTEPS, kx = tap / 3, ky = tap % 3;
-                Ops& o = ops[ks % 3];
+                Ops& o = ops[ks % (LA + 1)];
                 if constexpr (r < MA) {
                     lds_rd<((s * 36 + tap) * G::QW + r * 16) * 4>(o.a[r], aad);
                 } else {
@@ -267,17 +270,17 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
             };
             auto issue_batch = [&](auto KS) { static_for<NRD>([&](auto R) { issue_read(KS, R); }); };
             issue_batch(std::integral_constant<int, 0>());
-            issue_batch(std::integral_constant<int, 1>());
+            if constexpr (LA == 2) issue_batch(std::integral_constant<int, 1>());
             static_for<NKS>([&](auto KS) {
                 constexpr int ks = decltype(KS)::value;
                 constexpr int tap = ks / G::KSTEPS, kx = tap / 3, ky = tap % 3;
                 constexpr int nm = MA * G::RW * NB;               // MFMAs of a k-step
-                constexpr int nr2 = ks + 2 < NKS ? NRD : 0;       // reads of batch ks + 2, issued here
+                constexpr int nr2 = ks + LA < NKS ? NRD : 0;      // reads of batch ks + LA, issued here
                 constexpr int rpm = (nr2 + nm - 1) / nm;
 #pragma unroll
                 for (int k = ks * PER_KS; k < (ks + 1) * PER_KS && k < G::NSLOT; ++k) dma_slot(k, bn, r0n, ccn, nxt);
-                lgkm_wait<(ks + 1 < NKS ? (NRD < 15 ? NRD : 15) : 0)>();
-                Ops& o = ops[ks % 3];
+                lgkm_wait<(LA == 2 && ks + 1 < NKS ? (NRD < 15 ? NRD : 15) : 0)>();
+                Ops& o = ops[ks % (LA + 1)];
                 // (the values of this batch are defined from here on: nothing that uses them may be scheduled above the wait)
 #pragma unroll
                 for (int ma = 0; ma < MA; ++ma) asm volatile("" : "+v"(o.a[ma]));
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
                     if constexpr (nr2 > 0)
                         static_for<rpm>([&](auto J) {
                             constexpr int r = im * rpm + decltype(J)::value;
-                            if constexpr (r < nr2) issue_read(std::integral_constant<int, (ks + 2 < NKS ? ks + 2 : 0)>(), std::integral_constant<int, r>());
+                            if constexpr (r < nr2) issue_read(std::integral_constant<int, (ks + LA < NKS ? ks + LA : 0)>(), std::integral_constant<int, r>());
                         });
                 });
             });
@@ -441,31 +444,29 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
                         }
                         continue;
                     }
-                    f32x4 mk[G::RW][NB];
-                    int nval[G::RW][NB];
+                    // (per super-row: the masks of its NB tiles as one batch of loads, then its stores -- RW x NB of them at once would be
+                    //  245 registers on the tall units)
 #pragma unroll
                     for (int rw = 0; rw < G::RW; ++rw) {
+                        f32x4 mk[NB];
+                        int nval[NB];
                         const int row0 = r0E + (wr * G::RW + rw) * SR;
                         const int lim0 = (p.HO - row0) * WO, lim = lim0 < G::PX ? lim0 : G::PX;  // pixels of the super-row inside the image
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
                             const int f = 16 * (wp * G::NBW + nb) + 4 * kq;
-                            nval[rw][nb] = co < p.M ? lim - f : 0;
-                            mk[rw][nb] = f32x4{1.f, 1.f, 1.f, 1.f};
+                            nval[nb] = co < p.M ? lim - f : 0;
+                            mk[nb] = f32x4{1.f, 1.f, 1.f, 1.f};
                             if (p.relu_below != nullptr) {
                                 const float* m = p.relu_below + cbase + (size_t)row0 * WO + f;
-                                if (nval[rw][nb] >= 4) mk[rw][nb] = *(const f32x4u*)m;
+                                if (nval[nb] >= 4) mk[nb] = *(const f32x4u*)m;
                                 else {
 #pragma unroll
                                     for (int e = 0; e < 3; ++e)
-                                        if (e < nval[rw][nb]) mk[rw][nb][e] = m[e];
+                                        if (e < nval[nb]) mk[nb][e] = m[e];
                                 }
                             }
                         }
-                    }
-#pragma unroll
-                    for (int rw = 0; rw < G::RW; ++rw) {
-                        const int row0 = r0E + (wr * G::RW + rw) * SR;
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
                             const int f = 16 * (wp * G::NBW + nb) + 4 * kq;
@@ -474,16 +475,16 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 v[e] = acc[ma][rw][nb][e] + bs;
-                                if (p.relu_below != nullptr) v[e] = mk[rw][nb][e] <= 0.f ? 0.f : v[e];
+                                if (p.relu_below != nullptr) v[e] = mk[nb][e] <= 0.f ? 0.f : v[e];
                                 vr[e] = v[e] >= 0.f ? v[e] : 0.f;
                             }
-                            if (nval[rw][nb] >= 4) {
+                            if (nval[nb] >= 4) {
                                 if (p.y != nullptr) *(f32x4u*)(p.y + at) = v;
                                 if (p.y_relu != nullptr) *(f32x4u*)(p.y_relu + at) = vr;
                             } else {
 #pragma unroll
                                 for (int e = 0; e < 3; ++e)
-                                    if (e < nval[rw][nb]) {
+                                    if (e < nval[nb]) {
                                         if (p.y != nullptr) p.y[at + e] = v[e];
                                         if (p.y_relu != nullptr) p.y_relu[at + e] = vr[e];
                                     }
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(256) void rows_prep_batch(const RowsPrepBatch b) { 
 
 struct RowsPlan {
     RowsParams p;
-    int wi, pad, mt, qw, ntiles, blocks, rsel, sr, rows, ck;
+    int wi, pad, mt, qw, ntiles, blocks, rsel, sr, rows, ck, tall;
     size_t wt_floats;
 };
 
@@ -571,7 +572,28 @@ bool make_rows_plan(const cnn_conv2d_desc* d, int mode, RowsPlan* pl) {
     pl->qw = pl->mt + 16;
     pl->ntiles = (M + pl->mt - 1) / pl->mt;
     pl->sr = wi == 56 ? 2 : (wi == 28 ? 4 : (wi == 14 ? 14 : 1));
-    const int rg = (wi == 14 || wi == 7) ? wi : (pl->mt == 128 ? (wi == 28 ? 1 : 2) : 4) * pl->sr;  // output rows per workgroup unit
+    int rg = (wi == 14 || wi == 7) ? wi : (pl->mt == 128 ? (wi == 28 ? 1 : 2) : 4) * pl->sr;  // output rows per workgroup unit
+    // (round 6) TALL units for the batch-64 layers of the ResNet-shaped stack: 64 samples x 7 units of 8 (4) rows = 448 units leave 32 of
+    // 256 CUs without work (two units per workgroup: 224 workgroups).  A 56-wide plane as FOUR units of 14 rows (one wave = 16 channels x
+    // 7 super-rows), a 28-wide plane as four units of 7 rows (ONE super-row of 196 pixels = 13 blocks, 6 % idle lanes) are 256 units.  Taken
+    // when the estimated time -- units per workgroup x rows x (lanes per live pixel) -- is shorter (never at the VGG-shaped stack's batch 128).
+    pl->tall = 0;
+    if (const int tr = (wi == 56 && pl->mt == 64) ? 14 : ((wi == 28 && pl->mt == 128) ? 7 : 0); tr && ho % tr == 0 && CNN_OPT_INT("ROWS_TALL", 1) != 0) {
+        const int envb = CNN_OPT_INT("ROWS_BLOCKS", 0);
+        long long wantb = (envb > 0 ? envb : num_cus()) / pl->ntiles;
+        if (wantb < 1) wantb = 1;
+        auto cost = [&](int rows, double lane) {
+            const long long units = (long long)d->B * ((ho + rows - 1) / rows);
+            const long long w = wantb < units ? wantb : units;
+            return (double)((units + w - 1) / w) * rows * lane;
+        };
+        const double lane_tall = wi == 28 ? 208.0 / 196.0 : 1.0;
+        if (cost(tr, lane_tall) < cost(rg, 1.0) || CNN_OPT_INT("ROWS_TALL", 1) == 2) {
+            pl->tall = 1;
+            rg = tr;
+            if (wi == 28) pl->sr = 7;
+        }
+    }
     pl->rows = rg;
     // zero staging of the rows below the image needs the first of them on a 16-byte unit of the plane: staged row (hi + pad - r0), r0 a
     // multiple of rg, lead pad (4 - pad*wi % 4) % 4 in front
@@ -612,7 +634,8 @@ int launch_rows2(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, 
     size_t lds = G::lds_bytes;
     if (const int want = CNN_MEASURE_INT("ROWS_LDS", 0); want > (int)lds && want <= 160 * 1024) lds = (size_t)want;
     char name[48];
-    snprintf(name, sizeof(name), "conv_rows<%d,%d,%d>/%s", WI, PAD, MT, tag);
+    if (pl.tall) snprintf(name, sizeof(name), "conv_rows<%d,%d,%d,r%d>/%s", WI, PAD, MT, G::ROWS, tag);
+    else snprintf(name, sizeof(name), "conv_rows<%d,%d,%d>/%s", WI, PAD, MT, tag);
     CNN_KLAUNCH(s, name, (kern<<<dim3(pl.blocks, pl.ntiles), 256, lds, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W, d->Co,
                 d->k, d->s, d->pad);
     return CNN_AMD_OK;
@@ -630,6 +653,8 @@ int launch_any(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, hi
     if (pl.wi == 112 && pl.pad == 0) return pl.mt == 128 ? launch_rows<112, 0, 128>(pl, tag, d, s) : launch_rows<112, 0, 64>(pl, tag, d, s);
     if (pl.wi == 112 && pl.pad == 1) return pl.mt == 128 ? launch_rows<112, 1, 128>(pl, tag, d, s) : launch_rows<112, 1, 64>(pl, tag, d, s);
     if (pl.wi == 110) return pl.mt == 128 ? launch_rows<110, 2, 128>(pl, tag, d, s) : launch_rows<110, 2, 64>(pl, tag, d, s);
+    if (pl.wi == 56 && pl.tall) return launch_rows2<56, 1, 64, false, 2, 7, 1, 1>(pl, tag, d, s);  // (4 co waves x 7 super-rows of two rows)
+    if (pl.wi == 28 && pl.tall) return launch_rows2<28, 1, 128, false, 7, 1>(pl, tag, d, s);        // (one super-row of seven rows)
     if (pl.wi == 56) return pl.mt == 128 ? launch_rows2<56, 1, 128, false, 2, 2>(pl, tag, d, s) : launch_rows2<56, 1, 64, false, 2, 2>(pl, tag, d, s);
     if (pl.wi == 14) return launch_rows2<14, 1, 64, false, 14, 1, 2>(pl, tag, d, s);
     if (pl.wi == 7) return launch_rows2<7, 1, 64, false, 1, 1, 1, 1, 2, 16>(pl, tag, d, s);

@@ -360,6 +360,51 @@ def test_conv2d_row_kernel_vs_oracle(T, case, lib_option):
     assert_close(host(conv.backward_data(dyd, wd)), dx_ref, REL_TOL, "implicit GEMM data gradient")
 
 
+TALL_CASES = [
+    (2, 64, 56, 56, 64, 3, 1, 1),    # 56-wide planes as four units of 14 rows: four co waves x seven super-rows of two rows (49 tiles per wave)
+    (3, 32, 28, 56, 48, 3, 1, 1),    # ... 28 rows (two units per plane), partial tiles, odd batch
+    (2, 128, 28, 28, 128, 3, 1, 1),  # 28-wide planes as four units of 7 rows: one super-row of 196 pixels (13 blocks, the last one a quarter full)
+    (3, 72, 14, 28, 200, 3, 1, 1),   # ... 14 rows (two units per plane), partial tiles
+]
+
+
+@pytest.mark.parametrize("case", TALL_CASES, ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_conv2d_row_kernel_tall_units_vs_oracle(T, case, lib_option):
+    """conv_rows.hip's TALL units (round 6: the batch-64 layers of the ResNet-shaped stack as 256 units instead of 448; conv2d.cpp:69-92 /
+    168-199) against the oracle: forced here (ROWS_TALL=2: at these batch sizes the planner would not pick them), as one unit per workgroup
+    and with one workgroup walking every unit, with the ReLU / ReLU' epilogues; bit-identical to the short units (same sums, same order)"""
+    from cnn_amd import capi
+
+    x, w, b, dy = _conv_inputs(case, 445)
+    y_ref, _, _, dx_ref = _oracle_conv(case, x, w, b, dy)
+    conv = capi.Conv2d(*case)
+    xd, wd, bd, dyd = dev(T, x), dev(T, w), dev(T, b), dev(T, dy)
+    y0, dx0 = conv.forward(xd, wd, bd), conv.backward_data(dyd, wd)
+    lib_option("ROWS_TALL", "2")
+    for blocks in (None, "1"):
+        lib_option("ROWS_BLOCKS", blocks)
+        capi.kernel_timing(1)
+        y = conv.forward(xd, wd, bd)
+        dx = conv.backward_data(dyd, wd)
+        y2, r2 = T.full_like(y, 7.0), T.full_like(y, 7.0)
+        conv.forward_relu(xd, wd, bd, y2, r2)
+        relu_in = capi.relu_forward(xd - 0.5)
+        dxm = T.full_like(xd, 7.0)
+        conv.backward_data_relu(dyd, wd, relu_in, dxm)
+        T.cuda.synchronize()
+        names = [k.split("|")[0] for k in capi.kernel_timing_report()]
+        capi.kernel_timing(0)
+        tall = [n for n in names if n.startswith("conv_rows<") and ",r14>" in n or ",r7>" in n]
+        assert len(tall) == 4, names
+        assert_close(host(y), y_ref, REL_TOL, "tall units forward")
+        assert_close(host(dx), dx_ref, REL_TOL, "tall units data gradient")
+        assert_close(host(y2), y_ref, REL_TOL, "tall units forward + ReLU, pre-activation")
+        assert np.array_equal(host(r2), np.where(host(y2) >= 0, host(y2), np.float32(0)))
+        assert_close(host(dxm), np.where(host(relu_in) <= 0, np.float32(0), dx_ref), REL_TOL, "tall units data gradient + ReLU'")
+        assert np.array_equal(host(y).view(np.uint32), host(y0).view(np.uint32))
+        assert np.array_equal(host(dx).view(np.uint32), host(dx0).view(np.uint32))
+
+
 S2_CASES = [
     (3, 16, 55, 55, 32, 3, 2, 0),     # conv_layer_2 of the reference net (alexnet.cpp:17): 27x27 outputs flat-packed in units of 7 rows; data gradient in 28x28 domains
     (2, 32, 27, 27, 64, 3, 2, 0),     # conv_layer_3: 13x13 outputs, units of 7 rows (ragged last unit of 6)
