@@ -580,6 +580,61 @@ def test_small_plane_wgrad_at_the_stacks_full_sizes_vs_oracle(T, case):
     assert T.equal(gw2, gw1 * 2.0) and T.equal(gb2, gb1 * 2.0)
 
 
+@pytest.mark.parametrize("case", [(64, 64, 56, 56, 128, 3, 2, 1), (64, 256, 14, 14, 512, 3, 2, 1), (64, 128, 28, 28, 256, 3, 2, 1)], ids=lambda c: str(c).replace(" ", ""))
+def test_stride2_stage_entries_at_full_size_vs_oracle(T, case):
+    """the 3x3 / stride-2 stage entries of BASELINE configs[4] at its per-GPU batch, DEFAULT dispatch (round 6: conv_rows_s2.hip forward /
+    data gradient where they are the faster kernels, conv_wgrad_sp2.hip for the weight gradient; the window walk of conv2d.cpp:76-77):
+    forward, data gradient and data gradient + ReLU' against an oracle slice of five samples (per-sample independent passes,
+    conv2d.cpp:69,175); the weight gradient -- it couples all samples (conv2d.cpp:148) -- through a delta that is zero except on three
+    samples, which makes the full-size launch (64 .. 8 pixel ranges per tile) equal to the oracle's gradient of those samples x 3/B"""
+    from cnn_amd import capi
+
+    B, Ci, H, W, Co, k, s, pad = case
+    g = T.Generator(device="cuda").manual_seed(29)
+    x = T.rand((B, Ci, H, W), generator=g, device="cuda") - 0.4
+    w = T.randn((Co, Ci, k, k), generator=g, device="cuda") * float(np.sqrt(2.0 / (Ci * k * k)))
+    b = T.randn((Co,), generator=g, device="cuda") * 0.1
+    conv = capi.Conv2d(*case)
+    dy = T.rand(conv.out_shape(), generator=g, device="cuda") * 2 - 1
+    relu_in = capi.relu_forward(x)
+    capi.kernel_timing(1)
+    y = conv.forward(x, w, b)
+    dx = conv.backward_data(dy, w)
+    dxm = T.full_like(x, 7.0)
+    conv.backward_data_relu(dy, w, relu_in, dxm)
+    T.cuda.synchronize()
+    names = [key.split("|")[0] for key in capi.kernel_timing_report()]
+    capi.kernel_timing(0)
+    assert any(n.startswith("conv_s2<") and n.endswith("/fwd") for n in names), names
+    sel = [0, 1, B // 2 - 1, B // 2, B - 1]
+    xs, dys = x[sel].cpu().numpy(), dy[sel].cpu().numpy()
+    xp = np.pad(xs, ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+    wn = w.cpu().numpy()
+    y_ref = O.conv2d_forward(xp, wn, b.cpu().numpy(), s)
+    dx_ref = O.conv2d_backward(xp, dys, wn, s)[2][:, :, pad : pad + H, pad : pad + W]
+    assert_close(y[sel].cpu().numpy(), y_ref, REL_TOL, "full-size stride-2 forward, oracle slice")
+    assert_close(dx[sel].cpu().numpy(), dx_ref, REL_TOL, "full-size stride-2 data gradient, oracle slice")
+    assert_close(dxm[sel].cpu().numpy(), np.where(xs <= 0, np.float32(0), dx_ref), REL_TOL, "full-size stride-2 data gradient + ReLU', oracle slice")
+    assert T.equal(dxm, T.where(relu_in <= 0, T.zeros_like(dx), dx))
+    # weight gradient
+    sel3 = [0, B // 2, B - 1]
+    dz = T.zeros(conv.out_shape(), device="cuda")
+    dz[sel3] = dy[sel3]
+    capi.kernel_timing(1)
+    gw, gb = conv.backward_weight(x, dz, float(B))
+    names = [key.split("|")[0] for key in capi.kernel_timing_report()]
+    capi.kernel_timing(0)
+    assert any(n.startswith("wgrad_sp2<") for n in names), names
+    xp3 = np.pad(x[sel3].cpu().numpy(), ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+    gw_ref, gb_ref, _ = O.conv2d_backward(xp3, dz[sel3].cpu().numpy(), np.zeros((Co, Ci, k, k), np.float32), s)
+    assert_close(gw.cpu().numpy(), gw_ref * np.float32(3.0 / B), REL_TOL, "full-size stride-2 weight gradient, oracle slice")
+    assert_close(gb.cpu().numpy(), gb_ref * np.float32(3.0 / B), REL_TOL, "full-size stride-2 bias gradient, oracle slice")
+    gw1, gb1 = conv.backward_weight(x, dy, float(B))
+    gw1, gb1 = gw1.clone(), gb1.clone()
+    gw2, gb2 = conv.backward_weight(x, dy * 2.0, float(B))
+    assert T.equal(gw2, gw1 * 2.0) and T.equal(gb2, gb1 * 2.0)
+
+
 @pytest.mark.parametrize("case", [(7, 24, 14, 13, 40, 3, 1, 1), (3, 16, 9, 15, 32, 3, 1, 1), (5, 32, 14, 14, 64, 3, 1, 1)], ids=str)
 def test_wgrad_flattened_runs_of_8_equal_im2col(T, case, lib_option):
     """the weight gradient's flattened runs of 8 for rows of 9 .. 15 pixels (CNN_AMD_RD_FLAT8=1, a measurement switch: profiles/NOTEBOOK.md 9) against the im2col
