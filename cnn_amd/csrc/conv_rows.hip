@@ -56,8 +56,14 @@ constexpr int kCK = 8;
 //       on a 16-byte unit -- with NO halo rows: a tap that leaves its plane at the top / bottom / left / right is selected away by a
 //       compile-time lane mask per (block, tap) (what lies there is the neighbouring plane, the pad or the guard).
 // CK:   input channels per stage (8; 16 where a stage of 8 would be short against its fixed costs: the 7x7 instance, 7 tiles per wave)
-template <int WI, int PAD, int MT, bool RSEL = false, int SR = 1, int RW_ = 2, int WP = 1, int MA_ = 2, int PK_ = 1, int CK_ = 8>
+// PROD: a FIFTH wave does nothing but the stage DMA (round 6).  A wave issues one 1-KiB LDS-DMA instruction per ~100 cycles however idle the
+//       memory system is (NB section 9: tools/micro/dma_issue.hip), and while it does, it issues no MFMA: with the small planes' large filter
+//       share of a stage (7x7: 54 instructions per 252 MFMAs per wave) that was 10 - 17 % of the stage.  The MFMA waves of such an instance
+//       never touch the vector-memory queue inside the stage loop.  Needs two waves on one SIMD: instances with <= 256 registers only.
+template <int WI, int PAD, int MT, bool RSEL = false, int SR = 1, int RW_ = 2, int WP = 1, int MA_ = 2, int PK_ = 1, int CK_ = 8, bool PROD_ = false>
 struct RowsGeom {
+    static constexpr bool PROD = PROD_;
+    static constexpr int NDW = PROD ? 1 : 4;  // waves that issue the stage DMA
     static constexpr int CK = CK_;
     static_assert(CK == 8 || CK == 16, "channels per stage");
     static_assert(MT == 128 || MT == 64, "output channels per workgroup");
@@ -103,7 +109,7 @@ struct RowsGeom {
     static_assert(QXP % 32 == 16 && (9 * QW) % 32 == 16, "bank halves");
     static constexpr int XIMG = CK * QXP, WIMG = CK * 9 * QW;
     static constexpr int NIX = (XIMG / 4 + 63) / 64, NIWT = (WIMG / 4 + 63) / 64;  // DMA instructions per stage
-    static constexpr int NIWX = (NIX + 3) / 4, NIWW = (NIWT + 3) / 4;              // per wave
+    static constexpr int NIWX = (NIX + NDW - 1) / NDW, NIWW = (NIWT + NDW - 1) / NDW;  // per issuing wave
     static constexpr int NSLOT = NIWX + NIWW;
     static constexpr int XS = NIX * 256, WS = NIWT * 256;  // image sizes in whole instructions
     static constexpr int BUF = XS + WS;
@@ -111,11 +117,12 @@ struct RowsGeom {
     static constexpr size_t lds_bytes = (size_t)(2 * BUF + 4 * 256) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS plan");
     static constexpr int KSTEPS = CK / 4;  // MFMA k-steps per tap
+    static constexpr int THREADS = PROD ? 320 : 256;
 };
 
-template <int WI, int PAD, int MT, bool RSEL, int SR, int RW_, int WP, int MA, int PK, int CK>
-__global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
-    using G = RowsGeom<WI, PAD, MT, RSEL, SR, RW_, WP, MA, PK, CK>;
+template <int WI, int PAD, int MT, bool RSEL, int SR, int RW_, int WP, int MA, int PK, int CK, bool PROD>
+__global__ __launch_bounds__(PROD ? 320 : 256) void conv_rows_kernel(const RowsParams p) {
+    using G = RowsGeom<WI, PAD, MT, RSEL, SR, RW_, WP, MA, PK, CK, PROD>;
     constexpr int WO = G::WO, NB = G::NBW;  // (NB: the pixel blocks of THIS wave)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kq = lane >> 4;
@@ -131,11 +138,12 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
     // ---- this wave's share of a stage's x DMA, decoded once: byte offset from (first channel of the chunk, staged row 0) counted from
     //      PAD*WI + 4 floats in front of the tensor (xrs), and the last staged row the unit touches (units of rows above the image of the
     //      first row block are not fetched: for the first plane of the tensor they lie in front of the allocation)
+    const int dw = PROD ? 0 : wave;  // this wave among the waves that issue the stage DMA (PROD: the fifth wave alone)
     unsigned xd_off[G::NIWX];
     int xd_row[G::NIWX];   // last staged row the unit touches | first one << 8
 #pragma unroll
     for (int i = 0; i < G::NIWX; ++i) {
-        const int j = i * 4 + wave, q = j * 64 + lane;
+        const int j = i * G::NDW + dw, q = j * 64 + lane;
         const int plane = q / (G::QXP / 4), e = q - plane * (G::QXP / 4);
         const bool have = j < G::NIX && plane < CK && e * 4 < G::XSPAN;
         if constexpr (PK > 1) {
@@ -156,11 +164,11 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
     const __amdgpu_buffer_rsrc_t wrs =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.wt + (size_t)blockIdx.y * p.nchunk * G::WIMG), 0, (int)((unsigned)p.nchunk * G::WIMG * 4u), 0x00020000);
 
-    float* const dump = smem + G::DUMP + wave * 256;
+    float* const dump = smem + G::DUMP + dw * 256;
     // slot k of the DMA of stage (sample b, first output row r0, chunk cc) into `buf` = [x image][filter image]
     auto dma_slot = [&](int k, int b, int r0, int cc, float* buf) {
         if (k < G::NIWX) {
-            const int j = k * 4 + wave;
+            const int j = k * G::NDW + dw;
             float* d = j < G::NIX ? buf + j * 256 : dump;
             const int nneg = PAD - r0;      // staged rows above the image
             const int nv = H + PAD - r0;    // first staged row below it
@@ -171,12 +179,44 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
             }
             blds16(xrs, voff, (unsigned)((b * p.C + cc * CK) * HWI + r0 * WI) * 4u, d);
         } else {
-            const int i = k - G::NIWX, j = i * 4 + wave;
+            const int i = k - G::NIWX, j = i * G::NDW + dw;
             float* d = j < G::NIWT ? buf + G::XS + j * 256 : dump;
             const unsigned q = (unsigned)(j * 64 + lane);
             blds16(wrs, (j < G::NIWT && q * 4 < (unsigned)G::WIMG) ? q * 16u : kOob, (unsigned)cc * (unsigned)(G::WIMG * 4), d);
         }
     };
+
+    if constexpr (PROD) {
+        if (wave == 4) {
+            // ---- the producer: the MFMA waves' walk over (unit, chunk) stages, with nothing in it but the DMA of the stage behind, the wait
+            //      for it and the stage barrier.  Stage t + 1 is issued right behind barrier t (every MFMA wave has left the buffer it goes to)
+            //      and has landed (vmcnt(0), this wave's own instructions: all of them) before this wave arrives at barrier t + 1.
+            int b = u_lo / p.nrb, r0 = (u_lo - b * p.nrb) * G::ROWS;
+            if constexpr (PK > 1) b *= PK;
+#pragma unroll
+            for (int k = 0; k < G::NSLOT; ++k) dma_slot(k, b, r0, 0, smem);
+            int t = 0;
+            for (int u = u_lo; u < u_hi; ++u) {
+                int bu = b, r0u = r0;
+                if (u + 1 < u_hi) {
+                    if (r0 + G::ROWS < p.HO) r0u = r0 + G::ROWS;
+                    else { r0u = 0; bu = b + PK; }
+                }
+                for (int cc = 0; cc < p.nchunk; ++cc, ++t) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    const bool last_cc = cc + 1 == p.nchunk;
+                    if (last_cc && u + 1 == u_hi) break;  // (nothing behind the last stage)
+                    float* nxt = smem + ((t + 1) & 1) * G::BUF;
+                    const int bn = last_cc ? bu : b, r0n = last_cc ? r0u : r0, ccn = last_cc ? 0 : cc + 1;
+#pragma unroll
+                    for (int k = 0; k < G::NSLOT; ++k) dma_slot(k, bn, r0n, ccn, nxt);
+                }
+                b = bu; r0 = r0u;
+            }
+            return;
+        }
+    }
 
     // ---- per-lane operand bases (floats inside a buffer)
     const int b_base = PK > 1 ? kq * G::QXP + G::GUARD - WI - 1 + n : kq * G::QXP + G::LEAD + n - PAD + wr * G::RW * SR * WI + wp * G::NBW * 16;
@@ -199,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
     // (224 v_accvgpr_read + 224 v_accvgpr_write per 504 MFMAs in the round-5 ISA).
     int b = u_lo / p.nrb, r0 = (u_lo - b * p.nrb) * G::ROWS;
     if constexpr (PK > 1) b *= PK;  // (packed planes: a unit = PK samples, nrb = 1)
-    {
+    if constexpr (!PROD) {
 #pragma unroll
         for (int k = 0; k < G::NSLOT; ++k) dma_slot(k, b, r0, 0, smem);
     }
@@ -220,8 +260,9 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
             // stores -- a wait here would also wait for THOSE to drain (vmcnt counts stores; measured on the north-star forward, where all 256
             // workgroups store 29 MB in one burst every 8 stages: 5.6 us per unit, 8 % of the kernel); they drain under this stage's MFMAs and
             // the next stage's wait finds them gone
-            if (cc != 0 || u == u_lo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (!PROD && (cc != 0 || u == u_lo)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (PROD: the producer waits; this wave only has stores out)
+            if constexpr (PROD) __builtin_amdgcn_s_barrier();  // (the bare barrier: __syncthreads()'s fence would wait for the previous unit's stores)
+            else __syncthreads();
             float* nxt = smem + ((t + 1) & 1) * G::BUF;
             // the stage behind this one (behind the last one of the range: that one again)
             const bool last_cc = cc + 1 == p.nchunk;
@@ -277,8 +318,10 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
                 constexpr int nm = MA * G::RW * NB;               // MFMAs of a k-step
                 constexpr int nr2 = ks + LA < NKS ? NRD : 0;      // reads of batch ks + LA, issued here
                 constexpr int rpm = (nr2 + nm - 1) / nm;
+                if constexpr (!PROD) {
 #pragma unroll
-                for (int k = ks * PER_KS; k < (ks + 1) * PER_KS && k < G::NSLOT; ++k) dma_slot(k, bn, r0n, ccn, nxt);
+                    for (int k = ks * PER_KS; k < (ks + 1) * PER_KS && k < G::NSLOT; ++k) dma_slot(k, bn, r0n, ccn, nxt);
+                }
                 lgkm_wait<(LA == 2 && ks + 1 < NKS ? (NRD < 15 ? NRD : 15) : 0)>();
                 Ops& o = ops[ks % (LA + 1)];
                 // (the values of this batch are defined from here on: nothing that uses them may be scheduled above the wait)
@@ -317,7 +360,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const RowsParams p) {
                 });
             });
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the next unit's stage 0, issued early in the last stage: see above)
+        if constexpr (!PROD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the next unit's stage 0, issued early in the last stage: see above)
         acc_settle<MA * G::RW * NB>(&acc[0][0][0]);
         if (p.dbg != 1) {  // (ROWS_DBG=1, measurement only: no stores)
             // ---- this unit is complete: + bias, store.  The MFMAs ran with the PIXELS as the M operand (D[i][j]: lane (j = n, kq) holds rows
@@ -620,10 +663,10 @@ bool make_rows_plan(const cnn_conv2d_desc* d, int mode, RowsPlan* pl) {
     return true;
 }
 
-template <int WI, int PAD, int MT, bool RSEL, int SR = 1, int RW = 2, int WP = 1, int MA = 2, int PK = 1, int CK = 8>
+template <int WI, int PAD, int MT, bool RSEL, int SR = 1, int RW = 2, int WP = 1, int MA = 2, int PK = 1, int CK = 8, bool PROD = false>
 int launch_rows2(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, hipStream_t s) {
-    using G = RowsGeom<WI, PAD, MT, RSEL, SR, RW, WP, MA, PK, CK>;
-    auto kern = conv_rows_kernel<WI, PAD, MT, RSEL, SR, RW, WP, MA, PK, CK>;
+    using G = RowsGeom<WI, PAD, MT, RSEL, SR, RW, WP, MA, PK, CK, PROD>;
+    auto kern = conv_rows_kernel<WI, PAD, MT, RSEL, SR, RW, WP, MA, PK, CK, PROD>;
     if (G::ROWS != pl.rows || CK != pl.ck) return fail(CNN_AMD_E_BADARG, "conv_rows: plan / instance mismatch");
     static DeviceOnce attr_once;
     if (attr_once.needed()) {
@@ -636,7 +679,7 @@ int launch_rows2(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, 
     char name[48];
     if (pl.tall) snprintf(name, sizeof(name), "conv_rows<%d,%d,%d,r%d>/%s", WI, PAD, MT, G::ROWS, tag);
     else snprintf(name, sizeof(name), "conv_rows<%d,%d,%d>/%s", WI, PAD, MT, tag);
-    CNN_KLAUNCH(s, name, (kern<<<dim3(pl.blocks, pl.ntiles), 256, lds, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W, d->Co,
+    CNN_KLAUNCH(s, name, (kern<<<dim3(pl.blocks, pl.ntiles), G::THREADS, lds, s>>>(pl.p)), "B%d Ci%d %dx%d Co%d k%d s%d p%d", d->B, d->Ci, d->H, d->W, d->Co,
                 d->k, d->s, d->pad);
     return CNN_AMD_OK;
 }
@@ -656,8 +699,12 @@ int launch_any(const RowsPlan& pl, const char* tag, const cnn_conv2d_desc* d, hi
     if (pl.wi == 56 && pl.tall) return launch_rows2<56, 1, 64, false, 2, 7, 1, 1>(pl, tag, d, s);  // (4 co waves x 7 super-rows of two rows)
     if (pl.wi == 28 && pl.tall) return launch_rows2<28, 1, 128, false, 7, 1>(pl, tag, d, s);        // (one super-row of seven rows)
     if (pl.wi == 56) return pl.mt == 128 ? launch_rows2<56, 1, 128, false, 2, 2>(pl, tag, d, s) : launch_rows2<56, 1, 64, false, 2, 2>(pl, tag, d, s);
-    if (pl.wi == 14) return launch_rows2<14, 1, 64, false, 14, 1, 2>(pl, tag, d, s);
-    if (pl.wi == 7) return launch_rows2<7, 1, 64, false, 1, 1, 1, 1, 2, 16>(pl, tag, d, s);
+    // the 7x7 instance runs with a producer wave (ROWS_PROD=0: without; =2: the 14x14 instance too).  Measured, block 0's cycles for 258 k
+    // cycles of MFMA issue (ROWS_DBG=9, batch 64): 7x7 341 k -> 316 k (168 -> 158 us); 14x14 300 k either way (its 31 instructions per 252
+    // MFMAs were not what held it at 86 %), and 1 % slower at batch 128: it stays without.
+    const int prod = CNN_OPT_INT("ROWS_PROD", 1);
+    if (pl.wi == 14) return prod == 2 ? launch_rows2<14, 1, 64, false, 14, 1, 2, 2, 1, 8, true>(pl, tag, d, s) : launch_rows2<14, 1, 64, false, 14, 1, 2>(pl, tag, d, s);
+    if (pl.wi == 7) return prod != 0 ? launch_rows2<7, 1, 64, false, 1, 1, 1, 1, 2, 16, true>(pl, tag, d, s) : launch_rows2<7, 1, 64, false, 1, 1, 1, 1, 2, 16>(pl, tag, d, s);
     return launch_rows2<28, 1, 128, false, 4, 1>(pl, tag, d, s);
 }
 

@@ -354,6 +354,14 @@ def test_conv2d_row_kernel_vs_oracle(T, case, lib_option):
     assert_close(host(y2), y_ref, REL_TOL, "row kernel forward + ReLU, pre-activation")
     assert np.array_equal(host(r2), np.where(host(y2) >= 0, host(y2), np.float32(0)))  # relu.cpp:25 on the same sums
     assert_close(host(dxm), np.where(host(relu_in) <= 0, np.float32(0), dx_ref), REL_TOL, "row kernel data gradient + ReLU'")
+    if case[3] in (7, 14):
+        # the producer-wave variant of the small planes' instances (round 6: a fifth wave issues the stage DMA; default for 7x7) against its
+        # twin without one, with one workgroup walking every unit: same MFMAs on the same operands, bit for bit
+        lib_option("ROWS_PROD", "0" if case[3] == 7 else "2")
+        y3, dx3 = conv.forward(xd, wd, bd), conv.backward_data(dyd, wd)
+        assert np.array_equal(host(y3).view(np.uint32), host(y).view(np.uint32))
+        assert np.array_equal(host(dx3).view(np.uint32), host(dx).view(np.uint32))
+        lib_option("ROWS_PROD", None)
     lib_option("ROWS_BLOCKS", None)
     lib_option("CONV_ROWS", "0")
     assert_close(host(conv.forward(xd, wd, bd)), y_ref, REL_TOL, "implicit GEMM forward")
