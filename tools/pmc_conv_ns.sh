@@ -2,7 +2,7 @@
 # HBM traffic of the three north-star convolution passes (3x3, 64 -> 128, 112x112, batch 256): FETCH_SIZE and WRITE_SIZE in separate
 # rocprofv3 passes over tools/one_layer.py (MI355X_MICROARCH.md, HBM section), per launch, next to the algorithmic bytes.
 # usage (GPU box, repo root): bash tools/pmc_conv_ns.sh <tag>   -> gpurun_out/prof_<tag>/hbm_traffic_conv_ns.json
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG/conv_ns
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

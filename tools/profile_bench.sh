@@ -2,7 +2,7 @@
 # rocprofv3 captures of bench.py for a round: kernel trace + stats of the three BASELINE workloads, then the HBM-traffic PMC
 # passes of the headline configuration (separate runs, as MI355X_MICROARCH.md prescribes; never combined with other trace domains).
 # usage (on the GPU box, from the repo root): bash tools/profile_bench.sh <tag>     -> gpurun_out/prof_<tag>/
-TAG=${1:-r02}
+TAG=${1:-r06}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -33,6 +33,11 @@ CNN_AMD_SERIAL_BWD_GFLOP=0 python bench.py --config resnet18 --breakdown > $OUT/
 bash tools/run_tune.sh > /dev/null 2>&1; cp gpurun_out/tune_layers.log $OUT/layers_isolated.txt
 (python tools/tune_stack.py vgg11; python tools/tune_stack.py resnet18) > $OUT/stack_layers_isolated.txt 2>&1
 bash tools/pmc_conv_ns.sh $TAG > $OUT/hbm_traffic_conv_ns.txt 2>&1
+# (round 6) the 3x3 / stride-2 layers isolated (conv_rows_s2 / conv_wgrad_sp2 against the kernels they replace), and where the first block's kernels wait
+bash tools/s2_layers.sh > $OUT/s2_layers.txt 2>&1
+bash tools/s2_wgrad_layers.sh > $OUT/s2_wgrad_layers.txt 2>&1
+bash tools/pmc_first_block.sh > $OUT/pmc_first_block.txt 2>&1; cp gpurun_out/pmc_first_block/summary.json $OUT/pmc_first_block.json 2>/dev/null
+bash tools/timeline_cfg.sh rn resnet18 conv_stem_fwd > /dev/null 2>&1; cp gpurun_out/rn_timeline.txt $OUT/step_timeline_resnet18.txt 2>/dev/null
 # large raw traces stay out of the merge-back (64 MiB cap): keep the per-kernel stats and drop the per-launch traces
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
 find $OUT -name "*counter_collection.csv" -size +8M -delete
