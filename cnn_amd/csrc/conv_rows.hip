@@ -717,6 +717,11 @@ bool s2_info(const cnn_conv2d_desc* d, int mode, int* mt, int* qw, int* ck, int*
 int s2_run(const cnn_conv2d_desc* d, int mode, const float* in, const float* image, const float* bias, float* out, float* out_relu,
            const float* relu_below, hipStream_t s);
 
+// conv_rows_any.hip: the runtime-width member of the family takes every 3x3 / stride-1 geometry the instances above do not
+bool any_info(const cnn_conv2d_desc* d, int mode, int* mt, int* qw, int* ck, int* nchunk, int* ntiles, size_t* wt_floats);
+int any_run(const cnn_conv2d_desc* d, int mode, const float* in, const float* image, const float* bias, float* out, float* out_relu,
+            const float* relu_below, hipStream_t s);
+
 // the filter-image job of layer d in `mode`, whichever kernel family serves it
 static bool prep_job(const cnn_conv2d_desc* d, int mode, const float* w, float* image, RowsPrepJob* q, size_t* floats) {
     int mt, qw, ck, nchunk, ntiles;
@@ -726,7 +731,11 @@ static bool prep_job(const cnn_conv2d_desc* d, int mode, const float* w, float* 
         return true;
     }
     RowsPlan pl;
-    if (!make_rows_plan(d, mode, &pl)) return false;
+    if (!make_rows_plan(d, mode, &pl)) {
+        if (!any_info(d, mode, &mt, &qw, &ck, &nchunk, &ntiles, floats)) return false;
+        *q = RowsPrepJob{w, image, d->Co, d->Ci, mode, mt, qw, nchunk, ntiles, ck};
+        return true;
+    }
     *q = RowsPrepJob{w, image, d->Co, d->Ci, mode, pl.mt, pl.qw, pl.p.nchunk, pl.ntiles, pl.ck};
     *floats = pl.wt_floats;
     return true;
@@ -775,7 +784,7 @@ int rows_run(const cnn_conv2d_desc* d, int mode, const float* in, const float* i
              const float* relu_below, hipStream_t s) {
     if (d->s == 2) return s2_run(d, mode, in, image, bias, out, out_relu, relu_below, s);
     RowsPlan pl;
-    if (!make_rows_plan(d, mode, &pl)) return fail(CNN_AMD_E_BADARG, "conv_rows: geometry not covered");
+    if (!make_rows_plan(d, mode, &pl)) return any_run(d, mode, in, image, bias, out, out_relu, relu_below, s);
     pl.p.x = in; pl.p.wt = image; pl.p.bias = mode == 0 ? bias : nullptr; pl.p.y = out; pl.p.y_relu = out_relu; pl.p.relu_below = relu_below;
     const char* tag = mode == 0 ? (out_relu ? (out ? "fwd+relu" : "fwd,relu") : "fwd") : (relu_below ? "dgrad+relu" : "dgrad");
     return launch_any(pl, tag, d, s);

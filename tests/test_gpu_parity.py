@@ -368,6 +368,62 @@ def test_conv2d_row_kernel_vs_oracle(T, case, lib_option):
     assert_close(host(conv.backward_data(dyd, wd)), dx_ref, REL_TOL, "implicit GEMM data gradient")
 
 
+ANY_CASES = [
+    (2, 32, 9, 23, 40, 3, 1, 0),      # pad 0 (conv2d.cpp:41-42): 23-wide planes, class pitch 28: rows of 21 outputs, 7 rows = one unit; data gradient 21-wide pad 2
+    (2, 32, 30, 50, 64, 3, 1, 1),     # pad 1: 50-wide, balanced units of 8 / 7 rows, four channel chunks, both edge columns
+    (1, 32, 7, 109, 72, 3, 1, 0),     # 109-wide (class pitch 112): units of 4 rows (5 output rows = 3 + 2), partial channel tiles (72 = 64 + 8)
+    (2, 32, 5, 222, 32, 3, 1, 0),     # 222-wide (class pitch 224): units of 2 rows of 220 outputs (27.5 blocks), data gradient 220-wide pad 2 -> 222
+    (1, 32, 6, 223, 40, 3, 1, 1),     # ... odd width with pad 1: rows of 223 outputs, the row's last 16-byte unit straddles its end
+    (3, 40, 23, 21, 48, 3, 1, 1),     # 21-wide pad 1: 21 rows per unit would be 441 pixels -- 23 rows = 12 + 11, odd batch
+    (2, 64, 52, 52, 64, 3, 1, 0),     # the reference-style pad-0 VGG shapes: 52 -> 50
+    (1, 32, 100, 9, 32, 3, 1, 1),     # tall narrow planes: 9 columns, 25 rows per unit
+    (2, 32, 3, 96, 32, 3, 1, 0),      # one output row
+]
+
+
+@pytest.mark.parametrize("case", ANY_CASES, ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_conv2d_row_kernel_any_width_vs_oracle(T, case, lib_option):
+    """conv_rows_any.hip (round 6: the runtime-width member of the row-kernel family -- 3x3 / stride-1 layers of ANY plane size up to 224
+    columns, conv2d.cpp:41-42; forward conv2d.cpp:69-92, data gradient conv2d.cpp:168-199) against the oracle: default walk, one workgroup
+    walking every unit, the ReLU / ReLU' epilogues, and against the kernels it replaces (ROWS_ANY=0)"""
+    from cnn_amd import capi
+
+    x, w, b, dy = _conv_inputs(case, 455)
+    y_ref, _, _, dx_ref = _oracle_conv(case, x, w, b, dy)
+    conv = capi.Conv2d(*case)
+    xd, wd, bd, dyd = dev(T, x), dev(T, w), dev(T, b), dev(T, dy)
+    for blocks in (None, "1"):
+        lib_option("ROWS_BLOCKS", blocks)
+        capi.kernel_timing(1)
+        y = conv.forward(xd, wd, bd)
+        dx = conv.backward_data(dyd, wd)
+        y2, r2 = T.full_like(y, 7.0), T.full_like(y, 7.0)
+        conv.forward_relu(xd, wd, bd, y2, r2)
+        relu_in = capi.relu_forward(xd - 0.5)
+        dxm = T.full_like(xd, 7.0)
+        conv.backward_data_relu(dyd, wd, relu_in, dxm)
+        T.cuda.synchronize()
+        names = [k.split("|")[0] for k in capi.kernel_timing_report()]
+        capi.kernel_timing(0)
+        assert sum(n.startswith("conv_rows_any<") for n in names) == 4, names
+        assert_close(host(y), y_ref, REL_TOL, "any-width forward")
+        assert_close(host(dx), dx_ref, REL_TOL, "any-width data gradient")
+        assert_close(host(y2), y_ref, REL_TOL, "any-width forward + ReLU, pre-activation")
+        assert np.array_equal(host(r2), np.where(host(y2) >= 0, host(y2), np.float32(0)))
+        assert_close(host(dxm), np.where(host(relu_in) <= 0, np.float32(0), dx_ref), REL_TOL, "any-width data gradient + ReLU'")
+    lib_option("ROWS_BLOCKS", None)
+    # tensors whose neighbours in memory are NaN: nothing outside them reaches a sum (rows / columns staged past an edge are selected away)
+    big = T.full((xd.numel() + 8192,), float("nan"), device="cuda")
+    xn = big[4096 : 4096 + xd.numel()].view_as(xd).copy_(xd)
+    assert np.array_equal(host(conv.forward(xn, wd, bd)).view(np.uint32), host(y).view(np.uint32))
+    bigd = T.full((dyd.numel() + 8192,), float("nan"), device="cuda")
+    dyn = bigd[4096 : 4096 + dyd.numel()].view_as(dyd).copy_(dyd)
+    assert np.array_equal(host(conv.backward_data(dyn, wd)).view(np.uint32), host(dx).view(np.uint32))
+    lib_option("ROWS_ANY", "0")
+    assert_close(host(conv.forward(xd, wd, bd)), y_ref, REL_TOL, "the replaced kernel's forward")
+    assert_close(host(conv.backward_data(dyd, wd)), dx_ref, REL_TOL, "the replaced kernel's data gradient")
+
+
 TALL_CASES = [
     (2, 64, 56, 56, 64, 3, 1, 1),    # 56-wide planes as four units of 14 rows: four co waves x seven super-rows of two rows (49 tiles per wave)
     (3, 32, 28, 56, 48, 3, 1, 1),    # ... 28 rows (two units per plane), partial tiles, odd batch
