@@ -323,7 +323,9 @@ bool make_any_plan(const cnn_conv2d_desc* d, int mode, AnyPlan* pl) {
     const int wi = mode == 0 ? d->W : Wo, hi = mode == 0 ? d->H : Ho, pad = mode == 0 ? d->pad : 2 - d->pad;
     const int wo = mode == 0 ? Wo : d->W, ho = mode == 0 ? Ho : d->H;
     const int C = mode == 0 ? d->Ci : d->Co, M = mode == 0 ? d->Co : d->Ci;
-    if (C < 16 || C % kCK != 0 || M < 32 || (long long)C * M * 9 >= (1ll << 28)) return false;
+    // (any channel count from 8 / 16 up: the channels behind the tensor's last one in the last 8-channel stage are DMA lanes outside the
+    //  descriptor -- zeros -- and their filter rows are zeros in the image; output channels behind M are computed and not stored)
+    if (C < 8 || M < 16 || (long long)C * M * 9 >= (1ll << 28)) return false;
     if ((long long)d->B * C * hi * wi >= (1ll << 29) || (long long)d->B * M * ho * wo >= (1ll << 31)) return false;
     int cls = -1;
     for (int i = kNumClasses - 1; i >= 0; --i)

@@ -329,7 +329,7 @@ def test_measured_tile_choice_travels_between_processes(T):
     from cnn_amd import capi
 
     lib = capi.load()
-    d = capi.ConvDesc(2, 20, 20, 20, 40, 3, 1, 1)          # generic (20 channels: no whole 8-channel chunks for the row kernels): implicit GEMM in both directions
+    d = capi.ConvDesc(2, 20, 20, 20, 40, 5, 1, 2)          # generic (5x5: no row kernel): implicit GEMM in both directions
     first = capi.ConvDesc(2, 3, 224, 224, 16, 3, 2, 0)     # the reference net's first layer: specialised kernels, nothing to measure
     assert lib.cnn_conv2d_autotune_workspace_bytes(C.byref(first)) == 0
     capi.check(lib.cnn_conv2d_autotune_ws(C.byref(first), None, 0, capi._stream()), "cnn_conv2d_autotune_ws")  # (a no-op)
@@ -338,7 +338,7 @@ def test_measured_tile_choice_travels_between_processes(T):
     capi.check(lib.cnn_conv2d_tune_export(C.byref(d), out), "cnn_conv2d_tune_export")
     need = lib.cnn_conv2d_autotune_workspace_bytes(C.byref(d))
     if list(out)[:2] == [none, none]:  # (not measured yet in this process)
-        assert need > 4 * (2 * 20 * 400 + 2 * 40 * 400 + 40 * 20 * 9)
+        assert need > 4 * (2 * 20 * 400 + 2 * 40 * 400 + 40 * 20 * 25)
         assert lib.cnn_conv2d_autotune_ws(C.byref(d), None, 0, capi._stream()) != 0  # scratch is the caller's
         scratch = T.empty(need, dtype=T.uint8, device="cuda")
         capi.check(lib.cnn_conv2d_autotune_ws(C.byref(d), capi._ptr(scratch), need, capi._stream()), "cnn_conv2d_autotune_ws")
@@ -346,7 +346,7 @@ def test_measured_tile_choice_travels_between_processes(T):
         capi.check(lib.cnn_conv2d_tune_export(C.byref(d), out), "cnn_conv2d_tune_export")
     assert out[0] != none and out[1] != none
     assert lib.cnn_conv2d_autotune_workspace_bytes(C.byref(d)) == 0  # measured once per process
-    twin = capi.ConvDesc(3, 20, 20, 20, 40, 3, 1, 1)       # "another replica": same layer, its own table entry
+    twin = capi.ConvDesc(3, 20, 20, 20, 40, 5, 1, 2)       # "another replica": same layer, its own table entry
     got = (C.c_int32 * 4)()
     capi.check(lib.cnn_conv2d_tune_export(C.byref(twin), got), "cnn_conv2d_tune_export")
     if list(got)[:2] == [none, none]:
@@ -355,9 +355,9 @@ def test_measured_tile_choice_travels_between_processes(T):
         assert list(got) == list(out)
         assert lib.cnn_conv2d_autotune_workspace_bytes(C.byref(twin)) == 0  # pinned: not measured again
     # and the pinned tiles compute the same convolution (forward against the im2col fallback)
-    conv = capi.Conv2d(3, 20, 20, 20, 40, 3, 1, 1)
+    conv = capi.Conv2d(3, 20, 20, 20, 40, 5, 1, 2)
     x = T.from_numpy(uniform01(97, (3, 20, 20, 20))).cuda()
-    wgt = T.from_numpy(uniform01(98, (40, 20, 3, 3)) - 0.5).cuda()
+    wgt = T.from_numpy(uniform01(98, (40, 20, 5, 5)) - 0.5).cuda()
     bias = T.from_numpy(uniform01(99, (40,))).cuda()
     y = conv.forward(x, wgt, bias)
     ref = conv.forward_im2col(x, wgt, bias)

@@ -378,6 +378,8 @@ ANY_CASES = [
     (2, 64, 52, 52, 64, 3, 1, 0),     # the reference-style pad-0 VGG shapes: 52 -> 50
     (1, 32, 100, 9, 32, 3, 1, 1),     # tall narrow planes: 9 columns, 25 rows per unit
     (2, 32, 3, 96, 32, 3, 1, 0),      # one output row
+    (3, 20, 11, 37, 24, 3, 1, 1),     # channel counts that are no multiples of 8 / 16: the last stage's planes behind the tensor's last channel are staged as zeros
+    (2, 9, 14, 30, 17, 3, 1, 0),      # ... 9 -> 17 channels (data gradient 17 -> 9: below the kernel's floor of 16 output channels, stays on the generic path)
 ]
 
 
@@ -405,7 +407,7 @@ def test_conv2d_row_kernel_any_width_vs_oracle(T, case, lib_option):
         T.cuda.synchronize()
         names = [k.split("|")[0] for k in capi.kernel_timing_report()]
         capi.kernel_timing(0)
-        assert sum(n.startswith("conv_rows_any<") for n in names) == 4, names
+        assert sum(n.startswith("conv_rows_any<") for n in names) == (4 if case[1] >= 16 else 2), names
         assert_close(host(y), y_ref, REL_TOL, "any-width forward")
         assert_close(host(dx), dx_ref, REL_TOL, "any-width data gradient")
         assert_close(host(y2), y_ref, REL_TOL, "any-width forward + ReLU, pre-activation")
