@@ -36,6 +36,7 @@ bash tools/pmc_conv_ns.sh $TAG > $OUT/hbm_traffic_conv_ns.txt 2>&1
 # (round 6) the 3x3 / stride-2 layers isolated (conv_rows_s2 / conv_wgrad_sp2 against the kernels they replace), and where the first block's kernels wait
 bash tools/s2_layers.sh > $OUT/s2_layers.txt 2>&1
 bash tools/s2_wgrad_layers.sh > $OUT/s2_wgrad_layers.txt 2>&1
+bash tools/any_layers.sh > $OUT/any_layers.txt 2>&1
 bash tools/pmc_first_block.sh > $OUT/pmc_first_block.txt 2>&1; cp gpurun_out/pmc_first_block/summary.json $OUT/pmc_first_block.json 2>/dev/null
 bash tools/timeline_cfg.sh rn resnet18 conv_stem_fwd > /dev/null 2>&1; cp gpurun_out/rn_timeline.txt $OUT/step_timeline_resnet18.txt 2>/dev/null
 # large raw traces stay out of the merge-back (64 MiB cap): keep the per-kernel stats and drop the per-launch traces
