@@ -436,17 +436,21 @@ namespace cnn_amd {
 int sp2_wgrad_slots(const cnn_conv2d_desc* d);
 int sp2_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
 
+// conv_wgrad_sp_any.hip: the runtime-size member of the family takes every 3x3 / stride-1 geometry the instances here do not
+int spa_wgrad_slots(const cnn_conv2d_desc* d);
+int spa_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
+
 // number of partial slabs ([Co][Ci*9 + 1] floats each) the kernel writes, 0 when the geometry is not covered
 int sp_wgrad_slots(const cnn_conv2d_desc* d) {
     if (d->s == 2) return sp2_wgrad_slots(d);
     SpPlan pl;
-    return make_sp_plan(d, &pl) ? pl.kblocks : 0;
+    return make_sp_plan(d, &pl) ? pl.kblocks : spa_wgrad_slots(d);
 }
 
 int sp_wgrad_launch(const cnn_conv2d_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s) {
     if (d->s == 2) return sp2_wgrad_launch(d, x, dy, slabs, s);
     SpPlan pl;
-    if (!make_sp_plan(d, &pl)) return fail(CNN_AMD_E_BADARG, "wgrad_sp: geometry not covered");
+    if (!make_sp_plan(d, &pl)) return spa_wgrad_launch(d, x, dy, slabs, s);
     pl.p.x = x; pl.p.dy = dy; pl.p.slabs = slabs;
     const int unit = pl.unit;
     switch (pl.mode) {

@@ -278,6 +278,60 @@ def test_conv2d_wgrad_small_planes_stride2(T, case, lib_option):
     assert_close(host(gw3), gw_ref, REL_TOL, "the replaced kernel's weight grad")
 
 
+SPA_CASES = [
+    (2, 64, 9, 23, 64, 3, 1, 0),      # pad 0 (conv2d.cpp:41-42): 21 x 7 outputs = one column block of 21, 4 row pairs (the last one a single row)
+    (2, 40, 30, 50, 72, 3, 1, 1),     # pad 1: 50 outputs = two blocks of 28 (the second: 22 live columns), partial channel tiles, rows above / below the plane
+    (1, 64, 7, 109, 64, 3, 1, 0),     # 107 outputs: four blocks of 28 (23 live in the last), odd row count
+    (1, 32, 5, 222, 32, 3, 1, 0),     # 220 outputs: eight blocks, widths that are multiples of 4 (no fix-ups)
+    (1, 32, 6, 223, 40, 3, 1, 1),     # 223 in / out: odd width, the straddling units of x AND dy fixed up
+    (3, 64, 21, 21, 64, 3, 1, 0),     # 19 outputs: one block of 21, odd batch
+    (2, 128, 13, 13, 64, 3, 1, 1),    # two ci tiles
+    (5, 32, 3, 96, 32, 3, 1, 0),      # one output row (every pair's second row lies below the plane)
+    (40, 32, 12, 12, 32, 3, 1, 1),    # many stages per workgroup: the stage walk crosses row pairs, column blocks and samples
+]
+
+
+@pytest.mark.parametrize("case", SPA_CASES, ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_conv2d_wgrad_any_size_vs_oracle(T, case, lib_option):
+    """conv_wgrad_sp_any.hip (round 6: the runtime-size member of the LDS-staged output-stationary weight gradient, any plane size,
+    cpu/src/conv2d.cpp:117-159 / 41-42) against the oracle, on aligned and unaligned tensors, with NaN around the tensors (everything
+    outside them is a zero in LDS, never a value), one workgroup per tile walking every stage, and against the kernel it replaces"""
+    from cnn_amd import capi
+
+    lib_option("WGRAD_SP_ANY", "2")  # (also lifts the 32-channel floor of the default dispatch)
+    x, w, b, dy = _conv_inputs(case, 475)
+    _, gw_ref, gb_ref, _ = _oracle_conv(case, x, w, b, dy)
+    conv = capi.Conv2d(*case)
+    xd, dyd = dev(T, x), dev(T, dy)
+    capi.kernel_timing(1)
+    gw, gb = conv.backward_weight(xd, dyd, float(case[0]))
+    T.cuda.synchronize()
+    rep = capi.kernel_timing_report()
+    capi.kernel_timing(0)
+    assert any(k.startswith("wgrad_sp_any<") for k in rep), list(rep)
+    assert_close(host(gw), gw_ref, REL_TOL, "weight grad")
+    assert_close(host(gb), gb_ref, REL_TOL, "bias grad")
+    xs = T.empty(xd.numel() + 1, device="cuda")[1:].view_as(xd).copy_(xd)
+    dys = T.empty(dyd.numel() + 1, device="cuda")[1:].view_as(dyd).copy_(dyd)
+    assert xs.data_ptr() % 16 != 0
+    gw2, gb2 = conv.backward_weight(xs, dys, float(case[0]))
+    assert np.array_equal(host(gw), host(gw2)) and np.array_equal(host(gb), host(gb2))
+    big = T.full((xd.numel() + 8192,), float("nan"), device="cuda")
+    xn = big[4096 : 4096 + xd.numel()].view_as(xd).copy_(xd)
+    bigd = T.full((dyd.numel() + 8192,), float("nan"), device="cuda")
+    dyn = bigd[4096 : 4096 + dyd.numel()].view_as(dyd).copy_(dyd)
+    gw4, gb4 = conv.backward_weight(xn, dyn, float(case[0]))
+    assert np.array_equal(host(gw), host(gw4)) and np.array_equal(host(gb), host(gb4))
+    lib_option("SP_BLOCKS", "1")  # one pixel range per tile: a single workgroup walks every stage
+    gw5, gb5 = conv.backward_weight(xd, dyd, float(case[0]))
+    assert_close(host(gw5), gw_ref, REL_TOL, "weight grad, one workgroup per tile")
+    assert_close(host(gb5), gb_ref, REL_TOL, "bias grad, one workgroup per tile")
+    lib_option("SP_BLOCKS", None)
+    lib_option("WGRAD_SP_ANY", "0")
+    gw3, gb3 = conv.backward_weight(xd, dyd, float(case[0]))
+    assert_close(host(gw3), gw_ref, REL_TOL, "the replaced kernel's weight grad")
+
+
 @pytest.mark.parametrize("case", [SP_CASES[i] for i in (0, 2, 3, 5, 7)] + [(4, 16, 55, 55, 32, 3, 2, 0), (3, 64, 13, 13, 128, 3, 2, 0), (2, 32, 27, 27, 64, 3, 2, 0)],
                          ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
 def test_flat_slab_reduction_is_bit_identical_to_the_workgroup_one(T, case, lib_option):
