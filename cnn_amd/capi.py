@@ -108,6 +108,8 @@ SIGNATURES = {
     "cnn_batchnorm2d_forward": (C.c_int, [_P] * 8 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, _P, C.c_size_t, _P]),
     "cnn_batchnorm2d_forward_relu": (C.c_int, [_P] * 9 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, _P, C.c_size_t, _P]),
     "cnn_batchnorm2d_backward": (C.c_int, [_P] * 7 + [C.c_int] * 4 + [C.c_float, _P, C.c_size_t, _P]),
+    "cnn_batchnorm2d_backward_pooled_supported": (C.c_int, [C.c_int] * 4),
+    "cnn_batchnorm2d_backward_pooled": (C.c_int, [_P] * 10 + [C.c_int] * 4 + [C.c_float, _P, C.c_size_t, _P]),
     "cnn_batchnorm2d_partial_sums": (C.c_int, [_P, _P, C.c_float, _P] + [C.c_int] * 4 + [_P, C.c_size_t, _P]),
     "cnn_batchnorm2d_forward_from_sums": (C.c_int, [_P] * 10 + [C.c_float] + [C.c_int] * 4 + [C.c_float, C.c_float, _P]),
     "cnn_batchnorm2d_forward_from_sums_relu": (C.c_int, [_P] * 11 + [C.c_float] + [C.c_int] * 4 + [C.c_float, C.c_float, _P]),
@@ -616,6 +618,17 @@ class BatchNorm2d:
                                               _ptr(ggamma), _ptr(gbeta), self.B, self.C, self.H, self.W, self.eps,
                                               _ptr(self.ws), self.ws_bytes, _stream()), "cnn_batchnorm2d_backward")
         return dy
+
+    def backward_pooled_supported(self):
+        return bool(load().cnn_batchnorm2d_backward_pooled_supported(self.B, self.C, self.H, self.W))
+
+    def backward_pooled(self, x, dpool, mask, pooled, gamma, ggamma, gbeta, dx):
+        """BatchNorm2D <- ReLU <- MaxPool2D(2, 2) backward from the pooled domain (dpool, the pool's int32 mask and output): dx written,
+        ggamma / gbeta filled; bit-identical to maxpool2d_backward_relu + backward"""
+        check(load().cnn_batchnorm2d_backward_pooled(_ptr(x), _ptr(dpool), _ptr(mask), _ptr(pooled), _ptr(dx), _ptr(gamma), _ptr(self.saved_mean),
+                                                     _ptr(self.saved_var), _ptr(ggamma), _ptr(gbeta), self.B, self.C, self.H, self.W, self.eps,
+                                                     _ptr(self.ws), self.ws_bytes, _stream()), "cnn_batchnorm2d_backward_pooled")
+        return dx
 
 
 def prepare_filters(convs, weights, biases, fwd_bufs, dgrad_bufs):

@@ -260,13 +260,46 @@ __global__ __launch_bounds__(kBlock) void bn_apply(BnApply a, Geo q) {
     }
 }
 
+// (round 6) BatchNorm2D <- ReLU <- MaxPool2D(2, 2): the delta at the normalisation's output REBUILT from the pooled domain instead of read --
+// MaxPool2D::backward (pool2d.cpp:100-107: a window's delta goes to the element its mask names) and ReLU::backward (relu.cpp:37: 0 where the
+// ReLU output -- at a window's maximum that IS the pooled value -- is <= 0), element for element what maxpool_bwd_k2s2+relu (pool.hip)
+// writes.  The two backward kernels walk the SAME units / slots / lanes with the same arithmetic as with a materialised delta, so the
+// channel sums and dx are bit-identical to the three-kernel sequence; what goes away is the 4 B / element the pool's backward writes and the
+// 8 B / element the two passes read back (the stem of the ResNet-shaped stack: 205 MB each).  H even, W % 4 == 0.
+struct PoolDelta {
+    const float* dpool;
+    const int32_t* mask;
+    const float* pooled;
+    int W, PW, PHPW;   // input row length, pooled row length, pooled plane size
+    unsigned wmagic;   // ceil(2^32 / W): hw / W == umulhi(hw, wmagic) for hw < H * W
+};
+// the four deltas of the aligned slot at element hw (a multiple of 4) of plane `plane` = b * C + c; cbase = c * H * W (the mask holds
+// indices into the SAMPLE, pool2d.cpp:81)
+__device__ inline float4 pool_delta4(const PoolDelta& s, long long plane, int cbase, int hw) {
+    const int h = (int)__umulhi((unsigned)hw, s.wmagic), w = hw - h * s.W;
+    const long long wi = plane * s.PHPW + (long long)(h >> 1) * s.PW + (w >> 1);
+    const float2 dp = *(const float2*)(s.dpool + wi);
+    const int2 mk = *(const int2*)(s.mask + wi);
+    const float2 po = *(const float2*)(s.pooled + wi);
+    const float d0 = po.x <= 0.f ? 0.f : dp.x, d1 = po.y <= 0.f ? 0.f : dp.y;
+    const int f = cbase + hw, m0 = mk.x & 0x7fffffff, m1 = mk.y & 0x7fffffff;
+    return make_float4(m0 == f ? d0 : 0.f, m0 == f + 1 ? d0 : 0.f, m1 == f + 2 ? d1 : 0.f, m1 == f + 3 ? d1 : 0.f);
+}
+__device__ inline float pool_delta1(const PoolDelta& s, long long plane, int cbase, int hw) {
+    const int h = (int)__umulhi((unsigned)hw, s.wmagic), w = hw - h * s.W;
+    const long long wi = plane * s.PHPW + (long long)(h >> 1) * s.PW + (w >> 1);
+    const float d = s.pooled[wi] <= 0.f ? 0.f : s.dpool[wi];
+    return (s.mask[wi] & 0x7fffffff) == cbase + hw ? d : 0.f;
+}
+
 // partial sums of the backward pass, per channel (batchnorm2d.cpp:118-146):
 //   [0] sum dy*norm   [1] sum dy   [2] sum (dy*gamma)*(x-u)*(-0.5)*var_inv^3   [3] sum (x-u)
-__global__ __launch_bounds__(kBlock) void bn_bwd_stats(const float* __restrict__ x, const float* __restrict__ dy,
-                                                       const float* __restrict__ gamma,
-                                                       const float* __restrict__ saved_mean,
-                                                       const float* __restrict__ saved_var, float* __restrict__ part,
-                                                       float eps, Geo q) {
+template <bool POOLED>
+__global__ __launch_bounds__(kBlock) void bn_bwd_stats_t(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ saved_mean,
+                                                         const float* __restrict__ saved_var, float* __restrict__ part,
+                                                         float eps, Geo q, PoolDelta pd) {
     const int c = blockIdx.y, g = blockIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -286,29 +319,32 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_stats(const float* __restrict__
     for (long long un = ((long long)g * kWaves + wave) * q.P + wpart; un < q.units; un += (long long)q.G * kWaves * q.P) {
         long long g0, g1;
         unit_range(q, c, un, g0, g1);
+        const long long plane = (q.nseg == 1 ? un : un / q.nseg) * q.C + c, pbase = plane * q.HW;  // (POOLED: the unit's plane)
         walk_unit(
             g0, g1, sub, stride,
             [&](long long e) {
                 const float4 v = *(const float4*)(x + e);
-                const float4 d = *(const float4*)(dy + e);
+                const float4 d = POOLED ? pool_delta4(pd, plane, c * q.HW, (int)(e - pbase)) : *(const float4*)(dy + e);
                 one(v.x, d.x);
                 one(v.y, d.y);
                 one(v.z, d.z);
                 one(v.w, d.w);
             },
-            [&](long long e) { one(x[e], dy[e]); });
+            [&](long long e) { one(x[e], POOLED ? pool_delta1(pd, plane, c * q.HW, (int)(e - pbase)) : dy[e]); });
     }
     block_store_partials<4>(acc, part, q.G);
 }
 
-// dx = (dy*gamma)*var_inv + inv*2*(x-u) + u_g/L, in place on dy (batchnorm2d.cpp:148-155)
-__global__ __launch_bounds__(kBlock) void bn_bwd_apply(const float* __restrict__ x, float* __restrict__ dy,
-                                                       const float* __restrict__ gamma,
-                                                       const float* __restrict__ saved_mean,
-                                                       const float* __restrict__ saved_var,
-                                                       const float* __restrict__ part, float* __restrict__ ggamma,
-                                                       float* __restrict__ gbeta, float eps, Geo q,
-                                                       const float* __restrict__ gsums, float count) {
+// dx = (dy*gamma)*var_inv + inv*2*(x-u) + u_g/L, in place on dy (batchnorm2d.cpp:148-155); POOLED: dy rebuilt from the pooled domain
+// (pool_delta4), dx written to `dy` (nothing is read there)
+template <bool POOLED>
+__global__ __launch_bounds__(kBlock) void bn_bwd_apply_t(const float* __restrict__ x, float* __restrict__ dy,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ saved_mean,
+                                                         const float* __restrict__ saved_var,
+                                                         const float* __restrict__ part, float* __restrict__ ggamma,
+                                                         float* __restrict__ gbeta, float eps, Geo q,
+                                                         const float* __restrict__ gsums, float count, PoolDelta pd) {
 #pragma clang fp contract(off)
     const int c = blockIdx.y, g = blockIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
@@ -336,18 +372,22 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply(const float* __restrict__
     for (long long un = ((long long)g * kWaves + wave) * q.P + wpart; un < q.units; un += (long long)q.G * kWaves * q.P) {
         long long g0, g1;
         unit_range(q, c, un, g0, g1);
+        const long long plane = (q.nseg == 1 ? un : un / q.nseg) * q.C + c, pbase = plane * q.HW;  // (POOLED: the unit's plane)
         walk_unit(
             g0, g1, sub, stride,
             [&](long long e) {
                 const float4 v = *(const float4*)(x + e);
-                float4 d = *(float4*)(dy + e);
+                float4 d = POOLED ? pool_delta4(pd, plane, c * q.HW, (int)(e - pbase)) : *(float4*)(dy + e);
                 d.x = (d.x * gm) * var_inv + inv2 * (v.x - u) + u_term;
                 d.y = (d.y * gm) * var_inv + inv2 * (v.y - u) + u_term;
                 d.z = (d.z * gm) * var_inv + inv2 * (v.z - u) + u_term;
                 d.w = (d.w * gm) * var_inv + inv2 * (v.w - u) + u_term;
                 *(float4*)(dy + e) = d;
             },
-            [&](long long e) { dy[e] = (dy[e] * gm) * var_inv + inv2 * (x[e] - u) + u_term; });
+            [&](long long e) {
+                const float d = POOLED ? pool_delta1(pd, plane, c * q.HW, (int)(e - pbase)) : dy[e];
+                dy[e] = (d * gm) * var_inv + inv2 * (x[e] - u) + u_term;
+            });
     }
 }
 
@@ -701,10 +741,41 @@ int cnn_batchnorm2d_backward(const float* x, float* dy, const float* gamma, cons
     }
     float* part = (float*)workspace;
     CNN_KLAUNCH(s, "bn_bwd_stats",
-                (bn_bwd_stats<<<grid, kBlock, 0, s>>>(x, dy, gamma, saved_mean, saved_var, part, eps, q)), BN_TAG);
+                (bn_bwd_stats_t<false><<<grid, kBlock, 0, s>>>(x, dy, gamma, saved_mean, saved_var, part, eps, q, PoolDelta{})), BN_TAG);
     CNN_KLAUNCH(s, "bn_bwd_apply",
-                (bn_bwd_apply<<<grid, kBlock, 0, s>>>(x, dy, gamma, saved_mean, saved_var, part, ggamma, gbeta, eps, q, nullptr, 0.f)),
+                (bn_bwd_apply_t<false><<<grid, kBlock, 0, s>>>(x, dy, gamma, saved_mean, saved_var, part, ggamma, gbeta, eps, q, nullptr, 0.f, PoolDelta{})),
                 BN_TAG);
+    return CNN_AMD_OK;
+}
+
+int cnn_batchnorm2d_backward_pooled_supported(int B, int C, int H, int W) {
+    Geo q;
+    // (channels that fit one workgroup take the channel-resident kernel in cnn_batchnorm2d_backward: another summation order -- the pooled
+    //  form would not be bit-identical to the sequence it replaces there, and has nothing to save: 19 against 18 B / element)
+    return make_geo(B, C, H, W, &q) == CNN_AMD_OK && !channel_path(B, C, H, W) && H >= 2 && H % 2 == 0 && W % 4 == 0 &&
+                   (long long)C * H * W < (1ll << 31)
+               ? 1 : 0;
+}
+
+int cnn_batchnorm2d_backward_pooled(const float* x, const float* dpool, const int32_t* mask, const float* pooled, float* dx,
+                                    const float* gamma, const float* saved_mean, const float* saved_var, float* ggamma, float* gbeta,
+                                    int B, int C, int H, int W, float eps, void* workspace, size_t workspace_bytes, void* stream) {
+    Geo q;
+    int rc = make_geo(B, C, H, W, &q);
+    if (rc != CNN_AMD_OK) return rc;
+    CNN_REQUIRE(x && dpool && mask && pooled && dx && gamma && saved_mean && saved_var && ggamma && gbeta, "cnn_batchnorm2d_backward_pooled: null pointer");
+    CNN_REQUIRE(cnn_batchnorm2d_backward_pooled_supported(B, C, H, W), "cnn_batchnorm2d_backward_pooled: H must be even and W a multiple of 4 (%dx%d)", H, W);
+    CNN_REQUIRE(aligned16(x) && aligned16(dx) && ((uintptr_t)dpool & 7) == 0 && ((uintptr_t)mask & 7) == 0 && ((uintptr_t)pooled & 7) == 0,
+                "cnn_batchnorm2d_backward_pooled: x / dx must be 16-byte, the pooled-domain tensors 8-byte aligned");
+    CNN_REQUIRE(workspace && workspace_bytes >= cnn_batchnorm2d_workspace_bytes(B, C, H, W),
+                "cnn_batchnorm2d_backward_pooled: workspace too small (%zu bytes)", workspace_bytes);
+    hipStream_t s = as_stream(stream);
+    const dim3 grid(q.G, C);
+    const PoolDelta pd{dpool, mask, pooled, W, W / 2, (H / 2) * (W / 2), (unsigned)(((1ull << 32) + (unsigned)W - 1) / (unsigned)W)};
+    float* part = (float*)workspace;
+    CNN_KLAUNCH(s, "bn_bwd_stats+pool", (bn_bwd_stats_t<true><<<grid, kBlock, 0, s>>>(x, nullptr, gamma, saved_mean, saved_var, part, eps, q, pd)), BN_TAG);
+    CNN_KLAUNCH(s, "bn_bwd_apply+pool",
+                (bn_bwd_apply_t<true><<<grid, kBlock, 0, s>>>(x, dx, gamma, saved_mean, saved_var, part, ggamma, gbeta, eps, q, nullptr, 0.f, pd)), BN_TAG);
     return CNN_AMD_OK;
 }
 
@@ -779,7 +850,7 @@ int cnn_batchnorm2d_backward_sums(const float* x, const float* dy, const float* 
     hipStream_t s = as_stream(stream);
     float* part = (float*)workspace;
     CNN_KLAUNCH(s, "bn_bwd_stats",
-                (bn_bwd_stats<<<dim3(q.G, C), kBlock, 0, s>>>(x, dy, gamma, saved_mean, saved_var, part, eps, q)), BN_TAG);
+                (bn_bwd_stats_t<false><<<dim3(q.G, C), kBlock, 0, s>>>(x, dy, gamma, saved_mean, saved_var, part, eps, q, PoolDelta{})), BN_TAG);
     CNN_KLAUNCH(s, "bn_reduce_partials", (bn_reduce_partials<<<C, kWave, 0, s>>>(part, sums4, q.G, 4)), BN_TAG);
     return CNN_AMD_OK;
 }
@@ -795,8 +866,8 @@ int cnn_batchnorm2d_backward_from_sums(const float* x, float* dy, const float* g
     CNN_REQUIRE(aligned16(x) && aligned16(dy) && count > 0.f, "cnn_batchnorm2d_backward_from_sums: unaligned x / dy or count <= 0");
     hipStream_t s = as_stream(stream);
     CNN_KLAUNCH(s, "bn_bwd_apply/sync",
-                (bn_bwd_apply<<<dim3(q.G, C), kBlock, 0, s>>>(x, dy, gamma, saved_mean, saved_var, sums4, ggamma, gbeta, eps, q,
-                                                             sums4, count)),
+                (bn_bwd_apply_t<false><<<dim3(q.G, C), kBlock, 0, s>>>(x, dy, gamma, saved_mean, saved_var, sums4, ggamma, gbeta, eps, q,
+                                                                       sums4, count, PoolDelta{})),
                 BN_TAG);
     return CNN_AMD_OK;
 }

@@ -91,6 +91,7 @@ public:
 
 class ReLU;
 class MaxPool2D;
+class BatchNorm2D;
 
 class Conv2D : public Layer {
 private:
@@ -148,7 +149,11 @@ public:
     void save_weights(std::ofstream& writer) const override;
     void load_weights(std::ifstream& reader) override;
     int get_params_num() const;
-    void set_fused_relu(ReLU* relu) { fused_relu = relu; }  // addition (see architectures::fuse_layers)
+    void set_fused_relu(ReLU* relu) { fused_relu = relu; }
+    // additions used by the MaxPool2D behind this layer's ReLU (BatchNorm2D -> ReLU -> MaxPool2D(2, 2)): its backward pass runs this
+    // layer's from the pooled domain (cnn_batchnorm2d_backward_pooled: bit-identical) and arms the pass-through of backward()
+    bool backward_pooled_possible(int B) const;
+    void backward_pooled(const data_type* dpool, const int* mask, const data_type* pooled, data_type* dx, int B);  // addition (see architectures::fuse_layers)
     void set_comm(void* rccl_comm, int world, int rank) { comm = rccl_comm; comm_world = world; comm_rank = rank; }
     void set_fused_pool(MaxPool2D* pool) { fused_pool = pool; }
     void set_relu_below(ReLU* relu) { relu_below = relu; }
@@ -221,6 +226,7 @@ private:
     int cur_set = 0;
     int in_C = 0, in_H = 0, in_W = 0, batch = 0;
     ReLU* fused_relu_below = nullptr;  // the ReLU layer whose output is this pool's input (set by the container), or null
+    BatchNorm2D* fused_bn_below = nullptr;  // ... and the BatchNorm2D in front of THAT (BatchNorm2D -> ReLU -> this pool), or null
     bool forward_done = false;       // this pass' output + mask were written by the producing Conv2D kernel
     bool backward_passthrough = false;  // ... and the delta stays in the pooled domain for that Conv2D's backward
 
@@ -229,6 +235,7 @@ public:
         : Layer(_name), kernel_size(_kernel_size), step(_step), padding(0) {}
     ~MaxPool2D() override;
     void set_fused_relu_below(ReLU* relu) { fused_relu_below = relu; }  // addition (see architectures::fuse_layers)
+    void set_fused_bn_below(BatchNorm2D* bn) { fused_bn_below = bn; }   // addition: the three layers' backward passes as two kernels
     // additions used by Conv2D when the container fused Conv2D -> ReLU -> this pool into one kernel
     bool fusable_2x2() const { return kernel_size == 2 && step == 2; }
     void fused_forward_target(int B, int C, int H, int W, bool record, data_type** pooled, int** mask_out);  // arms forward_done
@@ -326,6 +333,7 @@ private:
     data_type* grads = nullptr;
     bool owns_params = true;
     bool grads_ready = false;
+    bool backward_done_by_pool = false;  // this pass' backward() already ran inside the pool's (see backward_pooled)
     data_type* saved_stats = nullptr;  // batch mean [C] then batch variance [C] (buffer_mean / buffer_var)
     BatchBuffer out_buf, in_stage, delta_stage;
     const data_type* saved_input = nullptr;
@@ -348,6 +356,10 @@ private:
 public:
     void set_comm(void* rccl_comm, int world) { comm = rccl_comm; comm_world = world; }
     void set_fused_relu(ReLU* relu) { fused_relu = relu; }
+    // additions used by the MaxPool2D behind this layer's ReLU (BatchNorm2D -> ReLU -> MaxPool2D(2, 2)): its backward pass runs this
+    // layer's from the pooled domain (cnn_batchnorm2d_backward_pooled: bit-identical) and arms the pass-through of backward()
+    bool backward_pooled_possible(int B) const;
+    void backward_pooled(const data_type* dpool, const int* mask, const data_type* pooled, data_type* dx, int B);
     std::vector<tensor> get_output() const override;
     void materialize() const;
     void set_param_snapshot(const data_type* snap, const bool* active) { snapshot = snap; snapshot_active = active; }

@@ -527,6 +527,14 @@ std::vector<tensor> MaxPool2D::backward(std::vector<tensor>& delta) {
     assert(mask != nullptr && "backward without a recorded forward (no_grad?)");
     if (delta_buf.empty()) delta_buf.allocate(batch, in_C, in_H, in_W, name + "_delta");
     const data_type* dy = batch_device_pointer(delta, delta_stage, name + "_dy");
+    if (fused_bn_below != nullptr && fused_relu_below != nullptr && fuse_layers && fusable_2x2() && padding == 0 &&
+        fused_bn_below->backward_pooled_possible(B)) {
+        // BatchNorm2D -> ReLU -> this pool: the three backward passes as two kernels that rebuild the delta between them from the pooled
+        // domain (bit-identical to the sequence; neither this layer's nor the ReLU's input gradient is materialised)
+        fused_bn_below->backward_pooled(dy, mask_dev(), pooled_dev(), delta_buf.base, B);
+        fused_relu_below->fused_backward_done();
+        return delta_buf.views;
+    }
     if (fused_relu_below != nullptr && fuse_layers) {  // also applies the ReLU::backward of the layer in front
         must(cnn_maxpool2d_backward_relu(dy, mask_dev(), pooled_dev(), delta_buf.base, B, in_C, in_H, in_W, kernel_size, step, stream),
              "cnn_maxpool2d_backward_relu");
@@ -753,8 +761,26 @@ std::vector<tensor> BatchNorm2D::get_output() const {
 
 // batchnorm2d.cpp:98-158: gamma / beta gradients (sums over the batch, not averaged) and the data gradient written
 // IN PLACE into the caller's delta, which is handed back
+bool BatchNorm2D::backward_pooled_possible(int B) const {
+    return saved_input != nullptr && !(comm != nullptr && comm_world > 1) && B == last_B &&
+           cnn_batchnorm2d_backward_pooled_supported(B, out_channels, in_H, in_W) != 0;
+}
+
+void BatchNorm2D::backward_pooled(const data_type* dpool, const int* mask, const data_type* pooled, data_type* dx, int B) {
+    const int C = out_channels;
+    must(cnn_batchnorm2d_backward_pooled(saved_input, dpool, mask, pooled, dx, params, saved_stats, saved_stats + C, grads, grads + C, B, C, in_H,
+                                         in_W, eps, workspace, workspace_bytes, stream),
+         "cnn_batchnorm2d_backward_pooled");
+    backward_done_by_pool = true;
+}
+
 std::vector<tensor> BatchNorm2D::backward(std::vector<tensor>& delta) {
     Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
+    if (backward_done_by_pool) {  // (the pool behind this layer's ReLU ran this pass from the pooled domain: delta already is dx)
+        backward_done_by_pool = false;
+        grads_ready = true;
+        return delta;
+    }
     const int B = (int)delta.size();
     assert(saved_input != nullptr && "backward without a recorded forward (no_grad?)");
     const int C = out_channels;

@@ -48,7 +48,12 @@ void Sequential::wire() {
         }
         // ReLU -> MaxPool2D: the ReLU's backward pass runs inside the pool's backward kernel
         if (auto* pool = dynamic_cast<MaxPool2D*>(next->get())) {
-            if (auto* relu = dynamic_cast<ReLU*>(it->get())) pool->set_fused_relu_below(relu);
+            if (auto* relu = dynamic_cast<ReLU*>(it->get())) {
+                pool->set_fused_relu_below(relu);
+                // BatchNorm2D -> ReLU -> MaxPool2D: ... and the normalisation's backward pass takes its delta from the pooled domain
+                if (it != layers_sequence.begin())
+                    if (auto* bn = dynamic_cast<BatchNorm2D*>(std::prev(it)->get())) pool->set_fused_bn_below(bn);
+            }
         }
         // ReLU -> Conv2D / LinearLayer: the ReLU's backward pass runs inside the consumer's data-gradient kernel
         if (auto* relu = dynamic_cast<ReLU*>(it->get())) {

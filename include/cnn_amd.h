@@ -355,6 +355,16 @@ int cnn_batchnorm2d_forward_relu(const float* x, float* y, float* y_relu, const 
 int cnn_batchnorm2d_backward(const float* x, float* dy, const float* gamma, const float* saved_mean,
                              const float* saved_var, float* ggamma, float* gbeta, int B, int C, int H, int W, float eps,
                              void* workspace, size_t workspace_bytes, void* stream);
+/* BatchNorm2D <- ReLU <- MaxPool2D(2, 2) (round 6): cnn_maxpool2d_backward_relu + cnn_batchnorm2d_backward without the tensor in between.
+ * The delta at the normalisation's output is REBUILT from the pooled domain -- dpool [B][C][H/2][W/2] (the pool's incoming delta), mask (the
+ * pool's int32 flat index into the sample, pool2d.cpp:81) and pooled (the pool's output = the ReLU output at the maximum: relu.cpp:37's test)
+ * -- inside the two backward kernels, which walk the same elements in the same order with the same arithmetic as cnn_batchnorm2d_backward:
+ * ggamma, gbeta and dx are BIT-IDENTICAL to the three-call sequence.  dx [B][C][H][W] is written (nothing is read there).  H even, W a
+ * multiple of 4 (_supported answers 1); x / dx 16-byte, dpool / mask / pooled 8-byte aligned; workspace as cnn_batchnorm2d_backward's. */
+int cnn_batchnorm2d_backward_pooled_supported(int B, int C, int H, int W);
+int cnn_batchnorm2d_backward_pooled(const float* x, const float* dpool, const int32_t* mask, const float* pooled, float* dx,
+                                    const float* gamma, const float* saved_mean, const float* saved_var, float* ggamma, float* gbeta,
+                                    int B, int C, int H, int W, float eps, void* workspace, size_t workspace_bytes, void* stream);
 
 /* BatchNorm2D with the batch SHARDED over data-parallel processes ("sync-BN"): the reference normalises over the whole
  * batch (batchnorm2d.cpp:46-63), so each rank computes per-channel partial sums, the caller all-reduces (sum) the small

@@ -321,3 +321,58 @@ def test_batchnorm_relu_only_output_and_its_recomputation(T, shape):
         again = T.full(shape, 7.0, device="cuda")
         bn.forward(x, gamma, beta, sm.clone(), sv.clone(), again, False)  # evaluation arithmetic on the saved batch statistics
         assert T.equal(again, y), float((again - y).abs().max())
+
+
+POOLED_SHAPES = [(2, 8, 112, 112), (6, 5, 60, 52), (1, 2, 140, 120), (2, 3, 2, 4), (2, 4, 66, 128), (3, 2, 74, 76)]  # (every channel beyond the one-workgroup limit: B*H*W > 16 K, or tiny)
+
+
+@pytest.mark.parametrize("shape", POOLED_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_batchnorm_backward_from_the_pooled_domain(T, shape):
+    """cnn_batchnorm2d_backward_pooled (round 6): BatchNorm2D <- ReLU <- MaxPool2D(2, 2) backward (batchnorm2d.cpp:98-158, relu.cpp:35-40,
+    pool2d.cpp:100-107) as two kernels that rebuild the delta between the layers from (dpool, mask, pooled): against the oracle's three
+    backward passes, and BIT-IDENTICAL to cnn_maxpool2d_backward_relu + cnn_batchnorm2d_backward (same elements, same order, same arithmetic)"""
+    from cnn_amd import capi
+
+    B, C, H, W = shape
+    x = (uniform_pm1(80, shape) * 2 + 0.3).astype(np.float32)
+    gamma = (uniform_pm1(81, (C,)) + 1.5).astype(np.float32)
+    beta = (uniform_pm1(82, (C,)) * 0.5).astype(np.float32)
+    mm0 = np.zeros(C, np.float32)
+    mv0 = np.ones(C, np.float32)
+    dpool = uniform_pm1(83, (B, C, H // 2, W // 2)).astype(np.float32)
+    # oracle: BN forward -> ReLU -> pool; backward pool -> ReLU' -> BN'
+    y_o, _, sm_o, sv_o, _, _ = O.batchnorm_forward(x, gamma, beta, mm0, mv0)
+    r_o = O.relu_forward(y_o)
+    p_o, m_o = O.maxpool_forward(r_o, 2, 2)
+    dr_o = O.maxpool_backward(dpool, m_o, shape, 2, 2)
+    dyo = O.relu_backward(r_o, dr_o)
+    dx_o, gg_o, gb_o = O.batchnorm_backward(x, dyo, gamma, sm_o, sv_o)
+
+    bn = capi.BatchNorm2d(B, C, H, W)
+    xd, gd, bd = dev(T, x), dev(T, gamma), dev(T, beta)
+    yd, rd = T.empty_like(xd), T.empty_like(xd)
+    bn.forward(xd, gd, bd, dev(T, mm0), dev(T, mv0), yd, training=True, y_relu=rd)
+    pooled, mask = capi.maxpool_forward(rd, 2, 2)
+    dpd = dev(T, dpool)
+    if not bn.backward_pooled_supported():  # (a channel that fits one workgroup: the sequence stays three kernels there)
+        assert B * H * W <= 16384
+        return
+    gg, gb, dx = T.full((C,), 7.0, device="cuda"), T.full((C,), 7.0, device="cuda"), T.full_like(xd, 7.0)
+    capi.kernel_timing(1)
+    bn.backward_pooled(xd, dpd, mask, pooled, gd, gg, gb, dx)
+    T.cuda.synchronize()
+    names = [k.split("|")[0] for k in capi.kernel_timing_report()]
+    capi.kernel_timing(0)
+    assert names == ["bn_bwd_stats+pool", "bn_bwd_apply+pool"], names
+    # (decisions: a ReLU / pool decision made on the HIP forward tensors can differ from the oracle's on a rounding-distance tie; on these
+    #  inputs none does -- asserted -- so the comparison is plain)
+    assert np.array_equal(host(mask), m_o) and np.array_equal(host(rd) > 0, r_o > 0)
+    assert_close(host(dx), dx_o, what="dx from the pooled domain")
+    assert_close(host(gg), gg_o, what="gamma gradient")
+    assert_close(host(gb), gb_o, what="beta gradient")
+    # the sequence it replaces, bit for bit
+    dy3 = capi.maxpool_backward_relu(dpd, mask, pooled, shape, 2, 2)
+    gg3, gb3 = T.empty((C,), device="cuda"), T.empty((C,), device="cuda")
+    bn.backward(xd, dy3, gd, gg3, gb3)
+    u32 = lambda t: host(t).view(np.uint32)
+    assert np.array_equal(u32(dx), u32(dy3)) and np.array_equal(u32(gg), u32(gg3)) and np.array_equal(u32(gb), u32(gb3))
