@@ -108,6 +108,8 @@ SIGNATURES = {
     "cnn_batchnorm2d_forward": (C.c_int, [_P] * 8 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, _P, C.c_size_t, _P]),
     "cnn_batchnorm2d_forward_relu": (C.c_int, [_P] * 9 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, _P, C.c_size_t, _P]),
     "cnn_batchnorm2d_backward": (C.c_int, [_P] * 7 + [C.c_int] * 4 + [C.c_float, _P, C.c_size_t, _P]),
+    "cnn_batchnorm2d_forward_relu_pool_supported": (C.c_int, [C.c_int] * 4),
+    "cnn_batchnorm2d_forward_relu_pool": (C.c_int, [_P] * 11 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, _P, C.c_size_t, _P]),
     "cnn_batchnorm2d_backward_pooled_supported": (C.c_int, [C.c_int] * 4),
     "cnn_batchnorm2d_backward_pooled": (C.c_int, [_P] * 10 + [C.c_int] * 4 + [C.c_float, _P, C.c_size_t, _P]),
     "cnn_batchnorm2d_partial_sums": (C.c_int, [_P, _P, C.c_float, _P] + [C.c_int] * 4 + [_P, C.c_size_t, _P]),
@@ -618,6 +620,14 @@ class BatchNorm2d:
                                               _ptr(ggamma), _ptr(gbeta), self.B, self.C, self.H, self.W, self.eps,
                                               _ptr(self.ws), self.ws_bytes, _stream()), "cnn_batchnorm2d_backward")
         return dy
+
+    def forward_relu_pool(self, x, gamma, beta, moving_mean, moving_var, pooled, mask, y=None, y_relu=None, training=True):
+        """BatchNorm2D -> ReLU -> MaxPool2D(2, 2) in one apply pass: pooled / mask written, y / y_relu only when given"""
+        check(load().cnn_batchnorm2d_forward_relu_pool(_ptr(x), _ptr(y), _ptr(y_relu), _ptr(pooled), _ptr(mask), _ptr(gamma), _ptr(beta),
+                                                       _ptr(moving_mean), _ptr(moving_var), _ptr(self.saved_mean), _ptr(self.saved_var), self.B,
+                                                       self.C, self.H, self.W, self.eps, self.momentum, 1 if training else 0, _ptr(self.ws),
+                                                       self.ws_bytes, _stream()), "cnn_batchnorm2d_forward_relu_pool")
+        return pooled
 
     def backward_pooled_supported(self):
         return bool(load().cnn_batchnorm2d_backward_pooled_supported(self.B, self.C, self.H, self.W))

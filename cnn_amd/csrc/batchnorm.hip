@@ -198,14 +198,10 @@ struct BnApply {
 // y = gamma * ((x - u) * var_inv) + beta  (batchnorm2d.cpp:69-77 / 84-92), moving statistics (:79-80)
 __device__ __forceinline__ float bn_relu(float v) { return v >= 0.f ? v : 0.f; }  // == elementwise.hip relu_f (relu.cpp:25)
 
-template <bool RELU>
-__global__ __launch_bounds__(kBlock) void bn_apply(BnApply a, Geo q) {
+// the channel's mean / variance of this pass (every workgroup of the channel computes the same two numbers from the same partials in the same
+// order), and -- workgroup 0 of the channel -- the saved / moving statistics (batchnorm2d.cpp:64-66, 79-80)
+__device__ __forceinline__ void bn_channel_stats(const BnApply& a, const Geo& q, int c, int g, int lane, float& u, float& var) {
 #pragma clang fp contract(off)
-    const int c = blockIdx.y, g = blockIdx.x;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int wpart = lane >> q.part_shift, stride = 1 << q.part_shift, sub = lane & (stride - 1);
-    float u, var;
     if (a.training) {
         if (a.gsum_x != nullptr) {
             u = a.gsum_x[c] / a.count;
@@ -232,6 +228,17 @@ __global__ __launch_bounds__(kBlock) void bn_apply(BnApply a, Geo q) {
         u = a.moving_mean[c];
         var = a.moving_var[c];
     }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(kBlock) void bn_apply(BnApply a, Geo q) {
+#pragma clang fp contract(off)
+    const int c = blockIdx.y, g = blockIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int wpart = lane >> q.part_shift, stride = 1 << q.part_shift, sub = lane & (stride - 1);
+    float u, var;
+    bn_channel_stats(a, q, c, g, lane, u, var);
     const float var_inv = 1.f / sqrtf(var + a.eps);
     const float gm = a.gamma[c], bt = a.beta[c];
     for (long long un = ((long long)g * kWaves + wave) * q.P + wpart; un < q.units; un += (long long)q.G * kWaves * q.P) {
@@ -257,6 +264,56 @@ __global__ __launch_bounds__(kBlock) void bn_apply(BnApply a, Geo q) {
                 if (!RELU || a.y != nullptr) a.y[e] = o;
                 if (RELU) a.y_relu[e] = bn_relu(o);
             });
+    }
+}
+
+// (round 6) BatchNorm2D -> ReLU -> MaxPool2D(2, 2) forward in ONE apply pass: a lane owns a pooling window -- two floats of row 2 ph and two
+// of row 2 ph + 1 -- normalises them (bn_apply's expression), applies ReLU (relu.cpp:25) and takes the window's maximum in the pool's scan
+// order with its strict '<' (pool2d.cpp:60-83: the first maximum wins; mask = flat index into the sample).  The normalised tensor and the
+// ReLU output are written only when asked for (a train step reads neither: BatchNorm2D::backward re-computes from x, the pooled-domain
+// backward pass below takes ReLU' from the pooled value).  Values are elementwise functions of x and the channel's statistics: bit-identical
+// to bn_apply -> maxpool_fwd.  H, W even.
+__global__ __launch_bounds__(kBlock) void bn_apply_pool(BnApply a, Geo q, float* __restrict__ pooled, int32_t* __restrict__ mask, int H, int W) {
+#pragma clang fp contract(off)
+    const int c = blockIdx.y, g = blockIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    float u, var;
+    bn_channel_stats(a, q, c, g, lane, u, var);
+    const float var_inv = 1.f / sqrtf(var + a.eps);
+    const float gm = a.gamma[c], bt = a.beta[c];
+    const int PH = H / 2, PW = W / 2;
+    const long long rows = (long long)q.B * PH;
+    for (long long un = (long long)g * kWaves + wave; un < rows; un += (long long)q.G * kWaves) {
+        const int b = (int)(un / PH), ph = (int)(un - (long long)b * PH);
+        const long long plane = (long long)b * q.C + c;
+        const long long r0 = plane * q.HW + (long long)(2 * ph) * W;
+        const int mbase = c * q.HW + 2 * ph * W;
+        for (int pw = lane; pw < PW; pw += kWave) {
+            const float2 t0 = *(const float2*)(a.x + r0 + 2 * pw), t1 = *(const float2*)(a.x + r0 + W + 2 * pw);
+            float2 o0, o1;
+            o0.x = gm * ((t0.x - u) * var_inv) + bt;
+            o0.y = gm * ((t0.y - u) * var_inv) + bt;
+            o1.x = gm * ((t1.x - u) * var_inv) + bt;
+            o1.y = gm * ((t1.y - u) * var_inv) + bt;
+            if (a.y != nullptr) {
+                *(float2*)(a.y + r0 + 2 * pw) = o0;
+                *(float2*)(a.y + r0 + W + 2 * pw) = o1;
+            }
+            o0.x = bn_relu(o0.x); o0.y = bn_relu(o0.y); o1.x = bn_relu(o1.x); o1.y = bn_relu(o1.y);
+            if (a.y_relu != nullptr) {
+                *(float2*)(a.y_relu + r0 + 2 * pw) = o0;
+                *(float2*)(a.y_relu + r0 + W + 2 * pw) = o1;
+            }
+            float best = o0.x;
+            int off = 0;
+            if (best < o0.y) { best = o0.y; off = 1; }
+            if (best < o1.x) { best = o1.x; off = W; }
+            if (best < o1.y) { best = o1.y; off = W + 1; }
+            const long long at = (plane * PH + ph) * PW + pw;
+            pooled[at] = best;
+            if (mask != nullptr) mask[at] = mbase + 2 * pw + off;
+        }
     }
 }
 
@@ -628,12 +685,14 @@ size_t cnn_batchnorm2d_workspace_bytes(int B, int C, int H, int W) {
 
 static int bn_forward_impl(const float* x, float* y, float* y_relu, const float* gamma, const float* beta, float* moving_mean,
                            float* moving_var, float* saved_mean, float* saved_var, int B, int C, int H, int W, float eps,
-                           float momentum, int training, void* workspace, size_t workspace_bytes, void* stream) {
+                           float momentum, int training, void* workspace, size_t workspace_bytes, void* stream, float* pooled = nullptr,
+                           int32_t* pool_mask = nullptr) {
     Geo q;
     int rc = make_geo(B, C, H, W, &q);
     if (rc != CNN_AMD_OK) return rc;
     // (round 4) y == NULL with y_relu: only the ReLU output is written (nothing in a train step reads the normalised tensor itself)
-    CNN_REQUIRE(x && (y || y_relu) && gamma && beta && moving_mean && moving_var, "cnn_batchnorm2d_forward: null pointer");
+    // (round 6) pooled: ReLU and MaxPool2D(2, 2) in the same apply pass; then neither y nor y_relu has to be written
+    CNN_REQUIRE(x && (y || y_relu || pooled) && gamma && beta && moving_mean && moving_var, "cnn_batchnorm2d_forward: null pointer");
     CNN_REQUIRE(aligned16(x) && aligned16(y) && aligned16(y_relu), "cnn_batchnorm2d_forward: x / y / y_relu must be 16-byte aligned");
     hipStream_t s = as_stream(stream);
     const dim3 grid(q.G, C);
@@ -643,7 +702,7 @@ static int bn_forward_impl(const float* x, float* y, float* y_relu, const float*
         CNN_REQUIRE(saved_mean && saved_var, "cnn_batchnorm2d_forward: training needs saved_mean / saved_var");
         CNN_REQUIRE(workspace && workspace_bytes >= cnn_batchnorm2d_workspace_bytes(B, C, H, W),
                     "cnn_batchnorm2d_forward: workspace too small (%zu bytes)", workspace_bytes);
-        if (channel_path(B, C, H, W)) {
+        if (channel_path(B, C, H, W) && pooled == nullptr) {
             const size_t lds = (size_t)B * H * W * sizeof(float);
             static DeviceOnce attr_once;
             if (attr_once.needed()) {
@@ -676,11 +735,33 @@ static int bn_forward_impl(const float* x, float* y, float* y_relu, const float*
             a.pilot = p1;  // (the second arena is free in this path: C <= C * G * 4)
         }
     }
-    if (y_relu)
+    if (pooled)
+        CNN_KLAUNCH(s, "bn_apply+relu+pool", (bn_apply_pool<<<grid, kBlock, 0, s>>>(a, q, pooled, pool_mask, H, W)), BN_TAG);
+    else if (y_relu)
         CNN_KLAUNCH(s, "bn_apply+relu", (bn_apply<true><<<grid, kBlock, 0, s>>>(a, q)), BN_TAG);
     else
         CNN_KLAUNCH(s, "bn_apply", (bn_apply<false><<<grid, kBlock, 0, s>>>(a, q)), BN_TAG);
     return CNN_AMD_OK;
+}
+
+int cnn_batchnorm2d_forward_relu_pool_supported(int B, int C, int H, int W) {
+    Geo q;
+    // (channels that fit one workgroup are normalised by the channel-resident kernel -- statistics and apply in one launch from LDS: the
+    //  pool stays its own kernel there)
+    return make_geo(B, C, H, W, &q) == CNN_AMD_OK && !channel_path(B, C, H, W) && H >= 2 && H % 2 == 0 && W >= 2 && W % 2 == 0 &&
+                   (long long)C * H * W < (1ll << 31)
+               ? 1 : 0;
+}
+
+int cnn_batchnorm2d_forward_relu_pool(const float* x, float* y, float* y_relu, float* pooled, int32_t* pool_mask, const float* gamma,
+                                      const float* beta, float* moving_mean, float* moving_var, float* saved_mean, float* saved_var, int B,
+                                      int C, int H, int W, float eps, float momentum, int training, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    CNN_REQUIRE(pooled != nullptr, "cnn_batchnorm2d_forward_relu_pool: null pooled");
+    CNN_REQUIRE(cnn_batchnorm2d_forward_relu_pool_supported(B, C, H, W), "cnn_batchnorm2d_forward_relu_pool: not supported for %dx%dx%dx%d", B, C, H, W);
+    CNN_REQUIRE(((uintptr_t)x & 7) == 0 && ((uintptr_t)y & 7) == 0 && ((uintptr_t)y_relu & 7) == 0, "cnn_batchnorm2d_forward_relu_pool: unaligned tensor");
+    return bn_forward_impl(x, y, y_relu, gamma, beta, moving_mean, moving_var, saved_mean, saved_var, B, C, H, W, eps, momentum, training, workspace,
+                           workspace_bytes, stream, pooled, pool_mask);
 }
 
 int cnn_batchnorm2d_forward(const float* x, float* y, const float* gamma, const float* beta, float* moving_mean,

@@ -149,11 +149,7 @@ public:
     void save_weights(std::ofstream& writer) const override;
     void load_weights(std::ifstream& reader) override;
     int get_params_num() const;
-    void set_fused_relu(ReLU* relu) { fused_relu = relu; }
-    // additions used by the MaxPool2D behind this layer's ReLU (BatchNorm2D -> ReLU -> MaxPool2D(2, 2)): its backward pass runs this
-    // layer's from the pooled domain (cnn_batchnorm2d_backward_pooled: bit-identical) and arms the pass-through of backward()
-    bool backward_pooled_possible(int B) const;
-    void backward_pooled(const data_type* dpool, const int* mask, const data_type* pooled, data_type* dx, int B);  // addition (see architectures::fuse_layers)
+    void set_fused_relu(ReLU* relu) { fused_relu = relu; }  // addition (see architectures::fuse_layers)
     void set_comm(void* rccl_comm, int world, int rank) { comm = rccl_comm; comm_world = world; comm_rank = rank; }
     void set_fused_pool(MaxPool2D* pool) { fused_pool = pool; }
     void set_relu_below(ReLU* relu) { relu_below = relu; }
@@ -236,6 +232,8 @@ public:
     ~MaxPool2D() override;
     void set_fused_relu_below(ReLU* relu) { fused_relu_below = relu; }  // addition (see architectures::fuse_layers)
     void set_fused_bn_below(BatchNorm2D* bn) { fused_bn_below = bn; }   // addition: the three layers' backward passes as two kernels
+    void own_backward() { backward_passthrough = false; }  // (a fused forward whose producer is NOT a Conv2D: backward() runs here)
+    bool plain_2x2() const { return kernel_size == 2 && step == 2 && padding == 0; }
     // additions used by Conv2D when the container fused Conv2D -> ReLU -> this pool into one kernel
     bool fusable_2x2() const { return kernel_size == 2 && step == 2; }
     void fused_forward_target(int B, int C, int H, int W, bool record, data_type** pooled, int** mask_out);  // arms forward_done
@@ -259,13 +257,16 @@ private:
     bool backward_done = false;  // this pass' delta was already masked by the consuming MaxPool2D kernel
     bool out_valid = true;       // false: the pool-fused pass did not write this layer's output (get_output re-computes it)
     const Conv2D* producer = nullptr;  // the convolution whose kernel writes this layer's output when fused
+    const BatchNorm2D* bn_producer = nullptr;  // ... or the normalisation (BatchNorm2D -> ReLU -> MaxPool2D in one apply pass)
 
 public:
     ReLU(std::string _name) : Layer(_name) {}
     std::vector<tensor> get_output() const override;
     bool output_valid() const { return out_valid; }
     void set_producer(const Conv2D* conv) { producer = conv; }
+    void set_bn_producer(const BatchNorm2D* bn) { bn_producer = bn; }
     data_type* rematerialize_target() { out_valid = true; return out_buf.base; }
+    data_type* rematerialize_target_const() const { const_cast<ReLU*>(this)->out_valid = true; return out_buf.base; }
     // additions used by Conv2D / MaxPool2D when the container fused this layer into their kernels
     data_type* fused_forward_target(int B, int C, int H, int W);  // output arena (allocated on first use); arms forward_done
     void fused_backward_done() { backward_done = true; }
@@ -345,6 +346,7 @@ private:
     int comm_world = 1;
     data_type* sync_sums = nullptr;  // [C] + [C] + [C][4] all-reduce operands
     ReLU* fused_relu = nullptr;      // the ReLU layer right behind this one (set by the container): its output comes from the apply pass
+    MaxPool2D* fused_pool = nullptr; // ... and the MaxPool2D behind THAT: pooled in the same pass
     // ---- fuse_pool_block: a training pass with a fused ReLU behind this layer writes ONLY the ReLU output (round 4); get_output() of
     // this layer re-computes the normalised tensor from the recorded input, the saved batch statistics and the gamma / beta of that pass
     mutable bool out_valid = true;
@@ -356,6 +358,8 @@ private:
 public:
     void set_comm(void* rccl_comm, int world) { comm = rccl_comm; comm_world = world; }
     void set_fused_relu(ReLU* relu) { fused_relu = relu; }
+    void set_fused_pool(MaxPool2D* pool) { fused_pool = pool; }  // addition: BatchNorm2D -> ReLU -> MaxPool2D(2, 2) in one apply pass
+    void materialize_relu() const;  // the ReLU output of a pass that wrote only the pooled tensor (ReLU::get_output)
     // additions used by the MaxPool2D behind this layer's ReLU (BatchNorm2D -> ReLU -> MaxPool2D(2, 2)): its backward pass runs this
     // layer's from the pooled domain (cnn_batchnorm2d_backward_pooled: bit-identical) and arms the pass-through of backward()
     bool backward_pooled_possible(int B) const;

@@ -567,6 +567,7 @@ void ReLU::fused_forward_skipped(int B, int C, int H, int W) {
 // alexnet.cpp:97,105 for a layer whose output the pool-fused pass did not write: the producing convolution re-computes it
 std::vector<tensor> ReLU::get_output() const {
     if (!out_valid && producer != nullptr) producer->materialize();
+    if (!out_valid && bn_producer != nullptr) bn_producer->materialize_relu();
     return Layer::get_output();
 }
 
@@ -720,7 +721,23 @@ std::vector<tensor> BatchNorm2D::forward(const std::vector<tensor>& input) {
                  "cnn_batchnorm2d_forward_from_sums");
         return output;
     }
-    if (y_relu)
+    if (y_relu && fused_pool != nullptr && fused_pool->plain_2x2() && cnn_batchnorm2d_forward_relu_pool_supported(B, C, H, W) != 0) {
+        // BatchNorm2D -> ReLU -> MaxPool2D(2, 2): the apply pass pools as well.  A training pass under fuse_pool_block writes neither the
+        // normalised tensor nor the ReLU output (backward() re-computes from x, the pool's backward pass takes ReLU' from the pooled value);
+        // both stay observable: get_output() re-computes them from the statistics this pass saved
+        data_type* pooled = nullptr;
+        int* pmask = nullptr;
+        fused_pool->fused_forward_target(B, C, H, W, /*record=*/!no_grad, &pooled, &pmask);
+        fused_pool->own_backward();
+        if (relu_only) {
+            fused_relu->fused_forward_skipped(B, C, H, W);
+            fused_relu->set_bn_producer(this);
+            y_relu = nullptr;
+        }
+        must(cnn_batchnorm2d_forward_relu_pool(x, y_out, y_relu, pooled, pmask, params, params + C, params + 2 * C, params + 3 * C, saved_stats,
+                                               saved_stats + C, B, C, H, W, eps, momentum, no_grad ? 0 : 1, workspace, workspace_bytes, stream),
+             "cnn_batchnorm2d_forward_relu_pool");
+    } else if (y_relu)
         must(cnn_batchnorm2d_forward_relu(x, y_out, y_relu, params, params + C, params + 2 * C, params + 3 * C, saved_stats,
                                           saved_stats + C, B, C, H, W, eps, momentum, no_grad ? 0 : 1, workspace, workspace_bytes,
                                           stream),
@@ -752,6 +769,21 @@ void BatchNorm2D::materialize() const {
                                  momentum, 0, workspace, workspace_bytes, stream),
          "cnn_batchnorm2d_forward");
     out_valid = true;
+}
+
+// the ReLU output of such a pass, on demand: relu(gamma * ((x - mean) * inv_std) + beta) with the saved statistics -- the evaluation entry's
+// arithmetic is the training pass' (see materialize())
+void BatchNorm2D::materialize_relu() const {
+    if (fused_relu == nullptr || fused_relu->output_valid()) return;
+    assert(saved_input != nullptr && "get_output() of a fused-away tensor before any forward pass");
+    if (recompute_lost)
+        throw std::runtime_error("cnn_amd host: " + name + ": get_output() of the ReLU output the last forward pass did not write, after the parameters that "
+                                 "pass used were overwritten: call forward() again, or set architectures::fuse_pool_block = false");
+    const int C = out_channels;
+    const data_type* gb = (snapshot != nullptr && snapshot_active != nullptr && *snapshot_active) ? snapshot : params;
+    must(cnn_batchnorm2d_forward_relu(saved_input, nullptr, fused_relu->rematerialize_target_const(), gb, gb + C, saved_stats, saved_stats + C, nullptr,
+                                      nullptr, last_B, C, in_H, in_W, eps, momentum, 0, workspace, workspace_bytes, stream),
+         "cnn_batchnorm2d_forward_relu");
 }
 
 std::vector<tensor> BatchNorm2D::get_output() const {

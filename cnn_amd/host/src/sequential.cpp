@@ -52,7 +52,10 @@ void Sequential::wire() {
                 pool->set_fused_relu_below(relu);
                 // BatchNorm2D -> ReLU -> MaxPool2D: ... and the normalisation's backward pass takes its delta from the pooled domain
                 if (it != layers_sequence.begin())
-                    if (auto* bn = dynamic_cast<BatchNorm2D*>(std::prev(it)->get())) pool->set_fused_bn_below(bn);
+                    if (auto* bn = dynamic_cast<BatchNorm2D*>(std::prev(it)->get())) {
+                        pool->set_fused_bn_below(bn);
+                        bn->set_fused_pool(pool);  // (forward: one apply pass writes the pooled tensor and the mask)
+                    }
             }
         }
         // ReLU -> Conv2D / LinearLayer: the ReLU's backward pass runs inside the consumer's data-gradient kernel

@@ -349,6 +349,15 @@ int cnn_batchnorm2d_forward_relu(const float* x, float* y, float* y_relu, const 
                                  float* moving_mean, float* moving_var, float* saved_mean, float* saved_var, int B, int C, int H,
                                  int W, float eps, float momentum, int training, void* workspace, size_t workspace_bytes,
                                  void* stream);
+/* BatchNorm2D -> ReLU -> MaxPool2D(2, 2) (round 6): the apply pass also pools -- pooled [B][C][H/2][W/2] and pool_mask (int32 flat index into
+ * the sample, pool2d.cpp:81; NULL: not recorded) are what cnn_maxpool2d_forward would make of y_relu, bit for bit (the pool's scan order and
+ * strict '<').  y and y_relu are each written only when non-NULL: a train step needs neither (cnn_batchnorm2d_backward_pooled takes the
+ * ReLU's test from `pooled`).  H, W even, channels beyond the one-workgroup limit (_supported answers 1); tensors 8-byte aligned. */
+int cnn_batchnorm2d_forward_relu_pool_supported(int B, int C, int H, int W);
+int cnn_batchnorm2d_forward_relu_pool(const float* x, float* y, float* y_relu, float* pooled, int32_t* pool_mask, const float* gamma,
+                                      const float* beta, float* moving_mean, float* moving_var, float* saved_mean, float* saved_var, int B,
+                                      int C, int H, int W, float eps, float momentum, int training, void* workspace, size_t workspace_bytes,
+                                      void* stream);
 /* dy is overwritten with dx IN PLACE, like the reference (:149-155).  ggamma[c] = sum dy*norm, gbeta[c] = sum dy:
  * plain sums over (B,H,W), NOT divided by the batch (:123-124).  x is the forward input, saved_* the batch
  * statistics of that forward call. */

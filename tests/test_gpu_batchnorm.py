@@ -376,3 +376,53 @@ def test_batchnorm_backward_from_the_pooled_domain(T, shape):
     bn.backward(xd, dy3, gd, gg3, gb3)
     u32 = lambda t: host(t).view(np.uint32)
     assert np.array_equal(u32(dx), u32(dy3)) and np.array_equal(u32(gg), u32(gg3)) and np.array_equal(u32(gb), u32(gb3))
+
+
+@pytest.mark.parametrize("shape", POOLED_SHAPES + [(2, 3, 30, 22)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+def test_batchnorm_relu_maxpool_in_one_apply_pass(T, shape, training):
+    """cnn_batchnorm2d_forward_relu_pool (round 6): BatchNorm2D -> ReLU -> MaxPool2D(2, 2) (batchnorm2d.cpp:24-95, relu.cpp:25,
+    pool2d.cpp:60-83) with the pool inside the apply pass: pooled tensor, mask, statistics and -- when asked for -- y and the ReLU output,
+    BIT-IDENTICAL to cnn_batchnorm2d_forward_relu + cnn_maxpool2d_forward; with neither y nor the ReLU output requested (the train step's
+    form) the same pooled tensor and mask"""
+    from cnn_amd import capi
+
+    B, C, H, W = shape
+    bn = capi.BatchNorm2d(B, C, H, W)
+    if not capi.load().cnn_batchnorm2d_forward_relu_pool_supported(B, C, H, W):
+        assert B * H * W <= 16384
+        return
+    x = (uniform_pm1(90, shape) * 2 + 0.3).astype(np.float32)
+    gamma = (uniform_pm1(91, (C,)) + 1.5).astype(np.float32)
+    beta = (uniform_pm1(92, (C,)) * 0.5).astype(np.float32)
+    mm0 = (uniform_pm1(93, (C,)) * 0.2).astype(np.float32)
+    mv0 = (uniform_pm1(94, (C,)) * 0.2 + 1.0).astype(np.float32)
+    xd, gd, bd = dev(T, x), dev(T, gamma), dev(T, beta)
+    u32 = lambda t: host(t).view(np.uint32)
+    # the two-call sequence
+    mm1, mv1 = dev(T, mm0), dev(T, mv0)
+    y1, r1 = T.empty_like(xd), T.empty_like(xd)
+    bn.forward(xd, gd, bd, mm1, mv1, y1, training=training, y_relu=r1)
+    p1, m1 = capi.maxpool_forward(r1, 2, 2)
+    sm1, sv1 = bn.saved_mean.clone(), bn.saved_var.clone()
+    # one pass, everything written
+    bn2 = capi.BatchNorm2d(B, C, H, W)
+    mm2, mv2 = dev(T, mm0), dev(T, mv0)
+    y2, r2 = T.full_like(xd, 7.0), T.full_like(xd, 7.0)
+    p2, m2 = T.full_like(p1, 7.0), T.full_like(m1, -3)
+    bn2.forward_relu_pool(xd, gd, bd, mm2, mv2, p2, m2, y=y2, y_relu=r2, training=training)
+    assert np.array_equal(u32(y2), u32(y1)) and np.array_equal(u32(r2), u32(r1))
+    assert np.array_equal(u32(p2), u32(p1)) and np.array_equal(host(m2), host(m1))
+    assert np.array_equal(u32(mm2), u32(mm1)) and np.array_equal(u32(mv2), u32(mv1))
+    if training:
+        assert np.array_equal(u32(bn2.saved_mean), u32(sm1)) and np.array_equal(u32(bn2.saved_var), u32(sv1))
+    # ... and the train step's form: only the pooled tensor and the mask
+    bn3 = capi.BatchNorm2d(B, C, H, W)
+    p3, m3 = T.full_like(p1, 7.0), T.full_like(m1, -3)
+    bn3.forward_relu_pool(xd, gd, bd, dev(T, mm0), dev(T, mv0), p3, m3, training=training)
+    assert np.array_equal(u32(p3), u32(p1)) and np.array_equal(host(m3), host(m1))
+    # against the oracle
+    if training:
+        y_o, _, _, _, _, _ = O.batchnorm_forward(x, gamma, beta, mm0, mv0)
+        p_o, _ = O.maxpool_forward(O.relu_forward(y_o), 2, 2)
+        assert_close(host(p3), p_o, what="pooled")
