@@ -272,6 +272,146 @@ __global__ __launch_bounds__(kThinWaves * 64) void conv_dgrad_thin_s2(const floa
     }
 }
 
+
+// ---- the same data gradient on PACKED fp32 FMAs (round 6) ----------------------------------------------------------------------------
+// The scalar-operand kernel above spends 147 v_fma_f32 per dy channel and grid position; on gfx950 v_pk_fma_f32 does two FMAs per lane
+// in the same issue slot.  Taps c and c + 1 (c odd) of a filter row multiply the SAME dy neighbour and feed the two column parities of
+// one pixel row: with the running sums kept as pairs (pw = 0, pw = 1) of (row parity ph, ci) they are ONE packed FMA -- filter pair as
+// an SGPR pair, the neighbour broadcast to both halves.  Tap 0 (pw = 1 only) stays a scalar FMA on the pair's second half: 4 instead of 7
+// instructions per filter row, 84 instead of 147 per channel, the SAME products added in the SAME order (bit-identical to the kernel
+// above).  The filters come re-packed, one 32-byte row per (channel, ci, tap row): [w0, 0, w1, w2, w3, w4, w5, w6] -- a row is one
+// s_load_dwordx8 whose register pairs are the packed operands; three rows per register set, one set ahead of the FMAs.
+constexpr int kThinPkRow = 8;
+__global__ void thin_pack_k7(const float* __restrict__ w, float* __restrict__ wp, int rows) {  // rows = Co * 3 * 7
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* src = w + (size_t)r * 7;
+    float* dst = wp + (size_t)r * kThinPkRow;
+    dst[0] = src[0];
+    dst[1] = 0.f;
+#pragma unroll
+    for (int c = 1; c < 7; ++c) dst[1 + c] = src[c];
+}
+
+__global__ __launch_bounds__(kThinWaves * 64) void conv_dgrad_thin_s2_pk7(const float* __restrict__ dy, const float* __restrict__ wp,
+                                                                         const float* __restrict__ relu_below, float* __restrict__ dx, int B,
+                                                                         int Co, int H, int W, int Ho, int Wo, int U, int V, int items_per_img) {
+    constexpr int K = 7, CI = 3, P = 3, NB = 4, J0 = 1, ROWS = CI * K;  // (geometry as in conv_dgrad_thin_s2<7>)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef float s8f __attribute__((ext_vector_type(8)));
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * kThinWaves + (threadIdx.x >> 6));
+    const int b = wid / items_per_img;
+    if (b >= B) return;
+    const int n = (wid - b * items_per_img) * 64 + lane;
+    const bool live = n < U * V;
+    const int hh = (live ? n : 0) / V, ww = (live ? n : 0) - hh * V;
+    constexpr unsigned kOOB = 0x7ffffffcu;
+    unsigned voff[NB][NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int oy = hh - J0 + j, ox = ww - J0 + i;
+            const bool ok = live && (unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo;
+            voff[j][i] = ok ? (unsigned)(oy * Wo + ox) * 4u : kOOB;
+        }
+    v2f acc[2][CI];  // [row parity][ci] = (column parity 0, column parity 1)
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) acc[ph][ci] = v2f{0.f, 0.f};
+    const int oplane = Ho * Wo;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * Co * oplane * 4u), 0x00020000);
+    int soff = b * Co * oplane * 4;
+    const float* wq0 = wp;  // wave-uniform
+    // (one 16-byte load per patch row instead of four 4-byte loads was measured SLOWER: 343 against 262 us -- NB round 6)
+    auto load_patch = [&](float (&v)[NB][NB], int so) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) v[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff[j][i], so, 0));
+    };
+    struct Rows3 {
+        s8f r0, r1, r2;
+    };
+    constexpr int NG = ROWS / 3;  // 7 groups of three rows per channel
+    static_assert(NG * 3 == ROWS, "three rows per register set");
+#define THIN_ACCS "v"(a00), "v"(a01), "v"(a02), "v"(a10), "v"(a11), "v"(a12)
+    auto issue = [&](auto G, Rows3& rs, const float* wq) {  // (the running sums as inputs: see the scalar kernel)
+        constexpr int off = decltype(G)::value * 3 * kThinPkRow * 4;
+        v2f &a00 = acc[0][0], &a01 = acc[0][1], &a02 = acc[0][2], &a10 = acc[1][0], &a11 = acc[1][1], &a12 = acc[1][2];  // (asm operands inside a generic lambda do not capture: named first)
+        asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(rs.r0) : "s"(wq), "n"(off), THIN_ACCS);
+        asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(rs.r1) : "s"(wq), "n"(off + 32));
+        asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(rs.r2) : "s"(wq), "n"(off + 64));
+    };
+#undef THIN_ACCS
+    auto landed = [&](Rows3& rs) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rs.r0), "+s"(rs.r1), "+s"(rs.r2)); };
+    auto row = [&](auto CR, const s8f& q, const float (&v)[NB][NB]) {
+        constexpr int cr = decltype(CR)::value, ci = cr / K, r = cr % K;
+        constexpr int ph = (r + P) & 1, j = (P + ph - r) / 2 + J0;
+        v2f a = acc[ph][ci];
+        a.y = __builtin_fmaf(q[0], v[j][3], a.y);                                        // tap 0: column parity 1, neighbour ww + 2
+        a = __builtin_elementwise_fma(v2f{q[2], q[3]}, v2f{v[j][2], v[j][2]}, a);        // taps 1, 2: neighbour ww + 1
+        a = __builtin_elementwise_fma(v2f{q[4], q[5]}, v2f{v[j][1], v[j][1]}, a);        // taps 3, 4: neighbour ww
+        a = __builtin_elementwise_fma(v2f{q[6], q[7]}, v2f{v[j][0], v[j][0]}, a);        // taps 5, 6: neighbour ww - 1
+        acc[ph][ci] = a;
+    };
+    auto fmas = [&](auto G, const Rows3& rs, const float (&v)[NB][NB]) {
+        constexpr int g = decltype(G)::value;
+        row(std::integral_constant<int, 3 * g>(), rs.r0, v);
+        row(std::integral_constant<int, 3 * g + 1>(), rs.r1, v);
+        row(std::integral_constant<int, 3 * g + 2>(), rs.r2, v);
+    };
+    auto accumulate = [&](const float (&v)[NB][NB], const float* wq) {
+        Rows3 ra, rb;
+        issue(std::integral_constant<int, 0>(), ra, wq);
+#define THIN_GROUP(G, CUR, NXT)                                                                  \
+    landed(CUR);                                                                                 \
+    if constexpr (G + 1 < NG) issue(std::integral_constant<int, (G + 1 < NG ? G + 1 : G)>(), NXT, wq); \
+    fmas(std::integral_constant<int, G>(), CUR, v);
+        THIN_GROUP(0, ra, rb) THIN_GROUP(1, rb, ra) THIN_GROUP(2, ra, rb) THIN_GROUP(3, rb, ra) THIN_GROUP(4, ra, rb) THIN_GROUP(5, rb, ra)
+        THIN_GROUP(6, ra, rb)
+#undef THIN_GROUP
+        static_assert(NG == 7, "THIN_GROUP sequence above");
+    };
+    int co = 0;
+    for (; co + 1 < Co; co += 2) {
+        float va[NB][NB], vb[NB][NB];
+        load_patch(va, soff);
+        load_patch(vb, soff + oplane * 4);
+        accumulate(va, wq0);
+        accumulate(vb, wq0 + ROWS * kThinPkRow);
+        soff += 2 * oplane * 4;
+        wq0 += 2 * ROWS * kThinPkRow;
+    }
+    if (co < Co) {
+        float va[NB][NB];
+        load_patch(va, soff);
+        accumulate(va, wq0);
+    }
+    if (live) {
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const int y = 2 * hh + ph;
+                if (y < H) {
+#pragma unroll
+                    for (int pw = 0; pw < 2; ++pw) {
+                        const int x = 2 * ww + pw;
+                        if (x < W) {
+                            const size_t o = (((size_t)b * CI + ci) * H + y) * W + x;
+                            float val = pw == 0 ? acc[ph][ci].x : acc[ph][ci].y;
+                            if (relu_below) val = (relu_below[o] <= 0.f) ? 0.f : val;
+                            dx[o] = val;
+                        }
+                    }
+                }
+            }
+    }
+}
+
 }  // namespace
 
 namespace cnn_amd {
@@ -287,13 +427,33 @@ bool thin_dgrad_supported(const cnn_conv2d_desc* d) {
     return d->Ci == 3 && d->k == 3 && d->s == 1 && d->pad >= 0 && d->pad <= 1 && (long long)d->B * ((d->H + 3) / 4) * ((d->W + 63) / 64) < (1ll << 31) - 8;
 }
 
-// w: the filters in the reference layout [Co][3][3][3] (for the *_prepared entry points: the verbatim copy cnn_conv2d_prepare_filters made)
-int thin_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* relu_below, float* dx, hipStream_t s) {
+// the packed image of the 7x7 stem's data gradient (conv_dgrad_thin_s2_pk7): floats, and the kernel that makes it; 0 = this layer has none
+size_t thin_dgrad_packed_floats(const cnn_conv2d_desc* d) {
+    if (!(d->Ci == 3 && d->k == 7 && d->s == 2 && d->pad == 3) || !thin_dgrad_supported(d)) return 0;
+    if (CNN_OPT_SET("DGRAD_THIN_PK") && CNN_OPT_INT("DGRAD_THIN_PK", 1) == 0) return 0;  // (A/B: the scalar-operand kernel)
+    return (size_t)d->Co * 3 * 7 * kThinPkRow;
+}
+int thin_dgrad_pack(const cnn_conv2d_desc* d, const float* w, float* image, hipStream_t s) {
+    const int rows = d->Co * 3 * 7;
+    CNN_KLAUNCH(s, "thin_pack_k7", (thin_pack_k7<<<(rows + 255) / 256, 256, 0, s>>>(w, image, rows)), "Co%d", d->Co);
+    return CNN_AMD_OK;
+}
+
+// w: the filters in the reference layout [Co][3][k][k] (for the *_prepared entry points: the verbatim copy cnn_conv2d_prepare_filters made);
+// packed (nullable): the image thin_dgrad_pack made of them, for layers with thin_dgrad_packed_floats() > 0
+int thin_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* packed, const float* relu_below, float* dx, hipStream_t s) {
     const int Ho = cnn_conv2d_out_dim(d->H, d->k, d->s, d->pad), Wo = cnn_conv2d_out_dim(d->W, d->k, d->s, d->pad);
     if (d->s == 2) {
         const int U = (d->H + 1) / 2, V = (d->W + 1) / 2, ipi = (U * V + 63) / 64;
         const long long nw = (long long)d->B * ipi;
         const unsigned g2 = (unsigned)((nw + kThinWaves - 1) / kThinWaves);
+        if (packed) {
+            CNN_KLAUNCH(s, relu_below ? "conv_dgrad_thin_pk<3,k7s2>+relu" : "conv_dgrad_thin_pk<3,k7s2>",
+                        (conv_dgrad_thin_s2_pk7<<<g2, kThinWaves * 64, 0, s>>>(dy, packed, relu_below, dx, d->B, d->Co, d->H, d->W, Ho, Wo, U, V, ipi)),
+                        CONV_TAG(d));
+            return CNN_AMD_OK;
+        }
+        CNN_REQUIRE(w != nullptr, "conv_dgrad_thin: the filters are null");
         CNN_KLAUNCH(s, relu_below ? "conv_dgrad_thin<3,k7s2>+relu" : "conv_dgrad_thin<3,k7s2>",
                     (conv_dgrad_thin_s2<7><<<g2, kThinWaves * 64, 0, s>>>(dy, w, relu_below, dx, d->B, d->Co, d->H, d->W, Ho, Wo, U, V, ipi)),
                     CONV_TAG(d));

@@ -1702,7 +1702,9 @@ bool fwd_rd_small(const cnn_conv2d_desc* d);           // conv_fwd_rd.hip: the s
 bool stem_fwd_supported(const cnn_conv2d_desc* d);     // conv_stem.hip: Ci = 3, 7x7, stride 2, pad 3 forward on its own MFMA kernel
 int stem_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, float* y_relu, hipStream_t s);
 bool thin_dgrad_supported(const cnn_conv2d_desc* d);   // conv_dgrad_thin.hip: VALU data gradient of thin (Ci = 3) stride-1 layers
-int thin_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* relu_below, float* dx, hipStream_t s);
+int thin_dgrad(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* packed, const float* relu_below, float* dx, hipStream_t s);
+size_t thin_dgrad_packed_floats(const cnn_conv2d_desc* d);  // > 0: the layer's data gradient reads a packed filter image (the 7x7 stem) ...
+int thin_dgrad_pack(const cnn_conv2d_desc* d, const float* w, float* image, hipStream_t s);  // ... made by this
 bool c11_supported(const cnn_conv2d_desc* d);          // conv_1x1.hip: 1x1 convolutions (stride 1 / 2) as plain LDS-tiled GEMMs
 int c11_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, float* y_relu, hipStream_t s);
 int c11_backward_data(const cnn_conv2d_desc* d, const float* dy, const float* w, const float* relu_below, float* dx, hipStream_t s);
@@ -1737,6 +1739,7 @@ size_t igemm_workspace_floats(const cnn_conv2d_desc* d) {
     if (pk_dgrad_s2_supported(d) && n < pk_dgrad_s2_workspace_floats(d)) n = pk_dgrad_s2_workspace_floats(d);
     if (fwd_rd_prepared_floats(d) > n) n = fwd_rd_prepared_floats(d);
     if (dgrad_rd_prepared_floats(d) > n) n = dgrad_rd_prepared_floats(d);
+    if (thin_dgrad_supported(d) && thin_dgrad_packed_floats(d) > n) n = thin_dgrad_packed_floats(d);
     for (int mode = 0; mode < 2; ++mode)
         if (rows_workspace_floats(d, mode) > n) n = rows_workspace_floats(d, mode);
     memo.put(d, n);
@@ -1782,8 +1785,16 @@ static int conv2d_backward_data_impl(const char* who, const cnn_conv2d_desc* d, 
     }
     if (c11_supported(d))  // (its "prepared" image is a verbatim copy of w)
         return c11_backward_data(d, dy, prepared ? (const float*)ws : w, relu_below, dx, as_stream(stream));
-    if (thin_dgrad_supported(d))  // (its "prepared" image is a verbatim copy of w)
-        return thin_dgrad(d, dy, prepared ? (const float*)ws : w, relu_below, dx, as_stream(stream));
+    if (thin_dgrad_supported(d)) {
+        const size_t pk = thin_dgrad_packed_floats(d);
+        if (pk == 0)  // (the "prepared" image of such a layer is a verbatim copy of w)
+            return thin_dgrad(d, dy, prepared ? (const float*)ws : w, nullptr, relu_below, dx, as_stream(stream));
+        if (prepared) return thin_dgrad(d, dy, nullptr, (const float*)ws, relu_below, dx, as_stream(stream));  // (prepared image = the packed one)
+        if (ws == nullptr || ws_bytes < pk * sizeof(float))
+            return thin_dgrad(d, dy, w, nullptr, relu_below, dx, as_stream(stream));  // (no room for the packed image: the scalar-operand kernel)
+        if (int rc = thin_dgrad_pack(d, w, (float*)ws, as_stream(stream))) return rc;
+        return thin_dgrad(d, dy, nullptr, (const float*)ws, relu_below, dx, as_stream(stream));
+    }
     if (rows_workspace_floats(d, MODE_DGRAD) > 0 && ws != nullptr && ws_bytes >= rows_workspace_floats(d, MODE_DGRAD) * sizeof(float) &&
         (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
         if (!prepared)
@@ -2125,6 +2136,10 @@ int cnn_conv2d_prepare_filters(int n, const cnn_conv2d_desc* descs, const float*
                 continue;
             }
             if (mode == MODE_DGRAD && !direct_conv_supported(&descs[i]) && thin_dgrad_supported(&descs[i])) {
+                if (thin_dgrad_packed_floats(&descs[i]) > 0) {  // the 7x7 stem: packed rows (conv_dgrad_thin_s2_pk7)
+                    if (int rc = thin_dgrad_pack(&descs[i], w[i], (float*)out, s)) return rc;
+                    continue;
+                }
                 // conv_dgrad_thin.hip reads the reference layout: its prepared image is a verbatim copy
                 CNN_HIP_CHECK(hipMemcpyAsync(out, w[i], sizeof(float) * (size_t)descs[i].Co * descs[i].Ci * descs[i].k * descs[i].k,
                                              hipMemcpyDeviceToDevice, s));

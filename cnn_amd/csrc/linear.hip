@@ -171,9 +171,9 @@ __global__ __launch_bounds__(kBlock) void linear_fwd_softmax_xent(const float* _
 #pragma unroll
             for (int u = 0; u < UK; ++u) {
                 float sj = 0.f;  // (linear_bwd_fused's expression, term by term)
-                sj += d0 * wk[u].a;
-                sj += d1 * wk[u].b;
-                sj += d2 * wk[u].c;
+                sj = __builtin_fmaf(d0, wk[u].a, sj);  // (explicit: the contraction must not depend on the loop shape)
+                sj = __builtin_fmaf(d1, wk[u].b, sj);
+                sj = __builtin_fmaf(d2, wk[u].c, sj);
                 dxb[threadIdx.x + u * kBlock] = (DX == 2 && xk[u] <= 0.f) ? 0.f : sj;
             }
         } else {
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void linear_fwd_softmax_xent(const float* _
                 float sj = 0.f;
 #pragma unroll
                 for (int j = 0; j < kOutTile; ++j)
-                    if (j < out) sj += dl[j] * wr[j];
+                    if (j < out) sj = __builtin_fmaf(dl[j], wr[j], sj);
                 dxb[i2] = (DX == 2 && xb[i2] <= 0.f) ? 0.f : sj;
             }
         }
@@ -268,56 +268,101 @@ __global__ __launch_bounds__(kBlock) void linear_bwd_x(const float* __restrict__
 // RELU: x is the output of the ReLU layer feeding this layer; dx is stored as (x <= 0 ? 0 : dx) = that layer's backward pass
 // (relu.cpp:38) -- the mask value is the x element this thread has loaded anyway.
 constexpr int kFG = 16;
-template <bool RELU, bool WRITE_DX = true>  // WRITE_DX = false: weight / bias gradient only (dx came from the head kernel)
+// OUT is a compile-time constant and the x loads of a 16-sample batch are issued -- unconditionally, on clamped indices -- before the
+// first FMA (round 6: with a runtime `out` the compiler had put every load of the loop behind its own branch and s_waitcnt vmcnt(0):
+// sixteen dependent round trips, 30 us for 4.7 MB); the sample group is wave-uniform, so a sample's dy row comes through the scalar cache.
+template <int OUT, bool RELU, bool WRITE_DX>  // WRITE_DX = false: weight / bias gradient only (dx came from the head kernel)
 __global__ __launch_bounds__(kNeur * kFG) void linear_bwd_fused(const float* __restrict__ x, const float* __restrict__ dy,
                                                                const float* __restrict__ w, float* __restrict__ gw,
                                                                float* __restrict__ gb, float* __restrict__ dx, int B,
-                                                               int in, int out, float divisor) {
-    __shared__ float red[kFG][kOutTile + 1][kNeur];
-    const int il = threadIdx.x & (kNeur - 1), grp = threadIdx.x / kNeur;
+                                                               int in, float divisor) {
+    static_assert(kNeur == kWave, "a sample group is one wave");
+    __shared__ float red[kFG][OUT + 1][kNeur];
+    const int il = threadIdx.x & (kNeur - 1), grp = __builtin_amdgcn_readfirstlane(threadIdx.x / kNeur);
     const int i = blockIdx.x * kNeur + il;
     const bool live = i < in;
+    const int ic = live ? i : in - 1;  // (lanes behind the last neuron load a valid address and store nothing)
     const int per = (B + kFG - 1) / kFG;
     const int bb = grp * per, be = min(B, bb + per);
-    float wr[kOutTile], acc[kOutTile], bsum = 0.f;
+    float wr[OUT], acc[OUT], bsum = 0.f;
 #pragma unroll
-    for (int j = 0; j < kOutTile; ++j) {
+    for (int j = 0; j < OUT; ++j) {
         acc[j] = 0.f;
-        wr[j] = (live && j < out) ? w[(size_t)i * out + j] : 0.f;
+        wr[j] = WRITE_DX ? w[(size_t)ic * OUT + j] : 0.f;
     }
-#pragma unroll 16  // (B = 256: all 16 x loads of a thread in flight at once -- the kernel shares the chip with an HBM-bound one)
-    for (int b = bb; b < be; ++b) {
-        const float xv = live ? x[(size_t)b * in + i] : 0.f;
-        const float* d = dy + (size_t)b * out;
-        float s = 0.f;
+    constexpr int U = 16;
+    for (int b0 = bb; b0 < be; b0 += U) {
+        float xv[U], dv[U][OUT];
 #pragma unroll
-        for (int j = 0; j < kOutTile; ++j)
-            if (j < out) {
-                const float dj = d[j];
-                acc[j] += xv * dj;
-                s += dj * wr[j];
+        for (int u = 0; u < U; ++u) xv[u] = x[(size_t)min(b0 + u, be - 1) * in + ic];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < OUT; ++j) dv[u][j] = dy[(size_t)min(b0 + u, be - 1) * OUT + j];  // (scalar loads: the row is wave-uniform)
+        const int nu = min(U, be - b0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (u < nu) {  // (wave-uniform)
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < OUT; ++j) {
+                    acc[j] = __builtin_fmaf(xv[u], dv[u][j], acc[j]);
+                    s = __builtin_fmaf(dv[u][j], wr[j], s);
+                }
+                if (WRITE_DX && live) dx[(size_t)(b0 + u) * in + i] = (RELU && xv[u] <= 0.f) ? 0.f : s;
             }
-        if (WRITE_DX && live) dx[(size_t)b * in + i] = (RELU && xv <= 0.f) ? 0.f : s;
-        if (blockIdx.x == 0 && il < out) bsum += d[il];  // lane j of every group: bias partial of output j
+        }
     }
+    if (blockIdx.x == 0)  // lane j < OUT of every group: bias partial of output j (all loads of a batch before the first sum)
+        for (int b0 = bb; b0 < be; b0 += U) {
+            float bv[U];
 #pragma unroll
-    for (int j = 0; j < kOutTile; ++j) red[grp][j][il] = acc[j];
-    red[grp][kOutTile][il] = bsum;
+            for (int u = 0; u < U; ++u) bv[u] = dy[(size_t)min(b0 + u, be - 1) * OUT + min(il, OUT - 1)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) bsum += b0 + u < be ? bv[u] : 0.f;
+        }
+#pragma unroll
+    for (int j = 0; j < OUT; ++j) red[grp][j][il] = acc[j];
+    red[grp][OUT][il] = bsum;
     __syncthreads();
     if (grp == 0) {
         if (live)
-            for (int j = 0; j < out; ++j) {
+#pragma unroll
+            for (int j = 0; j < OUT; ++j) {
                 float t = 0.f;
 #pragma unroll
                 for (int g2 = 0; g2 < kFG; ++g2) t += red[g2][j][il];
-                gw[(size_t)i * out + j] = t / divisor;
+                gw[(size_t)i * OUT + j] = t / divisor;
             }
-        if (blockIdx.x == 0 && il < out) {
+        if (blockIdx.x == 0 && il < OUT) {
             float t = 0.f;
 #pragma unroll
-            for (int g2 = 0; g2 < kFG; ++g2) t += red[g2][kOutTile][il];
+            for (int g2 = 0; g2 < kFG; ++g2) t += red[g2][OUT][il];
             gb[il] = t / divisor;
         }
+    }
+}
+
+template <int OUT>
+static void launch_bwd_fused(hipStream_t s, int variant, const float* x, const float* dy, const float* w, float* gw, float* gb, float* dx,
+                             int B, int in, float divisor) {
+    const dim3 grid(ceil_div(in, kNeur)), block(kNeur * kFG);
+    if (variant == 0) linear_bwd_fused<OUT, false, false><<<grid, block, 0, s>>>(x, dy, w, gw, gb, nullptr, B, in, divisor);
+    else if (variant == 1) launch_pub(linear_bwd_fused<OUT, true, true>, grid, block, 0, s, x, dy, w, gw, gb, dx, B, in, divisor);
+    else launch_pub(linear_bwd_fused<OUT, false, true>, grid, block, 0, s, x, dy, w, gw, gb, dx, B, in, divisor);
+}
+// variant 0: weight / bias gradient alone; 1: all three + the ReLU::backward of the layer in front; 2: all three
+static void launch_bwd_fused(hipStream_t s, int variant, const float* x, const float* dy, const float* w, float* gw, float* gb, float* dx,
+                             int B, int in, int out, float divisor) {
+    switch (out) {
+        case 1: return launch_bwd_fused<1>(s, variant, x, dy, w, gw, gb, dx, B, in, divisor);
+        case 2: return launch_bwd_fused<2>(s, variant, x, dy, w, gw, gb, dx, B, in, divisor);
+        case 3: return launch_bwd_fused<3>(s, variant, x, dy, w, gw, gb, dx, B, in, divisor);
+        case 4: return launch_bwd_fused<4>(s, variant, x, dy, w, gw, gb, dx, B, in, divisor);
+        case 5: return launch_bwd_fused<5>(s, variant, x, dy, w, gw, gb, dx, B, in, divisor);
+        case 6: return launch_bwd_fused<6>(s, variant, x, dy, w, gw, gb, dx, B, in, divisor);
+        case 7: return launch_bwd_fused<7>(s, variant, x, dy, w, gw, gb, dx, B, in, divisor);
+        default: return launch_bwd_fused<8>(s, variant, x, dy, w, gw, gb, dx, B, in, divisor);
     }
 }
 
@@ -341,20 +386,14 @@ static int linear_backward_impl(const float* x, const float* dy, const float* w,
     CNN_REQUIRE(B <= 65535, "cnn_linear_backward: B=%d exceeds the grid.y limit", B);
     hipStream_t s = as_stream(stream);
     if (gw && gb && !dx && x && w && out <= kOutTile) {  // the gradients of the parameters alone, in linear_bwd_fused's summation order
-        CNN_KLAUNCH(s, "linear_bwd_fused/wb",
-                    (linear_bwd_fused<false, false><<<dim3(ceil_div(in, kNeur)), dim3(kNeur * kFG), 0, s>>>(x, dy, w, gw, gb, nullptr, B, in, out, divisor)),
-                    "B%d in%d out%d", B, in, out);
+        CNN_KLAUNCH(s, "linear_bwd_fused/wb", launch_bwd_fused(s, 0, x, dy, w, gw, gb, nullptr, B, in, out, divisor), "B%d in%d out%d", B, in, out);
         return CNN_AMD_OK;
     }
     if (gw && gb && dx && x && w && out <= kOutTile) {
         if (relu_below)
-            CNN_KLAUNCH(s, "linear_bwd_fused+relu",
-                        (launch_pub(linear_bwd_fused<true>, dim3(ceil_div(in, kNeur)), dim3(kNeur * kFG), 0, s, x, dy, w, gw, gb, dx, B, in, out, divisor)),
-                        "B%d in%d out%d", B, in, out);
+            CNN_KLAUNCH(s, "linear_bwd_fused+relu", launch_bwd_fused(s, 1, x, dy, w, gw, gb, dx, B, in, out, divisor), "B%d in%d out%d", B, in, out);
         else
-            CNN_KLAUNCH(s, "linear_bwd_fused",
-                        (launch_pub(linear_bwd_fused<false>, dim3(ceil_div(in, kNeur)), dim3(kNeur * kFG), 0, s, x, dy, w, gw, gb, dx, B, in, out, divisor)),
-                        "B%d in%d out%d", B, in, out);
+            CNN_KLAUNCH(s, "linear_bwd_fused", launch_bwd_fused(s, 2, x, dy, w, gw, gb, dx, B, in, out, divisor), "B%d in%d out%d", B, in, out);
         return CNN_AMD_OK;
     }
     if (gw) {

@@ -525,6 +525,45 @@ def test_conv2d_row_kernel_tall_units_vs_oracle(T, case, lib_option):
         assert np.array_equal(host(dx).view(np.uint32), host(dx0).view(np.uint32))
 
 
+STEM_DGRAD_CASES = [
+    (2, 3, 64, 64, 8, 7, 2, 3),      # the 7x7 / stride-2 / pad-3 stem (ResNet-shaped stack): 32 x 32 grid positions, even channel count
+    (3, 3, 38, 44, 72, 7, 2, 3),     # ... 19 x 22 positions: the last wave of an image ragged, odd batch
+    (1, 3, 37, 45, 5, 7, 2, 3),      # ... odd planes (the last row / column of 2 x 2 blocks half outside), odd channel count (tail channel)
+]
+
+
+@pytest.mark.parametrize("case", STEM_DGRAD_CASES, ids=lambda c: "B%d_%dx%dx%d_to%d_k%ds%dp%d" % c)
+def test_conv2d_stem_data_gradient_packed_vs_oracle(T, case, lib_option):
+    """conv_dgrad_thin_s2_pk7 (round 6): the data gradient of the 3 -> Co, 7x7, stride-2, pad-3 stem (conv2d.cpp:168-199) on packed fp32
+    FMAs with the filters re-packed into 32-byte rows -- against the oracle, with and without the ReLU' epilogue, through the per-call
+    packing (workspace) and through the prepared image; bit-identical to the scalar-operand kernel (same products, same order)"""
+    from cnn_amd import capi
+
+    x, w, b, dy = _conv_inputs(case, 611)
+    _, _, _, dx_ref = _oracle_conv(case, x, w, b, dy)
+    conv = capi.Conv2d(*case)
+    xd, wd, dyd = dev(T, x), dev(T, w), dev(T, dy)
+    capi.kernel_timing(1)
+    dx = conv.backward_data(dyd, wd)
+    relu_in = capi.relu_forward(xd - 0.5)
+    dxm = T.full_like(xd, 7.0)
+    conv.backward_data_relu(dyd, wd, relu_in, dxm)
+    T.cuda.synchronize()
+    names = [k.split("|")[0] for k in capi.kernel_timing_report()]
+    capi.kernel_timing(0)
+    assert sum(n.startswith("conv_dgrad_thin_pk<3,k7s2>") for n in names) == 2 and "thin_pack_k7" in names, names
+    assert_close(host(dx), dx_ref, REL_TOL, "packed stem data gradient")
+    assert_close(host(dxm), np.where(host(relu_in) <= 0, np.float32(0), dx_ref), REL_TOL, "packed stem data gradient + ReLU'")
+    lib_option("DGRAD_THIN_PK", "0")
+    capi.kernel_timing(1)
+    dx0 = capi.Conv2d(*case).backward_data(dyd, wd)
+    T.cuda.synchronize()
+    names = [k.split("|")[0] for k in capi.kernel_timing_report()]
+    capi.kernel_timing(0)
+    assert "conv_dgrad_thin<3,k7s2>" in names, names
+    assert np.array_equal(host(dx).view(np.uint32), host(dx0).view(np.uint32))
+
+
 S2_CASES = [
     (3, 16, 55, 55, 32, 3, 2, 0),     # conv_layer_2 of the reference net (alexnet.cpp:17): 27x27 outputs flat-packed in units of 7 rows; data gradient in 28x28 domains
     (2, 32, 27, 27, 64, 3, 2, 0),     # conv_layer_3: 13x13 outputs, units of 7 rows (ragged last unit of 6)
