@@ -122,6 +122,24 @@ __global__ __launch_bounds__(kBlock) void linear_fwd_softmax_xent(const float* _
             }
         }
     }
+    if (BATCH && out == 3) {  // what the 18-wide loop left (the stacks' heads: in = 98 * 256): four iterations' loads at once, same order
+        constexpr int U = 4;
+        for (; i + (U - 1) * kBlock < in; i += U * kBlock) {
+            float xv[U];
+            w3 wv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                xv[u] = xb[i + u * kBlock];
+                wv[u] = *reinterpret_cast<const w3*>(w + (size_t)(i + u * kBlock) * 3);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc[0] = __builtin_fmaf(xv[u], wv[u].a, acc[0]);
+                acc[1] = __builtin_fmaf(xv[u], wv[u].b, acc[1]);
+                acc[2] = __builtin_fmaf(xv[u], wv[u].c, acc[2]);
+            }
+        }
+    }
 #pragma unroll 6
     for (; i < in; i += kBlock) {
         const float xv = xb[i];
@@ -177,7 +195,29 @@ __global__ __launch_bounds__(kBlock) void linear_fwd_softmax_xent(const float* _
                 dxb[threadIdx.x + u * kBlock] = (DX == 2 && xk[u] <= 0.f) ? 0.f : sj;
             }
         } else {
-            for (int i2 = threadIdx.x; i2 < in; i2 += kBlock) {
+            int i2 = threadIdx.x;
+            if (BATCH && out == 3) {  // (round 6) seven iterations' loads in flight (the stacks' heads: 98 iterations per thread, one round trip each before)
+                constexpr int U = 7;
+                const float d0 = dl[0], d1 = dl[1], d2 = dl[2];
+                for (; i2 + (U - 1) * kBlock < in; i2 += U * kBlock) {
+                    w3 wv[U];
+                    float xv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        wv[u] = *reinterpret_cast<const w3*>(w + (size_t)(i2 + u * kBlock) * 3);
+                        xv[u] = DX == 2 ? xb[i2 + u * kBlock] : 1.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        float sj = 0.f;
+                        sj = __builtin_fmaf(d0, wv[u].a, sj);
+                        sj = __builtin_fmaf(d1, wv[u].b, sj);
+                        sj = __builtin_fmaf(d2, wv[u].c, sj);
+                        dxb[i2 + u * kBlock] = (DX == 2 && xv[u] <= 0.f) ? 0.f : sj;
+                    }
+                }
+            }
+            for (; i2 < in; i2 += kBlock) {
                 const float* wr = w + (size_t)i2 * out;
                 float sj = 0.f;
 #pragma unroll
