@@ -64,6 +64,8 @@ __global__ __launch_bounds__(SWAVES * 64, 4) void conv_stem_fwd_kernel(const Ste
     extern __shared__ float lds[];
     float* const As = lds;                       // [148][SAP]
     float* const Xs = lds + (SKK + 1) * SAP;     // [3][13][264]
+    float* const Bs = Xs + SCI * SRIN * SLW;     // [64]: this channel block's bias (the epilogue reads it from LDS: a global load there would
+                                                 // wait -- vmcnt counts stores too -- for every store issued before it; round 6)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, kk = lane >> 5;
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(SWAVES * 64, 4) void conv_stem_fwd_kernel(const Ste
         const int co = e / (SKK + 1), k = e - co * (SKK + 1);
         As[k * SAP + co] = (k < SKK && co0 + co < p.Co) ? p.w[(size_t)(co0 + co) * SKK + k] : 0.f;
     }
+    if (tid < 64) Bs[tid] = co0 + tid < p.Co ? p.bias[co0 + tid] : 0.f;
 
     const int r = wave >> 1, ct0 = (wave & 1) * SNT;   // this wave's output row inside the group, first of its pixel tiles
     const int a_lane = kk * SAP + n;                    // + (2s) * SAP + mt * 32
@@ -84,13 +87,24 @@ __global__ __launch_bounds__(SWAVES * 64, 4) void conv_stem_fwd_kernel(const Ste
         const int iy0 = SS * oy0 - SPAD, ix0 = SS * ox0 - 4;  // staged element (row rr, column c) = x[iy0 + rr][ix0 + c]
         __syncthreads();  // (everybody is done with the previous item's rows; first pass: A is complete)
         // ---- stage: 3 x 13 rows x 66 16-byte chunks, zero outside the image (W % 4 == 0: a chunk is inside or outside as a whole)
-        for (int e = tid; e < SCI * SRIN * (SLW / 4) && !(p.dbg == 1 && it != (int)blockIdx.x); e += SWAVES * 64) {
-            const int row = e / (SLW / 4), c4 = e - row * (SLW / 4);
-            const int ci = row / SRIN, rr = row - ci * SRIN;
-            const int iy = iy0 + rr, ix = ix0 + 4 * c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix + 3 < p.W) v = *(const float4*)(p.x + (((size_t)b * SCI + ci) * p.H + iy) * p.W + ix);
-            *(float4*)(Xs + row * SLW + 4 * c4) = v;
+        // (all of a thread's chunks are loaded before the first one is stored: one memory round trip per item instead of six)
+        constexpr int NCH = SCI * SRIN * (SLW / 4), NIT = (NCH + SWAVES * 64 - 1) / (SWAVES * 64);
+        if (!(p.dbg == 1 && it != (int)blockIdx.x)) {
+            float4 v[NIT];
+#pragma unroll
+            for (int q = 0; q < NIT; ++q) {
+                const int e = tid + q * SWAVES * 64;
+                const int row = e / (SLW / 4), c4 = e - row * (SLW / 4);
+                const int ci = row / SRIN, rr = row - ci * SRIN;
+                const int iy = iy0 + rr, ix = ix0 + 4 * c4;
+                v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < NCH && iy >= 0 && iy < p.H && ix >= 0 && ix + 3 < p.W) v[q] = *(const float4*)(p.x + (((size_t)b * SCI + ci) * p.H + iy) * p.W + ix);
+            }
+#pragma unroll
+            for (int q = 0; q < NIT; ++q) {
+                const int e = tid + q * SWAVES * 64;
+                if (e < NCH) *(float4*)(Xs + e * 4) = v[q];  // (row * SLW + 4 * c4 == 4 * e: rows are SLW / 4 chunks long)
+            }
         }
         __syncthreads();
 
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(SWAVES * 64, 4) void conv_stem_fwd_kernel(const Ste
                         for (int i = 0; i < 16; ++i) {
                             const int dc = (i & 3) + 8 * (i >> 2);
                             if (cbase + dc < p.Co) {
-                                const float v = acc[mt][t][i] + p.bias[cbase + dc];  // conv2d.cpp:87: the bias is added to the finished sum
+                                const float v = acc[mt][t][i] + Bs[mt * 32 + 4 * kk + dc];  // conv2d.cpp:87: the bias is added to the finished sum
                                 if (p.y) p.y[obase + dc * plane] = v;
                                 if constexpr (RELU_OUT) p.y_relu[obase + dc * plane] = v >= 0.f ? v : 0.f;  // relu.cpp:25 (keeps -0.0, NaN -> 0)
                             }
@@ -292,7 +306,7 @@ int stem_forward(const cnn_conv2d_desc* d, const float* x, const float* w, const
     CNN_REQUIRE(items < (1ll << 31) && (long long)p.B * p.Co * p.Ho * p.Wo < (1ll << 31), "stem_forward: tensor too large for 32-bit offsets");
     p.items = (int)items;
     p.dbg = CNN_MEASURE_INT("STEM_DBG", 0);
-    const size_t lds_bytes = ((size_t)(SKK + 1) * SAP + (size_t)SCI * SRIN * SLW) * sizeof(float);
+    const size_t lds_bytes = ((size_t)(SKK + 1) * SAP + (size_t)SCI * SRIN * SLW + 64) * sizeof(float);
     static DeviceOnce attr_once[2];
     const int which = y_relu ? 1 : 0;
     if (attr_once[which].needed()) {
