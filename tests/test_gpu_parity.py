@@ -765,7 +765,7 @@ def test_relu_bit_exact(T, n):
         assert np.array_equal(host(capi.relu_forward(xo.contiguous())).view(np.uint32), y_ref.view(np.uint32))
 
 
-@pytest.mark.parametrize("B,n_in,n_out", [(4, 4608, 3), (3, 100, 10), (5, 33, 17), (37, 130, 8), (256, 4608, 3), (1, 7, 1)])
+@pytest.mark.parametrize("B,n_in,n_out", [(4, 4608, 3), (3, 100, 10), (5, 33, 17), (37, 130, 8), (256, 4608, 3), (1, 7, 1), (19, 25088, 3), (33, 6000, 2)])
 def test_linear_vs_oracle(T, B, n_in, n_out):
     from cnn_amd import capi
 
@@ -1619,7 +1619,7 @@ def test_linear_forward_softmax_xent_fusion_is_bit_identical(T, B, n_in, n_out):
 
 
 @pytest.mark.parametrize("relu", [0, 1], ids=["plain", "relu_below"])
-@pytest.mark.parametrize("B,n_in,n_out", [(256, 4608, 3), (7, 4608, 3), (5, 70, 8), (3, 33, 1), (4, 9216, 3)])
+@pytest.mark.parametrize("B,n_in,n_out", [(256, 4608, 3), (7, 4608, 3), (5, 70, 8), (3, 33, 1), (4, 9216, 3), (3, 25088, 3), (2, 7000, 3)])
 def test_linear_head_with_data_gradient_is_bit_identical(T, B, n_in, n_out, relu):
     """cnn_linear_forward_softmax_xent_dx (forward + loss head + the layer's data gradient in ONE kernel) and the parameter-only
     cnn_linear_backward(dx = NULL) against the unfused trio cnn_linear_forward_softmax_xent + cnn_linear_backward(_relu): logits,
