@@ -288,6 +288,14 @@ SPA_CASES = [
     (2, 128, 13, 13, 64, 3, 1, 1),    # two ci tiles
     (5, 32, 3, 96, 32, 3, 1, 0),      # one output row (every pair's second row lies below the plane)
     (40, 32, 12, 12, 32, 3, 1, 1),    # many stages per workgroup: the stage walk crosses row pairs, column blocks and samples
+    # 21-column blocks start anywhere modulo 4: the straddling unit of the LAST block is cut relative to that block's first column
+    # (found by tools/fuzz_conv.py late in round 6: the fix-up width had been taken from the row length alone)
+    (2, 32, 32, 32, 32, 3, 1, 0),     # 30 outputs = 21 + 9: three floats of the last block's third unit lie behind the row
+    (2, 96, 10, 42, 32, 3, 1, 0),     # 40 outputs = 21 + 19 (a row length that IS a multiple of 4: one float to zero all the same)
+    (1, 96, 21, 41, 48, 3, 1, 0),     # 39 = 21 + 18
+    (3, 72, 60, 60, 64, 3, 1, 1),     # 60 = 21 + 21 + 18, pad 1
+    (3, 32, 25, 59, 64, 3, 1, 1),     # 59 = 21 + 21 + 17
+    (1, 64, 6, 100, 64, 3, 1, 1),     # 100 = 4 x 21 + 16: the last block ends on a unit (nothing to fix), the row length does not matter
 ]
 
 
@@ -1673,3 +1681,51 @@ def test_grad_cam_matches_oracle_bit_for_bit(T, shape):
         same = (got.view(np.uint32) == cam_o.view(np.uint32)) | (np.isnan(got) & np.isnan(cam_o))  # (NaN payloads are not compared)
         assert same.all(), (variant, int((~same).sum()))
         assert np.array_equal(host(img), img_o), variant
+
+
+def _sweep_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    cases = []
+    for _ in range(n):
+        s_ = 1 if rs.rand() < 0.75 else 2
+        pad = int(rs.randint(0, 2))
+        B = int(rs.randint(1, 4))
+        Ci, Co = int(rs.choice([3, 8, 16, 24, 32, 40, 64, 72, 96])), int(rs.choice([8, 16, 24, 32, 48, 64, 80, 128]))
+        H, W = int(rs.randint(5, 64)), int(rs.randint(5, 64))
+        if rs.rand() < 0.3:
+            W = H
+        cases.append((B, Ci, H, W, Co, 3, s_, pad))
+    return cases
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_conv2d_random_geometries_default_dispatch_vs_oracle(T, seed):
+    """the DEFAULT dispatch of all three passes on 40 random 3x3 geometries per seed (stride 1 / 2, padding 0 / 1, planes of 5 .. 63 pixels,
+    3 .. 96 -> 8 .. 128 channels; conv2d.cpp:69-199 accepts every one of them) against the oracle: the shapes BETWEEN the hand-picked cases
+    above, where the runtime-size kernels (conv_rows_any, wgrad_sp_any) meet the per-width instances and the generic kernels.  The same
+    generator as tools/fuzz_conv.py, which found the wgrad_sp_any fix-up width bug on 30- / 39- / 40- / 59- / 60-wide outputs"""
+    from cnn_amd import capi
+
+    served = set()
+    for case in _sweep_cases(40, seed):
+        x, w, b, dy = _conv_inputs(case, 7000 + seed)
+        y_ref, gw_ref, gb_ref, dx_ref = _oracle_conv(case, x, w, b, dy)
+        conv = capi.Conv2d(*case)
+        xd, wd, bd, dyd = dev(T, x), dev(T, w), dev(T, b), dev(T, dy)
+        capi.kernel_timing(1)
+        y = conv.forward(xd, wd, bd)
+        dx = conv.backward_data(dyd, wd)
+        relu_in = capi.relu_forward(xd - 0.5)
+        dxm = T.full_like(xd, 7.0)
+        conv.backward_data_relu(dyd, wd, relu_in, dxm)
+        gw, gb = conv.backward_weight(xd, dyd, float(case[0]))
+        T.cuda.synchronize()
+        served |= {k.split("|")[0].split("<")[0] for k in capi.kernel_timing_report()}
+        capi.kernel_timing(0)
+        tag = "sweep B%d %dx%dx%d->%d s%d p%d" % (case[0], case[1], case[2], case[3], case[4], case[6], case[7])
+        assert_close(host(y), y_ref, REL_TOL, tag + " forward")
+        assert_close(host(dx), dx_ref, REL_TOL, tag + " data gradient")
+        assert_close(host(dxm), np.where(host(relu_in) <= 0, np.float32(0), dx_ref), REL_TOL, tag + " data gradient + ReLU'")
+        assert_close(host(gw), gw_ref, REL_TOL, tag + " weight gradient")
+        assert_close(host(gb), gb_ref, REL_TOL, tag + " bias gradient")
+    assert {"conv_rows_any", "wgrad_sp_any"} <= served, served

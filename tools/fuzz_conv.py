@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Random-geometry sweep of the DEFAULT dispatch of cnn_conv2d_forward / _backward_data(_relu) / _backward_weight against the CPU oracle
+(oracle/pyoracle.py; conv2d.cpp:69-199): 3x3 layers of stride 1 / 2 and padding 0 / 1 with random batch, channel counts and plane sizes --
+the shapes between the test suite's hand-picked cases, where the runtime-size kernels of round 6 (conv_rows_any, wgrad_sp_any) and the
+per-width instances meet.  Tensor-normalised 1e-4 like tests/util.py; prints which kernel served each pass.
+usage: fuzz_conv.py [cases=60] [seed=1]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from cnn_amd import capi
+from oracle import pyoracle as O
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+
+
+def rel(a, ref):
+    return float(np.abs(np.asarray(a, np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+worst, bad = 0.0, 0
+for it in range(n_cases):
+    s = 1 if rs.rand() < 0.75 else 2
+    pad = int(rs.randint(0, 2))
+    B = int(rs.randint(1, 4))
+    Ci, Co = int(rs.choice([3, 8, 16, 24, 32, 40, 64, 72, 96])), int(rs.choice([8, 16, 24, 32, 48, 64, 80, 128]))
+    H, W = int(rs.randint(5, 64)), int(rs.randint(5, 64))
+    if rs.rand() < 0.3:
+        W = H
+    case = (B, Ci, H, W, Co, 3, s, pad)
+    x = rs.rand(B, Ci, H, W).astype(np.float32)
+    w = (rs.standard_normal((Co, Ci, 3, 3)) * 0.1).astype(np.float32)
+    b = (rs.standard_normal(Co) * 0.1).astype(np.float32)
+    Ho, Wo = (H + 2 * pad - 3) // s + 1, (W + 2 * pad - 3) // s + 1
+    dy = (rs.rand(B, Co, Ho, Wo) * 2 - 1).astype(np.float32)
+    xp = np.pad(x, ((0, 0), (0, 0), (pad, pad), (pad, pad))) if pad else x
+    y_ref = O.conv2d_forward(xp, w, b, s)
+    gw_ref, gb_ref, dxp = O.conv2d_backward(xp, dy, w, s)
+    dx_ref = dxp[:, :, pad:pad + H, pad:pad + W] if pad else dxp
+    conv = capi.Conv2d(*case)
+    xd, wd, bd, dyd = (torch.from_numpy(t).cuda() for t in (x, w, b, dy))
+    capi.kernel_timing(1)
+    y = conv.forward(xd, wd, bd)
+    dx = conv.backward_data(dyd, wd)
+    relu_in = capi.relu_forward(xd - 0.5)
+    dxm = torch.full_like(xd, 7.0)
+    conv.backward_data_relu(dyd, wd, relu_in, dxm)
+    gw, gb = conv.backward_weight(xd, dyd, float(B))
+    torch.cuda.synchronize()
+    names = [k.split("|")[0] for k in capi.kernel_timing_report() if not any(t in k for t in ("prep", "reduce", "relu_f", "pack"))]
+    capi.kernel_timing(0)
+    errs = {"y": rel(y.cpu().numpy(), y_ref), "dx": rel(dx.cpu().numpy(), dx_ref),
+            "dx_relu": rel(dxm.cpu().numpy(), np.where(relu_in.cpu().numpy() <= 0, np.float32(0), dx_ref)),
+            "gw": rel(gw.cpu().numpy(), gw_ref), "gb": rel(gb.cpu().numpy(), gb_ref)}
+    e = max(errs.values())
+    worst = max(worst, e)
+    flag = "" if e <= 1e-4 else "   <-- FAIL " + str({k: f"{v:.2e}" for k, v in errs.items() if v > 1e-4})
+    bad += e > 1e-4
+    print(f"{str(case):42s} {e:.2e}  {' '.join(sorted(set(names)))}{flag}")
+print(f"FUZZ {'OK' if bad == 0 else 'FAILED'}: {n_cases} geometries, worst tensor-normalised error {worst:.2e}, {bad} above 1e-4")
+sys.exit(1 if bad else 0)

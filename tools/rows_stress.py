@@ -12,7 +12,11 @@ from cnn_amd import capi
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 SHAPES = [(16, 64, 112, 112, 128, 3, 1, 0), (16, 64, 112, 112, 128, 3, 1, 1), (16, 128, 56, 56, 256, 3, 1, 1), (32, 64, 56, 56, 64, 3, 1, 1),
-          (32, 256, 28, 28, 512, 3, 1, 1), (64, 256, 14, 14, 256, 3, 1, 1), (64, 512, 7, 7, 512, 3, 1, 1), (5, 48, 7, 7, 80, 3, 1, 1)]
+          (32, 256, 28, 28, 512, 3, 1, 1), (64, 256, 14, 14, 256, 3, 1, 1), (64, 512, 7, 7, 512, 3, 1, 1), (5, 48, 7, 7, 80, 3, 1, 1),
+          # round 6: tall units at batch 64, the stride-2 siblings, the runtime-size kernels (any width / any plane size)
+          (64, 64, 56, 56, 64, 3, 1, 1), (64, 128, 28, 28, 128, 3, 1, 1), (16, 64, 56, 56, 128, 3, 2, 1), (16, 128, 28, 28, 256, 3, 2, 1),
+          (16, 256, 14, 14, 512, 3, 2, 1), (8, 64, 109, 109, 64, 3, 1, 0), (8, 128, 52, 52, 128, 3, 1, 0), (16, 128, 23, 23, 256, 3, 1, 0),
+          (4, 32, 222, 222, 32, 3, 1, 0), (8, 64, 50, 50, 96, 3, 1, 1)]
 side = torch.cuda.Stream()
 noise_a = torch.rand((64 << 20,), device="cuda")  # 256 MB through the library's own ReLU kernel: the memory system and the wave slots stay busy
 noise_b = torch.empty_like(noise_a)
