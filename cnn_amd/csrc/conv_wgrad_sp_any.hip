@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void wgrad_spa_kernel(const SpaParams p) {
     // wave is decided here, once (wave-uniform bit sets: most slots hold none)
     const int c0_last = (p.ncb - 1) * CW;
     // (units are cut from the BLOCK's first column, and a 21-column block starts anywhere modulo 4: what counts is the row's end relative to
-    //  c0_last, not to column 0 -- round 6 fix: found by tools/fuzz_conv.py on 30- / 39- / 40- / 59- / 60-wide outputs)
+    //  c0_last, not to column 0 -- round 6 fix: found by tests/sweeps/fuzz_conv.py on 30- / 39- / 40- / 59- / 60-wide outputs)
     const int nz_d = (4 - ((WO - c0_last) & 3)) & 3, nz_x = (4 - ((W - c0_last) & 3)) & 3;  // floats to zero (0: the rows end on a unit)
     unsigned fixd_slots = 0, fixx_slots = 0;
     bool fixd_mine[G::NIWD], fixx_mine[G::NIWX];

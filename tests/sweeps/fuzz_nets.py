@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Random sequential networks through the C++ Layer classes (architectures::Sequential::train_step, cnn_amd/host) in three settings --
+default (fuse_layers + fuse_pool_block), fuse_pool_block off, fuse_layers off -- compared with each other BIT FOR BIT (losses, parameters,
+gradients, the delta with respect to the input, every layer's get_output() after the last step: the fused passes do not write some of
+those tensors and re-compute them on demand) and with the CPU oracle (oracle.pyoracle.SeqNet: logits and loss of the first step at 1e-4).
+The fusion wiring depends on neighbours and shapes (Conv2D -> ReLU, BatchNorm2D -> ReLU -> MaxPool2D(2,2) with the pool inside the apply
+pass and its backward from the pooled domain, ReLU' in the data gradients / the pool's backward): random layer lists reach the
+combinations the BASELINE stacks do not.     usage: fuzz_nets.py [nets=12] [seed=1] [big]
+big: inputs of 96 .. 160 pixels whose first block is Conv2D -> BatchNorm2D -> ReLU -> MaxPool2D(2,2) -- planes large enough for the
+general (not channel-resident) BatchNorm2D kernels, where the pool runs inside the apply pass and the backward pass starts from the pooled domain"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+
+from cnn_amd import hostapi
+from cnn_amd.stacks import he_init
+from oracle import pyoracle as O
+
+big = "big" in sys.argv[1:]
+sys.argv = [a for a in sys.argv if a != "big"]
+n_nets = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+lib = hostapi.load()
+
+
+bad = 0
+for it in range(n_nets):
+    # (shape bookkeeping is done by the oracle's own walk: build the spec first, then ask SeqNet for the layout)
+    S = int(rs.randint(16, 49))
+    Wd = S if rs.rand() < 0.6 else int(rs.randint(16, 49))
+    if big:
+        S, Wd = int(rs.randint(96, 161)), int(rs.randint(96, 161))
+    in_shape = (3, S, Wd)
+    H, W = S, Wd
+    spec = []
+    if big:
+        k = int(rs.choice([3, 3, 5]))
+        pad = int(rs.randint(0, k // 2 + 1))
+        spec += [("conv", int(rs.choice([8, 16, 24])), k, 1, pad), ("bn",), ("relu",), ("pool", 2, 2)]
+        H, W = (H + 2 * pad - k + 1 - 2) // 2 + 1, (W + 2 * pad - k + 1 - 2) // 2 + 1
+    for blk in range(int(rs.randint(1 if big else 2, 4 if big else 5))):
+        k = int(rs.choice([1, 3, 3, 3, 5]))
+        s = int(rs.choice([1, 1, 2]))
+        pad = int(rs.randint(0, k // 2 + 1))
+        if (H + 2 * pad - k) // s + 1 < 2 or (W + 2 * pad - k) // s + 1 < 2:
+            k, s, pad = 3, 1, 1
+        spec.append(("conv", int(rs.choice([8, 16, 24, 32, 40])), k, s, pad))
+        H, W = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+        if rs.rand() < 0.5:
+            spec.append(("bn",))
+        spec.append(("relu",))
+        if rs.rand() < 0.45 and H >= 4 and W >= 4:
+            pk, ps = (2, 2) if rs.rand() < 0.8 else (3, 2)
+            spec.append(("pool", pk, ps))
+            H, W = (H - pk) // ps + 1, (W - pk) // ps + 1
+    spec.append(("linear", 3))
+    B = int(rs.randint(2, 5))
+    onet = O.SeqNet(spec, in_shape)
+    p0 = he_init(onet.layers, 500 + it)
+    onet.params[:] = p0
+    x = rs.rand(B, *in_shape).astype(np.float32)
+    labels = (np.arange(B) % 3).astype(np.int32)
+    xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    names = hostapi._layer_names(spec)
+    runs = {}
+    try:
+        for mode, (fl, fp) in (("default", (1, 1)), ("no pool block", (1, 0)), ("no fusion", (0, 0))):
+            lib.cnnh_set_fuse_layers(fl)
+            lib.cnnh_set_fuse_pool_block(fp)
+            net = hostapi.HostSequential(spec, in_shape)
+            net.set_params(p0)
+            trace = []
+            for step in range(3):
+                net.train_step(xd, ld, 1e-3)
+                trace.append((net.last_loss(), net.get_params(), net.get_grads(), net.input_delta((B,) + in_shape)))
+            outs = {names[i]: net.layer_output(names[i], (B,) + tuple(e["out"])) for i, e in enumerate(onet.layers)}
+            if mode == "default":  # first step against the oracle
+                net2 = hostapi.HostSequential(spec, in_shape)
+                net2.set_params(p0)
+                net2.train_step(xd, ld, 1e-3)
+                logits = net2.layer_output("linear_1", (B, 3))
+                ologits = onet.forward(x)
+                oloss, _ = O.cross_entropy_backward(O.softmax(ologits), labels)
+                e_log = float(np.abs(logits.reshape(ologits.shape) - ologits).max() / max(np.abs(ologits).max(), 1e-30))
+                e_loss = abs(net2.last_loss() - oloss) / max(1.0, abs(oloss))
+                net2.close()
+            runs[mode] = (trace, outs)
+            net.close()
+    finally:
+        lib.cnnh_set_fuse_layers(1)
+        lib.cnnh_set_fuse_pool_block(1)
+    diffs = []
+    ref_trace, ref_outs = runs["no fusion"]
+    for mode in ("default", "no pool block"):
+        trace, outs = runs[mode]
+        for step, ((la, pa, ga, da), (lb, pb, gb, db)) in enumerate(zip(trace, ref_trace)):
+            for what, a, b in (("loss", np.float32(la), np.float32(lb)), ("params", pa, pb), ("grads", ga, gb), ("input delta", da, db)):
+                if not np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32)):  # (bit patterns: a diverged step's NaN loss equals itself)
+                    diffs.append(f"{mode}: step {step} {what} (max |d| {np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max():.2e})")
+        for nm in outs:
+            if not np.array_equal(outs[nm].view(np.uint32), ref_outs[nm].view(np.uint32)):
+                diffs.append(f"{mode}: get_output({nm})")
+    ok = not diffs and e_log <= 1e-4 and e_loss <= 1e-4
+    bad += not ok
+    print(f"net {it}: B{B} {in_shape} {spec}\n   vs oracle: logits {e_log:.2e} loss {e_loss:.2e}; fused vs unfused: {'bit-identical' if not diffs else diffs[:6]}{'' if ok else '   <-- FAIL'}")
+print(f"FUZZ NETS {'OK' if bad == 0 else 'FAILED'}: {n_nets} networks, {bad} with differences")
+sys.exit(1 if bad else 0)

@@ -289,7 +289,7 @@ SPA_CASES = [
     (5, 32, 3, 96, 32, 3, 1, 0),      # one output row (every pair's second row lies below the plane)
     (40, 32, 12, 12, 32, 3, 1, 1),    # many stages per workgroup: the stage walk crosses row pairs, column blocks and samples
     # 21-column blocks start anywhere modulo 4: the straddling unit of the LAST block is cut relative to that block's first column
-    # (found by tools/fuzz_conv.py late in round 6: the fix-up width had been taken from the row length alone)
+    # (found by tests/sweeps/fuzz_conv.py late in round 6: the fix-up width had been taken from the row length alone)
     (2, 32, 32, 32, 32, 3, 1, 0),     # 30 outputs = 21 + 9: three floats of the last block's third unit lie behind the row
     (2, 96, 10, 42, 32, 3, 1, 0),     # 40 outputs = 21 + 19 (a row length that IS a multiple of 4: one float to zero all the same)
     (1, 96, 21, 41, 48, 3, 1, 0),     # 39 = 21 + 18
@@ -1703,7 +1703,7 @@ def test_conv2d_random_geometries_default_dispatch_vs_oracle(T, seed):
     """the DEFAULT dispatch of all three passes on 40 random 3x3 geometries per seed (stride 1 / 2, padding 0 / 1, planes of 5 .. 63 pixels,
     3 .. 96 -> 8 .. 128 channels; conv2d.cpp:69-199 accepts every one of them) against the oracle: the shapes BETWEEN the hand-picked cases
     above, where the runtime-size kernels (conv_rows_any, wgrad_sp_any) meet the per-width instances and the generic kernels.  The same
-    generator as tools/fuzz_conv.py, which found the wgrad_sp_any fix-up width bug on 30- / 39- / 40- / 59- / 60-wide outputs"""
+    generator as tests/sweeps/fuzz_conv.py, which found the wgrad_sp_any fix-up width bug on 30- / 39- / 40- / 59- / 60-wide outputs"""
     from cnn_amd import capi
 
     served = set()
