@@ -3,7 +3,10 @@
 (oracle/pyoracle.py; conv2d.cpp:69-199): 3x3 layers of stride 1 / 2 and padding 0 / 1 with random batch, channel counts and plane sizes --
 the shapes between the test suite's hand-picked cases, where the runtime-size kernels of round 6 (conv_rows_any, wgrad_sp_any) and the
 per-width instances meet.  Tensor-normalised 1e-4 like tests/util.py; prints which kernel served each pass.
-usage: fuzz_conv.py [cases=60] [seed=1]"""
+usage: fuzz_conv.py [cases=60] [seed=1] [widths]
+widths: plane widths of the per-width kernel instances (7 / 14 / 28 / 56 / 112 / 110, the reference net's 55 / 27 / 13 and 224-wide first
+layers with 3 channels) with random heights, batches and channel counts: partial tiles, ragged row groups and odd batches of conv_rows,
+conv_rows_s2, wgrad_sp, wgrad_sp2, the first-layer and stem kernels"""
 import os
 import sys
 
@@ -14,6 +17,8 @@ import torch
 from cnn_amd import capi
 from oracle import pyoracle as O
 
+widths = "widths" in sys.argv[1:]
+sys.argv = [a for a in sys.argv if a != "widths"]
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 
@@ -31,11 +36,35 @@ for it in range(n_cases):
     H, W = int(rs.randint(5, 64)), int(rs.randint(5, 64))
     if rs.rand() < 0.3:
         W = H
-    case = (B, Ci, H, W, Co, 3, s, pad)
+    k = 3
+    if widths:
+        W = int(rs.choice([7, 14, 28, 56, 112, 110, 55, 27, 13, 224]))
+        B = int(rs.randint(1, 7))
+        if W == 224:  # first layers: 3 channels
+            Ci = 3
+            k, s, pad, Co = [(3, 2, 0, 16), (7, 2, 3, int(rs.choice([8, 64, 72]))), (3, 1, 1, int(rs.choice([16, 64])))][int(rs.randint(0, 3))]
+            H = int(rs.choice([224, 64, 37, 96]))
+            B = int(rs.randint(1, 4))
+        else:
+            H = W if rs.rand() < 0.6 else int(rs.randint(max(3, W // 8), W + 9))
+            if W >= 110:
+                H = int(rs.randint(3, 30))
+            if W in (55, 27, 13):
+                s, pad = 2, 0
+            elif W == 110:
+                s, pad = 1, int(rs.choice([0, 1, 2]) if False else rs.randint(0, 2))
+            else:
+                pad = 1 if rs.rand() < 0.85 else 0
+            Ci, Co = int(rs.choice([16, 32, 40, 64, 72, 128, 136])), int(rs.choice([32, 48, 64, 128, 160]))
+            if W >= 110:
+                Ci, Co = min(Ci, 64), min(Co, 128)
+        if (H + 2 * pad - k) // s + 1 < 1:
+            H = k
+    case = (B, Ci, H, W, Co, k, s, pad)
     x = rs.rand(B, Ci, H, W).astype(np.float32)
-    w = (rs.standard_normal((Co, Ci, 3, 3)) * 0.1).astype(np.float32)
+    w = (rs.standard_normal((Co, Ci, k, k)) * 0.1).astype(np.float32)
     b = (rs.standard_normal(Co) * 0.1).astype(np.float32)
-    Ho, Wo = (H + 2 * pad - 3) // s + 1, (W + 2 * pad - 3) // s + 1
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
     dy = (rs.rand(B, Co, Ho, Wo) * 2 - 1).astype(np.float32)
     xp = np.pad(x, ((0, 0), (0, 0), (pad, pad), (pad, pad))) if pad else x
     y_ref = O.conv2d_forward(xp, w, b, s)

@@ -35,3 +35,10 @@ def test_random_networks_fused_equals_unfused_and_match_oracle(mode):
     args = ["tests/sweeps/fuzz_nets.py", "10", "21"] + (["big"] if mode == "big" else [])
     out = _run(*args)
     assert "FUZZ NETS OK" in out
+
+
+def test_random_shapes_on_the_per_width_kernel_instances_vs_oracle():
+    """tests/sweeps/fuzz_conv.py widths: the plane widths of the per-width instances (7 / 14 / 28 / 56 / 112 / 110 / 55 / 27 / 13, 224-wide
+    3-channel first layers) with random heights, batches and channel counts, all three passes against the oracle (conv2d.cpp:69-199)"""
+    out = _run("tests/sweeps/fuzz_conv.py", "30", "31", "widths")
+    assert "FUZZ OK" in out
