@@ -56,6 +56,8 @@ for it in range(n_nets):
             pk, ps = (2, 2) if rs.rand() < 0.8 else (3, 2)
             spec.append(("pool", pk, ps))
             H, W = (H - pk) // ps + 1, (W - pk) // ps + 1
+        if rs.rand() < 0.2:
+            spec.append(("dropout", float(rs.choice([0.2, 0.5]))))  # (dropout.cpp: every layer's own engine, seed 1314)
     spec.append(("linear", 3))
     B = int(rs.randint(2, 5))
     onet = O.SeqNet(spec, in_shape)
