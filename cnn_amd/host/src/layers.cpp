@@ -11,6 +11,16 @@
 #include "architectures.h"
 #include "host_util.h"
 
+// A batch SMALLER than the first call's (the layers' buffers are sized by that one: conv2d.cpp:47-52) is processed as what it is: forward()
+// and backward() hand on as many tensors as they were given, not the whole buffer's views -- with the full vector a layer below would
+// also walk the stale samples behind the batch (round 6: found by tests/sweeps/fuzz_nets.py; the reference itself returns its whole
+// `output` / `delta_output` members, conv2d.cpp:93 / :201, and cannot run a smaller batch at all: its loss glue indexes the labels by them)
+static std::vector<tensor> first_n(const std::vector<tensor>& v, int B) {
+    if ((size_t)B >= v.size()) return v;
+    return std::vector<tensor>(v.begin(), v.begin() + B);
+}
+
+
 using namespace architectures;
 using cnn_amd_host::dev_alloc;
 using cnn_amd_host::must;
@@ -270,7 +280,7 @@ std::vector<tensor> Conv2D::forward(const std::vector<tensor>& input) {
     } else {
         must(cnn_conv2d_forward(&d, x, w_dev(), b_dev(), out_buf.base, workspace, workspace_bytes, stream), "cnn_conv2d_forward");
     }
-    return output;
+    return first_n(output, B);
 }
 
 bool Conv2D::next_pass_pool_fused(int B) const {
@@ -328,7 +338,7 @@ std::vector<tensor> Conv2D::backward(std::vector<tensor>& delta) {
              "cnn_conv2d_backward");  // joined in update_gradients / AlexNet::backward
     grads_ready = true;
     delta_valid = true;
-    return dbuf.views;
+    return first_n(dbuf.views, B);
 }
 
 // ---- fuse_pool_block: outputs the pass did not write, and the container-scheduled backward of a pool-fused first block ----
@@ -485,9 +495,9 @@ void MaxPool2D::fused_forward_target(int B, int C, int H, int W, bool record, da
 
 std::vector<tensor> MaxPool2D::forward(const std::vector<tensor>& input) {
     Tensor3D::device_work_enqueued();  // host copies of device views made before this call are stale from here on
-    if (forward_done) {  // written by the producing convolution's kernel in this pass
+    if (forward_done) {  // written by the producing convolution's / BatchNorm2D's kernel in this pass
         forward_done = false;
-        return output;
+        return first_n(output, (int)input.size());
     }
     backward_passthrough = false;
     const int B = (int)input.size();
@@ -513,7 +523,7 @@ std::vector<tensor> MaxPool2D::forward(const std::vector<tensor>& input) {
     const data_type* x = batch_device_pointer(input, in_stage, name);
     must(cnn_maxpool2d_forward(x, out_buf.base, no_grad ? nullptr : mask, B, C, H, W, kernel_size, step, stream),
          "cnn_maxpool2d_forward");
-    return output;
+    return first_n(output, B);
 }
 
 std::vector<tensor> MaxPool2D::backward(std::vector<tensor>& delta) {
@@ -533,7 +543,7 @@ std::vector<tensor> MaxPool2D::backward(std::vector<tensor>& delta) {
         // domain (bit-identical to the sequence; neither this layer's nor the ReLU's input gradient is materialised)
         fused_bn_below->backward_pooled(dy, mask_dev(), pooled_dev(), delta_buf.base, B);
         fused_relu_below->fused_backward_done();
-        return delta_buf.views;
+        return first_n(delta_buf.views, B);
     }
     if (fused_relu_below != nullptr && fuse_layers) {  // also applies the ReLU::backward of the layer in front
         must(cnn_maxpool2d_backward_relu(dy, mask_dev(), pooled_dev(), delta_buf.base, B, in_C, in_H, in_W, kernel_size, step, stream),
@@ -543,7 +553,7 @@ std::vector<tensor> MaxPool2D::backward(std::vector<tensor>& delta) {
         must(cnn_maxpool2d_backward(dy, mask_dev(), delta_buf.base, B, in_C, in_H, in_W, kernel_size, step, stream),
              "cnn_maxpool2d_backward");
     }
-    return delta_buf.views;
+    return first_n(delta_buf.views, B);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -576,7 +586,7 @@ std::vector<tensor> ReLU::forward(const std::vector<tensor>& input) {
     const int B = (int)input.size();
     if (forward_done) {  // written by the producing convolution's kernel in this pass
         forward_done = false;
-        return output;
+        return first_n(output, B);
     }
     if (out_buf.empty()) {
         out_buf.allocate(B, input[0]->C, input[0]->H, input[0]->W, name + "_output");
@@ -590,7 +600,7 @@ std::vector<tensor> ReLU::forward(const std::vector<tensor>& input) {
     const data_type* x = batch_device_pointer(input, in_stage, name);
     out_valid = true;
     must(cnn_relu_forward(x, out_buf.base, out_buf.sample_len * B, stream), "cnn_relu_forward");
-    return output;
+    return first_n(output, B);
 }
 
 // relu.cpp:30-44: masks the caller's delta IN PLACE and hands the same tensors back
@@ -719,7 +729,7 @@ std::vector<tensor> BatchNorm2D::forward(const std::vector<tensor>& input) {
             must(cnn_batchnorm2d_forward_from_sums(x, out_buf.base, params, params + C, params + 2 * C, params + 3 * C, saved_stats,
                                                    saved_stats + C, s1, s2, count, B, C, H, W, eps, momentum, stream),
                  "cnn_batchnorm2d_forward_from_sums");
-        return output;
+        return first_n(output, B);
     }
     if (y_relu && fused_pool != nullptr && fused_pool->plain_2x2() && cnn_batchnorm2d_forward_relu_pool_supported(B, C, H, W) != 0) {
         // BatchNorm2D -> ReLU -> MaxPool2D(2, 2): the apply pass pools as well.  A training pass under fuse_pool_block writes neither the
@@ -747,7 +757,7 @@ std::vector<tensor> BatchNorm2D::forward(const std::vector<tensor>& input) {
                                      saved_stats + C, B, C, H, W, eps, momentum, no_grad ? 0 : 1, workspace, workspace_bytes,
                                      stream),
              "cnn_batchnorm2d_forward");
-    return output;
+    return first_n(output, B);
 }
 
 // the normalised tensor of a pass that wrote only the ReLU output: gamma * ((x - mean) * inv_std) + beta with the batch statistics that pass
@@ -890,7 +900,7 @@ std::vector<tensor> Dropout::forward(const std::vector<tensor>& input) {
         for (int i = 0; i < C; ++i) mask[i] = i >= selected_num ? sequence[i] : -1;  // dropout.cpp:31-33
     const data_type* x = batch_device_pointer(input, in_stage, name);
     must(cnn_dropout_forward(x, out_buf.base, B, C, H, W, selected_num, no_grad ? 0 : 1, 1 - p, stream), "cnn_dropout_forward");
-    return output;
+    return first_n(output, B);
 }
 
 // dropout.cpp:57-69: in place on the caller's delta
@@ -976,7 +986,7 @@ std::vector<tensor> LinearLayer::forward(const std::vector<tensor>& input) {
     must(cnn_linear_forward(x, params, params + (size_t)in_channels * out_channels, out_buf.base, B, in_channels,
                             out_channels, stream),
          "cnn_linear_forward");
-    if (lazy_host_sync) return output;  // materialised on demand (Layer::get_output / Tensor3D::sync_to_host)
+    if (lazy_host_sync) return first_n(output, B);  // materialised on demand (Layer::get_output / Tensor3D::sync_to_host)
     // the callers read the logits on the host right away (softmax, func.cpp:24-28; argmax, cnn.cpp:92): one D2H
     std::vector<data_type> host((size_t)B * out_channels);
     must(cnn_memcpy_d2h(host.data(), out_buf.base, sizeof(data_type) * host.size(), stream), "cnn_memcpy_d2h");
@@ -986,7 +996,7 @@ std::vector<tensor> LinearLayer::forward(const std::vector<tensor>& input) {
         std::memcpy(output[b]->data, host.data() + (size_t)b * out_channels, sizeof(data_type) * out_channels);
         output[b]->mark_host_fresh();
     }
-    return output;
+    return first_n(output, B);
 }
 
 std::vector<tensor> LinearLayer::forward_loss_head(const std::vector<tensor>& input, const int* labels_dev, data_type* probs_dev,
@@ -1015,12 +1025,12 @@ std::vector<tensor> LinearLayer::forward_loss_head(const std::vector<tensor>& in
                                                 in_channels, out_channels, stream),
              "cnn_linear_forward_softmax_xent_dx");
         head_dx_done = true;
-        return output;
+        return first_n(output, B);
     }
     must(cnn_linear_forward_softmax_xent(x, params, params + (size_t)in_channels * out_channels, labels_dev, out_buf.base, probs_dev,
                                          delta_dev, loss_terms_dev, B, in_channels, out_channels, stream),
          "cnn_linear_forward_softmax_xent");
-    return output;
+    return first_n(output, B);
 }
 
 std::vector<tensor> LinearLayer::backward(std::vector<tensor>& delta) {
@@ -1065,7 +1075,7 @@ std::vector<tensor> LinearLayer::backward(std::vector<tensor>& delta) {
         }
         if (relu_below != nullptr && fuse_layers) relu_below->fused_backward_done();
         grads_ready = true;
-        return delta_buf.views;
+        return first_n(delta_buf.views, B);
     }
     if (relu_below != nullptr && fuse_layers) {  // the input IS that ReLU's output: its backward mask in the same kernel
         if (publish_backward) must(cnn_amd_publish_next_kernel(stream), "cnn_amd_publish_next_kernel");
@@ -1079,7 +1089,7 @@ std::vector<tensor> LinearLayer::backward(std::vector<tensor>& delta) {
              "cnn_linear_backward");
     }
     grads_ready = true;
-    return delta_buf.views;
+    return first_n(delta_buf.views, B);
 }
 
 void LinearLayer::join_pending(void* on_stream) {

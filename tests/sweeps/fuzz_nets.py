@@ -78,6 +78,11 @@ for it in range(n_nets):
             for step in range(3):
                 net.train_step(xd, ld, 1e-3)
                 trace.append((net.last_loss(), net.get_params(), net.get_grads(), net.input_delta((B,) + in_shape)))
+            # a SMALLER batch (the fused passes are sized for the first call's batch: the layers fall back), then the full one again
+            net.train_step(xd[: B - 1], ld[: B - 1], 1e-3)
+            trace.append((net.last_loss(), net.get_params(), net.get_grads(), net.input_delta((B,) + in_shape)))
+            net.train_step(xd, ld, 1e-3)
+            trace.append((net.last_loss(), net.get_params(), net.get_grads(), net.input_delta((B,) + in_shape)))
             outs = {names[i]: net.layer_output(names[i], (B,) + tuple(e["out"])) for i, e in enumerate(onet.layers)}
             if mode == "default":  # first step against the oracle
                 net2 = hostapi.HostSequential(spec, in_shape)
@@ -89,6 +94,15 @@ for it in range(n_nets):
                 e_log = float(np.abs(logits.reshape(ologits.shape) - ologits).max() / max(np.abs(ologits).max(), 1e-30))
                 e_loss = abs(net2.last_loss() - oloss) / max(1.0, abs(oloss))
                 net2.close()
+                # ... and the partial-batch step (trace[3]) after three full ones: loss and gradients (whole-arena norm; ReLU / pool decisions
+                # within rounding distance may flip over four steps -- a loose 5e-2; a stale sample in the batch moved the loss by ~1e-2 and the gradients by 0.1 - 0.9)
+                onet2 = O.SeqNet(spec, in_shape)  # (a fresh one: every Dropout layer's engine starts at its seed, like the net's)
+                onet2.params[:] = p0
+                for _ in range(3):
+                    onet2.train_step(x, labels, 1e-3)
+                pl, _ = onet2.train_step(x[: B - 1], labels[: B - 1], 1e-3)
+                e_ploss = abs(trace[3][0] - pl) / max(1.0, abs(pl)) if np.isfinite(pl) else 0.0
+                e_pgrad = float(np.abs(trace[3][2] - onet2.grads).max() / max(np.abs(onet2.grads).max(), 1e-30)) if np.isfinite(pl) else 0.0
             runs[mode] = (trace, outs)
             net.close()
     finally:
@@ -105,8 +119,8 @@ for it in range(n_nets):
         for nm in outs:
             if not np.array_equal(outs[nm].view(np.uint32), ref_outs[nm].view(np.uint32)):
                 diffs.append(f"{mode}: get_output({nm})")
-    ok = not diffs and e_log <= 1e-4 and e_loss <= 1e-4
+    ok = not diffs and e_log <= 1e-4 and e_loss <= 1e-4 and e_ploss <= 1e-3 and e_pgrad <= 5e-2
     bad += not ok
-    print(f"net {it}: B{B} {in_shape} {spec}\n   vs oracle: logits {e_log:.2e} loss {e_loss:.2e}; fused vs unfused: {'bit-identical' if not diffs else diffs[:6]}{'' if ok else '   <-- FAIL'}")
+    print(f"net {it}: B{B} {in_shape} {spec}\n   vs oracle: logits {e_log:.2e} loss {e_loss:.2e}, partial-batch step loss {e_ploss:.2e} grads {e_pgrad:.2e}; fused vs unfused: {'bit-identical' if not diffs else diffs[:6]}{'' if ok else '   <-- FAIL'}")
 print(f"FUZZ NETS {'OK' if bad == 0 else 'FAILED'}: {n_nets} networks, {bad} with differences")
 sys.exit(1 if bad else 0)

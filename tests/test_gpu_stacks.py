@@ -690,3 +690,42 @@ def test_dropout_layer_and_a_list_that_uses_it(T):
         hostapi.load().cnnh_set_no_grad(0)
     assert_close(logits, onet.forward(xb, training=False), REL_TOL, "no_grad forward (x * (1 - p))")
     net.close()
+
+
+PARTIAL_SPECS = [
+    [("conv", 32, 5, 1, 0), ("relu",), ("conv", 24, 5, 2, 2), ("relu",), ("linear", 3)],
+    [("conv", 24, 5, 1, 2), ("bn",), ("relu",), ("pool", 2, 2), ("conv", 24, 1, 1, 0), ("bn",), ("relu",), ("pool", 2, 2), ("linear", 3)],
+]
+
+
+@pytest.mark.parametrize("spec", PARTIAL_SPECS, ids=["plain", "bn_pool"])
+def test_a_smaller_batch_after_full_ones_is_processed_as_what_it_is(T, spec):
+    """three full train steps, then one with a batch SMALLER than the first call's (the layers' buffers are sized by that one: conv2d.cpp:47-52):
+    loss and every gradient of the small step against the oracle run on the same sequence.  Found by tests/sweeps/fuzz_nets.py late in round 6:
+    forward() / backward() handed on the whole buffer's views (like the reference's `return this->output`, conv2d.cpp:93 / :201), so every layer
+    behind the first one also walked the stale samples behind the batch -- convolution gradients off by 60 - 90 %, BatchNorm2D statistics over a
+    stale sample.  (The reference itself cannot run such a step: its loss glue indexes the labels by the returned vector.)"""
+    from cnn_amd import hostapi
+
+    in_shape, B = (3, 31, 29), 3
+    onet = O.SeqNet(spec, in_shape)
+    p0 = he_init(onet.layers, 7)
+    onet.params[:] = p0
+    x = uniform01(611, (B,) + in_shape)
+    labels = (np.arange(B) % 3).astype(np.int32)
+    xd, ld = T.from_numpy(x).cuda(), T.from_numpy(labels).cuda()
+    net = hostapi.HostSequential(spec, in_shape)
+    net.set_params(p0)
+    for _ in range(3):
+        onet.train_step(x, labels, 1e-3)
+        net.train_step(xd, ld, 1e-3)
+    oloss, _ = onet.train_step(x[: B - 1], labels[: B - 1], 1e-3)
+    net.train_step(xd[: B - 1], ld[: B - 1], 1e-3)
+    assert abs(net.last_loss() - oloss) <= 1e-4 * max(1.0, abs(oloss)), (net.last_loss(), oloss)
+    g = net.get_grads()
+    for e in onet.layers:
+        if e.get("n", 0) > 0:
+            sl = slice(e["off"], e["off"] + e["n"])
+            assert_close(g[sl], onet.grads[sl], 1e-3, f"small batch after full ones: {e['kind']} gradients")  # (four steps deep: 1e-3)
+    assert_close(net.get_params(), onet.params, REL_TOL, "small batch after full ones: parameters")
+    net.close()
