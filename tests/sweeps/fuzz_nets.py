@@ -105,6 +105,40 @@ for it in range(n_nets):
                 e_pgrad = float(np.abs(trace[3][2] - onet2.grads).max() / max(np.abs(onet2.grads).max(), 1e-30)) if np.isfinite(pl) else 0.0
             runs[mode] = (trace, outs)
             net.close()
+        # inference (architectures::no_grad: BatchNorm2D on its moving statistics, Dropout off, nothing recorded; inference.cpp's use of the
+        # classes) after two training steps: logits against the oracle in evaluation mode
+        net = hostapi.HostSequential(spec, in_shape)
+        net.set_params(p0)
+        onet3 = O.SeqNet(spec, in_shape)
+        onet3.params[:] = p0
+        for _ in range(2):
+            net.train_step(xd, ld, 1e-3)
+            onet3.train_step(x, labels, 1e-3)
+        lib.cnnh_set_no_grad(1)
+        try:
+            ev = net.forward_host(x)
+        finally:
+            lib.cnnh_set_no_grad(0)
+        oev = onet3.forward(x, training=False)
+        e_eval = float(np.abs(ev - oev.reshape(ev.shape)).max() / max(np.abs(oev).max(), 1e-30)) if np.all(np.isfinite(oev)) else 0.0
+        net.close()
+        # the reference's own loop through the same classes (cnn.cpp:79-90: forward -> host softmax / cross_entroy_backward -> backward ->
+        # update_gradients), from host tensors and from a device batch: parameters after every step against train_step's (host expf vs
+        # device expf may differ in the last bit of the probabilities: 2e-5 of the arena's largest parameter)
+        e_loop = 0.0
+        for how in ("device batch", "host tensors"):
+            net = hostapi.HostSequential(spec, in_shape)
+            net.set_params(p0)
+            for step in range(5):
+                xs, ls = (x[: B - 1], labels[: B - 1]) if step == 3 else (x, labels)
+                if how == "device batch":
+                    net.train_step_device(torch.from_numpy(xs).cuda(), ls, 1e-3)
+                else:
+                    net.train_step_host(xs, ls, 1e-3)
+                pr = runs["default"][0][step][1]
+                if np.all(np.isfinite(pr)):
+                    e_loop = max(e_loop, float(np.abs(net.get_params() - pr).max() / max(np.abs(pr).max(), 1e-30)))
+            net.close()
     finally:
         lib.cnnh_set_fuse_layers(1)
         lib.cnnh_set_fuse_pool_block(1)
@@ -119,8 +153,8 @@ for it in range(n_nets):
         for nm in outs:
             if not np.array_equal(outs[nm].view(np.uint32), ref_outs[nm].view(np.uint32)):
                 diffs.append(f"{mode}: get_output({nm})")
-    ok = not diffs and e_log <= 1e-4 and e_loss <= 1e-4 and e_ploss <= 1e-3 and e_pgrad <= 5e-2
+    ok = not diffs and e_log <= 1e-4 and e_loss <= 1e-4 and e_ploss <= 1e-3 and e_pgrad <= 5e-2 and e_loop <= 2e-5 and e_eval <= 2e-4
     bad += not ok
-    print(f"net {it}: B{B} {in_shape} {spec}\n   vs oracle: logits {e_log:.2e} loss {e_loss:.2e}, partial-batch step loss {e_ploss:.2e} grads {e_pgrad:.2e}; fused vs unfused: {'bit-identical' if not diffs else diffs[:6]}{'' if ok else '   <-- FAIL'}")
+    print(f"net {it}: B{B} {in_shape} {spec}\n   vs oracle: logits {e_log:.2e} loss {e_loss:.2e}, partial-batch step loss {e_ploss:.2e} grads {e_pgrad:.2e}; reference loop vs train_step params {e_loop:.2e}; inference logits {e_eval:.2e}; fused vs unfused: {'bit-identical' if not diffs else diffs[:6]}{'' if ok else '   <-- FAIL'}")
 print(f"FUZZ NETS {'OK' if bad == 0 else 'FAILED'}: {n_nets} networks, {bad} with differences")
 sys.exit(1 if bad else 0)
