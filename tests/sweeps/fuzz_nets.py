@@ -5,9 +5,10 @@ gradients, the delta with respect to the input, every layer's get_output() after
 those tensors and re-compute them on demand) and with the CPU oracle (oracle.pyoracle.SeqNet: logits and loss of the first step at 1e-4).
 The fusion wiring depends on neighbours and shapes (Conv2D -> ReLU, BatchNorm2D -> ReLU -> MaxPool2D(2,2) with the pool inside the apply
 pass and its backward from the pooled domain, ReLU' in the data gradients / the pool's backward): random layer lists reach the
-combinations the BASELINE stacks do not.     usage: fuzz_nets.py [nets=12] [seed=1] [big]
+combinations the BASELINE stacks do not.     usage: fuzz_nets.py [nets=12] [seed=1] [big] [dp]
 big: inputs of 96 .. 160 pixels whose first block is Conv2D -> BatchNorm2D -> ReLU -> MaxPool2D(2,2) -- planes large enough for the
-general (not channel-resident) BatchNorm2D kernels, where the pool runs inside the apply pass and the backward pass starts from the pooled domain"""
+general (not channel-resident) BatchNorm2D kernels, where the pool runs inside the apply pass and the backward pass starts from the pooled domain
+dp:  also with a one-rank RCCL communicator and the gradient exchange forced on (plain and bucketed): bit-identical to the plain step"""
 import os
 import sys
 
@@ -20,7 +21,8 @@ from cnn_amd.stacks import he_init
 from oracle import pyoracle as O
 
 big = "big" in sys.argv[1:]
-sys.argv = [a for a in sys.argv if a != "big"]
+dp = "dp" in sys.argv[1:]
+sys.argv = [a for a in sys.argv if a not in ("big", "dp")]
 n_nets = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 lib = hostapi.load()
@@ -122,6 +124,30 @@ for it in range(n_nets):
         oev = onet3.forward(x, training=False)
         e_eval = float(np.abs(ev - oev.reshape(ev.shape)).max() / max(np.abs(oev).max(), 1e-30)) if np.all(np.isfinite(oev)) else 0.0
         net.close()
+        # data parallelism with ONE rank (every collective the N-rank step issues is issued, every sum is an identity): a one-rank RCCL
+        # communicator with the exchange forced on, plain and bucketed (sync-BN reductions on the same communicator), against the default run
+        dp_diff = []
+        if dp:
+            from cnn_amd import capi
+            from cnn_amd.dp import RcclComm
+
+            comm = RcclComm(None, 1, 0)
+            for opt in ("DP_FORCE_EXCHANGE", "DP_FORCE_BUCKETS"):
+                capi.set_option(opt, "1")
+                try:
+                    net = hostapi.HostSequential(spec, in_shape)
+                    net.set_params(p0)
+                    net.set_comm(comm.handle, 1)
+                    for step in range(3):
+                        net.train_step(xd, ld, 1e-3)
+                        la, pa, ga, _ = runs["default"][0][step]
+                        for what, a, b in (("loss", np.float32(net.last_loss()), np.float32(la)), ("params", net.get_params(), pa), ("grads", net.get_grads(), ga)):
+                            if not np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32)):
+                                dp_diff.append(f"{opt}: step {step} {what}")
+                    net.close()
+                finally:
+                    capi.set_option(opt, None)
+            comm.destroy()
         # the reference's own loop through the same classes (cnn.cpp:79-90: forward -> host softmax / cross_entroy_backward -> backward ->
         # update_gradients), from host tensors and from a device batch: parameters after every step against train_step's (host expf vs
         # device expf may differ in the last bit of the probabilities: 2e-5 of the arena's largest parameter)
@@ -153,6 +179,7 @@ for it in range(n_nets):
         for nm in outs:
             if not np.array_equal(outs[nm].view(np.uint32), ref_outs[nm].view(np.uint32)):
                 diffs.append(f"{mode}: get_output({nm})")
+    diffs += dp_diff
     ok = not diffs and e_log <= 1e-4 and e_loss <= 1e-4 and e_ploss <= 1e-3 and e_pgrad <= 5e-2 and e_loop <= 2e-5 and e_eval <= 2e-4
     bad += not ok
     print(f"net {it}: B{B} {in_shape} {spec}\n   vs oracle: logits {e_log:.2e} loss {e_loss:.2e}, partial-batch step loss {e_ploss:.2e} grads {e_pgrad:.2e}; reference loop vs train_step params {e_loop:.2e}; inference logits {e_eval:.2e}; fused vs unfused: {'bit-identical' if not diffs else diffs[:6]}{'' if ok else '   <-- FAIL'}")

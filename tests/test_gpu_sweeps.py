@@ -30,9 +30,11 @@ def test_random_shapes_of_every_layer_type_vs_oracle(what):
 @pytest.mark.parametrize("mode", ["small", "big"])
 def test_random_networks_fused_equals_unfused_and_match_oracle(mode):
     """tests/sweeps/fuzz_nets.py: random layer lists through architectures::Sequential::train_step with every fusion on / the pool block off /
-    all fusions off -- losses, parameters, gradients, the input delta and every get_output() bit for bit, first-step logits and loss against
-    oracle.pyoracle.SeqNet (alexnet.cpp:35-65 for an arbitrary list)"""
-    args = ["tests/sweeps/fuzz_nets.py", "10", "21"] + (["big"] if mode == "big" else [])
+    all fusions off -- losses, parameters, gradients, the input delta and every get_output() bit for bit over three full steps, a step with a
+    SMALLER batch and a full one behind it; first-step logits / loss and the small step's loss / gradients against oracle.pyoracle.SeqNet
+    (alexnet.cpp:35-65 for an arbitrary list); the reference's own loop (cnn.cpp:79-90) from a device batch and from host tensors; inference
+    under no_grad; small: also through a one-rank RCCL communicator with the exchange forced on"""
+    args = ["tests/sweeps/fuzz_nets.py", "10", "21"] + (["big"] if mode == "big" else ["dp"])
     out = _run(*args)
     assert "FUZZ NETS OK" in out
 
