@@ -449,6 +449,21 @@ __global__ __launch_bounds__(256) void u8hwc_to_f32chw(const unsigned* __restric
         *(float4*)(d + 8 * (size_t)hw4) = c2;
     }
 }
+// ... and for images whose pixel count is no multiple of four (round 6: any H, W): one thread per pixel, three byte loads, three stores
+__global__ __launch_bounds__(256) void u8hwc_to_f32chw_px(const unsigned char* __restrict__ src, float* __restrict__ dst, const float* __restrict__ lut_g,
+                                                          int hw, long long px_total) {
+    __shared__ float lut[256];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < px_total; q += (long long)gridDim.x * 256) {
+        const long long b = q / hw;
+        const int i = (int)(q - b * hw);
+        float* d = dst + (size_t)b * 3 * hw + i;
+        d[0] = lut[src[3 * q]];
+        d[(size_t)hw] = lut[src[3 * q + 1]];
+        d[2 * (size_t)hw] = lut[src[3 * q + 2]];
+    }
+}
 }  // namespace
 
 int cnn_batch_stager_create(void** stager, size_t batch_bytes, int depth) {
@@ -472,7 +487,6 @@ int cnn_batch_stager_create(void** stager, size_t batch_bytes, int depth) {
 
 int cnn_batch_stager_create_u8(void** stager, int B, int H, int W, int depth) {
     CNN_REQUIRE(stager && B > 0 && H > 0 && W > 0 && depth >= 2 && depth <= 16, "cnn_batch_stager_create_u8: bad arguments (depth 2..16)");
-    CNN_REQUIRE(((long long)H * W) % 4 == 0, "cnn_batch_stager_create_u8: H*W must be a multiple of 4 (%d x %d)", H, W);
     Stager* st = new Stager();
     st->bytes = (size_t)B * H * W * 3;
     st->depth = depth;
@@ -533,10 +547,17 @@ int cnn_batch_stager_submit(void* stager, int slot, void** device_ptr) {
     if (st->in_use[slot]) CNN_HIP_CHECK(hipStreamWaitEvent(st->copy, st->consumed[slot], 0));
     CNN_HIP_CHECK(hipMemcpyAsync(st->dev[slot], st->host[slot], st->bytes, hipMemcpyHostToDevice, st->copy));
     if (st->lut != nullptr) {  // bytes -> the fp32 planar batch, behind the copy on the same stream
-        const int hw4 = st->H * st->W / 4;
-        const long long quads = (long long)st->B * hw4;
-        u8hwc_to_f32chw<<<stream_grid((size_t)quads, 256), 256, 0, st->copy>>>((const unsigned*)st->dev[slot], (float*)st->dev_f32[slot], st->lut, hw4,
-                                                                               quads);
+        const int hw = st->H * st->W;
+        if (hw % 4 == 0) {
+            const int hw4 = hw / 4;
+            const long long quads = (long long)st->B * hw4;
+            u8hwc_to_f32chw<<<stream_grid((size_t)quads, 256), 256, 0, st->copy>>>((const unsigned*)st->dev[slot], (float*)st->dev_f32[slot], st->lut,
+                                                                                   hw4, quads);
+        } else {
+            const long long px = (long long)st->B * hw;
+            u8hwc_to_f32chw_px<<<stream_grid((size_t)px, 256), 256, 0, st->copy>>>((const unsigned char*)st->dev[slot], (float*)st->dev_f32[slot],
+                                                                                   st->lut, hw, px);
+        }
         CNN_LAUNCH_CHECK();
     }
     CNN_HIP_CHECK(hipEventRecord(st->uploaded[slot], st->copy));

@@ -512,8 +512,8 @@ int cnn_batch_stager_create(void** stager, size_t batch_bytes, int depth);
  * bytes (cv::Mat CV_8UC3, channel order as it lies -- BGR for cv::imread).  The pinned slots and the H2D copies hold BYTES (a quarter
  * of the fp32 batch: 150 KB instead of 602 KB per 224 x 224 image); behind the copy, still on the stager's own stream, one kernel
  * writes the batch the layers consume -- fp32, planar [B][3][H][W], data[c*H*W + i] = byte * 1.f / 255 through a 256-entry table that
- * the HOST fills with that very expression, so the result is bit-identical to the reference's conversion.  submit() returns the fp32
- * batch; acquire / wait / release / destroy as above. */
+ * the HOST fills with that very expression, so the result is bit-identical to the reference's conversion.  Any H, W (pixel counts that
+ * are multiples of four take the 16-byte-store kernel).  submit() returns the fp32 batch; acquire / wait / release / destroy as above. */
 int cnn_batch_stager_create_u8(void** stager, int B, int H, int W, int depth);
 int cnn_batch_stager_destroy(void* stager);
 int cnn_batch_stager_acquire(void* stager, void** pinned_host, int* slot);

@@ -5,7 +5,9 @@
   pool  -- MaxPool2D forward (values + mask bit-exact, pool2d.cpp:40-83) and backward (+ the fused ReLU'), k in {2, 3}, step in {1, 2, 3}
   bn    -- BatchNorm2D training forward / backward, the fused BatchNorm -> ReLU -> MaxPool(2,2) forward and its pooled-domain backward
   lin   -- LinearLayer forward / backward and the fused loss head with dx
-usage: fuzz_layers.py [conv|pool|bn|lin|all] [cases=40] [seed=1]"""
+  misc  -- ReLU forward / backward and the SGD step at random (also unaligned) lengths, softmax + cross entropy, Dropout, Grad-CAM: bit-exact
+           against the oracle where the arithmetic is the reference's own order; the uint8 batch stager (byte * 1.f / 255, planar) at random sizes
+usage: fuzz_layers.py [conv|pool|bn|lin|misc|all] [cases=40] [seed=1]"""
 import os
 import sys
 
@@ -200,7 +202,73 @@ def lin_cases():
         report(f"linear B{B} {n_in}->{n_out}", errs)
 
 
-for name, fn in (("conv", conv_cases), ("pool", pool_cases), ("bn", bn_cases), ("lin", lin_cases)):
+def misc_cases():
+    import ctypes as C_
+
+    bits = lambda a, b: 0.0 if np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32)) else 1.0
+    for it in range(n_cases):
+        n = int(rs.randint(1, 300000)) if it % 3 else int(rs.randint(1, 70))
+        off = int(rs.randint(0, 4))  # (views that do not start on 16 bytes take the scalar paths)
+        x = (rs.rand(n + off) * 2 - 1).astype(np.float32)
+        x[rs.rand(n + off) < 0.05] = 0.0
+        x[rs.rand(n + off) < 0.02] = -0.0
+        d = (rs.rand(n + off) * 2 - 1).astype(np.float32)
+        xd, dd = dev(x)[off:], dev(d)[off:]
+        y = capi.relu_forward(xd.contiguous() if off == 0 else xd)
+        y_ref = O.relu_forward(x[off:])
+        dx = capi.relu_backward(y, dd.clone())
+        errs = {"relu": bits(y.cpu().numpy(), y_ref), "relu'": bits(dx.cpu().numpy(), O.relu_backward(y_ref, d[off:]))}
+        lr = float(rs.choice([1e-3, 0.05, 1.0]))
+        p_new = capi.sgd_update(dev(x)[off:].clone(), dd, lr)
+        errs["sgd"] = bits(p_new.cpu().numpy(), O.sgd_update(x[off:], d[off:], lr))
+        report(f"relu / sgd n={n} offset {off}", errs)
+        # softmax + cross entropy (func.cpp:16-73): clamped exp, sequential sums
+        B, ncls = int(rs.randint(1, 400)), int(rs.randint(1, 12))
+        logits = (rs.standard_normal((B, ncls)) * rs.choice([1, 10, 60])).astype(np.float32)
+        labels = rs.randint(0, ncls, B).astype(np.int32)
+        probs, delta, loss = capi.softmax_xent(dev(logits), dev(labels))
+        p_ref = O.softmax(logits)
+        l_ref, d_ref = O.cross_entropy_backward(p_ref, labels)
+        lv = float(loss.item()) / B
+        errs = {"probs": rel(probs.cpu().numpy(), p_ref), "delta": rel(delta.cpu().numpy(), d_ref),
+                "loss": 0.0 if (not np.isfinite(l_ref) and not np.isfinite(lv)) else abs(lv - l_ref) / max(1.0, abs(l_ref))}
+        report(f"softmax_xent B{B} classes {ncls}", errs)
+        # Dropout (dropout.cpp:7-69) and Grad-CAM (alexnet.cpp:107-140)
+        Bq, Cq, Hq, Wq = int(rs.randint(1, 5)), int(rs.randint(1, 100)), int(rs.randint(1, 30)), int(rs.randint(1, 30))
+        pq = float(rs.choice([0.1, 0.2, 0.29, 0.5, 0.75]))
+        xq = (rs.rand(Bq, Cq, Hq, Wq) * 2 - 1).astype(np.float32)
+        yq = capi.dropout_forward(dev(xq), pq, training=True)
+        yq_ref = O.dropout_forward(xq, pq, training=True)
+        ye = capi.dropout_forward(dev(xq), pq, training=False)
+        dq = capi.dropout_backward(dev(xq).clone(), pq)
+        # (the oracle's engine state: one training forward above, so its backward sees the same dropped channels -- the reference drops the
+        #  FIRST int(p * C) channels of a shuffled sequence seeded 1314: identical on every first call)
+        errs = {"dropout train": bits(yq.cpu().numpy(), yq_ref), "dropout eval": bits(ye.cpu().numpy(), O.dropout_forward(xq, pq, training=False))}
+        cam, img = capi.grad_cam(dev(np.abs(xq)))
+        cam_ref, img_ref = O.grad_cam(np.abs(xq))
+        errs["grad-cam map"] = bits(cam.cpu().numpy(), cam_ref)
+        errs["grad-cam picture"] = 0.0 if np.array_equal(img.cpu().numpy(), img_ref) else 1.0
+        report(f"dropout / grad-cam {(Bq, Cq, Hq, Wq)} p={pq}", errs)
+        # the uint8 stager: interleaved bytes -> planar fp32 * (1 / 255) with the reference's expression (byte * 1.f / 255)
+        if it % 4 == 0:
+            Bs, Hs, Ws = int(rs.randint(1, 5)), int(rs.randint(1, 60)), int(rs.randint(1, 60))
+            st = capi.BatchStager(u8_shape=(Bs, Hs, Ws), depth=2)
+            img8 = rs.randint(0, 256, (Bs, Hs, Ws, 3)).astype(np.uint8)
+            host, slot = st.acquire()
+            host[:] = img8.reshape(-1)
+            devp = st.submit(slot)
+            st.wait(slot)
+            out = torch.empty((Bs, 3, Hs, Ws), dtype=torch.float32, device="cuda")
+            capi.check(capi.load().cnn_memcpy_d2d(C_.c_void_p(out.data_ptr()), C_.c_void_p(devp), Bs * 3 * Hs * Ws * 4, capi._stream()), "d2d") if hasattr(capi.load(), "cnn_memcpy_d2d") else None
+            torch.cuda.synchronize()
+            st.release(slot)
+            ref = (img8.astype(np.float32) * np.float32(1.0) / np.float32(255)).transpose(0, 3, 1, 2)
+            if hasattr(capi.load(), "cnn_memcpy_d2d"):
+                report(f"u8 stager {(Bs, Hs, Ws)}", {"planar fp32": bits(out.cpu().numpy(), np.ascontiguousarray(ref))})
+            st.close()
+
+
+for name, fn in (("conv", conv_cases), ("pool", pool_cases), ("bn", bn_cases), ("lin", lin_cases), ("misc", misc_cases)):
     if what in (name, "all"):
         fn()
 print(f"FUZZ {'OK' if bad == 0 else 'FAILED'} ({what}): worst error {worst:.2e}, {bad} case(s) above {TOL:.0e}")

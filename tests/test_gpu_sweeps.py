@@ -18,11 +18,12 @@ def _run(*args):
     return r.stdout
 
 
-@pytest.mark.parametrize("what", ["conv", "pool", "bn", "lin"])
+@pytest.mark.parametrize("what", ["conv", "pool", "bn", "lin", "misc"])
 def test_random_shapes_of_every_layer_type_vs_oracle(what):
     """tests/sweeps/fuzz_layers.py: convolutions with wide planes / 1x1, 5x5, 7x7 filters / many units per workgroup (conv2d.cpp:69-199), MaxPool2D
     forward + mask + backward bit-exact (pool2d.cpp:40-107), BatchNorm2D training passes and the fused BatchNorm -> ReLU -> MaxPool forms
-    (batchnorm2d.cpp:24-158), LinearLayer and the fused loss head (linear.cpp:33-90, func.cpp:16-73)"""
+    (batchnorm2d.cpp:24-158), LinearLayer and the fused loss head (linear.cpp:33-90, func.cpp:16-73); misc: ReLU, SGD, softmax + cross
+    entropy, Dropout, Grad-CAM, the uint8 batch stager at random sizes"""
     out = _run("tests/sweeps/fuzz_layers.py", what, "24", "11")
     assert "FUZZ OK" in out
 
