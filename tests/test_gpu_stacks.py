@@ -698,7 +698,7 @@ PARTIAL_SPECS = [
 ]
 
 
-@pytest.mark.parametrize("spec", PARTIAL_SPECS, ids=["plain", "bn_pool"])
+@pytest.mark.parametrize("spec", PARTIAL_SPECS + ["alexnet", "alexnet_bn"], ids=["plain", "bn_pool", "alexnet", "alexnet_bn"])
 def test_a_smaller_batch_after_full_ones_is_processed_as_what_it_is(T, spec):
     """three full train steps, then one with a batch SMALLER than the first call's (the layers' buffers are sized by that one: conv2d.cpp:47-52):
     loss and every gradient of the small step against the oracle run on the same sequence.  Found by tests/sweeps/fuzz_nets.py late in round 6:
@@ -708,6 +708,8 @@ def test_a_smaller_batch_after_full_ones_is_processed_as_what_it_is(T, spec):
     from cnn_amd import hostapi
 
     in_shape, B = (3, 31, 29), 3
+    if isinstance(spec, str):  # the reference net itself (alexnet.cpp:10-33): pool-fused first block, fused step tail, deferred input gradient
+        spec, in_shape, B = S.alexnet(3, batch_norm=spec.endswith("_bn")), (3, 224, 224), 4
     onet = O.SeqNet(spec, in_shape)
     p0 = he_init(onet.layers, 7)
     onet.params[:] = p0
