@@ -18,7 +18,8 @@ from cnn_amd import capi
 from oracle import pyoracle as O
 
 widths = "widths" in sys.argv[1:]
-sys.argv = [a for a in sys.argv if a != "widths"]
+batches = "batches" in sys.argv[1:]  # square BASELINE planes (7 / 14 / 28 / 56, pad 1, stride 1 / 2) at batches of 1 .. 140: units per workgroup, ragged last units, tall units
+sys.argv = [a for a in sys.argv if a not in ("widths", "batches")]
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 
@@ -60,6 +61,14 @@ for it in range(n_cases):
                 Ci, Co = min(Ci, 64), min(Co, 128)
         if (H + 2 * pad - k) // s + 1 < 1:
             H = k
+    if batches:
+        k, pad = 3, 1
+        W = H = int(rs.choice([7, 7, 14, 14, 28, 56]))
+        s = 1 if rs.rand() < 0.7 else 2
+        Ci, Co = int(rs.choice([32, 64, 128])), int(rs.choice([32, 64, 128, 192]))
+        B = int(rs.randint(1, 141))
+        while B * H * W * Ci * Co > 6e9:
+            B = max(1, B // 2)
     case = (B, Ci, H, W, Co, k, s, pad)
     x = rs.rand(B, Ci, H, W).astype(np.float32)
     w = (rs.standard_normal((Co, Ci, k, k)) * 0.1).astype(np.float32)
