@@ -310,8 +310,9 @@ long long cnn_amd_kernel_timing_report(char* buf, size_t cap) {
     return (long long)out.size() + 1;
 }
 
-int cnn_conv2d_out_dim(int in, int k, int s, int pad) { return (in + 2 * pad - k) / s + 1; }
-int cnn_maxpool2d_out_dim(int in, int k, int step) { return (in - k) / step + 1; }
+// (a stride of 0 is a caller's bug, not a reason to raise SIGFPE in its process: 0 outputs)
+int cnn_conv2d_out_dim(int in, int k, int s, int pad) { return s > 0 ? (in + 2 * pad - k) / s + 1 : 0; }
+int cnn_maxpool2d_out_dim(int in, int k, int step) { return step > 0 ? (in - k) / step + 1 : 0; }
 
 int cnn_device_alloc(void** ptr, size_t bytes) {
     CNN_REQUIRE(ptr != nullptr, "cnn_device_alloc: ptr is null");

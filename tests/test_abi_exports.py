@@ -145,3 +145,16 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libcnn_amd.so")
     with pytest.raises(capi.CnnAmdError):
         capi.load()
+
+
+def test_every_entry_point_refuses_null_pointers_without_crashing():
+    """tests/sweeps/null_args.py: each status-returning entry point of include/cnn_amd.h in a child process, all pointers NULL -- once with
+    every size zero (any status, no signal), once with non-zero sizes (a non-zero status and a message).  Found on its first run:
+    cnn_conv2d_out_dim / cnn_maxpool2d_out_dim raised SIGFPE on a stride of 0"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "sweeps", "null_args.py")], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "NULL ARGS OK" in r.stdout, (r.stdout + r.stderr)[-2000:]
