@@ -19,7 +19,9 @@ from oracle import pyoracle as O
 
 widths = "widths" in sys.argv[1:]
 batches = "batches" in sys.argv[1:]  # square BASELINE planes (7 / 14 / 28 / 56, pad 1, stride 1 / 2) at batches of 1 .. 140: units per workgroup, ragged last units, tall units
-sys.argv = [a for a in sys.argv if a not in ("widths", "batches")]
+wild = "wild" in sys.argv[1:]  # anything the desc admits: odd k 1..7, strides 1..4, padding 0..4 (also > k/2), 1..40 channels (odd counts, 1, 3), planes 1..40; geometries
+#                                  without an output pixel must be REFUSED (a status, not a crash)
+sys.argv = [a for a in sys.argv if a not in ("widths", "batches", "wild")]
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 
@@ -69,6 +71,20 @@ for it in range(n_cases):
         B = int(rs.randint(1, 141))
         while B * H * W * Ci * Co > 6e9:
             B = max(1, B // 2)
+    if wild:
+        k, s, pad = int(rs.choice([1, 3, 5, 7])), int(rs.randint(1, 5)), int(rs.randint(0, 5))
+        B, Ci, Co = int(rs.randint(1, 4)), int(rs.randint(1, 41)), int(rs.randint(1, 41))
+        H, W = int(rs.randint(1, 41)), int(rs.randint(1, 41))
+        if (H + 2 * pad - k) // s + 1 < 1 or (W + 2 * pad - k) // s + 1 < 1 or H + 2 * pad < k or W + 2 * pad < k:
+            try:
+                conv = capi.Conv2d(B, Ci, H, W, Co, k, s, pad)
+                xd = torch.zeros((B, Ci, H, W), device="cuda")
+                conv.forward(xd, torch.zeros((Co, Ci, k, k), device="cuda"), torch.zeros((Co,), device="cuda"))
+                print(f"{str((B, Ci, H, W, Co, k, s, pad)):42s} no output pixel, and the call was ACCEPTED   <-- FAIL")
+                bad += 1
+            except (capi.CnnAmdError, AssertionError, ValueError, RuntimeError) as e:
+                print(f"{str((B, Ci, H, W, Co, k, s, pad)):42s} refused: {str(e)[:90]}")
+            continue
     case = (B, Ci, H, W, Co, k, s, pad)
     x = rs.rand(B, Ci, H, W).astype(np.float32)
     w = (rs.standard_normal((Co, Ci, k, k)) * 0.1).astype(np.float32)

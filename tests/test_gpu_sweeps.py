@@ -45,3 +45,10 @@ def test_random_shapes_on_the_per_width_kernel_instances_vs_oracle():
     3-channel first layers) with random heights, batches and channel counts, all three passes against the oracle (conv2d.cpp:69-199)"""
     out = _run("tests/sweeps/fuzz_conv.py", "30", "31", "widths")
     assert "FUZZ OK" in out
+
+
+def test_anything_the_descriptor_admits_vs_oracle_or_refused():
+    """tests/sweeps/fuzz_conv.py wild: odd filters 1..7, strides 1..4, padding 0..4 (also beyond k/2), 1..40 channels, planes of 1..40 pixels: all
+    three passes against the oracle (conv2d.cpp:69-199 on the zero-padded input), geometries without an output pixel refused with a status"""
+    out = _run("tests/sweeps/fuzz_conv.py", "40", "41", "wild")
+    assert "FUZZ OK" in out
