@@ -90,6 +90,8 @@ def pool_cases():
     for it in range(n_cases):
         k = int(rs.choice([2, 2, 3]))
         step = int(rs.choice([2, 2, 1, 3])) if k == 3 else int(rs.choice([2, 2, 1]))
+        if it % 4 == 3:  # any window / step (pool2d.cpp:14-15 accepts them)
+            k, step = int(rs.randint(1, 6)), int(rs.randint(1, 5))
         B, C = int(rs.randint(1, 5)), int(rs.randint(1, 40))
         H, W = int(rs.randint(k, 70)), int(rs.randint(k, 70))
         x = (rs.rand(B, C, H, W) * 2 - 1).astype(np.float32)
