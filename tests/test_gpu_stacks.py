@@ -728,6 +728,6 @@ def test_a_smaller_batch_after_full_ones_is_processed_as_what_it_is(T, spec):
     for e in onet.layers:
         if e.get("n", 0) > 0:
             sl = slice(e["off"], e["off"] + e["n"])
-            assert_close(g[sl], onet.grads[sl], 1e-3, f"small batch after full ones: {e['kind']} gradients")  # (four steps deep: 1e-3)
+            assert_close(g[sl], onet.grads[sl], REL_TOL, f"small batch after full ones: {e['kind']} gradients")
     assert_close(net.get_params(), onet.params, REL_TOL, "small batch after full ones: parameters")
     net.close()
