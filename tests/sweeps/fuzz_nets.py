@@ -148,6 +148,35 @@ for it in range(n_nets):
                 finally:
                     capi.set_option(opt, None)
             comm.destroy()
+        # checkpoint round trip (alexnet.cpp:67-90: every layer's parameters in list order) and Grad-CAM (alexnet.cpp:95-142) on a random layer
+        import tempfile
+
+        net = hostapi.HostSequential(spec, in_shape)
+        net.set_params(p0)
+        net.train_step(xd, ld, 1e-3)
+        net.train_step(xd, ld, 1e-3)
+        misc_diff = []
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "net.model")
+            net.save_checkpoint(path)
+            twin = hostapi.HostSequential(spec, in_shape)
+            twin.load_checkpoint(path)
+            if not np.array_equal(twin.get_params().view(np.uint32), net.get_params().view(np.uint32)):
+                misc_diff.append("checkpoint: parameters differ after save -> load")
+            la, lb = net.forward_host(x), twin.forward_host(x)
+            if not np.array_equal(la.view(np.uint32), lb.view(np.uint32)):
+                misc_diff.append("checkpoint: logits of the loaded net differ")
+            twin.close()
+        cam_layers = [i for i, e in enumerate(onet.layers) if e["kind"] in ("conv", "relu", "pool")]
+        ci = cam_layers[int(rs.randint(0, len(cam_layers)))]
+        Cq, Hq, Wq = onet.layers[ci]["out"]
+        net.forward_host(x)  # (a forward pass with gradients enabled precedes grad_cam, alexnet.cpp:95)
+        fea = net.layer_output(names[ci], (B, Cq, Hq, Wq))
+        img, cam = net.grad_cam(names[ci], (B, Hq, Wq))
+        cam_ref, img_ref = O.grad_cam(fea)
+        if not (np.array_equal(cam.view(np.uint32), cam_ref.view(np.uint32)) and np.array_equal(img, img_ref)):
+            misc_diff.append(f"grad_cam({names[ci]}) differs from the oracle's on the same feature map")
+        net.close()
         # the reference's own loop through the same classes (cnn.cpp:79-90: forward -> host softmax / cross_entroy_backward -> backward ->
         # update_gradients), from host tensors and from a device batch: parameters after every step against train_step's (host expf vs
         # device expf may differ in the last bit of the probabilities: 2e-5 of the arena's largest parameter)
@@ -179,7 +208,7 @@ for it in range(n_nets):
         for nm in outs:
             if not np.array_equal(outs[nm].view(np.uint32), ref_outs[nm].view(np.uint32)):
                 diffs.append(f"{mode}: get_output({nm})")
-    diffs += dp_diff
+    diffs += dp_diff + misc_diff
     ok = not diffs and e_log <= 1e-4 and e_loss <= 1e-4 and e_ploss <= 1e-3 and e_pgrad <= 5e-2 and e_loop <= 2e-5 and e_eval <= 2e-4
     bad += not ok
     print(f"net {it}: B{B} {in_shape} {spec}\n   vs oracle: logits {e_log:.2e} loss {e_loss:.2e}, partial-batch step loss {e_ploss:.2e} grads {e_pgrad:.2e}; reference loop vs train_step params {e_loop:.2e}; inference logits {e_eval:.2e}; fused vs unfused: {'bit-identical' if not diffs else diffs[:6]}{'' if ok else '   <-- FAIL'}")
