@@ -99,19 +99,44 @@ for it in range(n_cases):
     if os.environ.get("FUZZ_AUTOTUNE"):  # let the library measure and pin the implicit-GEMM tile of this geometry first (cnn_conv2d_autotune)
         conv.autotune()
     xd, wd, bd, dyd = (torch.from_numpy(t).cuda() for t in (x, w, b, dy))
+    # every output lives between two guard zones of a larger allocation: a kernel that stores outside its tensor shows up there
+    GUARD, CANARY = 4096, -12345.5
+    guards = []
+
+    MIS = int(os.environ.get("FUZZ_MISALIGN", "0"))  # every tensor MIS floats off a 16-byte boundary: plain pointers are all the C ABI asks for
+
+    def guarded(shape):
+        n = int(np.prod(shape))
+        big = torch.full((n + 2 * GUARD + MIS,), CANARY, dtype=torch.float32, device="cuda")
+        guards.append((big[MIS:], n))
+        return big[GUARD + MIS:GUARD + MIS + n].view(*shape)
+
+    if MIS:
+        def shifted(t):
+            big = torch.empty((t.numel() + MIS,), dtype=torch.float32, device="cuda")
+            big[MIS:] = t.reshape(-1)
+            return big[MIS:].view(*t.shape)
+
+        xd, wd, bd, dyd = shifted(xd), shifted(wd), shifted(bd), shifted(dyd)
+
     capi.kernel_timing(1)
-    y = conv.forward(xd, wd, bd)
-    dx = conv.backward_data(dyd, wd)
-    relu_in = capi.relu_forward(xd - 0.5)
-    dxm = torch.full_like(xd, 7.0)
+    y = conv.forward(xd, wd, bd, y=guarded((B, Co, Ho, Wo)))
+    dx = conv.backward_data(dyd, wd, dx=guarded((B, Ci, H, W)))
+    relu_in = capi.relu_forward((xd - 0.5).contiguous())
+    if MIS:
+        relu_in = shifted(relu_in)
+    dxm = guarded((B, Ci, H, W))
     conv.backward_data_relu(dyd, wd, relu_in, dxm)
-    gw, gb = conv.backward_weight(xd, dyd, float(B))
+    gw, gb = conv.backward_weight(xd, dyd, float(B), gw=guarded((Co, Ci, k, k)), gb=guarded((Co,)))
     torch.cuda.synchronize()
+    overrun = sum(int((big[:GUARD] != CANARY).sum().item()) + int((big[GUARD + n:] != CANARY).sum().item()) for big, n in guards)
     names = [k.split("|")[0] for k in capi.kernel_timing_report() if not any(t in k for t in ("prep", "reduce", "relu_f", "pack"))]
     capi.kernel_timing(0)
     errs = {"y": rel(y.cpu().numpy(), y_ref), "dx": rel(dx.cpu().numpy(), dx_ref),
             "dx_relu": rel(dxm.cpu().numpy(), np.where(relu_in.cpu().numpy() <= 0, np.float32(0), dx_ref)),
             "gw": rel(gw.cpu().numpy(), gw_ref), "gb": rel(gb.cpu().numpy(), gb_ref)}
+    if overrun:
+        errs["STORES OUTSIDE AN OUTPUT TENSOR (guard floats changed)"] = float(overrun)
     e = max(errs.values())
     worst = max(worst, e)
     flag = "" if e <= 1e-4 else "   <-- FAIL " + str({k: f"{v:.2e}" for k, v in errs.items() if v > 1e-4})
