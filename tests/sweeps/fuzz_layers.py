@@ -31,8 +31,33 @@ def rel(a, ref):
     return float(np.abs(np.asarray(a, np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30))
 
 
+MIS = int(os.environ.get("FUZZ_MISALIGN", "0"))  # every input tensor MIS elements off its allocation's start (plain pointers are all the C ABI asks for)
+GUARD, CANARY = 2048, -12345.5
+_guards = []
+
+
 def dev(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    if MIS == 0 or t.numel() == 0:
+        return t
+    big = torch.empty((t.numel() + MIS,), dtype=t.dtype, device="cuda")
+    big[MIS:] = t.reshape(-1)
+    return big[MIS:].view(*t.shape)
+
+
+def guarded(shape):
+    """an fp32 output between two guard zones of a larger allocation: a store outside the tensor changes a canary"""
+    n = int(np.prod(shape))
+    big = torch.full((n + 2 * GUARD + MIS,), CANARY, dtype=torch.float32, device="cuda")
+    _guards.append((big[MIS:], n))
+    return big[GUARD + MIS:GUARD + MIS + n].view(*shape)
+
+
+def overruns():
+    torch.cuda.synchronize()
+    bad_ = sum(int((b[:GUARD] != CANARY).sum().item()) + int((b[GUARD + n:] != CANARY).sum().item()) for b, n in _guards)
+    _guards.clear()
+    return {"STORES OUTSIDE AN OUTPUT TENSOR": float(bad_)} if bad_ else {}
 
 
 def report(tag, errs, names=""):
@@ -101,20 +126,23 @@ def pool_cases():
         dx_ref = O.maxpool_backward(dy, m_ref, x.shape, k, step)
         xd = dev(x)
         y, m = capi.maxpool_forward(xd, k, step)
-        dx = capi.maxpool_backward(dev(dy), m, x.shape, k, step)
+        dx = capi.maxpool_backward(dev(dy), m, x.shape, k, step, dx=guarded(x.shape))
         xr = np.maximum(x, 0)
         yr, mr = capi.maxpool_forward(dev(xr), k, step)
         yr_ref, mr_ref = O.maxpool_forward(xr, k, step)
-        dxr = capi.maxpool_backward_relu(dev(dy), mr, yr, x.shape, k, step)
+        dxr = capi.maxpool_backward_relu(dev(dy), mr, yr, x.shape, k, step, dx=guarded(x.shape))
         dxr_ref = np.where(xr <= 0, np.float32(0), O.maxpool_backward(dy, mr_ref, x.shape, k, step))
         errs = {"y": 0.0 if np.array_equal(y.cpu().numpy().view(np.uint32), y_ref.view(np.uint32)) else 1.0,
                 "mask": 0.0 if np.array_equal(m.cpu().numpy(), m_ref) else 1.0,
                 "dx": 0.0 if np.array_equal(dx.cpu().numpy().view(np.uint32), dx_ref.view(np.uint32)) else 1.0,
                 "dx+relu": 0.0 if np.array_equal(dxr.cpu().numpy().view(np.uint32), dxr_ref.view(np.uint32)) else 1.0}
+        errs.update(overruns())
         report(f"pool B{B} C{C} {H}x{W} k{k} step{step}", errs)
 
 
 def bn_cases():
+    global MIS
+    MIS = 0  # (include/cnn_amd.h: the BatchNorm2D entry points ask for 16-byte aligned tensors and refuse others with a status)
     for it in range(n_cases):
         B, C = int(rs.randint(1, 9)), int(rs.randint(1, 70))
         H, W = int(rs.randint(1, 40)), int(rs.randint(1, 40))
@@ -130,7 +158,7 @@ def bn_cases():
         dx_o, gg_o, gb_o = O.batchnorm_backward(x, dy, gamma, sm_o, sv_o)
         bn = capi.BatchNorm2d(B, C, H, W)
         xd, gd, bd, mmd, mvd = dev(x), dev(gamma), dev(beta), dev(mm0), dev(mv0)
-        yd, rd = torch.empty_like(xd), torch.empty_like(xd)
+        yd, rd = guarded(shape), guarded(shape)
         bn.forward(xd, gd, bd, mmd, mvd, yd, training=True, y_relu=rd)
         dyd = dev(dy)
         gg, gb = torch.full((C,), 7.0, device="cuda"), torch.full((C,), 7.0, device="cuda")
@@ -159,6 +187,7 @@ def bn_cases():
                 bn2.backward_pooled(xd, dpool, m2, p2, gd, gg2, gb2, dx2)
                 errs["pooled bwd"] = 0.0 if (torch.equal(dx2, d_relu) and torch.equal(gg1, gg2) and torch.equal(gb1, gb2)) else 1.0
                 tag += " +pooled-bwd"
+        errs.update(overruns())
         report(f"bn {shape}{tag}", errs)
 
 
@@ -175,11 +204,12 @@ def lin_cases():
         y_ref = O.linear_forward(x, w, b)
         gw_ref, gb_ref, dx_ref = O.linear_backward(x, dy, w)
         xd, wd = dev(x), dev(w)
-        y = capi.linear_forward(xd, wd, dev(b))
-        gw, gb, dx = capi.linear_backward(xd, dev(dy), wd, float(B))
+        y = capi.linear_forward(xd, wd, dev(b), y=guarded((B, n_out)))
+        gw, gb, dx = capi.linear_backward(xd, dev(dy), wd, float(B), gw=guarded((n_in, n_out)), gb=guarded((n_out,)), dx=guarded((B, n_in)))
         gw2, gb2, dxr = capi.linear_backward(xd, dev(dy), wd, float(B), relu_below=True)
         errs = {"y": rel(y.cpu().numpy(), y_ref), "gw": rel(gw.cpu().numpy(), gw_ref), "gb": rel(gb.cpu().numpy(), gb_ref),
                 "dx": rel(dx.cpu().numpy(), dx_ref), "dx+relu": rel(dxr.cpu().numpy(), np.where(x <= 0, np.float32(0), dx_ref))}
+        errs.update(overruns())
         if n_out > 8:  # (the fused head serves skinny layers: cnn_linear_forward_softmax_xent_dx requires out <= 8)
             report(f"linear B{B} {n_in}->{n_out}", errs)
             continue
