@@ -63,6 +63,14 @@ for it in range(n_nets):
     spec.append(("linear", 3))
     B = int(rs.randint(2, 5))
     onet = O.SeqNet(spec, in_shape)
+    # the bias gradient of a convolution that feeds a BatchNorm2D is exactly 0 (the batch mean is subtracted, batchnorm2d.cpp:46-61): what any
+    # fp32 implementation holds there is rounding noise of the sum of its deltas -- kept out of the relative comparisons (tests/util.py
+    # assert_noise_of_exact_zero bounds it in the suite)
+    live = np.ones(onet.n_params, bool)
+    for i, e in enumerate(onet.layers[:-1]):
+        if e["kind"] == "conv" and onet.layers[i + 1]["kind"] == "bn":
+            co = e["out"][0]
+            live[e["off"] + e["n"] - co : e["off"] + e["n"]] = False
     p0 = he_init(onet.layers, 500 + it)
     onet.params[:] = p0
     x = rs.rand(B, *in_shape).astype(np.float32)
@@ -70,6 +78,7 @@ for it in range(n_nets):
     xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
     names = hostapi._layer_names(spec)
     runs = {}
+    arbitrated = []
     try:
         for mode, (fl, fp) in (("default", (1, 1)), ("no pool block", (1, 0)), ("no fusion", (0, 0))):
             lib.cnnh_set_fuse_layers(fl)
@@ -97,14 +106,72 @@ for it in range(n_nets):
                 e_loss = abs(net2.last_loss() - oloss) / max(1.0, abs(oloss))
                 net2.close()
                 # ... and the partial-batch step (trace[3]) after three full ones: loss and gradients (whole-arena norm; ReLU / pool decisions
-                # within rounding distance may flip over four steps -- a loose 5e-2; a stale sample in the batch moved the loss by ~1e-2 and the gradients by 0.1 - 0.9)
+                # within rounding distance may flip over four steps: beyond 1e-4 / 1e-3 the fp64 restatement arbitrates, below)
                 onet2 = O.SeqNet(spec, in_shape)  # (a fresh one: every Dropout layer's engine starts at its seed, like the net's)
                 onet2.params[:] = p0
                 for _ in range(3):
                     onet2.train_step(x, labels, 1e-3)
                 pl, _ = onet2.train_step(x[: B - 1], labels[: B - 1], 1e-3)
                 e_ploss = abs(trace[3][0] - pl) / max(1.0, abs(pl)) if np.isfinite(pl) else 0.0
-                e_pgrad = float(np.abs(trace[3][2] - onet2.grads).max() / max(np.abs(onet2.grads).max(), 1e-30)) if np.isfinite(pl) else 0.0
+                e_pgrad = float(np.abs(trace[3][2] - onet2.grads)[live].max() / max(np.abs(onet2.grads).max(), 1e-30)) if np.isfinite(pl) else 0.0
+                if e_ploss > 1e-4 or e_pgrad > 1e-3:
+                    # several steps deep the fp32 ORACLE itself has drifted from the exact sequence (its sequential sums, flipped ReLU / pool
+                    # decisions: SURVEY.md H3): arbitrate with the fp64 restatement like tests/util.py -- the HIP path may be as far from
+                    # it as the fp32 oracle is (x 3), no further
+                    o64 = O.SeqNet(spec, in_shape, f64=True)
+                    o64.params[:] = p0
+                    for _ in range(3):
+                        o64.train_step(x, labels, 1e-3)
+                    pl64, _ = o64.train_step(x[: B - 1], labels[: B - 1], 1e-3)
+                    gmax = max(np.abs(o64.grads).max(), 1e-30)
+                    hip_g, ora_g = np.abs(trace[3][2] - o64.grads)[live].max() / gmax, np.abs(onet2.grads - o64.grads)[live].max() / gmax
+                    # per layer: as far from fp64 as the fp32 oracle (x 3) -- and for the WEIGHTS of a convolution that feeds a BatchNorm2D an absolute
+                    # 1e-1 of the layer's largest gradient (one- or two-sample batches on 100+ pixel planes reach 3e-2): they are sum(dx * x) over a dx whose sum is exactly 0 and an x that is not centred, i.e. the
+                    # exact-zero noise above times mean(x); measured on isolated BatchNorm2D backward passes (126 x 126 planes): that sum is off by
+                    # 1e-2 .. 3e-1 of its value on the HIP path and by 6e-2 .. 17 (!) in the fp32 oracle -- whichever is closer to fp64 is chance
+                    layers_ok = True
+                    for i_, e_ in enumerate(onet2.layers):
+                        if e_.get("n", 0) > 0:
+                            sl = slice(e_["off"], e_["off"] + e_["n"])
+                            lv = live[sl]
+                            m_ = max(np.abs(o64.grads[sl]).max(), 1e-300)
+                            h_, o_ = np.abs(trace[3][2][sl] - o64.grads[sl])[lv].max() / m_, np.abs(onet2.grads[sl] - o64.grads[sl])[lv].max() / m_
+                            feeds_bn = e_["kind"] == "conv" and i_ + 1 < len(onet2.layers) and onet2.layers[i_ + 1]["kind"] == "bn"
+                            layers_ok = layers_ok and h_ <= max(3 * max(o_, 1e-4), 1e-1 if feeds_bn else 0.0)
+                    if layers_ok:
+                        hip_g = 0.0
+                    hip_l, ora_l = abs(trace[3][0] - pl64) / max(1.0, abs(pl64)), abs(pl - pl64) / max(1.0, abs(pl64))
+                    # (a saturated step -- loss ~ 1e-8, the true class' probability one ulp from 1: delta = p - y is rounding noise of expf's last
+                    #  bit, and so is every gradient behind it; a relative error of noise says nothing)
+                    degenerate = gmax < 1e-6 or abs(pl64) < 1e-3  # (|delta| ~ the loss: below 1e-3 one ulp of p is > 6e-5 of delta)
+                    if (degenerate or hip_g <= 3 * max(ora_g, 1e-4)) and hip_l <= 3 * max(ora_l, 1e-5):
+                        arbitrated.append(f"partial-batch step: HIP {hip_g:.1e} / fp32 oracle {ora_g:.1e} from fp64")
+                        e_ploss, e_pgrad = 0.0, 0.0
+                    else:
+                        per = []
+                        for e in onet2.layers:
+                            if e.get("n", 0) > 0:
+                                sl = slice(e["off"], e["off"] + e["n"])
+                                m = max(np.abs(o64.grads[sl]).max(), 1e-300)
+                                per.append(f"{e['kind']} max|g| {m:.1e} HIP {np.abs(trace[3][2][sl] - o64.grads[sl]).max() / m:.1e} ora {np.abs(onet2.grads[sl] - o64.grads[sl]).max() / m:.1e}")
+                        if os.environ.get("FUZZ_DIAG"):  # the same sequence with other weight-gradient kernels: is it one kernel family?
+                            from cnn_amd import capi as capi_
+
+                            for opt in os.environ["FUZZ_DIAG"].split(","):
+                                capi_.set_option(opt, "0")
+                                n3 = hostapi.HostSequential(spec, in_shape)
+                                n3.set_params(p0)
+                                for _ in range(3):
+                                    n3.train_step(xd, ld, 1e-3)
+                                n3.train_step(xd[: B - 1], ld[: B - 1], 1e-3)
+                                g3 = n3.get_grads()
+                                n3.close()
+                                capi_.set_option(opt, None)
+                                e0 = onet2.layers[0]
+                                sl0 = slice(e0["off"], e0["off"] + e0["n"])
+                                per.append(f"[{opt}=0: first layer HIP {np.abs(g3[sl0] - o64.grads[sl0])[live[sl0]].max() / max(np.abs(o64.grads[sl0]).max(), 1e-300):.1e}]")
+                        arbitrated.append(f"partial-batch step NOT within 3 x the oracle's own distance: gradients HIP {hip_g:.1e} / fp32 oracle {ora_g:.1e}, "
+                                          f"loss HIP {hip_l:.1e} / oracle {ora_l:.1e} from fp64, B - 1 = {B - 1}; per layer: " + "; ".join(per))
             runs[mode] = (trace, outs)
             net.close()
         # inference (architectures::no_grad: BatchNorm2D on its moving statistics, Dropout off, nothing recorded; inference.cpp's use of the
@@ -124,6 +191,17 @@ for it in range(n_nets):
         oev = onet3.forward(x, training=False)
         e_eval = float(np.abs(ev - oev.reshape(ev.shape)).max() / max(np.abs(oev).max(), 1e-30)) if np.all(np.isfinite(oev)) else 0.0
         net.close()
+        if e_eval > 1e-4:
+            o64 = O.SeqNet(spec, in_shape, f64=True)
+            o64.params[:] = p0
+            for _ in range(2):
+                o64.train_step(x, labels, 1e-3)
+            e64 = o64.forward(x, training=False)
+            lmax = max(np.abs(e64).max(), 1e-30)
+            hip_e, ora_e = np.abs(ev - e64.reshape(ev.shape)).max() / lmax, np.abs(oev - e64).max() / lmax
+            if hip_e <= 3 * max(ora_e, 1e-5):
+                arbitrated.append(f"inference: HIP {hip_e:.1e} / fp32 oracle {ora_e:.1e} from fp64")
+                e_eval = 0.0
         # data parallelism with ONE rank (every collective the N-rank step issues is issued, every sum is an identity): a one-rank RCCL
         # communicator with the exchange forced on, plain and bucketed (sync-BN reductions on the same communicator), against the default run
         dp_diff = []
@@ -209,8 +287,8 @@ for it in range(n_nets):
             if not np.array_equal(outs[nm].view(np.uint32), ref_outs[nm].view(np.uint32)):
                 diffs.append(f"{mode}: get_output({nm})")
     diffs += dp_diff + misc_diff
-    ok = not diffs and e_log <= 1e-4 and e_loss <= 1e-4 and e_ploss <= 1e-3 and e_pgrad <= 5e-2 and e_loop <= 2e-5 and e_eval <= 2e-4
+    ok = not diffs and e_log <= 1e-4 and e_loss <= 1e-4 and e_ploss <= 1e-4 and e_pgrad <= 1e-3 and e_loop <= 2e-5 and e_eval <= 1e-4
     bad += not ok
-    print(f"net {it}: B{B} {in_shape} {spec}\n   vs oracle: logits {e_log:.2e} loss {e_loss:.2e}, partial-batch step loss {e_ploss:.2e} grads {e_pgrad:.2e}; reference loop vs train_step params {e_loop:.2e}; inference logits {e_eval:.2e}; fused vs unfused: {'bit-identical' if not diffs else diffs[:6]}{'' if ok else '   <-- FAIL'}")
+    print(f"net {it}: B{B} {in_shape} {spec}\n   vs oracle: logits {e_log:.2e} loss {e_loss:.2e}, partial-batch step loss {e_ploss:.2e} grads {e_pgrad:.2e}; reference loop vs train_step params {e_loop:.2e}; inference logits {e_eval:.2e}; fused vs unfused: {'bit-identical' if not diffs else diffs[:6]}{('; fp64-arbitrated: ' + '; '.join(arbitrated)) if arbitrated else ''}{'' if ok else '   <-- FAIL'}")
 print(f"FUZZ NETS {'OK' if bad == 0 else 'FAILED'}: {n_nets} networks, {bad} with differences")
 sys.exit(1 if bad else 0)
